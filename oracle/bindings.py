@@ -1,0 +1,395 @@
+"""ctypes bindings for the CPU checkers -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+* ``Oracle(dtype)``  -> oracle/libcmf_oracle_{double,float}.so   (our C restatement, cmf_oracle.c)
+* ``Reference(dtype)`` -> oracle/_ref/libcmfrec_ref_{double,float}.so (the real cmfrec, compiled from
+  /root/reference by oracle/Makefile; present only where it was built and shipped)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+c_real = {np.float64: C.c_double, np.float32: C.c_float}
+
+
+def _np_dtype(dtype):
+    dtype = np.dtype(dtype).type
+    if dtype not in (np.float64, np.float32):
+        raise ValueError("dtype must be float64 or float32")
+    return dtype
+
+
+def _suffix(dtype):
+    return "double" if _np_dtype(dtype) is np.float64 else "float"
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+
+
+def build_ref():
+    """Builds oracle/_ref from /root/reference (only possible where that tree exists)."""
+    if not os.path.isdir("/root/reference/src"):
+        return False
+    subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+    return True
+
+
+def _preload_openblas():
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)),
+                                  "scipy.libs", "libscipy_openblas*.so"))
+    for lib in libs:
+        C.CDLL(lib, mode=C.RTLD_GLOBAL)
+
+
+class Oracle:
+    def __init__(self, dtype=np.float64):
+        self.dtype = _np_dtype(dtype)
+        path = os.path.join(_HERE, "libcmf_oracle_%s.so" % _suffix(dtype))
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = C.CDLL(path)
+        assert self.lib.oracle_sizeof_real() == np.dtype(self.dtype).itemsize
+        self.real = c_real[self.dtype]
+
+    def _r(self, x):
+        return self.real(float(x))
+
+    def coo_to_csr_and_csc(self, row, col, val, m, n):
+        nnz = len(val)
+        row = np.ascontiguousarray(row, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        csr_p = np.zeros(m + 1, np.uint64); csr_i = np.zeros(nnz, np.int32); csr_v = np.zeros(nnz, self.dtype)
+        csc_p = np.zeros(n + 1, np.uint64); csc_i = np.zeros(nnz, np.int32); csc_v = np.zeros(nnz, self.dtype)
+        self.lib.oracle_coo_to_csr_and_csc(_ptr(row), _ptr(col), _ptr(val), C.c_int(m), C.c_int(n),
+                                           C.c_size_t(nnz), _ptr(csr_p), _ptr(csr_i), _ptr(csr_v),
+                                           _ptr(csc_p), _ptr(csc_i), _ptr(csc_v))
+        return (csr_p, csr_i, csr_v), (csc_p, csc_i, csc_v)
+
+    def optimizeA_implicit(self, A, B, csr, lam, k=None, nthreads=1, use_cg=True,
+                           precondition_cg=False, max_cg_steps=3, return_BtB=False):
+        """A [m, lda] in/out (modified in place), B [n, ldb]."""
+        assert A.dtype == self.dtype and B.dtype == self.dtype and A.flags.c_contiguous and B.flags.c_contiguous
+        m, lda = A.shape
+        n, ldb = B.shape
+        k = min(lda, ldb) if k is None else k
+        p, i, v = csr
+        BtB = np.zeros((k, k), self.dtype) if return_BtB else None
+        self.lib.oracle_optimizeA_implicit(_ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb),
+                                           C.c_int(m), C.c_int(n), C.c_int(k), _ptr(p), _ptr(i), _ptr(v),
+                                           self._r(lam), C.c_int(nthreads), C.c_bool(use_cg),
+                                           C.c_bool(precondition_cg), C.c_int(max_cg_steps), _ptr(BtB))
+        return BtB
+
+    def optimizeA_explicit(self, A, B, csr, lam, lam_last=None, k=None, scale_lam=False,
+                           scale_bias_const=False, nthreads=1, use_cg=True, precondition_cg=False,
+                           max_cg_steps=3):
+        assert A.dtype == self.dtype and B.dtype == self.dtype and A.flags.c_contiguous and B.flags.c_contiguous
+        m, lda = A.shape
+        n, ldb = B.shape
+        k = min(lda, ldb) if k is None else k
+        lam_last = lam if lam_last is None else lam_last
+        p, i, v = csr
+        self.lib.oracle_optimizeA_explicit(_ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb),
+                                           C.c_int(m), C.c_int(n), C.c_int(k), _ptr(p), _ptr(i), _ptr(v),
+                                           self._r(lam), self._r(lam_last), C.c_bool(scale_lam),
+                                           C.c_bool(scale_bias_const), C.c_int(nthreads), C.c_bool(use_cg),
+                                           C.c_bool(precondition_cg), C.c_int(max_cg_steps))
+
+    def optimizeA_dense_full(self, A, B, Xfull, lam, lam_last=None, k=None, do_B=False,
+                             scale_lam=False, nthreads=1):
+        m, lda = A.shape
+        n, ldb = B.shape
+        k = min(lda, ldb) if k is None else k
+        lam_last = lam if lam_last is None else lam_last
+        ldX = Xfull.shape[1]
+        self.lib.oracle_optimizeA_dense_full(_ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb),
+                                             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(Xfull),
+                                             C.c_size_t(ldX), C.c_bool(do_B), self._r(lam),
+                                             self._r(lam_last), C.c_bool(scale_lam), C.c_int(nthreads))
+
+    def optimizeA_collective_chol(self, A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=None,
+                                  k_main=0, k_user=0, k_item=0, scale_lam=False,
+                                  scale_lam_sideinfo=False, nthreads=1, m_u=None):
+        m, lda = A.shape
+        n, ldb = B.shape
+        p = Cm.shape[0]
+        lam_last = lam if lam_last is None else lam_last
+        m_u = U.shape[0] if m_u is None else m_u
+        pp, i, v = csr
+        self.lib.oracle_optimizeA_collective_chol(
+            _ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb), _ptr(Cm),
+            C.c_int(m), C.c_int(m_u), C.c_int(n), C.c_int(p),
+            C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            _ptr(pp), _ptr(i), _ptr(v), _ptr(U), self._r(lam), self._r(w_user), self._r(lam_last),
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_int(nthreads))
+
+    def calc_mean_and_center(self, X, nthreads=1):
+        self.lib.oracle_calc_mean_and_center.restype = self.real
+        return self.lib.oracle_calc_mean_and_center(_ptr(X), C.c_size_t(len(X)), C.c_int(nthreads))
+
+    def initialize_biases_twosided(self, m, n, csr, csc, lam_user, lam_item, scale_lam):
+        biasA = np.zeros(m, self.dtype); biasB = np.zeros(n, self.dtype)
+        self.lib.oracle_initialize_biases_twosided(C.c_int(m), C.c_int(n), _ptr(csr[0]), _ptr(csr[1]),
+                                                   _ptr(csr[2]), _ptr(csc[0]), _ptr(csc[1]), _ptr(csc[2]),
+                                                   self._r(lam_user), self._r(lam_item),
+                                                   C.c_bool(scale_lam), _ptr(biasA), _ptr(biasB))
+        return biasA, biasB
+
+    def fit_implicit_als(self, A, B, row, col, val, lam=1.0, alpha=1.0, apply_log_transf=False,
+                         niter=10, nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
+                         finalize_chol=False):
+        m, k = A.shape
+        n = B.shape[0]
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        return self.lib.oracle_fit_implicit_als(_ptr(A), _ptr(B), C.c_int(m), C.c_int(n), C.c_int(k),
+                                                _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
+                                                self._r(lam), self._r(alpha), C.c_bool(apply_log_transf),
+                                                C.c_int(niter), C.c_int(nthreads), C.c_bool(use_cg),
+                                                C.c_int(max_cg_steps), C.c_bool(precondition_cg),
+                                                C.c_bool(finalize_chol))
+
+    def fit_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None, Dm=None,
+                         U=None, II=None, user_bias=True, item_bias=True, center=True, lam=10.0,
+                         scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,
+                         w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=True, max_cg_steps=3,
+                         precondition_cg=False, finalize_chol=True, init_biases=False):
+        m = A.shape[0]; n = B.shape[0]
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        biasA = np.zeros(m, self.dtype) if biasA is None else biasA
+        biasB = np.zeros(n, self.dtype) if biasB is None else biasB
+        glob_mean = np.zeros(1, self.dtype)
+        m_u, p = (0, 0) if U is None else U.shape
+        n_i, q = (0, 0) if II is None else II.shape
+        Ucm = np.zeros(max(p, 1), self.dtype); Icm = np.zeros(max(q, 1), self.dtype)
+        if U is not None and Cm is None:
+            Cm = np.zeros((p, k_user + k), self.dtype)
+        if II is not None and Dm is None:
+            Dm = np.zeros((q, k_item + k), self.dtype)
+        ret = self.lib.oracle_fit_explicit_als(
+            _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(glob_mean), _ptr(Ucm),
+            _ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val),
+            C.c_size_t(len(val)), C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
+            self._r(lam), C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
+            _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
+            C.c_int(k_main), C.c_int(k_user), C.c_int(k_item), self._r(w_user), self._r(w_item),
+            C.c_int(niter), C.c_int(nthreads), C.c_bool(use_cg), C.c_int(max_cg_steps),
+            C.c_bool(precondition_cg), C.c_bool(finalize_chol), C.c_bool(init_biases))
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],
+                    U_colmeans=Ucm, I_colmeans=Icm)
+
+
+def ref_available(dtype=np.float64):
+    return os.path.exists(os.path.join(_HERE, "_ref", "libcmfrec_ref_%s.so" % _suffix(dtype)))
+
+
+class Reference:
+    """The real cmfrec (oracle/_ref), internal operators + the two fit_*_als entry points.
+
+    Signatures: /root/reference/src/cmfrec.h:986-1027 (optimizeA, optimizeA_implicit),
+    :1646-1683 (optimizeA_collective), :1851-1921 (fit_collective_{explicit,implicit}_als)."""
+
+    def __init__(self, dtype=np.float64):
+        self.dtype = _np_dtype(dtype)
+        path = os.path.join(_HERE, "_ref", "libcmfrec_ref_%s.so" % _suffix(dtype))
+        if not os.path.exists(path):
+            if not build_ref():
+                raise FileNotFoundError(path)
+        _preload_openblas()
+        self.lib = C.CDLL(path)
+        self.real = c_real[self.dtype]
+
+    def _r(self, x):
+        return self.real(float(x))
+
+    def _scratch(self, nelem):
+        return np.zeros(int(nelem), self.dtype)
+
+    def coo_to_csr_and_csc(self, row, col, val, m, n):
+        nnz = len(val)
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        csr_p = np.zeros(m + 1, np.uint64); csr_i = np.zeros(nnz, np.int32); csr_v = np.zeros(nnz, self.dtype)
+        csc_p = np.zeros(n + 1, np.uint64); csc_i = np.zeros(nnz, np.int32); csc_v = np.zeros(nnz, self.dtype)
+        self.lib.coo_to_csr_and_csc(_ptr(row), _ptr(col), _ptr(val), None, C.c_int(m), C.c_int(n),
+                                    C.c_size_t(nnz), _ptr(csr_p), _ptr(csr_i), _ptr(csr_v),
+                                    _ptr(csc_p), _ptr(csc_i), _ptr(csc_v), None, None, C.c_int(1))
+        return (csr_p, csr_i, csr_v), (csc_p, csc_i, csc_v)
+
+    def optimizeA_implicit(self, A, B, csr, lam, k=None, nthreads=1, use_cg=True,
+                           precondition_cg=False, max_cg_steps=3, return_BtB=False):
+        m, lda = A.shape
+        n, ldb = B.shape
+        k = min(lda, ldb) if k is None else k
+        p, i, v = csr
+        BtB = np.zeros((k, k), self.dtype)
+        buf = self._scratch(k * k * (nthreads + 2) + 16 * k * nthreads + 1024)
+        self.lib.optimizeA_implicit(_ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb),
+                                    C.c_int(m), C.c_int(n), C.c_int(k), _ptr(p), _ptr(i), _ptr(v),
+                                    self._r(lam), self._r(0.), C.c_int(nthreads), C.c_bool(False),
+                                    C.c_bool(use_cg), C.c_bool(precondition_cg), C.c_int(max_cg_steps),
+                                    C.c_bool(False), C.c_int(100), _ptr(BtB), _ptr(buf), None)
+        return BtB if return_BtB else None
+
+    def optimizeA(self, A, B, csr=None, Xfull=None, lam=1.0, lam_last=None, k=None, scale_lam=False,
+                  scale_bias_const=False, do_B=False, nthreads=1, use_cg=True, precondition_cg=False,
+                  max_cg_steps=3, full_dense=False):
+        """Case 4 (csr given) or Case 1 (Xfull given, full_dense=True) of optimizeA."""
+        m, lda = A.shape
+        n, ldb = B.shape
+        k = min(lda, ldb) if k is None else k
+        lam_last = lam if lam_last is None else lam_last
+        p, i, v = (None, None, None) if csr is None else csr
+        ldX = 0 if Xfull is None else Xfull.shape[1]
+        filled = C.c_bool(False)
+        buf = self._scratch(k * k * (nthreads + 4) + (n + m) * (nthreads + 2) + 16 * k * nthreads + 4096)
+        cnt_NA = np.zeros(max(m, n) + 1, np.int32)
+        self.lib.optimizeA(_ptr(A), C.c_int(lda), _ptr(B), C.c_int(ldb), C.c_int(m), C.c_int(n), C.c_int(k),
+                           _ptr(p), _ptr(i), _ptr(v), _ptr(Xfull), C.c_int(ldX),
+                           C.c_bool(full_dense), C.c_bool(False), C.c_bool(full_dense),
+                           _ptr(cnt_NA), None, C.c_bool(False),
+                           self._r(lam), self._r(lam_last), self._r(0.), self._r(0.),
+                           C.c_bool(scale_lam), C.c_bool(scale_bias_const), None,
+                           C.c_bool(do_B), C.c_int(nthreads), C.c_bool(False),
+                           C.c_bool(use_cg), C.c_bool(precondition_cg), C.c_int(max_cg_steps),
+                           C.c_bool(False), C.c_int(100),
+                           None, None, None, self._r(0.), None, self._r(1.),
+                           C.c_bool(False), None, C.byref(filled), _ptr(buf), None)
+
+    def optimizeA_collective(self, A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=None,
+                             k_main=0, k_user=0, k_item=0, scale_lam=False, scale_lam_sideinfo=False,
+                             nthreads=1, use_cg=False, m_u=None):
+        m, lda = A.shape
+        n, ldb = B.shape
+        p = Cm.shape[0]
+        lam_last = lam if lam_last is None else lam_last
+        m_u = U.shape[0] if m_u is None else m_u
+        pp, i, v = csr
+        k_totA = k_user + k + k_main
+        buf = self._scratch(k_totA * k_totA * (nthreads + 6) + (n + m) * (nthreads + 2) + 4096)
+        cnt_NA_u = np.zeros(max(m, m_u) + 1, np.int32)
+        flags = [C.c_bool(False) for _ in range(5)]
+        self.lib.optimizeA_collective(
+            _ptr(A), C.c_int(lda), _ptr(B), C.c_int(ldb), _ptr(Cm), None,
+            C.c_int(m), C.c_int(m_u), C.c_int(n), C.c_int(p),
+            C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            _ptr(pp), _ptr(i), _ptr(v), None, C.c_int(0),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False), None, None, C.c_bool(False),
+            None, C.c_int(0), C.c_int(0), C.c_bool(False),
+            None, None, None, _ptr(U), _ptr(cnt_NA_u), None,
+            C.c_bool(True), C.c_bool(False), C.c_bool(True), C.c_bool(False),
+            self._r(lam), self._r(w_user), self._r(1.), self._r(lam_last), self._r(0.), self._r(0.),
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), None,
+            C.c_bool(False), C.c_int(nthreads), C.c_bool(False),
+            C.c_bool(use_cg), C.c_int(3), C.c_bool(False), C.c_bool(False), C.c_int(100),
+            None, None, None, self._r(0.), C.c_bool(False),
+            None, None, None, None, None,
+            C.byref(flags[0]), C.byref(flags[1]), C.byref(flags[2]), C.byref(flags[3]), C.byref(flags[4]),
+            _ptr(buf), None)
+
+    def calc_mean_and_center(self, row, col, X, m, n, nthreads=1):
+        """Returns (glob_mean, centred copy of X)."""
+        Xp = (C.c_void_p * 1)(X.ctypes.data)
+        gm = np.zeros(1, self.dtype)
+        mod_x = C.c_bool(False); mod_xf = C.c_bool(False)
+        Xc = X.copy()
+        Xp[0] = Xc.ctypes.data
+        self.lib.calc_mean_and_center(_ptr(row), _ptr(col), Xp, C.c_size_t(len(X)), None, None,
+                                      C.c_int(m), C.c_int(n), None, None, None, None, None, None, None,
+                                      C.c_bool(False), C.c_bool(False), C.c_bool(True), C.c_int(nthreads),
+                                      _ptr(gm), C.byref(mod_x), C.byref(mod_xf), C.c_bool(True))
+        return gm[0], Xc
+
+    def initialize_biases_twosided(self, m, n, csr, csc, lam_user, lam_item, scale_lam, nthreads=1):
+        biasA = np.zeros(m, self.dtype); biasB = np.zeros(n, self.dtype)
+        self.lib.initialize_biases_twosided(
+            None, None, None, None, C.c_int(m), C.c_int(n), C.c_bool(False), C.c_bool(False), C.c_double(0.),
+            _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]), _ptr(csc[0]), _ptr(csc[1]), _ptr(csc[2]),
+            None, None, None, None, self._r(lam_user), self._r(lam_item), C.c_bool(scale_lam),
+            None, None, _ptr(biasA), _ptr(biasB), C.c_int(nthreads))
+        return biasA, biasB
+
+    def random_parallel(self, sizeA, sizeB, seed, normal, nthreads=1):
+        class ArraysToFill(C.Structure):
+            _fields_ = [("A", C.c_void_p), ("sizeA", C.c_size_t), ("B", C.c_void_p), ("sizeB", C.c_size_t)]
+        A = np.zeros(sizeA, self.dtype); B = np.zeros(max(sizeB, 1), self.dtype)
+        arr = ArraysToFill(A.ctypes.data, sizeA, B.ctypes.data if sizeB else None, sizeB)
+        self.lib.random_parallel.argtypes = [ArraysToFill, C.c_int, C.c_bool, C.c_int]
+        self.lib.random_parallel(arr, seed, normal, nthreads)
+        return A, B[:sizeB]
+
+    def fit_collective_implicit_als(self, A, B, row, col, val, k, lam=1.0, alpha=1.0, niter=10,
+                                    nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
+                                    finalize_chol=False, reset_values=False, seed=1,
+                                    apply_log_transf=False):
+        m = A.shape[0]; n = B.shape[0]
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        wmm = np.zeros(1, self.dtype)
+        return self.lib.fit_collective_implicit_als(
+            _ptr(A), _ptr(B), None, None, C.c_bool(reset_values), C.c_int(seed), None, None,
+            C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
+            self._r(lam), None, self._r(0.), None,
+            None, C.c_int(0), C.c_int(0), None, C.c_int(0), C.c_int(0),
+            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            C.c_bool(False), C.c_bool(False), C.c_int(0), C.c_int(0), C.c_int(0),
+            self._r(1.), self._r(1.), self._r(1.), _ptr(wmm),
+            self._r(alpha), C.c_bool(False), C.c_bool(apply_log_transf),
+            C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
+            C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
+            C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(False), None, None, None, None)
+
+    def fit_collective_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None,
+                                    Dm=None, U=None, II=None, user_bias=True, item_bias=True,
+                                    center=True, lam=10.0, scale_lam=False, scale_lam_sideinfo=False,
+                                    k_main=0, k_user=0, k_item=0, w_user=1.0, w_item=1.0, niter=10,
+                                    nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
+                                    finalize_chol=True, reset_values=False, seed=1):
+        m = A.shape[0]; n = B.shape[0]
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        biasA = np.zeros(m, self.dtype) if biasA is None else biasA
+        biasB = np.zeros(n, self.dtype) if biasB is None else biasB
+        glob_mean = np.zeros(1, self.dtype)
+        m_u, p = (0, 0) if U is None else U.shape
+        n_i, q = (0, 0) if II is None else II.shape
+        Ucm = np.zeros(max(p, 1), self.dtype); Icm = np.zeros(max(q, 1), self.dtype)
+        if U is not None and Cm is None:
+            Cm = np.zeros((p, k_user + k), self.dtype)
+        if II is not None and Dm is None:
+            Dm = np.zeros((q, k_item + k), self.dtype)
+        sbA = np.zeros(1, self.dtype); sbB = np.zeros(1, self.dtype)
+        ret = self.lib.fit_collective_explicit_als(
+            _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), None, None,
+            C.c_bool(False), C.c_bool(reset_values), C.c_int(seed),
+            _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
+            C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
+            None, None, C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
+            self._r(lam), None, self._r(0.), None,
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), _ptr(sbA), _ptr(sbB),
+            _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
+            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            self._r(1.), self._r(w_user), self._r(w_item), self._r(1.),
+            C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
+            C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
+            C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(False), C.c_bool(True), None, None, None, None, None, None, None, None, None)
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],
+                    U_colmeans=Ucm, I_colmeans=Icm)

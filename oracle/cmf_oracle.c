@@ -1,0 +1,738 @@
+/*
+ * cmf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  See cmf_oracle.h.
+ *
+ * Plain C99 + OpenMP restatement of cmfrec's ALS factor-update path (reference paths are
+ * relative to /root/reference).  No BLAS: the BLAS-1/2 calls of the reference are written out as
+ * sequential loops in the same order over the non-zeros, so that the only differences against the
+ * real reference are the intra-vector summation order of OpenBLAS' SIMD kernels and FMA
+ * contraction (tolerance-level, see tests/test_oracle_vs_ref.py).
+ */
+#include "cmf_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static int omp_get_thread_num(void) { return 0; }
+#endif
+
+#ifdef ORACLE_FLOAT
+#define sqrt_t sqrtf
+#define fabs_t fabsf
+#define log_t logf
+#define EPSILON_T FLT_EPSILON
+#else
+#define sqrt_t sqrt
+#define fabs_t fabs
+#define log_t log
+#define EPSILON_T DBL_EPSILON
+#endif
+
+int oracle_sizeof_real(void) { return (int)sizeof(real_t); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* small dense helpers                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+static real_t dot_(int_t k, const real_t *x, const real_t *y)
+{
+    real_t s = 0;
+    for (int_t i = 0; i < k; i++) s += x[i] * y[i];
+    return s;
+}
+static void axpy_(int_t k, real_t a, const real_t *x, real_t *y)
+{
+    for (int_t i = 0; i < k; i++) y[i] += a * x[i];
+}
+/* y = alpha * M x, M symmetric k x k with leading dimension ld (full storage) */
+static void symv_(int_t k, real_t alpha, const real_t *M, int_t ld, const real_t *x, real_t *y)
+{
+    for (int_t i = 0; i < k; i++) {
+        real_t s = 0;
+        for (int_t j = 0; j < k; j++) s += M[(size_t)i * ld + j] * x[j];
+        y[i] = alpha * s;
+    }
+}
+/* upper-triangular rank-1 update, helpers.c:1729-1739 (custom_syr, explicit fma) */
+static void syr_upper_(int_t k, real_t alpha, const real_t *x, real_t *M, int_t ld)
+{
+    for (int_t i = 0; i < k; i++) {
+        real_t t = alpha * x[i];
+        for (int_t j = i; j < k; j++)
+#ifdef ORACLE_FLOAT
+            M[(size_t)i * ld + j] = fmaf(t, x[j], M[(size_t)i * ld + j]);
+#else
+            M[(size_t)i * ld + j] = fma(t, x[j], M[(size_t)i * ld + j]);
+#endif
+    }
+}
+/* In-place Cholesky of the UPPER triangle of row-major M (== LAPACK 'L' on the column-major
+ * view, which is how the reference calls tposv_/tpotrf_, e.g. common.c:1066-1070). M = R^T R. */
+static int chol_upper_(int_t k, real_t *M, int_t ld)
+{
+    for (int_t i = 0; i < k; i++) {
+        for (int_t j = i; j < k; j++) {
+            real_t s = M[(size_t)i * ld + j];
+            for (int_t t = 0; t < i; t++) s -= M[(size_t)t * ld + i] * M[(size_t)t * ld + j];
+            if (i == j) {
+                if (!(s > 0)) return 1;
+                M[(size_t)i * ld + i] = sqrt_t(s);
+            } else {
+                M[(size_t)i * ld + j] = s / M[(size_t)i * ld + i];
+            }
+        }
+    }
+    return 0;
+}
+static void chol_solve_upper_(int_t k, const real_t *R, int_t ld, real_t *b)
+{
+    for (int_t i = 0; i < k; i++) {            /* R^T y = b */
+        real_t s = b[i];
+        for (int_t t = 0; t < i; t++) s -= R[(size_t)t * ld + i] * b[t];
+        b[i] = s / R[(size_t)i * ld + i];
+    }
+    for (int_t i = k - 1; i >= 0; i--) {       /* R x = y */
+        real_t s = b[i];
+        for (int_t t = i + 1; t < k; t++) s -= R[(size_t)i * ld + t] * b[t];
+        b[i] = s / R[(size_t)i * ld + i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void oracle_coo_to_csr_and_csc(const int_t *Xrow, const int_t *Xcol, const real_t *Xval,
+                               int_t m, int_t n, size_t nnz,
+                               size_t *csr_p, int_t *csr_i, real_t *csr_v,
+                               size_t *csc_p, int_t *csc_i, real_t *csc_v)
+{
+    /* helpers.c:1392-1402 */
+    memset(csr_p, 0, ((size_t)m + 1) * sizeof(size_t));
+    memset(csc_p, 0, ((size_t)n + 1) * sizeof(size_t));
+    for (size_t ix = 0; ix < nnz; ix++) {
+        csr_p[(size_t)Xrow[ix] + 1]++;
+        csc_p[(size_t)Xcol[ix] + 1]++;
+    }
+    for (int_t r = 0; r < m; r++) csr_p[(size_t)r + 1] += csr_p[r];
+    for (int_t c = 0; c < n; c++) csc_p[(size_t)c + 1] += csc_p[c];
+    /* helpers.c:1419-1446: stable placement in COO order */
+    size_t *cr = (size_t *)calloc((size_t)m + 1, sizeof(size_t));
+    size_t *cc = (size_t *)calloc((size_t)n + 1, sizeof(size_t));
+    for (size_t ix = 0; ix < nnz; ix++) {
+        size_t r = (size_t)Xrow[ix], c = (size_t)Xcol[ix];
+        size_t pr = csr_p[r] + cr[r]++;
+        csr_v[pr] = Xval[ix];
+        csr_i[pr] = Xcol[ix];
+        size_t pc = csc_p[c] + cc[c]++;
+        csc_v[pc] = Xval[ix];
+        csc_i[pc] = Xrow[ix];
+    }
+    free(cr);
+    free(cc);
+}
+
+void oracle_gram(const real_t *B, size_t ldb, int_t n, int_t k, real_t *out, int nthreads)
+{
+    (void)nthreads;
+    /* accumulate in double then round: the reference's syrk is a blocked BLAS-3 kernel whose
+       summation order is unspecified; tolerance-level agreement only */
+    double *acc = (double *)calloc((size_t)k * k, sizeof(double));
+    for (int_t r = 0; r < n; r++) {
+        const real_t *b = B + (size_t)r * ldb;
+        for (int_t i = 0; i < k; i++) {
+            double bi = b[i];
+            for (int_t j = i; j < k; j++) acc[(size_t)i * k + j] += bi * (double)b[j];
+        }
+    }
+    for (int_t i = 0; i < k; i++)
+        for (int_t j = i; j < k; j++) {
+            out[(size_t)i * k + j] = (real_t)acc[(size_t)i * k + j];
+            out[(size_t)j * k + i] = (real_t)acc[(size_t)i * k + j];
+        }
+    free(acc);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* implicit-feedback per-row solvers                                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* common.c:1914-1986 */
+static void implicit_cg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
+                            const real_t *Xa, const int_t *ixB, size_t nnz, real_t lam,
+                            const real_t *BtB, int_t max_cg_steps, real_t *buf)
+{
+    real_t *Ap = buf, *r = Ap + k, *p = r + k;
+    symv_(k, (real_t)-1, BtB, k, a, r);                                       /* :1932 */
+    for (size_t ix = 0; ix < nnz; ix++) {                                     /* :1936-1942 */
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        real_t coef = dot_(k, b, a);
+        axpy_(k, -(coef - (real_t)1.) * Xa[ix] - coef, b, r);
+    }
+    axpy_(k, -lam, a, r);                                                     /* :1943 */
+    memcpy(p, r, (size_t)k * sizeof(real_t));
+    real_t r_old = dot_(k, r, r);
+    if (r_old <= (real_t)1e-12) return;                                       /* :1952 */
+    for (int_t step = 0; step < max_cg_steps; step++) {
+        symv_(k, (real_t)1, BtB, k, p, Ap);                                   /* :1958 */
+        for (size_t ix = 0; ix < nnz; ix++) {                                 /* :1962-1968 */
+            const real_t *b = B + (size_t)ixB[ix] * ldb;
+            real_t coef = dot_(k, b, p);
+            axpy_(k, coef * (Xa[ix] - (real_t)1.) + coef, b, Ap);
+        }
+        axpy_(k, lam, p, Ap);
+        real_t alpha = r_old / dot_(k, Ap, p);
+        axpy_(k, alpha, p, a);
+        axpy_(k, -alpha, Ap, r);
+        real_t r_new = dot_(k, r, r);
+        if (r_new <= (real_t)1e-8) break;                                     /* :1979 */
+        real_t ratio = r_new / r_old;
+        for (int_t i = 0; i < k; i++) p[i] = p[i] * ratio + r[i];             /* :1982-1983 */
+        r_old = r_new;
+    }
+}
+
+/* common.c:1988-2061 (Jacobi-preconditioned, fixed step count) */
+static void implicit_pcg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
+                             const real_t *Xa, const int_t *ixB, size_t nnz, real_t lam,
+                             const real_t *BtB, int_t max_cg_steps, real_t *buf)
+{
+    real_t *Ap = buf, *r = Ap + k, *p = r + k, *z = p + k, *PC = z + k;
+    memset(PC, 0, (size_t)k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++) {                                     /* :2009-2014 */
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        for (int_t i = 0; i < k; i++) PC[i] += Xa[ix] * (b[i] * b[i]);
+    }
+    for (int_t i = 0; i < k; i++) PC[i] += BtB[(size_t)i * k + i];
+    for (int_t i = 0; i < k; i++) PC[i] = (real_t)1 / PC[i];
+    symv_(k, (real_t)-1, BtB, k, a, r);
+    for (size_t ix = 0; ix < nnz; ix++) {
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        real_t coef = dot_(k, b, a);
+        axpy_(k, -(coef - (real_t)1.) * Xa[ix] - coef, b, r);
+    }
+    axpy_(k, -lam, a, r);
+    for (int_t i = 0; i < k; i++) z[i] = r[i] * PC[i];
+    real_t r_old = dot_(k, z, r);
+    memcpy(p, z, (size_t)k * sizeof(real_t));
+    for (int_t step = 0; step < max_cg_steps; step++) {
+        symv_(k, (real_t)1, BtB, k, p, Ap);
+        for (size_t ix = 0; ix < nnz; ix++) {
+            const real_t *b = B + (size_t)ixB[ix] * ldb;
+            real_t coef = dot_(k, b, p);
+            axpy_(k, coef * (Xa[ix] - (real_t)1.) + coef, b, Ap);
+        }
+        axpy_(k, lam, p, Ap);
+        real_t alpha = r_old / dot_(k, Ap, p);
+        axpy_(k, alpha, p, a);
+        axpy_(k, -alpha, Ap, r);
+        for (int_t i = 0; i < k; i++) z[i] = r[i] * PC[i];
+        real_t r_new = dot_(k, z, r);
+        real_t ratio = r_new / r_old;
+        for (int_t i = 0; i < k; i++) p[i] = p[i] * ratio + z[i];
+        r_old = r_new;
+    }
+}
+
+/* common.c:2063-2126 (BtB already holds +lam on its diagonal, :3333) */
+static void implicit_chol_row(real_t *a, int_t k, const real_t *B, size_t ldb,
+                              const real_t *Xa, const int_t *ixB, size_t nnz,
+                              const real_t *BtB, real_t *buf)
+{
+    if (nnz == 0) { memset(a, 0, (size_t)k * sizeof(real_t)); return; }
+    for (size_t ix = 0; ix < nnz; ix++)                                        /* :2082-2085 */
+        axpy_(k, Xa[ix] + (real_t)1., B + (size_t)ixB[ix] * ldb, a);
+    real_t *M = buf;
+    memset(M, 0, (size_t)k * k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++)                                        /* :2091-2095 */
+        syr_upper_(k, Xa[ix], B + (size_t)ixB[ix] * ldb, M, k);
+    for (int_t i = 0; i < k; i++)                                              /* :2097 sum_mat */
+        for (int_t j = i; j < k; j++) M[(size_t)i * k + j] += BtB[(size_t)i * k + j];
+    if (chol_upper_(k, M, k) == 0) chol_solve_upper_(k, M, k, a);
+    else for (int_t i = 0; i < k; i++) a[i] = NAN;
+}
+
+void oracle_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                               int_t m, int_t n, int_t k,
+                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                               real_t lam, int nthreads,
+                               bool use_cg, bool precondition_cg, int_t max_cg_steps,
+                               real_t *BtB_out)
+{
+    if (nthreads < 1) nthreads = 1;
+    real_t *BtB = (real_t *)malloc((size_t)k * k * sizeof(real_t));
+    oracle_gram(B, ldb, n, k, BtB, nthreads);                                  /* :3328 */
+    if (!use_cg) {                                                             /* :3332-3335 */
+        for (int_t i = 0; i < k; i++) BtB[(size_t)i * k + i] += lam;
+        for (size_t ix = 0; ix < (size_t)m * lda - (lda - (size_t)k); ix++) A[ix] = 0;
+    }
+    size_t szbuf = use_cg ? (size_t)(precondition_cg ? 5 : 3) * k : (size_t)k * k;
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {                                         /* :3349-3417 */
+        size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
+        if (en <= st) continue;
+        real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
+        real_t *a = A + (size_t)ix * lda;
+        if (use_cg && !precondition_cg)
+            implicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, en - st, lam, BtB, max_cg_steps, buf);
+        else if (use_cg)
+            implicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, en - st, lam, BtB, max_cg_steps, buf);
+        else
+            implicit_chol_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, en - st, BtB, buf);
+    }
+    if (BtB_out != NULL) memcpy(BtB_out, BtB, (size_t)k * k * sizeof(real_t));
+    free(bufs);
+    free(BtB);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* explicit-feedback per-row solvers                                                            */
+/* ------------------------------------------------------------------------------------------ */
+/* common.c:1098-1188 (weight == NULL) */
+static void explicit_cg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
+                            const real_t *Xa, const int_t *ixB, size_t nnz,
+                            real_t lam, real_t lam_last, int_t max_cg_steps, real_t *buf)
+{
+    real_t *Ap = buf, *p = Ap + k, *r = p + k;
+    memset(r, 0, (size_t)k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1119-1124 */
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        real_t coef = dot_(k, b, a);
+        coef -= Xa[ix];
+        axpy_(k, -coef, b, r);
+    }
+    axpy_(k, -lam, a, r);                                                      /* :1138 */
+    if (lam != lam_last) r[k - 1] -= (lam_last - lam) * a[k - 1];
+    real_t r_old = dot_(k, r, r);
+    if (r_old <= (real_t)1e-12) return;                                        /* :1147 */
+    memcpy(p, r, (size_t)k * sizeof(real_t));
+    for (int_t step = 0; step < max_cg_steps; step++) {
+        memset(Ap, 0, (size_t)k * sizeof(real_t));
+        for (size_t ix = 0; ix < nnz; ix++) {                                  /* :1157-1160 */
+            const real_t *b = B + (size_t)ixB[ix] * ldb;
+            real_t coef = dot_(k, b, p);
+            axpy_(k, coef, b, Ap);
+        }
+        axpy_(k, lam, p, Ap);
+        if (lam != lam_last) Ap[k - 1] += (lam_last - lam) * p[k - 1];
+        real_t alpha = r_old / dot_(k, p, Ap);
+        axpy_(k, alpha, p, a);
+        axpy_(k, -alpha, Ap, r);
+        real_t r_new = dot_(k, r, r);
+        if (r_new <= (real_t)1e-8) break;                                      /* :1180 */
+        real_t ratio = r_new / r_old;
+        for (int_t i = 0; i < k; i++) p[i] = p[i] * ratio + r[i];
+        r_old = r_new;
+    }
+}
+
+/* common.c:1190-1291 (weight == NULL) */
+static void explicit_pcg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
+                             const real_t *Xa, const int_t *ixB, size_t nnz,
+                             real_t lam, real_t lam_last, int_t max_cg_steps, real_t *buf)
+{
+    real_t *Ap = buf, *p = Ap + k, *r = p + k, *z = r + k, *PC = z + k;
+    memset(r, 0, (size_t)k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++) {
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        real_t coef = dot_(k, b, a);
+        coef -= Xa[ix];
+        axpy_(k, -coef, b, r);
+    }
+    axpy_(k, -lam, a, r);
+    if (lam != lam_last) r[k - 1] -= (lam_last - lam) * a[k - 1];
+    memset(PC, 0, (size_t)k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1238-1243 */
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        for (int_t i = 0; i < k; i++) PC[i] += b[i] * b[i];
+    }
+    for (int_t i = 0; i < k; i++) PC[i] += lam;
+    if (lam != lam_last) PC[k - 1] += (lam_last - lam);
+    for (int_t i = 0; i < k; i++) PC[i] = (real_t)1 / PC[i];
+    for (int_t i = 0; i < k; i++) z[i] = r[i] * PC[i];
+    real_t r_old = dot_(k, z, r);
+    memcpy(p, z, (size_t)k * sizeof(real_t));
+    for (int_t step = 0; step < max_cg_steps; step++) {
+        memset(Ap, 0, (size_t)k * sizeof(real_t));
+        for (size_t ix = 0; ix < nnz; ix++) {
+            const real_t *b = B + (size_t)ixB[ix] * ldb;
+            real_t coef = dot_(k, b, p);
+            axpy_(k, coef, b, Ap);
+        }
+        axpy_(k, lam, p, Ap);
+        if (lam != lam_last) Ap[k - 1] += (lam_last - lam) * p[k - 1];
+        real_t alpha = r_old / dot_(k, p, Ap);
+        axpy_(k, alpha, p, a);
+        axpy_(k, -alpha, Ap, r);
+        for (int_t i = 0; i < k; i++) z[i] = r[i] * PC[i];
+        real_t r_new = dot_(k, z, r);
+        real_t ratio = r_new / r_old;
+        for (int_t i = 0; i < k; i++) p[i] = p[i] * ratio + z[i];
+        r_old = r_new;
+    }
+}
+
+/* common.c:978-1013 + :1060-1070 */
+static void explicit_chol_row(real_t *a, int_t k, const real_t *B, size_t ldb,
+                              const real_t *Xa, const int_t *ixB, size_t nnz,
+                              real_t lam, real_t lam_last, real_t *buf)
+{
+    memset(a, 0, (size_t)k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++)                      /* tgemv_dense_sp, helpers.c:1175 */
+        axpy_(k, Xa[ix], B + (size_t)ixB[ix] * ldb, a);
+    real_t *M = buf;
+    memset(M, 0, (size_t)k * k * sizeof(real_t));
+    for (size_t ix = 0; ix < nnz; ix++)
+        syr_upper_(k, (real_t)1, B + (size_t)ixB[ix] * ldb, M, k);
+    for (int_t i = 0; i < k - 1; i++) M[(size_t)i * k + i] += lam;            /* add_to_diag2 */
+    M[(size_t)(k - 1) * k + (k - 1)] += lam_last;
+    if (chol_upper_(k, M, k) == 0) chol_solve_upper_(k, M, k, a);
+    else for (int_t i = 0; i < k; i++) a[i] = NAN;
+}
+
+void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                               int_t m, int_t n, int_t k,
+                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                               real_t lam, real_t lam_last,
+                               bool scale_lam, bool scale_bias_const,
+                               int nthreads,
+                               bool use_cg, bool precondition_cg, int_t max_cg_steps)
+{
+    (void)n;
+    if (nthreads < 1) nthreads = 1;
+    size_t szbuf = (size_t)k * k;                                              /* :3244-3249 */
+    if (use_cg) szbuf = (size_t)(precondition_cg ? 5 : 3) * k;
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {                                         /* :3268-3299 */
+        size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
+        if (en <= st) continue;          /* empty rows are left untouched (:3270) */
+        size_t nnz = en - st;
+        real_t lam_i = lam, lam_last_i = lam_last;
+        if (scale_lam) {                                                       /* :679-723 */
+            lam_i *= (real_t)nnz;
+            if (!scale_bias_const) lam_last_i *= (real_t)nnz;
+        }
+        real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
+        real_t *a = A + (size_t)ix * lda;
+        if (use_cg && !precondition_cg)
+            explicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, lam_i, lam_last_i, max_cg_steps, buf);
+        else if (use_cg)
+            explicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, lam_i, lam_last_i, max_cg_steps, buf);
+        else
+            explicit_chol_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, lam_i, lam_last_i, buf);
+    }
+    free(bufs);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                 int_t m, int_t n, int_t k,
+                                 const real_t *Xfull, size_t ldX, bool do_B,
+                                 real_t lam, real_t lam_last, bool scale_lam, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    real_t *BtB = (real_t *)malloc((size_t)k * k * sizeof(real_t));
+    oracle_gram(B, ldb, n, k, BtB, nthreads);                                  /* :2824 */
+    real_t dl = scale_lam ? lam * (real_t)n : lam;                             /* :2832-2833 */
+    real_t dll = scale_lam ? lam_last * (real_t)n : lam_last;
+    for (int_t i = 0; i < k - 1; i++) BtB[(size_t)i * k + i] += dl;
+    BtB[(size_t)(k - 1) * k + (k - 1)] += dll;
+    int bad = chol_upper_(k, BtB, k);
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int_t i = 0; i < m; i++) {
+        real_t *a = A + (size_t)i * lda;
+        /* gemm, :2847-2855 -- accumulate in double (blocked BLAS-3 order is unspecified) */
+        double acc[512];
+        double *accp = (k <= 512) ? acc : (double *)calloc((size_t)k, sizeof(double));
+        for (int_t c = 0; c < k; c++) accp[c] = 0;
+        for (int_t j = 0; j < n; j++) {
+            double x = do_B ? Xfull[(size_t)j * ldX + i] : Xfull[(size_t)i * ldX + j];
+            const real_t *b = B + (size_t)j * ldb;
+            for (int_t c = 0; c < k; c++) accp[c] += x * (double)b[c];
+        }
+        for (int_t c = 0; c < k; c++) a[c] = (real_t)accp[c];
+        if (accp != acc) free(accp);
+        if (!bad) chol_solve_upper_(k, BtB, k, a);                             /* :2872 posv */
+        else for (int_t c = 0; c < k; c++) a[c] = NAN;
+    }
+    free(BtB);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                      const real_t *C,
+                                      int_t m, int_t m_u, int_t n, int_t p,
+                                      int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      const real_t *U,
+                                      real_t lam, real_t w_user, real_t lam_last,
+                                      bool scale_lam, bool scale_lam_sideinfo,
+                                      int nthreads)
+{
+    (void)n;
+    if (nthreads < 1) nthreads = 1;
+    int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main;
+    /* collective.c:4817-4822: A := 0 when not CG */
+    for (size_t ix = 0; ix < (size_t)m * lda - (lda - (size_t)k_totA); ix++) A[ix] = 0;
+    /* collective.c:5658-5668 + :6292-6296 : CtCw = w_user * C^T C */
+    real_t *CtCw = (real_t *)calloc((size_t)k_totC * k_totC + 1, sizeof(real_t));
+    if (p > 0 && U != NULL) {
+        oracle_gram(C, (size_t)k_totC, p, k_totC, CtCw, nthreads);
+        for (size_t i = 0; i < (size_t)k_totC * k_totC; i++) CtCw[i] *= w_user;
+    }
+    /* collective.c:5768-5773 : A[:m_u, :k_totC] = w_user * U C  (add_U = false) */
+    if (p > 0 && U != NULL) {
+        #pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int_t i = 0; i < m_u; i++) {
+            real_t *a = A + (size_t)i * lda;
+            for (int_t c = 0; c < k_totC; c++) {
+                double s = 0;
+                for (int_t j = 0; j < p; j++) s += (double)U[(size_t)i * p + j] * (double)C[(size_t)j * k_totC + c];
+                a[c] = (real_t)((double)w_user * s);
+            }
+        }
+    }
+    size_t szbuf = (size_t)k_totA * k_totA;
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {                                         /* :5865-5965 */
+        size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
+        size_t nnz = en - st;
+        bool has_u = (U != NULL && p > 0 && ix < m_u);
+        real_t *a = A + (size_t)ix * lda;
+        if (nnz == 0 && !has_u) { memset(a, 0, (size_t)k_totA * sizeof(real_t)); continue; } /* :1258-1268 */
+        real_t lam_i = lam, lam_last_i = lam_last;
+        if (scale_lam || scale_lam_sideinfo) {                                 /* :1285-1355 */
+            real_t mult = (real_t)nnz;
+            if (nnz == 0) mult = 1;                                            /* :1332-1336 */
+            if (scale_lam_sideinfo && has_u) mult += (real_t)p;                /* :1338-1346 */
+            lam_i *= mult;
+            lam_last_i *= mult;
+        }
+        real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
+        memset(M, 0, szbuf * sizeof(real_t));                                  /* :1536 */
+        if (has_u)                                                             /* :1566-1571 */
+            for (int_t i = 0; i < k_totC; i++)
+                for (int_t j = 0; j < k_totC; j++)
+                    M[(size_t)i * k_totA + j] = CtCw[(size_t)i * k_totC + j];
+        real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;            /* :1360 */
+        for (size_t jx = st; jx < en; jx++)                                    /* :1694-1699 */
+            syr_upper_(kb, (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
+        /* :1542-1543 tail already zero; :1738-1742 rhs += B^T x */
+        for (size_t jx = st; jx < en; jx++)
+            axpy_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+        for (int_t i = 0; i < k_totA - 1; i++) M[(size_t)i * k_totA + i] += lam_i; /* :1819 */
+        M[(size_t)(k_totA - 1) * k_totA + (k_totA - 1)] += lam_last_i;
+        if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
+        else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+    }
+    free(bufs);
+    free(CtCw);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+real_t oracle_calc_mean_and_center(real_t *X, size_t nnz, int nthreads)
+{
+    double xsum = 0;
+    real_t glob_mean;
+    if (nthreads >= 8) {                                                       /* common.c:3497-3505 */
+        #pragma omp parallel for schedule(static) num_threads(nthreads) reduction(+:xsum)
+        for (size_t ix = 0; ix < nnz; ix++) xsum += X[ix];
+        glob_mean = (real_t)(xsum / (double)nnz);
+    } else {                                                                   /* :3510-3512 */
+        size_t cnt = 0;
+        for (size_t ix = 0; ix < nnz; ix++) xsum += (X[ix] - xsum) / (double)(++cnt);
+        glob_mean = (real_t)xsum;
+    }
+    if (fabs_t(glob_mean) < sqrt_t(EPSILON_T)) glob_mean = 0;                  /* :3603 */
+    if (glob_mean != 0)
+        for (size_t ix = 0; ix < nnz; ix++) X[ix] -= glob_mean;                /* :3642-3643 */
+    return glob_mean;
+}
+
+void oracle_initialize_biases_twosided(int_t m, int_t n,
+                                       const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                       const size_t *Xcsc_p, const int_t *Xcsc_i, const real_t *Xcsc,
+                                       real_t lam_user, real_t lam_item, bool scale_lam,
+                                       real_t *biasA, real_t *biasB)
+{
+    if (fabs_t(lam_user) < EPSILON_T) lam_user = EPSILON_T;                    /* common.c:4434-4437 */
+    if (fabs_t(lam_item) < EPSILON_T) lam_item = EPSILON_T;
+    memset(biasA, 0, (size_t)m * sizeof(real_t));
+    memset(biasB, 0, (size_t)n * sizeof(real_t));
+    for (int iter = 0; iter < 5; iter++) {
+        for (int_t col = 0; col < n; col++) {                                  /* :4643-4669 */
+            double bmean = 0;
+            size_t st = Xcsc_p[col], en = Xcsc_p[(size_t)col + 1];
+            for (size_t ix = st; ix < en; ix++)
+                bmean += (Xcsc[ix] - biasA[Xcsc_i[ix]] - bmean) / (double)(ix - st + 1);
+            size_t cnt = en - st;
+            bmean *= (double)cnt / ((double)cnt + lam_item * (scale_lam ? (double)(cnt > 1 ? cnt : 1) : 1.));
+            biasB[col] = (real_t)bmean;
+        }
+        for (int_t row = 0; row < m; row++) {                                  /* :4799-4825 */
+            double bmean = 0;
+            size_t st = Xcsr_p[row], en = Xcsr_p[(size_t)row + 1];
+            for (size_t ix = st; ix < en; ix++)
+                bmean += (Xcsr[ix] - biasB[Xcsr_i[ix]] - bmean) / (double)(ix - st + 1);
+            size_t cnt = en - st;
+            if (cnt > 0)
+                bmean *= (double)cnt / ((double)cnt + lam_user * (scale_lam ? (double)cnt : 1.));
+            biasA[row] = (real_t)bmean;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int oracle_fit_implicit_als(real_t *A, real_t *B, int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            real_t lam, real_t alpha, bool apply_log_transf,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
+{
+    real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
+    memcpy(Xc, X, nnz * sizeof(real_t));
+    if (apply_log_transf) for (size_t i = 0; i < nnz; i++) Xc[i] = log_t(Xc[i]);  /* collective.c:9578-9587 */
+    if (alpha != (real_t)1.) for (size_t i = 0; i < nnz; i++) Xc[i] *= alpha;     /* :9588-9599 */
+    size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));
+    size_t *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
+    int_t *csr_i = (int_t *)malloc(nnz * sizeof(int_t)), *csc_i = (int_t *)malloc(nnz * sizeof(int_t));
+    real_t *csr_v = (real_t *)malloc(nnz * sizeof(real_t)), *csc_v = (real_t *)malloc(nnz * sizeof(real_t));
+    oracle_coo_to_csr_and_csc(ixA, ixB, Xc, m, n, nnz, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v);
+    free(Xc);
+    if (!use_cg) finalize_chol = false;                                           /* :9518 */
+    for (int_t iter = 0; iter < niter; iter++) {                                  /* :9827-10045 */
+        if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
+        oracle_optimizeA_implicit(B, (size_t)k, A, (size_t)k, n, m, k, csc_p, csc_i, csc_v,
+                                  lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+        oracle_optimizeA_implicit(A, (size_t)k, B, (size_t)k, m, n, k, csr_p, csr_i, csr_v,
+                                  lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+    }
+    free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
+    return 0;
+}
+
+/* column means + centering of a dense side-info matrix, common.c:4911-4997 (dense, no NaN) */
+static real_t *center_by_cols_dense(const real_t *U, int_t m_u, int_t p, real_t *colmeans)
+{
+    real_t *Uc = (real_t *)malloc((size_t)m_u * p * sizeof(real_t));
+    for (int_t c = 0; c < p; c++) colmeans[c] = 0;
+    for (int_t r = 0; r < m_u; r++)
+        for (int_t c = 0; c < p; c++) colmeans[c] += U[(size_t)r * p + c];
+    for (int_t c = 0; c < p; c++) colmeans[c] /= (double)m_u;
+    for (int_t r = 0; r < m_u; r++)
+        for (int_t c = 0; c < p; c++) Uc[(size_t)r * p + c] = U[(size_t)r * p + c] - colmeans[c];
+    return Uc;
+}
+
+int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
+                            real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,
+                            int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            bool user_bias, bool item_bias, bool center,
+                            real_t lam, bool scale_lam, bool scale_lam_sideinfo,
+                            const real_t *U, int_t m_u, int_t p,
+                            const real_t *II, int_t n_i, int_t q,
+                            int_t k_main, int_t k_user, int_t k_item,
+                            real_t w_user, real_t w_item,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+                            bool init_biases)
+{
+    if (U == NULL) { m_u = 0; p = 0; }
+    if (II == NULL) { n_i = 0; q = 0; }
+    if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
+    if (m_u > m || n_i > n) return 2;          /* restatement restricted (see header) */
+    if ((U != NULL || II != NULL) && use_cg) return 2;   /* block-CG not restated */
+    if (init_biases && (user_bias != item_bias)) return 2;
+    scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
+    if (!use_cg) finalize_chol = false;                                        /* :7481 */
+    int_t has_bias = (user_bias || item_bias) ? 1 : 0;
+    int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
+    size_t ldA = (size_t)(k_totA + has_bias), ldB = (size_t)(k_totB + has_bias);
+
+    real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
+    memcpy(Xc, X, nnz * sizeof(real_t));
+    *glob_mean = center ? oracle_calc_mean_and_center(Xc, nnz, nthreads) : (real_t)0;  /* :7552-7568 */
+    size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));
+    size_t *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
+    int_t *csr_i = (int_t *)malloc(nnz * sizeof(int_t)), *csc_i = (int_t *)malloc(nnz * sizeof(int_t));
+    real_t *csr_v = (real_t *)malloc(nnz * sizeof(real_t)), *csc_v = (real_t *)malloc(nnz * sizeof(real_t));
+    oracle_coo_to_csr_and_csc(ixA, ixB, Xc, m, n, nnz, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v);
+    free(Xc);
+    real_t *Uc = NULL, *Ic = NULL;
+    if (U != NULL) Uc = center_by_cols_dense(U, m_u, p, U_colmeans);           /* :7850ff preprocess_sideinfo_matrix */
+    if (II != NULL) Ic = center_by_cols_dense(II, n_i, q, I_colmeans);
+
+    real_t *A_bias = A, *B_bias = B, *csr_orig = NULL, *csc_orig = NULL;
+    if (has_bias) {                                                            /* :7651-7677 */
+        A_bias = (real_t *)malloc((size_t)m * ldA * sizeof(real_t));
+        B_bias = (real_t *)malloc((size_t)n * ldB * sizeof(real_t));
+        if (item_bias) { csr_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csr_orig, csr_v, nnz * sizeof(real_t)); }
+        if (user_bias) { csc_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csc_orig, csc_v, nnz * sizeof(real_t)); }
+    }
+    if (has_bias && init_biases)                                               /* :8164-8226 */
+        oracle_initialize_biases_twosided(m, n, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v,
+                                          lam, lam, scale_lam, biasA, biasB);
+    if (has_bias) {                                                            /* :8283-8317 */
+        for (int_t r = 0; r < m; r++) {
+            memcpy(A_bias + (size_t)r * ldA, A + (size_t)r * k_totA, (size_t)k_totA * sizeof(real_t));
+            A_bias[(size_t)r * ldA + k_totA] = user_bias ? biasA[r] : (real_t)1;
+        }
+        for (int_t c = 0; c < n; c++) {
+            memcpy(B_bias + (size_t)c * ldB, B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));
+            B_bias[(size_t)c * ldB + k_totB] = item_bias ? biasB[c] : (real_t)1;
+        }
+    }
+
+    for (int_t iter = 0; iter < niter; iter++) {                               /* :8334-8898 */
+        if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
+        if (U != NULL)                                                         /* :8358-8387 */
+            oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A_bias, ldA, p, m_u, k_user + k,
+                                        Uc, (size_t)p, true, lam / w_user, lam / w_user, scale_lam, nthreads);
+        if (II != NULL)                                                        /* :8409-8441 */
+            oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B_bias, ldB, q, n_i, k_item + k,
+                                        Ic, (size_t)q, true, lam / w_item, lam / w_item, scale_lam, nthreads);
+        if (item_bias)                                                         /* :8538-8543 */
+            for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
+        if (user_bias)                                                         /* :8566-8570 */
+            for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
+        if (II != NULL)                                                        /* :8634-8678 */
+            oracle_optimizeA_collective_chol(B_bias, ldB, A_bias, ldA, D, n, n_i, m, q,
+                                             k, k_main + (int_t)item_bias, k_item, k_user,
+                                             csc_p, csc_i, csc_v, Ic, lam, w_item, lam,
+                                             scale_lam, scale_lam_sideinfo, nthreads);
+        else                                                                   /* :8680-8717 */
+            oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
+                                      k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
+                                      lam, lam, scale_lam, false, nthreads,
+                                      use_cg, precondition_cg, max_cg_steps);
+        if (item_bias)                                                         /* :8723-8725 */
+            for (int_t c = 0; c < n; c++) biasB[c] = B_bias[(size_t)c * ldB + k_totB];
+        if (user_bias)                                                         /* :8728-8732 */
+            for (int_t c = 0; c < n; c++) B_bias[(size_t)c * ldB + k_totB] = 1;
+        if (item_bias)                                                         /* :8750-8754 */
+            for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
+        if (U != NULL)                                                         /* :8805-8845 */
+            oracle_optimizeA_collective_chol(A_bias, ldA, B_bias, ldB, C, m, m_u, n, p,
+                                             k, k_main + (int_t)user_bias, k_user, k_item,
+                                             csr_p, csr_i, csr_v, Uc, lam, w_user, lam,
+                                             scale_lam, scale_lam_sideinfo, nthreads);
+        else                                                                   /* :8847-8876 */
+            oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,
+                                      k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
+                                      lam, lam, scale_lam, false, nthreads,
+                                      use_cg, precondition_cg, max_cg_steps);
+        if (user_bias)                                                         /* :8882-8884 */
+            for (int_t r = 0; r < m; r++) biasA[r] = A_bias[(size_t)r * ldA + k_totA];
+    }
+    if (has_bias) {                                                            /* :8908-8920 */
+        for (int_t r = 0; r < m; r++)
+            memcpy(A + (size_t)r * k_totA, A_bias + (size_t)r * ldA, (size_t)k_totA * sizeof(real_t));
+        for (int_t c = 0; c < n; c++)
+            memcpy(B + (size_t)c * k_totB, B_bias + (size_t)c * ldB, (size_t)k_totB * sizeof(real_t));
+        free(A_bias); free(B_bias);
+    }
+    free(csr_orig); free(csc_orig); free(Uc); free(Ic);
+    free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
+    return 0;
+}

@@ -1,0 +1,130 @@
+/*
+ * cmf_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C99 + OpenMP, no BLAS) of the ALS factor-update hot path of
+ * david-cortes/cmfrec, written from the reading of the reference sources.  Every function cites
+ * the reference file:line it follows.  It is the parity checker for the HIP path and the "port"
+ * CPU baseline of bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it; the product (cmfrec_amd/) never does.
+ *
+ * Pinned against the real reference (oracle/_ref, built from /root/reference by oracle/Makefile)
+ * by tests/test_oracle_vs_ref.py and against the committed fixtures in tests/golden/ (generated
+ * from the real reference by tests/golden/make_golden.py).
+ *
+ * Precision is fixed per shared object like the reference (src/cmfrec.h:232-294):
+ *   libcmf_oracle_double.so : real_t = double      libcmf_oracle_float.so : real_t = float
+ * int_t = int (32 bit), CSR/CSC offsets are size_t (src/cmfrec.h:300-305, :991).
+ */
+#ifndef CMF_ORACLE_H
+#define CMF_ORACLE_H
+#include <stddef.h>
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef ORACLE_FLOAT
+typedef float real_t;
+#else
+typedef double real_t;
+#endif
+typedef int int_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int oracle_sizeof_real(void);
+
+/* helpers.c:1375-1491 -- stable counting sort COO -> CSR and CSC (entries keep COO order). */
+void oracle_coo_to_csr_and_csc(const int_t *Xrow, const int_t *Xcol, const real_t *Xval,
+                               int_t m, int_t n, size_t nnz,
+                               size_t *csr_p, int_t *csr_i, real_t *csr_v,
+                               size_t *csc_p, int_t *csc_i, real_t *csc_v);
+
+/* cblas_tsyrk(RowMajor, Upper, Trans) call sites common.c:2824,3328: out[k*k] = B[:, :k]^T B[:, :k].
+ * Both triangles are filled. */
+void oracle_gram(const real_t *B, size_t ldb, int_t n, int_t k, real_t *out, int nthreads);
+
+/* common.c:3305-3421 (optimizeA_implicit).  use_cg: factors_implicit_cg (:1914-1986) or, with
+ * precondition_cg, factors_implicit_pcg (:1988-2061); else factors_implicit_chol (:2063-2126).
+ * BtB_out (k*k, may be NULL) receives BtB exactly as the reference leaves precomputedBtB
+ * (with +lam on the diagonal in Cholesky mode). */
+void oracle_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                               int_t m, int_t n, int_t k,
+                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                               real_t lam, int nthreads,
+                               bool use_cg, bool precondition_cg, int_t max_cg_steps,
+                               real_t *BtB_out);
+
+/* common.c:3209-3302 (optimizeA, Case 4: sparse X, missing-as-NA, no weights) ->
+ * factors_closed_form sparse branches (:631-1095): CG (:1098-1188), PCG (:1190-1291) or
+ * Cholesky (:978-1013,1060-1070). */
+void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                               int_t m, int_t n, int_t k,
+                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                               real_t lam, real_t lam_last,
+                               bool scale_lam, bool scale_bias_const,
+                               int nthreads,
+                               bool use_cg, bool precondition_cg, int_t max_cg_steps);
+
+/* common.c:2793-2991 (optimizeA, Case 1: dense full X, no weights) -- the C / D update.
+ * do_B=false: A[m,k] = Xfull[m,n] B[n,k] (BtB+diag)^-1 ; do_B=true: Xfull is [n, ldX>=m] and is
+ * used transposed (:2852-2855). */
+void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                 int_t m, int_t n, int_t k,
+                                 const real_t *Xfull, size_t ldX, bool do_B,
+                                 real_t lam, real_t lam_last, bool scale_lam, int nthreads);
+
+/* collective.c:4720-5969 general branch (:5566-5968) with sparse X (missing-as-NA), dense full
+ * U (no NaN), Cholesky -> collective_closed_form_block (:1223-1847).  m_u may be < m (rows
+ * >= m_u have no side info: u_vec == NULL, collective.c:5935 guarded by the m>m_u split :4832). */
+void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                      const real_t *C,
+                                      int_t m, int_t m_u, int_t n, int_t p,
+                                      int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      const real_t *U,
+                                      real_t lam, real_t w_user, real_t lam_last,
+                                      bool scale_lam, bool scale_lam_sideinfo,
+                                      int nthreads);
+
+/* common.c:3423-3648 (sparse, unweighted branch :3494-3524, :3599-3604). Returns the mean and
+ * subtracts it from X in place. nthreads>=8 switches from the running mean to sum/cnt (:3497). */
+real_t oracle_calc_mean_and_center(real_t *X, size_t nnz, int nthreads);
+
+/* common.c:4410-4909 (sparse, unweighted, !NA_as_zero branches :4643-4669, :4799-4825). */
+void oracle_initialize_biases_twosided(int_t m, int_t n,
+                                       const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                       const size_t *Xcsc_p, const int_t *Xcsc_i, const real_t *Xcsc,
+                                       real_t lam_user, real_t lam_item, bool scale_lam,
+                                       real_t *biasA, real_t *biasB);
+
+/* collective.c:9375-10207 restricted to: no side info, k_main=k_user=k_item=0 allowed only as 0,
+ * w_main=1, no L1/nonneg.  reset_values must be false (caller injects A, B). */
+int oracle_fit_implicit_als(real_t *A, real_t *B, int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            real_t lam, real_t alpha, bool apply_log_transf,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol);
+
+/* collective.c:7263-9370 restricted to: sparse X missing-as-NA, no weights, optional dense full
+ * U[m_u,p] / II[n_i,q] (m_u<=m, n_i<=n), w_main=1, no L1/nonneg/implicit features.
+ * reset_values=false semantics: caller injects A, B (and biasA/biasB start values, C, D).
+ * With side info only Cholesky is restated (block-CG is SURVEY 8f). Returns 0 ok, 2 unsupported. */
+int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
+                            real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,
+                            int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            bool user_bias, bool item_bias, bool center,
+                            real_t lam, bool scale_lam, bool scale_lam_sideinfo,
+                            const real_t *U, int_t m_u, int_t p,
+                            const real_t *II, int_t n_i, int_t q,
+                            int_t k_main, int_t k_user, int_t k_item,
+                            real_t w_user, real_t w_item,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+                            bool init_biases);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
