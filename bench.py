@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- ALS iteration throughput of the MI355X-native cmfrec hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one ALS iteration (B half-step + A half-step, src/collective.c:9827-10045) over a
+synthetic implicit-feedback matrix with the shape/nnz of LastFM-360K (BASELINE.json configs[1]:
+CMF_implicit, ALS-CG, k=50, fp64, lambda=5, max_cg_steps=3), factors and CSR/CSC resident in HBM
+when the timed region starts.  value = rows/s = (users + items) / iteration time.
+
+N > 1: weak scaling.  Every rank owns one LastFM-sized user block (358,858 users, 17.3M nnz, own
+seed) and 1/N of the 160,112 items; each half-step updates the local block and is followed by an
+all-gather of the updated factor matrix over RCCL (torch.distributed, backend nccl).
+
+Prints ONE JSON line (rank 0) with the contract fields + "roofline" + "cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[1] / SURVEY.md 8d "C2"
+M_USERS, N_ITEMS, NNZ, K = 358_858, 160_112, 17_309_518, 50
+LAM, MAX_CG_STEPS = 5.0, 3
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_block(m, n, nnz, seed):
+    """SURVEY.md 8d generator: lognormal row weights, 1/rank^0.8 column weights (permuted),
+    1.35*nnz draws, unique, permute, keep nnz; counts = ceil(lognormal(3, 1.5))."""
+    rng = np.random.default_rng(seed)
+    rw = rng.lognormal(0, 1, m); rw /= rw.sum()
+    cw = 1.0 / np.arange(1, n + 1) ** 0.8; cw = rng.permutation(cw); cw /= cw.sum()
+    draws = int(1.35 * nnz)
+    rcdf = np.cumsum(rw); ccdf = np.cumsum(cw)
+    r = np.minimum(np.searchsorted(rcdf, rng.random(draws)), m - 1).astype(np.int64)
+    c = np.minimum(np.searchsorted(ccdf, rng.random(draws)), n - 1).astype(np.int64)
+    lin = np.unique(r * n + c)
+    lin = rng.permutation(lin)[:nnz]
+    if len(lin) < nnz:
+        raise RuntimeError("generator produced too few unique pairs")
+    row = (lin // n).astype(np.int32); col = (lin % n).astype(np.int32)
+    val = np.ceil(rng.lognormal(3, 1.5, nnz))
+    return row, col, val
+
+
+def to_csr(row, col, val, nrows):
+    """Stable COO -> CSR (entries keep COO order inside a row, like helpers.c:1375-1491)."""
+    order = np.argsort(row, kind="stable")
+    indptr = np.zeros(nrows + 1, np.uint64)
+    np.cumsum(np.bincount(row, minlength=nrows), out=indptr[1:])
+    return indptr, col[order].astype(np.int32), val[order]
+
+
+def algorithmic_bytes(nnz, rows, k, w=8):
+    """bytes_half = nnz*k*w (gather, once) + nnz*(4+w) (CSR) + (rows+1)*8 (indptr)
+    + 2*rows*k*w (warm start in, result out) + k*k*w (BtB)."""
+    return nnz * k * w + nnz * (4 + w) + (rows + 1) * 8 + 2 * rows * k * w + k * k * w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from cmfrec_amd.session import AlsSession
+    from cmfrec_amd.distributed import ShardedAls, GpuEngine
+
+    m_blk = int(M_USERS * args.scale); n = int(N_ITEMS * args.scale); nnz_blk = int(NNZ * args.scale)
+    m = m_blk * world
+    t0 = time.time()
+    row, col, val = synth_block(m_blk, n, nnz_blk, seed=2 + rank)       # C2 uses seed 2
+    t_gen = time.time() - t0
+
+    rng = np.random.default_rng(100 + rank)
+    A0_blk = rng.random((m_blk, K)) * 2.0 ** -7        # uniform start like the reference (collective.c:9762)
+    if world == 1:
+        csr = to_csr(row, col, val, m_blk)
+        csc = to_csr(col, row, val, n)
+        sess = AlsSession(m, n, K, implicit=True, dtype=np.float64, lam=LAM, use_cg=True, max_cg_steps=MAX_CG_STEPS,
+                          device=local_rank)
+        sess.set_X(csr, csc)
+        sess.set_factors(A=A0_blk, B=np.zeros((n, K)))
+        engine = None
+
+        def step():
+            sess.update("B"); sess.update("A")
+
+        def sync():
+            sess.sync()
+    else:
+        eng = GpuEngine.from_user_block(m_blk, n, K, row, col, val, A0_blk, lam=LAM, max_cg_steps=MAX_CG_STEPS,
+                                        rank=rank, world=world, device=local_rank)
+        engine = ShardedAls(eng, rank, world)
+        sess = eng.session
+
+        def step():
+            engine.iteration()
+
+        def sync():
+            sess.sync(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    sess.reset_timers()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    rows_per_s = (m + n) / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (per nnz-bin launch of the CG row kernel) ----
+    names = {0: "cg_rows_kernel<W=8> (rows > 256 nnz)", 1: "cg_rows_kernel<W=4> (65..256 nnz)",
+             2: "cg_rows_kernel<W=1> (<= 64 nnz)"}
+    kernels = []
+    for which in ("B", "A"):
+        for b in range(3):
+            ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
+            if cnt:
+                kernels.append(dict(step=which, kernel=names[b], ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
+                                    avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, K)))
+    dom = max(kernels, key=lambda d: d["ms_total"])
+    achieved = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
+    msA, cntA = sess.kernel_time("A"); msB, cntB = sess.kernel_time("B")
+    halfstep_ms = {"A": msA / max(cntA, 1), "B": msB / max(cntB, 1)}
+    iter_bytes = sum(d["alg_bytes"] for d in kernels)
+    roofline = dict(bound="hbm", kernel="%s, %s-step" % (dom["kernel"], dom["step"]), achieved=round(achieved, 1),
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    avg_launch_ms=round(dom["avg_ms"], 4),
+                    iteration={"alg_GB": round(iter_bytes / 1e9, 3), "halfstep_ms": halfstep_ms,
+                               "frac_of_hbm_peak": round(iter_bytes / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)},
+                    per_kernel=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4),
+                                     GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1)) for d in kernels])
+
+    # ---- CPU baseline: the reference itself (oracle/_ref) on this host, rank 0 / N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(row, col, val, m_blk, n, A0_blk)
+
+    if rank == 0:
+        out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=50 fp64",
+               "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "CMF_implicit ALS-CG k=50 fp64, LastFM-360K shape (synthetic): %d users x %d items, "
+                                      "%d nnz%s; lambda=5, max_cg_steps=3" % (m, n, nnz_blk * world,
+                                                                               " (1 LastFM-sized user block per GPU)" if world > 1 else ""),
+                          "parallelism": "row-block x%d + all-gather" % world if world > 1 else "single GPU",
+                          "gen_seconds": round(t_gen, 1)},
+               "roofline": roofline, "cpu_baseline": cpu}
+        if args.scale != 1.0:
+            out["config"]["INVALID_scaled_down"] = args.scale
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(row, col, val, m, n, A0):
+    """Times the CPU path beside the GPU number: the real reference (oracle/_ref, kind 'reference')
+    if it travelled with the repo, else our C restatement (kind 'port').  Sample: full B+A
+    half-steps of the same workload, all host cores."""
+    from oracle.bindings import Oracle, Reference, ref_available
+    cores = os.cpu_count() or 1
+    O = Oracle(np.float64)
+    csr, csc = O.coo_to_csr_and_csc(row, col, val, m, n)
+    if ref_available(np.float64):
+        eng, kind = Reference(np.float64), "reference"
+    else:
+        eng, kind = O, "port"
+    A = A0.copy(); B = np.zeros((n, K))
+    iters, t_tot = 0, 0.0
+    while iters < 3 and t_tot < 20.0:
+        t0 = time.perf_counter()
+        eng.optimizeA_implicit(B, A, csc, LAM, nthreads=cores, use_cg=True, max_cg_steps=MAX_CG_STEPS)
+        eng.optimizeA_implicit(A, B, csr, LAM, nthreads=cores, use_cg=True, max_cg_steps=MAX_CG_STEPS)
+        t_tot += time.perf_counter() - t0
+        iters += 1
+    s_per_iter = t_tot / iters
+    return {"value": round((m + n) / s_per_iter, 1), "unit": "rows/s", "cores": cores, "kind": kind,
+            "s_per_iteration": round(s_per_iter, 3),
+            "sample": "%d full ALS iterations (optimizeA_implicit B-step + A-step) of the same workload, "
+                      "OpenMP nthreads=%d, OpenBLAS from SciPy" % (iters, cores)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI in include/cmfrec_hip.h (libcmfrec_hip_{double,float}.so).
+
+The libraries are built in-tree by ``__graft_entry__.build()`` / ``make -C cmfrec_amd/csrc``.
+There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(_HERE, "lib")
+
+RETURN_CODES = {0: "ok", 1: "out of memory", 2: "invalid or unsupported input", 3: "interrupted",
+                4: "HIP runtime failure"}
+
+
+class Model(C.Structure):
+    """``cmfrec_hip_model`` (include/cmfrec_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "implicit", "m", "n", "k", "k_main", "k_user", "k_item", "user_bias", "item_bias",
+        "scale_lam", "scale_lam_sideinfo", "use_cg", "precondition_cg", "max_cg_steps",
+        "p", "q", "m_u", "n_i")] + [("lam", C.c_double), ("w_user", C.c_double), ("w_item", C.c_double)] + \
+        [(n, C.c_int32) for n in ("row_begin", "row_end", "col_begin", "col_end")]
+
+
+class ModelF(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "implicit", "m", "n", "k", "k_main", "k_user", "k_item", "user_bias", "item_bias",
+        "scale_lam", "scale_lam_sideinfo", "use_cg", "precondition_cg", "max_cg_steps",
+        "p", "q", "m_u", "n_i")] + [("lam", C.c_float), ("w_user", C.c_float), ("w_item", C.c_float)] + \
+        [(n, C.c_int32) for n in ("row_begin", "row_end", "col_begin", "col_end")]
+
+
+EXPORTED = [
+    "fit_collective_implicit_als", "fit_collective_explicit_als",
+    "cmfrec_hip_optimizeA_implicit", "cmfrec_hip_optimizeA_explicit",
+    "cmfrec_hip_optimizeA_dense_full", "cmfrec_hip_optimizeA_collective",
+    "cmfrec_hip_session_create", "cmfrec_hip_session_destroy", "cmfrec_hip_last_error",
+    "cmfrec_hip_session_set_X", "cmfrec_hip_session_set_factors", "cmfrec_hip_session_get_factors",
+    "cmfrec_hip_session_set_sideinfo", "cmfrec_hip_session_update", "cmfrec_hip_session_iterate",
+    "cmfrec_hip_session_sync", "cmfrec_hip_session_device_ptr", "cmfrec_hip_session_stream",
+    "cmfrec_hip_session_after_gather", "cmfrec_hip_session_kernel_time",
+    "cmfrec_hip_session_reset_timers", "cmfrec_hip_session_bin_stats", "cmfrec_hip_sizeof_real", "cmfrec_hip_build_info",
+]
+
+_cache = {}
+
+
+def lib_path(dtype):
+    suffix = "double" if np.dtype(dtype) == np.float64 else "float"
+    return os.path.join(LIBDIR, "libcmfrec_hip_%s.so" % suffix)
+
+
+def load(dtype=np.float64):
+    """Returns the ctypes handle of the library for ``dtype`` (float64 / float32)."""
+    dtype = np.dtype(dtype).type
+    if dtype not in (np.float64, np.float32):
+        raise ValueError("dtype must be float64 or float32")
+    if dtype in _cache:
+        return _cache[dtype]
+    path = lib_path(dtype)
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: the HIP extension has not been built (run __graft_entry__.build() or "
+            "`make -C cmfrec_amd/csrc`). cmfrec_amd has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    lib.cmfrec_hip_last_error.restype = C.c_char_p
+    lib.cmfrec_hip_build_info.restype = C.c_char_p
+    lib.cmfrec_hip_session_create.restype = C.c_void_p
+    lib.cmfrec_hip_session_device_ptr.restype = C.c_void_p
+    lib.cmfrec_hip_session_stream.restype = C.c_void_p
+    assert lib.cmfrec_hip_sizeof_real() == np.dtype(dtype).itemsize
+    _cache[dtype] = lib
+    return lib
+
+
+def real(dtype):
+    return C.c_double if np.dtype(dtype) == np.float64 else C.c_float
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check(rc, lib, what):
+    if rc == 0:
+        return
+    msg = lib.cmfrec_hip_last_error()
+    msg = msg.decode() if msg else ""
+    if rc == 1:
+        raise MemoryError("%s: out of memory. %s" % (what, msg))
+    if rc == 3:
+        raise InterruptedError("%s: procedure was interrupted" % what)
+    raise RuntimeError("%s failed with code %d (%s). %s" % (what, rc, RETURN_CODES.get(rc, "?"), msg))

@@ -1,0 +1,388 @@
+// cg_kernels.hpp -- conjugate-gradient ALS row updates for gfx950 (MI355X, wave64).
+//
+// Device-side replacement of the reference's per-row CG solvers and of the OpenMP row loops
+// that call them:
+//   implicit: factors_implicit_cg   /root/reference/src/common.c:1914-1986, loop :3349-3368
+//   explicit: factors_explicit_cg   /root/reference/src/common.c:1098-1188, loop :3259-3299
+//             (per-row lambda scaling of factors_closed_form, common.c:679-723)
+//
+// Mapping (see DESIGN.md "CG row kernel"): one wavefront (or W cooperating wavefronts) per row.
+// The 64 lanes form an 8 x 8 grid  lane = jj*8 + ll :
+//     jj = lane>>3  owns 8 consecutive non-zeros of a 64-nnz tile  (j = jj*8 + t, t<8)
+//     ll = lane&7   owns factor columns f = ll + 8*s, s<S           (S = ceil(k/8))
+// so every lane keeps an 8 x S register block of the gathered opposing-factor rows.  Each row of
+// B is read from HBM/L2 as 8-lane x 8-byte (64 B) contiguous segments, once; for rows whose
+// tiles fit the cooperating waves' registers the block is reused by all (steps+1) CG passes, so
+// the (s+1) gather passes of the reference become one.  Per pass and tile:
+//     phase 1  c_j  = B_j . v            8*S FMAs / lane + 3-stage transposed reduction over ll
+//     phase 2  out += w_j B_j            8*S FMAs / lane, reduced over jj once per pass
+// Vectors of length k live either "distributed" (lane f holds element f) or "replicated over
+// jj" (lane (jj,ll) holds elements ll+8s).  No LDS is used for the gather; LDS only holds the
+// k x k Gramian BtB of the implicit model (one copy per workgroup) and the cross-wave partials.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace cmfhip {
+
+constexpr int WAVE = 64;
+constexpr int TILE = 64;          // non-zeros per register tile
+constexpr int MAX_W = 8;          // max cooperating waves per row
+
+template <typename T>
+struct CgParams {
+    T *A;                 // [nrows_total, lda] matrix being updated, first solved column
+    size_t lda;
+    const T *B;           // opposing factor matrix, first used column
+    size_t ldb;
+    int k;                // columns solved (<= 8*S)
+    const size_t *indptr; // CSR of the local rows
+    const int *indices;
+    const T *values;
+    const T *bias_sub;    // explicit: x_j := x_j - bias_sub[idx_j] (fused "X - bias" sweep), or null
+    const int *order;     // row ids to process
+    int nrows;
+    const T *BtB;         // implicit: k x k Gramian of B (row-major, ld = k, both triangles)
+    T lam, lam_last;
+    int scale_lam, scale_bias_const;
+    int max_cg_steps;
+};
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Transposed butterfly: 8 values per lane, summed over the 8 lanes that differ in the lane bits
+// selected by masks (M2,M1,M0); the lane whose bits are (b2,b1,b0) ends with the total of
+// v[4*b2+2*b1+b0].
+template <typename T, int M2, int M1, int M0>
+__device__ __forceinline__ T treduce8(const T (&v)[8], int lane)
+{
+    T u[4], q[2];
+    bool h = (lane & M2) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        T keep = h ? v[i + 4] : v[i];
+        T send = h ? v[i] : v[i + 4];
+        u[i] = keep + __shfl_xor(send, M2);
+    }
+    h = (lane & M1) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        T keep = h ? u[i + 2] : u[i];
+        T send = h ? u[i] : u[i + 2];
+        q[i] = keep + __shfl_xor(send, M1);
+    }
+    h = (lane & M0) != 0;
+    T keep = h ? q[1] : q[0];
+    T send = h ? q[0] : q[1];
+    return keep + __shfl_xor(send, M0);
+}
+
+// LDS leading dimension for the staged Gramian: multiple of 8, == 8 or 24 (mod 32) doubles so
+// that the 4 jj-groups of a half-wave hit distinct banks with ds_read_b64.
+__host__ __device__ constexpr int gram_ld(int S) { return ((8 * S) % 32 == 8 || (8 * S) % 32 == 24) ? 8 * S : 8 * S + 8; }
+
+template <typename T, int S>
+struct RegTile {
+    T v[8][S];
+};
+
+template <typename T, int S>
+__device__ __forceinline__ void load_tile(RegTile<T, S> &tile, const T *__restrict__ Bm, size_t ldb,
+                                          int k, int my_idx, int cnt, int lane)
+{
+    const int jj = lane >> 3, ll = lane & 7;
+    const bool last_ok = (ll + 8 * (S - 1)) < k;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        int it = __shfl(my_idx, (lane & ~7) | t);
+        bool valid = (jj * 8 + t) < cnt;
+        const T *rp = Bm + (size_t)it * ldb + ll;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            bool ok = valid && (s < S - 1 || last_ok);
+            tile.v[t][s] = ok ? rp[8 * s] : T(0);
+        }
+    }
+}
+
+// One tile contribution:  c_j = B_j . vrep ; w_j = f(c_j, x_j) ; out[s] += sum_t w_j B_j[s]
+// MODE 0: residual pass, MODE 1: A*p pass.
+template <typename T, int S, bool IMPLICIT, int MODE>
+__device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid,
+                                          T (&out)[8], int lane)
+{
+    T c[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        T acc = T(0);
+#pragma unroll
+        for (int s = 0; s < S; s++) acc += tile.v[t][s] * vrep[s];
+        c[t] = acc;
+    }
+    T coef = treduce8<T, 4, 2, 1>(c, lane);      // lane j now holds B_j . v
+    T w;
+    if (IMPLICIT) {
+        if (MODE == 0) w = -(coef - T(1)) * x - coef;     // common.c:1939
+        else           w = coef * (x - T(1)) + coef;      // common.c:1965
+    } else {
+        if (MODE == 0) w = -(coef - x);                   // common.c:1121-1123
+        else           w = coef;                          // common.c:1158-1159
+    }
+    if (!valid) w = T(0);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        T wt = __shfl(w, (lane & ~7) | t);
+#pragma unroll
+        for (int s = 0; s < S; s++) out[s] += wt * tile.v[t][s];
+    }
+}
+
+// out[s] += sum_j wdist_j * G[j][ll+8s]  with the Gramian staged in LDS (rows padded to 64).
+template <typename T, int S>
+__device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, T (&out)[8], int lane)
+{
+    constexpr int LD = gram_ld(S);
+    const int jj = lane >> 3, ll = lane & 7;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        T wt = __shfl(wdist, (lane & ~7) | t);
+        const T *g = G + (jj * 8 + t) * LD + ll;
+#pragma unroll
+        for (int s = 0; s < S; s++) out[s] += wt * g[8 * s];
+    }
+}
+
+template <typename T, int S>
+__device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane)
+{
+    const int ll = lane & 7;
+#pragma unroll
+    for (int s = 0; s < S; s++) vrep[s] = __shfl(vdist, s * 8 + ll);
+}
+
+// Persistent kernel: W waves cooperate on one row (W = waves per row, blockDim.x = 64*W*RPB where
+// RPB rows are processed concurrently by one workgroup).
+template <typename T, int S, bool IMPLICIT, int W, int RPB>
+__global__ void __launch_bounds__(64 * W * RPB, 2)
+cg_rows_kernel(const CgParams<T> P)
+{
+    constexpr int LD = gram_ld(S);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *G = reinterpret_cast<T *>(smem_raw);                                  // [64][LD] (implicit)
+    T *red = G + (IMPLICIT ? 64 * LD : 0);                                   // [RPB][2][W][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int grp = wave / W;      // which concurrent row of this workgroup
+    const int wr = wave % W;       // wave index inside the row team
+    const int k = P.k;
+
+    if (IMPLICIT) {
+        for (int e = tid; e < 64 * LD; e += blockDim.x) {
+            int r = e / LD, c = e % LD;
+            G[e] = (r < k && c < k) ? P.BtB[(size_t)r * k + c] : T(0);
+        }
+        __syncthreads();
+    }
+    T *myred = red + (size_t)grp * 2 * W * 64;
+
+    const int nteams = gridDim.x * RPB;
+    int buf = 0;   // cross-wave exchange buffer parity; persists across rows
+    static_assert(W == 1 || RPB == 1, "multi-wave teams own their workgroup (barriers are per row)");
+    for (int rix = blockIdx.x * RPB + grp; rix < P.nrows; rix += nteams) {
+        const bool active = true;
+        const int row = P.order[rix];
+        const size_t st = P.indptr[row];
+        const int nnz = (int)(P.indptr[row + 1] - st);
+        const int ntiles = (nnz + TILE - 1) / TILE;
+        const int my_ntiles = (ntiles > wr) ? (ntiles - wr + W - 1) / W : 0;
+        const bool resident = my_ntiles <= 1;
+
+        T lam = P.lam, lam_last = P.lam_last;
+        if (!IMPLICIT && P.scale_lam) {                       // common.c:679-723
+            lam *= (T)nnz;
+            if (!P.scale_bias_const) lam_last *= (T)nnz;
+        }
+        T *arow = P.A + (size_t)row * P.lda;
+        T a_d = (active && lane < k) ? arow[lane] : T(0);
+
+        RegTile<T, S> tile;
+        T x_res = T(0);
+        bool valid_res = false;
+
+        auto run_pass = [&](T vdist, auto mode_tag, bool first) -> T {
+            constexpr int MODE = decltype(mode_tag)::value;
+            // keep the staged Gramian in LDS: without this the compiler hoists its 8*S loads per
+            // lane out of the pass / row loops and pins 16*S VGPRs (occupancy 2 -> 1 wave/SIMD)
+            asm volatile("" ::: "memory");
+            T vrep[S];
+            replicate<T, S>(vdist, vrep, lane);
+            T out[8];
+#pragma unroll
+            for (int s = 0; s < 8; s++) out[s] = T(0);
+            for (int tl = wr; tl < ntiles; tl += W) {
+                T x; bool valid;
+                if (!resident || first) {
+                    const int cnt = min(TILE, nnz - tl * TILE);
+                    valid = lane < cnt;
+                    const size_t pos = st + (size_t)tl * TILE + lane;
+                    int my_idx = valid ? P.indices[pos] : 0;
+                    x = valid ? P.values[pos] : T(0);
+                    if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
+                    load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
+                    x_res = x; valid_res = valid;
+                } else {
+                    x = x_res; valid = valid_res;
+                }
+                tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+            }
+            if (IMPLICIT && wr == 0)
+                gram_pass<T, S>(G, (MODE == 0) ? -vdist : vdist, out, lane);   // common.c:1932 / :1958
+            T tot = treduce8<T, 32, 16, 8>(out, lane);                        // lane f <- element f
+            if (W > 1) {
+                T *rb = myred + (size_t)buf * W * 64;
+                rb[wr * 64 + lane] = tot;
+                __syncthreads();
+                tot = T(0);
+#pragma unroll
+                for (int w = 0; w < W; w++) tot += rb[w * 64 + lane];
+                buf ^= 1;
+            }
+            return tot;
+        };
+
+        // ---- residual (common.c:1932-1943 / :1112-1139) ----
+        T r_d = run_pass(a_d, std::integral_constant<int, 0>{}, true);
+        r_d -= lam * a_d;
+        if (!IMPLICIT && lam != lam_last && lane == k - 1) r_d -= (lam_last - lam) * a_d;
+        if (lane >= k) r_d = T(0);
+        T p_d = r_d;
+        T r_old = wave_sum(r_d * r_d);
+        // r_old / r_new are bit-identical on every wave of the team (same LDS partials summed in
+        // the same order), so the data-dependent exits below are uniform over the workgroup.
+        bool done = (r_old <= (T)1e-12);            // common.c:1952 / :1147
+        for (int step = 0; step < P.max_cg_steps && !done; step++) {
+            T Ap_d = run_pass(p_d, std::integral_constant<int, 1>{}, false);
+            Ap_d += lam * p_d;
+            if (!IMPLICIT && lam != lam_last && lane == k - 1) Ap_d += (lam_last - lam) * p_d;
+            if (lane >= k) Ap_d = T(0);
+            T alpha = r_old / wave_sum(Ap_d * p_d);
+            a_d += alpha * p_d;
+            r_d -= alpha * Ap_d;
+            T r_new = wave_sum(r_d * r_d);
+            if (r_new <= (T)1e-8) done = true;      // common.c:1979 / :1180
+            else {
+                p_d = p_d * (r_new / r_old) + r_d;
+                r_old = r_new;
+            }
+        }
+        if (active && wr == 0 && lane < k) arow[lane] = a_d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Generic fallback (any k): one wavefront per row, lane f owns factors f, f+64, ...; the dot
+// product of every gathered row is a wave reduction.  Same arithmetic as above, used for k
+// beyond the register-tile instantiations and as an on-device cross-check of the tiled kernel.
+template <typename T, int NF, bool IMPLICIT>
+__global__ void __launch_bounds__(256)
+cg_rows_generic_kernel(const CgParams<T> P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int k = P.k;
+    for (int rix = wave_global; rix < P.nrows; rix += nwaves) {
+        const int row = P.order[rix];
+        const size_t st = P.indptr[row];
+        const int nnz = (int)(P.indptr[row + 1] - st);
+        T lam = P.lam, lam_last = P.lam_last;
+        if (!IMPLICIT && P.scale_lam) {
+            lam *= (T)nnz;
+            if (!P.scale_bias_const) lam_last *= (T)nnz;
+        }
+        T *arow = P.A + (size_t)row * P.lda;
+        T a[NF], r[NF], p[NF], Ap[NF];
+#pragma unroll
+        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; a[c] = (f < k) ? arow[f] : T(0); }
+
+        auto matvec = [&](const T (&v)[NF], T (&out)[NF], int mode) {
+#pragma unroll
+            for (int c = 0; c < NF; c++) out[c] = T(0);
+            if (IMPLICIT) {
+                for (int j = 0; j < k; j++) {                  // out = +-BtB v (row j of BtB times v_j)
+                    int cj = j >> 6, lj = j & 63;
+                    T vj = T(0);
+#pragma unroll
+                    for (int c = 0; c < NF; c++) if (c == cj) vj = __shfl(v[c], lj);
+                    if (mode == 0) vj = -vj;
+#pragma unroll
+                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f < k) out[c] += vj * P.BtB[(size_t)j * k + f]; }
+                }
+            }
+            for (int j = 0; j < nnz; j++) {
+                const int idx = P.indices[st + j];
+                T x = P.values[st + j];
+                if (!IMPLICIT && P.bias_sub != nullptr) x -= P.bias_sub[idx];
+                const T *b = P.B + (size_t)idx * P.ldb;
+                T bv[NF]; T part = T(0);
+#pragma unroll
+                for (int c = 0; c < NF; c++) { int f = lane + 64 * c; bv[c] = (f < k) ? b[f] : T(0); part += bv[c] * v[c]; }
+                T coef = wave_sum(part);
+                T w;
+                if (IMPLICIT) w = (mode == 0) ? (-(coef - T(1)) * x - coef) : (coef * (x - T(1)) + coef);
+                else          w = (mode == 0) ? -(coef - x) : coef;
+#pragma unroll
+                for (int c = 0; c < NF; c++) out[c] += w * bv[c];
+            }
+        };
+        auto vdot = [&](const T (&u)[NF], const T (&v)[NF]) {
+            T s = T(0);
+#pragma unroll
+            for (int c = 0; c < NF; c++) s += u[c] * v[c];
+            return wave_sum(s);
+        };
+        matvec(a, r, 0);
+#pragma unroll
+        for (int c = 0; c < NF; c++) {
+            int f = lane + 64 * c;
+            r[c] -= lam * a[c];
+            if (!IMPLICIT && lam != lam_last && f == k - 1) r[c] -= (lam_last - lam) * a[c];
+            if (f >= k) r[c] = T(0);
+            p[c] = r[c];
+        }
+        T r_old = vdot(r, r);
+        if (r_old > (T)1e-12) {
+            for (int step = 0; step < P.max_cg_steps; step++) {
+                matvec(p, Ap, 1);
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    int f = lane + 64 * c;
+                    Ap[c] += lam * p[c];
+                    if (!IMPLICIT && lam != lam_last && f == k - 1) Ap[c] += (lam_last - lam) * p[c];
+                    if (f >= k) Ap[c] = T(0);
+                }
+                T alpha = r_old / vdot(Ap, p);
+#pragma unroll
+                for (int c = 0; c < NF; c++) { a[c] += alpha * p[c]; r[c] -= alpha * Ap[c]; }
+                T r_new = vdot(r, r);
+                if (r_new <= (T)1e-8) break;
+                T ratio = r_new / r_old;
+#pragma unroll
+                for (int c = 0; c < NF; c++) p[c] = p[c] * ratio + r[c];
+                r_old = r_new;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f < k) arow[f] = a[c]; }
+    }
+}
+
+}  // namespace cmfhip

@@ -1,0 +1,187 @@
+// dense_kernels.hpp -- small dense helpers of the ALS path for gfx950.
+//
+//   gram_*        : G = B[:, :k]^T B[:, :k]            (cblas_tsyrk call sites, reference
+//                   src/common.c:2824, :3328; src/collective.c:6287-6296)
+//   column ops    : strided column copy / fill on the [rows, k+1] "factor + bias column" layout
+//                   (reference src/collective.c:8538-8543, :8723-8732, :8882-8884)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmfhip {
+
+// Stage 1: each workgroup reduces a contiguous chunk of rows into a private k x k partial (upper
+// and lower computed alike, the result is symmetric by construction: entry (i,j) and (j,i) are
+// the same products summed in the same order).  Stage 2 sums the partials in block order, so the
+// result is deterministic (no floating-point atomics).
+template <typename T>
+__global__ void __launch_bounds__(256)
+gram_partial_kernel(const T *__restrict__ B, size_t ldb, int n, int k, int rows_per_block,
+                    T *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *Bs = reinterpret_cast<T *>(smem_raw);          // [32][k]
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    const int nent = k * k;
+    constexpr int MAXE = 16;                          // entries per thread (k <= 64 -> 16)
+    T acc[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) acc[e] = T(0);
+    for (int rb = r0; rb < r1; rb += 32) {
+        const int nr = min(32, r1 - rb);
+        __syncthreads();
+        for (int e = tid; e < nr * k; e += 256) {
+            int r = e / k, c = e % k;
+            Bs[r * k + c] = B[(size_t)(rb + r) * ldb + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            int ent = tid + 256 * e;
+            if (ent < nent) {
+                int i = ent / k, j = ent % k;
+                int lo = min(i, j), hi = max(i, j);   // same operand order for (i,j) and (j,i)
+                T s = acc[e];
+                for (int r = 0; r < nr; r++) s += Bs[r * k + lo] * Bs[r * k + hi];
+                acc[e] = s;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < MAXE; e++) {
+        int ent = tid + 256 * e;
+        if (ent < nent) partial[(size_t)blockIdx.x * nent + ent] = acc[e];
+    }
+}
+
+template <typename T>
+__global__ void gram_reduce_kernel(const T *__restrict__ partial, int nblocks, int nent,
+                                   T *__restrict__ out, T scale, T add_diag, int k)
+{
+    int ent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ent >= nent) return;
+    T s = T(0);
+    for (int b = 0; b < nblocks; b++) s += partial[(size_t)b * nent + ent];
+    s *= scale;
+    if (ent / k == ent % k) s += add_diag;
+    out[ent] = s;
+}
+
+// generic-k fallback for the Gramian (k > 64): one thread per entry, rows streamed from L2.
+template <typename T>
+__global__ void gram_naive_kernel(const T *__restrict__ B, size_t ldb, int n, int k,
+                                  T *__restrict__ out, T scale, T add_diag)
+{
+    int ent = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ent >= k * k) return;
+    int i = ent / k, j = ent % k;
+    int lo = min(i, j), hi = max(i, j);
+    T s = T(0);
+    for (int r = 0; r < n; r++) s += B[(size_t)r * ldb + lo] * B[(size_t)r * ldb + hi];
+    s *= scale;
+    if (i == j) s += add_diag;
+    out[ent] = s;
+}
+
+template <typename T>
+__global__ void col_fill_kernel(T *__restrict__ M, size_t ld, int rows, int col, T value)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) M[(size_t)r * ld + col] = value;
+}
+
+template <typename T>
+__global__ void col_extract_kernel(const T *__restrict__ M, size_t ld, int rows, int col, T *__restrict__ out)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) out[r] = M[(size_t)r * ld + col];
+}
+
+template <typename T>
+__global__ void col_insert_kernel(T *__restrict__ M, size_t ld, int rows, int col, const T *__restrict__ in)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) M[(size_t)r * ld + col] = in[r];
+}
+
+// dst[r, 0:cols] = src[r, 0:cols] with different leading dimensions (copy_mat, helpers.c:1232)
+template <typename T>
+__global__ void copy_mat_kernel(const T *__restrict__ src, size_t lds, T *__restrict__ dst, size_t ldd,
+                                size_t rows, int cols)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * (size_t)cols) return;
+    size_t r = e / cols;
+    int c = (int)(e % cols);
+    dst[r * ldd + c] = src[r * lds + c];
+}
+
+template <typename T>
+__global__ void fill_kernel(T *__restrict__ p, size_t n, T value)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) p[e] = value;
+}
+
+// C[M,N] = alpha * op(A) * B  (row-major; op(A) = A[M,K] or, TRANSA, A stored as [K,M]).
+// Side-information contractions of the collective model: U*C (cblas_tgemm, reference
+// src/collective.c:5770-5773) and U^T*A (src/common.c:2852-2855).  64x64 output tile per
+// workgroup, 4x4 per thread, operands staged through LDS.
+template <typename T, bool TRANSA>
+__global__ void __launch_bounds__(256)
+gemm_kernel(int M, int N, int K, T alpha, const T *__restrict__ A, size_t lda,
+            const T *__restrict__ B, size_t ldb, T *__restrict__ C, size_t ldc)
+{
+    constexpr int BM = 64, BN = 64, BK = 16;
+    __shared__ T As[BK][BM + 4];
+    __shared__ T Bs[BK][BN + 4];
+    const int tid = threadIdx.x;
+    const int tx = tid % 16, ty = tid / 16;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    T acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = T(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        for (int e = tid; e < BK * BM; e += 256) {
+            int kk, mm;
+            if (TRANSA) { kk = e / BM; mm = e % BM; }
+            else        { mm = e / BK; kk = e % BK; }
+            int gm = m0 + mm, gk = k0 + kk;
+            T v = T(0);
+            if (gm < M && gk < K) v = TRANSA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
+            As[kk][mm] = v;
+        }
+        for (int e = tid; e < BK * BN; e += 256) {
+            int kk = e / BN, nn = e % BN;
+            int gk = k0 + kk, gn = n0 + nn;
+            Bs[kk][nn] = (gk < K && gn < N) ? B[(size_t)gk * ldb + gn] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk++) {
+            T av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) av[a] = As[kk][ty * 4 + a];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bv[b] = Bs[kk][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] += av[a] * bv[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int gm = m0 + ty * 4 + a, gn = n0 + tx * 4 + b;
+            if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = alpha * acc[a][b];
+        }
+}
+
+}  // namespace cmfhip

@@ -1,0 +1,270 @@
+// device.hpp -- host-side device plumbing for the ALS path: HBM buffers, CSR shards with the
+// nnz-binned row schedule, and the launchers of the row-update kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/cmfrec_hip.h"
+#include "cg_kernels.hpp"
+#include "chol_kernels.hpp"
+#include "dense_kernels.hpp"
+
+namespace cmfhip {
+
+extern thread_local std::string g_last_error;
+
+struct HipError {
+    int code;       // C-ABI return code: 1 OOM, 4 HIP failure
+};
+
+inline void hip_check(hipError_t e, const char *what, const char *file, int line)
+{
+    if (e == hipSuccess) return;
+    char buf[512];
+    snprintf(buf, sizeof buf, "cmfrec_hip: %s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+    fprintf(stderr, "%s\n", buf);
+    throw HipError{e == hipErrorOutOfMemory ? 1 : 4};
+}
+#define HIP_CHECK(x) ::cmfhip::hip_check((x), #x, __FILE__, __LINE__)
+
+template <typename T>
+struct DevBuf {
+    T *ptr = nullptr;
+    size_t n = 0;
+    bool owned = true;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (ptr && owned) (void)hipFree(ptr);
+        ptr = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        owned = true;
+        if (count) HIP_CHECK(hipMalloc((void **)&ptr, count * sizeof(T)));
+    }
+    void upload(const T *host, size_t count, hipStream_t st)
+    {
+        if (count > n) alloc(count);
+        if (count) HIP_CHECK(hipMemcpyAsync(ptr, host, count * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    void download(T *host, size_t count, hipStream_t st) const
+    {
+        if (count) HIP_CHECK(hipMemcpyAsync(host, ptr, count * sizeof(T), hipMemcpyDeviceToHost, st));
+    }
+};
+
+// Rows are scheduled longest-first inside three nnz bins; every bin is a persistent launch whose
+// teams stride over the sorted list, which balances the heavy-tailed row lengths the reference
+// handles with `omp schedule(dynamic)` (common.c:3259,3349).
+constexpr int LIGHT_MAX = TILE;          // <= 64 nnz : 1 wave / row, 4 rows / workgroup
+constexpr int MEDIUM_MAX = 4 * TILE;     // <= 256 nnz: 4 waves / row
+                                         // larger     : 8 waves / row (register-resident to 512 nnz)
+struct SparseShard {
+    int nrows = 0;
+    size_t nnz = 0;
+    DevBuf<size_t> p;
+    DevBuf<int> i;
+    DevBuf<real_t> v;
+    DevBuf<int> order;       // [heavy | medium | light | empty], each sorted by nnz descending
+    int n_heavy = 0, n_medium = 0, n_light = 0, n_empty = 0;
+    size_t nnz_heavy = 0, nnz_medium = 0, nnz_light = 0;
+    int max_nnz = 0;
+
+    void upload(int nrows_, const size_t *hp, const int *hi, const real_t *hv, hipStream_t st)
+    {
+        nrows = nrows_;
+        nnz = hp[nrows] - hp[0];
+        std::vector<size_t> p0(nrows + 1);
+        for (int r = 0; r <= nrows; r++) p0[r] = hp[r] - hp[0];
+        p.upload(p0.data(), nrows + 1, st);
+        i.upload(hi + hp[0], nnz, st);
+        v.upload(hv + hp[0], nnz, st);
+        std::vector<int> ord(nrows);
+        std::iota(ord.begin(), ord.end(), 0);
+        auto len = [&](int r) { return (long long)(p0[r + 1] - p0[r]); };
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len(a) > len(b); });
+        n_heavy = n_medium = n_light = n_empty = 0;
+        nnz_heavy = nnz_medium = nnz_light = 0;
+        for (int r : ord) {
+            long long l = len(r);
+            if (l > MEDIUM_MAX) { n_heavy++; nnz_heavy += (size_t)l; }
+            else if (l > LIGHT_MAX) { n_medium++; nnz_medium += (size_t)l; }
+            else if (l > 0) { n_light++; nnz_light += (size_t)l; }
+            else n_empty++;
+        }
+        max_nnz = nrows ? (int)len(ord[0]) : 0;
+        order.upload(ord.data(), nrows, st);
+        HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
+    }
+};
+
+struct DeviceInfo {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+};
+
+// HIP-event pairs around the launches of one nnz bin (0 heavy, 1 medium, 2 light) on the stream
+// the kernel runs on; read back by cmfrec_hip_session_kernel_time.
+struct EventPair { hipEvent_t a, b; };
+struct BinTimers {
+    std::vector<EventPair> ev[3];
+    void clear()
+    {
+        for (auto &v : ev) {
+            for (auto &p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+            v.clear();
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Gramian  out[k,k] = scale * B[:, :k]^T B[:, :k] + add_diag * I
+struct GramWorkspace {
+    DevBuf<real_t> partial;
+};
+
+inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *B, size_t ldb, int n, int k,
+                        real_t *out, real_t scale, real_t add_diag)
+{
+    if (k <= 64) {
+        int nblocks = std::max(1, std::min(dev.num_cus * 4, (n + 127) / 128));
+        int rpb = (n + nblocks - 1) / nblocks;
+        nblocks = (n + rpb - 1) / rpb;
+        if (nblocks < 1) nblocks = 1;
+        size_t need = (size_t)nblocks * k * k;
+        if (ws.partial.n < need) ws.partial.alloc(need);
+        size_t smem = (size_t)32 * k * sizeof(real_t);
+        hipLaunchKernelGGL(gram_partial_kernel<real_t>, dim3(nblocks), dim3(256), smem, dev.stream,
+                           B, ldb, n, k, rpb, ws.partial.ptr);
+        hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 255) / 256), dim3(256), 0, dev.stream,
+                           ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
+    } else {
+        hipLaunchKernelGGL(gram_naive_kernel<real_t>, dim3((k * k + 255) / 256), dim3(256), 0, dev.stream,
+                           B, ldb, n, k, out, scale, add_diag);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------
+// CG row updates
+struct CgCall {
+    real_t *A; size_t lda;
+    const real_t *B; size_t ldb;
+    int k;
+    const real_t *bias_sub;
+    const real_t *BtB;       // implicit only
+    real_t lam, lam_last;
+    bool scale_lam, scale_bias_const;
+    int max_cg_steps;
+    bool implicit;
+};
+
+enum class CgVariant { Auto, Generic };
+CgVariant cg_variant_from_env();
+
+template <int S, bool IMPLICIT, int W, int RPB>
+inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin)
+{
+    if (count <= 0) return;
+    EventPair ev{nullptr, nullptr};
+    if (tm) {
+        HIP_CHECK(hipEventCreate(&ev.a));
+        HIP_CHECK(hipEventCreate(&ev.b));
+        HIP_CHECK(hipEventRecord(ev.a, dev.stream));
+    }
+    P.order += first;
+    P.nrows = count;
+    constexpr int threads = 64 * W * RPB;
+    size_t smem = ((IMPLICIT ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
+    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB>;
+    static thread_local int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        if (smem > 48 * 1024)
+            HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int nb = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, smem));
+        blocks_per_cu = std::max(1, nb);
+    }
+    int teams_needed = (count + RPB - 1) / RPB;
+    int grid = std::min(teams_needed, dev.num_cus * blocks_per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, dev.stream, P);
+    HIP_CHECK(hipGetLastError());
+    if (tm) {
+        HIP_CHECK(hipEventRecord(ev.b, dev.stream));
+        tm->ev[bin].push_back(ev);
+    }
+}
+
+template <int S, bool IMPLICIT>
+inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm)
+{
+    // heavy rows first: they are the longest-running teams
+    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, 0, X.n_heavy, tm, 0);
+    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.n_heavy, X.n_medium, tm, 1);
+    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.n_heavy + X.n_medium, X.n_light, tm, 2);
+}
+
+template <int NF, bool IMPLICIT>
+inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X)
+{
+    int count = X.n_heavy + X.n_medium + X.n_light;
+    if (count <= 0) return;
+    P.nrows = count;
+    int grid = std::min((count + 3) / 4, dev.num_cus * 8);
+    hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT>), dim3(grid), dim3(256), 0, dev.stream, P);
+    HIP_CHECK(hipGetLastError());
+}
+
+inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &X, BinTimers *tm = nullptr)
+{
+    CgParams<real_t> P;
+    P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.k = c.k;
+    P.indptr = X.p.ptr; P.indices = X.i.ptr; P.values = X.v.ptr;
+    P.bias_sub = c.bias_sub; P.order = X.order.ptr; P.nrows = 0; P.BtB = c.BtB;
+    P.lam = c.lam; P.lam_last = c.lam_last;
+    P.scale_lam = c.scale_lam; P.scale_bias_const = c.scale_bias_const;
+    P.max_cg_steps = c.max_cg_steps;
+    const int S = (c.k + 7) / 8;
+    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8;
+    if (!generic) {
+#define CMF_CASE(SS)                                                        \
+    case SS:                                                                \
+        if (c.implicit) launch_cg_S<SS, true>(dev, P, X, tm);               \
+        else            launch_cg_S<SS, false>(dev, P, X, tm);              \
+        return 0;
+        switch (S) {
+            CMF_CASE(1) CMF_CASE(2) CMF_CASE(3) CMF_CASE(4)
+            CMF_CASE(5) CMF_CASE(6) CMF_CASE(7) CMF_CASE(8)
+        }
+#undef CMF_CASE
+    }
+    const int NF = (c.k + 63) / 64;
+#define CMF_GCASE(NN)                                                       \
+    case NN:                                                                \
+        if (c.implicit) launch_cg_generic<NN, true>(dev, P, X);             \
+        else            launch_cg_generic<NN, false>(dev, P, X);            \
+        return 0;
+    switch (NF) {
+        CMF_GCASE(1) CMF_GCASE(2) CMF_GCASE(3) CMF_GCASE(4) CMF_GCASE(5)
+    }
+#undef CMF_GCASE
+    g_last_error = "cmfrec_hip: CG path supports k <= 320 per solved matrix";
+    return 2;
+}
+
+}  // namespace cmfhip

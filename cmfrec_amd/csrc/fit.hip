@@ -1,0 +1,355 @@
+// fit.hip -- the two drop-in fit entry points (level 1 of include/cmfrec_hip.h).
+//
+// Host-side restatement of the driver logic of the reference's fit_collective_implicit_als
+// (/root/reference/src/collective.c:9375-10207) and fit_collective_explicit_als (:7263-9370) for
+// the supported option set: input validation, X := alpha*X / log, COO -> CSR + CSC (stable,
+// helpers.c:1375-1491), global mean (common.c:3423-3648), side-info column centering
+// (common.c:4911-4997), bias initialisation (common.c:4410-4909), start values, and the ALS loop
+// order C -> D -> B -> A, which runs on the device-resident session (session.hip).  Every
+// temporary is allocated and freed here; outputs are caller-allocated (cmfrec.h.in:240-241).
+#include <cfloat>
+#include <cmath>
+#include <csignal>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/cmfrec_hip.h"
+
+namespace {
+
+// ---- stable counting sort COO -> CSR / CSC (entries keep the COO order inside a row) --------
+void coo_to_csr_csc(const int_t *row, const int_t *col, const real_t *val, int_t m, int_t n, size_t nnz,
+                    std::vector<size_t> &rp, std::vector<int_t> &ri, std::vector<real_t> &rv,
+                    std::vector<size_t> &cp, std::vector<int_t> &ci, std::vector<real_t> &cv)
+{
+    rp.assign((size_t)m + 1, 0);
+    cp.assign((size_t)n + 1, 0);
+    ri.resize(nnz); rv.resize(nnz); ci.resize(nnz); cv.resize(nnz);
+    for (size_t e = 0; e < nnz; e++) {
+        rp[(size_t)row[e] + 1]++;
+        cp[(size_t)col[e] + 1]++;
+    }
+    for (int_t r = 0; r < m; r++) rp[(size_t)r + 1] += rp[r];
+    for (int_t c = 0; c < n; c++) cp[(size_t)c + 1] += cp[c];
+    std::vector<size_t> nr(rp.begin(), rp.end() - 1), nc(cp.begin(), cp.end() - 1);
+    for (size_t e = 0; e < nnz; e++) {
+        size_t a = nr[row[e]]++;
+        ri[a] = col[e]; rv[a] = val[e];
+        size_t b = nc[col[e]]++;
+        ci[b] = row[e]; cv[b] = val[e];
+    }
+}
+
+// ---- xoshiro256++ start values (Blackman & Vigna; splitmix64 seeding) ------------------------
+// NOTE: the draw stream is NOT bit-compatible with the reference's ziggurat sampler
+// (helpers.c:653-748) yet; parity runs inject the start values with reset_values=false.
+struct Xoshiro {
+    uint64_t s[4];
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    explicit Xoshiro(uint64_t seed)
+    {
+        for (int i = 0; i < 4; i++) {
+            uint64_t z = (seed += 0x9e3779b97f4a7c15ULL);
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+            s[i] = z ^ (z >> 31);
+        }
+    }
+    uint64_t next()
+    {
+        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return result;
+    }
+    double unif() { return (double)(next() >> 11) * 0x1.0p-53; }
+};
+
+void fill_random(real_t *arr, size_t n, int_t seed, bool normal, uint64_t stream)
+{
+    Xoshiro rng((uint64_t)(uint32_t)seed * 0x9E3779B1ULL + stream * 0xD1B54A32D192ED03ULL + 1);
+    if (!normal) {
+        for (size_t i = 0; i < n; i++) arr[i] = (real_t)(rng.unif() * 0x1.0p-7);
+        return;
+    }
+    for (size_t i = 0; i < n; i += 2) {   // Box-Muller, scaled 2^-7 like the reference's start values
+        double u1 = rng.unif(), u2 = rng.unif();
+        if (u1 < 1e-300) u1 = 1e-300;
+        double r = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586 * u2;
+        arr[i] = (real_t)(r * std::cos(th) * 0x1.0p-7);
+        if (i + 1 < n) arr[i + 1] = (real_t)(r * std::sin(th) * 0x1.0p-7);
+    }
+}
+
+// ---- SIGINT between half-steps (helpers.c:1493-1501, collective.c:9520-9531) -----------------
+volatile sig_atomic_t g_stop = 0;
+void on_sigint(int) { g_stop = 1; }
+struct SigGuard {
+    void (*old)(int) = nullptr;
+    bool armed = false;
+    explicit SigGuard(bool arm) : armed(arm)
+    {
+        if (arm) { g_stop = 0; old = signal(SIGINT, on_sigint); }
+    }
+    ~SigGuard() { if (armed) signal(SIGINT, old); }
+};
+
+#ifdef CMFREC_HIP_FLOAT
+const real_t EPS_T = FLT_EPSILON;
+#else
+const real_t EPS_T = DBL_EPSILON;
+#endif
+
+int fail(bool verbose, const char *msg)
+{
+    if (verbose) fprintf(stderr, "%s\n", msg);
+    return 2;
+}
+
+int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose)
+{
+    for (int it = 0; it < niter; it++) {
+        if (g_stop) return 3;
+        int chol = (finalize_chol && mdl.use_cg && it == niter - 1) ? 1 : 0;
+        int rc;
+        if (mdl.p > 0) { if (verbose) { printf("Updating C..."); fflush(stdout); }
+            if ((rc = cmfrec_hip_session_update(s, 'C', chol))) return rc; if (verbose) printf(" done\n"); }
+        if (g_stop) return 3;
+        if (mdl.q > 0) { if (verbose) { printf("Updating D..."); fflush(stdout); }
+            if ((rc = cmfrec_hip_session_update(s, 'D', chol))) return rc; if (verbose) printf(" done\n"); }
+        if (g_stop) return 3;
+        if (verbose) { printf("Updating B..."); fflush(stdout); }
+        if ((rc = cmfrec_hip_session_update(s, 'B', chol))) return rc;
+        if ((rc = cmfrec_hip_session_after_gather(s, 'B'))) return rc;
+        if (verbose) { cmfrec_hip_session_sync(s); printf(" done\n"); }
+        if (g_stop) return 3;
+        if (verbose) { printf("Updating A..."); fflush(stdout); }
+        if ((rc = cmfrec_hip_session_update(s, 'A', chol))) return rc;
+        if ((rc = cmfrec_hip_session_after_gather(s, 'A'))) return rc;
+        if (verbose) { cmfrec_hip_session_sync(s); printf(" done\n\tCompleted ALS iteration %2d\n\n", it + 1); fflush(stdout); }
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int_t fit_collective_implicit_als(
+    real_t *A, real_t *B, real_t *C, real_t *D, bool reset_values, int_t seed,
+    real_t *U_colmeans, real_t *I_colmeans, int_t m, int_t n, int_t k,
+    int_t ixA[], int_t ixB[], real_t *X, size_t nnz,
+    real_t lam, real_t *lam_unique, real_t l1_lam, real_t *l1_lam_unique,
+    real_t *U, int_t m_u, int_t p, real_t *II, int_t n_i, int_t q,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    int_t I_row[], int_t I_col[], real_t *I_sp, size_t nnz_I,
+    bool NA_as_zero_U, bool NA_as_zero_I, int_t k_main, int_t k_user, int_t k_item,
+    real_t w_main, real_t w_user, real_t w_item, real_t *w_main_multiplier,
+    real_t alpha, bool adjust_weight, bool apply_log_transf, int_t niter, int nthreads,
+    bool verbose, bool handle_interrupt, bool use_cg, int_t max_cg_steps, bool precondition_cg,
+    bool finalize_chol, bool nonneg, int_t max_cd_steps, bool nonneg_C, bool nonneg_D,
+    bool precompute_for_predictions, real_t *precomputedBtB, real_t *precomputedBeTBe,
+    real_t *precomputedBeTBeChol, real_t *precomputedCtUbias)
+{
+    (void)C; (void)D; (void)U_colmeans; (void)I_colmeans; (void)m_u; (void)p; (void)n_i; (void)q;
+    (void)U_row; (void)U_col; (void)I_row; (void)I_col; (void)NA_as_zero_U; (void)NA_as_zero_I;
+    (void)nthreads; (void)max_cd_steps; (void)nonneg_C; (void)nonneg_D; (void)precomputedBtB;
+    (void)precomputedBeTBe; (void)precomputedBeTBeChol; (void)precomputedCtUbias; (void)w_user; (void)w_item;
+    (void)handle_interrupt;
+    // collective.c:9406-9435
+    if (k_user || k_item) return fail(verbose, "Cannot pass 'k_user'/'k_item' without side information.");
+    if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
+    if (U || II || U_sp || I_sp || nnz_U || nnz_I)
+        return fail(verbose, "cmfrec_hip: implicit model with side information is not implemented (SURVEY 8f-1).");
+    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || precondition_cg || adjust_weight || precompute_for_predictions)
+        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / precondition_cg / adjust_weight / precompute_for_predictions are not implemented.");
+    if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
+    for (size_t e = 0; e < nnz; e++)
+        if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
+    if (w_main_multiplier) *w_main_multiplier = 1;
+    if (w_main != (real_t)1) lam /= w_main;                              // collective.c:9786-9811
+
+    SigGuard sig(true);
+    std::vector<real_t> Xs(X, X + nnz);                                  // X is copied before edits (:9578-9599)
+    if (apply_log_transf) for (auto &x : Xs) x = std::log(x);
+    if (alpha != (real_t)1) for (auto &x : Xs) x *= alpha;
+    std::vector<size_t> rp, cp; std::vector<int_t> ri, ci; std::vector<real_t> rv, cv;
+    coo_to_csr_csc(ixA, ixB, Xs.data(), m, n, nnz, rp, ri, rv, cp, ci, cv);
+    std::vector<real_t>().swap(Xs);
+
+    const int ktot = k + k_main;
+    if (reset_values) {                                                  // :9750-9774
+        fill_random(A, (size_t)m * ktot, seed, false, 0);
+        if (use_cg) memset(B, 0, (size_t)n * ktot * sizeof(real_t));
+        else fill_random(B, (size_t)n * ktot, seed, false, 1);           // values are irrelevant for Cholesky
+    }
+    if (!use_cg) finalize_chol = false;                                  // :9518
+
+    cmfrec_hip_model mdl;
+    memset(&mdl, 0, sizeof mdl);
+    mdl.implicit = 1; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main;
+    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.lam = lam; mdl.w_user = 1; mdl.w_item = 1;
+    mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
+    cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
+    if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
+    int rc = cmfrec_hip_session_set_X(s, rp.data(), ri.data(), rv.data(), cp.data(), ci.data(), cv.data());
+    if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
+    if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
+    int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose);
+    if (rc_loop == 0 || rc_loop == 3) {
+        int rc2 = cmfrec_hip_session_get_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
+        if (rc2) rc_loop = rc2;
+    }
+    cmfrec_hip_session_destroy(s);
+    if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
+    return rc_loop > 3 ? 1 : rc_loop;
+}
+
+int_t fit_collective_explicit_als(
+    real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D, real_t *Ai, real_t *Bi,
+    bool add_implicit_features, bool reset_values, int_t seed, real_t *glob_mean,
+    real_t *U_colmeans, real_t *I_colmeans, int_t m, int_t n, int_t k,
+    int_t ixA[], int_t ixB[], real_t *X, size_t nnz, real_t *Xfull, real_t *weight,
+    bool user_bias, bool item_bias, bool center, real_t lam, real_t *lam_unique,
+    real_t l1_lam, real_t *l1_lam_unique, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+    real_t *scaling_biasA, real_t *scaling_biasB, real_t *U, int_t m_u, int_t p, real_t *II, int_t n_i, int_t q,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U, int_t I_row[], int_t I_col[], real_t *I_sp, size_t nnz_I,
+    bool NA_as_zero_X, bool NA_as_zero_U, bool NA_as_zero_I, int_t k_main, int_t k_user, int_t k_item,
+    real_t w_main, real_t w_user, real_t w_item, real_t w_implicit, int_t niter, int nthreads,
+    bool verbose, bool handle_interrupt, bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+    bool nonneg, int_t max_cd_steps, bool nonneg_C, bool nonneg_D, bool precompute_for_predictions,
+    bool include_all_X, real_t *B_plus_bias, real_t *precomputedBtB, real_t *precomputedTransBtBinvBt,
+    real_t *precomputedBtXbias, real_t *precomputedBeTBeChol, real_t *precomputedBiTBi,
+    real_t *precomputedTransCtCinvCt, real_t *precomputedCtCw, real_t *precomputedCtUbias)
+{
+    (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB; (void)U_row; (void)U_col; (void)I_row; (void)I_col;
+    (void)NA_as_zero_U; (void)NA_as_zero_I; (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
+    (void)nonneg_C; (void)nonneg_D; (void)include_all_X; (void)B_plus_bias; (void)precomputedBtB;
+    (void)precomputedTransBtBinvBt; (void)precomputedBtXbias; (void)precomputedBeTBeChol; (void)precomputedBiTBi;
+    (void)precomputedTransCtCinvCt; (void)precomputedCtCw; (void)precomputedCtUbias;
+    // collective.c:7308-7329
+    if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
+    if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
+    if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
+    if (Xfull || weight || NA_as_zero_X || U_sp || I_sp || nnz_U || nnz_I || add_implicit_features)
+        return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / sparse side info / implicit features are not implemented.");
+    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || precondition_cg || scale_bias_const || precompute_for_predictions)
+        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / precondition_cg / scale_bias_const / precompute_for_predictions are not implemented.");
+    if (U == nullptr) { m_u = 0; p = 0; }
+    if (II == nullptr) { n_i = 0; q = 0; }
+    if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
+    if ((U || II) && use_cg) return fail(verbose, "cmfrec_hip: side information requires use_cg=false (block-CG: SURVEY 8f-1).");
+    if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
+    for (size_t e = 0; e < nnz; e++)
+        if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
+    for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
+    for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
+
+    SigGuard sig(true);
+    scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
+    if (!use_cg) finalize_chol = false;                                   // :7481
+    if (w_main != (real_t)1) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   // :7497-7521
+    const bool has_bias = user_bias || item_bias;
+    const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
+
+    // ---- global mean, common.c:3494-3524 + :3603 (nthreads selects running mean vs sum/cnt) ----
+    std::vector<real_t> Xs(X, X + nnz);
+    real_t gm = 0;
+    if (center) {
+        double xsum = 0;
+        if (nthreads >= 8) {
+            for (size_t e = 0; e < nnz; e++) xsum += Xs[e];
+            gm = (real_t)(xsum / (double)nnz);
+        } else {
+            size_t cnt = 0;
+            for (size_t e = 0; e < nnz; e++) xsum += (Xs[e] - xsum) / (double)(++cnt);
+            gm = (real_t)xsum;
+        }
+        if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
+        if (gm != 0) for (auto &x : Xs) x -= gm;
+    }
+    *glob_mean = gm;
+    std::vector<size_t> rp, cp; std::vector<int_t> ri, ci; std::vector<real_t> rv, cv;
+    coo_to_csr_csc(ixA, ixB, Xs.data(), m, n, nnz, rp, ri, rv, cp, ci, cv);
+    std::vector<real_t>().swap(Xs);
+
+    // ---- side information: column means + centering, common.c:4938-4997 ----
+    std::vector<real_t> Uc, Ic;
+    auto center_cols = [](const real_t *M, int rows, int cols, real_t *means, std::vector<real_t> &out) {
+        out.assign(M, M + (size_t)rows * cols);
+        for (int c = 0; c < cols; c++) means[c] = 0;
+        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) means[c] += M[(size_t)r * cols + c];
+        for (int c = 0; c < cols; c++) means[c] /= (double)rows;
+        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) out[(size_t)r * cols + c] -= means[c];
+    };
+    if (U) center_cols(U, m_u, p, U_colmeans, Uc);
+    if (II) center_cols(II, n_i, q, I_colmeans, Ic);
+
+    // ---- bias start values, common.c:4410-4909 (sparse, unweighted; both biases) ----
+    if (has_bias && reset_values) {
+        if (user_bias != item_bias)
+            return fail(verbose, "cmfrec_hip: reset_values with a single bias is not implemented (initialize_biases_onesided).");
+        real_t lam_u = lam, lam_i = lam;
+        if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
+        if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
+        memset(biasA, 0, (size_t)m * sizeof(real_t));
+        memset(biasB, 0, (size_t)n * sizeof(real_t));
+        for (int sweep = 0; sweep < 5; sweep++) {
+            for (int_t c = 0; c < n; c++) {                               // :4643-4669
+                double bm = 0;
+                size_t st = cp[c], en = cp[(size_t)c + 1], cnt = en - st;
+                for (size_t e = st; e < en; e++) bm += (cv[e] - biasA[ci[e]] - bm) / (double)(e - st + 1);
+                bm *= (double)cnt / ((double)cnt + lam_i * (scale_lam ? (double)(cnt > 1 ? cnt : 1) : 1.));
+                biasB[c] = (real_t)bm;
+            }
+            for (int_t r = 0; r < m; r++) {                               // :4799-4825
+                double bm = 0;
+                size_t st = rp[r], en = rp[(size_t)r + 1], cnt = en - st;
+                for (size_t e = st; e < en; e++) bm += (rv[e] - biasB[ri[e]] - bm) / (double)(e - st + 1);
+                if (cnt > 0) bm *= (double)cnt / ((double)cnt + lam_u * (scale_lam ? (double)cnt : 1.));
+                biasA[r] = (real_t)bm;
+            }
+        }
+    }
+    // ---- factor start values, collective.c:8241-8274 ----
+    if (reset_values) {
+        const bool fill_B = (II != nullptr);
+        fill_random(A, (size_t)m * k_totA, seed, true, 0);
+        if (fill_B) fill_random(B, (size_t)n * k_totB, seed, true, 1);
+        if (use_cg) {
+            if (!fill_B) memset(B, 0, (size_t)n * k_totB * sizeof(real_t));
+            if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
+            if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
+        } else if (!fill_B) {
+            fill_random(B, (size_t)n * k_totB, seed, true, 1);            // values are irrelevant for Cholesky
+        }
+    }
+
+    cmfrec_hip_model mdl;
+    memset(&mdl, 0, sizeof mdl);
+    mdl.implicit = 0; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
+    mdl.user_bias = user_bias; mdl.item_bias = item_bias; mdl.scale_lam = scale_lam; mdl.scale_lam_sideinfo = scale_lam_sideinfo;
+    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i;
+    mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
+    mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
+    cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
+    if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
+    int rc = cmfrec_hip_session_set_X(s, rp.data(), ri.data(), rv.data(), cp.data(), ci.data(), cv.data());
+    if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
+    if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, biasA, biasB, C, D);
+    if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
+    int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose);
+    if (rc_loop == 0 || rc_loop == 3) {
+        int rc2 = cmfrec_hip_session_get_factors(s, A, B, biasA, biasB, C, D);
+        if (rc2) rc_loop = rc2;
+    }
+    cmfrec_hip_session_destroy(s);
+    (void)has_bias;
+    if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
+    return rc_loop > 3 ? 1 : rc_loop;
+}
+
+}  // extern "C"

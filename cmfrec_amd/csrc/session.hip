@@ -1,0 +1,679 @@
+// session.hip -- device-resident ALS session (level 3 of include/cmfrec_hip.h) and the
+// operator-level entry points with host buffers (level 2).
+//
+// The session owns the state the reference's fit drivers keep on the host
+// (/root/reference/src/collective.c:7651-7677, :9468-9473): the factor matrices in the
+// "[rows, k_tot + bias]" layout, the bias vectors, CSR and CSC copies of X, side information and
+// the small k x k work matrices -- all resident in HBM for the whole fit.
+#include "device.hpp"
+#include <functional>
+#include <new>
+
+namespace cmfhip {
+
+thread_local std::string g_last_error;
+
+CgVariant cg_variant_from_env()
+{
+    static int cached = -1;
+    if (cached < 0) {
+        const char *e = getenv("CMFREC_HIP_CG_KERNEL");
+        cached = (e && strcmp(e, "generic") == 0) ? 1 : 0;
+    }
+    return cached ? CgVariant::Generic : CgVariant::Auto;
+}
+
+inline dim3 grid1d(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+struct CholCall {
+    real_t *A; size_t lda;
+    const real_t *B; size_t ldb;
+    int kt, koff;
+    const real_t *bias_sub;
+    const real_t *Minit; int kc; int rows_with_u; int p_side;
+    real_t lam, lam_last;
+    bool scale_lam, scale_lam_sideinfo, scale_bias_const;
+    int mode;
+};
+
+// X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
+static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, int nrows_prefilled = 0)
+{
+    CholParams<real_t> P;
+    P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.kt = c.kt; P.koff = c.koff;
+    P.indptr = X ? X->p.ptr : nullptr; P.indices = X ? X->i.ptr : nullptr; P.values = X ? X->v.ptr : nullptr;
+    P.bias_sub = c.bias_sub;
+    P.order = X ? X->order.ptr : nullptr;
+    if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
+    else if (c.mode == CHOL_COLLECTIVE) P.nrows = X->nrows;                       // empty rows too
+    else P.nrows = X->n_heavy + X->n_medium + X->n_light;                        // non-empty rows
+    P.Minit = c.Minit; P.kc = c.kc; P.rows_with_u = c.rows_with_u; P.p_side = c.p_side;
+    P.lam = c.lam; P.lam_last = c.lam_last;
+    P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
+    P.mode = c.mode;
+    if (P.nrows <= 0) return 0;
+    size_t smem = chol_lds_elems(c.kt) * sizeof(real_t);
+    if (smem > 160 * 1024) {
+        g_last_error = "cmfrec_hip: Cholesky path needs the k_t x k_t system in LDS (160 KiB): k_t too large";
+        return 2;
+    }
+    auto kern = chol_rows_kernel<real_t>;
+    static thread_local size_t smem_set = 0;
+    if (smem > 48 * 1024 && smem > smem_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        smem_set = smem;
+    }
+    int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(smem, 1)));
+    per_cu = std::min(per_cu, 8);
+    int grid = std::min(P.nrows, dev.num_cus * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, dev.stream, P);
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <bool TRANSA>
+static void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha, const real_t *A, size_t lda,
+                        const real_t *B, size_t ldb, real_t *C, size_t ldc)
+{
+    if (M <= 0 || N <= 0) return;
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_kernel<real_t, TRANSA>), grid, dim3(256), 0, dev.stream, M, N, K, alpha, A, lda, B, ldb, C, ldc);
+    HIP_CHECK(hipGetLastError());
+}
+
+static void init_device(DeviceInfo &dev, int device)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        g_last_error = "cmfrec_hip: no HIP device available (this library has no CPU fallback)";
+        fprintf(stderr, "%s\n", g_last_error.c_str());
+        throw HipError{4};
+    }
+    if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipGetDevice(&dev.device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, dev.device));
+    dev.num_cus = prop.multiProcessorCount;
+    HIP_CHECK(hipStreamCreateWithFlags(&dev.stream, hipStreamNonBlocking));
+}
+
+}  // namespace cmfhip
+
+using namespace cmfhip;
+
+struct cmfrec_hip_session {
+    cmfrec_hip_model mdl;
+    DeviceInfo dev;
+    int k_totA = 0, k_totB = 0, has_bias = 0;
+    size_t ldA = 0, ldB = 0;
+    DevBuf<real_t> A, B, biasA, biasB, C, D, U, II;
+    SparseShard Xr, Xc;
+    DevBuf<real_t> gram, ctc;
+    GramWorkspace gws;
+    std::vector<EventPair> evA, evB;     // whole half-steps
+    BinTimers binA, binB;                // row-update kernel launches per nnz bin
+
+    hipEvent_t new_event()
+    {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    ~cmfrec_hip_session()
+    {
+        for (auto &p : evA) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        for (auto &p : evB) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        binA.clear(); binB.clear();
+        if (dev.stream) (void)hipStreamDestroy(dev.stream);
+    }
+};
+
+static int guarded(const std::function<int()> &f)
+{
+    try {
+        return f();
+    } catch (const HipError &e) {
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_last_error = "cmfrec_hip: host out of memory";
+        return 1;
+    }
+}
+
+extern "C" {
+
+int cmfrec_hip_sizeof_real(void) { return (int)sizeof(real_t); }
+const char *cmfrec_hip_build_info(void)
+{
+#ifdef CMFREC_HIP_FLOAT
+    return "cmfrec_hip float gfx950";
+#else
+    return "cmfrec_hip double gfx950";
+#endif
+}
+const char *cmfrec_hip_last_error(void) { return g_last_error.c_str(); }
+
+cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int device)
+{
+    cmfrec_hip_session *s = nullptr;
+    int rc = guarded([&]() {
+        const cmfrec_hip_model &m = *model;
+        if (m.m <= 0 || m.n <= 0 || m.k < 0 || m.row_begin < 0 || m.row_end > m.m || m.col_begin < 0 ||
+            m.col_end > m.n || m.row_begin > m.row_end || m.col_begin > m.col_end) {
+            g_last_error = "cmfrec_hip: invalid model sizes";
+            return 2;
+        }
+        if (m.implicit && (m.user_bias || m.item_bias || m.p || m.q || m.k_user || m.k_item)) {
+            g_last_error = "cmfrec_hip: implicit model supports no biases / side information yet";
+            return 2;
+        }
+        if ((m.p > 0 && m.m_u > m.m) || (m.q > 0 && m.n_i > m.n)) {
+            g_last_error = "cmfrec_hip: side information with more rows than X is not supported";
+            return 2;
+        }
+        if ((m.p > 0 || m.q > 0) && m.use_cg) {
+            g_last_error = "cmfrec_hip: side information requires the Cholesky solver (block-CG not implemented)";
+            return 2;
+        }
+        if (m.precondition_cg) {
+            g_last_error = "cmfrec_hip: precondition_cg is not implemented";
+            return 2;
+        }
+        s = new cmfrec_hip_session();
+        s->mdl = m;
+        init_device(s->dev, device);
+        s->k_totA = m.k_user + m.k + m.k_main;
+        s->k_totB = m.k_item + m.k + m.k_main;
+        s->has_bias = (m.user_bias || m.item_bias) ? 1 : 0;
+        s->ldA = (size_t)(s->k_totA + s->has_bias);
+        s->ldB = (size_t)(s->k_totB + s->has_bias);
+        s->A.alloc((size_t)m.m * s->ldA);
+        s->B.alloc((size_t)m.n * s->ldB);
+        HIP_CHECK(hipMemsetAsync(s->A.ptr, 0, s->A.n * sizeof(real_t), s->dev.stream));
+        HIP_CHECK(hipMemsetAsync(s->B.ptr, 0, s->B.n * sizeof(real_t), s->dev.stream));
+        if (s->has_bias) {
+            s->biasA.alloc(m.m);
+            s->biasB.alloc(m.n);
+            HIP_CHECK(hipMemsetAsync(s->biasA.ptr, 0, (size_t)m.m * sizeof(real_t), s->dev.stream));
+            HIP_CHECK(hipMemsetAsync(s->biasB.ptr, 0, (size_t)m.n * sizeof(real_t), s->dev.stream));
+        }
+        int kmax = std::max(s->k_totA, s->k_totB) + 1;
+        s->gram.alloc((size_t)kmax * kmax);
+        s->ctc.alloc((size_t)kmax * kmax);
+        if (m.p > 0) s->C.alloc((size_t)m.p * (m.k_user + m.k));
+        if (m.q > 0) s->D.alloc((size_t)m.q * (m.k_item + m.k));
+        return 0;
+    });
+    if (rc != 0) {
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+void cmfrec_hip_session_destroy(cmfrec_hip_session *s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s->dev.stream);
+    delete s;
+}
+
+int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
+                             const size_t *csc_p, const int_t *csc_i, const real_t *csc_v)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        s->Xr.upload(s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->dev.stream);
+        s->Xc.upload(s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->dev.stream);
+        return 0;
+    });
+}
+
+static void upload_padded(cmfrec_hip_session *s, const real_t *host, size_t rows, int cols, real_t *dst, size_t ldd)
+{
+    if (!host || rows == 0) return;
+    if ((size_t)cols == ldd) {
+        HIP_CHECK(hipMemcpyAsync(dst, host, rows * cols * sizeof(real_t), hipMemcpyHostToDevice, s->dev.stream));
+    } else {
+        HIP_CHECK(hipMemcpy2DAsync(dst, ldd * sizeof(real_t), host, (size_t)cols * sizeof(real_t),
+                                   (size_t)cols * sizeof(real_t), rows, hipMemcpyHostToDevice, s->dev.stream));
+    }
+}
+static void download_padded(cmfrec_hip_session *s, real_t *host, size_t rows, int cols, const real_t *src, size_t lds)
+{
+    if (!host || rows == 0) return;
+    if ((size_t)cols == lds) {
+        HIP_CHECK(hipMemcpyAsync(host, src, rows * cols * sizeof(real_t), hipMemcpyDeviceToHost, s->dev.stream));
+    } else {
+        HIP_CHECK(hipMemcpy2DAsync(host, (size_t)cols * sizeof(real_t), src, lds * sizeof(real_t),
+                                   (size_t)cols * sizeof(real_t), rows, hipMemcpyDeviceToHost, s->dev.stream));
+    }
+}
+
+int cmfrec_hip_session_set_factors(cmfrec_hip_session *s, const real_t *A, const real_t *B, const real_t *biasA,
+                                   const real_t *biasB, const real_t *C, const real_t *D)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        hipStream_t st = s->dev.stream;
+        upload_padded(s, A, m.m, s->k_totA, s->A.ptr, s->ldA);
+        upload_padded(s, B, m.n, s->k_totB, s->B.ptr, s->ldB);
+        if (s->has_bias) {
+            // bias column of the [rows, k_tot+1] layout: the bias itself or ones (collective.c:8283-8317)
+            if (biasA && m.user_bias) s->biasA.upload(biasA, m.m, st);
+            if (biasB && m.item_bias) s->biasB.upload(biasB, m.n, st);
+            if (m.user_bias)
+                hipLaunchKernelGGL(col_insert_kernel<real_t>, grid1d(m.m), dim3(256), 0, st, s->A.ptr, s->ldA, m.m, s->k_totA, s->biasA.ptr);
+            else
+                hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(m.m), dim3(256), 0, st, s->A.ptr, s->ldA, m.m, s->k_totA, (real_t)1);
+            if (m.item_bias)
+                hipLaunchKernelGGL(col_insert_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, s->B.ptr, s->ldB, m.n, s->k_totB, s->biasB.ptr);
+            else
+                hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, s->B.ptr, s->ldB, m.n, s->k_totB, (real_t)1);
+            HIP_CHECK(hipGetLastError());
+        }
+        if (C && m.p > 0) s->C.upload(C, (size_t)m.p * (m.k_user + m.k), st);
+        if (D && m.q > 0) s->D.upload(D, (size_t)m.q * (m.k_item + m.k), st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_get_factors(cmfrec_hip_session *s, real_t *A, real_t *B, real_t *biasA, real_t *biasB,
+                                   real_t *C, real_t *D)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        hipStream_t st = s->dev.stream;
+        download_padded(s, A, m.m, s->k_totA, s->A.ptr, s->ldA);
+        download_padded(s, B, m.n, s->k_totB, s->B.ptr, s->ldB);
+        if (biasA && m.user_bias) s->biasA.download(biasA, m.m, st);
+        if (biasB && m.item_bias) s->biasB.download(biasB, m.n, st);
+        if (C && m.p > 0) s->C.download(C, (size_t)m.p * (m.k_user + m.k), st);
+        if (D && m.q > 0) s->D.download(D, (size_t)m.q * (m.k_item + m.k), st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, const real_t *II)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        if (U && m.p > 0) s->U.upload(U, (size_t)m.m_u * m.p, s->dev.stream);
+        if (II && m.q > 0) s->II.upload(II, (size_t)m.n_i * m.q, s->dev.stream);
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
+// ---- one half-step of the ALS loop on the local block -------------------------------------
+static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    hipStream_t st = dev.stream;
+    // "self" = matrix being updated, "opp" = the fixed one
+    real_t *self = isA ? s->A.ptr : s->B.ptr;
+    real_t *opp = isA ? s->B.ptr : s->A.ptr;
+    const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
+    const int rows_opp = isA ? m.n : m.m;
+    const int k_side_self = isA ? m.k_user : m.k_item, k_side_opp = isA ? m.k_item : m.k_user;
+    const int begin = isA ? m.row_begin : m.col_begin;
+    const SparseShard &X = isA ? s->Xr : s->Xc;
+    const bool self_bias = isA ? m.user_bias : m.item_bias;
+    const bool opp_bias = isA ? m.item_bias : m.user_bias;
+    const int p_self = isA ? m.p : m.q;
+    real_t *self_blk = self + (size_t)begin * ld_self;
+    const int kk = m.k + m.k_main;
+
+    if (m.implicit) {
+        // optimizeA_implicit, common.c:3305-3421
+        launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, chol ? m.lam : (real_t)0);
+        if (chol) {
+            if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st)); // :3334
+            CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, 0, nullptr,
+                       s->gram.ptr, 0, 0, 0, m.lam, m.lam, false, false, false, CHOL_IMPLICIT};
+            return launch_chol(dev, c, &X);
+        }
+        CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, nullptr, s->gram.ptr,
+                 m.lam, m.lam, false, false, m.max_cg_steps, true};
+        return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
+    }
+
+    // ---- explicit ----
+    // the opposing matrix' bias column is fixed to 1 while this one's bias is fitted (collective.c:8538-8543, :8728-8732)
+    if (self_bias) {
+        const int rows_fill = isA ? m.n : m.m;
+        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_fill), dim3(256), 0, st, opp, ld_opp, rows_fill,
+                           isA ? s->k_totB : s->k_totA, (real_t)1);
+        HIP_CHECK(hipGetLastError());
+    }
+    const real_t *bias_sub = nullptr;
+    if (opp_bias) bias_sub = isA ? s->biasB.ptr : s->biasA.ptr;             // fused "X - bias" (:8566-8570, :8750-8754)
+    const int ksolve = kk + (self_bias ? 1 : 0);
+    if (p_self > 0) {
+        // optimizeA_collective general branch, Cholesky (collective.c:5566-5968)
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+        const int rows_u = isA ? m.m_u : m.n_i;
+        const int kc = k_side_self + m.k, kt = k_side_self + ksolve;
+        const real_t w = isA ? m.w_user : m.w_item;
+        launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);            // :5658-5668
+        if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822
+        const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
+        launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
+                           self_blk, ld_self);                                                      // :5768-5773
+        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, s->ctc.ptr, kc, local_u,
+                   p_self, m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false,
+                   CHOL_COLLECTIVE};
+        return launch_chol(dev, c, &X);
+    }
+    const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;                                     // :7465
+    if (chol) {
+        CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, 0, bias_sub, nullptr, 0, 0, 0,
+                   m.lam, m.lam, scale_lam, false, false, CHOL_EXPLICIT};
+        return launch_chol(dev, c, &X);
+    }
+    CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, bias_sub, nullptr,
+             m.lam, m.lam, scale_lam, false, m.max_cg_steps, false};
+    return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
+}
+
+// C / D update: optimizeA Case 1 with do_B (common.c:2793-2991; Q6: always the transposed gemm)
+static int update_sideinfo(cmfrec_hip_session *s, bool isC)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    const int p = isC ? m.p : m.q;
+    if (p <= 0) return 0;
+    const int rows_u = isC ? m.m_u : m.n_i;
+    const int kc = (isC ? m.k_user : m.k_item) + m.k;
+    real_t *Cm = isC ? s->C.ptr : s->D.ptr;
+    const real_t *Um = isC ? s->U.ptr : s->II.ptr;
+    const real_t *F = isC ? s->A.ptr : s->B.ptr;
+    const size_t ldF = isC ? s->ldA : s->ldB;
+    const real_t w = isC ? m.w_user : m.w_item;
+    const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
+    real_t lam = m.lam / w;                                                                        // collective.c:8367, :8418
+    real_t diag = scale_lam ? lam * (real_t)rows_u : lam;                                          // common.c:2832
+    launch_gram(dev, s->gws, F, ldF, rows_u, kc, s->gram.ptr, (real_t)1, diag);                    // common.c:2824
+    launch_gemm<true>(dev, p, kc, rows_u, (real_t)1, Um, (size_t)p, F, ldF, Cm, (size_t)kc);       // common.c:2852-2855
+    CholCall c{Cm, (size_t)kc, nullptr, 0, kc, 0, nullptr, s->gram.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+    return launch_chol(dev, c, nullptr, p);                                                        // common.c:2872-2875
+}
+
+int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        hipStream_t st = s->dev.stream;
+        if (m.implicit || !s->has_bias) return 0;
+        if (which == 'B') {
+            if (m.item_bias)     // collective.c:8723-8725
+                hipLaunchKernelGGL(col_extract_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, s->B.ptr, s->ldB, m.n, s->k_totB, s->biasB.ptr);
+            if (m.user_bias)     // collective.c:8728-8732
+                hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, s->B.ptr, s->ldB, m.n, s->k_totB, (real_t)1);
+        } else if (which == 'A') {
+            if (m.user_bias)     // collective.c:8882-8884
+                hipLaunchKernelGGL(col_extract_kernel<real_t>, grid1d(m.m), dim3(256), 0, st, s->A.ptr, s->ldA, m.m, s->k_totA, s->biasA.ptr);
+            if (m.item_bias)     // collective.c:8538-8543 (done at the top of the next iteration in the reference)
+                hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(m.m), dim3(256), 0, st, s->A.ptr, s->ldA, m.m, s->k_totA, (real_t)1);
+        }
+        HIP_CHECK(hipGetLastError());
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const bool chol = use_cholesky || !s->mdl.use_cg;
+        if (which == 'A' || which == 'B') {
+            EventPair ev{s->new_event(), s->new_event()};
+            HIP_CHECK(hipEventRecord(ev.a, s->dev.stream));
+            int rc = update_factor(s, which == 'A', chol);
+            HIP_CHECK(hipEventRecord(ev.b, s->dev.stream));
+            (which == 'A' ? s->evA : s->evB).push_back(ev);
+            return rc;
+        }
+        if (which == 'C' || which == 'D') return update_sideinfo(s, which == 'C');
+        g_last_error = "cmfrec_hip: unknown update target";
+        return 2;
+    });
+}
+
+int cmfrec_hip_session_iterate(cmfrec_hip_session *s, int niter, int finalize_chol)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    if (m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n) {
+        g_last_error = "cmfrec_hip: iterate() needs a session that owns all rows (use update()+all-gather on shards)";
+        return 2;
+    }
+    for (int it = 0; it < niter; it++) {
+        // collective.c:8336-8340 / :9829-9830
+        int chol = (finalize_chol && m.use_cg && it == niter - 1) ? 1 : 0;
+        int rc;
+        if (m.p > 0 && (rc = cmfrec_hip_session_update(s, 'C', chol))) return rc;
+        if (m.q > 0 && (rc = cmfrec_hip_session_update(s, 'D', chol))) return rc;
+        if ((rc = cmfrec_hip_session_update(s, 'B', chol))) return rc;
+        if ((rc = cmfrec_hip_session_after_gather(s, 'B'))) return rc;
+        if ((rc = cmfrec_hip_session_update(s, 'A', chol))) return rc;
+        if ((rc = cmfrec_hip_session_after_gather(s, 'A'))) return rc;
+    }
+    return 0;
+}
+
+int cmfrec_hip_session_sync(cmfrec_hip_session *s)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
+void *cmfrec_hip_session_device_ptr(cmfrec_hip_session *s, int which, size_t *rows, size_t *ld)
+{
+    switch (which) {
+        case 'A': if (rows) *rows = s->mdl.m; if (ld) *ld = s->ldA; return s->A.ptr;
+        case 'B': if (rows) *rows = s->mdl.n; if (ld) *ld = s->ldB; return s->B.ptr;
+        case 'C': if (rows) *rows = s->mdl.p; if (ld) *ld = s->mdl.k_user + s->mdl.k; return s->C.ptr;
+        case 'D': if (rows) *rows = s->mdl.q; if (ld) *ld = s->mdl.k_item + s->mdl.k; return s->D.ptr;
+        case 'a': if (rows) *rows = s->mdl.m; if (ld) *ld = 1; return s->biasA.ptr;
+        case 'b': if (rows) *rows = s->mdl.n; if (ld) *ld = 1; return s->biasB.ptr;
+    }
+    return nullptr;
+}
+
+void *cmfrec_hip_session_stream(cmfrec_hip_session *s) { return (void *)s->dev.stream; }
+
+int cmfrec_hip_session_kernel_time(cmfrec_hip_session *s, int which, double *ms, long *launches)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        auto &v = (which == 'A') ? s->evA : s->evB;
+        double tot = 0;
+        for (auto &p : v) {
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, p.a, p.b));
+            tot += t;
+        }
+        if (ms) *ms = tot;
+        if (launches) *launches = (long)v.size();
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, double *ms, long *launches,
+                                 long *rows, unsigned long long *nnz)
+{
+    return guarded([&]() {
+        if (bin < 0 || bin > 2) return 2;
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        BinTimers &bt = (which == 'A') ? s->binA : s->binB;
+        const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
+        double tot = 0;
+        for (auto &p : bt.ev[bin]) {
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, p.a, p.b));
+            tot += t;
+        }
+        if (ms) *ms = tot;
+        if (launches) *launches = (long)bt.ev[bin].size();
+        if (rows) *rows = bin == 0 ? X.n_heavy : bin == 1 ? X.n_medium : X.n_light;
+        if (nnz) *nnz = bin == 0 ? X.nnz_heavy : bin == 1 ? X.nnz_medium : X.nnz_light;
+        return 0;
+    });
+}
+
+void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s)
+{
+    (void)hipStreamSynchronize(s->dev.stream);
+    s->binA.clear(); s->binB.clear();
+    for (auto *v : {&s->evA, &s->evB}) {
+        for (auto &p : *v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        v->clear();
+    }
+}
+
+// ============================ level 2: operators with host buffers ============================
+
+int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                                  const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr, real_t lam,
+                                  bool use_cg, bool precondition_cg, int_t max_cg_steps, real_t *BtB_out)
+{
+    return guarded([&]() {
+        if (precondition_cg) { g_last_error = "cmfrec_hip: precondition_cg is not implemented"; return 2; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> dA, dB, dG;
+        GramWorkspace gws;
+        SparseShard X;
+        dA.upload(A, (size_t)m * lda, dev.stream);
+        dB.upload(B, (size_t)n * ldb, dev.stream);
+        dG.alloc((size_t)k * k);
+        X.upload(m, Xcsr_p, Xcsr_i, Xcsr, dev.stream);
+        launch_gram(dev, gws, dB.ptr, ldb, n, k, dG.ptr, (real_t)1, use_cg ? (real_t)0 : lam);
+        int rc;
+        if (use_cg) {
+            CgCall c{dA.ptr, lda, dB.ptr, ldb, k, nullptr, dG.ptr, lam, lam, false, false, max_cg_steps, true};
+            rc = launch_cg(dev, c, X);
+        } else {
+            // common.c:3334 zeroes m*k - (lda-k) elements from A
+            HIP_CHECK(hipMemsetAsync(dA.ptr, 0, ((size_t)m * lda - (lda - (size_t)k)) * sizeof(real_t), dev.stream));
+            CholCall c{dA.ptr, lda, dB.ptr, ldb, k, 0, nullptr, dG.ptr, 0, 0, 0, lam, lam, false, false, false, CHOL_IMPLICIT};
+            rc = launch_chol(dev, c, &X);
+        }
+        dA.download(A, (size_t)m * lda, dev.stream);
+        if (BtB_out) dG.download(BtB_out, (size_t)k * k, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        HIP_CHECK(hipStreamDestroy(dev.stream));
+        return rc;
+    });
+}
+
+int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                                  const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                  const real_t *bias_sub, real_t lam, real_t lam_last, bool scale_lam,
+                                  bool scale_bias_const, bool use_cg, bool precondition_cg, int_t max_cg_steps)
+{
+    return guarded([&]() {
+        if (precondition_cg) { g_last_error = "cmfrec_hip: precondition_cg is not implemented"; return 2; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> dA, dB, dbias;
+        SparseShard X;
+        dA.upload(A, (size_t)m * lda, dev.stream);
+        dB.upload(B, (size_t)n * ldb, dev.stream);
+        if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
+        X.upload(m, Xcsr_p, Xcsr_i, Xcsr, dev.stream);
+        int rc;
+        if (use_cg) {
+            CgCall c{dA.ptr, lda, dB.ptr, ldb, k, bias_sub ? dbias.ptr : nullptr, nullptr, lam, lam_last, scale_lam,
+                     scale_bias_const, max_cg_steps, false};
+            rc = launch_cg(dev, c, X);
+        } else {
+            CholCall c{dA.ptr, lda, dB.ptr, ldb, k, 0, bias_sub ? dbias.ptr : nullptr, nullptr, 0, 0, 0, lam, lam_last,
+                       scale_lam, false, scale_bias_const, CHOL_EXPLICIT};
+            rc = launch_chol(dev, c, &X);
+        }
+        dA.download(A, (size_t)m * lda, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        HIP_CHECK(hipStreamDestroy(dev.stream));
+        return rc;
+    });
+}
+
+int cmfrec_hip_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                                    const real_t *Xfull, size_t ldX, bool do_B, real_t lam, real_t lam_last,
+                                    bool scale_lam)
+{
+    return guarded([&]() {
+        if (lam != lam_last) { g_last_error = "cmfrec_hip: dense_full supports lam_last == lam only"; return 2; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> dA, dB, dX, dG;
+        GramWorkspace gws;
+        dA.alloc((size_t)m * lda);
+        HIP_CHECK(hipMemsetAsync(dA.ptr, 0, dA.n * sizeof(real_t), dev.stream));
+        dB.upload(B, (size_t)n * ldb, dev.stream);
+        size_t xrows = do_B ? (size_t)n : (size_t)m;
+        dX.upload(Xfull, xrows * ldX, dev.stream);
+        dG.alloc((size_t)k * k);
+        launch_gram(dev, gws, dB.ptr, ldb, n, k, dG.ptr, (real_t)1, scale_lam ? lam * (real_t)n : lam);
+        if (do_B) launch_gemm<true>(dev, m, k, n, (real_t)1, dX.ptr, ldX, dB.ptr, ldb, dA.ptr, lda);
+        else      launch_gemm<false>(dev, m, k, n, (real_t)1, dX.ptr, ldX, dB.ptr, ldb, dA.ptr, lda);
+        CholCall c{dA.ptr, lda, nullptr, 0, k, 0, nullptr, dG.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+        int rc = launch_chol(dev, c, nullptr, m);
+        // only the k solved columns are written back (padding columns are never touched by the reference)
+        std::vector<real_t> tmp((size_t)m * lda);
+        dA.download(tmp.data(), (size_t)m * lda, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        for (int r = 0; r < m; r++) memcpy(A + (size_t)r * lda, tmp.data() + (size_t)r * lda, (size_t)k * sizeof(real_t));
+        HIP_CHECK(hipStreamDestroy(dev.stream));
+        return rc;
+    });
+}
+
+int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C, int_t m,
+                                    int_t m_u, int_t n, int_t p, int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                    const real_t *bias_sub, const real_t *U, real_t lam, real_t w_user,
+                                    real_t lam_last, bool scale_lam, bool scale_lam_sideinfo)
+{
+    return guarded([&]() {
+        if (m_u > m) { g_last_error = "cmfrec_hip: m_u > m is not supported"; return 2; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        const int kc = k_user + k, kt = k_user + k + k_main;
+        DevBuf<real_t> dA, dB, dC, dU, dG, dbias;
+        GramWorkspace gws;
+        SparseShard X;
+        dA.upload(A, (size_t)m * lda, dev.stream);
+        dB.upload(B, (size_t)n * ldb, dev.stream);
+        dC.upload(C, (size_t)p * kc, dev.stream);
+        dU.upload(U, (size_t)m_u * p, dev.stream);
+        if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
+        dG.alloc((size_t)kc * kc);
+        X.upload(m, Xcsr_p, Xcsr_i, Xcsr, dev.stream);
+        launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dG.ptr, w_user, (real_t)0);
+        // collective.c:4817-4822 zeroes max(m,m_u)*lda - (lda-k_totA) elements
+        HIP_CHECK(hipMemsetAsync(dA.ptr, 0, ((size_t)m * lda - (lda - (size_t)kt)) * sizeof(real_t), dev.stream));
+        launch_gemm<false>(dev, m_u, kc, p, w_user, dU.ptr, (size_t)p, dC.ptr, (size_t)kc, dA.ptr, lda);
+        CholCall c{dA.ptr, lda, dB.ptr + k_item, ldb, kt, k_user, bias_sub ? dbias.ptr : nullptr, dG.ptr, kc, m_u, p,
+                   lam, lam_last, (bool)(scale_lam || scale_lam_sideinfo), scale_lam_sideinfo, false, CHOL_COLLECTIVE};
+        int rc = launch_chol(dev, c, &X);
+        dA.download(A, (size_t)m * lda, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        HIP_CHECK(hipStreamDestroy(dev.stream));
+        return rc;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+"""Row-block multi-GPU ALS: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference has no distributed path; rows of a factor matrix are independent
+given the opposing matrix (every `omp parallel for` on the path is over rows), so users and items
+are split into contiguous blocks, each rank updates its own block of A / B on its GPU and the
+updated blocks are all-gathered after every half-step so that every rank holds full replicas as
+gather sources.  The only collective on the data path is that all-gather.
+
+``ShardedAls`` is written against a small engine protocol so the partitioning / gathering logic
+can be exercised on CPU with gloo (tests/test_distributed_gloo.py supplies an oracle-backed
+engine); ``GpuEngine`` is the real one (AlsSession, HBM-resident).
+"""
+import numpy as np
+
+
+def balanced_boundaries(counts, parts):
+    """Contiguous split of rows into ``parts`` blocks with (nearly) equal total nnz.
+    counts: nnz per row.  Returns parts+1 boundaries, non-decreasing, first 0, last len(counts)."""
+    counts = np.asarray(counts, np.int64)
+    n = len(counts)
+    csum = np.concatenate([[0], np.cumsum(counts)])
+    total = csum[-1]
+    bounds = [0]
+    for p in range(1, parts):
+        target = total * p / parts
+        b = int(np.searchsorted(csum, target, side="left"))
+        b = max(bounds[-1], min(b, n))
+        bounds.append(b)
+    bounds.append(n)
+    return bounds
+
+
+def equal_boundaries(n, parts):
+    step = -(-n // parts)
+    return [min(i * step, n) for i in range(parts)] + [n]
+
+
+class ShardedAls:
+    """ALS loop over row-block shards.  engine protocol:
+        engine.update(which, use_cholesky=False)   -- recompute the LOCAL block of 'A' or 'B'
+        engine.full(which)      -> 2-D torch tensor [rows, ld] (the local replica, updated in place)
+        engine.ranges(which)    -> list of (begin, end) per rank
+        engine.after_gather(which)
+        engine.pre_collective() / engine.post_collective()  -- stream hand-over hooks
+    """
+
+    def __init__(self, engine, rank, world, group=None):
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        self._stage = {}
+
+    def allgather(self, which):
+        import torch
+        import torch.distributed as dist
+        eng = self.engine
+        full = eng.full(which)
+        ranges = eng.ranges(which)
+        b0, b1 = ranges[self.rank]
+        sizes = [e - b for b, e in ranges]
+        eng.pre_collective()
+        if self.world == 1:
+            eng.post_collective()
+            return
+        ld = full.shape[1]
+        if len(set(sizes)) == 1 and sizes[0] * self.world == full.shape[0]:
+            # equal blocks tiling the matrix exactly: gather straight into the replica
+            local = full[b0:b1].clone()
+            dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=self.group)
+        else:
+            mx = max(sizes)
+            key = (which, mx, ld)
+            if key not in self._stage:
+                self._stage[key] = (torch.zeros((self.world, mx, ld), dtype=full.dtype, device=full.device),
+                                    torch.zeros((mx, ld), dtype=full.dtype, device=full.device))
+            stage, local = self._stage[key]
+            local[: b1 - b0].copy_(full[b0:b1])
+            dist.all_gather_into_tensor(stage.view(-1), local.view(-1), group=self.group)
+            for r, (rb, re) in enumerate(ranges):
+                if r != self.rank and re > rb:
+                    full[rb:re].copy_(stage[r, : re - rb])
+        eng.post_collective()
+
+    def half_step(self, which, use_cholesky=False):
+        self.engine.update(which, use_cholesky)
+        self.allgather(which)
+        self.engine.after_gather(which)
+
+    def iteration(self, use_cholesky=False):
+        # reference order: B then A (src/collective.c:9924-10022)
+        self.half_step("B", use_cholesky)
+        self.half_step("A", use_cholesky)
+
+
+class _DevArray:
+    """Zero-copy view of session-owned HBM for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, shape, dtype):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": np.dtype(dtype).str,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class GpuEngine:
+    """One rank's shard: an AlsSession that owns rows [row_begin,row_end) of A and columns
+    [col_begin,col_end) of B, plus torch views of its replicas for the RCCL all-gather."""
+
+    def __init__(self, session, row_ranges, col_ranges):
+        import torch
+        self.session = session
+        self._ranges = {"A": row_ranges, "B": col_ranges}
+        self._full = {}
+        for which in ("A", "B"):
+            ptr, rows, ld = session.device_ptr(which)
+            self._full[which] = torch.as_tensor(_DevArray(ptr, (rows, ld), session.dtype), device="cuda")
+
+    @classmethod
+    def from_user_block(cls, m_blk, n, k, row, col, val, A0_blk, lam, max_cg_steps, rank, world, device,
+                        dtype=np.float64):
+        """Implicit model, weak-scaling layout of bench.py: every rank brings its own user block
+        (local rows, global item ids); the CSC shard of the rank's item block is assembled from all
+        ranks' triplets with one all-gather at set-up."""
+        import torch
+        import torch.distributed as dist
+        from .session import AlsSession
+        m = m_blk * world
+        row_ranges = [(r * m_blk, (r + 1) * m_blk) for r in range(world)]
+        cb = equal_boundaries(n, world)
+        col_ranges = [(cb[r], cb[r + 1]) for r in range(world)]
+        c0, c1 = col_ranges[rank]
+        dev = torch.device("cuda", device)
+        g_row = torch.as_tensor(row.astype(np.int64) + rank * m_blk, device=dev).to(torch.int32)
+        g_col = torch.as_tensor(col, device=dev)
+        g_val = torch.as_tensor(val.astype(dtype), device=dev)
+        nn = len(val)
+        all_row = torch.empty(world * nn, dtype=torch.int32, device=dev)
+        all_col = torch.empty(world * nn, dtype=torch.int32, device=dev)
+        all_val = torch.empty(world * nn, dtype=g_val.dtype, device=dev)
+        dist.all_gather_into_tensor(all_row, g_row)
+        dist.all_gather_into_tensor(all_col, g_col)
+        dist.all_gather_into_tensor(all_val, g_val)
+        keep = (all_col >= c0) & (all_col < c1)
+        crow = all_row[keep].cpu().numpy(); ccol = (all_col[keep] - c0).cpu().numpy(); cval = all_val[keep].cpu().numpy()
+        del all_row, all_col, all_val, keep
+        order = np.argsort(row, kind="stable")
+        csr_p = np.zeros(m_blk + 1, np.uint64); np.cumsum(np.bincount(row, minlength=m_blk), out=csr_p[1:])
+        csr = (csr_p, col[order].astype(np.int32), val[order].astype(dtype))
+        order = np.argsort(ccol, kind="stable")
+        csc_p = np.zeros(c1 - c0 + 1, np.uint64); np.cumsum(np.bincount(ccol, minlength=c1 - c0), out=csc_p[1:])
+        csc = (csc_p, crow[order].astype(np.int32), cval[order].astype(dtype))
+        sess = AlsSession(m, n, k, implicit=True, dtype=dtype, lam=lam, use_cg=True, max_cg_steps=max_cg_steps,
+                          row_range=row_ranges[rank], col_range=col_ranges[rank], device=device)
+        sess.set_X(csr, csc)
+        eng = cls(sess, row_ranges, col_ranges)
+        # start values: every rank contributes its user block of A; B starts at zero (collective.c:9765-9768)
+        fullA = eng.full("A")
+        fullA[rank * m_blk:(rank + 1) * m_blk].copy_(torch.as_tensor(np.ascontiguousarray(A0_blk, dtype), device=dev))
+        eng.full("B").zero_()
+        torch.cuda.synchronize()
+        ShardedAls(eng, rank, world).allgather("A")
+        return eng
+
+    def full(self, which):
+        return self._full[which]
+
+    def ranges(self, which):
+        return self._ranges[which]
+
+    def update(self, which, use_cholesky=False):
+        self.session.update(which, use_cholesky)
+
+    def after_gather(self, which):
+        self.session.after_gather(which)
+
+    def pre_collective(self):
+        # the session launches on its own stream; RCCL runs on torch's
+        self.session.sync()
+
+    def post_collective(self):
+        import torch
+        torch.cuda.current_stream().synchronize()

@@ -1,0 +1,210 @@
+"""CMF / CMF_implicit estimators: the ``fit()`` surface of the reference's Python classes
+(/root/reference/cmfrec/__init__.py:2881-2896 ``CMF.__init__``, :4673-4683 ``CMF_implicit.__init__``,
+:938-1181 ``_fit_common``, :3150-3248 / :4882-4928 ``_fit``), driving the HIP library through
+the reference's own C signatures (include/cmfrec_hip.h level 1).
+
+Only the ALS path is offered (``method="als"``); options outside SURVEY.md section 8 raise
+``NotImplementedError`` / ``ValueError`` instead of silently doing something else.
+Inputs: ``X`` as a SciPy COO matrix (any sparse format is converted), or a ``(row, col, value)``
+triplet plus ``shape``; dense side information ``U`` [m_u, p] / ``I`` [n_i, q] as NumPy arrays.
+"""
+import ctypes as C
+import multiprocessing
+
+import numpy as np
+
+from . import _lib
+
+
+def _coo_triplet(X, shape=None):
+    if isinstance(X, tuple):
+        row, col, val = X
+        if shape is None:
+            shape = (int(np.max(row)) + 1, int(np.max(col)) + 1)
+    else:
+        import scipy.sparse as sp
+        if not sp.issparse(X):
+            raise TypeError("'X' must be a SciPy sparse matrix or a (row, col, value) triplet")
+        X = X.tocoo()
+        row, col, val, shape = X.row, X.col, X.data, X.shape
+    m, n = int(shape[0]), int(shape[1])
+    if max(m, n) > np.iinfo(np.int32).max:      # reference guard, __init__.py:1146-1149
+        raise ValueError("Error: dimensions of 'X' are too large for 32-bit indices.")
+    return (np.ascontiguousarray(row, np.int32), np.ascontiguousarray(col, np.int32), val, m, n)
+
+
+class _Base:
+    def _setup(self, use_float, nthreads, n_jobs):
+        self.use_float = bool(use_float)
+        self.dtype_ = np.float32 if self.use_float else np.float64
+        if n_jobs is not None:
+            nthreads = n_jobs
+        if nthreads is None or nthreads < 1:
+            nthreads = multiprocessing.cpu_count()
+        self.nthreads = int(nthreads)
+        self.is_fitted_ = False
+
+    def _lib(self):
+        return _lib.load(self.dtype_), _lib.real(self.dtype_)
+
+
+class CMF_implicit(_Base):
+    """Implicit-feedback model (iALS / WRMF), reference class ``CMF_implicit``."""
+
+    def __init__(self, k=50, lambda_=1e0, alpha=1., use_cg=True, k_user=0, k_item=0, k_main=0,
+                 w_main=1., w_user=10., w_item=10., l1_lambda=0., center_U=True, center_I=True,
+                 niter=10, NA_as_zero_user=False, NA_as_zero_item=False, nonneg=False, nonneg_C=False,
+                 nonneg_D=False, max_cd_steps=100, apply_log_transf=False,
+                 precompute_for_predictions=True, use_float=True, max_cg_steps=3,
+                 precondition_cg=False, finalize_chol=False, random_state=1, verbose=False,
+                 produce_dicts=False, handle_interrupt=True, nthreads=-1, n_jobs=None):
+        self.k = int(k); self.lambda_ = float(lambda_); self.alpha = float(alpha); self.use_cg = bool(use_cg)
+        self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
+        self.w_main = float(w_main); self.w_user = float(w_user); self.w_item = float(w_item)
+        self.l1_lambda = l1_lambda; self.niter = int(niter); self.nonneg = bool(nonneg)
+        self.apply_log_transf = bool(apply_log_transf)
+        self.precompute_for_predictions = bool(precompute_for_predictions)
+        self.max_cg_steps = int(max_cg_steps); self.precondition_cg = bool(precondition_cg)
+        self.finalize_chol = bool(finalize_chol); self.random_state = int(random_state)
+        self.verbose = bool(verbose); self.handle_interrupt = bool(handle_interrupt)
+        self._setup(use_float, nthreads, n_jobs)
+        if self.nonneg or nonneg_C or nonneg_D or l1_lambda:
+            raise NotImplementedError("nonneg / l1_lambda are not implemented in cmfrec_amd")
+
+    def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
+        """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
+        them from ``random_state`` (C argument ``reset_values=false``)."""
+        if U is not None or I is not None:
+            raise NotImplementedError("CMF_implicit with side information is not implemented (SURVEY.md 8f-1)")
+        row, col, val, m, n = _coo_triplet(X, shape)
+        lib, R = self._lib()
+        val = np.ascontiguousarray(val, self.dtype_)
+        ktot = self.k + self.k_main
+        reset = A0 is None
+        A = np.empty((m, ktot), self.dtype_) if reset else np.array(A0, self.dtype_, order="C", copy=True)
+        B = np.empty((n, ktot), self.dtype_) if (reset or B0 is None) else np.array(B0, self.dtype_, order="C", copy=True)
+        if not reset and B0 is None:
+            B[:] = 0
+        wmm = np.zeros(1, self.dtype_)
+        rc = lib.fit_collective_implicit_als(
+            _lib.ptr(A), _lib.ptr(B), None, None, C.c_bool(reset), C.c_int(self.random_state), None, None,
+            C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+            C.c_size_t(len(val)), R(self.lambda_), None, R(0.), None,
+            None, C.c_int(0), C.c_int(0), None, C.c_int(0), C.c_int(0),
+            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
+            R(self.w_main), R(self.w_user), R(self.w_item), _lib.ptr(wmm),
+            R(self.alpha), C.c_bool(False),        # adjust_weight is always False (__init__.py:4753)
+            C.c_bool(self.apply_log_transf), C.c_int(self.niter), C.c_int(self.nthreads),
+            C.c_bool(self.verbose), C.c_bool(self.handle_interrupt), C.c_bool(self.use_cg),
+            C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg), C.c_bool(self.finalize_chol),
+            C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(False), None, None, None, None)
+        _lib.check(rc, lib, "fit_collective_implicit_als")
+        self.A_, self.B_ = A, B
+        self.C_ = np.empty((0, 0), self.dtype_); self.D_ = np.empty((0, 0), self.dtype_)
+        self._w_main_multiplier = float(wmm[0])
+        self.is_fitted_ = True
+        return self
+
+    def predict(self, user, item):
+        """A_u . B_i for paired user / item ids (reference predict_multiple, common.c:5066-5106)."""
+        user = np.asarray(user); item = np.asarray(item)
+        return np.einsum("ij,ij->i", self.A_[user], self.B_[item])
+
+
+class CMF(_Base):
+    """Explicit-feedback collective model, reference class ``CMF`` (ALS only)."""
+
+    def __init__(self, k=40, lambda_=1e+1, method="als", use_cg=True, user_bias=True, item_bias=True,
+                 center=True, add_implicit_features=False, scale_lam=False, scale_lam_sideinfo=False,
+                 scale_bias_const=False, k_user=0, k_item=0, k_main=0, w_main=1., w_user=1., w_item=1.,
+                 w_implicit=0.5, l1_lambda=0., center_U=True, center_I=True, maxiter=800, niter=10,
+                 parallelize="separate", corr_pairs=4, max_cg_steps=3, precondition_cg=False,
+                 finalize_chol=True, NA_as_zero=False, NA_as_zero_user=False, NA_as_zero_item=False,
+                 nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
+                 precompute_for_predictions=True, include_all_X=True, use_float=True, random_state=1,
+                 verbose=False, print_every=10, handle_interrupt=True, produce_dicts=False, nthreads=-1,
+                 n_jobs=None):
+        if method != "als":
+            raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
+        if add_implicit_features or NA_as_zero or NA_as_zero_user or NA_as_zero_item or nonneg or nonneg_C \
+                or nonneg_D or l1_lambda or scale_bias_const:
+            raise NotImplementedError("add_implicit_features / NA_as_zero / nonneg / l1_lambda / scale_bias_const "
+                                      "are not implemented in cmfrec_amd")
+        if not (center_U and center_I):
+            raise NotImplementedError("center_U / center_I = False are not implemented in cmfrec_amd")
+        self.k = int(k); self.lambda_ = float(lambda_); self.use_cg = bool(use_cg)
+        self.user_bias = bool(user_bias); self.item_bias = bool(item_bias); self.center = bool(center)
+        self.scale_lam = bool(scale_lam); self.scale_lam_sideinfo = bool(scale_lam_sideinfo)
+        self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
+        self.w_main = float(w_main); self.w_user = float(w_user); self.w_item = float(w_item)
+        self.w_implicit = float(w_implicit); self.niter = int(niter); self.max_cg_steps = int(max_cg_steps)
+        self.precondition_cg = bool(precondition_cg); self.finalize_chol = bool(finalize_chol)
+        self.precompute_for_predictions = bool(precompute_for_predictions)
+        self.random_state = int(random_state); self.verbose = bool(verbose)
+        self.handle_interrupt = bool(handle_interrupt)
+        self._setup(use_float, nthreads, n_jobs)
+
+    def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None, biasA0=None, biasB0=None):
+        row, col, val, m, n = _coo_triplet(X, shape)
+        lib, R = self._lib()
+        dt = self.dtype_
+        val = np.ascontiguousarray(val, dt)
+        Uc = None if U is None else np.ascontiguousarray(U, dt)
+        Ic = None if I is None else np.ascontiguousarray(I, dt)
+        m_u, p = (0, 0) if Uc is None else Uc.shape
+        n_i, q = (0, 0) if Ic is None else Ic.shape
+        use_cg = self.use_cg
+        if (Uc is not None or Ic is not None) and use_cg:
+            raise NotImplementedError("side information requires use_cg=False in cmfrec_amd "
+                                      "(block-CG: SURVEY.md 8f-1)")
+        ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
+        reset = A0 is None
+        A = np.empty((max(m, m_u), ka), dt) if reset else np.array(A0, dt, order="C", copy=True)
+        B = np.empty((max(n, n_i), kb), dt) if (reset or B0 is None) else np.array(B0, dt, order="C", copy=True)
+        if not reset and B0 is None:
+            B[:] = 0
+        biasA = np.zeros(max(m, m_u), dt) if biasA0 is None else np.array(biasA0, dt, copy=True)
+        biasB = np.zeros(max(n, n_i), dt) if biasB0 is None else np.array(biasB0, dt, copy=True)
+        Cm = np.zeros((p, self.k_user + self.k), dt) if p else None
+        Dm = np.zeros((q, self.k_item + self.k), dt) if q else None
+        glob_mean = np.zeros(1, dt); Ucm = np.zeros(max(p, 1), dt); Icm = np.zeros(max(q, 1), dt)
+        sbA = np.zeros(1, dt); sbB = np.zeros(1, dt)
+        rc = lib.fit_collective_explicit_als(
+            _lib.ptr(biasA), _lib.ptr(biasB), _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), None, None,
+            C.c_bool(False), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean), _lib.ptr(Ucm),
+            _lib.ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+            C.c_size_t(len(val)), None, None, C.c_bool(self.user_bias), C.c_bool(self.item_bias),
+            C.c_bool(self.center), R(self.lambda_), None, R(0.), None, C.c_bool(self.scale_lam),
+            C.c_bool(self.scale_lam_sideinfo), C.c_bool(False), _lib.ptr(sbA), _lib.ptr(sbB),
+            _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
+            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
+            R(self.w_main), R(self.w_user), R(self.w_item), R(self.w_implicit),
+            C.c_int(self.niter), C.c_int(self.nthreads), C.c_bool(self.verbose), C.c_bool(self.handle_interrupt),
+            C.c_bool(use_cg), C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg),
+            C.c_bool(self.finalize_chol), C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(False), C.c_bool(True), None, None, None, None, None, None, None, None, None)
+        _lib.check(rc, lib, "fit_collective_explicit_als")
+        self.A_, self.B_ = A, B
+        self.C_ = Cm if Cm is not None else np.empty((0, 0), dt)
+        self.D_ = Dm if Dm is not None else np.empty((0, 0), dt)
+        self.user_bias_ = biasA if self.user_bias else np.empty(0, dt)
+        self.item_bias_ = biasB if self.item_bias else np.empty(0, dt)
+        self.glob_mean_ = float(glob_mean[0])
+        self._U_colmeans, self._I_colmeans = Ucm[:p], Icm[:q]
+        self.is_fitted_ = True
+        return self
+
+    def predict(self, user, item):
+        """glob_mean + biasA[u] + biasB[i] + A_u . B_i (reference predict_multiple, common.c:5098-5106)."""
+        user = np.asarray(user); item = np.asarray(item)
+        ku, ki = self.k_user, self.k_item
+        out = np.einsum("ij,ij->i", self.A_[user, ku:], self.B_[item, ki:]) + self.glob_mean_
+        if self.user_bias:
+            out = out + self.user_bias_[user]
+        if self.item_bias:
+            out = out + self.item_bias_[item]
+        return out

@@ -1,0 +1,114 @@
+"""Python handle of the device-resident ALS session (level 3 of include/cmfrec_hip.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class AlsSession:
+    """Factor matrices, CSR/CSC of X and side information resident in HBM; one ``update`` = one
+    half-step of the reference's ALS loop (src/collective.c:8334-8898 / :9827-10045)."""
+
+    def __init__(self, m, n, k, implicit, dtype=np.float64, lam=1.0, use_cg=True, max_cg_steps=3,
+                 k_main=0, k_user=0, k_item=0, user_bias=False, item_bias=False, scale_lam=False,
+                 scale_lam_sideinfo=False, p=0, q=0, m_u=0, n_i=0, w_user=1.0, w_item=1.0,
+                 row_range=None, col_range=None, device=-1):
+        self.dtype = np.dtype(dtype).type
+        self.lib = _lib.load(self.dtype)
+        M = _lib.Model if self.dtype is np.float64 else _lib.ModelF
+        rb, re = (0, m) if row_range is None else row_range
+        cb, ce = (0, n) if col_range is None else col_range
+        self.model = M(implicit=int(implicit), m=m, n=n, k=k, k_main=k_main, k_user=k_user, k_item=k_item,
+                       user_bias=int(user_bias), item_bias=int(item_bias), scale_lam=int(scale_lam),
+                       scale_lam_sideinfo=int(scale_lam_sideinfo), use_cg=int(use_cg), precondition_cg=0,
+                       max_cg_steps=max_cg_steps, p=p, q=q, m_u=m_u, n_i=n_i, lam=lam, w_user=w_user,
+                       w_item=w_item, row_begin=rb, row_end=re, col_begin=cb, col_end=ce)
+        self.m, self.n, self.k = m, n, k
+        self.k_totA = k_user + k + k_main
+        self.k_totB = k_item + k + k_main
+        self.has_bias = bool(user_bias or item_bias)
+        self.handle = self.lib.cmfrec_hip_session_create(C.byref(self.model), C.c_int(device))
+        if not self.handle:
+            msg = self.lib.cmfrec_hip_last_error()
+            raise RuntimeError("cmfrec_hip_session_create failed: %s" % (msg.decode() if msg else "?"))
+        self.handle = C.c_void_p(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.cmfrec_hip_session_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _c(self, a, dt=None):
+        return None if a is None else np.ascontiguousarray(a, self.dtype if dt is None else dt)
+
+    def set_X(self, csr, csc):
+        """csr / csc = (indptr uint64 rebased to the local block, indices int32 global, values)."""
+        keep = [self._c(csr[0], np.uint64), self._c(csr[1], np.int32), self._c(csr[2]),
+                self._c(csc[0], np.uint64), self._c(csc[1], np.int32), self._c(csc[2])]
+        _lib.check(self.lib.cmfrec_hip_session_set_X(self.handle, *[_lib.ptr(a) for a in keep]), self.lib, "set_X")
+
+    def set_factors(self, A=None, B=None, biasA=None, biasB=None, Cm=None, Dm=None):
+        keep = [self._c(x) for x in (A, B, biasA, biasB, Cm, Dm)]
+        _lib.check(self.lib.cmfrec_hip_session_set_factors(self.handle, *[_lib.ptr(a) for a in keep]), self.lib,
+                   "set_factors")
+
+    def get_factors(self):
+        mdl = self.model
+        out = dict(A=np.empty((self.m, self.k_totA), self.dtype), B=np.empty((self.n, self.k_totB), self.dtype))
+        out["biasA"] = np.empty(self.m, self.dtype) if mdl.user_bias else None
+        out["biasB"] = np.empty(self.n, self.dtype) if mdl.item_bias else None
+        out["C"] = np.empty((mdl.p, mdl.k_user + mdl.k), self.dtype) if mdl.p else None
+        out["D"] = np.empty((mdl.q, mdl.k_item + mdl.k), self.dtype) if mdl.q else None
+        _lib.check(self.lib.cmfrec_hip_session_get_factors(
+            self.handle, *[_lib.ptr(out[x]) for x in ("A", "B", "biasA", "biasB", "C", "D")]), self.lib, "get_factors")
+        return out
+
+    def set_sideinfo(self, U=None, II=None):
+        keep = [self._c(U), self._c(II)]
+        _lib.check(self.lib.cmfrec_hip_session_set_sideinfo(self.handle, *[_lib.ptr(a) for a in keep]), self.lib,
+                   "set_sideinfo")
+
+    def update(self, which, use_cholesky=False):
+        _lib.check(self.lib.cmfrec_hip_session_update(self.handle, C.c_int(ord(which)), C.c_int(int(use_cholesky))),
+                   self.lib, "update(%s)" % which)
+
+    def after_gather(self, which):
+        _lib.check(self.lib.cmfrec_hip_session_after_gather(self.handle, C.c_int(ord(which))), self.lib, "after_gather")
+
+    def iterate(self, niter, finalize_chol=False):
+        _lib.check(self.lib.cmfrec_hip_session_iterate(self.handle, C.c_int(niter), C.c_int(int(finalize_chol))),
+                   self.lib, "iterate")
+
+    def sync(self):
+        _lib.check(self.lib.cmfrec_hip_session_sync(self.handle), self.lib, "sync")
+
+    def device_ptr(self, which):
+        rows = C.c_size_t(0); ld = C.c_size_t(0)
+        p = self.lib.cmfrec_hip_session_device_ptr(self.handle, C.c_int(ord(which)), C.byref(rows), C.byref(ld))
+        return p, rows.value, ld.value
+
+    def stream(self):
+        return self.lib.cmfrec_hip_session_stream(self.handle)
+
+    def kernel_time(self, which):
+        ms = C.c_double(0); cnt = C.c_long(0)
+        _lib.check(self.lib.cmfrec_hip_session_kernel_time(self.handle, C.c_int(ord(which)), C.byref(ms), C.byref(cnt)),
+                   self.lib, "kernel_time")
+        return ms.value, cnt.value
+
+    def bin_stats(self, which, bin_):
+        """(ms, launches, rows, nnz) of the CG row kernel launches of nnz-bin ``bin_`` (0 heavy, 1 medium, 2 light)."""
+        ms = C.c_double(0); cnt = C.c_long(0); rows = C.c_long(0); nnz = C.c_ulonglong(0)
+        _lib.check(self.lib.cmfrec_hip_session_bin_stats(self.handle, C.c_int(ord(which)), C.c_int(bin_), C.byref(ms),
+                                                         C.byref(cnt), C.byref(rows), C.byref(nnz)), self.lib, "bin_stats")
+        return ms.value, cnt.value, rows.value, nnz.value
+
+    def reset_timers(self):
+        self.lib.cmfrec_hip_session_reset_timers(self.handle)

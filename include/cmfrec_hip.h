@@ -1,0 +1,236 @@
+/*
+ * cmfrec_hip.h -- C ABI of the MI355X-native ALS factor-update path behind cmfrec's interface.
+ *
+ * One shared object per precision, like the reference (setup.py:389-412 builds wrapper_double /
+ * wrapper_float from the same sources):
+ *     libcmfrec_hip_double.so : real_t = double        libcmfrec_hip_float.so : real_t = float
+ * (compile the including translation unit with -DCMFREC_HIP_FLOAT for the float library).
+ * int_t is the 32-bit `int` of the reference's default build (src/cmfrec.h:300-305); CSR/CSC
+ * offsets are size_t (src/cmfrec.h:991).  Dense matrices are row-major; missing optional pointers
+ * are NULL and optional sizes 0 (include/cmfrec.h.in:238-241).
+ *
+ * Three levels, from the outside in:
+ *   1. the two drop-in fit entry points, byte-for-byte the reference's positional signatures;
+ *   2. the operator boundary: one factor update with host buffers (what the reference's internal
+ *      optimizeA* functions compute), used by the parity tests;
+ *   3. a device-resident session (factors + CSR/CSC stay in HBM across half-iterations), which is
+ *      what level 1 drives and what bench.py times.
+ *
+ * Return codes (include/cmfrec.h.in:210-213): 0 ok, 1 out of memory (host or device), 2 invalid or
+ * unsupported input, 3 interrupted.  Additionally 4 = HIP runtime failure (no usable gfx950
+ * device, kernel launch error); there is NO CPU fallback.
+ */
+#ifndef CMFREC_HIP_H
+#define CMFREC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef CMFREC_HIP_FLOAT
+typedef float real_t;
+#else
+typedef double real_t;
+#endif
+typedef int int_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ============================ level 1: drop-in fit entry points ============================ */
+
+/* Replaces fit_collective_implicit_als, /root/reference/src/cmfrec.h:1893-1921 (body
+ * src/collective.c:9375-10207; documented in include/cmfrec.h.in:927-959).
+ * Supported in this round: no side information (U, II, U_sp, I_sp NULL), k_user=k_item=0,
+ * l1_lam=0, nonneg=false, w_main=1.  Anything else returns 2. */
+int_t fit_collective_implicit_als(
+    real_t *A, real_t *B,
+    real_t *C, real_t *D,
+    bool reset_values, int_t seed,
+    real_t *U_colmeans, real_t *I_colmeans,
+    int_t m, int_t n, int_t k,
+    int_t ixA[], int_t ixB[], real_t *X, size_t nnz,
+    real_t lam, real_t *lam_unique,
+    real_t l1_lam, real_t *l1_lam_unique,
+    real_t *U, int_t m_u, int_t p,
+    real_t *II, int_t n_i, int_t q,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    int_t I_row[], int_t I_col[], real_t *I_sp, size_t nnz_I,
+    bool NA_as_zero_U, bool NA_as_zero_I,
+    int_t k_main, int_t k_user, int_t k_item,
+    real_t w_main, real_t w_user, real_t w_item,
+    real_t *w_main_multiplier,
+    real_t alpha, bool adjust_weight, bool apply_log_transf,
+    int_t niter, int nthreads,
+    bool verbose, bool handle_interrupt,
+    bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+    bool nonneg, int_t max_cd_steps, bool nonneg_C, bool nonneg_D,
+    bool precompute_for_predictions,
+    real_t *precomputedBtB,
+    real_t *precomputedBeTBe,
+    real_t *precomputedBeTBeChol,
+    real_t *precomputedCtUbias);
+
+/* Replaces fit_collective_explicit_als, /root/reference/src/cmfrec.h:1851-1892 (body
+ * src/collective.c:7263-9370; include/cmfrec.h.in:885-926).
+ * Supported in this round: sparse X with missing-as-NA, no weights, biases/centering/scale_lam,
+ * CG or Cholesky, optional DENSE side information U[m_u<=m, p] / II[n_i<=n, q] without NaN
+ * (Cholesky only), k_main/k_user/k_item, w_user/w_item.  Anything else returns 2. */
+int_t fit_collective_explicit_als(
+    real_t *biasA, real_t *biasB,
+    real_t *A, real_t *B,
+    real_t *C, real_t *D,
+    real_t *Ai, real_t *Bi,
+    bool add_implicit_features,
+    bool reset_values, int_t seed,
+    real_t *glob_mean,
+    real_t *U_colmeans, real_t *I_colmeans,
+    int_t m, int_t n, int_t k,
+    int_t ixA[], int_t ixB[], real_t *X, size_t nnz,
+    real_t *Xfull,
+    real_t *weight,
+    bool user_bias, bool item_bias, bool center,
+    real_t lam, real_t *lam_unique,
+    real_t l1_lam, real_t *l1_lam_unique,
+    bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+    real_t *scaling_biasA, real_t *scaling_biasB,
+    real_t *U, int_t m_u, int_t p,
+    real_t *II, int_t n_i, int_t q,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    int_t I_row[], int_t I_col[], real_t *I_sp, size_t nnz_I,
+    bool NA_as_zero_X, bool NA_as_zero_U, bool NA_as_zero_I,
+    int_t k_main, int_t k_user, int_t k_item,
+    real_t w_main, real_t w_user, real_t w_item, real_t w_implicit,
+    int_t niter, int nthreads,
+    bool verbose, bool handle_interrupt,
+    bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+    bool nonneg, int_t max_cd_steps, bool nonneg_C, bool nonneg_D,
+    bool precompute_for_predictions,
+    bool include_all_X,
+    real_t *B_plus_bias,
+    real_t *precomputedBtB,
+    real_t *precomputedTransBtBinvBt,
+    real_t *precomputedBtXbias,
+    real_t *precomputedBeTBeChol,
+    real_t *precomputedBiTBi,
+    real_t *precomputedTransCtCinvCt,
+    real_t *precomputedCtCw,
+    real_t *precomputedCtUbias);
+
+/* ============================ level 2: operator boundary (host buffers) ==================== */
+
+/* One iALS half-step; replaces optimizeA_implicit, src/cmfrec.h:1014-1027 / src/common.c:3305-3421.
+ * A[m,lda] in/out, B[n,ldb]; the k solved columns start at A / B.  BtB_out (k*k) optional. */
+int cmfrec_hip_optimizeA_implicit(
+    real_t *A, size_t lda, const real_t *B, size_t ldb,
+    int_t m, int_t n, int_t k,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+    real_t lam,
+    bool use_cg, bool precondition_cg, int_t max_cg_steps,
+    real_t *BtB_out);
+
+/* One explicit-feedback half-step on sparse X (missing = NA, unweighted); replaces optimizeA
+ * Case 4, src/cmfrec.h:986-1008 / src/common.c:3209-3302.  bias_sub (length n, optional) is
+ * subtracted from the stored values on the fly, replacing the host sweeps collective.c:8566-8570 /
+ * :8750-8754. */
+int cmfrec_hip_optimizeA_explicit(
+    real_t *A, size_t lda, const real_t *B, size_t ldb,
+    int_t m, int_t n, int_t k,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+    const real_t *bias_sub,
+    real_t lam, real_t lam_last, bool scale_lam, bool scale_bias_const,
+    bool use_cg, bool precondition_cg, int_t max_cg_steps);
+
+/* Dense full side-information update (the C / D step); replaces optimizeA Case 1,
+ * src/common.c:2793-2991.  do_B: Xfull is [n, ldX] and used transposed (common.c:2852-2855). */
+int cmfrec_hip_optimizeA_dense_full(
+    real_t *A, size_t lda, const real_t *B, size_t ldb,
+    int_t m, int_t n, int_t k,
+    const real_t *Xfull, size_t ldX, bool do_B,
+    real_t lam, real_t lam_last, bool scale_lam);
+
+/* Collective (block-system) half-step with dense full U, Cholesky; replaces optimizeA_collective
+ * general branch, src/cmfrec.h:1646-1683 / src/collective.c:5566-5968 ->
+ * collective_closed_form_block (:1223-1847). */
+int cmfrec_hip_optimizeA_collective(
+    real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+    int_t m, int_t m_u, int_t n, int_t p,
+    int_t k, int_t k_main, int_t k_user, int_t k_item,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+    const real_t *bias_sub,
+    const real_t *U,
+    real_t lam, real_t w_user, real_t lam_last,
+    bool scale_lam, bool scale_lam_sideinfo);
+
+/* ============================ level 3: device-resident session ============================= */
+
+typedef struct cmfrec_hip_session cmfrec_hip_session;
+
+typedef struct cmfrec_hip_model {
+    int32_t implicit;                 /* 1: iALS (optimizeA_implicit), 0: explicit (optimizeA / _collective) */
+    int32_t m, n, k;                  /* global sizes, shared factors */
+    int32_t k_main, k_user, k_item;
+    int32_t user_bias, item_bias;     /* explicit only: bias rides as an extra column (collective.c:7651-7663) */
+    int32_t scale_lam, scale_lam_sideinfo;
+    int32_t use_cg, precondition_cg, max_cg_steps;
+    int32_t p, q, m_u, n_i;           /* dense side info widths / rows (0 = none) */
+    real_t lam, w_user, w_item;
+    /* row-block shard owned by this process (single GPU: [0,m) and [0,n)) */
+    int32_t row_begin, row_end, col_begin, col_end;
+} cmfrec_hip_model;
+
+/* device < 0: use the current HIP device. Returns NULL on failure (see cmfrec_hip_last_error). */
+cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int device);
+void cmfrec_hip_session_destroy(cmfrec_hip_session *s);
+const char *cmfrec_hip_last_error(void);
+
+/* CSR of the local user rows [row_begin,row_end) (indptr rebased to 0, column ids global) and CSC
+ * of the local item columns [col_begin,col_end) (row ids global).  Host buffers; copied to HBM. */
+int cmfrec_hip_session_set_X(cmfrec_hip_session *s,
+                             const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
+                             const size_t *csc_p, const int_t *csc_i, const real_t *csc_v);
+/* Full factor matrices A[m, k_user+k+k_main], B[n, k_item+k+k_main] (+ biasA[m], biasB[n] when the
+ * model has them; C[p,k_user+k], D[q,k_item+k]); host buffers.  NULL = leave unchanged. */
+int cmfrec_hip_session_set_factors(cmfrec_hip_session *s, const real_t *A, const real_t *B,
+                                   const real_t *biasA, const real_t *biasB,
+                                   const real_t *C, const real_t *D);
+int cmfrec_hip_session_get_factors(cmfrec_hip_session *s, real_t *A, real_t *B,
+                                   real_t *biasA, real_t *biasB, real_t *C, real_t *D);
+/* Dense side information, already centred by column (host does column means like
+ * common.c:4911-4997): U rows [0,m_u), II rows [0,n_i). */
+int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, const real_t *II);
+
+/* One update of the local block, asynchronous on the session stream. which: 'A','B','C','D'.
+ * use_cholesky != 0 forces the Cholesky solver for this call (finalize_chol). */
+int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky);
+/* niter full ALS iterations in the reference's order C, D, B, A (collective.c:8334-8898 /
+ * :9827-10045) on a single-GPU session. */
+int cmfrec_hip_session_iterate(cmfrec_hip_session *s, int niter, int finalize_chol);
+int cmfrec_hip_session_sync(cmfrec_hip_session *s);
+
+/* Device pointers for torch.distributed / RCCL plumbing (factor all-gather between half-steps).
+ * which 'A'/'B': the [rows, ld] matrix incl. the bias column; returns NULL if unknown. */
+void *cmfrec_hip_session_device_ptr(cmfrec_hip_session *s, int which, size_t *rows, size_t *ld);
+void *cmfrec_hip_session_stream(cmfrec_hip_session *s);
+/* To be called after the local block of `which` was refreshed on all ranks (after the all-gather):
+ * refreshes what is derived from the full matrix (bias vectors). */
+int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which);
+
+/* HIP-event time (ms) and launch count of the row-update kernels of `which` ('A' or 'B') since
+ * the last reset; synchronises the stream. */
+int cmfrec_hip_session_kernel_time(cmfrec_hip_session *s, int which, double *ms, long *launches);
+/* Per-kernel figures of the CG row-update launches of `which`: the rows are scheduled in three nnz
+ * bins (0: > 256 nnz, 8 waves/row; 1: 65..256, 4 waves/row; 2: <= 64, 1 wave/row), one persistent
+ * launch each.  ms = summed HIP-event time of that bin's launches since the last reset. */
+int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, double *ms, long *launches,
+                                 long *rows, unsigned long long *nnz);
+void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
+
+/* Build info: sizeof(real_t), and the gfx target the kernels were compiled for. */
+int cmfrec_hip_sizeof_real(void);
+const char *cmfrec_hip_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""GPU parity: whole fits through the drop-in C entry points (fit_collective_*_als, called via
+the CMF / CMF_implicit estimators) against the oracle with injected start values.
+Tolerances: relative Frobenius error <= 1e-6 fp64 / 1e-2 fp32 (CG), 1e-3 fp32 (Chol)."""
+import numpy as np
+import pytest
+
+from conftest import make_coo
+
+pytestmark = pytest.mark.gpu
+
+
+def frob(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def tol(dtype, mode):
+    if dtype is np.float64:
+        return 1e-6
+    return 1e-2 if "cg" in mode else 1e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", ["cg", "chol", "cg+fin"])
+def test_fit_implicit(oracles, dtype, mode):
+    from cmfrec_amd import CMF_implicit
+    O = oracles[dtype]
+    m, n, k = 900, 600, 50
+    row, col, val = make_coo(m, n, 30000, 21, dtype=dtype, heavy_row=(0, 500))
+    rng = np.random.default_rng(1)
+    A0 = (rng.standard_normal((m, k)) * 0.01).astype(dtype)
+    B0 = np.zeros((n, k), dtype)
+    kw = dict(niter=4, use_cg=mode != "chol", finalize_chol=mode == "cg+fin")
+    mdl = CMF_implicit(k=k, lambda_=5., alpha=1.5, use_float=dtype is np.float32, **kw).fit(
+        (row, col, val), shape=(m, n), A0=A0, B0=B0)
+    Ao, Bo = A0.copy(), B0.copy()
+    O.fit_implicit_als(Ao, Bo, row, col, val, lam=5., alpha=1.5, nthreads=4, **kw)
+    assert frob(mdl.A_, Ao) < tol(dtype, mode) and frob(mdl.B_, Bo) < tol(dtype, mode)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode,ub,ib", [("cg", True, True), ("chol", True, True), ("cg+fin", True, True),
+                                        ("cg", False, False), ("cg", True, False), ("chol", False, True)])
+def test_fit_explicit(oracles, dtype, mode, ub, ib):
+    from cmfrec_amd import CMF
+    O = oracles[dtype]
+    m, n, k = 800, 500, 50
+    row, col, val = make_coo(m, n, 30000, 22, counts=False, dtype=dtype, heavy_row=(1, 450))
+    rng = np.random.default_rng(2)
+    A0 = (rng.standard_normal((m, k)) * 0.01).astype(dtype)
+    B0 = np.zeros((n, k), dtype)
+    bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+    kw = dict(niter=3, use_cg=mode != "chol", finalize_chol=mode == "cg+fin", user_bias=ub, item_bias=ib,
+              scale_lam=True)
+    mdl = CMF(k=k, lambda_=0.05, use_float=dtype is np.float32, nthreads=1, **kw).fit(
+        (row, col, val), shape=(m, n), A0=A0, B0=B0, biasA0=bA, biasB0=bB)
+    Ao, Bo = A0.copy(), B0.copy()
+    ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), lam=0.05, nthreads=1, **kw)
+    t = tol(dtype, mode)
+    assert ro["ret"] == 0
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    assert abs(mdl.glob_mean_ - ro["glob_mean"]) <= 1e-6 * abs(ro["glob_mean"])
+    if ub:
+        assert frob(mdl.user_bias_, ro["biasA"]) < t
+    if ib:
+        assert frob(mdl.item_bias_, ro["biasB"]) < t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("useU,useI,ku,ki,km,sls", [(False, True, 0, 0, 0, False), (True, True, 0, 0, 0, False),
+                                                     (True, True, 2, 3, 1, True), (True, False, 1, 0, 0, False)])
+def test_fit_explicit_sideinfo(oracles, dtype, useU, useI, ku, ki, km, sls):
+    from cmfrec_amd import CMF
+    O = oracles[dtype]
+    m, n, k, p, q = 500, 320, 24, 12, 9
+    row, col, val = make_coo(m, n, 12000, 23, counts=False, dtype=dtype)
+    rng = np.random.default_rng(3)
+    U = (rng.standard_normal((m, p)) + 1).astype(dtype); II = (rng.standard_normal((n, q)) - 2).astype(dtype)
+    kA, kB = ku + k + km, ki + k + km
+    A0 = (rng.standard_normal((m, kA)) * 0.01).astype(dtype); B0 = (rng.standard_normal((n, kB)) * 0.01).astype(dtype)
+    kw = dict(niter=3, use_cg=False, k_user=ku, k_item=ki, k_main=km, w_user=0.5, w_item=2.0, scale_lam=True,
+              scale_lam_sideinfo=sls)
+    mdl = CMF(k=k, lambda_=0.05, use_float=dtype is np.float32, nthreads=1, **kw).fit(
+        (row, col, val), shape=(m, n), U=U if useU else None, I=II if useI else None, A0=A0, B0=B0)
+    Ao, Bo = A0.copy(), B0.copy()
+    ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, lam=0.05, U=U if useU else None, II=II if useI else None,
+                            nthreads=1, **kw)
+    t = tol(dtype, "chol")
+    assert ro["ret"] == 0
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    if useU:
+        assert frob(mdl.C_, ro["C"]) < t
+    if useI:
+        assert frob(mdl.D_, ro["D"]) < t

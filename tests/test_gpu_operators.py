@@ -1,0 +1,93 @@
+"""GPU parity: every operator of the HIP path (through the C ABI, host-buffer level) against the
+oracle on the same seeded inputs.  Tolerances: SURVEY.md 8d -- single operator call, fp64 1e-10
+relative (max-abs / max-abs), fp32 1e-4."""
+import numpy as np
+import pytest
+
+from conftest import make_coo, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = {np.float64: 1e-10, np.float32: 2e-4}
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k", [8, 50, 64])
+@pytest.mark.parametrize("mode", ["cg", "chol"])
+def test_optimizeA_implicit(oracles, dtype, k, mode):
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n = 700, 450
+    row, col, val = make_coo(m, n, 20000, 11 + k, dtype=dtype, heavy_row=(3, 400), empty_rows=(5, 17))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(k)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    kw = dict(use_cg=mode == "cg", max_cg_steps=3)
+    Gh = ops.optimizeA_implicit(Ah, B, csr, 4.0, return_BtB=True, **kw)
+    Go = O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, return_BtB=True, **kw)
+    assert rel_err(Gh, Go) < TOL[dtype]
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    if mode == "cg":   # empty rows are left untouched by the CG path (common.c:3354)
+        assert np.array_equal(Ah[5], A0[5]) and np.array_equal(Ah[17], A0[17])
+    else:              # and zeroed by the Cholesky path (common.c:3334)
+        assert not Ah[5].any()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k,pad", [(51, 1), (16, 0), (33, 2)])
+@pytest.mark.parametrize("mode", ["cg", "chol"])
+def test_optimizeA_explicit(oracles, dtype, k, pad, mode):
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n = 600, 380
+    row, col, val = make_coo(m, n, 15000, 5 + k, counts=False, dtype=dtype, heavy_row=(7, 300), empty_rows=(2,))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(k)
+    A0 = (rng.standard_normal((m, k + pad)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k + 1)) * 0.2).astype(dtype)
+    bias = (rng.standard_normal(n) * 0.3).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    kw = dict(k=k, lam_last=0.3, scale_lam=True, use_cg=mode == "cg", max_cg_steps=3)
+    ops.optimizeA_explicit(Ah, B, csr, 0.05, bias_sub=bias, **kw)
+    csr_sub = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))   # what the reference's host sweep does
+    O.optimizeA_explicit(Ao, B, csr_sub, 0.05, nthreads=4, **kw)
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    assert np.array_equal(Ah[2], A0[2])            # empty rows untouched in Case 4 (common.c:3270)
+    if pad:
+        assert np.array_equal(Ah[:, k:], A0[:, k:])   # padding columns never written
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_optimizeA_dense_full(oracles, dtype):
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    rng = np.random.default_rng(2)
+    m_u, p, kc = 500, 24, 20
+    U = rng.standard_normal((m_u, p)).astype(dtype)
+    Ab = (rng.standard_normal((m_u, kc + 2)) * 0.3).astype(dtype)
+    Ch, Co = np.zeros((p, kc), dtype), np.zeros((p, kc), dtype)
+    ops.optimizeA_dense_full(Ch, Ab, U, 0.7, k=kc, do_B=True, scale_lam=True)
+    O.optimizeA_dense_full(Co, Ab, U, 0.7, k=kc, do_B=True, scale_lam=True)
+    assert rel_err(Ch, Co) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ku,ki,km,sls,m_u", [(0, 0, 0, False, None), (2, 3, 1, True, None), (0, 0, 1, False, 350)])
+def test_optimizeA_collective(oracles, dtype, ku, ki, km, sls, m_u):
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n, p, k = 420, 300, 12, 14
+    row, col, val = make_coo(m, n, 9000, 3, counts=False, dtype=dtype, empty_rows=(4, 400))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(9)
+    kA, kB = ku + k + km, ki + k + km
+    Bm = (rng.standard_normal((n, kB + 1)) * 0.3).astype(dtype)
+    Cm = (rng.standard_normal((p, ku + k)) * 0.3).astype(dtype)
+    U = rng.standard_normal((m if m_u is None else m_u, p)).astype(dtype)
+    A0 = rng.standard_normal((m, kA + 1)).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    kw = dict(w_user=0.5, lam_last=0.2, k=k, k_main=km, k_user=ku, k_item=ki, scale_lam=True, scale_lam_sideinfo=sls)
+    ops.optimizeA_collective(Ah, Bm, Cm, csr, U, 0.05, **kw)
+    O.optimizeA_collective_chol(Ao, Bm, Cm, csr, U, 0.05, nthreads=4, **kw)
+    assert rel_err(Ah[:, :kA], Ao[:, :kA]) < TOL[dtype]
