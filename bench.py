@@ -194,11 +194,34 @@ def main():
 
 
 def cpu_baseline(row, col, val, m, n, A0):
-    """Times the CPU path beside the GPU number: the real reference (oracle/_ref, kind 'reference')
-    if it travelled with the repo, else our C restatement (kind 'port').  Sample: full B+A
-    half-steps of the same workload, all host cores."""
-    from oracle.bindings import Oracle, Reference, ref_available
+    """Times the CPU path beside the GPU number in a child process (a BLAS thread-pool failure must
+    not take the GPU result down): the real reference (oracle/_ref, kind 'reference') if it
+    travelled with the repo, else our C restatement (kind 'port').  Sample: full B+A half-steps of
+    the same workload.  The SciPy OpenBLAS the reference is linked against supports at most 128
+    calling threads, so nthreads = min(host cpus, 128), falling back to 64."""
+    import subprocess
+    import tempfile
     cores = os.cpu_count() or 1
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        path = os.path.join(td, "w.npz")
+        np.savez(path, row=row, col=col, val=val, A0=A0, m=m, n=n)
+        for nthreads in (min(cores, 128), min(cores, 64)):
+            env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS=str(nthreads))
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(nthreads)],
+                                   env=env, capture_output=True, text=True, timeout=600)
+            except subprocess.TimeoutExpired:
+                continue
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode == 0 and lines:
+                return json.loads(lines[-1])
+    return {"value": None, "unit": "rows/s", "cores": 0, "kind": "failed", "sample": "CPU baseline child failed"}
+
+
+def cpu_worker(path, nthreads):
+    from oracle.bindings import Oracle, Reference, ref_available
+    d = np.load(path)
+    row, col, val, A0, m, n = d["row"], d["col"], d["val"], d["A0"], int(d["m"]), int(d["n"])
     O = Oracle(np.float64)
     csr, csc = O.coo_to_csr_and_csc(row, col, val, m, n)
     if ref_available(np.float64):
@@ -209,16 +232,20 @@ def cpu_baseline(row, col, val, m, n, A0):
     iters, t_tot = 0, 0.0
     while iters < 3 and t_tot < 20.0:
         t0 = time.perf_counter()
-        eng.optimizeA_implicit(B, A, csc, LAM, nthreads=cores, use_cg=True, max_cg_steps=MAX_CG_STEPS)
-        eng.optimizeA_implicit(A, B, csr, LAM, nthreads=cores, use_cg=True, max_cg_steps=MAX_CG_STEPS)
+        eng.optimizeA_implicit(B, A, csc, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
+        eng.optimizeA_implicit(A, B, csr, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
         t_tot += time.perf_counter() - t0
         iters += 1
     s_per_iter = t_tot / iters
-    return {"value": round((m + n) / s_per_iter, 1), "unit": "rows/s", "cores": cores, "kind": kind,
-            "s_per_iteration": round(s_per_iter, 3),
-            "sample": "%d full ALS iterations (optimizeA_implicit B-step + A-step) of the same workload, "
-                      "OpenMP nthreads=%d, OpenBLAS from SciPy" % (iters, cores)}
+    print(json.dumps({"value": round((m + n) / s_per_iter, 1), "unit": "rows/s", "cores": nthreads, "kind": kind,
+                      "s_per_iteration": round(s_per_iter, 3),
+                      "sample": "%d full ALS iterations (optimizeA_implicit B-step + A-step, the reference's OpenMP row "
+                                "loop) of the same workload, nthreads=%d of %d host cpus, BLAS = SciPy OpenBLAS"
+                                % (iters, nthreads, os.cpu_count() or 1)}))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2], int(sys.argv[3]))
+    else:
+        main()
