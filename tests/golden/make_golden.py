@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the REAL reference (oracle/_ref, david-cortes/cmfrec compiled
+from /root/reference by oracle/Makefile).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Fixtures are data: seeded inputs + the reference's outputs.  No reference
+source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import make_coo          # noqa: E402
+from oracle.bindings import Reference  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-40s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def main():
+    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        R = Reference(dt)
+        # ---- G6: COO -> CSR/CSC ordering, global mean, bias initialisation ----
+        m, n = 120, 90
+        row, col, val = make_coo(m, n, 1500, 101, counts=False, dtype=dt, heavy_row=(3, 60), empty_rows=(7,))
+        csr, csc = R.coo_to_csr_and_csc(row, col, val, m, n)
+        gm, Xc = R.calc_mean_and_center(row, col, val, m, n, nthreads=1)
+        csr_c, csc_c = R.coo_to_csr_and_csc(row, col, Xc, m, n)
+        bA, bB = R.initialize_biases_twosided(m, n, csr_c, csc_c, 0.05, 0.05, True)
+        save("g6_prep_" + tag, row=row, col=col, val=val, m=m, n=n, csr_p=csr[0], csr_i=csr[1], csr_v=csr[2],
+             csc_p=csc[0], csc_i=csc[1], csc_v=csc[2], glob_mean=gm, val_centered=Xc, biasA=bA, biasB=bB,
+             lam_bias=0.05)
+
+        # ---- G1: optimizeA_implicit CG(3) / PCG(3) / Cholesky ----
+        m, n = 300, 200
+        row, col, val = make_coo(m, n, 6000, 102, dtype=dt, heavy_row=(11, 150), empty_rows=(5, 250))
+        csr, _ = R.coo_to_csr_and_csc(row, col, val, m, n)
+        out = dict(row=row, col=col, val=val, m=m, n=n, lam=4.0)
+        for k in (8, 50, 64):
+            rng = np.random.default_rng(k)
+            A0 = (rng.standard_normal((m, k)) * 0.05).astype(dt); B = (rng.standard_normal((n, k)) * 0.2).astype(dt)
+            out["A0_k%d" % k] = A0; out["B_k%d" % k] = B
+            for mode in ("cg", "pcg", "chol"):
+                A = A0.copy()
+                BtB = R.optimizeA_implicit(A, B, csr, 4.0, nthreads=2, use_cg=mode != "chol",
+                                           precondition_cg=mode == "pcg", max_cg_steps=3, return_BtB=True)
+                out["A_%s_k%d" % (mode, k)] = A
+                if mode == "cg":
+                    out["BtB_k%d" % k] = np.triu(BtB)
+        save("g1_implicit_" + tag, **out)
+
+        # ---- G2: optimizeA Case 4 (explicit sparse), scale_lam, lam_last != lam, lda = k + pad ----
+        row, col, val = make_coo(m, n, 6000, 103, counts=False, dtype=dt, heavy_row=(2, 120), empty_rows=(9,))
+        csr, _ = R.coo_to_csr_and_csc(row, col, val, m, n)
+        out = dict(row=row, col=col, val=val, m=m, n=n, lam=0.05, lam_last=0.3)
+        for k in (51, 17):
+            rng = np.random.default_rng(100 + k)
+            A0 = (rng.standard_normal((m, k + 1)) * 0.05).astype(dt); B = (rng.standard_normal((n, k + 2)) * 0.2).astype(dt)
+            out["A0_k%d" % k] = A0; out["B_k%d" % k] = B
+            for mode in ("cg", "pcg", "chol"):
+                A = A0.copy()
+                R.optimizeA(A, B, csr=csr, lam=0.05, lam_last=0.3, k=k, scale_lam=True, nthreads=2,
+                            use_cg=mode != "chol", precondition_cg=mode == "pcg", max_cg_steps=3)
+                out["A_%s_k%d" % (mode, k)] = A
+        save("g2_explicit_" + tag, **out)
+
+        # ---- G3: optimizeA_collective general branch, dense U, Cholesky ----
+        out = dict(row=row, col=col, val=val, m=m, n=n, lam=0.05, lam_last=0.2, w_user=0.5)
+        rng = np.random.default_rng(7)
+        for ci, (p, k, ku, ki, km, sls) in enumerate(((16, 12, 0, 0, 0, False), (32, 10, 2, 3, 1, True))):
+            kA, kB = ku + k + km, ki + k + km
+            Bm = (rng.standard_normal((n, kB + 1)) * 0.3).astype(dt); Cm = (rng.standard_normal((p, ku + k)) * 0.3).astype(dt)
+            U = rng.standard_normal((m, p)).astype(dt)
+            A = rng.standard_normal((m, kA + 1)).astype(dt)
+            out.update({"B_%d" % ci: Bm, "C_%d" % ci: Cm, "U_%d" % ci: U, "A0_%d" % ci: A.copy(),
+                        "cfg_%d" % ci: np.array([p, k, ku, ki, km, int(sls)])})
+            R.optimizeA_collective(A, Bm, Cm, csr, U, 0.05, w_user=0.5, lam_last=0.2, k=k, k_main=km, k_user=ku,
+                                   k_item=ki, scale_lam=True, scale_lam_sideinfo=sls, nthreads=2)
+            out["A_%d" % ci] = A
+        save("g3_collective_" + tag, **out)
+
+        # ---- G4: optimizeA Case 1, do_B (the C / D update) ----
+        rng = np.random.default_rng(8)
+        m_u, p, kc = 250, 16, 20
+        U = rng.standard_normal((m_u, p)).astype(dt); Ab = (rng.standard_normal((m_u, kc + 1)) * 0.3).astype(dt)
+        Cm = np.zeros((p, kc), dt)
+        R.optimizeA(Cm, Ab, Xfull=U, lam=0.7, k=kc, do_B=True, scale_lam=True, full_dense=True, use_cg=False)
+        save("g4_dense_full_" + tag, U=U, A_bias=Ab, C=Cm, lam=0.7, kc=kc)
+
+        # ---- G5: whole fits with injected start values ----
+        m, n, k = 400, 250, 16
+        rng = np.random.default_rng(9)
+        row, col, val = make_coo(m, n, 8000, 104, dtype=dt, heavy_row=(0, 200))
+        out = dict(row=row, col=col, val=val, m=m, n=n, k=k, lam=5.0, alpha=1.5, niter=5)
+        A0 = (rng.standard_normal((m, k)) * 0.01).astype(dt)
+        out["A0"] = A0
+        for mode in ("cg", "chol", "cgfin"):
+            A, B = A0.copy(), np.zeros((n, k), dt)
+            R.fit_collective_implicit_als(A, B, row, col, val, k, lam=5.0, alpha=1.5, niter=5, nthreads=2,
+                                          use_cg=mode != "chol", finalize_chol=mode == "cgfin")
+            out["A_" + mode] = A; out["B_" + mode] = B
+        save("g5_fit_implicit_" + tag, **out)
+
+        row, col, val = make_coo(m, n, 8000, 105, counts=False, dtype=dt, heavy_row=(1, 180))
+        out = dict(row=row, col=col, val=val, m=m, n=n, k=k, lam=0.05, niter=4)
+        A0 = (rng.standard_normal((m, k)) * 0.01).astype(dt)
+        bA0 = (rng.standard_normal(m) * 0.1).astype(dt); bB0 = (rng.standard_normal(n) * 0.1).astype(dt)
+        out.update(A0=A0, biasA0=bA0, biasB0=bB0)
+        for mode in ("cg", "chol", "cgfin"):
+            A, B = A0.copy(), np.zeros((n, k), dt)
+            r = R.fit_collective_explicit_als(A, B, row, col, val, k, biasA=bA0.copy(), biasB=bB0.copy(), lam=0.05,
+                                              scale_lam=True, niter=4, nthreads=2, use_cg=mode != "chol",
+                                              finalize_chol=mode == "cgfin")
+            out.update({"A_" + mode: A, "B_" + mode: B, "biasA_" + mode: r["biasA"], "biasB_" + mode: r["biasB"],
+                        "glob_mean": r["glob_mean"]})
+        save("g5_fit_explicit_" + tag, **out)
+
+        p, q = 12, 9
+        U = (rng.standard_normal((m, p)) + 1).astype(dt); II = (rng.standard_normal((n, q)) - 2).astype(dt)
+        ku, ki, km = 2, 3, 1
+        A0 = (rng.standard_normal((m, ku + k + km)) * 0.01).astype(dt); B0 = (rng.standard_normal((n, ki + k + km)) * 0.01).astype(dt)
+        A, B = A0.copy(), B0.copy()
+        r = R.fit_collective_explicit_als(A, B, row, col, val, k, lam=0.05, scale_lam=True, scale_lam_sideinfo=True,
+                                          niter=3, nthreads=2, use_cg=False, U=U, II=II, k_user=ku, k_item=ki, k_main=km,
+                                          w_user=0.5, w_item=2.0)
+        save("g5_fit_sideinfo_" + tag, row=row, col=col, val=val, m=m, n=n, k=k, U=U, II=II, A0=A0, B0=B0, A=A, B=B,
+             C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
+             U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"], cfg=np.array([ku, ki, km]))
+
+        # ---- RNG streams of the reference (pins the start-value generator) ----
+        out = {}
+        for seed in (1, 123):
+            for size in (1000, 2 ** 18 + 1000):
+                for normal in (True, False):
+                    a, _ = R.random_parallel(size, 0, seed, normal)
+                    out["seed%d_size%d_%s" % (seed, size, "normal" if normal else "unif")] = a[:64]
+        save("g7_rng_" + tag, **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""CPU, world_size 2, gloo: the row-block sharding + all-gather orchestration of
+cmfrec_amd.distributed.ShardedAls.  The per-shard half-step is supplied by an oracle-backed engine
+(test infrastructure) so that the N>1 control path -- block ranges, even / uneven all-gather,
+replica consistency -- is exercised without a GPU and must reproduce the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+class OracleEngine:
+    """Engine protocol of ShardedAls on CPU: full replicas as torch tensors, the local block
+    recomputed with the oracle's optimizeA_implicit on the CSR/CSC shard."""
+
+    def __init__(self, O, A, B, csr, csc, row_ranges, col_ranges, rank, lam):
+        self.O, self.rank, self.lam = O, rank, lam
+        self.A, self.B = A, B                       # numpy, shared memory with the torch views
+        self.tA, self.tB = torch.from_numpy(A), torch.from_numpy(B)
+        self._ranges = {"A": row_ranges, "B": col_ranges}
+        r0, r1 = row_ranges[rank]; c0, c1 = col_ranges[rank]
+        self.csr = self._slice(csr, r0, r1)
+        self.csc = self._slice(csc, c0, c1)
+
+    @staticmethod
+    def _slice(csr, b, e):
+        p, i, v = csr
+        lo, hi = int(p[b]), int(p[e])
+        return ((p[b:e + 1] - p[b]).astype(np.uint64), i[lo:hi].copy(), v[lo:hi].copy())
+
+    def full(self, which):
+        return self.tA if which == "A" else self.tB
+
+    def ranges(self, which):
+        return self._ranges[which]
+
+    def update(self, which, use_cholesky=False):
+        b, e = self._ranges[which][self.rank]
+        if which == "A":
+            blk = np.ascontiguousarray(self.A[b:e])
+            self.O.optimizeA_implicit(blk, self.B, self.csr, self.lam, use_cg=not use_cholesky)
+            self.A[b:e] = blk
+        else:
+            blk = np.ascontiguousarray(self.B[b:e])
+            self.O.optimizeA_implicit(blk, self.A, self.csc, self.lam, use_cg=not use_cholesky)
+            self.B[b:e] = blk
+
+    def after_gather(self, which):
+        pass
+
+    def pre_collective(self):
+        pass
+
+    def post_collective(self):
+        pass
+
+
+def _worker(rank, world, port, balanced, out_dir):
+    from conftest import make_coo
+    from oracle.bindings import Oracle
+    from cmfrec_amd.distributed import ShardedAls, balanced_boundaries, equal_boundaries
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = Oracle(np.float64)
+    m, n, k = 301, 200, 8
+    row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
+    csr, csc = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((m, k)) * 0.01
+    B = np.zeros((n, k))
+    if balanced:
+        rb = balanced_boundaries(np.diff(csr[0].astype(np.int64)), world)
+        cb = balanced_boundaries(np.diff(csc[0].astype(np.int64)), world)
+    else:
+        rb, cb = equal_boundaries(m, world), equal_boundaries(n, world)
+    rr = [(rb[i], rb[i + 1]) for i in range(world)]
+    cr = [(cb[i], cb[i + 1]) for i in range(world)]
+    eng = OracleEngine(O, A, B, csr, csc, rr, cr, rank, 4.0)
+    als = ShardedAls(eng, rank, world)
+    for _ in range(3):
+        als.iteration()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("balanced", [False, True])
+def test_two_rank_als_matches_single_process(tmp_path, balanced, oracles):
+    from conftest import make_coo
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), balanced, str(tmp_path)), nprocs=world, join=True)
+    O = oracles[np.float64]
+    m, n, k = 301, 200, 8
+    row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
+    A = np.random.default_rng(3).standard_normal((m, k)) * 0.01
+    B = np.zeros((n, k))
+    O.fit_implicit_als(A, B, row, col, val, lam=4.0, niter=3)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    # replicas agree bit-for-bit across ranks and equal the single-process fit exactly
+    assert np.array_equal(r0["A"], r1["A"]) and np.array_equal(r0["B"], r1["B"])
+    assert np.array_equal(r0["A"], A) and np.array_equal(r0["B"], B)
+
+
+def test_boundaries():
+    from cmfrec_amd.distributed import balanced_boundaries, equal_boundaries
+    assert equal_boundaries(10, 4) == [0, 3, 6, 9, 10]
+    assert equal_boundaries(160112, 8)[-2:] == [140098, 160112]
+    cnt = np.array([100, 1, 1, 1, 1, 1, 1, 94])
+    b = balanced_boundaries(cnt, 2)
+    assert b[0] == 0 and b[-1] == 8 and b == sorted(b)
+    s0, s1 = cnt[b[0]:b[1]].sum(), cnt[b[1]:b[2]].sum()
+    assert abs(int(s0) - int(s1)) <= 100
+    assert balanced_boundaries(np.zeros(5, int), 3)[-1] == 5

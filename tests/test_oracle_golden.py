@@ -1,0 +1,90 @@
+"""CPU: the oracle (oracle/cmf_oracle.c) against the golden vectors captured from the real
+reference (tests/golden/make_golden.py).  This is what pins the oracle on machines where
+/root/reference does not exist.  Tolerances: per-call 1e-10 fp64 / 2e-4 fp32;
+whole fits 1e-6 fp64 / 1e-2 fp32 relative Frobenius."""
+import numpy as np
+import pytest
+
+import golden_cases as gc
+
+DT = [np.float64, np.float32]
+TOL = {np.float64: 1e-10, np.float32: 2e-4}
+TOL_FIT = {np.float64: 1e-6, np.float32: 1e-2}
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_prep(oracles, dtype):
+    O = oracles[dtype]
+    g = gc.load("g6_prep", dtype)
+    m, n = int(g["m"]), int(g["n"])
+    csr, csc = O.coo_to_csr_and_csc(g["row"], g["col"], g["val"], m, n)
+    for got, name in zip(csr + csc, ("csr_p", "csr_i", "csr_v", "csc_p", "csc_i", "csc_v")):
+        assert np.array_equal(got, g[name]), name          # stable ordering is exact
+    v = g["val"].copy()
+    gm = O.calc_mean_and_center(v, nthreads=1)
+    assert gm == g["glob_mean"] and np.array_equal(v, g["val_centered"])
+    csr_c, csc_c = O.coo_to_csr_and_csc(g["row"], g["col"], v, m, n)
+    bA, bB = O.initialize_biases_twosided(m, n, csr_c, csc_c, float(g["lam_bias"]), float(g["lam_bias"]), True)
+    assert np.array_equal(bA, g["biasA"]) and np.array_equal(bB, g["biasB"])   # bit-exact
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_operators(oracles, dtype):
+    O = oracles[dtype]
+    worst = 0.0
+    for name, got, exp in gc.implicit_cases(gc.load("g1_implicit", dtype), O, O.optimizeA_implicit):
+        e = gc.maxrel(got, exp); worst = max(worst, e)
+        assert e < TOL[dtype], (name, e)
+    for name, got, exp in gc.explicit_cases(gc.load("g2_explicit", dtype), O, O.optimizeA_explicit):
+        e = gc.maxrel(got, exp)
+        assert e < TOL[dtype], (name, e)
+    for name, got, exp in gc.collective_cases(gc.load("g3_collective", dtype), O, O.optimizeA_collective_chol):
+        e = gc.maxrel(got, exp)
+        assert e < TOL[dtype], (name, e)
+    g = gc.load("g4_dense_full", dtype)
+    C = np.zeros_like(g["C"])
+    O.optimizeA_dense_full(C, g["A_bias"], g["U"], float(g["lam"]), k=int(g["kc"]), do_B=True, scale_lam=True)
+    assert gc.maxrel(C, g["C"]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_gram_matches_reference_syrk(oracles, dtype):
+    O = oracles[dtype]
+    g = gc.load("g1_implicit", dtype)
+    csr, _ = gc.csr_from(g, O)
+    for k in (8, 50, 64):
+        A = g["A0_k%d" % k].copy()
+        BtB = O.optimizeA_implicit(A, g["B_k%d" % k], csr, float(g["lam"]), return_BtB=True)
+        assert gc.maxrel(np.triu(BtB), g["BtB_k%d" % k]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_fits(oracles, dtype):
+    O = oracles[dtype]
+    t = TOL_FIT[dtype]
+    g = gc.load("g5_fit_implicit", dtype)
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    for mode in ("cg", "chol", "cgfin"):
+        A, B = g["A0"].copy(), np.zeros((n, k), dtype)
+        O.fit_implicit_als(A, B, g["row"], g["col"], g["val"], lam=float(g["lam"]), alpha=float(g["alpha"]),
+                           niter=int(g["niter"]), use_cg=mode != "chol", finalize_chol=mode == "cgfin")
+        assert gc.frob(A, g["A_" + mode]) < t and gc.frob(B, g["B_" + mode]) < t, mode
+    g = gc.load("g5_fit_explicit", dtype)
+    for mode in ("cg", "chol", "cgfin"):
+        A, B = g["A0"].copy(), np.zeros((n, k), dtype)
+        r = O.fit_explicit_als(A, B, g["row"], g["col"], g["val"], k, biasA=g["biasA0"].copy(), biasB=g["biasB0"].copy(),
+                               lam=float(g["lam"]), scale_lam=True, niter=int(g["niter"]), use_cg=mode != "chol",
+                               finalize_chol=mode == "cgfin")
+        assert r["ret"] == 0 and r["glob_mean"] == g["glob_mean"]
+        assert gc.frob(A, g["A_" + mode]) < t and gc.frob(B, g["B_" + mode]) < t, mode
+        assert gc.frob(r["biasA"], g["biasA_" + mode]) < t and gc.frob(r["biasB"], g["biasB_" + mode]) < t
+    g = gc.load("g5_fit_sideinfo", dtype)
+    ku, ki, km = [int(x) for x in g["cfg"]]
+    A, B = g["A0"].copy(), g["B0"].copy()
+    r = O.fit_explicit_als(A, B, g["row"], g["col"], g["val"], k, lam=0.05, scale_lam=True, scale_lam_sideinfo=True,
+                           niter=3, use_cg=False, U=g["U"], II=g["II"], k_user=ku, k_item=ki, k_main=km, w_user=0.5,
+                           w_item=2.0)
+    assert r["ret"] == 0
+    for got, key in ((A, "A"), (B, "B"), (r["C"], "C"), (r["D"], "D"), (r["biasA"], "biasA"), (r["biasB"], "biasB")):
+        assert gc.frob(got, g[key]) < t, key
+    assert gc.maxrel(r["U_colmeans"], g["U_colmeans"]) < 1e-6

@@ -1,0 +1,75 @@
+"""CPU: the oracle against the REAL reference run live (oracle/_ref, built from /root/reference by
+oracle/Makefile) on fresh seeded problems, both precisions, 1 vs many threads.  Skipped where the
+reference library is not available (it is built in the build container and shipped to the GPU box
+as a binary; /root/reference itself never travels)."""
+import numpy as np
+import pytest
+
+from conftest import make_coo, rel_err
+from oracle.bindings import Reference, ref_available
+
+pytestmark = pytest.mark.skipif(not ref_available(np.float64), reason="oracle/_ref not built")
+TOL = {np.float64: 1e-11, np.float32: 2e-4}
+
+
+@pytest.fixture(scope="module")
+def refs():
+    return {np.float64: Reference(np.float64), np.float32: Reference(np.float32)}
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_operators_live(oracles, refs, dtype):
+    O, R = oracles[dtype], refs[dtype]
+    m, n, k = 260, 170, 50
+    row, col, val = make_coo(m, n, 5000, 31, dtype=dtype, heavy_row=(4, 120), empty_rows=(6,))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    csr_r, _ = R.coo_to_csr_and_csc(row, col, val, m, n)
+    for a, b in zip(csr, csr_r):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(5)
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B = (rng.standard_normal((n, k)) * 0.3).astype(dtype)
+    for mode in ("cg", "pcg", "chol"):
+        kw = dict(use_cg=mode != "chol", precondition_cg=mode == "pcg", max_cg_steps=3)
+        Ao, Ar = A0.copy(), A0.copy()
+        O.optimizeA_implicit(Ao, B, csr, 5.0, nthreads=3, **kw)
+        R.optimizeA_implicit(Ar, B, csr, 5.0, nthreads=2, **kw)
+        assert rel_err(Ao, Ar) < TOL[dtype], mode
+        Ao, Ar = A0.copy(), A0.copy()
+        kw.update(k=k - 1, lam_last=0.3, scale_lam=True)
+        O.optimizeA_explicit(Ao, B, csr, 0.05, nthreads=3, **kw)
+        R.optimizeA(Ar, B, csr=csr, lam=0.05, nthreads=2, **kw)
+        assert rel_err(Ao, Ar) < TOL[dtype], mode
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_determinism_across_threads(refs, dtype):
+    """The reference is bit-reproducible across nthreads for a fixed start."""
+    R = refs[dtype]
+    m, n, k = 200, 150, 16
+    row, col, val = make_coo(m, n, 4000, 33, dtype=dtype)
+    rng = np.random.default_rng(6)
+    A0 = (rng.standard_normal((m, k)) * 0.01).astype(dtype)
+    outs = []
+    for nt in (1, 4):
+        A, B = A0.copy(), np.zeros((n, k), dtype)
+        R.fit_collective_implicit_als(A, B, row, col, val, k, lam=3.0, niter=3, nthreads=nt)
+        outs.append((A, B))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fits_live(oracles, refs, dtype):
+    O, R = oracles[dtype], refs[dtype]
+    tol = 1e-10 if dtype is np.float64 else 2e-3
+    m, n, k = 300, 200, 12
+    rng = np.random.default_rng(7)
+    row, col, val = make_coo(m, n, 6000, 34, counts=False, dtype=dtype)
+    for mode, ub, ib in (("cg", True, True), ("chol", True, False), ("cg", False, True)):
+        A0 = (rng.standard_normal((m, k)) * 0.01).astype(dtype)
+        bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+        kw = dict(lam=0.05, scale_lam=True, niter=3, use_cg=mode != "chol", finalize_chol=False, user_bias=ub, item_bias=ib)
+        Ao, Bo, Ar, Br = A0.copy(), np.zeros((n, k), dtype), A0.copy(), np.zeros((n, k), dtype)
+        ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), nthreads=2, **kw)
+        assert ro["ret"] == 0 and rr["ret"] == 0
+        assert rel_err(Ao, Ar) < tol and rel_err(Bo, Br) < tol, (mode, ub, ib)
