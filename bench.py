@@ -148,11 +148,11 @@ def main():
     rows_per_s = (m + n) / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (per nnz-bin launch of the CG row kernel) ----
-    names = {0: "cg_rows_kernel<W=8> (rows > 256 nnz)", 1: "cg_rows_kernel<W=4> (65..256 nnz)",
-             2: "cg_rows_kernel<W=1> (<= 64 nnz)"}
+    names = {0: "cg_rows_kernel<W=8> (257..2048 nnz)", 1: "cg_rows_kernel<W=4> (65..256 nnz)",
+             2: "cg_rows_kernel<W=1> (<= 64 nnz)", 3: "vh_pass+vh_update x4 (rows > 2048 nnz, split rows)"}
     kernels = []
     for which in ("B", "A"):
-        for b in range(3):
+        for b in range(4):
             ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
             if cnt:
                 kernels.append(dict(step=which, kernel=names[b], ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,

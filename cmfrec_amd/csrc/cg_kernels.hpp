@@ -288,6 +288,130 @@ cg_rows_kernel(const CgParams<T> P)
 }
 
 // ------------------------------------------------------------------------------------------
+// Very heavy rows (nnz > VH_MIN): one workgroup cannot own such a row without becoming the serial
+// tail of the half-step (a single popular item can hold > 1e5 non-zeros), so every CG pass of these
+// rows is split over many workgroups: vh_pass_kernel computes the partial  sum_j w_j B_j  of one
+// 512-nnz chunk (8 waves x one 64-nnz tile, same register-tile arithmetic as cg_rows_kernel) and
+// vh_update_kernel (one wavefront per row) adds the partials in chunk order (deterministic, no
+// floating-point atomics), the Gramian term and does the CG vector update.  One launch pair per
+// pass; kernel boundaries are the grid-wide synchronisation.
+constexpr int VH_CHUNK_TILES = 8;
+
+template <typename T>
+struct VhState {
+    T *r, *p;               // [nvh][64] distributed CG vectors (a lives in the factor matrix itself)
+    T *r_old;               // [nvh]
+    int *done;              // [nvh]
+    T *part;                // [nchunks][64]
+    const int *chunk_row;   // [nchunks] index of the very-heavy row (position in `order`)
+    const int *chunk_first; // [nchunks] first tile of the chunk inside its row
+    const int *chunk_off;   // [nvh+1] chunk range of every row
+    int nvh, nchunks;
+};
+
+template <typename T, int S, bool IMPLICIT, int MODE>
+__global__ void __launch_bounds__(64 * VH_CHUNK_TILES, 2)
+vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
+{
+    __shared__ T red[VH_CHUNK_TILES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    const int vi = V.chunk_row[c];
+    if (MODE == 1 && V.done[vi]) return;
+    const int row = P.order[vi];
+    const size_t st = P.indptr[row];
+    const int nnz = (int)(P.indptr[row + 1] - st);
+    const int tl = V.chunk_first[c] + wave;
+    const int k = P.k;
+    T vdist;
+    if (MODE == 0) vdist = (lane < k) ? P.A[(size_t)row * P.lda + lane] : T(0);
+    else           vdist = V.p[(size_t)vi * 64 + lane];
+    T out[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) out[s] = T(0);
+    if (tl * TILE < nnz) {
+        const int cnt = min(TILE, nnz - tl * TILE);
+        const bool valid = lane < cnt;
+        const size_t pos = st + (size_t)tl * TILE + lane;
+        int my_idx = valid ? P.indices[pos] : 0;
+        T x = valid ? P.values[pos] : T(0);
+        if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
+        RegTile<T, S> tile;
+        load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
+        T vrep[S];
+        replicate<T, S>(vdist, vrep, lane);
+        tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+    }
+    T tot = treduce8<T, 32, 16, 8>(out, lane);
+    red[wave][lane] = tot;
+    __syncthreads();
+    if (wave == 0) {
+        T s = T(0);
+#pragma unroll
+        for (int w = 0; w < VH_CHUNK_TILES; w++) s += red[w][lane];
+        V.part[(size_t)c * 64 + lane] = s;
+    }
+}
+
+template <typename T, bool IMPLICIT, int MODE>
+__global__ void __launch_bounds__(64)
+vh_update_kernel(const CgParams<T> P, const VhState<T> V)
+{
+    const int lane = threadIdx.x;
+    const int vi = blockIdx.x;
+    if (MODE == 1 && V.done[vi]) return;
+    const int k = P.k;
+    const int row = P.order[vi];
+    const int nnz = (int)(P.indptr[row + 1] - P.indptr[row]);
+    T lam = P.lam, lam_last = P.lam_last;
+    if (!IMPLICIT && P.scale_lam) {
+        lam *= (T)nnz;
+        if (!P.scale_bias_const) lam_last *= (T)nnz;
+    }
+    T *arow = P.A + (size_t)row * P.lda;
+    T a_d = (lane < k) ? arow[lane] : T(0);
+    T v = (MODE == 0) ? a_d : V.p[(size_t)vi * 64 + lane];
+    T tot = T(0);
+    for (int c = V.chunk_off[vi]; c < V.chunk_off[vi + 1]; c++) tot += V.part[(size_t)c * 64 + lane];
+    if (IMPLICIT) {                                    // + (+-) BtB v   (common.c:1932 / :1958)
+        T g = T(0);
+        for (int j = 0; j < k; j++) {
+            T vj = __shfl(v, j);
+            if (lane < k) g += vj * P.BtB[(size_t)j * k + lane];
+        }
+        tot += (MODE == 0) ? -g : g;
+    }
+    if (MODE == 0) {
+        T r_d = tot - lam * a_d;
+        if (!IMPLICIT && lam != lam_last && lane == k - 1) r_d -= (lam_last - lam) * a_d;
+        if (lane >= k) r_d = T(0);
+        T r_old = wave_sum(r_d * r_d);
+        V.r[(size_t)vi * 64 + lane] = r_d;
+        V.p[(size_t)vi * 64 + lane] = r_d;
+        if (lane == 0) { V.r_old[vi] = r_old; V.done[vi] = (r_old <= (T)1e-12) ? 1 : 0; }
+    } else {
+        T p_d = v;
+        T r_d = V.r[(size_t)vi * 64 + lane];
+        T r_old = V.r_old[vi];
+        T Ap_d = tot + lam * p_d;
+        if (!IMPLICIT && lam != lam_last && lane == k - 1) Ap_d += (lam_last - lam) * p_d;
+        if (lane >= k) Ap_d = T(0);
+        T alpha = r_old / wave_sum(Ap_d * p_d);
+        a_d += alpha * p_d;
+        r_d -= alpha * Ap_d;
+        T r_new = wave_sum(r_d * r_d);
+        if (lane < k) arow[lane] = a_d;
+        if (r_new <= (T)1e-8) {
+            if (lane == 0) V.done[vi] = 1;
+        } else {
+            V.p[(size_t)vi * 64 + lane] = p_d * (r_new / r_old) + r_d;
+            V.r[(size_t)vi * 64 + lane] = r_d;
+            if (lane == 0) V.r_old[vi] = r_new;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Generic fallback (any k): one wavefront per row, lane f owns factors f, f+64, ...; the dot
 // product of every gathered row is a wave reduction.  Same arithmetic as above, used for k
 // beyond the register-tile instantiations and as an on-device cross-check of the tiled kernel.

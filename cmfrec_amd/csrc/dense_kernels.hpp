@@ -52,21 +52,28 @@ gram_partial_kernel(const T *__restrict__ B, size_t ldb, int n, int k, int rows_
 #pragma unroll
     for (int e = 0; e < MAXE; e++) {
         int ent = tid + 256 * e;
-        if (ent < nent) partial[(size_t)blockIdx.x * nent + ent] = acc[e];
+        if (ent < nent) partial[(size_t)ent * gridDim.x + blockIdx.x] = acc[e];     // [entry][block]
     }
 }
 
+// one wavefront per entry: lane l adds blocks l, l+64, ... in order, then a fixed butterfly --
+// the summation order depends only on (n, k), never on scheduling.
 template <typename T>
-__global__ void gram_reduce_kernel(const T *__restrict__ partial, int nblocks, int nent,
-                                   T *__restrict__ out, T scale, T add_diag, int k)
+__global__ void __launch_bounds__(256)
+gram_reduce_kernel(const T *__restrict__ partial, int nblocks, int nent,
+                   T *__restrict__ out, T scale, T add_diag, int k)
 {
-    int ent = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int ent = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ent >= nent) return;
+    const T *src = partial + (size_t)ent * nblocks;
     T s = T(0);
-    for (int b = 0; b < nblocks; b++) s += partial[(size_t)b * nent + ent];
+    for (int b = lane; b < nblocks; b += 64) s += src[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     s *= scale;
     if (ent / k == ent % k) s += add_diag;
-    out[ent] = s;
+    if (lane == 0) out[ent] = s;
 }
 
 // generic-k fallback for the Gramian (k > 64): one thread per entry, rows streamed from L2.

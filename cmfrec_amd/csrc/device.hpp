@@ -72,17 +72,22 @@ struct DevBuf {
 // handles with `omp schedule(dynamic)` (common.c:3259,3349).
 constexpr int LIGHT_MAX = TILE;          // <= 64 nnz : 1 wave / row, 4 rows / workgroup
 constexpr int MEDIUM_MAX = 4 * TILE;     // <= 256 nnz: 4 waves / row
-                                         // larger     : 8 waves / row (register-resident to 512 nnz)
+constexpr int HEAVY_MAX = 2048;          // <= 2048   : 8 waves / row (register-resident to 512 nnz)
+                                         // larger     : "very heavy", every CG pass split over many workgroups
 struct SparseShard {
     int nrows = 0;
     size_t nnz = 0;
     DevBuf<size_t> p;
     DevBuf<int> i;
     DevBuf<real_t> v;
-    DevBuf<int> order;       // [heavy | medium | light | empty], each sorted by nnz descending
-    int n_heavy = 0, n_medium = 0, n_light = 0, n_empty = 0;
-    size_t nnz_heavy = 0, nnz_medium = 0, nnz_light = 0;
+    DevBuf<int> order;       // [very heavy | heavy | medium | light | empty], each sorted by nnz descending
+    int n_vheavy = 0, n_heavy = 0, n_medium = 0, n_light = 0, n_empty = 0;
+    size_t nnz_vheavy = 0, nnz_heavy = 0, nnz_medium = 0, nnz_light = 0;
     int max_nnz = 0;
+    // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
+    int n_chunks = 0;
+    DevBuf<int> vh_chunk_row, vh_chunk_first, vh_chunk_off, vh_done;
+    DevBuf<real_t> vh_r, vh_p, vh_r_old, vh_part;
 
     void upload(int nrows_, const size_t *hp, const int *hi, const real_t *hv, hipStream_t st)
     {
@@ -97,17 +102,33 @@ struct SparseShard {
         std::iota(ord.begin(), ord.end(), 0);
         auto len = [&](int r) { return (long long)(p0[r + 1] - p0[r]); };
         std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len(a) > len(b); });
-        n_heavy = n_medium = n_light = n_empty = 0;
-        nnz_heavy = nnz_medium = nnz_light = 0;
+        n_vheavy = n_heavy = n_medium = n_light = n_empty = 0;
+        nnz_vheavy = nnz_heavy = nnz_medium = nnz_light = 0;
+        std::vector<int> c_row, c_first, c_off(1, 0);
         for (int r : ord) {
             long long l = len(r);
-            if (l > MEDIUM_MAX) { n_heavy++; nnz_heavy += (size_t)l; }
+            if (l > HEAVY_MAX) {
+                int ntiles = (int)((l + TILE - 1) / TILE);
+                for (int t0 = 0; t0 < ntiles; t0 += VH_CHUNK_TILES) { c_row.push_back(n_vheavy); c_first.push_back(t0); }
+                c_off.push_back((int)c_row.size());
+                n_vheavy++; nnz_vheavy += (size_t)l;
+            }
+            else if (l > MEDIUM_MAX) { n_heavy++; nnz_heavy += (size_t)l; }
             else if (l > LIGHT_MAX) { n_medium++; nnz_medium += (size_t)l; }
             else if (l > 0) { n_light++; nnz_light += (size_t)l; }
             else n_empty++;
         }
         max_nnz = nrows ? (int)len(ord[0]) : 0;
         order.upload(ord.data(), nrows, st);
+        n_chunks = (int)c_row.size();
+        if (n_vheavy) {
+            vh_chunk_row.upload(c_row.data(), c_row.size(), st);
+            vh_chunk_first.upload(c_first.data(), c_first.size(), st);
+            vh_chunk_off.upload(c_off.data(), c_off.size(), st);
+            vh_done.alloc(n_vheavy); vh_r_old.alloc(n_vheavy);
+            vh_r.alloc((size_t)n_vheavy * 64); vh_p.alloc((size_t)n_vheavy * 64);
+            vh_part.alloc((size_t)n_chunks * 64);
+        }
         HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
     }
 };
@@ -122,7 +143,7 @@ struct DeviceInfo {
 // the kernel runs on; read back by cmfrec_hip_session_kernel_time.
 struct EventPair { hipEvent_t a, b; };
 struct BinTimers {
-    std::vector<EventPair> ev[3];
+    std::vector<EventPair> ev[4];     // 0 heavy, 1 medium, 2 light, 3 very heavy (whole split-row sequence)
     void clear()
     {
         for (auto &v : ev) {
@@ -151,7 +172,7 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
         size_t smem = (size_t)32 * k * sizeof(real_t);
         hipLaunchKernelGGL(gram_partial_kernel<real_t>, dim3(nblocks), dim3(256), smem, dev.stream,
                            B, ldb, n, k, rpb, ws.partial.ptr);
-        hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 255) / 256), dim3(256), 0, dev.stream,
+        hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 3) / 4), dim3(256), 0, dev.stream,
                            ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
     } else {
         hipLaunchKernelGGL(gram_naive_kernel<real_t>, dim3((k * k + 255) / 256), dim3(256), 0, dev.stream,
@@ -210,19 +231,50 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
+// very heavy rows: one (pass, update) launch pair per CG pass
+template <int S, bool IMPLICIT>
+inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, BinTimers *tm)
+{
+    if (X.n_vheavy <= 0) return;
+    EventPair ev{nullptr, nullptr};
+    if (tm) {
+        HIP_CHECK(hipEventCreate(&ev.a));
+        HIP_CHECK(hipEventCreate(&ev.b));
+        HIP_CHECK(hipEventRecord(ev.a, dev.stream));
+    }
+    VhState<real_t> V;
+    V.r = X.vh_r.ptr; V.p = X.vh_p.ptr; V.r_old = X.vh_r_old.ptr; V.done = X.vh_done.ptr; V.part = X.vh_part.ptr;
+    V.chunk_row = X.vh_chunk_row.ptr; V.chunk_first = X.vh_chunk_first.ptr; V.chunk_off = X.vh_chunk_off.ptr;
+    V.nvh = X.n_vheavy; V.nchunks = X.n_chunks;
+    P.nrows = X.n_vheavy;
+    const dim3 gp(X.n_chunks), bp(64 * VH_CHUNK_TILES), gu(X.n_vheavy), bu(64);
+    hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 0>), gp, bp, 0, dev.stream, P, V);
+    hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0>), gu, bu, 0, dev.stream, P, V);
+    for (int step = 0; step < P.max_cg_steps; step++) {
+        hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 1>), gp, bp, 0, dev.stream, P, V);
+        hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 1>), gu, bu, 0, dev.stream, P, V);
+    }
+    HIP_CHECK(hipGetLastError());
+    if (tm) {
+        HIP_CHECK(hipEventRecord(ev.b, dev.stream));
+        tm->ev[3].push_back(ev);
+    }
+}
+
 template <int S, bool IMPLICIT>
 inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm)
 {
-    // heavy rows first: they are the longest-running teams
-    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, 0, X.n_heavy, tm, 0);
-    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.n_heavy, X.n_medium, tm, 1);
-    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.n_heavy + X.n_medium, X.n_light, tm, 2);
+    launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm);
+    // then longest rows first: they are the longest-running teams
+    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.n_vheavy, X.n_heavy, tm, 0);
+    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.n_vheavy + X.n_heavy, X.n_medium, tm, 1);
+    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.n_vheavy + X.n_heavy + X.n_medium, X.n_light, tm, 2);
 }
 
 template <int NF, bool IMPLICIT>
 inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X)
 {
-    int count = X.n_heavy + X.n_medium + X.n_light;
+    int count = X.n_vheavy + X.n_heavy + X.n_medium + X.n_light;
     if (count <= 0) return;
     P.nrows = count;
     int grid = std::min((count + 3) / 4, dev.num_cus * 8);

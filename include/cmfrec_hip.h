@@ -220,8 +220,10 @@ int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which);
  * the last reset; synchronises the stream. */
 int cmfrec_hip_session_kernel_time(cmfrec_hip_session *s, int which, double *ms, long *launches);
 /* Per-kernel figures of the CG row-update launches of `which`: the rows are scheduled in three nnz
- * bins (0: > 256 nnz, 8 waves/row; 1: 65..256, 4 waves/row; 2: <= 64, 1 wave/row), one persistent
- * launch each.  ms = summed HIP-event time of that bin's launches since the last reset. */
+ * bins (0: 257..2048 nnz, 8 waves/row; 1: 65..256, 4 waves/row; 2: <= 64, 1 wave/row), one persistent
+ * launch each, plus bin 3: rows > 2048 nnz, whose CG passes are split over many workgroups (one
+ * launch pair per pass; the figure covers the whole sequence).  ms = summed HIP-event time of that
+ * bin's launches since the last reset. */
 int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, double *ms, long *launches,
                                  long *rows, unsigned long long *nnz);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);

@@ -91,3 +91,34 @@ def test_optimizeA_collective(oracles, dtype, ku, ki, km, sls, m_u):
     ops.optimizeA_collective(Ah, Bm, Cm, csr, U, 0.05, **kw)
     O.optimizeA_collective_chol(Ao, Bm, Cm, csr, U, 0.05, nthreads=4, **kw)
     assert rel_err(Ah[:, :kA], Ao[:, :kA]) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("implicit", [True, False])
+def test_very_heavy_rows_split_path(oracles, dtype, implicit):
+    """Rows above 2048 nnz take the split-row path (one launch pair per CG pass); 257..2048 the
+    8-wave team with re-streamed tiles; both must agree with the sequential reference sums."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n, k = 60, 5000, 50
+    row, col, val = make_coo(m, n, 12000, 41, counts=implicit, dtype=dtype, heavy_row=(3, 4500), empty_rows=(8,))
+    # a second very heavy row and a 257..2048 one
+    rng = np.random.default_rng(4)
+    extra_r = np.concatenate([np.full(2500, 10, np.int32), np.full(900, 11, np.int32)])
+    keep = (row != 10) & (row != 11)
+    extra_c = np.concatenate([rng.choice(n, 2500, replace=False), rng.choice(n, 900, replace=False)]).astype(np.int32)
+    extra_v = (np.ceil(rng.lognormal(1, 1, 3400)) if implicit else 0.5 * rng.integers(1, 11, 3400)).astype(dtype)
+    row = np.concatenate([row[keep], extra_r]); col = np.concatenate([col[keep], extra_c]); val = np.concatenate([val[keep], extra_v])
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    assert np.diff(csr[0].astype(np.int64)).max() > 2048
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    if implicit:
+        ops.optimizeA_implicit(Ah, B, csr, 4.0)
+        O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4)
+    else:
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True)
+        O.optimizeA_explicit(Ao, B, csr, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    assert np.array_equal(Ah[8], A0[8])
