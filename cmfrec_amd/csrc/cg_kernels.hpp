@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "lanes.hpp"
+
 namespace cmfhip {
 
 constexpr int WAVE = 64;
@@ -50,43 +52,51 @@ struct CgParams {
 };
 
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ T wave_sum(T v) { return lanes::wave_sum(v); }
 
-// Transposed butterfly: 8 values per lane, summed over the 8 lanes that differ in the lane bits
-// selected by masks (M2,M1,M0); the lane whose bits are (b2,b1,b0) ends with the total of
-// v[4*b2+2*b1+b0].
-template <typename T, int M2, int M1, int M0>
-__device__ __forceinline__ T treduce8(const T (&v)[8], int lane)
+// Transposed butterfly over the lane bits 0..2 (the 8 lanes of one non-zero group): 8 values per
+// lane in, the lane whose low bits are b ends with the 8-lane total of v[b].
+template <typename T>
+__device__ __forceinline__ T treduce8_low(const T (&v)[8], int lane)
 {
     T u[4], q[2];
-    bool h = (lane & M2) != 0;
+    bool h = (lane & 4) != 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         T keep = h ? v[i + 4] : v[i];
-        T send = h ? v[i] : v[i + 4];
-        u[i] = keep + __shfl_xor(send, M2);
+        u[i] = keep + lanes::recv_xor4(v[i], v[i + 4]);
     }
-    h = (lane & M1) != 0;
+    h = (lane & 2) != 0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         T keep = h ? u[i + 2] : u[i];
         T send = h ? u[i] : u[i + 2];
-        q[i] = keep + __shfl_xor(send, M1);
+        q[i] = keep + lanes::xor2(send);
     }
-    h = (lane & M0) != 0;
+    h = (lane & 1) != 0;
     T keep = h ? q[1] : q[0];
     T send = h ? q[0] : q[1];
-    return keep + __shfl_xor(send, M0);
+    return keep + lanes::xor1(send);
 }
 
-// LDS leading dimension for the staged Gramian: multiple of 8, == 8 or 24 (mod 32) doubles so
-// that the 4 jj-groups of a half-wave hit distinct banks with ds_read_b64.
-__host__ __device__ constexpr int gram_ld(int S) { return ((8 * S) % 32 == 8 || (8 * S) % 32 == 24) ? 8 * S : 8 * S + 8; }
+// Transposed butterfly over the lane bits 3..5 (the 8 non-zero groups): the lane whose bits 3..5
+// are jj ends with the total of v[jj] over the 8 lanes that share its low bits.
+template <typename T>
+__device__ __forceinline__ T treduce8_high(const T (&v)[8], int lane)
+{
+    T u[4], q[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) u[i] = lanes::tswap32_add(v[i], v[i + 4]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) q[i] = lanes::tswap16_add(u[i], u[i + 2]);
+    const bool h = (lane & 8) != 0;
+    T keep = h ? q[1] : q[0];
+    return keep + lanes::recv_xor8(q[0], q[1]);
+}
+
+// LDS leading dimension for the staged Gramian: odd, so that the jj-groups of a lane group land on
+// distinct banks both for ds_read_b64 (32 lanes, 64 banks) and ds_read2_b64 (16 lanes, 32 banks).
+__host__ __device__ constexpr int gram_ld(int S) { return 8 * S + 1; }
 
 template <typename T, int S>
 struct RegTile {
@@ -99,9 +109,13 @@ __device__ __forceinline__ void load_tile(RegTile<T, S> &tile, const T *__restri
 {
     const int jj = lane >> 3, ll = lane & 7;
     const bool last_ok = (ll + 8 * (S - 1)) < k;
+    int its[8];
+    its[0] = lanes::bcast8<0>(my_idx); its[1] = lanes::bcast8<1>(my_idx); its[2] = lanes::bcast8<2>(my_idx);
+    its[3] = lanes::bcast8<3>(my_idx); its[4] = lanes::bcast8<4>(my_idx); its[5] = lanes::bcast8<5>(my_idx);
+    its[6] = lanes::bcast8<6>(my_idx); its[7] = lanes::bcast8<7>(my_idx);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        int it = __shfl(my_idx, (lane & ~7) | t);
+        int it = its[t];
         bool valid = (jj * 8 + t) < cnt;
         const T *rp = Bm + (size_t)it * ldb + ll;
 #pragma unroll
@@ -126,7 +140,7 @@ __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&v
         for (int s = 0; s < S; s++) acc += tile.v[t][s] * vrep[s];
         c[t] = acc;
     }
-    T coef = treduce8<T, 4, 2, 1>(c, lane);      // lane j now holds B_j . v
+    T coef = treduce8_low<T>(c, lane);           // lane j now holds B_j . v
     T w;
     if (IMPLICIT) {
         if (MODE == 0) w = -(coef - T(1)) * x - coef;     // common.c:1939
@@ -136,26 +150,33 @@ __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&v
         else           w = coef;                          // common.c:1158-1159
     }
     if (!valid) w = T(0);
+    T wts[8];
+    wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
+    wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        T wt = __shfl(w, (lane & ~7) | t);
 #pragma unroll
-        for (int s = 0; s < S; s++) out[s] += wt * tile.v[t][s];
+        for (int s = 0; s < S; s++) out[s] += wts[t] * tile.v[t][s];
     }
 }
 
 // out[s] += sum_j wdist_j * G[j][ll+8s]  with the Gramian staged in LDS (rows padded to 64).
-template <typename T, int S>
-__device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, T (&out)[8], int lane)
+// The 8 row-slices t are dealt to the W waves of the team (wave wr takes t = wr, wr+W, ...).
+template <typename T, int S, int W>
+__device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, T (&out)[8], int lane, int wr)
 {
     constexpr int LD = gram_ld(S);
     const int jj = lane >> 3, ll = lane & 7;
+    T wts[8];
+    wts[0] = lanes::bcast8<0>(wdist); wts[1] = lanes::bcast8<1>(wdist); wts[2] = lanes::bcast8<2>(wdist);
+    wts[3] = lanes::bcast8<3>(wdist); wts[4] = lanes::bcast8<4>(wdist); wts[5] = lanes::bcast8<5>(wdist);
+    wts[6] = lanes::bcast8<6>(wdist); wts[7] = lanes::bcast8<7>(wdist);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        T wt = __shfl(wdist, (lane & ~7) | t);
+        if (W > 1 && (t % W) != wr) continue;
         const T *g = G + (jj * 8 + t) * LD + ll;
 #pragma unroll
-        for (int s = 0; s < S; s++) out[s] += wt * g[8 * s];
+        for (int s = 0; s < S; s++) out[s] += wts[t] * g[8 * s];
     }
 }
 
@@ -243,9 +264,9 @@ cg_rows_kernel(const CgParams<T> P)
                 }
                 tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
             }
-            if (IMPLICIT && wr == 0)
-                gram_pass<T, S>(G, (MODE == 0) ? -vdist : vdist, out, lane);   // common.c:1932 / :1958
-            T tot = treduce8<T, 32, 16, 8>(out, lane);                        // lane f <- element f
+            if (IMPLICIT)
+                gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, out, lane, wr);   // common.c:1932 / :1958
+            T tot = treduce8_high<T>(out, lane);                              // lane f <- element f
             if (W > 1) {
                 T *rb = myred + (size_t)buf * W * 64;
                 rb[wr * 64 + lane] = tot;
@@ -342,7 +363,7 @@ vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
         replicate<T, S>(vdist, vrep, lane);
         tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
     }
-    T tot = treduce8<T, 32, 16, 8>(out, lane);
+    T tot = treduce8_high<T>(out, lane);
     red[wave][lane] = tot;
     __syncthreads();
     if (wave == 0) {

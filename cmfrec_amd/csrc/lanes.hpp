@@ -1,0 +1,110 @@
+// lanes.hpp -- cross-lane primitives for wave64 on gfx950 without touching the LDS pipe:
+// DPP (quad_perm / row_shl / row_shr / row_ror with bank masks) inside 16-lane rows and
+// v_permlane16_swap / v_permlane32_swap across rows.  All helpers work on float and double
+// (doubles are moved as two dwords).  Verified on device by cmfrec_hip_selftest_lanes().
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cmfhip {
+namespace lanes {
+
+constexpr int QP_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int QP_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int ROW_SHL4 = 0x104;    // lane i <- lane i+4 (inside a 16-lane row)
+constexpr int ROW_SHR4 = 0x114;    // lane i <- lane i-4
+constexpr int ROW_ROR8 = 0x128;    // lane i <- lane (i+8)%16
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK, false);
+}
+
+// ---- apply a dword -> dword lane operation to float / double / int ---------------------------
+template <typename F> __device__ __forceinline__ int map(int x, F f) { return f(x); }
+template <typename F> __device__ __forceinline__ float map(float x, F f) { return __int_as_float(f(__float_as_int(x))); }
+template <typename F> __device__ __forceinline__ double map(double x, F f)
+{
+    return __hiloint2double(f(__double2hiint(x)), f(__double2loint(x)));
+}
+template <typename F> __device__ __forceinline__ int map2(int a, int b, F f) { return f(a, b); }
+template <typename F> __device__ __forceinline__ float map2(float a, float b, F f)
+{
+    return __int_as_float(f(__float_as_int(a), __float_as_int(b)));
+}
+template <typename F> __device__ __forceinline__ double map2(double a, double b, F f)
+{
+    return __hiloint2double(f(__double2hiint(a), __double2hiint(b)), f(__double2loint(a), __double2loint(b)));
+}
+
+template <typename T> __device__ __forceinline__ T xor1(T x) { return map(x, [](int v) { return dpp<QP_XOR1, 0xF>(v, v); }); }
+template <typename T> __device__ __forceinline__ T xor2(T x) { return map(x, [](int v) { return dpp<QP_XOR2, 0xF>(v, v); }); }
+template <typename T> __device__ __forceinline__ T xor4(T x)
+{
+    return map(x, [](int v) { int t = dpp<ROW_SHL4, 0x5>(v, v); return dpp<ROW_SHR4, 0xA>(t, v); });
+}
+template <typename T> __device__ __forceinline__ T xor8(T x) { return map(x, [](int v) { return dpp<ROW_ROR8, 0xF>(v, v); }); }
+
+// lanes with (lane & M) == 0 receive a[lane ^ M], the others b[lane ^ M]  (M = 4 or 8)
+template <typename T> __device__ __forceinline__ T recv_xor4(T a, T b)
+{
+    return map2(a, b, [](int x, int y) { int t = dpp<ROW_SHL4, 0x5>(x, x); return dpp<ROW_SHR4, 0xA>(t, y); });
+}
+template <typename T> __device__ __forceinline__ T recv_xor8(T a, T b)
+{
+    return map2(a, b, [](int x, int y) { int t = dpp<ROW_ROR8, 0x3>(x, x); return dpp<ROW_ROR8, 0xC>(t, y); });
+}
+
+// result: lanes < 32 : a[l] + a[l+32] ;  lanes >= 32 : b[l-32] + b[l]
+template <typename T> __device__ __forceinline__ T tswap32_add(T a, T b);
+template <> __device__ __forceinline__ float tswap32_add(float a, float b)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <> __device__ __forceinline__ double tswap32_add(double a, double b)
+{
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// result: lanes with (lane&16)==0 : a[l] + a[l+16] ;  others : b[l-16] + b[l]
+template <typename T> __device__ __forceinline__ T tswap16_add(T a, T b);
+template <> __device__ __forceinline__ float tswap16_add(float a, float b)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <> __device__ __forceinline__ double tswap16_add(double a, double b)
+{
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// value of lane ((lane & ~7) | t) for every lane (t compile-time)
+template <int t, typename T> __device__ __forceinline__ T bcast8(T x)
+{
+    constexpr int q = t & 3;
+    constexpr int QP = q | (q << 2) | (q << 4) | (q << 6);
+    return map(x, [](int v) {
+        int y = dpp<QP, 0xF>(v, v);
+        if (t < 4) return dpp<ROW_SHR4, 0xA>(y, y);      // odd quads fetch from the even quad
+        else       return dpp<ROW_SHL4, 0x5>(y, y);      // even quads fetch from the odd quad
+    });
+}
+
+// full wave sum, identical on every lane
+template <typename T> __device__ __forceinline__ T wave_sum(T v)
+{
+    v += xor1(v);
+    v += xor2(v);
+    v += xor4(v);
+    v += xor8(v);
+    v = tswap16_add(v, v);
+    v = tswap32_add(v, v);
+    return v;
+}
+
+}  // namespace lanes
+}  // namespace cmfhip

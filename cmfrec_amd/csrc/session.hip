@@ -677,3 +677,71 @@ int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size
 }
 
 }  // extern "C"
+
+// ---- on-device self-test of the cross-lane primitives (lanes.hpp) -----------------------------
+namespace cmfhip {
+__global__ void lanes_selftest_kernel(real_t *out)
+{
+    const int lane = threadIdx.x;
+    const real_t x = (real_t)(lane * 3 + 1);
+    const real_t y = (real_t)(1000 + lane);
+    real_t *o = out + lane;
+    o[0 * 64] = lanes::xor1(x);
+    o[1 * 64] = lanes::xor2(x);
+    o[2 * 64] = lanes::xor4(x);
+    o[3 * 64] = lanes::xor8(x);
+    o[4 * 64] = lanes::recv_xor4(x, y);
+    o[5 * 64] = lanes::recv_xor8(x, y);
+    o[6 * 64] = lanes::tswap32_add(x, y);
+    o[7 * 64] = lanes::tswap16_add(x, y);
+    o[8 * 64] = lanes::bcast8<0>(x);
+    o[9 * 64] = lanes::bcast8<3>(x);
+    o[10 * 64] = lanes::bcast8<5>(x);
+    o[11 * 64] = lanes::bcast8<7>(x);
+    o[12 * 64] = lanes::wave_sum(x);
+    real_t v[8];
+    for (int i = 0; i < 8; i++) v[i] = (real_t)(lane + 100 * i);
+    o[13 * 64] = treduce8_low<real_t>(v, lane);
+    o[14 * 64] = treduce8_high<real_t>(v, lane);
+}
+}  // namespace cmfhip
+
+extern "C" int cmfrec_hip_selftest_lanes(void)
+{
+    int bad = -1;
+    int rc = guarded([&]() {
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> d;
+        d.alloc(15 * 64);
+        hipLaunchKernelGGL(lanes_selftest_kernel, dim3(1), dim3(64), 0, dev.stream, d.ptr);
+        HIP_CHECK(hipGetLastError());
+        std::vector<real_t> h(15 * 64);
+        d.download(h.data(), h.size(), dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        HIP_CHECK(hipStreamDestroy(dev.stream));
+        auto X = [](int l) { return (double)(l * 3 + 1); };
+        auto Y = [](int l) { return (double)(1000 + l); };
+        bad = 0;
+        for (int l = 0; l < 64; l++) {
+            double e[15];
+            e[0] = X(l ^ 1); e[1] = X(l ^ 2); e[2] = X(l ^ 4); e[3] = X(l ^ 8);
+            e[4] = (l & 4) ? Y(l ^ 4) : X(l ^ 4);
+            e[5] = (l & 8) ? Y(l ^ 8) : X(l ^ 8);
+            e[6] = (l < 32) ? X(l) + X(l + 32) : Y(l - 32) + Y(l);
+            e[7] = (l & 16) ? Y(l - 16) + Y(l) : X(l) + X(l + 16);
+            e[8] = X((l & ~7) | 0); e[9] = X((l & ~7) | 3); e[10] = X((l & ~7) | 5); e[11] = X((l & ~7) | 7);
+            double s = 0; for (int j = 0; j < 64; j++) s += X(j);
+            e[12] = s;
+            { int b = l & 7; double t = 0; for (int j = 0; j < 8; j++) t += (double)(((l & ~7) | j) + 100 * b); e[13] = t; }
+            { int b = l >> 3; double t = 0; for (int j = 0; j < 8; j++) t += (double)(((l & 7) | (j << 3)) + 100 * b); e[14] = t; }
+            for (int c = 0; c < 15; c++)
+                if ((double)h[c * 64 + l] != e[c]) {
+                    if (bad < 8) fprintf(stderr, "lanes selftest: case %d lane %d got %g expected %g\n", c, l, (double)h[c * 64 + l], e[c]);
+                    bad++;
+                }
+        }
+        return 0;
+    });
+    return rc ? -rc : bad;
+}

@@ -228,6 +228,10 @@ int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, doub
                                  long *rows, unsigned long long *nnz);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
+/* Runs the on-device self-test of the cross-lane primitives (DPP / permlane swaps) the row kernels
+ * are built on; returns the number of mismatching lanes (0 = ok), negative = HIP failure. */
+int cmfrec_hip_selftest_lanes(void);
+
 /* Build info: sizeof(real_t), and the gfx target the kernels were compiled for. */
 int cmfrec_hip_sizeof_real(void);
 const char *cmfrec_hip_build_info(void);

@@ -122,3 +122,10 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit):
         O.optimizeA_explicit(Ao, B, csr, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
     assert rel_err(Ah, Ao) < TOL[dtype]
     assert np.array_equal(Ah[8], A0[8])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lane_primitives_selftest(dtype):
+    """DPP / permlane-swap shuffles, broadcasts and the transposed butterflies, checked lane by lane."""
+    from cmfrec_amd import _lib
+    assert _lib.load(dtype).cmfrec_hip_selftest_lanes() == 0
