@@ -31,6 +31,17 @@ namespace cmfhip {
 constexpr int WAVE = 64;
 constexpr int TILE = 64;          // non-zeros per register tile
 constexpr int MAX_W = 8;          // max cooperating waves per row
+#ifndef CMF_CG_WAVES_PER_SIMD
+#define CMF_CG_WAVES_PER_SIMD 2   // register budget of the row kernels: 2 -> 256 VGPRs, 3 -> 168 (spills)
+#endif
+
+// One entry per row in processing order: replaces the order[] -> indptr[] pointer chase in the
+// persistent kernels (one 16-byte load gives the row id, its length and its CSR offset).
+struct RowDesc {
+    int row;
+    int nnz;
+    unsigned long long st;
+};
 
 template <typename T>
 struct CgParams {
@@ -44,6 +55,7 @@ struct CgParams {
     const T *values;
     const T *bias_sub;    // explicit: x_j := x_j - bias_sub[idx_j] (fused "X - bias" sweep), or null
     const int *order;     // row ids to process
+    const RowDesc *desc;  // same rows, same order, with length and CSR offset
     int nrows;
     const T *BtB;         // implicit: k x k Gramian of B (row-major, ld = k, both triangles)
     T lam, lam_last;
@@ -191,7 +203,7 @@ __device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane)
 // Persistent kernel: W waves cooperate on one row (W = waves per row, blockDim.x = 64*W*RPB where
 // RPB rows are processed concurrently by one workgroup).
 template <typename T, int S, bool IMPLICIT, int W, int RPB>
-__global__ void __launch_bounds__(64 * W * RPB, 2)
+__global__ void __launch_bounds__(64 * W * RPB, CMF_CG_WAVES_PER_SIMD)
 cg_rows_kernel(const CgParams<T> P)
 {
     constexpr int LD = gram_ld(S);
@@ -217,11 +229,40 @@ cg_rows_kernel(const CgParams<T> P)
     const int nteams = gridDim.x * RPB;
     int buf = 0;   // cross-wave exchange buffer parity; persists across rows
     static_assert(W == 1 || RPB == 1, "multi-wave teams own their workgroup (barriers are per row)");
-    for (int rix = blockIdx.x * RPB + grp; rix < P.nrows; rix += nteams) {
-        const bool active = true;
-        const int row = P.order[rix];
-        const size_t st = P.indptr[row];
-        const int nnz = (int)(P.indptr[row + 1] - st);
+
+    // Software pipeline over the team's rows: while row i is being solved, the descriptor of row
+    // i+2 and the first-tile indices / values / warm start of row i+1 are already in flight, so
+    // the only exposed memory latency per row is the gather of its opposing-factor rows.
+    struct Pre { int idx; T x; T a; };
+    auto load_desc = [&](int rix_) -> RowDesc {
+        RowDesc d; d.row = 0; d.nnz = 0; d.st = 0;
+        if (rix_ < P.nrows) d = P.desc[rix_];
+        d.row = __builtin_amdgcn_readfirstlane(d.row);
+        d.nnz = __builtin_amdgcn_readfirstlane(d.nnz);
+        d.st = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.st >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(d.st & 0xffffffffu));
+        return d;
+    };
+    auto load_pre = [&](const RowDesc &d) -> Pre {
+        Pre q; q.idx = 0; q.x = T(0); q.a = T(0);
+        const int cnt = min(TILE, d.nnz - wr * TILE);
+        if (lane < cnt) {
+            const size_t pos = d.st + (size_t)wr * TILE + lane;
+            q.idx = P.indices[pos];
+            q.x = P.values[pos];
+            if (!IMPLICIT && P.bias_sub != nullptr) q.x -= P.bias_sub[q.idx];
+        }
+        if (d.nnz > 0 && lane < k) q.a = P.A[(size_t)d.row * P.lda + lane];
+        return q;
+    };
+    int rix = blockIdx.x * RPB + grp;
+    RowDesc dcur = load_desc(rix);
+    RowDesc dnxt = load_desc(rix + nteams);
+    Pre pcur = load_pre(dcur);
+    for (; rix < P.nrows; rix += nteams) {
+        const int row = dcur.row;
+        const size_t st = dcur.st;
+        const int nnz = dcur.nnz;
         const int ntiles = (nnz + TILE - 1) / TILE;
         const int my_ntiles = (ntiles > wr) ? (ntiles - wr + W - 1) / W : 0;
         const bool resident = my_ntiles <= 1;
@@ -232,11 +273,16 @@ cg_rows_kernel(const CgParams<T> P)
             if (!P.scale_bias_const) lam_last *= (T)nnz;
         }
         T *arow = P.A + (size_t)row * P.lda;
-        T a_d = (active && lane < k) ? arow[lane] : T(0);
+        T a_d = pcur.a;
 
+        // first tile of this wave: gather now (critical path), then start the next row's loads
         RegTile<T, S> tile;
-        T x_res = T(0);
-        bool valid_res = false;
+        const int cnt0 = min(TILE, nnz - wr * TILE);
+        T x_res = pcur.x;
+        bool valid_res = lane < cnt0;
+        if (cnt0 > 0) load_tile<T, S>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
+        const RowDesc dnn = load_desc(rix + 2 * nteams);
+        const Pre pnxt = load_pre(dnxt);
 
         auto run_pass = [&](T vdist, auto mode_tag, bool first) -> T {
             constexpr int MODE = decltype(mode_tag)::value;
@@ -250,7 +296,8 @@ cg_rows_kernel(const CgParams<T> P)
             for (int s = 0; s < 8; s++) out[s] = T(0);
             for (int tl = wr; tl < ntiles; tl += W) {
                 T x; bool valid;
-                if (!resident || first) {
+                const bool have = (tl == wr) && (resident || first);   // still in registers
+                if (!have) {
                     const int cnt = min(TILE, nnz - tl * TILE);
                     valid = lane < cnt;
                     const size_t pos = st + (size_t)tl * TILE + lane;
@@ -258,7 +305,6 @@ cg_rows_kernel(const CgParams<T> P)
                     x = valid ? P.values[pos] : T(0);
                     if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
                     load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
-                    x_res = x; valid_res = valid;
                 } else {
                     x = x_res; valid = valid_res;
                 }
@@ -304,7 +350,8 @@ cg_rows_kernel(const CgParams<T> P)
                 r_old = r_new;
             }
         }
-        if (active && wr == 0 && lane < k) arow[lane] = a_d;
+        if (wr == 0 && lane < k) arow[lane] = a_d;
+        dcur = dnxt; dnxt = dnn; pcur = pnxt;
     }
 }
 

@@ -67,22 +67,36 @@ struct DevBuf {
     }
 };
 
-// Rows are scheduled longest-first inside three nnz bins; every bin is a persistent launch whose
-// teams stride over the sorted list, which balances the heavy-tailed row lengths the reference
-// handles with `omp schedule(dynamic)` (common.c:3259,3349).
-constexpr int LIGHT_MAX = TILE;          // <= 64 nnz : 1 wave / row, 4 rows / workgroup
-constexpr int MEDIUM_MAX = 4 * TILE;     // <= 256 nnz: 4 waves / row
-constexpr int HEAVY_MAX = 2048;          // <= 2048   : 8 waves / row (register-resident to 512 nnz)
-                                         // larger     : "very heavy", every CG pass split over many workgroups
+// Rows are scheduled longest-first inside nnz bins; every bin is a persistent launch whose teams
+// stride over the sorted list, which balances the heavy-tailed row lengths the reference handles
+// with `omp schedule(dynamic)` (common.c:3259,3349).  A row of a bin with W waves per row keeps its
+// gathered tiles in registers when it has <= 64*W non-zeros.
+constexpr int NBINS = 5;
+constexpr int BIN_VHEAVY = 0;   // > 2048 nnz : every CG pass split over many workgroups (vh_* kernels)
+constexpr int BIN_HEAVY = 1;    // 257..2048  : 8 waves / row (register-resident up to 512 nnz, else re-streamed)
+constexpr int BIN_MED4 = 2;     // 129..256   : 4 waves / row
+constexpr int BIN_MED2 = 3;     // 65..128    : 2 waves / row
+constexpr int BIN_LIGHT = 4;    // 1..64      : 1 wave / row, 4 rows / workgroup
+constexpr int BIN_MIN_NNZ[NBINS] = {2049, 257, 129, 65, 1};
+inline int bin_of(long long nnz)
+{
+    for (int b = 0; b < NBINS; b++)
+        if (nnz >= BIN_MIN_NNZ[b]) return b;
+    return -1;   // empty row
+}
+
 struct SparseShard {
     int nrows = 0;
     size_t nnz = 0;
     DevBuf<size_t> p;
     DevBuf<int> i;
     DevBuf<real_t> v;
-    DevBuf<int> order;       // [very heavy | heavy | medium | light | empty], each sorted by nnz descending
-    int n_vheavy = 0, n_heavy = 0, n_medium = 0, n_light = 0, n_empty = 0;
-    size_t nnz_vheavy = 0, nnz_heavy = 0, nnz_medium = 0, nnz_light = 0;
+    DevBuf<int> order;       // row ids sorted by nnz descending: [bin 0 | bin 1 | ... | bin 4 | empty rows]
+    DevBuf<RowDesc> desc;    // same order: {row, nnz, CSR offset}
+    int bin_rows[NBINS] = {0, 0, 0, 0, 0};
+    int bin_first[NBINS] = {0, 0, 0, 0, 0};
+    size_t bin_nnz[NBINS] = {0, 0, 0, 0, 0};
+    int n_nonempty = 0, n_empty = 0;
     int max_nnz = 0;
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
     int n_chunks = 0;
@@ -102,31 +116,37 @@ struct SparseShard {
         std::iota(ord.begin(), ord.end(), 0);
         auto len = [&](int r) { return (long long)(p0[r + 1] - p0[r]); };
         std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len(a) > len(b); });
-        n_vheavy = n_heavy = n_medium = n_light = n_empty = 0;
-        nnz_vheavy = nnz_heavy = nnz_medium = nnz_light = 0;
+        for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
+        n_empty = 0;
         std::vector<int> c_row, c_first, c_off(1, 0);
-        for (int r : ord) {
-            long long l = len(r);
-            if (l > HEAVY_MAX) {
+        std::vector<RowDesc> dsc(nrows);
+        for (int q = 0; q < nrows; q++) {
+            const int r = ord[q];
+            const long long l = len(r);
+            dsc[q].row = r; dsc[q].nnz = (int)l; dsc[q].st = (unsigned long long)p0[r];
+            const int b = bin_of(l);
+            if (b < 0) { n_empty++; continue; }
+            if (b == BIN_VHEAVY) {
                 int ntiles = (int)((l + TILE - 1) / TILE);
-                for (int t0 = 0; t0 < ntiles; t0 += VH_CHUNK_TILES) { c_row.push_back(n_vheavy); c_first.push_back(t0); }
+                for (int t0 = 0; t0 < ntiles; t0 += VH_CHUNK_TILES) { c_row.push_back(bin_rows[b]); c_first.push_back(t0); }
                 c_off.push_back((int)c_row.size());
-                n_vheavy++; nnz_vheavy += (size_t)l;
             }
-            else if (l > MEDIUM_MAX) { n_heavy++; nnz_heavy += (size_t)l; }
-            else if (l > LIGHT_MAX) { n_medium++; nnz_medium += (size_t)l; }
-            else if (l > 0) { n_light++; nnz_light += (size_t)l; }
-            else n_empty++;
+            bin_rows[b]++; bin_nnz[b] += (size_t)l;
         }
+        int acc = 0;
+        for (int b = 0; b < NBINS; b++) { bin_first[b] = acc; acc += bin_rows[b]; }
+        n_nonempty = acc;
         max_nnz = nrows ? (int)len(ord[0]) : 0;
         order.upload(ord.data(), nrows, st);
+        desc.upload(dsc.data(), nrows, st);
         n_chunks = (int)c_row.size();
-        if (n_vheavy) {
+        if (bin_rows[BIN_VHEAVY]) {
+            const int nvh = bin_rows[BIN_VHEAVY];
             vh_chunk_row.upload(c_row.data(), c_row.size(), st);
             vh_chunk_first.upload(c_first.data(), c_first.size(), st);
             vh_chunk_off.upload(c_off.data(), c_off.size(), st);
-            vh_done.alloc(n_vheavy); vh_r_old.alloc(n_vheavy);
-            vh_r.alloc((size_t)n_vheavy * 64); vh_p.alloc((size_t)n_vheavy * 64);
+            vh_done.alloc(nvh); vh_r_old.alloc(nvh);
+            vh_r.alloc((size_t)nvh * 64); vh_p.alloc((size_t)nvh * 64);
             vh_part.alloc((size_t)n_chunks * 64);
         }
         HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
@@ -143,7 +163,7 @@ struct DeviceInfo {
 // the kernel runs on; read back by cmfrec_hip_session_kernel_time.
 struct EventPair { hipEvent_t a, b; };
 struct BinTimers {
-    std::vector<EventPair> ev[4];     // 0 heavy, 1 medium, 2 light, 3 very heavy (whole split-row sequence)
+    std::vector<EventPair> ev[NBINS]; // per nnz bin (bin 0 = whole split-row sequence of the very heavy rows)
     void clear()
     {
         for (auto &v : ev) {
@@ -209,6 +229,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
         HIP_CHECK(hipEventRecord(ev.a, dev.stream));
     }
     P.order += first;
+    P.desc += first;
     P.nrows = count;
     constexpr int threads = 64 * W * RPB;
     size_t smem = ((IMPLICIT ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
@@ -235,7 +256,8 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
 template <int S, bool IMPLICIT>
 inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, BinTimers *tm)
 {
-    if (X.n_vheavy <= 0) return;
+    const int nvh = X.bin_rows[BIN_VHEAVY];
+    if (nvh <= 0) return;
     EventPair ev{nullptr, nullptr};
     if (tm) {
         HIP_CHECK(hipEventCreate(&ev.a));
@@ -245,9 +267,9 @@ inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const Sp
     VhState<real_t> V;
     V.r = X.vh_r.ptr; V.p = X.vh_p.ptr; V.r_old = X.vh_r_old.ptr; V.done = X.vh_done.ptr; V.part = X.vh_part.ptr;
     V.chunk_row = X.vh_chunk_row.ptr; V.chunk_first = X.vh_chunk_first.ptr; V.chunk_off = X.vh_chunk_off.ptr;
-    V.nvh = X.n_vheavy; V.nchunks = X.n_chunks;
-    P.nrows = X.n_vheavy;
-    const dim3 gp(X.n_chunks), bp(64 * VH_CHUNK_TILES), gu(X.n_vheavy), bu(64);
+    V.nvh = nvh; V.nchunks = X.n_chunks;
+    P.nrows = nvh;
+    const dim3 gp(X.n_chunks), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64);
     hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 0>), gp, bp, 0, dev.stream, P, V);
     hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0>), gu, bu, 0, dev.stream, P, V);
     for (int step = 0; step < P.max_cg_steps; step++) {
@@ -257,7 +279,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const Sp
     HIP_CHECK(hipGetLastError());
     if (tm) {
         HIP_CHECK(hipEventRecord(ev.b, dev.stream));
-        tm->ev[3].push_back(ev);
+        tm->ev[BIN_VHEAVY].push_back(ev);
     }
 }
 
@@ -266,15 +288,16 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
 {
     launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm);
     // then longest rows first: they are the longest-running teams
-    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.n_vheavy, X.n_heavy, tm, 0);
-    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.n_vheavy + X.n_heavy, X.n_medium, tm, 1);
-    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.n_vheavy + X.n_heavy + X.n_medium, X.n_light, tm, 2);
+    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY);
+    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4);
+    launch_cg_bin<S, IMPLICIT, 2, 1>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2);
+    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT);
 }
 
 template <int NF, bool IMPLICIT>
 inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X)
 {
-    int count = X.n_vheavy + X.n_heavy + X.n_medium + X.n_light;
+    int count = X.n_nonempty;
     if (count <= 0) return;
     P.nrows = count;
     int grid = std::min((count + 3) / 4, dev.num_cus * 8);
@@ -287,7 +310,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     CgParams<real_t> P;
     P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.k = c.k;
     P.indptr = X.p.ptr; P.indices = X.i.ptr; P.values = X.v.ptr;
-    P.bias_sub = c.bias_sub; P.order = X.order.ptr; P.nrows = 0; P.BtB = c.BtB;
+    P.bias_sub = c.bias_sub; P.order = X.order.ptr; P.desc = X.desc.ptr; P.nrows = 0; P.BtB = c.BtB;
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_bias_const = c.scale_bias_const;
     P.max_cg_steps = c.max_cg_steps;

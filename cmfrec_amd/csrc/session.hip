@@ -46,7 +46,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.order = X ? X->order.ptr : nullptr;
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
     else if (c.mode == CHOL_COLLECTIVE) P.nrows = X->nrows;                       // empty rows too
-    else P.nrows = X->n_vheavy + X->n_heavy + X->n_medium + X->n_light;          // non-empty rows
+    else P.nrows = X->n_nonempty;                                                // non-empty rows
     P.Minit = c.Minit; P.kc = c.kc; P.rows_with_u = c.rows_with_u; P.p_side = c.p_side;
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
@@ -514,7 +514,7 @@ int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, doub
                                  long *rows, unsigned long long *nnz)
 {
     return guarded([&]() {
-        if (bin < 0 || bin > 3) return 2;
+        if (bin < 0 || bin >= NBINS) return 2;
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         BinTimers &bt = (which == 'A') ? s->binA : s->binB;
         const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
@@ -526,8 +526,8 @@ int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, doub
         }
         if (ms) *ms = tot;
         if (launches) *launches = (long)bt.ev[bin].size();
-        if (rows) *rows = bin == 0 ? X.n_heavy : bin == 1 ? X.n_medium : bin == 2 ? X.n_light : X.n_vheavy;
-        if (nnz) *nnz = bin == 0 ? X.nnz_heavy : bin == 1 ? X.nnz_medium : bin == 2 ? X.nnz_light : X.nnz_vheavy;
+        if (rows) *rows = X.bin_rows[bin];
+        if (nnz) *nnz = X.bin_nnz[bin];
         return 0;
     });
 }

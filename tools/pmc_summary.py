@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 counter-collection CSVs (one directory per --pmc pass, written under
+gpurun_out/ on the GPU box) into a small JSON that is committed under profiles/ and read by bench.py
+for the roofline "traffic" field.
+
+    python tools/pmc_summary.py gpurun_out/pmc_r01_* -o profiles/r01_pmc_summary.json
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE
+are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request, so reads are doubled.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dirs", nargs="+")
+    ap.add_argument("-o", "--out", required=True)
+    args = ap.parse_args()
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in args.dirs:
+        for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+            per_dispatch = collections.defaultdict(float)
+            names = {}
+            for r in csv.DictReader(open(f)):
+                key = (int(r["Dispatch_Id"]), r["Counter_Name"])
+                per_dispatch[key] += float(r["Counter_Value"])
+                names[int(r["Dispatch_Id"])] = r["Kernel_Name"]
+            for (disp, cname), v in sorted(per_dispatch.items()):
+                agg[names[disp]][cname].append(v)
+    out = {}
+    for kname, counters in agg.items():
+        if "cmfhip" not in kname:
+            continue
+        # bench.py launches B-step then A-step; the MODE=1 split-row kernels run max_cg_steps=3 times per half-step
+        per_half = 3 if (("vh_pass_kernel" in kname or "vh_update_kernel" in kname) and kname.split("(")[0].rstrip().endswith(", 1>")) else 1
+        ent = {}
+        for c, v in counters.items():
+            halves = [sum(v[i:i + per_half]) for i in range(0, len(v) - per_half + 1, per_half)]
+            ent[c] = {"mean": sum(v) / len(v), "launches": len(v),
+                      "per_halfstep_B": sum(halves[0::2]) / max(len(halves[0::2]), 1),
+                      "per_halfstep_A": sum(halves[1::2]) / max(len(halves[1::2]), 1)}
+        for step in ("A", "B"):
+            if "FETCH_SIZE" in ent:
+                ent["hbm_read_bytes_%s" % step] = ent["FETCH_SIZE"]["per_halfstep_" + step] * 1024 * 2
+            if "WRITE_SIZE" in ent:
+                ent["hbm_write_bytes_%s" % step] = ent["WRITE_SIZE"]["per_halfstep_" + step] * 1024
+        out[kname] = ent
+    json.dump({"note": "counter sums per half-step (bench.py order: B-step then A-step); FETCH_SIZE/WRITE_SIZE in KiB, "
+                       "FETCH_SIZE x2 gfx950 correction applied in hbm_read_bytes_*", "kernels": out},
+              open(args.out, "w"), indent=1, sort_keys=True)
+    print("wrote", args.out, len(out), "kernels")
+
+
+if __name__ == "__main__":
+    main()
