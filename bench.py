@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"],
+                    help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
+                         "MovieLens10M-shaped configs of BASELINE.json (single GPU, side measurements)")
     args = ap.parse_args()
 
     import torch
@@ -93,6 +96,8 @@ def main():
 
     from cmfrec_amd.session import AlsSession
     from cmfrec_amd.distributed import ShardedAls, GpuEngine
+    if args.workload != "c2":
+        return side_workload(args, local_rank)
 
     m_blk = int(M_USERS * args.scale); n = int(N_ITEMS * args.scale); nnz_blk = int(NNZ * args.scale)
     m = m_blk * world
@@ -153,10 +158,10 @@ def main():
     # ---- roofline of the dominant kernel (per nnz-bin launch of the CG row kernel) ----
     names = {0: "vh_pass+vh_update x4 (rows > 2048 nnz, split rows)", 1: "cg_rows_kernel<W=8> (257..2048 nnz)",
              2: "cg_rows_kernel<W=4> (129..256 nnz)", 3: "cg_rows_kernel<W=2> (65..128 nnz)",
-             4: "cg_rows_kernel<W=1> (<= 64 nnz)"}
+             4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel (<= 32 nnz)"}
     kernels = []
     for which in ("B", "A"):
-        for b in range(5):
+        for b in range(6):
             ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
             if cnt:
                 kernels.append(dict(step=which, kernel=names[b], ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
@@ -199,6 +204,43 @@ def main():
         dist.destroy_process_group()
 
 
+def side_workload(args, device):
+    """C1: CMF explicit ALS-CG k=50 fp64, biases + centering, lambda=0.05 scale_lam (MovieLens10M shape).
+    C3: CMF explicit ALS-Cholesky k=128 fp64 + dense item side info (q=64).  Synthetic ratings with
+    the SURVEY.md 8d generator (seed 1).  Prints per-iteration time and the half-step breakdown."""
+    from cmfrec_amd.session import AlsSession
+    m, n, nnz = int(69_878 * args.scale), int(10_677 * args.scale), int(10_000_054 * args.scale)
+    row, col, _ = synth_block(m, n, nnz, seed=1)
+    rng = np.random.default_rng(1)
+    val = 0.5 * rng.integers(1, 11, nnz)
+    val = val - val.mean()
+    chol = args.workload == "c3"
+    k = 128 if chol else 50
+    q = 64 if chol else 0
+    sess = AlsSession(m, n, k, implicit=False, dtype=np.float64, lam=0.05, use_cg=not chol, max_cg_steps=3,
+                      user_bias=True, item_bias=True, scale_lam=True, q=q, n_i=n if q else 0, device=device)
+    sess.set_X(to_csr(row, col, val, m), to_csr(col, row, val, n))
+    if q:
+        II = rng.standard_normal((n, q)); II -= II.mean(0)
+        sess.set_sideinfo(II=II)
+    sess.set_factors(A=rng.standard_normal((m, k)) * 2.0 ** -7, B=rng.standard_normal((n, k)) * 2.0 ** -7 if chol else np.zeros((n, k)),
+                     biasA=np.zeros(m), biasB=np.zeros(n), Dm=np.zeros((q, k)) if q else None)
+    import torch
+    for _ in range(args.warmup):
+        sess.iterate(1)
+    sess.sync(); sess.reset_timers()
+    t0 = time.perf_counter()
+    sess.iterate(args.steps)
+    sess.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    msA, cA = sess.kernel_time("A"); msB, cB = sess.kernel_time("B")
+    f = sess.get_factors()
+    print(json.dumps({"workload": args.workload, "ms_per_iteration": round(dt * 1e3, 3), "rows_per_s": round((m + n) / dt, 1),
+                      "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "k": k, "m": m, "n": n, "nnz": nnz,
+                      "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
+                      "note": "side measurement, not the headline metric"}))
+
+
 def pmc_traffic(dom):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_latest.json, produced by tools/pmc_summary.py from separate --pmc runs of this
@@ -208,13 +250,13 @@ def pmc_traffic(dom):
         return None
     ks = json.load(open(path))["kernels"]
     tags = {"cg_rows_kernel<W=8>": [", 8, 1>"], "cg_rows_kernel<W=4>": [", 4, 1>"], "cg_rows_kernel<W=2>": [", 2, 1>"],
-            "cg_rows_kernel<W=1>": [", 1, 4>"],
+            "cg_rows_kernel<W=1>": [", 1, 4>"], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel"],
             "vh_pass": ["vh_pass_kernel", "vh_update_kernel"]}
     want = next(v for k, v in tags.items() if dom["kernel"].startswith(k))
     tot, found = 0.0, False
     for name, ent in ks.items():
         head = name.split("(")[0]
-        if any(t in head for t in want) and ("cg_rows_kernel" in head) == ("cg_rows" in dom["kernel"]):
+        if any(t in head for t in want) and ("cg_rows_kernel<" in head) == dom["kernel"].startswith("cg_rows_kernel"):
             r = ent.get("hbm_read_bytes_" + dom["step"]); w = ent.get("hbm_write_bytes_" + dom["step"])
             if r is not None and w is not None:
                 tot += r + w; found = True

@@ -71,13 +71,14 @@ struct DevBuf {
 // stride over the sorted list, which balances the heavy-tailed row lengths the reference handles
 // with `omp schedule(dynamic)` (common.c:3259,3349).  A row of a bin with W waves per row keeps its
 // gathered tiles in registers when it has <= 64*W non-zeros.
-constexpr int NBINS = 5;
+constexpr int NBINS = 6;
 constexpr int BIN_VHEAVY = 0;   // > 2048 nnz : every CG pass split over many workgroups (vh_* kernels)
 constexpr int BIN_HEAVY = 1;    // 257..2048  : 8 waves / row (register-resident up to 512 nnz, else re-streamed)
 constexpr int BIN_MED4 = 2;     // 129..256   : 4 waves / row
 constexpr int BIN_MED2 = 3;     // 65..128    : 2 waves / row
-constexpr int BIN_LIGHT = 4;    // 1..64      : 1 wave / row, 4 rows / workgroup
-constexpr int BIN_MIN_NNZ[NBINS] = {2049, 257, 129, 65, 1};
+constexpr int BIN_LIGHT = 4;    // 33..64     : 1 wave / row, 4 rows / workgroup
+constexpr int BIN_TINY = 5;     // 1..32      : 1 wave / row, half-size tiles, double-buffered gather
+constexpr int BIN_MIN_NNZ[NBINS] = {2049, 257, 129, 65, 33, 1};
 inline int bin_of(long long nnz)
 {
     for (int b = 0; b < NBINS; b++)
@@ -93,9 +94,9 @@ struct SparseShard {
     DevBuf<real_t> v;
     DevBuf<int> order;       // row ids sorted by nnz descending: [bin 0 | bin 1 | ... | bin 4 | empty rows]
     DevBuf<RowDesc> desc;    // same order: {row, nnz, CSR offset}
-    int bin_rows[NBINS] = {0, 0, 0, 0, 0};
-    int bin_first[NBINS] = {0, 0, 0, 0, 0};
-    size_t bin_nnz[NBINS] = {0, 0, 0, 0, 0};
+    int bin_rows[NBINS] = {0, 0, 0, 0, 0, 0};
+    int bin_first[NBINS] = {0, 0, 0, 0, 0, 0};
+    size_t bin_nnz[NBINS] = {0, 0, 0, 0, 0, 0};
     int n_nonempty = 0, n_empty = 0;
     int max_nnz = 0;
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
@@ -252,6 +253,36 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
+template <int S, bool IMPLICIT>
+inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm)
+{
+    if (count <= 0) return;
+    EventPair ev{nullptr, nullptr};
+    if (tm) {
+        HIP_CHECK(hipEventCreate(&ev.a));
+        HIP_CHECK(hipEventCreate(&ev.b));
+        HIP_CHECK(hipEventRecord(ev.a, dev.stream));
+    }
+    P.order += first;
+    P.desc += first;
+    P.nrows = count;
+    size_t smem = (IMPLICIT ? (size_t)64 * gram_ld(S) : 0) * sizeof(real_t);
+    auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT>;
+    static thread_local int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int nb = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
+        blocks_per_cu = std::max(1, nb);
+    }
+    int grid = std::min((count + 3) / 4, dev.num_cus * blocks_per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, dev.stream, P);
+    HIP_CHECK(hipGetLastError());
+    if (tm) {
+        HIP_CHECK(hipEventRecord(ev.b, dev.stream));
+        tm->ev[BIN_TINY].push_back(ev);
+    }
+}
+
 // very heavy rows: one (pass, update) launch pair per CG pass
 template <int S, bool IMPLICIT>
 inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, BinTimers *tm)
@@ -269,7 +300,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const Sp
     V.chunk_row = X.vh_chunk_row.ptr; V.chunk_first = X.vh_chunk_first.ptr; V.chunk_off = X.vh_chunk_off.ptr;
     V.nvh = nvh; V.nchunks = X.n_chunks;
     P.nrows = nvh;
-    const dim3 gp(X.n_chunks), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64);
+    const dim3 gp(X.n_chunks), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64 * VH_UPD_WAVES);
     hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 0>), gp, bp, 0, dev.stream, P, V);
     hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0>), gu, bu, 0, dev.stream, P, V);
     for (int step = 0; step < P.max_cg_steps; step++) {
@@ -292,6 +323,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4);
     launch_cg_bin<S, IMPLICIT, 2, 1>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2);
     launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT);
+    launch_cg_tiny<S, IMPLICIT>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm);
 }
 
 template <int NF, bool IMPLICIT>

@@ -219,9 +219,10 @@ int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which);
 /* HIP-event time (ms) and launch count of the row-update kernels of `which` ('A' or 'B') since
  * the last reset; synchronises the stream. */
 int cmfrec_hip_session_kernel_time(cmfrec_hip_session *s, int which, double *ms, long *launches);
-/* Per-kernel figures of the CG row-update launches of `which`.  Rows are scheduled in five nnz bins,
+/* Per-kernel figures of the CG row-update launches of `which`.  Rows are scheduled in six nnz bins,
  * one persistent launch each: bin 1: 257..2048 nnz (8 waves/row), 2: 129..256 (4 waves/row),
- * 3: 65..128 (2 waves/row), 4: 1..64 (1 wave/row); bin 0: rows > 2048 nnz, whose CG passes are
+ * 3: 65..128 (2 waves/row), 4: 33..64 (1 wave/row), 5: 1..32 (1 wave/row, half tiles, double-buffered
+ * gather); bin 0: rows > 2048 nnz, whose CG passes are
  * split over many workgroups (one launch pair per pass; the figure covers the whole sequence).
  * ms = summed HIP-event time of that bin's launches since the last reset. */
 int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, double *ms, long *launches,
