@@ -76,6 +76,76 @@ gram_reduce_kernel(const T *__restrict__ partial, int nblocks, int nent,
     if (lane == 0) out[ent] = s;
 }
 
+// MFMA Gramian (k <= 64): the dense B^T B precompute on the matrix cores.
+//   fp64: v_mfma_f64_16x16x4_f64   A[i=l&15][kk=l>>4], B[kk=l>>4][j=l&15], D col=l&15, row=(l>>4)+4*reg
+//   fp32: v_mfma_f32_16x16x4_f32   same A/B operand map,                   D col=l&15, row=(l>>4)*4+reg
+// One MFMA step consumes 4 rows of B: every lane loads B[row0 + (l>>4)][16*cb + (l&15)] for the
+// (up to 4) column blocks -- 4 rows x 128 B per block, coalesced -- and the 10 upper 16x16 tiles
+// are updated with tile(bi,bj) += val[bi]^T val[bj].  A workgroup (4 waves) owns a slab of rows,
+// its waves' accumulators are added in wave order through LDS and written as [entry][block]
+// partials for the same deterministic second stage as the VALU version.
+template <typename T> struct MfmaAcc;
+template <> struct MfmaAcc<double> {
+    typedef double vec __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vec mma(double a, double b, vec c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct MfmaAcc<float> {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vec mma(float a, float b, vec c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gram_mfma_partial_kernel(const T *__restrict__ B, size_t ldb, int n, int k, int rows_per_block,
+                         T *__restrict__ partial)
+{
+    using Acc = MfmaAcc<T>;
+    using vec = typename Acc::vec;
+    __shared__ T red[4][10][4][64];                       // [wave][tile][reg][lane]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(n, r0 + rows_per_block);
+    const int kk = lane >> 4, cc = lane & 15;
+    vec acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) acc[t] = vec{0, 0, 0, 0};
+    for (int rb = r0 + 4 * wave; rb < r1; rb += 16) {
+        const int row = rb + kk;
+        T val[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            const int col = 16 * cb + cc;
+            val[cb] = (row < r1 && col < k) ? B[(size_t)row * ldb + col] : T(0);
+        }
+        int t = 0;
+#pragma unroll
+        for (int bi = 0; bi < 4; bi++)
+#pragma unroll
+            for (int bj = bi; bj < 4; bj++) { acc[t] = Acc::mma(val[bi], val[bj], acc[t]); t++; }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][t][r][lane] = acc[t][r];
+    __syncthreads();
+    // entry (i,j) with i in tile-row bi, j in tile-col bj: thread -> (tile, reg, lane)
+    for (int e = threadIdx.x; e < 10 * 4 * 64; e += 256) {
+        const int t = e / 256, r = (e / 64) % 4, l = e % 64;
+        int bi = 0, rem = t;
+        while (rem >= 4 - bi) { rem -= 4 - bi; bi++; }
+        const int bj = bi + rem;
+        const int i = 16 * bi + Acc::row_of(l, r), j = 16 * bj + (l & 15);
+        if (i < k && j < k) {
+            T sum = red[0][t][r][l];
+            sum += red[1][t][r][l]; sum += red[2][t][r][l]; sum += red[3][t][r][l];
+            partial[(size_t)(i * k + j) * gridDim.x + blockIdx.x] = sum;
+            if (bi != bj || i != j) partial[(size_t)(j * k + i) * gridDim.x + blockIdx.x] = sum;
+        }
+    }
+}
+
 // generic-k fallback for the Gramian (k > 64): one thread per entry, rows streamed from L2.
 template <typename T>
 __global__ void gram_naive_kernel(const T *__restrict__ B, size_t ldb, int n, int k,

@@ -190,9 +190,15 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
         if (nblocks < 1) nblocks = 1;
         size_t need = (size_t)nblocks * k * k;
         if (ws.partial.n < need) ws.partial.alloc(need);
-        size_t smem = (size_t)32 * k * sizeof(real_t);
-        hipLaunchKernelGGL(gram_partial_kernel<real_t>, dim3(nblocks), dim3(256), smem, dev.stream,
-                           B, ldb, n, k, rpb, ws.partial.ptr);
+        static const bool use_valu = getenv("CMFREC_HIP_GRAM_VALU") != nullptr;    // A/B switch, MFMA is the default
+        if (use_valu) {
+            size_t smem = (size_t)32 * k * sizeof(real_t);
+            hipLaunchKernelGGL(gram_partial_kernel<real_t>, dim3(nblocks), dim3(256), smem, dev.stream,
+                               B, ldb, n, k, rpb, ws.partial.ptr);
+        } else {
+            hipLaunchKernelGGL(gram_mfma_partial_kernel<real_t>, dim3(nblocks), dim3(256), 0, dev.stream,
+                               B, ldb, n, k, rpb, ws.partial.ptr);
+        }
         hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 3) / 4), dim3(256), 0, dev.stream,
                            ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
     } else {

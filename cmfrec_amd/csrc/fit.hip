@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/cmfrec_hip.h"
+#include "rng_host.hpp"
 
 namespace {
 
@@ -38,49 +39,6 @@ void coo_to_csr_csc(const int_t *row, const int_t *col, const real_t *val, int_t
         ri[a] = col[e]; rv[a] = val[e];
         size_t b = nc[col[e]]++;
         ci[b] = row[e]; cv[b] = val[e];
-    }
-}
-
-// ---- xoshiro256++ start values (Blackman & Vigna; splitmix64 seeding) ------------------------
-// NOTE: the draw stream is NOT bit-compatible with the reference's ziggurat sampler
-// (helpers.c:653-748) yet; parity runs inject the start values with reset_values=false.
-struct Xoshiro {
-    uint64_t s[4];
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    explicit Xoshiro(uint64_t seed)
-    {
-        for (int i = 0; i < 4; i++) {
-            uint64_t z = (seed += 0x9e3779b97f4a7c15ULL);
-            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-            z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-            s[i] = z ^ (z >> 31);
-        }
-    }
-    uint64_t next()
-    {
-        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
-        const uint64_t t = s[1] << 17;
-        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return result;
-    }
-    double unif() { return (double)(next() >> 11) * 0x1.0p-53; }
-};
-
-void fill_random(real_t *arr, size_t n, int_t seed, bool normal, uint64_t stream)
-{
-    Xoshiro rng((uint64_t)(uint32_t)seed * 0x9E3779B1ULL + stream * 0xD1B54A32D192ED03ULL + 1);
-    if (!normal) {
-        for (size_t i = 0; i < n; i++) arr[i] = (real_t)(rng.unif() * 0x1.0p-7);
-        return;
-    }
-    for (size_t i = 0; i < n; i += 2) {   // Box-Muller, scaled 2^-7 like the reference's start values
-        double u1 = rng.unif(), u2 = rng.unif();
-        if (u1 < 1e-300) u1 = 1e-300;
-        double r = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586 * u2;
-        arr[i] = (real_t)(r * std::cos(th) * 0x1.0p-7);
-        if (i + 1 < n) arr[i + 1] = (real_t)(r * std::sin(th) * 0x1.0p-7);
     }
 }
 
@@ -138,6 +96,13 @@ int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool
 
 extern "C" {
 
+/* Start values exactly as the reference's random_parallel (helpers.c:927-1043) draws them. */
+int cmfrec_hip_random_parallel(real_t *A, size_t sizeA, real_t *B, size_t sizeB, int_t seed, bool normal)
+{
+    cmfrng::random_parallel<real_t>(A, sizeA, B, sizeB, seed, normal);
+    return CMF_ZIGGURAT_TABLES_EXACT;
+}
+
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B, real_t *C, real_t *D, bool reset_values, int_t seed,
     real_t *U_colmeans, real_t *I_colmeans, int_t m, int_t n, int_t k,
@@ -181,10 +146,10 @@ int_t fit_collective_implicit_als(
     std::vector<real_t>().swap(Xs);
 
     const int ktot = k + k_main;
-    if (reset_values) {                                                  // :9750-9774
-        fill_random(A, (size_t)m * ktot, seed, false, 0);
+    if (reset_values) {                                                  // :9750-9774 (no item side info: only A is drawn)
+        cmfrng::random_parallel<real_t>(A, (size_t)m * ktot, nullptr, 0, seed, false);
         if (use_cg) memset(B, 0, (size_t)n * ktot * sizeof(real_t));
-        else fill_random(B, (size_t)n * ktot, seed, false, 1);           // values are irrelevant for Cholesky
+        // Cholesky: B's start values are never read (the B-step runs first), left as passed like the reference
     }
     if (!use_cg) finalize_chol = false;                                  // :9518
 
@@ -317,14 +282,11 @@ int_t fit_collective_explicit_als(
     // ---- factor start values, collective.c:8241-8274 ----
     if (reset_values) {
         const bool fill_B = (II != nullptr);
-        fill_random(A, (size_t)m * k_totA, seed, true, 0);
-        if (fill_B) fill_random(B, (size_t)n * k_totB, seed, true, 1);
+        cmfrng::random_parallel<real_t>(A, (size_t)m * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n * k_totB : 0, seed, true);
         if (use_cg) {
             if (!fill_B) memset(B, 0, (size_t)n * k_totB * sizeof(real_t));
             if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
             if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
-        } else if (!fill_B) {
-            fill_random(B, (size_t)n * k_totB, seed, true, 1);            // values are irrelevant for Cholesky
         }
     }
 

@@ -233,6 +233,12 @@ void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
  * are built on; returns the number of mismatching lanes (0 = ok), negative = HIP failure. */
 int cmfrec_hip_selftest_lanes(void);
 
+/* Start values as the reference's random_parallel draws them (src/helpers.c:927-1043; xoshiro256++
+ * seeded by splitmix64, truncated ziggurat normals or uniforms, scaled 2^-7): A <- stream(seed),
+ * B <- the stream jumped once.  Host-only.  Returns 1 if the ziggurat tables are NumPy's exact
+ * constants, 0 if they were recomputed (<= 1 ulp apart). */
+int cmfrec_hip_random_parallel(real_t *A, size_t sizeA, real_t *B, size_t sizeB, int_t seed, bool normal);
+
 /* Build info: sizeof(real_t), and the gfx target the kernels were compiled for. */
 int cmfrec_hip_sizeof_real(void);
 const char *cmfrec_hip_build_info(void);

@@ -92,3 +92,31 @@ def test_fit_explicit_sideinfo(oracles, dtype, useU, useI, ku, ki, km, sls):
         assert frob(mdl.C_, ro["C"]) < t
     if useI:
         assert frob(mdl.D_, ro["D"]) < t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_seeded_fit_matches_reference_seed(dtype):
+    """reset_values=true: the start values come from the seed exactly as in the reference
+    (xoshiro256++ / ziggurat, helpers.c:927-1043), so a seeded fit() reproduces the reference's own
+    seeded fit -- checked against the real reference where oracle/_ref is available."""
+    from oracle.bindings import Reference, ref_available
+    if not ref_available(dtype):
+        pytest.skip("oracle/_ref not built")
+    from cmfrec_amd import CMF, CMF_implicit
+    R = Reference(dtype)
+    uf = dtype is np.float32
+    m, n, k = 700, 500, 24
+    row, col, val = make_coo(m, n, 20000, 31, dtype=dtype)
+    mdl = CMF_implicit(k=k, lambda_=3., niter=3, random_state=123, use_float=uf).fit((row, col, val), shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+    R.fit_collective_implicit_als(Ar, Br, row, col, val, k, lam=3., niter=3, nthreads=2, reset_values=True, seed=123)
+    t = 1e-6 if dtype is np.float64 else 1e-2
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t
+    row, col, val = make_coo(m, n, 20000, 32, counts=False, dtype=dtype)
+    mdl = CMF(k=k, lambda_=0.05, scale_lam=True, niter=3, random_state=7, use_float=uf, nthreads=1).fit(
+        (row, col, val), shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+    rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, scale_lam=True, niter=3, nthreads=2,
+                                       reset_values=True, seed=7)
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t
+    assert frob(mdl.user_bias_, rr["biasA"]) < t and frob(mdl.item_bias_, rr["biasB"]) < t
