@@ -255,11 +255,25 @@ int_t fit_collective_explicit_als(
 
     // ---- bias start values, common.c:4410-4909 (sparse, unweighted; both biases) ----
     if (has_bias && reset_values) {
-        if (user_bias != item_bias)
-            return fail(verbose, "cmfrec_hip: reset_values with a single bias is not implemented (initialize_biases_onesided).");
         real_t lam_u = lam, lam_i = lam;
         if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
         if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
+        // initialize_biases_onesided, common.c:4265-4289 (sparse, unweighted, missing-as-NA)
+        auto onesided = [&](const std::vector<size_t> &ptr, const std::vector<real_t> &vals, int_t rows, real_t lam_b,
+                            real_t *bias) {
+            for (int_t r = 0; r < rows; r++) {
+                double bm = 0;
+                size_t st = ptr[r], en = ptr[(size_t)r + 1], cnt = en - st;
+                for (size_t e = st; e < en; e++) bm += (vals[e] - bm) / (double)(e - st + 1);
+                bm *= (double)cnt / ((double)cnt + lam_b * (scale_lam ? (double)(cnt > 1 ? cnt : 1) : 1.));
+                bias[r] = (real_t)bm;
+            }
+        };
+        if (user_bias && !item_bias) {                                    // collective.c:8166-8185
+            onesided(rp, rv, m, lam_u, biasA);
+        } else if (item_bias && !user_bias) {                             // :8187-8204 (only when the B-step uses CG)
+            if (use_cg) onesided(cp, cv, n, lam_i, biasB);
+        } else {
         memset(biasA, 0, (size_t)m * sizeof(real_t));
         memset(biasB, 0, (size_t)n * sizeof(real_t));
         for (int sweep = 0; sweep < 5; sweep++) {
@@ -277,6 +291,7 @@ int_t fit_collective_explicit_als(
                 if (cnt > 0) bm *= (double)cnt / ((double)cnt + lam_u * (scale_lam ? (double)cnt : 1.));
                 biasA[r] = (real_t)bm;
             }
+        }
         }
     }
     // ---- factor start values, collective.c:8241-8274 ----

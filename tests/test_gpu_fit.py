@@ -120,3 +120,15 @@ def test_seeded_fit_matches_reference_seed(dtype):
                                        reset_values=True, seed=7)
     assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t
     assert frob(mdl.user_bias_, rr["biasA"]) < t and frob(mdl.item_bias_, rr["biasB"]) < t
+    # a single bias: one-sided bias initialisation (common.c:4130-4289)
+    for ub, ib in ((True, False), (False, True)):
+        mdl = CMF(k=k, lambda_=0.05, scale_lam=True, niter=3, random_state=9, use_float=uf, nthreads=1, user_bias=ub,
+                  item_bias=ib).fit((row, col, val), shape=(m, n))
+        Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+        rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, scale_lam=True, niter=3, nthreads=2,
+                                           reset_values=True, seed=9, user_bias=ub, item_bias=ib)
+        assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t, (ub, ib)
+        if ub:
+            assert frob(mdl.user_bias_, rr["biasA"]) < t
+        if ib:
+            assert frob(mdl.item_bias_, rr["biasB"]) < t
