@@ -61,6 +61,7 @@ struct CgParams {
     T lam, lam_last;
     int scale_lam, scale_bias_const;
     int max_cg_steps;
+    int precond;          // Jacobi-preconditioned CG (factors_*_pcg): generic kernel only
 };
 
 template <typename T>
@@ -784,6 +785,59 @@ cg_rows_generic_kernel(const CgParams<T> P)
             if (f >= k) r[c] = T(0);
             p[c] = r[c];
         }
+        if (P.precond) {
+            // factors_implicit_pcg common.c:1988-2061 / factors_explicit_pcg :1190-1291:
+            // Jacobi preconditioner, fixed number of steps, no early exits
+            T PC[NF], z[NF];
+#pragma unroll
+            for (int c = 0; c < NF; c++) PC[c] = T(0);
+            for (int j = 0; j < nnz; j++) {
+                const int idx = P.indices[st + j];
+                T x = P.values[st + j];
+                const T *b = P.B + (size_t)idx * P.ldb;
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    int f = lane + 64 * c;
+                    T bv = (f < k) ? b[f] : T(0);
+                    PC[c] += IMPLICIT ? x * (bv * bv) : bv * bv;                 // :2009-2014 / :1238-1243
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NF; c++) {
+                int f = lane + 64 * c;
+                if (IMPLICIT) PC[c] += (f < k) ? P.BtB[(size_t)f * k + f] : T(1);
+                else {
+                    PC[c] += lam;
+                    if (lam != lam_last && f == k - 1) PC[c] += (lam_last - lam);
+                }
+                PC[c] = T(1) / PC[c];
+                z[c] = (f < k) ? r[c] * PC[c] : T(0);
+                p[c] = z[c];
+            }
+            T r_old = vdot(z, r);
+            for (int step = 0; step < P.max_cg_steps; step++) {
+                matvec(p, Ap, 1);
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    int f = lane + 64 * c;
+                    Ap[c] += lam * p[c];
+                    if (!IMPLICIT && lam != lam_last && f == k - 1) Ap[c] += (lam_last - lam) * p[c];
+                    if (f >= k) Ap[c] = T(0);
+                }
+                T alpha = r_old / vdot(Ap, p);
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    int f = lane + 64 * c;
+                    a[c] += alpha * p[c]; r[c] -= alpha * Ap[c];
+                    z[c] = (f < k) ? r[c] * PC[c] : T(0);
+                }
+                T r_new = vdot(z, r);
+                T ratio = r_new / r_old;
+#pragma unroll
+                for (int c = 0; c < NF; c++) p[c] = p[c] * ratio + z[c];
+                r_old = r_new;
+            }
+        } else {
         T r_old = vdot(r, r);
         if (r_old > (T)1e-12) {
             for (int step = 0; step < P.max_cg_steps; step++) {
@@ -805,6 +859,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 for (int c = 0; c < NF; c++) p[c] = p[c] * ratio + r[c];
                 r_old = r_new;
             }
+        }
         }
 #pragma unroll
         for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f < k) arow[f] = a[c]; }

@@ -220,6 +220,7 @@ struct CgCall {
     bool scale_lam, scale_bias_const;
     int max_cg_steps;
     bool implicit;
+    bool precond = false;
 };
 
 enum class CgVariant { Auto, Generic };
@@ -352,8 +353,10 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_bias_const = c.scale_bias_const;
     P.max_cg_steps = c.max_cg_steps;
+    P.precond = c.precond ? 1 : 0;
     const int S = (c.k + 7) / 8;
-    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8;
+    // the Jacobi-preconditioned variant (not a default anywhere in the reference) runs on the generic kernel
+    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond;
     if (!generic) {
 #define CMF_CASE(SS)                                                        \
     case SS:                                                                \

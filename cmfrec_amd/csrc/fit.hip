@@ -129,8 +129,8 @@ int_t fit_collective_implicit_als(
     if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
     if (U || II || U_sp || I_sp || nnz_U || nnz_I)
         return fail(verbose, "cmfrec_hip: implicit model with side information is not implemented (SURVEY 8f-1).");
-    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || precondition_cg || adjust_weight || precompute_for_predictions)
-        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / precondition_cg / adjust_weight / precompute_for_predictions are not implemented.");
+    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight || precompute_for_predictions)
+        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / adjust_weight / precompute_for_predictions are not implemented.");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
@@ -156,7 +156,7 @@ int_t fit_collective_implicit_als(
     cmfrec_hip_model mdl;
     memset(&mdl, 0, sizeof mdl);
     mdl.implicit = 1; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main;
-    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.lam = lam; mdl.w_user = 1; mdl.w_item = 1;
+    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.lam = lam; mdl.w_user = 1; mdl.w_item = 1;
     mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
@@ -201,8 +201,8 @@ int_t fit_collective_explicit_als(
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
     if (Xfull || weight || NA_as_zero_X || U_sp || I_sp || nnz_U || nnz_I || add_implicit_features)
         return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / sparse side info / implicit features are not implemented.");
-    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || precondition_cg || scale_bias_const || precompute_for_predictions)
-        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / precondition_cg / scale_bias_const / precompute_for_predictions are not implemented.");
+    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const || precompute_for_predictions)
+        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / scale_bias_const / precompute_for_predictions are not implemented.");
     if (U == nullptr) { m_u = 0; p = 0; }
     if (II == nullptr) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
@@ -309,7 +309,7 @@ int_t fit_collective_explicit_als(
     memset(&mdl, 0, sizeof mdl);
     mdl.implicit = 0; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
     mdl.user_bias = user_bias; mdl.item_bias = item_bias; mdl.scale_lam = scale_lam; mdl.scale_lam_sideinfo = scale_lam_sideinfo;
-    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i;
+    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i;
     mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);

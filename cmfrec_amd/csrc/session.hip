@@ -176,10 +176,6 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
             g_last_error = "cmfrec_hip: side information requires the Cholesky solver (block-CG not implemented)";
             return 2;
         }
-        if (m.precondition_cg) {
-            g_last_error = "cmfrec_hip: precondition_cg is not implemented";
-            return 2;
-        }
         s = new cmfrec_hip_session();
         s->mdl = m;
         init_device(s->dev, device);
@@ -341,7 +337,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
             return launch_chol(dev, c, &X);
         }
         CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, nullptr, s->gram.ptr,
-                 m.lam, m.lam, false, false, m.max_cg_steps, true};
+                 m.lam, m.lam, false, false, m.max_cg_steps, true, (bool)m.precondition_cg};
         return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
     }
 
@@ -380,7 +376,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
         return launch_chol(dev, c, &X);
     }
     CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, bias_sub, nullptr,
-             m.lam, m.lam, scale_lam, false, m.max_cg_steps, false};
+             m.lam, m.lam, scale_lam, false, m.max_cg_steps, false, (bool)m.precondition_cg};
     return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
 }
 
@@ -549,7 +545,6 @@ int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t
                                   bool use_cg, bool precondition_cg, int_t max_cg_steps, real_t *BtB_out)
 {
     return guarded([&]() {
-        if (precondition_cg) { g_last_error = "cmfrec_hip: precondition_cg is not implemented"; return 2; }
         DeviceInfo dev;
         init_device(dev, -1);
         DevBuf<real_t> dA, dB, dG;
@@ -562,7 +557,7 @@ int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t
         launch_gram(dev, gws, dB.ptr, ldb, n, k, dG.ptr, (real_t)1, use_cg ? (real_t)0 : lam);
         int rc;
         if (use_cg) {
-            CgCall c{dA.ptr, lda, dB.ptr, ldb, k, nullptr, dG.ptr, lam, lam, false, false, max_cg_steps, true};
+            CgCall c{dA.ptr, lda, dB.ptr, ldb, k, nullptr, dG.ptr, lam, lam, false, false, max_cg_steps, true, precondition_cg};
             rc = launch_cg(dev, c, X);
         } else {
             // common.c:3334 zeroes m*k - (lda-k) elements from A
@@ -584,7 +579,6 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
                                   bool scale_bias_const, bool use_cg, bool precondition_cg, int_t max_cg_steps)
 {
     return guarded([&]() {
-        if (precondition_cg) { g_last_error = "cmfrec_hip: precondition_cg is not implemented"; return 2; }
         DeviceInfo dev;
         init_device(dev, -1);
         DevBuf<real_t> dA, dB, dbias;
@@ -596,7 +590,7 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
         int rc;
         if (use_cg) {
             CgCall c{dA.ptr, lda, dB.ptr, ldb, k, bias_sub ? dbias.ptr : nullptr, nullptr, lam, lam_last, scale_lam,
-                     scale_bias_const, max_cg_steps, false};
+                     scale_bias_const, max_cg_steps, false, precondition_cg};
             rc = launch_cg(dev, c, X);
         } else {
             CholCall c{dA.ptr, lda, dB.ptr, ldb, k, 0, bias_sub ? dbias.ptr : nullptr, nullptr, 0, 0, 0, lam, lam_last,

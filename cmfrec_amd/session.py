@@ -13,7 +13,7 @@ class AlsSession:
     def __init__(self, m, n, k, implicit, dtype=np.float64, lam=1.0, use_cg=True, max_cg_steps=3,
                  k_main=0, k_user=0, k_item=0, user_bias=False, item_bias=False, scale_lam=False,
                  scale_lam_sideinfo=False, p=0, q=0, m_u=0, n_i=0, w_user=1.0, w_item=1.0,
-                 row_range=None, col_range=None, device=-1):
+                 row_range=None, col_range=None, device=-1, precondition_cg=False):
         self.dtype = np.dtype(dtype).type
         self.lib = _lib.load(self.dtype)
         M = _lib.Model if self.dtype is np.float64 else _lib.ModelF
@@ -21,7 +21,7 @@ class AlsSession:
         cb, ce = (0, n) if col_range is None else col_range
         self.model = M(implicit=int(implicit), m=m, n=n, k=k, k_main=k_main, k_user=k_user, k_item=k_item,
                        user_bias=int(user_bias), item_bias=int(item_bias), scale_lam=int(scale_lam),
-                       scale_lam_sideinfo=int(scale_lam_sideinfo), use_cg=int(use_cg), precondition_cg=0,
+                       scale_lam_sideinfo=int(scale_lam_sideinfo), use_cg=int(use_cg), precondition_cg=int(precondition_cg),
                        max_cg_steps=max_cg_steps, p=p, q=q, m_u=m_u, n_i=n_i, lam=lam, w_user=w_user,
                        w_item=w_item, row_begin=rb, row_end=re, col_begin=cb, col_end=ce)
         self.m, self.n, self.k = m, n, k

@@ -17,11 +17,11 @@ def frob(a, b):
 def tol(dtype, mode):
     if dtype is np.float64:
         return 1e-6
-    return 1e-2 if "cg" in mode else 1e-3
+    return 1e-2 if "cg" in mode else 1e-3     # "pcg" contains "cg"
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("mode", ["cg", "chol", "cg+fin"])
+@pytest.mark.parametrize("mode", ["cg", "chol", "cg+fin", "pcg"])
 def test_fit_implicit(oracles, dtype, mode):
     from cmfrec_amd import CMF_implicit
     O = oracles[dtype]
@@ -30,7 +30,7 @@ def test_fit_implicit(oracles, dtype, mode):
     rng = np.random.default_rng(1)
     A0 = (rng.standard_normal((m, k)) * 0.01).astype(dtype)
     B0 = np.zeros((n, k), dtype)
-    kw = dict(niter=4, use_cg=mode != "chol", finalize_chol=mode == "cg+fin")
+    kw = dict(niter=4, use_cg=mode != "chol", finalize_chol=mode == "cg+fin", precondition_cg=mode == "pcg")
     mdl = CMF_implicit(k=k, lambda_=5., alpha=1.5, use_float=dtype is np.float32, **kw).fit(
         (row, col, val), shape=(m, n), A0=A0, B0=B0)
     Ao, Bo = A0.copy(), B0.copy()
@@ -39,7 +39,7 @@ def test_fit_implicit(oracles, dtype, mode):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("mode,ub,ib", [("cg", True, True), ("chol", True, True), ("cg+fin", True, True),
+@pytest.mark.parametrize("mode,ub,ib", [("cg", True, True), ("chol", True, True), ("cg+fin", True, True), ("pcg", True, True),
                                         ("cg", False, False), ("cg", True, False), ("chol", False, True)])
 def test_fit_explicit(oracles, dtype, mode, ub, ib):
     from cmfrec_amd import CMF
@@ -51,7 +51,7 @@ def test_fit_explicit(oracles, dtype, mode, ub, ib):
     B0 = np.zeros((n, k), dtype)
     bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
     kw = dict(niter=3, use_cg=mode != "chol", finalize_chol=mode == "cg+fin", user_bias=ub, item_bias=ib,
-              scale_lam=True)
+              scale_lam=True, precondition_cg=mode == "pcg")
     mdl = CMF(k=k, lambda_=0.05, use_float=dtype is np.float32, nthreads=1, **kw).fit(
         (row, col, val), shape=(m, n), A0=A0, B0=B0, biasA0=bA, biasB0=bB)
     Ao, Bo = A0.copy(), B0.copy()

@@ -15,9 +15,9 @@ TOL_FIT = {np.float64: 1e-6, np.float32: 1e-2}
 def test_operators(oracles, dtype):
     from cmfrec_amd import ops
     O = oracles[dtype]   # only used for the (exact) COO -> CSR conversion of the stored triplets
-    for name, got, exp in gc.implicit_cases(gc.load("g1_implicit", dtype), O, ops.optimizeA_implicit, modes=("cg", "chol")):
+    for name, got, exp in gc.implicit_cases(gc.load("g1_implicit", dtype), O, ops.optimizeA_implicit):
         assert gc.maxrel(got, exp) < TOL[dtype], name
-    for name, got, exp in gc.explicit_cases(gc.load("g2_explicit", dtype), O, ops.optimizeA_explicit, modes=("cg", "chol")):
+    for name, got, exp in gc.explicit_cases(gc.load("g2_explicit", dtype), O, ops.optimizeA_explicit):
         assert gc.maxrel(got, exp) < TOL[dtype], name
     for name, got, exp in gc.collective_cases(gc.load("g3_collective", dtype), O, ops.optimizeA_collective):
         assert gc.maxrel(got, exp) < TOL[dtype], name

@@ -12,7 +12,7 @@ TOL = {np.float64: 1e-10, np.float32: 2e-4}
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("k", [8, 50, 64])
-@pytest.mark.parametrize("mode", ["cg", "chol"])
+@pytest.mark.parametrize("mode", ["cg", "chol", "pcg"])
 def test_optimizeA_implicit(oracles, dtype, k, mode):
     from cmfrec_amd import ops
     O = oracles[dtype]
@@ -23,12 +23,12 @@ def test_optimizeA_implicit(oracles, dtype, k, mode):
     A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
     B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
     Ah, Ao = A0.copy(), A0.copy()
-    kw = dict(use_cg=mode == "cg", max_cg_steps=3)
+    kw = dict(use_cg=mode != "chol", precondition_cg=mode == "pcg", max_cg_steps=3)
     Gh = ops.optimizeA_implicit(Ah, B, csr, 4.0, return_BtB=True, **kw)
     Go = O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, return_BtB=True, **kw)
     assert rel_err(Gh, Go) < TOL[dtype]
     assert rel_err(Ah, Ao) < TOL[dtype]
-    if mode == "cg":   # empty rows are left untouched by the CG path (common.c:3354)
+    if mode != "chol":   # empty rows are left untouched by the CG path (common.c:3354)
         assert np.array_equal(Ah[5], A0[5]) and np.array_equal(Ah[17], A0[17])
     else:              # and zeroed by the Cholesky path (common.c:3334)
         assert not Ah[5].any()
@@ -36,7 +36,7 @@ def test_optimizeA_implicit(oracles, dtype, k, mode):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("k,pad", [(51, 1), (16, 0), (33, 2)])
-@pytest.mark.parametrize("mode", ["cg", "chol"])
+@pytest.mark.parametrize("mode", ["cg", "chol", "pcg"])
 def test_optimizeA_explicit(oracles, dtype, k, pad, mode):
     from cmfrec_amd import ops
     O = oracles[dtype]
@@ -48,7 +48,7 @@ def test_optimizeA_explicit(oracles, dtype, k, pad, mode):
     B = (rng.standard_normal((n, k + 1)) * 0.2).astype(dtype)
     bias = (rng.standard_normal(n) * 0.3).astype(dtype)
     Ah, Ao = A0.copy(), A0.copy()
-    kw = dict(k=k, lam_last=0.3, scale_lam=True, use_cg=mode == "cg", max_cg_steps=3)
+    kw = dict(k=k, lam_last=0.3, scale_lam=True, use_cg=mode != "chol", precondition_cg=mode == "pcg", max_cg_steps=3)
     ops.optimizeA_explicit(Ah, B, csr, 0.05, bias_sub=bias, **kw)
     csr_sub = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))   # what the reference's host sweep does
     O.optimizeA_explicit(Ao, B, csr_sub, 0.05, nthreads=4, **kw)
