@@ -52,21 +52,33 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
     P.mode = c.mode;
     if (P.nrows <= 0) return 0;
-    size_t smem = chol_lds_elems(c.kt) * sizeof(real_t);
+    const int T = chol_tiles(c.kt);
+    int NTT = T <= 4 ? 4 : T <= 6 ? 6 : T <= 9 ? 9 : T <= 12 ? 12 : 16;
+    size_t smem = chol_lds_elems(c.kt, NTT) * sizeof(real_t);
     if (smem > 160 * 1024) {
         g_last_error = "cmfrec_hip: Cholesky path needs the k_t x k_t system in LDS (160 KiB): k_t too large";
         return 2;
     }
-    auto kern = chol_rows_kernel<real_t>;
-    static thread_local size_t smem_set = 0;
-    if (smem > 48 * 1024 && smem > smem_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        smem_set = smem;
-    }
     int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(smem, 1)));
     per_cu = std::min(per_cu, 8);
     int grid = std::min(P.nrows, dev.num_cus * per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, dev.stream, P);
+    auto launch = [&](auto kern) {
+        if (smem > 48 * 1024)
+            HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, dev.stream, P);
+    };
+    // <tiles per wave, 16-blocks per dimension>
+    if (T <= 4) launch(chol_rows_kernel<real_t, 3, 4>);
+    else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 6>);
+    else if (T <= 9) launch(chol_rows_kernel<real_t, 12, 9>);
+#ifdef CMFREC_HIP_FLOAT
+    else if (T <= 12) launch(chol_rows_kernel<real_t, 20, 12>);
+    else if (T <= 16) launch(chol_rows_kernel<real_t, 34, 16>);
+#endif
+    else {
+        g_last_error = "cmfrec_hip: Cholesky path: k_t too large for the register-tiled rank-k update";
+        return 2;
+    }
     HIP_CHECK(hipGetLastError());
     return 0;
 }
