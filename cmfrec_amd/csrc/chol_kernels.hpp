@@ -8,16 +8,27 @@
 //   collective: collective_closed_form_block          /root/reference/src/collective.c:1534-1846
 //               (row loop collective.c:5865-5965), sparse X + dense full U, add_X=true add_U=false
 //
-// One workgroup (256 threads) per row.  The k_t x k_t normal matrix lives in LDS for its whole
-// life: initialised (zeros | BtB+lam*I | w*CtC in the upper-left block), accumulated from the
-// gathered rows of the opposing factor matrix (staged through LDS in chunks, 4x4 register blocks
-// per thread over the upper triangle), factorised in place (right-looking Cholesky) and used for
-// the two triangular solves.  Only the upper triangle is referenced, as in the reference
-// (tposv_ 'L' on the column-major view == upper of the row-major one).
+// One workgroup (256 threads, 4 wavefronts) per row, persistent over rows; the k_t x k_t normal matrix
+// never leaves the MFMA accumulators: its upper triangle is cut into 16x16 tiles, tile t of the packed
+// order is owned by wave t & 3, in the C/D register layout of v_mfma_*_16x16x4.
+//   1. rank-k update  G = sum_j w_j B_j B_j^T  (+ right-hand side) from the gathered rows, staged through
+//      a two-slot LDS ring; indices are fetched two chunks ahead and rows one chunk ahead.
+//   2. the initial matrix (lam*I | BtB+lam*I | w*CtC block) is added in the same layout.
+//   3. blocked right-looking Cholesky  M = R^T R, 16 columns per step:
+//        a. the owner wave of the diagonal tile factorises it and inverts the factor (column per lane,
+//           v_readlane broadcasts), publishes inv(R_kk) in LDS;
+//        b. panel tiles  X = inv(R_kk)^T * tile  and  c. trailing tiles  tile -= X_i^T X_j  are MFMAs whose
+//           operands are exactly the C/D-layout registers of the tiles (the k index of a 16x16x4 step is
+//           free to be permuted), exchanged between waves through LDS in lane-linear order;
+//        the forward substitution rides along on the VALU.
+//   4. blocked backward substitution: every wave applies its own tiles (DPP row reductions).
+// Only the upper triangle is referenced, as in the reference (tposv_ 'L' on the column-major view
+// == upper of the row-major one).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include "lanes.hpp"
 
 namespace cmfhip {
 
@@ -44,28 +55,33 @@ struct CholParams {
 };
 
 constexpr int CHOL_CHUNK = 16;     // gathered rows staged per round (4 MFMA k-steps)
-__host__ __device__ inline int chol_ldm(int kt) { return kt | 1; }     // odd leading dimension
 __host__ __device__ inline int chol_tiles(int kt) { return (kt + 15) / 16; }
-// staged chunk: [CHUNK][lds] in the coordinates of the unknowns, lds == 16 (mod 32) so that the
-// 4 rows x 16 columns an MFMA operand read touches land on distinct banks
-__host__ __device__ inline int chol_lds_chunk(int kt) { int T = chol_tiles(kt); return 16 * T + ((T % 2 == 0) ? 16 : 0); }
-__host__ __device__ inline size_t chol_lds_elems(int kt, int NTT)
-{
-    const int ldc = 16 * NTT + ((NTT % 2 == 0) ? 16 : 0);
-    return (size_t)kt * chol_ldm(kt) + (size_t)CHOL_CHUNK * ldc + 2 * (size_t)kt + 2 * CHOL_CHUNK + 8;
-}
 
 template <typename T> struct CholMfma;
 template <> struct CholMfma<double> {
     typedef double vec __attribute__((ext_vector_type(4)));
+    static constexpr int LDR = 17;      // leading dimension of inv(R_kk) in LDS: conflict-free row writes and operand reads
     static __device__ __forceinline__ vec mma(double a, double b, vec c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
+    // position of tile element (i, j) in the lane-linear C/D layout [r][lane]
+    static __device__ __forceinline__ int cidx(int i, int j) { return (i >> 2) * 64 + (i & 3) * 16 + j; }
 };
 template <> struct CholMfma<float> {
     typedef float vec __attribute__((ext_vector_type(4)));
+    static constexpr int LDR = 20;
     static __device__ __forceinline__ vec mma(float a, float b, vec c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
+    static __device__ __forceinline__ int cidx(int i, int j) { return (i & 3) * 64 + (i >> 2) * 16 + j; }
 };
+
+// LDS: ring of 2 x [CHUNK][ldc] staged rows (later: the panel tiles X, NTT x 256), inv(R_kk) for every
+// block, right-hand side, solution, chunk weights
+template <typename T>
+__host__ __device__ inline size_t chol_lds_elems(int NTT)
+{
+    const size_t ldc = 16 * NTT + ((NTT % 2 == 0) ? 16 : 0);
+    return 2 * (size_t)CHOL_CHUNK * ldc + (size_t)NTT * 16 * CholMfma<T>::LDR + 2 * 16 * (size_t)NTT + 4 * CHOL_CHUNK + 8;
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -88,8 +104,6 @@ __host__ __device__ constexpr int tile_bj(int t, int NTT)
     while (rem >= NTT - bi) { rem -= NTT - bi; bi++; }
     return bi + rem;
 }
-// index of entry (a, b), b >= a, in a packed upper triangle of T x T register blocks
-__host__ __device__ constexpr int tri_index(int a, int b, int T) { return a * T - a * (a - 1) / 2 + (b - a); }
 
 // wave-uniform broadcast of one lane's value (v_readlane_b32, no LDS round trip)
 __device__ __forceinline__ float bcast_lane(float v, int src)
@@ -101,46 +115,118 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// TPW = upper 16x16 tiles of the normal matrix owned by one wave (tiles t = wave, wave+4, ...).
-template <typename T, int TPW, int NTT>
-__global__ void __launch_bounds__(256)
+// 1/sqrt(x): hardware estimate + two Newton steps (goldschmidt form), relative error ~1e-16 in double
+__device__ __forceinline__ double inv_sqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
+    e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);
+}
+__device__ __forceinline__ float inv_sqrt(float x)
+{
+    float y = __builtin_amdgcn_rsqf(x);
+    float e = __builtin_fmaf(-x * y, y, 1.0f);
+    return __builtin_fmaf(y * e, 0.5f, y);
+}
+
+// Diagonal block: d = the 16x16 tile D (C/D layout) of one wave.  Computes R (R^T R = D, upper) and
+// inv(R) with lane j holding column j (all four 16-lane groups work redundantly); the row R[c][*]
+// broadcast by v_readlane at pivot c drives both the elimination and the inversion recurrence
+// (forward substitution of R^T V = I, right-looking).  slot <- inv(R) row-major [16][LDR]; it doubles
+// as the transposition scratch, so it must hold >= 256 elements.
+template <typename T>
+__device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *slot, int lane)
+{
+    using Mf = CholMfma<T>;
+#pragma unroll
+    for (int r = 0; r < 4; r++) slot[r * 64 + lane] = d[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int j = lane & 15;
+    T col[16], t[16], w[16];
+    T one = T(1);
+    asm volatile("" : "+v"(one));          // opaque: keeps the identity columns from being hoisted out of the row loop
+#pragma unroll
+    for (int i = 0; i < 16; i++) { col[i] = slot[Mf::cidx(i, j)]; t[i] = (i == j) ? one : T(0); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    static_for<0, 16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        const T piv = bcast_lane(col[c], c);
+        const T rs = inv_sqrt(piv);
+        const T Rc = col[c] * rs;                   // R[c][j], meaningful for j >= c
+        const T wc = t[c] * rs;                     // inv(R)[j][c]
+        w[c] = wc;
+        static_for<c + 1, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const T sv = bcast_lane(Rc, i);         // R[c][i]
+            col[i] -= sv * Rc;
+            t[i] -= sv * wc;
+            __builtin_amdgcn_sched_barrier(0);      // keep each broadcast next to its use: the scalar file cannot hold a hoisted row
+        });
+    });
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) slot[j * Mf::LDR + c] = w[c];
+    }
+}
+
+// NTT = tiles per dimension of the compiled grid (k_t <= 16 NTT);  NW = wavefronts per workgroup
+// (wave w owns tiles t = w, w + NW, ... of the packed upper triangle and stages 16 / NW gathered rows).
+template <typename T, int NTT, int NW>
+__global__ void __launch_bounds__(64 * NW, 1)
 chol_rows_kernel(const CholParams<T> P)
 {
     using Mf = CholMfma<T>;
     using vec = typename Mf::vec;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int kt = P.kt, koff = P.koff, kb = kt - koff;
-    const int ldm = chol_ldm(kt);
+    const int kt = P.kt, koff = P.koff;
+    const int nb = chol_tiles(kt);                  // 16-blocks that hold unknowns (the rest of the grid is padding)
     constexpr int ldc = 16 * NTT + ((NTT % 2 == 0) ? 16 : 0);   // == 16 (mod 32): conflict-free MFMA operand reads
-    constexpr int NTALL = NTT * (NTT + 1) / 2;      // all upper tiles of the NTT x NTT grid (columns >= kt are zero padded)
-    static_assert(TPW * 4 >= NTALL, "tiles per wave");
-    T *M = reinterpret_cast<T *>(smem_raw);                // [kt][ldm]
-    T *Bs = M + (size_t)kt * ldm;                          // [CHUNK][ldc], unknown coordinates, zero padded
-    T *rhs = Bs + (size_t)CHOL_CHUNK * ldc;                // [kt]
-    T *rdiag = rhs + kt;                                   // [kt] reciprocals of the Cholesky diagonal
-    T *wsc = rdiag + kt;                                   // [CHUNK] rank-1 weights
-    T *wrh = wsc + CHOL_CHUNK;                             // [CHUNK] rhs weights
+    constexpr int NTALL = NTT * (NTT + 1) / 2;
+    constexpr int LDR = Mf::LDR, RSZ = 16 * LDR;
+    constexpr int TPW = (NTALL + NW - 1) / NW;      // tile slots per wave
+    constexpr int NTH = 64 * NW;
+    constexpr int RPW = CHOL_CHUNK / NW;            // staged rows per wave and chunk
+    constexpr int NCJ = (16 * NTT + 63) / 64;       // 64-column groups of a staged row
+    static_assert(CHOL_CHUNK % NW == 0 && NTH >= 16 * NTT, "workgroup shape");
+    static_assert(RSZ >= 256, "inv(R) slot doubles as a tile scratch");
+    T *ring = reinterpret_cast<T *>(smem_raw);             // 2 x [CHUNK][ldc];  after the gather: X tiles [NTT][256]
+    T *rinv = ring + 2 * (size_t)CHOL_CHUNK * ldc;         // [NTT][16][LDR]
+    T *rhs = rinv + (size_t)NTT * RSZ;                     // [16 NTT]  right-hand side -> y (in place)
+    T *xall = rhs + 16 * NTT;                              // [16 NTT]  solution
+    T *wsc = xall + 16 * NTT;                              // 2 x [CHUNK] rank-1 weights
+    T *wrh = wsc + 2 * CHOL_CHUNK;                         // 2 x [CHUNK] rhs weights
+    T *Xt = ring;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 15;
 
-    // this wave's tiles (wave-uniform): t = wave, wave+4, ...
-    int t_bi[TPW], t_bj[TPW];
+    // this wave's tiles: t = wave, wave+NW, ...  kept as the operand column offsets (16 bi, 16 bj) of the
+    // staged rows; idle slots are marked bi > bj.  Wave-uniform values, deliberately held in vector
+    // registers: as scalars they would be spilled and restored around every use.
+    int offa[TPW], offb[TPW];
 #pragma unroll
     for (int tt = 0; tt < TPW; tt++) {
-        const int t = wave + 4 * tt;
-        t_bi[tt] = (t < NTALL) ? tile_bi(min(t, NTALL - 1), NTT) : -1;
-        t_bj[tt] = (t < NTALL) ? tile_bj(min(t, NTALL - 1), NTT) : -1;
+        const int t = wave + NW * tt;
+        const int bi = tile_bi(min(t, NTALL - 1), NTT), bj = tile_bj(min(t, NTALL - 1), NTT);
+        const bool real = (t < NTALL) && (bj < nb);          // padding tiles are never referenced
+        offa[tt] = real ? 16 * bi : 16;
+        offb[tt] = real ? 16 * bj : 0;
     }
+#define T_BI(tt) (offa[tt] >> 4)
+#define T_BJ(tt) (offb[tt] >> 4)
+#define T_REAL(tt) (offa[tt] <= offb[tt])
 
-    // staging map of this thread: element e = tid + 256u of the [CHUNK][ldc] chunk -> (row, column)
-    constexpr int NPRE = NTT + 1;            // 16 * ldc / 256 staged elements per thread (ldc <= 16*NTT + 16)
-    int st_r[NPRE], st_c[NPRE];
+    // staging: wave w gathers rows RPW*w .. RPW*w + RPW-1 of a chunk, lane l the unknowns l, l+64, ...
+    int scol[NCJ];                             // column of B to read (clamped); valid <=> svalid bit
+    unsigned svalid = 0;
 #pragma unroll
-    for (int u = 0; u < NPRE; u++) {
-        const int e = tid + 256 * u;
-        st_r[u] = e / ldc;
-        st_c[u] = e - st_r[u] * ldc;
-        if (st_r[u] >= CHOL_CHUNK) { st_r[u] = CHOL_CHUNK; st_c[u] = 0; }    // out of the chunk
+    for (int j = 0; j < NCJ; j++) {
+        const int c = lane + 64 * j;
+        const bool ok = (c >= koff && c < kt);
+        scol[j] = ok ? c - koff : 0;
+        svalid |= ok ? (1u << j) : 0u;
     }
 
     for (int rix = blockIdx.x; rix < P.nrows; rix += gridDim.x) {
@@ -150,7 +236,7 @@ chol_rows_kernel(const CholParams<T> P)
         T *arow = P.A + (size_t)row * P.lda;
         const bool has_u = (P.mode == CHOL_PREFILLED) || ((P.mode == CHOL_COLLECTIVE) && row < P.rows_with_u);
         if (P.mode == CHOL_COLLECTIVE && nnz == 0 && !has_u) {          // collective.c:1258-1268
-            for (int e = tid; e < kt; e += 256) arow[e] = T(0);
+            for (int e = tid; e < kt; e += NTH) arow[e] = T(0);
             continue;
         }
         T lam = P.lam, lam_last = P.lam_last;
@@ -167,199 +253,187 @@ chol_rows_kernel(const CholParams<T> P)
                 lam_last *= mult;
             }
         }
-        __syncthreads();          // previous row's LDS readers are done
-        // ---- initialise M (incl. the diagonal shift) and rhs ----
-        for (int e = tid; e < kt * ldm; e += 256) {
-            int i = e / ldm, j = e % ldm;
-            T v = T(0);
-            if (j < kt) {
-                if (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED) v = P.Minit[(size_t)i * kt + j];
-                else {
-                    if (has_u && i < P.kc && j < P.kc) v = P.Minit[(size_t)i * P.kc + j];   // collective.c:1566-1571
-                    if (i == j) v += (i == kt - 1) ? lam_last : lam;   // add_to_diag2: common.c:1060-1062, collective.c:1819
-                }
-            }
-            M[e] = v;
-        }
-        for (int e = tid; e < kt; e += 256)
-            rhs[e] = has_u ? arow[e] : T(0);   // w*U*C prefilled (collective.c:5768-5773)
-        // ---- rank-k update on the matrix cores: M[koff:, koff:] += sum_j w_j B_j B_j^T ----
+        // ---- 1. rank-k update on the matrix cores: G[koff:, koff:] = sum_j w_j B_j B_j^T ----
         vec acc[TPW];
 #pragma unroll
         for (int tt = 0; tt < TPW; tt++) acc[tt] = vec{0, 0, 0, 0};
-        // The gathered rows of chunk c+1 are fetched into registers while the MFMAs of chunk c run,
-        // so the gather latency (index load -> row load) is off the critical path.
-        const int nstage = min(NPRE, (CHOL_CHUNK * ldc + 255) / 256);
-        T pre[NPRE];
+        // right-hand side: thread t owns unknown t
+        T racc = (has_u && tid < kt) ? arow[tid] : T(0);               // w*U*C prefilled (collective.c:5768-5773)
+        // software pipeline over chunks of CHOL_CHUNK gathered rows:
+        //   indices (+ x values) of chunk c+2  ->  rows (+ bias of x) of chunk c+1  ->  LDS slot / MFMAs of chunk c
+        // loads are unconditional on clamped addresses, padding is selected to zero afterwards
+        T pre[RPW][NCJ];
+        int idn[RPW];
+        int widx = 0; T wx = T(0);
         T pre_wsyr = T(0), pre_wrhs = T(0);
-        auto fetch = [&](int c0) {
-            const int nr = min(CHOL_CHUNK, nnz - c0);
-            // all index loads first, then all row loads: two memory latencies per chunk instead of
-            // one dependent (index -> row) pair after the other
-            int idxs[NPRE];
+        int nr_rows = 0, nr_idx = 0;
+        auto load_idx = [&](int c0) {
+            nr_idx = min(CHOL_CHUNK, nnz - c0);
 #pragma unroll
-            for (int u = 0; u < NPRE; u++) {
-                const bool ok = u < nstage && st_r[u] < nr && st_c[u] >= koff && st_c[u] < kt;
-                idxs[u] = ok ? P.indices[st + c0 + st_r[u]] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < NPRE; u++)
-                pre[u] = (idxs[u] >= 0) ? P.B[(size_t)idxs[u] * P.ldb + (st_c[u] - koff)] : T(0);
-            pre_wsyr = T(0); pre_wrhs = T(0);
-            if (tid < nr) {
-                const int idx = P.indices[st + c0 + tid];
-                T x = P.values[st + c0 + tid];
-                if (P.bias_sub != nullptr) x -= P.bias_sub[idx];
-                pre_wsyr = (P.mode == CHOL_IMPLICIT) ? x : T(1);           // common.c:2091-2095 vs :1007-1012
-                pre_wrhs = (P.mode == CHOL_IMPLICIT) ? x + T(1) : x;       // common.c:2082-2085 vs :991-996
-            }
+            for (int i = 0; i < RPW; i++) idn[i] = P.indices[st + c0 + min(RPW * wave + i, nr_idx - 1)];
+            const int mine = min(tid, nr_idx - 1);
+            widx = P.indices[st + c0 + mine]; wx = P.values[st + c0 + mine];
         };
-        if (nnz > 0) fetch(0);
-        for (int c0 = 0; c0 < nnz; c0 += CHOL_CHUNK) {
-            const int nr = min(CHOL_CHUNK, nnz - c0);
-            __syncthreads();                                  // previous chunk consumed (and M/rhs init visible)
+        auto load_rows = [&]() {
+            nr_rows = nr_idx;
 #pragma unroll
-            for (int u = 0; u < NPRE; u++)
-                if (u < nstage && st_r[u] < CHOL_CHUNK) Bs[tid + 256 * u] = pre[u];
-            if (tid < CHOL_CHUNK) { wsc[tid] = pre_wsyr; wrh[tid] = pre_wrhs; }
-            __syncthreads();
-            if (c0 + CHOL_CHUNK < nnz) fetch(c0 + CHOL_CHUNK);          // next chunk: loads in flight during the MFMAs
-            for (int e = koff + tid; e < kt; e += 256) {                   // rhs[e] += sum_r wrhs_r B_r[e]
-                T s = rhs[e];
-                for (int r = 0; r < nr; r++) s += wrh[r] * Bs[r * ldc + e];
-                rhs[e] = s;
+            for (int i = 0; i < RPW; i++)
+#pragma unroll
+                for (int j = 0; j < NCJ; j++) pre[i][j] = P.B[(size_t)idn[i] * P.ldb + scol[j]];
+            T x = wx;
+            if (P.bias_sub != nullptr) x -= P.bias_sub[widx];
+            pre_wsyr = (P.mode == CHOL_IMPLICIT) ? x : T(1);           // common.c:2091-2095 vs :1007-1012
+            pre_wrhs = (P.mode == CHOL_IMPLICIT) ? x + T(1) : x;       // common.c:2082-2085 vs :991-996
+        };
+        if (nnz > 0) { load_idx(0); load_rows(); }
+        if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
+        __syncthreads();          // previous row's LDS readers (backward substitution) are done
+        for (int c0 = 0, slot = 0; c0 < nnz; c0 += CHOL_CHUNK, slot ^= 1) {
+            T *Bs = ring + (size_t)slot * CHOL_CHUNK * ldc;
+#pragma unroll
+            for (int i = 0; i < RPW; i++)
+#pragma unroll
+                for (int j = 0; j < NCJ; j++)
+                    if (lane + 64 * j < ldc)
+                        Bs[(RPW * wave + i) * ldc + lane + 64 * j] =
+                            (RPW * wave + i < nr_rows && ((svalid >> j) & 1u)) ? pre[i][j] : T(0);
+            if (tid < CHOL_CHUNK) {
+                wsc[slot * CHOL_CHUNK + tid] = (tid < nr_rows) ? pre_wsyr : T(0);
+                wrh[slot * CHOL_CHUNK + tid] = (tid < nr_rows) ? pre_wrhs : T(0);
             }
+            __syncthreads();                  // slot visible; the other slot may still be read by slower waves
+            if (c0 + CHOL_CHUNK < nnz) load_rows();                           // chunk c+1: in flight during the MFMAs
+            if (c0 + 2 * CHOL_CHUNK < nnz) load_idx(c0 + 2 * CHOL_CHUNK);     // chunk c+2
+            if (tid >= koff && tid < kt) {                                     // rhs[e] += sum_r wrhs_r B_r[e]
+#pragma unroll
+                for (int r = 0; r < CHOL_CHUNK; r++) racc += wrh[slot * CHOL_CHUNK + r] * Bs[r * ldc + tid];   // padded rows: weight 0, row 0
+            }
+            // straight-line: operand reads of every slot, weights, MFMAs (idle slots run on tile 0 and are ignored)
 #pragma unroll
             for (int q = 0; q < CHOL_CHUNK / 4; q++) {
                 const int rr = 4 * q + (lane >> 4);
-                const T w = wsc[rr];
-                const T *brow = Bs + rr * ldc + (lane & 15);
-                T opa[TPW], opb[TPW];                          // all operand reads first, then the MFMAs back to back
+                const T *brow = Bs + rr * ldc + lm;
+                const T w = wsc[slot * CHOL_CHUNK + rr];       // 1 in the explicit models
+                T opa[TPW], opb[TPW];
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++) { opa[tt] = brow[offa[tt]]; opb[tt] = brow[offb[tt]]; }
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++) acc[tt] = Mf::mma(opa[tt] * w, opb[tt], acc[tt]);
+                __builtin_amdgcn_sched_barrier(0);       // one k-step of operands in registers at a time
+            }
+        }
+        // ---- 2. the initial matrix, in the accumulator layout (padding: identity) ----
+        {
+            const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED);
+            const int lim = full ? kt : (has_u ? P.kc : 0);            // Minit is [lim, lim]
+            if (lim > 0) {                                             // unconditional loads on clamped addresses
 #pragma unroll
                 for (int tt = 0; tt < TPW; tt++) {
-                    opa[tt] = (t_bi[tt] >= 0) ? brow[16 * t_bi[tt]] : T(0);
-                    opb[tt] = (t_bi[tt] >= 0) ? brow[16 * t_bj[tt]] : T(0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int gi = offa[tt] + Mf::row_of(lane, r), gj = offb[tt] + lm;
+                        const int lo = min(gi, gj), hi = max(gi, gj);
+                        const T v = P.Minit[(size_t)min(lo, lim - 1) * lim + min(hi, lim - 1)];   // collective.c:1566-1571
+                        acc[tt][r] += (hi < lim) ? v : T(0);
+                    }
                 }
-#pragma unroll
-                for (int tt = 0; tt < TPW; tt++)
-                    if (t_bi[tt] >= 0) acc[tt] = Mf::mma(w * opa[tt], opb[tt], acc[tt]);
             }
-        }
-        __syncthreads();
-        // accumulators -> M (each upper-triangle entry has exactly one owner)
 #pragma unroll
-        for (int tt = 0; tt < TPW; tt++) {
-            if (t_bi[tt] >= 0) {
+            for (int tt = 0; tt < TPW; tt++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int gi = 16 * t_bi[tt] + Mf::row_of(lane, r), gj = 16 * t_bj[tt] + (lane & 15);
-                    if (gi < kt && gj < kt && gj >= gi) M[(size_t)gi * ldm + gj] += acc[tt][r];
+                    const int gi = offa[tt] + Mf::row_of(lane, r), gj = offb[tt] + lm;
+                    T dv = T(0);
+                    if (gi == gj) dv = (gi >= kt) ? T(1) : (full ? T(0) : ((gi == kt - 1) ? lam_last : lam));   // add_to_diag2: common.c:1060-1062, collective.c:1819
+                    acc[tt][r] += dv;
+                }
+            }
+        }
+        if (tid < 16 * NTT) rhs[tid] = (tid < kt) ? racc : T(0);
+        __syncthreads();                      // ring fully consumed (X tiles alias it), rhs visible
+        // ---- 3. blocked Cholesky  M = R^T R ----
+        for (int kbk = 0; kbk < nb; kbk++) {
+            T *rslot = rinv + (size_t)kbk * RSZ;
+            {   // a. diagonal block, by its owner wave
+                vec d = vec{0, 0, 0, 0};
+                bool mine = false;
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++)
+                    if (T_BI(tt) == kbk && T_BJ(tt) == kbk) { d = acc[tt]; mine = true; }
+                if (mine) chol_diag_block<T>(d, rslot, lane);
+            }
+            __syncthreads();
+            {   // b. panel tiles of block row kbk:  X = inv(R_kk)^T * tile
+                T ainv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) ainv[r] = rslot[Mf::row_of(lane, r) * LDR + lm];
+                if (wave == 0) {              // y_k = inv(R_kk)^T rhs_k, in place
+                    T yv = T(0);
+#pragma unroll
+                    for (int l = 0; l < 16; l++) yv += rslot[l * LDR + lm] * rhs[16 * kbk + l];
+                    if (lane < 16) rhs[16 * kbk + lane] = yv;
+                }
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++) {
+                    if (T_BI(tt) == kbk && T_BJ(tt) > kbk) {
+                        vec x = vec{0, 0, 0, 0};
+#pragma unroll
+                        for (int r = 0; r < 4; r++) x = Mf::mma(ainv[r], acc[tt][r], x);
+                        acc[tt] = x;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) Xt[T_BJ(tt) * 256 + r * 64 + lane] = x[r];
+                    }
+                }
+            }
+            __syncthreads();
+            // c. trailing tiles:  tile(bi, bj) -= X_bi^T X_bj ;  forward substitution of the later blocks
+#pragma unroll
+            for (int tt = 0; tt < TPW; tt++) {
+                if (T_BI(tt) > kbk && T_REAL(tt)) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        acc[tt] = Mf::mma(-Xt[T_BI(tt) * 256 + r * 64 + lane], Xt[T_BJ(tt) * 256 + r * 64 + lane], acc[tt]);
+                }
+            }
+            {
+                const int jg = tid;
+                if (jg >= 16 * (kbk + 1) && jg < 16 * nb) {
+                    T sacc = rhs[jg];
+                    const T *xt = Xt + (jg >> 4) * 256;
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; k2++) sacc -= xt[Mf::cidx(k2, jg & 15)] * rhs[16 * kbk + k2];
+                    rhs[jg] = sacc;
                 }
             }
         }
         __syncthreads();
-        // ---- Cholesky M = R^T R in registers.  Thread (ty, tx) of the 16 x 16 grid owns the entries
-        //      (i = ty + 16a, j = tx + 16b), b >= a  (cyclic distribution: the work stays balanced as
-        //      the trailing matrix shrinks).  Column c: the owners of row c publish their (unscaled) row
-        //      and y_c through a double-buffered LDS line, one barrier, then every thread updates its
-        //      own registers with  M_ij -= (M_ci / piv) M_cj ; the forward substitution of the right-hand
-        //      side rides along as an extra column.  Rows are scaled by 1/sqrt(piv) at the end.
-        {
-            constexpr int NTRI = NTT * (NTT + 1) / 2;
-            const int ty = tid >> 4, tx = tid & 15;
-            T mreg[NTRI];
-            T yv[NTT];
-            static_for<0, NTT>([&](auto ac) {
-                constexpr int a = decltype(ac)::value;
-                const int i = ty + 16 * a;
-                static_for<a, NTT>([&](auto bc) {
-                    constexpr int b = decltype(bc)::value;
-                    const int j = tx + 16 * b;
-                    T v = (i == j) ? T(1) : T(0);                       // rows / columns >= kt: identity padding
-                    if (i < kt && j < kt) v = (j >= i) ? M[(size_t)i * ldm + j] : T(0);
-                    mreg[tri_index(a, b, NTT)] = v;
-                });
-                yv[a] = (i < kt) ? rhs[i] : T(0);
-            });
-            T *line = Bs;                                               // 2 x (16*NTT + 16) elements
-            constexpr int LN = 16 * NTT + 16;
-            __syncthreads();
-            static_for<0, NTT>([&](auto a0c) {
-                constexpr int A0 = decltype(a0c)::value;
-                for (int cc = 0; cc < 16; cc++) {
-                    const int c = 16 * A0 + cc;
-                    if (c >= kt) break;
-                    T *buf = line + (c & 1) * LN;
-                    if (ty == cc) {
-                        static_for<A0, NTT>([&](auto bc) {
-                            constexpr int b = decltype(bc)::value;
-                            buf[tx + 16 * b] = mreg[tri_index(A0, b, NTT)];
-                        });
-                        if (tx == 0) buf[16 * NTT] = yv[A0];
+        // ---- 4. backward substitution R x = y, one block column per step ----
+        for (int bjk = nb - 1; bjk >= 0; bjk--) {
+            const T *rslot = rinv + (size_t)bjk * RSZ;
+            T xm = T(0);                          // x[16 bjk + lm], computed redundantly by every 16-lane group
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) xm += rslot[lm * LDR + n2] * rhs[16 * bjk + n2];
+            if (wave == 0 && lane < 16) xall[16 * bjk + lane] = xm;
+#pragma unroll
+            for (int tt = 0; tt < TPW; tt++) {
+                if (T_BJ(tt) == bjk && T_BI(tt) < bjk) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        T pr = acc[tt][r] * xm;
+                        pr += lanes::xor1(pr); pr += lanes::xor2(pr); pr += lanes::xor4(pr); pr += lanes::xor8(pr);
+                        if (lm == 0) rhs[offa[tt] + Mf::row_of(lane, r)] -= pr;
                     }
-                    __syncthreads();
-                    const T piv = buf[c];
-                    const T inv = T(1) / piv;
-                    const T ycv = buf[16 * NTT];
-                    if (tid == 0) rdiag[c] = piv;
-                    T colv[NTT];
-                    static_for<A0, NTT>([&](auto bc) {
-                        constexpr int b = decltype(bc)::value;
-                        colv[b] = buf[tx + 16 * b];
-                    });
-                    static_for<A0, NTT>([&](auto ac) {
-                        constexpr int a = decltype(ac)::value;
-                        const int i = ty + 16 * a;
-                        const T fi = (i > c && i < kt) ? buf[i] * inv : T(0);
-                        static_for<a, NTT>([&](auto bc) {
-                            constexpr int b = decltype(bc)::value;
-                            mreg[tri_index(a, b, NTT)] -= fi * colv[b];
-                        });
-                        yv[a] -= fi * ycv;
-                    });
-                }
-            });
-            __syncthreads();                                            // all pivots are in rdiag[]
-            static_for<0, NTT>([&](auto ac) {
-                constexpr int a = decltype(ac)::value;
-                const int i = ty + 16 * a;
-                if (i < kt) {
-                    const T isq = T(1) / sqrt(rdiag[i]);
-                    static_for<a, NTT>([&](auto bc) {
-                        constexpr int b = decltype(bc)::value;
-                        const int j = tx + 16 * b;
-                        if (j < kt && j >= i) M[(size_t)i * ldm + j] = mreg[tri_index(a, b, NTT)] * isq;
-                    });
-                    if (tx == 0) rhs[i] = yv[a] * isq;                  // y = R^-T rhs
-                }
-            });
-            __syncthreads();
-            for (int e = tid; e < kt; e += 256) rdiag[e] = T(1) / M[(size_t)e * ldm + e];
-            __syncthreads();
-        }
-        // ---- backward substitution R x = y by one wavefront, vector in registers (lane l owns
-        //      elements l, l+64, ...): no workgroup barriers on this serial chain
-        if (wave == 0) {
-            constexpr int NE = 5;                         // kt <= 320
-            T x[NE];
-#pragma unroll
-            for (int e = 0; e < NE; e++) x[e] = (lane + 64 * e < kt) ? rhs[lane + 64 * e] : T(0);
-            for (int c = kt - 1; c >= 0; c--) {           // R x = y
-                T xc = T(0);
-#pragma unroll
-                for (int e = 0; e < NE; e++) if ((c >> 6) == e) xc = bcast_lane(x[e], c & 63);
-                xc *= rdiag[c];
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    const int i = lane + 64 * e;
-                    if (i == c) x[e] = xc;
-                    else if (i < c) x[e] -= M[(size_t)i * ldm + c] * xc;
                 }
             }
-#pragma unroll
-            for (int e = 0; e < NE; e++) if (lane + 64 * e < kt) arow[lane + 64 * e] = x[e];
+            __syncthreads();
         }
+        if (wave == 0)
+            for (int e = lane; e < kt; e += 64) arow[e] = xall[e];
     }
 }
+
+#undef T_BI
+#undef T_BJ
+#undef T_REAL
 
 }  // namespace cmfhip

@@ -54,31 +54,26 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
     int NTT = T <= 4 ? 4 : T <= 6 ? 6 : T <= 9 ? 9 : T <= 12 ? 12 : 16;
-    size_t smem = chol_lds_elems(c.kt, NTT) * sizeof(real_t);
-    if (smem > 160 * 1024) {
-        g_last_error = "cmfrec_hip: Cholesky path needs the k_t x k_t system in LDS (160 KiB): k_t too large";
+    size_t smem = chol_lds_elems<real_t>(NTT) * sizeof(real_t);
+    if (T > 16 || (sizeof(real_t) == 8 && T > 9)) {
+        g_last_error = "cmfrec_hip: Cholesky path: k_t too large for the register-resident normal matrix "
+                       "(k_t <= 144 in double, <= 256 in single precision)";
         return 2;
     }
-    int per_cu = std::max(1, (int)((160 * 1024) / std::max<size_t>(smem, 1)));
-    per_cu = std::min(per_cu, 8);
-    int grid = std::min(P.nrows, dev.num_cus * per_cu);
-    auto launch = [&](auto kern) {
+    auto launch = [&](auto kern, int nw) {
+        int grid = std::min(P.nrows, dev.num_cus);
         if (smem > 48 * 1024)
             HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, dev.stream, P);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, dev.stream, P);
     };
-    // <tiles per wave, 16-blocks per dimension>
-    if (T <= 4) launch(chol_rows_kernel<real_t, 3, 4>);
-    else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 6>);
-    else if (T <= 9) launch(chol_rows_kernel<real_t, 12, 9>);
+    // <16-blocks per dimension, wavefronts per workgroup>
+    if (T <= 4) launch(chol_rows_kernel<real_t, 4, 4>, 4);
+    else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 8>, 8);
+    else if (T <= 9) launch(chol_rows_kernel<real_t, 9, 8>, 8);
 #ifdef CMFREC_HIP_FLOAT
-    else if (T <= 12) launch(chol_rows_kernel<real_t, 20, 12>);
-    else if (T <= 16) launch(chol_rows_kernel<real_t, 34, 16>);
+    else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8>, 8);
+    else launch(chol_rows_kernel<real_t, 16, 8>, 8);
 #endif
-    else {
-        g_last_error = "cmfrec_hip: Cholesky path: k_t too large for the register-tiled rank-k update";
-        return 2;
-    }
     HIP_CHECK(hipGetLastError());
     return 0;
 }
