@@ -52,9 +52,9 @@ struct CholParams {
     T lam, lam_last;
     int scale_lam, scale_lam_sideinfo, scale_bias_const;
     int mode;
+    int *counter;              // zero-initialised: rows are handed out to the workgroups in `order` (heaviest first)
 };
 
-constexpr int CHOL_CHUNK = 16;     // gathered rows staged per round (4 MFMA k-steps)
 __host__ __device__ inline int chol_tiles(int kt) { return (kt + 15) / 16; }
 
 template <typename T> struct CholMfma;
@@ -77,10 +77,10 @@ template <> struct CholMfma<float> {
 // LDS: ring of 2 x [CHUNK][ldc] staged rows (later: the panel tiles X, NTT x 256), inv(R_kk) for every
 // block, right-hand side, solution, chunk weights
 template <typename T>
-__host__ __device__ inline size_t chol_lds_elems(int NTT)
+__host__ __device__ inline size_t chol_lds_elems(int NTT, int CH)
 {
     const size_t ldc = 16 * NTT + ((NTT % 2 == 0) ? 16 : 0);
-    return 2 * (size_t)CHOL_CHUNK * ldc + (size_t)NTT * 16 * CholMfma<T>::LDR + 2 * 16 * (size_t)NTT + 4 * CHOL_CHUNK + 8;
+    return 2 * (size_t)CH * ldc + (size_t)NTT * 16 * CholMfma<T>::LDR + 2 * 16 * (size_t)NTT + 4 * CH + 8;
 }
 
 template <int I, int N, typename F>
@@ -115,66 +115,93 @@ __device__ __forceinline__ double bcast_lane(double v, int src)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// 1/sqrt(x): hardware estimate + two Newton steps (goldschmidt form), relative error ~1e-16 in double
-__device__ __forceinline__ double inv_sqrt(double x)
+// value of lane `src` for every lane through the LDS crossbar (ds_bpermute_b32): unlike v_readlane the
+// result stays in vector registers, so a row of broadcasts can be in flight at once
+__device__ __forceinline__ float perm_lane(float v, int src)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double e = __builtin_fma(-x * y, y, 1.0);
-    y = __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
-    e = __builtin_fma(-x * y, y, 1.0);
-    return __builtin_fma(y * e, 0.5, y);
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src * 4, __float_as_int(v)));
 }
-__device__ __forceinline__ float inv_sqrt(float x)
+__device__ __forceinline__ double perm_lane(double v, int src)
 {
-    float y = __builtin_amdgcn_rsqf(x);
-    float e = __builtin_fmaf(-x * y, y, 1.0f);
-    return __builtin_fmaf(y * e, 0.5f, y);
+    return __hiloint2double(__builtin_amdgcn_ds_bpermute(src * 4, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(src * 4, __double2loint(v)));
 }
 
-// Diagonal block: d = the 16x16 tile D (C/D layout) of one wave.  Computes R (R^T R = D, upper) and
-// inv(R) with lane j holding column j (all four 16-lane groups work redundantly); the row R[c][*]
-// broadcast by v_readlane at pivot c drives both the elimination and the inversion recurrence
-// (forward substitution of R^T V = I, right-looking).  slot <- inv(R) row-major [16][LDR]; it doubles
-// as the transposition scratch, so it must hold >= 256 elements.
+// 1/sqrt(x) in four short steps (hardware estimate + one third-order correction, relative error
+// ~1e-16 in double) so that the chain of the next pivot can be interleaved with the updates of the
+// current one.
+template <typename T> struct RsqChain {
+    T x, y, e, p, q;
+    __device__ __forceinline__ void s0(T xin) { x = xin; y = hw_rsq(x); }
+    __device__ __forceinline__ void s1() { e = fma_(-(x * y), y, T(1)); }
+    __device__ __forceinline__ void s2() { p = fma_(e, T(0.375), T(0.5)); q = y * e; }
+    __device__ __forceinline__ T s3() { return fma_(q, p, y); }
+    static __device__ __forceinline__ double hw_rsq(double v) { return __builtin_amdgcn_rsq(v); }
+    static __device__ __forceinline__ float hw_rsq(float v) { return __builtin_amdgcn_rsqf(v); }
+    static __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+};
+
+// Diagonal block: d = the 16x16 tile D (C/D layout) of one wave, nact = rows of it that hold unknowns
+// (the rest is identity padding).  Computes R (R^T R = D, upper) and inv(R), one column per lane:
+// lanes 0-15 carry the columns of D -> R, lanes 16-31 the columns of I -> inv(R)^T (forward substitution
+// of R^T V = I, right-looking), so that the one row R[c][*] broadcast by v_readlane at pivot c and the one
+// FMA per (pivot, row) serve the elimination and the inversion at once (lanes 32-63 mirror them).
+// slot <- inv(R) row-major [16][LDR]; it doubles as the transposition scratch (>= 256 elements).
 template <typename T>
-__device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *slot, int lane)
+__device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *slot, int lane, int nact)
 {
     using Mf = CholMfma<T>;
 #pragma unroll
     for (int r = 0; r < 4; r++) slot[r * 64 + lane] = d[r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int j = lane & 15;
-    T col[16], t[16], w[16];
+    const bool inv_half = (lane & 16) != 0;
+    T u[16];
     T one = T(1);
     asm volatile("" : "+v"(one));          // opaque: keeps the identity columns from being hoisted out of the row loop
 #pragma unroll
-    for (int i = 0; i < 16; i++) { col[i] = slot[Mf::cidx(i, j)]; t[i] = (i == j) ? one : T(0); }
+    for (int i = 0; i < 16; i++) {
+        const T dv = slot[Mf::cidx(i, j)];
+        u[i] = inv_half ? ((i == j) ? one : T(0)) : dv;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    T *wrow = slot + j * Mf::LDR;
+    RsqChain<T> ch;
+    ch.s0(bcast_lane(u[0], 0)); ch.s1(); ch.s2();
+    T rs = ch.s3();
     static_for<0, 16>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        const T piv = bcast_lane(col[c], c);
-        const T rs = inv_sqrt(piv);
-        const T Rc = col[c] * rs;                   // R[c][j], meaningful for j >= c
-        const T wc = t[c] * rs;                     // inv(R)[j][c]
-        w[c] = wc;
-        static_for<c + 1, 16>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const T sv = bcast_lane(Rc, i);         // R[c][i]
-            col[i] -= sv * Rc;
-            t[i] -= sv * wc;
-            __builtin_amdgcn_sched_barrier(0);      // keep each broadcast next to its use: the scalar file cannot hold a hoisted row
-        });
+        if (c < nact) {
+            const T v = u[c] * rs;                  // lanes 0-15: R[c][j] (j >= c);  lanes 16-31: inv(R)[j][c]
+            if (lane >= 16 && lane < 32) wrow[c] = v;
+            const bool more = (c + 1 < nact);
+            static_for<c + 1, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                u[i] -= perm_lane(v, i) * v;        // R[c][i] from lane i
+                // 1/sqrt of the next pivot, one step per update so its latency hides behind them
+                if (more) {
+                    if (i == c + 1) ch.s0(bcast_lane(u[c + 1], c + 1));
+                    if (i == c + 2) ch.s1();
+                    if (i == c + 3) ch.s2();
+                    if (i == c + 4) rs = ch.s3();
+                }
+            });
+            if (more) {                             // late pivots: fewer than four updates to hide behind
+                if (c + 1 >= 15) ch.s1();
+                if (c + 1 >= 14) ch.s2();
+                if (c + 1 >= 13) rs = ch.s3();
+            }
+        } else {
+            if (lane >= 16 && lane < 32) wrow[c] = u[c];   // identity padding: R = inv(R) = I there
+        }
     });
-    if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) slot[j * Mf::LDR + c] = w[c];
-    }
 }
 
 // NTT = tiles per dimension of the compiled grid (k_t <= 16 NTT);  NW = wavefronts per workgroup
-// (wave w owns tiles t = w, w + NW, ... of the packed upper triangle and stages 16 / NW gathered rows).
-template <typename T, int NTT, int NW>
-__global__ void __launch_bounds__(64 * NW, 1)
+// (wave w owns tiles t = w, w + NW, ... of the packed upper triangle and stages CHOL_CHUNK / NW of the
+// CHOL_CHUNK gathered rows of a round);  WGS = workgroups per CU the register budget is set for.
+template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS>
+__global__ void __launch_bounds__(64 * NW, WGS)
 chol_rows_kernel(const CholParams<T> P)
 {
     using Mf = CholMfma<T>;
@@ -229,7 +256,13 @@ chol_rows_kernel(const CholParams<T> P)
         svalid |= ok ? (1u << j) : 0u;
     }
 
-    for (int rix = blockIdx.x; rix < P.nrows; rix += gridDim.x) {
+    __shared__ int s_rix;
+    for (;;) {
+        if (tid == 0) s_rix = atomicAdd(P.counter, 1);
+        __syncthreads();
+        const int rix = s_rix;
+        __syncthreads();                            // s_rix may be rewritten
+        if (rix >= P.nrows) break;
         const int row = (P.order != nullptr) ? P.order[rix] : rix;
         const size_t st = (P.mode == CHOL_PREFILLED) ? 0 : P.indptr[row];
         const int nnz = (P.mode == CHOL_PREFILLED) ? 0 : (int)(P.indptr[row + 1] - st);
@@ -360,7 +393,7 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
                 for (int tt = 0; tt < TPW; tt++)
                     if (T_BI(tt) == kbk && T_BJ(tt) == kbk) { d = acc[tt]; mine = true; }
-                if (mine) chol_diag_block<T>(d, rslot, lane);
+                if (mine) chol_diag_block<T>(d, rslot, lane, min(16, kt - 16 * kbk));
             }
             __syncthreads();
             {   // b. panel tiles of block row kbk:  X = inv(R_kk)^T * tile
@@ -376,9 +409,11 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
                 for (int tt = 0; tt < TPW; tt++) {
                     if (T_BI(tt) == kbk && T_BJ(tt) > kbk) {
-                        vec x = vec{0, 0, 0, 0};
-#pragma unroll
-                        for (int r = 0; r < 4; r++) x = Mf::mma(ainv[r], acc[tt][r], x);
+                        vec x = Mf::mma(ainv[0], acc[tt][0], vec{0, 0, 0, 0});          // two independent chains
+                        vec x2 = Mf::mma(ainv[2], acc[tt][2], vec{0, 0, 0, 0});
+                        x = Mf::mma(ainv[1], acc[tt][1], x);
+                        x2 = Mf::mma(ainv[3], acc[tt][3], x2);
+                        x += x2;
                         acc[tt] = x;
 #pragma unroll
                         for (int r = 0; r < 4; r++) Xt[T_BJ(tt) * 256 + r * 64 + lane] = x[r];
@@ -386,14 +421,24 @@ chol_rows_kernel(const CholParams<T> P)
                 }
             }
             __syncthreads();
-            // c. trailing tiles:  tile(bi, bj) -= X_bi^T X_bj ;  forward substitution of the later blocks
+            // c. trailing tiles:  tile(bi, bj) -= X_bi^T X_bj ;  forward substitution of the later blocks.
+            //    Operands of every slot are read unconditionally (two k-steps at a time); the MFMAs of one
+            //    k-step are independent of each other.
 #pragma unroll
-            for (int tt = 0; tt < TPW; tt++) {
-                if (T_BI(tt) > kbk && T_REAL(tt)) {
+            for (int half = 0; half < 2; half++) {
+                T xa[TPW][2], xb[TPW][2];
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        acc[tt] = Mf::mma(-Xt[T_BI(tt) * 256 + r * 64 + lane], Xt[T_BJ(tt) * 256 + r * 64 + lane], acc[tt]);
-                }
+                for (int tt = 0; tt < TPW; tt++)
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; r2++) {
+                        xa[tt][r2] = -Xt[offa[tt] * 16 + (2 * half + r2) * 64 + lane];
+                        xb[tt][r2] = Xt[offb[tt] * 16 + (2 * half + r2) * 64 + lane];
+                    }
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+                    for (int tt = 0; tt < TPW; tt++)
+                        if (T_BI(tt) > kbk && T_REAL(tt)) acc[tt] = Mf::mma(xa[tt][r2], xb[tt][r2], acc[tt]);
             }
             {
                 const int jg = tid;
@@ -417,18 +462,23 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
             for (int tt = 0; tt < TPW; tt++) {
                 if (T_BJ(tt) == bjk && T_BI(tt) < bjk) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        T pr = acc[tt][r] * xm;
-                        pr += lanes::xor1(pr); pr += lanes::xor2(pr); pr += lanes::xor4(pr); pr += lanes::xor8(pr);
-                        if (lm == 0) rhs[offa[tt] + Mf::row_of(lane, r)] -= pr;
-                    }
+                    // sum over the 16 lanes of a row for the four registers at once: after two
+                    // select-and-exchange steps lane l carries register (l & 3), then two plain butterflies
+                    const T p0 = acc[tt][0] * xm, p1 = acc[tt][1] * xm, p2 = acc[tt][2] * xm, p3 = acc[tt][3] * xm;
+                    const bool o1 = (lm & 1) != 0, o2 = (lm & 2) != 0;
+                    const T s01 = (o1 ? p1 : p0) + lanes::xor1(o1 ? p0 : p1);
+                    const T s23 = (o1 ? p3 : p2) + lanes::xor1(o1 ? p2 : p3);
+                    T sr = (o2 ? s23 : s01) + lanes::xor2(o2 ? s01 : s23);
+                    sr += lanes::xor4(sr);
+                    sr += lanes::xor8(sr);
+                    if (lm < 4) rhs[offa[tt] + Mf::row_of(lane, lm)] -= sr;
                 }
             }
             __syncthreads();
         }
         if (wave == 0)
             for (int e = lane; e < kt; e += 64) arow[e] = xall[e];
+
     }
 }
 

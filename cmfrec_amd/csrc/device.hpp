@@ -158,6 +158,7 @@ struct DeviceInfo {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    DevBuf<int> row_counter;        // work counter of the dynamically scheduled row kernels (zeroed before each launch)
 };
 
 // HIP-event pairs around the launches of one nnz bin (0 heavy, 1 medium, 2 light) on the stream

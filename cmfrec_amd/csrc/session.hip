@@ -53,26 +53,28 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.mode = c.mode;
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
-    int NTT = T <= 4 ? 4 : T <= 6 ? 6 : T <= 9 ? 9 : T <= 12 ? 12 : 16;
-    size_t smem = chol_lds_elems<real_t>(NTT) * sizeof(real_t);
     if (T > 16 || (sizeof(real_t) == 8 && T > 9)) {
         g_last_error = "cmfrec_hip: Cholesky path: k_t too large for the register-resident normal matrix "
                        "(k_t <= 144 in double, <= 256 in single precision)";
         return 2;
     }
-    auto launch = [&](auto kern, int nw) {
-        int grid = std::min(P.nrows, dev.num_cus);
+    if (!dev.row_counter.ptr) const_cast<DeviceInfo &>(dev).row_counter.alloc(16);
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, sizeof(int), dev.stream));
+    P.counter = dev.row_counter.ptr;
+    auto launch = [&](auto kern, int ntt, int nw, int ch, int wgs) {
+        size_t smem = chol_lds_elems<real_t>(ntt, ch) * sizeof(real_t);
+        int grid = std::min(P.nrows, dev.num_cus * wgs);
         if (smem > 48 * 1024)
             HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, dev.stream, P);
     };
-    // <16-blocks per dimension, wavefronts per workgroup>
-    if (T <= 4) launch(chol_rows_kernel<real_t, 4, 4>, 4);
-    else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 8>, 8);
-    else if (T <= 9) launch(chol_rows_kernel<real_t, 9, 8>, 8);
+    // <16-blocks per dimension, wavefronts per workgroup, gathered rows per round, workgroups per CU>
+    if (T <= 4) launch(chol_rows_kernel<real_t, 4, 4, 16, 2>, 4, 4, 16, 2);
+    else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 8, 32, 1>, 6, 8, 32, 1);
+    else if (T <= 9) launch(chol_rows_kernel<real_t, 9, 8, 32, 1>, 9, 8, 32, 1);
 #ifdef CMFREC_HIP_FLOAT
-    else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8>, 8);
-    else launch(chol_rows_kernel<real_t, 16, 8>, 8);
+    else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 32, 1>, 12, 8, 32, 1);
+    else launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
 #endif
     HIP_CHECK(hipGetLastError());
     return 0;
