@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
                          "MovieLens10M-shaped configs of BASELINE.json (single GPU, side measurements)")
     args = ap.parse_args()
@@ -96,6 +96,8 @@ def main():
 
     from cmfrec_amd.session import AlsSession
     from cmfrec_amd.distributed import ShardedAls, GpuEngine
+    if args.workload == "fit":
+        return whole_fit(args)
     if args.workload != "c2":
         return side_workload(args, local_rank)
 
@@ -202,6 +204,30 @@ def main():
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+def whole_fit(args):
+    """Whole CMF_implicit.fit() of C2 through the drop-in C ABI (fit_collective_implicit_als): host COO in,
+    host factors out, 15 iterations, seeded start values -- the PCIe- and preprocessing-inclusive number
+    DESIGN.md quotes beside the resident-data metric.  CMFREC_HIP_TIMING=1 prints the host phases."""
+    from cmfrec_amd.models import CMF_implicit
+    import scipy.sparse as sp
+    m, n, nnz = int(M_USERS * args.scale), int(N_ITEMS * args.scale), int(NNZ * args.scale)
+    row, col, val = synth_block(m, n, nnz, seed=2)
+    X = sp.coo_matrix((val, (row, col)), shape=(m, n))
+    niter = 15
+    model = CMF_implicit(k=K, lambda_=LAM, niter=niter, use_float=False, use_cg=True, finalize_chol=False,
+                         max_cg_steps=MAX_CG_STEPS, precompute_for_predictions=False)
+    times = []
+    for _ in range(max(1, args.steps // 5)):
+        t0 = time.perf_counter()
+        model.fit(X)
+        times.append(time.perf_counter() - t0)
+    print(json.dumps({"workload": "whole fit(), C2, %d iterations, host COO in / host factors out" % niter,
+                      "seconds": [round(t, 3) for t in times], "best_s": round(min(times), 3),
+                      "rows_per_s_whole_fit": round((m + n) * niter / min(times), 1),
+                      "finite": bool(np.isfinite(model.A_).all() and np.isfinite(model.B_).all()),
+                      "note": "side measurement, not the headline metric"}))
 
 
 def side_workload(args, device):

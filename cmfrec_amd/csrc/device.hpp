@@ -117,14 +117,27 @@ struct SparseShard {
         std::iota(ord.begin(), ord.end(), 0);
         auto len = [&](int r) { return (long long)(p0[r + 1] - p0[r]); };
         std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return len(a) > len(b); });
+        std::vector<RowDesc> dsc(nrows);
+        std::vector<unsigned> lens(nrows);
+        for (int q = 0; q < nrows; q++) {
+            const int r = ord[q];
+            dsc[q].row = r; dsc[q].nnz = (int)len(r); dsc[q].st = (unsigned long long)p0[r];
+            lens[q] = (unsigned)len(r);
+        }
+        order.upload(ord.data(), nrows, st);
+        desc.upload(dsc.data(), nrows, st);
+        build_bins(lens.data(), st);
+        HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
+    }
+
+    // nnz bins, split-row work list and CG state from the row lengths in processing order (descending)
+    void build_bins(const unsigned *lens_sorted, hipStream_t st)
+    {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
         n_empty = 0;
         std::vector<int> c_row, c_first, c_off(1, 0);
-        std::vector<RowDesc> dsc(nrows);
         for (int q = 0; q < nrows; q++) {
-            const int r = ord[q];
-            const long long l = len(r);
-            dsc[q].row = r; dsc[q].nnz = (int)l; dsc[q].st = (unsigned long long)p0[r];
+            const long long l = (long long)lens_sorted[q];
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -137,9 +150,7 @@ struct SparseShard {
         int acc = 0;
         for (int b = 0; b < NBINS; b++) { bin_first[b] = acc; acc += bin_rows[b]; }
         n_nonempty = acc;
-        max_nnz = nrows ? (int)len(ord[0]) : 0;
-        order.upload(ord.data(), nrows, st);
-        desc.upload(dsc.data(), nrows, st);
+        max_nnz = nrows ? (int)lens_sorted[0] : 0;
         n_chunks = (int)c_row.size();
         if (bin_rows[BIN_VHEAVY]) {
             const int nvh = bin_rows[BIN_VHEAVY];
@@ -150,7 +161,7 @@ struct SparseShard {
             vh_r.alloc((size_t)nvh * 64); vh_p.alloc((size_t)nvh * 64);
             vh_part.alloc((size_t)n_chunks * 64);
         }
-        HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
+        HIP_CHECK(hipStreamSynchronize(st));
     }
 };
 

@@ -12,6 +12,8 @@
 #include <csignal>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/cmfrec_hip.h"
@@ -60,6 +62,19 @@ const real_t EPS_T = FLT_EPSILON;
 #else
 const real_t EPS_T = DBL_EPSILON;
 #endif
+
+// CMFREC_HIP_TIMING=1: wall-clock of the host phases of a fit on stderr
+struct PhaseTimer {
+    bool on = getenv("CMFREC_HIP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cmfrec_hip timing] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 int fail(bool verbose, const char *msg)
 {
@@ -137,13 +152,15 @@ int_t fit_collective_implicit_als(
     if (w_main_multiplier) *w_main_multiplier = 1;
     if (w_main != (real_t)1) lam /= w_main;                              // collective.c:9786-9811
 
+    PhaseTimer tm;
+    tm.lap("validate");
     SigGuard sig(true);
-    std::vector<real_t> Xs(X, X + nnz);                                  // X is copied before edits (:9578-9599)
-    if (apply_log_transf) for (auto &x : Xs) x = std::log(x);
-    if (alpha != (real_t)1) for (auto &x : Xs) x *= alpha;
-    std::vector<size_t> rp, cp; std::vector<int_t> ri, ci; std::vector<real_t> rv, cv;
-    coo_to_csr_csc(ixA, ixB, Xs.data(), m, n, nnz, rp, ri, rv, cp, ci, cv);
-    std::vector<real_t>().swap(Xs);
+    std::vector<real_t> Xs;                                              // X is copied before edits (:9578-9599)
+    if (apply_log_transf) {
+        Xs.assign(X, X + nnz);
+        for (auto &x : Xs) x = std::log(x);
+    }
+    tm.lap("log transform");
 
     const int ktot = k + k_main;
     if (reset_values) {                                                  // :9750-9774 (no item side info: only A is drawn)
@@ -152,6 +169,7 @@ int_t fit_collective_implicit_als(
         // Cholesky: B's start values are never read (the B-step runs first), left as passed like the reference
     }
     if (!use_cg) finalize_chol = false;                                  // :9518
+    tm.lap("start values");
 
     cmfrec_hip_model mdl;
     memset(&mdl, 0, sizeof mdl);
@@ -160,15 +178,25 @@ int_t fit_collective_implicit_als(
     mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
-    int rc = cmfrec_hip_session_set_X(s, rp.data(), ri.data(), rv.data(), cp.data(), ci.data(), cv.data());
+    tm.lap("session create");
+    // X := alpha * X and COO -> CSR + CSC happen on the device (coo_device.hpp), same entry order as helpers.c:1375-1491
+    int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, alpha);
+    std::vector<real_t>().swap(Xs);
+    tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
+    if (tm.on) cmfrec_hip_session_sync(s);
+    tm.lap("set_factors");
     int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose);
+    if (tm.on) cmfrec_hip_session_sync(s);
+    tm.lap("ALS iterations");
     if (rc_loop == 0 || rc_loop == 3) {
         int rc2 = cmfrec_hip_session_get_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
         if (rc2) rc_loop = rc2;
     }
+    tm.lap("get_factors");
     cmfrec_hip_session_destroy(s);
+    tm.lap("session destroy");
     if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
     return rc_loop > 3 ? 1 : rc_loop;
 }

@@ -6,6 +6,7 @@
 // "[rows, k_tot + bias]" layout, the bias vectors, CSR and CSC copies of X, side information and
 // the small k x k work matrices -- all resident in HBM for the whole fit.
 #include "device.hpp"
+#include "coo_device.hpp"
 #include <functional>
 #include <new>
 
@@ -231,6 +232,40 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const i
         HIP_CHECK(hipSetDevice(s->dev.device));
         s->Xr.upload(s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->dev.stream);
         s->Xc.upload(s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->dev.stream);
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
+                                 size_t nnz, real_t alpha)
+{
+    return guarded([&]() {
+        const cmfrec_hip_model &m = s->mdl;
+        if (m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n) {
+            g_last_error = "cmfrec_hip_session_set_X_coo: only for sessions that own all rows and columns";
+            return 2;
+        }
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        DevBuf<int> dr, dc; DevBuf<real_t> dv;
+        dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
+        shard_from_coo(s->Xr, m.m, dr.ptr, dc.ptr, dv.ptr, nnz, alpha, s->dev.stream);
+        shard_from_coo(s->Xc, m.n, dc.ptr, dr.ptr, dv.ptr, nnz, alpha, s->dev.stream);
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_get_X(cmfrec_hip_session *s, int which, size_t *indptr, int_t *indices, real_t *values,
+                             int_t *order)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const SparseShard &X = (which == 'r' || which == 'R') ? s->Xr : s->Xc;
+        if (indptr) X.p.download(indptr, (size_t)X.nrows + 1, s->dev.stream);
+        if (indices) X.i.download(indices, X.nnz, s->dev.stream);
+        if (values) X.v.download(values, X.nnz, s->dev.stream);
+        if (order) X.order.download(order, (size_t)X.nrows, s->dev.stream);
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
 }

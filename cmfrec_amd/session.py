@@ -54,6 +54,26 @@ class AlsSession:
                 self._c(csc[0], np.uint64), self._c(csc[1], np.int32), self._c(csc[2])]
         _lib.check(self.lib.cmfrec_hip_session_set_X(self.handle, *[_lib.ptr(a) for a in keep]), self.lib, "set_X")
 
+    def set_X_coo(self, row, col, val, alpha=1.0):
+        """COO triplet (int32 row / col ids, values); CSR and CSC are built on the device with the
+        reference's entry order (stable in COO order, src/helpers.c:1375-1491)."""
+        R = _lib.real(self.dtype)
+        keep = [self._c(row, np.int32), self._c(col, np.int32), self._c(val)]
+        _lib.check(self.lib.cmfrec_hip_session_set_X_coo(self.handle, *[_lib.ptr(a) for a in keep],
+                                                         C.c_size_t(len(keep[2])), R(alpha)), self.lib, "set_X_coo")
+
+    def get_X(self, which):
+        """(indptr uint64, indices int32, values, order int32) of the resident CSR ('r') / CSC ('c')."""
+        rows = self.m if which == "r" else self.n
+        indptr = np.empty(rows + 1, np.uint64)
+        _lib.check(self.lib.cmfrec_hip_session_get_X(self.handle, C.c_int(ord(which)), _lib.ptr(indptr), None, None, None),
+                   self.lib, "get_X")
+        nnz = int(indptr[-1])
+        ind = np.empty(nnz, np.int32); val = np.empty(nnz, self.dtype); order = np.empty(rows, np.int32)
+        _lib.check(self.lib.cmfrec_hip_session_get_X(self.handle, C.c_int(ord(which)), None, _lib.ptr(ind), _lib.ptr(val),
+                                                     _lib.ptr(order)), self.lib, "get_X")
+        return indptr, ind, val, order
+
     def set_factors(self, A=None, B=None, biasA=None, biasB=None, Cm=None, Dm=None):
         keep = [self._c(x) for x in (A, B, biasA, biasB, Cm, Dm)]
         _lib.check(self.lib.cmfrec_hip_session_set_factors(self.handle, *[_lib.ptr(a) for a in keep]), self.lib,

@@ -189,6 +189,15 @@ const char *cmfrec_hip_last_error(void);
 int cmfrec_hip_session_set_X(cmfrec_hip_session *s,
                              const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
                              const size_t *csc_p, const int_t *csc_i, const real_t *csc_v);
+/* Same from the COO triplet (host buffers): CSR and CSC are built in HBM by a stable sort, i.e. with the
+ * entry order of coo_to_csr_and_csc (src/helpers.c:1375-1491); values are multiplied by alpha on the way
+ * (src/collective.c:9606-9611).  Only for sessions that own all rows and columns. */
+int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
+                                 size_t nnz, real_t alpha);
+/* Copies the resident CSR (which = 'r') or CSC ('c') back: indptr[rows+1], indices[nnz], values[nnz],
+ * order[rows] = rows in processing order.  NULL = skip. */
+int cmfrec_hip_session_get_X(cmfrec_hip_session *s, int which, size_t *indptr, int_t *indices, real_t *values,
+                             int_t *order);
 /* Full factor matrices A[m, k_user+k+k_main], B[n, k_item+k+k_main] (+ biasA[m], biasB[n] when the
  * model has them; C[p,k_user+k], D[q,k_item+k]); host buffers.  NULL = leave unchanged. */
 int cmfrec_hip_session_set_factors(cmfrec_hip_session *s, const real_t *A, const real_t *B,

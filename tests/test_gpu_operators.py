@@ -129,3 +129,40 @@ def test_lane_primitives_selftest(dtype):
     """DPP / permlane-swap shuffles, broadcasts and the transposed butterflies, checked lane by lane."""
     from cmfrec_amd import _lib
     assert _lib.load(dtype).cmfrec_hip_selftest_lanes() == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("m,n,nnz", [(300, 200, 6000), (5000, 70000, 400000), (7, 3, 0)])
+def test_coo_device_matches_host(dtype, m, n, nnz):
+    """COO -> CSR / CSC on the device (coo_device.hpp) against the reference's counting sort
+    (helpers.c:1375-1491: stable in COO order): index work bit-exact, values one IEEE multiply."""
+    from cmfrec_amd.session import AlsSession
+    rng = np.random.default_rng(5)
+    row = rng.integers(0, m, nnz).astype(np.int32)         # duplicates and empty rows on purpose
+    col = rng.integers(0, n, nnz).astype(np.int32)
+    if nnz:
+        row[: nnz // 10] = 3                                # one heavy row (exercises the > 2048 bin when large)
+    val = rng.lognormal(size=nnz).astype(dtype)
+    alpha = dtype(2.5)
+    s = AlsSession(m, n, 8, implicit=True, dtype=dtype)
+    s.set_X_coo(row, col, val, alpha=float(alpha))
+    for which, key, other, rows in (("r", row, col, m), ("c", col, row, n)):
+        p, i, v, order = s.get_X(which)
+        perm = np.argsort(key, kind="stable")
+        cnt = np.bincount(key, minlength=rows)
+        assert np.array_equal(p, np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64))
+        assert np.array_equal(i, other[perm])
+        assert np.array_equal(v, val[perm] * alpha)
+        assert np.array_equal(order, np.argsort(-cnt, kind="stable").astype(np.int32))
+    # a half-step on the device-built shards equals one on the host-built ones
+    if nnz:
+        A0 = rng.normal(size=(m, 8)).astype(dtype) * 0.1
+        B0 = rng.normal(size=(n, 8)).astype(dtype) * 0.1
+        s.set_factors(A=A0, B=B0); s.update("A"); fa = s.get_factors()["A"]
+        s2 = AlsSession(m, n, 8, implicit=True, dtype=dtype)
+        permr = np.argsort(row, kind="stable"); permc = np.argsort(col, kind="stable")
+        pr = np.concatenate([[0], np.cumsum(np.bincount(row, minlength=m))]).astype(np.uint64)
+        pc = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=n))]).astype(np.uint64)
+        s2.set_X((pr, col[permr], val[permr] * alpha), (pc, row[permc], val[permc] * alpha))
+        s2.set_factors(A=A0, B=B0); s2.update("A"); fb = s2.get_factors()["A"]
+        assert np.array_equal(fa, fb)

@@ -33,6 +33,21 @@ __global__ void __launch_bounds__(256) k_f32(float *out, int iters)
     for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// v_fma_f64 / v_fma_f32 issue rate: NACC independent chains per lane
+template <typename T, int NACC>
+__global__ void __launch_bounds__(256) k_fma(T *out, int iters)
+{
+    T acc[NACC];
+    for (int i = 0; i < NACC; i++) acc[i] = T(threadIdx.x + i);
+    T a = T(1.0) + T(threadIdx.x) * T(1e-9), b = T(1e-3);
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = acc[i] * a + b;
+    }
+    T s = 0;
+    for (int i = 0; i < NACC; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 // dependent chain of LDS reads: latency per ds_read_b64
 __global__ void __launch_bounds__(64) k_lds(int *out, int iters)
 {
@@ -71,6 +86,19 @@ int main()
     run([&] { hipLaunchKernelGGL(k_f64<1>, dim3(ncu), dim3(256), 0, 0, o, iters); }, "f64 dependent chain", 1.0 * iters, 1);
     run([&] { hipLaunchKernelGGL(k_f32<8>, dim3(ncu), dim3(256), 0, 0, (float *)o, iters); }, "f32 16x16x4, 1 wave/SIMD", 8.0 * iters, 1);
     run([&] { hipLaunchKernelGGL(k_f32<1>, dim3(ncu), dim3(256), 0, 0, (float *)o, iters); }, "f32 dependent chain", 1.0 * iters, 1);
+    auto runf = [&](auto launch, const char *name, double fma_per_wave, int waves_per_simd) {
+        launch(); hipDeviceSynchronize();
+        hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double cyc = ms * 1e-3 * clk;
+        printf("%-28s %8.3f ms  -> %.2f cycles per wave-FMA per SIMD (%d waves/SIMD) = %.1f TFLOP/s\n", name, ms,
+               cyc / (fma_per_wave * waves_per_simd), waves_per_simd, fma_per_wave * waves_per_simd * 4 * ncu * 128 / (ms * 1e-3) / 1e12);
+    };
+    runf([&] { hipLaunchKernelGGL((k_fma<double, 16>), dim3(ncu), dim3(256), 0, 0, o, iters); }, "v_fma_f64, 1 wave/SIMD", 16.0 * iters, 1);
+    runf([&] { hipLaunchKernelGGL((k_fma<double, 16>), dim3(4 * ncu), dim3(256), 0, 0, o, iters); }, "v_fma_f64, 4 waves/SIMD", 16.0 * iters, 4);
+    runf([&] { hipLaunchKernelGGL((k_fma<double, 1>), dim3(ncu), dim3(256), 0, 0, o, iters); }, "v_fma_f64 dependent", 1.0 * iters, 1);
+    runf([&] { hipLaunchKernelGGL((k_fma<float, 16>), dim3(ncu), dim3(256), 0, 0, (float *)o, iters); }, "v_fma_f32, 1 wave/SIMD", 16.0 * iters, 1);
+    runf([&] { hipLaunchKernelGGL((k_fma<float, 16>), dim3(4 * ncu), dim3(256), 0, 0, (float *)o, iters); }, "v_fma_f32, 4 waves/SIMD", 16.0 * iters, 4);
     {
         int *oi = (int *)o;
         hipLaunchKernelGGL(k_lds, dim3(1), dim3(64), 0, 0, oi, 100000); hipDeviceSynchronize();
