@@ -99,6 +99,8 @@ struct SparseShard {
     size_t bin_nnz[NBINS] = {0, 0, 0, 0, 0, 0};
     int n_nonempty = 0, n_empty = 0;
     int max_nnz = 0;
+    int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
+    static constexpr int LONG_ROW = 1024;
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
     int n_chunks = 0;
     DevBuf<int> vh_chunk_row, vh_chunk_first, vh_chunk_off, vh_done;
@@ -134,10 +136,11 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0;
+        n_empty = 0; n_long = 0;
         std::vector<int> c_row, c_first, c_off(1, 0);
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
+            if (l > LONG_ROW) n_long++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {

@@ -2,9 +2,9 @@
 //
 // Host-side restatement of the driver logic of the reference's fit_collective_implicit_als
 // (/root/reference/src/collective.c:9375-10207) and fit_collective_explicit_als (:7263-9370) for
-// the supported option set: input validation, X := alpha*X / log, COO -> CSR + CSC (stable,
-// helpers.c:1375-1491), global mean (common.c:3423-3648), side-info column centering
-// (common.c:4911-4997), bias initialisation (common.c:4410-4909), start values, and the ALS loop
+// the supported option set: input validation, log transform, global mean (common.c:3423-3648), side-info column centering
+// (common.c:4911-4997), start values; X := (X - mean)*alpha, COO -> CSR + CSC (stable, helpers.c:1375-1491)
+// and the bias initialisation (common.c:4410-4909) run on the device (coo_device.hpp); the ALS loop
 // order C -> D -> B -> A, which runs on the device-resident session (session.hip).  Every
 // temporary is allocated and freed here; outputs are caller-allocated (cmfrec.h.in:240-241).
 #include <cfloat>
@@ -20,29 +20,6 @@
 #include "rng_host.hpp"
 
 namespace {
-
-// ---- stable counting sort COO -> CSR / CSC (entries keep the COO order inside a row) --------
-void coo_to_csr_csc(const int_t *row, const int_t *col, const real_t *val, int_t m, int_t n, size_t nnz,
-                    std::vector<size_t> &rp, std::vector<int_t> &ri, std::vector<real_t> &rv,
-                    std::vector<size_t> &cp, std::vector<int_t> &ci, std::vector<real_t> &cv)
-{
-    rp.assign((size_t)m + 1, 0);
-    cp.assign((size_t)n + 1, 0);
-    ri.resize(nnz); rv.resize(nnz); ci.resize(nnz); cv.resize(nnz);
-    for (size_t e = 0; e < nnz; e++) {
-        rp[(size_t)row[e] + 1]++;
-        cp[(size_t)col[e] + 1]++;
-    }
-    for (int_t r = 0; r < m; r++) rp[(size_t)r + 1] += rp[r];
-    for (int_t c = 0; c < n; c++) cp[(size_t)c + 1] += cp[c];
-    std::vector<size_t> nr(rp.begin(), rp.end() - 1), nc(cp.begin(), cp.end() - 1);
-    for (size_t e = 0; e < nnz; e++) {
-        size_t a = nr[row[e]]++;
-        ri[a] = col[e]; rv[a] = val[e];
-        size_t b = nc[col[e]]++;
-        ci[b] = row[e]; cv[b] = val[e];
-    }
-}
 
 // ---- SIGINT between half-steps (helpers.c:1493-1501, collective.c:9520-9531) -----------------
 volatile sig_atomic_t g_stop = 0;
@@ -180,7 +157,7 @@ int_t fit_collective_implicit_als(
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
     tm.lap("session create");
     // X := alpha * X and COO -> CSR + CSC happen on the device (coo_device.hpp), same entry order as helpers.c:1375-1491
-    int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, alpha);
+    int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, (real_t)0, alpha);
     std::vector<real_t>().swap(Xs);
     tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
@@ -248,26 +225,24 @@ int_t fit_collective_explicit_als(
     const bool has_bias = user_bias || item_bias;
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
 
-    // ---- global mean, common.c:3494-3524 + :3603 (nthreads selects running mean vs sum/cnt) ----
-    std::vector<real_t> Xs(X, X + nnz);
+    // ---- global mean, common.c:3494-3524 + :3603 (nthreads selects running mean vs sum/cnt); the
+    //      subtraction itself happens on the device while the CSR / CSC are built ----
+    PhaseTimer tm;
     real_t gm = 0;
     if (center) {
         double xsum = 0;
         if (nthreads >= 8) {
-            for (size_t e = 0; e < nnz; e++) xsum += Xs[e];
+            for (size_t e = 0; e < nnz; e++) xsum += X[e];
             gm = (real_t)(xsum / (double)nnz);
         } else {
             size_t cnt = 0;
-            for (size_t e = 0; e < nnz; e++) xsum += (Xs[e] - xsum) / (double)(++cnt);
+            for (size_t e = 0; e < nnz; e++) xsum += (X[e] - xsum) / (double)(++cnt);
             gm = (real_t)xsum;
         }
         if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
-        if (gm != 0) for (auto &x : Xs) x -= gm;
     }
     *glob_mean = gm;
-    std::vector<size_t> rp, cp; std::vector<int_t> ri, ci; std::vector<real_t> rv, cv;
-    coo_to_csr_csc(ixA, ixB, Xs.data(), m, n, nnz, rp, ri, rv, cp, ci, cv);
-    std::vector<real_t>().swap(Xs);
+    tm.lap("global mean");
 
     // ---- side information: column means + centering, common.c:4938-4997 ----
     std::vector<real_t> Uc, Ic;
@@ -281,47 +256,7 @@ int_t fit_collective_explicit_als(
     if (U) center_cols(U, m_u, p, U_colmeans, Uc);
     if (II) center_cols(II, n_i, q, I_colmeans, Ic);
 
-    // ---- bias start values, common.c:4410-4909 (sparse, unweighted; both biases) ----
-    if (has_bias && reset_values) {
-        real_t lam_u = lam, lam_i = lam;
-        if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
-        if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
-        // initialize_biases_onesided, common.c:4265-4289 (sparse, unweighted, missing-as-NA)
-        auto onesided = [&](const std::vector<size_t> &ptr, const std::vector<real_t> &vals, int_t rows, real_t lam_b,
-                            real_t *bias) {
-            for (int_t r = 0; r < rows; r++) {
-                double bm = 0;
-                size_t st = ptr[r], en = ptr[(size_t)r + 1], cnt = en - st;
-                for (size_t e = st; e < en; e++) bm += (vals[e] - bm) / (double)(e - st + 1);
-                bm *= (double)cnt / ((double)cnt + lam_b * (scale_lam ? (double)(cnt > 1 ? cnt : 1) : 1.));
-                bias[r] = (real_t)bm;
-            }
-        };
-        if (user_bias && !item_bias) {                                    // collective.c:8166-8185
-            onesided(rp, rv, m, lam_u, biasA);
-        } else if (item_bias && !user_bias) {                             // :8187-8204 (only when the B-step uses CG)
-            if (use_cg) onesided(cp, cv, n, lam_i, biasB);
-        } else {
-        memset(biasA, 0, (size_t)m * sizeof(real_t));
-        memset(biasB, 0, (size_t)n * sizeof(real_t));
-        for (int sweep = 0; sweep < 5; sweep++) {
-            for (int_t c = 0; c < n; c++) {                               // :4643-4669
-                double bm = 0;
-                size_t st = cp[c], en = cp[(size_t)c + 1], cnt = en - st;
-                for (size_t e = st; e < en; e++) bm += (cv[e] - biasA[ci[e]] - bm) / (double)(e - st + 1);
-                bm *= (double)cnt / ((double)cnt + lam_i * (scale_lam ? (double)(cnt > 1 ? cnt : 1) : 1.));
-                biasB[c] = (real_t)bm;
-            }
-            for (int_t r = 0; r < m; r++) {                               // :4799-4825
-                double bm = 0;
-                size_t st = rp[r], en = rp[(size_t)r + 1], cnt = en - st;
-                for (size_t e = st; e < en; e++) bm += (rv[e] - biasB[ri[e]] - bm) / (double)(e - st + 1);
-                if (cnt > 0) bm *= (double)cnt / ((double)cnt + lam_u * (scale_lam ? (double)cnt : 1.));
-                biasA[r] = (real_t)bm;
-            }
-        }
-        }
-    }
+    tm.lap("side info centring");
     // ---- factor start values, collective.c:8241-8274 ----
     if (reset_values) {
         const bool fill_B = (II != nullptr);
@@ -342,17 +277,32 @@ int_t fit_collective_explicit_als(
     mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
-    int rc = cmfrec_hip_session_set_X(s, rp.data(), ri.data(), rv.data(), cp.data(), ci.data(), cv.data());
+    tm.lap("start values + session");
+    // X - mean, COO -> CSR + CSC and the bias start values are computed on the device (coo_device.hpp)
+    int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, X, nnz, gm, (real_t)1);
+    tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
-    if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, biasA, biasB, C, D);
+    if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
+    if (tm.on) cmfrec_hip_session_sync(s);
+    tm.lap("side info + factors upload");
+    if (!rc && has_bias && reset_values) {                                // common.c:4410-4909; lambdas clipped like :4449-4452
+        real_t lam_u = lam, lam_i = lam;
+        if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
+        if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
+        rc = cmfrec_hip_session_init_biases(s, lam_u, lam_i);
+    }
+    if (tm.on) cmfrec_hip_session_sync(s);
+    tm.lap("bias init");
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose);
+    if (tm.on) cmfrec_hip_session_sync(s);
+    tm.lap("ALS iterations");
     if (rc_loop == 0 || rc_loop == 3) {
         int rc2 = cmfrec_hip_session_get_factors(s, A, B, biasA, biasB, C, D);
         if (rc2) rc_loop = rc2;
     }
     cmfrec_hip_session_destroy(s);
-    (void)has_bias;
+    tm.lap("get_factors + destroy");
     if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
     return rc_loop > 3 ? 1 : rc_loop;
 }

@@ -237,7 +237,7 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const i
 }
 
 int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
-                                 size_t nnz, real_t alpha)
+                                 size_t nnz, real_t subtract, real_t alpha)
 {
     return guarded([&]() {
         const cmfrec_hip_model &m = s->mdl;
@@ -248,9 +248,49 @@ int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const 
         HIP_CHECK(hipSetDevice(s->dev.device));
         DevBuf<int> dr, dc; DevBuf<real_t> dv;
         dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
-        shard_from_coo(s->Xr, m.m, dr.ptr, dc.ptr, dv.ptr, nnz, alpha, s->dev.stream);
-        shard_from_coo(s->Xc, m.n, dc.ptr, dr.ptr, dv.ptr, nnz, alpha, s->dev.stream);
+        shard_from_coo(s->Xr, m.m, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
+        shard_from_coo(s->Xc, m.n, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_init_biases(cmfrec_hip_session *s, real_t lam_user, real_t lam_item)
+{
+    return guarded([&]() {
+        const cmfrec_hip_model &m = s->mdl;
+        if (m.implicit || !s->has_bias) { g_last_error = "cmfrec_hip_session_init_biases: the model has no biases"; return 2; }
+        if (m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n) {
+            g_last_error = "cmfrec_hip_session_init_biases: only for sessions that own all rows and columns";
+            return 2;
+        }
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        hipStream_t st = s->dev.stream;
+        auto sweep = [&](const SparseShard &X, const real_t *other, real_t lam_b, int user_rule, real_t *bias) {
+            if (X.n_long > 0)
+                hipLaunchKernelGGL(bias_sweep_long_kernel, dim3(X.n_long), dim3(64), 0, st, X.p.ptr, X.i.ptr, X.v.ptr, other,
+                                   X.order.ptr, X.n_long, lam_b, (int)m.scale_lam, user_rule, bias);
+            if (X.nrows > X.n_long)
+                hipLaunchKernelGGL(bias_sweep_kernel, dim3((X.nrows - X.n_long + 63) / 64), dim3(64), 0, st, X.p.ptr, X.i.ptr,
+                                   X.v.ptr, other, X.order.ptr, X.n_long, X.nrows, lam_b, (int)m.scale_lam, user_rule, bias);
+        };
+        if (m.user_bias && !m.item_bias) {                                // collective.c:8166-8185
+            sweep(s->Xr, nullptr, lam_user, 0, s->biasA.ptr);
+        } else if (m.item_bias && !m.user_bias) {                         // :8187-8204 (only when the B-step uses CG)
+            if (m.use_cg) sweep(s->Xc, nullptr, lam_item, 0, s->biasB.ptr);
+        } else {                                                          // common.c:4410-4909, five sweeps, items first
+            HIP_CHECK(hipMemsetAsync(s->biasA.ptr, 0, (size_t)m.m * sizeof(real_t), st));
+            HIP_CHECK(hipMemsetAsync(s->biasB.ptr, 0, (size_t)m.n * sizeof(real_t), st));
+            for (int it = 0; it < 5; it++) {
+                sweep(s->Xc, s->biasA.ptr, lam_item, 0, s->biasB.ptr);
+                sweep(s->Xr, s->biasB.ptr, lam_user, 1, s->biasA.ptr);
+            }
+        }
+        if (m.user_bias)
+            hipLaunchKernelGGL(col_insert_kernel<real_t>, grid1d(m.m), dim3(256), 0, st, s->A.ptr, s->ldA, m.m, s->k_totA, s->biasA.ptr);
+        if (m.item_bias)
+            hipLaunchKernelGGL(col_insert_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, s->B.ptr, s->ldB, m.n, s->k_totB, s->biasB.ptr);
+        HIP_CHECK(hipGetLastError());
         return 0;
     });
 }

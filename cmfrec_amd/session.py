@@ -54,13 +54,18 @@ class AlsSession:
                 self._c(csc[0], np.uint64), self._c(csc[1], np.int32), self._c(csc[2])]
         _lib.check(self.lib.cmfrec_hip_session_set_X(self.handle, *[_lib.ptr(a) for a in keep]), self.lib, "set_X")
 
-    def set_X_coo(self, row, col, val, alpha=1.0):
+    def init_biases(self, lam_user, lam_item):
+        """Bias start values on the device (reference initialize_biases_*, src/common.c:4410-4909)."""
+        R = _lib.real(self.dtype)
+        _lib.check(self.lib.cmfrec_hip_session_init_biases(self.handle, R(lam_user), R(lam_item)), self.lib, "init_biases")
+
+    def set_X_coo(self, row, col, val, alpha=1.0, subtract=0.0):
         """COO triplet (int32 row / col ids, values); CSR and CSC are built on the device with the
         reference's entry order (stable in COO order, src/helpers.c:1375-1491)."""
         R = _lib.real(self.dtype)
         keep = [self._c(row, np.int32), self._c(col, np.int32), self._c(val)]
         _lib.check(self.lib.cmfrec_hip_session_set_X_coo(self.handle, *[_lib.ptr(a) for a in keep],
-                                                         C.c_size_t(len(keep[2])), R(alpha)), self.lib, "set_X_coo")
+                                                         C.c_size_t(len(keep[2])), R(subtract), R(alpha)), self.lib, "set_X_coo")
 
     def get_X(self, which):
         """(indptr uint64, indices int32, values, order int32) of the resident CSR ('r') / CSC ('c')."""

@@ -190,10 +190,15 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s,
                              const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
                              const size_t *csc_p, const int_t *csc_i, const real_t *csc_v);
 /* Same from the COO triplet (host buffers): CSR and CSC are built in HBM by a stable sort, i.e. with the
- * entry order of coo_to_csr_and_csc (src/helpers.c:1375-1491); values are multiplied by alpha on the way
- * (src/collective.c:9606-9611).  Only for sessions that own all rows and columns. */
+ * entry order of coo_to_csr_and_csc (src/helpers.c:1375-1491); values become (x - subtract) * alpha on the
+ * way (centring src/common.c:3603-3613; confidence src/collective.c:9606-9611).  Only for sessions that own
+ * all rows and columns. */
 int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
-                                 size_t nnz, real_t alpha);
+                                 size_t nnz, real_t subtract, real_t alpha);
+/* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
+ * _onesided (src/common.c:4410-4909, 4265-4289; call sites src/collective.c:8166-8220): written to the
+ * session's bias vectors and the bias columns of A / B.  Call after set_X* and set_factors. */
+int cmfrec_hip_session_init_biases(cmfrec_hip_session *s, real_t lam_user, real_t lam_item);
 /* Copies the resident CSR (which = 'r') or CSC ('c') back: indptr[rows+1], indices[nnz], values[nnz],
  * order[rows] = rows in processing order.  NULL = skip. */
 int cmfrec_hip_session_get_X(cmfrec_hip_session *s, int which, size_t *indptr, int_t *indices, real_t *values,

@@ -166,3 +166,44 @@ def test_coo_device_matches_host(dtype, m, n, nnz):
         s2.set_X((pr, col[permr], val[permr] * alpha), (pc, row[permc], val[permc] * alpha))
         s2.set_factors(A=A0, B=B0); s2.update("A"); fb = s2.get_factors()["A"]
         assert np.array_equal(fa, fb)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("scale_lam", [False, True])
+@pytest.mark.parametrize("long_rows", [False, True])
+def test_bias_init_device_matches_oracle(oracles, dtype, scale_lam, long_rows):
+    """Centring + two-sided bias start values computed on the device (coo_device.hpp) against the
+    oracle's restatement of calc_mean_and_center / initialize_biases_twosided
+    (common.c:3423-3648, 4410-4909): sequential per-row running means in the same order.  Centring
+    and the CSR are bit-exact; the biases agree to 1 ulp-level (the compiled reference fuses
+    `cnt + lam*cnt` into an FMA in one of the two sweeps, the device kernel in neither)."""
+    from cmfrec_amd.session import AlsSession
+    O = oracles[dtype]
+    m, n, k = 400, 250, 4
+    row, col, val = make_coo(m, n, 9000, seed=11, counts=False, dtype=dtype, empty_rows=(5, 17))
+    if long_rows:      # rows / columns beyond 1024 entries take the wave-parallel sum (same mean up to rounding)
+        m, n = 3000, 2500
+        row, col, val = make_coo(m, n, 60000, seed=12, counts=False, dtype=dtype, heavy_row=(3, 1800), empty_rows=(5, 17))
+        rng = np.random.default_rng(3)
+        extra = np.setdiff1d(rng.choice(m, 1500, replace=False), row[col == 7]).astype(np.int32)
+        extra = extra[(extra != 5) & (extra != 17)]
+        row = np.concatenate([row, extra]); col = np.concatenate([col, np.full(len(extra), 7, np.int32)])
+        val = np.concatenate([val, (0.5 * rng.integers(1, 11, len(extra))).astype(dtype)])
+        assert np.bincount(row).max() > 1024 and np.bincount(col).max() > 1024
+    Xc = val.copy()
+    gm = O.calc_mean_and_center(Xc, nthreads=1)            # centres Xc in place, returns the mean
+    assert gm != 0
+    csr, csc = O.coo_to_csr_and_csc(row, col, Xc, m, n)
+    lam = 0.7
+    bA, bB = O.initialize_biases_twosided(m, n, csr, csc, lam, lam, scale_lam)
+    s = AlsSession(m, n, k, implicit=False, dtype=dtype, lam=lam, user_bias=True, item_bias=True, scale_lam=scale_lam)
+    s.set_X_coo(row, col, val, subtract=float(gm))
+    p, i, v, _ = s.get_X("r")
+    assert np.array_equal(v, csr[2]) and np.array_equal(i, csr[1])
+    s.set_factors(A=np.zeros((m, k), dtype), B=np.zeros((n, k), dtype))
+    s.init_biases(lam, lam)
+    f = s.get_factors()
+    tol = 1e-13 if dtype is np.float64 else 2e-6
+    assert np.abs(f["biasA"] - bA).max() <= tol * max(1.0, np.abs(bA).max())
+    assert np.abs(f["biasB"] - bB).max() <= tol * max(1.0, np.abs(bB).max())
+    assert np.array_equal(f["biasA"][[5, 17]], np.zeros(2, dtype))          # rows without entries
