@@ -14,6 +14,7 @@
 #include "cg_kernels.hpp"
 #include "chol_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "gram_cg_kernels.hpp"
 
 namespace cmfhip {
 
@@ -105,6 +106,11 @@ struct SparseShard {
     int n_chunks = 0;
     DevBuf<int> vh_chunk_row, vh_chunk_first, vh_chunk_off, vh_done;
     DevBuf<real_t> vh_r, vh_p, vh_r_old, vh_part;
+    // Gramian path of the very heavy rows (gram_cg_kernels.hpp): slices of <= GRAM_SLICE non-zeros
+    static constexpr int GRAM_SLICE = 2048;
+    int n_slices = 0;
+    DevBuf<int> sl_vrow, sl_first, sl_count, row_sl_off;
+    DevBuf<real_t> gram_part;
 
     void upload(int nrows_, const size_t *hp, const int *hi, const real_t *hv, hipStream_t st)
     {
@@ -138,6 +144,7 @@ struct SparseShard {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
         n_empty = 0; n_long = 0;
         std::vector<int> c_row, c_first, c_off(1, 0);
+        std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
@@ -147,6 +154,13 @@ struct SparseShard {
                 int ntiles = (int)((l + TILE - 1) / TILE);
                 for (int t0 = 0; t0 < ntiles; t0 += VH_CHUNK_TILES) { c_row.push_back(bin_rows[b]); c_first.push_back(t0); }
                 c_off.push_back((int)c_row.size());
+                // equal slices, multiples of 16 non-zeros (one staging round)
+                const int nsl = (int)((l + GRAM_SLICE - 1) / GRAM_SLICE);
+                const int per = (int)((((l + nsl - 1) / nsl) + 15) / 16 * 16);
+                for (long long f = 0; f < l; f += per) {
+                    s_row.push_back(bin_rows[b]); s_first.push_back((int)f); s_count.push_back((int)std::min<long long>(per, l - f));
+                }
+                s_off.push_back((int)s_row.size());
             }
             bin_rows[b]++; bin_nnz[b] += (size_t)l;
         }
@@ -163,6 +177,12 @@ struct SparseShard {
             vh_done.alloc(nvh); vh_r_old.alloc(nvh);
             vh_r.alloc((size_t)nvh * 64); vh_p.alloc((size_t)nvh * 64);
             vh_part.alloc((size_t)n_chunks * 64);
+            n_slices = (int)s_row.size();
+            sl_vrow.upload(s_row.data(), s_row.size(), st);
+            sl_first.upload(s_first.data(), s_first.size(), st);
+            sl_count.upload(s_count.data(), s_count.size(), st);
+            row_sl_off.upload(s_off.data(), s_off.size(), st);
+            gram_part.alloc((size_t)n_slices * GRAM_PART);
         }
         HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -316,6 +336,28 @@ inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const Sp
         HIP_CHECK(hipEventCreate(&ev.a));
         HIP_CHECK(hipEventCreate(&ev.b));
         HIP_CHECK(hipEventRecord(ev.a, dev.stream));
+    }
+    // CMFREC_HIP_VH=gram: read the gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp).
+    // Measured on C2 (fp64): 1.53 ms against 1.28 ms for the streaming path below -- v_mfma_f64_16x16x4 issues at
+    // 107-141 cycles on this part, no faster than the FP64 VALU, so 6x the flops do not pay for 4x fewer bytes.
+    // Kept as an option (and as an on-device cross-check of the split-row path); default: stream.
+    const char *vh_env = getenv("CMFREC_HIP_VH");
+    const bool use_gram = vh_env != nullptr && strcmp(vh_env, "gram") == 0;
+    if (P.k <= 16 * GRAM_NTT && use_gram) {
+        // one gather: Gramian slices on the matrix cores, then CG on the k x k system (gram_cg_kernels.hpp)
+        GramParams<real_t> G;
+        G.sl_vrow = X.sl_vrow.ptr; G.sl_first = X.sl_first.ptr; G.sl_count = X.sl_count.ptr; G.row_sl_off = X.row_sl_off.ptr;
+        G.part = X.gram_part.ptr; G.n_slices = X.n_slices; G.nvh = nvh;
+        P.nrows = nvh;
+        hipLaunchKernelGGL((gram_slice_kernel<real_t, IMPLICIT>), dim3(std::min(X.n_slices, dev.num_cus * 2)), dim3(64 * GRAM_NW), 0,
+                           dev.stream, P, G);
+        hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 4)), dim3(256), 0, dev.stream, P, G);
+        HIP_CHECK(hipGetLastError());
+        if (tm) {
+            HIP_CHECK(hipEventRecord(ev.b, dev.stream));
+            tm->ev[BIN_VHEAVY].push_back(ev);
+        }
+        return;
     }
     VhState<real_t> V;
     V.r = X.vh_r.ptr; V.p = X.vh_p.ptr; V.r_old = X.vh_r_old.ptr; V.done = X.vh_done.ptr; V.part = X.vh_part.ptr;

@@ -1,0 +1,247 @@
+// gram_cg_kernels.hpp -- CG row update of the very heavy rows through the row's own Gramian (k_t <= 64).
+//
+// A row with thousands of non-zeros does not fit a team's registers, so the tiled kernels of
+// cg_kernels.hpp would have to re-stream its gathered rows for every one of the max_cg_steps+1 passes
+// (4.9x the algorithmic HBM bytes measured on the split-row path).  The operator of the reference's CG,
+//     implicit (factors_implicit_cg, src/common.c:1914-1986):  Ap = (BtB + lam I) p + sum_j x_j (B_j.p) B_j
+//     explicit (factors_explicit_cg, src/common.c:1098-1188):  Ap = diag(lam..lam_last) p + sum_j (B_j.p) B_j
+// is linear in the k_t x k_t matrix  G = sum_j w_j B_j B_j^T  (w = x | 1), so for these rows the gathered rows
+// are read ONCE:
+//   gram_slice_kernel : a slice (<= GRAM_SLICE non-zeros) of a row per workgroup; G on the matrix cores
+//                       (same staging ring / C-layout tiles as chol_kernels.hpp) and the residual's vector
+//                       part  v = sum_j (x_j - B_j.a) B_j  (implicit, quirk Q1)  |  sum_j x_j B_j  (explicit)
+//                       -> per-slice partials in HBM (no floating-point atomics);
+//   gram_cg_kernel    : per row, partials summed in slice order, M = G + (BtB + lam I | diag) in LDS,
+//                       r = v - M a, then the reference's CG steps with dense matrix-vector products,
+//                       same absolute thresholds (1e-12 / 1e-8).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cg_kernels.hpp"
+#include "chol_kernels.hpp"
+#include "lanes.hpp"
+
+namespace cmfhip {
+
+constexpr int GRAM_NTT = 4;                              // k_t <= 64
+constexpr int GRAM_NTILES = GRAM_NTT * (GRAM_NTT + 1) / 2;
+constexpr int GRAM_PART = GRAM_NTILES * 256 + 64;        // elements of one slice partial: tiles (C layout) + v
+constexpr int GRAM_CH = 32;                              // gathered rows per staging round
+constexpr int GRAM_NW = 4;                               // wavefronts per workgroup
+
+template <typename T>
+struct GramParams {
+    const int *sl_vrow;        // slice -> ordinal of its row in the very-heavy bin (= position in desc)
+    const int *sl_first;       // slice -> first non-zero inside the row
+    const int *sl_count;       // slice -> number of non-zeros
+    const int *row_sl_off;     // [nvh + 1] slices of a row are contiguous
+    T *part;                   // [n_slices][GRAM_PART]
+    int n_slices, nvh;
+};
+
+// sums of c[0..7] over the 64 lanes in 10 exchanges: afterwards lane l holds the total of c[l >> 3]
+template <typename T>
+__device__ __forceinline__ T treduce8_rows(const T (&c)[8], int lane)
+{
+    T n4[4], n2[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) n4[i] = lanes::tswap32_add(c[i], c[4 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; i++) n2[i] = lanes::tswap16_add(n4[i], n4[2 + i]);
+    T n1 = ((lane & 8) ? n2[1] : n2[0]) + lanes::recv_xor8(n2[0], n2[1]);
+    n1 += lanes::xor4(n1);
+    n1 += lanes::xor2(n1);
+    n1 += lanes::xor1(n1);
+    return n1;
+}
+
+template <typename T, bool IMPLICIT>
+__global__ void __launch_bounds__(64 * GRAM_NW, 2)
+gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
+{
+    using Mf = CholMfma<T>;
+    using vec = typename Mf::vec;
+    constexpr int NTT = GRAM_NTT, NW = GRAM_NW, CH = GRAM_CH;
+    constexpr int ldc = 16 * NTT + 16;                        // 80 == 16 (mod 32)
+    constexpr int NTALL = GRAM_NTILES;
+    constexpr int TPW = (NTALL + NW - 1) / NW;
+    constexpr int RPW = CH / NW;
+    static_assert(RPW == 8, "treduce8_rows");
+    __shared__ T ring[2 * CH * ldc];
+    __shared__ T wsc[2 * CH];
+    __shared__ T vpart[NW * 64];
+    const int kt = P.k;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15;
+    int offa[TPW], offb[TPW];
+#pragma unroll
+    for (int tt = 0; tt < TPW; tt++) {
+        const int t = min(wave + NW * tt, NTALL - 1);         // idle slots recompute the last tile, never stored
+        offa[tt] = 16 * tile_bi(t, NTT);
+        offb[tt] = 16 * tile_bj(t, NTT);
+    }
+    const int scol = (lane < kt) ? lane : 0;
+    const bool svalid = lane < kt;
+    const int myrow = lane >> 3;                              // lane 8i owns the weights of staged row i of this wave
+
+    for (int sl = blockIdx.x; sl < Gp.n_slices; sl += gridDim.x) {
+        const RowDesc d = P.desc[Gp.sl_vrow[sl]];
+        const size_t st = d.st + (size_t)Gp.sl_first[sl];
+        const int nnz = Gp.sl_count[sl];
+        const T *arow = P.A + (size_t)d.row * P.lda;
+        const T a_l = (IMPLICIT && svalid) ? arow[lane] : T(0);
+        vec acc[TPW];
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++) acc[tt] = vec{0, 0, 0, 0};
+        T racc = T(0);                                        // v[lane], this wave's rows only
+        T pre[RPW];
+        int idn[RPW];
+        int idx_l = 0; T x_l = T(0), xw_l = T(0);
+        int nr_rows = 0, nr_idx = 0;
+        auto load_idx = [&](int c0) {
+            nr_idx = min(CH, nnz - c0);
+#pragma unroll
+            for (int i = 0; i < RPW; i++) idn[i] = P.indices[st + c0 + min(RPW * wave + i, nr_idx - 1)];
+            const size_t e = st + c0 + min(RPW * wave + myrow, nr_idx - 1);
+            idx_l = P.indices[e]; x_l = P.values[e];
+        };
+        auto load_rows = [&]() {
+            nr_rows = nr_idx;
+#pragma unroll
+            for (int i = 0; i < RPW; i++) pre[i] = P.B[(size_t)idn[i] * P.ldb + scol];
+            xw_l = x_l;
+            if (!IMPLICIT && P.bias_sub != nullptr) xw_l -= P.bias_sub[idx_l];
+        };
+        if (nnz > 0) { load_idx(0); load_rows(); }
+        if (nnz > CH) load_idx(CH);
+        __syncthreads();                      // previous slice's readers are done
+        for (int c0 = 0, slot = 0; c0 < nnz; c0 += CH, slot ^= 1) {
+            T *Bs = ring + slot * CH * ldc;
+            T bv[RPW], prod[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; i++) {
+                bv[i] = (RPW * wave + i < nr_rows && svalid) ? pre[i] : T(0);
+                Bs[(RPW * wave + i) * ldc + lane] = bv[i];
+                if (lane < ldc - 64) Bs[(RPW * wave + i) * ldc + 64 + lane] = T(0);
+                prod[i] = bv[i] * a_l;
+            }
+            // weights of this wave's rows (lane 8i: row i):  G weight x | 1,  v weight x - B_j.a | x
+            const bool live_l = (RPW * wave + myrow < nr_rows);
+            T wv = live_l ? xw_l : T(0);
+            if (IMPLICIT) wv -= treduce8_rows(prod, lane);                // common.c:1936-1943 (0 for padded rows)
+            if ((lane & 7) == 0) wsc[slot * CH + RPW * wave + myrow] = live_l ? (IMPLICIT ? xw_l : T(1)) : T(0);
+#pragma unroll
+            for (int i = 0; i < RPW; i++) racc += bcast_lane(wv, 8 * i) * bv[i];
+            __syncthreads();
+            if (c0 + CH < nnz) load_rows();
+            if (c0 + 2 * CH < nnz) load_idx(c0 + 2 * CH);
+#pragma unroll
+            for (int q = 0; q < CH / 4; q++) {
+                const int rr = 4 * q + (lane >> 4);
+                const T *brow = Bs + rr * ldc + lm;
+                const T w = wsc[slot * CH + rr];
+                T opa[TPW], opb[TPW];
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++) { opa[tt] = brow[offa[tt]]; opb[tt] = brow[offb[tt]]; }
+#pragma unroll
+                for (int tt = 0; tt < TPW; tt++) acc[tt] = Mf::mma(opa[tt] * w, opb[tt], acc[tt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        T *out = Gp.part + (size_t)sl * GRAM_PART;
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++) {
+            const int t = wave + NW * tt;
+            if (t < NTALL) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[tt][r];
+            }
+        }
+        __syncthreads();                      // vpart of the previous slice has been read
+        vpart[wave * 64 + lane] = racc;
+        __syncthreads();
+        if (tid < 64) {
+            T vs = T(0);
+#pragma unroll
+            for (int w2 = 0; w2 < NW; w2++) vs += vpart[w2 * 64 + tid];
+            out[NTALL * 256 + tid] = (tid < kt) ? vs : T(0);
+        }
+    }
+}
+
+// one workgroup (256 threads) per very heavy row; wave 0 runs the CG
+template <typename T, bool IMPLICIT>
+__global__ void __launch_bounds__(256)
+gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
+{
+    using Mf = CholMfma<T>;
+    constexpr int NTT = GRAM_NTT, NTALL = GRAM_NTILES, LDM = 65;
+    __shared__ T M[64 * LDM];
+    __shared__ T vec_s[64];                   // the vector a dense product is taken with
+    const int kt = P.k;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int vr = blockIdx.x; vr < Gp.nvh; vr += gridDim.x) {
+        const RowDesc d = P.desc[vr];
+        T *arow = P.A + (size_t)d.row * P.lda;
+        const int s0 = Gp.row_sl_off[vr], s1 = Gp.row_sl_off[vr + 1];
+        T lam = P.lam, lam_last = P.lam_last;
+        if (!IMPLICIT && P.scale_lam) {                       // common.c:679-723
+            lam *= (T)d.nnz;
+            if (!P.scale_bias_const) lam_last *= (T)d.nnz;
+        }
+        __syncthreads();                      // previous row's CG is done with M
+        // G = sum of the slice partials, in slice order;  M = G + (BtB + lam I | diag(lam .. lam_last)), both triangles
+        for (int e = tid; e < NTALL * 256; e += 256) {
+            T s = T(0);
+            for (int sl = s0; sl < s1; sl += 8) {
+                T t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = (sl + u < s1) ? Gp.part[(size_t)(sl + u) * GRAM_PART + e] : T(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += t8[u];
+            }
+            const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
+            const int i = 16 * tile_bi(t, NTT) + Mf::row_of(l, r), j = 16 * tile_bj(t, NTT) + (l & 15);
+            if (j >= i && j < kt) {           // diagonal tiles: the upper half only, mirrored
+                if (IMPLICIT) s += P.BtB[(size_t)i * kt + j];
+                if (i == j) s += (!IMPLICIT && i == kt - 1) ? lam_last : lam;
+                M[i * LDM + j] = s;
+                M[j * LDM + i] = s;
+            }
+        }
+        T v = T(0);
+        if (tid < 64)
+            for (int sl = s0; sl < s1; sl++) v += Gp.part[(size_t)sl * GRAM_PART + NTALL * 256 + tid];
+        __syncthreads();
+        if (tid < 64) {                       // one wavefront: lane e <-> unknown e
+            const bool live = lane < kt;
+            T a = live ? arow[lane] : T(0);
+            auto mul = [&](T x) {             // (M x)[lane]
+                vec_s[lane] = x;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                T y = T(0);
+                if (live)
+                    for (int c = 0; c < kt; c++) y += M[lane * LDM + c] * vec_s[c];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return y;
+            };
+            T r = live ? v - mul(a) : T(0);   // common.c:1932-1943 / :1128-1139
+            T p = r;
+            T r_old = lanes::wave_sum(r * r);
+            if (r_old > (T)1e-12) {           // :1952 / :1147
+                for (int step = 0; step < P.max_cg_steps; step++) {
+                    const T Ap = live ? mul(p) : T(0);
+                    const T alpha = r_old / lanes::wave_sum(Ap * p);
+                    a += alpha * p; r -= alpha * Ap;
+                    const T r_new = lanes::wave_sum(r * r);
+                    if (r_new <= (T)1e-8) break;              // :1979 / :1180
+                    p = p * (r_new / r_old) + r;
+                    r_old = r_new;
+                }
+            }
+            if (live) arow[lane] = a;
+        }
+    }
+}
+
+}  // namespace cmfhip

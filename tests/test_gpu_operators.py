@@ -95,10 +95,13 @@ def test_optimizeA_collective(oracles, dtype, ku, ki, km, sls, m_u):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("implicit", [True, False])
-def test_very_heavy_rows_split_path(oracles, dtype, implicit):
-    """Rows above 2048 nnz take the split-row path (one launch pair per CG pass); 257..2048 the
-    8-wave team with re-streamed tiles; both must agree with the sequential reference sums."""
+@pytest.mark.parametrize("vh", ["stream", "gram"])
+def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, monkeypatch):
+    """Rows above 2048 nnz take the split-row path (one launch pair per CG pass) or, with
+    CMFREC_HIP_VH=gram, the single-gather Gramian path (gram_cg_kernels.hpp); 257..2048 the 8-wave
+    team with re-streamed tiles; all must agree with the sequential reference sums."""
     from cmfrec_amd import ops
+    monkeypatch.setenv("CMFREC_HIP_VH", vh)
     O = oracles[dtype]
     m, n, k = 60, 5000, 50
     row, col, val = make_coo(m, n, 12000, 41, counts=implicit, dtype=dtype, heavy_row=(3, 4500), empty_rows=(8,))
