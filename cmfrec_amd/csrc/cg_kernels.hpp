@@ -576,7 +576,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
 // vh_update_kernel (one wavefront per row) adds the partials in chunk order (deterministic, no
 // floating-point atomics), the Gramian term and does the CG vector update.  One launch pair per
 // pass; kernel boundaries are the grid-wide synchronisation.
-constexpr int VH_CHUNK_TILES = 8;
+constexpr int VH_CHUNK_TILES = 4;
 
 template <typename T>
 struct VhState {
@@ -585,24 +585,27 @@ struct VhState {
     int *done;              // [nvh]
     T *part;                // [nchunks][64]
     const int *chunk_row;   // [nchunks] index of the very-heavy row (position in `order`)
-    const int *chunk_first; // [nchunks] first tile of the chunk inside its row
+    const int *chunk_start; // [nchunks] first non-zero of the chunk inside its row
+    const int *chunk_cnt;   // [nchunks] non-zeros of the chunk (<= 64 * VH_CHUNK_TILES)
     const int *chunk_off;   // [nvh+1] chunk range of every row
-    int nvh, nchunks;
+    const int *launch;      // [nlaunch] workgroup -> chunk (-1: none): chunks of one range of gathered rows share an XCD
+    int nvh, nchunks, nlaunch;
 };
 
 template <typename T, int S, bool IMPLICIT, int MODE>
-__global__ void __launch_bounds__(64 * VH_CHUNK_TILES, 2)
+__global__ void __launch_bounds__(64 * VH_CHUNK_TILES, 3)
 vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
 {
     __shared__ T red[VH_CHUNK_TILES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x;
+    const int c = V.launch[blockIdx.x];
+    if (c < 0) return;
     const int vi = V.chunk_row[c];
     if (MODE == 1 && V.done[vi]) return;
     const int row = P.order[vi];
-    const size_t st = P.indptr[row];
-    const int nnz = (int)(P.indptr[row + 1] - st);
-    const int tl = V.chunk_first[c] + wave;
+    const size_t st = P.indptr[row] + (size_t)V.chunk_start[c];
+    const int nnz = V.chunk_cnt[c];          // of this chunk
+    const int tl = wave;
     const int k = P.k;
     T vdist;
     if (MODE == 0) vdist = (lane < k) ? P.A[(size_t)row * P.lda + lane] : T(0);

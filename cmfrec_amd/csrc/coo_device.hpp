@@ -116,7 +116,9 @@ struct u32_to_size {
 };
 
 // d_key / d_other / d_val: the COO triplet in HBM (key = the index that becomes the row of this shard)
-inline void shard_from_coo(SparseShard &S, int nrows, const int *d_key, const int *d_other, const real_t *d_val,
+inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st);
+
+inline void shard_from_coo(SparseShard &S, int nrows, int n_other, const int *d_key, const int *d_other, const real_t *d_val,
                            size_t nnz, real_t subtract, real_t alpha, hipStream_t st)
 {
     S.nrows = nrows; S.nnz = nnz;
@@ -163,6 +165,112 @@ inline void shard_from_coo(SparseShard &S, int nrows, const int *d_key, const in
         HIP_CHECK(hipStreamSynchronize(st));
         S.build_bins(hl.data(), st);
     }
+    finalize_vheavy(S, n_other, st);
+}
+
+// ---- very heavy rows: XCD-aware split-row schedule ---------------------------------------------
+// The split-row path re-gathers the opposing rows of a very heavy row once per CG pass.  Popular items
+// share their users, so the passes of all very heavy rows touch the same opposing rows over and over:
+// if the entries of these rows are ordered by opposing index and cut at the same NX index boundaries,
+// chunks of one index range read one 1/NX slice of the opposing matrix.  Workgroup b runs on XCD b % 8
+// (observed placement, used for speed only), so range x is launched at positions 8q + x and swept in
+// index order: the slice streams through that XCD's 4 MiB L2 once per pass instead of every chunk
+// pulling its rows over the fabric.  Sorting a row's entries is a (stable) permutation of its sums.
+constexpr int VH_NX_MAX = 64;
+constexpr int VH_XCDS = 8;
+
+__global__ void vh_partition_kernel(const RowDesc *__restrict__ desc, const int *__restrict__ idx, int nvh, int n_other,
+                                    int VH_NX, int *__restrict__ off /* [nvh][VH_NX + 1] */)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvh * (VH_NX + 1)) return;
+    const int vi = t / (VH_NX + 1), x = t % (VH_NX + 1);
+    const RowDesc d = desc[vi];
+    const long long bound = ((long long)n_other * x + VH_NX - 1) / VH_NX;     // first index of range x
+    int lo = 0, hi = d.nnz;
+    while (lo < hi) {                                                            // lower_bound in the sorted row
+        const int mid = (lo + hi) >> 1;
+        if (idx[d.st + mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    off[t] = lo;
+}
+
+inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st)
+{
+    const int nvh = S.bin_rows[BIN_VHEAVY];
+    if (nvh <= 0 || n_other <= 0 || getenv("CMFREC_HIP_VH_NOSORT")) return;
+    int VH_NX = 8;                                  // index ranges (a multiple of the XCD count)
+    if (const char *e = getenv("CMFREC_HIP_VH_RANGES")) VH_NX = std::max(VH_XCDS, std::min(VH_NX_MAX, atoi(e) / VH_XCDS * VH_XCDS));
+    std::vector<RowDesc> hd(nvh);
+    HIP_CHECK(hipMemcpyAsync(hd.data(), S.desc.ptr, (size_t)nvh * sizeof(RowDesc), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    // 1. entries of every very heavy row by opposing index (stable)
+    {
+        std::vector<unsigned long long> hb(nvh), he(nvh);
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int v = 0; v < nvh; v++) {
+            hb[v] = hd[v].st; he[v] = hd[v].st + (unsigned long long)hd[v].nnz;
+            lo = std::min(lo, hb[v]); hi = std::max(hi, he[v]);
+        }
+        DevBuf<unsigned long long> db, de; db.upload(hb.data(), nvh, st); de.upload(he.data(), nvh, st);
+        DevBuf<int> ki; DevBuf<real_t> kv;
+        ki.alloc(S.nnz); kv.alloc(S.nnz);
+        HIP_CHECK(hipMemcpyAsync(ki.ptr, S.i.ptr, S.nnz * sizeof(int), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(kv.ptr, S.v.ptr, S.nnz * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+        unsigned bits = 1;
+        while (bits < 32 && (1ull << bits) < (unsigned long long)n_other) bits++;
+        size_t bytes = 0;
+        HIP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, bytes, ki.ptr, S.i.ptr, kv.ptr, S.v.ptr, S.nnz, (unsigned)nvh,
+                                                      db.ptr, de.ptr, 0u, bits, st));
+        DevBuf<unsigned char> tmp; tmp.alloc(bytes + 16);
+        HIP_CHECK(rocprim::segmented_radix_sort_pairs(tmp.ptr, bytes, ki.ptr, S.i.ptr, kv.ptr, S.v.ptr, S.nnz, (unsigned)nvh,
+                                                      db.ptr, de.ptr, 0u, bits, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // 2. where the index ranges start inside each row
+    std::vector<int> off((size_t)nvh * (VH_NX + 1));
+    {
+        DevBuf<int> doff; doff.alloc(off.size());
+        hipLaunchKernelGGL(vh_partition_kernel, dim3((int)(off.size() + 255) / 256), dim3(256), 0, st, S.desc.ptr, S.i.ptr, nvh,
+                           n_other, VH_NX, doff.ptr);
+        doff.download(off.data(), off.size(), st);
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // 3. chunks (row-contiguous: the order their partials are added in) and the launch map
+    const int CHN = TILE * VH_CHUNK_TILES;
+    std::vector<int> c_row, c_start, c_cnt, c_off(1, 0);
+    struct Key { double pos; int chunk; };
+    std::vector<Key> per_x[VH_XCDS];
+    for (int v = 0; v < nvh; v++) {
+        for (int x = 0; x < VH_NX; x++) {
+            const int a = off[(size_t)v * (VH_NX + 1) + x], b = off[(size_t)v * (VH_NX + 1) + x + 1], len = b - a;
+            if (len <= 0) continue;
+            const int nch = (len + CHN - 1) / CHN;
+            const int per = (((len + nch - 1) / nch) + 7) / 8 * 8;
+            for (int f = 0; f < len; f += per) {
+                per_x[x % VH_XCDS].push_back(Key{(double)(x / VH_XCDS) + (double)f / (double)len, (int)c_row.size()});   // range x -> XCD x % 8, ranges in turn
+                c_row.push_back(v); c_start.push_back(a + f); c_cnt.push_back(std::min(per, len - f));
+            }
+        }
+        c_off.push_back((int)c_row.size());
+    }
+    size_t longest = 0;
+    for (int x = 0; x < VH_XCDS; x++) {
+        std::stable_sort(per_x[x].begin(), per_x[x].end(), [](const Key &a, const Key &b) { return a.pos < b.pos; });
+        longest = std::max(longest, per_x[x].size());
+    }
+    std::vector<int> launch(longest * VH_XCDS, -1);
+    for (int x = 0; x < VH_XCDS; x++)
+        for (size_t q = 0; q < per_x[x].size(); q++) launch[q * VH_XCDS + x] = per_x[x][q].chunk;
+    S.set_vh_chunks(c_row, c_start, c_cnt, c_off, launch, st);
+}
+
+// host CSR -> shard (SparseShard::upload) + the very-heavy-row schedule
+inline void shard_from_csr(SparseShard &S, int nrows, const size_t *hp, const int *hi, const real_t *hv, int n_other,
+                           hipStream_t st)
+{
+    S.upload(nrows, hp, hi, hv, st);
+    finalize_vheavy(S, n_other, st);
 }
 
 }  // namespace cmfhip

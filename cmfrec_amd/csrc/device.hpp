@@ -104,7 +104,8 @@ struct SparseShard {
     static constexpr int LONG_ROW = 1024;
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
     int n_chunks = 0;
-    DevBuf<int> vh_chunk_row, vh_chunk_first, vh_chunk_off, vh_done;
+    DevBuf<int> vh_chunk_row, vh_chunk_start, vh_chunk_cnt, vh_chunk_off, vh_launch, vh_done;
+    int n_launch = 0;
     DevBuf<real_t> vh_r, vh_p, vh_r_old, vh_part;
     // Gramian path of the very heavy rows (gram_cg_kernels.hpp): slices of <= GRAM_SLICE non-zeros
     static constexpr int GRAM_SLICE = 2048;
@@ -138,12 +139,29 @@ struct SparseShard {
         HIP_CHECK(hipStreamSynchronize(st));   // host staging vectors go out of scope
     }
 
+    // split-row work list: chunks (row-contiguous, the order their partials are added in) and the
+    // workgroup -> chunk map of the pass kernel (empty: identity)
+    void set_vh_chunks(const std::vector<int> &c_row, const std::vector<int> &c_start, const std::vector<int> &c_cnt,
+                       const std::vector<int> &c_off, std::vector<int> launch, hipStream_t st)
+    {
+        n_chunks = (int)c_row.size();
+        if (launch.empty()) { launch.resize(n_chunks); std::iota(launch.begin(), launch.end(), 0); }
+        n_launch = (int)launch.size();
+        vh_chunk_row.upload(c_row.data(), c_row.size(), st);
+        vh_chunk_start.upload(c_start.data(), c_start.size(), st);
+        vh_chunk_cnt.upload(c_cnt.data(), c_cnt.size(), st);
+        vh_chunk_off.upload(c_off.data(), c_off.size(), st);
+        vh_launch.upload(launch.data(), launch.size(), st);
+        vh_part.alloc((size_t)n_chunks * 64);
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+
     // nnz bins, split-row work list and CG state from the row lengths in processing order (descending)
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
         n_empty = 0; n_long = 0;
-        std::vector<int> c_row, c_first, c_off(1, 0);
+        std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
@@ -151,8 +169,10 @@ struct SparseShard {
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
-                int ntiles = (int)((l + TILE - 1) / TILE);
-                for (int t0 = 0; t0 < ntiles; t0 += VH_CHUNK_TILES) { c_row.push_back(bin_rows[b]); c_first.push_back(t0); }
+                const int CHN = TILE * VH_CHUNK_TILES;
+                for (long long f = 0; f < l; f += CHN) {
+                    c_row.push_back(bin_rows[b]); c_first.push_back((int)f); c_cnt.push_back((int)std::min<long long>(CHN, l - f));
+                }
                 c_off.push_back((int)c_row.size());
                 // equal slices, multiples of 16 non-zeros (one staging round)
                 const int nsl = (int)((l + GRAM_SLICE - 1) / GRAM_SLICE);
@@ -168,15 +188,11 @@ struct SparseShard {
         for (int b = 0; b < NBINS; b++) { bin_first[b] = acc; acc += bin_rows[b]; }
         n_nonempty = acc;
         max_nnz = nrows ? (int)lens_sorted[0] : 0;
-        n_chunks = (int)c_row.size();
         if (bin_rows[BIN_VHEAVY]) {
             const int nvh = bin_rows[BIN_VHEAVY];
-            vh_chunk_row.upload(c_row.data(), c_row.size(), st);
-            vh_chunk_first.upload(c_first.data(), c_first.size(), st);
-            vh_chunk_off.upload(c_off.data(), c_off.size(), st);
+            set_vh_chunks(c_row, c_first, c_cnt, c_off, std::vector<int>(), st);      // row order; finalize_vheavy() refines it
             vh_done.alloc(nvh); vh_r_old.alloc(nvh);
             vh_r.alloc((size_t)nvh * 64); vh_p.alloc((size_t)nvh * 64);
-            vh_part.alloc((size_t)n_chunks * 64);
             n_slices = (int)s_row.size();
             sl_vrow.upload(s_row.data(), s_row.size(), st);
             sl_first.upload(s_first.data(), s_first.size(), st);
@@ -361,10 +377,11 @@ inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const Sp
     }
     VhState<real_t> V;
     V.r = X.vh_r.ptr; V.p = X.vh_p.ptr; V.r_old = X.vh_r_old.ptr; V.done = X.vh_done.ptr; V.part = X.vh_part.ptr;
-    V.chunk_row = X.vh_chunk_row.ptr; V.chunk_first = X.vh_chunk_first.ptr; V.chunk_off = X.vh_chunk_off.ptr;
-    V.nvh = nvh; V.nchunks = X.n_chunks;
+    V.chunk_row = X.vh_chunk_row.ptr; V.chunk_start = X.vh_chunk_start.ptr; V.chunk_cnt = X.vh_chunk_cnt.ptr;
+    V.chunk_off = X.vh_chunk_off.ptr; V.launch = X.vh_launch.ptr;
+    V.nvh = nvh; V.nchunks = X.n_chunks; V.nlaunch = X.n_launch;
     P.nrows = nvh;
-    const dim3 gp(X.n_chunks), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64 * VH_UPD_WAVES);
+    const dim3 gp(X.n_launch), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64 * VH_UPD_WAVES);
     hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 0>), gp, bp, 0, dev.stream, P, V);
     hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0>), gu, bu, 0, dev.stream, P, V);
     for (int step = 0; step < P.max_cg_steps; step++) {

@@ -230,8 +230,8 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const i
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
-        s->Xr.upload(s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->dev.stream);
-        s->Xc.upload(s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->dev.stream);
+        shard_from_csr(s->Xr, s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->mdl.n, s->dev.stream);
+        shard_from_csr(s->Xc, s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->mdl.m, s->dev.stream);
         return 0;
     });
 }
@@ -248,8 +248,8 @@ int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const 
         HIP_CHECK(hipSetDevice(s->dev.device));
         DevBuf<int> dr, dc; DevBuf<real_t> dv;
         dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
-        shard_from_coo(s->Xr, m.m, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
-        shard_from_coo(s->Xc, m.n, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
+        shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
+        shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
@@ -637,7 +637,7 @@ int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t
         dA.upload(A, (size_t)m * lda, dev.stream);
         dB.upload(B, (size_t)n * ldb, dev.stream);
         dG.alloc((size_t)k * k);
-        X.upload(m, Xcsr_p, Xcsr_i, Xcsr, dev.stream);
+        shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         launch_gram(dev, gws, dB.ptr, ldb, n, k, dG.ptr, (real_t)1, use_cg ? (real_t)0 : lam);
         int rc;
         if (use_cg) {
@@ -670,7 +670,7 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
         dA.upload(A, (size_t)m * lda, dev.stream);
         dB.upload(B, (size_t)n * ldb, dev.stream);
         if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
-        X.upload(m, Xcsr_p, Xcsr_i, Xcsr, dev.stream);
+        shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         int rc;
         if (use_cg) {
             CgCall c{dA.ptr, lda, dB.ptr, ldb, k, bias_sub ? dbias.ptr : nullptr, nullptr, lam, lam_last, scale_lam,
@@ -739,7 +739,7 @@ int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size
         dU.upload(U, (size_t)m_u * p, dev.stream);
         if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
         dG.alloc((size_t)kc * kc);
-        X.upload(m, Xcsr_p, Xcsr_i, Xcsr, dev.stream);
+        shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dG.ptr, w_user, (real_t)0);
         // collective.c:4817-4822 zeroes max(m,m_u)*lda - (lda-k_totA) elements
         HIP_CHECK(hipMemsetAsync(dA.ptr, 0, ((size_t)m * lda - (lda - (size_t)kt)) * sizeof(real_t), dev.stream));
