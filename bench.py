@@ -158,7 +158,7 @@ def main():
     rows_per_s = (m + n) / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel (per nnz-bin launch of the CG row kernel) ----
-    names = {0: "vh_pass+vh_update x4 (rows > 2048 nnz, split rows)", 1: "cg_rows_kernel<W=8> (257..2048 nnz)",
+    names = {0: "vh_pass+vh_update x4 (rows > 1024 nnz, split rows)", 1: "cg_rows_kernel<W=8> (257..1024 nnz)",
              2: "cg_rows_kernel<W=4> (129..256 nnz)", 3: "cg_rows_kernel<W=2> (65..128 nnz)",
              4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel (<= 32 nnz)"}
     kernels = []

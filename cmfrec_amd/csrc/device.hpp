@@ -73,16 +73,22 @@ struct DevBuf {
 // with `omp schedule(dynamic)` (common.c:3259,3349).  A row of a bin with W waves per row keeps its
 // gathered tiles in registers when it has <= 64*W non-zeros.
 constexpr int NBINS = 6;
-constexpr int BIN_VHEAVY = 0;   // > 2048 nnz : every CG pass split over many workgroups (vh_* kernels)
-constexpr int BIN_HEAVY = 1;    // 257..2048  : 8 waves / row (register-resident up to 512 nnz, else re-streamed)
+constexpr int BIN_VHEAVY = 0;   // > 1024 nnz : every CG pass split over many workgroups (vh_* kernels); measured on C2: 2048 -> 5.05, 1024 -> 4.93, 512 -> 5.11 ms
+constexpr int BIN_HEAVY = 1;    // 257..1024  : 8 waves / row (register-resident up to 512 nnz, else re-streamed)
 constexpr int BIN_MED4 = 2;     // 129..256   : 4 waves / row
 constexpr int BIN_MED2 = 3;     // 65..128    : 2 waves / row
 constexpr int BIN_LIGHT = 4;    // 33..64     : 1 wave / row, 4 rows / workgroup
 constexpr int BIN_TINY = 5;     // 1..32      : 1 wave / row, half-size tiles, double-buffered gather
-constexpr int BIN_MIN_NNZ[NBINS] = {2049, 257, 129, 65, 33, 1};
+constexpr int BIN_MIN_NNZ[NBINS] = {1025, 257, 129, 65, 33, 1};
+inline int vheavy_min_nnz()
+{
+    static const int v = getenv("CMFREC_HIP_VH_MIN") ? std::max(258, atoi(getenv("CMFREC_HIP_VH_MIN"))) : BIN_MIN_NNZ[BIN_VHEAVY];
+    return v;
+}
 inline int bin_of(long long nnz)
 {
-    for (int b = 0; b < NBINS; b++)
+    if (nnz >= vheavy_min_nnz()) return BIN_VHEAVY;
+    for (int b = 1; b < NBINS; b++)
         if (nnz >= BIN_MIN_NNZ[b]) return b;
     return -1;   // empty row
 }

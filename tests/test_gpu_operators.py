@@ -97,15 +97,15 @@ def test_optimizeA_collective(oracles, dtype, ku, ki, km, sls, m_u):
 @pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("vh", ["stream", "gram"])
 def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, monkeypatch):
-    """Rows above 2048 nnz take the split-row path (one launch pair per CG pass) or, with
-    CMFREC_HIP_VH=gram, the single-gather Gramian path (gram_cg_kernels.hpp); 257..2048 the 8-wave
+    """Rows above 1024 nnz take the split-row path (one launch pair per CG pass) or, with
+    CMFREC_HIP_VH=gram, the single-gather Gramian path (gram_cg_kernels.hpp); 257..1024 the 8-wave
     team with re-streamed tiles; all must agree with the sequential reference sums."""
     from cmfrec_amd import ops
     monkeypatch.setenv("CMFREC_HIP_VH", vh)
     O = oracles[dtype]
     m, n, k = 60, 5000, 50
     row, col, val = make_coo(m, n, 12000, 41, counts=implicit, dtype=dtype, heavy_row=(3, 4500), empty_rows=(8,))
-    # a second very heavy row and a 257..2048 one
+    # a second very heavy row and a 257..1024 one
     rng = np.random.default_rng(4)
     extra_r = np.concatenate([np.full(2500, 10, np.int32), np.full(900, 11, np.int32)])
     keep = (row != 10) & (row != 11)
@@ -144,7 +144,7 @@ def test_coo_device_matches_host(dtype, m, n, nnz):
     row = rng.integers(0, m, nnz).astype(np.int32)         # duplicates and empty rows on purpose
     col = rng.integers(0, n, nnz).astype(np.int32)
     if nnz:
-        row[: nnz // 10] = 3                                # one heavy row (exercises the > 2048 bin when large)
+        row[: nnz // 10] = 3                                # one heavy row (exercises the > 1024 bin when large)
     val = rng.lognormal(size=nnz).astype(dtype)
     alpha = dtype(2.5)
     s = AlsSession(m, n, 8, implicit=True, dtype=dtype)
@@ -154,7 +154,7 @@ def test_coo_device_matches_host(dtype, m, n, nnz):
         perm = np.argsort(key, kind="stable")
         cnt = np.bincount(key, minlength=rows)
         ptr = np.concatenate([[0], np.cumsum(cnt)])
-        for r in np.nonzero(cnt > 2048)[0]:                 # very heavy rows: entries by opposing index (stable), the
+        for r in np.nonzero(cnt > 1024)[0]:                 # very heavy rows: entries by opposing index (stable), the
             seg = perm[ptr[r]:ptr[r + 1]]                   # XCD-aware split-row schedule (coo_device.hpp)
             perm[ptr[r]:ptr[r + 1]] = seg[np.argsort(other[seg], kind="stable")]
         assert np.array_equal(p, ptr.astype(np.uint64))
