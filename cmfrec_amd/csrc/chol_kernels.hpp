@@ -33,6 +33,10 @@
 namespace cmfhip {
 
 enum CholMode { CHOL_EXPLICIT = 0, CHOL_IMPLICIT = 1, CHOL_COLLECTIVE = 2,
+                CHOL_COLLECTIVE_IMPLICIT = 4 /* implicit-feedback weights + side information:
+                                      M = Mfull[kt,kt] (BeTBe without the C^T C block, lam included)
+                                        + Minit[kc,kc] (w C^T C) for rows with side information,
+                                      rhs = the prefilled w U C row + sum (x+1) B  (collective.c:1849-2131) */,
                 CHOL_PREFILLED = 3 /* M = Minit[kt,kt] (diag included), rhs = the row itself, no gather:
                                       the multi-RHS posv of the C / D update, common.c:2872-2875 */ };
 
@@ -45,7 +49,8 @@ struct CholParams {
     const size_t *indptr; const int *indices; const T *values;
     const T *bias_sub;         // x_j := x_j - bias_sub[idx_j], or null
     const int *order; int nrows;
-    const T *Minit;            // implicit: BtB + lam*I [kt,kt];  collective: w*CtC [kc,kc];  explicit: null
+    const T *Minit;            // implicit: BtB + lam*I [kt,kt];  collective (both): w*CtC [kc,kc];  explicit: null
+    const T *Mfull;            // collective implicit: [kt,kt] matrix every solved row starts from;  else null
     int kc;                    // collective: size of the side-info block (k_user + k), else 0
     int rows_with_u;           // collective: rows < rows_with_u carry side information
     int p_side;                // collective: number of side-info columns (scale_lam_sideinfo)
@@ -267,8 +272,10 @@ chol_rows_kernel(const CholParams<T> P)
         const size_t st = (P.mode == CHOL_PREFILLED) ? 0 : P.indptr[row];
         const int nnz = (P.mode == CHOL_PREFILLED) ? 0 : (int)(P.indptr[row + 1] - st);
         T *arow = P.A + (size_t)row * P.lda;
-        const bool has_u = (P.mode == CHOL_PREFILLED) || ((P.mode == CHOL_COLLECTIVE) && row < P.rows_with_u);
-        if (P.mode == CHOL_COLLECTIVE && nnz == 0 && !has_u) {          // collective.c:1258-1268
+        const bool coll = (P.mode == CHOL_COLLECTIVE || P.mode == CHOL_COLLECTIVE_IMPLICIT);
+        const bool impl_w = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_COLLECTIVE_IMPLICIT);
+        const bool has_u = (P.mode == CHOL_PREFILLED) || (coll && row < P.rows_with_u);
+        if (coll && nnz == 0 && !has_u) {                               // collective.c:1258-1268, :1876-1885
             for (int e = tid; e < kt; e += NTH) arow[e] = T(0);
             continue;
         }
@@ -315,8 +322,8 @@ chol_rows_kernel(const CholParams<T> P)
                 for (int j = 0; j < NCJ; j++) pre[i][j] = P.B[(size_t)idn[i] * P.ldb + scol[j]];
             T x = wx;
             if (P.bias_sub != nullptr) x -= P.bias_sub[widx];
-            pre_wsyr = (P.mode == CHOL_IMPLICIT) ? x : T(1);           // common.c:2091-2095 vs :1007-1012
-            pre_wrhs = (P.mode == CHOL_IMPLICIT) ? x + T(1) : x;       // common.c:2082-2085 vs :991-996
+            pre_wsyr = impl_w ? x : T(1);           // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
+            pre_wrhs = impl_w ? x + T(1) : x;       // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
         };
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
@@ -358,26 +365,32 @@ chol_rows_kernel(const CholParams<T> P)
         // ---- 2. the initial matrix, in the accumulator layout (padding: identity) ----
         {
             const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED);
-            const int lim = full ? kt : (has_u ? P.kc : 0);            // Minit is [lim, lim]
-            if (lim > 0) {                                             // unconditional loads on clamped addresses
+            const T *M1 = full ? P.Minit : P.Mfull;                    // [kt, kt], every row
+            const T *M2 = (!full && has_u) ? P.Minit : nullptr;        // [kc, kc], rows with side information
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {                     // unconditional loads on clamped addresses
+                const T *Mi = pass ? M2 : M1;
+                const int lim = pass ? P.kc : kt;
+                if (Mi == nullptr || lim <= 0) continue;
 #pragma unroll
                 for (int tt = 0; tt < TPW; tt++) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int gi = offa[tt] + Mf::row_of(lane, r), gj = offb[tt] + lm;
                         const int lo = min(gi, gj), hi = max(gi, gj);
-                        const T v = P.Minit[(size_t)min(lo, lim - 1) * lim + min(hi, lim - 1)];   // collective.c:1566-1571
+                        const T v = Mi[(size_t)min(lo, lim - 1) * lim + min(hi, lim - 1)];   // collective.c:1566-1571
                         acc[tt][r] += (hi < lim) ? v : T(0);
                     }
                 }
             }
+            const bool add_lam = (P.mode == CHOL_EXPLICIT || P.mode == CHOL_COLLECTIVE);
 #pragma unroll
             for (int tt = 0; tt < TPW; tt++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int gi = offa[tt] + Mf::row_of(lane, r), gj = offb[tt] + lm;
                     T dv = T(0);
-                    if (gi == gj) dv = (gi >= kt) ? T(1) : (full ? T(0) : ((gi == kt - 1) ? lam_last : lam));   // add_to_diag2: common.c:1060-1062, collective.c:1819
+                    if (gi == gj) dv = (gi >= kt) ? T(1) : (!add_lam ? T(0) : ((gi == kt - 1) ? lam_last : lam));   // add_to_diag2: common.c:1060-1062, collective.c:1819
                     acc[tt][r] += dv;
                 }
             }

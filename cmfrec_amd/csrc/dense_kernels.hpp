@@ -261,4 +261,19 @@ gemm_kernel(int M, int N, int K, T alpha, const T *__restrict__ A, size_t lda,
         }
 }
 
+// out[kt,kt] := blockdiag(lam * I[ks], G[kk,kk])  (kt = ks + kk): the part of Be^T Be every row shares in the
+// implicit model with side information, collective.c:6121-6135 (G = BtB + lam I already)
+template <typename T>
+__global__ void betbe_base_kernel(const T *__restrict__ G, int kk, int ks, T lam, T *__restrict__ out)
+{
+    const int kt = ks + kk;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kt * kt; e += gridDim.x * blockDim.x) {
+        const int i = e / kt, j = e % kt;
+        T v = T(0);
+        if (i >= ks && j >= ks) v = G[(size_t)(i - ks) * kk + (j - ks)];
+        else if (i == j) v = lam;
+        out[e] = v;
+    }
+}
+
 }  // namespace cmfhip

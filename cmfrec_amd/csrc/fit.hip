@@ -111,23 +111,29 @@ int_t fit_collective_implicit_als(
     bool precompute_for_predictions, real_t *precomputedBtB, real_t *precomputedBeTBe,
     real_t *precomputedBeTBeChol, real_t *precomputedCtUbias)
 {
-    (void)C; (void)D; (void)U_colmeans; (void)I_colmeans; (void)m_u; (void)p; (void)n_i; (void)q;
     (void)U_row; (void)U_col; (void)I_row; (void)I_col; (void)NA_as_zero_U; (void)NA_as_zero_I;
     (void)nthreads; (void)max_cd_steps; (void)nonneg_C; (void)nonneg_D; (void)precomputedBtB;
-    (void)precomputedBeTBe; (void)precomputedBeTBeChol; (void)precomputedCtUbias; (void)w_user; (void)w_item;
+    (void)precomputedBeTBe; (void)precomputedBeTBeChol; (void)precomputedCtUbias;
     (void)handle_interrupt;
     // collective.c:9406-9435
-    if (k_user || k_item) return fail(verbose, "Cannot pass 'k_user'/'k_item' without side information.");
+    if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
+    if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (U || II || U_sp || I_sp || nnz_U || nnz_I)
-        return fail(verbose, "cmfrec_hip: implicit model with side information is not implemented (SURVEY 8f-1).");
+    if (U_sp || I_sp || nnz_U || nnz_I)
+        return fail(verbose, "cmfrec_hip: sparse side information is not implemented.");
+    if (U == nullptr) { m_u = 0; p = 0; }
+    if (II == nullptr) { n_i = 0; q = 0; }
+    if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
+    if ((U || II) && use_cg) return fail(verbose, "cmfrec_hip: side information requires use_cg=false (block-CG: SURVEY 8f-1).");
+    for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
+    for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
     if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight || precompute_for_predictions)
         return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / adjust_weight / precompute_for_predictions are not implemented.");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
     if (w_main_multiplier) *w_main_multiplier = 1;
-    if (w_main != (real_t)1) lam /= w_main;                              // collective.c:9786-9811
+    if (w_main != (real_t)1) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   // collective.c:9786-9811
 
     PhaseTimer tm;
     tm.lap("validate");
@@ -139,19 +145,38 @@ int_t fit_collective_implicit_als(
     }
     tm.lap("log transform");
 
-    const int ktot = k + k_main;
-    if (reset_values) {                                                  // :9750-9774 (no item side info: only A is drawn)
-        cmfrng::random_parallel<real_t>(A, (size_t)m * ktot, nullptr, 0, seed, false);
-        if (use_cg) memset(B, 0, (size_t)n * ktot * sizeof(real_t));
-        // Cholesky: B's start values are never read (the B-step runs first), left as passed like the reference
+    // ---- side information: column means + centering, common.c:4938-4997 (only when the means are asked for) ----
+    std::vector<real_t> Uc, Ic;
+    auto center_cols = [](const real_t *M, int rows, int cols, real_t *means, std::vector<real_t> &out) {
+        out.assign(M, M + (size_t)rows * cols);
+        if (means == nullptr) return;
+        for (int c = 0; c < cols; c++) means[c] = 0;
+        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) means[c] += M[(size_t)r * cols + c];
+        for (int c = 0; c < cols; c++) means[c] /= (double)rows;
+        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) out[(size_t)r * cols + c] -= means[c];
+    };
+    if (U) center_cols(U, m_u, p, U_colmeans, Uc);
+    if (II) center_cols(II, n_i, q, I_colmeans, Ic);
+
+    const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
+    if (reset_values) {                                                  // :9750-9774
+        const bool fill_B = (II != nullptr);
+        cmfrng::random_parallel<real_t>(A, (size_t)m * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n * k_totB : 0, seed, false);
+        if (use_cg) {
+            if (!fill_B) memset(B, 0, (size_t)n * k_totB * sizeof(real_t));
+            if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
+            if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
+        }
+        // Cholesky: start values that are never read (the C / D / B steps run first) are left as passed, like the reference
     }
     if (!use_cg) finalize_chol = false;                                  // :9518
     tm.lap("start values");
 
     cmfrec_hip_model mdl;
     memset(&mdl, 0, sizeof mdl);
-    mdl.implicit = 1; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main;
-    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.lam = lam; mdl.w_user = 1; mdl.w_item = 1;
+    mdl.implicit = 1; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
+    mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.lam = lam;
+    mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
@@ -160,7 +185,8 @@ int_t fit_collective_implicit_als(
     int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, (real_t)0, alpha);
     std::vector<real_t>().swap(Xs);
     tm.lap("set_X_coo (upload, sort, bins)");
-    if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
+    if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
+    if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, C, D);
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("set_factors");
@@ -168,7 +194,7 @@ int_t fit_collective_implicit_als(
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("ALS iterations");
     if (rc_loop == 0 || rc_loop == 3) {
-        int rc2 = cmfrec_hip_session_get_factors(s, A, B, nullptr, nullptr, nullptr, nullptr);
+        int rc2 = cmfrec_hip_session_get_factors(s, A, B, nullptr, nullptr, C, D);
         if (rc2) rc_loop = rc2;
     }
     tm.lap("get_factors");
@@ -248,6 +274,7 @@ int_t fit_collective_explicit_als(
     std::vector<real_t> Uc, Ic;
     auto center_cols = [](const real_t *M, int rows, int cols, real_t *means, std::vector<real_t> &out) {
         out.assign(M, M + (size_t)rows * cols);
+        if (means == nullptr) return;                                     // no centring asked for (common.c:4938)
         for (int c = 0; c < cols; c++) means[c] = 0;
         for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) means[c] += M[(size_t)r * cols + c];
         for (int c = 0; c < cols; c++) means[c] /= (double)rows;

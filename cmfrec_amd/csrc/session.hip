@@ -35,6 +35,7 @@ struct CholCall {
     real_t lam, lam_last;
     bool scale_lam, scale_lam_sideinfo, scale_bias_const;
     int mode;
+    const real_t *Mfull = nullptr;
 };
 
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
@@ -46,9 +47,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.bias_sub = c.bias_sub;
     P.order = X ? X->order.ptr : nullptr;
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
-    else if (c.mode == CHOL_COLLECTIVE) P.nrows = X->nrows;                       // empty rows too
+    else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT) P.nrows = X->nrows;   // empty rows too
     else P.nrows = X->n_nonempty;                                                // non-empty rows
-    P.Minit = c.Minit; P.kc = c.kc; P.rows_with_u = c.rows_with_u; P.p_side = c.p_side;
+    P.Minit = c.Minit; P.Mfull = c.Mfull; P.kc = c.kc; P.rows_with_u = c.rows_with_u; P.p_side = c.p_side;
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
     P.mode = c.mode;
@@ -119,7 +120,7 @@ struct cmfrec_hip_session {
     size_t ldA = 0, ldB = 0;
     DevBuf<real_t> A, B, biasA, biasB, C, D, U, II;
     SparseShard Xr, Xc;
-    DevBuf<real_t> gram, ctc;
+    DevBuf<real_t> gram, ctc, betbe;
     GramWorkspace gws;
     std::vector<EventPair> evA, evB;     // whole half-steps
     BinTimers binA, binB;                // row-update kernel launches per nnz bin
@@ -174,8 +175,12 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
             g_last_error = "cmfrec_hip: invalid model sizes";
             return 2;
         }
-        if (m.implicit && (m.user_bias || m.item_bias || m.p || m.q || m.k_user || m.k_item)) {
-            g_last_error = "cmfrec_hip: implicit model supports no biases / side information yet";
+        if (m.implicit && (m.user_bias || m.item_bias)) {
+            g_last_error = "cmfrec_hip: the implicit model has no biases";
+            return 2;
+        }
+        if ((m.k_user && !m.p) || (m.k_item && !m.q)) {
+            g_last_error = "cmfrec_hip: k_user / k_item need side information";
             return 2;
         }
         if ((m.p > 0 && m.m_u > m.m) || (m.q > 0 && m.n_i > m.n)) {
@@ -207,6 +212,7 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
         int kmax = std::max(s->k_totA, s->k_totB) + 1;
         s->gram.alloc((size_t)kmax * kmax);
         s->ctc.alloc((size_t)kmax * kmax);
+        s->betbe.alloc((size_t)kmax * kmax);
         if (m.p > 0) s->C.alloc((size_t)m.p * (m.k_user + m.k));
         if (m.q > 0) s->D.alloc((size_t)m.q * (m.k_item + m.k));
         return 0;
@@ -411,6 +417,25 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
     real_t *self_blk = self + (size_t)begin * ld_self;
     const int kk = m.k + m.k_main;
 
+    if (m.implicit && p_self > 0) {
+        // optimizeA_collective_implicit, Cholesky, dense full side information (collective.c:5971-6244)
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+        const int rows_u = isA ? m.m_u : m.n_i;
+        const int kc = k_side_self + m.k, kt = k_side_self + kk;
+        const real_t w = isA ? m.w_user : m.w_item;
+        launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, m.lam);     // :6056-6061
+        hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, m.lam,
+                           s->betbe.ptr);                                                           // :6121-6135
+        launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);            // :6138-6160
+        if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :6018-6019
+        const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
+        launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
+                           self_blk, ld_self);                                                      // :6163-6168
+        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, nullptr, s->ctc.ptr, kc, local_u,
+                   p_self, m.lam, m.lam, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
+        return launch_chol(dev, c, &X);
+    }
     if (m.implicit) {
         // optimizeA_implicit, common.c:3305-3421
         launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, chol ? m.lam : (real_t)0);

@@ -62,6 +62,7 @@ class CMF_implicit(_Base):
         self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
         self.w_main = float(w_main); self.w_user = float(w_user); self.w_item = float(w_item)
         self.l1_lambda = l1_lambda; self.niter = int(niter); self.nonneg = bool(nonneg)
+        self.center_U = bool(center_U); self.center_I = bool(center_I)
         self.apply_log_transf = bool(apply_log_transf)
         self.precompute_for_predictions = bool(precompute_for_predictions)
         self.max_cg_steps = int(max_cg_steps); self.precondition_cg = bool(precondition_cg)
@@ -73,24 +74,38 @@ class CMF_implicit(_Base):
 
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
-        them from ``random_state`` (C argument ``reset_values=false``)."""
-        if U is not None or I is not None:
-            raise NotImplementedError("CMF_implicit with side information is not implemented (SURVEY.md 8f-1)")
+        them from ``random_state`` (C argument ``reset_values=false``).  ``U`` / ``I``: dense side
+        information without missing values (then ``use_cg=False`` is required: the block-CG solver of
+        the reference is not implemented)."""
         row, col, val, m, n = _coo_triplet(X, shape)
         lib, R = self._lib()
-        val = np.ascontiguousarray(val, self.dtype_)
-        ktot = self.k + self.k_main
+        dt = self.dtype_
+        val = np.ascontiguousarray(val, dt)
+        Uc = None if U is None else np.ascontiguousarray(U, dt)
+        Ic = None if I is None else np.ascontiguousarray(I, dt)
+        m_u, p = (0, 0) if Uc is None else Uc.shape
+        n_i, q = (0, 0) if Ic is None else Ic.shape
+        if (p or q) and self.use_cg:
+            raise NotImplementedError("side information requires use_cg=False in cmfrec_amd "
+                                      "(block-CG: SURVEY.md 8f-1)")
+        if m_u > m or n_i > n:
+            raise NotImplementedError("side information with more rows than X is not implemented in cmfrec_amd")
+        ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
         reset = A0 is None
-        A = np.empty((m, ktot), self.dtype_) if reset else np.array(A0, self.dtype_, order="C", copy=True)
-        B = np.empty((n, ktot), self.dtype_) if (reset or B0 is None) else np.array(B0, self.dtype_, order="C", copy=True)
+        A = np.empty((m, ka), dt) if reset else np.array(A0, dt, order="C", copy=True)
+        B = np.empty((n, kb), dt) if (reset or B0 is None) else np.array(B0, dt, order="C", copy=True)
         if not reset and B0 is None:
             B[:] = 0
-        wmm = np.zeros(1, self.dtype_)
+        Cm = np.zeros((p, self.k_user + self.k), dt) if p else None
+        Dm = np.zeros((q, self.k_item + self.k), dt) if q else None
+        Ucm = np.zeros(max(p, 1), dt); Icm = np.zeros(max(q, 1), dt)
+        wmm = np.zeros(1, dt)
         rc = lib.fit_collective_implicit_als(
-            _lib.ptr(A), _lib.ptr(B), None, None, C.c_bool(reset), C.c_int(self.random_state), None, None,
+            _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), C.c_bool(reset), C.c_int(self.random_state),
+            _lib.ptr(Ucm) if (p and self.center_U) else None, _lib.ptr(Icm) if (q and self.center_I) else None,
             C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
             C.c_size_t(len(val)), R(self.lambda_), None, R(0.), None,
-            None, C.c_int(0), C.c_int(0), None, C.c_int(0), C.c_int(0),
+            _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
             C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), _lib.ptr(wmm),
@@ -102,7 +117,9 @@ class CMF_implicit(_Base):
             C.c_bool(False), None, None, None, None)
         _lib.check(rc, lib, "fit_collective_implicit_als")
         self.A_, self.B_ = A, B
-        self.C_ = np.empty((0, 0), self.dtype_); self.D_ = np.empty((0, 0), self.dtype_)
+        self.C_ = Cm if Cm is not None else np.empty((0, 0), dt)
+        self.D_ = Dm if Dm is not None else np.empty((0, 0), dt)
+        self._U_colmeans, self._I_colmeans = Ucm[:p], Icm[:q]
         self._w_main_multiplier = float(wmm[0])
         self.is_fitted_ = True
         return self
@@ -110,7 +127,7 @@ class CMF_implicit(_Base):
     def predict(self, user, item):
         """A_u . B_i for paired user / item ids (reference predict_multiple, common.c:5066-5106)."""
         user = np.asarray(user); item = np.asarray(item)
-        return np.einsum("ij,ij->i", self.A_[user], self.B_[item])
+        return np.einsum("ij,ij->i", self.A_[user, self.k_user:], self.B_[item, self.k_item:])
 
 
 class CMF(_Base):

@@ -41,8 +41,11 @@ extern "C" {
 
 /* Replaces fit_collective_implicit_als, /root/reference/src/cmfrec.h:1893-1921 (body
  * src/collective.c:9375-10207; documented in include/cmfrec.h.in:927-959).
- * Supported in this round: no side information (U, II, U_sp, I_sp NULL), k_user=k_item=0,
- * l1_lam=0, nonneg=false, w_main=1.  Anything else returns 2. */
+ * Supported: CG / PCG / Cholesky without side information; with DENSE side information
+ * U[m_u<=m, p] / II[n_i<=n, q] without NaN (k_user, k_item, k_main, w_main, w_user, w_item as the
+ * reference) only use_cg=false (optimizeA_collective_implicit, src/collective.c:5971-6244; the block-CG of
+ * :2905 is not built).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight, no precompute.
+ * Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
     real_t *C, real_t *D,

@@ -162,6 +162,29 @@ class Oracle:
                                                 C.c_int(max_cg_steps), C.c_bool(precondition_cg),
                                                 C.c_bool(finalize_chol))
 
+    def fit_implicit_als_sideinfo(self, A, B, row, col, val, k, Cm=None, Dm=None, U=None, II=None, lam=1.0,
+                                  alpha=1.0, apply_log_transf=False, k_main=0, k_user=0, k_item=0, w_main=1.0,
+                                  w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=False, max_cg_steps=3,
+                                  precondition_cg=False, finalize_chol=False):
+        m = A.shape[0]; n = B.shape[0]
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        m_u, p = (0, 0) if U is None else U.shape
+        n_i, q = (0, 0) if II is None else II.shape
+        Ucm = np.zeros(max(p, 1), self.dtype); Icm = np.zeros(max(q, 1), self.dtype)
+        if U is not None and Cm is None:
+            Cm = np.zeros((p, k_user + k), self.dtype)
+        if II is not None and Dm is None:
+            Dm = np.zeros((q, k_item + k), self.dtype)
+        ret = self.lib.oracle_fit_implicit_als_sideinfo(
+            _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(Ucm), _ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(k),
+            _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
+            _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
+            C.c_int(k_main), C.c_int(k_user), C.c_int(k_item), self._r(w_main), self._r(w_user), self._r(w_item),
+            self._r(lam), self._r(alpha), C.c_bool(apply_log_transf), C.c_int(niter), C.c_int(nthreads),
+            C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol))
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm)
+
     def fit_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None, Dm=None,
                          U=None, II=None, user_bias=True, item_bias=True, center=True, lam=10.0,
                          scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,
@@ -335,24 +358,35 @@ class Reference:
     def fit_collective_implicit_als(self, A, B, row, col, val, k, lam=1.0, alpha=1.0, niter=10,
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                                     finalize_chol=False, reset_values=False, seed=1,
-                                    apply_log_transf=False):
+                                    apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
+                                    k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0):
         m = A.shape[0]; n = B.shape[0]
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         wmm = np.zeros(1, self.dtype)
-        return self.lib.fit_collective_implicit_als(
-            _ptr(A), _ptr(B), None, None, C.c_bool(reset_values), C.c_int(seed), None, None,
+        m_u, p = (0, 0) if U is None else U.shape
+        n_i, q = (0, 0) if II is None else II.shape
+        Ucm = np.zeros(max(p, 1), self.dtype); Icm = np.zeros(max(q, 1), self.dtype)
+        if U is not None and Cm is None:
+            Cm = np.zeros((p, k_user + k), self.dtype)
+        if II is not None and Dm is None:
+            Dm = np.zeros((q, k_item + k), self.dtype)
+        ret = self.lib.fit_collective_implicit_als(
+            _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), C.c_bool(reset_values), C.c_int(seed), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             self._r(lam), None, self._r(0.), None,
-            None, C.c_int(0), C.c_int(0), None, C.c_int(0), C.c_int(0),
+            _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
-            C.c_bool(False), C.c_bool(False), C.c_int(0), C.c_int(0), C.c_int(0),
-            self._r(1.), self._r(1.), self._r(1.), _ptr(wmm),
+            C.c_bool(False), C.c_bool(False), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            self._r(w_main), self._r(w_user), self._r(w_item), _ptr(wmm),
             self._r(alpha), C.c_bool(False), C.c_bool(apply_log_transf),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
             C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
             C.c_bool(False), None, None, None, None)
+        if U is None and II is None:
+            return ret
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm)
 
     def fit_collective_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None,
                                     Dm=None, U=None, II=None, user_bias=True, item_bias=True,

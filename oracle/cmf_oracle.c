@@ -529,6 +529,72 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
     free(CtCw);
 }
 
+/* optimizeA_collective_implicit (collective.c:5971-6244) + collective_closed_form_block_implicit
+ * (:1849-2131): implicit-feedback X, dense full U without NaN, Cholesky.  m_u <= m: rows >= m_u go
+ * through optimizeA_implicit on the k+k_main block at column offset k_user (:6037-6054), their k_user
+ * coordinates stay 0 (A was zeroed, :6018-6019). */
+void oracle_optimizeA_collective_implicit_chol(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                               const real_t *C,
+                                               int_t m, int_t m_u, int_t n, int_t p,
+                                               int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                               const real_t *U, real_t lam, real_t w_user, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main;
+    for (int_t i = 0; i < m; i++) memset(A + (size_t)i * lda, 0, (size_t)k_totA * sizeof(real_t));   /* :6018-6019 */
+    /* BtB + lam I  (:6056-6061) */
+    real_t *BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
+    oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
+    for (int_t i = 0; i < kb; i++) BtB[(size_t)i * kb + i] += lam;
+    /* BeTBe: LR = BtB + lam I, first k_user diagonal entries lam, UL += w C^T C  (:6121-6160) */
+    real_t *BeTBe = (real_t *)calloc((size_t)k_totA * k_totA + 1, sizeof(real_t));
+    for (int_t i = 0; i < kb; i++)
+        for (int_t j = 0; j < kb; j++) BeTBe[(size_t)(k_user + i) * k_totA + (k_user + j)] = BtB[(size_t)i * kb + j];
+    for (int_t i = 0; i < k_user; i++) BeTBe[(size_t)i * k_totA + i] += lam;
+    real_t *CtC = (real_t *)calloc((size_t)k_totC * k_totC + 1, sizeof(real_t));
+    oracle_gram(C, (size_t)k_totC, p, k_totC, CtC, nthreads);
+    for (int_t i = 0; i < k_totC; i++)
+        for (int_t j = 0; j < k_totC; j++) BeTBe[(size_t)i * k_totA + j] += w_user * CtC[(size_t)i * k_totC + j];
+    /* A[:m_u, :k_totC] = w U C  (:6163-6168) */
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int_t i = 0; i < m_u; i++) {
+        real_t *a = A + (size_t)i * lda;
+        for (int_t c = 0; c < k_totC; c++) {
+            double s = 0;
+            for (int_t j = 0; j < p; j++) s += (double)U[(size_t)i * p + j] * (double)C[(size_t)j * k_totC + c];
+            a[c] = (real_t)((double)w_user * s);
+        }
+    }
+    size_t szbuf = (size_t)k_totA * k_totA;
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {
+        size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
+        real_t *a = A + (size_t)ix * lda;
+        real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
+        if (ix < m_u) {                                                        /* :1849-2131, few_NAs branch */
+            memcpy(M, BeTBe, szbuf * sizeof(real_t));
+            for (size_t jx = st; jx < en; jx++)                                /* :2097-2101 */
+                axpy_(kb, Xcsr[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+            real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;
+            for (size_t jx = st; jx < en; jx++)                                /* :2103-2108 */
+                syr_upper_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
+            if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
+            else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+        } else if (en > st) {                                                  /* optimizeA_implicit, common.c:2063-2126 */
+            for (int_t i = 0; i < kb; i++) memcpy(M + (size_t)i * kb, BtB + (size_t)i * kb, (size_t)kb * sizeof(real_t));
+            for (size_t jx = st; jx < en; jx++)
+                axpy_(kb, Xcsr[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+            for (size_t jx = st; jx < en; jx++)
+                syr_upper_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, M, kb);
+            if (chol_upper_(kb, M, kb) == 0) chol_solve_upper_(kb, M, kb, a + k_user);
+            else for (int_t i = 0; i < kb; i++) a[k_user + i] = NAN;
+        }
+    }
+    free(bufs); free(BtB); free(BeTBe); free(CtC);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 real_t oracle_calc_mean_and_center(real_t *X, size_t nnz, int nthreads)
 {
@@ -582,35 +648,6 @@ void oracle_initialize_biases_twosided(int_t m, int_t n,
     }
 }
 
-/* ------------------------------------------------------------------------------------------ */
-int oracle_fit_implicit_als(real_t *A, real_t *B, int_t m, int_t n, int_t k,
-                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
-                            real_t lam, real_t alpha, bool apply_log_transf,
-                            int_t niter, int nthreads,
-                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
-{
-    real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
-    memcpy(Xc, X, nnz * sizeof(real_t));
-    if (apply_log_transf) for (size_t i = 0; i < nnz; i++) Xc[i] = log_t(Xc[i]);  /* collective.c:9578-9587 */
-    if (alpha != (real_t)1.) for (size_t i = 0; i < nnz; i++) Xc[i] *= alpha;     /* :9588-9599 */
-    size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));
-    size_t *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
-    int_t *csr_i = (int_t *)malloc(nnz * sizeof(int_t)), *csc_i = (int_t *)malloc(nnz * sizeof(int_t));
-    real_t *csr_v = (real_t *)malloc(nnz * sizeof(real_t)), *csc_v = (real_t *)malloc(nnz * sizeof(real_t));
-    oracle_coo_to_csr_and_csc(ixA, ixB, Xc, m, n, nnz, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v);
-    free(Xc);
-    if (!use_cg) finalize_chol = false;                                           /* :9518 */
-    for (int_t iter = 0; iter < niter; iter++) {                                  /* :9827-10045 */
-        if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
-        oracle_optimizeA_implicit(B, (size_t)k, A, (size_t)k, n, m, k, csc_p, csc_i, csc_v,
-                                  lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
-        oracle_optimizeA_implicit(A, (size_t)k, B, (size_t)k, m, n, k, csr_p, csr_i, csr_v,
-                                  lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
-    }
-    free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
-    return 0;
-}
-
 /* column means + centering of a dense side-info matrix, common.c:4911-4997 (dense, no NaN) */
 static real_t *center_by_cols_dense(const real_t *U, int_t m_u, int_t p, real_t *colmeans)
 {
@@ -623,6 +660,82 @@ static real_t *center_by_cols_dense(const real_t *U, int_t m_u, int_t p, real_t 
         for (int_t c = 0; c < p; c++) Uc[(size_t)r * p + c] = U[(size_t)r * p + c] - colmeans[c];
     return Uc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* fit_collective_implicit_als, collective.c:9375-10207, for: sparse X, optional dense full U / II without
+ * NaN (then Cholesky only), m_u <= m, n_i <= n, reset_values = false.  A[m, k_user+k+k_main],
+ * B[n, k_item+k+k_main], C[p, k_user+k], D[q, k_item+k]. */
+int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
+                                     real_t *U_colmeans, real_t *I_colmeans,
+                                     int_t m, int_t n, int_t k,
+                                     const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                                     const real_t *U, int_t m_u, int_t p, const real_t *II, int_t n_i, int_t q,
+                                     int_t k_main, int_t k_user, int_t k_item,
+                                     real_t w_main, real_t w_user, real_t w_item,
+                                     real_t lam, real_t alpha, bool apply_log_transf,
+                                     int_t niter, int nthreads,
+                                     bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
+{
+    if ((U != NULL || II != NULL) && use_cg) return 2;                            /* block-CG not restated */
+    if (U == NULL) { m_u = 0; p = 0; }
+    if (II == NULL) { n_i = 0; q = 0; }
+    if (m_u > m || n_i > n) return 2;
+    int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
+    real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
+    memcpy(Xc, X, nnz * sizeof(real_t));
+    if (apply_log_transf) for (size_t i = 0; i < nnz; i++) Xc[i] = log_t(Xc[i]);  /* collective.c:9578-9587 */
+    if (alpha != (real_t)1.) for (size_t i = 0; i < nnz; i++) Xc[i] *= alpha;     /* :9588-9599 */
+    size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));
+    size_t *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
+    int_t *csr_i = (int_t *)malloc(nnz * sizeof(int_t)), *csc_i = (int_t *)malloc(nnz * sizeof(int_t));
+    real_t *csr_v = (real_t *)malloc(nnz * sizeof(real_t)), *csc_v = (real_t *)malloc(nnz * sizeof(real_t));
+    oracle_coo_to_csr_and_csc(ixA, ixB, Xc, m, n, nnz, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v);
+    free(Xc);
+    real_t *Uc = NULL, *Ic = NULL;
+    if (U != NULL) Uc = center_by_cols_dense(U, m_u, p, U_colmeans);              /* :9640ff preprocess_sideinfo_matrix */
+    if (II != NULL) Ic = center_by_cols_dense(II, n_i, q, I_colmeans);
+    if (w_main != (real_t)1.) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   /* :9786-9811 */
+    if (!use_cg) finalize_chol = false;                                           /* :9518 */
+    for (int_t iter = 0; iter < niter; iter++) {                                  /* :9827-10045 */
+        if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
+        if (U != NULL)                                                            /* :9834-9873 */
+            oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A, (size_t)k_totA, p, m_u, k_user + k,
+                                        Uc, (size_t)p, true, lam / w_user, lam / w_user, false, nthreads);
+        if (II != NULL)                                                           /* :9877-9917 */
+            oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B, (size_t)k_totB, q, n_i, k_item + k,
+                                        Ic, (size_t)q, true, lam / w_item, lam / w_item, false, nthreads);
+        if (II != NULL)                                                           /* :9924-9963 */
+            oracle_optimizeA_collective_implicit_chol(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m, q,
+                                                      k, k_main, k_item, k_user, csc_p, csc_i, csc_v,
+                                                      Ic, lam, w_item, nthreads);
+        else                                                                      /* :9965-9981 */
+            oracle_optimizeA_implicit(B + k_item, (size_t)k_totB, A + k_user, (size_t)k_totA, n, m, k + k_main,
+                                      csc_p, csc_i, csc_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+        if (U != NULL)                                                            /* :9985-10022 */
+            oracle_optimizeA_collective_implicit_chol(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n, p,
+                                                      k, k_main, k_user, k_item, csr_p, csr_i, csr_v,
+                                                      Uc, lam, w_user, nthreads);
+        else
+            oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n, k + k_main,
+                                      csr_p, csr_i, csr_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+    }
+    free(Uc); free(Ic);
+    free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
+    return 0;
+}
+
+int oracle_fit_implicit_als(real_t *A, real_t *B, int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            real_t lam, real_t alpha, bool apply_log_transf,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
+{
+    return oracle_fit_implicit_als_sideinfo(A, B, NULL, NULL, NULL, NULL, m, n, k, ixA, ixB, X, nnz,
+                                            NULL, 0, 0, NULL, 0, 0, 0, 0, 0, (real_t)1, (real_t)1, (real_t)1,
+                                            lam, alpha, apply_log_transf, niter, nthreads,
+                                            use_cg, max_cg_steps, precondition_cg, finalize_chol);
+}
+
 
 int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                             real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,

@@ -100,6 +100,25 @@ void oracle_initialize_biases_twosided(int_t m, int_t n,
 
 /* collective.c:9375-10207 restricted to: no side info, k_main=k_user=k_item=0 allowed only as 0,
  * w_main=1, no L1/nonneg.  reset_values must be false (caller injects A, B). */
+/* collective.c:5971-6244 + :1849-2131: implicit X + dense full U (no NaN), Cholesky, m_u <= m */
+void oracle_optimizeA_collective_implicit_chol(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                               const real_t *C,
+                                               int_t m, int_t m_u, int_t n, int_t p,
+                                               int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                               const real_t *U, real_t lam, real_t w_user, int nthreads);
+
+int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
+                                     real_t *U_colmeans, real_t *I_colmeans,
+                                     int_t m, int_t n, int_t k,
+                                     const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                                     const real_t *U, int_t m_u, int_t p, const real_t *II, int_t n_i, int_t q,
+                                     int_t k_main, int_t k_user, int_t k_item,
+                                     real_t w_main, real_t w_user, real_t w_item,
+                                     real_t lam, real_t alpha, bool apply_log_transf,
+                                     int_t niter, int nthreads,
+                                     bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol);
+
 int oracle_fit_implicit_als(real_t *A, real_t *B, int_t m, int_t n, int_t k,
                             const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
                             real_t lam, real_t alpha, bool apply_log_transf,

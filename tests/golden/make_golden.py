@@ -136,6 +136,18 @@ def main():
              C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
              U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"], cfg=np.array([ku, ki, km]))
 
+        # ---- implicit model with dense side information, Cholesky (collective.c:5971-6244) ----
+        row, col, val = make_coo(m, n, 8000, 106, dtype=dt, heavy_row=(2, 150), empty_rows=(7, 390))
+        m_u, n_i = m - 40, n                       # users beyond m_u carry no side information
+        U = (rng.standard_normal((m_u, p)) + 1).astype(dt); II = (rng.standard_normal((n_i, q)) - 2).astype(dt)
+        A0 = (rng.standard_normal((m, ku + k + km)) * 0.01).astype(dt); B0 = (rng.standard_normal((n, ki + k + km)) * 0.01).astype(dt)
+        A, B = A0.copy(), B0.copy()
+        r = R.fit_collective_implicit_als(A, B, row, col, val, k, lam=3.0, alpha=2.0, niter=3, nthreads=2, use_cg=False,
+                                          U=U, II=II, k_user=ku, k_item=ki, k_main=km, w_main=0.5, w_user=4.0, w_item=0.8)
+        assert r["ret"] == 0
+        save("g8_fit_implicit_sideinfo_" + tag, row=row, col=col, val=val, m=m, n=n, k=k, U=U, II=II, A0=A0, B0=B0, A=A, B=B,
+             C=r["C"], D=r["D"], U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"], cfg=np.array([ku, ki, km]))
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

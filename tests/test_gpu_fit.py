@@ -95,6 +95,35 @@ def test_fit_explicit_sideinfo(oracles, dtype, useU, useI, ku, ki, km, sls):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("useU,useI,ku,ki,km,m_u", [(False, True, 0, 0, 0, None), (True, True, 0, 0, 0, 500),
+                                                     (True, True, 2, 3, 1, 430), (True, False, 1, 0, 0, 500)])
+def test_fit_implicit_sideinfo(oracles, dtype, useU, useI, ku, ki, km, m_u):
+    """CMF_implicit with dense side information (Cholesky): optimizeA_collective_implicit +
+    collective_closed_form_block_implicit (collective.c:5971-6244, 1849-2131) on the device."""
+    from cmfrec_amd import CMF_implicit
+    O = oracles[dtype]
+    m, n, k, p, q = 500, 320, 24, 12, 9
+    row, col, val = make_coo(m, n, 12000, 29, counts=True, dtype=dtype, empty_rows=(3, 480))
+    rng = np.random.default_rng(5)
+    U = (rng.standard_normal((m_u or m, p)) + 1).astype(dtype); II = (rng.standard_normal((n, q)) - 2).astype(dtype)
+    kA, kB = ku + k + km, ki + k + km
+    A0 = (rng.standard_normal((m, kA)) * 0.01).astype(dtype); B0 = (rng.standard_normal((n, kB)) * 0.01).astype(dtype)
+    kw = dict(niter=3, use_cg=False, k_user=ku, k_item=ki, k_main=km, w_main=0.5, w_user=4.0, w_item=0.8, alpha=2.0)
+    mdl = CMF_implicit(k=k, lambda_=3.0, use_float=dtype is np.float32, **kw).fit(
+        (row, col, val), shape=(m, n), U=U if useU else None, I=II if useI else None, A0=A0, B0=B0)
+    Ao, Bo = A0.copy(), B0.copy()
+    ro = O.fit_implicit_als_sideinfo(Ao, Bo, row, col, val, k, lam=3.0, U=U if useU else None, II=II if useI else None,
+                                     nthreads=1, **kw)
+    t = tol(dtype, "chol")
+    assert ro["ret"] == 0
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    if useU:
+        assert frob(mdl.C_, ro["C"]) < t
+    if useI:
+        assert frob(mdl.D_, ro["D"]) < t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_seeded_fit_matches_reference_seed(dtype):
     """reset_values=true: the start values come from the seed exactly as in the reference
     (xoshiro256++ / ziggurat, helpers.c:927-1043), so a seeded fit() reproduces the reference's own

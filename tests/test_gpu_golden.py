@@ -57,3 +57,11 @@ def test_fits(dtype):
     for got, key in ((mdl.A_, "A"), (mdl.B_, "B"), (mdl.C_, "C"), (mdl.D_, "D"), (mdl.user_bias_, "biasA"),
                      (mdl.item_bias_, "biasB")):
         assert gc.frob(got, g[key]) < t, key
+    g = gc.load("g8_fit_implicit_sideinfo", dtype)
+    ku, ki, km = [int(x) for x in g["cfg"]]
+    mdl = CMF_implicit(k=k, lambda_=3.0, alpha=2.0, niter=3, use_cg=False, k_user=ku, k_item=ki, k_main=km, w_main=0.5,
+                       w_user=4.0, w_item=0.8, use_float=uf).fit(
+        (g["row"], g["col"], g["val"]), shape=(m, n), U=g["U"], I=g["II"], A0=g["A0"], B0=g["B0"])
+    for got, key in ((mdl.A_, "A"), (mdl.B_, "B"), (mdl.C_, "C"), (mdl.D_, "D")):
+        assert gc.frob(got, g[key]) < t, key
+    assert gc.maxrel(mdl._U_colmeans, g["U_colmeans"]) < 1e-6

@@ -88,3 +88,13 @@ def test_fits(oracles, dtype):
     for got, key in ((A, "A"), (B, "B"), (r["C"], "C"), (r["D"], "D"), (r["biasA"], "biasA"), (r["biasB"], "biasB")):
         assert gc.frob(got, g[key]) < t, key
     assert gc.maxrel(r["U_colmeans"], g["U_colmeans"]) < 1e-6
+    g = gc.load("g8_fit_implicit_sideinfo", dtype)
+    ku, ki, km = [int(x) for x in g["cfg"]]
+    A, B = g["A0"].copy(), g["B0"].copy()
+    r = O.fit_implicit_als_sideinfo(A, B, g["row"], g["col"], g["val"], k, lam=3.0, alpha=2.0, niter=3, use_cg=False,
+                                    U=g["U"], II=g["II"], k_user=ku, k_item=ki, k_main=km, w_main=0.5, w_user=4.0,
+                                    w_item=0.8)
+    assert r["ret"] == 0
+    for got, key in ((A, "A"), (B, "B"), (r["C"], "C"), (r["D"], "D")):
+        assert gc.frob(got, g[key]) < t, key
+    assert gc.maxrel(r["U_colmeans"], g["U_colmeans"]) < 1e-6 and gc.maxrel(r["I_colmeans"], g["I_colmeans"]) < 1e-6

@@ -73,3 +73,29 @@ def test_fits_live(oracles, refs, dtype):
         rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), nthreads=2, **kw)
         assert ro["ret"] == 0 and rr["ret"] == 0
         assert rel_err(Ao, Ar) < tol and rel_err(Bo, Br) < tol, (mode, ub, ib)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fit_implicit_sideinfo_live(oracles, refs, dtype):
+    """Implicit model with dense side information, Cholesky (optimizeA_collective_implicit,
+    collective.c:5971-6244): k_user / k_item / k_main, m_u < m, n_i < n, w_main folding, one side only."""
+    O, R = oracles[dtype], refs[dtype]
+    tol = 1e-10 if dtype is np.float64 else 2e-3
+    m, n, k = 120, 90, 6
+    row, col, val = make_coo(m, n, 1500, 3, counts=True, dtype=dtype, empty_rows=(4, 110))
+    rng = np.random.default_rng(7)
+    for ku, ki, km, m_u, n_i, wm in ((0, 0, 0, 120, 90, 1.0), (2, 3, 1, 100, 90, 0.5), (0, 2, 0, None, 70, 1.0)):
+        U = None if m_u is None else rng.standard_normal((m_u, 5)).astype(dtype)
+        II = rng.standard_normal((n_i, 4)).astype(dtype)
+        kua = ku if U is not None else 0
+        A0 = (rng.standard_normal((m, kua + k + km)) * 0.1).astype(dtype)
+        B0 = (rng.standard_normal((n, ki + k + km)) * 0.1).astype(dtype)
+        kw = dict(lam=2.0, alpha=1.5, niter=3, use_cg=False, k_main=km, k_user=kua, k_item=ki, w_main=wm, w_user=3.0,
+                  w_item=0.7, U=U, II=II)
+        a1, b1, a2, b2 = A0.copy(), B0.copy(), A0.copy(), B0.copy()
+        r1 = R.fit_collective_implicit_als(a1, b1, row, col, val, k, nthreads=2, **kw)
+        r2 = O.fit_implicit_als_sideinfo(a2, b2, row, col, val, k, nthreads=2, **kw)
+        assert r1["ret"] == 0 and r2["ret"] == 0
+        assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol and rel_err(r2["D"], r1["D"]) < tol
+        if U is not None:
+            assert rel_err(r2["C"], r1["C"]) < tol
