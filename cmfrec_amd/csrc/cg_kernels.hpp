@@ -62,6 +62,14 @@ struct CgParams {
     int scale_lam, scale_bias_const;
     int max_cg_steps;
     int precond;          // Jacobi-preconditioned CG (factors_*_pcg): generic kernel only
+    // ---- block system with dense side information (collective_block_cg[_implicit], generic kernel only) ----
+    // unknowns per row kt = koff + k: coordinates [koff, kt) couple to X (the k columns above), [0, kc) to U
+    int koff = 0, kc = 0;
+    const T *CtC = nullptr;   // [kc, kc] C^T C, NOT multiplied by w_side (collective.c:2156)
+    const T *UC = nullptr;    // [rows_with_u, kc] U C of the local rows, NOT multiplied by w_side
+    T w_side = 0;
+    int rows_with_u = 0;      // local rows < rows_with_u carry side information; the others are plain rows
+    int p_side = 0, scale_lam_sideinfo = 0;
 };
 
 template <typename T>
@@ -717,10 +725,11 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Generic fallback (any k): one wavefront per row, lane f owns factors f, f+64, ...; the dot
-// product of every gathered row is a wave reduction.  Same arithmetic as above, used for k
-// beyond the register-tile instantiations and as an on-device cross-check of the tiled kernel.
+// One wavefront per row, lane <-> unknown (any k_t <= 64 NF).  Serves k > 64, the Jacobi-preconditioned
+// variants (factors_*_pcg) and the block systems with dense side information
+// (collective_block_cg, src/collective.c:2134-2903; collective_block_cg_implicit, :2905-3303; dense full U
+// without NaN, prefer_CtC branch): unknowns [koff, k_t) couple to X through the gathered rows (+ BtB in the
+// implicit model), unknowns [0, kc) to U through w C^T C and the constant w (U C)_row.
 template <typename T, int NF, bool IMPLICIT>
 __global__ void __launch_bounds__(256)
 cg_rows_generic_kernel(const CgParams<T> P)
@@ -728,33 +737,64 @@ cg_rows_generic_kernel(const CgParams<T> P)
     const int lane = threadIdx.x & 63;
     const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int k = P.k;
+    const int kx = P.k, koff = P.koff, kt = koff + kx, kc = P.kc;
+    const bool coll = kc > 0;
     for (int rix = wave_global; rix < P.nrows; rix += nwaves) {
         const int row = P.order[rix];
         const size_t st = P.indptr[row];
         const int nnz = (int)(P.indptr[row + 1] - st);
+        const bool has_u = coll && row < P.rows_with_u;
+        if (nnz == 0 && !has_u) continue;                     // plain rows without entries stay untouched (common.c:3270,3354)
+        const int lo = has_u ? 0 : koff;                      // rows without side information: the X block only (collective.c:4832-5101)
         T lam = P.lam, lam_last = P.lam_last;
-        if (!IMPLICIT && P.scale_lam) {
-            lam *= (T)nnz;
-            if (!P.scale_bias_const) lam_last *= (T)nnz;
+        if (!IMPLICIT) {
+            if (has_u) {
+                if (P.scale_lam || P.scale_lam_sideinfo) {    // collective.c:1285-1355
+                    T mult = (nnz > 0) ? (T)nnz : T(1);
+                    if (P.scale_lam_sideinfo) mult += (T)P.p_side;
+                    lam *= mult; lam_last *= mult;
+                }
+            } else if (P.scale_lam) {                         // common.c:679-723
+                lam *= (T)nnz;
+                if (!P.scale_bias_const) lam_last *= (T)nnz;
+            }
         }
         T *arow = P.A + (size_t)row * P.lda;
+        const T *ucrow = has_u ? P.UC + (size_t)row * kc : nullptr;
         T a[NF], r[NF], p[NF], Ap[NF];
 #pragma unroll
-        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; a[c] = (f < k) ? arow[f] : T(0); }
+        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; a[c] = (f >= lo && f < kt) ? arow[f] : T(0); }
 
+        auto bcast = [&](const T (&v)[NF], int j) {           // v[j] for every lane
+            T vj = T(0);
+#pragma unroll
+            for (int c = 0; c < NF; c++) if (c == (j >> 6)) vj = __shfl(v[c], j & 63);
+            return vj;
+        };
         auto matvec = [&](const T (&v)[NF], T (&out)[NF], int mode) {
 #pragma unroll
             for (int c = 0; c < NF; c++) out[c] = T(0);
             if (IMPLICIT) {
-                for (int j = 0; j < k; j++) {                  // out = +-BtB v (row j of BtB times v_j)
-                    int cj = j >> 6, lj = j & 63;
-                    T vj = T(0);
-#pragma unroll
-                    for (int c = 0; c < NF; c++) if (c == cj) vj = __shfl(v[c], lj);
+                for (int j = 0; j < kx; j++) {                 // out[koff:] = +-BtB v[koff:]
+                    T vj = bcast(v, koff + j);
                     if (mode == 0) vj = -vj;
 #pragma unroll
-                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f < k) out[c] += vj * P.BtB[(size_t)j * k + f]; }
+                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < kt) out[c] += vj * P.BtB[(size_t)j * kx + (f - koff)]; }
+                }
+            }
+            if (has_u) {                                       // out[:kc] = w (UC_row - CtC v[:kc])  |  w CtC v[:kc]
+                T acc[NF];
+#pragma unroll
+                for (int c = 0; c < NF; c++) acc[c] = T(0);
+                for (int j = 0; j < kc; j++) {
+                    const T vj = bcast(v, j);
+#pragma unroll
+                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f < kc) acc[c] += vj * P.CtC[(size_t)j * kc + f]; }
+                }
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    int f = lane + 64 * c;
+                    if (f < kc) out[c] += (mode == 0) ? P.w_side * (ucrow[f] - acc[c]) : P.w_side * acc[c];
                 }
             }
             for (int j = 0; j < nnz; j++) {
@@ -764,7 +804,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 const T *b = P.B + (size_t)idx * P.ldb;
                 T bv[NF]; T part = T(0);
 #pragma unroll
-                for (int c = 0; c < NF; c++) { int f = lane + 64 * c; bv[c] = (f < k) ? b[f] : T(0); part += bv[c] * v[c]; }
+                for (int c = 0; c < NF; c++) { int f = lane + 64 * c; bv[c] = (f >= koff && f < kt) ? b[f - koff] : T(0); part += bv[c] * v[c]; }
                 T coef = wave_sum(part);
                 T w;
                 if (IMPLICIT) w = (mode == 0) ? (-(coef - T(1)) * x - coef) : (coef * (x - T(1)) + coef);
@@ -779,18 +819,19 @@ cg_rows_generic_kernel(const CgParams<T> P)
             for (int c = 0; c < NF; c++) s += u[c] * v[c];
             return wave_sum(s);
         };
+        auto live = [&](int f) { return f >= lo && f < kt; };
         matvec(a, r, 0);
 #pragma unroll
         for (int c = 0; c < NF; c++) {
             int f = lane + 64 * c;
             r[c] -= lam * a[c];
-            if (!IMPLICIT && lam != lam_last && f == k - 1) r[c] -= (lam_last - lam) * a[c];
-            if (f >= k) r[c] = T(0);
+            if (!IMPLICIT && lam != lam_last && f == kt - 1) r[c] -= (lam_last - lam) * a[c];
+            if (!live(f)) r[c] = T(0);
             p[c] = r[c];
         }
         if (P.precond) {
-            // factors_implicit_pcg common.c:1988-2061 / factors_explicit_pcg :1190-1291:
-            // Jacobi preconditioner, fixed number of steps, no early exits
+            // factors_implicit_pcg common.c:1988-2061 / factors_explicit_pcg :1190-1291 / the block versions
+            // collective.c:2180-2316, :2960-3010: Jacobi preconditioner, fixed number of steps, no early exits
             T PC[NF], z[NF];
 #pragma unroll
             for (int c = 0; c < NF; c++) PC[c] = T(0);
@@ -801,20 +842,21 @@ cg_rows_generic_kernel(const CgParams<T> P)
 #pragma unroll
                 for (int c = 0; c < NF; c++) {
                     int f = lane + 64 * c;
-                    T bv = (f < k) ? b[f] : T(0);
+                    T bv = (f >= koff && f < kt) ? b[f - koff] : T(0);
                     PC[c] += IMPLICIT ? x * (bv * bv) : bv * bv;                 // :2009-2014 / :1238-1243
                 }
             }
 #pragma unroll
             for (int c = 0; c < NF; c++) {
                 int f = lane + 64 * c;
-                if (IMPLICIT) PC[c] += (f < k) ? P.BtB[(size_t)f * k + f] : T(1);
+                if (has_u && f < kc) PC[c] += P.CtC[(size_t)f * kc + f];         // sum_l C_l^2, unweighted (collective.c:2281-2286)
+                if (IMPLICIT) PC[c] += (f >= koff && f < kt) ? P.BtB[(size_t)(f - koff) * kx + (f - koff)] : T(0);
                 else {
                     PC[c] += lam;
-                    if (lam != lam_last && f == k - 1) PC[c] += (lam_last - lam);
+                    if (lam != lam_last && f == kt - 1) PC[c] += (lam_last - lam);
                 }
-                PC[c] = T(1) / PC[c];
-                z[c] = (f < k) ? r[c] * PC[c] : T(0);
+                PC[c] = live(f) ? T(1) / PC[c] : T(0);
+                z[c] = r[c] * PC[c];
                 p[c] = z[c];
             }
             T r_old = vdot(z, r);
@@ -824,15 +866,14 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 for (int c = 0; c < NF; c++) {
                     int f = lane + 64 * c;
                     Ap[c] += lam * p[c];
-                    if (!IMPLICIT && lam != lam_last && f == k - 1) Ap[c] += (lam_last - lam) * p[c];
-                    if (f >= k) Ap[c] = T(0);
+                    if (!IMPLICIT && lam != lam_last && f == kt - 1) Ap[c] += (lam_last - lam) * p[c];
+                    if (!live(f)) Ap[c] = T(0);
                 }
                 T alpha = r_old / vdot(Ap, p);
 #pragma unroll
                 for (int c = 0; c < NF; c++) {
-                    int f = lane + 64 * c;
                     a[c] += alpha * p[c]; r[c] -= alpha * Ap[c];
-                    z[c] = (f < k) ? r[c] * PC[c] : T(0);
+                    z[c] = r[c] * PC[c];
                 }
                 T r_new = vdot(z, r);
                 T ratio = r_new / r_old;
@@ -849,8 +890,8 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 for (int c = 0; c < NF; c++) {
                     int f = lane + 64 * c;
                     Ap[c] += lam * p[c];
-                    if (!IMPLICIT && lam != lam_last && f == k - 1) Ap[c] += (lam_last - lam) * p[c];
-                    if (f >= k) Ap[c] = T(0);
+                    if (!IMPLICIT && lam != lam_last && f == kt - 1) Ap[c] += (lam_last - lam) * p[c];
+                    if (!live(f)) Ap[c] = T(0);
                 }
                 T alpha = r_old / vdot(Ap, p);
 #pragma unroll
@@ -865,7 +906,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
         }
         }
 #pragma unroll
-        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f < k) arow[f] = a[c]; }
+        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (live(f)) arow[f] = a[c]; }
     }
 }
 

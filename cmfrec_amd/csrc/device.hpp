@@ -278,6 +278,12 @@ struct CgCall {
     int max_cg_steps;
     bool implicit;
     bool precond = false;
+    // block system with dense side information (A points at the first unknown, koff of them precede the X block)
+    int koff = 0, kc = 0;
+    const real_t *CtC = nullptr, *UC = nullptr;
+    real_t w_side = 0;
+    int rows_with_u = 0, p_side = 0;
+    bool scale_lam_sideinfo = false;
 };
 
 enum class CgVariant { Auto, Generic };
@@ -416,7 +422,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
 template <int NF, bool IMPLICIT>
 inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X)
 {
-    int count = X.n_nonempty;
+    int count = (P.kc > 0) ? X.nrows : X.n_nonempty;       // rows without entries still have side information
     if (count <= 0) return;
     P.nrows = count;
     int grid = std::min((count + 3) / 4, dev.num_cus * 8);
@@ -434,9 +440,12 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.scale_lam = c.scale_lam; P.scale_bias_const = c.scale_bias_const;
     P.max_cg_steps = c.max_cg_steps;
     P.precond = c.precond ? 1 : 0;
+    P.koff = c.koff; P.kc = c.kc; P.CtC = c.CtC; P.UC = c.UC; P.w_side = c.w_side;
+    P.rows_with_u = c.rows_with_u; P.p_side = c.p_side; P.scale_lam_sideinfo = c.scale_lam_sideinfo ? 1 : 0;
     const int S = (c.k + 7) / 8;
-    // the Jacobi-preconditioned variant (not a default anywhere in the reference) runs on the generic kernel
-    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond;
+    // the Jacobi-preconditioned variants (not a default anywhere in the reference) and the block systems with side
+    // information run on the generic kernel
+    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond || c.kc > 0;
     if (!generic) {
 #define CMF_CASE(SS)                                                        \
     case SS:                                                                \
@@ -449,7 +458,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
         }
 #undef CMF_CASE
     }
-    const int NF = (c.k + 63) / 64;
+    const int NF = (c.koff + c.k + 63) / 64;
 #define CMF_GCASE(NN)                                                       \
     case NN:                                                                \
         if (c.implicit) launch_cg_generic<NN, true>(dev, P, X);             \

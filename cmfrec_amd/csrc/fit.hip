@@ -124,7 +124,6 @@ int_t fit_collective_implicit_als(
     if (U == nullptr) { m_u = 0; p = 0; }
     if (II == nullptr) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
-    if ((U || II) && use_cg) return fail(verbose, "cmfrec_hip: side information requires use_cg=false (block-CG: SURVEY 8f-1).");
     for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
     for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
     if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight || precompute_for_predictions)
@@ -237,7 +236,6 @@ int_t fit_collective_explicit_als(
     if (U == nullptr) { m_u = 0; p = 0; }
     if (II == nullptr) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
-    if ((U || II) && use_cg) return fail(verbose, "cmfrec_hip: side information requires use_cg=false (block-CG: SURVEY 8f-1).");
     if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");

@@ -120,7 +120,7 @@ struct cmfrec_hip_session {
     size_t ldA = 0, ldB = 0;
     DevBuf<real_t> A, B, biasA, biasB, C, D, U, II;
     SparseShard Xr, Xc;
-    DevBuf<real_t> gram, ctc, betbe;
+    DevBuf<real_t> gram, ctc, betbe, ucA, ucB;
     GramWorkspace gws;
     std::vector<EventPair> evA, evB;     // whole half-steps
     BinTimers binA, binB;                // row-update kernel launches per nnz bin
@@ -187,10 +187,6 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
             g_last_error = "cmfrec_hip: side information with more rows than X is not supported";
             return 2;
         }
-        if ((m.p > 0 || m.q > 0) && m.use_cg) {
-            g_last_error = "cmfrec_hip: side information requires the Cholesky solver (block-CG not implemented)";
-            return 2;
-        }
         s = new cmfrec_hip_session();
         s->mdl = m;
         init_device(s->dev, device);
@@ -215,6 +211,8 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
         s->betbe.alloc((size_t)kmax * kmax);
         if (m.p > 0) s->C.alloc((size_t)m.p * (m.k_user + m.k));
         if (m.q > 0) s->D.alloc((size_t)m.q * (m.k_item + m.k));
+        if (m.p > 0 && m.use_cg) s->ucA.alloc((size_t)std::max(1, m.m_u) * (m.k_user + m.k));     // U C of the block CG
+        if (m.q > 0 && m.use_cg) s->ucB.alloc((size_t)std::max(1, m.n_i) * (m.k_item + m.k));
         return 0;
     });
     if (rc != 0) {
@@ -417,6 +415,40 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
     real_t *self_blk = self + (size_t)begin * ld_self;
     const int kk = m.k + m.k_main;
 
+    if (p_self > 0 && !chol) {
+        // block CG on the collective system, dense full side information: collective_block_cg (explicit,
+        // collective.c:2134-2903) / collective_block_cg_implicit (:2905-3303), prefer_CtC branch
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+        const int rows_u = isA ? m.m_u : m.n_i;
+        const int kc = k_side_self + m.k;
+        const real_t w = isA ? m.w_user : m.w_item;
+        const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
+        real_t *uc = isA ? s->ucA.ptr : s->ucB.ptr;
+        launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, (real_t)1, (real_t)0);   // C^T C, unweighted
+        launch_gemm<false>(dev, local_u, kc, p_self, (real_t)1, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
+                           uc, (size_t)kc);                                                        // U C
+        const real_t *bias_sub_cg = nullptr;
+        int kx = kk;
+        if (m.implicit) {
+            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, (real_t)0);
+        } else {
+            if (self_bias) {
+                const int rows_fill = isA ? m.n : m.m;
+                hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_fill), dim3(256), 0, st, opp, ld_opp, rows_fill,
+                                   isA ? s->k_totB : s->k_totA, (real_t)1);
+                HIP_CHECK(hipGetLastError());
+                kx += 1;
+            }
+            if (opp_bias) bias_sub_cg = isA ? s->biasB.ptr : s->biasA.ptr;
+        }
+        CgCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kx, bias_sub_cg, m.implicit ? s->gram.ptr : nullptr,
+                 m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
+                 (bool)m.precondition_cg};
+        c.koff = k_side_self; c.kc = kc; c.CtC = s->ctc.ptr; c.UC = uc; c.w_side = w; c.rows_with_u = local_u;
+        c.p_side = p_self; c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo;
+        return launch_cg(dev, c, X, nullptr);
+    }
     if (m.implicit && p_self > 0) {
         // optimizeA_collective_implicit, Cholesky, dense full side information (collective.c:5971-6244)
         const real_t *Cm = isA ? s->C.ptr : s->D.ptr;

@@ -75,8 +75,7 @@ class CMF_implicit(_Base):
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
         them from ``random_state`` (C argument ``reset_values=false``).  ``U`` / ``I``: dense side
-        information without missing values (then ``use_cg=False`` is required: the block-CG solver of
-        the reference is not implemented)."""
+        information without missing values."""
         row, col, val, m, n = _coo_triplet(X, shape)
         lib, R = self._lib()
         dt = self.dtype_
@@ -85,9 +84,6 @@ class CMF_implicit(_Base):
         Ic = None if I is None else np.ascontiguousarray(I, dt)
         m_u, p = (0, 0) if Uc is None else Uc.shape
         n_i, q = (0, 0) if Ic is None else Ic.shape
-        if (p or q) and self.use_cg:
-            raise NotImplementedError("side information requires use_cg=False in cmfrec_amd "
-                                      "(block-CG: SURVEY.md 8f-1)")
         if m_u > m or n_i > n:
             raise NotImplementedError("side information with more rows than X is not implemented in cmfrec_amd")
         ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
@@ -173,9 +169,6 @@ class CMF(_Base):
         m_u, p = (0, 0) if Uc is None else Uc.shape
         n_i, q = (0, 0) if Ic is None else Ic.shape
         use_cg = self.use_cg
-        if (Uc is not None or Ic is not None) and use_cg:
-            raise NotImplementedError("side information requires use_cg=False in cmfrec_amd "
-                                      "(block-CG: SURVEY.md 8f-1)")
         ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
         reset = A0 is None
         A = np.empty((max(m, m_u), ka), dt) if reset else np.array(A0, dt, order="C", copy=True)

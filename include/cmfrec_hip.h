@@ -41,10 +41,11 @@ extern "C" {
 
 /* Replaces fit_collective_implicit_als, /root/reference/src/cmfrec.h:1893-1921 (body
  * src/collective.c:9375-10207; documented in include/cmfrec.h.in:927-959).
- * Supported: CG / PCG / Cholesky without side information; with DENSE side information
- * U[m_u<=m, p] / II[n_i<=n, q] without NaN (k_user, k_item, k_main, w_main, w_user, w_item as the
- * reference) only use_cg=false (optimizeA_collective_implicit, src/collective.c:5971-6244; the block-CG of
- * :2905 is not built).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight, no precompute.
+ * Supported: CG / PCG / Cholesky, optionally with DENSE side information U[m_u<=m, p] / II[n_i<=n, q]
+ * without NaN (k_user, k_item, k_main, w_main, w_user, w_item as the reference): Cholesky
+ * (optimizeA_collective_implicit, src/collective.c:5971-6244) or block CG / PCG
+ * (collective_block_cg_implicit, :2905-3303).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight,
+ * no precompute.
  * Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
@@ -77,8 +78,9 @@ int_t fit_collective_implicit_als(
 /* Replaces fit_collective_explicit_als, /root/reference/src/cmfrec.h:1851-1892 (body
  * src/collective.c:7263-9370; include/cmfrec.h.in:885-926).
  * Supported in this round: sparse X with missing-as-NA, no weights, biases/centering/scale_lam,
- * CG or Cholesky, optional DENSE side information U[m_u<=m, p] / II[n_i<=n, q] without NaN
- * (Cholesky only), k_main/k_user/k_item, w_user/w_item.  Anything else returns 2. */
+ * CG / PCG or Cholesky, optional DENSE side information U[m_u<=m, p] / II[n_i<=n, q] without NaN
+ * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
+ * k_main/k_user/k_item, w_user/w_item.  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,

@@ -529,6 +529,129 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
     free(CtCw);
 }
 
+/* Block CG on the collective system, dense full U without NaN (prefer_CtC branches):
+ * collective_block_cg (collective.c:2134-2903; called from collective_closed_form_block :1223-1533 with the
+ * row's lambda scaling :1285-1355) and collective_block_cg_implicit (:2905-3303).  Unknowns [k_user, k_totA)
+ * couple to X, unknowns [0, k_user+k) to U.  Rows >= m_u are plain rows (optimizeA / optimizeA_implicit on the
+ * X block, collective.c:4832-5101, :6037-6054): their first k_user unknowns are not touched. */
+void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                                    int_t m, int_t m_u, int_t n, int_t p,
+                                    int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                    const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                    const real_t *U, real_t lam, real_t w_user, real_t lam_last,
+                                    bool scale_lam, bool scale_lam_sideinfo, bool implicit,
+                                    int_t max_cg_steps, bool precondition_cg, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    const int_t kt = k_user + k + k_main, kc = k_user + k, kb = k + k_main;
+    real_t *CtC = (real_t *)calloc((size_t)kc * kc + 1, sizeof(real_t));
+    oracle_gram(C, (size_t)kc, p, kc, CtC, nthreads);                            /* unweighted, collective.c:5855-5860 */
+    real_t *BtB = NULL;
+    if (implicit) {                                                              /* :6056-6061, no lambda with CG */
+        BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
+        oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
+    }
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {
+        const size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
+        const size_t nnz = en - st;
+        const bool has_u = ix < m_u;
+        if (nnz == 0 && !has_u) continue;
+        const int_t lo = has_u ? 0 : k_user;
+        real_t *a = A + (size_t)ix * lda;
+        real_t lam_i = lam, lam_last_i = lam_last;
+        if (!implicit) {
+            if (has_u) {
+                if (scale_lam || scale_lam_sideinfo) {                           /* :1285-1355 */
+                    real_t mult = (nnz > 0) ? (real_t)nnz : (real_t)1;
+                    if (scale_lam_sideinfo) mult += (real_t)p;
+                    lam_i *= mult; lam_last_i *= mult;
+                }
+            } else if (scale_lam) { lam_i *= (real_t)nnz; lam_last_i *= (real_t)nnz; }   /* common.c:679-723 */
+        }
+        real_t r[512], pp[512], Ap[512], z[512], PC[512], ctu[512];
+        /* Ap-type product: out = [BtB v_x] + sum_j w_j(B_j.v_x) B_j + w CtC v_u  (no lambda) */
+        #define BLOCK_MATVEC(v, out, resid)                                                              \
+            do {                                                                                          \
+                for (int_t f = 0; f < kt; f++) out[f] = 0;                                                \
+                if (implicit)                                                                             \
+                    for (int_t i = 0; i < kb; i++) {                                                      \
+                        double sacc = 0;                                                                  \
+                        for (int_t j = 0; j < kb; j++) sacc += (double)BtB[(size_t)i * kb + j] * (double)v[k_user + j]; \
+                        out[k_user + i] = (real_t)((resid) ? -sacc : sacc);                               \
+                    }                                                                                     \
+                for (size_t jx = st; jx < en; jx++) {                                                     \
+                    const real_t *b = B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb;                      \
+                    real_t coef = 0;                                                                      \
+                    for (int_t f = 0; f < kb; f++) coef += b[f] * v[k_user + f];                          \
+                    real_t wgt;                                                                           \
+                    if (implicit) wgt = (resid) ? (-(coef - (real_t)1) * Xcsr[jx] - coef) : (coef * (Xcsr[jx] - (real_t)1) + coef); \
+                    else          wgt = (resid) ? (-coef + Xcsr[jx]) : coef;                              \
+                    for (int_t f = 0; f < kb; f++) out[k_user + f] += wgt * b[f];                         \
+                }                                                                                         \
+                if (has_u)                                                                                \
+                    for (int_t i = 0; i < kc; i++) {                                                      \
+                        double sacc = 0;                                                                  \
+                        for (int_t j = 0; j < kc; j++) sacc += (double)CtC[(size_t)i * kc + j] * (double)v[j]; \
+                        out[i] += (resid) ? w_user * (ctu[i] - (real_t)sacc) : w_user * (real_t)sacc;     \
+                    }                                                                                     \
+            } while (0)
+        if (has_u)                                                               /* C^T u, :2500-2515 / :3040-3046 */
+            for (int_t i = 0; i < kc; i++) {
+                double sacc = 0;
+                for (int_t l = 0; l < p; l++) sacc += (double)U[(size_t)ix * p + l] * (double)C[(size_t)l * kc + i];
+                ctu[i] = (real_t)sacc;
+            }
+        BLOCK_MATVEC(a, r, 1);
+        for (int_t f = 0; f < kt; f++) r[f] -= lam_i * a[f];                     /* diag(lam) */
+        if (!implicit && lam_i != lam_last_i) r[kt - 1] -= (lam_last_i - lam_i) * a[kt - 1];
+        for (int_t f = 0; f < lo; f++) r[f] = 0;
+        real_t r_old, r_new;
+        if (precondition_cg) {
+            for (int_t f = 0; f < kt; f++) PC[f] = 0;
+            for (size_t jx = st; jx < en; jx++) {
+                const real_t *b = B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb;
+                for (int_t f = 0; f < kb; f++) PC[k_user + f] += (implicit ? Xcsr[jx] : (real_t)1) * b[f] * b[f];
+            }
+            if (has_u) for (int_t f = 0; f < kc; f++) PC[f] += CtC[(size_t)f * kc + f];   /* unweighted, :2281-2286 */
+            if (implicit) for (int_t f = 0; f < kb; f++) PC[k_user + f] += BtB[(size_t)f * kb + f];
+            else {
+                for (int_t f = 0; f < kt; f++) PC[f] += lam_i;
+                if (lam_i != lam_last_i) PC[kt - 1] += (lam_last_i - lam_i);
+            }
+            for (int_t f = 0; f < kt; f++) PC[f] = (f >= lo) ? (real_t)1 / PC[f] : 0;
+            r_old = 0;
+            for (int_t f = 0; f < kt; f++) { z[f] = r[f] * PC[f]; pp[f] = z[f]; r_old += z[f] * r[f]; }
+        } else {
+            r_old = 0;
+            for (int_t f = 0; f < kt; f++) { pp[f] = r[f]; r_old += r[f] * r[f]; }
+            if (r_old <= (real_t)1e-12) continue;
+        }
+        for (int_t step = 0; step < max_cg_steps; step++) {
+            BLOCK_MATVEC(pp, Ap, 0);
+            for (int_t f = 0; f < kt; f++) Ap[f] += lam_i * pp[f];
+            if (!implicit && lam_i != lam_last_i) Ap[kt - 1] += (lam_last_i - lam_i) * pp[kt - 1];
+            for (int_t f = 0; f < lo; f++) Ap[f] = 0;
+            real_t pAp = 0;
+            for (int_t f = 0; f < kt; f++) pAp += pp[f] * Ap[f];
+            const real_t alpha = r_old / pAp;
+            for (int_t f = lo; f < kt; f++) { a[f] += alpha * pp[f]; r[f] -= alpha * Ap[f]; }
+            r_new = 0;
+            if (precondition_cg) {
+                for (int_t f = 0; f < kt; f++) { z[f] = r[f] * PC[f]; r_new += z[f] * r[f]; }
+                for (int_t f = 0; f < kt; f++) pp[f] = pp[f] * (r_new / r_old) + z[f];
+            } else {
+                for (int_t f = 0; f < kt; f++) r_new += r[f] * r[f];
+                if (r_new <= (real_t)1e-8) break;
+                for (int_t f = 0; f < kt; f++) pp[f] = pp[f] * (r_new / r_old) + r[f];
+            }
+            r_old = r_new;
+        }
+        #undef BLOCK_MATVEC
+    }
+    free(CtC); free(BtB);
+}
+
 /* optimizeA_collective_implicit (collective.c:5971-6244) + collective_closed_form_block_implicit
  * (:1849-2131): implicit-feedback X, dense full U without NaN, Cholesky.  m_u <= m: rows >= m_u go
  * through optimizeA_implicit on the k+k_main block at column offset k_user (:6037-6054), their k_user
@@ -676,7 +799,6 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
                                      int_t niter, int nthreads,
                                      bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
 {
-    if ((U != NULL || II != NULL) && use_cg) return 2;                            /* block-CG not restated */
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n) return 2;
@@ -704,14 +826,22 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
         if (II != NULL)                                                           /* :9877-9917 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B, (size_t)k_totB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, false, nthreads);
-        if (II != NULL)                                                           /* :9924-9963 */
+        if (II != NULL && use_cg)                                                 /* :9924-9963 */
+            oracle_optimizeA_collective_cg(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m, q, k, k_main, k_item, k_user,
+                                           csc_p, csc_i, csc_v, Ic, lam, w_item, lam, false, false, true,
+                                           max_cg_steps, precondition_cg, nthreads);
+        else if (II != NULL)
             oracle_optimizeA_collective_implicit_chol(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m, q,
                                                       k, k_main, k_item, k_user, csc_p, csc_i, csc_v,
                                                       Ic, lam, w_item, nthreads);
         else                                                                      /* :9965-9981 */
             oracle_optimizeA_implicit(B + k_item, (size_t)k_totB, A + k_user, (size_t)k_totA, n, m, k + k_main,
                                       csc_p, csc_i, csc_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
-        if (U != NULL)                                                            /* :9985-10022 */
+        if (U != NULL && use_cg)                                                  /* :9985-10022 */
+            oracle_optimizeA_collective_cg(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n, p, k, k_main, k_user, k_item,
+                                           csr_p, csr_i, csr_v, Uc, lam, w_user, lam, false, false, true,
+                                           max_cg_steps, precondition_cg, nthreads);
+        else if (U != NULL)
             oracle_optimizeA_collective_implicit_chol(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n, p,
                                                       k, k_main, k_user, k_item, csr_p, csr_i, csr_v,
                                                       Uc, lam, w_user, nthreads);
@@ -755,7 +885,6 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
     if (m_u > m || n_i > n) return 2;          /* restatement restricted (see header) */
-    if ((U != NULL || II != NULL) && use_cg) return 2;   /* block-CG not restated */
     if (init_biases && (user_bias != item_bias)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     if (!use_cg) finalize_chol = false;                                        /* :7481 */
@@ -809,7 +938,11 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
         if (user_bias)                                                         /* :8566-8570 */
             for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
-        if (II != NULL)                                                        /* :8634-8678 */
+        if (II != NULL && use_cg)                                              /* :8634-8678 */
+            oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
+                                           csc_p, csc_i, csc_v, Ic, lam, w_item, lam, scale_lam, scale_lam_sideinfo, false,
+                                           max_cg_steps, precondition_cg, nthreads);
+        else if (II != NULL)
             oracle_optimizeA_collective_chol(B_bias, ldB, A_bias, ldA, D, n, n_i, m, q,
                                              k, k_main + (int_t)item_bias, k_item, k_user,
                                              csc_p, csc_i, csc_v, Ic, lam, w_item, lam,
@@ -825,7 +958,11 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
             for (int_t c = 0; c < n; c++) B_bias[(size_t)c * ldB + k_totB] = 1;
         if (item_bias)                                                         /* :8750-8754 */
             for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
-        if (U != NULL)                                                         /* :8805-8845 */
+        if (U != NULL && use_cg)                                               /* :8805-8845 */
+            oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
+                                           csr_p, csr_i, csr_v, Uc, lam, w_user, lam, scale_lam, scale_lam_sideinfo, false,
+                                           max_cg_steps, precondition_cg, nthreads);
+        else if (U != NULL)
             oracle_optimizeA_collective_chol(A_bias, ldA, B_bias, ldB, C, m, m_u, n, p,
                                              k, k_main + (int_t)user_bias, k_user, k_item,
                                              csr_p, csr_i, csr_v, Uc, lam, w_user, lam,

@@ -124,6 +124,43 @@ def test_fit_implicit_sideinfo(oracles, dtype, useU, useI, ku, ki, km, m_u):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("implicit", [False, True])
+@pytest.mark.parametrize("pcg,ku,ki,km,m_u,fin", [(False, 0, 0, 0, 500, False), (False, 2, 3, 1, 430, True),
+                                                   (True, 1, 0, 2, 500, False)])
+def test_fit_sideinfo_block_cg(oracles, dtype, implicit, pcg, ku, ki, km, m_u, fin):
+    """Side information with use_cg=True: the block CG / PCG of the collective system
+    (collective_block_cg, collective.c:2134-2903; collective_block_cg_implicit, :2905-3303) on the device,
+    optionally finishing with a Cholesky iteration (finalize_chol)."""
+    from cmfrec_amd import CMF, CMF_implicit
+    O = oracles[dtype]
+    m, n, k, p, q = 500, 320, 24, 12, 9
+    row, col, val = make_coo(m, n, 12000, 31, counts=implicit, dtype=dtype, empty_rows=(3, 480))
+    rng = np.random.default_rng(6)
+    U = (rng.standard_normal((m_u, p)) + 1).astype(dtype); II = (rng.standard_normal((n, q)) - 2).astype(dtype)
+    kA, kB = ku + k + km, ki + k + km
+    A0 = (rng.standard_normal((m, kA)) * 0.01).astype(dtype); B0 = (rng.standard_normal((n, kB)) * 0.01).astype(dtype)
+    Ao, Bo = A0.copy(), B0.copy()
+    if implicit:
+        kw = dict(niter=3, use_cg=True, precondition_cg=pcg, finalize_chol=fin, k_user=ku, k_item=ki, k_main=km, w_main=0.5,
+                  w_user=4.0, w_item=0.8, alpha=2.0)
+        mdl = CMF_implicit(k=k, lambda_=3.0, use_float=dtype is np.float32, **kw).fit(
+            (row, col, val), shape=(m, n), U=U, I=II, A0=A0, B0=B0)
+        ro = O.fit_implicit_als_sideinfo(Ao, Bo, row, col, val, k, lam=3.0, U=U, II=II, nthreads=1, **kw)
+    else:
+        kw = dict(niter=3, use_cg=True, precondition_cg=pcg, finalize_chol=fin, k_user=ku, k_item=ki, k_main=km,
+                  w_user=0.5, w_item=2.0, scale_lam=True, scale_lam_sideinfo=ku > 0)
+        mdl = CMF(k=k, lambda_=0.05, use_float=dtype is np.float32, nthreads=1, **kw).fit(
+            (row, col, val), shape=(m, n), U=U, I=II, A0=A0, B0=B0)
+        ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, lam=0.05, U=U, II=II, nthreads=1, **kw)
+    t = tol(dtype, "cg")
+    assert ro["ret"] == 0
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    assert frob(mdl.C_, ro["C"]) < t and frob(mdl.D_, ro["D"]) < t
+    if not implicit:
+        assert frob(mdl.user_bias_, ro["biasA"]) < t and frob(mdl.item_bias_, ro["biasB"]) < t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_seeded_fit_matches_reference_seed(dtype):
     """reset_values=true: the start values come from the seed exactly as in the reference
     (xoshiro256++ / ziggurat, helpers.c:927-1043), so a seeded fit() reproduces the reference's own

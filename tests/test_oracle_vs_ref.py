@@ -99,3 +99,42 @@ def test_fit_implicit_sideinfo_live(oracles, refs, dtype):
         assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol and rel_err(r2["D"], r1["D"]) < tol
         if U is not None:
             assert rel_err(r2["C"], r1["C"]) < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("pcg", [False, True])
+def test_fit_block_cg_live(oracles, refs, dtype, pcg):
+    """Side information with use_cg=True: collective_block_cg (explicit, collective.c:2134-2903) and
+    collective_block_cg_implicit (:2905-3303), CG and Jacobi-PCG, against the compiled reference."""
+    O, R = oracles[dtype], refs[dtype]
+    tol = 1e-10 if dtype is np.float64 else 5e-3
+    m, n, k = 120, 90, 6
+    rng = np.random.default_rng(7)
+    for ku, ki, km, m_u, n_i, wm in ((0, 0, 0, 120, 90, 1.0), (2, 3, 1, 100, 90, 0.5), (0, 2, 0, None, 70, 1.0)):
+        U = None if m_u is None else rng.standard_normal((m_u, 5)).astype(dtype)
+        II = rng.standard_normal((n_i, 4)).astype(dtype)
+        kua = ku if U is not None else 0
+        A0 = (rng.standard_normal((m, kua + k + km)) * 0.1).astype(dtype)
+        B0 = (rng.standard_normal((n, ki + k + km)) * 0.1).astype(dtype)
+        C0 = None if U is None else (rng.standard_normal((5, kua + k)) * 0.1).astype(dtype)
+        D0 = (rng.standard_normal((4, ki + k)) * 0.1).astype(dtype)
+        cp = lambda x: None if x is None else x.copy()
+        row, col, val = make_coo(m, n, 1500, 3, counts=True, dtype=dtype, empty_rows=(4, 110))
+        kw = dict(lam=2.0, alpha=1.5, niter=3, use_cg=True, max_cg_steps=3, precondition_cg=pcg, k_main=km, k_user=kua,
+                  k_item=ki, w_main=wm, w_user=3.0, w_item=0.7, U=U, II=II)
+        a1, b1, a2, b2 = A0.copy(), B0.copy(), A0.copy(), B0.copy()
+        r1 = R.fit_collective_implicit_als(a1, b1, row, col, val, k, nthreads=2, Cm=cp(C0), Dm=cp(D0), **kw)
+        r2 = O.fit_implicit_als_sideinfo(a2, b2, row, col, val, k, nthreads=2, Cm=cp(C0), Dm=cp(D0), **kw)
+        assert r1["ret"] == 0 and r2["ret"] == 0
+        assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol and rel_err(r2["D"], r1["D"]) < tol, ("implicit", ku, ki, km)
+        row, col, val = make_coo(m, n, 1500, 4, counts=False, dtype=dtype, empty_rows=(4, 110))
+        kw = dict(lam=0.3, niter=3, use_cg=True, max_cg_steps=3, precondition_cg=pcg, finalize_chol=False, k_main=km,
+                  k_user=kua, k_item=ki, w_user=3.0, w_item=0.7, U=U, II=II, scale_lam=True, scale_lam_sideinfo=ku > 0)
+        bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+        a1, b1, a2, b2 = A0.copy(), B0.copy(), A0.copy(), B0.copy()
+        r1 = R.fit_collective_explicit_als(a1, b1, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), nthreads=2,
+                                           Cm=cp(C0), Dm=cp(D0), **kw)
+        r2 = O.fit_explicit_als(a2, b2, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), nthreads=2, Cm=cp(C0),
+                                Dm=cp(D0), **kw)
+        assert r1["ret"] == 0 and r2["ret"] == 0
+        assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol and rel_err(r2["biasA"], r1["biasA"]) < tol, ("explicit", ku, ki, km)
