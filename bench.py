@@ -201,9 +201,26 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu}
         if args.scale != 1.0:
             out["config"]["INVALID_scaled_down"] = args.scale
-        print(json.dumps(out))
+        final_line = json.dumps(out)
+    else:
+        final_line = None
     if use_dist:
         dist.destroy_process_group()
+    emit_last_line(final_line)
+
+
+def emit_last_line(line):
+    """The result must be the LAST line on stdout.  RCCL writes a version banner through C stdio, which
+    sits in libc's buffer until exit and would land after a Python print(); so: flush Python's buffer,
+    flush every C stream (fflush(NULL)), then write the JSON line and flush again."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if line is not None:
+        print(line, flush=True)
 
 
 def whole_fit(args):
