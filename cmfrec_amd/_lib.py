@@ -37,7 +37,7 @@ EXPORTED = [
     "cmfrec_hip_optimizeA_implicit", "cmfrec_hip_optimizeA_explicit",
     "cmfrec_hip_optimizeA_dense_full", "cmfrec_hip_optimizeA_collective",
     "cmfrec_hip_session_create", "cmfrec_hip_session_destroy", "cmfrec_hip_last_error",
-    "cmfrec_hip_session_set_X", "cmfrec_hip_session_set_X_coo", "cmfrec_hip_session_init_biases", "cmfrec_hip_session_get_X", "cmfrec_hip_session_set_factors", "cmfrec_hip_session_get_factors",
+    "cmfrec_hip_session_set_X", "cmfrec_hip_session_set_X_coo", "cmfrec_hip_session_precompute", "cmfrec_hip_session_init_biases", "cmfrec_hip_session_get_X", "cmfrec_hip_session_set_factors", "cmfrec_hip_session_get_factors",
     "cmfrec_hip_session_set_sideinfo", "cmfrec_hip_session_update", "cmfrec_hip_session_iterate",
     "cmfrec_hip_session_sync", "cmfrec_hip_session_device_ptr", "cmfrec_hip_session_stream",
     "cmfrec_hip_session_after_gather", "cmfrec_hip_session_kernel_time",

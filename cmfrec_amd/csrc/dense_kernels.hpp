@@ -261,6 +261,48 @@ gemm_kernel(int M, int N, int K, T alpha, const T *__restrict__ A, size_t lda,
         }
 }
 
+// In-place Cholesky of one small matrix, M = R^T R, upper triangle of the row-major matrix (what LAPACK's
+// potrf('L') leaves on the column-major view, src/collective.c:9241, :10107); the strict lower triangle is not
+// touched.  One workgroup; the matrix stays in global memory (n <= a few hundred, called once per fit).
+template <typename T>
+__global__ void __launch_bounds__(256)
+potrf_upper_kernel(T *__restrict__ M, int n)
+{
+    __shared__ T s_piv;
+    const int tid = threadIdx.x;
+    for (int c = 0; c < n; c++) {
+        if (tid == 0) { s_piv = sqrt(M[(size_t)c * n + c]); M[(size_t)c * n + c] = s_piv; }
+        __syncthreads();
+        const T piv = s_piv;
+        for (int j = c + 1 + tid; j < n; j += 256) M[(size_t)c * n + j] /= piv;
+        __syncthreads();
+        const int rem = n - c - 1;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int i = c + 1 + e / rem, j = c + 1 + e % rem;
+            if (j >= i) M[(size_t)i * n + j] -= M[(size_t)c * n + i] * M[(size_t)c * n + j];
+        }
+        __syncthreads();
+    }
+}
+
+// dst[off + i][off + j] (+)= scale * src[i][j] for an [ns, ns] block placed at (off, off) of an [nd, nd] matrix
+template <typename T>
+__global__ void add_block_kernel(const T *__restrict__ src, int ns, T scale, T *__restrict__ dst, int nd, int off)
+{
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < ns * ns; e += gridDim.x * blockDim.x) {
+        const int i = e / ns, j = e % ns;
+        dst[(size_t)(off + i) * nd + (off + j)] += scale * src[e];
+    }
+}
+
+// M[i][i] += value for i in [first, last)
+template <typename T>
+__global__ void add_diag_kernel(T *__restrict__ M, int n, int first, int last, T value)
+{
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < last) M[(size_t)i * n + i] += value;
+}
+
 // out[kt,kt] := blockdiag(lam * I[ks], G[kk,kk])  (kt = ks + kk): the part of Be^T Be every row shares in the
 // implicit model with side information, collective.c:6121-6135 (G = BtB + lam I already)
 template <typename T>

@@ -112,8 +112,8 @@ int_t fit_collective_implicit_als(
     real_t *precomputedBeTBeChol, real_t *precomputedCtUbias)
 {
     (void)U_row; (void)U_col; (void)I_row; (void)I_col; (void)NA_as_zero_U; (void)NA_as_zero_I;
-    (void)nthreads; (void)max_cd_steps; (void)nonneg_C; (void)nonneg_D; (void)precomputedBtB;
-    (void)precomputedBeTBe; (void)precomputedBeTBeChol; (void)precomputedCtUbias;
+    (void)nthreads; (void)max_cd_steps; (void)nonneg_C; (void)nonneg_D;
+    (void)precomputedCtUbias;            // only written with sparse U + NA_as_zero_U (collective.c:10111), not supported
     (void)handle_interrupt;
     // collective.c:9406-9435
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
@@ -126,8 +126,10 @@ int_t fit_collective_implicit_als(
     if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
     for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
     for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
-    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight || precompute_for_predictions)
-        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / adjust_weight / precompute_for_predictions are not implemented.");
+    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight)
+        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / adjust_weight are not implemented.");
+    if (precompute_for_predictions && precomputedBtB == nullptr)
+        return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
@@ -197,6 +199,15 @@ int_t fit_collective_implicit_als(
         if (rc2) rc_loop = rc2;
     }
     tm.lap("get_factors");
+    if ((rc_loop == 0 || rc_loop == 3) && precompute_for_predictions) {   // collective.c:10056-10115 (also after an interrupt, :10034-10043)
+        if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }
+        const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
+        int rc2 = cmfrec_hip_session_precompute(s, last_chol, precomputedBtB, nullptr, U ? precomputedBeTBe : nullptr,
+                                                U ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
+        if (rc2) rc_loop = rc2;
+        if (verbose) printf("  done\n");
+        tm.lap("precompute epilogue");
+    }
     cmfrec_hip_session_destroy(s);
     tm.lap("session destroy");
     if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
@@ -222,17 +233,20 @@ int_t fit_collective_explicit_als(
 {
     (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB; (void)U_row; (void)U_col; (void)I_row; (void)I_col;
     (void)NA_as_zero_U; (void)NA_as_zero_I; (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
-    (void)nonneg_C; (void)nonneg_D; (void)include_all_X; (void)B_plus_bias; (void)precomputedBtB;
-    (void)precomputedTransBtBinvBt; (void)precomputedBtXbias; (void)precomputedBeTBeChol; (void)precomputedBiTBi;
-    (void)precomputedTransCtCinvCt; (void)precomputedCtCw; (void)precomputedCtUbias;
+    (void)nonneg_C; (void)nonneg_D; (void)include_all_X;      // n_max == n here (n_i <= n), so include_all_X changes nothing
+    (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
+    (void)precomputedBiTBi;        // only with add_implicit_features, not supported
+    (void)precomputedCtUbias;      // only with sparse U + NA_as_zero_U, not supported
     // collective.c:7308-7329
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
     if (Xfull || weight || NA_as_zero_X || U_sp || I_sp || nnz_U || nnz_I || add_implicit_features)
         return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / sparse side info / implicit features are not implemented.");
-    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const || precompute_for_predictions)
-        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / scale_bias_const / precompute_for_predictions are not implemented.");
+    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const)
+        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / scale_bias_const are not implemented.");
+    if (precompute_for_predictions && precomputedBtB == nullptr)
+        return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (U == nullptr) { m_u = 0; p = 0; }
     if (II == nullptr) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
@@ -326,8 +340,23 @@ int_t fit_collective_explicit_als(
         int rc2 = cmfrec_hip_session_get_factors(s, A, B, biasA, biasB, C, D);
         if (rc2) rc_loop = rc2;
     }
+    if ((rc_loop == 0 || rc_loop == 3) && precompute_for_predictions) {   // collective.c:8936-9249
+        if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }
+        const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
+        int rc2 = cmfrec_hip_session_precompute(s, last_chol, precomputedBtB, precomputedTransBtBinvBt, nullptr,
+                                                U ? precomputedBeTBeChol : nullptr, U ? precomputedCtCw : nullptr,
+                                                U ? precomputedTransCtCinvCt : nullptr);
+        if (rc2) rc_loop = rc2;
+        if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
+            for (int_t c = 0; c < n; c++) {
+                memcpy(B_plus_bias + (size_t)c * (k_totB + 1), B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));
+                B_plus_bias[(size_t)c * (k_totB + 1) + k_totB] = 1;
+            }
+        }
+        if (verbose) printf("  done\n");
+    }
     cmfrec_hip_session_destroy(s);
-    tm.lap("get_factors + destroy");
+    tm.lap("get_factors + precompute + destroy");
     if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
     return rc_loop > 3 ? 1 : rc_loop;
 }

@@ -544,6 +544,96 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC)
     return launch_chol(dev, c, nullptr, p);                                                        // common.c:2872-2875
 }
 
+// The matrices the reference keeps for predictions on new data (the step after the path),
+// from the factors resident in the session:
+//   implicit (epilogue of fit_collective_implicit_als, src/collective.c:10056-10115):
+//     BtB = B^T B + lam I;  with user side information  BeTBe = blockdiag(lam I, BtB) + w C^T C  and its Cholesky factor
+//   explicit (epilogue of fit_collective_explicit_als, :8936-9249), Bp = [B(:, k_item:) | 1 if user_bias]:
+//     BtB = Bp^T Bp;  TransBtBinvBt = Bp (BtB + lam (n if scale_lam) I)^-1;  CtCw = w C^T C;
+//     TransCtCinvCt = C (C^T C + lam (p if scale_lam) / w I)^-1;
+//     BeTBeChol = chol(blockdiag(0, BtB) + CtCw + lam mult I),  mult = p + n | n | 1
+// Host output buffers, NULL = skip; square matrices are complete (both triangles) except the Cholesky factors
+// (upper triangle R, M = R^T R; the strict lower triangle holds the lower triangle of M).
+int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky, real_t *BtB, real_t *TransBtBinvBt,
+                                  real_t *BeTBe, real_t *BeTBeChol, real_t *CtCw, real_t *TransCtCinvCt)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        const DeviceInfo &dev = s->dev;
+        hipStream_t st = dev.stream;
+        const int kk = m.k + m.k_main, ub = (!m.implicit && m.user_bias) ? 1 : 0;
+        const int kp = kk + ub, kc = m.k_user + m.k, kq = m.k_user + kp;
+        const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
+        DevBuf<real_t> Bp, G, M, T1;
+        Bp.alloc((size_t)m.n * kp); G.alloc((size_t)kp * kp);
+        hipLaunchKernelGGL(copy_mat_kernel<real_t>, grid1d((size_t)m.n * kk), dim3(256), 0, st, s->B.ptr + m.k_item, s->ldB, Bp.ptr,
+                           (size_t)kp, (size_t)m.n, kk);
+        if (ub) hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, Bp.ptr, (size_t)kp, m.n, kk, (real_t)1);
+        launch_gram(dev, s->gws, Bp.ptr, (size_t)kp, m.n, kp, G.ptr, (real_t)1, m.implicit ? m.lam : (real_t)0);
+        if (BtB) G.download(BtB, (size_t)kp * kp, st);
+        if (TransBtBinvBt && !m.implicit) {                               // collective.c:9034-9082
+            M.alloc((size_t)kp * kp);
+            HIP_CHECK(hipMemcpyAsync(M.ptr, G.ptr, (size_t)kp * kp * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kp), dim3(256), 0, st, M.ptr, kp, 0, kp,
+                               m.lam * (real_t)(m.scale_lam ? m.n : 1));
+            CholCall c{Bp.ptr, (size_t)kp, nullptr, 0, kp, 0, nullptr, M.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+            int rc = launch_chol(dev, c, nullptr, m.n);
+            if (rc) return rc;
+            Bp.download(TransBtBinvBt, (size_t)m.n * kp, st);
+        }
+        if (m.p > 0) {
+            const real_t w = m.w_user;
+            DevBuf<real_t> CtC, Cc;
+            CtC.alloc((size_t)kc * kc);
+            launch_gram(dev, s->gws, s->C.ptr, (size_t)kc, m.p, kc, CtC.ptr, (real_t)1, (real_t)0);
+            if (TransCtCinvCt && !m.implicit) {                           // :9083-9142
+                M.alloc((size_t)kc * kc); Cc.alloc((size_t)m.p * kc);
+                HIP_CHECK(hipMemcpyAsync(M.ptr, CtC.ptr, (size_t)kc * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+                HIP_CHECK(hipMemcpyAsync(Cc.ptr, s->C.ptr, (size_t)m.p * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kc), dim3(256), 0, st, M.ptr, kc, 0, kc,
+                                   m.lam * (real_t)(m.scale_lam ? m.p : 1) / w);
+                CholCall c{Cc.ptr, (size_t)kc, nullptr, 0, kc, 0, nullptr, M.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+                int rc = launch_chol(dev, c, nullptr, m.p);
+                if (rc) return rc;
+                Cc.download(TransCtCinvCt, (size_t)m.p * kc, st);
+            }
+            if (CtCw) {                                                   // w C^T C
+                T1.alloc((size_t)kc * kc);
+                HIP_CHECK(hipMemsetAsync(T1.ptr, 0, (size_t)kc * kc * sizeof(real_t), st));
+                hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, w, T1.ptr, kc, 0);
+                T1.download(CtCw, (size_t)kc * kc, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+            if (BeTBe || BeTBeChol) {                                     // :9184-9243 / :10073-10110
+                M.alloc((size_t)kq * kq);
+                HIP_CHECK(hipMemsetAsync(M.ptr, 0, (size_t)kq * kq * sizeof(real_t), st));
+                hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kp * kp), dim3(256), 0, st, G.ptr, kp, (real_t)1, M.ptr, kq, m.k_user);
+                // Quirk Q9 (reference behaviour, reproduced on purpose -- see DESIGN.md "Parity"): in the implicit model
+                // whose last iteration ran CG (no finalize_chol) the epilogue scales the cached C^T C by w_user only `if (w_user == 1.)`
+                // (src/collective.c:10077, the test is inverted), so for w_user != 1 the UNWEIGHTED C^T C ends up in
+                // BeTBe / BeTBeChol.  With Cholesky (or w_user == 1) the weighted matrix comes out, as intended.
+                const real_t w_betbe = (m.implicit && !last_step_cholesky) ? (real_t)1 : w;
+                hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, w_betbe, M.ptr, kq, 0);
+                if (m.implicit) {                                         // lam is already inside G; the k_user block gets its own
+                    if (m.k_user) hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(m.k_user), dim3(256), 0, st, M.ptr, kq, 0, m.k_user, m.lam);
+                } else {
+                    const real_t mult = m.scale_lam_sideinfo ? (real_t)(m.p + m.n) : (scale_lam ? (real_t)m.n : (real_t)1);
+                    hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kq), dim3(256), 0, st, M.ptr, kq, 0, kq, m.lam * mult);
+                }
+                if (BeTBe) M.download(BeTBe, (size_t)kq * kq, st);
+                if (BeTBeChol) {
+                    hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, st, M.ptr, kq);
+                    M.download(BeTBeChol, (size_t)kq * kq, st);
+                }
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    });
+}
+
 int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which)
 {
     return guarded([&]() {

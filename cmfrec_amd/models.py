@@ -96,6 +96,11 @@ class CMF_implicit(_Base):
         Dm = np.zeros((q, self.k_item + self.k), dt) if q else None
         Ucm = np.zeros(max(p, 1), dt); Icm = np.zeros(max(q, 1), dt)
         wmm = np.zeros(1, dt)
+        pre = self.precompute_for_predictions
+        kq = self.k_user + self.k + self.k_main
+        BtB = np.zeros((self.k + self.k_main,) * 2, dt) if pre else None
+        BeTBe = np.zeros((kq, kq), dt) if (pre and p) else None
+        BeTBeChol = np.zeros((kq, kq), dt) if (pre and p) else None
         rc = lib.fit_collective_implicit_als(
             _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), C.c_bool(reset), C.c_int(self.random_state),
             _lib.ptr(Ucm) if (p and self.center_U) else None, _lib.ptr(Icm) if (q and self.center_I) else None,
@@ -110,13 +115,18 @@ class CMF_implicit(_Base):
             C.c_bool(self.verbose), C.c_bool(self.handle_interrupt), C.c_bool(self.use_cg),
             C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg), C.c_bool(self.finalize_chol),
             C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
-            C.c_bool(False), None, None, None, None)
+            C.c_bool(pre), _lib.ptr(BtB), _lib.ptr(BeTBe), _lib.ptr(BeTBeChol), None)
         _lib.check(rc, lib, "fit_collective_implicit_als")
         self.A_, self.B_ = A, B
         self.C_ = Cm if Cm is not None else np.empty((0, 0), dt)
         self.D_ = Dm if Dm is not None else np.empty((0, 0), dt)
         self._U_colmeans, self._I_colmeans = Ucm[:p], Icm[:q]
         self._w_main_multiplier = float(wmm[0])
+        # precomputed matrices for predictions on new data, reference attribute names (cmfrec/__init__.py:4893-4927)
+        e = np.empty((0, 0), dt)
+        self._BtB = BtB if BtB is not None else e
+        self._BeTBe = BeTBe if BeTBe is not None else e
+        self._BeTBeChol = BeTBeChol if BeTBeChol is not None else e
         self.is_fitted_ = True
         return self
 
@@ -181,6 +191,14 @@ class CMF(_Base):
         Dm = np.zeros((q, self.k_item + self.k), dt) if q else None
         glob_mean = np.zeros(1, dt); Ucm = np.zeros(max(p, 1), dt); Icm = np.zeros(max(q, 1), dt)
         sbA = np.zeros(1, dt); sbB = np.zeros(1, dt)
+        pre = self.precompute_for_predictions
+        kp = self.k + self.k_main + int(self.user_bias); kc = self.k_user + self.k; kq = self.k_user + kp
+        Bpb = np.zeros((max(n, n_i), kb + 1), dt) if (pre and self.user_bias) else None
+        BtB = np.zeros((kp, kp), dt) if pre else None
+        TBt = np.zeros((max(n, n_i), kp), dt) if pre else None
+        BeChol = np.zeros((kq, kq), dt) if (pre and p) else None
+        TCt = np.zeros((p, kc), dt) if (pre and p) else None
+        CtCw = np.zeros((kc, kc), dt) if (pre and p) else None
         rc = lib.fit_collective_explicit_als(
             _lib.ptr(biasA), _lib.ptr(biasB), _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), None, None,
             C.c_bool(False), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean), _lib.ptr(Ucm),
@@ -196,8 +214,17 @@ class CMF(_Base):
             C.c_int(self.niter), C.c_int(self.nthreads), C.c_bool(self.verbose), C.c_bool(self.handle_interrupt),
             C.c_bool(use_cg), C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg),
             C.c_bool(self.finalize_chol), C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
-            C.c_bool(False), C.c_bool(True), None, None, None, None, None, None, None, None, None)
+            C.c_bool(pre), C.c_bool(True), _lib.ptr(Bpb), _lib.ptr(BtB), _lib.ptr(TBt), None, _lib.ptr(BeChol), None,
+            _lib.ptr(TCt), _lib.ptr(CtCw), None)
         _lib.check(rc, lib, "fit_collective_explicit_als")
+        # precomputed matrices for predictions on new data, reference attribute names (cmfrec/__init__.py:3211-3247)
+        e = np.empty((0, 0), dt)
+        self._B_plus_bias = Bpb if Bpb is not None else e
+        self._BtB = BtB if BtB is not None else e
+        self._TransBtBinvBt = TBt if TBt is not None else e
+        self._BeTBeChol = BeChol if BeChol is not None else e
+        self._TransCtCinvCt = TCt if TCt is not None else e
+        self._CtCw = CtCw if CtCw is not None else e
         self.A_, self.B_ = A, B
         self.C_ = Cm if Cm is not None else np.empty((0, 0), dt)
         self.D_ = Dm if Dm is not None else np.empty((0, 0), dt)

@@ -234,6 +234,17 @@ void *cmfrec_hip_session_stream(cmfrec_hip_session *s);
 /* To be called after the local block of `which` was refreshed on all ranks (after the all-gather):
  * refreshes what is derived from the full matrix (bias vectors). */
 int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which);
+/* The "precompute_for_predictions" epilogue of the fit drivers (src/collective.c:8936-9249, 10056-10115) from
+ * the resident factors.  Host buffers, NULL = skip.  With kp = k + k_main (+1 with a user bias, explicit),
+ * kc = k_user + k, kq = k_user + kp:  BtB[kp, kp] (implicit: + lam I);  explicit only: TransBtBinvBt[n, kp],
+ * TransCtCinvCt[p, kc];  with user side information: CtCw[kc, kc] (explicit), BeTBe[kq, kq] (implicit),
+ * BeTBeChol[kq, kq] (upper triangle = the factor R, M = R^T R).
+ * last_step_cholesky: whether the last iteration of the fit used the Cholesky solver (use_cg=false or
+ * finalize_chol).  It only matters for quirk Q9 of the reference, which this library reproduces: in the implicit
+ * model with user side information, after a CG last step, BeTBe / BeTBeChol carry the UNWEIGHTED C^T C when
+ * w_user != 1 (src/collective.c:10077 tests `w_user == 1.` where `!=` was meant); see DESIGN.md, Parity. */
+int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky, real_t *BtB, real_t *TransBtBinvBt,
+                                  real_t *BeTBe, real_t *BeTBeChol, real_t *CtCw, real_t *TransCtCinvCt);
 
 /* HIP-event time (ms) and launch count of the row-update kernels of `which` ('A' or 'B') since
  * the last reset; synchronises the stream. */

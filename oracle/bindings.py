@@ -359,7 +359,8 @@ class Reference:
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                                     finalize_chol=False, reset_values=False, seed=1,
                                     apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
-                                    k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0):
+                                    k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
+                                    precompute=False):
         m = A.shape[0]; n = B.shape[0]
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
@@ -371,6 +372,9 @@ class Reference:
             Cm = np.zeros((p, k_user + k), self.dtype)
         if II is not None and Dm is None:
             Dm = np.zeros((q, k_item + k), self.dtype)
+        kq = k_user + k + k_main
+        pre = dict(BtB=np.zeros((k + k_main, k + k_main), self.dtype), BeTBe=np.zeros((kq, kq), self.dtype),
+                   BeTBeChol=np.zeros((kq, kq), self.dtype), CtUbias=np.zeros(max(k_user + k, 1), self.dtype)) if precompute else None
         ret = self.lib.fit_collective_implicit_als(
             _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), C.c_bool(reset_values), C.c_int(seed), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
@@ -383,17 +387,18 @@ class Reference:
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
             C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
-            C.c_bool(False), None, None, None, None)
-        if U is None and II is None:
+            C.c_bool(precompute), _ptr(pre["BtB"]) if pre else None, _ptr(pre["BeTBe"]) if pre else None,
+            _ptr(pre["BeTBeChol"]) if pre else None, _ptr(pre["CtUbias"]) if pre else None)
+        if U is None and II is None and not precompute:
             return ret
-        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm)
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm, pre=pre)
 
     def fit_collective_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None,
                                     Dm=None, U=None, II=None, user_bias=True, item_bias=True,
                                     center=True, lam=10.0, scale_lam=False, scale_lam_sideinfo=False,
                                     k_main=0, k_user=0, k_item=0, w_user=1.0, w_item=1.0, niter=10,
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
-                                    finalize_chol=True, reset_values=False, seed=1):
+                                    finalize_chol=True, reset_values=False, seed=1, precompute=False):
         m = A.shape[0]; n = B.shape[0]
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
@@ -408,6 +413,15 @@ class Reference:
         if II is not None and Dm is None:
             Dm = np.zeros((q, k_item + k), self.dtype)
         sbA = np.zeros(1, self.dtype); sbB = np.zeros(1, self.dtype)
+        kp = k + k_main + int(user_bias); kc = k_user + k; kq = k_user + kp
+        pre = None
+        if precompute:
+            pre = dict(B_plus_bias=np.zeros((n, k_item + k + k_main + 1), self.dtype), BtB=np.zeros((kp, kp), self.dtype),
+                       TransBtBinvBt=np.zeros((n, kp), self.dtype), BtXbias=np.zeros(kp, self.dtype),
+                       BeTBeChol=np.zeros((kq, kq), self.dtype), BiTBi=np.zeros((k + k_main, k + k_main), self.dtype),
+                       TransCtCinvCt=np.zeros((max(Cm.shape[0] if Cm is not None else 1, 1), max(kc, 1)), self.dtype),
+                       CtCw=np.zeros((max(kc, 1), max(kc, 1)), self.dtype), CtUbias=np.zeros(max(kc, 1), self.dtype))
+        pp = (lambda key: _ptr(pre[key])) if pre else (lambda key: None)
         ret = self.lib.fit_collective_explicit_als(
             _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), None, None,
             C.c_bool(False), C.c_bool(reset_values), C.c_int(seed),
@@ -424,6 +438,7 @@ class Reference:
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
             C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
-            C.c_bool(False), C.c_bool(True), None, None, None, None, None, None, None, None, None)
+            C.c_bool(precompute), C.c_bool(True), pp("B_plus_bias"), pp("BtB"), pp("TransBtBinvBt"), pp("BtXbias"),
+            pp("BeTBeChol"), pp("BiTBi"), pp("TransCtCinvCt"), pp("CtCw"), pp("CtUbias"))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],
-                    U_colmeans=Ucm, I_colmeans=Icm)
+                    U_colmeans=Ucm, I_colmeans=Icm, pre=pre)

@@ -148,6 +148,33 @@ def main():
         save("g8_fit_implicit_sideinfo_" + tag, row=row, col=col, val=val, m=m, n=n, k=k, U=U, II=II, A0=A0, B0=B0, A=A, B=B,
              C=r["C"], D=r["D"], U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"], cfg=np.array([ku, ki, km]))
 
+        # ---- precompute_for_predictions epilogue (collective.c:8936-9249, 10056-10115) ----
+        # implicit + side information, last step CG, w_user != 1: pins quirk Q9 (unweighted C^T C in BeTBe)
+        row, col, val = make_coo(m, n, 8000, 107, dtype=dt)
+        A0 = (rng.standard_normal((m, ku + k + km)) * 0.01).astype(dt); B0 = (rng.standard_normal((n, ki + k + km)) * 0.01).astype(dt)
+        U = (rng.standard_normal((m, p)) + 1).astype(dt); II = (rng.standard_normal((n, q)) - 2).astype(dt)
+        out = dict(row=row, col=col, val=val, m=m, n=n, k=k, U=U, II=II, A0=A0, B0=B0, cfg=np.array([ku, ki, km]))
+        for mode in ("cg", "chol"):
+            A, B = A0.copy(), B0.copy()
+            r = R.fit_collective_implicit_als(A, B, row, col, val, k, lam=3.0, alpha=2.0, niter=2, nthreads=2,
+                                              use_cg=mode == "cg", U=U, II=II, k_user=ku, k_item=ki, k_main=km,
+                                              w_main=0.5, w_user=4.0, w_item=0.8, precompute=True)
+            assert r["ret"] == 0
+            out.update({"B_" + mode: B, "C_" + mode: r["C"], "BtB_" + mode: np.triu(r["pre"]["BtB"]),
+                        "BeTBe_" + mode: np.triu(r["pre"]["BeTBe"]), "BeTBeChol_" + mode: np.triu(r["pre"]["BeTBeChol"])})
+        save("g9_precompute_implicit_" + tag, **out)
+        row, col, val = make_coo(m, n, 8000, 108, counts=False, dtype=dt)
+        A, B = A0.copy(), B0.copy()
+        r = R.fit_collective_explicit_als(A, B, row, col, val, k, lam=0.05, scale_lam=True, scale_lam_sideinfo=True, niter=2,
+                                          nthreads=2, use_cg=False, U=U, II=II, k_user=ku, k_item=ki, k_main=km,
+                                          w_user=0.5, w_item=2.0, precompute=True)
+        assert r["ret"] == 0
+        pr = r["pre"]
+        save("g9_precompute_explicit_" + tag, row=row, col=col, val=val, m=m, n=n, k=k, U=U, II=II, A0=A0, B0=B0,
+             cfg=np.array([ku, ki, km]), B=B, C=r["C"], B_plus_bias=pr["B_plus_bias"], BtB=np.triu(pr["BtB"]),
+             TransBtBinvBt=pr["TransBtBinvBt"], BeTBeChol=np.triu(pr["BeTBeChol"]), CtCw=np.triu(pr["CtCw"]),
+             TransCtCinvCt=pr["TransCtCinvCt"])
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -65,3 +65,52 @@ def test_fits(dtype):
     for got, key in ((mdl.A_, "A"), (mdl.B_, "B"), (mdl.C_, "C"), (mdl.D_, "D")):
         assert gc.frob(got, g[key]) < t, key
     assert gc.maxrel(mdl._U_colmeans, g["U_colmeans"]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_precompute_epilogue(dtype):
+    """precompute_for_predictions: the matrices the reference keeps for predictions on new
+    data, computed on the device from the resident factors, against the reference's own outputs
+    (collective.c:8936-9249, 10056-10115).  Includes quirk Q9: after a CG last step the implicit model's
+    BeTBe / BeTBeChol carry the UNWEIGHTED C^T C when w_user != 1 (the reference tests `w_user == 1.` where
+    `!=` was meant, collective.c:10077) -- reproduced on purpose, and asserted here so a fix is a conscious act."""
+    from cmfrec_amd import CMF, CMF_implicit
+    uf = dtype is np.float32
+    t = 2e-5 if uf else 1e-9               # fits of 2 iterations + small dense algebra
+    up = np.triu
+    g = gc.load("g9_precompute_implicit", dtype)
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    ku, ki, km = [int(x) for x in g["cfg"]]
+    for mode in ("cg", "chol"):
+        mdl = CMF_implicit(k=k, lambda_=3.0, alpha=2.0, niter=2, use_cg=mode == "cg", k_user=ku, k_item=ki, k_main=km,
+                           w_main=0.5, w_user=4.0, w_item=0.8, use_float=uf, precompute_for_predictions=True).fit(
+            (g["row"], g["col"], g["val"]), shape=(m, n), U=g["U"], I=g["II"], A0=g["A0"], B0=g["B0"])
+        assert gc.frob(up(mdl._BtB), g["BtB_" + mode]) < t, mode
+        assert gc.frob(up(mdl._BeTBe), g["BeTBe_" + mode]) < t, mode
+        assert gc.frob(up(mdl._BeTBeChol), g["BeTBeChol_" + mode]) < t, mode
+        # what each convention means, from the model's own factors (w_user / w_main = 8, lam / w_main = 6)
+        B, C = np.asarray(mdl.B_, np.float64), np.asarray(mdl.C_, np.float64)
+        G = B[:, ki:].T @ B[:, ki:] + 6.0 * np.eye(k + km)
+        kq = ku + k + km
+        M = np.zeros((kq, kq)); M[ku:, ku:] = G; M[np.arange(ku), np.arange(ku)] += 6.0
+        weighted = M.copy(); weighted[:ku + k, :ku + k] += 8.0 * (C.T @ C)
+        unweighted = M.copy(); unweighted[:ku + k, :ku + k] += 1.0 * (C.T @ C)
+        expect = unweighted if mode == "cg" else weighted               # Q9
+        assert gc.frob(up(mdl._BeTBe), up(expect)) < (1e-5 if uf else 1e-12), mode
+    g = gc.load("g9_precompute_explicit", dtype)
+    mdl = CMF(k=k, lambda_=0.05, scale_lam=True, scale_lam_sideinfo=True, niter=2, use_cg=False, k_user=ku, k_item=ki,
+              k_main=km, w_user=0.5, w_item=2.0, use_float=uf, nthreads=1, precompute_for_predictions=True).fit(
+        (g["row"], g["col"], g["val"]), shape=(m, n), U=g["U"], I=g["II"], A0=g["A0"], B0=g["B0"])
+    assert gc.frob(mdl._B_plus_bias, g["B_plus_bias"]) < t
+    assert gc.frob(up(mdl._BtB), g["BtB"]) < t
+    assert gc.frob(mdl._TransBtBinvBt, g["TransBtBinvBt"]) < t
+    assert gc.frob(up(mdl._CtCw), g["CtCw"]) < t
+    assert gc.frob(mdl._TransCtCinvCt, g["TransCtCinvCt"]) < t
+    assert gc.frob(up(mdl._BeTBeChol), g["BeTBeChol"]) < t
+    # without side information and without biases: only BtB and TransBtBinvBt
+    mdl = CMF(k=k, lambda_=0.05, niter=1, user_bias=False, item_bias=False, use_float=uf, nthreads=1).fit(
+        (g["row"], g["col"], g["val"]), shape=(m, n), A0=g["A0"][:, ku:ku + k])
+    B = np.asarray(mdl.B_, np.float64)
+    assert gc.frob(mdl._BtB, B.T @ B) < (1e-5 if uf else 1e-12)
+    assert gc.frob(mdl._TransBtBinvBt, np.linalg.solve(B.T @ B + 0.05 * np.eye(k), B.T).T) < (1e-4 if uf else 1e-10)
+    assert mdl._B_plus_bias.size == 0 and mdl._BeTBeChol.size == 0
