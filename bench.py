@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
                          "MovieLens10M-shaped configs of BASELINE.json (single GPU, side measurements)")
     args = ap.parse_args()
@@ -98,6 +98,8 @@ def main():
     from cmfrec_amd.distributed import ShardedAls, GpuEngine
     if args.workload == "fit":
         return whole_fit(args)
+    if args.workload == "c4shard":
+        return c4_shard(args, local_rank)
     if args.workload != "c2":
         return side_workload(args, local_rank)
 
@@ -244,6 +246,41 @@ def whole_fit(args):
                       "seconds": [round(t, 3) for t in times], "best_s": round(min(times), 3),
                       "rows_per_s_whole_fit": round((m + n) * niter / min(times), 1),
                       "finite": bool(np.isfinite(model.A_).all() and np.isfinite(model.B_).all()),
+                      "note": "side measurement, not the headline metric"}))
+
+
+def c4_shard(args, device):
+    """One GPU's share of BASELINE config 4 (10M x 1M, nnz 5e8, k=64 fp32 on 8 GPUs): 1.25M users x 1M items,
+    62.5M nnz, implicit ALS-CG in single precision, as a single-GPU problem (no collectives): exercises the
+    fp32 kernels and the 64-bit offsets at production size.  Side measurement."""
+    from cmfrec_amd.session import AlsSession
+    m, n, nnz = int(1_250_000 * args.scale), int(1_000_000 * args.scale), int(62_500_000 * args.scale)
+    t0 = time.time()
+    row, col, val = synth_block(m, n, nnz, seed=4)
+    t_gen = time.time() - t0
+    k = 64
+    sess = AlsSession(m, n, k, implicit=True, dtype=np.float32, lam=5.0, use_cg=True, max_cg_steps=3, device=device)
+    t0 = time.time()
+    sess.set_X_coo(row, col, val.astype(np.float32))
+    t_setx = time.time() - t0
+    rng = np.random.default_rng(7)
+    sess.set_factors(A=(rng.random((m, k), dtype=np.float32) * 2.0 ** -7), B=np.zeros((n, k), np.float32))
+    for _ in range(args.warmup):
+        sess.iterate(1)
+    sess.sync(); sess.reset_timers()
+    t0 = time.perf_counter()
+    sess.iterate(args.steps)
+    sess.sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    msA, cA = sess.kernel_time("A"); msB, cB = sess.kernel_time("B")
+    f = sess.get_factors()
+    alg = algorithmic_bytes(nnz, m, k, 4) + algorithmic_bytes(nnz, n, k, 4)
+    print(json.dumps({"workload": "c4 shard (1/8 of 10M x 1M, nnz 5e8), implicit ALS-CG k=64 fp32, one GPU",
+                      "ms_per_iteration": round(dt * 1e3, 3), "rows_per_s": round((m + n) / dt, 1),
+                      "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "alg_GB": round(alg / 1e9, 2),
+                      "frac_of_hbm_peak": round(alg / dt / 8e12, 3), "m": m, "n": n, "nnz": nnz,
+                      "gen_seconds": round(t_gen, 1), "set_X_coo_seconds": round(t_setx, 2),
+                      "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
                       "note": "side measurement, not the headline metric"}))
 
 
