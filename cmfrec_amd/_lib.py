@@ -21,7 +21,7 @@ class Model(C.Structure):
         "implicit", "m", "n", "k", "k_main", "k_user", "k_item", "user_bias", "item_bias",
         "scale_lam", "scale_lam_sideinfo", "use_cg", "precondition_cg", "max_cg_steps",
         "p", "q", "m_u", "n_i")] + [("lam", C.c_double), ("w_user", C.c_double), ("w_item", C.c_double)] + \
-        [(n, C.c_int32) for n in ("row_begin", "row_end", "col_begin", "col_end")]
+        [(n, C.c_int32) for n in ("row_begin", "row_end", "col_begin", "col_end", "m_x", "n_x")]
 
 
 class ModelF(C.Structure):
@@ -29,7 +29,7 @@ class ModelF(C.Structure):
         "implicit", "m", "n", "k", "k_main", "k_user", "k_item", "user_bias", "item_bias",
         "scale_lam", "scale_lam_sideinfo", "use_cg", "precondition_cg", "max_cg_steps",
         "p", "q", "m_u", "n_i")] + [("lam", C.c_float), ("w_user", C.c_float), ("w_item", C.c_float)] + \
-        [(n, C.c_int32) for n in ("row_begin", "row_end", "col_begin", "col_end")]
+        [(n, C.c_int32) for n in ("row_begin", "row_end", "col_begin", "col_end", "m_x", "n_x")]
 
 
 EXPORTED = [
@@ -41,7 +41,7 @@ EXPORTED = [
     "cmfrec_hip_session_set_sideinfo", "cmfrec_hip_session_update", "cmfrec_hip_session_iterate",
     "cmfrec_hip_session_sync", "cmfrec_hip_session_device_ptr", "cmfrec_hip_session_stream",
     "cmfrec_hip_session_after_gather", "cmfrec_hip_session_kernel_time",
-    "cmfrec_hip_session_reset_timers", "cmfrec_hip_session_bin_stats", "cmfrec_hip_sizeof_real", "cmfrec_hip_build_info", "cmfrec_hip_selftest_lanes", "cmfrec_hip_random_parallel",
+    "cmfrec_hip_session_reset_timers", "cmfrec_hip_session_bin_stats", "cmfrec_hip_sizeof_real", "cmfrec_hip_sizeof_model", "cmfrec_hip_build_info", "cmfrec_hip_selftest_lanes", "cmfrec_hip_random_parallel",
 ]
 
 _cache = {}
@@ -71,6 +71,10 @@ def load(dtype=np.float64):
     lib.cmfrec_hip_session_device_ptr.restype = C.c_void_p
     lib.cmfrec_hip_session_stream.restype = C.c_void_p
     assert lib.cmfrec_hip_sizeof_real() == np.dtype(dtype).itemsize
+    mirror = Model if dtype is np.float64 else ModelF
+    if lib.cmfrec_hip_sizeof_model() != C.sizeof(mirror):
+        raise RuntimeError("cmfrec_amd: the ctypes mirror of cmfrec_hip_model (%d bytes) does not match the library (%d)"
+                           % (C.sizeof(mirror), lib.cmfrec_hip_sizeof_model()))
     _cache[dtype] = lib
     return lib
 

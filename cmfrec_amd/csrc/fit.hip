@@ -7,6 +7,7 @@
 // and the bias initialisation (common.c:4410-4909) run on the device (coo_device.hpp); the ALS loop
 // order C -> D -> B -> A, which runs on the device-resident session (session.hip).  Every
 // temporary is allocated and freed here; outputs are caller-allocated (cmfrec.h.in:240-241).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <csignal>
@@ -123,7 +124,6 @@ int_t fit_collective_implicit_als(
         return fail(verbose, "cmfrec_hip: sparse side information is not implemented.");
     if (U == nullptr) { m_u = 0; p = 0; }
     if (II == nullptr) { n_i = 0; q = 0; }
-    if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
     for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
     for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
     if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight)
@@ -160,11 +160,12 @@ int_t fit_collective_implicit_als(
     if (II) center_cols(II, n_i, q, I_colmeans, Ic);
 
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
+    const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);     // rows of A / B (collective.c:9437-9440)
     if (reset_values) {                                                  // :9750-9774
         const bool fill_B = (II != nullptr);
-        cmfrng::random_parallel<real_t>(A, (size_t)m * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n * k_totB : 0, seed, false);
+        cmfrng::random_parallel<real_t>(A, (size_t)m_max * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n_max * k_totB : 0, seed, false);
         if (use_cg) {
-            if (!fill_B) memset(B, 0, (size_t)n * k_totB * sizeof(real_t));
+            if (!fill_B) memset(B, 0, (size_t)n_max * k_totB * sizeof(real_t));
             if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
             if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
         }
@@ -175,10 +176,11 @@ int_t fit_collective_implicit_als(
 
     cmfrec_hip_model mdl;
     memset(&mdl, 0, sizeof mdl);
-    mdl.implicit = 1; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
+    mdl.implicit = 1; mdl.m = m_max; mdl.n = n_max; mdl.m_x = m; mdl.n_x = n;
+    mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
     mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.lam = lam;
     mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i; mdl.w_user = w_user; mdl.w_item = w_item;
-    mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
+    mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
     tm.lap("session create");
@@ -202,7 +204,7 @@ int_t fit_collective_implicit_als(
     if ((rc_loop == 0 || rc_loop == 3) && precompute_for_predictions) {   // collective.c:10056-10115 (also after an interrupt, :10034-10043)
         if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }
         const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
-        int rc2 = cmfrec_hip_session_precompute(s, last_chol, precomputedBtB, nullptr, U ? precomputedBeTBe : nullptr,
+        int rc2 = cmfrec_hip_session_precompute(s, last_chol, 0, precomputedBtB, nullptr, U ? precomputedBeTBe : nullptr,
                                                 U ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
         if (rc2) rc_loop = rc2;
         if (verbose) printf("  done\n");
@@ -233,7 +235,7 @@ int_t fit_collective_explicit_als(
 {
     (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB; (void)U_row; (void)U_col; (void)I_row; (void)I_col;
     (void)NA_as_zero_U; (void)NA_as_zero_I; (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
-    (void)nonneg_C; (void)nonneg_D; (void)include_all_X;      // n_max == n here (n_i <= n), so include_all_X changes nothing
+    (void)nonneg_C; (void)nonneg_D;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // only with add_implicit_features, not supported
     (void)precomputedCtUbias;      // only with sparse U + NA_as_zero_U, not supported
@@ -249,7 +251,6 @@ int_t fit_collective_explicit_als(
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (U == nullptr) { m_u = 0; p = 0; }
     if (II == nullptr) { n_i = 0; q = 0; }
-    if (m_u > m || n_i > n) return fail(verbose, "cmfrec_hip: side information with more rows than X is not implemented.");
     if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
@@ -262,6 +263,7 @@ int_t fit_collective_explicit_als(
     if (w_main != (real_t)1) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   // :7497-7521
     const bool has_bias = user_bias || item_bias;
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
+    const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);      // rows of A / B (collective.c:7332-7335)
 
     // ---- global mean, common.c:3494-3524 + :3603 (nthreads selects running mean vs sum/cnt); the
     //      subtraction itself happens on the device while the CSR / CSC are built ----
@@ -299,9 +301,9 @@ int_t fit_collective_explicit_als(
     // ---- factor start values, collective.c:8241-8274 ----
     if (reset_values) {
         const bool fill_B = (II != nullptr);
-        cmfrng::random_parallel<real_t>(A, (size_t)m * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n * k_totB : 0, seed, true);
+        cmfrng::random_parallel<real_t>(A, (size_t)m_max * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n_max * k_totB : 0, seed, true);
         if (use_cg) {
-            if (!fill_B) memset(B, 0, (size_t)n * k_totB * sizeof(real_t));
+            if (!fill_B) memset(B, 0, (size_t)n_max * k_totB * sizeof(real_t));
             if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
             if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
         }
@@ -309,11 +311,12 @@ int_t fit_collective_explicit_als(
 
     cmfrec_hip_model mdl;
     memset(&mdl, 0, sizeof mdl);
-    mdl.implicit = 0; mdl.m = m; mdl.n = n; mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
+    mdl.implicit = 0; mdl.m = m_max; mdl.n = n_max; mdl.m_x = m; mdl.n_x = n;
+    mdl.k = k; mdl.k_main = k_main; mdl.k_user = k_user; mdl.k_item = k_item;
     mdl.user_bias = user_bias; mdl.item_bias = item_bias; mdl.scale_lam = scale_lam; mdl.scale_lam_sideinfo = scale_lam_sideinfo;
     mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i;
     mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
-    mdl.row_begin = 0; mdl.row_end = m; mdl.col_begin = 0; mdl.col_end = n;
+    mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
     tm.lap("start values + session");
@@ -340,15 +343,19 @@ int_t fit_collective_explicit_als(
         int rc2 = cmfrec_hip_session_get_factors(s, A, B, biasA, biasB, C, D);
         if (rc2) rc_loop = rc2;
     }
+    if (rc_loop == 0 || rc_loop == 3) {                                   // no bias beyond the shape of X (collective.c:8296, :8923-8925)
+        if (user_bias) for (int_t r = m; r < m_max; r++) biasA[r] = 0;
+        if (item_bias) for (int_t c = n; c < n_max; c++) biasB[c] = 0;
+    }
     if ((rc_loop == 0 || rc_loop == 3) && precompute_for_predictions) {   // collective.c:8936-9249
         if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }
         const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
-        int rc2 = cmfrec_hip_session_precompute(s, last_chol, precomputedBtB, precomputedTransBtBinvBt, nullptr,
+        int rc2 = cmfrec_hip_session_precompute(s, last_chol, include_all_X ? 1 : 0, precomputedBtB, precomputedTransBtBinvBt, nullptr,
                                                 U ? precomputedBeTBeChol : nullptr, U ? precomputedCtCw : nullptr,
                                                 U ? precomputedTransCtCinvCt : nullptr);
         if (rc2) rc_loop = rc2;
         if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
-            for (int_t c = 0; c < n; c++) {
+            for (int_t c = 0; c < n_max; c++) {
                 memcpy(B_plus_bias + (size_t)c * (k_totB + 1), B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));
                 B_plus_bias[(size_t)c * (k_totB + 1) + k_totB] = 1;
             }

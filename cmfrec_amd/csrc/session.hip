@@ -155,6 +155,7 @@ static int guarded(const std::function<int()> &f)
 extern "C" {
 
 int cmfrec_hip_sizeof_real(void) { return (int)sizeof(real_t); }
+int cmfrec_hip_sizeof_model(void) { return (int)sizeof(cmfrec_hip_model); }
 const char *cmfrec_hip_build_info(void)
 {
 #ifdef CMFREC_HIP_FLOAT
@@ -183,8 +184,8 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
             g_last_error = "cmfrec_hip: k_user / k_item need side information";
             return 2;
         }
-        if ((m.p > 0 && m.m_u > m.m) || (m.q > 0 && m.n_i > m.n)) {
-            g_last_error = "cmfrec_hip: side information with more rows than X is not supported";
+        if ((m.p > 0 && m.m_u > m.m) || (m.q > 0 && m.n_i > m.n) || m.m_x > m.m || m.n_x > m.n) {
+            g_last_error = "cmfrec_hip: m / n must be the rows of A / B: max(m_x, m_u) and max(n_x, n_i)";
             return 2;
         }
         s = new cmfrec_hip_session();
@@ -396,6 +397,32 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
 }
 
 // ---- one half-step of the ALS loop on the local block -------------------------------------
+// Explicit model: rows that exist only in the side information (beyond the shape of X) are fitted to it alone,
+//   a[:kc] = (C^T C + (lam / w) (p if scale_lam) I)^-1 C^T u     (optimizeA Case 1 on U[m_x:], collective.c:4967-5101)
+// their remaining unknowns are zero under Cholesky (A was zeroed) and left alone under CG.
+static int solve_sideinfo_only_rows(cmfrec_hip_session *s, bool isA, bool chol, int first, int count)
+{
+    if (count <= 0) return 0;
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    real_t *self = isA ? s->A.ptr : s->B.ptr;
+    const size_t ld_self = isA ? s->ldA : s->ldB;
+    const int begin = isA ? m.row_begin : m.col_begin;
+    const int p_self = isA ? m.p : m.q, kc = (isA ? m.k_user : m.k_item) + m.k;
+    const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+    const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+    const real_t w = isA ? m.w_user : m.w_item;
+    const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;                                    // :7465
+    real_t *rows = self + (size_t)(begin + first) * ld_self;
+    if (chol) HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)count * ld_self * sizeof(real_t), dev.stream));
+    launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->betbe.ptr, (real_t)1,
+                (m.lam / w) * (real_t)(scale_lam ? p_self : 1));                                   // common.c:2824-2832
+    launch_gemm<false>(dev, count, kc, p_self, (real_t)1, Um + (size_t)(begin + first) * p_self, (size_t)p_self, Cm,
+                       (size_t)kc, rows, ld_self);                                                 // common.c:2847-2855
+    CholCall c{rows, ld_self, nullptr, 0, kc, 0, nullptr, s->betbe.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+    return launch_chol(dev, c, nullptr, count);                                                    // common.c:2872-2875
+}
+
 static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
 {
     const cmfrec_hip_model &m = s->mdl;
@@ -405,7 +432,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
     real_t *self = isA ? s->A.ptr : s->B.ptr;
     real_t *opp = isA ? s->B.ptr : s->A.ptr;
     const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
-    const int rows_opp = isA ? m.n : m.m;
+    const int rows_opp = isA ? (m.n_x > 0 ? m.n_x : m.n) : (m.m_x > 0 ? m.m_x : m.m);   // rows of the opposing matrix that X refers to (the Gramian's rows)
     const int k_side_self = isA ? m.k_user : m.k_item, k_side_opp = isA ? m.k_item : m.k_user;
     const int begin = isA ? m.row_begin : m.col_begin;
     const SparseShard &X = isA ? s->Xr : s->Xc;
@@ -414,6 +441,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
     const int p_self = isA ? m.p : m.q;
     real_t *self_blk = self + (size_t)begin * ld_self;
     const int kk = m.k + m.k_main;
+    const int rows_x_self = isA ? (m.m_x > 0 ? m.m_x : m.m) : (m.n_x > 0 ? m.n_x : m.n);          // rows of this matrix X has
 
     if (p_self > 0 && !chol) {
         // block CG on the collective system, dense full side information: collective_block_cg (explicit,
@@ -445,9 +473,14 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
         CgCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kx, bias_sub_cg, m.implicit ? s->gram.ptr : nullptr,
                  m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
                  (bool)m.precondition_cg};
-        c.koff = k_side_self; c.kc = kc; c.CtC = s->ctc.ptr; c.UC = uc; c.w_side = w; c.rows_with_u = local_u;
+        // explicit model: rows beyond X are not part of the block system (solve_sideinfo_only_rows)
+        const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
+        const int local_u_main = m.implicit ? local_u : std::min(local_u, local_x);
+        c.koff = k_side_self; c.kc = kc; c.CtC = s->ctc.ptr; c.UC = uc; c.w_side = w; c.rows_with_u = local_u_main;
         c.p_side = p_self; c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo;
-        return launch_cg(dev, c, X, nullptr);
+        int rc = launch_cg(dev, c, X, nullptr);
+        if (rc) return rc;
+        return solve_sideinfo_only_rows(s, isA, false, local_u_main, local_u - local_u_main);
     }
     if (m.implicit && p_self > 0) {
         // optimizeA_collective_implicit, Cholesky, dense full side information (collective.c:5971-6244)
@@ -505,10 +538,14 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
         const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
         launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
                            self_blk, ld_self);                                                      // :5768-5773
-        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, s->ctc.ptr, kc, local_u,
+        const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
+        const int local_u_main = std::min(local_u, local_x);              // rows beyond X: solve_sideinfo_only_rows
+        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, s->ctc.ptr, kc, local_u_main,
                    p_self, m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false,
                    CHOL_COLLECTIVE};
-        return launch_chol(dev, c, &X);
+        int rc = launch_chol(dev, c, &X);
+        if (rc) return rc;
+        return solve_sideinfo_only_rows(s, isA, true, local_u_main, local_u - local_u_main);
     }
     const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;                                     // :7465
     if (chol) {
@@ -554,12 +591,15 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC)
 //     BeTBeChol = chol(blockdiag(0, BtB) + CtCw + lam mult I),  mult = p + n | n | 1
 // Host output buffers, NULL = skip; square matrices are complete (both triangles) except the Cholesky factors
 // (upper triangle R, M = R^T R; the strict lower triangle holds the lower triangle of M).
-int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky, real_t *BtB, real_t *TransBtBinvBt,
-                                  real_t *BeTBe, real_t *BeTBeChol, real_t *CtCw, real_t *TransCtCinvCt)
+int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky, int include_all_X, real_t *BtB,
+                                  real_t *TransBtBinvBt, real_t *BeTBe, real_t *BeTBeChol, real_t *CtCw,
+                                  real_t *TransCtCinvCt)
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
-        const cmfrec_hip_model &m = s->mdl;
+        cmfrec_hip_model m = s->mdl;
+        // rows of B that enter: n_max with include_all_X (explicit model only), else the columns of X (collective.c:9013-9016)
+        if (!(include_all_X && !m.implicit) && m.n_x > 0) m.n = m.n_x;
         const DeviceInfo &dev = s->dev;
         hipStream_t st = dev.stream;
         const int kk = m.k + m.k_main, ub = (!m.implicit && m.user_bias) ? 1 : 0;

@@ -84,12 +84,10 @@ class CMF_implicit(_Base):
         Ic = None if I is None else np.ascontiguousarray(I, dt)
         m_u, p = (0, 0) if Uc is None else Uc.shape
         n_i, q = (0, 0) if Ic is None else Ic.shape
-        if m_u > m or n_i > n:
-            raise NotImplementedError("side information with more rows than X is not implemented in cmfrec_amd")
         ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
         reset = A0 is None
-        A = np.empty((m, ka), dt) if reset else np.array(A0, dt, order="C", copy=True)
-        B = np.empty((n, kb), dt) if (reset or B0 is None) else np.array(B0, dt, order="C", copy=True)
+        A = np.empty((max(m, m_u), ka), dt) if reset else np.array(A0, dt, order="C", copy=True)     # m_max rows
+        B = np.empty((max(n, n_i), kb), dt) if (reset or B0 is None) else np.array(B0, dt, order="C", copy=True)
         if not reset and B0 is None:
             B[:] = 0
         Cm = np.zeros((p, self.k_user + self.k), dt) if p else None

@@ -13,7 +13,7 @@ class AlsSession:
     def __init__(self, m, n, k, implicit, dtype=np.float64, lam=1.0, use_cg=True, max_cg_steps=3,
                  k_main=0, k_user=0, k_item=0, user_bias=False, item_bias=False, scale_lam=False,
                  scale_lam_sideinfo=False, p=0, q=0, m_u=0, n_i=0, w_user=1.0, w_item=1.0,
-                 row_range=None, col_range=None, device=-1, precondition_cg=False):
+                 row_range=None, col_range=None, device=-1, precondition_cg=False, m_x=0, n_x=0):
         self.dtype = np.dtype(dtype).type
         self.lib = _lib.load(self.dtype)
         M = _lib.Model if self.dtype is np.float64 else _lib.ModelF
@@ -23,7 +23,7 @@ class AlsSession:
                        user_bias=int(user_bias), item_bias=int(item_bias), scale_lam=int(scale_lam),
                        scale_lam_sideinfo=int(scale_lam_sideinfo), use_cg=int(use_cg), precondition_cg=int(precondition_cg),
                        max_cg_steps=max_cg_steps, p=p, q=q, m_u=m_u, n_i=n_i, lam=lam, w_user=w_user,
-                       w_item=w_item, row_begin=rb, row_end=re, col_begin=cb, col_end=ce)
+                       w_item=w_item, row_begin=rb, row_end=re, col_begin=cb, col_end=ce, m_x=m_x, n_x=n_x)
         self.m, self.n, self.k = m, n, k
         self.k_totA = k_user + k + k_main
         self.k_totB = k_item + k + k_main

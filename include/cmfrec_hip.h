@@ -41,8 +41,8 @@ extern "C" {
 
 /* Replaces fit_collective_implicit_als, /root/reference/src/cmfrec.h:1893-1921 (body
  * src/collective.c:9375-10207; documented in include/cmfrec.h.in:927-959).
- * Supported: CG / PCG / Cholesky, optionally with DENSE side information U[m_u<=m, p] / II[n_i<=n, q]
- * without NaN (k_user, k_item, k_main, w_main, w_user, w_item as the reference): Cholesky
+ * Supported: CG / PCG / Cholesky, optionally with DENSE side information U[m_u, p] / II[n_i, q] without NaN
+ * (m_u, n_i may exceed m, n: A, B then have max(m, m_u) / max(n, n_i) rows, src/collective.c:9437-9440) (k_user, k_item, k_main, w_main, w_user, w_item as the reference): Cholesky
  * (optimizeA_collective_implicit, src/collective.c:5971-6244) or block CG / PCG
  * (collective_block_cg_implicit, :2905-3303).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight,
  * no precompute.
@@ -78,7 +78,8 @@ int_t fit_collective_implicit_als(
 /* Replaces fit_collective_explicit_als, /root/reference/src/cmfrec.h:1851-1892 (body
  * src/collective.c:7263-9370; include/cmfrec.h.in:885-926).
  * Supported in this round: sparse X with missing-as-NA, no weights, biases/centering/scale_lam,
- * CG / PCG or Cholesky, optional DENSE side information U[m_u<=m, p] / II[n_i<=n, q] without NaN
+ * CG / PCG or Cholesky, optional DENSE side information U[m_u, p] / II[n_i, q] without NaN (m_u, n_i may exceed
+ * m, n: rows known from side information only are fitted to it alone and get a zero bias, :4967-5101, :8296)
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
  * k_main/k_user/k_item, w_user/w_item.  Anything else returns 2. */
 int_t fit_collective_explicit_als(
@@ -182,6 +183,10 @@ typedef struct cmfrec_hip_model {
     real_t lam, w_user, w_item;
     /* row-block shard owned by this process (single GPU: [0,m) and [0,n)) */
     int32_t row_begin, row_end, col_begin, col_end;
+    /* m, n are the rows of A and B.  Side information may describe more users / items than X has rows / columns
+     * (m_u > m_x: the reference's m_max = max(m, m_u), src/collective.c:7332-7335): then m_x / n_x give the shape
+     * of X; 0 = same as m / n.  Rows beyond m_x are solved from their side information alone. */
+    int32_t m_x, n_x;
 } cmfrec_hip_model;
 
 /* device < 0: use the current HIP device. Returns NULL on failure (see cmfrec_hip_last_error). */
@@ -239,12 +244,14 @@ int cmfrec_hip_session_after_gather(cmfrec_hip_session *s, int which);
  * kc = k_user + k, kq = k_user + kp:  BtB[kp, kp] (implicit: + lam I);  explicit only: TransBtBinvBt[n, kp],
  * TransCtCinvCt[p, kc];  with user side information: CtCw[kc, kc] (explicit), BeTBe[kq, kq] (implicit),
  * BeTBeChol[kq, kq] (upper triangle = the factor R, M = R^T R).
+ * include_all_X (explicit model): use all max(n, n_i) rows of B, else the n columns X has (collective.c:9013).
  * last_step_cholesky: whether the last iteration of the fit used the Cholesky solver (use_cg=false or
  * finalize_chol).  It only matters for quirk Q9 of the reference, which this library reproduces: in the implicit
  * model with user side information, after a CG last step, BeTBe / BeTBeChol carry the UNWEIGHTED C^T C when
  * w_user != 1 (src/collective.c:10077 tests `w_user == 1.` where `!=` was meant); see DESIGN.md, Parity. */
-int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky, real_t *BtB, real_t *TransBtBinvBt,
-                                  real_t *BeTBe, real_t *BeTBeChol, real_t *CtCw, real_t *TransCtCinvCt);
+int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky, int include_all_X, real_t *BtB,
+                                  real_t *TransBtBinvBt, real_t *BeTBe, real_t *BeTBeChol, real_t *CtCw,
+                                  real_t *TransCtCinvCt);
 
 /* HIP-event time (ms) and launch count of the row-update kernels of `which` ('A' or 'B') since
  * the last reset; synchronises the stream. */
@@ -271,6 +278,8 @@ int cmfrec_hip_random_parallel(real_t *A, size_t sizeA, real_t *B, size_t sizeB,
 
 /* Build info: sizeof(real_t), and the gfx target the kernels were compiled for. */
 int cmfrec_hip_sizeof_real(void);
+/* sizeof(cmfrec_hip_model) as compiled: lets a binding verify its mirror of the struct before the first call. */
+int cmfrec_hip_sizeof_model(void);
 const char *cmfrec_hip_build_info(void);
 
 #ifdef __cplusplus

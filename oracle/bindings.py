@@ -165,8 +165,8 @@ class Oracle:
     def fit_implicit_als_sideinfo(self, A, B, row, col, val, k, Cm=None, Dm=None, U=None, II=None, lam=1.0,
                                   alpha=1.0, apply_log_transf=False, k_main=0, k_user=0, k_item=0, w_main=1.0,
                                   w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=False, max_cg_steps=3,
-                                  precondition_cg=False, finalize_chol=False):
-        m = A.shape[0]; n = B.shape[0]
+                                  precondition_cg=False, finalize_chol=False, m=None, n=None):
+        m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         m_u, p = (0, 0) if U is None else U.shape
@@ -189,12 +189,12 @@ class Oracle:
                          U=None, II=None, user_bias=True, item_bias=True, center=True, lam=10.0,
                          scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,
                          w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=True, max_cg_steps=3,
-                         precondition_cg=False, finalize_chol=True, init_biases=False):
-        m = A.shape[0]; n = B.shape[0]
+                         precondition_cg=False, finalize_chol=True, init_biases=False, m=None, n=None):
+        m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
-        biasA = np.zeros(m, self.dtype) if biasA is None else biasA
-        biasB = np.zeros(n, self.dtype) if biasB is None else biasB
+        biasA = np.zeros(A.shape[0], self.dtype) if biasA is None else biasA
+        biasB = np.zeros(B.shape[0], self.dtype) if biasB is None else biasB
         glob_mean = np.zeros(1, self.dtype)
         m_u, p = (0, 0) if U is None else U.shape
         n_i, q = (0, 0) if II is None else II.shape
@@ -360,8 +360,8 @@ class Reference:
                                     finalize_chol=False, reset_values=False, seed=1,
                                     apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
-                                    precompute=False):
-        m = A.shape[0]; n = B.shape[0]
+                                    precompute=False, m=None, n=None):
+        m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         wmm = np.zeros(1, self.dtype)
@@ -398,12 +398,12 @@ class Reference:
                                     center=True, lam=10.0, scale_lam=False, scale_lam_sideinfo=False,
                                     k_main=0, k_user=0, k_item=0, w_user=1.0, w_item=1.0, niter=10,
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
-                                    finalize_chol=True, reset_values=False, seed=1, precompute=False):
-        m = A.shape[0]; n = B.shape[0]
+                                    finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None):
+        m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
-        biasA = np.zeros(m, self.dtype) if biasA is None else biasA
-        biasB = np.zeros(n, self.dtype) if biasB is None else biasB
+        biasA = np.zeros(A.shape[0], self.dtype) if biasA is None else biasA
+        biasB = np.zeros(B.shape[0], self.dtype) if biasB is None else biasB
         glob_mean = np.zeros(1, self.dtype)
         m_u, p = (0, 0) if U is None else U.shape
         n_i, q = (0, 0) if II is None else II.shape

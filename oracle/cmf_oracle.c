@@ -801,7 +801,11 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
 {
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
-    if (m_u > m || n_i > n) return 2;
+    /* side information may cover more users / items than X: A, B have max(m, m_u) / max(n, n_i) rows
+     * (collective.c:9437-9440); X is padded with empty rows / columns, the Gramians keep X's own shape */
+    const int_t m_x = m, n_x = n;
+    if (m_u > m) m = m_u;
+    if (n_i > n) n = n_i;
     int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
     real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
     memcpy(Xc, X, nnz * sizeof(real_t));
@@ -827,26 +831,26 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B, (size_t)k_totB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, false, nthreads);
         if (II != NULL && use_cg)                                                 /* :9924-9963 */
-            oracle_optimizeA_collective_cg(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m, q, k, k_main, k_item, k_user,
+            oracle_optimizeA_collective_cg(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m_x, q, k, k_main, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lam, w_item, lam, false, false, true,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (II != NULL)
-            oracle_optimizeA_collective_implicit_chol(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m, q,
+            oracle_optimizeA_collective_implicit_chol(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m_x, q,
                                                       k, k_main, k_item, k_user, csc_p, csc_i, csc_v,
                                                       Ic, lam, w_item, nthreads);
         else                                                                      /* :9965-9981 */
-            oracle_optimizeA_implicit(B + k_item, (size_t)k_totB, A + k_user, (size_t)k_totA, n, m, k + k_main,
+            oracle_optimizeA_implicit(B + k_item, (size_t)k_totB, A + k_user, (size_t)k_totA, n, m_x, k + k_main,
                                       csc_p, csc_i, csc_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
         if (U != NULL && use_cg)                                                  /* :9985-10022 */
-            oracle_optimizeA_collective_cg(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n, p, k, k_main, k_user, k_item,
+            oracle_optimizeA_collective_cg(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n_x, p, k, k_main, k_user, k_item,
                                            csr_p, csr_i, csr_v, Uc, lam, w_user, lam, false, false, true,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (U != NULL)
-            oracle_optimizeA_collective_implicit_chol(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n, p,
+            oracle_optimizeA_collective_implicit_chol(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n_x, p,
                                                       k, k_main, k_user, k_item, csr_p, csr_i, csr_v,
                                                       Uc, lam, w_user, nthreads);
         else
-            oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n, k + k_main,
+            oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n_x, k + k_main,
                                       csr_p, csr_i, csr_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
     }
     free(Uc); free(Ic);
@@ -884,7 +888,12 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
-    if (m_u > m || n_i > n) return 2;          /* restatement restricted (see header) */
+    /* side information may cover more users / items than X: A, B have max(m, m_u) / max(n, n_i) rows
+     * (collective.c:7332-7335); X is padded with empty rows / columns.  The rows beyond X are fitted to their
+     * side information alone by a separate dense solve (optimizeA Case 1, collective.c:4967-5101). */
+    const int_t m_x = m, n_x = n;
+    if (m_u > m) m = m_u;
+    if (n_i > n) n = n_i;
     if (init_biases && (user_bias != item_bias)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     if (!use_cg) finalize_chol = false;                                        /* :7481 */
@@ -939,11 +948,11 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
         if (user_bias)                                                         /* :8566-8570 */
             for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
         if (II != NULL && use_cg)                                              /* :8634-8678 */
-            oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
+            oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lam, w_item, lam, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (II != NULL)
-            oracle_optimizeA_collective_chol(B_bias, ldB, A_bias, ldA, D, n, n_i, m, q,
+            oracle_optimizeA_collective_chol(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q,
                                              k, k_main + (int_t)item_bias, k_item, k_user,
                                              csc_p, csc_i, csc_v, Ic, lam, w_item, lam,
                                              scale_lam, scale_lam_sideinfo, nthreads);
@@ -952,6 +961,15 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
                                       k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
                                       lam, lam, scale_lam, false, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
+        if (II != NULL) {
+        if (n_i > n_x) {                                            /* rows known from side information only */
+            if (!use_cg)
+                for (int_t r = n_x; r < n_i; r++) memset(B_bias + (size_t)r * ldB, 0, (size_t)(k_totB + has_bias) * sizeof(real_t));
+            oracle_optimizeA_dense_full(B_bias + (size_t)n_x * ldB, ldB, D, (size_t)(k_item + k), n_i - n_x, q,
+                                        k_item + k, Ic + (size_t)n_x * q, (size_t)q, false, lam / w_item, lam / w_item,
+                                        scale_lam, nthreads);
+        }
+        }
         if (item_bias)                                                         /* :8723-8725 */
             for (int_t c = 0; c < n; c++) biasB[c] = B_bias[(size_t)c * ldB + k_totB];
         if (user_bias)                                                         /* :8728-8732 */
@@ -959,11 +977,11 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
         if (item_bias)                                                         /* :8750-8754 */
             for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
         if (U != NULL && use_cg)                                               /* :8805-8845 */
-            oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
+            oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                            csr_p, csr_i, csr_v, Uc, lam, w_user, lam, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (U != NULL)
-            oracle_optimizeA_collective_chol(A_bias, ldA, B_bias, ldB, C, m, m_u, n, p,
+            oracle_optimizeA_collective_chol(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p,
                                              k, k_main + (int_t)user_bias, k_user, k_item,
                                              csr_p, csr_i, csr_v, Uc, lam, w_user, lam,
                                              scale_lam, scale_lam_sideinfo, nthreads);
@@ -972,6 +990,15 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
                                       k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
                                       lam, lam, scale_lam, false, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
+        if (U != NULL) {
+        if (m_u > m_x) {                                            /* rows known from side information only */
+            if (!use_cg)
+                for (int_t r = m_x; r < m_u; r++) memset(A_bias + (size_t)r * ldA, 0, (size_t)(k_totA + has_bias) * sizeof(real_t));
+            oracle_optimizeA_dense_full(A_bias + (size_t)m_x * ldA, ldA, C, (size_t)(k_user + k), m_u - m_x, p,
+                                        k_user + k, Uc + (size_t)m_x * p, (size_t)p, false, lam / w_user, lam / w_user,
+                                        scale_lam, nthreads);
+        }
+        }
         if (user_bias)                                                         /* :8882-8884 */
             for (int_t r = 0; r < m; r++) biasA[r] = A_bias[(size_t)r * ldA + k_totA];
     }
@@ -982,6 +1009,8 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
             memcpy(B + (size_t)c * k_totB, B_bias + (size_t)c * ldB, (size_t)k_totB * sizeof(real_t));
         free(A_bias); free(B_bias);
     }
+    if (user_bias) for (int_t r = m_x; r < m; r++) biasA[r] = 0;                /* :8296, :8923: no bias beyond X */
+    if (item_bias) for (int_t c = n_x; c < n; c++) biasB[c] = 0;                /* :8308, :8925 */
     free(csr_orig); free(csc_orig); free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;

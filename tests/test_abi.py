@@ -34,8 +34,12 @@ def test_exports(dtype):
 
 def test_model_struct_layout():
     from cmfrec_amd import _lib
-    assert C.sizeof(_lib.Model) == 18 * 4 + 3 * 8 + 4 * 4
-    assert C.sizeof(_lib.ModelF) == 18 * 4 + 3 * 4 + 4 * 4
+    # 18 int32 + lam, w_user, w_item + row/col ranges (4) + m_x, n_x; and the compiled struct says the same
+    assert C.sizeof(_lib.Model) == 18 * 4 + 3 * 8 + 6 * 4
+    assert C.sizeof(_lib.ModelF) == 18 * 4 + 3 * 4 + 6 * 4
+    for dt, mirror in ((np.float64, _lib.Model), (np.float32, _lib.ModelF)):
+        lib = C.CDLL(_lib.lib_path(dt))
+        assert lib.cmfrec_hip_sizeof_model() == C.sizeof(mirror)
 
 
 def test_no_cpu_fallback():

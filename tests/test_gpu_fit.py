@@ -161,6 +161,43 @@ def test_fit_sideinfo_block_cg(oracles, dtype, implicit, pcg, ku, ki, km, m_u, f
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("implicit", [False, True])
+@pytest.mark.parametrize("cg,ku,ki,km", [(False, 0, 0, 0), (False, 2, 3, 1), (True, 1, 0, 2)])
+def test_fit_sideinfo_beyond_X(oracles, dtype, implicit, cg, ku, ki, km):
+    """m_u > m and n_i > n: users / items known only from their side information (collective.c:4832-5101,
+    6037-6090): factor matrices with max(m, m_u) / max(n, n_i) rows, zero biases beyond X."""
+    from cmfrec_amd import CMF, CMF_implicit
+    O = oracles[dtype]
+    m, n, k, p, q, m_u, n_i = 500, 320, 24, 12, 9, 540, 350
+    row, col, val = make_coo(m, n, 12000, 33, counts=implicit, dtype=dtype, empty_rows=(3, 480))
+    rng = np.random.default_rng(8)
+    U = (rng.standard_normal((m_u, p)) + 1).astype(dtype); II = (rng.standard_normal((n_i, q)) - 2).astype(dtype)
+    A0 = (rng.standard_normal((m_u, ku + k + km)) * 0.01).astype(dtype)
+    B0 = (rng.standard_normal((n_i, ki + k + km)) * 0.01).astype(dtype)
+    Ao, Bo = A0.copy(), B0.copy()
+    if implicit:
+        kw = dict(niter=3, use_cg=cg, k_user=ku, k_item=ki, k_main=km, w_main=0.5, w_user=4.0, w_item=0.8, alpha=2.0)
+        mdl = CMF_implicit(k=k, lambda_=3.0, use_float=dtype is np.float32, **kw).fit(
+            (row, col, val), shape=(m, n), U=U, I=II, A0=A0, B0=B0)
+        ro = O.fit_implicit_als_sideinfo(Ao, Bo, row, col, val, k, lam=3.0, U=U, II=II, nthreads=1, m=m, n=n, **kw)
+    else:
+        kw = dict(niter=3, use_cg=cg, finalize_chol=False, k_user=ku, k_item=ki, k_main=km, w_user=0.5, w_item=2.0,
+                  scale_lam=True, scale_lam_sideinfo=ku > 0)
+        mdl = CMF(k=k, lambda_=0.05, use_float=dtype is np.float32, nthreads=1, **kw).fit(
+            (row, col, val), shape=(m, n), U=U, I=II, A0=A0, B0=B0)
+        ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, lam=0.05, U=U, II=II, nthreads=1, m=m, n=n, **kw)
+    t = tol(dtype, "cg" if cg else "chol")
+    assert ro["ret"] == 0
+    assert mdl.A_.shape[0] == m_u and mdl.B_.shape[0] == n_i
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    assert frob(mdl.A_[m:], Ao[m:]) < t and frob(mdl.B_[n:], Bo[n:]) < t              # the rows beyond X on their own
+    assert frob(mdl.C_, ro["C"]) < t and frob(mdl.D_, ro["D"]) < t
+    if not implicit:
+        assert frob(mdl.user_bias_, ro["biasA"]) < t and frob(mdl.item_bias_, ro["biasB"]) < t
+        assert not mdl.user_bias_[m:].any() and not mdl.item_bias_[n:].any()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_seeded_fit_matches_reference_seed(dtype):
     """reset_values=true: the start values come from the seed exactly as in the reference
     (xoshiro256++ / ziggurat, helpers.c:927-1043), so a seeded fit() reproduces the reference's own

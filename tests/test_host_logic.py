@@ -30,7 +30,7 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         CMF_implicit(l1_lambda=0.1)
     with pytest.raises(NotImplementedError):
-        CMF_implicit().fit((np.array([0]), np.array([0]), np.ones(1)), U=np.ones((3, 2)), shape=(1, 1))   # m_u > m
+        CMF_implicit(nonneg=True)
 
 
 def test_coo_input_handling():

@@ -138,3 +138,42 @@ def test_fit_block_cg_live(oracles, refs, dtype, pcg):
                                 Dm=cp(D0), **kw)
         assert r1["ret"] == 0 and r2["ret"] == 0
         assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol and rel_err(r2["biasA"], r1["biasA"]) < tol, ("explicit", ku, ki, km)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sideinfo_beyond_X_live(oracles, refs, dtype):
+    """Side information that covers more users / items than X has rows / columns (m_u > m, n_i > n; the m != m_u
+    split of optimizeA_collective, collective.c:4832-5101, and its implicit counterpart :6037-6054, 6073-6090):
+    A, B have max(m, m_u) / max(n, n_i) rows; explicit model: the extra rows are a separate dense solve on the side
+    information with the scale_lam multiplier p, their biases are zero (:8296, :8923)."""
+    O, R = oracles[dtype], refs[dtype]
+    tol = 1e-10 if dtype is np.float64 else 5e-3
+    m, n, k, m_u, n_i = 120, 90, 6, 135, 100
+    rng = np.random.default_rng(7)
+    for cg, pcg, ku, ki, km, sl, sls in ((False, False, 0, 0, 0, True, False), (True, False, 2, 3, 1, True, True),
+                                         (True, True, 0, 0, 0, False, False)):
+        U = rng.standard_normal((m_u, 5)).astype(dtype); II = rng.standard_normal((n_i, 4)).astype(dtype)
+        A0 = (rng.standard_normal((m_u, ku + k + km)) * 0.1).astype(dtype)
+        B0 = (rng.standard_normal((n_i, ki + k + km)) * 0.1).astype(dtype)
+        C0 = (rng.standard_normal((5, ku + k)) * 0.1).astype(dtype); D0 = (rng.standard_normal((4, ki + k)) * 0.1).astype(dtype)
+        row, col, val = make_coo(m, n, 1500, 3, counts=True, dtype=dtype, empty_rows=(4, 110))
+        kw = dict(lam=2.0, alpha=1.5, niter=3, use_cg=cg, precondition_cg=pcg, max_cg_steps=3, k_main=km, k_user=ku, k_item=ki,
+                  w_main=0.5, w_user=3.0, w_item=0.7, U=U, II=II, m=m, n=n)
+        a1, b1, a2, b2 = A0.copy(), B0.copy(), A0.copy(), B0.copy()
+        r1 = R.fit_collective_implicit_als(a1, b1, row, col, val, k, nthreads=2, Cm=C0.copy(), Dm=D0.copy(), **kw)
+        r2 = O.fit_implicit_als_sideinfo(a2, b2, row, col, val, k, nthreads=2, Cm=C0.copy(), Dm=D0.copy(), **kw)
+        assert r1["ret"] == 0 and r2["ret"] == 0
+        assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol and rel_err(r2["C"], r1["C"]) < tol, ("implicit", cg, pcg)
+        row, col, val = make_coo(m, n, 1500, 4, counts=False, dtype=dtype, empty_rows=(4, 110))
+        kw = dict(lam=0.3, niter=3, use_cg=cg, precondition_cg=pcg, max_cg_steps=3, finalize_chol=False, k_main=km, k_user=ku,
+                  k_item=ki, w_user=3.0, w_item=0.7, U=U, II=II, scale_lam=sl, scale_lam_sideinfo=sls, m=m, n=n)
+        bA = (rng.standard_normal(m_u) * 0.1).astype(dtype); bB = (rng.standard_normal(n_i) * 0.1).astype(dtype)
+        a1, b1, a2, b2 = A0.copy(), B0.copy(), A0.copy(), B0.copy()
+        r1 = R.fit_collective_explicit_als(a1, b1, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), nthreads=2,
+                                           Cm=C0.copy(), Dm=D0.copy(), **kw)
+        r2 = O.fit_explicit_als(a2, b2, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), nthreads=2, Cm=C0.copy(),
+                                Dm=D0.copy(), **kw)
+        assert r1["ret"] == 0 and r2["ret"] == 0
+        assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol, ("explicit", cg, pcg)
+        assert np.abs(r2["biasA"] - r1["biasA"]).max() < tol and np.abs(r2["biasB"] - r1["biasB"]).max() < tol
+        assert not r1["biasA"][m:].any() and not r1["biasB"][n:].any()          # the reference's own behaviour
