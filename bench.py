@@ -176,14 +176,26 @@ def main():
     msA, cntA = sess.kernel_time("A"); msB, cntB = sess.kernel_time("B")
     halfstep_ms = {"A": msA / max(cntA, 1), "B": msB / max(cntB, 1)}
     iter_bytes = sum(d["alg_bytes"] for d in kernels)
+    # how a per-bin figure maps onto `rocprofv3 --kernel-trace --stats` rows (those average over BOTH half-steps)
+    prof_names = {0: ["vh_pass_kernel<..., 0> x1 + vh_pass_kernel<..., 1> x%d" % MAX_CG_STEPS,
+                      "vh_update_kernel<..., 0> x1 + vh_update_kernel<..., 1> x%d" % MAX_CG_STEPS],
+                  1: ["cg_rows_kernel<double, 7, true, 8, 1>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1>"],
+                  3: ["cg_rows_kernel<double, 7, true, 2, 1>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4>"],
+                  5: ["cg_rows_tiny_kernel<double, 7, true>"]}
+    inv = {v: b for b, v in names.items()}
+    for d in kernels:
+        other = [e for e in kernels if e["kernel"] == d["kernel"] and e["step"] != d["step"]]
+        d["rocprof"] = {"kernels": prof_names[inv[d["kernel"]]],
+                        "avg_ms_over_both_halfsteps": round((d["avg_ms"] + (other[0]["avg_ms"] if other else 0.0)) / (2 if other else 1), 4)}
     roofline = dict(bound="hbm", kernel="%s, %s-step" % (dom["kernel"], dom["step"]), achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     alg_bytes_per_launch=dom["alg_bytes"],
-                    avg_launch_ms=round(dom["avg_ms"], 4),
+                    avg_launch_ms=round(dom["avg_ms"], 4), rocprof=dom["rocprof"],
                     iteration={"alg_GB": round(iter_bytes / 1e9, 3), "halfstep_ms": halfstep_ms,
                                "frac_of_hbm_peak": round(iter_bytes / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)},
                     per_kernel=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4),
-                                     GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1)) for d in kernels])
+                                     GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1), rocprof=d["rocprof"])
+                                for d in kernels])
 
     # ---- CPU baseline: the reference itself (oracle/_ref) on this host, rank 0 / N=1 only ----
     cpu = None
