@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import make_coo          # noqa: E402
+import golden_cases as gc              # noqa: E402
 from oracle.bindings import Reference  # noqa: E402
 
 
@@ -174,6 +175,36 @@ def main():
              cfg=np.array([ku, ki, km]), B=B, C=r["C"], B_plus_bias=pr["B_plus_bias"], BtB=np.triu(pr["BtB"]),
              TransBtBinvBt=pr["TransBtBinvBt"], BeTBeChol=np.triu(pr["BeTBeChol"]), CtCw=np.triu(pr["CtCw"]),
              TransCtCinvCt=pr["TransCtCinvCt"])
+
+        # ---- G10: result metrics of the benchmarks -- RMSE (explicit) and P@10 (implicit) from the reference's own
+        #      15-iteration fits on a train / held-out split (SURVEY.md 8c G7, 8d "results parity") ----
+        mm, nn, kk = 600, 400, 16
+        mrng = np.random.default_rng(77)
+        row, col, val = make_coo(mm, nn, 30000, 109, counts=False, dtype=dt)
+        Pt = (mrng.standard_normal((mm, 4)) @ mrng.standard_normal((4, nn)))                 # low-rank signal + noise
+        val = (3.0 + Pt[row, col] + 0.3 * mrng.standard_normal(len(row))).astype(dt)
+        te = mrng.random(len(row)) < 0.2
+        A0 = (mrng.standard_normal((mm, kk)) * 0.01).astype(dt)
+        A, B = A0.copy(), np.zeros((nn, kk), dt)
+        r = R.fit_collective_explicit_als(A, B, row[~te], col[~te], val[~te], kk, lam=0.05, scale_lam=True, niter=15,
+                                          nthreads=2, use_cg=True, finalize_chol=False)
+        assert r["ret"] == 0
+        out = dict(m=mm, n=nn, k=kk, A0=A0, e_row=row[~te], e_col=col[~te], e_val=val[~te], e_trow=row[te], e_tcol=col[te],
+                   e_tval=val[te], rmse=gc.rmse(A, B, r["biasA"], r["biasB"], r["glob_mean"], row[te], col[te], val[te]))
+        # implicit data with structure to recover: 8 user clusters, each interacting with its own block of 50 items
+        # (95 %) plus a little noise elsewhere, so the held-out items of a user are predictable from the others
+        row, col, val = make_coo(mm, nn, 180000, 110, counts=True, dtype=dt)
+        own = (col // 50) == (row % 8)
+        keep = own | (mrng.random(len(row)) < 0.02)
+        row, col, val = row[keep], col[keep], val[keep]
+        te = mrng.random(len(row)) < 0.2
+        A, B = A0.copy(), np.zeros((nn, kk), dt)
+        rc = R.fit_collective_implicit_als(A, B, row[~te], col[~te], val[~te], kk, lam=5.0, niter=15, nthreads=2, use_cg=True)
+        assert rc == 0
+        out.update(i_row=row[~te], i_col=col[~te], i_val=val[~te], i_trow=row[te], i_tcol=col[te],
+                   p_at_10=gc.precision_at_k(A, B, row[~te], col[~te], row[te], col[te], 10))
+        print("   reference metrics: RMSE %.6f   P@10 %.6f" % (out["rmse"], out["p_at_10"]))
+        save("g10_metrics_" + tag, **out)
 
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}

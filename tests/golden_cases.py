@@ -56,3 +56,36 @@ def frob(a, b):
 def maxrel(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+# ---- result metrics of the reference's benchmarks (SURVEY.md 8c G7, 8d "results parity") ----
+def rmse(A, B, biasA, biasB, glob_mean, urow, icol, y):
+    """Root mean squared error of  glob_mean + biasA[u] + biasB[i] + A_u . B_i  on held-out pairs
+    (reference predict_multiple, src/common.c:5098-5106; benchmark_explicit_cmfrec.ipynb)."""
+    pred = np.einsum("ij,ij->i", np.asarray(A, np.float64)[urow], np.asarray(B, np.float64)[icol]) + float(glob_mean)
+    if biasA is not None and len(biasA):
+        pred = pred + np.asarray(biasA, np.float64)[urow]
+    if biasB is not None and len(biasB):
+        pred = pred + np.asarray(biasB, np.float64)[icol]
+    return float(np.sqrt(np.mean((pred - np.asarray(y, np.float64)) ** 2)))
+
+
+def precision_at_k(A, B, train_row, train_col, test_row, test_col, k=10):
+    """P@k as the reference's implicit benchmark computes it (benchmark_implicit_cmfrec.ipynb, cell 3): for every
+    user with held-out items, rank all items by A_u . B_i, drop the user's training items, take the top k and
+    count the fraction that are held-out items of that user; mean over those users."""
+    A = np.asarray(A, np.float64); B = np.asarray(B, np.float64)
+    n = B.shape[0]
+    seen = {}
+    for u, i in zip(train_row, train_col):
+        seen.setdefault(int(u), []).append(int(i))
+    held = {}
+    for u, i in zip(test_row, test_col):
+        held.setdefault(int(u), set()).add(int(i))
+    hits = []
+    for u, items in sorted(held.items()):
+        s = B @ A[u]
+        s[seen.get(u, [])] = -np.inf
+        top = np.argpartition(-s, min(k, n - 1))[:k]
+        hits.append(len(items.intersection(top.tolist())) / float(k))
+    return float(np.mean(hits))

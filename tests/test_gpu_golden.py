@@ -114,3 +114,24 @@ def test_precompute_epilogue(dtype):
     assert gc.frob(mdl._BtB, B.T @ B) < (1e-5 if uf else 1e-12)
     assert gc.frob(mdl._TransBtBinvBt, np.linalg.solve(B.T @ B + 0.05 * np.eye(k), B.T).T) < (1e-4 if uf else 1e-10)
     assert mdl._B_plus_bias.size == 0 and mdl._BeTBeChol.size == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_result_metrics(dtype):
+    """Results parity on the benchmark metrics: RMSE of the explicit model and P@10 of the implicit
+    model after 15 ALS-CG iterations on the GPU against the values the reference's own fits give on the same
+    train / held-out split (RMSE to 1e-6 fp64 / 1e-4 fp32; P@10 to 1e-4 fp64 -- one ranking flip in 560 users x 10
+    slots moves it by 1.8e-4, so fp32 gets 2e-3)."""
+    from cmfrec_amd import CMF, CMF_implicit
+    uf = dtype is np.float32
+    g = gc.load("g10_metrics", dtype)
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    mdl = CMF(k=k, lambda_=0.05, scale_lam=True, niter=15, use_cg=True, finalize_chol=False, use_float=uf, nthreads=1).fit(
+        (g["e_row"], g["e_col"], g["e_val"]), shape=(m, n), A0=g["A0"], B0=np.zeros((n, k), dtype),
+        biasA0=np.zeros(m, dtype), biasB0=np.zeros(n, dtype))
+    got = gc.rmse(mdl.A_, mdl.B_, mdl.user_bias_, mdl.item_bias_, mdl.glob_mean_, g["e_trow"], g["e_tcol"], g["e_tval"])
+    assert abs(got - float(g["rmse"])) < (1e-6 if not uf else 1e-4), (got, float(g["rmse"]))
+    mdl = CMF_implicit(k=k, lambda_=5.0, niter=15, use_cg=True, use_float=uf).fit(
+        (g["i_row"], g["i_col"], g["i_val"]), shape=(m, n), A0=g["A0"], B0=np.zeros((n, k), dtype))
+    got = gc.precision_at_k(mdl.A_, mdl.B_, g["i_row"], g["i_col"], g["i_trow"], g["i_tcol"], 10)
+    assert abs(got - float(g["p_at_10"])) < (1e-4 if not uf else 2e-3), (got, float(g["p_at_10"]))

@@ -98,3 +98,21 @@ def test_fits(oracles, dtype):
     for got, key in ((A, "A"), (B, "B"), (r["C"], "C"), (r["D"], "D")):
         assert gc.frob(got, g[key]) < t, key
     assert gc.maxrel(r["U_colmeans"], g["U_colmeans"]) < 1e-6 and gc.maxrel(r["I_colmeans"], g["I_colmeans"]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_result_metrics(oracles, dtype):
+    """RMSE (explicit) and P@10 (implicit) of 15-iteration fits equal the reference's (SURVEY.md 8d:
+    RMSE to 1e-6 fp64 / 1e-4 fp32, P@10 to 1e-4)."""
+    O = oracles[dtype]
+    g = gc.load("g10_metrics", dtype)
+    m, n, k = int(g["m"]), int(g["n"]), int(g["k"])
+    A, B = g["A0"].copy(), np.zeros((n, k), dtype)
+    r = O.fit_explicit_als(A, B, g["e_row"], g["e_col"], g["e_val"], k, lam=0.05, scale_lam=True, niter=15, use_cg=True,
+                           finalize_chol=False)
+    got = gc.rmse(A, B, r["biasA"], r["biasB"], r["glob_mean"], g["e_trow"], g["e_tcol"], g["e_tval"])
+    assert abs(got - float(g["rmse"])) < (1e-6 if dtype is np.float64 else 1e-4)
+    A, B = g["A0"].copy(), np.zeros((n, k), dtype)
+    O.fit_implicit_als(A, B, g["i_row"], g["i_col"], g["i_val"], lam=5.0, niter=15, use_cg=True)
+    got = gc.precision_at_k(A, B, g["i_row"], g["i_col"], g["i_trow"], g["i_tcol"], 10)
+    assert abs(got - float(g["p_at_10"])) < (1e-4 if dtype is np.float64 else 2e-3)
