@@ -35,7 +35,7 @@ class ModelF(C.Structure):
 EXPORTED = [
     "fit_collective_implicit_als", "fit_collective_explicit_als",
     "cmfrec_hip_optimizeA_implicit", "cmfrec_hip_optimizeA_explicit",
-    "cmfrec_hip_optimizeA_dense_full", "cmfrec_hip_optimizeA_collective",
+    "cmfrec_hip_optimizeA_dense_full", "cmfrec_hip_optimizeA_collective", "cmfrec_hip_topN_batch",
     "cmfrec_hip_session_create", "cmfrec_hip_session_destroy", "cmfrec_hip_last_error",
     "cmfrec_hip_session_set_X", "cmfrec_hip_session_set_X_coo", "cmfrec_hip_session_precompute", "cmfrec_hip_session_init_biases", "cmfrec_hip_session_get_X", "cmfrec_hip_session_set_factors", "cmfrec_hip_session_get_factors",
     "cmfrec_hip_session_set_sideinfo", "cmfrec_hip_session_update", "cmfrec_hip_session_iterate",

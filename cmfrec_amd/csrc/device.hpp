@@ -15,6 +15,7 @@
 #include "chol_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gram_cg_kernels.hpp"
+#include "topn_kernels.hpp"
 
 namespace cmfhip {
 

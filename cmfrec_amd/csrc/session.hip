@@ -906,6 +906,50 @@ int cmfrec_hip_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size
     });
 }
 
+int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B, size_t ldb, int_t n, int_t k,
+                          const real_t *biasB, const size_t excl_p[], const int_t excl_i[], int_t n_top,
+                          int_t *out_ids, real_t *out_scores)
+{
+    return guarded([&]() {
+        if (nu <= 0 || n <= 0 || k <= 0 || n_top <= 0 || !A || !B || !out_ids) {
+            g_last_error = "cmfrec_hip_topN_batch: invalid arguments";
+            return 2;
+        }
+        if (k > TOPN_KMAX || n_top > TOPN_NMAX || n_top > n) {
+            g_last_error = "cmfrec_hip_topN_batch: needs k <= 64 and n_top <= min(128, n)";
+            return 2;
+        }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> dA, dB, dbias, dsc;
+        DevBuf<size_t> dep; DevBuf<int> dei, dids;
+        dA.upload(A, (size_t)nu * lda, dev.stream);
+        dB.upload(B, (size_t)n * ldb, dev.stream);
+        if (biasB) dbias.upload(biasB, (size_t)n, dev.stream);
+        if (excl_p) {
+            dep.upload(excl_p, (size_t)nu + 1, dev.stream);
+            dei.upload(excl_i, std::max<size_t>(excl_p[nu], 1), dev.stream);
+        }
+        dids.alloc((size_t)nu * n_top);
+        if (out_scores) dsc.alloc((size_t)nu * n_top);
+        TopnParams<real_t> P;
+        P.A = dA.ptr; P.lda = lda; P.nu = nu; P.B = dB.ptr; P.ldb = ldb; P.n = n; P.k = k;
+        P.biasB = biasB ? dbias.ptr : nullptr;
+        P.excl_p = excl_p ? dep.ptr : nullptr; P.excl_i = excl_p ? dei.ptr : nullptr;
+        P.n_top = n_top; P.out_ids = dids.ptr; P.out_scores = out_scores ? dsc.ptr : nullptr;
+        const size_t smem = topn_lds_bytes(sizeof(real_t));
+        HIP_CHECK(hipFuncSetAttribute((const void *)topn_kernel<real_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int tiles = (nu + TOPN_UT - 1) / TOPN_UT;
+        hipLaunchKernelGGL(topn_kernel<real_t>, dim3(std::min(tiles, dev.num_cus * 2)), dim3(TOPN_TH), smem, dev.stream, P);
+        HIP_CHECK(hipGetLastError());
+        dids.download(out_ids, (size_t)nu * n_top, dev.stream);
+        if (out_scores) dsc.download(out_scores, (size_t)nu * n_top, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        HIP_CHECK(hipStreamDestroy(dev.stream));
+        return 0;
+    });
+}
+
 int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C, int_t m,
                                     int_t m_u, int_t n, int_t p, int_t k, int_t k_main, int_t k_user, int_t k_item,
                                     const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,

@@ -48,6 +48,23 @@ class _Base:
         return _lib.load(self.dtype_), _lib.real(self.dtype_)
 
 
+def _topN(self, users, n, exclude, biasB):
+    """Shared body of ``CMF.topN_batch`` / ``CMF_implicit.topN_batch``."""
+    from . import ops
+    users = np.atleast_1d(np.asarray(users, np.int64))
+    A = np.ascontiguousarray(self.A_[users][:, self.k_user:])
+    B = np.ascontiguousarray(self.B_[:, self.k_item:])
+    excl = None
+    if exclude is not None:                       # scipy CSR / (indptr, indices) over ALL users: take the asked rows
+        ip, ix = (exclude.indptr, exclude.indices) if hasattr(exclude, "indptr") else exclude
+        ip = np.asarray(ip, np.int64); ix = np.asarray(ix)
+        lens = ip[users + 1] - ip[users]
+        ep = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        take = np.concatenate([np.arange(ip[u], ip[u + 1]) for u in users]) if lens.sum() else np.zeros(0, np.int64)
+        excl = (ep, ix[take].astype(np.int32))
+    return ops.topN_batch(A, B, n_top=n, biasB=biasB, exclude=excl)
+
+
 class CMF_implicit(_Base):
     """Implicit-feedback model (iALS / WRMF), reference class ``CMF_implicit``."""
 
@@ -127,6 +144,11 @@ class CMF_implicit(_Base):
         self._BeTBeChol = BeTBeChol if BeTBeChol is not None else e
         self.is_fitted_ = True
         return self
+
+    def topN_batch(self, users, n=10, exclude=None):
+        """Top-``n`` item ids and scores (A_u . B_i) for a batch of users, ranked on the GPU; ``exclude``: CSR of items
+        to skip per user (e.g. the training matrix).  Batch form of the reference's ``topN`` (common.c:5127-5380)."""
+        return _topN(self, users, n, exclude, None)
 
     def predict(self, user, item):
         """A_u . B_i for paired user / item ids (reference predict_multiple, common.c:5066-5106)."""
@@ -232,6 +254,17 @@ class CMF(_Base):
         self._U_colmeans, self._I_colmeans = Ucm[:p], Icm[:q]
         self.is_fitted_ = True
         return self
+
+    def topN_batch(self, users, n=10, exclude=None):
+        """Top-``n`` item ids and scores for a batch of users, ranked on the GPU by A_u . B_i + item_bias[i] (the user
+        bias and the global mean do not change the order; the reference adds them to the scores, common.c:5339-5345,
+        and so does this method).  ``exclude``: CSR of items to skip per user."""
+        ids, sc = _topN(self, users, n, exclude, self.item_bias_ if self.item_bias else None)
+        users = np.atleast_1d(np.asarray(users, np.int64))
+        sc = sc + self.glob_mean_
+        if self.user_bias:
+            sc = sc + np.asarray(self.user_bias_)[users][:, None]
+        return ids, sc
 
     def predict(self, user, item):
         """glob_mean + biasA[u] + biasB[i] + A_u . B_i (reference predict_multiple, common.c:5098-5106)."""

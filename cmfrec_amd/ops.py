@@ -88,3 +88,26 @@ def optimizeA_collective(A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=Non
         _lib.ptr(i), _lib.ptr(v), _lib.ptr(bs), _lib.ptr(Uc), R(lam), R(w_user), R(lam_last), C.c_bool(scale_lam),
         C.c_bool(scale_lam_sideinfo))
     _lib.check(rc, lib, "optimizeA_collective")
+
+
+def topN_batch(A, B, n_top=10, biasB=None, exclude=None):
+    """Top-N item ids (and scores) for every row of ``A``: score = A_u . B_i (+ biasB[i]), descending, ties by lower
+    id; ``exclude`` = (indptr, indices) CSR of items to skip per user (sorted here).  Batch counterpart of the
+    reference's per-user ``topN`` (src/common.c:5127-5380)."""
+    A = np.ascontiguousarray(A); B = np.ascontiguousarray(B, A.dtype)
+    lib, R = _prep(A, B)
+    nu, lda = A.shape
+    n, ldb = B.shape
+    ids = np.empty((nu, n_top), np.int32); sc = np.empty((nu, n_top), A.dtype)
+    bs = None if biasB is None else np.ascontiguousarray(biasB, A.dtype)
+    ep = ei = None
+    if exclude is not None:
+        ep = np.ascontiguousarray(exclude[0], np.uint64)
+        ei = np.ascontiguousarray(exclude[1], np.int32)
+        owner = np.repeat(np.arange(nu), np.diff(ep.astype(np.int64)))
+        ei = np.ascontiguousarray(ei[np.lexsort((ei, owner))])          # each list ascending (the kernel binary-searches it)
+    rc = lib.cmfrec_hip_topN_batch(_lib.ptr(A), C.c_size_t(lda), C.c_int(nu), _lib.ptr(B), C.c_size_t(ldb), C.c_int(n),
+                                   C.c_int(lda), _lib.ptr(bs), _lib.ptr(ep), _lib.ptr(ei), C.c_int(n_top), _lib.ptr(ids),
+                                   _lib.ptr(sc))
+    _lib.check(rc, lib, "topN_batch")
+    return ids, sc

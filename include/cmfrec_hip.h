@@ -266,6 +266,16 @@ int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, doub
                                  long *rows, unsigned long long *nnz);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
+/* Batched top-N (the step after the path; the reference ranks one user per call: topN, src/common.c:5127-5380).
+ * score(u, i) = A_u . B_i (+ biasB[i]) over the k columns starting at A / B (skip k_user / k_item by offsetting the
+ * pointers), items in the user's exclusion list (CSR over the nu users, each list sorted ascending; NULL = none)
+ * are skipped, the n_top best item ids per user are returned in descending score (ties: lower id first), -1 where
+ * fewer than n_top items remain.  out_scores (optional) holds the scores as defined above; the reference adds
+ * glob_mean + biasA[u] afterwards, which does not change the order.  k <= 64, n_top <= 128. */
+int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B, size_t ldb, int_t n, int_t k,
+                          const real_t *biasB, const size_t excl_p[], const int_t excl_i[], int_t n_top,
+                          int_t *out_ids, real_t *out_scores);
+
 /* Runs the on-device self-test of the cross-lane primitives (DPP / permlane swaps) the row kernels
  * are built on; returns the number of mismatching lanes (0 = ok), negative = HIP failure. */
 int cmfrec_hip_selftest_lanes(void);

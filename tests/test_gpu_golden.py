@@ -135,3 +135,13 @@ def test_result_metrics(dtype):
         (g["i_row"], g["i_col"], g["i_val"]), shape=(m, n), A0=g["A0"], B0=np.zeros((n, k), dtype))
     got = gc.precision_at_k(mdl.A_, mdl.B_, g["i_row"], g["i_col"], g["i_trow"], g["i_tcol"], 10)
     assert abs(got - float(g["p_at_10"])) < (1e-4 if not uf else 2e-3), (got, float(g["p_at_10"]))
+    # the same metric with the ranking done on the device (batched top-N, exclusion = the training matrix)
+    import scipy.sparse as sp
+    train = sp.csr_matrix((np.ones(len(g["i_row"])), (g["i_row"], g["i_col"])), shape=(m, n))
+    users = np.unique(g["i_trow"])
+    ids, _ = mdl.topN_batch(users, n=10, exclude=train)
+    held = {}
+    for u, i in zip(g["i_trow"], g["i_tcol"]):
+        held.setdefault(int(u), set()).add(int(i))
+    p10 = float(np.mean([len(held[int(u)].intersection(ids[j].tolist())) / 10.0 for j, u in enumerate(users)]))
+    assert abs(p10 - got) < (1e-12 if not uf else 2e-3)

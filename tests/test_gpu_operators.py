@@ -218,3 +218,34 @@ def test_bias_init_device_matches_oracle(oracles, dtype, scale_lam, long_rows):
     assert np.abs(f["biasA"] - bA).max() <= tol * max(1.0, np.abs(bA).max())
     assert np.abs(f["biasB"] - bB).max() <= tol * max(1.0, np.abs(bB).max())
     assert np.array_equal(f["biasA"][[5, 17]], np.zeros(2, dtype))          # rows without entries
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("nu,n,k,n_top", [(37, 1000, 50, 10), (5, 300, 17, 100), (64, 5000, 64, 10)])
+def test_topN_batch(dtype, nu, n, k, n_top):
+    """Batched top-N (topn_kernels.hpp) against a plain ranking: score = A_u . B_i + biasB[i], excluded items
+    skipped, descending, ties by lower id (reference scoring rule: topN, common.c:5127-5380)."""
+    from cmfrec_amd import ops
+    rng = np.random.default_rng(nu + n)
+    A = rng.standard_normal((nu, k)).astype(dtype); B = rng.standard_normal((n, k)).astype(dtype)
+    B[7] = B[3]; B[11] = B[3]                                   # exact ties
+    bias = rng.standard_normal(n).astype(dtype); bias[7] = bias[3]; bias[11] = bias[3]
+    lens = rng.integers(0, min(60, n - n_top), nu); lens[0] = 0
+    ep = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ei = np.concatenate([rng.choice(n, l, replace=False) for l in lens]).astype(np.int32) if lens.sum() else np.zeros(0, np.int32)
+    ids, sc = ops.topN_batch(A, B, n_top=n_top, biasB=bias, exclude=(ep, ei))
+    S = (A.astype(np.float64) @ B.astype(np.float64).T) + bias.astype(np.float64)
+    for u in range(nu):
+        s = S[u].copy(); s[ei[int(ep[u]):int(ep[u + 1])]] = -np.inf
+        want = np.lexsort((np.arange(n), -s))[:n_top]
+        if dtype is np.float64:
+            assert np.array_equal(ids[u], want), u
+        else:                                                    # fp32 scores may swap near-ties: compare as scores
+            assert np.allclose(np.sort(s[ids[u]])[::-1], s[want], rtol=1e-4, atol=1e-4), u
+            assert len(set(ids[u].tolist())) == n_top and not set(ids[u].tolist()) & set(ei[int(ep[u]):int(ep[u + 1])].tolist())
+        assert np.allclose(sc[u], s[ids[u]], rtol=1e-12 if dtype is np.float64 else 1e-4, atol=1e-12 if dtype is np.float64 else 1e-4)
+    # no bias, no exclusion, and P@10 of a golden fit computed through the device ranking
+    ids2, _ = ops.topN_batch(A, B, n_top=min(n_top, 10))
+    S2 = A.astype(np.float64) @ B.astype(np.float64).T
+    if dtype is np.float64:
+        assert np.array_equal(ids2[1], np.lexsort((np.arange(n), -S2[1]))[:min(n_top, 10)])
