@@ -55,9 +55,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.mode = c.mode;
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
-    if (T > 16 || (sizeof(real_t) == 8 && T > 9)) {
+    if (T > 17 || (sizeof(real_t) == 8 && T > 16)) {
         g_last_error = "cmfrec_hip: Cholesky path: k_t too large for the register-resident normal matrix "
-                       "(k_t <= 144 in double, <= 256 in single precision)";
+                       "(k_t <= 256 in double, <= 272 in single precision)";
         return 2;
     }
     if (!dev.row_counter.ptr) const_cast<DeviceInfo &>(dev).row_counter.alloc(16);
@@ -76,6 +76,10 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     else if (T <= 9) launch(chol_rows_kernel<real_t, 9, 8, 32, 1>, 9, 8, 32, 1);
 #ifdef CMFREC_HIP_FLOAT
     else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 32, 1>, 12, 8, 32, 1);
+    else if (T <= 16) launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
+    else launch(chol_rows_kernel<real_t, 17, 8, 16, 1>, 17, 8, 16, 1);        // k = 256 + bias (BASELINE config 5)
+#else
+    else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 16, 1>, 12, 8, 16, 1);
     else launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
 #endif
     HIP_CHECK(hipGetLastError());

@@ -249,3 +249,26 @@ def test_topN_batch(dtype, nu, n, k, n_top):
     S2 = A.astype(np.float64) @ B.astype(np.float64).T
     if dtype is np.float64:
         assert np.array_equal(ids2[1], np.lexsort((np.arange(n), -S2[1]))[:min(n_top, 10)])
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float64, 161), (np.float64, 250), (np.float32, 200), (np.float32, 257)])
+@pytest.mark.parametrize("implicit", [False, True])
+def test_cholesky_large_k(oracles, dtype, k, implicit):
+    """Closed-form row update beyond k_t = 144: the 12/16/17-block instantiations of chol_rows_kernel (k = 256 + bias
+    in single precision is BASELINE config 5's system size)."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n = 48, 700
+    row, col, val = make_coo(m, n, 9000, 3 + k, counts=implicit, dtype=dtype, heavy_row=(3, 600), empty_rows=(5,))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(k)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    if implicit:
+        ops.optimizeA_implicit(Ah, B, csr, 4.0, use_cg=False)
+        O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, use_cg=False)
+    else:
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, k=k, lam_last=0.3, scale_lam=True, use_cg=False)
+        O.optimizeA_explicit(Ao, B, csr, 0.05, k=k, lam_last=0.3, scale_lam=True, use_cg=False, nthreads=4)
+    assert rel_err(Ah, Ao) < (1e-9 if dtype is np.float64 else 1e-3)
