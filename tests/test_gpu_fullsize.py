@@ -1,0 +1,108 @@
+"""Parity properties at BASELINE.json's full size (configuration 2: 358,858 x 160,112, 17.3 M non-zeros, k=50 fp64),
+where the CPU oracle would take minutes per call: size-independent properties of the ALS half-steps instead
+(run-to-run bit reproducibility, the normal equations of sampled rows, monotone objective, invariance to the order
+of the COO entries, CG -> closed form)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K, LAM = 50, 5.0
+
+
+@pytest.fixture(scope="module")
+def c2():
+    import bench
+    row, col, val = bench.synth_block(bench.M_USERS, bench.N_ITEMS, bench.NNZ, seed=2)
+    rng = np.random.default_rng(100)
+    A0 = rng.random((bench.M_USERS, K)) * 2.0 ** -7
+    return bench.M_USERS, bench.N_ITEMS, row, col, val.astype(np.float64), A0
+
+
+def _session(c2, use_cg, rowperm=None):
+    from cmfrec_amd.session import AlsSession
+    m, n, row, col, val, A0 = c2
+    s = AlsSession(m, n, K, implicit=True, dtype=np.float64, lam=LAM, use_cg=use_cg, max_cg_steps=3)
+    if rowperm is None:
+        s.set_X_coo(row, col, val)
+    else:
+        s.set_X_coo(row[rowperm], col[rowperm], val[rowperm])
+    s.set_factors(A=A0, B=np.zeros((n, K)))
+    return s
+
+
+def _objective(A, B, row, col, val, lam):
+    """Implicit-feedback objective  sum_all c_ui (p_ui - a_u.b_i)^2 + lam (|A|^2 + |B|^2),  c = 1 + x, p = [x > 0],
+    with the dense part through  sum_all (a.b)^2 = <A^T A, B^T B>  (Hu, Koren, Volinsky; the model of
+    fit_collective_implicit_als, src/collective.c:9375)."""
+    pred = np.einsum("ij,ij->i", A[row], B[col])
+    dense = float(np.sum((A.T @ A) * (B.T @ B)))
+    nz = float(np.sum((1.0 + val) * (1.0 - pred) ** 2 - pred ** 2))
+    return dense + nz + lam * (float(np.sum(A * A)) + float(np.sum(B * B)))
+
+
+def test_full_size_properties(c2):
+    m, n, row, col, val, A0 = c2
+    # ---- 1. bit reproducibility: two independent sessions, two CG iterations ----
+    s1 = _session(c2, True); s1.iterate(2); f1 = s1.get_factors()
+    s2 = _session(c2, True); s2.iterate(2); f2 = s2.get_factors()
+    assert np.array_equal(f1["A"], f2["A"]) and np.array_equal(f1["B"], f2["B"])
+    assert np.isfinite(f1["A"]).all() and np.isfinite(f1["B"]).all()
+    # ---- 2. the objective never increases over CG iterations ----
+    obj = [_objective(f1["A"], f1["B"], row, col, val, LAM)]
+    for _ in range(3):
+        s1.iterate(1); f = s1.get_factors()
+        obj.append(_objective(f["A"], f["B"], row, col, val, LAM))
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(obj, obj[1:])), obj
+    # ---- 3. the order of the COO entries only changes rounding (row sums are re-associated) ----
+    perm = np.random.default_rng(5).permutation(len(row))
+    s3 = _session(c2, True, rowperm=perm); s3.iterate(2); f3 = s3.get_factors()
+    assert np.abs(f3["A"] - f1["A"]).max() <= 1e-9 * np.abs(f1["A"]).max()
+    assert np.abs(f3["B"] - f1["B"]).max() <= 1e-9 * np.abs(f1["B"]).max()
+
+
+def test_full_size_normal_equations(c2):
+    """Cholesky half-step at full size: sampled users (the heaviest, the lightest, random ones) satisfy
+    (B^T B + lam I + sum_j x_j b_j b_j^T) a = sum_j (x_j + 1) b_j   (factors_implicit_chol, common.c:2063-2126)."""
+    m, n, row, col, val, A0 = c2
+    from cmfrec_amd.session import AlsSession
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((n, K)) * 0.1
+    s = AlsSession(m, n, K, implicit=True, dtype=np.float64, lam=LAM, use_cg=False)
+    s.set_X_coo(row, col, val)
+    s.set_factors(A=A0, B=B)
+    s.update("A")
+    A = s.get_factors()["A"]
+    cnt = np.bincount(row, minlength=m)
+    order = np.argsort(row, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(cnt)])
+    G = B.T @ B + LAM * np.eye(K)
+    users = np.concatenate([np.argsort(-cnt)[:5], np.nonzero(cnt == 1)[0][:5], rng.choice(np.nonzero(cnt > 0)[0], 40, replace=False)])
+    for u in users:
+        e = order[ptr[u]:ptr[u + 1]]
+        Bu = B[col[e]]; x = val[e]
+        M = G + (Bu * x[:, None]).T @ Bu
+        rhs = Bu.T @ (x + 1.0)
+        assert np.abs(M @ A[u] - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max()), (u, cnt[u])
+    assert not A[cnt == 0].any()                                   # rows without entries are zero in Cholesky mode (:3334)
+
+
+def test_full_size_explicit_cg_reaches_closed_form():
+    """Configuration 1's shape (69,878 x 10,677, 10 M ratings): many CG steps from a warm start converge to the
+    Cholesky solution of the same half-step (explicit model, common.c:1098-1188 vs :978-1070)."""
+    import bench
+    from cmfrec_amd.session import AlsSession
+    m, n, nnz, k = 69_878, 10_677, 10_000_054, 50
+    row, col, _ = bench.synth_block(m, n, nnz, seed=1)
+    rng = np.random.default_rng(1)
+    val = 0.5 * rng.integers(1, 11, nnz); val = val - val.mean()
+    B = rng.standard_normal((n, k)) * 0.1
+    out = {}
+    for use_cg in (False, True):
+        s = AlsSession(m, n, k, implicit=False, dtype=np.float64, lam=0.05, use_cg=use_cg, max_cg_steps=60, scale_lam=True)
+        s.set_X_coo(row, col, val)
+        s.set_factors(A=np.zeros((m, k)), B=B)
+        s.update("A")
+        out[use_cg] = s.get_factors()["A"]
+    err = np.abs(out[True] - out[False]).max() / np.abs(out[False]).max()
+    assert err < 1e-3, err                       # CG stops at |r|^2 <= 1e-8 (absolute, common.c:1180)
