@@ -69,6 +69,7 @@ struct CgParams {
     const T *UC = nullptr;    // [rows_with_u, kc] U C of the local rows, NOT multiplied by w_side
     T w_side = 0;
     int rows_with_u = 0;      // local rows < rows_with_u carry side information; the others are plain rows
+    int row_first = 0;        // generic kernel: first position of the processing order to handle
     int p_side = 0, scale_lam_sideinfo = 0;
 };
 
@@ -730,16 +731,22 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
 // (collective_block_cg, src/collective.c:2134-2903; collective_block_cg_implicit, :2905-3303; dense full U
 // without NaN, prefer_CtC branch): unknowns [koff, k_t) couple to X through the gathered rows (+ BtB in the
 // implicit model), unknowns [0, kc) to U through w C^T C and the constant w (U C)_row.
-template <typename T, int NF, bool IMPLICIT>
+// TEAM = 1: one wavefront per row (4 rows per workgroup).  TEAM = 4: the four wavefronts of a workgroup share a
+// row -- its non-zeros are dealt round-robin, every product is summed across the waves through LDS in wave order, and
+// all four carry identical copies of a, r, p (the scalars of the CG are then bit-identical, so the exits agree).
+// P.row_first .. P.nrows of the processing order are handled.
+template <typename T, int NF, bool IMPLICIT, int TEAM>
 __global__ void __launch_bounds__(256)
 cg_rows_generic_kernel(const CgParams<T> P)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    static_assert(TEAM == 1 || TEAM == 4, "team");
+    __shared__ T red[TEAM == 1 ? 1 : 4][64 * NF];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int unit_global = (TEAM == 1) ? ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) : (int)blockIdx.x;
+    const int nunits = (TEAM == 1) ? ((gridDim.x * blockDim.x) >> 6) : (int)gridDim.x;
     const int kx = P.k, koff = P.koff, kt = koff + kx, kc = P.kc;
     const bool coll = kc > 0;
-    for (int rix = wave_global; rix < P.nrows; rix += nwaves) {
+    for (int rix = P.row_first + unit_global; rix < P.nrows; rix += nunits) {
         const int row = P.order[rix];
         const size_t st = P.indptr[row];
         const int nnz = (int)(P.indptr[row + 1] - st);
@@ -797,7 +804,10 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     if (f < kc) out[c] += (mode == 0) ? P.w_side * (ucrow[f] - acc[c]) : P.w_side * acc[c];
                 }
             }
-            for (int j = 0; j < nnz; j++) {
+            T gat[NF];                                         // the gathered part, this wave's share of the non-zeros
+#pragma unroll
+            for (int c = 0; c < NF; c++) gat[c] = T(0);
+            for (int j = (TEAM == 1 ? 0 : wv); j < nnz; j += TEAM) {
                 const int idx = P.indices[st + j];
                 T x = P.values[st + j];
                 if (!IMPLICIT && P.bias_sub != nullptr) x -= P.bias_sub[idx];
@@ -810,8 +820,23 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 if (IMPLICIT) w = (mode == 0) ? (-(coef - T(1)) * x - coef) : (coef * (x - T(1)) + coef);
                 else          w = (mode == 0) ? -(coef - x) : coef;
 #pragma unroll
-                for (int c = 0; c < NF; c++) out[c] += w * bv[c];
+                for (int c = 0; c < NF; c++) gat[c] += w * bv[c];
             }
+            if (TEAM > 1) {                                    // sum over the waves, in wave order, identical everywhere
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NF; c++) red[wv][lane + 64 * c] = gat[c];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    T sacc = T(0);
+#pragma unroll
+                    for (int w2 = 0; w2 < TEAM; w2++) sacc += red[w2][lane + 64 * c];
+                    gat[c] = sacc;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NF; c++) out[c] += gat[c];
         };
         auto vdot = [&](const T (&u)[NF], const T (&v)[NF]) {
             T s = T(0);
@@ -835,7 +860,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
             T PC[NF], z[NF];
 #pragma unroll
             for (int c = 0; c < NF; c++) PC[c] = T(0);
-            for (int j = 0; j < nnz; j++) {
+            for (int j = (TEAM == 1 ? 0 : wv); j < nnz; j += TEAM) {
                 const int idx = P.indices[st + j];
                 T x = P.values[st + j];
                 const T *b = P.B + (size_t)idx * P.ldb;
@@ -844,6 +869,19 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     int f = lane + 64 * c;
                     T bv = (f >= koff && f < kt) ? b[f - koff] : T(0);
                     PC[c] += IMPLICIT ? x * (bv * bv) : bv * bv;                 // :2009-2014 / :1238-1243
+                }
+            }
+            if (TEAM > 1) {
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NF; c++) red[wv][lane + 64 * c] = PC[c];
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    T sacc = T(0);
+#pragma unroll
+                    for (int w2 = 0; w2 < TEAM; w2++) sacc += red[w2][lane + 64 * c];
+                    PC[c] = sacc;
                 }
             }
 #pragma unroll
@@ -905,8 +943,10 @@ cg_rows_generic_kernel(const CgParams<T> P)
             }
         }
         }
+        if (TEAM == 1 || wv == 0) {
 #pragma unroll
-        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (live(f)) arow[f] = a[c]; }
+            for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (live(f)) arow[f] = a[c]; }
+        }
     }
 }
 

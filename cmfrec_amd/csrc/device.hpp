@@ -425,9 +425,18 @@ inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const S
 {
     int count = (P.kc > 0) ? X.nrows : X.n_nonempty;       // rows without entries still have side information
     if (count <= 0) return;
-    P.nrows = count;
-    int grid = std::min((count + 3) / 4, dev.num_cus * 8);
-    hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT>), dim3(grid), dim3(256), 0, dev.stream, P);
+    // rows of 129 non-zeros and more (they lead the processing order): a workgroup per row; the rest: a wavefront per row
+    const int nteam = std::min(count, X.bin_first[BIN_MED2]);
+    if (nteam > 0) {
+        P.row_first = 0; P.nrows = nteam;
+        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 4>), dim3(std::min(nteam, dev.num_cus * 8)), dim3(256), 0,
+                           dev.stream, P);
+    }
+    if (count > nteam) {
+        P.row_first = nteam; P.nrows = count;
+        int grid = std::min((count - nteam + 3) / 4, dev.num_cus * 8);
+        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 1>), dim3(grid), dim3(256), 0, dev.stream, P);
+    }
     HIP_CHECK(hipGetLastError());
 }
 
