@@ -58,6 +58,7 @@ struct CholParams {
     int scale_lam, scale_lam_sideinfo, scale_bias_const;
     int mode;
     int *counter;              // zero-initialised: rows are handed out to the workgroups in `order` (heaviest first)
+    int row_first;             // positions row_first .. nrows-1 of the processing order are handled
 };
 
 __host__ __device__ inline int chol_tiles(int kt) { return (kt + 15) / 16; }
@@ -263,7 +264,7 @@ chol_rows_kernel(const CholParams<T> P)
 
     __shared__ int s_rix;
     for (;;) {
-        if (tid == 0) s_rix = atomicAdd(P.counter, 1);
+        if (tid == 0) s_rix = P.row_first + atomicAdd(P.counter, 1);
         __syncthreads();
         const int rix = s_rix;
         __syncthreads();                            // s_rix may be rewritten

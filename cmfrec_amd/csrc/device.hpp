@@ -215,7 +215,27 @@ struct DeviceInfo {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf<int> row_counter;        // work counter of the dynamically scheduled row kernels (zeroed before each launch)
+    DevBuf<int> row_counter;        // work counters of the dynamically scheduled row kernels (zeroed before each launch)
+    // second stream + events for two row kernels that may overlap (heavy-row teams beside light-row teams); created on
+    // first use, owned here
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    DeviceInfo() = default;
+    DeviceInfo(const DeviceInfo &) = delete;
+    DeviceInfo &operator=(const DeviceInfo &) = delete;
+    ~DeviceInfo()
+    {
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+        if (join_ev) (void)hipEventDestroy(join_ev);
+        if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    }
+    void ensure_aux()
+    {
+        if (aux_stream) return;
+        HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    }
 };
 
 // HIP-event pairs around the launches of one nnz bin (0 heavy, 1 medium, 2 light) on the stream

@@ -61,17 +61,47 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         return 2;
     }
     if (!dev.row_counter.ptr) const_cast<DeviceInfo &>(dev).row_counter.alloc(16);
-    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, sizeof(int), dev.stream));
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 2 * sizeof(int), dev.stream));
     P.counter = dev.row_counter.ptr;
+    P.row_first = 0;
+    hipStream_t run_on = dev.stream;
     auto launch = [&](auto kern, int ntt, int nw, int ch, int wgs) {
         size_t smem = chol_lds_elems<real_t>(ntt, ch) * sizeof(real_t);
-        int grid = std::min(P.nrows, dev.num_cus * wgs);
+        int grid = std::min(P.nrows - P.row_first, dev.num_cus * wgs);
+        if (grid <= 0) return;
         if (smem > 48 * 1024)
             HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, dev.stream, P);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, run_on, P);
     };
-    // <16-blocks per dimension, wavefronts per workgroup, gathered rows per round, workgroups per CU>
-    if (T <= 4) launch(chol_rows_kernel<real_t, 4, 4, 16, 2>, 4, 4, 16, 2);
+    // <16-blocks per dimension, wavefronts per workgroup, gathered rows per round, waves per SIMD>
+    if (T <= 4) {
+        // k_t <= 64: the whole system is 10 tiles.  Rows of 129 non-zeros and more (they lead the processing order) get
+        // a four-wave workgroup, the others a two-wave one: with few gathered rows the per-row latency chain dominates
+        // and more rows in flight per CU win (C2 A-step 20.9 -> 12.8 ms).  The two launches overlap on two streams, so
+        // the light rows fill the CUs while the heaviest rows finish.
+        const int total = P.nrows;
+        const int nheavy = (X != nullptr) ? std::min(total, X->bin_first[BIN_MED2]) : total;
+        DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+        const bool two = nheavy > 0 && total > nheavy;
+        if (two) {
+            d.ensure_aux();
+            HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
+            HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
+        }
+        if (nheavy > 0) {
+            P.nrows = nheavy;
+            launch(chol_rows_kernel<real_t, 4, 4, 16, 2>, 4, 4, 16, 2);
+        }
+        if (total > nheavy) {
+            P.row_first = nheavy; P.nrows = total; P.counter = dev.row_counter.ptr + 1;
+            if (two) run_on = d.aux_stream;
+            launch(chol_rows_kernel<real_t, 4, 2, 16, 2>, 4, 2, 16, 4);
+            if (two) {
+                HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
+                HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
+            }
+        }
+    }
     else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 8, 32, 1>, 6, 8, 32, 1);
     else if (T <= 9) launch(chol_rows_kernel<real_t, 9, 8, 32, 1>, 9, 8, 32, 1);
 #ifdef CMFREC_HIP_FLOAT
