@@ -291,7 +291,9 @@ chol_rows_kernel(const CholParams<T> P)
                 T mult = (nnz > 0) ? (T)nnz : T(1);
                 if (P.scale_lam_sideinfo && has_u) mult += (T)P.p_side;
                 lam *= mult;
-                lam_last *= mult;
+                // rows without side information are plain factors_closed_form rows when new rows are fitted
+                // (collective.c:3772-3815): there scale_bias_const keeps the bias' lambda (common.c:679-723)
+                if (has_u || !P.scale_bias_const) lam_last *= mult;
             }
         }
         // ---- 1. rank-k update on the matrix cores: G[koff:, koff:] = sum_j w_j B_j B_j^T ----

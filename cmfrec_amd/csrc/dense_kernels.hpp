@@ -318,4 +318,24 @@ __global__ void betbe_base_kernel(const T *__restrict__ G, int kk, int ks, T lam
     }
 }
 
+// U[r, c] -= colmeans[c]  (preprocess_vec on the rows of new side information, collective.c:6337-6349)
+template <typename T>
+__global__ void sub_colmeans_kernel(T *__restrict__ U, size_t rows, int p, const T *__restrict__ colmeans)
+{
+    const size_t total = rows * (size_t)p;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+        U[e] -= colmeans[e % (size_t)p];
+}
+
+// rows of A that have side information but no entries in X take the side-information-only ("cold") solution:
+// A[r, :kc] = cold[r, :kc], the remaining unknowns (k_main, bias) are zero  (collective.c:10683-10703, :3639-3660)
+template <typename T>
+__global__ void cold_select_kernel(T *__restrict__ A, size_t lda, int kt, int kc, const T *__restrict__ cold,
+                                   const size_t *__restrict__ indptr, int rows_u)
+{
+    const int r = blockIdx.x;
+    if (r >= rows_u || indptr[r + 1] != indptr[r]) return;
+    for (int e = threadIdx.x; e < kt; e += blockDim.x) A[(size_t)r * lda + e] = (e < kc) ? cold[(size_t)r * kc + e] : T(0);
+}
+
 }  // namespace cmfhip

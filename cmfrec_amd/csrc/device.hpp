@@ -228,6 +228,7 @@ struct DeviceInfo {
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (join_ev) (void)hipEventDestroy(join_ev);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
+        if (stream) (void)hipStreamDestroy(stream);
     }
     void ensure_aux()
     {

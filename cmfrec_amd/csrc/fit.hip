@@ -368,4 +368,133 @@ int_t fit_collective_explicit_als(
     return rc_loop > 3 ? 1 : rc_loop;
 }
 
+// ---- factors of new rows (the step after the path) -----------------------------------------------------
+// Same positional signatures as the reference (src/cmfrec.h:2004-2071).  Supported: sparse X (COO or CSR, missing = not
+// observed), dense U without NaN, no binary side information / weights / implicit features / L1 / non-negativity /
+// NA_as_zero.  Anything else returns 2 with a message on stderr.  The precomputed matrices of the reference's
+// signature are optional accelerators there; here the small Gramians are rebuilt on the device from B and C (BtB of the
+// implicit model and TransCtCinvCt are used when given, because they decide the result: collective.c:11270-11280, :3380).
+static int unsupported_multiple(const char *what)
+{
+    fprintf(stderr, "cmfrec_hip: factors_collective_*_multiple: %s is not supported by the HIP build\n", what);
+    return 2;
+}
+
+int_t factors_collective_explicit_multiple(
+    real_t *A, real_t *biasA, int_t m,
+    real_t *U, int_t m_u, int_t p,
+    bool NA_as_zero_U, bool NA_as_zero_X,
+    bool nonneg,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    size_t U_csr_p[], int_t U_csr_i[], real_t *U_csr,
+    real_t *Ub, int_t m_ubin, int_t pbin,
+    real_t *C, real_t *Cb,
+    real_t glob_mean, real_t *biasB,
+    real_t *U_colmeans,
+    real_t *X, int_t ixA[], int_t ixB[], size_t nnz,
+    size_t *Xcsr_p, int_t *Xcsr_i, real_t *Xcsr,
+    real_t *Xfull, int_t n,
+    real_t *weight,
+    real_t *B,
+    real_t *Bi, bool add_implicit_features,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t *lam_unique,
+    real_t l1_lam, real_t *l1_lam_unique,
+    bool scale_lam, bool scale_lam_sideinfo,
+    bool scale_bias_const, real_t scaling_biasA,
+    real_t w_main, real_t w_user, real_t w_implicit,
+    int_t n_max, bool include_all_X,
+    real_t *BtB, real_t *TransBtBinvBt, real_t *BtXbias, real_t *BeTBeChol, real_t *BiTBi,
+    real_t *TransCtCinvCt, real_t *CtCw, real_t *CtUbias, real_t *B_plus_bias,
+    int nthreads)
+{
+    (void)U_row; (void)U_col; (void)U_sp; (void)U_csr_i; (void)U_csr; (void)m_ubin; (void)pbin; (void)Cb; (void)w_implicit;
+    (void)BtB; (void)TransBtBinvBt; (void)BtXbias; (void)BeTBeChol; (void)BiTBi; (void)CtCw; (void)CtUbias; (void)B_plus_bias;
+    (void)nthreads;
+    if (NA_as_zero_U || NA_as_zero_X) return unsupported_multiple("NA_as_zero");
+    if (nonneg) return unsupported_multiple("nonneg");
+    if (nnz_U || U_csr_p) return unsupported_multiple("sparse side information");
+    if (Ub) return unsupported_multiple("binary side information");
+    if (Xfull) return unsupported_multiple("dense X");
+    if (weight) return unsupported_multiple("observation weights");
+    if (Bi || add_implicit_features) return unsupported_multiple("implicit features");
+    if (l1_lam != 0 || l1_lam_unique) return unsupported_multiple("L1 regularisation");
+    if (U == nullptr) { m_u = 0; }
+    if (std::max(m, m_u) <= 0) return 0;
+    if (U) for (size_t e = 0; e < (size_t)m_u * (size_t)p; e++) if (std::isnan(U[e])) return unsupported_multiple("missing values in U");
+    // factors_collective_explicit_single, collective.c:10611-10630
+    real_t lam_bias = lam;
+    if (lam_unique) { lam_bias = lam_unique[biasA ? 0 : 2]; lam = lam_unique[2]; }
+    if (!biasA) scale_bias_const = false;
+    if ((scale_lam || scale_lam_sideinfo) && scale_bias_const) lam_bias *= scaling_biasA;
+    if (w_main != 1) { w_user /= w_main; lam /= w_main; lam_bias /= w_main; }   // collective_factors_warm, :3694-3702
+    // rows without side information and without a bias: the reference passes scale_lam where factors_closed_form
+    // expects scale_bias_const (:3789-3799), so the last factor keeps the unscaled lam
+    if (!biasA) scale_bias_const = scale_lam || scale_lam_sideinfo;
+    // preprocess_vec, :6337-6388: x -= biasB[col] + glob_mean.  The mean goes here, the bias is fused into the gather.
+    const size_t nz = Xcsr_p ? Xcsr_p[m] : nnz;
+    const real_t *vals = Xcsr_p ? Xcsr : X;
+    std::vector<real_t> shifted;
+    if (glob_mean != 0 && nz) {
+        shifted.assign(vals, vals + nz);
+        for (size_t e = 0; e < nz; e++) shifted[e] -= glob_mean;
+        vals = shifted.data();
+    }
+    const int_t n_rows_B = include_all_X ? std::max(n, n_max) : n;
+    int rc = cmfrec_hip_factors_multiple(A, biasA, m, m_u, U ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
+                                         Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n_rows_B, C, biasB, k, k_user, k_item,
+                                         k_main, lam, lam_bias, lam, w_user, false, scale_lam, scale_lam_sideinfo,
+                                         scale_bias_const, nullptr, TransCtCinvCt);
+    return rc > 3 ? 1 : rc;
+}
+
+int_t factors_collective_implicit_multiple(
+    real_t *A, int_t m,
+    real_t *U, int_t m_u, int_t p,
+    bool NA_as_zero_U,
+    bool nonneg,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    size_t U_csr_p[], int_t U_csr_i[], real_t *U_csr,
+    real_t *X, int_t ixA[], int_t ixB[], size_t nnz,
+    size_t *Xcsr_p, int_t *Xcsr_i, real_t *Xcsr,
+    real_t *B, int_t n,
+    real_t *C,
+    real_t *U_colmeans,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t l1_lam, real_t alpha, real_t w_main, real_t w_user,
+    real_t w_main_multiplier,
+    bool apply_log_transf,
+    real_t *BeTBe, real_t *BtB, real_t *BeTBeChol, real_t *CtUbias,
+    int nthreads)
+{
+    (void)U_row; (void)U_col; (void)U_sp; (void)U_csr_i; (void)U_csr; (void)BeTBe; (void)CtUbias; (void)nthreads;
+    if (NA_as_zero_U) return unsupported_multiple("NA_as_zero");
+    if (nonneg) return unsupported_multiple("nonneg");
+    if (nnz_U || U_csr_p) return unsupported_multiple("sparse side information");
+    if (l1_lam != 0) return unsupported_multiple("L1 regularisation");
+    if (U == nullptr) m_u = 0;
+    if (std::max(m, m_u) <= 0) return 0;                                        // rows out: max(m, m_u), collective.c:11210
+    if (U) for (size_t e = 0; e < (size_t)m_u * (size_t)p; e++) if (std::isnan(U[e])) return unsupported_multiple("missing values in U");
+    // BtB as the reference builds it when none is passed: + the lam of the call, before the w_main rescaling
+    // (collective.c:11270-11280; not built for a single row without BeTBeChol either, where the row function does the same)
+    const real_t lam_x = lam;
+    real_t wm = w_main * w_main_multiplier;                                     // collective_factors_warm_implicit, :4000-4004
+    if (wm != 1) { lam /= wm; w_user /= wm; }
+    const size_t nz = Xcsr_p ? Xcsr_p[m] : nnz;
+    const real_t *vals = Xcsr_p ? Xcsr : X;
+    std::vector<real_t> scaled;
+    if ((apply_log_transf || alpha != 1) && nz) {
+        scaled.assign(vals, vals + nz);
+        if (apply_log_transf) for (size_t e = 0; e < nz; e++) scaled[e] = std::log(scaled[e]);   // :10802-10810
+        if (alpha != 1) for (size_t e = 0; e < nz; e++) scaled[e] *= alpha;                      // :4006-4016
+        vals = scaled.data();
+    }
+    // a precomputed BeTBeChol without BtB means the caller's BtB is unknown: rebuild (equal for consistent inputs)
+    (void)BeTBeChol;
+    int rc = cmfrec_hip_factors_multiple(A, nullptr, m, m_u, U ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
+                                         Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n, C, nullptr, k, k_user, k_item, k_main,
+                                         lam, lam, BtB ? lam : lam_x, w_user, true, false, false, false, BtB, nullptr);
+    return rc > 3 ? 1 : rc;
+}
+
 }  // extern "C"

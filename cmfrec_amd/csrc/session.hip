@@ -170,7 +170,6 @@ struct cmfrec_hip_session {
         for (auto &p : evA) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         for (auto &p : evB) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         binA.clear(); binB.clear();
-        if (dev.stream) (void)hipStreamDestroy(dev.stream);
     }
 };
 
@@ -873,7 +872,6 @@ int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t
         dA.download(A, (size_t)m * lda, dev.stream);
         if (BtB_out) dG.download(BtB_out, (size_t)k * k, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
-        HIP_CHECK(hipStreamDestroy(dev.stream));
         return rc;
     });
 }
@@ -904,7 +902,6 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
         }
         dA.download(A, (size_t)m * lda, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
-        HIP_CHECK(hipStreamDestroy(dev.stream));
         return rc;
     });
 }
@@ -935,7 +932,6 @@ int cmfrec_hip_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size
         dA.download(tmp.data(), (size_t)m * lda, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
         for (int r = 0; r < m; r++) memcpy(A + (size_t)r * lda, tmp.data() + (size_t)r * lda, (size_t)k * sizeof(real_t));
-        HIP_CHECK(hipStreamDestroy(dev.stream));
         return rc;
     });
 }
@@ -979,7 +975,6 @@ int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B
         dids.download(out_ids, (size_t)nu * n_top, dev.stream);
         if (out_scores) dsc.download(out_scores, (size_t)nu * n_top, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
-        HIP_CHECK(hipStreamDestroy(dev.stream));
         return 0;
     });
 }
@@ -1014,8 +1009,148 @@ int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size
         int rc = launch_chol(dev, c, &X);
         dA.download(A, (size_t)m * lda, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
-        HIP_CHECK(hipStreamDestroy(dev.stream));
         return rc;
+    });
+}
+
+// Factors of rows that were not part of the fit, all of them in one pass (the step after the path):
+// factors_collective_explicit_multiple (collective.c:10865-11174) / factors_collective_implicit_multiple
+// (:11176-11340) restricted to sparse X (COO or CSR, values already transformed: minus the global mean, times
+// alpha) and dense side information without missing values.  Per row (collective_factors_warm :3555-3964,
+// collective_factors_cold :3309-3440, the *_implicit twins :3442-3553, :3966-4087) this is the closed-form row
+// update of the fit with B (and C) fixed:
+//   explicit, no U:       factors_closed_form on [B | 1]            -> Cholesky mode EXPLICIT
+//   explicit, U, nnz > 0: collective_closed_form_block              -> mode COLLECTIVE
+//   explicit, U, nnz = 0: "cold" (C^T C + (lam/w)(p if scale_lam_sideinfo) I)^-1 C^T u, bias 0; the last of the
+//                         k_user+k unknowns keeps the unscaled lam/w (scale_bias_const := scale_lam_sideinfo in the
+//                         call at :3397-3411); with TransCtCinvCt given it is u^T TransCtCinvCt (:3380-3386)
+//   implicit:             factors_implicit_chol / collective_closed_form_block_implicit -> modes IMPLICIT /
+//                         COLLECTIVE_IMPLICIT; lam_x is what sits on the diagonal of the X block (the reference adds
+//                         the *unscaled* lam there when it builds BtB itself, :11270-11280, and lam / w_main on the
+//                         k_user block), BtB_pre (lam included) replaces B^T B + lam_x I when given.
+int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U,
+                                const real_t *U_colmeans, const int_t ixA[], const int_t ixB[], const real_t *X,
+                                size_t nnz, const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                const real_t *B, int_t n, const real_t *C, const real_t *biasB, int_t k, int_t k_user,
+                                int_t k_item, int_t k_main, real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
+                                bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+                                const real_t *BtB_pre, const real_t *TransCtCinvCt_pre)
+{
+    return guarded([&]() {
+        const int m_max = std::max(m_x, (p > 0 && U) ? m_u : 0);
+        if (m_max <= 0) return 0;
+        if (!A || !B || n <= 0 || k < 0 || (p > 0 && U && !C) || (nnz > 0 && !Xcsr_p && (!ixA || !ixB || !X)) ||
+            (implicit && biasA)) {
+            g_last_error = "cmfrec_hip_factors_multiple: invalid arguments";
+            return 2;
+        }
+        if (!(p > 0 && U)) { p = 0; m_u = 0; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        hipStream_t st = dev.stream;
+        const int ub = biasA ? 1 : 0;
+        const int kc = k_user + k, kk = k + k_main, kt = k_user + kk + ub, ktA = k_user + kk;
+        const size_t ldb_host = (size_t)(k_item + kk), ldB = ldb_host + ub, ldA = (size_t)kt;
+        DevBuf<real_t> dA, dB, dC, dU, dmeans, dbias, dG, dM, dCtC, dcold, dT;
+        GramWorkspace gws;
+        SparseShard Xs;
+        dB.alloc((size_t)n * ldB);
+        HIP_CHECK(hipMemcpy2DAsync(dB.ptr, ldB * sizeof(real_t), B, ldb_host * sizeof(real_t), ldb_host * sizeof(real_t),
+                                   (size_t)n, hipMemcpyHostToDevice, st));
+        if (ub) hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(n), dim3(256), 0, st, dB.ptr, ldB, n, (int)ldb_host, (real_t)1);
+        if (biasB) dbias.upload(biasB, (size_t)n, st);
+        dA.alloc((size_t)m_max * ldA);
+        HIP_CHECK(hipMemsetAsync(dA.ptr, 0, dA.n * sizeof(real_t), st));
+        if (Xcsr_p) {
+            std::vector<size_t> pp((size_t)m_max + 1);
+            for (int r = 0; r <= m_max; r++) pp[r] = Xcsr_p[std::min(r, m_x)];
+            shard_from_csr(Xs, m_max, pp.data(), Xcsr_i, Xcsr, n, st);
+        } else if (nnz == 0) {
+            std::vector<size_t> pp((size_t)m_max + 1, 0);
+            shard_from_csr(Xs, m_max, pp.data(), nullptr, nullptr, n, st);
+        } else {
+            DevBuf<int> dr, dc; DevBuf<real_t> dv;
+            dr.upload(ixA, std::max<size_t>(nnz, 1), st); dc.upload(ixB, std::max<size_t>(nnz, 1), st);
+            dv.upload(X, std::max<size_t>(nnz, 1), st);
+            shard_from_coo(Xs, m_max, n, dr.ptr, dc.ptr, dv.ptr, nnz, (real_t)0, (real_t)1, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (p > 0) {
+            dC.upload(C, (size_t)p * kc, st);
+            dU.upload(U, (size_t)m_u * p, st);
+            if (U_colmeans) {
+                dmeans.upload(U_colmeans, (size_t)p, st);
+                hipLaunchKernelGGL(sub_colmeans_kernel<real_t>, grid1d((size_t)m_u * p), dim3(256), 0, st, dU.ptr, (size_t)m_u, p,
+                                   dmeans.ptr);
+            }
+            dCtC.alloc((size_t)kc * kc);
+        }
+        const real_t *opp = dB.ptr + k_item;
+        const real_t *bias_sub = biasB ? dbias.ptr : nullptr;
+        int rc = 0;
+        if (implicit) {
+            dG.alloc((size_t)kk * kk);
+            if (BtB_pre) dG.upload(BtB_pre, (size_t)kk * kk, st);
+            else launch_gram(dev, gws, opp, ldB, n, kk, dG.ptr, (real_t)1, lam_x);
+            if (p == 0) {
+                CholCall c{dA.ptr + k_user, ldA, opp, ldB, kk, 0, nullptr, dG.ptr, 0, 0, 0, lam, lam, false, false, false,
+                           CHOL_IMPLICIT};
+                rc = launch_chol(dev, c, &Xs);
+            } else {
+                dM.alloc((size_t)ktA * ktA);
+                hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)ktA * ktA), dim3(256), 0, st, dG.ptr, kk, k_user, lam,
+                                   dM.ptr);
+                launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dCtC.ptr, w_user, (real_t)0);
+                launch_gemm<false>(dev, m_u, kc, p, w_user, dU.ptr, (size_t)p, dC.ptr, (size_t)kc, dA.ptr, ldA);
+                CholCall c{dA.ptr, ldA, opp, ldB, ktA, k_user, nullptr, dCtC.ptr, kc, m_u, p, lam, lam, false, false, false,
+                           CHOL_COLLECTIVE_IMPLICIT, dM.ptr};
+                rc = launch_chol(dev, c, &Xs);
+            }
+        } else if (p == 0) {
+            CholCall c{dA.ptr + k_user, ldA, opp, ldB, kk + ub, 0, bias_sub, nullptr, 0, 0, 0, lam, lam_bias,
+                       (bool)(scale_lam || scale_lam_sideinfo), false, scale_bias_const, CHOL_EXPLICIT};
+            rc = launch_chol(dev, c, &Xs);
+        } else {
+            launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dCtC.ptr, w_user, (real_t)0);
+            launch_gemm<false>(dev, m_u, kc, p, w_user, dU.ptr, (size_t)p, dC.ptr, (size_t)kc, dA.ptr, ldA);
+            CholCall c{dA.ptr, ldA, opp, ldB, kt, k_user, bias_sub, dCtC.ptr, kc, m_u, p, lam, lam_bias,
+                       (bool)(scale_lam || scale_lam_sideinfo), scale_lam_sideinfo, scale_bias_const, CHOL_COLLECTIVE};
+            rc = launch_chol(dev, c, &Xs);
+            if (rc == 0) {
+                // cold rows
+                dcold.alloc((size_t)m_u * kc);
+                if (TransCtCinvCt_pre) {
+                    dT.upload(TransCtCinvCt_pre, (size_t)p * kc, st);
+                    launch_gemm<false>(dev, m_u, kc, p, (real_t)1, dU.ptr, (size_t)p, dT.ptr, (size_t)kc, dcold.ptr, (size_t)kc);
+                } else {
+                    dM.alloc((size_t)kc * kc);
+                    const real_t lc = lam / w_user;
+                    launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dM.ptr, (real_t)1, scale_lam_sideinfo ? lc * (real_t)p : lc);
+                    if (scale_lam_sideinfo)
+                        hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3(1), dim3(64), 0, st, dM.ptr, kc, kc - 1, kc,
+                                           lc - lc * (real_t)p);
+                    launch_gemm<false>(dev, m_u, kc, p, (real_t)1, dU.ptr, (size_t)p, dC.ptr, (size_t)kc, dcold.ptr, (size_t)kc);
+                    CholCall cc{dcold.ptr, (size_t)kc, nullptr, 0, kc, 0, nullptr, dM.ptr, 0, 0, 0, 0, 0, false, false, false,
+                                CHOL_PREFILLED};
+                    rc = launch_chol(dev, cc, nullptr, m_u);
+                }
+                hipLaunchKernelGGL(cold_select_kernel<real_t>, dim3(m_u), dim3(64), 0, st, dA.ptr, ldA, kt, kc, dcold.ptr,
+                                   Xs.p.ptr, m_u);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        if (rc) return rc;
+        HIP_CHECK(hipMemcpy2DAsync(A, (size_t)ktA * sizeof(real_t), dA.ptr, ldA * sizeof(real_t), (size_t)ktA * sizeof(real_t),
+                                   (size_t)m_max, hipMemcpyDeviceToHost, st));
+        if (ub) {
+            DevBuf<real_t> dba;
+            dba.alloc((size_t)m_max);
+            hipLaunchKernelGGL(col_extract_kernel<real_t>, grid1d(m_max), dim3(256), 0, st, dA.ptr, ldA, m_max, ktA, dba.ptr);
+            dba.download(biasA, (size_t)m_max, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
     });
 }
 
@@ -1062,7 +1197,6 @@ extern "C" int cmfrec_hip_selftest_lanes(void)
         std::vector<real_t> h(15 * 64);
         d.download(h.data(), h.size(), dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
-        HIP_CHECK(hipStreamDestroy(dev.stream));
         auto X = [](int l) { return (double)(l * 3 + 1); };
         auto Y = [](int l) { return (double)(1000 + l); };
         bad = 0;

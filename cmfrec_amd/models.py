@@ -65,6 +65,22 @@ def _topN(self, users, n, exclude, biasB):
     return ops.topN_batch(A, B, n_top=n, biasB=biasB, exclude=excl)
 
 
+def _new_rows(X, n, dt):
+    """COO triplet of new rows: ``X`` is a SciPy sparse matrix [m_x, n], a (row, col, val) triplet or None."""
+    if X is None:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, dt), 0
+    if isinstance(X, tuple):
+        row, col, val = X
+        m_x = int(np.max(row)) + 1 if len(row) else 0
+    else:
+        X = X.tocoo()
+        if X.shape[1] > n:
+            raise ValueError("'X' has more columns than the model has items")
+        row, col, val, m_x = X.row, X.col, X.data, X.shape[0]
+    return (np.ascontiguousarray(row, np.int32), np.ascontiguousarray(col, np.int32),
+            np.ascontiguousarray(val, dt), int(m_x))
+
+
 class CMF_implicit(_Base):
     """Implicit-feedback model (iALS / WRMF), reference class ``CMF_implicit``."""
 
@@ -144,6 +160,34 @@ class CMF_implicit(_Base):
         self._BeTBeChol = BeTBeChol if BeTBeChol is not None else e
         self.is_fitted_ = True
         return self
+
+    def factors_multiple(self, X=None, U=None):
+        """Factors of new users from their interactions ``X`` [m_x, n] (sparse) and / or dense attributes ``U`` [m_u, p]
+        (reference ``CMF_implicit.factors_multiple``, cmfrec/__init__.py:5313; C function
+        factors_collective_implicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main]."""
+        if X is None and U is None:
+            raise ValueError("Must pass at least one of 'X', 'U'.")
+        lib, R = self._lib()
+        dt = self.dtype_
+        n = self.B_.shape[0]
+        row, col, val, m_x = _new_rows(X, n, dt)
+        Uc = None if (U is None or not self.C_.shape[0]) else np.ascontiguousarray(U, dt)
+        m_u, p = (0, 0) if Uc is None else Uc.shape
+        A = np.empty((max(m_x, m_u), self.k_user + self.k + self.k_main), dt)
+        has = lambda M: M is not None and M.shape[0] > 0
+        rc = lib.factors_collective_implicit_multiple(
+            _lib.ptr(A), C.c_int(m_x), _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(False),
+            None, None, None, C.c_size_t(0), None, None, None,
+            _lib.ptr(val), _lib.ptr(row), _lib.ptr(col), C.c_size_t(len(val)), None, None, None,
+            _lib.ptr(self.B_), C.c_int(n), _lib.ptr(self.C_) if p else None,
+            _lib.ptr(self._U_colmeans) if (p and len(self._U_colmeans)) else None,
+            C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
+            R(self.lambda_), R(0.), R(self.alpha), R(self.w_main), R(self.w_user), R(self._w_main_multiplier),
+            C.c_bool(self.apply_log_transf),
+            _lib.ptr(self._BeTBe) if has(self._BeTBe) else None, _lib.ptr(self._BtB) if has(self._BtB) else None,
+            _lib.ptr(self._BeTBeChol) if has(self._BeTBeChol) else None, None, C.c_int(self.nthreads))
+        _lib.check(rc, lib, "factors_collective_implicit_multiple")
+        return A
 
     def topN_batch(self, users, n=10, exclude=None):
         """Top-``n`` item ids and scores (A_u . B_i) for a batch of users, ranked on the GPU; ``exclude``: CSR of items
@@ -254,6 +298,43 @@ class CMF(_Base):
         self._U_colmeans, self._I_colmeans = Ucm[:p], Icm[:q]
         self.is_fitted_ = True
         return self
+
+    def factors_multiple(self, X=None, U=None, return_bias=False):
+        """Factors (and bias) of new users from their ratings ``X`` [m_x, n] (sparse) and / or dense attributes ``U``
+        [m_u, p] (reference ``CMF.factors_multiple``, cmfrec/__init__.py:3706; C function
+        factors_collective_explicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main], or ``(A, bias)``."""
+        if X is None and U is None:
+            raise ValueError("Must pass at least one of 'X', 'U'.")
+        lib, R = self._lib()
+        dt = self.dtype_
+        n = self.B_.shape[0]
+        row, col, val, m_x = _new_rows(X, n, dt)
+        Uc = None if (U is None or not self.C_.shape[0]) else np.ascontiguousarray(U, dt)
+        m_u, p = (0, 0) if Uc is None else Uc.shape
+        mm = max(m_x, m_u)
+        A = np.empty((mm, self.k_user + self.k + self.k_main), dt)
+        biasA = np.empty(mm, dt) if self.user_bias else None
+        has = lambda M: M is not None and M.shape[0] > 0
+        rc = lib.factors_collective_explicit_multiple(
+            _lib.ptr(A), _lib.ptr(biasA), C.c_int(m_x), _lib.ptr(Uc), C.c_int(m_u), C.c_int(p),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            None, None, None, C.c_size_t(0), None, None, None, None, C.c_int(0), C.c_int(0),
+            _lib.ptr(self.C_) if p else None, None, R(self.glob_mean_),
+            _lib.ptr(self.item_bias_) if self.item_bias else None,
+            _lib.ptr(self._U_colmeans) if (p and len(self._U_colmeans)) else None,
+            _lib.ptr(val), _lib.ptr(row), _lib.ptr(col), C.c_size_t(len(val)), None, None, None,
+            None, C.c_int(n), None, _lib.ptr(self.B_), None, C.c_bool(False),
+            C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
+            R(self.lambda_), None, R(0.), None, C.c_bool(self.scale_lam), C.c_bool(self.scale_lam_sideinfo),
+            C.c_bool(False), R(1.), R(self.w_main), R(self.w_user), R(self.w_implicit),
+            C.c_int(n), C.c_bool(True),
+            None, None, None, None, None,
+            _lib.ptr(self._TransCtCinvCt) if (p and has(self._TransCtCinvCt)) else None, None, None, None,
+            C.c_int(self.nthreads))
+        _lib.check(rc, lib, "factors_collective_explicit_multiple")
+        if return_bias:
+            return A, biasA
+        return A
 
     def topN_batch(self, users, n=10, exclude=None):
         """Top-``n`` item ids and scores for a batch of users, ranked on the GPU by A_u . B_i + item_bias[i] (the user

@@ -168,6 +168,82 @@ int cmfrec_hip_optimizeA_collective(
     real_t lam, real_t w_user, real_t lam_last,
     bool scale_lam, bool scale_lam_sideinfo);
 
+/* Factors of rows that were not part of the fit, one batched pass (level 2 under the two drop-in entry points below):
+ * the closed-form row update of the fit with B (and C) fixed -- collective_factors_warm / _cold and their implicit
+ * twins, src/collective.c:3309-4087.  X: COO (ixA, ixB, X, nnz) or CSR (Xcsr_*, m_x+1 offsets), values already
+ * shifted by the global mean / scaled by alpha; biasB is subtracted inside the gather.  U raw, U_colmeans subtracted on
+ * the device.  A is [max(m_x, m_u), k_user+k+k_main], biasA (optional) one value per row.  lam_x: what the implicit
+ * model puts on the diagonal of the X block (see factors_collective_implicit_multiple below); BtB_pre (implicit,
+ * lam included) and TransCtCinvCt_pre ([p, k_user+k]) replace the matrices otherwise rebuilt from B and C. */
+int cmfrec_hip_factors_multiple(
+    real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U, const real_t *U_colmeans,
+    const int_t ixA[], const int_t ixB[], const real_t *X, size_t nnz,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+    const real_t *B, int_t n, const real_t *C, const real_t *biasB,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
+    bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+    const real_t *BtB_pre, const real_t *TransCtCinvCt_pre);
+
+/* Replace factors_collective_explicit_multiple / factors_collective_implicit_multiple,
+ * /root/reference/src/cmfrec.h:2004-2047 and :2048-2071 (bodies src/collective.c:10865-11174, :11176-11340): same
+ * positional parameters, same return codes (0 ok, 1 out of memory, 2 invalid / unsupported).  Supported: sparse X
+ * (COO or CSR), dense U without NaN (rows beyond m get the side-information-only solution, rows beyond m_u the plain
+ * one), user bias, lam_unique, scale_lam / scale_lam_sideinfo / scale_bias_const, w_main / w_user, alpha and
+ * apply_log_transf.  NA_as_zero, nonneg, L1, weights, dense X, sparse or binary side information and implicit
+ * features return 2.  Of the precomputed matrices only BtB (implicit) and TransCtCinvCt (explicit) are read -- the
+ * ones that change the result; the others are rebuilt on the device from B and C.
+ * Two details of the reference that are kept: (1) without a precomputed BtB the implicit version puts the lam of the
+ * call, *not* lam / w_main, on the diagonal of the X block (collective.c:11270-11280) while the k_user block gets
+ * lam / w_main; (2) the side-information-only solution of the explicit version under scale_lam_sideinfo scales lam by
+ * p on all but the last of the k_user+k unknowns (:3397-3411). */
+int_t factors_collective_explicit_multiple(
+    real_t *A, real_t *biasA, int_t m,
+    real_t *U, int_t m_u, int_t p,
+    bool NA_as_zero_U, bool NA_as_zero_X,
+    bool nonneg,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    size_t U_csr_p[], int_t U_csr_i[], real_t *U_csr,
+    real_t *Ub, int_t m_ubin, int_t pbin,
+    real_t *C, real_t *Cb,
+    real_t glob_mean, real_t *biasB,
+    real_t *U_colmeans,
+    real_t *X, int_t ixA[], int_t ixB[], size_t nnz,
+    size_t *Xcsr_p, int_t *Xcsr_i, real_t *Xcsr,
+    real_t *Xfull, int_t n,
+    real_t *weight,
+    real_t *B,
+    real_t *Bi, bool add_implicit_features,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t *lam_unique,
+    real_t l1_lam, real_t *l1_lam_unique,
+    bool scale_lam, bool scale_lam_sideinfo,
+    bool scale_bias_const, real_t scaling_biasA,
+    real_t w_main, real_t w_user, real_t w_implicit,
+    int_t n_max, bool include_all_X,
+    real_t *BtB, real_t *TransBtBinvBt, real_t *BtXbias, real_t *BeTBeChol, real_t *BiTBi,
+    real_t *TransCtCinvCt, real_t *CtCw, real_t *CtUbias, real_t *B_plus_bias,
+    int nthreads);
+
+int_t factors_collective_implicit_multiple(
+    real_t *A, int_t m,
+    real_t *U, int_t m_u, int_t p,
+    bool NA_as_zero_U,
+    bool nonneg,
+    int_t U_row[], int_t U_col[], real_t *U_sp, size_t nnz_U,
+    size_t U_csr_p[], int_t U_csr_i[], real_t *U_csr,
+    real_t *X, int_t ixA[], int_t ixB[], size_t nnz,
+    size_t *Xcsr_p, int_t *Xcsr_i, real_t *Xcsr,
+    real_t *B, int_t n,
+    real_t *C,
+    real_t *U_colmeans,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t l1_lam, real_t alpha, real_t w_main, real_t w_user,
+    real_t w_main_multiplier,
+    bool apply_log_transf,
+    real_t *BeTBe, real_t *BtB, real_t *BeTBeChol, real_t *CtUbias,
+    int nthreads);
+
 /* ============================ level 3: device-resident session ============================= */
 
 typedef struct cmfrec_hip_session cmfrec_hip_session;

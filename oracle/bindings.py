@@ -148,6 +148,46 @@ class Oracle:
                                                    C.c_bool(scale_lam), _ptr(biasA), _ptr(biasB))
         return biasA, biasB
 
+    def factors_explicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, biasB=None,
+                                  glob_mean=0.0, user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0,
+                                  k_item=0, scale_lam=False, scale_lam_sideinfo=False, scale_bias_const=False,
+                                  scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, TransCtCinvCt=None):
+        """Restatement of factors_collective_explicit_multiple; same arguments as Reference.factors_explicit_multiple."""
+        n = B.shape[0]
+        csr, _ = self.coo_to_csr_and_csc(row, col, val, m, n)
+        m_u = 0 if U is None else U.shape[0]
+        p = 0 if U is None else U.shape[1]
+        mm = max(m, m_u)
+        A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
+        biasA = np.full(mm, np.nan, self.dtype) if user_bias else None
+        Uc = None if U is None else np.ascontiguousarray(U, self.dtype)
+        self.lib.oracle_factors_explicit_multiple(
+            _ptr(A), _ptr(biasA), C.c_int(m), _ptr(Uc), C.c_int(m_u), C.c_int(p), _ptr(Cm),
+            self._r(glob_mean), _ptr(biasB), _ptr(U_colmeans), _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]),
+            C.c_int(n), _ptr(B), C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
+            self._r(lam), self._r(lam if lam_bias is None else lam_bias),
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), self._r(scaling_biasA),
+            self._r(w_main), self._r(w_user), _ptr(TransCtCinvCt), C.c_int(nthreads))
+        return A, biasA
+
+    def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0,
+                                  alpha=1.0, k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0,
+                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None):
+        """Restatement of factors_collective_implicit_multiple; same arguments as Reference.factors_implicit_multiple."""
+        n = B.shape[0]
+        csr, _ = self.coo_to_csr_and_csc(row, col, val, m, n)
+        m_u = 0 if U is None else U.shape[0]
+        p = 0 if U is None else U.shape[1]
+        A = np.full((max(m, m_u), k_user + k + k_main), np.nan, self.dtype)
+        Uc = None if U is None else np.ascontiguousarray(U, self.dtype)
+        self.lib.oracle_factors_implicit_multiple(
+            _ptr(A), C.c_int(m), _ptr(Uc), C.c_int(m_u), C.c_int(p), _ptr(Cm), _ptr(U_colmeans),
+            _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]), C.c_int(n), _ptr(B),
+            C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
+            self._r(lam), self._r(alpha), self._r(w_main), self._r(w_user), self._r(w_main_multiplier),
+            C.c_bool(apply_log_transf), _ptr(BtB), C.c_int(nthreads))
+        return A
+
     def fit_implicit_als(self, A, B, row, col, val, lam=1.0, alpha=1.0, apply_log_transf=False,
                          niter=10, nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                          finalize_chol=False):
@@ -323,6 +363,77 @@ class Reference:
             None, None, None, None, None,
             C.byref(flags[0]), C.byref(flags[1]), C.byref(flags[2]), C.byref(flags[3]), C.byref(flags[4]),
             _ptr(buf), None)
+
+    def factors_explicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, biasB=None,
+                                  glob_mean=0.0, user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0,
+                                  k_item=0, scale_lam=False, scale_lam_sideinfo=False, scale_bias_const=False,
+                                  scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, n=None, TransCtCinvCt=None):
+        """factors_collective_explicit_multiple (src/cmfrec.h:2004-2047, collective.c:10865-11174): sparse X of the
+        new rows as COO, optional dense U.  Returns (A, biasA or None)."""
+        n_max, ldb = B.shape
+        n = n_max if n is None else n
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype).copy()
+        nnz = len(val)
+        m_u = 0 if U is None else U.shape[0]
+        p = 0 if U is None else U.shape[1]
+        mm = max(m, m_u)
+        A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
+        biasA = np.full(mm, np.nan, self.dtype) if user_bias else None
+        lam_unique = None
+        if lam_bias is not None and lam_bias != lam:
+            lam_unique = np.zeros(6, self.dtype); lam_unique[0] = lam_bias; lam_unique[2] = lam
+        Uc = None if U is None else np.ascontiguousarray(U, self.dtype).copy()
+        rc = self.lib.factors_collective_explicit_multiple(
+            _ptr(A), _ptr(biasA), C.c_int(m),
+            _ptr(Uc), C.c_int(m_u), C.c_int(p),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            None, None, None, C.c_size_t(0), None, None, None,
+            None, C.c_int(0), C.c_int(0),
+            _ptr(Cm), None,
+            self._r(glob_mean), _ptr(biasB), _ptr(U_colmeans),
+            _ptr(val), _ptr(row), _ptr(col), C.c_size_t(nnz),
+            None, None, None,
+            None, C.c_int(n), None,
+            _ptr(B), None, C.c_bool(False),
+            C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
+            self._r(lam), _ptr(lam_unique), self._r(0.), None,
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), self._r(scaling_biasA),
+            self._r(w_main), self._r(w_user), self._r(1.),
+            C.c_int(n_max), C.c_bool(True),
+            None, None, None, None, None, _ptr(TransCtCinvCt), None, None, None,
+            C.c_int(nthreads))
+        assert rc == 0, rc
+        return A, biasA
+
+    def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0,
+                                  alpha=1.0, k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0,
+                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None):
+        """factors_collective_implicit_multiple (src/cmfrec.h:2048-2071, collective.c:11176-11340)."""
+        n, ldb = B.shape
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype).copy()
+        nnz = len(val)
+        m_u = 0 if U is None else U.shape[0]
+        p = 0 if U is None else U.shape[1]
+        mm = max(m, m_u)
+        A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
+        Uc = None if U is None else np.ascontiguousarray(U, self.dtype).copy()
+        rc = self.lib.factors_collective_implicit_multiple(
+            _ptr(A), C.c_int(m),
+            _ptr(Uc), C.c_int(m_u), C.c_int(p),
+            C.c_bool(False), C.c_bool(False),
+            None, None, None, C.c_size_t(0), None, None, None,
+            _ptr(val), _ptr(row), _ptr(col), C.c_size_t(nnz),
+            None, None, None,
+            _ptr(B), C.c_int(n), _ptr(Cm), _ptr(U_colmeans),
+            C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
+            self._r(lam), self._r(0.), self._r(alpha), self._r(w_main), self._r(w_user), self._r(w_main_multiplier),
+            C.c_bool(apply_log_transf),
+            None, _ptr(BtB), None, None,
+            C.c_int(nthreads))
+        assert rc == 0, rc
+        return A
 
     def calc_mean_and_center(self, row, col, X, m, n, nthreads=1):
         """Returns (glob_mean, centred copy of X)."""

@@ -1015,3 +1015,202 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Factors of new rows. */
+void oracle_factors_explicit_multiple(real_t *A, real_t *biasA, int_t m,
+                                      const real_t *U, int_t m_u, int_t p, const real_t *C,
+                                      real_t glob_mean, const real_t *biasB, const real_t *U_colmeans,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      int_t n, const real_t *B,
+                                      int_t k, int_t k_user, int_t k_item, int_t k_main,
+                                      real_t lam, real_t lam_bias,
+                                      bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const, real_t scaling_biasA,
+                                      real_t w_main, real_t w_user, const real_t *TransCtCinvCt, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (U == NULL || p <= 0) { m_u = 0; p = 0; }
+    const int_t m_max = m > m_u ? m : m_u;
+    const int_t ub = biasA != NULL;
+    const int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main + ub, kt = k_totA + ub;
+    const size_t ldb0 = (size_t)(k_item + k + k_main), ldb = ldb0 + (size_t)ub;
+    /* factors_collective_explicit_single :10611-10630 */
+    if (!ub) scale_bias_const = false;
+    if ((scale_lam || scale_lam_sideinfo) && scale_bias_const) lam_bias *= scaling_biasA;
+    /* append_ones_last_col, :10927-10937 */
+    real_t *Bp = (real_t *)malloc((size_t)n * ldb * sizeof(real_t));
+    for (int_t j = 0; j < n; j++) {
+        memcpy(Bp + (size_t)j * ldb, B + (size_t)j * ldb0, ldb0 * sizeof(real_t));
+        if (ub) Bp[(size_t)j * ldb + ldb0] = 1;
+    }
+    /* cold rows: lam / w_user on C^T C (collective_factors_cold :3353-3357, :3397-3411) */
+    const real_t lam_cold = lam / w_user;
+    /* collective_factors_warm :3694-3702 */
+    real_t lam_w = lam, lam_bias_w = lam_bias, w_user_w = w_user;
+    if (w_main != 1) { w_user_w /= w_main; lam_w /= w_main; lam_bias_w /= w_main; }
+    real_t *CtC = NULL;
+    if (p > 0) {
+        CtC = (real_t *)calloc((size_t)k_totC * k_totC + 1, sizeof(real_t));
+        oracle_gram(C, (size_t)k_totC, p, k_totC, CtC, nthreads);
+    }
+    size_t maxnnz = 1;
+    for (int_t i = 0; i < m; i++) if (Xcsr_p[i + 1] - Xcsr_p[i] > maxnnz) maxnnz = Xcsr_p[i + 1] - Xcsr_p[i];
+    const size_t szbuf = (size_t)kt * kt + (size_t)kt + maxnnz + (size_t)(p > 0 ? p : 1);
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    const bool sl = scale_lam || scale_lam_sideinfo;                           /* :3631 */
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m_max; ix++) {
+        real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
+        real_t *M = buf, *sol = buf + (size_t)kt * kt, *x = sol + kt, *u = x + maxnnz;
+        real_t *a = A + (size_t)ix * k_totA;
+        const size_t st = ix < m ? Xcsr_p[ix] : 0, en = ix < m ? Xcsr_p[(size_t)ix + 1] : 0, nnz = en - st;
+        const bool has_u = ix < m_u;
+        memset(a, 0, (size_t)k_totA * sizeof(real_t));
+        if (ub) biasA[ix] = 0;
+        if (nnz == 0 && !has_u) continue;                                      /* :3634-3650 */
+        for (size_t jx = 0; jx < nnz; jx++)                                    /* preprocess_vec :6337-6388 */
+            x[jx] = Xcsr[st + jx] - (biasB ? (biasB[Xcsr_i[st + jx]] + glob_mean) : glob_mean);
+        if (has_u) for (int_t c = 0; c < p; c++) u[c] = U[(size_t)ix * p + c] - (U_colmeans ? U_colmeans[c] : 0);
+        if (nnz == 0) {                                                        /* cold, :3309-3440 */
+            if (TransCtCinvCt != NULL) {
+                for (int_t c = 0; c < k_totC; c++) {
+                    double s = 0;
+                    for (int_t j = 0; j < p; j++) s += (double)u[j] * (double)TransCtCinvCt[(size_t)j * k_totC + c];
+                    a[c] = (real_t)s;
+                }
+                continue;
+            }
+            for (int_t c = 0; c < k_totC; c++) {
+                double s = 0;
+                for (int_t j = 0; j < p; j++) s += (double)u[j] * (double)C[(size_t)j * k_totC + c];
+                sol[c] = (real_t)s;
+            }
+            for (int_t i = 0; i < k_totC; i++)
+                for (int_t j = 0; j < k_totC; j++) M[(size_t)i * k_totC + j] = CtC[(size_t)i * k_totC + j];
+            /* factors_closed_form with scale_lam = scale_bias_const = scale_lam_sideinfo: lam * p on all but the last */
+            for (int_t i = 0; i < k_totC; i++)
+                M[(size_t)i * k_totC + i] += (scale_lam_sideinfo && i < k_totC - 1) ? lam_cold * (real_t)p : lam_cold;
+            if (chol_upper_(k_totC, M, k_totC) == 0) chol_solve_upper_(k_totC, M, k_totC, sol);
+            else for (int_t i = 0; i < k_totC; i++) sol[i] = NAN;
+            memcpy(a, sol, (size_t)k_totC * sizeof(real_t));
+            continue;
+        }
+        if (!has_u) {                                                          /* factors_closed_form, :3772-3815 */
+            /* without a bias the call passes scale_lam in the place of scale_bias_const (:3789-3799), so the last
+             * factor keeps the unscaled lam */
+            real_t lam_i = lam_w, lam_last_i = ub ? lam_bias_w : lam_w;
+            if (sl) {
+                lam_i *= (real_t)nnz;
+                if (ub && !scale_bias_const) lam_last_i *= (real_t)nnz;
+            }
+            explicit_chol_row(sol, kb, Bp + k_item, ldb, x, Xcsr_i + st, nnz, lam_i, lam_last_i, M);
+            memcpy(a + k_user, sol, (size_t)(k + k_main) * sizeof(real_t));
+            if (ub) biasA[ix] = sol[k + k_main];
+            continue;
+        }
+        /* collective_closed_form_block on [B | 1], :3866-3930 -> :1223-1847 */
+        real_t mult = 1;
+        if (sl) { mult = (real_t)nnz; if (scale_lam_sideinfo) mult += (real_t)p; }
+        memset(M, 0, (size_t)kt * kt * sizeof(real_t));
+        memset(sol, 0, (size_t)kt * sizeof(real_t));
+        for (int_t i = 0; i < k_totC; i++)
+            for (int_t j = 0; j < k_totC; j++) M[(size_t)i * kt + j] = w_user_w * CtC[(size_t)i * k_totC + j];
+        for (int_t c = 0; c < k_totC; c++) {
+            double s = 0;
+            for (int_t j = 0; j < p; j++) s += (double)u[j] * (double)C[(size_t)j * k_totC + c];
+            sol[c] = (real_t)((double)w_user_w * s);
+        }
+        real_t *Mlr = M + (size_t)k_user + (size_t)k_user * kt;
+        for (size_t jx = 0; jx < nnz; jx++)
+            syr_upper_(kb, (real_t)1, Bp + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, Mlr, kt);
+        for (size_t jx = 0; jx < nnz; jx++)
+            axpy_(kb, x[jx], Bp + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, sol + k_user);
+        for (int_t i = 0; i < kt - 1; i++) M[(size_t)i * kt + i] += lam_w * mult;
+        M[(size_t)(kt - 1) * kt + (kt - 1)] += (ub ? lam_bias_w : lam_w) * mult;
+        if (chol_upper_(kt, M, kt) == 0) chol_solve_upper_(kt, M, kt, sol);
+        else for (int_t i = 0; i < kt; i++) sol[i] = NAN;
+        memcpy(a, sol, (size_t)k_totA * sizeof(real_t));
+        if (ub) biasA[ix] = sol[k_totA];
+    }
+    free(bufs); free(Bp); free(CtC);
+}
+
+void oracle_factors_implicit_multiple(real_t *A, int_t m,
+                                      const real_t *U, int_t m_u, int_t p, const real_t *C, const real_t *U_colmeans,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      int_t n, const real_t *B,
+                                      int_t k, int_t k_user, int_t k_item, int_t k_main,
+                                      real_t lam, real_t alpha, real_t w_main, real_t w_user, real_t w_main_multiplier,
+                                      bool apply_log_transf, const real_t *BtB_in, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (U == NULL || p <= 0) { m_u = 0; p = 0; }
+    const int_t m_max = m > m_u ? m : m_u;
+    const int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main;
+    const size_t ldb = (size_t)(k_item + k + k_main);
+    /* :11270-11280: BtB + lam I with the lam of the call */
+    real_t *BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
+    if (BtB_in) memcpy(BtB, BtB_in, (size_t)kb * kb * sizeof(real_t));
+    else {
+        oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
+        for (int_t i = 0; i < kb; i++) BtB[(size_t)i * kb + i] += lam;
+    }
+    /* collective_factors_warm_implicit :4000-4004 (and _cold_implicit :3490-3497) */
+    real_t wm = w_main * w_main_multiplier;
+    if (wm != 1) { lam /= wm; w_user /= wm; }
+    real_t *CtC = NULL;
+    if (p > 0) {
+        CtC = (real_t *)calloc((size_t)k_totC * k_totC + 1, sizeof(real_t));
+        oracle_gram(C, (size_t)k_totC, p, k_totC, CtC, nthreads);
+    }
+    size_t maxnnz = 1;
+    for (int_t i = 0; i < m; i++) if (Xcsr_p[i + 1] - Xcsr_p[i] > maxnnz) maxnnz = Xcsr_p[i + 1] - Xcsr_p[i];
+    const size_t szbuf = (size_t)k_totA * k_totA + maxnnz + (size_t)(p > 0 ? p : 1);
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int_t ix = 0; ix < m_max; ix++) {
+        real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
+        real_t *M = buf, *x = buf + (size_t)k_totA * k_totA, *u = x + maxnnz;
+        real_t *a = A + (size_t)ix * k_totA;
+        const size_t st = ix < m ? Xcsr_p[ix] : 0, en = ix < m ? Xcsr_p[(size_t)ix + 1] : 0, nnz = en - st;
+        const bool has_u = ix < m_u;
+        memset(a, 0, (size_t)k_totA * sizeof(real_t));
+        if (nnz == 0 && !has_u) continue;
+        for (size_t jx = 0; jx < nnz; jx++) {
+            real_t v = Xcsr[st + jx];
+            if (apply_log_transf) v = (real_t)log((double)v);                  /* :10802-10810 */
+            x[jx] = (alpha != 1) ? v * alpha : v;                              /* :4006-4016 */
+        }
+        if (!has_u) {                                                          /* factors_implicit_chol, :4057-4067 */
+            for (int_t i = 0; i < kb; i++) memcpy(M + (size_t)i * kb, BtB + (size_t)i * kb, (size_t)kb * sizeof(real_t));
+            for (size_t jx = 0; jx < nnz; jx++)
+                axpy_(kb, x[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, a + k_user);
+            for (size_t jx = 0; jx < nnz; jx++)
+                syr_upper_(kb, x[jx], B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, M, kb);
+            if (chol_upper_(kb, M, kb) == 0) chol_solve_upper_(kb, M, kb, a + k_user);
+            else for (int_t i = 0; i < kb; i++) a[k_user + i] = NAN;
+            continue;
+        }
+        /* collective_closed_form_block_implicit, few_NAs branch with a precomputed BtB (:1966-1990) */
+        for (int_t c = 0; c < p; c++) u[c] = U[(size_t)ix * p + c] - (U_colmeans ? U_colmeans[c] : 0);
+        memset(M, 0, (size_t)k_totA * k_totA * sizeof(real_t));
+        for (int_t i = 0; i < k_totC; i++)
+            for (int_t j = 0; j < k_totC; j++) M[(size_t)i * k_totA + j] = w_user * CtC[(size_t)i * k_totC + j];
+        for (int_t i = 0; i < kb; i++)
+            for (int_t j = 0; j < kb; j++) M[(size_t)(k_user + i) * k_totA + (k_user + j)] += BtB[(size_t)i * kb + j];
+        for (int_t i = 0; i < k_user; i++) M[(size_t)i * k_totA + i] += lam;
+        for (int_t c = 0; c < k_totC; c++) {
+            double s = 0;
+            for (int_t j = 0; j < p; j++) s += (double)u[j] * (double)C[(size_t)j * k_totC + c];
+            a[c] = (real_t)((double)w_user * s);
+        }
+        for (size_t jx = 0; jx < nnz; jx++)
+            axpy_(kb, x[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, a + k_user);
+        real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;
+        for (size_t jx = 0; jx < nnz; jx++)
+            syr_upper_(kb, x[jx], B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, Mlr, k_totA);
+        if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
+        else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+    }
+    free(bufs); free(BtB); free(CtC);
+}

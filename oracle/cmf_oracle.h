@@ -143,6 +143,33 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
                             bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
                             bool init_biases);
 
+/* Factors of new rows: factors_collective_explicit_multiple (collective.c:10865-11174) -> per row
+ * factors_collective_explicit_single (:10575-10739) -> collective_factors_warm (:3555-3964) / collective_factors_cold
+ * (:3309-3440), restricted to sparse X (CSR of the new rows, m rows) and dense U[m_u, p] without NaN.
+ * A[max(m, m_u), k_user+k+k_main]; biasA (nullable) switches the user bias on ([B | 1] layout, lam_bias on the last
+ * unknown).  TransCtCinvCt (nullable, [p, k_user+k]) is what the cold rows use when given (:3380-3386). */
+void oracle_factors_explicit_multiple(real_t *A, real_t *biasA, int_t m,
+                                      const real_t *U, int_t m_u, int_t p, const real_t *C,
+                                      real_t glob_mean, const real_t *biasB, const real_t *U_colmeans,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      int_t n, const real_t *B,
+                                      int_t k, int_t k_user, int_t k_item, int_t k_main,
+                                      real_t lam, real_t lam_bias,
+                                      bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const, real_t scaling_biasA,
+                                      real_t w_main, real_t w_user, const real_t *TransCtCinvCt, int nthreads);
+
+/* factors_collective_implicit_multiple (collective.c:11176-11340) -> factors_collective_implicit_single (:10741-10863)
+ * -> collective_factors_warm_implicit (:3966-4087) / collective_factors_cold_implicit (:3442-3553); same restrictions.
+ * BtB (nullable, [k+k_main]^2, lam included) as the caller precomputed it; when NULL it is built with the lam of the
+ * call *before* the w_main rescaling (:11270-11280). */
+void oracle_factors_implicit_multiple(real_t *A, int_t m,
+                                      const real_t *U, int_t m_u, int_t p, const real_t *C, const real_t *U_colmeans,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      int_t n, const real_t *B,
+                                      int_t k, int_t k_user, int_t k_item, int_t k_main,
+                                      real_t lam, real_t alpha, real_t w_main, real_t w_user, real_t w_main_multiplier,
+                                      bool apply_log_transf, const real_t *BtB, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

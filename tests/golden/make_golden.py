@@ -206,6 +206,18 @@ def main():
         print("   reference metrics: RMSE %.6f   P@10 %.6f" % (out["rmse"], out["p_at_10"]))
         save("g10_metrics_" + tag, **out)
 
+        # ---- G11: factors of new rows (factors_collective_{explicit,implicit}_multiple) ----
+        out = {}
+        for k in (6, 50):
+            d = gc.new_rows_problem(dt, k)
+            for name, kind, kw in gc.new_rows_cases(d):
+                A, bA = gc.run_new_rows(R, kind, dict(kw, nthreads=2))
+                key = "k%d_%s" % (k, name.split()[0])
+                out["A_" + key] = A
+                if bA is not None:
+                    out["biasA_" + key] = bA
+        save("g11_new_rows_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -89,3 +89,153 @@ def precision_at_k(A, B, train_row, train_col, test_row, test_col, k=10):
         top = np.argpartition(-s, min(k, n - 1))[:k]
         hits.append(len(items.intersection(top.tolist())) / float(k))
     return float(np.mean(hits))
+
+
+# ---- factors of new rows (factors_collective_*_multiple) -------------------------------------------------
+def new_rows_problem(dtype, k, seed=11):
+    """Seeded model (B, C, biases, column means) + new rows (COO with empty rows, dense U) for a given k."""
+    rng = np.random.default_rng(seed + k)
+    n, m, p = 70, 48, 5
+    ku, ki, km = 2, 1, 1
+    d = dict(n=n, m=m, p=p, k=k, ku=ku, ki=ki, km=km)
+    d["B_plain"] = (rng.standard_normal((n, k)) * 0.3).astype(dtype)
+    d["B_full"] = (rng.standard_normal((n, ki + k + km)) * 0.3).astype(dtype)
+    d["C_plain"] = (rng.standard_normal((p, k)) * 0.3).astype(dtype)
+    d["C_full"] = (rng.standard_normal((p, ku + k)) * 0.3).astype(dtype)
+    d["biasB"] = (rng.standard_normal(n) * 0.2).astype(dtype)
+    d["U_more"] = rng.standard_normal((m + 7, p)).astype(dtype)          # m_u > m
+    d["U_less"] = rng.standard_normal((m - 9, p)).astype(dtype)          # m_u < m
+    d["colmeans"] = (rng.standard_normal(p) * 0.1).astype(dtype)
+    lin = rng.choice(m * n, size=14 * m, replace=False)
+    row = (lin // n).astype(np.int32); col = (lin % n).astype(np.int32)
+    keep = (row != 3) & (row != 17) & (row != m - 2)                      # empty rows, with and without U
+    d["row"], d["col"] = row[keep], col[keep]
+    d["ratings"] = (0.5 * rng.integers(1, 11, keep.sum())).astype(dtype)
+    d["counts"] = np.ceil(rng.lognormal(1, 1, keep.sum())).astype(dtype)
+    return d
+
+
+def new_rows_cases(d):
+    """(name, kind, kwargs) for every configuration; kwargs fit Oracle/Reference.factors_{explicit,implicit}_multiple."""
+    k, ku, ki, km = d["k"], d["ku"], d["ki"], d["km"]
+    X = (d["row"], d["col"])
+    lam_c = 0.7 / 2.5
+    Cf = d["C_full"].astype(np.float64)
+    T = np.linalg.solve(Cf.T @ Cf + lam_c * np.eye(ku + k), Cf.T).T.astype(d["C_full"].dtype)   # [p, ku+k]
+    ex = [
+        ("e0 bias scale_lam lam_bias", dict(B=d["B_plain"], biasB=d["biasB"], glob_mean=3.1, user_bias=True, lam=0.6,
+                                            lam_bias=1.1, scale_lam=True)),
+        ("e1 plain w_main", dict(B=d["B_plain"], lam=2.0, w_main=1.5)),
+        ("e2 U>m bias both scalings k_*", dict(B=d["B_full"], Cm=d["C_full"], U=d["U_more"], U_colmeans=d["colmeans"],
+                                                biasB=d["biasB"], glob_mean=3.1, user_bias=True, lam=0.7, lam_bias=1.3,
+                                                k_main=km, k_user=ku, k_item=ki, scale_lam=True, scale_lam_sideinfo=True,
+                                                w_main=1.5, w_user=2.5)),
+        ("e3 U<m scale_lam", dict(B=d["B_plain"], Cm=d["C_plain"], U=d["U_less"], glob_mean=-0.4, lam=0.7, scale_lam=True,
+                                  w_user=0.8)),
+        ("e4 bias scale_bias_const", dict(B=d["B_plain"], biasB=d["biasB"], user_bias=True, lam=0.6, lam_bias=0.9,
+                                          scale_lam=True, scale_bias_const=True, scaling_biasA=0.4)),
+        ("e5 U TransCtCinvCt", dict(B=d["B_full"], Cm=d["C_full"], U=d["U_more"], U_colmeans=d["colmeans"], user_bias=True,
+                                    lam=0.7, k_main=km, k_user=ku, k_item=ki, w_user=2.5, TransCtCinvCt=T)),
+        ("e6 U only sideinfo scaling", dict(B=d["B_plain"], Cm=d["C_plain"], U=d["U_more"], lam=0.7,
+                                            scale_lam_sideinfo=True, scale_bias_const=True, user_bias=True, scaling_biasA=0.5,
+                                            w_user=1.7)),
+    ]
+    Bf = d["B_full"].astype(np.float64)[:, ki:]
+    BtB = (Bf.T @ Bf + 0.45 * np.eye(k + km)).astype(d["B_full"].dtype)
+    im = [
+        ("i0 plain alpha", dict(B=d["B_plain"], lam=0.7, alpha=2.0)),
+        ("i1 U>m w_main k_*", dict(B=d["B_full"], Cm=d["C_full"], U=d["U_more"], U_colmeans=d["colmeans"], lam=0.7, alpha=2.0,
+                                   k_main=km, k_user=ku, k_item=ki, w_main=1.5, w_user=2.5, w_main_multiplier=0.8)),
+        # (apply_log_transf cannot be pinned: the reference's row function takes the logarithm of a freshly allocated,
+        #  uninitialised buffer, collective.c:10802-10810)
+        ("i2 U<m BtB", dict(B=d["B_full"], Cm=d["C_full"], U=d["U_less"], lam=0.45, k_main=km, k_user=ku, k_item=ki,
+                            w_user=4.0, BtB=BtB)),
+        ("i3 plain w_main", dict(B=d["B_plain"], lam=0.7, w_main=2.0)),
+    ]
+    for name, kw in ex:
+        yield name, "explicit", dict(row=X[0], col=X[1], val=d["ratings"], m=d["m"], k=k, **kw)
+    for name, kw in im:
+        yield name, "implicit", dict(row=X[0], col=X[1], val=d["counts"], m=d["m"], k=k, **kw)
+
+
+def run_new_rows(engine, kind, kw):
+    """Returns (A, biasA or None)."""
+    if kind == "explicit":
+        return engine.factors_explicit_multiple(**kw)
+    return engine.factors_implicit_multiple(**kw), None
+
+
+class HipNewRows:
+    """The product's factors_collective_{explicit,implicit}_multiple (the reference's positional C signatures) behind
+    the keyword interface of Oracle / Reference."""
+
+    def __init__(self, dtype):
+        import ctypes as C
+        from cmfrec_amd import _lib
+        self.C, self._lib, self.dtype = C, _lib, dtype
+        self.lib = _lib.load(dtype)
+        self.R = _lib.real(dtype)
+
+    def factors_explicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, biasB=None, glob_mean=0.0,
+                                  user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0, k_item=0, scale_lam=False,
+                                  scale_lam_sideinfo=False, scale_bias_const=False, scaling_biasA=1.0, w_main=1.0,
+                                  w_user=1.0, nthreads=1, TransCtCinvCt=None, csr=None):
+        C, P, R = self.C, self._lib.ptr, self.R
+        n = B.shape[0]
+        m_u, p = (0, 0) if U is None else U.shape
+        mm = max(m, m_u)
+        A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
+        biasA = np.full(mm, np.nan, self.dtype) if user_bias else None
+        lam_unique = None
+        if lam_bias is not None and lam_bias != lam:
+            lam_unique = np.zeros(6, self.dtype); lam_unique[0] = lam_bias; lam_unique[2] = lam
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        coo = (P(val), P(row), P(col), C.c_size_t(len(val)), None, None, None)
+        if csr is not None:
+            coo = (None, None, None, C.c_size_t(0), P(csr[0]), P(csr[1]), P(csr[2]))
+        rc = self.lib.factors_collective_explicit_multiple(
+            P(A), P(biasA), C.c_int(m), P(U), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            None, None, None, C.c_size_t(0), None, None, None, None, C.c_int(0), C.c_int(0),
+            P(Cm), None, R(glob_mean), P(biasB), P(U_colmeans), *coo,
+            None, C.c_int(n), None, P(B), None, C.c_bool(False),
+            C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
+            R(lam), P(lam_unique), R(0.), None, C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
+            C.c_bool(scale_bias_const), R(scaling_biasA), R(w_main), R(w_user), R(1.), C.c_int(n), C.c_bool(True),
+            None, None, None, None, None, P(TransCtCinvCt), None, None, None, C.c_int(nthreads))
+        assert rc == 0, (rc, self.lib.cmfrec_hip_last_error())
+        return A, biasA
+
+    def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0, alpha=1.0,
+                                  k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_main_multiplier=1.0,
+                                  apply_log_transf=False, nthreads=1, BtB=None, csr=None):
+        C, P, R = self.C, self._lib.ptr, self.R
+        n = B.shape[0]
+        m_u, p = (0, 0) if U is None else U.shape
+        A = np.full((max(m, m_u), k_user + k + k_main), np.nan, self.dtype)
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        coo = (P(val), P(row), P(col), C.c_size_t(len(val)), None, None, None)
+        if csr is not None:
+            coo = (None, None, None, C.c_size_t(0), P(csr[0]), P(csr[1]), P(csr[2]))
+        rc = self.lib.factors_collective_implicit_multiple(
+            P(A), C.c_int(m), P(U), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(False),
+            None, None, None, C.c_size_t(0), None, None, None, *coo,
+            P(B), C.c_int(n), P(Cm), P(U_colmeans), C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
+            R(lam), R(0.), R(alpha), R(w_main), R(w_user), R(w_main_multiplier), C.c_bool(apply_log_transf),
+            None, P(BtB), None, None, C.c_int(nthreads))
+        assert rc == 0, (rc, self.lib.cmfrec_hip_last_error())
+        return A
+
+
+def new_rows_vs_golden(engine, dtype, extra=None):
+    """Yields (label, error) of an engine against the g11 fixture (the reference's outputs)."""
+    g = load("g11_new_rows", dtype)
+    for k in (6, 50):
+        d = new_rows_problem(dtype, k)
+        for name, kind, kw in new_rows_cases(d):
+            A, bA = run_new_rows(engine, kind, dict(kw, **(extra or {})))
+            key = "k%d_%s" % (k, name.split()[0])
+            yield "k=%d %s" % (k, name), maxrel(A, g["A_" + key])
+            if bA is not None:
+                yield "k=%d %s (bias)" % (k, name), maxrel(bA, g["biasA_" + key])

@@ -235,3 +235,50 @@ def test_seeded_fit_matches_reference_seed(dtype):
             assert frob(mdl.user_bias_, rr["biasA"]) < t
         if ib:
             assert frob(mdl.item_bias_, rr["biasB"]) < t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("side", [False, True])
+def test_factors_multiple_after_fit(oracles, dtype, side):
+    """``factors_multiple`` of the estimators (factors_collective_*_multiple underneath).  A fit that ends on a Cholesky
+    A-step leaves exactly the closed-form factors of its own training rows, so handing the training data back must
+    reproduce A_ (and the user biases); then genuinely new rows are checked against the oracle."""
+    import scipy.sparse as sp
+    import golden_cases as gc
+    from cmfrec_amd import CMF, CMF_implicit
+    O = oracles[dtype]
+    t = 1e-9 if dtype is np.float64 else 2e-3
+    m, n, k, p = 900, 500, 24, 6
+    rng = np.random.default_rng(5)
+    U = rng.standard_normal((m, p)).astype(dtype) if side else None
+    row, col, val = make_coo(m, n, 20000, 8, counts=False, dtype=dtype, heavy_row=(5, 300), empty_rows=() if side else (9,))
+    X = sp.coo_matrix((val, (row, col)), shape=(m, n))
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    mdl = CMF(k=k, lambda_=0.8, niter=3, use_cg=False, use_float=dtype is np.float32, scale_lam=True, w_user=2.0,
+              precompute_for_predictions=side).fit(X, U=U, A0=A0, B0=B0)
+    A, bias = mdl.factors_multiple(X, U=U, return_bias=True)
+    ne = np.ones(m, bool) if side else (np.arange(m) != 9)      # the fit leaves a row without data at its start value
+    assert gc.maxrel(A[ne], mdl.A_[ne]) < t and gc.maxrel(bias[ne], mdl.user_bias_[ne]) < t
+    assert side or (not A[9].any() and bias[9] == 0)            # ... new rows without data are zero (collective.c:3634)
+    # new rows: a slice of other users, fewer rows of side information than of X
+    row2, col2, val2 = make_coo(300, n, 5000, 9, counts=False, dtype=dtype, empty_rows=(2, 250))
+    U2 = rng.standard_normal((260, p)).astype(dtype) if side else None
+    A, bias = mdl.factors_multiple((row2, col2, val2), U=U2, return_bias=True)
+    kw = dict(B=mdl.B_, row=row2, col=col2, val=val2, m=300, k=k, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_,
+              user_bias=True, lam=0.8, scale_lam=True, w_user=2.0, nthreads=4)
+    if side:
+        kw.update(Cm=mdl.C_, U=U2, U_colmeans=mdl._U_colmeans, TransCtCinvCt=mdl._TransCtCinvCt)
+    Ao, bo = O.factors_explicit_multiple(**kw)
+    assert A.shape == (300, k) and gc.maxrel(A, Ao) < t and gc.maxrel(bias, bo) < t
+
+    row, col, val = make_coo(m, n, 20000, 10, counts=True, dtype=dtype, heavy_row=(5, 300), empty_rows=() if side else (9,))
+    X = sp.coo_matrix((val, (row, col)), shape=(m, n))
+    mi = CMF_implicit(k=k, lambda_=2.0, alpha=1.5, niter=3, use_cg=False, use_float=dtype is np.float32, w_user=2.0,
+                      ).fit(X, U=U, A0=A0, B0=B0)
+    assert gc.maxrel(mi.factors_multiple(X, U=U)[ne], mi.A_[ne]) < t
+    row2, col2, val2 = make_coo(300, n, 5000, 11, counts=True, dtype=dtype, empty_rows=(2, 250))
+    A = mi.factors_multiple((row2, col2, val2), U=U2)
+    kw = dict(B=mi.B_, row=row2, col=col2, val=val2, m=300, k=k, lam=2.0, alpha=1.5, w_user=2.0, nthreads=4, BtB=mi._BtB)
+    if side:
+        kw.update(Cm=mi.C_, U=U2, U_colmeans=mi._U_colmeans)
+    assert gc.maxrel(A, O.factors_implicit_multiple(**kw)) < t

@@ -145,3 +145,18 @@ def test_result_metrics(dtype):
         held.setdefault(int(u), set()).add(int(i))
     p10 = float(np.mean([len(held[int(u)].intersection(ids[j].tolist())) / 10.0 for j, u in enumerate(users)]))
     assert abs(p10 - got) < (1e-12 if not uf else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_new_rows(oracles, dtype):
+    """G11 through the drop-in entry points factors_collective_{explicit,implicit}_multiple (COO input), then the same
+    rows handed over as CSR."""
+    H = gc.HipNewRows(dtype)
+    for label, err in gc.new_rows_vs_golden(H, dtype):
+        assert err < TOL[dtype], (label, err)
+    d = gc.new_rows_problem(dtype, 6)
+    for name, kind, kw in gc.new_rows_cases(d):
+        csr, _ = oracles[dtype].coo_to_csr_and_csc(kw["row"], kw["col"], kw["val"], kw["m"], kw["B"].shape[0])
+        a1, b1 = gc.run_new_rows(H, kind, kw)
+        a2, b2 = gc.run_new_rows(H, kind, dict(kw, csr=csr))
+        assert gc.maxrel(a2, a1) < TOL[dtype], name

@@ -116,3 +116,11 @@ def test_result_metrics(oracles, dtype):
     O.fit_implicit_als(A, B, g["i_row"], g["i_col"], g["i_val"], lam=5.0, niter=15, use_cg=True)
     got = gc.precision_at_k(A, B, g["i_row"], g["i_col"], g["i_trow"], g["i_tcol"], 10)
     assert abs(got - float(g["p_at_10"])) < (1e-4 if dtype is np.float64 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_new_rows(oracles, dtype):
+    """G11: factors of new rows (factors_collective_{explicit,implicit}_multiple): warm rows with and without side
+    information, side-information-only rows, empty rows, bias, the lambda scalings and their two quirks."""
+    for label, err in gc.new_rows_vs_golden(oracles[dtype], dtype, dict(nthreads=2)):
+        assert err < TOL[dtype], (label, err)

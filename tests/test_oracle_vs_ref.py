@@ -177,3 +177,21 @@ def test_sideinfo_beyond_X_live(oracles, refs, dtype):
         assert rel_err(a2, a1) < tol and rel_err(b2, b1) < tol, ("explicit", cg, pcg)
         assert np.abs(r2["biasA"] - r1["biasA"]).max() < tol and np.abs(r2["biasB"] - r1["biasB"]).max() < tol
         assert not r1["biasA"][m:].any() and not r1["biasB"][n:].any()          # the reference's own behaviour
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_new_rows_live(oracles, refs, dtype):
+    """factors_collective_{explicit,implicit}_multiple live (collective.c:10865-11340) on a problem of another seed
+    than the committed fixture, 1 vs 3 threads."""
+    import golden_cases as gc
+    O, R = oracles[dtype], refs[dtype]
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    for k in (5, 33):
+        d = gc.new_rows_problem(dtype, k, seed=29)
+        for name, kind, kw in gc.new_rows_cases(d):
+            a1, b1 = gc.run_new_rows(R, kind, dict(kw, nthreads=3))
+            a2, b2 = gc.run_new_rows(O, kind, dict(kw, nthreads=1))
+            assert not np.isnan(a1).any(), name
+            assert gc.maxrel(a2, a1) < tol, (name, k)
+            if b1 is not None:
+                assert gc.maxrel(b2, b1) < tol, (name, k)
