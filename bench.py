@@ -126,8 +126,10 @@ def main():
         def sync():
             sess.sync()
     else:
+        # the A-step finishes in parts so that each part's all-gather overlaps the kernels of the next ones
+        a_parts = int(os.environ.get("CMFREC_HIP_AG_PARTS", "4"))
         eng = GpuEngine.from_user_block(m_blk, n, K, row, col, val, A0_blk, lam=LAM, max_cg_steps=MAX_CG_STEPS,
-                                        rank=rank, world=world, device=local_rank)
+                                        rank=rank, world=world, device=local_rank, a_parts=a_parts)
         engine = ShardedAls(eng, rank, world)
         sess = eng.session
 
@@ -169,8 +171,10 @@ def main():
             ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
             if cnt:
                 kernels.append(dict(step=which, kernel=names[b], ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
-                                    avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, K)))
-    dom = max(kernels, key=lambda d: d["ms_total"])
+                                    avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, K),
+                                    overlapped=sess.bin_overlaps(which, b)))
+    # launches that run beside other kernels (few split rows on the second stream) have no duration of their own
+    dom = max([d for d in kernels if not d["overlapped"]], key=lambda d: d["ms_total"])
     achieved = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
     traffic = pmc_traffic(dom) if args.scale == 1.0 and world == 1 else None
     msA, cntA = sess.kernel_time("A"); msB, cntB = sess.kernel_time("B")
@@ -194,7 +198,8 @@ def main():
                     iteration={"alg_GB": round(iter_bytes / 1e9, 3), "halfstep_ms": halfstep_ms,
                                "frac_of_hbm_peak": round(iter_bytes / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)},
                     per_kernel=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4),
-                                     GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1), rocprof=d["rocprof"])
+                                     GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1), rocprof=d["rocprof"],
+                                     **({"runs_beside_other_kernels": True} if d["overlapped"] else {}))
                                 for d in kernels])
 
     # ---- CPU baseline: the reference itself (oracle/_ref) on this host, rank 0 / N=1 only ----

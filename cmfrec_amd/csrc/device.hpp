@@ -108,6 +108,13 @@ struct SparseShard {
     int n_nonempty = 0, n_empty = 0;
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
+    bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
+    // few split rows (less than about one round of workgroups per CG pass): their launch sequence is a chain of
+    // latencies and runs on the second stream beside the other bins
+    bool vh_runs_aside(int num_cus) const
+    {
+        return bin_rows[0] > 0 && n_chunks <= 4 * num_cus && getenv("CMFREC_HIP_VH_INLINE") == nullptr;
+    }
     static constexpr int LONG_ROW = 1024;
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
     int n_chunks = 0;
@@ -312,14 +319,14 @@ enum class CgVariant { Auto, Generic };
 CgVariant cg_variant_from_env();
 
 template <int S, bool IMPLICIT, int W, int RPB>
-inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin)
+inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
 {
     if (count <= 0) return;
     EventPair ev{nullptr, nullptr};
     if (tm) {
         HIP_CHECK(hipEventCreate(&ev.a));
         HIP_CHECK(hipEventCreate(&ev.b));
-        HIP_CHECK(hipEventRecord(ev.a, dev.stream));
+        HIP_CHECK(hipEventRecord(ev.a, st));
     }
     P.order += first;
     P.desc += first;
@@ -337,23 +344,23 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
     int teams_needed = (count + RPB - 1) / RPB;
     int grid = std::min(teams_needed, dev.num_cus * blocks_per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, dev.stream, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, st, P);
     HIP_CHECK(hipGetLastError());
     if (tm) {
-        HIP_CHECK(hipEventRecord(ev.b, dev.stream));
+        HIP_CHECK(hipEventRecord(ev.b, st));
         tm->ev[bin].push_back(ev);
     }
 }
 
 template <int S, bool IMPLICIT>
-inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm)
+inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st)
 {
     if (count <= 0) return;
     EventPair ev{nullptr, nullptr};
     if (tm) {
         HIP_CHECK(hipEventCreate(&ev.a));
         HIP_CHECK(hipEventCreate(&ev.b));
-        HIP_CHECK(hipEventRecord(ev.a, dev.stream));
+        HIP_CHECK(hipEventRecord(ev.a, st));
     }
     P.order += first;
     P.desc += first;
@@ -367,20 +374,21 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         blocks_per_cu = std::max(1, nb);
     }
     int grid = std::min((count + 3) / 4, dev.num_cus * blocks_per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, dev.stream, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, P);
     HIP_CHECK(hipGetLastError());
     if (tm) {
-        HIP_CHECK(hipEventRecord(ev.b, dev.stream));
+        HIP_CHECK(hipEventRecord(ev.b, st));
         tm->ev[BIN_TINY].push_back(ev);
     }
 }
 
 // very heavy rows: one (pass, update) launch pair per CG pass
 template <int S, bool IMPLICIT>
-inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, BinTimers *tm)
+inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const SparseShard &X, BinTimers *tm, hipStream_t st)
 {
     const int nvh = X.bin_rows[BIN_VHEAVY];
     if (nvh <= 0) return;
+    struct { hipStream_t stream; int num_cus; } dev{st, dev_.num_cus};      // everything below launches on `st`
     EventPair ev{nullptr, nullptr};
     if (tm) {
         HIP_CHECK(hipEventCreate(&ev.a));
@@ -432,13 +440,33 @@ inline void launch_cg_vheavy(const DeviceInfo &dev, CgParams<real_t> P, const Sp
 template <int S, bool IMPLICIT>
 inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm)
 {
-    launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm);
+    // Few split rows (less than about one round of workgroups per pass: the users of C2) make their launch sequence --
+    // 2 kernels per CG pass -- a chain of latencies, 0.08 ms with next to no work; it then runs on the second stream
+    // beside the other bins.  Many split rows (the items of C2) fill the chip by themselves and stay in line.
+    const bool vh_aside = X.bin_rows[BIN_VHEAVY] > 0 && X.vh_runs_aside(dev.num_cus);
+    // A shard that is one of several parts of a block (multi-GPU overlap, session.hip) has a quarter of the rows per
+    // launch, so ramp-up and tail of every bin weigh four times as much: its bins alternate between the two streams,
+    // the next bin fills the CUs the previous one is vacating.  (Not for whole blocks: there the per-bin event timings
+    // feed the roofline report and must not overlap.)
+    const bool alt = X.is_part && getenv("CMFREC_HIP_PART_SERIAL") == nullptr;
+    DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+    if (vh_aside || alt) {
+        d.ensure_aux();
+        HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
+        HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
+    }
+    hipStream_t s0 = dev.stream, s1 = alt ? d.aux_stream : dev.stream;
+    launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm, (vh_aside || alt) ? d.aux_stream : dev.stream);
     // then longest rows first: they are the longest-running teams
-    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY);
-    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4);
-    launch_cg_bin<S, IMPLICIT, 2, 1>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2);
-    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT);
-    launch_cg_tiny<S, IMPLICIT>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm);
+    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY, s0);
+    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4, s1);
+    launch_cg_bin<S, IMPLICIT, 2, 1>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2, s0);
+    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT, s1);
+    launch_cg_tiny<S, IMPLICIT>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, s0);
+    if (vh_aside || alt) {
+        HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
+        HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
+    }
 }
 
 template <int NF, bool IMPLICIT>

@@ -8,6 +8,7 @@
 #include "device.hpp"
 #include "coo_device.hpp"
 #include <functional>
+#include <memory>
 #include <new>
 
 namespace cmfhip {
@@ -154,6 +155,11 @@ struct cmfrec_hip_session {
     size_t ldA = 0, ldB = 0;
     DevBuf<real_t> A, B, biasA, biasB, C, D, U, II;
     SparseShard Xr, Xc;
+    // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
+    // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
+    std::vector<std::unique_ptr<SparseShard>> XrParts;
+    std::vector<int> partBegin;          // nparts + 1 local row offsets
+    std::vector<hipEvent_t> partEv;
     DevBuf<real_t> gram, ctc, betbe, ucA, ucB;
     GramWorkspace gws;
     std::vector<EventPair> evA, evB;     // whole half-steps
@@ -170,6 +176,7 @@ struct cmfrec_hip_session {
         for (auto &p : evA) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         for (auto &p : evB) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         binA.clear(); binB.clear();
+        for (auto e : partEv) (void)hipEventDestroy(e);
     }
 };
 
@@ -270,6 +277,56 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const i
         HIP_CHECK(hipSetDevice(s->dev.device));
         shard_from_csr(s->Xr, s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->mdl.n, s->dev.stream);
         shard_from_csr(s->Xc, s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->mdl.m, s->dev.stream);
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_set_A_parts(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
+                                   int nparts)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const int nrows = s->mdl.row_end - s->mdl.row_begin;
+        s->XrParts.clear(); s->partBegin.clear();
+        for (auto e : s->partEv) (void)hipEventDestroy(e);
+        s->partEv.clear();
+        if (nparts <= 1) return 0;
+        if (s->mdl.p > 0) { g_last_error = "cmfrec_hip_session_set_A_parts: not with user side information"; return 2; }
+        nparts = std::min(nparts, std::max(1, nrows));
+        const int step = (nrows + nparts - 1) / nparts;
+        for (int c = 0; c <= nparts; c++) s->partBegin.push_back(std::min(c * step, nrows));
+        std::vector<size_t> pp;
+        for (int c = 0; c < nparts; c++) {
+            const int r0 = s->partBegin[c], r1 = s->partBegin[c + 1];
+            pp.resize((size_t)(r1 - r0) + 1);
+            for (int r = r0; r <= r1; r++) pp[r - r0] = csr_p[r] - csr_p[r0];
+            s->XrParts.emplace_back(new SparseShard());
+            s->XrParts.back()->is_part = true;
+            shard_from_csr(*s->XrParts.back(), r1 - r0, pp.data(), csr_i + csr_p[r0], csr_v + csr_p[r0], s->mdl.n, s->dev.stream);
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));              // pp is reused
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            s->partEv.push_back(e);
+        }
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_part_range(cmfrec_hip_session *s, int part, int *begin, int *end)
+{
+    if (part < 0 || part >= (int)s->XrParts.size()) return 2;
+    if (begin) *begin = s->partBegin[part];
+    if (end) *end = s->partBegin[part + 1];
+    return 0;
+}
+
+int cmfrec_hip_session_nparts(cmfrec_hip_session *s) { return (int)s->XrParts.size(); }
+
+int cmfrec_hip_session_stream_wait_part(cmfrec_hip_session *s, int part, void *stream)
+{
+    return guarded([&]() {
+        if (part < 0 || part >= (int)s->partEv.size()) { g_last_error = "cmfrec_hip_session_stream_wait_part: no such part"; return 2; }
+        HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, s->partEv[part], 0));
         return 0;
     });
 }
@@ -456,7 +513,7 @@ static int solve_sideinfo_only_rows(cmfrec_hip_session *s, bool isA, bool chol, 
     return launch_chol(dev, c, nullptr, count);                                                    // common.c:2872-2875
 }
 
-static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
+static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = -1)
 {
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
@@ -468,11 +525,15 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
     const int rows_opp = isA ? (m.n_x > 0 ? m.n_x : m.n) : (m.m_x > 0 ? m.m_x : m.m);   // rows of the opposing matrix that X refers to (the Gramian's rows)
     const int k_side_self = isA ? m.k_user : m.k_item, k_side_opp = isA ? m.k_item : m.k_user;
     const int begin = isA ? m.row_begin : m.col_begin;
-    const SparseShard &X = isA ? s->Xr : s->Xc;
+    const SparseShard &X = (part >= 0) ? *s->XrParts[part] : (isA ? s->Xr : s->Xc);
     const bool self_bias = isA ? m.user_bias : m.item_bias;
     const bool opp_bias = isA ? m.item_bias : m.user_bias;
     const int p_self = isA ? m.p : m.q;
-    real_t *self_blk = self + (size_t)begin * ld_self;
+    real_t *self_blk = self + (size_t)(begin + (part >= 0 ? s->partBegin[part] : 0)) * ld_self;
+    if (part >= 0 && (!isA || p_self > 0)) {
+        g_last_error = "cmfrec_hip: row parts are only built for A-steps without side information";
+        return 2;
+    }
     const int kk = m.k + m.k_main;
     const int rows_x_self = isA ? (m.m_x > 0 ? m.m_x : m.m) : (m.n_x > 0 ? m.n_x : m.n);          // rows of this matrix X has
 
@@ -535,8 +596,9 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol)
         return launch_chol(dev, c, &X);
     }
     if (m.implicit) {
-        // optimizeA_implicit, common.c:3305-3421
-        launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, chol ? m.lam : (real_t)0);
+        // optimizeA_implicit, common.c:3305-3421 (the Gramian once per half-step: parts > 0 reuse it)
+        if (part <= 0)
+            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, chol ? m.lam : (real_t)0);
         if (chol) {
             if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st)); // :3334
             CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, 0, nullptr,
@@ -738,7 +800,15 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
         if (which == 'A' || which == 'B') {
             EventPair ev{s->new_event(), s->new_event()};
             HIP_CHECK(hipEventRecord(ev.a, s->dev.stream));
-            int rc = update_factor(s, which == 'A', chol);
+            int rc = 0;
+            if (which == 'A' && !s->XrParts.empty()) {
+                for (int c = 0; c < (int)s->XrParts.size() && rc == 0; c++) {
+                    rc = update_factor(s, true, chol, c);
+                    HIP_CHECK(hipEventRecord(s->partEv[c], s->dev.stream));
+                }
+            } else {
+                rc = update_factor(s, which == 'A', chol);
+            }
             HIP_CHECK(hipEventRecord(ev.b, s->dev.stream));
             (which == 'A' ? s->evA : s->evB).push_back(ev);
             return rc;
@@ -825,11 +895,20 @@ int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, doub
             tot += t;
         }
         if (ms) *ms = tot;
-        if (launches) *launches = (long)bt.ev[bin].size();
+        // with row parts every half-step launches each bin once per part: report half-steps, not launches
+        const long per_step = (which == 'A' && !s->XrParts.empty()) ? (long)s->XrParts.size() : 1;
+        if (launches) *launches = (long)bt.ev[bin].size() / per_step;
         if (rows) *rows = X.bin_rows[bin];
         if (nnz) *nnz = X.bin_nnz[bin];
         return 0;
     });
+}
+
+int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
+{
+    const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
+    if (which == 'A' && !s->XrParts.empty()) return 1;                    // the bins of a part alternate between two streams
+    return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus)) ? 1 : 0;
 }
 
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s)

@@ -42,6 +42,9 @@ class ShardedAls:
         engine.ranges(which)    -> list of (begin, end) per rank
         engine.after_gather(which)
         engine.pre_collective() / engine.post_collective()  -- stream hand-over hooks
+      optional, for overlapping the all-gather with the update (allgather_parts):
+        engine.parts(which) -> [(r0, r1)] local row offsets in completion order, engine.comm_stream(),
+        engine.wait_part(which, part, stream), engine.join_comm(stream)
     """
 
     def __init__(self, engine, rank, world, group=None):
@@ -79,9 +82,46 @@ class ShardedAls:
                     full[rb:re].copy_(stage[r, : re - rb])
         eng.post_collective()
 
+    def allgather_parts(self, which, parts):
+        """All-gather of a block that its engine completes part by part (engine.parts): the collective of part c is
+        issued on the engine's communication stream as soon as that part's rows are final, beside the kernels of the
+        parts after it.  Needs equal blocks on all ranks (each part is one all_gather_into_tensor into a staging
+        buffer [world, rows, ld], copied into the replica on the same stream)."""
+        import contextlib
+        import torch
+        import torch.distributed as dist
+        eng = self.engine
+        full = eng.full(which)
+        ranges = eng.ranges(which)
+        b0, _ = ranges[self.rank]
+        blk = ranges[0][1] - ranges[0][0]
+        ld = full.shape[1]
+        view = full.view(self.world, blk, ld)
+        cs = eng.comm_stream()
+        for c, (r0, r1) in enumerate(parts):
+            key = (which, "part", c, r1 - r0, ld)
+            if key not in self._stage:
+                self._stage[key] = torch.empty((self.world, r1 - r0, ld), dtype=full.dtype, device=full.device)
+            stage = self._stage[key]
+            eng.wait_part(which, c, cs)
+            with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
+                dist.all_gather_into_tensor(stage.view(-1), full[b0 + r0:b0 + r1].reshape(-1), group=self.group)
+                if self.rank > 0:
+                    view[:self.rank, r0:r1].copy_(stage[:self.rank])
+                if self.rank + 1 < self.world:
+                    view[self.rank + 1:, r0:r1].copy_(stage[self.rank + 1:])
+        eng.join_comm(cs)
+
     def half_step(self, which, use_cholesky=False):
+        import torch.distributed as dist
         self.engine.update(which, use_cholesky)
-        self.allgather(which)
+        parts = self.engine.parts(which) if hasattr(self.engine, "parts") else None
+        sizes = {e - b for b, e in self.engine.ranges(which)}
+        if parts and len(parts) > 1 and len(sizes) == 1 and dist.is_initialized() and \
+                next(iter(sizes)) * self.world == self.engine.full(which).shape[0]:
+            self.allgather_parts(which, parts)
+        else:
+            self.allgather(which)
         self.engine.after_gather(which)
 
     def iteration(self, use_cholesky=False):
@@ -113,7 +153,7 @@ class GpuEngine:
 
     @classmethod
     def from_user_block(cls, m_blk, n, k, row, col, val, A0_blk, lam, max_cg_steps, rank, world, device,
-                        dtype=np.float64):
+                        dtype=np.float64, a_parts=1):
         """Implicit model, weak-scaling layout of bench.py: every rank brings its own user block
         (local rows, global item ids); the CSC shard of the rank's item block is assembled from all
         ranks' triplets with one all-gather at set-up."""
@@ -148,6 +188,8 @@ class GpuEngine:
         sess = AlsSession(m, n, k, implicit=True, dtype=dtype, lam=lam, use_cg=True, max_cg_steps=max_cg_steps,
                           row_range=row_ranges[rank], col_range=col_ranges[rank], device=device)
         sess.set_X(csr, csc)
+        if a_parts > 1:
+            sess.set_A_parts(csr, a_parts)
         eng = cls(sess, row_ranges, col_ranges)
         # start values: every rank contributes its user block of A; B starts at zero (collective.c:9765-9768)
         fullA = eng.full("A")
@@ -168,6 +210,24 @@ class GpuEngine:
 
     def after_gather(self, which):
         self.session.after_gather(which)
+
+    def parts(self, which):
+        return self.session.part_ranges() if which == "A" else []
+
+    def comm_stream(self):
+        import torch
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream()
+        return self._comm
+
+    def wait_part(self, which, part, stream):
+        self.session.stream_wait_part(part, stream.cuda_stream)
+
+    def join_comm(self, stream):
+        # the last part's collective was issued after that part's event, so once the communication stream has
+        # drained the session's stream has nothing of this half-step left either
+        stream.synchronize()
+        self.session.sync()
 
     def pre_collective(self):
         # the session launches on its own stream; RCCL runs on torch's

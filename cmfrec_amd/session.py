@@ -54,6 +54,28 @@ class AlsSession:
                 self._c(csc[0], np.uint64), self._c(csc[1], np.int32), self._c(csc[2])]
         _lib.check(self.lib.cmfrec_hip_session_set_X(self.handle, *[_lib.ptr(a) for a in keep]), self.lib, "set_X")
 
+    def set_A_parts(self, csr, nparts):
+        """Cuts the local rows of A into ``nparts`` contiguous parts (same ``csr`` as given to set_X): update('A') then
+        completes part by part, so each part's all-gather can overlap the kernels of the next ones (distributed.py)."""
+        keep = [self._c(csr[0], np.uint64), self._c(csr[1], np.int32), self._c(csr[2])]
+        _lib.check(self.lib.cmfrec_hip_session_set_A_parts(self.handle, *[_lib.ptr(a) for a in keep], C.c_int(int(nparts))),
+                   self.lib, "set_A_parts")
+
+    def part_ranges(self):
+        """[(begin, end)] local row offsets of the parts of A ([] when A is not split)."""
+        out = []
+        for c in range(self.lib.cmfrec_hip_session_nparts(self.handle)):
+            b = C.c_int(0); e = C.c_int(0)
+            _lib.check(self.lib.cmfrec_hip_session_part_range(self.handle, C.c_int(c), C.byref(b), C.byref(e)), self.lib,
+                       "part_range")
+            out.append((b.value, e.value))
+        return out
+
+    def stream_wait_part(self, part, raw_stream):
+        """Makes the HIP stream ``raw_stream`` (an integer handle) wait until part ``part`` of the last update('A') is done."""
+        _lib.check(self.lib.cmfrec_hip_session_stream_wait_part(self.handle, C.c_int(part), C.c_void_p(raw_stream)), self.lib,
+                   "stream_wait_part")
+
     def init_biases(self, lam_user, lam_item):
         """Bias start values on the device (reference initialize_biases_*, src/common.c:4410-4909)."""
         R = _lib.real(self.dtype)
@@ -134,6 +156,10 @@ class AlsSession:
         _lib.check(self.lib.cmfrec_hip_session_bin_stats(self.handle, C.c_int(ord(which)), C.c_int(bin_), C.byref(ms),
                                                          C.byref(cnt), C.byref(rows), C.byref(nnz)), self.lib, "bin_stats")
         return ms.value, cnt.value, rows.value, nnz.value
+
+    def bin_overlaps(self, which, bin_):
+        """True when the launches of that bin run beside other kernels, so that bin_stats' time is not a kernel duration."""
+        return bool(self.lib.cmfrec_hip_session_bin_overlaps(self.handle, C.c_int(ord(which)), C.c_int(bin_)))
 
     def reset_timers(self):
         self.lib.cmfrec_hip_session_reset_timers(self.handle)

@@ -279,6 +279,17 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s,
  * entry order of coo_to_csr_and_csc (src/helpers.c:1375-1491); values become (x - subtract) * alpha on the
  * way (centring src/common.c:3603-3613; confidence src/collective.c:9606-9611).  Only for sessions that own
  * all rows and columns. */
+/* Multi-GPU overlap (optional, after set_X with the same CSR): cut the local rows of A into `nparts` contiguous parts
+ * with their own processing orders.  update('A') then finishes part after part and records one event per part;
+ * stream_wait_part makes another stream (the one the all-gather of that part is issued on) wait for it, so the
+ * collective of a finished part runs beside the kernels of the following ones.  Sessions without user side
+ * information only.  nparts <= 1 removes the split. */
+int cmfrec_hip_session_set_A_parts(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i,
+                                   const real_t *csr_v, int nparts);
+int cmfrec_hip_session_nparts(cmfrec_hip_session *s);
+int cmfrec_hip_session_part_range(cmfrec_hip_session *s, int part, int *begin, int *end);   /* local row offsets */
+int cmfrec_hip_session_stream_wait_part(cmfrec_hip_session *s, int part, void *stream);
+
 int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
                                  size_t nnz, real_t subtract, real_t alpha);
 /* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
@@ -340,6 +351,9 @@ int cmfrec_hip_session_kernel_time(cmfrec_hip_session *s, int which, double *ms,
  * ms = summed HIP-event time of that bin's launches since the last reset. */
 int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, double *ms, long *launches,
                                  long *rows, unsigned long long *nnz);
+/* 1 if the launches of that bin run beside other kernels (few split rows on the second stream; every bin of a block
+ * that is updated in parts): their event timings then include the neighbours' work and are not a kernel duration. */
+int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
 /* Batched top-N (the step after the path; the reference ranks one user per call: topN, src/common.c:5127-5380).

@@ -56,6 +56,27 @@ class OracleEngine:
     def after_gather(self, which):
         pass
 
+    # optional part-wise all-gather (ShardedAls.allgather_parts): on the CPU the parts are complete when update() returns
+    nparts = 0
+
+    def parts(self, which):
+        if which != "A" or self.nparts <= 1:
+            return []
+        b, e = self._ranges["A"][self.rank]
+        step = -(-(e - b) // self.nparts)
+        return [(min(c * step, e - b), min((c + 1) * step, e - b)) for c in range(self.nparts)]
+
+    def comm_stream(self):
+        return None
+
+    def wait_part(self, which, part, stream):
+        pass
+
+    joined = 0
+
+    def join_comm(self, stream):
+        self.joined += 1
+
     def pre_collective(self):
         pass
 
@@ -63,7 +84,7 @@ class OracleEngine:
         pass
 
 
-def _worker(rank, world, port, balanced, out_dir):
+def _worker(rank, world, port, balanced, out_dir, m=301, nparts=0):
     from conftest import make_coo
     from oracle.bindings import Oracle
     from cmfrec_amd.distributed import ShardedAls, balanced_boundaries, equal_boundaries
@@ -71,7 +92,7 @@ def _worker(rank, world, port, balanced, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     O = Oracle(np.float64)
-    m, n, k = 301, 200, 8
+    n, k = 200, 8
     row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
     csr, csc = O.coo_to_csr_and_csc(row, col, val, m, n)
     rng = np.random.default_rng(3)
@@ -85,10 +106,13 @@ def _worker(rank, world, port, balanced, out_dir):
     rr = [(rb[i], rb[i + 1]) for i in range(world)]
     cr = [(cb[i], cb[i + 1]) for i in range(world)]
     eng = OracleEngine(O, A, B, csr, csc, rr, cr, rank, 4.0)
+    eng.nparts = nparts
     als = ShardedAls(eng, rank, world)
+    if nparts > 1:
+        assert len(eng.parts("A")) == nparts
     for _ in range(3):
         als.iteration()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B, joined=eng.joined)
     dist.destroy_process_group()
 
 
@@ -124,3 +148,21 @@ def test_boundaries():
     s0, s1 = cnt[b[0]:b[1]].sum(), cnt[b[1]:b[2]].sum()
     assert abs(int(s0) - int(s1)) <= 100
     assert balanced_boundaries(np.zeros(5, int), 3)[-1] == 5
+
+
+def test_two_rank_partwise_allgather(tmp_path, oracles):
+    """The overlap path of the multi-GPU bench: equal user blocks, the A block gathered in three parts
+    (ShardedAls.allgather_parts); must still be the single-process fit, bit for bit."""
+    from conftest import make_coo
+    world, m = 2, 300
+    mp.spawn(_worker, args=(world, _free_port(), False, str(tmp_path), m, 3), nprocs=world, join=True)
+    O = oracles[np.float64]
+    n, k = 200, 8
+    row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
+    A = np.random.default_rng(3).standard_normal((m, k)) * 0.01
+    B = np.zeros((n, k))
+    O.fit_implicit_als(A, B, row, col, val, lam=4.0, niter=3)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["A"], r1["A"]) and np.array_equal(r0["B"], r1["B"])
+    assert np.array_equal(r0["A"], A) and np.array_equal(r0["B"], B)
+    assert int(r0["joined"]) == 3 and int(r1["joined"]) == 3          # the part-wise path was really taken, once per iteration

@@ -1,0 +1,52 @@
+"""GPU, one rank: the multi-GPU engine of bench.py (GpuEngine + ShardedAls over RCCL) with the A block cut into parts
+whose all-gathers overlap the following parts' kernels.  With one rank the collectives degenerate to copies, so this
+pins the control path -- part boundaries, events between the session's stream and the communication stream, staging
+copies -- against a plain single-session run.  (The 2-rank logic runs on CPU with gloo, test_distributed_gloo.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("parts", [1, 4])
+def test_one_rank_engine_matches_session(parts):
+    import torch
+    import torch.distributed as dist
+    from cmfrec_amd.session import AlsSession
+    from cmfrec_amd.distributed import GpuEngine, ShardedAls
+    m, n, k, nnz = 20000, 6000, 50, 600000
+    row, col, val = bench.synth_block(m, n, nnz, seed=5)
+    A0 = np.random.default_rng(1).random((m, k)) * 2.0 ** -7
+    ref = AlsSession(m, n, k, implicit=True, dtype=np.float64, lam=5.0, use_cg=True, max_cg_steps=3)
+    ref.set_X(bench.to_csr(row, col, val, m), bench.to_csr(col, row, val, n))
+    ref.set_factors(A=A0, B=np.zeros((n, k)))
+    for _ in range(3):
+        ref.update("B"); ref.update("A")
+    f = ref.get_factors(); Ar, Br = f["A"], f["B"]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng = GpuEngine.from_user_block(m, n, k, row, col, val, A0, lam=5.0, max_cg_steps=3, rank=0, world=1, device=0,
+                                        a_parts=parts)
+        assert len(eng.parts("A")) == (parts if parts > 1 else 0)
+        als = ShardedAls(eng, 0, 1)
+        for _ in range(3):
+            als.iteration()
+        torch.cuda.synchronize()
+        f = eng.session.get_factors(); A, B = f["A"], f["B"]
+    finally:
+        dist.destroy_process_group()
+    # the parts change which rows share a launch, not the arithmetic of a row
+    assert np.array_equal(B, Br) and np.array_equal(A, Ar)
