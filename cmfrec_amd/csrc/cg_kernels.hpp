@@ -43,6 +43,9 @@ struct RowDesc {
     unsigned long long st;
 };
 
+constexpr int CG_NCOUNTERS = 64;        // work counters per launch of a tiled CG kernel ...
+constexpr int CG_COUNTER_STRIDE = 32;    // ... each on its own 128-byte line
+
 template <typename T>
 struct CgParams {
     T *A;                 // [nrows_total, lda] matrix being updated, first solved column
@@ -70,6 +73,8 @@ struct CgParams {
     T w_side = 0;
     int rows_with_u = 0;      // local rows < rows_with_u carry side information; the others are plain rows
     int row_first = 0;        // generic kernel: first position of the processing order to handle
+    int *counter = nullptr;   // tiled kernels: work counter of this launch (zero at launch); a team's first row is its own
+                              // index, the following ones are claimed in order (longest rows first) from here
     int p_side = 0, scale_lam_sideinfo = 0;
 };
 
@@ -227,16 +232,45 @@ cg_rows_kernel(const CgParams<T> P)
     const int wr = wave % W;       // wave index inside the row team
     const int k = P.k;
 
+    const int nteams = gridDim.x * RPB;
+    // Dynamic row scheduling: team t starts with position t of the processing order and claims every further
+    // position from the launch's counter, always two rows ahead of the one it is solving (the descriptor / index
+    // prefetch below needs them early).  Rows are sorted longest first, so this is longest-processing-time-first
+    // list scheduling; above all a team that becomes resident late (other kernels on the CUs: a collective, the
+    // neighbouring bin) simply takes fewer rows instead of dragging a full static share behind the launch.
+    // Multi-wave teams: wave 0 claims, the position travels through LDS and is ordered by the barrier of the row's
+    // first pass.
+    // (Same-address atomics with return serialise at about 7 ns each on this part -- 2 ms for the 250 k short rows of
+    // C2's users -- so a launch has CG_NCOUNTERS counters on separate cache lines; counter j hands out the positions
+    // nteams + j + CG_NCOUNTERS * c, and a team uses the counter of its index modulo CG_NCOUNTERS.)
+    __shared__ int s_claim[4];
+    const int cslot = (blockIdx.x * RPB + grp) % CG_NCOUNTERS;
+    int *const my_counter = P.counter + cslot * CG_COUNTER_STRIDE;
+    const int cbase = nteams + cslot;
+    auto issue_claim = [&]() -> int {
+        int v = 0;
+        if (wr == 0 && lane == 0) v = atomicAdd(my_counter, 1);
+        return v;
+    };
+    int rnxt, rnn;
+    if (W == 1) {
+        const int c1 = issue_claim(), c2 = issue_claim();
+        rnxt = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(c1);
+        rnn = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(c2);
+    } else if (wr == 0 && lane == 0) {
+        s_claim[2] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
+        s_claim[3] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
+    }
     if (IMPLICIT) {
         for (int e = tid; e < 64 * LD; e += blockDim.x) {
             int r = e / LD, c = e % LD;
             G[e] = (r < k && c < k) ? P.BtB[(size_t)r * k + c] : T(0);
         }
-        __syncthreads();
     }
+    if (IMPLICIT || W > 1) __syncthreads();
+    if (W > 1) { rnxt = s_claim[2]; rnn = s_claim[3]; }
     T *myred = red + (size_t)grp * 2 * W * 64;
 
-    const int nteams = gridDim.x * RPB;
     int buf = 0;   // cross-wave exchange buffer parity; persists across rows
     static_assert(W == 1 || RPB == 1, "multi-wave teams own their workgroup (barriers are per row)");
 
@@ -267,9 +301,10 @@ cg_rows_kernel(const CgParams<T> P)
     };
     int rix = blockIdx.x * RPB + grp;
     RowDesc dcur = load_desc(rix);
-    RowDesc dnxt = load_desc(rix + nteams);
+    RowDesc dnxt = load_desc(rnxt);
     Pre pcur = load_pre(dcur);
-    for (; rix < P.nrows; rix += nteams) {
+    int pend = issue_claim();      // the position after rnn; lands while this row is solved
+    for (int it = 0; rix < P.nrows; it++) {
         const int row = dcur.row;
         const size_t st = dcur.st;
         const int nnz = dcur.nnz;
@@ -291,7 +326,7 @@ cg_rows_kernel(const CgParams<T> P)
         T x_res = pcur.x;
         bool valid_res = lane < cnt0;
         if (cnt0 > 0) load_tile<T, S>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
-        const RowDesc dnn = load_desc(rix + 2 * nteams);
+        const RowDesc dnn = load_desc(rnn);
         const Pre pnxt = load_pre(dnxt);
 
         auto run_pass = [&](T vdist, auto mode_tag, bool first) -> T {
@@ -326,6 +361,7 @@ cg_rows_kernel(const CgParams<T> P)
             if (W > 1) {
                 T *rb = myred + (size_t)buf * W * 64;
                 rb[wr * 64 + lane] = tot;
+                if (first && wr == 0 && lane == 0) s_claim[it & 1] = cbase + CG_NCOUNTERS * pend;
                 __syncthreads();
                 tot = T(0);
 #pragma unroll
@@ -361,7 +397,10 @@ cg_rows_kernel(const CgParams<T> P)
             }
         }
         if (wr == 0 && lane < k) arow[lane] = a_d;
+        const int r3 = (W == 1) ? cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(pend) : s_claim[it & 1];
         dcur = dnxt; dnxt = dnn; pcur = pnxt;
+        rix = rnxt; rnxt = rnn; rnn = r3;
+        pend = issue_claim();
     }
 }
 
@@ -540,16 +579,32 @@ cg_rows_tiny_kernel(const CgParams<T> P)
 
     int rix = blockIdx.x * 4 + (tid >> 6);
 #if CMF_TINY_WAVES_PER_SIMD >= 3
-    {   // single tile buffer, latency hidden by the other wavefronts of the SIMD
-        RowDesc d0 = load_desc(rix), d1 = load_desc(rix + nwaves);
+    {   // single tile buffer, latency hidden by the other wavefronts of the SIMD; rows are claimed dynamically, two
+        // ahead (see cg_rows_kernel)
+        const int cslot = rix % CG_NCOUNTERS;
+        int *const my_counter = P.counter + cslot * CG_COUNTER_STRIDE;
+        const int cbase = nwaves + cslot;
+        auto issue_claim = [&]() -> int {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(my_counter, 1);
+            return v;
+        };
+        const int c1 = issue_claim(), c2 = issue_claim();
+        int rnxt = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(c1);
+        int rnn = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(c2);
+        RowDesc d0 = load_desc(rix), d1 = load_desc(rnxt);
         Pre p0 = load_pre(d0);
         RegTile4<T, S> tA;
-        for (; rix < P.nrows; rix += nwaves) {
+        int pend = issue_claim();
+        while (rix < P.nrows) {
             load_tile4<T, S>(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
-            RowDesc d2 = load_desc(rix + 2 * nwaves);
+            RowDesc d2 = load_desc(rnn);
             Pre p1 = load_pre(d1);
             solve(d0, p0, tA);
+            const int r3 = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(pend);
             d0 = d1; p0 = p1; d1 = d2;
+            rix = rnxt; rnxt = rnn; rnn = r3;
+            pend = issue_claim();
         }
         return;
     }

@@ -318,6 +318,10 @@ struct CgCall {
 enum class CgVariant { Auto, Generic };
 CgVariant cg_variant_from_env();
 
+// layout of DeviceInfo::row_counter: [0, 64) the Cholesky kernels' counters, then CG_NCOUNTERS padded counters per nnz bin
+constexpr size_t ROW_COUNTER_INTS = 64 + (size_t)NBINS * CG_NCOUNTERS * CG_COUNTER_STRIDE;
+inline size_t cg_counter_offset(int bin) { return 64 + (size_t)bin * CG_NCOUNTERS * CG_COUNTER_STRIDE; }
+
 template <int S, bool IMPLICIT, int W, int RPB>
 inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
 {
@@ -331,6 +335,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     P.order += first;
     P.desc += first;
     P.nrows = count;
+    P.counter = dev.row_counter.ptr + cg_counter_offset(bin);          // zeroed by launch_cg_S
     constexpr int threads = 64 * W * RPB;
     size_t smem = ((IMPLICIT ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
     auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB>;
@@ -365,6 +370,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     P.order += first;
     P.desc += first;
     P.nrows = count;
+    P.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
     size_t smem = (IMPLICIT ? (size_t)64 * gram_ld(S) : 0) * sizeof(real_t);
     auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT>;
     static thread_local int blocks_per_cu = 0;
@@ -443,6 +449,8 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     // Few split rows (less than about one round of workgroups per pass: the users of C2) make their launch sequence --
     // 2 kernels per CG pass -- a chain of latencies, 0.08 ms with next to no work; it then runs on the second stream
     // beside the other bins.  Many split rows (the items of C2) fill the chip by themselves and stay in line.
+    if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, ROW_COUNTER_INTS * sizeof(int), dev.stream));   // work counters of the bins
     const bool vh_aside = X.bin_rows[BIN_VHEAVY] > 0 && X.vh_runs_aside(dev.num_cus);
     // A shard that is one of several parts of a block (multi-GPU overlap, session.hip) has a quarter of the rows per
     // launch, so ramp-up and tail of every bin weigh four times as much: its bins alternate between the two streams,

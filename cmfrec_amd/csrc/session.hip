@@ -61,7 +61,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                        "(k_t <= 256 in double, <= 272 in single precision)";
         return 2;
     }
-    if (!dev.row_counter.ptr) const_cast<DeviceInfo &>(dev).row_counter.alloc(16);
+    if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 2 * sizeof(int), dev.stream));
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
