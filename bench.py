@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard", "c5shard"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
                          "MovieLens10M-shaped configs of BASELINE.json (single GPU, side measurements)")
     args = ap.parse_args()
@@ -100,6 +100,8 @@ def main():
         return whole_fit(args)
     if args.workload == "c4shard":
         return c4_shard(args, local_rank)
+    if args.workload == "c5shard":
+        return c5_shard(args, local_rank)
     if args.workload != "c2":
         return side_workload(args, local_rank)
 
@@ -298,6 +300,55 @@ def c4_shard(args, device):
                       "frac_of_hbm_peak": round(alg / dt / 8e12, 3), "m": m, "n": n, "nnz": nnz,
                       "gen_seconds": round(t_gen, 1), "set_X_coo_seconds": round(t_setx, 2),
                       "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
+                      "note": "side measurement, not the headline metric"}))
+
+
+def c5_shard(args, device):
+    """An eighth of one GPU's share of BASELINE config 5 (1e8 x 1e6, nnz 2e9, k=256 fp32, 512-dim dense side information
+    on both sides, Cholesky, 8 GPUs): 1.5625M users x 125k items, 31.25M nnz (20 per user as in the full problem),
+    U[m, 512], I[n, 512], user and item biases, as a single-GPU problem.  Exercises the 17-tile single-precision
+    Cholesky kernel in COLLECTIVE mode and the side-information GEMMs at production width.  Side measurement."""
+    from cmfrec_amd.session import AlsSession
+    sc = 0.125 * args.scale
+    m, n, nnz = int(12_500_000 * sc), int(1_000_000 * sc), int(250_000_000 * sc)
+    k, p, q = 256, 512, 512
+    t0 = time.time()
+    row, col, _ = synth_block(m, n, nnz, seed=5)
+    rng = np.random.default_rng(5)
+    val = (0.5 * rng.integers(1, 11, nnz)).astype(np.float32)
+    val -= val.mean()
+    U = rng.standard_normal((m, p), dtype=np.float32)
+    II = rng.standard_normal((n, q), dtype=np.float32)
+    t_gen = time.time() - t0
+    sess = AlsSession(m, n, k, implicit=False, dtype=np.float32, lam=0.05, use_cg=False, user_bias=True, item_bias=True,
+                      scale_lam=True, p=p, m_u=m, q=q, n_i=n, device=device)
+    sess.set_X_coo(row, col, val)
+    sess.set_sideinfo(U=U, II=II)
+    sess.set_factors(A=rng.standard_normal((m, k), dtype=np.float32) * np.float32(2.0 ** -7),
+                     B=rng.standard_normal((n, k), dtype=np.float32) * np.float32(2.0 ** -7),
+                     biasA=np.zeros(m, np.float32), biasB=np.zeros(n, np.float32),
+                     Cm=np.zeros((p, k), np.float32), Dm=np.zeros((q, k), np.float32))
+    steps = max(1, min(args.steps, 3)); warm = min(args.warmup, 1)
+    for _ in range(warm):
+        sess.iterate(1)
+    sess.sync(); sess.reset_timers()
+    t0 = time.perf_counter()
+    sess.iterate(steps)
+    sess.sync()
+    dt = (time.perf_counter() - t0) / steps
+    msA, cA = sess.kernel_time("A"); msB, cB = sess.kernel_time("B")
+    f = sess.get_factors()
+    kt = k + 1
+    # SURVEY 8d: Gramians nnz*kt*(kt+1) + Cholesky kt^3/3 + 2 kt^2 per row, both half-steps; side-information GEMMs 2*rows*p*k (x3:
+    # U C for the right-hand sides, U^T A and the C update)
+    flops = 2 * nnz * kt * (kt + 1) + (m + n) * (kt ** 3 / 3 + 2 * kt * kt) + 3 * 2 * (m * p + n * q) * k
+    print(json.dumps({"workload": "1/8 of a c5 GPU share (1e8 x 1e6, nnz 2e9, k=256 fp32, p=q=512, Cholesky): %d x %d, %d nnz"
+                                  % (m, n, nnz),
+                      "ms_per_iteration": round(dt * 1e3, 2), "rows_per_s": round((m + n) / dt, 1),
+                      "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)},
+                      "alg_TFLOP": round(flops / 1e12, 2), "TFLOPs": round(flops / dt / 1e12, 1),
+                      "gen_seconds": round(t_gen, 1), "steps": steps,
+                      "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all() and np.isfinite(f["C"]).all()),
                       "note": "side measurement, not the headline metric"}))
 
 

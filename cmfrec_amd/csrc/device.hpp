@@ -2,6 +2,7 @@
 // nnz-binned row schedule, and the launchers of the row-update kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -227,15 +228,33 @@ struct DeviceInfo {
     // first use, owned here
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // rocBLAS handle for the plain dense contractions of the side-information path (U C, U^T A, A^T A for k > 64);
+    // created on first use, bound to `stream`, atomics off (bit-reproducible results)
+    rocblas_handle blas = nullptr;
     DeviceInfo() = default;
     DeviceInfo(const DeviceInfo &) = delete;
     DeviceInfo &operator=(const DeviceInfo &) = delete;
     ~DeviceInfo()
     {
+        if (blas) (void)rocblas_destroy_handle(blas);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (join_ev) (void)hipEventDestroy(join_ev);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (stream) (void)hipStreamDestroy(stream);
+    }
+    rocblas_handle ensure_blas()
+    {
+        if (!blas) {
+            if (rocblas_create_handle(&blas) != rocblas_status_success) {
+                blas = nullptr;
+                g_last_error = "cmfrec_hip: rocblas_create_handle failed";
+                throw HipError{1};
+            }
+            (void)rocblas_set_atomics_mode(blas, rocblas_atomics_not_allowed);
+            (void)rocblas_set_pointer_mode(blas, rocblas_pointer_mode_host);
+        }
+        (void)rocblas_set_stream(blas, stream);
+        return blas;
     }
     void ensure_aux()
     {
@@ -288,8 +307,20 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
         hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 3) / 4), dim3(256), 0, dev.stream,
                            ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
     } else {
-        hipLaunchKernelGGL(gram_naive_kernel<real_t>, dim3((k * k + 255) / 256), dim3(256), 0, dev.stream,
-                           B, ldb, n, k, out, scale, add_diag);
+        // k > 64: out = scale * B^T B as one library GEMM (row-major B[n, ldb] is the column-major [ldb, n] whose
+        // first k rows are B^T), then the diagonal shift; both triangles are filled
+        rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
+        const real_t zero = 0;
+#ifdef CMFREC_HIP_FLOAT
+        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, k, k, n, &scale, B, (int)ldb, B,
+                                          (int)ldb, &zero, out, k);
+#else
+        rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, k, k, n, &scale, B, (int)ldb, B,
+                                          (int)ldb, &zero, out, k);
+#endif
+        if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm (Gramian) failed"; throw HipError{1}; }
+        if (add_diag != 0)
+            hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3((k + 255) / 256), dim3(256), 0, dev.stream, out, k, 0, k, add_diag);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -456,7 +487,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     // launch, so ramp-up and tail of every bin weigh four times as much: its bins alternate between the two streams,
     // the next bin fills the CUs the previous one is vacating.  (Not for whole blocks: there the per-bin event timings
     // feed the roofline report and must not overlap.)
-    const bool alt = X.is_part && getenv("CMFREC_HIP_PART_SERIAL") == nullptr;
+    const bool alt = (X.is_part && getenv("CMFREC_HIP_PART_SERIAL") == nullptr) || getenv("CMFREC_HIP_BINS_ALT") != nullptr;
     DeviceInfo &d = const_cast<DeviceInfo &>(dev);
     if (vh_aside || alt) {
         d.ensure_aux();
@@ -464,7 +495,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
         HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
     }
     hipStream_t s0 = dev.stream, s1 = alt ? d.aux_stream : dev.stream;
-    launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm, (vh_aside || alt) ? d.aux_stream : dev.stream);
+    launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm, (vh_aside || (alt && X.is_part)) ? d.aux_stream : dev.stream);
     // then longest rows first: they are the longest-running teams
     launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY, s0);
     launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4, s1);

@@ -108,7 +108,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
 #ifdef CMFREC_HIP_FLOAT
     else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 32, 1>, 12, 8, 32, 1);
     else if (T <= 16) launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
-    else launch(chol_rows_kernel<real_t, 17, 8, 16, 1>, 17, 8, 16, 1);        // k = 256 + bias (BASELINE config 5)
+    // k = 256 + bias (BASELINE config 5).  Two workgroups per CU do not pay here: at the 128 VGPRs that allows the
+    // kernel spills (c5 share 1.6 -> 4.0 s per A-step; the same on 9 tiles in double: 22.6 -> 25.6 ms).
+    else launch(chol_rows_kernel<real_t, 17, 8, 16, 1>, 17, 8, 16, 1);
 #else
     else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 16, 1>, 12, 8, 16, 1);
     else launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
@@ -122,9 +124,26 @@ static void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
                         const real_t *B, size_t ldb, real_t *C, size_t ldc)
 {
     if (M <= 0 || N <= 0) return;
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    hipLaunchKernelGGL((gemm_kernel<real_t, TRANSA>), grid, dim3(256), 0, dev.stream, M, N, K, alpha, A, lda, B, ldb, C, ldc);
-    HIP_CHECK(hipGetLastError());
+    // C[M, N] = alpha * op(A) B, all row-major.  These are the plain dense contractions of the side-information path
+    // (U C, U^T A, I D ...): a library GEMM.  Row-major C is the column-major C^T = B^T op(A)^T, and a row-major matrix
+    // is its own transpose in column-major storage, so: first operand B (no transpose), second operand A with the
+    // transposition flag inverted.
+    static const bool own = getenv("CMFREC_HIP_GEMM_OWN") != nullptr;        // A/B switch: the LDS-tiled kernel of dense_kernels.hpp
+    if (own || K <= 0) {
+        dim3 grid((N + 63) / 64, (M + 63) / 64);
+        hipLaunchKernelGGL((gemm_kernel<real_t, TRANSA>), grid, dim3(256), 0, dev.stream, M, N, K, alpha, A, lda, B, ldb, C, ldc);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
+    const real_t zero = 0;
+    const rocblas_operation opA = TRANSA ? rocblas_operation_transpose : rocblas_operation_none;
+#ifdef CMFREC_HIP_FLOAT
+    rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
+#else
+    rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
+#endif
+    if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm failed"; throw HipError{1}; }
 }
 
 static void init_device(DeviceInfo &dev, int device)
