@@ -440,6 +440,12 @@ chol_rows_kernel(const CholParams<T> P)
             // c. trailing tiles:  tile(bi, bj) -= X_bi^T X_bj ;  forward substitution of the later blocks.
             //    Operands of every slot are read unconditionally (two k-steps at a time); the MFMAs of one
             //    k-step are independent of each other.
+            // A wave's slots are in tile order, i.e. by block row, so the live tiles (block row > kbk) are the suffix
+            // [tt0, TPW) of them: a scalar compare per MFMA.  (The per-slot tile coordinates live in vector registers,
+            // see above; predicates on them compile to exec-mask juggling around every MFMA.)  Padding tiles inside
+            // the suffix are updated too: nothing reads them.
+            const int ft1 = (kbk + 1) * NTT - ((kbk + 1) * kbk) / 2;            // first tile of block row kbk + 1
+            const int tt0 = max(0, (ft1 - __builtin_amdgcn_readfirstlane(wave) + NW - 1) / NW);
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 T xa[TPW][2], xb[TPW][2];
@@ -454,7 +460,7 @@ chol_rows_kernel(const CholParams<T> P)
                 for (int r2 = 0; r2 < 2; r2++)
 #pragma unroll
                     for (int tt = 0; tt < TPW; tt++)
-                        if (T_BI(tt) > kbk && T_REAL(tt)) acc[tt] = Mf::mma(xa[tt][r2], xb[tt][r2], acc[tt]);
+                        if (tt >= tt0) acc[tt] = Mf::mma(xa[tt][r2], xb[tt][r2], acc[tt]);
             }
             {
                 const int jg = tid;
