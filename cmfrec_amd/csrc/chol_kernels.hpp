@@ -52,6 +52,16 @@ struct CholParams {
     const T *Minit;            // implicit: BtB + lam*I [kt,kt];  collective (both): w*CtC [kc,kc];  explicit: null
     const T *Mfull;            // collective implicit: [kt,kt] matrix every solved row starts from;  else null
     int kc;                    // collective: size of the side-info block (k_user + k), else 0
+    // optional second gather source (sparse side information: the row's entries of U select rows of C):
+    // after the nnz entries of X the row has indptr2[row+1] - indptr2[row] more entries (indices2, values2) that gather
+    // rows of B2[*, ldb2] into the unknowns [0, kc2), weighted w2 (rank-1 terms) and w2 * value (right-hand side)
+    const size_t *indptr2 = nullptr;
+    const int *indices2 = nullptr;
+    const T *values2 = nullptr;
+    const T *B2 = nullptr;
+    size_t ldb2 = 0;
+    int kc2 = 0;
+    T w2 = 0;
     int rows_with_u;           // collective: rows < rows_with_u carry side information
     int p_side;                // collective: number of side-info columns (scale_lam_sideinfo)
     T lam, lam_last;
@@ -262,6 +272,17 @@ chol_rows_kernel(const CholParams<T> P)
         svalid |= ok ? (1u << j) : 0u;
     }
 
+    const bool two_src = P.indptr2 != nullptr;
+    int scol2[NCJ];
+    unsigned svalid2 = 0;
+#pragma unroll
+    for (int j = 0; j < NCJ; j++) {
+        const int c = lane + 64 * j;
+        const bool ok = two_src && (c < P.kc2);
+        scol2[j] = ok ? c : 0;
+        svalid2 |= ok ? (1u << j) : 0u;
+    }
+
     __shared__ int s_rix;
     for (;;) {
         if (tid == 0) s_rix = P.row_first + atomicAdd(P.counter, 1);
@@ -271,7 +292,10 @@ chol_rows_kernel(const CholParams<T> P)
         if (rix >= P.nrows) break;
         const int row = (P.order != nullptr) ? P.order[rix] : rix;
         const size_t st = (P.mode == CHOL_PREFILLED) ? 0 : P.indptr[row];
-        const int nnz = (P.mode == CHOL_PREFILLED) ? 0 : (int)(P.indptr[row + 1] - st);
+        const int nnz1 = (P.mode == CHOL_PREFILLED) ? 0 : (int)(P.indptr[row + 1] - st);
+        const size_t st2 = (two_src && row < P.rows_with_u) ? P.indptr2[row] : 0;
+        const int nnz2 = (two_src && row < P.rows_with_u) ? (int)(P.indptr2[row + 1] - st2) : 0;
+        const int nnz = nnz1 + nnz2;              // entries to gather; nnz1 of them are observations of X
         T *arow = P.A + (size_t)row * P.lda;
         const bool coll = (P.mode == CHOL_COLLECTIVE || P.mode == CHOL_COLLECTIVE_IMPLICIT);
         const bool impl_w = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_COLLECTIVE_IMPLICIT);
@@ -283,13 +307,13 @@ chol_rows_kernel(const CholParams<T> P)
         T lam = P.lam, lam_last = P.lam_last;
         if (P.mode == CHOL_EXPLICIT) {
             if (P.scale_lam) {                                           // common.c:679-723
-                lam *= (T)nnz;
-                if (!P.scale_bias_const) lam_last *= (T)nnz;
+                lam *= (T)nnz1;
+                if (!P.scale_bias_const) lam_last *= (T)nnz1;
             }
         } else if (P.mode == CHOL_COLLECTIVE) {
             if (P.scale_lam || P.scale_lam_sideinfo) {                   // collective.c:1285-1355
-                T mult = (nnz > 0) ? (T)nnz : T(1);
-                if (P.scale_lam_sideinfo && has_u) mult += (T)P.p_side;
+                T mult = (nnz1 > 0) ? (T)nnz1 : T(1);
+                if (P.scale_lam_sideinfo && has_u) mult += two_src ? (T)nnz2 : (T)P.p_side;   // :1338-1346
                 lam *= mult;
                 // rows without side information are plain factors_closed_form rows when new rows are fitted
                 // (collective.c:3772-3815): there scale_bias_const keeps the bias' lambda (common.c:679-723)
@@ -310,23 +334,39 @@ chol_rows_kernel(const CholParams<T> P)
         int widx = 0; T wx = T(0);
         T pre_wsyr = T(0), pre_wrhs = T(0);
         int nr_rows = 0, nr_idx = 0;
+        unsigned src_idx = 0, src_rows = 0;       // bit i: staged row i of this wave comes from the second source
+        bool wsrc2 = false;
+        // entry e of the row: e < nnz1 -> observation e of X, else side-information entry e - nnz1
         auto load_idx = [&](int c0) {
             nr_idx = min(CHOL_CHUNK, nnz - c0);
+            src_idx = 0;
 #pragma unroll
-            for (int i = 0; i < RPW; i++) idn[i] = P.indices[st + c0 + min(RPW * wave + i, nr_idx - 1)];
-            const int mine = min(tid, nr_idx - 1);
-            widx = P.indices[st + c0 + mine]; wx = P.values[st + c0 + mine];
+            for (int i = 0; i < RPW; i++) {
+                const int e = c0 + min(RPW * wave + i, nr_idx - 1);
+                const bool s2 = e >= nnz1;
+                idn[i] = s2 ? P.indices2[st2 + (e - nnz1)] : P.indices[st + e];
+                src_idx |= s2 ? (1u << i) : 0u;
+            }
+            const int e = c0 + min(tid, nr_idx - 1);
+            wsrc2 = e >= nnz1;
+            widx = wsrc2 ? 0 : P.indices[st + e];
+            wx = wsrc2 ? P.values2[st2 + (e - nnz1)] : P.values[st + e];
         };
         auto load_rows = [&]() {
             nr_rows = nr_idx;
+            src_rows = src_idx;
 #pragma unroll
-            for (int i = 0; i < RPW; i++)
+            for (int i = 0; i < RPW; i++) {
+                const bool s2 = (src_idx >> i) & 1u;
+                const T *base = s2 ? P.B2 + (size_t)idn[i] * P.ldb2 : P.B + (size_t)idn[i] * P.ldb;
 #pragma unroll
-                for (int j = 0; j < NCJ; j++) pre[i][j] = P.B[(size_t)idn[i] * P.ldb + scol[j]];
+                for (int j = 0; j < NCJ; j++) pre[i][j] = base[s2 ? scol2[j] : scol[j]];
+            }
             T x = wx;
-            if (P.bias_sub != nullptr) x -= P.bias_sub[widx];
+            if (P.bias_sub != nullptr && !wsrc2) x -= P.bias_sub[widx];
             pre_wsyr = impl_w ? x : T(1);           // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
             pre_wrhs = impl_w ? x + T(1) : x;       // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
+            if (wsrc2) { pre_wsyr = P.w2; pre_wrhs = P.w2 * wx; }       // collective.c:1636-1653, :1719-1731 (sparse u_vec)
         };
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
@@ -339,7 +379,7 @@ chol_rows_kernel(const CholParams<T> P)
                 for (int j = 0; j < NCJ; j++)
                     if (lane + 64 * j < ldc)
                         Bs[(RPW * wave + i) * ldc + lane + 64 * j] =
-                            (RPW * wave + i < nr_rows && ((svalid >> j) & 1u)) ? pre[i][j] : T(0);
+                            (RPW * wave + i < nr_rows && (((((src_rows >> i) & 1u) ? svalid2 : svalid) >> j) & 1u)) ? pre[i][j] : T(0);
             if (tid < CHOL_CHUNK) {
                 wsc[slot * CHOL_CHUNK + tid] = (tid < nr_rows) ? pre_wsyr : T(0);
                 wrh[slot * CHOL_CHUNK + tid] = (tid < nr_rows) ? pre_wrhs : T(0);
@@ -347,7 +387,7 @@ chol_rows_kernel(const CholParams<T> P)
             __syncthreads();                  // slot visible; the other slot may still be read by slower waves
             if (c0 + CHOL_CHUNK < nnz) load_rows();                           // chunk c+1: in flight during the MFMAs
             if (c0 + 2 * CHOL_CHUNK < nnz) load_idx(c0 + 2 * CHOL_CHUNK);     // chunk c+2
-            if (tid >= koff && tid < kt) {                                     // rhs[e] += sum_r wrhs_r B_r[e]
+            if ((tid >= koff || two_src) && tid < kt) {                        // rhs[e] += sum_r wrhs_r B_r[e]
 #pragma unroll
                 for (int r = 0; r < CHOL_CHUNK; r++) racc += wrh[slot * CHOL_CHUNK + r] * Bs[r * ldc + tid];   // padded rows: weight 0, row 0
             }

@@ -112,7 +112,7 @@ int_t fit_collective_implicit_als(
     bool precompute_for_predictions, real_t *precomputedBtB, real_t *precomputedBeTBe,
     real_t *precomputedBeTBeChol, real_t *precomputedCtUbias)
 {
-    (void)U_row; (void)U_col; (void)I_row; (void)I_col; (void)NA_as_zero_U; (void)NA_as_zero_I;
+
     (void)nthreads; (void)max_cd_steps; (void)nonneg_C; (void)nonneg_D;
     (void)precomputedCtUbias;            // only written with sparse U + NA_as_zero_U (collective.c:10111), not supported
     (void)handle_interrupt;
@@ -120,12 +120,21 @@ int_t fit_collective_implicit_als(
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (U_sp || I_sp || nnz_U || nnz_I)
-        return fail(verbose, "cmfrec_hip: sparse side information is not implemented.");
-    if (U == nullptr) { m_u = 0; p = 0; }
-    if (II == nullptr) { n_i = 0; q = 0; }
-    for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
-    for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
+    // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.
+    const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
+    if (NA_as_zero_U || NA_as_zero_I) return fail(verbose, "cmfrec_hip: NA_as_zero_U / NA_as_zero_I are not implemented.");
+    if ((spU || spI) && use_cg)
+        return fail(verbose, "cmfrec_hip: sparse side information needs use_cg = false (the block CG on it is not implemented).");
+    if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
+        return fail(verbose, "cmfrec_hip: sparse side information must be COO triplets with rows inside X.");
+    if (U == nullptr && !spU) { m_u = 0; p = 0; }
+    if (II == nullptr && !spI) { n_i = 0; q = 0; }
+    if (U) for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
+    if (II) for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
+    for (size_t e = 0; spU && e < nnz_U; e++)
+        if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
+    for (size_t e = 0; spI && e < nnz_I; e++)
+        if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
     if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight)
         return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / adjust_weight are not implemented.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
@@ -162,12 +171,12 @@ int_t fit_collective_implicit_als(
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
     const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);     // rows of A / B (collective.c:9437-9440)
     if (reset_values) {                                                  // :9750-9774
-        const bool fill_B = (II != nullptr);
+        const bool fill_B = (II != nullptr || spI);
         cmfrng::random_parallel<real_t>(A, (size_t)m_max * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n_max * k_totB : 0, seed, false);
         if (use_cg) {
             if (!fill_B) memset(B, 0, (size_t)n_max * k_totB * sizeof(real_t));
-            if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
-            if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
+            if (U || spU) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
+            if (II || spI) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
         }
         // Cholesky: start values that are never read (the C / D / B steps run first) are left as passed, like the reference
     }
@@ -189,6 +198,8 @@ int_t fit_collective_implicit_als(
     std::vector<real_t>().swap(Xs);
     tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
+    if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
+    if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, C, D);
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     if (tm.on) cmfrec_hip_session_sync(s);
@@ -233,8 +244,8 @@ int_t fit_collective_explicit_als(
     real_t *precomputedBtXbias, real_t *precomputedBeTBeChol, real_t *precomputedBiTBi,
     real_t *precomputedTransCtCinvCt, real_t *precomputedCtCw, real_t *precomputedCtUbias)
 {
-    (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB; (void)U_row; (void)U_col; (void)I_row; (void)I_col;
-    (void)NA_as_zero_U; (void)NA_as_zero_I; (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
+    (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB;
+    (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
     (void)nonneg_C; (void)nonneg_D;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // only with add_implicit_features, not supported
@@ -243,19 +254,29 @@ int_t fit_collective_explicit_als(
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (Xfull || weight || NA_as_zero_X || U_sp || I_sp || nnz_U || nnz_I || add_implicit_features)
-        return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / sparse side info / implicit features are not implemented.");
+    if (Xfull || weight || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I || add_implicit_features)
+        return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / implicit features are not implemented.");
+    // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.
+    const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
+    if ((spU || spI) && use_cg)
+        return fail(verbose, "cmfrec_hip: sparse side information needs use_cg = false (the block CG on it is not implemented).");
+    if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
+        return fail(verbose, "cmfrec_hip: sparse side information must be COO triplets with rows inside X.");
+    for (size_t e = 0; spU && e < nnz_U; e++)
+        if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
+    for (size_t e = 0; spI && e < nnz_I; e++)
+        if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
     if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const)
         return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / scale_bias_const are not implemented.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
-    if (U == nullptr) { m_u = 0; p = 0; }
-    if (II == nullptr) { n_i = 0; q = 0; }
+    if (U == nullptr && !spU) { m_u = 0; p = 0; }
+    if (II == nullptr && !spI) { n_i = 0; q = 0; }
     if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
-    for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
-    for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
+    if (U) for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
+    if (II) for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
 
     SigGuard sig(true);
     scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
@@ -300,12 +321,12 @@ int_t fit_collective_explicit_als(
     tm.lap("side info centring");
     // ---- factor start values, collective.c:8241-8274 ----
     if (reset_values) {
-        const bool fill_B = (II != nullptr);
+        const bool fill_B = (II != nullptr || spI);
         cmfrng::random_parallel<real_t>(A, (size_t)m_max * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n_max * k_totB : 0, seed, true);
         if (use_cg) {
             if (!fill_B) memset(B, 0, (size_t)n_max * k_totB * sizeof(real_t));
-            if (U) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
-            if (II) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
+            if (U || spU) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));
+            if (II || spI) memset(D, 0, (size_t)q * (k_item + k) * sizeof(real_t));
         }
     }
 
@@ -324,6 +345,8 @@ int_t fit_collective_explicit_als(
     int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, X, nnz, gm, (real_t)1);
     tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
+    if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
+    if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("side info + factors upload");

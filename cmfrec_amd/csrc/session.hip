@@ -37,6 +37,12 @@ struct CholCall {
     bool scale_lam, scale_lam_sideinfo, scale_bias_const;
     int mode;
     const real_t *Mfull = nullptr;
+    // second gather source (sparse side information): rows of B2[*, ldb2] selected by X2's entries, unknowns [0, kc2)
+    const SparseShard *X2 = nullptr;
+    const real_t *B2 = nullptr;
+    size_t ldb2 = 0;
+    int kc2 = 0;
+    real_t w2 = 0;
 };
 
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
@@ -54,6 +60,10 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
     P.mode = c.mode;
+    if (c.X2) {
+        P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr;
+        P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2;
+    }
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
     if (T > 17 || (sizeof(real_t) == 8 && T > 16)) {
@@ -174,6 +184,9 @@ struct cmfrec_hip_session {
     size_t ldA = 0, ldB = 0;
     DevBuf<real_t> A, B, biasA, biasB, C, D, U, II;
     SparseShard Xr, Xc;
+    // sparse side information (missing = absent): CSR by user / item for the factor updates, CSC by attribute for C / D
+    SparseShard Usr, Usc, Isr, Isc;
+    bool sparseU = false, sparseI = false;
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
     std::vector<std::unique_ptr<SparseShard>> XrParts;
@@ -505,6 +518,34 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
     });
 }
 
+int cmfrec_hip_session_set_sideinfo_sparse(cmfrec_hip_session *s, int which, const int_t *row, const int_t *col,
+                                           const real_t *val, size_t nnz)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        const bool isU = (which == 'U');
+        const int rows = isU ? m.m_u : m.n_i, cols = isU ? m.p : m.q;
+        if ((which != 'U' && which != 'I') || rows <= 0 || cols <= 0 || nnz == 0) {
+            g_last_error = "cmfrec_hip_session_set_sideinfo_sparse: needs 'U' / 'I', the model's m_u, p / n_i, q and entries";
+            return 2;
+        }
+        if (rows > (isU ? (m.m_x > 0 ? m.m_x : m.m) : (m.n_x > 0 ? m.n_x : m.n)) || m.row_begin != 0 || m.row_end != m.m ||
+            m.col_begin != 0 || m.col_end != m.n) {
+            g_last_error = "cmfrec_hip: sparse side information: rows beyond X and sharded sessions are not supported";
+            return 2;
+        }
+        DevBuf<int> dr, dc; DevBuf<real_t> dv;
+        dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
+        // CSR over ALL rows of the factor matrix (rows beyond m_u / n_i are empty), CSC over the attributes
+        shard_from_coo(isU ? s->Usr : s->Isr, isU ? m.m : m.n, cols, dr.ptr, dc.ptr, dv.ptr, nnz, (real_t)0, (real_t)1, s->dev.stream);
+        shard_from_coo(isU ? s->Usc : s->Isc, cols, rows, dc.ptr, dr.ptr, dv.ptr, nnz, (real_t)0, (real_t)1, s->dev.stream);
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        (isU ? s->sparseU : s->sparseI) = true;
+        return 0;
+    });
+}
+
 // ---- one half-step of the ALS loop on the local block -------------------------------------
 // Explicit model: rows that exist only in the side information (beyond the shape of X) are fitted to it alone,
 //   a[:kc] = (C^T C + (lam / w) (p if scale_lam) I)^-1 C^T u     (optimizeA Case 1 on U[m_x:], collective.c:4967-5101)
@@ -556,6 +597,42 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const int kk = m.k + m.k_main;
     const int rows_x_self = isA ? (m.m_x > 0 ? m.m_x : m.m) : (m.n_x > 0 ? m.n_x : m.n);          // rows of this matrix X has
 
+    const bool sparse_side = isA ? s->sparseU : s->sparseI;
+    if (p_self > 0 && sparse_side) {
+        // sparse side information (missing = absent): the row's attributes are a second gather source of the same
+        // Cholesky launch (collective.c:1636-1653, :1719-1731 / :2003-2021); the block CG on it is not built
+        if (!chol) {
+            g_last_error = "cmfrec_hip: sparse side information needs the Cholesky updates (use_cg = false)";
+            return 2;
+        }
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const SparseShard &Us = isA ? s->Usr : s->Isr;
+        const int rows_u = isA ? m.m_u : m.n_i;
+        const int kc = k_side_self + m.k;
+        const real_t w = isA ? m.w_user : m.w_item;
+        if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822, :6018-6019
+        if (m.implicit) {
+            const int kt = k_side_self + kk;
+            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, m.lam);
+            hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, m.lam,
+                               s->betbe.ptr);
+            CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, nullptr, nullptr, kc, rows_u, p_self, m.lam,
+                       m.lam, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
+            c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
+            return launch_chol(dev, c, &X);
+        }
+        if (self_bias) {
+            const int rows_fill = isA ? m.n : m.m;
+            hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_fill), dim3(256), 0, st, opp, ld_opp, rows_fill,
+                               isA ? s->k_totB : s->k_totA, (real_t)1);
+        }
+        const int kt = k_side_self + kk + (self_bias ? 1 : 0);
+        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr,
+                   nullptr, kc, rows_u, p_self, m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo),
+                   (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE};
+        c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
+        return launch_chol(dev, c, &X);
+    }
     if (p_self > 0 && !chol) {
         // block CG on the collective system, dense full side information: collective_block_cg (explicit,
         // collective.c:2134-2903) / collective_block_cg_implicit (:2905-3303), prefer_CtC branch
@@ -673,7 +750,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
 }
 
 // C / D update: optimizeA Case 1 with do_B (common.c:2793-2991; Q6: always the transposed gemm)
-static int update_sideinfo(cmfrec_hip_session *s, bool isC)
+static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol)
 {
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
@@ -688,6 +765,18 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC)
     const real_t w = isC ? m.w_user : m.w_item;
     const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
     real_t lam = m.lam / w;                                                                        // collective.c:8367, :8418
+    if (isC ? s->sparseU : s->sparseI) {
+        // sparse side information: optimizeA Case 4 on its CSC -- one row of C per attribute, gathered from the
+        // first k_side+k columns of the factor matrix (collective.c:8354-8386; attributes nobody has stay untouched)
+        const SparseShard &Uc = isC ? s->Usc : s->Isc;
+        if (!chol) {
+            CgCall cg{Cm, (size_t)kc, F, ldF, kc, nullptr, nullptr, lam, lam, scale_lam, false, m.max_cg_steps, false,
+                      (bool)m.precondition_cg};
+            return launch_cg(dev, cg, Uc);
+        }
+        CholCall c{Cm, (size_t)kc, F, ldF, kc, 0, nullptr, nullptr, 0, 0, 0, lam, lam, scale_lam, false, false, CHOL_EXPLICIT};
+        return launch_chol(dev, c, &Uc);
+    }
     real_t diag = scale_lam ? lam * (real_t)rows_u : lam;                                          // common.c:2832
     launch_gram(dev, s->gws, F, ldF, rows_u, kc, s->gram.ptr, (real_t)1, diag);                    // common.c:2824
     launch_gemm<true>(dev, p, kc, rows_u, (real_t)1, Um, (size_t)p, F, ldF, Cm, (size_t)kc);       // common.c:2852-2855
@@ -832,7 +921,7 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
             (which == 'A' ? s->evA : s->evB).push_back(ev);
             return rc;
         }
-        if (which == 'C' || which == 'D') return update_sideinfo(s, which == 'C');
+        if (which == 'C' || which == 'D') return update_sideinfo(s, which == 'C', chol);
         g_last_error = "cmfrec_hip: unknown update target";
         return 2;
     });
@@ -1107,6 +1196,60 @@ int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size
         int rc = launch_chol(dev, c, &X);
         dA.download(A, (size_t)m * lda, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
+        return rc;
+    });
+}
+
+// Collective half-step with SPARSE side information (U given as CSR over the m_u rows that have any): the branches of
+// collective_closed_form_block (collective.c:1223-1847) / collective_closed_form_block_implicit (:1849-2131) with
+// u_vec == NULL, u_vec_sp != NULL, !NA_as_zero_U: the row's present attributes add  w * C_j C_j^T  to the upper-left
+// [k_user+k]^2 block (:1636-1653, :2003-2011) and  w * u_j C_j  to the right-hand side (:1719-1731, :2013-2021); under
+// scale_lam_sideinfo lambda is also multiplied by their number (:1338-1346).  Both gathers -- rows of B through X, rows of
+// C through U -- run through the same staging ring and matrix-core rank-1 updates of one kernel launch.
+int cmfrec_hip_optimizeA_collective_sparse(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C, int_t m,
+                                           int_t m_u, int_t n, int_t p, int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                           const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                           const real_t *bias_sub, const size_t Ucsr_p[], const int_t Ucsr_i[],
+                                           const real_t *Ucsr, real_t lam, real_t w_user, real_t lam_last, bool scale_lam,
+                                           bool scale_lam_sideinfo, bool implicit)
+{
+    return guarded([&]() {
+        if (m_u > m) { g_last_error = "cmfrec_hip: m_u > m is not supported here"; return 2; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        const int kc = k_user + k, kk = k + k_main, kt = k_user + kk;
+        DevBuf<real_t> dA, dB, dC, dG, dM, dbias;
+        GramWorkspace gws;
+        SparseShard X, Us;
+        dA.alloc((size_t)m * lda);
+        HIP_CHECK(hipMemsetAsync(dA.ptr, 0, dA.n * sizeof(real_t), dev.stream));          // collective.c:4817-4822, :6018-6019
+        dB.upload(B, (size_t)n * ldb, dev.stream);
+        dC.upload(C, (size_t)p * kc, dev.stream);
+        if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
+        shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
+        std::vector<size_t> up((size_t)m + 1);
+        for (int r = 0; r <= m; r++) up[r] = Ucsr_p[std::min(r, m_u)];
+        shard_from_csr(Us, m, up.data(), Ucsr_i, Ucsr, p, dev.stream);
+        int rc;
+        if (implicit) {
+            dG.alloc((size_t)kk * kk); dM.alloc((size_t)kt * kt);
+            launch_gram(dev, gws, dB.ptr + k_item, ldb, n, kk, dG.ptr, (real_t)1, lam);
+            hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, dev.stream, dG.ptr, kk, k_user, lam,
+                               dM.ptr);
+            CholCall c{dA.ptr, lda, dB.ptr + k_item, ldb, kt, k_user, nullptr, nullptr, kc, m_u, p, lam, lam, false, false, false,
+                       CHOL_COLLECTIVE_IMPLICIT, dM.ptr};
+            c.X2 = &Us; c.B2 = dC.ptr; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w_user;
+            rc = launch_chol(dev, c, &X);
+        } else {
+            CholCall c{dA.ptr, lda, dB.ptr + k_item, ldb, kt, k_user, bias_sub ? dbias.ptr : nullptr, nullptr, kc, m_u, p, lam,
+                       lam_last, (bool)(scale_lam || scale_lam_sideinfo), scale_lam_sideinfo, false, CHOL_COLLECTIVE};
+            c.X2 = &Us; c.B2 = dC.ptr; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w_user;
+            rc = launch_chol(dev, c, &X);
+        }
+        std::vector<real_t> tmp((size_t)m * lda);
+        dA.download(tmp.data(), (size_t)m * lda, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        for (int r = 0; r < m; r++) memcpy(A + (size_t)r * lda, tmp.data() + (size_t)r * lda, (size_t)kt * sizeof(real_t));
         return rc;
     });
 }

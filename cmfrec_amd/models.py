@@ -81,6 +81,17 @@ def _new_rows(X, n, dt):
             np.ascontiguousarray(val, dt), int(m_x))
 
 
+def _side_info(M, dt):
+    """Side information for fit(): dense array -> (array, None); SciPy sparse matrix -> (None, (row, col, val, rows, cols))."""
+    if M is None:
+        return None, None
+    if hasattr(M, "tocoo"):
+        M = M.tocoo()
+        return None, (np.ascontiguousarray(M.row, np.int32), np.ascontiguousarray(M.col, np.int32),
+                      np.ascontiguousarray(M.data, dt), int(M.shape[0]), int(M.shape[1]))
+    return np.ascontiguousarray(M, dt), None
+
+
 class CMF_implicit(_Base):
     """Implicit-feedback model (iALS / WRMF), reference class ``CMF_implicit``."""
 
@@ -108,15 +119,19 @@ class CMF_implicit(_Base):
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
         them from ``random_state`` (C argument ``reset_values=false``).  ``U`` / ``I``: dense side
-        information without missing values."""
+        information without missing values, or SciPy sparse matrices (missing = absent; needs ``use_cg=False``)."""
         row, col, val, m, n = _coo_triplet(X, shape)
         lib, R = self._lib()
         dt = self.dtype_
         val = np.ascontiguousarray(val, dt)
-        Uc = None if U is None else np.ascontiguousarray(U, dt)
-        Ic = None if I is None else np.ascontiguousarray(I, dt)
+        Uc, Us = _side_info(U, dt)
+        Ic, Is = _side_info(I, dt)
         m_u, p = (0, 0) if Uc is None else Uc.shape
         n_i, q = (0, 0) if Ic is None else Ic.shape
+        if Us is not None: m_u, p = Us[3], Us[4]
+        if Is is not None: n_i, q = Is[3], Is[4]
+        spU = (None, None, None, C.c_size_t(0)) if Us is None else (_lib.ptr(Us[0]), _lib.ptr(Us[1]), _lib.ptr(Us[2]), C.c_size_t(len(Us[2])))
+        spI = (None, None, None, C.c_size_t(0)) if Is is None else (_lib.ptr(Is[0]), _lib.ptr(Is[1]), _lib.ptr(Is[2]), C.c_size_t(len(Is[2])))
         ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
         reset = A0 is None
         A = np.empty((max(m, m_u), ka), dt) if reset else np.array(A0, dt, order="C", copy=True)     # m_max rows
@@ -138,7 +153,7 @@ class CMF_implicit(_Base):
             C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
             C.c_size_t(len(val)), R(self.lambda_), None, R(0.), None,
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
-            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            *spU, *spI,
             C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), _lib.ptr(wmm),
             R(self.alpha), C.c_bool(False),        # adjust_weight is always False (__init__.py:4753)
@@ -238,10 +253,14 @@ class CMF(_Base):
         lib, R = self._lib()
         dt = self.dtype_
         val = np.ascontiguousarray(val, dt)
-        Uc = None if U is None else np.ascontiguousarray(U, dt)
-        Ic = None if I is None else np.ascontiguousarray(I, dt)
+        Uc, Us = _side_info(U, dt)
+        Ic, Is = _side_info(I, dt)
         m_u, p = (0, 0) if Uc is None else Uc.shape
         n_i, q = (0, 0) if Ic is None else Ic.shape
+        if Us is not None: m_u, p = Us[3], Us[4]
+        if Is is not None: n_i, q = Is[3], Is[4]
+        spU = (None, None, None, C.c_size_t(0)) if Us is None else (_lib.ptr(Us[0]), _lib.ptr(Us[1]), _lib.ptr(Us[2]), C.c_size_t(len(Us[2])))
+        spI = (None, None, None, C.c_size_t(0)) if Is is None else (_lib.ptr(Is[0]), _lib.ptr(Is[1]), _lib.ptr(Is[2]), C.c_size_t(len(Is[2])))
         use_cg = self.use_cg
         ka, kb = self.k_user + self.k + self.k_main, self.k_item + self.k + self.k_main
         reset = A0 is None
@@ -271,7 +290,7 @@ class CMF(_Base):
             C.c_bool(self.center), R(self.lambda_), None, R(0.), None, C.c_bool(self.scale_lam),
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(False), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
-            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            *spU, *spI,
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
             C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), R(self.w_implicit),

@@ -90,6 +90,26 @@ def optimizeA_collective(A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=Non
     _lib.check(rc, lib, "optimizeA_collective")
 
 
+def optimizeA_collective_sparse(A, B, Cm, csr, U_csr, lam, w_user=1.0, lam_last=None, k=None, k_main=0, k_user=0, k_item=0,
+                                bias_sub=None, scale_lam=False, scale_lam_sideinfo=False, implicit=False):
+    """Collective half-step with SPARSE side information, Cholesky: ``U_csr`` = (indptr[m_u+1], indices, values) over the
+    first m_u rows (reference optimizeA_collective / optimizeA_collective_implicit with U_csr, !NA_as_zero_U)."""
+    lib, R = _prep(A, B)
+    m, lda = A.shape
+    n, ldb = B.shape
+    lam_last = lam if lam_last is None else lam_last
+    p, i, v = _csr(csr, A.dtype)
+    up, ui, uv = _csr(U_csr, A.dtype)
+    Cm = np.ascontiguousarray(Cm, A.dtype)
+    bs = None if bias_sub is None else np.ascontiguousarray(bias_sub, A.dtype)
+    rc = lib.cmfrec_hip_optimizeA_collective_sparse(
+        _lib.ptr(A), C.c_size_t(lda), _lib.ptr(B), C.c_size_t(ldb), _lib.ptr(Cm), C.c_int(m), C.c_int(len(up) - 1), C.c_int(n),
+        C.c_int(Cm.shape[0]), C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item), _lib.ptr(p), _lib.ptr(i), _lib.ptr(v),
+        _lib.ptr(bs), _lib.ptr(up), _lib.ptr(ui), _lib.ptr(uv), R(lam), R(w_user), R(lam_last), C.c_bool(scale_lam),
+        C.c_bool(scale_lam_sideinfo), C.c_bool(implicit))
+    _lib.check(rc, lib, "optimizeA_collective_sparse")
+
+
 def topN_batch(A, B, n_top=10, biasB=None, exclude=None):
     """Top-N item ids (and scores) for every row of ``A``: score = A_u . B_i (+ biasB[i]), descending, ties by lower
     id; ``exclude`` = (indptr, indices) CSR of items to skip per user (sorted here).  Batch counterpart of the

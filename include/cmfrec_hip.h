@@ -46,7 +46,8 @@ extern "C" {
  * (optimizeA_collective_implicit, src/collective.c:5971-6244) or block CG / PCG
  * (collective_block_cg_implicit, :2905-3303).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight,
  * no precompute.
- * Anything else returns 2. */
+ * or, with Cholesky updates (use_cg = false), SPARSE side information as COO triplets (U_row / U_col / U_sp / nnz_U and the
+ * I_* twins; missing = absent, rows within X's; collective.c:1849-2131 with u_vec_sp).  Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
     real_t *C, real_t *D,
@@ -81,7 +82,8 @@ int_t fit_collective_implicit_als(
  * CG / PCG or Cholesky, optional DENSE side information U[m_u, p] / II[n_i, q] without NaN (m_u, n_i may exceed
  * m, n: rows known from side information only are fitted to it alone and get a zero bias, :4967-5101, :8296)
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
- * k_main/k_user/k_item, w_user/w_item.  Anything else returns 2. */
+ * k_main/k_user/k_item, w_user/w_item; with Cholesky updates also SPARSE side information as COO triplets (missing =
+ * absent, rows within X's; collective_closed_form_block with u_vec_sp, :1636-1653, :1719-1731).  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,
@@ -244,6 +246,20 @@ int_t factors_collective_implicit_multiple(
     real_t *BeTBe, real_t *BtB, real_t *BeTBeChol, real_t *CtUbias,
     int nthreads);
 
+/* The same half-step with SPARSE side information: U as CSR over its m_u rows (missing attributes are simply absent,
+ * !NA_as_zero_U).  Explicit (implicit = false: collective_closed_form_block, src/collective.c:1223-1847) or implicit
+ * model (collective_closed_form_block_implicit, :1849-2131), Cholesky.  A is overwritten ([m, lda], first
+ * k_user+k+k_main columns). */
+int cmfrec_hip_optimizeA_collective_sparse(
+    real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+    int_t m, int_t m_u, int_t n, int_t p,
+    int_t k, int_t k_main, int_t k_user, int_t k_item,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+    const real_t *bias_sub,
+    const size_t Ucsr_p[], const int_t Ucsr_i[], const real_t *Ucsr,
+    real_t lam, real_t w_user, real_t lam_last,
+    bool scale_lam, bool scale_lam_sideinfo, bool implicit);
+
 /* ============================ level 3: device-resident session ============================= */
 
 typedef struct cmfrec_hip_session cmfrec_hip_session;
@@ -310,6 +326,11 @@ int cmfrec_hip_session_get_factors(cmfrec_hip_session *s, real_t *A, real_t *B,
 /* Dense side information, already centred by column (host does column means like
  * common.c:4911-4997): U rows [0,m_u), II rows [0,n_i). */
 int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, const real_t *II);
+/* SPARSE side information as COO triplets (which = 'U': [m_u, p], 'I': [n_i, q]; missing = absent, no centring):
+ * CSR by row and CSC by attribute are built on the device.  The factor updates then need use_cg = 0 (the row's
+ * attributes become a second gather source of the Cholesky kernel), C / D follow use_cg.  m_u <= rows of X. */
+int cmfrec_hip_session_set_sideinfo_sparse(cmfrec_hip_session *s, int which, const int_t *row, const int_t *col,
+                                           const real_t *val, size_t nnz);
 
 /* One update of the local block, asynchronous on the session stream. which: 'A','B','C','D'.
  * use_cholesky != 0 forces the Cholesky solver for this call (finalize_chol). */

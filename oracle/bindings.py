@@ -33,6 +33,15 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _coo_args(coo, dtype):
+    """(row ptr, col ptr, val ptr, nnz, keep-alive) of a COO side-information triplet, or NULLs."""
+    if coo is None:
+        return (None, None, None, C.c_size_t(0), None)
+    r = np.ascontiguousarray(coo[0], np.int32); c = np.ascontiguousarray(coo[1], np.int32)
+    v = np.ascontiguousarray(coo[2], dtype)
+    return (_ptr(r), _ptr(c), _ptr(v), C.c_size_t(len(v)), (r, c, v))
+
+
 def build_oracle():
     subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
 
@@ -135,6 +144,46 @@ class Oracle:
             C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             _ptr(pp), _ptr(i), _ptr(v), _ptr(U), self._r(lam), self._r(w_user), self._r(lam_last),
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_int(nthreads))
+
+    def optimizeA_collective_sparse(self, A, B, Cm, csr, U_csr, lam, w_user=1.0, lam_last=None, k=None, k_main=0,
+                                    k_user=0, k_item=0, scale_lam=False, scale_lam_sideinfo=False, implicit=False,
+                                    nthreads=1):
+        m, lda = A.shape
+        n, ldb = B.shape
+        lam_last = lam if lam_last is None else lam_last
+        up, ui, uv = U_csr
+        self.lib.oracle_optimizeA_collective_sparse_chol(
+            _ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb), _ptr(Cm), C.c_int(m), C.c_int(len(up) - 1), C.c_int(n),
+            C.c_int(Cm.shape[0]), C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]), _ptr(up), _ptr(ui), _ptr(uv),
+            self._r(lam), self._r(w_user), self._r(lam_last), C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
+            C.c_bool(implicit), C.c_int(nthreads))
+
+    def fit_als_sparse_sideinfo(self, A, B, row, col, val, k, implicit, U_coo=None, I_coo=None, Cm=None, Dm=None,
+                                biasA=None, biasB=None, user_bias=False, item_bias=False, center=False, lam=1.0, alpha=1.0,
+                                scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0, w_main=1.0,
+                                w_user=1.0, w_item=1.0, niter=3, nthreads=1):
+        """Whole fit with sparse side information (U_coo / I_coo = (row, col, val, rows, cols)), Cholesky updates."""
+        m, n = A.shape[0], B.shape[0]
+        row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
+        val = np.ascontiguousarray(val, self.dtype)
+        su, si = _coo_args(U_coo, self.dtype), _coo_args(I_coo, self.dtype)
+        m_u, p = (0, 0) if U_coo is None else (U_coo[3], U_coo[4])
+        n_i, q = (0, 0) if I_coo is None else (I_coo[3], I_coo[4])
+        if p and Cm is None: Cm = np.zeros((p, k_user + k), self.dtype)
+        if q and Dm is None: Dm = np.zeros((q, k_item + k), self.dtype)
+        biasA = np.zeros(m, self.dtype) if biasA is None else biasA
+        biasB = np.zeros(n, self.dtype) if biasB is None else biasB
+        gm = np.zeros(1, self.dtype)
+        ret = self.lib.oracle_fit_als_sparse_sideinfo(
+            C.c_bool(implicit), _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(gm),
+            C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
+            C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center), self._r(lam), self._r(alpha),
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
+            su[0], su[1], su[2], su[3], C.c_int(m_u), C.c_int(p), si[0], si[1], si[2], si[3], C.c_int(n_i), C.c_int(q),
+            C.c_int(k_main), C.c_int(k_user), C.c_int(k_item), self._r(w_main), self._r(w_user), self._r(w_item),
+            C.c_int(niter), C.c_int(nthreads))
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=gm[0])
 
     def calc_mean_and_center(self, X, nthreads=1):
         self.lib.oracle_calc_mean_and_center.restype = self.real
@@ -335,11 +384,15 @@ class Reference:
 
     def optimizeA_collective(self, A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=None,
                              k_main=0, k_user=0, k_item=0, scale_lam=False, scale_lam_sideinfo=False,
-                             nthreads=1, use_cg=False, m_u=None):
+                             nthreads=1, use_cg=False, m_u=None, U_csr=None):
+        """U dense [m_u, p], or sparse: U=None and U_csr=(indptr[m_u+1], indices, values)."""
         m, lda = A.shape
         n, ldb = B.shape
         p = Cm.shape[0]
         lam_last = lam if lam_last is None else lam_last
+        if U_csr is not None:
+            return self._optimizeA_collective_sparse(A, B, Cm, csr, U_csr, lam, w_user, lam_last, k, k_main, k_user, k_item,
+                                                     scale_lam, scale_lam_sideinfo, nthreads)
         m_u = U.shape[0] if m_u is None else m_u
         pp, i, v = csr
         k_totA = k_user + k + k_main
@@ -435,6 +488,60 @@ class Reference:
         assert rc == 0, rc
         return A
 
+    def optimizeA_collective_implicit_sparse(self, A, B, Cm, csr, U_csr, lam, w_user=1.0, k=None, k_main=0, k_user=0,
+                                             k_item=0, nthreads=1):
+        """optimizeA_collective_implicit (src/cmfrec.h:1442-1467) with sparse U, Cholesky.  A [m, k_user+k+k_main] and
+        B [n, k_item+k+k_main] are contiguous (the function takes no leading dimensions)."""
+        m, ka = A.shape
+        n, kb = B.shape
+        assert ka == k_user + k + k_main and kb == k_item + k + k_main
+        p = Cm.shape[0]
+        up, ui, uv = U_csr
+        pp, i, v = csr
+        k_totA = k_user + k + k_main
+        BtB = np.zeros((k + k_main) ** 2, self.dtype)
+        buf = self._scratch(k_totA * k_totA * (nthreads + 8) + (n + m + p) * (nthreads + 2) + 4096)
+        flags = [C.c_bool(False) for _ in range(4)]
+        self.lib.optimizeA_collective_implicit(
+            _ptr(A), _ptr(B), _ptr(Cm), C.c_int(m), C.c_int(len(up) - 1), C.c_int(n), C.c_int(p),
+            C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            _ptr(pp), _ptr(i), _ptr(v), _ptr(up), _ptr(ui), _ptr(uv), None, None, None,
+            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            self._r(lam), self._r(0.), self._r(w_user), C.c_int(nthreads), C.c_bool(False),
+            C.c_bool(False), C.c_int(3), C.c_bool(False), C.c_bool(False), C.c_int(100),
+            _ptr(BtB), None, None, None, None,
+            C.byref(flags[0]), C.byref(flags[1]), C.byref(flags[2]), C.byref(flags[3]),
+            _ptr(buf), None)
+
+    def _optimizeA_collective_sparse(self, A, B, Cm, csr, U_csr, lam, w_user, lam_last, k, k_main, k_user, k_item,
+                                     scale_lam, scale_lam_sideinfo, nthreads):
+        m, lda = A.shape
+        n, ldb = B.shape
+        p = Cm.shape[0]
+        up, ui, uv = U_csr
+        m_u = len(up) - 1
+        pp, i, v = csr
+        k_totA = k_user + k + k_main
+        buf = self._scratch(k_totA * k_totA * (nthreads + 6) + (n + m + p) * (nthreads + 2) + 4096)
+        flags = [C.c_bool(False) for _ in range(5)]
+        self.lib.optimizeA_collective(
+            _ptr(A), C.c_int(lda), _ptr(B), C.c_int(ldb), _ptr(Cm), None,
+            C.c_int(m), C.c_int(m_u), C.c_int(n), C.c_int(p),
+            C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            _ptr(pp), _ptr(i), _ptr(v), None, C.c_int(0),
+            C.c_bool(False), C.c_bool(False), C.c_bool(False), None, None, C.c_bool(False),
+            None, C.c_int(0), C.c_int(0), C.c_bool(False),
+            _ptr(up), _ptr(ui), _ptr(uv), None, None, None,
+            C.c_bool(False), C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            self._r(lam), self._r(w_user), self._r(1.), self._r(lam_last), self._r(0.), self._r(0.),
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), None,
+            C.c_bool(False), C.c_int(nthreads), C.c_bool(False),
+            C.c_bool(False), C.c_int(3), C.c_bool(False), C.c_bool(False), C.c_int(100),
+            None, None, None, self._r(0.), C.c_bool(False),
+            None, None, None, None, None,
+            C.byref(flags[0]), C.byref(flags[1]), C.byref(flags[2]), C.byref(flags[3]), C.byref(flags[4]),
+            _ptr(buf), None)
+
     def calc_mean_and_center(self, row, col, X, m, n, nthreads=1):
         """Returns (glob_mean, centred copy of X)."""
         Xp = (C.c_void_p * 1)(X.ctypes.data)
@@ -471,17 +578,21 @@ class Reference:
                                     finalize_chol=False, reset_values=False, seed=1,
                                     apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
-                                    precompute=False, m=None, n=None):
+                                    precompute=False, m=None, n=None, U_coo=None, I_coo=None):
+        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         wmm = np.zeros(1, self.dtype)
         m_u, p = (0, 0) if U is None else U.shape
         n_i, q = (0, 0) if II is None else II.shape
+        su, si = _coo_args(U_coo, self.dtype), _coo_args(I_coo, self.dtype)
+        if U_coo is not None: m_u, p = U_coo[3], U_coo[4]
+        if I_coo is not None: n_i, q = I_coo[3], I_coo[4]
         Ucm = np.zeros(max(p, 1), self.dtype); Icm = np.zeros(max(q, 1), self.dtype)
-        if U is not None and Cm is None:
+        if p and Cm is None:
             Cm = np.zeros((p, k_user + k), self.dtype)
-        if II is not None and Dm is None:
+        if q and Dm is None:
             Dm = np.zeros((q, k_item + k), self.dtype)
         kq = k_user + k + k_main
         pre = dict(BtB=np.zeros((k + k_main, k + k_main), self.dtype), BeTBe=np.zeros((kq, kq), self.dtype),
@@ -491,7 +602,7 @@ class Reference:
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             self._r(lam), None, self._r(0.), None,
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
-            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             self._r(w_main), self._r(w_user), self._r(w_item), _ptr(wmm),
             self._r(alpha), C.c_bool(False), C.c_bool(apply_log_transf),
@@ -500,7 +611,7 @@ class Reference:
             C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
             C.c_bool(precompute), _ptr(pre["BtB"]) if pre else None, _ptr(pre["BeTBe"]) if pre else None,
             _ptr(pre["BeTBeChol"]) if pre else None, _ptr(pre["CtUbias"]) if pre else None)
-        if U is None and II is None and not precompute:
+        if U is None and II is None and not precompute and U_coo is None and I_coo is None:
             return ret
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm, pre=pre)
 
@@ -509,7 +620,9 @@ class Reference:
                                     center=True, lam=10.0, scale_lam=False, scale_lam_sideinfo=False,
                                     k_main=0, k_user=0, k_item=0, w_user=1.0, w_item=1.0, niter=10,
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
-                                    finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None):
+                                    finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
+                                    U_coo=None, I_coo=None):
+        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
@@ -518,10 +631,13 @@ class Reference:
         glob_mean = np.zeros(1, self.dtype)
         m_u, p = (0, 0) if U is None else U.shape
         n_i, q = (0, 0) if II is None else II.shape
+        su, si = _coo_args(U_coo, self.dtype), _coo_args(I_coo, self.dtype)
+        if U_coo is not None: m_u, p = U_coo[3], U_coo[4]
+        if I_coo is not None: n_i, q = I_coo[3], I_coo[4]
         Ucm = np.zeros(max(p, 1), self.dtype); Icm = np.zeros(max(q, 1), self.dtype)
-        if U is not None and Cm is None:
+        if p and Cm is None:
             Cm = np.zeros((p, k_user + k), self.dtype)
-        if II is not None and Dm is None:
+        if q and Dm is None:
             Dm = np.zeros((q, k_item + k), self.dtype)
         sbA = np.zeros(1, self.dtype); sbB = np.zeros(1, self.dtype)
         kp = k + k_main + int(user_bias); kc = k_user + k; kq = k_user + kp
@@ -542,7 +658,7 @@ class Reference:
             self._r(lam), None, self._r(0.), None,
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
-            None, None, None, C.c_size_t(0), None, None, None, C.c_size_t(0),
+            *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
             C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             self._r(1.), self._r(w_user), self._r(w_item), self._r(1.),

@@ -1214,3 +1214,178 @@ void oracle_factors_implicit_multiple(real_t *A, int_t m,
     }
     free(bufs); free(BtB); free(CtC);
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* optimizeA_collective (explicit, collective.c:5566-5968 -> collective_closed_form_block :1223-1847) and
+ * optimizeA_collective_implicit (:5971-6244 -> collective_closed_form_block_implicit :1849-2131) with SPARSE side
+ * information: u_vec == NULL, u_vec_sp != NULL, !NA_as_zero_U ("add_C" branches :1636-1653 / :2003-2011 and the
+ * tgemv_dense_sp right-hand sides :1719-1731 / :2013-2021); Cholesky; U_csr has m_u rows. */
+void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                                             int_t m, int_t m_u, int_t n, int_t p,
+                                             int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                             const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                             const size_t *Ucsr_p, const int_t *Ucsr_i, const real_t *Ucsr,
+                                             real_t lam, real_t w_user, real_t lam_last,
+                                             bool scale_lam, bool scale_lam_sideinfo, bool implicit, int nthreads)
+{
+    (void)p;
+    if (nthreads < 1) nthreads = 1;
+    const int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main;
+    for (int_t i = 0; i < m; i++) memset(A + (size_t)i * lda, 0, (size_t)k_totA * sizeof(real_t));  /* :4817-4822, :6018-6019 */
+    real_t *BtB = NULL;
+    if (implicit) {                                                            /* :6056-6061 */
+        BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
+        oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
+        for (int_t i = 0; i < kb; i++) BtB[(size_t)i * kb + i] += lam;
+    }
+    const size_t szbuf = (size_t)k_totA * k_totA;
+    real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {
+        const size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1], nnz = en - st;
+        const size_t us = ix < m_u ? Ucsr_p[ix] : 0, ue = ix < m_u ? Ucsr_p[(size_t)ix + 1] : 0, nnz_u = ue - us;
+        real_t *a = A + (size_t)ix * lda;
+        if (nnz == 0 && nnz_u == 0) continue;                                  /* :1258-1268, :1876-1885: zeros */
+        real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
+        memset(M, 0, szbuf * sizeof(real_t));
+        real_t lam_i = lam, lam_last_i = lam_last;
+        if (!implicit && (scale_lam || scale_lam_sideinfo)) {                  /* :1285-1355 */
+            real_t mult = nnz ? (real_t)nnz : (real_t)1;
+            if (scale_lam_sideinfo) mult += (real_t)nnz_u;                     /* :1338-1346 */
+            lam_i *= mult; lam_last_i *= mult;
+        }
+        for (size_t jx = us; jx < ue; jx++)                                    /* :1636-1653 / :2003-2011 */
+            syr_upper_(k_totC, w_user, C + (size_t)Ucsr_i[jx] * k_totC, M, k_totA);
+        for (size_t jx = us; jx < ue; jx++)                                    /* :1719-1731 / :2013-2021 */
+            axpy_(k_totC, w_user * Ucsr[jx], C + (size_t)Ucsr_i[jx] * k_totC, a);
+        real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;
+        if (implicit) {
+            for (int_t i = 0; i < kb; i++)
+                for (int_t j = i; j < kb; j++) Mlr[(size_t)i * k_totA + j] += BtB[(size_t)i * kb + j];
+            for (int_t i = 0; i < k_user; i++) M[(size_t)i * k_totA + i] += lam;
+            for (size_t jx = st; jx < en; jx++)
+                axpy_(kb, Xcsr[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+            for (size_t jx = st; jx < en; jx++)
+                syr_upper_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
+        } else {
+            for (size_t jx = st; jx < en; jx++)
+                syr_upper_(kb, (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
+            for (size_t jx = st; jx < en; jx++)
+                axpy_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+            for (int_t i = 0; i < k_totA - 1; i++) M[(size_t)i * k_totA + i] += lam_i;
+            M[(size_t)(k_totA - 1) * k_totA + (k_totA - 1)] += lam_last_i;
+        }
+        if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
+        else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+    }
+    free(bufs); free(BtB);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fit_collective_explicit_als (collective.c:7263-9370) / fit_collective_implicit_als (:9375-10207) with SPARSE side
+ * information on either side (COO triplets, missing = absent, no centring of it), Cholesky updates (use_cg = false),
+ * m_u <= m, n_i <= n, reset_values = false.  A side without side information is a plain optimizeA / optimizeA_implicit
+ * step.  C / D: optimizeA Case 4 on the CSC of U / I with lam / w (:8354-8441, :9834-9917).  Explicit: optional
+ * biases (start values passed in) and centring; implicit: alpha scaling, w_main folded into lam / w_user / w_item. */
+int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
+                                   real_t *glob_mean, int_t m, int_t n, int_t k,
+                                   const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                                   bool user_bias, bool item_bias, bool center,
+                                   real_t lam, real_t alpha, bool scale_lam, bool scale_lam_sideinfo,
+                                   const int_t *U_row, const int_t *U_col, const real_t *U_sp, size_t nnz_U, int_t m_u, int_t p,
+                                   const int_t *I_row, const int_t *I_col, const real_t *I_sp, size_t nnz_I, int_t n_i, int_t q,
+                                   int_t k_main, int_t k_user, int_t k_item,
+                                   real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads)
+{
+    if (nnz_U == 0) { m_u = 0; p = 0; }
+    if (nnz_I == 0) { n_i = 0; q = 0; }
+    if (m_u > m || n_i > n || (k_user && !p) || (k_item && !q)) return 2;
+    if (implicit) { user_bias = item_bias = center = false; scale_lam = scale_lam_sideinfo = false; }
+    scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
+    if (w_main != (real_t)1.) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   /* :7497-7521, :9786-9811 */
+    const int_t has_bias = (user_bias || item_bias) ? 1 : 0;
+    const int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main, kcu = k_user + k, kci = k_item + k;
+    const size_t ldA = (size_t)(k_totA + has_bias), ldB = (size_t)(k_totB + has_bias);
+    real_t *Xc = (real_t *)malloc((nnz + 1) * sizeof(real_t));
+    memcpy(Xc, X, nnz * sizeof(real_t));
+    if (implicit && alpha != (real_t)1.) for (size_t i = 0; i < nnz; i++) Xc[i] *= alpha;
+    if (glob_mean) *glob_mean = center ? oracle_calc_mean_and_center(Xc, nnz, nthreads) : (real_t)0;
+    size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t)), *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
+    int_t *csr_i = (int_t *)malloc((nnz + 1) * sizeof(int_t)), *csc_i = (int_t *)malloc((nnz + 1) * sizeof(int_t));
+    real_t *csr_v = (real_t *)malloc((nnz + 1) * sizeof(real_t)), *csc_v = (real_t *)malloc((nnz + 1) * sizeof(real_t));
+    oracle_coo_to_csr_and_csc(ixA, ixB, Xc, m, n, nnz, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v);
+    free(Xc);
+    /* side information: CSR by row, CSC by attribute (convert_sparse_X on U / I, collective.c:6452) */
+    size_t *Ur_p = NULL, *Uc_p = NULL, *Ir_p = NULL, *Ic_p = NULL;
+    int_t *Ur_i = NULL, *Uc_i = NULL, *Ir_i = NULL, *Ic_i = NULL;
+    real_t *Ur_v = NULL, *Uc_v = NULL, *Ir_v = NULL, *Ic_v = NULL;
+    if (p) {
+        Ur_p = (size_t *)malloc(((size_t)m_u + 1) * sizeof(size_t)); Uc_p = (size_t *)malloc(((size_t)p + 1) * sizeof(size_t));
+        Ur_i = (int_t *)malloc(nnz_U * sizeof(int_t)); Uc_i = (int_t *)malloc(nnz_U * sizeof(int_t));
+        Ur_v = (real_t *)malloc(nnz_U * sizeof(real_t)); Uc_v = (real_t *)malloc(nnz_U * sizeof(real_t));
+        oracle_coo_to_csr_and_csc(U_row, U_col, U_sp, m_u, p, nnz_U, Ur_p, Ur_i, Ur_v, Uc_p, Uc_i, Uc_v);
+    }
+    if (q) {
+        Ir_p = (size_t *)malloc(((size_t)n_i + 1) * sizeof(size_t)); Ic_p = (size_t *)malloc(((size_t)q + 1) * sizeof(size_t));
+        Ir_i = (int_t *)malloc(nnz_I * sizeof(int_t)); Ic_i = (int_t *)malloc(nnz_I * sizeof(int_t));
+        Ir_v = (real_t *)malloc(nnz_I * sizeof(real_t)); Ic_v = (real_t *)malloc(nnz_I * sizeof(real_t));
+        oracle_coo_to_csr_and_csc(I_row, I_col, I_sp, n_i, q, nnz_I, Ir_p, Ir_i, Ir_v, Ic_p, Ic_i, Ic_v);
+    }
+    real_t *A_b = A, *B_b = B, *csr_orig = NULL, *csc_orig = NULL;
+    if (has_bias) {                                                            /* :7651-7677, :8283-8317 */
+        A_b = (real_t *)malloc((size_t)m * ldA * sizeof(real_t));
+        B_b = (real_t *)malloc((size_t)n * ldB * sizeof(real_t));
+        if (item_bias) { csr_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csr_orig, csr_v, nnz * sizeof(real_t)); }
+        if (user_bias) { csc_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csc_orig, csc_v, nnz * sizeof(real_t)); }
+        for (int_t r = 0; r < m; r++) {
+            memcpy(A_b + (size_t)r * ldA, A + (size_t)r * k_totA, (size_t)k_totA * sizeof(real_t));
+            A_b[(size_t)r * ldA + k_totA] = user_bias ? biasA[r] : (real_t)1;
+        }
+        for (int_t c = 0; c < n; c++) {
+            memcpy(B_b + (size_t)c * ldB, B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));
+            B_b[(size_t)c * ldB + k_totB] = item_bias ? biasB[c] : (real_t)1;
+        }
+    }
+    for (int_t iter = 0; iter < niter; iter++) {
+        if (p) oracle_optimizeA_explicit(C, (size_t)kcu, A_b, ldA, p, m_u, kcu, Uc_p, Uc_i, Uc_v, lam / w_user, lam / w_user,
+                                         scale_lam, false, nthreads, false, false, 3);
+        if (q) oracle_optimizeA_explicit(D, (size_t)kci, B_b, ldB, q, n_i, kci, Ic_p, Ic_i, Ic_v, lam / w_item, lam / w_item,
+                                         scale_lam, false, nthreads, false, false, 3);
+        if (item_bias) for (int_t r = 0; r < m; r++) A_b[(size_t)r * ldA + k_totA] = 1;
+        if (user_bias) for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
+        if (q)
+            oracle_optimizeA_collective_sparse_chol(B_b, ldB, A_b, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
+                                                    csc_p, csc_i, csc_v, Ir_p, Ir_i, Ir_v, lam, w_item, lam, scale_lam,
+                                                    scale_lam_sideinfo, implicit, nthreads);
+        else if (implicit)
+            oracle_optimizeA_implicit(B_b + k_item, ldB, A_b + k_user, ldA, n, m, k + k_main, csc_p, csc_i, csc_v, lam, nthreads,
+                                      false, false, 3, NULL);
+        else
+            oracle_optimizeA_explicit(B_b + k_item, ldB, A_b + k_user, ldA, n, m, k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
+                                      lam, lam, scale_lam, false, nthreads, false, false, 3);
+        if (item_bias) for (int_t c = 0; c < n; c++) biasB[c] = B_b[(size_t)c * ldB + k_totB];
+        if (user_bias) for (int_t c = 0; c < n; c++) B_b[(size_t)c * ldB + k_totB] = 1;
+        if (item_bias) for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
+        if (p)
+            oracle_optimizeA_collective_sparse_chol(A_b, ldA, B_b, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
+                                                    csr_p, csr_i, csr_v, Ur_p, Ur_i, Ur_v, lam, w_user, lam, scale_lam,
+                                                    scale_lam_sideinfo, implicit, nthreads);
+        else if (implicit)
+            oracle_optimizeA_implicit(A_b + k_user, ldA, B_b + k_item, ldB, m, n, k + k_main, csr_p, csr_i, csr_v, lam, nthreads,
+                                      false, false, 3, NULL);
+        else
+            oracle_optimizeA_explicit(A_b + k_user, ldA, B_b + k_item, ldB, m, n, k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
+                                      lam, lam, scale_lam, false, nthreads, false, false, 3);
+        if (user_bias) for (int_t r = 0; r < m; r++) biasA[r] = A_b[(size_t)r * ldA + k_totA];
+    }
+    if (has_bias) {
+        for (int_t r = 0; r < m; r++) memcpy(A + (size_t)r * k_totA, A_b + (size_t)r * ldA, (size_t)k_totA * sizeof(real_t));
+        for (int_t c = 0; c < n; c++) memcpy(B + (size_t)c * k_totB, B_b + (size_t)c * ldB, (size_t)k_totB * sizeof(real_t));
+        free(A_b); free(B_b);
+    }
+    free(csr_orig); free(csc_orig);
+    free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
+    free(Ur_p); free(Uc_p); free(Ir_p); free(Ic_p); free(Ur_i); free(Uc_i); free(Ir_i); free(Ic_i);
+    free(Ur_v); free(Uc_v); free(Ir_v); free(Ic_v);
+    return 0;
+}

@@ -218,6 +218,16 @@ def main():
                     out["biasA_" + key] = bA
         save("g11_new_rows_" + tag, **out)
 
+        # ---- G12: fits with sparse side information (Cholesky updates) ----
+        out = {}
+        d = gc.sparse_sideinfo_problem(dt)
+        for ci, (name, implicit, which, sl, sls) in enumerate(gc.SPARSE_SIDE_CASES):
+            r = gc.sparse_sideinfo_reference(R, d, implicit, which, sl, sls)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g12_sparse_sideinfo_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

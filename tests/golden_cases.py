@@ -239,3 +239,93 @@ def new_rows_vs_golden(engine, dtype, extra=None):
             yield "k=%d %s" % (k, name), maxrel(A, g["A_" + key])
             if bA is not None:
                 yield "k=%d %s (bias)" % (k, name), maxrel(bA, g["biasA_" + key])
+
+
+# ---- sparse side information (missing = absent), Cholesky updates -----------------------------------------------------
+def sparse_sideinfo_problem(dtype, seed=41):
+    """Seeded problem for fits with sparse U / I: returns dict with X triplets (ratings and counts), side-information COO
+    tuples (row, col, val, rows, cols) and start values."""
+    rng = np.random.default_rng(seed)
+    m, n, k, p, q, m_u, n_i = 90, 70, 6, 9, 7, 80, 70
+    ku, ki, km = 2, 1, 1
+    d = dict(m=m, n=n, k=k, ku=ku, ki=ki, km=km)
+    def coo(rows, cols, cnt, empty):
+        lin = rng.choice(rows * cols, size=cnt, replace=False)
+        r = (lin // cols).astype(np.int32); c = (lin % cols).astype(np.int32)
+        keep = ~np.isin(r, empty)
+        return r[keep], c[keep]
+    ur, uc = coo(m_u, p, 280, (3, 5)); ir, ic = coo(n_i, q, 220, (4,))
+    d["U_coo"] = (ur, uc, rng.standard_normal(len(ur)).astype(dtype), m_u, p)
+    d["I_coo"] = (ir, ic, rng.standard_normal(len(ir)).astype(dtype), n_i, q)
+    xr, xc = coo(m, n, 1100, (3, 7, 85))
+    d["row"], d["col"] = xr, xc
+    d["ratings"] = (0.5 * rng.integers(1, 11, len(xr))).astype(dtype)
+    d["counts"] = np.ceil(rng.lognormal(1, 1, len(xr))).astype(dtype)
+    d["A0"] = (rng.standard_normal((m, ku + k + km)) * 0.1).astype(dtype); d["B0"] = (rng.standard_normal((n, ki + k + km)) * 0.1).astype(dtype)
+    d["C0"] = (rng.standard_normal((p, ku + k)) * 0.1).astype(dtype); d["D0"] = (rng.standard_normal((q, ki + k)) * 0.1).astype(dtype)
+    d["bA"] = (rng.standard_normal(m) * 0.1).astype(dtype); d["bB"] = (rng.standard_normal(n) * 0.1).astype(dtype)
+    return d
+
+
+SPARSE_SIDE_CASES = [("implicit UI", True, "UI", False, False), ("explicit UI", False, "UI", False, False),
+                     ("explicit UI scaled", False, "UI", True, True), ("explicit U", False, "U", True, False),
+                     ("implicit I", True, "I", False, False)]
+
+
+def sparse_sideinfo_reference(R, d, implicit, which, sl, sls, nthreads=2):
+    """The real reference on the problem; returns dict(A, B, C, D, biasA, biasB, glob_mean)."""
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, use_cg=False, nthreads=nthreads,
+              U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
+              Cm=d["C0"][:, d["ku"] - ku:].copy() if "U" in which else None, Dm=d["D0"][:, d["ki"] - ki:].copy() if "I" in which else None)
+    if implicit:
+        r = R.fit_collective_implicit_als(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, w_main=0.5, **kw)
+        return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"])
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **kw)
+    return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+
+
+def sparse_sideinfo_oracle(O, d, implicit, which, sl, sls, nthreads=2):
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads,
+              U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
+              Cm=d["C0"][:, d["ku"] - ku:].copy() if "U" in which else None, Dm=d["D0"][:, d["ki"] - ki:].copy() if "I" in which else None)
+    if implicit:
+        return O.fit_als_sparse_sideinfo(A0, B0, d["row"], d["col"], d["counts"], d["k"], True, lam=2.0, alpha=1.5, w_main=0.5, **kw)
+    return O.fit_als_sparse_sideinfo(A0, B0, d["row"], d["col"], d["ratings"], d["k"], False, biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                     user_bias=True, item_bias=True, center=True, lam=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **kw)
+
+
+def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype):
+    """The product: the estimators with SciPy sparse side information."""
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF, CMF_implicit
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    U = mk(d["U_coo"]) if "U" in which else None; I = mk(d["I_coo"]) if "I" in which else None
+    common = dict(k=d["k"], k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, use_cg=False,
+                  use_float=dtype is np.float32, precompute_for_predictions=False)
+    shape = (d["m"], d["n"])
+    if implicit:
+        mdl = CMF_implicit(lambda_=2.0, alpha=1.5, w_main=0.5, **common)
+        # start values of C / D cannot be injected through the estimator: the first C / D update overwrites them anyway
+        mdl.fit((d["row"], d["col"], d["counts"]), U=U, I=I, shape=shape, A0=A0, B0=B0)
+        return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_)
+    mdl = CMF(lambda_=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **common)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=I, shape=shape, A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, biasA=mdl.user_bias_, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_)
+
+
+def compare_fits(got, exp):
+    """Largest relative error over the factor matrices / biases both sides carry."""
+    err = 0.0
+    for key in ("A", "B", "C", "D", "biasA", "biasB"):
+        if key in exp and exp[key] is not None and got.get(key) is not None and np.size(exp[key]):
+            err = max(err, maxrel(got[key], exp[key]))
+    if "glob_mean" in exp and "glob_mean" in got:
+        err = max(err, abs(float(got["glob_mean"]) - float(exp["glob_mean"])))
+    return err

@@ -160,3 +160,17 @@ def test_new_rows(oracles, dtype):
         a1, b1 = gc.run_new_rows(H, kind, kw)
         a2, b2 = gc.run_new_rows(H, kind, dict(kw, csr=csr))
         assert gc.maxrel(a2, a1) < TOL[dtype], name
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_sparse_sideinfo(oracles, dtype):
+    """G12 through the estimators (fit_collective_*_als with U / I as COO triplets), and against the oracle."""
+    g = gc.load("g12_sparse_sideinfo", dtype)
+    d = gc.sparse_sideinfo_problem(dtype)
+    for ci, (name, implicit, which, sl, sls) in enumerate(gc.SPARSE_SIDE_CASES):
+        got = gc.sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        tol = 1e-9 if dtype is np.float64 else 1e-3          # three Cholesky iterations from injected start values
+        assert gc.compare_fits(got, exp) < tol, name
+        orc = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls)
+        assert gc.compare_fits(got, orc) < tol, name

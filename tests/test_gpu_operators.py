@@ -272,3 +272,33 @@ def test_cholesky_large_k(oracles, dtype, k, implicit):
         ops.optimizeA_explicit(Ah, B, csr, 0.05, k=k, lam_last=0.3, scale_lam=True, use_cg=False)
         O.optimizeA_explicit(Ao, B, csr, 0.05, k=k, lam_last=0.3, scale_lam=True, use_cg=False, nthreads=4)
     assert rel_err(Ah, Ao) < (1e-9 if dtype is np.float64 else 1e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k,ku,ki,km", [(8, 0, 0, 0), (50, 2, 1, 1), (120, 3, 0, 2)])
+def test_collective_sparse_sideinfo(oracles, dtype, k, ku, ki, km):
+    """Two gather sources in one launch of the Cholesky row kernel: rows of B through X and rows of C through the sparse
+    side information; explicit (with the lambda scalings and the fused bias subtraction) and implicit."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    tol = 1e-10 if dtype is np.float64 else 3e-4
+    rng = np.random.default_rng(k)
+    m, n, p, m_u = 700, 500, 40, 640
+    B = (rng.standard_normal((n, ki + k + km)) * 0.3).astype(dtype); Cm = (rng.standard_normal((p, ku + k)) * 0.3).astype(dtype)
+    ur, uc, _ = make_coo(m_u, p, 5000, 21, counts=False, dtype=dtype, heavy_row=(8, 35), empty_rows=(3, 5, 600))
+    uv = rng.standard_normal(len(ur)).astype(dtype)
+    ucsr, _ = O.coo_to_csr_and_csc(ur, uc, uv, m_u, p)
+    bias = (rng.standard_normal(n) * 0.1).astype(dtype)
+    for implicit in (False, True):
+        row, col, val = make_coo(m, n, 14000, 22, counts=implicit, dtype=dtype, heavy_row=(9, 300), empty_rows=(3, 7, 650))
+        csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+        A0 = rng.standard_normal((m, ku + k + km)).astype(dtype)
+        for sl, sls in (((False, False),) if implicit else ((False, False), (True, False), (True, True))):
+            a1, a2 = A0.copy(), A0.copy()
+            kw = dict(w_user=2.5, lam_last=None if implicit else 1.3, k=k, k_main=km, k_user=ku, k_item=ki, scale_lam=sl,
+                      scale_lam_sideinfo=sls, implicit=implicit)
+            ops.optimizeA_collective_sparse(a1, B, Cm, csr, ucsr, 0.7, bias_sub=None if implicit else bias, **kw)
+            csr_b = csr if implicit else (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+            O.optimizeA_collective_sparse(a2, B, Cm, csr_b, ucsr, 0.7, nthreads=4, **kw)
+            assert rel_err(a1, a2) < tol, (implicit, sl, sls)
+            assert not a1[3].any() and not a1[650].any()          # neither observations nor attributes

@@ -124,3 +124,14 @@ def test_new_rows(oracles, dtype):
     information, side-information-only rows, empty rows, bias, the lambda scalings and their two quirks."""
     for label, err in gc.new_rows_vs_golden(oracles[dtype], dtype, dict(nthreads=2)):
         assert err < TOL[dtype], (label, err)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_sideinfo(oracles, dtype):
+    """G12: fits with sparse side information, the reference's outputs."""
+    g = gc.load("g12_sparse_sideinfo", dtype)
+    d = gc.sparse_sideinfo_problem(dtype)
+    for ci, (name, implicit, which, sl, sls) in enumerate(gc.SPARSE_SIDE_CASES):
+        got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert gc.compare_fits(got, exp) < TOL[dtype], name

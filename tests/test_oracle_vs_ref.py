@@ -195,3 +195,51 @@ def test_new_rows_live(oracles, refs, dtype):
             assert gc.maxrel(a2, a1) < tol, (name, k)
             if b1 is not None:
                 assert gc.maxrel(b2, b1) < tol, (name, k)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sparse_sideinfo_live(oracles, refs, dtype):
+    """Collective half-step with SPARSE side information (U as CSR, missing = absent): optimizeA_collective general
+    branch (collective.c:5566-5968 -> :1223-1847) and optimizeA_collective_implicit (:5971-6244 -> :1849-2131), Cholesky.
+    Rows with observations but no attributes, attributes but no observations, neither, and rows beyond m_u."""
+    O, R = oracles[dtype], refs[dtype]
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    rng = np.random.default_rng(4)
+    m, n, k, p, m_u = 90, 70, 7, 11, 80
+    for ku, ki, km in ((0, 0, 0), (2, 1, 1)):
+        B = rng.standard_normal((n, ki + k + km)).astype(dtype); Cm = rng.standard_normal((p, ku + k)).astype(dtype)
+        ur, uc, _ = make_coo(m_u, p, 260, 12, counts=False, dtype=dtype, empty_rows=(3, 5))
+        uv = rng.standard_normal(len(ur)).astype(dtype)
+        ucsr, _ = R.coo_to_csr_and_csc(ur, uc, uv, m_u, p)
+        for counts in (False, True):
+            row, col, val = make_coo(m, n, 900, 11, counts=counts, dtype=dtype, heavy_row=(9, 50), empty_rows=(3, 7, 85))
+            csr, _ = R.coo_to_csr_and_csc(row, col, val, m, n)
+            A0 = rng.standard_normal((m, ku + k + km)).astype(dtype)
+            if counts:
+                a1, a2 = A0.copy(), A0.copy()
+                R.optimizeA_collective_implicit_sparse(a1, B, Cm, csr, ucsr, 0.7, w_user=2.5, k=k, k_main=km, k_user=ku,
+                                                       k_item=ki, nthreads=2)
+                O.optimizeA_collective_sparse(a2, B, Cm, csr, ucsr, 0.7, w_user=2.5, k=k, k_main=km, k_user=ku, k_item=ki,
+                                              implicit=True, nthreads=1)
+                assert rel_err(a2, a1) < tol, ("implicit", ku)
+                assert not a1[3].any() and not a1[85].any()
+                continue
+            for sl, sls in ((False, False), (True, False), (True, True)):
+                a1, a2 = A0.copy(), A0.copy()
+                kw = dict(w_user=2.5, lam_last=1.3, k=k, k_main=km, k_user=ku, k_item=ki, scale_lam=sl, scale_lam_sideinfo=sls)
+                R.optimizeA_collective(a1, B, Cm, csr, None, 0.7, U_csr=ucsr, nthreads=2, **kw)
+                O.optimizeA_collective_sparse(a2, B, Cm, csr, ucsr, 0.7, nthreads=1, **kw)
+                assert rel_err(a2, a1) < tol, ("explicit", ku, sl, sls)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fit_sparse_sideinfo_live(oracles, refs, dtype):
+    """Whole fits with sparse side information on one or both sides (collective.c:7263-10207, Cholesky updates):
+    C / D as optimizeA Case 4 on the attributes' CSC, A / B with the row's attributes as extra rank-1 terms."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    d = gc.sparse_sideinfo_problem(dtype, seed=43)
+    for name, implicit, which, sl, sls in gc.SPARSE_SIDE_CASES:
+        exp = gc.sparse_sideinfo_reference(refs[dtype], d, implicit, which, sl, sls, nthreads=3)
+        got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls, nthreads=1)
+        assert gc.compare_fits(got, exp) < tol, name
