@@ -216,7 +216,9 @@ __device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *
 // NTT = tiles per dimension of the compiled grid (k_t <= 16 NTT);  NW = wavefronts per workgroup
 // (wave w owns tiles t = w, w + NW, ... of the packed upper triangle and stages CHOL_CHUNK / NW of the
 // CHOL_CHUNK gathered rows of a round);  WGS = workgroups per CU the register budget is set for.
-template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS>
+// TWO_SRC compiles the second gather source in (sparse side information); the single-source build carries none of its
+// selects (they cost 4-19 % on the plain Cholesky configurations when they were unconditional).
+template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS, bool TWO_SRC = false>
 __global__ void __launch_bounds__(64 * NW, WGS)
 chol_rows_kernel(const CholParams<T> P)
 {
@@ -272,7 +274,7 @@ chol_rows_kernel(const CholParams<T> P)
         svalid |= ok ? (1u << j) : 0u;
     }
 
-    const bool two_src = P.indptr2 != nullptr;
+    const bool two_src = TWO_SRC && P.indptr2 != nullptr;
     int scol2[NCJ];
     unsigned svalid2 = 0;
 #pragma unroll

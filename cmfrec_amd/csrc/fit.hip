@@ -431,18 +431,18 @@ int_t factors_collective_explicit_multiple(
     real_t *TransCtCinvCt, real_t *CtCw, real_t *CtUbias, real_t *B_plus_bias,
     int nthreads)
 {
-    (void)U_row; (void)U_col; (void)U_sp; (void)U_csr_i; (void)U_csr; (void)m_ubin; (void)pbin; (void)Cb; (void)w_implicit;
+    (void)m_ubin; (void)pbin; (void)Cb; (void)w_implicit;
     (void)BtB; (void)TransBtBinvBt; (void)BtXbias; (void)BeTBeChol; (void)BiTBi; (void)CtCw; (void)CtUbias; (void)B_plus_bias;
     (void)nthreads;
     if (NA_as_zero_U || NA_as_zero_X) return unsupported_multiple("NA_as_zero");
     if (nonneg) return unsupported_multiple("nonneg");
-    if (nnz_U || U_csr_p) return unsupported_multiple("sparse side information");
+    const bool spU = (U == nullptr && (nnz_U || U_csr_p));
     if (Ub) return unsupported_multiple("binary side information");
     if (Xfull) return unsupported_multiple("dense X");
     if (weight) return unsupported_multiple("observation weights");
     if (Bi || add_implicit_features) return unsupported_multiple("implicit features");
     if (l1_lam != 0 || l1_lam_unique) return unsupported_multiple("L1 regularisation");
-    if (U == nullptr) { m_u = 0; }
+    if (U == nullptr && !spU) { m_u = 0; }
     if (std::max(m, m_u) <= 0) return 0;
     if (U) for (size_t e = 0; e < (size_t)m_u * (size_t)p; e++) if (std::isnan(U[e])) return unsupported_multiple("missing values in U");
     // factors_collective_explicit_single, collective.c:10611-10630
@@ -464,10 +464,12 @@ int_t factors_collective_explicit_multiple(
         vals = shifted.data();
     }
     const int_t n_rows_B = include_all_X ? std::max(n, n_max) : n;
-    int rc = cmfrec_hip_factors_multiple(A, biasA, m, m_u, U ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
+    int rc = cmfrec_hip_factors_multiple(A, biasA, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
                                          Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n_rows_B, C, biasB, k, k_user, k_item,
                                          k_main, lam, lam_bias, lam, w_user, false, scale_lam, scale_lam_sideinfo,
-                                         scale_bias_const, nullptr, TransCtCinvCt);
+                                         scale_bias_const, nullptr, TransCtCinvCt, U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i,
+                                         U_csr);
+    if (rc == 2) fprintf(stderr, "%s\n", cmfrec_hip_last_error());
     return rc > 3 ? 1 : rc;
 }
 
@@ -490,12 +492,12 @@ int_t factors_collective_implicit_multiple(
     real_t *BeTBe, real_t *BtB, real_t *BeTBeChol, real_t *CtUbias,
     int nthreads)
 {
-    (void)U_row; (void)U_col; (void)U_sp; (void)U_csr_i; (void)U_csr; (void)BeTBe; (void)CtUbias; (void)nthreads;
+    (void)BeTBe; (void)CtUbias; (void)nthreads;
     if (NA_as_zero_U) return unsupported_multiple("NA_as_zero");
     if (nonneg) return unsupported_multiple("nonneg");
-    if (nnz_U || U_csr_p) return unsupported_multiple("sparse side information");
+    const bool spU = (U == nullptr && (nnz_U || U_csr_p));
     if (l1_lam != 0) return unsupported_multiple("L1 regularisation");
-    if (U == nullptr) m_u = 0;
+    if (U == nullptr && !spU) m_u = 0;
     if (std::max(m, m_u) <= 0) return 0;                                        // rows out: max(m, m_u), collective.c:11210
     if (U) for (size_t e = 0; e < (size_t)m_u * (size_t)p; e++) if (std::isnan(U[e])) return unsupported_multiple("missing values in U");
     // BtB as the reference builds it when none is passed: + the lam of the call, before the w_main rescaling
@@ -514,9 +516,10 @@ int_t factors_collective_implicit_multiple(
     }
     // a precomputed BeTBeChol without BtB means the caller's BtB is unknown: rebuild (equal for consistent inputs)
     (void)BeTBeChol;
-    int rc = cmfrec_hip_factors_multiple(A, nullptr, m, m_u, U ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
+    int rc = cmfrec_hip_factors_multiple(A, nullptr, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
                                          Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n, C, nullptr, k, k_user, k_item, k_main,
-                                         lam, lam, BtB ? lam : lam_x, w_user, true, false, false, false, BtB, nullptr);
+                                         lam, lam, BtB ? lam : lam_x, w_user, true, false, false, false, BtB, nullptr,
+                                         U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr);
     return rc > 3 ? 1 : rc;
 }
 

@@ -75,6 +75,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 2 * sizeof(int), dev.stream));
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
+    const bool two_src = c.X2 != nullptr;
+    // the two-source build (sparse side information) only where it is asked for
+#define CHOL_KERN(a, b, c_, d) (two_src ? chol_rows_kernel<real_t, a, b, c_, d, true> : chol_rows_kernel<real_t, a, b, c_, d, false>)
     hipStream_t run_on = dev.stream;
     auto launch = [&](auto kern, int ntt, int nw, int ch, int wgs) {
         size_t smem = chol_lds_elems<real_t>(ntt, ch) * sizeof(real_t);
@@ -101,30 +104,31 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         }
         if (nheavy > 0) {
             P.nrows = nheavy;
-            launch(chol_rows_kernel<real_t, 4, 4, 16, 2>, 4, 4, 16, 2);
+            launch(CHOL_KERN(4, 4, 16, 2), 4, 4, 16, 2);
         }
         if (total > nheavy) {
             P.row_first = nheavy; P.nrows = total; P.counter = dev.row_counter.ptr + 1;
             if (two) run_on = d.aux_stream;
-            launch(chol_rows_kernel<real_t, 4, 2, 16, 2>, 4, 2, 16, 4);
+            launch(CHOL_KERN(4, 2, 16, 2), 4, 2, 16, 4);
             if (two) {
                 HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
                 HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
             }
         }
     }
-    else if (T <= 6) launch(chol_rows_kernel<real_t, 6, 8, 32, 1>, 6, 8, 32, 1);
-    else if (T <= 9) launch(chol_rows_kernel<real_t, 9, 8, 32, 1>, 9, 8, 32, 1);
+    else if (T <= 6) launch(CHOL_KERN(6, 8, 32, 1), 6, 8, 32, 1);
+    else if (T <= 9) launch(CHOL_KERN(9, 8, 32, 1), 9, 8, 32, 1);
 #ifdef CMFREC_HIP_FLOAT
-    else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 32, 1>, 12, 8, 32, 1);
-    else if (T <= 16) launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
+    else if (T <= 12) launch(CHOL_KERN(12, 8, 32, 1), 12, 8, 32, 1);
+    else if (T <= 16) launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
     // k = 256 + bias (BASELINE config 5).  Two workgroups per CU do not pay here: at the 128 VGPRs that allows the
     // kernel spills (c5 share 1.6 -> 4.0 s per A-step; the same on 9 tiles in double: 22.6 -> 25.6 ms).
-    else launch(chol_rows_kernel<real_t, 17, 8, 16, 1>, 17, 8, 16, 1);
+    else launch(CHOL_KERN(17, 8, 16, 1), 17, 8, 16, 1);
 #else
-    else if (T <= 12) launch(chol_rows_kernel<real_t, 12, 8, 16, 1>, 12, 8, 16, 1);
-    else launch(chol_rows_kernel<real_t, 16, 8, 16, 1>, 16, 8, 16, 1);
+    else if (T <= 12) launch(CHOL_KERN(12, 8, 16, 1), 12, 8, 16, 1);
+    else launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
 #endif
+#undef CHOL_KERN
     HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1275,17 +1279,26 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
                                 const real_t *B, int_t n, const real_t *C, const real_t *biasB, int_t k, int_t k_user,
                                 int_t k_item, int_t k_main, real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
                                 bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
-                                const real_t *BtB_pre, const real_t *TransCtCinvCt_pre)
+                                const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
+                                const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
+                                const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr)
 {
     return guarded([&]() {
-        const int m_max = std::max(m_x, (p > 0 && U) ? m_u : 0);
+        // sparse side information (COO or CSR over m_u rows, missing = absent): second gather source of the row kernel
+        const bool spU = (U == nullptr && p > 0 && ((nnz_U > 0 && U_row && U_col && U_sp) || U_csr_p));
+        const int m_max = std::max(m_x, (p > 0 && (U || spU)) ? m_u : 0);
         if (m_max <= 0) return 0;
-        if (!A || !B || n <= 0 || k < 0 || (p > 0 && U && !C) || (nnz > 0 && !Xcsr_p && (!ixA || !ixB || !X)) ||
+        if (!A || !B || n <= 0 || k < 0 || (p > 0 && (U || spU) && !C) || (nnz > 0 && !Xcsr_p && (!ixA || !ixB || !X)) ||
             (implicit && biasA)) {
             g_last_error = "cmfrec_hip_factors_multiple: invalid arguments";
             return 2;
         }
-        if (!(p > 0 && U)) { p = 0; m_u = 0; }
+        if (spU && !implicit && scale_lam_sideinfo) {
+            g_last_error = "cmfrec_hip_factors_multiple: sparse side information with scale_lam_sideinfo is not supported "
+                           "(the reference scales the rows without observations differently, collective.c:3397-3411)";
+            return 2;
+        }
+        if (!(p > 0 && (U || spU))) { p = 0; m_u = 0; }
         DeviceInfo dev;
         init_device(dev, -1);
         hipStream_t st = dev.stream;
@@ -1316,7 +1329,20 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
             shard_from_coo(Xs, m_max, n, dr.ptr, dc.ptr, dv.ptr, nnz, (real_t)0, (real_t)1, st);
             HIP_CHECK(hipStreamSynchronize(st));
         }
-        if (p > 0) {
+        SparseShard Us;
+        if (spU) {
+            dC.upload(C, (size_t)p * kc, st);
+            if (U_csr_p) {
+                std::vector<size_t> up((size_t)m_max + 1);
+                for (int r = 0; r <= m_max; r++) up[r] = U_csr_p[std::min(r, m_u)];
+                shard_from_csr(Us, m_max, up.data(), U_csr_i, U_csr, p, st);
+            } else {
+                DevBuf<int> dr, dc; DevBuf<real_t> dv;
+                dr.upload(U_row, nnz_U, st); dc.upload(U_col, nnz_U, st); dv.upload(U_sp, nnz_U, st);
+                shard_from_coo(Us, m_max, p, dr.ptr, dc.ptr, dv.ptr, nnz_U, (real_t)0, (real_t)1, st);
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+        } else if (p > 0) {
             dC.upload(C, (size_t)p * kc, st);
             dU.upload(U, (size_t)m_u * p, st);
             if (U_colmeans) {
@@ -1337,6 +1363,14 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
                 CholCall c{dA.ptr + k_user, ldA, opp, ldB, kk, 0, nullptr, dG.ptr, 0, 0, 0, lam, lam, false, false, false,
                            CHOL_IMPLICIT};
                 rc = launch_chol(dev, c, &Xs);
+            } else if (spU) {
+                dM.alloc((size_t)ktA * ktA);
+                hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)ktA * ktA), dim3(256), 0, st, dG.ptr, kk, k_user, lam,
+                                   dM.ptr);
+                CholCall c{dA.ptr, ldA, opp, ldB, ktA, k_user, nullptr, nullptr, kc, m_u, p, lam, lam, false, false, false,
+                           CHOL_COLLECTIVE_IMPLICIT, dM.ptr};
+                c.X2 = &Us; c.B2 = dC.ptr; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w_user;
+                rc = launch_chol(dev, c, &Xs);
             } else {
                 dM.alloc((size_t)ktA * ktA);
                 hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)ktA * ktA), dim3(256), 0, st, dG.ptr, kk, k_user, lam,
@@ -1350,6 +1384,13 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
         } else if (p == 0) {
             CholCall c{dA.ptr + k_user, ldA, opp, ldB, kk + ub, 0, bias_sub, nullptr, 0, 0, 0, lam, lam_bias,
                        (bool)(scale_lam || scale_lam_sideinfo), false, scale_bias_const, CHOL_EXPLICIT};
+            rc = launch_chol(dev, c, &Xs);
+        } else if (spU) {
+            // rows with attributes but no observations come out of the same launch: without scale_lam_sideinfo the
+            // "cold" solution (collective.c:3309-3440 with u_vec_sp) is the block system with an empty X part
+            CholCall c{dA.ptr, ldA, opp, ldB, kt, k_user, bias_sub, nullptr, kc, m_u, p, lam, lam_bias, scale_lam, false,
+                       scale_bias_const, CHOL_COLLECTIVE};
+            c.X2 = &Us; c.B2 = dC.ptr; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w_user;
             rc = launch_chol(dev, c, &Xs);
         } else {
             launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dCtC.ptr, w_user, (real_t)0);

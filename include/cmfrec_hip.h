@@ -185,15 +185,18 @@ int cmfrec_hip_factors_multiple(
     int_t k, int_t k_user, int_t k_item, int_t k_main,
     real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
     bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
-    const real_t *BtB_pre, const real_t *TransCtCinvCt_pre);
+    const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
+    /* sparse side information instead of U (NULL): COO triplets or CSR over the m_u rows, missing = absent */
+    const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
+    const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr);
 
 /* Replace factors_collective_explicit_multiple / factors_collective_implicit_multiple,
  * /root/reference/src/cmfrec.h:2004-2047 and :2048-2071 (bodies src/collective.c:10865-11174, :11176-11340): same
  * positional parameters, same return codes (0 ok, 1 out of memory, 2 invalid / unsupported).  Supported: sparse X
  * (COO or CSR), dense U without NaN (rows beyond m get the side-information-only solution, rows beyond m_u the plain
  * one), user bias, lam_unique, scale_lam / scale_lam_sideinfo / scale_bias_const, w_main / w_user, alpha and
- * apply_log_transf.  NA_as_zero, nonneg, L1, weights, dense X, sparse or binary side information and implicit
- * features return 2.  Of the precomputed matrices only BtB (implicit) and TransCtCinvCt (explicit) are read -- the
+ * apply_log_transf; sparse side information (COO or CSR; not together with scale_lam_sideinfo in the explicit
+ * version).  NA_as_zero, nonneg, L1, weights, dense X, binary side information and implicit features return 2.  Of the precomputed matrices only BtB (implicit) and TransCtCinvCt (explicit) are read -- the
  * ones that change the result; the others are rebuilt on the device from B and C.
  * Two details of the reference that are kept: (1) without a precomputed BtB the implicit version puts the lam of the
  * call, *not* lam / w_main, on the diagonal of the X block (collective.c:11270-11280) while the k_user block gets

@@ -159,6 +159,39 @@ class Oracle:
             self._r(lam), self._r(w_user), self._r(lam_last), C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
             C.c_bool(implicit), C.c_int(nthreads))
 
+    def _factors_multiple_sparse(self, implicit, B, row, col, val, m, k, Cm, U_coo, biasB=None, glob_mean=0.0,
+                                 user_bias=False, lam=1.0, lam_bias=None, alpha=1.0, k_main=0, k_user=0, k_item=0,
+                                 scale_lam=False, w_main=1.0, w_user=1.0, nthreads=1):
+        """New rows with SPARSE side information: per row this is the collective closed form with the row's attributes as
+        rank-1 terms (collective_factors_warm / _cold with u_vec_sp -> collective_closed_form_block[_implicit],
+        collective.c:3555-4087), i.e. oracle_optimizeA_collective_sparse_chol on [B | 1] after the preprocessing of
+        factors_collective_*_single (:10575-10863).  Not for scale_lam_sideinfo / bias-less scale_lam (quirks Q11, Q12)."""
+        n = B.shape[0]
+        ur, uc, uv, m_u, p = U_coo
+        mm = max(m, m_u)
+        val = np.asarray(val, self.dtype)
+        if implicit:
+            x = val * self.dtype(alpha) if alpha != 1 else val
+            lam_x = lam                                              # :11270-11280: the X block keeps the lam of the call
+        else:
+            x = val - ((np.asarray(biasB, self.dtype)[col] + self.dtype(glob_mean)) if biasB is not None else self.dtype(glob_mean))
+        csr, _ = self.coo_to_csr_and_csc(row, col, x.astype(self.dtype), mm, n)
+        ucsr, _ = self.coo_to_csr_and_csc(ur, uc, uv, m_u, p)
+        lam_bias = lam if lam_bias is None else lam_bias
+        if w_main != 1:
+            lam, lam_bias, w_user = lam / w_main, lam_bias / w_main, w_user / w_main
+        ub = 1 if (user_bias and not implicit) else 0
+        Bp = np.ascontiguousarray(np.hstack([B, np.ones((n, 1), self.dtype)]) if ub else B, self.dtype)
+        A = np.zeros((mm, k_user + k + k_main + ub), self.dtype)
+        if implicit and lam_x != lam:
+            raise NotImplementedError("w_main != 1 with sparse side information: the X block keeps the unscaled lam")
+        self.optimizeA_collective_sparse(A, Bp, Cm, csr, ucsr, lam, w_user=w_user, lam_last=lam_bias if ub else lam, k=k,
+                                         k_main=k_main + ub, k_user=k_user, k_item=k_item, scale_lam=scale_lam,
+                                         implicit=implicit, nthreads=nthreads)
+        if ub:
+            return np.ascontiguousarray(A[:, :-1]), A[:, -1].copy()
+        return A, None
+
     def fit_als_sparse_sideinfo(self, A, B, row, col, val, k, implicit, U_coo=None, I_coo=None, Cm=None, Dm=None,
                                 biasA=None, biasB=None, user_bias=False, item_bias=False, center=False, lam=1.0, alpha=1.0,
                                 scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0, w_main=1.0,
@@ -200,8 +233,12 @@ class Oracle:
     def factors_explicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, biasB=None,
                                   glob_mean=0.0, user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0,
                                   k_item=0, scale_lam=False, scale_lam_sideinfo=False, scale_bias_const=False,
-                                  scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, TransCtCinvCt=None):
+                                  scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, TransCtCinvCt=None, U_coo=None):
         """Restatement of factors_collective_explicit_multiple; same arguments as Reference.factors_explicit_multiple."""
+        if U_coo is not None:
+            return self._factors_multiple_sparse(False, B, row, col, val, m, k, Cm, U_coo, biasB=biasB, glob_mean=glob_mean,
+                                                 user_bias=user_bias, lam=lam, lam_bias=lam_bias, k_main=k_main, k_user=k_user,
+                                                 k_item=k_item, scale_lam=scale_lam, w_main=w_main, w_user=w_user, nthreads=nthreads)
         n = B.shape[0]
         csr, _ = self.coo_to_csr_and_csc(row, col, val, m, n)
         m_u = 0 if U is None else U.shape[0]
@@ -221,8 +258,12 @@ class Oracle:
 
     def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0,
                                   alpha=1.0, k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0,
-                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None):
+                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None, U_coo=None):
         """Restatement of factors_collective_implicit_multiple; same arguments as Reference.factors_implicit_multiple."""
+        if U_coo is not None:
+            return self._factors_multiple_sparse(True, B, row, col, val, m, k, Cm, U_coo, lam=lam, alpha=alpha, k_main=k_main,
+                                                 k_user=k_user, k_item=k_item, w_main=w_main * w_main_multiplier, w_user=w_user,
+                                                 nthreads=nthreads)[0]
         n = B.shape[0]
         csr, _ = self.coo_to_csr_and_csc(row, col, val, m, n)
         m_u = 0 if U is None else U.shape[0]
@@ -420,7 +461,8 @@ class Reference:
     def factors_explicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, biasB=None,
                                   glob_mean=0.0, user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0,
                                   k_item=0, scale_lam=False, scale_lam_sideinfo=False, scale_bias_const=False,
-                                  scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, n=None, TransCtCinvCt=None):
+                                  scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, n=None, TransCtCinvCt=None,
+                                  U_coo=None):
         """factors_collective_explicit_multiple (src/cmfrec.h:2004-2047, collective.c:10865-11174): sparse X of the
         new rows as COO, optional dense U.  Returns (A, biasA or None)."""
         n_max, ldb = B.shape
@@ -430,6 +472,12 @@ class Reference:
         nnz = len(val)
         m_u = 0 if U is None else U.shape[0]
         p = 0 if U is None else U.shape[1]
+        # sparse side information goes in as CSR: the COO branch of the reference converts with m instead of m_u rows into
+        # an m_u+1 allocation (collective.c:10970-10986) and corrupts the heap unless m_u == m
+        ucsr = (None, None, None)
+        if U_coo is not None:
+            m_u, p = U_coo[3], U_coo[4]
+            ucsr, _ = self.coo_to_csr_and_csc(U_coo[0], U_coo[1], np.ascontiguousarray(U_coo[2], self.dtype), m_u, p)
         mm = max(m, m_u)
         A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
         biasA = np.full(mm, np.nan, self.dtype) if user_bias else None
@@ -441,7 +489,7 @@ class Reference:
             _ptr(A), _ptr(biasA), C.c_int(m),
             _ptr(Uc), C.c_int(m_u), C.c_int(p),
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
-            None, None, None, C.c_size_t(0), None, None, None,
+            None, None, None, C.c_size_t(0), _ptr(ucsr[0]), _ptr(ucsr[1]), _ptr(ucsr[2]),
             None, C.c_int(0), C.c_int(0),
             _ptr(Cm), None,
             self._r(glob_mean), _ptr(biasB), _ptr(U_colmeans),
@@ -461,7 +509,7 @@ class Reference:
 
     def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0,
                                   alpha=1.0, k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0,
-                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None):
+                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None, U_coo=None):
         """factors_collective_implicit_multiple (src/cmfrec.h:2048-2071, collective.c:11176-11340)."""
         n, ldb = B.shape
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -469,6 +517,10 @@ class Reference:
         nnz = len(val)
         m_u = 0 if U is None else U.shape[0]
         p = 0 if U is None else U.shape[1]
+        ucsr = (None, None, None)
+        if U_coo is not None:                     # as CSR, see factors_explicit_multiple
+            m_u, p = U_coo[3], U_coo[4]
+            ucsr, _ = self.coo_to_csr_and_csc(U_coo[0], U_coo[1], np.ascontiguousarray(U_coo[2], self.dtype), m_u, p)
         mm = max(m, m_u)
         A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
         Uc = None if U is None else np.ascontiguousarray(U, self.dtype).copy()
@@ -476,7 +528,7 @@ class Reference:
             _ptr(A), C.c_int(m),
             _ptr(Uc), C.c_int(m_u), C.c_int(p),
             C.c_bool(False), C.c_bool(False),
-            None, None, None, C.c_size_t(0), None, None, None,
+            None, None, None, C.c_size_t(0), _ptr(ucsr[0]), _ptr(ucsr[1]), _ptr(ucsr[2]),
             _ptr(val), _ptr(row), _ptr(col), C.c_size_t(nnz),
             None, None, None,
             _ptr(B), C.c_int(n), _ptr(Cm), _ptr(U_colmeans),

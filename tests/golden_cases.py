@@ -152,6 +152,17 @@ def new_rows_cases(d):
                             w_user=4.0, BtB=BtB)),
         ("i3 plain w_main", dict(B=d["B_plain"], lam=0.7, w_main=2.0)),
     ]
+    # sparse side information for the new rows (missing = absent): attributes of U_less' shape, two thirds dropped.
+    rng = np.random.default_rng(5)
+    mask = rng.random(d["U_less"].shape) < 0.35
+    mask[4] = False; mask[3, :2] = True                     # row 4: observations only; row 3: attributes only
+    ur, uc = np.nonzero(mask)
+    U_coo = (ur.astype(np.int32), uc.astype(np.int32), d["U_less"][mask], d["U_less"].shape[0], d["U_less"].shape[1])
+    ex.append(("e7 sparse U bias scale_lam", dict(B=d["B_full"], Cm=d["C_full"], U_coo=U_coo, biasB=d["biasB"], glob_mean=3.1,
+                                                  user_bias=True, lam=0.7, lam_bias=1.3, k_main=km, k_user=ku, k_item=ki,
+                                                  scale_lam=True, w_main=1.5, w_user=2.5)))
+    im.append(("i4 sparse U", dict(B=d["B_full"], Cm=d["C_full"], U_coo=U_coo, lam=0.7, alpha=2.0, k_main=km, k_user=ku,
+                                   k_item=ki, w_user=2.5)))
     for name, kw in ex:
         yield name, "explicit", dict(row=X[0], col=X[1], val=d["ratings"], m=d["m"], k=k, **kw)
     for name, kw in im:
@@ -179,10 +190,15 @@ class HipNewRows:
     def factors_explicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, biasB=None, glob_mean=0.0,
                                   user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0, k_item=0, scale_lam=False,
                                   scale_lam_sideinfo=False, scale_bias_const=False, scaling_biasA=1.0, w_main=1.0,
-                                  w_user=1.0, nthreads=1, TransCtCinvCt=None, csr=None):
+                                  w_user=1.0, nthreads=1, TransCtCinvCt=None, csr=None, U_coo=None):
         C, P, R = self.C, self._lib.ptr, self.R
         n = B.shape[0]
         m_u, p = (0, 0) if U is None else U.shape
+        su = (None, None, None, C.c_size_t(0))
+        if U_coo is not None:
+            keep_u = (np.ascontiguousarray(U_coo[0], np.int32), np.ascontiguousarray(U_coo[1], np.int32),
+                      np.ascontiguousarray(U_coo[2], self.dtype))
+            su = (P(keep_u[0]), P(keep_u[1]), P(keep_u[2]), C.c_size_t(len(keep_u[2]))); m_u, p = U_coo[3], U_coo[4]
         mm = max(m, m_u)
         A = np.full((mm, k_user + k + k_main), np.nan, self.dtype)
         biasA = np.full(mm, np.nan, self.dtype) if user_bias else None
@@ -196,7 +212,7 @@ class HipNewRows:
             coo = (None, None, None, C.c_size_t(0), P(csr[0]), P(csr[1]), P(csr[2]))
         rc = self.lib.factors_collective_explicit_multiple(
             P(A), P(biasA), C.c_int(m), P(U), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(False), C.c_bool(False),
-            None, None, None, C.c_size_t(0), None, None, None, None, C.c_int(0), C.c_int(0),
+            *su, None, None, None, None, C.c_int(0), C.c_int(0),
             P(Cm), None, R(glob_mean), P(biasB), P(U_colmeans), *coo,
             None, C.c_int(n), None, P(B), None, C.c_bool(False),
             C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
@@ -208,10 +224,15 @@ class HipNewRows:
 
     def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0, alpha=1.0,
                                   k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_main_multiplier=1.0,
-                                  apply_log_transf=False, nthreads=1, BtB=None, csr=None):
+                                  apply_log_transf=False, nthreads=1, BtB=None, csr=None, U_coo=None):
         C, P, R = self.C, self._lib.ptr, self.R
         n = B.shape[0]
         m_u, p = (0, 0) if U is None else U.shape
+        su = (None, None, None, C.c_size_t(0))
+        if U_coo is not None:
+            keep_u = (np.ascontiguousarray(U_coo[0], np.int32), np.ascontiguousarray(U_coo[1], np.int32),
+                      np.ascontiguousarray(U_coo[2], self.dtype))
+            su = (P(keep_u[0]), P(keep_u[1]), P(keep_u[2]), C.c_size_t(len(keep_u[2]))); m_u, p = U_coo[3], U_coo[4]
         A = np.full((max(m, m_u), k_user + k + k_main), np.nan, self.dtype)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
@@ -220,7 +241,7 @@ class HipNewRows:
             coo = (None, None, None, C.c_size_t(0), P(csr[0]), P(csr[1]), P(csr[2]))
         rc = self.lib.factors_collective_implicit_multiple(
             P(A), C.c_int(m), P(U), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(False),
-            None, None, None, C.c_size_t(0), None, None, None, *coo,
+            *su, None, None, None, *coo,
             P(B), C.c_int(n), P(Cm), P(U_colmeans), C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
             R(lam), R(0.), R(alpha), R(w_main), R(w_user), R(w_main_multiplier), C.c_bool(apply_log_transf),
             None, P(BtB), None, None, C.c_int(nthreads))
