@@ -172,7 +172,10 @@ def main():
         for b in range(6):
             ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
             if cnt:
-                kernels.append(dict(step=which, kernel=names[b], ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
+                name_b = names[b]
+                if b == 0 and sess.vh_mode(which) == 2:
+                    name_b = "gram_slice+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"
+                kernels.append(dict(step=which, kernel=name_b, ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
                                     avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, K),
                                     overlapped=sess.bin_overlaps(which, b)))
     # launches that run beside other kernels (few split rows on the second stream) have no duration of their own
@@ -189,6 +192,8 @@ def main():
                   3: ["cg_rows_kernel<double, 7, true, 2, 1>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4>"],
                   5: ["cg_rows_tiny_kernel<double, 7, true>"]}
     inv = {v: b for b, v in names.items()}
+    inv["gram_slice+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
+    prof_names[6] = ["gram_slice_kernel<double, true>", "gram_cg_kernel<double, true>"]
     for d in kernels:
         other = [e for e in kernels if e["kernel"] == d["kernel"] and e["step"] != d["step"]]
         # (a launch that runs beside other kernels has no duration of its own, and rocprof's average mixes it in:
@@ -403,7 +408,7 @@ def pmc_traffic(dom):
     ks = json.load(open(path))["kernels"]
     tags = {"cg_rows_kernel<W=8>": [", 8, 1>"], "cg_rows_kernel<W=4>": [", 4, 1>"], "cg_rows_kernel<W=2>": [", 2, 1>"],
             "cg_rows_kernel<W=1>": [", 1, 4>"], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel"],
-            "vh_pass": ["vh_pass_kernel", "vh_update_kernel"]}
+            "vh_pass": ["vh_pass_kernel", "vh_update_kernel"], "gram_slice": ["gram_slice_kernel", "gram_cg_kernel"]}
     want = next(v for k, v in tags.items() if dom["kernel"].startswith(k))
     tot, found = 0.0, False
     for name, ent in ks.items():

@@ -110,6 +110,13 @@ struct SparseShard {
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
+    int n_other = 0;         // rows of the opposing matrix the entries refer to
+    // Split rows: stream their gathered rows once per CG pass (default) or read them once and run the CG on the row's
+    // own Gramian (gram_cg_kernels.hpp).  Streaming lives on the rows being shared between the split rows of a launch
+    // -- sorted entries, one slice of the opposing matrix per XCD --: with 15 references per opposing row and pass (C2's
+    // items) it takes 0.89 ms against 1.23 ms; a rank's item block of an 8-GPU run has 2.8 (the opposing matrix is 8
+    // times taller) and streaming costs 2.13 ms against 1.80 ms (tools/microbench/weak_scaling_bstep.py).
+    bool prefer_gram() const { return n_other > 0 && (double)bin_nnz[0] < 3.5 * (double)n_other; }
     // few split rows (less than about one round of workgroups per CG pass): their launch sequence is a chain of
     // latencies and runs on the second stream beside the other bins
     bool vh_runs_aside(int num_cus) const
@@ -437,7 +444,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     // 107-141 cycles on this part, no faster than the FP64 VALU, so 6x the flops do not pay for 4x fewer bytes.
     // Kept as an option (and as an on-device cross-check of the split-row path); default: stream.
     const char *vh_env = getenv("CMFREC_HIP_VH");
-    const bool use_gram = vh_env != nullptr && strcmp(vh_env, "gram") == 0;
+    const bool use_gram = (vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram();     // "stream" / "gram" force one
     if (P.k <= 16 * GRAM_NTT && use_gram) {
         // one gather: Gramian slices on the matrix cores, then CG on the k x k system (gram_cg_kernels.hpp)
         GramParams<real_t> G;

@@ -1023,6 +1023,15 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
     return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus)) ? 1 : 0;
 }
 
+int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which)
+{
+    const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
+    if (X.bin_rows[BIN_VHEAVY] <= 0) return 0;
+    const char *e = getenv("CMFREC_HIP_VH");
+    const bool gram = (e != nullptr) ? strcmp(e, "gram") == 0 : X.prefer_gram();
+    return (gram && s->mdl.k + s->mdl.k_main <= 16 * GRAM_NTT) ? 2 : 1;
+}
+
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s)
 {
     (void)hipStreamSynchronize(s->dev.stream);

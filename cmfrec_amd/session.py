@@ -161,5 +161,9 @@ class AlsSession:
         """True when the launches of that bin run beside other kernels, so that bin_stats' time is not a kernel duration."""
         return bool(self.lib.cmfrec_hip_session_bin_overlaps(self.handle, C.c_int(ord(which)), C.c_int(bin_)))
 
+    def vh_mode(self, which):
+        """0: no split rows on that side; 1: streamed per CG pass; 2: single gather + CG on the row's Gramian."""
+        return int(self.lib.cmfrec_hip_session_vh_mode(self.handle, C.c_int(ord(which))))
+
     def reset_timers(self):
         self.lib.cmfrec_hip_session_reset_timers(self.handle)

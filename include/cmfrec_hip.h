@@ -378,6 +378,9 @@ int cmfrec_hip_session_bin_stats(cmfrec_hip_session *s, int which, int bin, doub
 /* 1 if the launches of that bin run beside other kernels (few split rows on the second stream; every bin of a block
  * that is updated in parts): their event timings then include the neighbours' work and are not a kernel duration. */
 int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin);
+/* How the split rows (> 1024 entries) of that side are solved: 0 none, 1 streamed once per CG pass, 2 read once, CG on the
+ * row's own Gramian (chosen when few split rows share an opposing row, e.g. a rank's item block of a multi-GPU run). */
+int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
 /* Batched top-N (the step after the path; the reference ranks one user per call: topN, src/common.c:5127-5380).
