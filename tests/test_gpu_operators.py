@@ -121,8 +121,10 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, monkeypatch):
         ops.optimizeA_implicit(Ah, B, csr, 4.0)
         O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4)
     else:
-        ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True)
-        O.optimizeA_explicit(Ao, B, csr, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
+        bias = (rng.standard_normal(n) * 0.2).astype(dtype)          # the fused "X - bias" of the fit's half-steps
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True, bias_sub=bias)
+        csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+        O.optimizeA_explicit(Ao, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
     assert rel_err(Ah, Ao) < TOL[dtype]
     assert np.array_equal(Ah[8], A0[8])
 
