@@ -73,6 +73,12 @@ struct CgParams {
     T w_side = 0;
     int rows_with_u = 0;      // local rows < rows_with_u carry side information; the others are plain rows
     int row_first = 0;        // generic kernel: first position of the processing order to handle
+    // generic kernel, SPARSE side information instead of CtC / UC (collective_block_cg u_vec_sp branches,
+    // collective.c:2292-2298, :2609-2621, :2847-2860): the row's attributes gather rows of C2[*, kc]
+    const size_t *indptr2 = nullptr;
+    const int *indices2 = nullptr;
+    const T *values2 = nullptr;
+    const T *C2 = nullptr;
     int *counter = nullptr;   // tiled kernels: work counter of this launch (zero at launch); a team's first row is its own
                               // index, the following ones are claimed in order (longest rows first) from here
     int p_side = 0, scale_lam_sideinfo = 0;
@@ -807,13 +813,21 @@ cg_rows_generic_kernel(const CgParams<T> P)
         const int nnz = (int)(P.indptr[row + 1] - st);
         const bool has_u = coll && row < P.rows_with_u;
         if (nnz == 0 && !has_u) continue;                     // plain rows without entries stay untouched (common.c:3270,3354)
+        const bool sparse_u = P.indptr2 != nullptr;
+        const size_t st2 = (sparse_u && has_u) ? P.indptr2[row] : 0;
+        const int nnz2 = (sparse_u && has_u) ? (int)(P.indptr2[row + 1] - st2) : 0;
+        if (sparse_u && has_u && nnz == 0 && nnz2 == 0) {     // neither observations nor attributes: zeros (collective.c:1258-1268)
+            if (TEAM == 1 || wv == 0)
+                for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);
+            continue;
+        }
         const int lo = has_u ? 0 : koff;                      // rows without side information: the X block only (collective.c:4832-5101)
         T lam = P.lam, lam_last = P.lam_last;
         if (!IMPLICIT) {
             if (has_u) {
                 if (P.scale_lam || P.scale_lam_sideinfo) {    // collective.c:1285-1355
                     T mult = (nnz > 0) ? (T)nnz : T(1);
-                    if (P.scale_lam_sideinfo) mult += (T)P.p_side;
+                    if (P.scale_lam_sideinfo) mult += sparse_u ? (T)nnz2 : (T)P.p_side;
                     lam *= mult; lam_last *= mult;
                 }
             } else if (P.scale_lam) {                         // common.c:679-723
@@ -822,7 +836,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
             }
         }
         T *arow = P.A + (size_t)row * P.lda;
-        const T *ucrow = has_u ? P.UC + (size_t)row * kc : nullptr;
+        const T *ucrow = (has_u && !sparse_u) ? P.UC + (size_t)row * kc : nullptr;
         T a[NF], r[NF], p[NF], Ap[NF];
 #pragma unroll
         for (int c = 0; c < NF; c++) { int f = lane + 64 * c; a[c] = (f >= lo && f < kt) ? arow[f] : T(0); }
@@ -844,7 +858,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < kt) out[c] += vj * P.BtB[(size_t)j * kx + (f - koff)]; }
                 }
             }
-            if (has_u) {                                       // out[:kc] = w (UC_row - CtC v[:kc])  |  w CtC v[:kc]
+            if (has_u && !sparse_u) {                          // out[:kc] = w (UC_row - CtC v[:kc])  |  w CtC v[:kc]
                 T acc[NF];
 #pragma unroll
                 for (int c = 0; c < NF; c++) acc[c] = T(0);
@@ -876,6 +890,18 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 else          w = (mode == 0) ? -(coef - x) : coef;
 #pragma unroll
                 for (int c = 0; c < NF; c++) gat[c] += w * bv[c];
+            }
+            // sparse side information: every present attribute j adds  w (u_j - C_j.v) C_j  /  w (C_j.v) C_j  to [0, kc)
+            for (int j = (TEAM == 1 ? 0 : wv); j < nnz2; j += TEAM) {
+                const T *cj = P.C2 + (size_t)P.indices2[st2 + j] * kc;
+                const T uj = P.values2[st2 + j];
+                T cv[NF]; T part = T(0);
+#pragma unroll
+                for (int c = 0; c < NF; c++) { int f = lane + 64 * c; cv[c] = (f < kc) ? cj[f] : T(0); part += cv[c] * v[c]; }
+                const T coef = wave_sum(part);
+                const T w = (mode == 0) ? P.w_side * (-coef + uj) : P.w_side * coef;
+#pragma unroll
+                for (int c = 0; c < NF; c++) gat[c] += w * cv[c];
             }
             if (TEAM > 1) {                                    // sum over the waves, in wave order, identical everywhere
                 __syncthreads();
@@ -926,6 +952,15 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     PC[c] += IMPLICIT ? x * (bv * bv) : bv * bv;                 // :2009-2014 / :1238-1243
                 }
             }
+            for (int j = (TEAM == 1 ? 0 : wv); j < nnz2; j += TEAM) {            // C_j^2, unweighted (collective.c:2292-2298, :2993-2999)
+                const T *cj = P.C2 + (size_t)P.indices2[st2 + j] * kc;
+#pragma unroll
+                for (int c = 0; c < NF; c++) {
+                    int f = lane + 64 * c;
+                    T cvv = (f < kc) ? cj[f] : T(0);
+                    PC[c] += cvv * cvv;
+                }
+            }
             if (TEAM > 1) {
                 __syncthreads();
 #pragma unroll
@@ -942,7 +977,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
 #pragma unroll
             for (int c = 0; c < NF; c++) {
                 int f = lane + 64 * c;
-                if (has_u && f < kc) PC[c] += P.CtC[(size_t)f * kc + f];         // sum_l C_l^2, unweighted (collective.c:2281-2286)
+                if (has_u && !sparse_u && f < kc) PC[c] += P.CtC[(size_t)f * kc + f];   // sum_l C_l^2, unweighted (collective.c:2281-2286)
                 if (IMPLICIT) PC[c] += (f >= koff && f < kt) ? P.BtB[(size_t)(f - koff) * kx + (f - koff)] : T(0);
                 else {
                     PC[c] += lam;

@@ -351,6 +351,9 @@ struct CgCall {
     real_t w_side = 0;
     int rows_with_u = 0, p_side = 0;
     bool scale_lam_sideinfo = false;
+    // ... or sparse side information: the row's attributes (X2, CSR over the same rows) gather rows of C2[*, kc]
+    const SparseShard *X2 = nullptr;
+    const real_t *C2 = nullptr;
 };
 
 enum class CgVariant { Auto, Generic };
@@ -547,6 +550,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.precond = c.precond ? 1 : 0;
     P.koff = c.koff; P.kc = c.kc; P.CtC = c.CtC; P.UC = c.UC; P.w_side = c.w_side;
     P.rows_with_u = c.rows_with_u; P.p_side = c.p_side; P.scale_lam_sideinfo = c.scale_lam_sideinfo ? 1 : 0;
+    if (c.X2) { P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr; P.C2 = c.C2; }
     const int S = (c.k + 7) / 8;
     // the Jacobi-preconditioned variants (not a default anywhere in the reference) and the block systems with side
     // information run on the generic kernel

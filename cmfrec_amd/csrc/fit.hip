@@ -123,8 +123,6 @@ int_t fit_collective_implicit_als(
     // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.
     const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
     if (NA_as_zero_U || NA_as_zero_I) return fail(verbose, "cmfrec_hip: NA_as_zero_U / NA_as_zero_I are not implemented.");
-    if ((spU || spI) && use_cg)
-        return fail(verbose, "cmfrec_hip: sparse side information needs use_cg = false (the block CG on it is not implemented).");
     if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
         return fail(verbose, "cmfrec_hip: sparse side information must be COO triplets with rows inside X.");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
@@ -258,8 +256,6 @@ int_t fit_collective_explicit_als(
         return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / implicit features are not implemented.");
     // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.
     const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
-    if ((spU || spI) && use_cg)
-        return fail(verbose, "cmfrec_hip: sparse side information needs use_cg = false (the block CG on it is not implemented).");
     if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
         return fail(verbose, "cmfrec_hip: sparse side information must be COO triplets with rows inside X.");
     for (size_t e = 0; spU && e < nnz_U; e++)

@@ -605,15 +605,34 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     if (p_self > 0 && sparse_side) {
         // sparse side information (missing = absent): the row's attributes are a second gather source of the same
         // Cholesky launch (collective.c:1636-1653, :1719-1731 / :2003-2021); the block CG on it is not built
-        if (!chol) {
-            g_last_error = "cmfrec_hip: sparse side information needs the Cholesky updates (use_cg = false)";
-            return 2;
-        }
         const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
         const SparseShard &Us = isA ? s->Usr : s->Isr;
         const int rows_u = isA ? m.m_u : m.n_i;
         const int kc = k_side_self + m.k;
         const real_t w = isA ? m.w_user : m.w_item;
+        if (!chol) {
+            // block CG / PCG with the attributes as a second gathered term (collective_block_cg u_vec_sp branches,
+            // collective.c:2292-2298, :2609-2621, :2847-2860; implicit: :2993-2999 ff.), generic kernel
+            const real_t *bias_sub_cg = nullptr;
+            int kx = kk;
+            if (m.implicit) {
+                launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, (real_t)0);
+            } else {
+                if (self_bias) {
+                    const int rows_fill = isA ? m.n : m.m;
+                    hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_fill), dim3(256), 0, st, opp, ld_opp, rows_fill,
+                                       isA ? s->k_totB : s->k_totA, (real_t)1);
+                    kx += 1;
+                }
+                if (opp_bias) bias_sub_cg = isA ? s->biasB.ptr : s->biasA.ptr;
+            }
+            CgCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kx, bias_sub_cg, m.implicit ? s->gram.ptr : nullptr,
+                     m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
+                     (bool)m.precondition_cg};
+            c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
+            c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo; c.X2 = &Us; c.C2 = Cm;
+            return launch_cg(dev, c, X, nullptr);
+        }
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822, :6018-6019
         if (m.implicit) {
             const int kt = k_side_self + kk;

@@ -119,7 +119,7 @@ class CMF_implicit(_Base):
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
         them from ``random_state`` (C argument ``reset_values=false``).  ``U`` / ``I``: dense side
-        information without missing values, or SciPy sparse matrices (missing = absent; needs ``use_cg=False``)."""
+        information without missing values, or SciPy sparse matrices (missing = absent)."""
         row, col, val, m, n = _coo_triplet(X, shape)
         lib, R = self._lib()
         dt = self.dtype_

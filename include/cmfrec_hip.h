@@ -46,8 +46,8 @@ extern "C" {
  * (optimizeA_collective_implicit, src/collective.c:5971-6244) or block CG / PCG
  * (collective_block_cg_implicit, :2905-3303).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight,
  * no precompute.
- * or, with Cholesky updates (use_cg = false), SPARSE side information as COO triplets (U_row / U_col / U_sp / nnz_U and the
- * I_* twins; missing = absent, rows within X's; collective.c:1849-2131 with u_vec_sp).  Anything else returns 2. */
+ * or SPARSE side information as COO triplets (U_row / U_col / U_sp / nnz_U and the I_* twins; missing = absent, rows
+ * within X's; collective.c:1849-2131 / :2905-3303 with u_vec_sp).  Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
     real_t *C, real_t *D,
@@ -82,8 +82,8 @@ int_t fit_collective_implicit_als(
  * CG / PCG or Cholesky, optional DENSE side information U[m_u, p] / II[n_i, q] without NaN (m_u, n_i may exceed
  * m, n: rows known from side information only are fitted to it alone and get a zero bias, :4967-5101, :8296)
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
- * k_main/k_user/k_item, w_user/w_item; with Cholesky updates also SPARSE side information as COO triplets (missing =
- * absent, rows within X's; collective_closed_form_block with u_vec_sp, :1636-1653, :1719-1731).  Anything else returns 2. */
+ * k_main/k_user/k_item, w_user/w_item; also SPARSE side information as COO triplets (missing = absent, rows within
+ * X's; collective_closed_form_block / collective_block_cg with u_vec_sp, :1636-1653, :1719-1731, :2609-2621).  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,
@@ -330,8 +330,8 @@ int cmfrec_hip_session_get_factors(cmfrec_hip_session *s, real_t *A, real_t *B,
  * common.c:4911-4997): U rows [0,m_u), II rows [0,n_i). */
 int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, const real_t *II);
 /* SPARSE side information as COO triplets (which = 'U': [m_u, p], 'I': [n_i, q]; missing = absent, no centring):
- * CSR by row and CSC by attribute are built on the device.  The factor updates then need use_cg = 0 (the row's
- * attributes become a second gather source of the Cholesky kernel), C / D follow use_cg.  m_u <= rows of X. */
+ * CSR by row and CSC by attribute are built on the device.  Cholesky updates: the row's attributes are a second gather
+ * source of the row kernel; CG / PCG: a second gathered term of the block CG (generic kernel).  m_u <= rows of X. */
 int cmfrec_hip_session_set_sideinfo_sparse(cmfrec_hip_session *s, int which, const int_t *row, const int_t *col,
                                            const real_t *val, size_t nnz);
 

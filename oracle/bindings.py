@@ -147,11 +147,19 @@ class Oracle:
 
     def optimizeA_collective_sparse(self, A, B, Cm, csr, U_csr, lam, w_user=1.0, lam_last=None, k=None, k_main=0,
                                     k_user=0, k_item=0, scale_lam=False, scale_lam_sideinfo=False, implicit=False,
-                                    nthreads=1):
+                                    nthreads=1, use_cg=False, precondition_cg=False, max_cg_steps=3):
         m, lda = A.shape
         n, ldb = B.shape
         lam_last = lam if lam_last is None else lam_last
         up, ui, uv = U_csr
+        if use_cg:
+            self.lib.oracle_optimizeA_collective_sparse_cg(
+                _ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb), _ptr(Cm), C.c_int(m), C.c_int(len(up) - 1), C.c_int(n),
+                C.c_int(Cm.shape[0]), C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+                _ptr(csr[0]), _ptr(csr[1]), _ptr(csr[2]), _ptr(up), _ptr(ui), _ptr(uv),
+                self._r(lam), self._r(w_user), self._r(lam_last), C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
+                C.c_bool(implicit), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_int(nthreads))
+            return
         self.lib.oracle_optimizeA_collective_sparse_chol(
             _ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb), _ptr(Cm), C.c_int(m), C.c_int(len(up) - 1), C.c_int(n),
             C.c_int(Cm.shape[0]), C.c_int(k), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
@@ -195,8 +203,9 @@ class Oracle:
     def fit_als_sparse_sideinfo(self, A, B, row, col, val, k, implicit, U_coo=None, I_coo=None, Cm=None, Dm=None,
                                 biasA=None, biasB=None, user_bias=False, item_bias=False, center=False, lam=1.0, alpha=1.0,
                                 scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0, w_main=1.0,
-                                w_user=1.0, w_item=1.0, niter=3, nthreads=1):
-        """Whole fit with sparse side information (U_coo / I_coo = (row, col, val, rows, cols)), Cholesky updates."""
+                                w_user=1.0, w_item=1.0, niter=3, nthreads=1, use_cg=False, max_cg_steps=3,
+                                precondition_cg=False, finalize_chol=False):
+        """Whole fit with sparse side information (U_coo / I_coo = (row, col, val, rows, cols))."""
         m, n = A.shape[0], B.shape[0]
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
@@ -215,7 +224,8 @@ class Oracle:
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
             su[0], su[1], su[2], su[3], C.c_int(m_u), C.c_int(p), si[0], si[1], si[2], si[3], C.c_int(n_i), C.c_int(q),
             C.c_int(k_main), C.c_int(k_user), C.c_int(k_item), self._r(w_main), self._r(w_user), self._r(w_item),
-            C.c_int(niter), C.c_int(nthreads))
+            C.c_int(niter), C.c_int(nthreads), C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg),
+            C.c_bool(finalize_chol))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=gm[0])
 
     def calc_mean_and_center(self, X, nthreads=1):
@@ -425,7 +435,7 @@ class Reference:
 
     def optimizeA_collective(self, A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=None,
                              k_main=0, k_user=0, k_item=0, scale_lam=False, scale_lam_sideinfo=False,
-                             nthreads=1, use_cg=False, m_u=None, U_csr=None):
+                             nthreads=1, use_cg=False, m_u=None, U_csr=None, precondition_cg=False):
         """U dense [m_u, p], or sparse: U=None and U_csr=(indptr[m_u+1], indices, values)."""
         m, lda = A.shape
         n, ldb = B.shape
@@ -433,7 +443,7 @@ class Reference:
         lam_last = lam if lam_last is None else lam_last
         if U_csr is not None:
             return self._optimizeA_collective_sparse(A, B, Cm, csr, U_csr, lam, w_user, lam_last, k, k_main, k_user, k_item,
-                                                     scale_lam, scale_lam_sideinfo, nthreads)
+                                                     scale_lam, scale_lam_sideinfo, nthreads, use_cg, precondition_cg)
         m_u = U.shape[0] if m_u is None else m_u
         pp, i, v = csr
         k_totA = k_user + k + k_main
@@ -541,7 +551,7 @@ class Reference:
         return A
 
     def optimizeA_collective_implicit_sparse(self, A, B, Cm, csr, U_csr, lam, w_user=1.0, k=None, k_main=0, k_user=0,
-                                             k_item=0, nthreads=1):
+                                             k_item=0, nthreads=1, use_cg=False, precondition_cg=False):
         """optimizeA_collective_implicit (src/cmfrec.h:1442-1467) with sparse U, Cholesky.  A [m, k_user+k+k_main] and
         B [n, k_item+k+k_main] are contiguous (the function takes no leading dimensions)."""
         m, ka = A.shape
@@ -560,13 +570,13 @@ class Reference:
             _ptr(pp), _ptr(i), _ptr(v), _ptr(up), _ptr(ui), _ptr(uv), None, None, None,
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
             self._r(lam), self._r(0.), self._r(w_user), C.c_int(nthreads), C.c_bool(False),
-            C.c_bool(False), C.c_int(3), C.c_bool(False), C.c_bool(False), C.c_int(100),
+            C.c_bool(use_cg), C.c_int(3), C.c_bool(precondition_cg), C.c_bool(False), C.c_int(100),
             _ptr(BtB), None, None, None, None,
             C.byref(flags[0]), C.byref(flags[1]), C.byref(flags[2]), C.byref(flags[3]),
             _ptr(buf), None)
 
     def _optimizeA_collective_sparse(self, A, B, Cm, csr, U_csr, lam, w_user, lam_last, k, k_main, k_user, k_item,
-                                     scale_lam, scale_lam_sideinfo, nthreads):
+                                     scale_lam, scale_lam_sideinfo, nthreads, use_cg=False, precondition_cg=False):
         m, lda = A.shape
         n, ldb = B.shape
         p = Cm.shape[0]
@@ -588,7 +598,7 @@ class Reference:
             self._r(lam), self._r(w_user), self._r(1.), self._r(lam_last), self._r(0.), self._r(0.),
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), None,
             C.c_bool(False), C.c_int(nthreads), C.c_bool(False),
-            C.c_bool(False), C.c_int(3), C.c_bool(False), C.c_bool(False), C.c_int(100),
+            C.c_bool(use_cg), C.c_int(3), C.c_bool(precondition_cg), C.c_bool(False), C.c_int(100),
             None, None, None, self._r(0.), C.c_bool(False),
             None, None, None, None, None,
             C.byref(flags[0]), C.byref(flags[1]), C.byref(flags[2]), C.byref(flags[3]), C.byref(flags[4]),

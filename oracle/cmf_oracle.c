@@ -534,18 +534,23 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
  * row's lambda scaling :1285-1355) and collective_block_cg_implicit (:2905-3303).  Unknowns [k_user, k_totA)
  * couple to X, unknowns [0, k_user+k) to U.  Rows >= m_u are plain rows (optimizeA / optimizeA_implicit on the
  * X block, collective.c:4832-5101, :6037-6054): their first k_user unknowns are not touched. */
-void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
-                                    int_t m, int_t m_u, int_t n, int_t p,
-                                    int_t k, int_t k_main, int_t k_user, int_t k_item,
-                                    const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
-                                    const real_t *U, real_t lam, real_t w_user, real_t lam_last,
-                                    bool scale_lam, bool scale_lam_sideinfo, bool implicit,
-                                    int_t max_cg_steps, bool precondition_cg, int nthreads)
+/* U dense [m_u, p] (prefer_CtC branches), or U == NULL and the row's attributes as CSR (u_vec_sp branches:
+ * residual :2609-2621, products :2847-2860, preconditioner :2292-2298 -- each present attribute j contributes
+ * w (u_j - C_j.a) C_j,  w (C_j.p) C_j  and  C_j^2 (unweighted); lambda counts them under scale_lam_sideinfo). */
+static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                               int_t m, int_t m_u, int_t n, int_t p,
+                               int_t k, int_t k_main, int_t k_user, int_t k_item,
+                               const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                               const real_t *U, const size_t *Ucsr_p, const int_t *Ucsr_i, const real_t *Ucsr,
+                               real_t lam, real_t w_user, real_t lam_last,
+                               bool scale_lam, bool scale_lam_sideinfo, bool implicit,
+                               int_t max_cg_steps, bool precondition_cg, int nthreads)
 {
     if (nthreads < 1) nthreads = 1;
+    const bool sparse_u = (U == NULL && Ucsr_p != NULL);
     const int_t kt = k_user + k + k_main, kc = k_user + k, kb = k + k_main;
     real_t *CtC = (real_t *)calloc((size_t)kc * kc + 1, sizeof(real_t));
-    oracle_gram(C, (size_t)kc, p, kc, CtC, nthreads);                            /* unweighted, collective.c:5855-5860 */
+    if (!sparse_u) oracle_gram(C, (size_t)kc, p, kc, CtC, nthreads);             /* unweighted, collective.c:5855-5860 */
     real_t *BtB = NULL;
     if (implicit) {                                                              /* :6056-6061, no lambda with CG */
         BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
@@ -556,15 +561,20 @@ void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size
         const size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
         const size_t nnz = en - st;
         const bool has_u = ix < m_u;
-        if (nnz == 0 && !has_u) continue;
-        const int_t lo = has_u ? 0 : k_user;
+        const size_t us = (sparse_u && has_u) ? Ucsr_p[ix] : 0, ue = (sparse_u && has_u) ? Ucsr_p[(size_t)ix + 1] : 0;
         real_t *a = A + (size_t)ix * lda;
+        if (nnz == 0 && !has_u) continue;                                        /* plain rows without entries stay untouched */
+        if (nnz == 0 && sparse_u && ue == us) {                                  /* :1258-1268: neither observations nor attributes */
+            memset(a, 0, (size_t)kt * sizeof(real_t));
+            continue;
+        }
+        const int_t lo = has_u ? 0 : k_user;
         real_t lam_i = lam, lam_last_i = lam_last;
         if (!implicit) {
             if (has_u) {
                 if (scale_lam || scale_lam_sideinfo) {                           /* :1285-1355 */
                     real_t mult = (nnz > 0) ? (real_t)nnz : (real_t)1;
-                    if (scale_lam_sideinfo) mult += (real_t)p;
+                    if (scale_lam_sideinfo) mult += sparse_u ? (real_t)(ue - us) : (real_t)p;
                     lam_i *= mult; lam_last_i *= mult;
                 }
             } else if (scale_lam) { lam_i *= (real_t)nnz; lam_last_i *= (real_t)nnz; }   /* common.c:679-723 */
@@ -589,14 +599,22 @@ void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size
                     else          wgt = (resid) ? (-coef + Xcsr[jx]) : coef;                              \
                     for (int_t f = 0; f < kb; f++) out[k_user + f] += wgt * b[f];                         \
                 }                                                                                         \
-                if (has_u)                                                                                \
+                if (has_u && sparse_u)                                                                    \
+                    for (size_t jx = us; jx < ue; jx++) {                                                 \
+                        const real_t *cj = C + (size_t)Ucsr_i[jx] * kc;                                   \
+                        real_t coef = 0;                                                                  \
+                        for (int_t f = 0; f < kc; f++) coef += cj[f] * v[f];                              \
+                        const real_t wgt = (resid) ? w_user * (-coef + Ucsr[jx]) : w_user * coef;        \
+                        for (int_t f = 0; f < kc; f++) out[f] += wgt * cj[f];                             \
+                    }                                                                                     \
+                else if (has_u)                                                                           \
                     for (int_t i = 0; i < kc; i++) {                                                      \
                         double sacc = 0;                                                                  \
                         for (int_t j = 0; j < kc; j++) sacc += (double)CtC[(size_t)i * kc + j] * (double)v[j]; \
                         out[i] += (resid) ? w_user * (ctu[i] - (real_t)sacc) : w_user * (real_t)sacc;     \
                     }                                                                                     \
             } while (0)
-        if (has_u)                                                               /* C^T u, :2500-2515 / :3040-3046 */
+        if (has_u && !sparse_u)                                                  /* C^T u, :2500-2515 / :3040-3046 */
             for (int_t i = 0; i < kc; i++) {
                 double sacc = 0;
                 for (int_t l = 0; l < p; l++) sacc += (double)U[(size_t)ix * p + l] * (double)C[(size_t)l * kc + i];
@@ -613,7 +631,12 @@ void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size
                 const real_t *b = B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb;
                 for (int_t f = 0; f < kb; f++) PC[k_user + f] += (implicit ? Xcsr[jx] : (real_t)1) * b[f] * b[f];
             }
-            if (has_u) for (int_t f = 0; f < kc; f++) PC[f] += CtC[(size_t)f * kc + f];   /* unweighted, :2281-2286 */
+            if (has_u && sparse_u)
+                for (size_t jx = us; jx < ue; jx++) {
+                    const real_t *cj = C + (size_t)Ucsr_i[jx] * kc;
+                    for (int_t f = 0; f < kc; f++) PC[f] += cj[f] * cj[f];               /* unweighted, :2292-2298 */
+                }
+            else if (has_u) for (int_t f = 0; f < kc; f++) PC[f] += CtC[(size_t)f * kc + f];   /* unweighted, :2281-2286 */
             if (implicit) for (int_t f = 0; f < kb; f++) PC[k_user + f] += BtB[(size_t)f * kb + f];
             else {
                 for (int_t f = 0; f < kt; f++) PC[f] += lam_i;
@@ -650,6 +673,33 @@ void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size
         #undef BLOCK_MATVEC
     }
     free(CtC); free(BtB);
+}
+
+void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                                    int_t m, int_t m_u, int_t n, int_t p,
+                                    int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                    const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                    const real_t *U, real_t lam, real_t w_user, real_t lam_last,
+                                    bool scale_lam, bool scale_lam_sideinfo, bool implicit,
+                                    int_t max_cg_steps, bool precondition_cg, int nthreads)
+{
+    collective_cg_impl(A, lda, B, ldb, C, m, m_u, n, p, k, k_main, k_user, k_item, Xcsr_p, Xcsr_i, Xcsr, U, NULL, NULL, NULL,
+                       lam, w_user, lam_last, scale_lam, scale_lam_sideinfo, implicit, max_cg_steps, precondition_cg, nthreads);
+}
+
+/* the same with sparse side information (U as CSR over m_u rows) */
+void oracle_optimizeA_collective_sparse_cg(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                                           int_t m, int_t m_u, int_t n, int_t p,
+                                           int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                           const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                           const size_t *Ucsr_p, const int_t *Ucsr_i, const real_t *Ucsr,
+                                           real_t lam, real_t w_user, real_t lam_last,
+                                           bool scale_lam, bool scale_lam_sideinfo, bool implicit,
+                                           int_t max_cg_steps, bool precondition_cg, int nthreads)
+{
+    collective_cg_impl(A, lda, B, ldb, C, m, m_u, n, p, k, k_main, k_user, k_item, Xcsr_p, Xcsr_i, Xcsr, NULL, Ucsr_p, Ucsr_i,
+                       Ucsr, lam, w_user, lam_last, scale_lam, scale_lam_sideinfo, implicit, max_cg_steps, precondition_cg,
+                       nthreads);
 }
 
 /* optimizeA_collective_implicit (collective.c:5971-6244) + collective_closed_form_block_implicit
@@ -1295,7 +1345,8 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
                                    const int_t *U_row, const int_t *U_col, const real_t *U_sp, size_t nnz_U, int_t m_u, int_t p,
                                    const int_t *I_row, const int_t *I_col, const real_t *I_sp, size_t nnz_I, int_t n_i, int_t q,
                                    int_t k_main, int_t k_user, int_t k_item,
-                                   real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads)
+                                   real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads,
+                                   bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
 {
     if (nnz_U == 0) { m_u = 0; p = 0; }
     if (nnz_I == 0) { n_i = 0; q = 0; }
@@ -1346,36 +1397,46 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
             B_b[(size_t)c * ldB + k_totB] = item_bias ? biasB[c] : (real_t)1;
         }
     }
+    if (!use_cg) finalize_chol = false;
     for (int_t iter = 0; iter < niter; iter++) {
+        if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;          /* :8336-8340, :9829-9830 */
         if (p) oracle_optimizeA_explicit(C, (size_t)kcu, A_b, ldA, p, m_u, kcu, Uc_p, Uc_i, Uc_v, lam / w_user, lam / w_user,
-                                         scale_lam, false, nthreads, false, false, 3);
+                                         scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         if (q) oracle_optimizeA_explicit(D, (size_t)kci, B_b, ldB, q, n_i, kci, Ic_p, Ic_i, Ic_v, lam / w_item, lam / w_item,
-                                         scale_lam, false, nthreads, false, false, 3);
+                                         scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         if (item_bias) for (int_t r = 0; r < m; r++) A_b[(size_t)r * ldA + k_totA] = 1;
         if (user_bias) for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
-        if (q)
+        if (q && use_cg)
+            oracle_optimizeA_collective_sparse_cg(B_b, ldB, A_b, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
+                                                  csc_p, csc_i, csc_v, Ir_p, Ir_i, Ir_v, lam, w_item, lam, scale_lam,
+                                                  scale_lam_sideinfo, implicit, max_cg_steps, precondition_cg, nthreads);
+        else if (q)
             oracle_optimizeA_collective_sparse_chol(B_b, ldB, A_b, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                                     csc_p, csc_i, csc_v, Ir_p, Ir_i, Ir_v, lam, w_item, lam, scale_lam,
                                                     scale_lam_sideinfo, implicit, nthreads);
         else if (implicit)
             oracle_optimizeA_implicit(B_b + k_item, ldB, A_b + k_user, ldA, n, m, k + k_main, csc_p, csc_i, csc_v, lam, nthreads,
-                                      false, false, 3, NULL);
+                                      use_cg, precondition_cg, max_cg_steps, NULL);
         else
             oracle_optimizeA_explicit(B_b + k_item, ldB, A_b + k_user, ldA, n, m, k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
-                                      lam, lam, scale_lam, false, nthreads, false, false, 3);
+                                      lam, lam, scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         if (item_bias) for (int_t c = 0; c < n; c++) biasB[c] = B_b[(size_t)c * ldB + k_totB];
         if (user_bias) for (int_t c = 0; c < n; c++) B_b[(size_t)c * ldB + k_totB] = 1;
         if (item_bias) for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
-        if (p)
+        if (p && use_cg)
+            oracle_optimizeA_collective_sparse_cg(A_b, ldA, B_b, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
+                                                  csr_p, csr_i, csr_v, Ur_p, Ur_i, Ur_v, lam, w_user, lam, scale_lam,
+                                                  scale_lam_sideinfo, implicit, max_cg_steps, precondition_cg, nthreads);
+        else if (p)
             oracle_optimizeA_collective_sparse_chol(A_b, ldA, B_b, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                                     csr_p, csr_i, csr_v, Ur_p, Ur_i, Ur_v, lam, w_user, lam, scale_lam,
                                                     scale_lam_sideinfo, implicit, nthreads);
         else if (implicit)
             oracle_optimizeA_implicit(A_b + k_user, ldA, B_b + k_item, ldB, m, n, k + k_main, csr_p, csr_i, csr_v, lam, nthreads,
-                                      false, false, 3, NULL);
+                                      use_cg, precondition_cg, max_cg_steps, NULL);
         else
             oracle_optimizeA_explicit(A_b + k_user, ldA, B_b + k_item, ldB, m, n, k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
-                                      lam, lam, scale_lam, false, nthreads, false, false, 3);
+                                      lam, lam, scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         if (user_bias) for (int_t r = 0; r < m; r++) biasA[r] = A_b[(size_t)r * ldA + k_totA];
     }
     if (has_bias) {

@@ -181,8 +181,19 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
                                              real_t lam, real_t w_user, real_t lam_last,
                                              bool scale_lam, bool scale_lam_sideinfo, bool implicit, int nthreads);
 
-/* Whole fits with SPARSE side information (COO, missing = absent), Cholesky updates, m_u <= m, n_i <= n, injected start
- * values: fit_collective_explicit_als (collective.c:7263-9370) / fit_collective_implicit_als (:9375-10207). */
+/* Block CG / PCG on the collective system with SPARSE side information (collective_block_cg :2134-2903 and
+ * collective_block_cg_implicit :2905-3303, u_vec_sp branches). */
+void oracle_optimizeA_collective_sparse_cg(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                                           int_t m, int_t m_u, int_t n, int_t p,
+                                           int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                           const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                           const size_t *Ucsr_p, const int_t *Ucsr_i, const real_t *Ucsr,
+                                           real_t lam, real_t w_user, real_t lam_last,
+                                           bool scale_lam, bool scale_lam_sideinfo, bool implicit,
+                                           int_t max_cg_steps, bool precondition_cg, int nthreads);
+
+/* Whole fits with SPARSE side information (COO, missing = absent), Cholesky or CG / PCG updates, m_u <= m, n_i <= n,
+ * injected start values: fit_collective_explicit_als (collective.c:7263-9370) / fit_collective_implicit_als (:9375-10207). */
 int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                                    real_t *glob_mean, int_t m, int_t n, int_t k,
                                    const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
@@ -191,7 +202,8 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
                                    const int_t *U_row, const int_t *U_col, const real_t *U_sp, size_t nnz_U, int_t m_u, int_t p,
                                    const int_t *I_row, const int_t *I_col, const real_t *I_sp, size_t nnz_I, int_t n_i, int_t q,
                                    int_t k_main, int_t k_user, int_t k_item,
-                                   real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads);
+                                   real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads,
+                                   bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol);
 
 #ifdef __cplusplus
 }

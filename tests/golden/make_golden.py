@@ -226,6 +226,11 @@ def main():
             for key, v in r.items():
                 if v is not None:
                     out["c%d_%s" % (ci, key)] = v
+        for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.SPARSE_SIDE_CG_CASES):
+            r = gc.sparse_sideinfo_reference(R, d, implicit, which, sl, sls, solver=solver)
+            for key, v in r.items():
+                if v is not None:
+                    out["g%d_%s" % (ci, key)] = v
         save("g12_sparse_sideinfo_" + tag, **out)
 
         # ---- RNG streams of the reference (pins the start-value generator) ----

@@ -291,15 +291,26 @@ def sparse_sideinfo_problem(dtype, seed=41):
 SPARSE_SIDE_CASES = [("implicit UI", True, "UI", False, False), ("explicit UI", False, "UI", False, False),
                      ("explicit UI scaled", False, "UI", True, True), ("explicit U", False, "U", True, False),
                      ("implicit I", True, "I", False, False)]
+# the same problems with the CG solvers: (name, implicit, sides, scale_lam, scale_lam_sideinfo, solver kwargs)
+SPARSE_SIDE_CG_CASES = [("implicit UI cg", True, "UI", False, False, dict(use_cg=True)),
+                        ("explicit UI cg+finalize", False, "UI", True, True, dict(use_cg=True, finalize_chol=True)),
+                        ("explicit U pcg", False, "U", True, False, dict(use_cg=True, precondition_cg=True)),
+                        # (implicit PCG with k_item > 0: rows without attributes divide by a zero preconditioner in the reference,
+                        #  collective.c:2993-3003, NaN on both sides -- so this one runs without item-only factors)
+                        ("implicit I pcg", True, "I", False, False, dict(use_cg=True, precondition_cg=True, no_k_side=True))]
 
 
-def sparse_sideinfo_reference(R, d, implicit, which, sl, sls, nthreads=2):
+def sparse_sideinfo_reference(R, d, implicit, which, sl, sls, nthreads=2, solver=None):
     """The real reference on the problem; returns dict(A, B, C, D, biasA, biasB, glob_mean)."""
-    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    solver = dict(solver or {}); nks = solver.pop("no_k_side", False)
+    ku = d["ku"] if ("U" in which and not nks) else 0; ki = d["ki"] if ("I" in which and not nks) else 0
     A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
-    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, use_cg=False, nthreads=nthreads,
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver or {})
+    cz = 0 if sv["use_cg"] else 1          # CG warm-starts C / D: the estimators start them at zero, so do these runs
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, **sv,
               U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
-              Cm=d["C0"][:, d["ku"] - ku:].copy() if "U" in which else None, Dm=d["D0"][:, d["ki"] - ki:].copy() if "I" in which else None)
+              Cm=(d["C0"][:, d["ku"] - ku:] * cz).copy() if "U" in which else None,
+              Dm=(d["D0"][:, d["ki"] - ki:] * cz).copy() if "I" in which else None)
     if implicit:
         r = R.fit_collective_implicit_als(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, w_main=0.5, **kw)
         return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"])
@@ -308,28 +319,33 @@ def sparse_sideinfo_reference(R, d, implicit, which, sl, sls, nthreads=2):
     return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
 
 
-def sparse_sideinfo_oracle(O, d, implicit, which, sl, sls, nthreads=2):
-    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+def sparse_sideinfo_oracle(O, d, implicit, which, sl, sls, nthreads=2, solver=None):
+    solver = dict(solver or {}); nks = solver.pop("no_k_side", False)
+    ku = d["ku"] if ("U" in which and not nks) else 0; ki = d["ki"] if ("I" in which and not nks) else 0
     A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
-    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads,
+    cz = 0 if (solver or {}).get("use_cg") else 1
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, **(solver or {}),
               U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
-              Cm=d["C0"][:, d["ku"] - ku:].copy() if "U" in which else None, Dm=d["D0"][:, d["ki"] - ki:].copy() if "I" in which else None)
+              Cm=(d["C0"][:, d["ku"] - ku:] * cz).copy() if "U" in which else None,
+              Dm=(d["D0"][:, d["ki"] - ki:] * cz).copy() if "I" in which else None)
     if implicit:
         return O.fit_als_sparse_sideinfo(A0, B0, d["row"], d["col"], d["counts"], d["k"], True, lam=2.0, alpha=1.5, w_main=0.5, **kw)
     return O.fit_als_sparse_sideinfo(A0, B0, d["row"], d["col"], d["ratings"], d["k"], False, biasA=d["bA"].copy(), biasB=d["bB"].copy(),
                                      user_bias=True, item_bias=True, center=True, lam=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **kw)
 
 
-def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype):
+def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
     """The product: the estimators with SciPy sparse side information."""
     import scipy.sparse as sp
     from cmfrec_amd import CMF, CMF_implicit
-    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    solver = dict(solver or {}); nks = solver.pop("no_k_side", False)
+    ku = d["ku"] if ("U" in which and not nks) else 0; ki = d["ki"] if ("I" in which and not nks) else 0
     A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
     mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
     U = mk(d["U_coo"]) if "U" in which else None; I = mk(d["I_coo"]) if "I" in which else None
-    common = dict(k=d["k"], k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, use_cg=False,
-                  use_float=dtype is np.float32, precompute_for_predictions=False)
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver or {})
+    common = dict(k=d["k"], k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3,
+                  use_float=dtype is np.float32, precompute_for_predictions=False, **sv)
     shape = (d["m"], d["n"])
     if implicit:
         mdl = CMF_implicit(lambda_=2.0, alpha=1.5, w_main=0.5, **common)
@@ -346,7 +362,8 @@ def compare_fits(got, exp):
     err = 0.0
     for key in ("A", "B", "C", "D", "biasA", "biasB"):
         if key in exp and exp[key] is not None and got.get(key) is not None and np.size(exp[key]):
-            err = max(err, maxrel(got[key], exp[key]))
+            e = maxrel(got[key], exp[key])
+            err = max(err, e) if np.isfinite(e) else float("inf")        # NaN anywhere is a failure, never silently dropped
     if "glob_mean" in exp and "glob_mean" in got:
         err = max(err, abs(float(got["glob_mean"]) - float(exp["glob_mean"])))
     return err

@@ -174,3 +174,8 @@ def test_sparse_sideinfo(oracles, dtype):
         assert gc.compare_fits(got, exp) < tol, name
         orc = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls)
         assert gc.compare_fits(got, orc) < tol, name
+    for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.SPARSE_SIDE_CG_CASES):
+        got = gc.sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=solver)
+        exp = {key[len("g%d_" % ci):]: g[key] for key in g.files if key.startswith("g%d_" % ci)}
+        tol = 1e-8 if dtype is np.float64 else 1e-2           # three CG iterations (1e-6 / 1e-2 for fits)
+        assert exp and gc.compare_fits(got, exp) < tol, name

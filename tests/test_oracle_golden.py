@@ -135,3 +135,7 @@ def test_sparse_sideinfo(oracles, dtype):
         got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls)
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert gc.compare_fits(got, exp) < TOL[dtype], name
+    for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.SPARSE_SIDE_CG_CASES):
+        got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls, solver=solver)
+        exp = {key[len("g%d_" % ci):]: g[key] for key in g.files if key.startswith("g%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name      # CG fits: the fit tolerance

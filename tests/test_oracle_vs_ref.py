@@ -230,6 +230,12 @@ def test_sparse_sideinfo_live(oracles, refs, dtype):
                 R.optimizeA_collective(a1, B, Cm, csr, None, 0.7, U_csr=ucsr, nthreads=2, **kw)
                 O.optimizeA_collective_sparse(a2, B, Cm, csr, ucsr, 0.7, nthreads=1, **kw)
                 assert rel_err(a2, a1) < tol, ("explicit", ku, sl, sls)
+                for pcg in (False, True):
+                    a1, a2 = A0.copy(), A0.copy()
+                    R.optimizeA_collective(a1, B, Cm, csr, None, 0.7, U_csr=ucsr, nthreads=2, use_cg=True, precondition_cg=pcg, **kw)
+                    O.optimizeA_collective_sparse(a2, B, Cm, csr, ucsr, 0.7, nthreads=1, use_cg=True, precondition_cg=pcg, **kw)
+                    assert rel_err(a2, a1) < tol, ("explicit cg", ku, sl, sls, pcg)
+                    assert not a1[3].any() and np.array_equal(a1[85], A0[85])      # no data at all: zeros; beyond m_u: untouched
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -242,4 +248,9 @@ def test_fit_sparse_sideinfo_live(oracles, refs, dtype):
     for name, implicit, which, sl, sls in gc.SPARSE_SIDE_CASES:
         exp = gc.sparse_sideinfo_reference(refs[dtype], d, implicit, which, sl, sls, nthreads=3)
         got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls, nthreads=1)
+        assert gc.compare_fits(got, exp) < tol, name
+    # block CG / PCG with the attributes as a second gathered term (collective.c:2134-3303, u_vec_sp branches)
+    for name, implicit, which, sl, sls, solver in gc.SPARSE_SIDE_CG_CASES:
+        exp = gc.sparse_sideinfo_reference(refs[dtype], d, implicit, which, sl, sls, nthreads=3, solver=solver)
+        got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls, nthreads=1, solver=solver)
         assert gc.compare_fits(got, exp) < tol, name
