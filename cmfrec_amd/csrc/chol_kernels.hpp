@@ -62,6 +62,10 @@ struct CholParams {
     size_t ldb2 = 0;
     int kc2 = 0;
     T w2 = 0;
+    // non-negative factors: the assembled system is solved by the reference's cyclic coordinate descent instead of the
+    // Cholesky factorisation (solve_nonneg, common.c:2131-2179), at most max_cd_steps sweeps
+    int nonneg = 0;
+    int max_cd_steps = 100;
     int rows_with_u;           // collective: rows < rows_with_u carry side information
     int p_side;                // collective: number of side-info columns (scale_lam_sideinfo)
     T lam, lam_last;
@@ -439,6 +443,63 @@ chol_rows_kernel(const CholParams<T> P)
                     acc[tt][r] += dv;
                 }
             }
+        }
+        if (P.nonneg) {
+            // ---- 3'. non-negative solution by cyclic coordinate descent (solve_nonneg, common.c:2131-2179):
+            //   a = 0, g = rhs;  sweep ix = 0..kt-1:  new = max(a_ix + g_ix / M_ix,ix, 0);  if |new - a_ix| > 1e-8:
+            //   g -= (new - a_ix) M[ix, :], a_ix = new;  stop after a sweep that moved less than 1e-8 in total.
+            // The matrix leaves the accumulators for LDS (full, both triangles, [kt][kt] over the staging area -- the
+            // launch reserves kt^2 + 2 kt elements), one wavefront sweeps with lane <-> unknown.
+            __syncthreads();                  // ring fully consumed
+            T *Mn = ring;
+            T *gn = ring + (size_t)kt * kt;
+#pragma unroll
+            for (int tt = 0; tt < TPW; tt++) {
+                if (!T_REAL(tt)) continue;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gi = offa[tt] + Mf::row_of(lane, r), gj = offb[tt] + lm;
+                    if (gi < kt && gj < kt) {
+                        Mn[(size_t)gi * kt + gj] = acc[tt][r];
+                        Mn[(size_t)gj * kt + gi] = acc[tt][r];           // fill_lower_triangle
+                    }
+                }
+            }
+            if (tid < kt) gn[tid] = racc;
+            __syncthreads();
+            if (wave == 0) {
+                constexpr int NFN = (16 * NTT + 63) / 64;
+                T an[NFN], gg[NFN];
+#pragma unroll
+                for (int c = 0; c < NFN; c++) { an[c] = T(0); gg[c] = (lane + 64 * c < kt) ? gn[lane + 64 * c] : T(0); }
+                const int sweeps = (P.max_cd_steps > 0) ? P.max_cd_steps : 0x7fffffff;
+                for (int it = 0; it < sweeps; it++) {
+                    T moved = T(0);
+                    for (int ix = 0; ix < kt; ix++) {
+                        const int cq = ix >> 6, lq = ix & 63;
+                        T a_ix = T(0), g_ix = T(0);
+#pragma unroll
+                        for (int c = 0; c < NFN; c++)
+                            if (c == cq) { a_ix = bcast_lane(an[c], lq); g_ix = bcast_lane(gg[c], lq); }
+                        T nv = a_ix + g_ix / Mn[(size_t)ix * kt + ix];
+                        nv = (nv > T(0)) ? nv : T(0);                       // max2(newval, 0.): NaN -> 0 like the reference's macro
+                        const T dv = nv - a_ix;
+                        if (fabs(dv) > T(1e-8)) {
+                            moved += fabs(dv);
+#pragma unroll
+                            for (int c = 0; c < NFN; c++) {
+                                const int f = lane + 64 * c;
+                                if (f < kt) gg[c] -= dv * Mn[(size_t)ix * kt + f];
+                                if (c == cq && lane == lq) an[c] = nv;
+                            }
+                        }
+                    }
+                    if (!(moved >= T(1e-8)) || isinf(moved)) break;          // isnan / !isfinite / < 1e-8
+                }
+#pragma unroll
+                for (int c = 0; c < NFN; c++) if (lane + 64 * c < kt) arow[lane + 64 * c] = an[c];
+            }
+            continue;                         // the next row starts with a barrier
         }
         if (tid < 16 * NTT) rhs[tid] = (tid < kt) ? racc : T(0);
         __syncthreads();                      // ring fully consumed (X tiles alias it), rhs visible

@@ -238,6 +238,10 @@ struct DeviceInfo {
     // rocBLAS handle for the plain dense contractions of the side-information path (U C, U^T A, A^T A for k > 64);
     // created on first use, bound to `stream`, atomics off (bit-reproducible results)
     rocblas_handle blas = nullptr;
+    // solver option of the update in progress (set by the session around a half-step): closed-form rows are solved by
+    // the non-negative coordinate descent instead of the Cholesky factorisation
+    mutable bool nonneg_now = false;
+    mutable int max_cd_steps = 100;
     DeviceInfo() = default;
     DeviceInfo(const DeviceInfo &) = delete;
     DeviceInfo &operator=(const DeviceInfo &) = delete;

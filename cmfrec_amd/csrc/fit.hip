@@ -113,7 +113,7 @@ int_t fit_collective_implicit_als(
     real_t *precomputedBeTBeChol, real_t *precomputedCtUbias)
 {
 
-    (void)nthreads; (void)max_cd_steps; (void)nonneg_C; (void)nonneg_D;
+    (void)nthreads;
     (void)precomputedCtUbias;            // only written with sparse U + NA_as_zero_U (collective.c:10111), not supported
     (void)handle_interrupt;
     // collective.c:9406-9435
@@ -133,8 +133,9 @@ int_t fit_collective_implicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight)
-        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / adjust_weight are not implemented.");
+    if (l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight)
+        return fail(verbose, "cmfrec_hip: L1 / lam_unique / adjust_weight are not implemented.");
+    if (nonneg) use_cg = false;                                           // collective.c:9513-9517
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
@@ -198,6 +199,7 @@ int_t fit_collective_implicit_als(
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
+    if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, C, D);
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     if (tm.on) cmfrec_hip_session_sync(s);
@@ -244,7 +246,6 @@ int_t fit_collective_explicit_als(
 {
     (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB;
     (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
-    (void)nonneg_C; (void)nonneg_D;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // only with add_implicit_features, not supported
     (void)precomputedCtUbias;      // only with sparse U + NA_as_zero_U, not supported
@@ -262,8 +263,9 @@ int_t fit_collective_explicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (nonneg || l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const)
-        return fail(verbose, "cmfrec_hip: nonneg / L1 / lam_unique / scale_bias_const are not implemented.");
+    if (l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const)
+        return fail(verbose, "cmfrec_hip: L1 / lam_unique / scale_bias_const are not implemented.");
+    if (nonneg) use_cg = false;                                           // collective.c:7474-7479
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
@@ -343,6 +345,7 @@ int_t fit_collective_explicit_als(
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
+    if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("side info + factors upload");
@@ -431,7 +434,6 @@ int_t factors_collective_explicit_multiple(
     (void)BtB; (void)TransBtBinvBt; (void)BtXbias; (void)BeTBeChol; (void)BiTBi; (void)CtCw; (void)CtUbias; (void)B_plus_bias;
     (void)nthreads;
     if (NA_as_zero_U || NA_as_zero_X) return unsupported_multiple("NA_as_zero");
-    if (nonneg) return unsupported_multiple("nonneg");
     const bool spU = (U == nullptr && (nnz_U || U_csr_p));
     if (Ub) return unsupported_multiple("binary side information");
     if (Xfull) return unsupported_multiple("dense X");
@@ -463,8 +465,8 @@ int_t factors_collective_explicit_multiple(
     int rc = cmfrec_hip_factors_multiple(A, biasA, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
                                          Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n_rows_B, C, biasB, k, k_user, k_item,
                                          k_main, lam, lam_bias, lam, w_user, false, scale_lam, scale_lam_sideinfo,
-                                         scale_bias_const, nullptr, TransCtCinvCt, U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i,
-                                         U_csr);
+                                         scale_bias_const, nullptr, nonneg ? nullptr : TransCtCinvCt, U_row, U_col, U_sp, nnz_U,
+                                         U_csr_p, U_csr_i, U_csr, nonneg);
     if (rc == 2) fprintf(stderr, "%s\n", cmfrec_hip_last_error());
     return rc > 3 ? 1 : rc;
 }
@@ -490,7 +492,6 @@ int_t factors_collective_implicit_multiple(
 {
     (void)BeTBe; (void)CtUbias; (void)nthreads;
     if (NA_as_zero_U) return unsupported_multiple("NA_as_zero");
-    if (nonneg) return unsupported_multiple("nonneg");
     const bool spU = (U == nullptr && (nnz_U || U_csr_p));
     if (l1_lam != 0) return unsupported_multiple("L1 regularisation");
     if (U == nullptr && !spU) m_u = 0;
@@ -515,7 +516,7 @@ int_t factors_collective_implicit_multiple(
     int rc = cmfrec_hip_factors_multiple(A, nullptr, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
                                          Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n, C, nullptr, k, k_user, k_item, k_main,
                                          lam, lam, BtB ? lam : lam_x, w_user, true, false, false, false, BtB, nullptr,
-                                         U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr);
+                                         U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr, nonneg);
     return rc > 3 ? 1 : rc;
 }
 

@@ -43,6 +43,9 @@ struct CholCall {
     size_t ldb2 = 0;
     int kc2 = 0;
     real_t w2 = 0;
+    // non-negative factors: coordinate descent on the assembled system instead of the Cholesky solve
+    bool nonneg = false;
+    int max_cd_steps = 100;
 };
 
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
@@ -64,8 +67,15 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr;
         P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2;
     }
+    const bool nonneg = c.nonneg || dev.nonneg_now;
+    P.nonneg = nonneg ? 1 : 0; P.max_cd_steps = dev.nonneg_now ? dev.max_cd_steps : c.max_cd_steps;
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
+    const size_t smem_nonneg = nonneg ? ((size_t)c.kt * c.kt + 2 * (size_t)c.kt + 64) * sizeof(real_t) : 0;
+    if (smem_nonneg > 160 * 1024) {
+        g_last_error = "cmfrec_hip: nonneg: the k_t x k_t system must fit the 160 KB of LDS (k_t <= 140 in double, 199 in single precision)";
+        return 2;
+    }
     if (T > 17 || (sizeof(real_t) == 8 && T > 16)) {
         g_last_error = "cmfrec_hip: Cholesky path: k_t too large for the register-resident normal matrix "
                        "(k_t <= 256 in double, <= 272 in single precision)";
@@ -80,7 +90,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
 #define CHOL_KERN(a, b, c_, d) (two_src ? chol_rows_kernel<real_t, a, b, c_, d, true> : chol_rows_kernel<real_t, a, b, c_, d, false>)
     hipStream_t run_on = dev.stream;
     auto launch = [&](auto kern, int ntt, int nw, int ch, int wgs) {
-        size_t smem = chol_lds_elems<real_t>(ntt, ch) * sizeof(real_t);
+        size_t smem = std::max(chol_lds_elems<real_t>(ntt, ch) * sizeof(real_t), smem_nonneg);
         int grid = std::min(P.nrows - P.row_first, dev.num_cus * wgs);
         if (grid <= 0) return;
         if (smem > 48 * 1024)
@@ -191,6 +201,9 @@ struct cmfrec_hip_session {
     // sparse side information (missing = absent): CSR by user / item for the factor updates, CSC by attribute for C / D
     SparseShard Usr, Usc, Isr, Isc;
     bool sparseU = false, sparseI = false;
+    // non-negativity constraints (solve_nonneg instead of the Cholesky solve; they switch the CG off for that matrix)
+    bool nonneg = false, nonneg_C = false, nonneg_D = false;
+    int max_cd_steps = 100;
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
     std::vector<std::unique_ptr<SparseShard>> XrParts;
@@ -520,6 +533,13 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
+}
+
+int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps)
+{
+    s->nonneg = nonneg != 0; s->nonneg_C = nonneg_C != 0; s->nonneg_D = nonneg_D != 0;
+    s->max_cd_steps = max_cd_steps;
+    return 0;
 }
 
 int cmfrec_hip_session_set_sideinfo_sparse(cmfrec_hip_session *s, int which, const int_t *row, const int_t *col,
@@ -927,7 +947,13 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
-        const bool chol = use_cholesky || !s->mdl.use_cg;
+        const bool nn = (which == 'A' || which == 'B') ? s->nonneg : (which == 'C' ? s->nonneg_C : s->nonneg_D);
+        const bool chol = use_cholesky || !s->mdl.use_cg || nn;       // common.c:725, :2781, :3320: no CG with nonneg
+        struct NonnegScope {                                          // the closed-form launches of this update
+            const DeviceInfo &d;
+            NonnegScope(const DeviceInfo &d_, bool on, int steps) : d(d_) { d.nonneg_now = on; d.max_cd_steps = steps; }
+            ~NonnegScope() { d.nonneg_now = false; }
+        } scope(s->dev, nn, s->max_cd_steps);
         if (which == 'A' || which == 'B') {
             EventPair ev{s->new_event(), s->new_event()};
             HIP_CHECK(hipEventRecord(ev.a, s->dev.stream));
@@ -1309,7 +1335,7 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
                                 bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
                                 const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
                                 const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
-                                const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr)
+                                const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr, bool nonneg)
 {
     return guarded([&]() {
         // sparse side information (COO or CSR over m_u rows, missing = absent): second gather source of the row kernel
@@ -1331,6 +1357,10 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
         init_device(dev, -1);
         hipStream_t st = dev.stream;
         const int ub = biasA ? 1 : 0;
+        // non-negative factors: every row system below goes through solve_nonneg with the reference's sweep limit for
+        // new rows, 10 x the number of unknowns (collective.c:3401, :3800-3931, :4041-4054)
+        dev.nonneg_now = nonneg;
+        dev.max_cd_steps = 10 * (k_user + k + k_main + ub);
         const int kc = k_user + k, kk = k + k_main, kt = k_user + kk + ub, ktA = k_user + kk;
         const size_t ldb_host = (size_t)(k_item + kk), ldB = ldb_host + ub, ldA = (size_t)kt;
         DevBuf<real_t> dA, dB, dC, dU, dmeans, dbias, dG, dM, dCtC, dcold, dT;

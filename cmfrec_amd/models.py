@@ -113,8 +113,9 @@ class CMF_implicit(_Base):
         self.finalize_chol = bool(finalize_chol); self.random_state = int(random_state)
         self.verbose = bool(verbose); self.handle_interrupt = bool(handle_interrupt)
         self._setup(use_float, nthreads, n_jobs)
-        if self.nonneg or nonneg_C or nonneg_D or l1_lambda:
-            raise NotImplementedError("nonneg / l1_lambda are not implemented in cmfrec_amd")
+        self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D); self.max_cd_steps = int(max_cd_steps)
+        if l1_lambda:
+            raise NotImplementedError("l1_lambda is not implemented in cmfrec_amd")
 
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
@@ -160,7 +161,7 @@ class CMF_implicit(_Base):
             C.c_bool(self.apply_log_transf), C.c_int(self.niter), C.c_int(self.nthreads),
             C.c_bool(self.verbose), C.c_bool(self.handle_interrupt), C.c_bool(self.use_cg),
             C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg), C.c_bool(self.finalize_chol),
-            C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(self.nonneg), C.c_int(self.max_cd_steps), C.c_bool(self.nonneg_C), C.c_bool(self.nonneg_D),
             C.c_bool(pre), _lib.ptr(BtB), _lib.ptr(BeTBe), _lib.ptr(BeTBeChol), None)
         _lib.check(rc, lib, "fit_collective_implicit_als")
         self.A_, self.B_ = A, B
@@ -191,7 +192,7 @@ class CMF_implicit(_Base):
         A = np.empty((max(m_x, m_u), self.k_user + self.k + self.k_main), dt)
         has = lambda M: M is not None and M.shape[0] > 0
         rc = lib.factors_collective_implicit_multiple(
-            _lib.ptr(A), C.c_int(m_x), _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(False),
+            _lib.ptr(A), C.c_int(m_x), _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), C.c_bool(False), C.c_bool(self.nonneg),
             None, None, None, C.c_size_t(0), None, None, None,
             _lib.ptr(val), _lib.ptr(row), _lib.ptr(col), C.c_size_t(len(val)), None, None, None,
             _lib.ptr(self.B_), C.c_int(n), _lib.ptr(self.C_) if p else None,
@@ -230,10 +231,11 @@ class CMF(_Base):
                  n_jobs=None):
         if method != "als":
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
-        if add_implicit_features or NA_as_zero or NA_as_zero_user or NA_as_zero_item or nonneg or nonneg_C \
-                or nonneg_D or l1_lambda or scale_bias_const:
-            raise NotImplementedError("add_implicit_features / NA_as_zero / nonneg / l1_lambda / scale_bias_const "
+        if add_implicit_features or NA_as_zero or NA_as_zero_user or NA_as_zero_item or l1_lambda or scale_bias_const:
+            raise NotImplementedError("add_implicit_features / NA_as_zero / l1_lambda / scale_bias_const "
                                       "are not implemented in cmfrec_amd")
+        self.nonneg = bool(nonneg); self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D)
+        self.max_cd_steps = int(max_cd_steps)
         if not (center_U and center_I):
             raise NotImplementedError("center_U / center_I = False are not implemented in cmfrec_amd")
         self.k = int(k); self.lambda_ = float(lambda_); self.use_cg = bool(use_cg)
@@ -296,7 +298,8 @@ class CMF(_Base):
             R(self.w_main), R(self.w_user), R(self.w_item), R(self.w_implicit),
             C.c_int(self.niter), C.c_int(self.nthreads), C.c_bool(self.verbose), C.c_bool(self.handle_interrupt),
             C.c_bool(use_cg), C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg),
-            C.c_bool(self.finalize_chol), C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(self.finalize_chol), C.c_bool(self.nonneg), C.c_int(self.max_cd_steps), C.c_bool(self.nonneg_C),
+            C.c_bool(self.nonneg_D),
             C.c_bool(pre), C.c_bool(True), _lib.ptr(Bpb), _lib.ptr(BtB), _lib.ptr(TBt), None, _lib.ptr(BeChol), None,
             _lib.ptr(TCt), _lib.ptr(CtCw), None)
         _lib.check(rc, lib, "fit_collective_explicit_als")
@@ -336,7 +339,7 @@ class CMF(_Base):
         has = lambda M: M is not None and M.shape[0] > 0
         rc = lib.factors_collective_explicit_multiple(
             _lib.ptr(A), _lib.ptr(biasA), C.c_int(m_x), _lib.ptr(Uc), C.c_int(m_u), C.c_int(p),
-            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            C.c_bool(False), C.c_bool(False), C.c_bool(self.nonneg),
             None, None, None, C.c_size_t(0), None, None, None, None, C.c_int(0), C.c_int(0),
             _lib.ptr(self.C_) if p else None, None, R(self.glob_mean_),
             _lib.ptr(self.item_bias_) if self.item_bias else None,

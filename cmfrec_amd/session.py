@@ -76,6 +76,11 @@ class AlsSession:
         _lib.check(self.lib.cmfrec_hip_session_stream_wait_part(self.handle, C.c_int(part), C.c_void_p(raw_stream)), self.lib,
                    "stream_wait_part")
 
+    def set_nonneg(self, nonneg=True, nonneg_C=False, nonneg_D=False, max_cd_steps=100):
+        """Non-negative factors: coordinate descent (reference solve_nonneg) instead of the Cholesky / CG solves."""
+        _lib.check(self.lib.cmfrec_hip_session_set_nonneg(self.handle, C.c_int(int(nonneg)), C.c_int(int(nonneg_C)),
+                                                          C.c_int(int(nonneg_D)), C.c_int(int(max_cd_steps))), self.lib, "set_nonneg")
+
     def init_biases(self, lam_user, lam_item):
         """Bias start values on the device (reference initialize_biases_*, src/common.c:4410-4909)."""
         R = _lib.real(self.dtype)

@@ -47,7 +47,8 @@ extern "C" {
  * (collective_block_cg_implicit, :2905-3303).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight,
  * no precompute.
  * or SPARSE side information as COO triplets (U_row / U_col / U_sp / nnz_U and the I_* twins; missing = absent, rows
- * within X's; collective.c:1849-2131 / :2905-3303 with u_vec_sp).  Anything else returns 2. */
+ * within X's; collective.c:1849-2131 / :2905-3303 with u_vec_sp); nonneg / nonneg_C / nonneg_D with max_cd_steps
+ * (solve_nonneg, common.c:2131-2179; k_t <= 140 / 199).  Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
     real_t *C, real_t *D,
@@ -83,7 +84,8 @@ int_t fit_collective_implicit_als(
  * m, n: rows known from side information only are fitted to it alone and get a zero bias, :4967-5101, :8296)
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
  * k_main/k_user/k_item, w_user/w_item; also SPARSE side information as COO triplets (missing = absent, rows within
- * X's; collective_closed_form_block / collective_block_cg with u_vec_sp, :1636-1653, :1719-1731, :2609-2621).  Anything else returns 2. */
+ * X's; collective_closed_form_block / collective_block_cg with u_vec_sp, :1636-1653, :1719-1731, :2609-2621); nonneg /
+ * nonneg_C / nonneg_D with max_cd_steps (solve_nonneg, common.c:2131-2179).  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,
@@ -188,7 +190,8 @@ int cmfrec_hip_factors_multiple(
     const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
     /* sparse side information instead of U (NULL): COO triplets or CSR over the m_u rows, missing = absent */
     const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
-    const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr);
+    const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr,
+    bool nonneg /* solve_nonneg instead of the Cholesky solves, 10 (k_user+k+k_main[+1]) sweeps at most */);
 
 /* Replace factors_collective_explicit_multiple / factors_collective_implicit_multiple,
  * /root/reference/src/cmfrec.h:2004-2047 and :2048-2071 (bodies src/collective.c:10865-11174, :11176-11340): same
@@ -196,7 +199,8 @@ int cmfrec_hip_factors_multiple(
  * (COO or CSR), dense U without NaN (rows beyond m get the side-information-only solution, rows beyond m_u the plain
  * one), user bias, lam_unique, scale_lam / scale_lam_sideinfo / scale_bias_const, w_main / w_user, alpha and
  * apply_log_transf; sparse side information (COO or CSR; not together with scale_lam_sideinfo in the explicit
- * version).  NA_as_zero, nonneg, L1, weights, dense X, binary side information and implicit features return 2.  Of the precomputed matrices only BtB (implicit) and TransCtCinvCt (explicit) are read -- the
+ * version).  NA_as_zero, L1, weights, dense X, binary side information and implicit features return 2; nonneg is
+ * supported (solve_nonneg on every row system).  Of the precomputed matrices only BtB (implicit) and TransCtCinvCt (explicit) are read -- the
  * ones that change the result; the others are rebuilt on the device from B and C.
  * Two details of the reference that are kept: (1) without a precomputed BtB the implicit version puts the lam of the
  * call, *not* lam / w_main, on the diagonal of the X block (collective.c:11270-11280) while the k_user block gets
@@ -329,6 +333,11 @@ int cmfrec_hip_session_get_factors(cmfrec_hip_session *s, real_t *A, real_t *B,
 /* Dense side information, already centred by column (host does column means like
  * common.c:4911-4997): U rows [0,m_u), II rows [0,n_i). */
 int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, const real_t *II);
+/* Non-negativity constraints: nonneg for A and B, nonneg_C / nonneg_D for the side-information factors.  The closed-form
+ * row systems are then solved by the reference's cyclic coordinate descent (solve_nonneg, src/common.c:2131-2179,
+ * at most max_cd_steps sweeps, 0 = until converged) and the CG is switched off for that matrix (common.c:725, :2781).
+ * The k_t x k_t system lives in LDS: k_t <= 140 (double) / 199 (single). */
+int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps);
 /* SPARSE side information as COO triplets (which = 'U': [m_u, p], 'I': [n_i, q]; missing = absent, no centring):
  * CSR by row and CSC by attribute are built on the device.  Cholesky updates: the row's attributes are a second gather
  * source of the row kernel; CG / PCG: a second gathered term of the block CG (generic kernel).  m_u <= rows of X. */

@@ -75,6 +75,14 @@ class Oracle:
     def _r(self, x):
         return self.real(float(x))
 
+    def set_nonneg(self, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100):
+        """Non-negativity option of the following fits (solve_nonneg instead of the Cholesky solve; no CG)."""
+        self.lib.oracle_set_nonneg(C.c_bool(nonneg), C.c_bool(nonneg_C), C.c_bool(nonneg_D), C.c_int(max_cd_steps))
+
+    def set_nonneg_now(self, on, max_cd_steps=100):
+        """The same for operator-level calls outside a fit."""
+        self.lib.oracle_set_nonneg_now(C.c_bool(on), C.c_int(max_cd_steps))
+
     def coo_to_csr_and_csc(self, row, col, val, m, n):
         nnz = len(val)
         row = np.ascontiguousarray(row, np.int32)
@@ -640,7 +648,8 @@ class Reference:
                                     finalize_chol=False, reset_values=False, seed=1,
                                     apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
-                                    precompute=False, m=None, n=None, U_coo=None, I_coo=None):
+                                    precompute=False, m=None, n=None, U_coo=None, I_coo=None, nonneg=False,
+                                    nonneg_C=False, nonneg_D=False, max_cd_steps=100):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -670,7 +679,7 @@ class Reference:
             self._r(alpha), C.c_bool(False), C.c_bool(apply_log_transf),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
-            C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(nonneg), C.c_int(max_cd_steps), C.c_bool(nonneg_C), C.c_bool(nonneg_D),
             C.c_bool(precompute), _ptr(pre["BtB"]) if pre else None, _ptr(pre["BeTBe"]) if pre else None,
             _ptr(pre["BeTBeChol"]) if pre else None, _ptr(pre["CtUbias"]) if pre else None)
         if U is None and II is None and not precompute and U_coo is None and I_coo is None:
@@ -683,7 +692,7 @@ class Reference:
                                     k_main=0, k_user=0, k_item=0, w_user=1.0, w_item=1.0, niter=10,
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
-                                    U_coo=None, I_coo=None):
+                                    U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -726,7 +735,7 @@ class Reference:
             self._r(1.), self._r(w_user), self._r(w_item), self._r(1.),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
-            C.c_bool(False), C.c_int(100), C.c_bool(False), C.c_bool(False),
+            C.c_bool(nonneg), C.c_int(max_cd_steps), C.c_bool(nonneg_C), C.c_bool(nonneg_D),
             C.c_bool(precompute), C.c_bool(True), pp("B_plus_bias"), pp("BtB"), pp("TransBtBinvBt"), pp("BtXbias"),
             pp("BeTBeChol"), pp("BiTBi"), pp("TransCtCinvCt"), pp("CtCw"), pp("CtUbias"))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],

@@ -99,6 +99,50 @@ static void chol_solve_upper_(int_t k, const real_t *R, int_t ld, real_t *b)
     }
 }
 
+/* solve_nonneg, common.c:2131-2179 (no L1): cyclic coordinate descent on the normal equations, a >= 0.
+ * M: k x k, upper triangle valid (the lower one is filled here like fill_lower_triangle, helpers.c:1624). */
+static void solve_nonneg_(int_t k, real_t *M, int_t ld, real_t *b, long max_cd_steps)
+{
+    for (int_t r = 1; r < k; r++)
+        for (int_t c = 0; c < r; c++) M[(size_t)r * ld + c] = M[(size_t)c * ld + r];
+    real_t a_prev[1024];
+    for (int_t i = 0; i < k; i++) a_prev[i] = 0;
+    if (max_cd_steps <= 0) max_cd_steps = 0x7fffffff;
+    for (long iter = 0; iter < max_cd_steps; iter++) {
+        real_t diff_iter = 0;
+        for (int_t ix = 0; ix < k; ix++) {
+            real_t newval = a_prev[ix] + b[ix] / M[(size_t)ix * ld + ix];
+            newval = (newval >= 0) ? newval : 0;
+            const real_t diff_val = newval - a_prev[ix];
+            if (fabs((double)diff_val) > 1e-8) {
+                diff_iter += (real_t)fabs((double)diff_val);
+                for (int_t f = 0; f < k; f++) b[f] -= diff_val * M[(size_t)ix * ld + f];
+                a_prev[ix] = newval;
+            }
+        }
+        if (isnan(diff_iter) || !isfinite(diff_iter) || diff_iter < 1e-8) break;
+    }
+    for (int_t i = 0; i < k; i++) b[i] = a_prev[i];
+}
+
+/* What the closed-form row functions end with: posv, or solve_nonneg when the option is on (common.c:1066-1090,
+ * :2101-2126, collective.c:1822-1846, :2107-2131).  The option is process-wide test-infrastructure state. */
+static bool g_nonneg = false, g_nn_AB = false, g_nn_C = false, g_nn_D = false;
+static long g_max_cd = 100;
+void oracle_set_nonneg(bool nonneg, bool nonneg_C, bool nonneg_D, int_t max_cd_steps)
+{
+    g_nn_AB = nonneg; g_nn_C = nonneg_C; g_nn_D = nonneg_D; g_max_cd = max_cd_steps;
+    g_nonneg = false;
+}
+/* for operator-level calls outside a fit */
+void oracle_set_nonneg_now(bool on, int_t max_cd_steps) { g_nonneg = on; g_max_cd = max_cd_steps; }
+static void solve_sym_(int_t k, real_t *M, int_t ld, real_t *b)
+{
+    if (g_nonneg) { solve_nonneg_(k, M, ld, b, g_max_cd); return; }
+    if (chol_upper_(k, M, ld) == 0) { chol_solve_upper_(k, M, ld, b); return; }
+    for (int_t i = 0; i < k; i++) b[i] = NAN;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 void oracle_coo_to_csr_and_csc(const int_t *Xrow, const int_t *Xcol, const real_t *Xval,
                                int_t m, int_t n, size_t nnz,
@@ -245,8 +289,7 @@ static void implicit_chol_row(real_t *a, int_t k, const real_t *B, size_t ldb,
         syr_upper_(k, Xa[ix], B + (size_t)ixB[ix] * ldb, M, k);
     for (int_t i = 0; i < k; i++)                                              /* :2097 sum_mat */
         for (int_t j = i; j < k; j++) M[(size_t)i * k + j] += BtB[(size_t)i * k + j];
-    if (chol_upper_(k, M, k) == 0) chol_solve_upper_(k, M, k, a);
-    else for (int_t i = 0; i < k; i++) a[i] = NAN;
+    solve_sym_(k, M, k, a);
 }
 
 void oracle_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
@@ -384,8 +427,7 @@ static void explicit_chol_row(real_t *a, int_t k, const real_t *B, size_t ldb,
         syr_upper_(k, (real_t)1, B + (size_t)ixB[ix] * ldb, M, k);
     for (int_t i = 0; i < k - 1; i++) M[(size_t)i * k + i] += lam;            /* add_to_diag2 */
     M[(size_t)(k - 1) * k + (k - 1)] += lam_last;
-    if (chol_upper_(k, M, k) == 0) chol_solve_upper_(k, M, k, a);
-    else for (int_t i = 0; i < k; i++) a[i] = NAN;
+    solve_sym_(k, M, k, a);
 }
 
 void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
@@ -436,7 +478,8 @@ void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t 
     real_t dll = scale_lam ? lam_last * (real_t)n : lam_last;
     for (int_t i = 0; i < k - 1; i++) BtB[(size_t)i * k + i] += dl;
     BtB[(size_t)(k - 1) * k + (k - 1)] += dll;
-    int bad = chol_upper_(k, BtB, k);
+    const bool nonneg = g_nonneg;                                              /* solve_nonneg_batch, :2890-2902: the matrix is shared, not factored */
+    int bad = nonneg ? 0 : chol_upper_(k, BtB, k);
     #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int_t i = 0; i < m; i++) {
         real_t *a = A + (size_t)i * lda;
@@ -451,7 +494,13 @@ void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t 
         }
         for (int_t c = 0; c < k; c++) a[c] = (real_t)accp[c];
         if (accp != acc) free(accp);
-        if (!bad) chol_solve_upper_(k, BtB, k, a);                             /* :2872 posv */
+        if (nonneg) {
+            real_t *Mc = (real_t *)malloc((size_t)k * k * sizeof(real_t));
+            memcpy(Mc, BtB, (size_t)k * k * sizeof(real_t));
+            solve_nonneg_(k, Mc, k, a, g_max_cd);
+            free(Mc);
+        }
+        else if (!bad) chol_solve_upper_(k, BtB, k, a);                        /* :2872 posv */
         else for (int_t c = 0; c < k; c++) a[c] = NAN;
     }
     free(BtB);
@@ -522,8 +571,7 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
             axpy_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
         for (int_t i = 0; i < k_totA - 1; i++) M[(size_t)i * k_totA + i] += lam_i; /* :1819 */
         M[(size_t)(k_totA - 1) * k_totA + (k_totA - 1)] += lam_last_i;
-        if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
-        else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+        solve_sym_(k_totA, M, k_totA, a);
     }
     free(bufs);
     free(CtCw);
@@ -753,16 +801,14 @@ void oracle_optimizeA_collective_implicit_chol(real_t *A, size_t lda, const real
             real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;
             for (size_t jx = st; jx < en; jx++)                                /* :2103-2108 */
                 syr_upper_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
-            if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
-            else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+            solve_sym_(k_totA, M, k_totA, a);
         } else if (en > st) {                                                  /* optimizeA_implicit, common.c:2063-2126 */
             for (int_t i = 0; i < kb; i++) memcpy(M + (size_t)i * kb, BtB + (size_t)i * kb, (size_t)kb * sizeof(real_t));
             for (size_t jx = st; jx < en; jx++)
                 axpy_(kb, Xcsr[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
             for (size_t jx = st; jx < en; jx++)
                 syr_upper_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, M, kb);
-            if (chol_upper_(kb, M, kb) == 0) chol_solve_upper_(kb, M, kb, a + k_user);
-            else for (int_t i = 0; i < kb; i++) a[k_user + i] = NAN;
+            solve_sym_(kb, M, kb, a + k_user);
         }
     }
     free(bufs); free(BtB); free(BeTBe); free(CtC);
@@ -871,15 +917,19 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
     if (U != NULL) Uc = center_by_cols_dense(U, m_u, p, U_colmeans);              /* :9640ff preprocess_sideinfo_matrix */
     if (II != NULL) Ic = center_by_cols_dense(II, n_i, q, I_colmeans);
     if (w_main != (real_t)1.) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   /* :9786-9811 */
+    if (g_nn_AB) use_cg = false;                                                  /* :9513-9517 */
     if (!use_cg) finalize_chol = false;                                           /* :9518 */
     for (int_t iter = 0; iter < niter; iter++) {                                  /* :9827-10045 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
+        g_nonneg = g_nn_C;
         if (U != NULL)                                                            /* :9834-9873 */
             oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A, (size_t)k_totA, p, m_u, k_user + k,
                                         Uc, (size_t)p, true, lam / w_user, lam / w_user, false, nthreads);
+        g_nonneg = g_nn_D;
         if (II != NULL)                                                           /* :9877-9917 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B, (size_t)k_totB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, false, nthreads);
+        g_nonneg = g_nn_AB;
         if (II != NULL && use_cg)                                                 /* :9924-9963 */
             oracle_optimizeA_collective_cg(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m_x, q, k, k_main, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lam, w_item, lam, false, false, true,
@@ -903,6 +953,7 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
             oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n_x, k + k_main,
                                       csr_p, csr_i, csr_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
     }
+    g_nonneg = false;
     free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;
@@ -946,6 +997,7 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     if (n_i > n) n = n_i;
     if (init_biases && (user_bias != item_bias)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
+    if (g_nn_AB) use_cg = false;                                               /* :7474-7479 */
     if (!use_cg) finalize_chol = false;                                        /* :7481 */
     int_t has_bias = (user_bias || item_bias) ? 1 : 0;
     int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
@@ -987,12 +1039,15 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
 
     for (int_t iter = 0; iter < niter; iter++) {                               /* :8334-8898 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
+        g_nonneg = g_nn_C;
         if (U != NULL)                                                         /* :8358-8387 */
             oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A_bias, ldA, p, m_u, k_user + k,
                                         Uc, (size_t)p, true, lam / w_user, lam / w_user, scale_lam, nthreads);
+        g_nonneg = g_nn_D;
         if (II != NULL)                                                        /* :8409-8441 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B_bias, ldB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, scale_lam, nthreads);
+        g_nonneg = g_nn_AB;
         if (item_bias)                                                         /* :8538-8543 */
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
         if (user_bias)                                                         /* :8566-8570 */
@@ -1061,6 +1116,7 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     }
     if (user_bias) for (int_t r = m_x; r < m; r++) biasA[r] = 0;                /* :8296, :8923: no bias beyond X */
     if (item_bias) for (int_t c = n_x; c < n; c++) biasB[c] = 0;                /* :8308, :8925 */
+    g_nonneg = false;
     free(csr_orig); free(csc_orig); free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;
@@ -1140,8 +1196,7 @@ void oracle_factors_explicit_multiple(real_t *A, real_t *biasA, int_t m,
             /* factors_closed_form with scale_lam = scale_bias_const = scale_lam_sideinfo: lam * p on all but the last */
             for (int_t i = 0; i < k_totC; i++)
                 M[(size_t)i * k_totC + i] += (scale_lam_sideinfo && i < k_totC - 1) ? lam_cold * (real_t)p : lam_cold;
-            if (chol_upper_(k_totC, M, k_totC) == 0) chol_solve_upper_(k_totC, M, k_totC, sol);
-            else for (int_t i = 0; i < k_totC; i++) sol[i] = NAN;
+            solve_sym_(k_totC, M, k_totC, sol);
             memcpy(a, sol, (size_t)k_totC * sizeof(real_t));
             continue;
         }
@@ -1177,8 +1232,7 @@ void oracle_factors_explicit_multiple(real_t *A, real_t *biasA, int_t m,
             axpy_(kb, x[jx], Bp + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, sol + k_user);
         for (int_t i = 0; i < kt - 1; i++) M[(size_t)i * kt + i] += lam_w * mult;
         M[(size_t)(kt - 1) * kt + (kt - 1)] += (ub ? lam_bias_w : lam_w) * mult;
-        if (chol_upper_(kt, M, kt) == 0) chol_solve_upper_(kt, M, kt, sol);
-        else for (int_t i = 0; i < kt; i++) sol[i] = NAN;
+        solve_sym_(kt, M, kt, sol);
         memcpy(a, sol, (size_t)k_totA * sizeof(real_t));
         if (ub) biasA[ix] = sol[k_totA];
     }
@@ -1237,8 +1291,7 @@ void oracle_factors_implicit_multiple(real_t *A, int_t m,
                 axpy_(kb, x[jx] + (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, a + k_user);
             for (size_t jx = 0; jx < nnz; jx++)
                 syr_upper_(kb, x[jx], B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, M, kb);
-            if (chol_upper_(kb, M, kb) == 0) chol_solve_upper_(kb, M, kb, a + k_user);
-            else for (int_t i = 0; i < kb; i++) a[k_user + i] = NAN;
+            solve_sym_(kb, M, kb, a + k_user);
             continue;
         }
         /* collective_closed_form_block_implicit, few_NAs branch with a precomputed BtB (:1966-1990) */
@@ -1259,8 +1312,7 @@ void oracle_factors_implicit_multiple(real_t *A, int_t m,
         real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;
         for (size_t jx = 0; jx < nnz; jx++)
             syr_upper_(kb, x[jx], B + (size_t)k_item + (size_t)Xcsr_i[st + jx] * ldb, Mlr, k_totA);
-        if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
-        else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+        solve_sym_(k_totA, M, k_totA, a);
     }
     free(bufs); free(BtB); free(CtC);
 }
@@ -1325,8 +1377,7 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
             for (int_t i = 0; i < k_totA - 1; i++) M[(size_t)i * k_totA + i] += lam_i;
             M[(size_t)(k_totA - 1) * k_totA + (k_totA - 1)] += lam_last_i;
         }
-        if (chol_upper_(k_totA, M, k_totA) == 0) chol_solve_upper_(k_totA, M, k_totA, a);
-        else for (int_t i = 0; i < k_totA; i++) a[i] = NAN;
+        solve_sym_(k_totA, M, k_totA, a);
     }
     free(bufs); free(BtB);
 }
@@ -1397,13 +1448,17 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
             B_b[(size_t)c * ldB + k_totB] = item_bias ? biasB[c] : (real_t)1;
         }
     }
+    if (g_nn_AB) use_cg = false;                                               /* :7474-7479 */
     if (!use_cg) finalize_chol = false;
     for (int_t iter = 0; iter < niter; iter++) {
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;          /* :8336-8340, :9829-9830 */
+        g_nonneg = g_nn_C;
         if (p) oracle_optimizeA_explicit(C, (size_t)kcu, A_b, ldA, p, m_u, kcu, Uc_p, Uc_i, Uc_v, lam / w_user, lam / w_user,
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
+        g_nonneg = g_nn_D;
         if (q) oracle_optimizeA_explicit(D, (size_t)kci, B_b, ldB, q, n_i, kci, Ic_p, Ic_i, Ic_v, lam / w_item, lam / w_item,
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
+        g_nonneg = g_nn_AB;
         if (item_bias) for (int_t r = 0; r < m; r++) A_b[(size_t)r * ldA + k_totA] = 1;
         if (user_bias) for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
         if (q && use_cg)
@@ -1444,6 +1499,7 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
         for (int_t c = 0; c < n; c++) memcpy(B + (size_t)c * k_totB, B_b + (size_t)c * ldB, (size_t)k_totB * sizeof(real_t));
         free(A_b); free(B_b);
     }
+    g_nonneg = false;
     free(csr_orig); free(csc_orig);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     free(Ur_p); free(Uc_p); free(Ir_p); free(Ic_p); free(Ur_i); free(Uc_i); free(Ir_i); free(Ic_i);

@@ -205,6 +205,12 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
                                    real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads,
                                    bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol);
 
+/* Non-negativity option for everything above (process-wide, test infrastructure): the fits use solve_nonneg
+ * (common.c:2131-2179) for A / B (nonneg), C (nonneg_C), D (nonneg_D) and switch the CG off like the reference
+ * (collective.c:7474-7479); oracle_set_nonneg_now turns it on for operator-level calls outside a fit. */
+void oracle_set_nonneg(bool nonneg, bool nonneg_C, bool nonneg_D, int_t max_cd_steps);
+void oracle_set_nonneg_now(bool on, int_t max_cd_steps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,16 @@ def main():
                     out["g%d_%s" % (ci, key)] = v
         save("g12_sparse_sideinfo_" + tag, **out)
 
+        # ---- G13: non-negative factors ----
+        out = {}
+        d = gc.nonneg_problem(dt)
+        for ci, (name, implicit, side, opts) in enumerate(gc.NONNEG_CASES):
+            r = gc.nonneg_reference(R, d, implicit, side, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g13_nonneg_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

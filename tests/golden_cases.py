@@ -367,3 +367,83 @@ def compare_fits(got, exp):
     if "glob_mean" in exp and "glob_mean" in got:
         err = max(err, abs(float(got["glob_mean"]) - float(exp["glob_mean"])))
     return err
+
+
+# ---- non-negative factors (solve_nonneg instead of the Cholesky / CG solves) -----------------------------------------
+def nonneg_problem(dtype, seed=51):
+    rng = np.random.default_rng(seed)
+    m, n, k = 140, 100, 8
+    d = dict(m=m, n=n, k=k)
+    lin = rng.choice(m * n, size=2200, replace=False)
+    row = (lin // n).astype(np.int32); col = (lin % n).astype(np.int32)
+    keep = ~np.isin(row, (4, 120))
+    d["row"], d["col"] = row[keep], col[keep]
+    d["ratings"] = (0.5 * rng.integers(1, 11, keep.sum())).astype(dtype)
+    d["counts"] = np.ceil(rng.lognormal(1, 1, keep.sum())).astype(dtype)
+    d["A0"] = np.abs(rng.standard_normal((m, k)) * 0.1).astype(dtype); d["B0"] = np.abs(rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    d["bA"] = (rng.standard_normal(m) * 0.1).astype(dtype); d["bB"] = (rng.standard_normal(n) * 0.1).astype(dtype)
+    d["U"] = np.abs(rng.standard_normal((m, 5))).astype(dtype); d["I"] = np.abs(rng.standard_normal((n, 4))).astype(dtype)
+    return d
+
+
+# (name, implicit, side information, constructor / fit options)
+NONNEG_CASES = [
+    ("implicit", True, False, dict(nonneg=True, use_cg=True)),                       # the CG request is overridden
+    ("explicit biases", False, False, dict(nonneg=True, scale_lam=True)),
+    ("explicit side info, all constrained", False, True, dict(nonneg=True, nonneg_C=True, nonneg_D=True, user_bias=False,
+                                                             item_bias=False, center=False)),
+    ("implicit side info, C only", True, True, dict(nonneg_C=True, use_cg=False)),
+    ("explicit few sweeps", False, False, dict(nonneg=True, max_cd_steps=3, user_bias=False, item_bias=False, center=False)),
+]
+
+
+def nonneg_reference(R, d, implicit, side, opts, nthreads=2):
+    o = dict(opts)
+    A0, B0 = d["A0"].copy(), d["B0"].copy()
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    if implicit:
+        r = R.fit_collective_implicit_als(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, niter=3,
+                                          U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads,
+                                          use_cg=o.pop("use_cg", False), **o)
+        r = r if isinstance(r, dict) else dict(A=A0, B=B0, C=None, D=None)
+        return dict(A=A0, B=B0, C=r.get("C"), D=r.get("D"))
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads,
+                                      use_cg=o.pop("use_cg", False), finalize_chol=False, **o)
+    return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+
+
+def nonneg_oracle(O, d, implicit, side, opts, nthreads=2):
+    o = dict(opts)
+    O.set_nonneg(o.pop("nonneg", False), o.pop("nonneg_C", False), o.pop("nonneg_D", False), o.pop("max_cd_steps", 100))
+    try:
+        A0, B0 = d["A0"].copy(), d["B0"].copy()
+        U, II = (d["U"], d["I"]) if side else (None, None)
+        if implicit:
+            r = O.fit_implicit_als_sideinfo(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, niter=3, U=U, II=II,
+                                            w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=o.pop("use_cg", False), **o)
+            return dict(A=A0, B=B0, C=r.get("C"), D=r.get("D"))
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                               niter=3, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=o.pop("use_cg", False),
+                               finalize_chol=False, **o)
+        return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+    finally:
+        O.set_nonneg(False, False, False, 100)
+
+
+def nonneg_hip(d, implicit, side, opts, dtype):
+    from cmfrec_amd import CMF, CMF_implicit
+    o = dict(opts)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    common = dict(k=d["k"], niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False)
+    shape = (d["m"], d["n"])
+    if implicit:
+        mdl = CMF_implicit(lambda_=2.0, alpha=1.5, use_cg=o.pop("use_cg", False), **common, **o)
+        mdl.fit((d["row"], d["col"], d["counts"]), U=U, I=II, shape=shape, A0=d["A0"], B0=d["B0"])
+        return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_)
+    mdl = CMF(lambda_=0.3, use_cg=o.pop("use_cg", False), finalize_chol=False, **common, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=shape, A0=d["A0"], B0=d["B0"], biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out

@@ -179,3 +179,20 @@ def test_sparse_sideinfo(oracles, dtype):
         exp = {key[len("g%d_" % ci):]: g[key] for key in g.files if key.startswith("g%d_" % ci)}
         tol = 1e-8 if dtype is np.float64 else 1e-2           # three CG iterations (1e-6 / 1e-2 for fits)
         assert exp and gc.compare_fits(got, exp) < tol, name
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_nonneg(oracles, dtype):
+    """G13 through the estimators: the coordinate-descent phase of the row kernel (nonneg, nonneg_C / nonneg_D, sweep
+    limit) against the reference's outputs and against the oracle.  The descent branches on |step| > 1e-8, so a matrix
+    that differs in the last bits can take a different path: the tolerance is the fit tolerance."""
+    g = gc.load("g13_nonneg", dtype)
+    d = gc.nonneg_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, implicit, side, opts) in enumerate(gc.NONNEG_CASES):
+        got = gc.nonneg_hip(d, implicit, side, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.nonneg_oracle(oracles[dtype], d, implicit, side, opts)) < tol, name
+        if opts.get("nonneg"):
+            assert (got["A"] >= 0).all() and (got["B"] >= 0).all()

@@ -26,11 +26,12 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         CMF(method="lbfgs")
     with pytest.raises(NotImplementedError):
-        CMF(nonneg=True)
+        CMF(NA_as_zero=True)
     with pytest.raises(NotImplementedError):
         CMF_implicit(l1_lambda=0.1)
     with pytest.raises(NotImplementedError):
-        CMF_implicit(nonneg=True)
+        CMF(add_implicit_features=True)
+    assert CMF(nonneg=True, nonneg_C=True).nonneg_C and CMF_implicit(nonneg=True, max_cd_steps=50).max_cd_steps == 50
 
 
 def test_coo_input_handling():

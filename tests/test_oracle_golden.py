@@ -139,3 +139,14 @@ def test_sparse_sideinfo(oracles, dtype):
         got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls, solver=solver)
         exp = {key[len("g%d_" % ci):]: g[key] for key in g.files if key.startswith("g%d_" % ci)}
         assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name      # CG fits: the fit tolerance
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_nonneg(oracles, dtype):
+    """G13: non-negative fits, the reference's outputs."""
+    g = gc.load("g13_nonneg", dtype)
+    d = gc.nonneg_problem(dtype)
+    for ci, (name, implicit, side, opts) in enumerate(gc.NONNEG_CASES):
+        got = gc.nonneg_oracle(oracles[dtype], d, implicit, side, opts)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL[dtype], name

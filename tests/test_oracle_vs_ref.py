@@ -254,3 +254,18 @@ def test_fit_sparse_sideinfo_live(oracles, refs, dtype):
         exp = gc.sparse_sideinfo_reference(refs[dtype], d, implicit, which, sl, sls, nthreads=3, solver=solver)
         got = gc.sparse_sideinfo_oracle(oracles[dtype], d, implicit, which, sl, sls, nthreads=1, solver=solver)
         assert gc.compare_fits(got, exp) < tol, name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_nonneg_live(oracles, refs, dtype):
+    """Non-negative factors: solve_nonneg (common.c:2131-2179) in place of the Cholesky solves of A / B (nonneg) and
+    C / D (nonneg_C / nonneg_D), CG switched off (collective.c:7474-7479, :9513-9517); sweep limit honoured."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    d = gc.nonneg_problem(dtype, seed=53)
+    for name, implicit, side, opts in gc.NONNEG_CASES:
+        exp = gc.nonneg_reference(refs[dtype], d, implicit, side, opts, nthreads=3)
+        got = gc.nonneg_oracle(oracles[dtype], d, implicit, side, opts, nthreads=1)
+        assert gc.compare_fits(got, exp) < tol, name
+        if opts.get("nonneg"):
+            assert (exp["A"] >= 0).all() and (exp["B"] >= 0).all() and (exp["A"] == 0).mean() > 0.2
