@@ -66,6 +66,10 @@ struct CholParams {
     // Cholesky factorisation (solve_nonneg, common.c:2131-2179), at most max_cd_steps sweeps
     int nonneg = 0;
     int max_cd_steps = 100;
+    // L1 penalty (elastic net): l1 on every unknown, l1_last on the last one; scaled per row exactly like lam / lam_last.
+    // With nonneg it shifts the right-hand side of solve_nonneg, without it the system goes through solve_elasticnet
+    // (common.c:2228-2294: the same descent on a positive and a negative part, a = a+ - a-).
+    T l1 = 0, l1_last = 0;
     int rows_with_u;           // collective: rows < rows_with_u carry side information
     int p_side;                // collective: number of side-info columns (scale_lam_sideinfo)
     T lam, lam_last;
@@ -311,10 +315,11 @@ chol_rows_kernel(const CholParams<T> P)
             continue;
         }
         T lam = P.lam, lam_last = P.lam_last;
+        T l1 = P.l1, l1_last = P.l1_last;
         if (P.mode == CHOL_EXPLICIT) {
             if (P.scale_lam) {                                           // common.c:679-723
-                lam *= (T)nnz1;
-                if (!P.scale_bias_const) lam_last *= (T)nnz1;
+                lam *= (T)nnz1; l1 *= (T)nnz1;
+                if (!P.scale_bias_const) { lam_last *= (T)nnz1; l1_last *= (T)nnz1; }
             }
         } else if (P.mode == CHOL_COLLECTIVE) {
             if (P.scale_lam || P.scale_lam_sideinfo) {                   // collective.c:1285-1355
@@ -324,6 +329,7 @@ chol_rows_kernel(const CholParams<T> P)
                 // rows without side information are plain factors_closed_form rows when new rows are fitted
                 // (collective.c:3772-3815): there scale_bias_const keeps the bias' lambda (common.c:679-723)
                 if (has_u || !P.scale_bias_const) lam_last *= mult;
+                if (!P.scale_bias_const) { l1 *= mult; l1_last *= mult; }      // collective.c:1349-1354
             }
         }
         // ---- 1. rank-k update on the matrix cores: G[koff:, koff:] = sum_j w_j B_j B_j^T ----
@@ -444,7 +450,7 @@ chol_rows_kernel(const CholParams<T> P)
                 }
             }
         }
-        if (P.nonneg) {
+        if (P.nonneg || P.l1 != T(0) || P.l1_last != T(0)) {
             // ---- 3'. non-negative solution by cyclic coordinate descent (solve_nonneg, common.c:2131-2179):
             //   a = 0, g = rhs;  sweep ix = 0..kt-1:  new = max(a_ix + g_ix / M_ix,ix, 0);  if |new - a_ix| > 1e-8:
             //   g -= (new - a_ix) M[ix, :], a_ix = new;  stop after a sweep that moved less than 1e-8 in total.
@@ -467,11 +473,63 @@ chol_rows_kernel(const CholParams<T> P)
             }
             if (tid < kt) gn[tid] = racc;
             __syncthreads();
-            if (wave == 0) {
+            if (wave == 0 && !P.nonneg) {
+                // solve_elasticnet (common.c:2228-2294): g+ = rhs - l1, g- = -rhs - l1; per sweep the descent step on a+
+                // (g+ -= step M_ix, g- += step M_ix), then on a- (the other way round); a = a+ - a-
+                constexpr int NFN = (16 * NTT + 63) / 64;
+                T ap[NFN], am[NFN], gp[NFN], gm[NFN];
+#pragma unroll
+                for (int c = 0; c < NFN; c++) {
+                    const int f = lane + 64 * c;
+                    const T b = (f < kt) ? gn[f] : T(0);
+                    const T l = (f == kt - 1) ? l1_last : l1;
+                    ap[c] = T(0); am[c] = T(0);
+                    gp[c] = (f < kt) ? b - l : T(0);
+                    gm[c] = (f < kt) ? -b - l : T(0);
+                }
+                const int sweeps = (P.max_cd_steps > 0) ? P.max_cd_steps : 0x7fffffff;
+                for (int it = 0; it < sweeps; it++) {
+                    T moved = T(0);
+#pragma unroll 1
+                    for (int side = 0; side < 2; side++) {
+                        for (int ix = 0; ix < kt; ix++) {
+                            const int cq = ix >> 6, lq = ix & 63;
+                            T a_ix = T(0), g_ix = T(0);
+#pragma unroll
+                            for (int c = 0; c < NFN; c++)
+                                if (c == cq) {
+                                    a_ix = bcast_lane(side ? am[c] : ap[c], lq);
+                                    g_ix = bcast_lane(side ? gm[c] : gp[c], lq);
+                                }
+                            T nv = a_ix + g_ix / Mn[(size_t)ix * kt + ix];
+                            nv = (nv > T(0)) ? nv : T(0);
+                            const T dv = nv - a_ix;
+                            if (fabs(dv) > T(1e-8)) {
+                                moved += fabs(dv);
+#pragma unroll
+                                for (int c = 0; c < NFN; c++) {
+                                    const int f = lane + 64 * c;
+                                    const T stepv = (f < kt) ? dv * Mn[(size_t)ix * kt + f] : T(0);
+                                    if (side) { gp[c] += stepv; gm[c] -= stepv; }
+                                    else      { gm[c] += stepv; gp[c] -= stepv; }
+                                    if (c == cq && lane == lq) { if (side) am[c] = nv; else ap[c] = nv; }
+                                }
+                            }
+                        }
+                    }
+                    if (!(moved >= T(1e-8)) || isinf(moved)) break;
+                }
+#pragma unroll
+                for (int c = 0; c < NFN; c++) if (lane + 64 * c < kt) arow[lane + 64 * c] = ap[c] - am[c];
+            } else if (wave == 0) {
                 constexpr int NFN = (16 * NTT + 63) / 64;
                 T an[NFN], gg[NFN];
 #pragma unroll
-                for (int c = 0; c < NFN; c++) { an[c] = T(0); gg[c] = (lane + 64 * c < kt) ? gn[lane + 64 * c] : T(0); }
+                for (int c = 0; c < NFN; c++) {
+                    const int f = lane + 64 * c;
+                    an[c] = T(0);
+                    gg[c] = (f < kt) ? gn[f] - ((f == kt - 1) ? l1_last : l1) : T(0);          // common.c:2148-2154
+                }
                 const int sweeps = (P.max_cd_steps > 0) ? P.max_cd_steps : 0x7fffffff;
                 for (int it = 0; it < sweeps; it++) {
                     T moved = T(0);

@@ -133,16 +133,18 @@ int_t fit_collective_implicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (l1_lam != 0 || l1_lam_unique || lam_unique || adjust_weight)
-        return fail(verbose, "cmfrec_hip: L1 / lam_unique / adjust_weight are not implemented.");
-    if (nonneg) use_cg = false;                                           // collective.c:9513-9517
+    if (l1_lam_unique || lam_unique || adjust_weight)
+        return fail(verbose, "cmfrec_hip: l1_lam_unique / lam_unique / adjust_weight are not implemented.");
+    if (l1_lam != 0 && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
+        return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
+    if (nonneg || nonneg_C || nonneg_D || l1_lam != 0) use_cg = false;    // collective.c:9568-9571 (any of them, unlike the explicit model)
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
     if (w_main_multiplier) *w_main_multiplier = 1;
-    if (w_main != (real_t)1) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   // collective.c:9786-9811
+    if (w_main != (real_t)1) { lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; }   // collective.c:9786-9811
 
     PhaseTimer tm;
     tm.lap("validate");
@@ -200,6 +202,7 @@ int_t fit_collective_implicit_als(
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
+    if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, C, D);
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     if (tm.on) cmfrec_hip_session_sync(s);
@@ -263,9 +266,11 @@ int_t fit_collective_explicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (l1_lam != 0 || l1_lam_unique || lam_unique || scale_bias_const)
-        return fail(verbose, "cmfrec_hip: L1 / lam_unique / scale_bias_const are not implemented.");
-    if (nonneg) use_cg = false;                                           // collective.c:7474-7479
+    if (l1_lam_unique || lam_unique || scale_bias_const)
+        return fail(verbose, "cmfrec_hip: l1_lam_unique / lam_unique / scale_bias_const are not implemented.");
+    if (l1_lam != 0 && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
+        return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
+    if (nonneg || l1_lam != 0) use_cg = false;                            // collective.c:7474-7479
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
@@ -279,7 +284,7 @@ int_t fit_collective_explicit_als(
     SigGuard sig(true);
     scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
     if (!use_cg) finalize_chol = false;                                   // :7481
-    if (w_main != (real_t)1) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   // :7497-7521
+    if (w_main != (real_t)1) { lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; }   // :7497-7521
     const bool has_bias = user_bias || item_bias;
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
     const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);      // rows of A / B (collective.c:7332-7335)
@@ -346,6 +351,7 @@ int_t fit_collective_explicit_als(
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
+    if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("side info + factors upload");

@@ -67,11 +67,15 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr;
         P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2;
     }
+    const bool l1on = dev.l1_now != (real_t)0;
     const bool nonneg = c.nonneg || dev.nonneg_now;
-    P.nonneg = nonneg ? 1 : 0; P.max_cd_steps = dev.nonneg_now ? dev.max_cd_steps : c.max_cd_steps;
+    P.nonneg = nonneg ? 1 : 0; P.max_cd_steps = (dev.nonneg_now || l1on) ? dev.max_cd_steps : c.max_cd_steps;
+    // PREFILLED launches carry their lambda inside the prefilled matrix, scaled on the host (common.c:2832-2833): their L1
+    // penalty takes the same factor (solve_elasticnet_batch / solve_nonneg_batch calls, :2876-2902)
+    P.l1 = P.l1_last = (c.mode == CHOL_PREFILLED) ? dev.l1_now * dev.l1_scale : dev.l1_now;
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
-    const size_t smem_nonneg = nonneg ? ((size_t)c.kt * c.kt + 2 * (size_t)c.kt + 64) * sizeof(real_t) : 0;
+    const size_t smem_nonneg = (nonneg || l1on) ? ((size_t)c.kt * c.kt + 2 * (size_t)c.kt + 64) * sizeof(real_t) : 0;
     if (smem_nonneg > 160 * 1024) {
         g_last_error = "cmfrec_hip: nonneg: the k_t x k_t system must fit the 160 KB of LDS (k_t <= 140 in double, 199 in single precision)";
         return 2;
@@ -204,6 +208,7 @@ struct cmfrec_hip_session {
     // non-negativity constraints (solve_nonneg instead of the Cholesky solve; they switch the CG off for that matrix)
     bool nonneg = false, nonneg_C = false, nonneg_D = false;
     int max_cd_steps = 100;
+    real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
     std::vector<std::unique_ptr<SparseShard>> XrParts;
@@ -538,6 +543,13 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
 int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps)
 {
     s->nonneg = nonneg != 0; s->nonneg_C = nonneg_C != 0; s->nonneg_D = nonneg_D != 0;
+    s->max_cd_steps = max_cd_steps;
+    return 0;
+}
+
+int cmfrec_hip_session_set_l1(cmfrec_hip_session *s, real_t l1_lam, int max_cd_steps)
+{
+    s->l1_lam = l1_lam;
     s->max_cd_steps = max_cd_steps;
     return 0;
 }
@@ -948,12 +960,18 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
         const bool nn = (which == 'A' || which == 'B') ? s->nonneg : (which == 'C' ? s->nonneg_C : s->nonneg_D);
-        const bool chol = use_cholesky || !s->mdl.use_cg || nn;       // common.c:725, :2781, :3320: no CG with nonneg
-        struct NonnegScope {                                          // the closed-form launches of this update
+        const real_t l1 = (which == 'A' || which == 'B') ? s->l1_lam
+                          : (which == 'C' ? s->l1_lam / s->mdl.w_user : s->l1_lam / s->mdl.w_item);   // collective.c:8369-8423
+        const bool chol = use_cholesky || !s->mdl.use_cg || nn || l1 != 0;   // common.c:725, :2781, :3320: no CG with nonneg / L1
+        struct SolveScope {                                           // the closed-form launches of this update
             const DeviceInfo &d;
-            NonnegScope(const DeviceInfo &d_, bool on, int steps) : d(d_) { d.nonneg_now = on; d.max_cd_steps = steps; }
-            ~NonnegScope() { d.nonneg_now = false; }
-        } scope(s->dev, nn, s->max_cd_steps);
+            SolveScope(const DeviceInfo &d_, bool on, int steps, real_t l1_, real_t sc) : d(d_)
+            { d.nonneg_now = on; d.max_cd_steps = steps; d.l1_now = l1_; d.l1_scale = sc; }
+            ~SolveScope() { d.nonneg_now = false; d.l1_now = 0; d.l1_scale = 1; }
+        } scope(s->dev, nn, s->max_cd_steps, l1,
+                // the dense C / D update scales lambda -- and the penalty -- by the number of rows of U / I (common.c:2832, :2882)
+                ((which == 'C' || which == 'D') && (s->mdl.scale_lam || s->mdl.scale_lam_sideinfo))
+                    ? (real_t)(which == 'C' ? s->mdl.m_u : s->mdl.n_i) : (real_t)1);
         if (which == 'A' || which == 'B') {
             EventPair ev{s->new_event(), s->new_event()};
             HIP_CHECK(hipEventRecord(ev.a, s->dev.stream));

@@ -114,8 +114,9 @@ class CMF_implicit(_Base):
         self.verbose = bool(verbose); self.handle_interrupt = bool(handle_interrupt)
         self._setup(use_float, nthreads, n_jobs)
         self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D); self.max_cd_steps = int(max_cd_steps)
-        if l1_lambda:
-            raise NotImplementedError("l1_lambda is not implemented in cmfrec_amd")
+        if not np.isscalar(l1_lambda):
+            raise NotImplementedError("per-matrix l1_lambda is not implemented in cmfrec_amd")
+        self.l1_lambda = float(l1_lambda)
 
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
@@ -152,7 +153,7 @@ class CMF_implicit(_Base):
             _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), C.c_bool(reset), C.c_int(self.random_state),
             _lib.ptr(Ucm) if (p and self.center_U) else None, _lib.ptr(Icm) if (q and self.center_I) else None,
             C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
-            C.c_size_t(len(val)), R(self.lambda_), None, R(0.), None,
+            C.c_size_t(len(val)), R(self.lambda_), None, R(self.l1_lambda), None,
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
             C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
@@ -183,6 +184,8 @@ class CMF_implicit(_Base):
         factors_collective_implicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main]."""
         if X is None and U is None:
             raise ValueError("Must pass at least one of 'X', 'U'.")
+        if self.l1_lambda:
+            raise NotImplementedError("factors_multiple with l1_lambda is not implemented in cmfrec_amd")
         lib, R = self._lib()
         dt = self.dtype_
         n = self.B_.shape[0]
@@ -231,9 +234,12 @@ class CMF(_Base):
                  n_jobs=None):
         if method != "als":
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
-        if add_implicit_features or NA_as_zero or NA_as_zero_user or NA_as_zero_item or l1_lambda or scale_bias_const:
-            raise NotImplementedError("add_implicit_features / NA_as_zero / l1_lambda / scale_bias_const "
+        if add_implicit_features or NA_as_zero or NA_as_zero_user or NA_as_zero_item or scale_bias_const:
+            raise NotImplementedError("add_implicit_features / NA_as_zero / scale_bias_const "
                                       "are not implemented in cmfrec_amd")
+        if not np.isscalar(l1_lambda):
+            raise NotImplementedError("per-matrix l1_lambda is not implemented in cmfrec_amd")
+        self.l1_lambda = float(l1_lambda)
         self.nonneg = bool(nonneg); self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D)
         self.max_cd_steps = int(max_cd_steps)
         if not (center_U and center_I):
@@ -289,7 +295,7 @@ class CMF(_Base):
             C.c_bool(False), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean), _lib.ptr(Ucm),
             _lib.ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
             C.c_size_t(len(val)), None, None, C.c_bool(self.user_bias), C.c_bool(self.item_bias),
-            C.c_bool(self.center), R(self.lambda_), None, R(0.), None, C.c_bool(self.scale_lam),
+            C.c_bool(self.center), R(self.lambda_), None, R(self.l1_lambda), None, C.c_bool(self.scale_lam),
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(False), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
@@ -327,6 +333,8 @@ class CMF(_Base):
         factors_collective_explicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main], or ``(A, bias)``."""
         if X is None and U is None:
             raise ValueError("Must pass at least one of 'X', 'U'.")
+        if self.l1_lambda:
+            raise NotImplementedError("factors_multiple with l1_lambda is not implemented in cmfrec_amd")
         lib, R = self._lib()
         dt = self.dtype_
         n = self.B_.shape[0]

@@ -48,7 +48,7 @@ extern "C" {
  * no precompute.
  * or SPARSE side information as COO triplets (U_row / U_col / U_sp / nnz_U and the I_* twins; missing = absent, rows
  * within X's; collective.c:1849-2131 / :2905-3303 with u_vec_sp); nonneg / nonneg_C / nonneg_D with max_cd_steps
- * (solve_nonneg, common.c:2131-2179; k_t <= 140 / 199).  Anything else returns 2. */
+ * (solve_nonneg, common.c:2131-2179; k_t <= 140 / 199) and a scalar l1_lam (solve_elasticnet, :2228-2294).  Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
     real_t *C, real_t *D,
@@ -85,7 +85,7 @@ int_t fit_collective_implicit_als(
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
  * k_main/k_user/k_item, w_user/w_item; also SPARSE side information as COO triplets (missing = absent, rows within
  * X's; collective_closed_form_block / collective_block_cg with u_vec_sp, :1636-1653, :1719-1731, :2609-2621); nonneg /
- * nonneg_C / nonneg_D with max_cd_steps (solve_nonneg, common.c:2131-2179).  Anything else returns 2. */
+ * nonneg_C / nonneg_D with max_cd_steps (solve_nonneg, common.c:2131-2179) and a scalar l1_lam (solve_elasticnet).  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,
@@ -338,6 +338,10 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
  * at most max_cd_steps sweeps, 0 = until converged) and the CG is switched off for that matrix (common.c:725, :2781).
  * The k_t x k_t system lives in LDS: k_t <= 140 (double) / 199 (single). */
 int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps);
+/* L1 penalty (one value for every matrix: A, B and the bias columns take l1_lam, C / D l1_lam / w_user, / w_item;
+ * scaled per row like lambda).  Systems are then solved by solve_elasticnet (src/common.c:2228-2294), or by
+ * solve_nonneg with the penalty on the right-hand side where a non-negativity constraint applies; no CG. */
+int cmfrec_hip_session_set_l1(cmfrec_hip_session *s, real_t l1_lam, int max_cd_steps);
 /* SPARSE side information as COO triplets (which = 'U': [m_u, p], 'I': [n_i, q]; missing = absent, no centring):
  * CSR by row and CSC by attribute are built on the device.  Cholesky updates: the row's attributes are a second gather
  * source of the row kernel; CG / PCG: a second gathered term of the block CG (generic kernel).  m_u <= rows of X. */

@@ -79,6 +79,10 @@ class Oracle:
         """Non-negativity option of the following fits (solve_nonneg instead of the Cholesky solve; no CG)."""
         self.lib.oracle_set_nonneg(C.c_bool(nonneg), C.c_bool(nonneg_C), C.c_bool(nonneg_D), C.c_int(max_cd_steps))
 
+    def set_l1(self, l1_lam, max_cd_steps=100):
+        """L1 penalty of the following fits (solve_elasticnet / shifted solve_nonneg; no CG)."""
+        self.lib.oracle_set_l1(self._r(l1_lam), C.c_int(max_cd_steps))
+
     def set_nonneg_now(self, on, max_cd_steps=100):
         """The same for operator-level calls outside a fit."""
         self.lib.oracle_set_nonneg_now(C.c_bool(on), C.c_int(max_cd_steps))
@@ -649,7 +653,7 @@ class Reference:
                                     apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
                                     precompute=False, m=None, n=None, U_coo=None, I_coo=None, nonneg=False,
-                                    nonneg_C=False, nonneg_D=False, max_cd_steps=100):
+                                    nonneg_C=False, nonneg_D=False, max_cd_steps=100, l1_lam=0.0):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -671,7 +675,7 @@ class Reference:
         ret = self.lib.fit_collective_implicit_als(
             _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), C.c_bool(reset_values), C.c_int(seed), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
-            self._r(lam), None, self._r(0.), None,
+            self._r(lam), None, self._r(l1_lam), None,
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
@@ -692,7 +696,8 @@ class Reference:
                                     k_main=0, k_user=0, k_item=0, w_user=1.0, w_item=1.0, niter=10,
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
-                                    U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100):
+                                    U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
+                                    l1_lam=0.0):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -726,7 +731,7 @@ class Reference:
             _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             None, None, C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
-            self._r(lam), None, self._r(0.), None,
+            self._r(lam), None, self._r(l1_lam), None,
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],

@@ -125,6 +125,52 @@ static void solve_nonneg_(int_t k, real_t *M, int_t ld, real_t *b, long max_cd_s
     for (int_t i = 0; i < k; i++) b[i] = a_prev[i];
 }
 
+/* solve_elasticnet, common.c:2228-2294: the same descent on a positive and a negative part, a = a+ - a-. */
+static void solve_elasticnet_(int_t k, real_t *M, int_t ld, real_t *b, real_t l1, real_t l1_last, long max_cd_steps)
+{
+    for (int_t r = 1; r < k; r++)
+        for (int_t c = 0; c < r; c++) M[(size_t)r * ld + c] = M[(size_t)c * ld + r];
+    real_t bneg[1024], ap[1024], an[1024];
+    for (int_t i = 0; i < k; i++) { ap[i] = 0; an[i] = 0; bneg[i] = -b[i] - l1; }
+    for (int_t i = 0; i < k; i++) b[i] -= l1;
+    if (l1 != l1_last) { b[k - 1] -= (l1_last - l1); bneg[k - 1] -= (l1_last - l1); }
+    if (max_cd_steps <= 0) max_cd_steps = 0x7fffffff;
+    for (long iter = 0; iter < max_cd_steps; iter++) {
+        real_t diff_iter = 0;
+        for (int_t ix = 0; ix < k; ix++) {
+            real_t newval = ap[ix] + b[ix] / M[(size_t)ix * ld + ix];
+            newval = (newval >= 0) ? newval : 0;
+            const real_t d = newval - ap[ix];
+            if (fabs((double)d) > 1e-8) {
+                diff_iter += (real_t)fabs((double)d);
+                for (int_t f = 0; f < k; f++) bneg[f] += d * M[(size_t)ix * ld + f];
+                for (int_t f = 0; f < k; f++) b[f] -= d * M[(size_t)ix * ld + f];
+                ap[ix] = newval;
+            }
+        }
+        for (int_t ix = 0; ix < k; ix++) {
+            real_t newval = an[ix] + bneg[ix] / M[(size_t)ix * ld + ix];
+            newval = (newval >= 0) ? newval : 0;
+            const real_t d = newval - an[ix];
+            if (fabs((double)d) > 1e-8) {
+                diff_iter += (real_t)fabs((double)d);
+                for (int_t f = 0; f < k; f++) b[f] += d * M[(size_t)ix * ld + f];
+                for (int_t f = 0; f < k; f++) bneg[f] -= d * M[(size_t)ix * ld + f];
+                an[ix] = newval;
+            }
+        }
+        if (isnan(diff_iter) || !isfinite(diff_iter) || diff_iter < 1e-8) break;
+    }
+    for (int_t i = 0; i < k; i++) b[i] = ap[i] - an[i];
+}
+
+/* L1 penalty of the step in progress (g_l1: base value of the matrix being updated) times the row's lambda multiplier
+ * (t_l1_mult, set by the row loops where they scale lam): the reference scales both alike (common.c:716-722,
+ * collective.c:1349-1354) */
+static real_t g_l1 = 0, g_l1_base = 0;
+static __thread real_t t_l1_mult = 1;
+void oracle_set_l1(real_t l1_lam, int_t max_cd_steps);
+
 /* What the closed-form row functions end with: posv, or solve_nonneg when the option is on (common.c:1066-1090,
  * :2101-2126, collective.c:1822-1846, :2107-2131).  The option is process-wide test-infrastructure state. */
 static bool g_nonneg = false, g_nn_AB = false, g_nn_C = false, g_nn_D = false;
@@ -132,13 +178,21 @@ static long g_max_cd = 100;
 void oracle_set_nonneg(bool nonneg, bool nonneg_C, bool nonneg_D, int_t max_cd_steps)
 {
     g_nn_AB = nonneg; g_nn_C = nonneg_C; g_nn_D = nonneg_D; g_max_cd = max_cd_steps;
-    g_nonneg = false;
+    g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
 }
 /* for operator-level calls outside a fit */
 void oracle_set_nonneg_now(bool on, int_t max_cd_steps) { g_nonneg = on; g_max_cd = max_cd_steps; }
+void oracle_set_l1(real_t l1_lam, int_t max_cd_steps) { g_l1_base = l1_lam; g_l1 = 0; g_max_cd = max_cd_steps; }
+void oracle_set_l1_now(real_t l1, int_t max_cd_steps) { g_l1 = l1; g_max_cd = max_cd_steps; }
 static void solve_sym_(int_t k, real_t *M, int_t ld, real_t *b)
 {
-    if (g_nonneg) { solve_nonneg_(k, M, ld, b, g_max_cd); return; }
+    const real_t l1 = g_l1 * t_l1_mult;
+    if (g_nonneg) {
+        if (l1 != 0) for (int_t i = 0; i < k; i++) b[i] -= l1;                  /* common.c:2148-2154 */
+        solve_nonneg_(k, M, ld, b, g_max_cd);
+        return;
+    }
+    if (l1 != 0) { solve_elasticnet_(k, M, ld, b, l1, l1, g_max_cd); return; }
     if (chol_upper_(k, M, ld) == 0) { chol_solve_upper_(k, M, ld, b); return; }
     for (int_t i = 0; i < k; i++) b[i] = NAN;
 }
@@ -309,7 +363,8 @@ void oracle_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t ld
     size_t szbuf = use_cg ? (size_t)(precondition_cg ? 5 : 3) * k : (size_t)k * k;
     real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
     #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
-    for (int_t ix = 0; ix < m; ix++) {                                         /* :3349-3417 */
+    for (int_t ix = 0; ix < m; ix++) {
+        t_l1_mult = 1;                                                         /* no row scaling of lambda / l1 in the implicit model */                                         /* :3349-3417 */
         size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
         if (en <= st) continue;
         real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
@@ -449,9 +504,11 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
         if (en <= st) continue;          /* empty rows are left untouched (:3270) */
         size_t nnz = en - st;
         real_t lam_i = lam, lam_last_i = lam_last;
+        t_l1_mult = 1;
         if (scale_lam) {                                                       /* :679-723 */
             lam_i *= (real_t)nnz;
             if (!scale_bias_const) lam_last_i *= (real_t)nnz;
+            t_l1_mult = (real_t)nnz;
         }
         real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
         real_t *a = A + (size_t)ix * lda;
@@ -478,7 +535,8 @@ void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t 
     real_t dll = scale_lam ? lam_last * (real_t)n : lam_last;
     for (int_t i = 0; i < k - 1; i++) BtB[(size_t)i * k + i] += dl;
     BtB[(size_t)(k - 1) * k + (k - 1)] += dll;
-    const bool nonneg = g_nonneg;                                              /* solve_nonneg_batch, :2890-2902: the matrix is shared, not factored */
+    const real_t l1_rows = g_l1 * (scale_lam ? (real_t)n : (real_t)1);          /* :2882-2883, :2896-2897 */
+    const bool nonneg = g_nonneg || l1_rows != 0;                               /* solve_*_batch, :2876-2902: the matrix is shared, not factored */
     int bad = nonneg ? 0 : chol_upper_(k, BtB, k);
     #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int_t i = 0; i < m; i++) {
@@ -497,7 +555,10 @@ void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t 
         if (nonneg) {
             real_t *Mc = (real_t *)malloc((size_t)k * k * sizeof(real_t));
             memcpy(Mc, BtB, (size_t)k * k * sizeof(real_t));
-            solve_nonneg_(k, Mc, k, a, g_max_cd);
+            if (g_nonneg) {
+                if (l1_rows != 0) for (int_t c = 0; c < k; c++) a[c] -= l1_rows;
+                solve_nonneg_(k, Mc, k, a, g_max_cd);
+            } else solve_elasticnet_(k, Mc, k, a, l1_rows, l1_rows, g_max_cd);
             free(Mc);
         }
         else if (!bad) chol_solve_upper_(k, BtB, k, a);                        /* :2872 posv */
@@ -556,7 +617,8 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
             if (scale_lam_sideinfo && has_u) mult += (real_t)p;                /* :1338-1346 */
             lam_i *= mult;
             lam_last_i *= mult;
-        }
+            t_l1_mult = mult;
+        } else t_l1_mult = 1;
         real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
         memset(M, 0, szbuf * sizeof(real_t));                                  /* :1536 */
         if (has_u)                                                             /* :1566-1571 */
@@ -791,6 +853,7 @@ void oracle_optimizeA_collective_implicit_chol(real_t *A, size_t lda, const real
     real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
     #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
     for (int_t ix = 0; ix < m; ix++) {
+        t_l1_mult = 1;
         size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
         real_t *a = A + (size_t)ix * lda;
         real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
@@ -895,6 +958,7 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
                                      int_t niter, int nthreads,
                                      bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
 {
+    const real_t w_main_orig = w_main;
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     /* side information may cover more users / items than X: A, B have max(m, m_u) / max(n, n_i) rows
@@ -917,19 +981,20 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
     if (U != NULL) Uc = center_by_cols_dense(U, m_u, p, U_colmeans);              /* :9640ff preprocess_sideinfo_matrix */
     if (II != NULL) Ic = center_by_cols_dense(II, n_i, q, I_colmeans);
     if (w_main != (real_t)1.) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   /* :9786-9811 */
-    if (g_nn_AB) use_cg = false;                                                  /* :9513-9517 */
+    const real_t l1f = g_l1_base / ((w_main_orig != (real_t)1.) ? w_main_orig : (real_t)1.);   /* :9789 */
+    if (g_nn_AB || g_nn_C || g_nn_D || l1f != 0) use_cg = false;                  /* :9568-9571: any of them */
     if (!use_cg) finalize_chol = false;                                           /* :9518 */
     for (int_t iter = 0; iter < niter; iter++) {                                  /* :9827-10045 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
-        g_nonneg = g_nn_C;
+        g_nonneg = g_nn_C; g_l1 = l1f / w_user;
         if (U != NULL)                                                            /* :9834-9873 */
             oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A, (size_t)k_totA, p, m_u, k_user + k,
                                         Uc, (size_t)p, true, lam / w_user, lam / w_user, false, nthreads);
-        g_nonneg = g_nn_D;
+        g_nonneg = g_nn_D; g_l1 = l1f / w_item;
         if (II != NULL)                                                           /* :9877-9917 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B, (size_t)k_totB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, false, nthreads);
-        g_nonneg = g_nn_AB;
+        g_nonneg = g_nn_AB; g_l1 = l1f;
         if (II != NULL && use_cg)                                                 /* :9924-9963 */
             oracle_optimizeA_collective_cg(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m_x, q, k, k_main, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lam, w_item, lam, false, false, true,
@@ -953,7 +1018,7 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
             oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n_x, k + k_main,
                                       csr_p, csr_i, csr_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
     }
-    g_nonneg = false;
+    g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
     free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;
@@ -997,7 +1062,8 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     if (n_i > n) n = n_i;
     if (init_biases && (user_bias != item_bias)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
-    if (g_nn_AB) use_cg = false;                                               /* :7474-7479 */
+    const real_t l1f = g_l1_base;
+    if (g_nn_AB || l1f != 0) use_cg = false;                                   /* :7474-7479 */
     if (!use_cg) finalize_chol = false;                                        /* :7481 */
     int_t has_bias = (user_bias || item_bias) ? 1 : 0;
     int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
@@ -1039,15 +1105,15 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
 
     for (int_t iter = 0; iter < niter; iter++) {                               /* :8334-8898 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
-        g_nonneg = g_nn_C;
+        g_nonneg = g_nn_C; g_l1 = l1f / w_user;
         if (U != NULL)                                                         /* :8358-8387 */
             oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A_bias, ldA, p, m_u, k_user + k,
                                         Uc, (size_t)p, true, lam / w_user, lam / w_user, scale_lam, nthreads);
-        g_nonneg = g_nn_D;
+        g_nonneg = g_nn_D; g_l1 = l1f / w_item;
         if (II != NULL)                                                        /* :8409-8441 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B_bias, ldB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, scale_lam, nthreads);
-        g_nonneg = g_nn_AB;
+        g_nonneg = g_nn_AB; g_l1 = l1f;
         if (item_bias)                                                         /* :8538-8543 */
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
         if (user_bias)                                                         /* :8566-8570 */
@@ -1116,7 +1182,7 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     }
     if (user_bias) for (int_t r = m_x; r < m; r++) biasA[r] = 0;                /* :8296, :8923: no bias beyond X */
     if (item_bias) for (int_t c = n_x; c < n; c++) biasB[c] = 0;                /* :8308, :8925 */
-    g_nonneg = false;
+    g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
     free(csr_orig); free(csc_orig); free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;
@@ -1355,7 +1421,8 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
             real_t mult = nnz ? (real_t)nnz : (real_t)1;
             if (scale_lam_sideinfo) mult += (real_t)nnz_u;                     /* :1338-1346 */
             lam_i *= mult; lam_last_i *= mult;
-        }
+            t_l1_mult = mult;
+        } else t_l1_mult = 1;
         for (size_t jx = us; jx < ue; jx++)                                    /* :1636-1653 / :2003-2011 */
             syr_upper_(k_totC, w_user, C + (size_t)Ucsr_i[jx] * k_totC, M, k_totA);
         for (size_t jx = us; jx < ue; jx++)                                    /* :1719-1731 / :2013-2021 */
@@ -1404,6 +1471,7 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
     if (m_u > m || n_i > n || (k_user && !p) || (k_item && !q)) return 2;
     if (implicit) { user_bias = item_bias = center = false; scale_lam = scale_lam_sideinfo = false; }
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
+    const real_t l1f = g_l1_base / ((w_main != (real_t)1.) ? w_main : (real_t)1.);
     if (w_main != (real_t)1.) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   /* :7497-7521, :9786-9811 */
     const int_t has_bias = (user_bias || item_bias) ? 1 : 0;
     const int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main, kcu = k_user + k, kci = k_item + k;
@@ -1448,17 +1516,17 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
             B_b[(size_t)c * ldB + k_totB] = item_bias ? biasB[c] : (real_t)1;
         }
     }
-    if (g_nn_AB) use_cg = false;                                               /* :7474-7479 */
+    if (g_nn_AB || l1f != 0 || (implicit && (g_nn_C || g_nn_D))) use_cg = false;   /* :7474-7479, :9568-9571 */
     if (!use_cg) finalize_chol = false;
     for (int_t iter = 0; iter < niter; iter++) {
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;          /* :8336-8340, :9829-9830 */
-        g_nonneg = g_nn_C;
+        g_nonneg = g_nn_C; g_l1 = l1f / w_user;
         if (p) oracle_optimizeA_explicit(C, (size_t)kcu, A_b, ldA, p, m_u, kcu, Uc_p, Uc_i, Uc_v, lam / w_user, lam / w_user,
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
-        g_nonneg = g_nn_D;
+        g_nonneg = g_nn_D; g_l1 = l1f / w_item;
         if (q) oracle_optimizeA_explicit(D, (size_t)kci, B_b, ldB, q, n_i, kci, Ic_p, Ic_i, Ic_v, lam / w_item, lam / w_item,
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
-        g_nonneg = g_nn_AB;
+        g_nonneg = g_nn_AB; g_l1 = l1f;
         if (item_bias) for (int_t r = 0; r < m; r++) A_b[(size_t)r * ldA + k_totA] = 1;
         if (user_bias) for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
         if (q && use_cg)
@@ -1499,7 +1567,7 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
         for (int_t c = 0; c < n; c++) memcpy(B + (size_t)c * k_totB, B_b + (size_t)c * ldB, (size_t)k_totB * sizeof(real_t));
         free(A_b); free(B_b);
     }
-    g_nonneg = false;
+    g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
     free(csr_orig); free(csc_orig);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     free(Ur_p); free(Uc_p); free(Ir_p); free(Ic_p); free(Ur_i); free(Uc_i); free(Ir_i); free(Ic_i);

@@ -210,6 +210,10 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
  * (collective.c:7474-7479); oracle_set_nonneg_now turns it on for operator-level calls outside a fit. */
 void oracle_set_nonneg(bool nonneg, bool nonneg_C, bool nonneg_D, int_t max_cd_steps);
 void oracle_set_nonneg_now(bool on, int_t max_cd_steps);
+/* L1 penalty (scalar l1_lam) of the following fits / of operator-level calls: solve_elasticnet (common.c:2228-2294),
+ * or the shifted right-hand side of solve_nonneg; scaled per row like lambda; no CG. */
+void oracle_set_l1(real_t l1_lam, int_t max_cd_steps);
+void oracle_set_l1_now(real_t l1, int_t max_cd_steps);
 
 #ifdef __cplusplus
 }

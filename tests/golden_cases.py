@@ -392,8 +392,17 @@ NONNEG_CASES = [
     ("explicit biases", False, False, dict(nonneg=True, scale_lam=True)),
     ("explicit side info, all constrained", False, True, dict(nonneg=True, nonneg_C=True, nonneg_D=True, user_bias=False,
                                                              item_bias=False, center=False)),
-    ("implicit side info, C only", True, True, dict(nonneg_C=True, use_cg=False)),
+    ("implicit side info, C only", True, True, dict(nonneg_C=True, use_cg=True)),      # implicit: any constraint switches the CG off
     ("explicit few sweeps", False, False, dict(nonneg=True, max_cd_steps=3, user_bias=False, item_bias=False, center=False)),
+    # L1 penalty: solve_elasticnet (common.c:2228-2294), or solve_nonneg with the penalty on the right-hand side.
+    # (Not pinned: the implicit model WITHOUT side information and without nonneg -- factors_implicit_chol hands
+    #  solve_elasticnet a matrix whose lower triangle was never filled, common.c:2106-2115, fill_lower = false.)
+    ("explicit l1, biases, scale_lam", False, False, dict(l1_lam=0.02, scale_lam=True)),
+    ("explicit l1 + nonneg, side info", False, True, dict(l1_lam=0.05, nonneg=True, nonneg_C=True, user_bias=False, item_bias=False,
+                                                         center=False)),
+    ("implicit l1, side info", True, True, dict(l1_lam=0.3)),
+    ("explicit l1, side info, both scalings", False, True, dict(l1_lam=0.01, scale_lam=True, scale_lam_sideinfo=True)),
+    ("implicit l1 + nonneg", True, False, dict(l1_lam=0.2, nonneg=True)),
 ]
 
 
@@ -415,7 +424,8 @@ def nonneg_reference(R, d, implicit, side, opts, nthreads=2):
 
 def nonneg_oracle(O, d, implicit, side, opts, nthreads=2):
     o = dict(opts)
-    O.set_nonneg(o.pop("nonneg", False), o.pop("nonneg_C", False), o.pop("nonneg_D", False), o.pop("max_cd_steps", 100))
+    O.set_nonneg(o.pop("nonneg", False), o.pop("nonneg_C", False), o.pop("nonneg_D", False), o.get("max_cd_steps", 100))
+    O.set_l1(o.pop("l1_lam", 0.0), o.pop("max_cd_steps", 100))
     try:
         A0, B0 = d["A0"].copy(), d["B0"].copy()
         U, II = (d["U"], d["I"]) if side else (None, None)
@@ -429,11 +439,14 @@ def nonneg_oracle(O, d, implicit, side, opts, nthreads=2):
         return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
     finally:
         O.set_nonneg(False, False, False, 100)
+        O.set_l1(0.0, 100)
 
 
 def nonneg_hip(d, implicit, side, opts, dtype):
     from cmfrec_amd import CMF, CMF_implicit
     o = dict(opts)
+    if "l1_lam" in o:
+        o["l1_lambda"] = o.pop("l1_lam")
     U, II = (d["U"], d["I"]) if side else (None, None)
     common = dict(k=d["k"], niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False)
     shape = (d["m"], d["n"])

@@ -28,7 +28,8 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         CMF(NA_as_zero=True)
     with pytest.raises(NotImplementedError):
-        CMF_implicit(l1_lambda=0.1)
+        CMF_implicit(l1_lambda=np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6]))
+    assert CMF_implicit(l1_lambda=0.1).l1_lambda == 0.1
     with pytest.raises(NotImplementedError):
         CMF(add_implicit_features=True)
     assert CMF(nonneg=True, nonneg_C=True).nonneg_C and CMF_implicit(nonneg=True, max_cd_steps=50).max_cd_steps == 50
