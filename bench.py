@@ -392,8 +392,20 @@ def side_workload(args, device):
     dt = (time.perf_counter() - t0) / args.steps
     msA, cA = sess.kernel_time("A"); msB, cB = sess.kernel_time("B")
     f = sess.get_factors()
+    kt = k + 1
+    extra = {}
+    if chol:
+        # Gramians nnz*kt*(kt+1) + Cholesky kt^3/3 + 2 kt^2 per row, both half-steps (+ the small side-information GEMMs)
+        flops = 2 * nnz * kt * (kt + 1) + (m + n) * (kt ** 3 / 3 + 2 * kt * kt) + 3 * 2 * n * q * k
+        gath = 2 * (nnz * kt * 8 + nnz * 12)
+        extra = {"alg_TFLOP": round(flops / 1e12, 3), "TFLOPs": round(flops / dt / 1e12, 1),
+                 "frac_of_fp64_vector_peak_78.6": round(flops / dt / 78.6e12, 3),
+                 "gather_GB": round(gath / 1e9, 2), "gather_frac_of_hbm_peak": round(gath / dt / 8e12, 3)}
+    else:
+        alg = algorithmic_bytes(nnz, m, kt) + algorithmic_bytes(nnz, n, kt)
+        extra = {"alg_GB": round(alg / 1e9, 2), "frac_of_hbm_peak": round(alg / dt / 8e12, 3)}
     print(json.dumps({"workload": args.workload, "ms_per_iteration": round(dt * 1e3, 3), "rows_per_s": round((m + n) / dt, 1),
-                      "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "k": k, "m": m, "n": n, "nnz": nnz,
+                      "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "k": k, "m": m, "n": n, "nnz": nnz, **extra,
                       "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
                       "note": "side measurement, not the headline metric"}))
 
