@@ -326,6 +326,10 @@ int_t fit_collective_explicit_als(
     if (reset_values) {
         const bool fill_B = (II != nullptr || spI);
         cmfrng::random_parallel<real_t>(A, (size_t)m_max * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n_max * k_totB : 0, seed, true);
+        if (nonneg) {                                                     // :8256-8263: non-negative start values
+            for (size_t e = 0; e < (size_t)m_max * k_totA; e++) A[e] = std::fabs(A[e]);
+            if (fill_B) for (size_t e = 0; e < (size_t)n_max * k_totB; e++) B[e] = std::fabs(B[e]);
+        }
         if (use_cg) {
             if (!fill_B) memset(B, 0, (size_t)n_max * k_totB * sizeof(real_t));
             if (U || spU) memset(C, 0, (size_t)p * (k_user + k) * sizeof(real_t));

@@ -235,6 +235,25 @@ def test_seeded_fit_matches_reference_seed(dtype):
             assert frob(mdl.user_bias_, rr["biasA"]) < t
         if ib:
             assert frob(mdl.item_bias_, rr["biasB"]) < t
+    # non-negative factors: the seeded start values are made non-negative (collective.c:8256-8263) and the CG is off
+    mdl = CMF(k=k, lambda_=0.05, niter=2, random_state=11, use_float=uf, nthreads=1, nonneg=True, user_bias=False,
+              item_bias=False, center=False).fit((row, col, val), shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+    R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, niter=2, nthreads=2, reset_values=True, seed=11, nonneg=True,
+                                  user_bias=False, item_bias=False, center=False)
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and (mdl.A_ >= 0).all()
+    # sparse item side information with the CG solvers: B gets seeded values, D starts at zero (:8243-8273)
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    ir = rng.integers(0, n, 3000).astype(np.int32); ic = rng.integers(0, 12, 3000).astype(np.int32)
+    key = np.unique(ir.astype(np.int64) * 12 + ic); ir = (key // 12).astype(np.int32); ic = (key % 12).astype(np.int32)
+    iv = rng.standard_normal(len(ir)).astype(dtype)
+    mdl = CMF(k=k, lambda_=0.05, scale_lam=True, niter=3, random_state=13, use_float=uf, nthreads=1, w_item=2.0).fit(
+        (row, col, val), I=sp.coo_matrix((iv, (ir, ic)), shape=(n, 12)), shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+    rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, scale_lam=True, niter=3, nthreads=2, reset_values=True,
+                                       seed=13, w_item=2.0, I_coo=(ir, ic, iv, n, 12))
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and frob(mdl.D_, rr["D"]) < t
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
