@@ -38,7 +38,10 @@ enum CholMode { CHOL_EXPLICIT = 0, CHOL_IMPLICIT = 1, CHOL_COLLECTIVE = 2,
                                         + Minit[kc,kc] (w C^T C) for rows with side information,
                                       rhs = the prefilled w U C row + sum (x+1) B  (collective.c:1849-2131) */,
                 CHOL_PREFILLED = 3 /* M = Minit[kt,kt] (diag included), rhs = the row itself, no gather:
-                                      the multi-RHS posv of the C / D update, common.c:2872-2875 */ };
+                                      the multi-RHS posv of the C / D update, common.c:2872-2875 */,
+                CHOL_NAZ = 5 /* missing-as-zero, unweighted (optimizeA Case 3, common.c:3100-3205): every row shares
+                                M = Minit[kt,kt] (B^T B + diag), rhs = sum_j x_j B_j over the row's entries
+                                (tgemm_sp_dense); rows without entries are left to the caller (zero) */ };
 
 template <typename T>
 struct CholParams {
@@ -62,6 +65,13 @@ struct CholParams {
     size_t ldb2 = 0;
     int kc2 = 0;
     T w2 = 0;
+    // by default the second source lands on the unknowns [0, kc2) with rank-1 weight w2 (side information).  The
+    // implicit-features term of the explicit model (collective.c:1704-1707, :1757-1771) uses it differently: rows of Bi
+    // at the X block's offset, right-hand side only (w2_syr = 0: such chunks skip the matrix cores).
+    int koff2 = 0;
+    int w2_syr_zero = 0;
+    int rows_src2 = -1;                   // rows that have second-source entries (default: rows_with_u)
+    const T *values_override = nullptr;   // read the entries' values from here instead of `values` (all-ones indicator)
     // non-negative factors: the assembled system is solved by the reference's cyclic coordinate descent instead of the
     // Cholesky factorisation (solve_nonneg, common.c:2131-2179), at most max_cd_steps sweeps
     int nonneg = 0;
@@ -288,8 +298,8 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
     for (int j = 0; j < NCJ; j++) {
         const int c = lane + 64 * j;
-        const bool ok = two_src && (c < P.kc2);
-        scol2[j] = ok ? c : 0;
+        const bool ok = two_src && (c >= P.koff2) && (c < P.koff2 + P.kc2);
+        scol2[j] = ok ? c - P.koff2 : 0;
         svalid2 |= ok ? (1u << j) : 0u;
     }
 
@@ -302,13 +312,18 @@ chol_rows_kernel(const CholParams<T> P)
         if (rix >= P.nrows) break;
         const int row = (P.order != nullptr) ? P.order[rix] : rix;
         const size_t st = (P.mode == CHOL_PREFILLED) ? 0 : P.indptr[row];
+        // the right-hand-side-only variants (CHOL_NAZ, w2_syr_zero) live in the TWO_SRC build: the plain build keeps its
+        // straight-line chunk loop (a branch around the MFMAs cost the k = 128 double-precision step 16 %)
+        const T *xvals = (TWO_SRC && P.values_override != nullptr) ? P.values_override : P.values;
         const int nnz1 = (P.mode == CHOL_PREFILLED) ? 0 : (int)(P.indptr[row + 1] - st);
-        const size_t st2 = (two_src && row < P.rows_with_u) ? P.indptr2[row] : 0;
-        const int nnz2 = (two_src && row < P.rows_with_u) ? (int)(P.indptr2[row + 1] - st2) : 0;
+        const bool in2 = two_src && row < (P.rows_src2 >= 0 ? P.rows_src2 : P.rows_with_u);
+        const size_t st2 = in2 ? P.indptr2[row] : 0;
+        const int nnz2 = in2 ? (int)(P.indptr2[row + 1] - st2) : 0;
         const int nnz = nnz1 + nnz2;              // entries to gather; nnz1 of them are observations of X
         T *arow = P.A + (size_t)row * P.lda;
         const bool coll = (P.mode == CHOL_COLLECTIVE || P.mode == CHOL_COLLECTIVE_IMPLICIT);
         const bool impl_w = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_COLLECTIVE_IMPLICIT);
+        const bool naz = TWO_SRC && (P.mode == CHOL_NAZ);
         const bool has_u = (P.mode == CHOL_PREFILLED) || (coll && row < P.rows_with_u);
         if (coll && nnz == 0 && !has_u) {                               // collective.c:1258-1268, :1876-1885
             for (int e = tid; e < kt; e += NTH) arow[e] = T(0);
@@ -324,7 +339,7 @@ chol_rows_kernel(const CholParams<T> P)
         } else if (P.mode == CHOL_COLLECTIVE) {
             if (P.scale_lam || P.scale_lam_sideinfo) {                   // collective.c:1285-1355
                 T mult = (nnz1 > 0) ? (T)nnz1 : T(1);
-                if (P.scale_lam_sideinfo && has_u) mult += two_src ? (T)nnz2 : (T)P.p_side;   // :1338-1346
+                if (P.scale_lam_sideinfo && has_u) mult += (two_src && !P.w2_syr_zero) ? (T)nnz2 : (T)P.p_side;   // :1338-1346
                 lam *= mult;
                 // rows without side information are plain factors_closed_form rows when new rows are fitted
                 // (collective.c:3772-3815): there scale_bias_const keeps the bias' lambda (common.c:679-723)
@@ -362,7 +377,7 @@ chol_rows_kernel(const CholParams<T> P)
             const int e = c0 + min(tid, nr_idx - 1);
             wsrc2 = e >= nnz1;
             widx = wsrc2 ? 0 : P.indices[st + e];
-            wx = wsrc2 ? P.values2[st2 + (e - nnz1)] : P.values[st + e];
+            wx = wsrc2 ? P.values2[st2 + (e - nnz1)] : xvals[st + e];
         };
         auto load_rows = [&]() {
             nr_rows = nr_idx;
@@ -378,7 +393,8 @@ chol_rows_kernel(const CholParams<T> P)
             if (P.bias_sub != nullptr && !wsrc2) x -= P.bias_sub[widx];
             pre_wsyr = impl_w ? x : T(1);           // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
             pre_wrhs = impl_w ? x + T(1) : x;       // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
-            if (wsrc2) { pre_wsyr = P.w2; pre_wrhs = P.w2 * wx; }       // collective.c:1636-1653, :1719-1731 (sparse u_vec)
+            if (naz) pre_wsyr = T(0);               // the matrix is shared (common.c:3130-3140)
+            if (wsrc2) { pre_wsyr = P.w2_syr_zero ? T(0) : P.w2; pre_wrhs = P.w2 * wx; }   // collective.c:1636-1653, :1719-1731
         };
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
@@ -403,23 +419,27 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
                 for (int r = 0; r < CHOL_CHUNK; r++) racc += wrh[slot * CHOL_CHUNK + r] * Bs[r * ldc + tid];   // padded rows: weight 0, row 0
             }
+            // chunks whose rank-1 weights are all zero contribute to the right-hand side only
+            const bool skip_mma = TWO_SRC && (naz || (two_src && P.w2_syr_zero && c0 >= nnz1));
             // straight-line: operand reads of every slot, weights, MFMAs (idle slots run on tile 0 and are ignored)
+            if (!skip_mma) {
 #pragma unroll
-            for (int q = 0; q < CHOL_CHUNK / 4; q++) {
-                const int rr = 4 * q + (lane >> 4);
-                const T *brow = Bs + rr * ldc + lm;
-                const T w = wsc[slot * CHOL_CHUNK + rr];       // 1 in the explicit models
-                T opa[TPW], opb[TPW];
+                for (int q = 0; q < CHOL_CHUNK / 4; q++) {
+                    const int rr = 4 * q + (lane >> 4);
+                    const T *brow = Bs + rr * ldc + lm;
+                    const T w = wsc[slot * CHOL_CHUNK + rr];       // 1 in the explicit models
+                    T opa[TPW], opb[TPW];
 #pragma unroll
-                for (int tt = 0; tt < TPW; tt++) { opa[tt] = brow[offa[tt]]; opb[tt] = brow[offb[tt]]; }
+                    for (int tt = 0; tt < TPW; tt++) { opa[tt] = brow[offa[tt]]; opb[tt] = brow[offb[tt]]; }
 #pragma unroll
-                for (int tt = 0; tt < TPW; tt++) acc[tt] = Mf::mma(opa[tt] * w, opb[tt], acc[tt]);
-                __builtin_amdgcn_sched_barrier(0);       // one k-step of operands in registers at a time
+                    for (int tt = 0; tt < TPW; tt++) acc[tt] = Mf::mma(opa[tt] * w, opb[tt], acc[tt]);
+                    __builtin_amdgcn_sched_barrier(0);       // one k-step of operands in registers at a time
+                }
             }
         }
         // ---- 2. the initial matrix, in the accumulator layout (padding: identity) ----
         {
-            const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED);
+            const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED || P.mode == CHOL_NAZ);
             const T *M1 = full ? P.Minit : P.Mfull;                    // [kt, kt], every row
             const T *M2 = (!full && has_u) ? P.Minit : nullptr;        // [kc, kc], rows with side information
 #pragma unroll 1

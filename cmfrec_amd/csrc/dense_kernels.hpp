@@ -318,6 +318,17 @@ __global__ void betbe_base_kernel(const T *__restrict__ G, int kk, int ks, T lam
     }
 }
 
+// out[kt, kt] = 0 except the [kb, kb] block at (ks, ks), which takes G  (sum_mat of BiTBi into the X block of the row's
+// system, collective.c:1704-1707)
+template <typename T>
+__global__ void embed_block_kernel(const T *__restrict__ G, int kb, int ks, int kt, T *__restrict__ out)
+{
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kt * kt; e += gridDim.x * blockDim.x) {
+        const int i = e / kt - ks, j = e % kt - ks;
+        out[e] = (i >= 0 && j >= 0 && i < kb && j < kb) ? G[(size_t)i * kb + j] : T(0);
+    }
+}
+
 // U[r, c] -= colmeans[c]  (preprocess_vec on the rows of new side information, collective.c:6337-6349)
 template <typename T>
 __global__ void sub_colmeans_kernel(T *__restrict__ U, size_t rows, int p, const T *__restrict__ colmeans)

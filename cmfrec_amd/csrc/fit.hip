@@ -60,7 +60,7 @@ int fail(bool verbose, const char *msg)
     return 2;
 }
 
-int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose)
+int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose, bool implicit_feats = false)
 {
     for (int it = 0; it < niter; it++) {
         if (g_stop) return 3;
@@ -72,6 +72,14 @@ int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool
         if (mdl.q > 0) { if (verbose) { printf("Updating D..."); fflush(stdout); }
             if ((rc = cmfrec_hip_session_update(s, 'D', chol))) return rc; if (verbose) printf(" done\n"); }
         if (g_stop) return 3;
+        if (implicit_feats) {                                             // collective.c:8448-8534
+            if (verbose) { printf("Updating Bi..."); fflush(stdout); }
+            if ((rc = cmfrec_hip_session_update(s, 'b', 1))) return rc;
+            if (verbose) { printf(" done\nUpdating Ai..."); fflush(stdout); }
+            if ((rc = cmfrec_hip_session_update(s, 'a', 1))) return rc;
+            if (verbose) printf(" done\n");
+            if (g_stop) return 3;
+        }
         if (verbose) { printf("Updating B..."); fflush(stdout); }
         if ((rc = cmfrec_hip_session_update(s, 'B', chol))) return rc;
         if ((rc = cmfrec_hip_session_after_gather(s, 'B'))) return rc;
@@ -247,17 +255,34 @@ int_t fit_collective_explicit_als(
     real_t *precomputedBtXbias, real_t *precomputedBeTBeChol, real_t *precomputedBiTBi,
     real_t *precomputedTransCtCinvCt, real_t *precomputedCtCw, real_t *precomputedCtUbias)
 {
-    (void)Ai; (void)Bi; (void)scaling_biasA; (void)scaling_biasB;
-    (void)w_implicit; (void)handle_interrupt; (void)max_cd_steps;
+    (void)scaling_biasA; (void)scaling_biasB;
+    (void)handle_interrupt; (void)max_cd_steps;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
-    (void)precomputedBiTBi;        // only with add_implicit_features, not supported
+    (void)precomputedBiTBi;        // with add_implicit_features the prediction matrices are not produced here
     (void)precomputedCtUbias;      // only with sparse U + NA_as_zero_U, not supported
     // collective.c:7308-7329
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (Xfull || weight || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I || add_implicit_features)
-        return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero / implicit features are not implemented.");
+    if (Xfull || weight || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I)
+        return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero are not implemented.");
+    // implicit features (Ai, Bi on the binary "was observed" matrix): closed-form solves, dense or no side information
+    // inside the shape of X, prediction matrices not produced
+    if (add_implicit_features) {
+        if (!Ai || !Bi) return fail(verbose, "cmfrec_hip: add_implicit_features needs the Ai and Bi outputs.");
+        if (nnz_U || nnz_I) return fail(verbose, "cmfrec_hip: implicit features with sparse side information are not implemented.");
+        if ((U && m_u > m) || (II && n_i > n))
+            return fail(verbose, "cmfrec_hip: implicit features with side information beyond X are not implemented.");
+        if (precompute_for_predictions)
+            return fail(verbose, "cmfrec_hip: implicit features: precompute_for_predictions is not implemented.");
+        // the reference itself crashes on add_implicit_features with nonneg or an L1 penalty (its Ai / Bi updates are handed
+        // a NULL thread-local buffer, collective.c:8487-8489): nothing to pin against, so not offered
+        if (nonneg || l1_lam != 0)
+            return fail(verbose, "cmfrec_hip: implicit features with nonneg / L1 are not implemented.");
+        if (use_cg)
+            return fail(verbose, "cmfrec_hip: implicit features: the conjugate-gradient solver is not implemented (use_cg = false).");
+        if (!(w_implicit > 0)) return fail(verbose, "cmfrec_hip: w_implicit must be positive.");
+    }
     // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.
     const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
     if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
@@ -284,7 +309,7 @@ int_t fit_collective_explicit_als(
     SigGuard sig(true);
     scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
     if (!use_cg) finalize_chol = false;                                   // :7481
-    if (w_main != (real_t)1) { lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; }   // :7497-7521
+    if (w_main != (real_t)1) { lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; w_implicit /= w_main; }   // :7497-7521
     const bool has_bias = user_bias || item_bias;
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
     const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);      // rows of A / B (collective.c:7332-7335)
@@ -324,7 +349,7 @@ int_t fit_collective_explicit_als(
     tm.lap("side info centring");
     // ---- factor start values, collective.c:8241-8274 ----
     if (reset_values) {
-        const bool fill_B = (II != nullptr || spI);
+        const bool fill_B = (II != nullptr || spI || add_implicit_features);
         cmfrng::random_parallel<real_t>(A, (size_t)m_max * k_totA, fill_B ? B : nullptr, fill_B ? (size_t)n_max * k_totB : 0, seed, true);
         if (nonneg) {                                                     // :8256-8263: non-negative start values
             for (size_t e = 0; e < (size_t)m_max * k_totA; e++) A[e] = std::fabs(A[e]);
@@ -357,6 +382,8 @@ int_t fit_collective_explicit_als(
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
+    // Ai / Bi need no start values: their first update is a closed-form solve (collective.c:8236-8240)
+    if (!rc && add_implicit_features) rc = cmfrec_hip_session_set_implicit_features(s, w_implicit, nullptr, nullptr);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("side info + factors upload");
     if (!rc && has_bias && reset_values) {                                // common.c:4410-4909; lambdas clipped like :4449-4452
@@ -368,11 +395,12 @@ int_t fit_collective_explicit_als(
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("bias init");
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
-    int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose);
+    int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose, add_implicit_features);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("ALS iterations");
     if (rc_loop == 0 || rc_loop == 3) {
         int rc2 = cmfrec_hip_session_get_factors(s, A, B, biasA, biasB, C, D);
+        if (!rc2 && add_implicit_features) rc2 = cmfrec_hip_session_get_implicit_features(s, Ai, Bi);
         if (rc2) rc_loop = rc2;
     }
     if (rc_loop == 0 || rc_loop == 3) {                                   // no bias beyond the shape of X (collective.c:8296, :8923-8925)

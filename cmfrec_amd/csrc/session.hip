@@ -46,6 +46,12 @@ struct CholCall {
     // non-negative factors: coordinate descent on the assembled system instead of the Cholesky solve
     bool nonneg = false;
     int max_cd_steps = 100;
+    // second source placed at unknown koff2 and used for the right-hand side only (implicit-features term)
+    int koff2 = 0;
+    bool w2_syr_zero = false;
+    int rows2 = -1;
+    const real_t *values2 = nullptr;         // values of the second source (default: X2's own)
+    const real_t *values_override = nullptr; // values of the first source (default: X's own)
 };
 
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
@@ -64,15 +70,16 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
     P.mode = c.mode;
     if (c.X2) {
-        P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr;
-        P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2;
+        P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.values2 ? c.values2 : c.X2->v.ptr;
+        P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2; P.koff2 = c.koff2; P.w2_syr_zero = c.w2_syr_zero ? 1 : 0; P.rows_src2 = c.rows2;
     }
+    P.values_override = c.values_override;
     const bool l1on = dev.l1_now != (real_t)0;
     const bool nonneg = c.nonneg || dev.nonneg_now;
     P.nonneg = nonneg ? 1 : 0; P.max_cd_steps = (dev.nonneg_now || l1on) ? dev.max_cd_steps : c.max_cd_steps;
     // PREFILLED launches carry their lambda inside the prefilled matrix, scaled on the host (common.c:2832-2833): their L1
     // penalty takes the same factor (solve_elasticnet_batch / solve_nonneg_batch calls, :2876-2902)
-    P.l1 = P.l1_last = (c.mode == CHOL_PREFILLED) ? dev.l1_now * dev.l1_scale : dev.l1_now;
+    P.l1 = P.l1_last = (c.mode == CHOL_PREFILLED || c.mode == CHOL_NAZ) ? dev.l1_now * dev.l1_scale : dev.l1_now;
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
     const size_t smem_nonneg = (nonneg || l1on) ? ((size_t)c.kt * c.kt + 2 * (size_t)c.kt + 64) * sizeof(real_t) : 0;
@@ -89,7 +96,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 2 * sizeof(int), dev.stream));
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
-    const bool two_src = c.X2 != nullptr;
+    const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ;      // CHOL_NAZ is part of that build only
     // the two-source build (sparse side information) only where it is asked for
 #define CHOL_KERN(a, b, c_, d) (two_src ? chol_rows_kernel<real_t, a, b, c_, d, true> : chol_rows_kernel<real_t, a, b, c_, d, false>)
     hipStream_t run_on = dev.stream;
@@ -208,6 +215,11 @@ struct cmfrec_hip_session {
     // non-negativity constraints (solve_nonneg instead of the Cholesky solve; they switch the CG off for that matrix)
     bool nonneg = false, nonneg_C = false, nonneg_D = false;
     int max_cd_steps = 100;
+    // implicit features of the explicit model (add_implicit_features): Ai [m, k+k_main], Bi [n, k+k_main] factorise the
+    // binary "was observed" matrix alongside X (collective.c:8448-8534); Cholesky-type solves only
+    bool implicit_feats = false;
+    real_t w_implicit = 1;
+    DevBuf<real_t> Ai, Bi, bitbi, bitbi_full, ones;
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
@@ -547,6 +559,62 @@ int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_
     return 0;
 }
 
+int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_implicit, const real_t *Ai, const real_t *Bi)
+{
+    return guarded([&]() {
+        const cmfrec_hip_model &m = s->mdl;
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        if (m.implicit) { g_last_error = "cmfrec_hip: add_implicit_features belongs to the explicit-feedback model"; return 2; }
+        if (m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n || !s->XrParts.empty()) {
+            g_last_error = "cmfrec_hip: add_implicit_features: sharded sessions are not built";
+            return 2;
+        }
+        if (s->sparseU || s->sparseI) {
+            g_last_error = "cmfrec_hip: add_implicit_features together with sparse side information is not built";
+            return 2;
+        }
+        if ((m.m_x > 0 && m.m_x < m.m) || (m.n_x > 0 && m.n_x < m.n)) {
+            g_last_error = "cmfrec_hip: add_implicit_features: side information must not cover rows / columns beyond X";
+            return 2;
+        }
+        if (s->Xr.p.ptr == nullptr || s->Xc.p.ptr == nullptr) {
+            g_last_error = "cmfrec_hip: add_implicit_features: set X first";
+            return 2;
+        }
+        if (!(w_implicit > 0)) { g_last_error = "cmfrec_hip: w_implicit must be positive"; return 2; }
+        const int kk = m.k + m.k_main;
+        const int ktmax = std::max(s->k_totA, s->k_totB) + 1;
+        s->Ai.alloc((size_t)m.m * kk); s->Bi.alloc((size_t)m.n * kk);
+        s->bitbi.alloc((size_t)kk * kk); s->bitbi_full.alloc((size_t)ktmax * ktmax);
+        const size_t nnz = s->Xr.nnz;
+        s->ones.alloc(std::max<size_t>(nnz, 1));
+        std::vector<real_t> one(std::max<size_t>(nnz, 1), (real_t)1);
+        HIP_CHECK(hipMemcpyAsync(s->ones.ptr, one.data(), one.size() * sizeof(real_t), hipMemcpyHostToDevice, s->dev.stream));
+        if (Ai) HIP_CHECK(hipMemcpyAsync(s->Ai.ptr, Ai, (size_t)m.m * kk * sizeof(real_t), hipMemcpyHostToDevice, s->dev.stream));
+        else HIP_CHECK(hipMemsetAsync(s->Ai.ptr, 0, (size_t)m.m * kk * sizeof(real_t), s->dev.stream));
+        if (Bi) HIP_CHECK(hipMemcpyAsync(s->Bi.ptr, Bi, (size_t)m.n * kk * sizeof(real_t), hipMemcpyHostToDevice, s->dev.stream));
+        else HIP_CHECK(hipMemsetAsync(s->Bi.ptr, 0, (size_t)m.n * kk * sizeof(real_t), s->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        s->w_implicit = w_implicit;
+        s->implicit_feats = true;
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, real_t *Bi)
+{
+    return guarded([&]() {
+        const cmfrec_hip_model &m = s->mdl;
+        if (!s->implicit_feats) { g_last_error = "cmfrec_hip: the session has no implicit features"; return 2; }
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const int kk = m.k + m.k_main;
+        if (Ai) HIP_CHECK(hipMemcpyAsync(Ai, s->Ai.ptr, (size_t)m.m * kk * sizeof(real_t), hipMemcpyDeviceToHost, s->dev.stream));
+        if (Bi) HIP_CHECK(hipMemcpyAsync(Bi, s->Bi.ptr, (size_t)m.n * kk * sizeof(real_t), hipMemcpyDeviceToHost, s->dev.stream));
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
 int cmfrec_hip_session_set_l1(cmfrec_hip_session *s, real_t l1_lam, int max_cd_steps)
 {
     s->l1_lam = l1_lam;
@@ -633,6 +701,10 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const int kk = m.k + m.k_main;
     const int rows_x_self = isA ? (m.m_x > 0 ? m.m_x : m.m) : (m.n_x > 0 ? m.n_x : m.n);          // rows of this matrix X has
 
+    if (s->implicit_feats && !chol) {
+        g_last_error = "cmfrec_hip: add_implicit_features: the conjugate-gradient solver is not built (use_cg = false)";
+        return 2;
+    }
     const bool sparse_side = isA ? s->sparseU : s->sparseI;
     if (p_self > 0 && sparse_side) {
         // sparse side information (missing = absent): the row's attributes are a second gather source of the same
@@ -772,6 +844,24 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const real_t *bias_sub = nullptr;
     if (opp_bias) bias_sub = isA ? s->biasB.ptr : s->biasA.ptr;             // fused "X - bias" (:8566-8570, :8750-8754)
     const int ksolve = kk + (self_bias ? 1 : 0);
+    // implicit features: w_i Bi^T Bi joins the X block of every row's matrix (collective.c:1704-1707) and
+    // w_i sum_{j observed} Bi_j its right-hand side (:1757-1771).  The second gather source of the Cholesky launch reads
+    // the same sparsity pattern with unit values from Bi, right-hand side only.
+    const real_t *Fi = nullptr;
+    if (s->implicit_feats) {
+        Fi = isA ? s->Bi.ptr : s->Ai.ptr;
+        const int kt_i = k_side_self + ksolve;
+        launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, s->w_implicit, (real_t)0);
+        hipLaunchKernelGGL(embed_block_kernel<real_t>, grid1d(kt_i * kt_i), dim3(256), 0, st, s->bitbi.ptr, kk, k_side_self,
+                           kt_i, s->bitbi_full.ptr);
+        HIP_CHECK(hipGetLastError());
+    }
+    auto add_implicit_term = [&](CholCall &c) {
+        if (Fi == nullptr) return;
+        c.Mfull = s->bitbi_full.ptr;
+        c.X2 = &X; c.values2 = s->ones.ptr; c.B2 = Fi; c.ldb2 = (size_t)kk; c.kc2 = kk; c.koff2 = k_side_self;
+        c.w2 = s->w_implicit; c.w2_syr_zero = true; c.rows2 = X.nrows;
+    };
     if (p_self > 0) {
         // optimizeA_collective general branch, Cholesky (collective.c:5566-5968)
         const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
@@ -789,11 +879,20 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, s->ctc.ptr, kc, local_u_main,
                    p_self, m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false,
                    CHOL_COLLECTIVE};
+        add_implicit_term(c);
         int rc = launch_chol(dev, c, &X);
         if (rc) return rc;
         return solve_sideinfo_only_rows(s, isA, true, local_u_main, local_u - local_u_main);
     }
     const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;                                     // :7465
+    if (Fi != nullptr) {
+        // without side information on this side the reference still takes optimizeA_collective (collective.c:8612, :8783)
+        if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822
+        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, ksolve, 0, bias_sub, nullptr, 0, 0, 0,
+                   m.lam, m.lam, scale_lam, false, false, CHOL_COLLECTIVE};
+        add_implicit_term(c);
+        return launch_chol(dev, c, &X);
+    }
     if (chol) {
         CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, 0, bias_sub, nullptr, 0, 0, 0,
                    m.lam, m.lam, scale_lam, false, false, CHOL_EXPLICIT};
@@ -802,6 +901,27 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, bias_sub, nullptr,
              m.lam, m.lam, scale_lam, false, m.max_cg_steps, false, (bool)m.precondition_cg};
     return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
+}
+
+// Ai / Bi update: optimizeA Case 3 on the binary indicator of X (collective.c:8448-8534; common.c:3116-3205): one
+// shared matrix F^T F + lam/w_i (x rows of F under scale_lam), right-hand sides sum_{j observed} F_j
+static int update_implicit_feats(cmfrec_hip_session *s, bool isAi)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    const int kk = m.k + m.k_main;
+    real_t *self = isAi ? s->Ai.ptr : s->Bi.ptr;
+    const real_t *F = isAi ? s->B.ptr + m.k_item : s->A.ptr + m.k_user;      // B_bias + k_item / A_bias + k_user
+    const size_t ldf = isAi ? s->ldB : s->ldA;
+    const int rows_f = isAi ? m.n : m.m, rows_self = isAi ? m.m : m.n;
+    const SparseShard &X = isAi ? s->Xr : s->Xc;
+    const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
+    const real_t lam = (m.lam / s->w_implicit) * (scale_lam ? (real_t)rows_f : (real_t)1);
+    launch_gram(dev, s->gws, F, ldf, rows_f, kk, s->gram.ptr, (real_t)1, lam);
+    HIP_CHECK(hipMemsetAsync(self, 0, (size_t)rows_self * kk * sizeof(real_t), dev.stream));
+    CholCall c{self, (size_t)kk, F, ldf, kk, 0, nullptr, s->gram.ptr, 0, 0, 0, lam, lam, false, false, false, CHOL_NAZ};
+    c.values_override = s->ones.ptr;
+    return launch_chol(dev, c, &X);
 }
 
 // C / D update: optimizeA Case 1 with do_B (common.c:2793-2991; Q6: always the transposed gemm)
@@ -959,8 +1079,9 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
-        const bool nn = (which == 'A' || which == 'B') ? s->nonneg : (which == 'C' ? s->nonneg_C : s->nonneg_D);
-        const real_t l1 = (which == 'A' || which == 'B') ? s->l1_lam
+        const bool isAB = (which == 'A' || which == 'B'), isImp = (which == 'a' || which == 'b');
+        const bool nn = (isAB || isImp) ? s->nonneg : (which == 'C' ? s->nonneg_C : s->nonneg_D);
+        const real_t l1 = isAB ? s->l1_lam : isImp ? s->l1_lam / s->w_implicit                          // collective.c:8472-8475
                           : (which == 'C' ? s->l1_lam / s->mdl.w_user : s->l1_lam / s->mdl.w_item);   // collective.c:8369-8423
         const bool chol = use_cholesky || !s->mdl.use_cg || nn || l1 != 0;   // common.c:725, :2781, :3320: no CG with nonneg / L1
         struct SolveScope {                                           // the closed-form launches of this update
@@ -970,8 +1091,10 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
             ~SolveScope() { d.nonneg_now = false; d.l1_now = 0; d.l1_scale = 1; }
         } scope(s->dev, nn, s->max_cd_steps, l1,
                 // the dense C / D update scales lambda -- and the penalty -- by the number of rows of U / I (common.c:2832, :2882)
-                ((which == 'C' || which == 'D') && (s->mdl.scale_lam || s->mdl.scale_lam_sideinfo))
-                    ? (real_t)(which == 'C' ? s->mdl.m_u : s->mdl.n_i) : (real_t)1);
+                // the Ai / Bi update (Case 3) by the rows of the fixed matrix (common.c:3131, :3182)
+                ((which == 'C' || which == 'D' || isImp) && (s->mdl.scale_lam || s->mdl.scale_lam_sideinfo))
+                    ? (real_t)(which == 'C' ? s->mdl.m_u : which == 'D' ? s->mdl.n_i : which == 'a' ? s->mdl.n : s->mdl.m)
+                    : (real_t)1);
         if (which == 'A' || which == 'B') {
             EventPair ev{s->new_event(), s->new_event()};
             HIP_CHECK(hipEventRecord(ev.a, s->dev.stream));
@@ -989,6 +1112,7 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
             return rc;
         }
         if (which == 'C' || which == 'D') return update_sideinfo(s, which == 'C', chol);
+        if ((which == 'a' || which == 'b') && s->implicit_feats) return update_implicit_feats(s, which == 'a');
         g_last_error = "cmfrec_hip: unknown update target";
         return 2;
     });
@@ -1007,6 +1131,10 @@ int cmfrec_hip_session_iterate(cmfrec_hip_session *s, int niter, int finalize_ch
         int rc;
         if (m.p > 0 && (rc = cmfrec_hip_session_update(s, 'C', chol))) return rc;
         if (m.q > 0 && (rc = cmfrec_hip_session_update(s, 'D', chol))) return rc;
+        if (s->implicit_feats) {                                              // collective.c:8448-8534: Bi, then Ai
+            if ((rc = cmfrec_hip_session_update(s, 'b', 1))) return rc;
+            if ((rc = cmfrec_hip_session_update(s, 'a', 1))) return rc;
+        }
         if ((rc = cmfrec_hip_session_update(s, 'B', chol))) return rc;
         if ((rc = cmfrec_hip_session_after_gather(s, 'B'))) return rc;
         if ((rc = cmfrec_hip_session_update(s, 'A', chol))) return rc;

@@ -338,6 +338,15 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
  * at most max_cd_steps sweeps, 0 = until converged) and the CG is switched off for that matrix (common.c:725, :2781).
  * The k_t x k_t system lives in LDS: k_t <= 140 (double) / 199 (single). */
 int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps);
+/* Implicit features of the explicit model (add_implicit_features of fit_collective_explicit_als,
+ * /root/reference/src/collective.c:7269, :8448-8534): Ai [m, k+k_main] and Bi [n, k+k_main] factorise the binary
+ * "was observed" pattern of X with weight w_implicit (already divided by w_main).  After this call the session's
+ * updates 'b' (Bi from A) and 'a' (Ai from B) exist, iterate() runs them between D and B like the reference, and the
+ * A / B updates carry the extra term (collective.c:1704-1707, :1757-1771).  Ai / Bi may be NULL (start values are never
+ * read by the closed-form updates).  Cholesky-type solves only; whole-matrix sessions, dense or no side information. */
+int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_implicit, const real_t *Ai, const real_t *Bi);
+int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, real_t *Bi);
+
 /* L1 penalty (one value for every matrix: A, B and the bias columns take l1_lam, C / D l1_lam / w_user, / w_item;
  * scaled per row like lambda).  Systems are then solved by solve_elasticnet (src/common.c:2228-2294), or by
  * solve_nonneg with the penalty on the right-hand side where a non-negativity constraint applies; no CG. */

@@ -341,8 +341,13 @@ class Oracle:
                          U=None, II=None, user_bias=True, item_bias=True, center=True, lam=10.0,
                          scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,
                          w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=True, max_cg_steps=3,
-                         precondition_cg=False, finalize_chol=True, init_biases=False, m=None, n=None):
+                         precondition_cg=False, finalize_chol=True, init_biases=False, m=None, n=None,
+                         add_implicit_features=False, w_implicit=1.0, w_main=1.0):
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
+        if w_main != 1.0:                                                            # collective.c:7497-7521
+            lam, w_user, w_item, w_implicit = lam / w_main, w_user / w_main, w_item / w_main, w_implicit / w_main
+        Ai = np.zeros((A.shape[0], k + k_main), self.dtype) if add_implicit_features else None
+        Bi = np.zeros((B.shape[0], k + k_main), self.dtype) if add_implicit_features else None
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         biasA = np.zeros(A.shape[0], self.dtype) if biasA is None else biasA
@@ -355,8 +360,9 @@ class Oracle:
             Cm = np.zeros((p, k_user + k), self.dtype)
         if II is not None and Dm is None:
             Dm = np.zeros((q, k_item + k), self.dtype)
-        ret = self.lib.oracle_fit_explicit_als(
-            _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(glob_mean), _ptr(Ucm),
+        ret = self.lib.oracle_fit_explicit_als_implicit_features(
+            _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(Ai), _ptr(Bi), self._r(w_implicit),
+            _ptr(glob_mean), _ptr(Ucm),
             _ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val),
             C.c_size_t(len(val)), C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
             self._r(lam), C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo),
@@ -365,7 +371,7 @@ class Oracle:
             C.c_int(niter), C.c_int(nthreads), C.c_bool(use_cg), C.c_int(max_cg_steps),
             C.c_bool(precondition_cg), C.c_bool(finalize_chol), C.c_bool(init_biases))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],
-                    U_colmeans=Ucm, I_colmeans=Icm)
+                    U_colmeans=Ucm, I_colmeans=Icm, Ai=Ai, Bi=Bi)
 
 
 def ref_available(dtype=np.float64):
@@ -697,11 +703,13 @@ class Reference:
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
-                                    l1_lam=0.0):
+                                    l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
+        Ai = np.zeros((A.shape[0], k + k_main), self.dtype) if add_implicit_features else None
+        Bi = np.zeros((B.shape[0], k + k_main), self.dtype) if add_implicit_features else None
         biasA = np.zeros(A.shape[0], self.dtype) if biasA is None else biasA
         biasB = np.zeros(B.shape[0], self.dtype) if biasB is None else biasB
         glob_mean = np.zeros(1, self.dtype)
@@ -726,8 +734,8 @@ class Reference:
                        CtCw=np.zeros((max(kc, 1), max(kc, 1)), self.dtype), CtUbias=np.zeros(max(kc, 1), self.dtype))
         pp = (lambda key: _ptr(pre[key])) if pre else (lambda key: None)
         ret = self.lib.fit_collective_explicit_als(
-            _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), None, None,
-            C.c_bool(False), C.c_bool(reset_values), C.c_int(seed),
+            _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(Ai), _ptr(Bi),
+            C.c_bool(add_implicit_features), C.c_bool(reset_values), C.c_int(seed),
             _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             None, None, C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
@@ -737,11 +745,11 @@ class Reference:
             *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
             C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
-            self._r(1.), self._r(w_user), self._r(w_item), self._r(1.),
+            self._r(w_main), self._r(w_user), self._r(w_item), self._r(w_implicit),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
             C.c_bool(nonneg), C.c_int(max_cd_steps), C.c_bool(nonneg_C), C.c_bool(nonneg_D),
             C.c_bool(precompute), C.c_bool(True), pp("B_plus_bias"), pp("BtB"), pp("TransBtBinvBt"), pp("BtXbias"),
             pp("BeTBeChol"), pp("BiTBi"), pp("TransCtCinvCt"), pp("CtCw"), pp("CtUbias"))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],
-                    U_colmeans=Ucm, I_colmeans=Icm, pre=pre)
+                    U_colmeans=Ucm, I_colmeans=Icm, pre=pre, Ai=Ai, Bi=Bi)

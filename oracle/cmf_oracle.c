@@ -568,6 +568,52 @@ void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Missing-as-zero rows on an unweighted sparse matrix (optimizeA Case 3, common.c:3116-3205): one matrix
+ * B^T B + lam (x n under scale_lam) for every row, right-hand sides X B (tgemm_sp_dense).  Xcsr == NULL: unit values
+ * (the binary indicator the Ai / Bi updates of add_implicit_features run on, collective.c:8448-8534). */
+void oracle_optimizeA_naz(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                          const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                          real_t lam, real_t lam_last, bool scale_lam, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    real_t *BtB = (real_t *)malloc((size_t)k * k * sizeof(real_t));
+    oracle_gram(B, ldb, n, k, BtB, nthreads);                                  /* :3128-3131 */
+    for (int_t i = 0; i < k - 1; i++) BtB[(size_t)i * k + i] += scale_lam ? lam * (real_t)n : lam;   /* :3137-3138 */
+    BtB[(size_t)(k - 1) * k + (k - 1)] += scale_lam ? lam_last * (real_t)n : lam_last;
+    const real_t l1_rows = g_l1 * (scale_lam ? (real_t)n : (real_t)1);          /* :3182-3183, :3195-3196 */
+    const bool cd = g_nonneg || l1_rows != 0;
+    int bad = cd ? 0 : chol_upper_(k, BtB, k);                                 /* :3171-3175 posv */
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {
+        real_t *a = A + (size_t)ix * lda;
+        memset(a, 0, (size_t)k * sizeof(real_t));                              /* :3139-3144 */
+        for (size_t jx = Xcsr_p[ix]; jx < Xcsr_p[(size_t)ix + 1]; jx++)       /* :3145-3151 */
+            axpy_(k, Xcsr ? Xcsr[jx] : (real_t)1, B + (size_t)Xcsr_i[jx] * ldb, a);
+        if (cd) {
+            real_t *Mc = (real_t *)malloc((size_t)k * k * sizeof(real_t));
+            memcpy(Mc, BtB, (size_t)k * k * sizeof(real_t));
+            if (g_nonneg) {
+                if (l1_rows != 0) for (int_t c = 0; c < k; c++) a[c] -= l1_rows;
+                solve_nonneg_(k, Mc, k, a, g_max_cd);
+            } else solve_elasticnet_(k, Mc, k, a, l1_rows, l1_rows, g_max_cd);
+            free(Mc);
+        }
+        else if (!bad) chol_solve_upper_(k, BtB, k, a);
+        else for (int_t c = 0; c < k; c++) a[c] = NAN;
+    }
+    free(BtB);
+}
+
+static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                      const real_t *C,
+                                      int_t m, int_t m_u, int_t n, int_t p,
+                                      int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      const real_t *U,
+                                      real_t lam, real_t w_user, real_t lam_last,
+                                      bool scale_lam, bool scale_lam_sideinfo,
+                                      int nthreads,
+                                      const real_t *Bi, int_t k_main_i, real_t w_implicit);
 void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, size_t ldb,
                                       const real_t *C,
                                       int_t m, int_t m_u, int_t n, int_t p,
@@ -578,8 +624,31 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
                                       bool scale_lam, bool scale_lam_sideinfo,
                                       int nthreads)
 {
-    (void)n;
+    collective_chol_impl(A, lda, B, ldb, C, m, m_u, n, p, k, k_main, k_user, k_item, Xcsr_p, Xcsr_i, Xcsr, U,
+                         lam, w_user, lam_last, scale_lam, scale_lam_sideinfo, nthreads, NULL, 0, (real_t)1);
+}
+
+/* Bi != NULL: the implicit-features term -- w_i Bi^T Bi on the X block of every solved row (collective.c:5689-5695,
+ * :1704-1707) and w_i sum_{j observed} Bi_j on its right-hand side (:1757-1771); Bi is [n, k + k_main_i]. */
+static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t ldb,
+                                      const real_t *C,
+                                      int_t m, int_t m_u, int_t n, int_t p,
+                                      int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                      const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                                      const real_t *U,
+                                      real_t lam, real_t w_user, real_t lam_last,
+                                      bool scale_lam, bool scale_lam_sideinfo,
+                                      int nthreads,
+                                      const real_t *Bi, int_t k_main_i, real_t w_implicit)
+{
     if (nthreads < 1) nthreads = 1;
+    const int_t kbi = k + k_main_i;
+    real_t *BiTBi = NULL;
+    if (Bi != NULL) {
+        BiTBi = (real_t *)malloc((size_t)kbi * kbi * sizeof(real_t));
+        oracle_gram(Bi, (size_t)kbi, n, kbi, BiTBi, nthreads);
+        for (size_t i = 0; i < (size_t)kbi * kbi; i++) BiTBi[i] *= w_implicit;
+    }
     int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main;
     /* collective.c:4817-4822: A := 0 when not CG */
     for (size_t ix = 0; ix < (size_t)m * lda - (lda - (size_t)k_totA); ix++) A[ix] = 0;
@@ -631,12 +700,19 @@ void oracle_optimizeA_collective_chol(real_t *A, size_t lda, const real_t *B, si
         /* :1542-1543 tail already zero; :1738-1742 rhs += B^T x */
         for (size_t jx = st; jx < en; jx++)
             axpy_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+        if (Bi != NULL) {
+            for (int_t i = 0; i < kbi; i++)                                    /* :1704-1707 */
+                for (int_t j = i; j < kbi; j++) Mlr[(size_t)i * k_totA + j] += BiTBi[(size_t)i * kbi + j];
+            for (size_t jx = st; jx < en; jx++)                                /* :1764-1770 */
+                axpy_(kbi, w_implicit, Bi + (size_t)Xcsr_i[jx] * kbi, a + k_user);
+        }
         for (int_t i = 0; i < k_totA - 1; i++) M[(size_t)i * k_totA + i] += lam_i; /* :1819 */
         M[(size_t)(k_totA - 1) * k_totA + (k_totA - 1)] += lam_last_i;
         solve_sym_(k_totA, M, k_totA, a);
     }
     free(bufs);
     free(CtCw);
+    free(BiTBi);
 }
 
 /* Block CG on the collective system, dense full U without NaN (prefer_CtC branches):
@@ -1051,6 +1127,30 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
                             bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
                             bool init_biases)
 {
+    return oracle_fit_explicit_als_implicit_features(biasA, biasB, A, B, C, D, NULL, NULL, (real_t)1, glob_mean, U_colmeans,
+                                                     I_colmeans, m, n, k, ixA, ixB, X, nnz, user_bias, item_bias, center, lam,
+                                                     scale_lam, scale_lam_sideinfo, U, m_u, p, II, n_i, q, k_main, k_user,
+                                                     k_item, w_user, w_item, niter, nthreads, use_cg, max_cg_steps,
+                                                     precondition_cg, finalize_chol, init_biases);
+}
+
+/* Ai, Bi != NULL: add_implicit_features (collective.c:8448-8534 and the extra term of the A / B updates); closed-form
+ * solves only, side information inside the shape of X.  Iteration order C, D, Bi, Ai, B, A. */
+int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
+                            real_t *Ai, real_t *Bi, real_t w_implicit,
+                            real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,
+                            int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            bool user_bias, bool item_bias, bool center,
+                            real_t lam, bool scale_lam, bool scale_lam_sideinfo,
+                            const real_t *U, int_t m_u, int_t p,
+                            const real_t *II, int_t n_i, int_t q,
+                            int_t k_main, int_t k_user, int_t k_item,
+                            real_t w_user, real_t w_item,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+                            bool init_biases)
+{
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
@@ -1061,6 +1161,8 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
     if (m_u > m) m = m_u;
     if (n_i > n) n = n_i;
     if (init_biases && (user_bias != item_bias)) return 2;
+    const bool imp = (Ai != NULL && Bi != NULL);
+    if (imp && (use_cg || m_u > m_x || n_i > n_x)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     const real_t l1f = g_l1_base;
     if (g_nn_AB || l1f != 0) use_cg = false;                                   /* :7474-7479 */
@@ -1113,6 +1215,13 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
         if (II != NULL)                                                        /* :8409-8441 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B_bias, ldB, q, n_i, k_item + k,
                                         Ic, (size_t)q, true, lam / w_item, lam / w_item, scale_lam, nthreads);
+        g_nonneg = g_nn_AB; g_l1 = l1f / w_implicit;
+        if (imp) {                                                             /* :8448-8534 */
+            oracle_optimizeA_naz(Bi, (size_t)(k + k_main), A_bias + k_user, ldA, n, m, k + k_main, csc_p, csc_i, NULL,
+                                 lam / w_implicit, lam / w_implicit, scale_lam, nthreads);
+            oracle_optimizeA_naz(Ai, (size_t)(k + k_main), B_bias + k_item, ldB, m, n, k + k_main, csr_p, csr_i, NULL,
+                                 lam / w_implicit, lam / w_implicit, scale_lam, nthreads);
+        }
         g_nonneg = g_nn_AB; g_l1 = l1f;
         if (item_bias)                                                         /* :8538-8543 */
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
@@ -1122,11 +1231,11 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
             oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lam, w_item, lam, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
-        else if (II != NULL)
-            oracle_optimizeA_collective_chol(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q,
+        else if (II != NULL || imp)                                            /* :8612 */
+            collective_chol_impl(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q,
                                              k, k_main + (int_t)item_bias, k_item, k_user,
                                              csc_p, csc_i, csc_v, Ic, lam, w_item, lam,
-                                             scale_lam, scale_lam_sideinfo, nthreads);
+                                             scale_lam, scale_lam_sideinfo, nthreads, imp ? Ai : NULL, k_main, w_implicit);
         else                                                                   /* :8680-8717 */
             oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
                                       k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
@@ -1151,11 +1260,11 @@ int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, 
             oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                            csr_p, csr_i, csr_v, Uc, lam, w_user, lam, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
-        else if (U != NULL)
-            oracle_optimizeA_collective_chol(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p,
+        else if (U != NULL || imp)                                             /* :8783 */
+            collective_chol_impl(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p,
                                              k, k_main + (int_t)user_bias, k_user, k_item,
                                              csr_p, csr_i, csr_v, Uc, lam, w_user, lam,
-                                             scale_lam, scale_lam_sideinfo, nthreads);
+                                             scale_lam, scale_lam_sideinfo, nthreads, imp ? Bi : NULL, k_main, w_implicit);
         else                                                                   /* :8847-8876 */
             oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,
                                       k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,

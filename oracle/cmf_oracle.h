@@ -129,6 +129,23 @@ int oracle_fit_implicit_als(real_t *A, real_t *B, int_t m, int_t n, int_t k,
  * U[m_u,p] / II[n_i,q] (m_u<=m, n_i<=n), w_main=1, no L1/nonneg/implicit features.
  * reset_values=false semantics: caller injects A, B (and biasA/biasB start values, C, D).
  * With side info only Cholesky is restated (block-CG is SURVEY 8f). Returns 0 ok, 2 unsupported. */
+void oracle_optimizeA_naz(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                          const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
+                          real_t lam, real_t lam_last, bool scale_lam, int nthreads);
+int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
+                            real_t *Ai, real_t *Bi, real_t w_implicit,
+                            real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,
+                            int_t m, int_t n, int_t k,
+                            const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
+                            bool user_bias, bool item_bias, bool center,
+                            real_t lam, bool scale_lam, bool scale_lam_sideinfo,
+                            const real_t *U, int_t m_u, int_t p,
+                            const real_t *II, int_t n_i, int_t q,
+                            int_t k_main, int_t k_user, int_t k_item,
+                            real_t w_user, real_t w_item,
+                            int_t niter, int nthreads,
+                            bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
+                            bool init_biases);
 int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                             real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,
                             int_t m, int_t n, int_t k,

@@ -243,6 +243,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g13_nonneg_" + tag, **out)
 
+        # ---- G14: implicit features of the explicit model ----
+        out = {}
+        d = gc.nonneg_problem(dt)
+        for ci, (name, side, opts) in enumerate(gc.IMPLICIT_FEATS_CASES):
+            r = gc.implicit_feats_reference(R, d, side, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g14_implicit_feats_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -360,7 +360,7 @@ def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
 def compare_fits(got, exp):
     """Largest relative error over the factor matrices / biases both sides carry."""
     err = 0.0
-    for key in ("A", "B", "C", "D", "biasA", "biasB"):
+    for key in ("A", "B", "C", "D", "biasA", "biasB", "Ai", "Bi"):
         if key in exp and exp[key] is not None and got.get(key) is not None and np.size(exp[key]):
             e = maxrel(got[key], exp[key])
             err = max(err, e) if np.isfinite(e) else float("inf")        # NaN anywhere is a failure, never silently dropped
@@ -457,6 +457,77 @@ def nonneg_hip(d, implicit, side, opts, dtype):
     mdl = CMF(lambda_=0.3, use_cg=o.pop("use_cg", False), finalize_chol=False, **common, **o)
     mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=shape, A0=d["A0"], B0=d["B0"], biasA0=d["bA"], biasB0=d["bB"])
     out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
+# ---- implicit features of the explicit model (add_implicit_features, collective.c:8448-8534) -------------------------
+# (name, side information, options)
+IMPLICIT_FEATS_CASES = [
+    ("plain", False, dict()),
+    ("scale_lam k_main", False, dict(scale_lam=True, k_main=2, w_implicit=0.7)),
+    ("side info", True, dict(k_user=2, k_item=1, k_main=1, scale_lam_sideinfo=True, w_implicit=1.5)),
+    ("no biases w_main", False, dict(user_bias=False, item_bias=False, center=False, w_main=2.0)),
+    ("user bias only", True, dict(item_bias=False, w_implicit=0.25)),
+    # not pinned: nonneg / L1 together with implicit features -- the reference segfaults on them (verified here with
+    # nonneg=True and with l1_lam=0.05, one and two threads), so the product rejects the combination
+]
+
+
+def _impf_start(d, o):
+    """Start values wide enough for the case's k_user / k_item / k_main (deterministic extension of the problem's A0, B0)."""
+    rng = np.random.default_rng(77)
+    dt = d["A0"].dtype
+    ku, ki, km = o.get("k_user", 0), o.get("k_item", 0), o.get("k_main", 0)
+    ext = lambda M, left, right: np.ascontiguousarray(np.hstack(
+        [np.abs(rng.standard_normal((M.shape[0], left)) * 0.1).astype(dt), M,
+         np.abs(rng.standard_normal((M.shape[0], right)) * 0.1).astype(dt)]))
+    return ext(d["A0"], ku, km), ext(d["B0"], ki, km)
+
+
+def implicit_feats_reference(R, d, side, opts, nthreads=2):
+    o = dict(opts); niter = o.pop("niter", 3)
+    A0, B0 = _impf_start(d, o)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=niter, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads,
+                                      use_cg=False, finalize_chol=False, add_implicit_features=True, **o)
+    assert r["ret"] == 0
+    return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
+                Ai=r["Ai"], Bi=r["Bi"])
+
+
+def implicit_feats_oracle(O, d, side, opts, nthreads=2):
+    o = dict(opts)
+    niter = o.pop("niter", 3)
+    O.set_nonneg(o.pop("nonneg", False), False, False, 100)
+    O.set_l1(o.pop("l1_lam", 0.0) / o.get("w_main", 1.0), 100)
+    try:
+        A0, B0 = _impf_start(d, o)
+        U, II = (d["U"], d["I"]) if side else (None, None)
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                               niter=niter, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=False,
+                               finalize_chol=False, add_implicit_features=True, **o)
+        assert r["ret"] == 0
+        return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
+                    Ai=r["Ai"], Bi=r["Bi"])
+    finally:
+        O.set_nonneg(False, False, False, 100)
+        O.set_l1(0.0, 100)
+
+
+def implicit_feats_hip(d, side, opts, dtype):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    niter = o.pop("niter", 3)
+    o.setdefault("w_implicit", 1.0)           # the estimator's default is 0.5 (cmfrec/__init__.py), the C default used above 1
+    A0, B0 = _impf_start(d, o)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    mdl = CMF(k=d["k"], niter=niter, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, lambda_=0.3, use_cg=False,
+              finalize_chol=False, add_implicit_features=True, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_, Ai=mdl.Ai_, Bi=mdl.Bi_)
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     return out

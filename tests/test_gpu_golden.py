@@ -196,3 +196,17 @@ def test_nonneg(oracles, dtype):
         assert gc.compare_fits(got, gc.nonneg_oracle(oracles[dtype], d, implicit, side, opts)) < tol, name
         if opts.get("nonneg"):
             assert (got["A"] >= 0).all() and (got["B"] >= 0).all()
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_implicit_features(oracles, dtype):
+    """G14 through the estimator: Ai / Bi by the shared-matrix launch (CHOL_NAZ) and the A / B updates with the
+    implicit-features term as a right-hand-side-only second gather source, against the reference's outputs and the oracle."""
+    g = gc.load("g14_implicit_feats", dtype)
+    d = gc.nonneg_problem(dtype)
+    tol = 1e-8 if dtype is np.float64 else 1e-2
+    for ci, (name, side, opts) in enumerate(gc.IMPLICIT_FEATS_CASES):
+        got = gc.implicit_feats_hip(d, side, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and "Ai" in exp and gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.implicit_feats_oracle(oracles[dtype], d, side, opts)) < tol, name

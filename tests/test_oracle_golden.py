@@ -150,3 +150,14 @@ def test_nonneg(oracles, dtype):
         got = gc.nonneg_oracle(oracles[dtype], d, implicit, side, opts)
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert exp and gc.compare_fits(got, exp) < TOL[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_implicit_features(oracles, dtype):
+    """G14: add_implicit_features fits (Ai, Bi and the extra term of the A / B updates), the reference's outputs."""
+    g = gc.load("g14_implicit_feats", dtype)
+    d = gc.nonneg_problem(dtype)
+    for ci, (name, side, opts) in enumerate(gc.IMPLICIT_FEATS_CASES):
+        got = gc.implicit_feats_oracle(oracles[dtype], d, side, opts)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and "Ai" in exp and gc.compare_fits(got, exp) < TOL[dtype], name

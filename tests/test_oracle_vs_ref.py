@@ -269,3 +269,16 @@ def test_nonneg_live(oracles, refs, dtype):
         assert gc.compare_fits(got, exp) < tol, name
         if opts.get("nonneg"):
             assert (exp["A"] >= 0).all() and (exp["B"] >= 0).all() and (exp["A"] == 0).mean() > 0.2
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_implicit_features_live(oracles, refs, dtype):
+    """add_implicit_features: the Ai / Bi updates (optimizeA Case 3 on the binary indicator, collective.c:8448-8534) and the
+    extra term of the A / B updates (:1704-1707, :1757-1771), with and without side information, biases, scaled lambda."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    d = gc.nonneg_problem(dtype, seed=57)
+    for name, side, opts in gc.IMPLICIT_FEATS_CASES:
+        exp = gc.implicit_feats_reference(refs[dtype], d, side, opts, nthreads=3)
+        got = gc.implicit_feats_oracle(oracles[dtype], d, side, opts, nthreads=1)
+        assert np.abs(exp["Ai"]).sum() > 0 and gc.compare_fits(got, exp) < tol, name
