@@ -243,6 +243,7 @@ struct DeviceInfo {
     mutable bool nonneg_now = false;
     mutable int max_cd_steps = 100;
     mutable real_t l1_now = 0;      // L1 penalty of the update in progress (already divided by w_user / w_item for C / D)
+    mutable real_t l1_last_now = 0; // ... of the last unknown (the bias' own penalty under l1_lam_unique)
     mutable real_t l1_scale = 1;    // ... times this for the launches whose lambda is scaled by a row count on the host
     DeviceInfo() = default;
     DeviceInfo(const DeviceInfo &) = delete;

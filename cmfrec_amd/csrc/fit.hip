@@ -141,18 +141,23 @@ int_t fit_collective_implicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (l1_lam_unique || lam_unique || adjust_weight)
-        return fail(verbose, "cmfrec_hip: l1_lam_unique / lam_unique / adjust_weight are not implemented.");
-    if (l1_lam != 0 && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
+    if (adjust_weight) return fail(verbose, "cmfrec_hip: adjust_weight is not implemented.");
+    if ((l1_lam != 0 || l1_lam_unique) && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
-    if (nonneg || nonneg_C || nonneg_D || l1_lam != 0) use_cg = false;    // collective.c:9568-9571 (any of them, unlike the explicit model)
+    if (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique) use_cg = false;    // collective.c:9568-9571 (any of them, unlike the explicit model)
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
     if (w_main_multiplier) *w_main_multiplier = 1;
-    if (w_main != (real_t)1) { lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; }   // collective.c:9786-9811
+    // per-matrix penalties: entries 2..5 = A, B, C, D (the bias slots are unused by this model, collective.c:9793-9809)
+    real_t lam6[6], l16[6];
+    for (int e = 0; e < 6; e++) { lam6[e] = lam_unique ? lam_unique[e] : lam; l16[e] = l1_lam_unique ? l1_lam_unique[e] : l1_lam; }
+    if (w_main != (real_t)1) {                                            // collective.c:9786-9811
+        lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main;
+        for (int e = 2; e < 6; e++) { lam6[e] /= w_main; l16[e] /= w_main; }
+    }
 
     PhaseTimer tm;
     tm.lap("validate");
@@ -211,6 +216,8 @@ int_t fit_collective_implicit_als(
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
+    if (!rc && (lam_unique || l1_lam_unique))
+        rc = cmfrec_hip_session_set_lam_unique(s, lam_unique ? lam6 : nullptr, l1_lam_unique ? l16 : nullptr, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, nullptr, nullptr, C, D);
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     if (tm.on) cmfrec_hip_session_sync(s);
@@ -277,7 +284,7 @@ int_t fit_collective_explicit_als(
             return fail(verbose, "cmfrec_hip: implicit features: precompute_for_predictions is not implemented.");
         // the reference itself crashes on add_implicit_features with nonneg or an L1 penalty (its Ai / Bi updates are handed
         // a NULL thread-local buffer, collective.c:8487-8489): nothing to pin against, so not offered
-        if (nonneg || l1_lam != 0)
+        if (nonneg || l1_lam != 0 || l1_lam_unique)
             return fail(verbose, "cmfrec_hip: implicit features with nonneg / L1 are not implemented.");
         if (use_cg)
             return fail(verbose, "cmfrec_hip: implicit features: the conjugate-gradient solver is not implemented (use_cg = false).");
@@ -291,11 +298,10 @@ int_t fit_collective_explicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (l1_lam_unique || lam_unique || scale_bias_const)
-        return fail(verbose, "cmfrec_hip: l1_lam_unique / lam_unique / scale_bias_const are not implemented.");
-    if (l1_lam != 0 && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
+    if (scale_bias_const) return fail(verbose, "cmfrec_hip: scale_bias_const is not implemented.");
+    if ((l1_lam != 0 || l1_lam_unique) && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
-    if (nonneg || l1_lam != 0) use_cg = false;                            // collective.c:7474-7479
+    if (nonneg || l1_lam != 0 || l1_lam_unique) use_cg = false;           // collective.c:7474-7479
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
@@ -309,7 +315,13 @@ int_t fit_collective_explicit_als(
     SigGuard sig(true);
     scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
     if (!use_cg) finalize_chol = false;                                   // :7481
-    if (w_main != (real_t)1) { lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; w_implicit /= w_main; }   // :7497-7521
+    // per-matrix penalties, order: user bias, item bias, A, B, C, D (collective.c:430)
+    real_t lam6[6], l16[6];
+    for (int e = 0; e < 6; e++) { lam6[e] = lam_unique ? lam_unique[e] : lam; l16[e] = l1_lam_unique ? l1_lam_unique[e] : l1_lam; }
+    if (w_main != (real_t)1) {                                            // :7497-7521
+        lam /= w_main; l1_lam /= w_main; w_user /= w_main; w_item /= w_main; w_implicit /= w_main;
+        for (int e = 0; e < 6; e++) { lam6[e] /= w_main; l16[e] /= w_main; }
+    }
     const bool has_bias = user_bias || item_bias;
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
     const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);      // rows of A / B (collective.c:7332-7335)
@@ -381,13 +393,15 @@ int_t fit_collective_explicit_als(
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
+    if (!rc && (lam_unique || l1_lam_unique))
+        rc = cmfrec_hip_session_set_lam_unique(s, lam_unique ? lam6 : nullptr, l1_lam_unique ? l16 : nullptr, (int)max_cd_steps);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
     // Ai / Bi need no start values: their first update is a closed-form solve (collective.c:8236-8240)
     if (!rc && add_implicit_features) rc = cmfrec_hip_session_set_implicit_features(s, w_implicit, nullptr, nullptr);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("side info + factors upload");
     if (!rc && has_bias && reset_values) {                                // common.c:4410-4909; lambdas clipped like :4449-4452
-        real_t lam_u = lam, lam_i = lam;
+        real_t lam_u = lam6[0], lam_i = lam6[1];                          // collective.c:8178, :8197, :8218-8219
         if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
         if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
         rc = cmfrec_hip_session_init_biases(s, lam_u, lam_i);

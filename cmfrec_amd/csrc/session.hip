@@ -74,12 +74,13 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2; P.koff2 = c.koff2; P.w2_syr_zero = c.w2_syr_zero ? 1 : 0; P.rows_src2 = c.rows2;
     }
     P.values_override = c.values_override;
-    const bool l1on = dev.l1_now != (real_t)0;
+    const bool l1on = dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0;
     const bool nonneg = c.nonneg || dev.nonneg_now;
     P.nonneg = nonneg ? 1 : 0; P.max_cd_steps = (dev.nonneg_now || l1on) ? dev.max_cd_steps : c.max_cd_steps;
     // PREFILLED launches carry their lambda inside the prefilled matrix, scaled on the host (common.c:2832-2833): their L1
     // penalty takes the same factor (solve_elasticnet_batch / solve_nonneg_batch calls, :2876-2902)
-    P.l1 = P.l1_last = (c.mode == CHOL_PREFILLED || c.mode == CHOL_NAZ) ? dev.l1_now * dev.l1_scale : dev.l1_now;
+    const real_t l1_mult = (c.mode == CHOL_PREFILLED || c.mode == CHOL_NAZ) ? dev.l1_scale : (real_t)1;
+    P.l1 = dev.l1_now * l1_mult; P.l1_last = dev.l1_last_now * l1_mult;
     if (P.nrows <= 0) return 0;
     const int T = chol_tiles(c.kt);
     const size_t smem_nonneg = (nonneg || l1on) ? ((size_t)c.kt * c.kt + 2 * (size_t)c.kt + 64) * sizeof(real_t) : 0;
@@ -220,6 +221,9 @@ struct cmfrec_hip_session {
     bool implicit_feats = false;
     real_t w_implicit = 1;
     DevBuf<real_t> Ai, Bi, bitbi, bitbi_full, ones;
+    // per-matrix penalties, the reference's lam_unique / l1_lam_unique order (collective.c:430): user bias, item bias, A, B,
+    // C, D -- after the w_main rescaling.  Scalar lam / l1_lam fill all six.
+    real_t lam6[6] = {0, 0, 0, 0, 0, 0}, l16[6] = {0, 0, 0, 0, 0, 0};
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
@@ -313,6 +317,7 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
             HIP_CHECK(hipMemsetAsync(s->biasB.ptr, 0, (size_t)m.n * sizeof(real_t), s->dev.stream));
         }
         int kmax = std::max(s->k_totA, s->k_totB) + 1;
+        for (int e = 0; e < 6; e++) s->lam6[e] = s->mdl.lam;
         s->gram.alloc((size_t)kmax * kmax);
         s->ctc.alloc((size_t)kmax * kmax);
         s->betbe.alloc((size_t)kmax * kmax);
@@ -615,9 +620,20 @@ int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, 
     });
 }
 
+int cmfrec_hip_session_set_lam_unique(cmfrec_hip_session *s, const real_t *lam_unique, const real_t *l1_lam_unique, int max_cd_steps)
+{
+    if (lam_unique) for (int e = 0; e < 6; e++) s->lam6[e] = lam_unique[e];
+    if (l1_lam_unique) {
+        for (int e = 0; e < 6; e++) s->l16[e] = l1_lam_unique[e];
+        s->max_cd_steps = max_cd_steps;
+    }
+    return 0;
+}
+
 int cmfrec_hip_session_set_l1(cmfrec_hip_session *s, real_t l1_lam, int max_cd_steps)
 {
     s->l1_lam = l1_lam;
+    for (int e = 0; e < 6; e++) s->l16[e] = l1_lam;
     s->max_cd_steps = max_cd_steps;
     return 0;
 }
@@ -670,7 +686,7 @@ static int solve_sideinfo_only_rows(cmfrec_hip_session *s, bool isA, bool chol, 
     real_t *rows = self + (size_t)(begin + first) * ld_self;
     if (chol) HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)count * ld_self * sizeof(real_t), dev.stream));
     launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->betbe.ptr, (real_t)1,
-                (m.lam / w) * (real_t)(scale_lam ? p_self : 1));                                   // common.c:2824-2832
+                (s->lam6[isA ? 2 : 3] / w) * (real_t)(scale_lam ? p_self : 1));                                   // common.c:2824-2832
     launch_gemm<false>(dev, count, kc, p_self, (real_t)1, Um + (size_t)(begin + first) * p_self, (size_t)p_self, Cm,
                        (size_t)kc, rows, ld_self);                                                 // common.c:2847-2855
     CholCall c{rows, ld_self, nullptr, 0, kc, 0, nullptr, s->betbe.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
@@ -693,6 +709,9 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const bool self_bias = isA ? m.user_bias : m.item_bias;
     const bool opp_bias = isA ? m.item_bias : m.user_bias;
     const int p_self = isA ? m.p : m.q;
+    // lam_unique[2] / [3] for A / B; the bias, when fitted, takes lam_unique[0] / [1] (collective.c:8649-8654, :8820-8825)
+    const real_t lam_self = s->lam6[isA ? 2 : 3];
+    const real_t lam_last_self = (!m.implicit && self_bias) ? s->lam6[isA ? 0 : 1] : lam_self;
     real_t *self_blk = self + (size_t)(begin + (part >= 0 ? s->partBegin[part] : 0)) * ld_self;
     if (part >= 0 && (!isA || p_self > 0)) {
         g_last_error = "cmfrec_hip: row parts are only built for A-steps without side information";
@@ -731,7 +750,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
                 if (opp_bias) bias_sub_cg = isA ? s->biasB.ptr : s->biasA.ptr;
             }
             CgCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kx, bias_sub_cg, m.implicit ? s->gram.ptr : nullptr,
-                     m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
+                     lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
                      (bool)m.precondition_cg};
             c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
             c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo; c.X2 = &Us; c.C2 = Cm;
@@ -740,11 +759,11 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822, :6018-6019
         if (m.implicit) {
             const int kt = k_side_self + kk;
-            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, m.lam);
-            hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, m.lam,
+            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, lam_self);
+            hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, lam_self,
                                s->betbe.ptr);
-            CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, nullptr, nullptr, kc, rows_u, p_self, m.lam,
-                       m.lam, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
+            CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, nullptr, nullptr, kc, rows_u, p_self, lam_self,
+                       lam_last_self, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
             c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
             return launch_chol(dev, c, &X);
         }
@@ -755,7 +774,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         }
         const int kt = k_side_self + kk + (self_bias ? 1 : 0);
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr,
-                   nullptr, kc, rows_u, p_self, m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo),
+                   nullptr, kc, rows_u, p_self, lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo),
                    (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE};
         c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
         return launch_chol(dev, c, &X);
@@ -788,7 +807,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
             if (opp_bias) bias_sub_cg = isA ? s->biasB.ptr : s->biasA.ptr;
         }
         CgCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kx, bias_sub_cg, m.implicit ? s->gram.ptr : nullptr,
-                 m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
+                 lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
                  (bool)m.precondition_cg};
         // explicit model: rows beyond X are not part of the block system (solve_sideinfo_only_rows)
         const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
@@ -806,8 +825,8 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         const int rows_u = isA ? m.m_u : m.n_i;
         const int kc = k_side_self + m.k, kt = k_side_self + kk;
         const real_t w = isA ? m.w_user : m.w_item;
-        launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, m.lam);     // :6056-6061
-        hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, m.lam,
+        launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, lam_self);     // :6056-6061
+        hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, lam_self,
                            s->betbe.ptr);                                                           // :6121-6135
         launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);            // :6138-6160
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :6018-6019
@@ -815,21 +834,21 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
                            self_blk, ld_self);                                                      // :6163-6168
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, nullptr, s->ctc.ptr, kc, local_u,
-                   p_self, m.lam, m.lam, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
+                   p_self, lam_self, lam_last_self, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
         return launch_chol(dev, c, &X);
     }
     if (m.implicit) {
         // optimizeA_implicit, common.c:3305-3421 (the Gramian once per half-step: parts > 0 reuse it)
         if (part <= 0)
-            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, chol ? m.lam : (real_t)0);
+            launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, chol ? lam_self : (real_t)0);
         if (chol) {
             if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st)); // :3334
             CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, 0, nullptr,
-                       s->gram.ptr, 0, 0, 0, m.lam, m.lam, false, false, false, CHOL_IMPLICIT};
+                       s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_IMPLICIT};
             return launch_chol(dev, c, &X);
         }
         CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, nullptr, s->gram.ptr,
-                 m.lam, m.lam, false, false, m.max_cg_steps, true, (bool)m.precondition_cg};
+                 lam_self, lam_last_self, false, false, m.max_cg_steps, true, (bool)m.precondition_cg};
         return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
     }
 
@@ -877,7 +896,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
         const int local_u_main = std::min(local_u, local_x);              // rows beyond X: solve_sideinfo_only_rows
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, s->ctc.ptr, kc, local_u_main,
-                   p_self, m.lam, m.lam, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false,
+                   p_self, lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false,
                    CHOL_COLLECTIVE};
         add_implicit_term(c);
         int rc = launch_chol(dev, c, &X);
@@ -889,17 +908,17 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         // without side information on this side the reference still takes optimizeA_collective (collective.c:8612, :8783)
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, ksolve, 0, bias_sub, nullptr, 0, 0, 0,
-                   m.lam, m.lam, scale_lam, false, false, CHOL_COLLECTIVE};
+                   lam_self, lam_last_self, scale_lam, false, false, CHOL_COLLECTIVE};
         add_implicit_term(c);
         return launch_chol(dev, c, &X);
     }
     if (chol) {
         CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, 0, bias_sub, nullptr, 0, 0, 0,
-                   m.lam, m.lam, scale_lam, false, false, CHOL_EXPLICIT};
+                   lam_self, lam_last_self, scale_lam, false, false, CHOL_EXPLICIT};
         return launch_chol(dev, c, &X);
     }
     CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, bias_sub, nullptr,
-             m.lam, m.lam, scale_lam, false, m.max_cg_steps, false, (bool)m.precondition_cg};
+             lam_self, lam_last_self, scale_lam, false, m.max_cg_steps, false, (bool)m.precondition_cg};
     return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
 }
 
@@ -916,7 +935,7 @@ static int update_implicit_feats(cmfrec_hip_session *s, bool isAi)
     const int rows_f = isAi ? m.n : m.m, rows_self = isAi ? m.m : m.n;
     const SparseShard &X = isAi ? s->Xr : s->Xc;
     const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
-    const real_t lam = (m.lam / s->w_implicit) * (scale_lam ? (real_t)rows_f : (real_t)1);
+    const real_t lam = (s->lam6[isAi ? 2 : 3] / s->w_implicit) * (scale_lam ? (real_t)rows_f : (real_t)1);   // :8469, :8510
     launch_gram(dev, s->gws, F, ldf, rows_f, kk, s->gram.ptr, (real_t)1, lam);
     HIP_CHECK(hipMemsetAsync(self, 0, (size_t)rows_self * kk * sizeof(real_t), dev.stream));
     CholCall c{self, (size_t)kk, F, ldf, kk, 0, nullptr, s->gram.ptr, 0, 0, 0, lam, lam, false, false, false, CHOL_NAZ};
@@ -939,7 +958,7 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol)
     const size_t ldF = isC ? s->ldA : s->ldB;
     const real_t w = isC ? m.w_user : m.w_item;
     const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
-    real_t lam = m.lam / w;                                                                        // collective.c:8367, :8418
+    real_t lam = s->lam6[isC ? 4 : 5] / w;                                                                    // collective.c:8367, :8418
     if (isC ? s->sparseU : s->sparseI) {
         // sparse side information: optimizeA Case 4 on its CSC -- one row of C per attribute, gathered from the
         // first k_side+k columns of the factor matrix (collective.c:8354-8386; attributes nobody has stay untouched)
@@ -988,13 +1007,21 @@ int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky,
         hipLaunchKernelGGL(copy_mat_kernel<real_t>, grid1d((size_t)m.n * kk), dim3(256), 0, st, s->B.ptr + m.k_item, s->ldB, Bp.ptr,
                            (size_t)kp, (size_t)m.n, kk);
         if (ub) hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(m.n), dim3(256), 0, st, Bp.ptr, (size_t)kp, m.n, kk, (real_t)1);
-        launch_gram(dev, s->gws, Bp.ptr, (size_t)kp, m.n, kp, G.ptr, (real_t)1, m.implicit ? m.lam : (real_t)0);
+        // lam_unique[2] for the users' systems, the bias' own lam_unique[0] as a correction of the last diagonal entry
+        // (collective.c:9066-9074, :9225-9238).  Implicit model: the Gramian keeps the lambda of the last A-step when that ran
+        // Cholesky (lam_unique[2]), else the epilogue adds the scalar lam (:10062-10075).
+        const real_t lamA = m.implicit ? (last_step_cholesky ? s->lam6[2] : m.lam) : s->lam6[2];
+        const real_t lam_bias_diff = ub ? s->lam6[0] - s->lam6[2] : (real_t)0;
+        launch_gram(dev, s->gws, Bp.ptr, (size_t)kp, m.n, kp, G.ptr, (real_t)1, m.implicit ? lamA : (real_t)0);
         if (BtB) G.download(BtB, (size_t)kp * kp, st);
         if (TransBtBinvBt && !m.implicit) {                               // collective.c:9034-9082
             M.alloc((size_t)kp * kp);
             HIP_CHECK(hipMemcpyAsync(M.ptr, G.ptr, (size_t)kp * kp * sizeof(real_t), hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kp), dim3(256), 0, st, M.ptr, kp, 0, kp,
-                               m.lam * (real_t)(m.scale_lam ? m.n : 1));
+                               lamA * (real_t)(m.scale_lam ? m.n : 1));
+            if (lam_bias_diff != 0)
+                hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(1), dim3(256), 0, st, M.ptr, kp, kp - 1, kp,
+                                   lam_bias_diff * (real_t)(m.scale_lam ? m.n : 1));
             CholCall c{Bp.ptr, (size_t)kp, nullptr, 0, kp, 0, nullptr, M.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
             int rc = launch_chol(dev, c, nullptr, m.n);
             if (rc) return rc;
@@ -1010,7 +1037,7 @@ int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky,
                 HIP_CHECK(hipMemcpyAsync(M.ptr, CtC.ptr, (size_t)kc * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
                 HIP_CHECK(hipMemcpyAsync(Cc.ptr, s->C.ptr, (size_t)m.p * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
                 hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kc), dim3(256), 0, st, M.ptr, kc, 0, kc,
-                                   m.lam * (real_t)(m.scale_lam ? m.p : 1) / w);
+                                   lamA * (real_t)(m.scale_lam ? m.p : 1) / w);
                 CholCall c{Cc.ptr, (size_t)kc, nullptr, 0, kc, 0, nullptr, M.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
                 int rc = launch_chol(dev, c, nullptr, m.p);
                 if (rc) return rc;
@@ -1034,10 +1061,12 @@ int cmfrec_hip_session_precompute(cmfrec_hip_session *s, int last_step_cholesky,
                 const real_t w_betbe = (m.implicit && !last_step_cholesky) ? (real_t)1 : w;
                 hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, w_betbe, M.ptr, kq, 0);
                 if (m.implicit) {                                         // lam is already inside G; the k_user block gets its own
-                    if (m.k_user) hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(m.k_user), dim3(256), 0, st, M.ptr, kq, 0, m.k_user, m.lam);
+                    if (m.k_user) hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(m.k_user), dim3(256), 0, st, M.ptr, kq, 0, m.k_user, lamA);
                 } else {
                     const real_t mult = m.scale_lam_sideinfo ? (real_t)(m.p + m.n) : (scale_lam ? (real_t)m.n : (real_t)1);
-                    hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kq), dim3(256), 0, st, M.ptr, kq, 0, kq, m.lam * mult);
+                    hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kq), dim3(256), 0, st, M.ptr, kq, 0, kq, lamA * mult);
+                    if (lam_bias_diff != 0)
+                        hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(1), dim3(256), 0, st, M.ptr, kq, kq - 1, kq, lam_bias_diff * mult);
                 }
                 if (BeTBe) M.download(BeTBe, (size_t)kq * kq, st);
                 if (BeTBeChol) {
@@ -1081,15 +1110,19 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
         HIP_CHECK(hipSetDevice(s->dev.device));
         const bool isAB = (which == 'A' || which == 'B'), isImp = (which == 'a' || which == 'b');
         const bool nn = (isAB || isImp) ? s->nonneg : (which == 'C' ? s->nonneg_C : s->nonneg_D);
-        const real_t l1 = isAB ? s->l1_lam : isImp ? s->l1_lam / s->w_implicit                          // collective.c:8472-8475
-                          : (which == 'C' ? s->l1_lam / s->mdl.w_user : s->l1_lam / s->mdl.w_item);   // collective.c:8369-8423
-        const bool chol = use_cholesky || !s->mdl.use_cg || nn || l1 != 0;   // common.c:725, :2781, :3320: no CG with nonneg / L1
+        // l1_lam_unique order: user bias, item bias, A, B, C, D (collective.c:8652-8654, :8823-8825, :8369-8423, :8472-8516)
+        const bool ub = !s->mdl.implicit && s->mdl.user_bias, ib = !s->mdl.implicit && s->mdl.item_bias;
+        const real_t l1 = which == 'A' ? s->l16[2] : which == 'B' ? s->l16[3] : which == 'a' ? s->l16[2] / s->w_implicit
+                          : which == 'b' ? s->l16[3] / s->w_implicit
+                          : (which == 'C' ? s->l16[4] / s->mdl.w_user : s->l16[5] / s->mdl.w_item);
+        const real_t l1_last = which == 'A' ? s->l16[ub ? 0 : 2] : which == 'B' ? s->l16[ib ? 1 : 3] : l1;
+        const bool chol = use_cholesky || !s->mdl.use_cg || nn || l1 != 0 || l1_last != 0;   // common.c:725, :2781, :3320: no CG with nonneg / L1
         struct SolveScope {                                           // the closed-form launches of this update
             const DeviceInfo &d;
-            SolveScope(const DeviceInfo &d_, bool on, int steps, real_t l1_, real_t sc) : d(d_)
-            { d.nonneg_now = on; d.max_cd_steps = steps; d.l1_now = l1_; d.l1_scale = sc; }
-            ~SolveScope() { d.nonneg_now = false; d.l1_now = 0; d.l1_scale = 1; }
-        } scope(s->dev, nn, s->max_cd_steps, l1,
+            SolveScope(const DeviceInfo &d_, bool on, int steps, real_t l1_, real_t l1l, real_t sc) : d(d_)
+            { d.nonneg_now = on; d.max_cd_steps = steps; d.l1_now = l1_; d.l1_last_now = l1l; d.l1_scale = sc; }
+            ~SolveScope() { d.nonneg_now = false; d.l1_now = 0; d.l1_last_now = 0; d.l1_scale = 1; }
+        } scope(s->dev, nn, s->max_cd_steps, l1, l1_last,
                 // the dense C / D update scales lambda -- and the penalty -- by the number of rows of U / I (common.c:2832, :2882)
                 // the Ai / Bi update (Case 3) by the rows of the fixed matrix (common.c:3131, :3182)
                 ((which == 'C' || which == 'D' || isImp) && (s->mdl.scale_lam || s->mdl.scale_lam_sideinfo))

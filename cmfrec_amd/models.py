@@ -92,6 +92,18 @@ def _side_info(M, dt):
     return np.ascontiguousarray(M, dt), None
 
 
+def _penalty(value, name):
+    """``lambda_`` / ``l1_lambda``: a number, or six numbers (user bias, item bias, A, B, C, D) like the reference
+    (cmfrec/__init__.py:99-101).  Returns (scalar, array-or-None); with an array the scalar handed to C is 0, as the
+    reference does (cmfrec/__init__.py:3179-3180)."""
+    if np.isscalar(value):
+        return float(value), None
+    arr = np.asarray(value, np.float64).reshape(-1)
+    if arr.shape[0] != 6:
+        raise ValueError("'%s' must be a single number or an array with 6 entries." % name)
+    return 0.0, arr
+
+
 class CMF_implicit(_Base):
     """Implicit-feedback model (iALS / WRMF), reference class ``CMF_implicit``."""
 
@@ -102,7 +114,8 @@ class CMF_implicit(_Base):
                  precompute_for_predictions=True, use_float=True, max_cg_steps=3,
                  precondition_cg=False, finalize_chol=False, random_state=1, verbose=False,
                  produce_dicts=False, handle_interrupt=True, nthreads=-1, n_jobs=None):
-        self.k = int(k); self.lambda_ = float(lambda_); self.alpha = float(alpha); self.use_cg = bool(use_cg)
+        self.k = int(k); self.alpha = float(alpha); self.use_cg = bool(use_cg)
+        self.lambda_, self._lam6 = _penalty(lambda_, "lambda_")
         self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
         self.w_main = float(w_main); self.w_user = float(w_user); self.w_item = float(w_item)
         self.l1_lambda = l1_lambda; self.niter = int(niter); self.nonneg = bool(nonneg)
@@ -114,9 +127,7 @@ class CMF_implicit(_Base):
         self.verbose = bool(verbose); self.handle_interrupt = bool(handle_interrupt)
         self._setup(use_float, nthreads, n_jobs)
         self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D); self.max_cd_steps = int(max_cd_steps)
-        if not np.isscalar(l1_lambda):
-            raise NotImplementedError("per-matrix l1_lambda is not implemented in cmfrec_amd")
-        self.l1_lambda = float(l1_lambda)
+        self.l1_lambda, self._l16 = _penalty(l1_lambda, "l1_lambda")
 
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None):
         """Fits the model.  ``A0``/``B0`` (optional) inject the start values instead of drawing
@@ -125,6 +136,8 @@ class CMF_implicit(_Base):
         row, col, val, m, n = _coo_triplet(X, shape)
         lib, R = self._lib()
         dt = self.dtype_
+        lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, dt)
+        l16 = None if self._l16 is None else np.ascontiguousarray(self._l16, dt)
         val = np.ascontiguousarray(val, dt)
         Uc, Us = _side_info(U, dt)
         Ic, Is = _side_info(I, dt)
@@ -153,7 +166,7 @@ class CMF_implicit(_Base):
             _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), C.c_bool(reset), C.c_int(self.random_state),
             _lib.ptr(Ucm) if (p and self.center_U) else None, _lib.ptr(Icm) if (q and self.center_I) else None,
             C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
-            C.c_size_t(len(val)), R(self.lambda_), None, R(self.l1_lambda), None,
+            C.c_size_t(len(val)), R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
             C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
@@ -184,8 +197,9 @@ class CMF_implicit(_Base):
         factors_collective_implicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main]."""
         if X is None and U is None:
             raise ValueError("Must pass at least one of 'X', 'U'.")
-        if self.l1_lambda:
+        if self.l1_lambda or self._l16 is not None:
             raise NotImplementedError("factors_multiple with l1_lambda is not implemented in cmfrec_amd")
+        lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, self.dtype_)
         lib, R = self._lib()
         dt = self.dtype_
         n = self.B_.shape[0]
@@ -201,7 +215,8 @@ class CMF_implicit(_Base):
             _lib.ptr(self.B_), C.c_int(n), _lib.ptr(self.C_) if p else None,
             _lib.ptr(self._U_colmeans) if (p and len(self._U_colmeans)) else None,
             C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
-            R(self.lambda_), R(0.), R(self.alpha), R(self.w_main), R(self.w_user), R(self._w_main_multiplier),
+            R(self.lambda_ if lam6 is None else float(lam6[2])), R(0.), R(self.alpha), R(self.w_main), R(self.w_user),
+            R(self._w_main_multiplier),
             C.c_bool(self.apply_log_transf),
             _lib.ptr(self._BeTBe) if has(self._BeTBe) else None, _lib.ptr(self._BtB) if has(self._BtB) else None,
             _lib.ptr(self._BeTBeChol) if has(self._BeTBeChol) else None, None, C.c_int(self.nthreads))
@@ -236,18 +251,17 @@ class CMF(_Base):
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
         if NA_as_zero or NA_as_zero_user or NA_as_zero_item or scale_bias_const:
             raise NotImplementedError("NA_as_zero / scale_bias_const are not implemented in cmfrec_amd")
-        if add_implicit_features and (use_cg or nonneg or l1_lambda):
+        if add_implicit_features and (use_cg or nonneg or not np.isscalar(l1_lambda) or l1_lambda):
             raise NotImplementedError("add_implicit_features: only the Cholesky solver is implemented in cmfrec_amd "
                                       "(pass use_cg=False; no nonneg / l1_lambda)")
         self.add_implicit_features = bool(add_implicit_features)
-        if not np.isscalar(l1_lambda):
-            raise NotImplementedError("per-matrix l1_lambda is not implemented in cmfrec_amd")
-        self.l1_lambda = float(l1_lambda)
+        self.l1_lambda, self._l16 = _penalty(l1_lambda, "l1_lambda")
         self.nonneg = bool(nonneg); self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D)
         self.max_cd_steps = int(max_cd_steps)
         if not (center_U and center_I):
             raise NotImplementedError("center_U / center_I = False are not implemented in cmfrec_amd")
-        self.k = int(k); self.lambda_ = float(lambda_); self.use_cg = bool(use_cg)
+        self.k = int(k); self.use_cg = bool(use_cg)
+        self.lambda_, self._lam6 = _penalty(lambda_, "lambda_")
         self.user_bias = bool(user_bias); self.item_bias = bool(item_bias); self.center = bool(center)
         self.scale_lam = bool(scale_lam); self.scale_lam_sideinfo = bool(scale_lam_sideinfo)
         self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
@@ -263,6 +277,8 @@ class CMF(_Base):
         row, col, val, m, n = _coo_triplet(X, shape)
         lib, R = self._lib()
         dt = self.dtype_
+        lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, dt)
+        l16 = None if self._l16 is None else np.ascontiguousarray(self._l16, dt)
         val = np.ascontiguousarray(val, dt)
         Uc, Us = _side_info(U, dt)
         Ic, Is = _side_info(I, dt)
@@ -302,7 +318,7 @@ class CMF(_Base):
             C.c_bool(imp), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean), _lib.ptr(Ucm),
             _lib.ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
             C.c_size_t(len(val)), None, None, C.c_bool(self.user_bias), C.c_bool(self.item_bias),
-            C.c_bool(self.center), R(self.lambda_), None, R(self.l1_lambda), None, C.c_bool(self.scale_lam),
+            C.c_bool(self.center), R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16), C.c_bool(self.scale_lam),
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(False), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
@@ -342,8 +358,9 @@ class CMF(_Base):
         factors_collective_explicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main], or ``(A, bias)``."""
         if X is None and U is None:
             raise ValueError("Must pass at least one of 'X', 'U'.")
-        if self.l1_lambda:
+        if self.l1_lambda or self._l16 is not None:
             raise NotImplementedError("factors_multiple with l1_lambda is not implemented in cmfrec_amd")
+        lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, self.dtype_)
         if self.add_implicit_features:
             raise NotImplementedError("factors_multiple with add_implicit_features is not implemented in cmfrec_amd")
         lib, R = self._lib()
@@ -366,7 +383,7 @@ class CMF(_Base):
             _lib.ptr(val), _lib.ptr(row), _lib.ptr(col), C.c_size_t(len(val)), None, None, None,
             None, C.c_int(n), None, _lib.ptr(self.B_), None, C.c_bool(False),
             C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
-            R(self.lambda_), None, R(0.), None, C.c_bool(self.scale_lam), C.c_bool(self.scale_lam_sideinfo),
+            R(self.lambda_), _lib.ptr(lam6), R(0.), None, C.c_bool(self.scale_lam), C.c_bool(self.scale_lam_sideinfo),
             C.c_bool(False), R(1.), R(self.w_main), R(self.w_user), R(self.w_implicit),
             C.c_int(n), C.c_bool(True),
             None, None, None, None, None,

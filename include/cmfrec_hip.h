@@ -347,6 +347,14 @@ int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_
 int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_implicit, const real_t *Ai, const real_t *Bi);
 int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, real_t *Bi);
 
+/* Per-matrix penalties (lam_unique / l1_lam_unique of the fit entry points, /root/reference/src/collective.c:430):
+ * six values each in the order user bias, item bias, A, B, C, D, already divided by w_main.  Either pointer may be NULL
+ * (that family keeps the scalar of the model / of set_l1).  The A / B updates use [2] / [3] and, for a fitted bias, [0] /
+ * [1] on the last unknown (:8649-8654, :8820-8825); C / D use [4] / w_user, [5] / w_item (:8367, :8418); the implicit
+ * model ignores [0], [1]. */
+int cmfrec_hip_session_set_lam_unique(cmfrec_hip_session *s, const real_t *lam_unique, const real_t *l1_lam_unique,
+                                      int max_cd_steps);
+
 /* L1 penalty (one value for every matrix: A, B and the bias columns take l1_lam, C / D l1_lam / w_user, / w_item;
  * scaled per row like lambda).  Systems are then solved by solve_elasticnet (src/common.c:2228-2294), or by
  * solve_nonneg with the penalty on the right-hand side where a non-negativity constraint applies; no CG. */

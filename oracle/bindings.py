@@ -83,6 +83,13 @@ class Oracle:
         """L1 penalty of the following fits (solve_elasticnet / shifted solve_nonneg; no CG)."""
         self.lib.oracle_set_l1(self._r(l1_lam), C.c_int(max_cd_steps))
 
+    def set_lam_unique(self, lam_unique=None, l1_lam_unique=None):
+        """Per-matrix penalties of the following fits (user bias, item bias, A, B, C, D); None switches them off.  The
+        explicit fit expects them divided by w_main already, the implicit one divides entries 2..5 itself."""
+        cv = lambda a: None if a is None else np.ascontiguousarray(a, self.dtype)
+        self._lam6, self._l16 = cv(lam_unique), cv(l1_lam_unique)
+        self.lib.oracle_set_lam_unique(_ptr(self._lam6), _ptr(self._l16))
+
     def set_nonneg_now(self, on, max_cd_steps=100):
         """The same for operator-level calls outside a fit."""
         self.lib.oracle_set_nonneg_now(C.c_bool(on), C.c_int(max_cd_steps))
@@ -659,9 +666,12 @@ class Reference:
                                     apply_log_transf=False, Cm=None, Dm=None, U=None, II=None,
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
                                     precompute=False, m=None, n=None, U_coo=None, I_coo=None, nonneg=False,
-                                    nonneg_C=False, nonneg_D=False, max_cd_steps=100, l1_lam=0.0):
+                                    nonneg_C=False, nonneg_D=False, max_cd_steps=100, l1_lam=0.0, lam_unique=None,
+                                    l1_lam_unique=None):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
+        lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
+        l16 = None if l1_lam_unique is None else np.ascontiguousarray(l1_lam_unique, self.dtype)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         wmm = np.zeros(1, self.dtype)
@@ -681,7 +691,7 @@ class Reference:
         ret = self.lib.fit_collective_implicit_als(
             _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), C.c_bool(reset_values), C.c_int(seed), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
-            self._r(lam), None, self._r(l1_lam), None,
+            self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
@@ -703,9 +713,12 @@ class Reference:
                                     nthreads=1, use_cg=True, max_cg_steps=3, precondition_cg=False,
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
-                                    l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0):
+                                    l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
+                                    l1_lam_unique=None):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
+        lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
+        l16 = None if l1_lam_unique is None else np.ascontiguousarray(l1_lam_unique, self.dtype)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)
         Ai = np.zeros((A.shape[0], k + k_main), self.dtype) if add_implicit_features else None
@@ -739,7 +752,7 @@ class Reference:
             _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             None, None, C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
-            self._r(lam), None, self._r(l1_lam), None,
+            self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],

@@ -184,15 +184,30 @@ void oracle_set_nonneg(bool nonneg, bool nonneg_C, bool nonneg_D, int_t max_cd_s
 void oracle_set_nonneg_now(bool on, int_t max_cd_steps) { g_nonneg = on; g_max_cd = max_cd_steps; }
 void oracle_set_l1(real_t l1_lam, int_t max_cd_steps) { g_l1_base = l1_lam; g_l1 = 0; g_max_cd = max_cd_steps; }
 void oracle_set_l1_now(real_t l1, int_t max_cd_steps) { g_l1 = l1; g_max_cd = max_cd_steps; }
+/* per-matrix penalties (lam_unique / l1_lam_unique, collective.c:430): user bias, item bias, A, B, C, D -- as the caller
+ * passes them (the fits divide by w_main like the reference, :7503-7520, :9793-9809) */
+static bool g_has_lam6 = false, g_has_l16 = false;
+static real_t g_lam6[6], g_l16[6];
+void oracle_set_lam_unique(const real_t *lam6, const real_t *l16)
+{
+    g_has_lam6 = lam6 != NULL; g_has_l16 = l16 != NULL;
+    for (int i = 0; i < 6; i++) { g_lam6[i] = lam6 ? lam6[i] : 0; g_l16[i] = l16 ? l16[i] : 0; }
+}
+static bool g_l1_last_set = false;       /* the last unknown (a fitted bias) carries its own L1 penalty */
+static real_t g_l1_last = 0;
 static void solve_sym_(int_t k, real_t *M, int_t ld, real_t *b)
 {
     const real_t l1 = g_l1 * t_l1_mult;
+    const real_t l1_last = g_l1_last_set ? g_l1_last * t_l1_mult : l1;
     if (g_nonneg) {
-        if (l1 != 0) for (int_t i = 0; i < k; i++) b[i] -= l1;                  /* common.c:2148-2154 */
+        if (l1 != 0 || l1_last != 0) {                                          /* common.c:2148-2154 */
+            for (int_t i = 0; i < k - 1; i++) b[i] -= l1;
+            b[k - 1] -= l1_last;
+        }
         solve_nonneg_(k, M, ld, b, g_max_cd);
         return;
     }
-    if (l1 != 0) { solve_elasticnet_(k, M, ld, b, l1, l1, g_max_cd); return; }
+    if (l1 != 0 || l1_last != 0) { solve_elasticnet_(k, M, ld, b, l1, l1_last, g_max_cd); return; }
     if (chol_upper_(k, M, ld) == 0) { chol_solve_upper_(k, M, ld, b); return; }
     for (int_t i = 0; i < k; i++) b[i] = NAN;
 }
@@ -1058,41 +1073,47 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
     if (II != NULL) Ic = center_by_cols_dense(II, n_i, q, I_colmeans);
     if (w_main != (real_t)1.) { lam /= w_main; w_user /= w_main; w_item /= w_main; }   /* :9786-9811 */
     const real_t l1f = g_l1_base / ((w_main_orig != (real_t)1.) ? w_main_orig : (real_t)1.);   /* :9789 */
-    if (g_nn_AB || g_nn_C || g_nn_D || l1f != 0) use_cg = false;                  /* :9568-9571: any of them */
+    if (g_nn_AB || g_nn_C || g_nn_D || l1f != 0 || g_has_l16) use_cg = false;     /* :9568-9571: any of them */
+    const real_t wdiv = (w_main_orig != (real_t)1.) ? w_main_orig : (real_t)1.;   /* :9793-9809: entries 2..5 */
+    const real_t lamA = g_has_lam6 ? g_lam6[2] / wdiv : lam, lamB = g_has_lam6 ? g_lam6[3] / wdiv : lam;
+    const real_t lamC = g_has_lam6 ? g_lam6[4] / wdiv : lam, lamD = g_has_lam6 ? g_lam6[5] / wdiv : lam;
+    const real_t l1A = g_has_l16 ? g_l16[2] / wdiv : l1f, l1B = g_has_l16 ? g_l16[3] / wdiv : l1f;
+    const real_t l1C = g_has_l16 ? g_l16[4] / wdiv : l1f, l1D = g_has_l16 ? g_l16[5] / wdiv : l1f;
     if (!use_cg) finalize_chol = false;                                           /* :9518 */
     for (int_t iter = 0; iter < niter; iter++) {                                  /* :9827-10045 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
-        g_nonneg = g_nn_C; g_l1 = l1f / w_user;
+        g_nonneg = g_nn_C; g_l1 = l1C / w_user;
         if (U != NULL)                                                            /* :9834-9873 */
             oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A, (size_t)k_totA, p, m_u, k_user + k,
-                                        Uc, (size_t)p, true, lam / w_user, lam / w_user, false, nthreads);
-        g_nonneg = g_nn_D; g_l1 = l1f / w_item;
+                                        Uc, (size_t)p, true, lamC / w_user, lamC / w_user, false, nthreads);
+        g_nonneg = g_nn_D; g_l1 = l1D / w_item;
         if (II != NULL)                                                           /* :9877-9917 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B, (size_t)k_totB, q, n_i, k_item + k,
-                                        Ic, (size_t)q, true, lam / w_item, lam / w_item, false, nthreads);
-        g_nonneg = g_nn_AB; g_l1 = l1f;
+                                        Ic, (size_t)q, true, lamD / w_item, lamD / w_item, false, nthreads);
+        g_nonneg = g_nn_AB; g_l1 = l1B;
         if (II != NULL && use_cg)                                                 /* :9924-9963 */
             oracle_optimizeA_collective_cg(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m_x, q, k, k_main, k_item, k_user,
-                                           csc_p, csc_i, csc_v, Ic, lam, w_item, lam, false, false, true,
+                                           csc_p, csc_i, csc_v, Ic, lamB, w_item, lamB, false, false, true,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (II != NULL)
             oracle_optimizeA_collective_implicit_chol(B, (size_t)k_totB, A, (size_t)k_totA, D, n, n_i, m_x, q,
                                                       k, k_main, k_item, k_user, csc_p, csc_i, csc_v,
-                                                      Ic, lam, w_item, nthreads);
+                                                      Ic, lamB, w_item, nthreads);
         else                                                                      /* :9965-9981 */
             oracle_optimizeA_implicit(B + k_item, (size_t)k_totB, A + k_user, (size_t)k_totA, n, m_x, k + k_main,
-                                      csc_p, csc_i, csc_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+                                      csc_p, csc_i, csc_v, lamB, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+        g_l1 = l1A;
         if (U != NULL && use_cg)                                                  /* :9985-10022 */
             oracle_optimizeA_collective_cg(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n_x, p, k, k_main, k_user, k_item,
-                                           csr_p, csr_i, csr_v, Uc, lam, w_user, lam, false, false, true,
+                                           csr_p, csr_i, csr_v, Uc, lamA, w_user, lamA, false, false, true,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (U != NULL)
             oracle_optimizeA_collective_implicit_chol(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n_x, p,
                                                       k, k_main, k_user, k_item, csr_p, csr_i, csr_v,
-                                                      Uc, lam, w_user, nthreads);
+                                                      Uc, lamA, w_user, nthreads);
         else
             oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n_x, k + k_main,
-                                      csr_p, csr_i, csr_v, lam, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+                                      csr_p, csr_i, csr_v, lamA, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
     }
     g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
     free(Uc); free(Ic);
@@ -1165,7 +1186,15 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     if (imp && (use_cg || m_u > m_x || n_i > n_x)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     const real_t l1f = g_l1_base;
-    if (g_nn_AB || l1f != 0) use_cg = false;                                   /* :7474-7479 */
+    if (g_nn_AB || l1f != 0 || g_has_l16) use_cg = false;                      /* :7474-7479 */
+    /* lam_unique / l1_lam_unique: [2] / [3] for A / B with [0] / [1] on a fitted bias (:8649-8654, :8820-8825), [4] / [5] for
+     * C / D (:8367, :8418), [3] / [2] for Bi / Ai (:8469, :8510) */
+    const real_t lamA = g_has_lam6 ? g_lam6[2] : lam, lamB = g_has_lam6 ? g_lam6[3] : lam;
+    const real_t lamC = g_has_lam6 ? g_lam6[4] : lam, lamD = g_has_lam6 ? g_lam6[5] : lam;
+    const real_t lamAl = (g_has_lam6 && user_bias) ? g_lam6[0] : lamA, lamBl = (g_has_lam6 && item_bias) ? g_lam6[1] : lamB;
+    const real_t l1A = g_has_l16 ? g_l16[2] : l1f, l1B = g_has_l16 ? g_l16[3] : l1f;
+    const real_t l1C = g_has_l16 ? g_l16[4] : l1f, l1D = g_has_l16 ? g_l16[5] : l1f;
+    const real_t l1Al = (g_has_l16 && user_bias) ? g_l16[0] : l1A, l1Bl = (g_has_l16 && item_bias) ? g_l16[1] : l1B;
     if (!use_cg) finalize_chol = false;                                        /* :7481 */
     int_t has_bias = (user_bias || item_bias) ? 1 : 0;
     int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
@@ -1193,7 +1222,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     }
     if (has_bias && init_biases)                                               /* :8164-8226 */
         oracle_initialize_biases_twosided(m, n, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v,
-                                          lam, lam, scale_lam, biasA, biasB);
+                                          g_has_lam6 ? g_lam6[0] : lam, g_has_lam6 ? g_lam6[1] : lam, scale_lam, biasA, biasB);
     if (has_bias) {                                                            /* :8283-8317 */
         for (int_t r = 0; r < m; r++) {
             memcpy(A_bias + (size_t)r * ldA, A + (size_t)r * k_totA, (size_t)k_totA * sizeof(real_t));
@@ -1207,46 +1236,47 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
 
     for (int_t iter = 0; iter < niter; iter++) {                               /* :8334-8898 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
-        g_nonneg = g_nn_C; g_l1 = l1f / w_user;
+        g_nonneg = g_nn_C; g_l1 = l1C / w_user; g_l1_last_set = false;
         if (U != NULL)                                                         /* :8358-8387 */
             oracle_optimizeA_dense_full(C, (size_t)(k_user + k), A_bias, ldA, p, m_u, k_user + k,
-                                        Uc, (size_t)p, true, lam / w_user, lam / w_user, scale_lam, nthreads);
-        g_nonneg = g_nn_D; g_l1 = l1f / w_item;
+                                        Uc, (size_t)p, true, lamC / w_user, lamC / w_user, scale_lam, nthreads);
+        g_nonneg = g_nn_D; g_l1 = l1D / w_item;
         if (II != NULL)                                                        /* :8409-8441 */
             oracle_optimizeA_dense_full(D, (size_t)(k_item + k), B_bias, ldB, q, n_i, k_item + k,
-                                        Ic, (size_t)q, true, lam / w_item, lam / w_item, scale_lam, nthreads);
-        g_nonneg = g_nn_AB; g_l1 = l1f / w_implicit;
+                                        Ic, (size_t)q, true, lamD / w_item, lamD / w_item, scale_lam, nthreads);
+        g_nonneg = g_nn_AB; g_l1 = l1B / w_implicit;
         if (imp) {                                                             /* :8448-8534 */
             oracle_optimizeA_naz(Bi, (size_t)(k + k_main), A_bias + k_user, ldA, n, m, k + k_main, csc_p, csc_i, NULL,
-                                 lam / w_implicit, lam / w_implicit, scale_lam, nthreads);
+                                 lamB / w_implicit, lamB / w_implicit, scale_lam, nthreads);
+            g_l1 = l1A / w_implicit;
             oracle_optimizeA_naz(Ai, (size_t)(k + k_main), B_bias + k_item, ldB, m, n, k + k_main, csr_p, csr_i, NULL,
-                                 lam / w_implicit, lam / w_implicit, scale_lam, nthreads);
+                                 lamA / w_implicit, lamA / w_implicit, scale_lam, nthreads);
         }
-        g_nonneg = g_nn_AB; g_l1 = l1f;
+        g_nonneg = g_nn_AB; g_l1 = l1B; g_l1_last = l1Bl; g_l1_last_set = true;
         if (item_bias)                                                         /* :8538-8543 */
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
         if (user_bias)                                                         /* :8566-8570 */
             for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
         if (II != NULL && use_cg)                                              /* :8634-8678 */
             oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
-                                           csc_p, csc_i, csc_v, Ic, lam, w_item, lam, scale_lam, scale_lam_sideinfo, false,
+                                           csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (II != NULL || imp)                                            /* :8612 */
             collective_chol_impl(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q,
                                              k, k_main + (int_t)item_bias, k_item, k_user,
-                                             csc_p, csc_i, csc_v, Ic, lam, w_item, lam,
+                                             csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Ai : NULL, k_main, w_implicit);
         else                                                                   /* :8680-8717 */
             oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
                                       k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
-                                      lam, lam, scale_lam, false, nthreads,
+                                      lamB, lamBl, scale_lam, false, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
         if (II != NULL) {
         if (n_i > n_x) {                                            /* rows known from side information only */
             if (!use_cg)
                 for (int_t r = n_x; r < n_i; r++) memset(B_bias + (size_t)r * ldB, 0, (size_t)(k_totB + has_bias) * sizeof(real_t));
             oracle_optimizeA_dense_full(B_bias + (size_t)n_x * ldB, ldB, D, (size_t)(k_item + k), n_i - n_x, q,
-                                        k_item + k, Ic + (size_t)n_x * q, (size_t)q, false, lam / w_item, lam / w_item,
+                                        k_item + k, Ic + (size_t)n_x * q, (size_t)q, false, lamB / w_item, lamB / w_item,
                                         scale_lam, nthreads);
         }
         }
@@ -1254,28 +1284,29 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
             for (int_t c = 0; c < n; c++) biasB[c] = B_bias[(size_t)c * ldB + k_totB];
         if (user_bias)                                                         /* :8728-8732 */
             for (int_t c = 0; c < n; c++) B_bias[(size_t)c * ldB + k_totB] = 1;
+        g_l1 = l1A; g_l1_last = l1Al;
         if (item_bias)                                                         /* :8750-8754 */
             for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
         if (U != NULL && use_cg)                                               /* :8805-8845 */
             oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
-                                           csr_p, csr_i, csr_v, Uc, lam, w_user, lam, scale_lam, scale_lam_sideinfo, false,
+                                           csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
         else if (U != NULL || imp)                                             /* :8783 */
             collective_chol_impl(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p,
                                              k, k_main + (int_t)user_bias, k_user, k_item,
-                                             csr_p, csr_i, csr_v, Uc, lam, w_user, lam,
+                                             csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Bi : NULL, k_main, w_implicit);
         else                                                                   /* :8847-8876 */
             oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,
                                       k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
-                                      lam, lam, scale_lam, false, nthreads,
+                                      lamA, lamAl, scale_lam, false, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
         if (U != NULL) {
         if (m_u > m_x) {                                            /* rows known from side information only */
             if (!use_cg)
                 for (int_t r = m_x; r < m_u; r++) memset(A_bias + (size_t)r * ldA, 0, (size_t)(k_totA + has_bias) * sizeof(real_t));
             oracle_optimizeA_dense_full(A_bias + (size_t)m_x * ldA, ldA, C, (size_t)(k_user + k), m_u - m_x, p,
-                                        k_user + k, Uc + (size_t)m_x * p, (size_t)p, false, lam / w_user, lam / w_user,
+                                        k_user + k, Uc + (size_t)m_x * p, (size_t)p, false, lamA / w_user, lamA / w_user,
                                         scale_lam, nthreads);
         }
         }
@@ -1291,7 +1322,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     }
     if (user_bias) for (int_t r = m_x; r < m; r++) biasA[r] = 0;                /* :8296, :8923: no bias beyond X */
     if (item_bias) for (int_t c = n_x; c < n; c++) biasB[c] = 0;                /* :8308, :8925 */
-    g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
+    g_nonneg = false; g_l1 = 0; t_l1_mult = 1; g_l1_last_set = false;
     free(csr_orig); free(csc_orig); free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     return 0;

@@ -253,6 +253,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g14_implicit_feats_" + tag, **out)
 
+        # ---- G15: per-matrix penalties (lam_unique / l1_lam_unique) ----
+        out = {}
+        d = gc.nonneg_problem(dt)
+        for ci, (name, implicit, side, opts) in enumerate(gc.LAM_UNIQUE_CASES):
+            r = gc.lam_unique_reference(R, d, implicit, side, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g15_lam_unique_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

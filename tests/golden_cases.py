@@ -360,7 +360,7 @@ def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
 def compare_fits(got, exp):
     """Largest relative error over the factor matrices / biases both sides carry."""
     err = 0.0
-    for key in ("A", "B", "C", "D", "biasA", "biasB", "Ai", "Bi"):
+    for key in ("A", "B", "C", "D", "biasA", "biasB", "Ai", "Bi", "TransBtBinvBt", "BeTBeChol"):
         if key in exp and exp[key] is not None and got.get(key) is not None and np.size(exp[key]):
             e = maxrel(got[key], exp[key])
             err = max(err, e) if np.isfinite(e) else float("inf")        # NaN anywhere is a failure, never silently dropped
@@ -530,4 +530,95 @@ def implicit_feats_hip(d, side, opts, dtype):
     out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_, Ai=mdl.Ai_, Bi=mdl.Bi_)
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
+# ---- per-matrix penalties (lam_unique / l1_lam_unique: user bias, item bias, A, B, C, D; collective.c:430) ------------
+LAM6 = [0.7, 0.2, 0.4, 0.25, 1.5, 0.6]
+L16 = [0.02, 0.0, 0.05, 0.03, 0.04, 0.01]
+# (name, implicit, side information, options)
+LAM_UNIQUE_CASES = [
+    ("explicit chol", False, False, dict(lam_unique=LAM6, use_cg=False)),
+    ("explicit cg finalize", False, False, dict(lam_unique=LAM6, use_cg=True, finalize_chol=True, scale_lam=True)),
+    ("explicit side info", False, True, dict(lam_unique=LAM6, use_cg=False, k_user=1, k_item=2, w_main=2.0)),
+    ("explicit side info cg", False, True, dict(lam_unique=LAM6, use_cg=True, item_bias=False, scale_lam_sideinfo=True)),
+    ("explicit l1 per matrix", False, True, dict(lam_unique=LAM6, l1_lam_unique=L16)),
+    ("explicit implicit features", False, False, dict(lam_unique=LAM6, use_cg=False, add_implicit_features=True, w_implicit=0.8)),
+    ("implicit cg", True, False, dict(lam_unique=LAM6, use_cg=True)),
+    ("implicit side info chol", True, True, dict(lam_unique=LAM6, use_cg=False, k_user=1, w_main=0.5)),
+    ("implicit side info l1 + nonneg", True, True, dict(lam_unique=LAM6, l1_lam_unique=L16, nonneg=True)),
+    # the matrices for predictions: lam_unique[2] on the diagonals, the bias' lam_unique[0] as a correction of the last
+    # entry (collective.c:9066-9074, :9225-9238)
+    ("explicit precompute", False, True, dict(lam_unique=LAM6, use_cg=False, scale_lam=True, precompute=True)),
+]
+
+
+def lam_unique_reference(R, d, implicit, side, opts, nthreads=2):
+    o = dict(opts)
+    A0, B0 = _impf_start(d, o)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    if implicit:
+        r = R.fit_collective_implicit_als(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, niter=3,
+                                          U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads,
+                                          use_cg=o.pop("use_cg", False), **o)
+        r = r if isinstance(r, dict) else dict(C=None, D=None)
+        return dict(A=A0, B=B0, C=r.get("C"), D=r.get("D"))
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads,
+                                      use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+    if r["Ai"] is not None: out.update(Ai=r["Ai"], Bi=r["Bi"])
+    if r.get("pre"): out.update(TransBtBinvBt=r["pre"]["TransBtBinvBt"], BeTBeChol=np.triu(r["pre"]["BeTBeChol"]))
+    return out
+
+
+def lam_unique_oracle(O, d, implicit, side, opts, nthreads=2):
+    o = dict(opts)
+    wm = o.get("w_main", 1.0); o.pop("precompute", None)
+    lam6 = np.asarray(o.pop("lam_unique"), np.float64); l16 = o.pop("l1_lam_unique", None)
+    O.set_nonneg(o.pop("nonneg", False), False, False, 100)
+    try:
+        A0, B0 = _impf_start(d, o)
+        U, II = (d["U"], d["I"]) if side else (None, None)
+        if implicit:          # the implicit driver rescales by w_main itself
+            O.set_lam_unique(lam6, l16)
+            r = O.fit_implicit_als_sideinfo(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, niter=3, U=U, II=II,
+                                            w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=o.pop("use_cg", False), **o)
+            return dict(A=A0, B=B0, C=r.get("C"), D=r.get("D"))
+        O.set_lam_unique(lam6 / wm, None if l16 is None else np.asarray(l16, np.float64) / wm)
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                               niter=3, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=o.pop("use_cg", False),
+                               finalize_chol=o.pop("finalize_chol", False), **o)
+        assert r["ret"] == 0
+        out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+        if r["Ai"] is not None: out.update(Ai=r["Ai"], Bi=r["Bi"])
+        return out
+    finally:
+        O.set_nonneg(False, False, False, 100)
+        O.set_lam_unique(None, None)
+
+
+def lam_unique_hip(d, implicit, side, opts, dtype):
+    from cmfrec_amd import CMF, CMF_implicit
+    o = dict(opts)
+    o["lambda_"] = o.pop("lam_unique")
+    if "l1_lam_unique" in o:
+        o["l1_lambda"] = o.pop("l1_lam_unique")
+    A0, B0 = _impf_start(d, o)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    common = dict(k=d["k"], niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32,
+                  precompute_for_predictions=o.pop("precompute", False))
+    shape = (d["m"], d["n"])
+    if implicit:
+        mdl = CMF_implicit(alpha=1.5, use_cg=o.pop("use_cg", False), **common, **o)
+        mdl.fit((d["row"], d["col"], d["counts"]), U=U, I=II, shape=shape, A0=A0, B0=B0)
+        return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_)
+    mdl = CMF(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **common, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=shape, A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    if mdl.add_implicit_features: out.update(Ai=mdl.Ai_, Bi=mdl.Bi_)
+    if mdl.precompute_for_predictions: out.update(TransBtBinvBt=mdl._TransBtBinvBt, BeTBeChol=np.triu(mdl._BeTBeChol))
     return out

@@ -210,3 +210,19 @@ def test_implicit_features(oracles, dtype):
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert exp and "Ai" in exp and gc.compare_fits(got, exp) < tol, name
         assert gc.compare_fits(got, gc.implicit_feats_oracle(oracles[dtype], d, side, opts)) < tol, name
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_lam_unique(oracles, dtype):
+    """G15 through the estimators (lambda_ / l1_lambda as six numbers): per-matrix penalties in every update, the bias'
+    own penalty on the last unknown, and the prediction matrices built from them."""
+    g = gc.load("g15_lam_unique", dtype)
+    d = gc.nonneg_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, implicit, side, opts) in enumerate(gc.LAM_UNIQUE_CASES):
+        got = gc.lam_unique_hip(d, implicit, side, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        if opts.get("precompute"):
+            assert "TransBtBinvBt" in exp and "TransBtBinvBt" in got
+        assert gc.compare_fits(got, gc.lam_unique_oracle(oracles[dtype], d, implicit, side, opts)) < tol, name

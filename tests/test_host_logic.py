@@ -27,11 +27,14 @@ def test_unsupported_options_raise():
         CMF(method="lbfgs")
     with pytest.raises(NotImplementedError):
         CMF(NA_as_zero=True)
-    with pytest.raises(NotImplementedError):
-        CMF_implicit(l1_lambda=np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6]))
+    six = CMF_implicit(l1_lambda=np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6]), lambda_=[1, 2, 3, 4, 5, 6])
+    assert six.l1_lambda == 0.0 and six._l16[5] == 0.6 and six.lambda_ == 0.0 and six._lam6[2] == 3.0   # scalar 0 + array, like the reference
+    with pytest.raises(ValueError):
+        CMF(lambda_=[1.0, 2.0])
     assert CMF_implicit(l1_lambda=0.1).l1_lambda == 0.1
     with pytest.raises(NotImplementedError):
-        CMF(add_implicit_features=True)
+        CMF(add_implicit_features=True)                      # default use_cg=True: only the Cholesky solver is built
+    assert CMF(add_implicit_features=True, use_cg=False).add_implicit_features
     assert CMF(nonneg=True, nonneg_C=True).nonneg_C and CMF_implicit(nonneg=True, max_cd_steps=50).max_cd_steps == 50
 
 

@@ -161,3 +161,14 @@ def test_implicit_features(oracles, dtype):
         got = gc.implicit_feats_oracle(oracles[dtype], d, side, opts)
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert exp and "Ai" in exp and gc.compare_fits(got, exp) < TOL[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lam_unique(oracles, dtype):
+    """G15: per-matrix penalties lam_unique / l1_lam_unique in both models, the reference's outputs."""
+    g = gc.load("g15_lam_unique", dtype)
+    d = gc.nonneg_problem(dtype)
+    for ci, (name, implicit, side, opts) in enumerate(gc.LAM_UNIQUE_CASES):
+        got = gc.lam_unique_oracle(oracles[dtype], d, implicit, side, opts)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name

@@ -282,3 +282,16 @@ def test_implicit_features_live(oracles, refs, dtype):
         exp = gc.implicit_feats_reference(refs[dtype], d, side, opts, nthreads=3)
         got = gc.implicit_feats_oracle(oracles[dtype], d, side, opts, nthreads=1)
         assert np.abs(exp["Ai"]).sum() > 0 and gc.compare_fits(got, exp) < tol, name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lam_unique_live(oracles, refs, dtype):
+    """lam_unique / l1_lam_unique: A / B take [2] / [3] with [0] / [1] on a fitted bias (collective.c:8649-8654, :8820-8825),
+    C / D [4] / [5] (:8367, :8418), Bi / Ai [3] / [2] (:8469, :8510); the implicit model ignores the bias slots."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    d = gc.nonneg_problem(dtype, seed=59)
+    for name, implicit, side, opts in gc.LAM_UNIQUE_CASES:
+        exp = gc.lam_unique_reference(refs[dtype], d, implicit, side, opts, nthreads=3)
+        got = gc.lam_unique_oracle(oracles[dtype], d, implicit, side, opts, nthreads=1)
+        assert gc.compare_fits(got, exp) < tol, name
