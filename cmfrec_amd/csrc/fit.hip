@@ -60,6 +60,48 @@ int fail(bool verbose, const char *msg)
     return 2;
 }
 
+// Dense side information with missing values (NaN).  The reference centres the present entries of each column
+// (center_by_cols, common.c:4938-4997) and then uses, for every row / column, only what is present -- the same
+// arithmetic as its sparse-side-information route run on the centred values (collective.c:1566-1653: the C^T C block
+// and the right-hand side over the present attributes, lambda scaled by their count; optimizeA Case 2 for C / D).  So
+// such a matrix is handed to the sparse route as COO triplets of its centred present entries.
+struct DenseNanSide {
+    std::vector<int_t> row, col;
+    std::vector<real_t> val;
+    bool convert(const real_t *M, int_t rows, int_t cols, real_t *means)
+    {
+        bool any = false;
+        for (size_t e = 0; e < (size_t)rows * cols && !any; e++) any = std::isnan(M[e]);
+        if (!any) return false;
+        std::vector<double> sum((size_t)cols, 0.0);
+        std::vector<size_t> cnt((size_t)cols, 0);
+        for (int_t r = 0; r < rows; r++)
+            for (int_t c = 0; c < cols; c++) {
+                const real_t v = M[(size_t)r * cols + c];
+                if (!std::isnan(v)) { sum[c] += v; cnt[c]++; }
+            }
+        for (int_t c = 0; means && c < cols; c++) means[c] = (real_t)(sum[c] / (double)cnt[c]);
+        for (int_t r = 0; r < rows; r++)
+            for (int_t c = 0; c < cols; c++) {
+                const real_t v = M[(size_t)r * cols + c];
+                if (std::isnan(v)) continue;
+                row.push_back(r); col.push_back(c); val.push_back(means ? v - means[c] : v);
+            }
+        return true;
+    }
+};
+
+// column means of sparse side information are reported like the reference does (common.c:4976-4990); the fit itself runs on
+// the values as given (the centred copy center_by_cols makes is not the one coo_to_csr_and_csc reads, collective.c:6541-6558)
+void sparse_colmeans(const int_t *col, const real_t *val, size_t nnz, int_t cols, real_t *means)
+{
+    if (!means) return;
+    std::vector<double> sum((size_t)cols, 0.0);
+    std::vector<size_t> cnt((size_t)cols, 0);
+    for (size_t e = 0; e < nnz; e++) { sum[col[e]] += val[e]; cnt[col[e]]++; }
+    for (int_t c = 0; c < cols; c++) means[c] = (real_t)(sum[c] / (double)cnt[c]);
+}
+
 int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose, bool implicit_feats = false)
 {
     for (int it = 0; it < niter; it++) {
@@ -128,15 +170,33 @@ int_t fit_collective_implicit_als(
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.
+    // dense side information with NaN -> the sparse route on its centred present entries
+    DenseNanSide nanU, nanI;
+    const bool hadU = (U != nullptr);
+    bool nan_side = false;
+    if (U && m_u > 0 && p > 0 && nanU.convert(U, m_u, p, U_colmeans)) {
+        U = nullptr; U_row = nanU.row.data(); U_col = nanU.col.data(); U_sp = nanU.val.data(); nnz_U = nanU.val.size(); nan_side = true;
+    } else if (U == nullptr && nnz_U > 0 && U_row && U_col && U_sp) {
+        bool ok = true;
+        for (size_t e = 0; e < nnz_U && ok; e++) ok = (U_col[e] >= 0 && U_col[e] < p);
+        if (ok) sparse_colmeans(U_col, U_sp, nnz_U, p, U_colmeans);
+    }
+    if (II && n_i > 0 && q > 0 && nanI.convert(II, n_i, q, I_colmeans)) {
+        II = nullptr; I_row = nanI.row.data(); I_col = nanI.col.data(); I_sp = nanI.val.data(); nnz_I = nanI.val.size(); nan_side = true;
+    } else if (II == nullptr && nnz_I > 0 && I_row && I_col && I_sp) {
+        bool ok = true;
+        for (size_t e = 0; e < nnz_I && ok; e++) ok = (I_col[e] >= 0 && I_col[e] < q);
+        if (ok) sparse_colmeans(I_col, I_sp, nnz_I, q, I_colmeans);
+    }
+    if (nan_side && nnz_U == 0 && nanU.row.empty() && hadU && U == nullptr)
+        return fail(verbose, "cmfrec_hip: U has no present entries.");
+    // side information: dense or sparse COO (missing = absent).  Sparse: rows within X.
     const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
     if (NA_as_zero_U || NA_as_zero_I) return fail(verbose, "cmfrec_hip: NA_as_zero_U / NA_as_zero_I are not implemented.");
     if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
         return fail(verbose, "cmfrec_hip: sparse side information must be COO triplets with rows inside X.");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
     if (II == nullptr && !spI) { n_i = 0; q = 0; }
-    if (U) for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
-    if (II) for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
     for (size_t e = 0; spU && e < nnz_U; e++)
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
@@ -145,6 +205,11 @@ int_t fit_collective_implicit_als(
     if ((l1_lam != 0 || l1_lam_unique) && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
     if (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique) use_cg = false;    // collective.c:9568-9571 (any of them, unlike the explicit model)
+    // For rows with few missing values the reference corrects a precomputed Gramian instead of summing the present entries
+    // (factors_closed_form, common.c:762-790): the same solution with the Cholesky solver, but CG then restarts from zero with
+    // k steps (:2958-2985) and the non-negative / L1 solvers see another matrix layout -- not restated, so not offered.
+    if (nan_side && (use_cg || nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
+        return fail(verbose, "cmfrec_hip: NaN in dense side information: only the plain Cholesky solver is implemented.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
@@ -233,8 +298,8 @@ int_t fit_collective_implicit_als(
     if ((rc_loop == 0 || rc_loop == 3) && precompute_for_predictions) {   // collective.c:10056-10115 (also after an interrupt, :10034-10043)
         if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }
         const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
-        int rc2 = cmfrec_hip_session_precompute(s, last_chol, 0, precomputedBtB, nullptr, U ? precomputedBeTBe : nullptr,
-                                                U ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
+        int rc2 = cmfrec_hip_session_precompute(s, last_chol, 0, precomputedBtB, nullptr, hadU ? precomputedBeTBe : nullptr,
+                                                hadU ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
         if (rc2) rc_loop = rc2;
         if (verbose) printf("  done\n");
         tm.lap("precompute epilogue");
@@ -273,6 +338,26 @@ int_t fit_collective_explicit_als(
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
     if (Xfull || weight || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I)
         return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero are not implemented.");
+    // dense side information with NaN -> the sparse route on its centred present entries
+    DenseNanSide nanU, nanI;
+    const bool hadU = (U != nullptr);
+    bool nan_side = false;
+    if (U && m_u > 0 && p > 0 && nanU.convert(U, m_u, p, U_colmeans)) {
+        U = nullptr; U_row = nanU.row.data(); U_col = nanU.col.data(); U_sp = nanU.val.data(); nnz_U = nanU.val.size(); nan_side = true;
+    } else if (U == nullptr && nnz_U > 0 && U_row && U_col && U_sp) {
+        bool ok = true;
+        for (size_t e = 0; e < nnz_U && ok; e++) ok = (U_col[e] >= 0 && U_col[e] < p);
+        if (ok) sparse_colmeans(U_col, U_sp, nnz_U, p, U_colmeans);
+    }
+    if (II && n_i > 0 && q > 0 && nanI.convert(II, n_i, q, I_colmeans)) {
+        II = nullptr; I_row = nanI.row.data(); I_col = nanI.col.data(); I_sp = nanI.val.data(); nnz_I = nanI.val.size(); nan_side = true;
+    } else if (II == nullptr && nnz_I > 0 && I_row && I_col && I_sp) {
+        bool ok = true;
+        for (size_t e = 0; e < nnz_I && ok; e++) ok = (I_col[e] >= 0 && I_col[e] < q);
+        if (ok) sparse_colmeans(I_col, I_sp, nnz_I, q, I_colmeans);
+    }
+    if (nan_side && nnz_U == 0 && nanU.row.empty() && hadU && U == nullptr)
+        return fail(verbose, "cmfrec_hip: U has no present entries.");
     // implicit features (Ai, Bi on the binary "was observed" matrix): closed-form solves, dense or no side information
     // inside the shape of X, prediction matrices not produced
     if (add_implicit_features) {
@@ -302,6 +387,12 @@ int_t fit_collective_explicit_als(
     if ((l1_lam != 0 || l1_lam_unique) && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
     if (nonneg || l1_lam != 0 || l1_lam_unique) use_cg = false;           // collective.c:7474-7479
+    // For rows with few missing values the reference corrects a precomputed Gramian instead of summing the present entries
+    // (factors_closed_form, common.c:762-790).  Unscaled lambda + Cholesky: the same solution.  Under scale_lam that Gramian
+    // already carries lam x (all rows) (:3031-3032), CG restarts from zero with k steps (:2958-2985), and the non-negative /
+    // L1 solvers see another matrix layout -- per-row rules that are not restated, so those combinations are not offered.
+    if (nan_side && (use_cg || scale_lam || scale_lam_sideinfo || nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
+        return fail(verbose, "cmfrec_hip: NaN in dense side information: only the Cholesky solver with unscaled lambda is implemented.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
@@ -309,8 +400,6 @@ int_t fit_collective_explicit_als(
     if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
-    if (U) for (size_t e = 0; e < (size_t)m_u * p; e++) if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NaN in U is not implemented.");
-    if (II) for (size_t e = 0; e < (size_t)n_i * q; e++) if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NaN in I is not implemented.");
 
     SigGuard sig(true);
     scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
@@ -425,8 +514,8 @@ int_t fit_collective_explicit_als(
         if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }
         const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
         int rc2 = cmfrec_hip_session_precompute(s, last_chol, include_all_X ? 1 : 0, precomputedBtB, precomputedTransBtBinvBt, nullptr,
-                                                U ? precomputedBeTBeChol : nullptr, U ? precomputedCtCw : nullptr,
-                                                U ? precomputedTransCtCinvCt : nullptr);
+                                                hadU ? precomputedBeTBeChol : nullptr, hadU ? precomputedCtCw : nullptr,
+                                                hadU ? precomputedTransCtCinvCt : nullptr);
         if (rc2) rc_loop = rc2;
         if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
             for (int_t c = 0; c < n_max; c++) {

@@ -263,6 +263,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g15_lam_unique_" + tag, **out)
 
+        # ---- G16: dense side information with missing values ----
+        out = {}
+        d = gc.nan_side_problem(dt)
+        for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.NAN_SIDE_CASES):
+            r = gc.nan_side_reference(R, d, implicit, which, sl, sls, solver=solver)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g16_nan_side_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

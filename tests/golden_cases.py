@@ -360,7 +360,7 @@ def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
 def compare_fits(got, exp):
     """Largest relative error over the factor matrices / biases both sides carry."""
     err = 0.0
-    for key in ("A", "B", "C", "D", "biasA", "biasB", "Ai", "Bi", "TransBtBinvBt", "BeTBeChol"):
+    for key in ("A", "B", "C", "D", "biasA", "biasB", "Ai", "Bi", "TransBtBinvBt", "BeTBeChol", "U_colmeans", "I_colmeans"):
         if key in exp and exp[key] is not None and got.get(key) is not None and np.size(exp[key]):
             e = maxrel(got[key], exp[key])
             err = max(err, e) if np.isfinite(e) else float("inf")        # NaN anywhere is a failure, never silently dropped
@@ -621,4 +621,92 @@ def lam_unique_hip(d, implicit, side, opts, dtype):
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     if mdl.add_implicit_features: out.update(Ai=mdl.Ai_, Bi=mdl.Bi_)
     if mdl.precompute_for_predictions: out.update(TransBtBinvBt=mdl._TransBtBinvBt, BeTBeChol=np.triu(mdl._BeTBeChol))
+    return out
+
+
+# ---- dense side information with missing values (NaN): present entries only, centred column-wise ----------------------
+def nan_side_problem(dtype, seed=61):
+    d = sparse_sideinfo_problem(dtype, seed)
+    rng = np.random.default_rng(seed + 1)
+    mk = lambda c: (lambda M: (M.__setitem__((c[0], c[1]), c[2]), M)[1])(np.full((c[3], c[4]), np.nan, dtype))
+    d["U_nan"], d["I_nan"] = mk(d["U_coo"]), mk(d["I_coo"])            # dense matrices, NaN where the sparse ones have nothing
+    # nearly complete matrices (the reference's near_dense branches): 4 % missing
+    few = lambda rows, cols: (lambda M: (M.__setitem__(rng.random((rows, cols)) < 0.04, np.nan), M)[1])(
+        rng.standard_normal((rows, cols)).astype(dtype))
+    d["U_few"], d["I_few"] = few(*d["U_nan"].shape), few(*d["I_nan"].shape)
+    return d
+
+
+def _nan_mats(d, solver):
+    solver = dict(solver or {})
+    few = solver.pop("few", False)
+    return (d["U_few"], d["I_few"]) if few else (d["U_nan"], d["I_nan"]), (solver or None)
+
+
+def centred_coo(M):
+    """(row, col, centred value, rows, cols) of the present entries + the column means (center_by_cols, common.c:4938-4997)."""
+    means = np.nanmean(M.astype(np.float64), axis=0).astype(M.dtype)
+    r, c = np.nonzero(~np.isnan(M))
+    return (r.astype(np.int32), c.astype(np.int32), (M[r, c] - means[c]).astype(M.dtype), M.shape[0], M.shape[1]), means
+
+
+# Cholesky solver, unscaled lambda: there the reference's shortcut for rows with few missing values (a precomputed Gramian
+# minus the missing rows, common.c:762-790) solves the same system.  Under scale_lam that Gramian already carries
+# lam x (all rows), and CG restarts such rows from zero with k steps -- per-row rules the product does not restate (it
+# returns 2 for them); measured here: 3e-2 .. 1e-1 apart on the nearly complete matrices.
+NAN_SIDE_CASES = [("implicit UI", True, "UI", False, False, None), ("explicit UI", False, "UI", False, False, None),
+                  ("explicit U", False, "U", False, False, None), ("implicit I", True, "I", False, False, None),
+                  ("explicit UI nearly complete", False, "UI", False, False, dict(few=True)),
+                  ("implicit UI nearly complete", True, "UI", False, False, dict(few=True))]
+
+
+def nan_side_reference(R, d, implicit, which, sl, sls, nthreads=2, solver=None):
+    """The real reference on DENSE U / I with NaN."""
+    (Un, In), solver = _nan_mats(d, solver)
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver or {})
+    cz = 0 if sv["use_cg"] else 1
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, **sv,
+              U=Un if "U" in which else None, II=In if "I" in which else None,
+              Cm=(d["C0"][:, d["ku"] - ku:] * cz).copy() if "U" in which else None,
+              Dm=(d["D0"][:, d["ki"] - ki:] * cz).copy() if "I" in which else None)
+    if implicit:
+        r = R.fit_collective_implicit_als(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, w_main=0.5, **kw)
+        return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"])
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **kw)
+    return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
+                U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"])
+
+
+def nan_side_oracle(O, d, implicit, which, sl, sls, nthreads=2, solver=None):
+    """The oracle's sparse-side-information fit on the centred present entries."""
+    d2 = dict(d)
+    (Un, In), solver = _nan_mats(d, solver)
+    d2["U_coo"], _ = centred_coo(Un); d2["I_coo"], _ = centred_coo(In)
+    return sparse_sideinfo_oracle(O, d2, implicit, which, sl, sls, nthreads=nthreads, solver=solver)
+
+
+def nan_side_hip(d, implicit, which, sl, sls, dtype, solver=None):
+    """The product: the estimators with dense U / I that contain NaN."""
+    from cmfrec_amd import CMF, CMF_implicit
+    (Un, In), solver = _nan_mats(d, solver)
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    U = Un if "U" in which else None; I = In if "I" in which else None
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver or {})
+    common = dict(k=d["k"], k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3,
+                  use_float=dtype is np.float32, precompute_for_predictions=False, **sv)
+    shape = (d["m"], d["n"])
+    if implicit:
+        mdl = CMF_implicit(lambda_=2.0, alpha=1.5, w_main=0.5, **common)
+        mdl.fit((d["row"], d["col"], d["counts"]), U=U, I=I, shape=shape, A0=A0, B0=B0)
+        out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_)
+    else:
+        mdl = CMF(lambda_=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **common)
+        mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=I, shape=shape, A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+        out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, biasA=mdl.user_bias_, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_)
+    if U is not None: out["U_colmeans"] = mdl._U_colmeans
+    if I is not None: out["I_colmeans"] = mdl._I_colmeans
     return out

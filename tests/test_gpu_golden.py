@@ -226,3 +226,39 @@ def test_lam_unique(oracles, dtype):
         if opts.get("precompute"):
             assert "TransBtBinvBt" in exp and "TransBtBinvBt" in got
         assert gc.compare_fits(got, gc.lam_unique_oracle(oracles[dtype], d, implicit, side, opts)) < tol, name
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_nan_side_info(oracles, dtype):
+    """G16 through the estimators: dense U / I with NaN (centred present entries on the sparse route), column means
+    reported like the reference."""
+    g = gc.load("g16_nan_side", dtype)
+    d = gc.nan_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.NAN_SIDE_CASES):
+        got = gc.nan_side_hip(d, implicit, which, sl, sls, dtype, solver=solver)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and ("U_colmeans" in got) == ("U" in which) and ("I_colmeans" in got) == ("I" in which), name
+        assert gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.nan_side_oracle(oracles[dtype], d, implicit, which, sl, sls, solver=solver)) < tol, name
+    # the combinations whose per-row rules are not restated are refused, not approximated
+    for bad in (dict(use_cg=True), ):
+        with pytest.raises(RuntimeError):
+            gc.nan_side_hip(d, True, "U", False, False, dtype, solver=bad)
+    with pytest.raises(RuntimeError):
+        gc.nan_side_hip(d, False, "U", True, False, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_sparse_side_info_colmeans(dtype):
+    """Sparse side information: the column means over the present entries are reported (common.c:4976-4990) although the fit
+    runs on the values as given."""
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF_implicit
+    d = gc.sparse_sideinfo_problem(dtype)
+    c = d["U_coo"]
+    U = sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    mdl = CMF_implicit(k=d["k"], niter=1, use_float=dtype is np.float32, precompute_for_predictions=False, use_cg=False)
+    mdl.fit((d["row"], d["col"], d["counts"]), U=U, shape=(d["m"], d["n"]))
+    exp = np.bincount(c[1], weights=c[2].astype(np.float64), minlength=c[4]) / np.bincount(c[1], minlength=c[4])
+    assert np.allclose(mdl._U_colmeans, exp, rtol=1e-5 if dtype is np.float32 else 1e-12, atol=1e-6 if dtype is np.float32 else 1e-13)

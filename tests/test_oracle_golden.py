@@ -172,3 +172,14 @@ def test_lam_unique(oracles, dtype):
         got = gc.lam_unique_oracle(oracles[dtype], d, implicit, side, opts)
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_nan_side_info(oracles, dtype):
+    """G16: dense U / I with NaN in the reference == the sparse route on the centred present entries."""
+    g = gc.load("g16_nan_side", dtype)
+    d = gc.nan_side_problem(dtype)
+    for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.NAN_SIDE_CASES):
+        got = gc.nan_side_oracle(oracles[dtype], d, implicit, which, sl, sls, solver=solver)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name

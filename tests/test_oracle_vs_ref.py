@@ -295,3 +295,17 @@ def test_lam_unique_live(oracles, refs, dtype):
         exp = gc.lam_unique_reference(refs[dtype], d, implicit, side, opts, nthreads=3)
         got = gc.lam_unique_oracle(oracles[dtype], d, implicit, side, opts, nthreads=1)
         assert gc.compare_fits(got, exp) < tol, name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_nan_side_info_live(oracles, refs, dtype):
+    """Dense side information with NaN: the reference centres the present entries (common.c:4938-4997) and uses only those
+    (collective.c:1566-1653; optimizeA Case 2 for C / D) -- identical to its sparse route on the centred values, which is how
+    the product runs it.  Sparse and nearly complete matrices, Cholesky and CG."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    d = gc.nan_side_problem(dtype, seed=67)
+    for name, implicit, which, sl, sls, solver in gc.NAN_SIDE_CASES:
+        exp = gc.nan_side_reference(refs[dtype], d, implicit, which, sl, sls, nthreads=3, solver=solver)
+        got = gc.nan_side_oracle(oracles[dtype], d, implicit, which, sl, sls, nthreads=1, solver=solver)
+        assert gc.compare_fits(got, exp) < tol, name
