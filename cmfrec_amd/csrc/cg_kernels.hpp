@@ -82,6 +82,13 @@ struct CgParams {
     int *counter = nullptr;   // tiled kernels: work counter of this launch (zero at launch); a team's first row is its own
                               // index, the following ones are claimed in order (longest rows first) from here
     int p_side = 0, scale_lam_sideinfo = 0;
+    // generic kernel, implicit features of the explicit model (collective_block_cg, collective.c:2301-2304, :2624-2643,
+    // :2862-2868): Bi [*, ki] is gathered at the row's observed positions with unit values (right-hand side only) and
+    // BiTBi [ki, ki] = Bi^T Bi (unweighted) acts on the unknowns [koff, koff + ki); both enter with weight w_imp
+    const T *Bi = nullptr;
+    const T *BiTBi = nullptr;
+    int ki = 0;
+    T w_imp = 0;
 };
 
 template <typename T>
@@ -812,7 +819,11 @@ cg_rows_generic_kernel(const CgParams<T> P)
         const size_t st = P.indptr[row];
         const int nnz = (int)(P.indptr[row + 1] - st);
         const bool has_u = coll && row < P.rows_with_u;
-        if (nnz == 0 && !has_u) continue;                     // plain rows without entries stay untouched (common.c:3270,3354)
+        if (nnz == 0 && !has_u) {                             // plain rows without entries stay untouched (common.c:3270,3354)
+            if (P.Bi != nullptr && (TEAM == 1 || wv == 0))    // ... but with implicit features the row runs through
+                for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);   // optimizeA_collective: zeros (collective.c:1258-1268)
+            continue;
+        }
         const bool sparse_u = P.indptr2 != nullptr;
         const size_t st2 = (sparse_u && has_u) ? P.indptr2[row] : 0;
         const int nnz2 = (sparse_u && has_u) ? (int)(P.indptr2[row + 1] - st2) : 0;
@@ -873,6 +884,18 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     if (f < kc) out[c] += (mode == 0) ? P.w_side * (ucrow[f] - acc[c]) : P.w_side * acc[c];
                 }
             }
+            if (!IMPLICIT && P.Bi != nullptr) {                // out[koff : koff+ki] -+= w_i BiTBi v[koff:]  (collective.c:2626-2629, :2864-2867)
+                T acc[NF];
+#pragma unroll
+                for (int c = 0; c < NF; c++) acc[c] = T(0);
+                for (int j = 0; j < P.ki; j++) {
+                    const T vj = bcast(v, koff + j);
+#pragma unroll
+                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < koff + P.ki) acc[c] += vj * P.BiTBi[(size_t)j * P.ki + (f - koff)]; }
+                }
+#pragma unroll
+                for (int c = 0; c < NF; c++) out[c] += (mode == 0) ? -P.w_imp * acc[c] : P.w_imp * acc[c];
+            }
             T gat[NF];                                         // the gathered part, this wave's share of the non-zeros
 #pragma unroll
             for (int c = 0; c < NF; c++) gat[c] = T(0);
@@ -890,6 +913,11 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 else          w = (mode == 0) ? -(coef - x) : coef;
 #pragma unroll
                 for (int c = 0; c < NF; c++) gat[c] += w * bv[c];
+                if (!IMPLICIT && mode == 0 && P.Bi != nullptr) {                  // + w_i Bi_j (tgemv_dense_sp on ones, collective.c:2638-2643)
+                    const T *bi = P.Bi + (size_t)idx * P.ki;
+#pragma unroll
+                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < koff + P.ki) gat[c] += P.w_imp * bi[f - koff]; }
+                }
             }
             // sparse side information: every present attribute j adds  w (u_j - C_j.v) C_j  /  w (C_j.v) C_j  to [0, kc)
             for (int j = (TEAM == 1 ? 0 : wv); j < nnz2; j += TEAM) {
@@ -978,6 +1006,8 @@ cg_rows_generic_kernel(const CgParams<T> P)
             for (int c = 0; c < NF; c++) {
                 int f = lane + 64 * c;
                 if (has_u && !sparse_u && f < kc) PC[c] += P.CtC[(size_t)f * kc + f];   // sum_l C_l^2, unweighted (collective.c:2281-2286)
+                if (!IMPLICIT && P.Bi != nullptr && f >= koff && f < koff + P.ki)
+                    PC[c] += P.BiTBi[(size_t)(f - koff) * P.ki + (f - koff)];           // unweighted too (collective.c:2301-2304)
                 if (IMPLICIT) PC[c] += (f >= koff && f < kt) ? P.BtB[(size_t)(f - koff) * kx + (f - koff)] : T(0);
                 else {
                     PC[c] += lam;

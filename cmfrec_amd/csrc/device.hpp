@@ -361,6 +361,10 @@ struct CgCall {
     // ... or sparse side information: the row's attributes (X2, CSR over the same rows) gather rows of C2[*, kc]
     const SparseShard *X2 = nullptr;
     const real_t *C2 = nullptr;
+    // implicit features of the explicit model: Bi [*, ki], BiTBi = Bi^T Bi (unweighted), weight w_imp
+    const real_t *Bi = nullptr, *BiTBi = nullptr;
+    int ki = 0;
+    real_t w_imp = 0;
 };
 
 enum class CgVariant { Auto, Generic };
@@ -528,7 +532,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
 template <int NF, bool IMPLICIT>
 inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X)
 {
-    int count = (P.kc > 0) ? X.nrows : X.n_nonempty;       // rows without entries still have side information
+    int count = (P.kc > 0 || P.Bi != nullptr) ? X.nrows : X.n_nonempty;   // rows without entries still have side information / get zeroed
     if (count <= 0) return;
     // rows of 129 non-zeros and more (they lead the processing order): a workgroup per row; the rest: a wavefront per row
     const int nteam = std::min(count, X.bin_first[BIN_MED2]);
@@ -558,10 +562,11 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.koff = c.koff; P.kc = c.kc; P.CtC = c.CtC; P.UC = c.UC; P.w_side = c.w_side;
     P.rows_with_u = c.rows_with_u; P.p_side = c.p_side; P.scale_lam_sideinfo = c.scale_lam_sideinfo ? 1 : 0;
     if (c.X2) { P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr; P.C2 = c.C2; }
+    P.Bi = c.Bi; P.BiTBi = c.BiTBi; P.ki = c.ki; P.w_imp = c.w_imp;
     const int S = (c.k + 7) / 8;
     // the Jacobi-preconditioned variants (not a default anywhere in the reference) and the block systems with side
     // information run on the generic kernel
-    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond || c.kc > 0;
+    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond || c.kc > 0 || c.Bi != nullptr;
     if (!generic) {
 #define CMF_CASE(SS)                                                        \
     case SS:                                                                \

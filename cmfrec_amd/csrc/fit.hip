@@ -371,8 +371,6 @@ int_t fit_collective_explicit_als(
         // a NULL thread-local buffer, collective.c:8487-8489): nothing to pin against, so not offered
         if (nonneg || l1_lam != 0 || l1_lam_unique)
             return fail(verbose, "cmfrec_hip: implicit features with nonneg / L1 are not implemented.");
-        if (use_cg)
-            return fail(verbose, "cmfrec_hip: implicit features: the conjugate-gradient solver is not implemented (use_cg = false).");
         if (!(w_implicit > 0)) return fail(verbose, "cmfrec_hip: w_implicit must be positive.");
     }
     // side information: dense (no NaN) or sparse COO (missing = absent).  Sparse: Cholesky updates only, rows within X.

@@ -720,10 +720,6 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const int kk = m.k + m.k_main;
     const int rows_x_self = isA ? (m.m_x > 0 ? m.m_x : m.m) : (m.n_x > 0 ? m.n_x : m.n);          // rows of this matrix X has
 
-    if (s->implicit_feats && !chol) {
-        g_last_error = "cmfrec_hip: add_implicit_features: the conjugate-gradient solver is not built (use_cg = false)";
-        return 2;
-    }
     const bool sparse_side = isA ? s->sparseU : s->sparseI;
     if (p_self > 0 && sparse_side) {
         // sparse side information (missing = absent): the row's attributes are a second gather source of the same
@@ -814,6 +810,11 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         const int local_u_main = m.implicit ? local_u : std::min(local_u, local_x);
         c.koff = k_side_self; c.kc = kc; c.CtC = s->ctc.ptr; c.UC = uc; c.w_side = w; c.rows_with_u = local_u_main;
         c.p_side = p_self; c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo;
+        if (s->implicit_feats && !m.implicit) {                 // collective.c:2301-2304, :2624-2643, :2862-2868
+            const real_t *Fi = isA ? s->Bi.ptr : s->Ai.ptr;
+            launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, (real_t)1, (real_t)0);
+            c.Bi = Fi; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
+        }
         int rc = launch_cg(dev, c, X, nullptr);
         if (rc) return rc;
         return solve_sideinfo_only_rows(s, isA, false, local_u_main, local_u - local_u_main);
@@ -867,7 +868,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     // w_i sum_{j observed} Bi_j its right-hand side (:1757-1771).  The second gather source of the Cholesky launch reads
     // the same sparsity pattern with unit values from Bi, right-hand side only.
     const real_t *Fi = nullptr;
-    if (s->implicit_feats) {
+    if (s->implicit_feats && chol) {
         Fi = isA ? s->Bi.ptr : s->Ai.ptr;
         const int kt_i = k_side_self + ksolve;
         launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, s->w_implicit, (real_t)0);
@@ -919,6 +920,13 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     }
     CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, bias_sub, nullptr,
              lam_self, lam_last_self, scale_lam, false, m.max_cg_steps, false, (bool)m.precondition_cg};
+    if (s->implicit_feats) {
+        // block CG with the implicit-features term (collective_block_cg without side information on this side,
+        // collective.c:2624-2643, :2862-2868): generic kernel; rows without entries are zeroed (:1258-1268)
+        const real_t *Fc = isA ? s->Bi.ptr : s->Ai.ptr;
+        launch_gram(dev, s->gws, Fc, (size_t)kk, rows_opp, kk, s->bitbi.ptr, (real_t)1, (real_t)0);
+        c.Bi = Fc; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
+    }
     return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
 }
 

@@ -251,9 +251,9 @@ class CMF(_Base):
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
         if NA_as_zero or NA_as_zero_user or NA_as_zero_item or scale_bias_const:
             raise NotImplementedError("NA_as_zero / scale_bias_const are not implemented in cmfrec_amd")
-        if add_implicit_features and (use_cg or nonneg or not np.isscalar(l1_lambda) or l1_lambda):
-            raise NotImplementedError("add_implicit_features: only the Cholesky solver is implemented in cmfrec_amd "
-                                      "(pass use_cg=False; no nonneg / l1_lambda)")
+        if add_implicit_features and (nonneg or not np.isscalar(l1_lambda) or l1_lambda):
+            raise NotImplementedError("add_implicit_features together with nonneg / l1_lambda is not implemented in "
+                                      "cmfrec_amd (the reference itself crashes on it)")
         self.add_implicit_features = bool(add_implicit_features)
         self.l1_lambda, self._l16 = _penalty(l1_lambda, "l1_lambda")
         self.nonneg = bool(nonneg); self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D)

@@ -343,7 +343,8 @@ int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_
  * "was observed" pattern of X with weight w_implicit (already divided by w_main).  After this call the session's
  * updates 'b' (Bi from A) and 'a' (Ai from B) exist, iterate() runs them between D and B like the reference, and the
  * A / B updates carry the extra term (collective.c:1704-1707, :1757-1771).  Ai / Bi may be NULL (start values are never
- * read by the closed-form updates).  Cholesky-type solves only; whole-matrix sessions, dense or no side information. */
+ * read by the closed-form updates).  Ai / Bi are always closed-form; A / B run Cholesky or the block CG like the rest of
+ * the model.  Whole-matrix sessions, dense or no side information. */
 int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_implicit, const real_t *Ai, const real_t *Bi);
 int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, real_t *Bi);
 

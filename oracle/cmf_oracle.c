@@ -738,6 +738,11 @@ static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t 
 /* U dense [m_u, p] (prefer_CtC branches), or U == NULL and the row's attributes as CSR (u_vec_sp branches:
  * residual :2609-2621, products :2847-2860, preconditioner :2292-2298 -- each present attribute j contributes
  * w (u_j - C_j.a) C_j,  w (C_j.p) C_j  and  C_j^2 (unweighted); lambda counts them under scale_lam_sideinfo). */
+/* implicit-features term of the block CG (collective.c:2301-2304, :2624-2643, :2862-2868), set by the explicit fit around
+ * its A / B updates: Bi [n, ki] gathered at the observed positions (unit values), Bi^T Bi (unweighted) on the X block */
+static const real_t *g_cg_Bi = NULL;
+static int_t g_cg_ki = 0;
+static real_t g_cg_wimp = 0;
 static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
                                int_t m, int_t m_u, int_t n, int_t p,
                                int_t k, int_t k_main, int_t k_user, int_t k_item,
@@ -757,6 +762,14 @@ static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ld
         BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
         oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
     }
+    const real_t *Bi = implicit ? NULL : g_cg_Bi;
+    const int_t ki = g_cg_ki;
+    const real_t wimp = g_cg_wimp;
+    real_t *BiTBi = NULL;
+    if (Bi != NULL) {
+        BiTBi = (real_t *)calloc((size_t)ki * ki + 1, sizeof(real_t));
+        oracle_gram(Bi, (size_t)ki, n, ki, BiTBi, nthreads);
+    }
     #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
     for (int_t ix = 0; ix < m; ix++) {
         const size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
@@ -764,7 +777,10 @@ static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ld
         const bool has_u = ix < m_u;
         const size_t us = (sparse_u && has_u) ? Ucsr_p[ix] : 0, ue = (sparse_u && has_u) ? Ucsr_p[(size_t)ix + 1] : 0;
         real_t *a = A + (size_t)ix * lda;
-        if (nnz == 0 && !has_u) continue;                                        /* plain rows without entries stay untouched */
+        if (nnz == 0 && !has_u) {                                                /* plain rows without entries stay untouched */
+            if (Bi != NULL) memset(a, 0, (size_t)kt * sizeof(real_t));           /* ... unless optimizeA_collective ran them (:1258-1268) */
+            continue;
+        }
         if (nnz == 0 && sparse_u && ue == us) {                                  /* :1258-1268: neither observations nor attributes */
             memset(a, 0, (size_t)kt * sizeof(real_t));
             continue;
@@ -799,7 +815,15 @@ static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ld
                     if (implicit) wgt = (resid) ? (-(coef - (real_t)1) * Xcsr[jx] - coef) : (coef * (Xcsr[jx] - (real_t)1) + coef); \
                     else          wgt = (resid) ? (-coef + Xcsr[jx]) : coef;                              \
                     for (int_t f = 0; f < kb; f++) out[k_user + f] += wgt * b[f];                         \
+                    if (Bi != NULL && (resid))                                                            \
+                        for (int_t f = 0; f < ki; f++) out[k_user + f] += wimp * Bi[(size_t)Xcsr_i[jx] * ki + f]; \
                 }                                                                                         \
+                if (Bi != NULL)                                                                           \
+                    for (int_t i = 0; i < ki; i++) {                                                      \
+                        double sacc = 0;                                                                  \
+                        for (int_t j = 0; j < ki; j++) sacc += (double)BiTBi[(size_t)i * ki + j] * (double)v[k_user + j]; \
+                        out[k_user + i] += (resid) ? -wimp * (real_t)sacc : wimp * (real_t)sacc;          \
+                    }                                                                                     \
                 if (has_u && sparse_u)                                                                    \
                     for (size_t jx = us; jx < ue; jx++) {                                                 \
                         const real_t *cj = C + (size_t)Ucsr_i[jx] * kc;                                   \
@@ -838,6 +862,7 @@ static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ld
                     for (int_t f = 0; f < kc; f++) PC[f] += cj[f] * cj[f];               /* unweighted, :2292-2298 */
                 }
             else if (has_u) for (int_t f = 0; f < kc; f++) PC[f] += CtC[(size_t)f * kc + f];   /* unweighted, :2281-2286 */
+            if (Bi != NULL) for (int_t f = 0; f < ki; f++) PC[k_user + f] += BiTBi[(size_t)f * ki + f];   /* unweighted, :2301-2304 */
             if (implicit) for (int_t f = 0; f < kb; f++) PC[k_user + f] += BtB[(size_t)f * kb + f];
             else {
                 for (int_t f = 0; f < kt; f++) PC[f] += lam_i;
@@ -873,7 +898,7 @@ static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ld
         }
         #undef BLOCK_MATVEC
     }
-    free(CtC); free(BtB);
+    free(CtC); free(BtB); free(BiTBi);
 }
 
 void oracle_optimizeA_collective_cg(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
@@ -1183,7 +1208,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     if (n_i > n) n = n_i;
     if (init_biases && (user_bias != item_bias)) return 2;
     const bool imp = (Ai != NULL && Bi != NULL);
-    if (imp && (use_cg || m_u > m_x || n_i > n_x)) return 2;
+    if (imp && (m_u > m_x || n_i > n_x)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     const real_t l1f = g_l1_base;
     if (g_nn_AB || l1f != 0 || g_has_l16) use_cg = false;                      /* :7474-7479 */
@@ -1257,7 +1282,8 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
         if (user_bias)                                                         /* :8566-8570 */
             for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
-        if (II != NULL && use_cg)                                              /* :8634-8678 */
+        g_cg_Bi = imp ? Ai : NULL; g_cg_ki = k + k_main; g_cg_wimp = w_implicit;
+        if ((II != NULL || imp) && use_cg)                                     /* :8634-8678 */
             oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
@@ -1287,7 +1313,8 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         g_l1 = l1A; g_l1_last = l1Al;
         if (item_bias)                                                         /* :8750-8754 */
             for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
-        if (U != NULL && use_cg)                                               /* :8805-8845 */
+        g_cg_Bi = imp ? Bi : NULL;
+        if ((U != NULL || imp) && use_cg)                                      /* :8805-8845 */
             oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                            csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
@@ -1310,6 +1337,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                         scale_lam, nthreads);
         }
         }
+        g_cg_Bi = NULL;
         if (user_bias)                                                         /* :8882-8884 */
             for (int_t r = 0; r < m; r++) biasA[r] = A_bias[(size_t)r * ldA + k_totA];
     }

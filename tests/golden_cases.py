@@ -470,6 +470,10 @@ IMPLICIT_FEATS_CASES = [
     ("side info", True, dict(k_user=2, k_item=1, k_main=1, scale_lam_sideinfo=True, w_implicit=1.5)),
     ("no biases w_main", False, dict(user_bias=False, item_bias=False, center=False, w_main=2.0)),
     ("user bias only", True, dict(item_bias=False, w_implicit=0.25)),
+    # block CG with the implicit-features term (collective.c:2301-2304, :2624-2643, :2862-2868); Ai / Bi stay closed-form
+    ("cg", False, dict(use_cg=True, k_main=1, w_implicit=0.6)),
+    ("cg side info finalize", True, dict(use_cg=True, finalize_chol=True, k_user=1, k_item=1, scale_lam=True)),
+    ("pcg side info", True, dict(use_cg=True, precondition_cg=True, w_implicit=1.3, user_bias=False)),
     # not pinned: nonneg / L1 together with implicit features -- the reference segfaults on them (verified here with
     # nonneg=True and with l1_lam=0.05, one and two threads), so the product rejects the combination
 ]
@@ -492,7 +496,8 @@ def implicit_feats_reference(R, d, side, opts, nthreads=2):
     U, II = (d["U"], d["I"]) if side else (None, None)
     r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
                                       lam=0.3, niter=niter, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads,
-                                      use_cg=False, finalize_chol=False, add_implicit_features=True, **o)
+                                      use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      add_implicit_features=True, **o)
     assert r["ret"] == 0
     return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
                 Ai=r["Ai"], Bi=r["Bi"])
@@ -507,8 +512,8 @@ def implicit_feats_oracle(O, d, side, opts, nthreads=2):
         A0, B0 = _impf_start(d, o)
         U, II = (d["U"], d["I"]) if side else (None, None)
         r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
-                               niter=niter, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=False,
-                               finalize_chol=False, add_implicit_features=True, **o)
+                               niter=niter, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads, use_cg=o.pop("use_cg", False),
+                               finalize_chol=o.pop("finalize_chol", False), add_implicit_features=True, **o)
         assert r["ret"] == 0
         return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"],
                     Ai=r["Ai"], Bi=r["Bi"])
@@ -524,8 +529,8 @@ def implicit_feats_hip(d, side, opts, dtype):
     o.setdefault("w_implicit", 1.0)           # the estimator's default is 0.5 (cmfrec/__init__.py), the C default used above 1
     A0, B0 = _impf_start(d, o)
     U, II = (d["U"], d["I"]) if side else (None, None)
-    mdl = CMF(k=d["k"], niter=niter, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, lambda_=0.3, use_cg=False,
-              finalize_chol=False, add_implicit_features=True, **o)
+    mdl = CMF(k=d["k"], niter=niter, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, lambda_=0.3, use_cg=o.pop("use_cg", False),
+              finalize_chol=o.pop("finalize_chol", False), add_implicit_features=True, **o)
     mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
     out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_, Ai=mdl.Ai_, Bi=mdl.Bi_)
     if mdl.user_bias: out["biasA"] = mdl.user_bias_

@@ -33,8 +33,8 @@ def test_unsupported_options_raise():
         CMF(lambda_=[1.0, 2.0])
     assert CMF_implicit(l1_lambda=0.1).l1_lambda == 0.1
     with pytest.raises(NotImplementedError):
-        CMF(add_implicit_features=True)                      # default use_cg=True: only the Cholesky solver is built
-    assert CMF(add_implicit_features=True, use_cg=False).add_implicit_features
+        CMF(add_implicit_features=True, nonneg=True)         # the reference crashes on this combination: nothing to pin
+    assert CMF(add_implicit_features=True).add_implicit_features and CMF(add_implicit_features=True, use_cg=False).w_implicit == 0.5
     assert CMF(nonneg=True, nonneg_C=True).nonneg_C and CMF_implicit(nonneg=True, max_cd_steps=50).max_cd_steps == 50
 
 
