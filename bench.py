@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
+    ap.add_argument("--implicit-features", action="store_true", help="side workloads c1 / c3: add the implicit-features matrices Ai, Bi")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard", "c5shard"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
                          "MovieLens10M-shaped configs of BASELINE.json (single GPU, side measurements)")
@@ -382,6 +383,8 @@ def side_workload(args, device):
         sess.set_sideinfo(II=II)
     sess.set_factors(A=rng.standard_normal((m, k)) * 2.0 ** -7, B=rng.standard_normal((n, k)) * 2.0 ** -7 if chol else np.zeros((n, k)),
                      biasA=np.zeros(m), biasB=np.zeros(n), Dm=np.zeros((q, k)) if q else None)
+    if args.implicit_features:           # the reference's "ALS-CG / Chol + implicit features" benchmark lines (benchmark/README.md:28-29)
+        sess.set_implicit_features(0.5)
     import torch
     for _ in range(args.warmup):
         sess.iterate(1)
@@ -404,7 +407,8 @@ def side_workload(args, device):
     else:
         alg = algorithmic_bytes(nnz, m, kt) + algorithmic_bytes(nnz, n, kt)
         extra = {"alg_GB": round(alg / 1e9, 2), "frac_of_hbm_peak": round(alg / dt / 8e12, 3)}
-    print(json.dumps({"workload": args.workload, "ms_per_iteration": round(dt * 1e3, 3), "rows_per_s": round((m + n) / dt, 1),
+    print(json.dumps({"workload": args.workload + ("+implicit_features" if args.implicit_features else ""),
+                      "ms_per_iteration": round(dt * 1e3, 3), "rows_per_s": round((m + n) / dt, 1),
                       "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "k": k, "m": m, "n": n, "nnz": nnz, **extra,
                       "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
                       "note": "side measurement, not the headline metric"}))

@@ -804,11 +804,12 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
 // all four carry identical copies of a, r, p (the scalars of the CG are then bit-identical, so the exits agree).
 // P.row_first .. P.nrows of the processing order are handled.
 template <typename T, int NF, bool IMPLICIT, int TEAM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TEAM == 16 ? 1024 : 256)
 cg_rows_generic_kernel(const CgParams<T> P)
 {
-    static_assert(TEAM == 1 || TEAM == 4, "team");
-    __shared__ T red[TEAM == 1 ? 1 : 4][64 * NF];
+    // TEAM 1: four independent wavefronts per workgroup, a row each; TEAM 4 / 16: the whole workgroup on one row
+    static_assert(TEAM == 1 || TEAM == 4 || TEAM == 16, "team");
+    __shared__ T red[TEAM][64 * NF];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int unit_global = (TEAM == 1) ? ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) : (int)blockIdx.x;
     const int nunits = (TEAM == 1) ? ((gridDim.x * blockDim.x) >> 6) : (int)gridDim.x;
@@ -899,24 +900,43 @@ cg_rows_generic_kernel(const CgParams<T> P)
             T gat[NF];                                         // the gathered part, this wave's share of the non-zeros
 #pragma unroll
             for (int c = 0; c < NF; c++) gat[c] = T(0);
-            for (int j = (TEAM == 1 ? 0 : wv); j < nnz; j += TEAM) {
-                const int idx = P.indices[st + j];
-                T x = P.values[st + j];
-                if (!IMPLICIT && P.bias_sub != nullptr) x -= P.bias_sub[idx];
-                const T *b = P.B + (size_t)idx * P.ldb;
-                T bv[NF]; T part = T(0);
+            // four entries in flight per wave: their loads and dot products are independent, only the accumulation into
+            // gat keeps the entry order (so the sums are the ones of the one-at-a-time loop)
+            constexpr int UNR = 4;
+            for (int j0 = (TEAM == 1 ? 0 : wv); j0 < nnz; j0 += TEAM * UNR) {
+                int idx[UNR]; T x[UNR]; T bv[UNR][NF]; T part[UNR];
 #pragma unroll
-                for (int c = 0; c < NF; c++) { int f = lane + 64 * c; bv[c] = (f >= koff && f < kt) ? b[f - koff] : T(0); part += bv[c] * v[c]; }
-                T coef = wave_sum(part);
-                T w;
-                if (IMPLICIT) w = (mode == 0) ? (-(coef - T(1)) * x - coef) : (coef * (x - T(1)) + coef);
-                else          w = (mode == 0) ? -(coef - x) : coef;
+                for (int u = 0; u < UNR; u++) {
+                    const int j = j0 + u * TEAM;
+                    const bool ok = j < nnz;
+                    idx[u] = ok ? P.indices[st + j] : 0;
+                    x[u] = ok ? P.values[st + j] : T(0);
+                }
 #pragma unroll
-                for (int c = 0; c < NF; c++) gat[c] += w * bv[c];
-                if (!IMPLICIT && mode == 0 && P.Bi != nullptr) {                  // + w_i Bi_j (tgemv_dense_sp on ones, collective.c:2638-2643)
-                    const T *bi = P.Bi + (size_t)idx * P.ki;
+                for (int u = 0; u < UNR; u++) {
+                    const bool ok = (j0 + u * TEAM) < nnz;
+                    if (!IMPLICIT && P.bias_sub != nullptr && ok) x[u] -= P.bias_sub[idx[u]];
+                    const T *b = P.B + (size_t)idx[u] * P.ldb;
+                    part[u] = T(0);
 #pragma unroll
-                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < koff + P.ki) gat[c] += P.w_imp * bi[f - koff]; }
+                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; bv[u][c] = (ok && f >= koff && f < kt) ? b[f - koff] : T(0); part[u] += bv[u][c] * v[c]; }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; u++) part[u] = wave_sum(part[u]);
+#pragma unroll
+                for (int u = 0; u < UNR; u++) {
+                    if ((j0 + u * TEAM) >= nnz) break;
+                    const T coef = part[u];
+                    T w;
+                    if (IMPLICIT) w = (mode == 0) ? (-(coef - T(1)) * x[u] - coef) : (coef * (x[u] - T(1)) + coef);
+                    else          w = (mode == 0) ? -(coef - x[u]) : coef;
+#pragma unroll
+                    for (int c = 0; c < NF; c++) gat[c] += w * bv[u][c];
+                    if (!IMPLICIT && mode == 0 && P.Bi != nullptr) {              // + w_i Bi_j (tgemv_dense_sp on ones, collective.c:2638-2643)
+                        const T *bi = P.Bi + (size_t)idx[u] * P.ki;
+#pragma unroll
+                        for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < koff + P.ki) gat[c] += P.w_imp * bi[f - koff]; }
+                    }
                 }
             }
             // sparse side information: every present attribute j adds  w (u_j - C_j.v) C_j  /  w (C_j.v) C_j  to [0, kc)

@@ -534,11 +534,19 @@ inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const S
 {
     int count = (P.kc > 0 || P.Bi != nullptr) ? X.nrows : X.n_nonempty;   // rows without entries still have side information / get zeroed
     if (count <= 0) return;
-    // rows of 129 non-zeros and more (they lead the processing order): a workgroup per row; the rest: a wavefront per row
+    // rows of 129 non-zeros and more (they lead the processing order): a workgroup per row -- sixteen wavefronts for the
+    // rows beyond 1024 non-zeros (the longest row is the critical path of the launch: C1's items with implicit features
+    // 31 -> 13 ms), four for the others; the rest: a wavefront per row
     const int nteam = std::min(count, X.bin_first[BIN_MED2]);
-    if (nteam > 0) {
-        P.row_first = 0; P.nrows = nteam;
-        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 4>), dim3(std::min(nteam, dev.num_cus * 8)), dim3(256), 0,
+    const int nvh = std::min(nteam, X.bin_rows[BIN_VHEAVY]);
+    if (nvh > 0) {
+        P.row_first = 0; P.nrows = nvh;
+        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 16>), dim3(std::min(nvh, dev.num_cus * 2)), dim3(1024), 0,
+                           dev.stream, P);
+    }
+    if (nteam > nvh) {
+        P.row_first = nvh; P.nrows = nteam;
+        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 4>), dim3(std::min(nteam - nvh, dev.num_cus * 8)), dim3(256), 0,
                            dev.stream, P);
     }
     if (count > nteam) {

@@ -81,6 +81,30 @@ class AlsSession:
         _lib.check(self.lib.cmfrec_hip_session_set_nonneg(self.handle, C.c_int(int(nonneg)), C.c_int(int(nonneg_C)),
                                                           C.c_int(int(nonneg_D)), C.c_int(int(max_cd_steps))), self.lib, "set_nonneg")
 
+    def set_implicit_features(self, w_implicit=0.5, Ai=None, Bi=None):
+        """Implicit features of the explicit model (reference ``add_implicit_features``): ``iterate`` then updates Bi and
+        Ai between D and B and the A / B updates carry the extra term.  Call after ``set_X``."""
+        R = _lib.real(self.dtype)
+        cv = lambda M: None if M is None else np.ascontiguousarray(M, self.dtype)
+        Ai, Bi = cv(Ai), cv(Bi)
+        _lib.check(self.lib.cmfrec_hip_session_set_implicit_features(self.handle, R(w_implicit), _lib.ptr(Ai), _lib.ptr(Bi)),
+                   self.lib, "set_implicit_features")
+        self._kk_imp = True
+
+    def get_implicit_features(self, m, n, kk):
+        """(Ai [m, kk], Bi [n, kk]) with kk = k + k_main."""
+        Ai = np.empty((m, kk), self.dtype); Bi = np.empty((n, kk), self.dtype)
+        _lib.check(self.lib.cmfrec_hip_session_get_implicit_features(self.handle, _lib.ptr(Ai), _lib.ptr(Bi)), self.lib,
+                   "get_implicit_features")
+        return Ai, Bi
+
+    def set_lam_unique(self, lam_unique=None, l1_lam_unique=None, max_cd_steps=100):
+        """Per-matrix penalties: six values each (user bias, item bias, A, B, C, D), already divided by w_main."""
+        cv = lambda a: None if a is None else np.ascontiguousarray(a, self.dtype)
+        l6, l16 = cv(lam_unique), cv(l1_lam_unique)
+        _lib.check(self.lib.cmfrec_hip_session_set_lam_unique(self.handle, _lib.ptr(l6), _lib.ptr(l16), C.c_int(int(max_cd_steps))),
+                   self.lib, "set_lam_unique")
+
     def init_biases(self, lam_user, lam_item):
         """Bias start values on the device (reference initialize_biases_*, src/common.c:4410-4909)."""
         R = _lib.real(self.dtype)
