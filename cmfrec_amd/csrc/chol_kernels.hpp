@@ -71,6 +71,8 @@ struct CholParams {
     int koff2 = 0;
     int w2_syr_zero = 0;
     int rows_src2 = -1;                   // rows that have second-source entries (default: rows_with_u)
+    int rhs_only = 0;                     // CHOL_NAZ: store the gathered right-hand side and stop (the shared matrix is
+                                          // factorised once by the caller, the solve is one triangular-solve pair)
     const T *values_override = nullptr;   // read the entries' values from here instead of `values` (all-ones indicator)
     // non-negative factors: the assembled system is solved by the reference's cyclic coordinate descent instead of the
     // Cholesky factorisation (solve_nonneg, common.c:2131-2179), at most max_cd_steps sweeps
@@ -436,6 +438,10 @@ chol_rows_kernel(const CholParams<T> P)
                     __builtin_amdgcn_sched_barrier(0);       // one k-step of operands in registers at a time
                 }
             }
+        }
+        if (TWO_SRC && P.rhs_only) {
+            if (tid < kt) arow[tid] = racc;
+            continue;                     // the loop head's barrier orders the staging ring against the next row
         }
         // ---- 2. the initial matrix, in the accumulator layout (padding: identity) ----
         {

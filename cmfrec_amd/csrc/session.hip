@@ -52,6 +52,7 @@ struct CholCall {
     int rows2 = -1;
     const real_t *values2 = nullptr;         // values of the second source (default: X2's own)
     const real_t *values_override = nullptr; // values of the first source (default: X's own)
+    bool rhs_only = false;                   // CHOL_NAZ: gather the right-hand sides only
 };
 
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
@@ -73,7 +74,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.values2 ? c.values2 : c.X2->v.ptr;
         P.B2 = c.B2; P.ldb2 = c.ldb2; P.kc2 = c.kc2; P.w2 = c.w2; P.koff2 = c.koff2; P.w2_syr_zero = c.w2_syr_zero ? 1 : 0; P.rows_src2 = c.rows2;
     }
-    P.values_override = c.values_override;
+    P.values_override = c.values_override; P.rhs_only = c.rhs_only ? 1 : 0;
     const bool l1on = dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0;
     const bool nonneg = c.nonneg || dev.nonneg_now;
     P.nonneg = nonneg ? 1 : 0; P.max_cd_steps = (dev.nonneg_now || l1on) ? dev.max_cd_steps : c.max_cd_steps;
@@ -180,6 +181,28 @@ static void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
     rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
 #endif
     if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm failed"; throw HipError{1}; }
+}
+
+// X := X (R^T R)^-1 for the row-major [rows, k] block X (ld = ldx) and the row-major upper Cholesky factor R [k, k] of a
+// shared matrix: the multi-right-hand-side posv of optimizeA Case 3 (common.c:3171-3175) as two library triangular
+// solves.  In the library's column-major reading X is [k, rows] and R's memory is the lower factor L = R^T: L y = b, L^T x = y.
+static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real_t *R, real_t *X, size_t ldx)
+{
+    if (rows <= 0 || k <= 0) return;
+    rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
+    const real_t one = 1;
+#ifdef CMFREC_HIP_FLOAT
+    rocblas_status r1 = rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                      k, rows, &one, R, k, X, (int)ldx);
+    rocblas_status r2 = rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                      k, rows, &one, R, k, X, (int)ldx);
+#else
+    rocblas_status r1 = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                      k, rows, &one, R, k, X, (int)ldx);
+    rocblas_status r2 = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                      k, rows, &one, R, k, X, (int)ldx);
+#endif
+    if (r1 != rocblas_status_success || r2 != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS trsm failed"; throw HipError{1}; }
 }
 
 static void init_device(DeviceInfo &dev, int device)
@@ -948,7 +971,17 @@ static int update_implicit_feats(cmfrec_hip_session *s, bool isAi)
     HIP_CHECK(hipMemsetAsync(self, 0, (size_t)rows_self * kk * sizeof(real_t), dev.stream));
     CholCall c{self, (size_t)kk, F, ldf, kk, 0, nullptr, s->gram.ptr, 0, 0, 0, lam, lam, false, false, false, CHOL_NAZ};
     c.values_override = s->ones.ptr;
-    return launch_chol(dev, c, &X);
+    if (dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || getenv("CMFREC_HIP_NAZ_PER_ROW") != nullptr)
+        return launch_chol(dev, c, &X);             // coordinate descent: per row on the assembled system
+    // one factorisation of the shared matrix, the row kernel only gathers the right-hand sides (first version: the
+    // matrix factorised once per row -- c1 + implicit features 8 ms for Bi + Ai)
+    c.rhs_only = true;
+    int rc = launch_chol(dev, c, &X);
+    if (rc) return rc;
+    hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, dev.stream, s->gram.ptr, kk);
+    HIP_CHECK(hipGetLastError());
+    launch_potrs_rows(dev, rows_self, kk, s->gram.ptr, self, (size_t)kk);
+    return 0;
 }
 
 // C / D update: optimizeA Case 1 with do_B (common.c:2793-2991; Q6: always the transposed gemm)
