@@ -44,11 +44,12 @@ extern "C" {
  * Supported: CG / PCG / Cholesky, optionally with DENSE side information U[m_u, p] / II[n_i, q] without NaN
  * (m_u, n_i may exceed m, n: A, B then have max(m, m_u) / max(n, n_i) rows, src/collective.c:9437-9440) (k_user, k_item, k_main, w_main, w_user, w_item as the reference): Cholesky
  * (optimizeA_collective_implicit, src/collective.c:5971-6244) or block CG / PCG
- * (collective_block_cg_implicit, :2905-3303).  l1_lam=0, nonneg=false, no lam_unique, no adjust_weight,
- * no precompute.
+ * (collective_block_cg_implicit, :2905-3303).  No adjust_weight.
  * or SPARSE side information as COO triplets (U_row / U_col / U_sp / nnz_U and the I_* twins; missing = absent, rows
  * within X's; collective.c:1849-2131 / :2905-3303 with u_vec_sp); nonneg / nonneg_C / nonneg_D with max_cd_steps
- * (solve_nonneg, common.c:2131-2179; k_t <= 140 / 199) and a scalar l1_lam (solve_elasticnet, :2228-2294).  Anything else returns 2. */
+ * (solve_nonneg, common.c:2131-2179; k_t <= 140 / 199), l1_lam (solve_elasticnet, :2228-2294) and the per-matrix
+ * lam_unique / l1_lam_unique (entries 2..5: A, B, C, D; :9793-9809, :9855-10016); dense U / II with NaN (= missing) under the
+ * plain Cholesky solver; precompute_for_predictions.  Anything else returns 2. */
 int_t fit_collective_implicit_als(
     real_t *A, real_t *B,
     real_t *C, real_t *D,
@@ -85,7 +86,12 @@ int_t fit_collective_implicit_als(
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
  * k_main/k_user/k_item, w_user/w_item; also SPARSE side information as COO triplets (missing = absent, rows within
  * X's; collective_closed_form_block / collective_block_cg with u_vec_sp, :1636-1653, :1719-1731, :2609-2621); nonneg /
- * nonneg_C / nonneg_D with max_cd_steps (solve_nonneg, common.c:2131-2179) and a scalar l1_lam (solve_elasticnet).  Anything else returns 2. */
+ * nonneg_C / nonneg_D with max_cd_steps (solve_nonneg, common.c:2131-2179), l1_lam (solve_elasticnet) and the per-matrix
+ * lam_unique / l1_lam_unique (user bias, item bias, A, B, C, D; :8178-8219, :8367-8423, :8649-8654, :8820-8825, :9066-9238);
+ * add_implicit_features with Ai, Bi, w_implicit (:8448-8534, :1704-1771, :2301-2304, :2624-2643, :2862-2868; Cholesky or
+ * CG / PCG, dense or no side information inside X, not with nonneg / L1 / precompute_for_predictions); dense U / II with
+ * NaN (= missing) under the Cholesky solver with unscaled lambda.  Not built: NA_as_zero_*, dense X, weights,
+ * scale_bias_const.  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,
