@@ -889,10 +889,25 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 T acc[NF];
 #pragma unroll
                 for (int c = 0; c < NF; c++) acc[c] = T(0);
-                for (int j = 0; j < P.ki; j++) {
-                    const T vj = bcast(v, koff + j);
+                // four rows of the matrix in flight: the loads do not depend on v
+                for (int j0 = 0; j0 < P.ki; j0 += 4) {
+                    T mrow[4][NF];
 #pragma unroll
-                    for (int c = 0; c < NF; c++) { int f = lane + 64 * c; if (f >= koff && f < koff + P.ki) acc[c] += vj * P.BiTBi[(size_t)j * P.ki + (f - koff)]; }
+                    for (int u = 0; u < 4; u++) {
+                        const int j = min(j0 + u, P.ki - 1);
+#pragma unroll
+                        for (int c = 0; c < NF; c++) {
+                            int f = lane + 64 * c;
+                            mrow[u][c] = (f >= koff && f < koff + P.ki) ? P.BiTBi[(size_t)j * P.ki + (f - koff)] : T(0);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (j0 + u >= P.ki) break;
+                        const T vj = bcast(v, koff + j0 + u);
+#pragma unroll
+                        for (int c = 0; c < NF; c++) acc[c] += vj * mrow[u][c];
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < NF; c++) out[c] += (mode == 0) ? -P.w_imp * acc[c] : P.w_imp * acc[c];
