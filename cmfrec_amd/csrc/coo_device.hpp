@@ -52,19 +52,20 @@ __global__ void coo_gather_kernel(const unsigned *__restrict__ perm, const int *
 // one wavefront per row, lane-strided double sums + a fixed butterfly, mean = sum / cnt: the same quantity up
 // to rounding (the strictly sequential form costs ~100 ns per entry on a GPU thread: 90 ms for the ten sweeps
 // of a MovieLens-10M-shaped matrix).
-__device__ __forceinline__ double bias_scale(size_t cnt, real_t lam_b, int scale_lam, int user_rule)
+// extra: attributes counted on top of the row's entries under scale_lam_sideinfo (wsumA / wsumB, collective.c:8071-8104)
+__device__ __forceinline__ double bias_scale(size_t cnt, real_t lam_b, int scale_lam, int user_rule, int extra = 0)
 {
 #pragma clang fp contract(off)
     // unfused on purpose: the reference's own binary (gcc -ffp-contract=fast) fuses cnt + lam*cnt into an FMA in the
     // item sweep but not in the user sweep -- a lowering accident, not semantics (differences of 1 ulp)
-    const double sc = user_rule ? (double)cnt : (double)(cnt > 1 ? cnt : 1);
+    const double sc = (user_rule ? (double)cnt : (double)(cnt > 1 ? cnt : 1)) + (double)extra;
     const double den = (double)cnt + (double)lam_b * (scale_lam ? sc : 1.);
     return (!user_rule || cnt > 0) ? (double)cnt / den : 1.;
 }
 
 __global__ void bias_sweep_kernel(const size_t *__restrict__ p, const int *__restrict__ idx, const real_t *__restrict__ v,
                                   const real_t *__restrict__ other, const int *__restrict__ order, int first_q, int rows,
-                                  real_t lam_b, int scale_lam, int user_rule, real_t *__restrict__ bias)
+                                  real_t lam_b, int scale_lam, int user_rule, real_t *__restrict__ bias, int extra, int extra_rows)
 {
 #pragma clang fp contract(off)
     const int q = first_q + blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,14 +78,14 @@ __global__ void bias_sweep_kernel(const size_t *__restrict__ p, const int *__res
     } else {
         for (size_t e = st; e < en; e++) bm += (v[e] - bm) / (double)(e - st + 1);
     }
-    bm *= bias_scale(cnt, lam_b, scale_lam, user_rule);
+    bm *= bias_scale(cnt, lam_b, scale_lam, user_rule, r < extra_rows ? extra : 0);
     bias[r] = (real_t)bm;
 }
 
 __global__ void __launch_bounds__(64)
 bias_sweep_long_kernel(const size_t *__restrict__ p, const int *__restrict__ idx, const real_t *__restrict__ v,
                        const real_t *__restrict__ other, const int *__restrict__ order, int n_long,
-                       real_t lam_b, int scale_lam, int user_rule, real_t *__restrict__ bias)
+                       real_t lam_b, int scale_lam, int user_rule, real_t *__restrict__ bias, int extra, int extra_rows)
 {
 #pragma clang fp contract(off)
     const int q = blockIdx.x;
@@ -98,7 +99,7 @@ bias_sweep_long_kernel(const size_t *__restrict__ p, const int *__restrict__ idx
         for (size_t e = st + threadIdx.x; e < en; e += 64) sum += (double)v[e];
     }
     sum = lanes::wave_sum(sum);
-    if (threadIdx.x == 0) bias[r] = (real_t)((sum / (double)cnt) * bias_scale(cnt, lam_b, scale_lam, user_rule));
+    if (threadIdx.x == 0) bias[r] = (real_t)((sum / (double)cnt) * bias_scale(cnt, lam_b, scale_lam, user_rule, r < extra_rows ? extra : 0));
 }
 
 __global__ void coo_desc_kernel(const unsigned *__restrict__ ord, const unsigned *__restrict__ len_sorted,

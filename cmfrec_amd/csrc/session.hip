@@ -455,13 +455,23 @@ int cmfrec_hip_session_init_biases(cmfrec_hip_session *s, real_t lam_user, real_
         }
         HIP_CHECK(hipSetDevice(s->dev.device));
         hipStream_t st = s->dev.stream;
+        // under scale_lam_sideinfo the rows that have side information count its attributes too (wsumA / wsumB,
+        // collective.c:8071-8104).  For sparse side information the reference adds `U_csr_p[row+1] - U_csr[row]` there -- an
+        // index minus a value (:8086): nothing to pin, so that combination is refused
+        if (m.scale_lam_sideinfo && ((s->sparseU && m.user_bias) || (s->sparseI && m.item_bias))) {
+            g_last_error = "cmfrec_hip: bias start values with scale_lam_sideinfo and sparse side information are not defined by the reference";
+            return 2;
+        }
         auto sweep = [&](const SparseShard &X, const real_t *other, real_t lam_b, int user_rule, real_t *bias) {
+            const bool users = (&X == &s->Xr);
+            const int extra = m.scale_lam_sideinfo ? (users ? m.p : m.q) : 0, extra_rows = users ? m.m_u : m.n_i;
             if (X.n_long > 0)
                 hipLaunchKernelGGL(bias_sweep_long_kernel, dim3(X.n_long), dim3(64), 0, st, X.p.ptr, X.i.ptr, X.v.ptr, other,
-                                   X.order.ptr, X.n_long, lam_b, (int)m.scale_lam, user_rule, bias);
+                                   X.order.ptr, X.n_long, lam_b, (int)m.scale_lam, user_rule, bias, extra, extra_rows);
             if (X.nrows > X.n_long)
                 hipLaunchKernelGGL(bias_sweep_kernel, dim3((X.nrows - X.n_long + 63) / 64), dim3(64), 0, st, X.p.ptr, X.i.ptr,
-                                   X.v.ptr, other, X.order.ptr, X.n_long, X.nrows, lam_b, (int)m.scale_lam, user_rule, bias);
+                                   X.v.ptr, other, X.order.ptr, X.n_long, X.nrows, lam_b, (int)m.scale_lam, user_rule, bias, extra,
+                                   extra_rows);
         };
         if (m.user_bias && !m.item_bias) {                                // collective.c:8166-8185
             sweep(s->Xr, nullptr, lam_user, 0, s->biasA.ptr);

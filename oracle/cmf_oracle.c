@@ -1013,6 +1013,9 @@ real_t oracle_calc_mean_and_center(real_t *X, size_t nnz, int nthreads)
     return glob_mean;
 }
 
+/* rows < g_init_rows_u / columns < g_init_cols_i count g_init_p / g_init_q attributes on top of their entries: wsumA /
+ * wsumB under scale_lam_sideinfo with dense side information (collective.c:8071-8104), set by the fit around its call */
+static int_t g_init_p = 0, g_init_rows_u = 0, g_init_q = 0, g_init_cols_i = 0;
 void oracle_initialize_biases_twosided(int_t m, int_t n,
                                        const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
                                        const size_t *Xcsc_p, const int_t *Xcsc_i, const real_t *Xcsc,
@@ -1030,7 +1033,8 @@ void oracle_initialize_biases_twosided(int_t m, int_t n,
             for (size_t ix = st; ix < en; ix++)
                 bmean += (Xcsc[ix] - biasA[Xcsc_i[ix]] - bmean) / (double)(ix - st + 1);
             size_t cnt = en - st;
-            bmean *= (double)cnt / ((double)cnt + lam_item * (scale_lam ? (double)(cnt > 1 ? cnt : 1) : 1.));
+            bmean *= (double)cnt / ((double)cnt + lam_item * (scale_lam ? (double)(cnt > 1 ? cnt : 1)
+                                                                          + (double)(col < g_init_cols_i ? g_init_q : 0) : 1.));
             biasB[col] = (real_t)bmean;
         }
         for (int_t row = 0; row < m; row++) {                                  /* :4799-4825 */
@@ -1040,7 +1044,8 @@ void oracle_initialize_biases_twosided(int_t m, int_t n,
                 bmean += (Xcsr[ix] - biasB[Xcsr_i[ix]] - bmean) / (double)(ix - st + 1);
             size_t cnt = en - st;
             if (cnt > 0)
-                bmean *= (double)cnt / ((double)cnt + lam_user * (scale_lam ? (double)cnt : 1.));
+                bmean *= (double)cnt / ((double)cnt + lam_user * (scale_lam ? (double)cnt
+                                                                          + (double)(row < g_init_rows_u ? g_init_p : 0) : 1.));
             biasA[row] = (real_t)bmean;
         }
     }
@@ -1245,9 +1250,11 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         if (item_bias) { csr_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csr_orig, csr_v, nnz * sizeof(real_t)); }
         if (user_bias) { csc_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csc_orig, csc_v, nnz * sizeof(real_t)); }
     }
+    if (scale_lam_sideinfo) { g_init_p = (U != NULL) ? p : 0; g_init_rows_u = m_u; g_init_q = (II != NULL) ? q : 0; g_init_cols_i = n_i; }
     if (has_bias && init_biases)                                               /* :8164-8226 */
         oracle_initialize_biases_twosided(m, n, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v,
                                           g_has_lam6 ? g_lam6[0] : lam, g_has_lam6 ? g_lam6[1] : lam, scale_lam, biasA, biasB);
+    g_init_p = g_init_q = 0; g_init_rows_u = g_init_cols_i = 0;
     if (has_bias) {                                                            /* :8283-8317 */
         for (int_t r = 0; r < m; r++) {
             memcpy(A_bias + (size_t)r * ldA, A + (size_t)r * k_totA, (size_t)k_totA * sizeof(real_t));

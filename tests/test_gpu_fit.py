@@ -254,6 +254,16 @@ def test_seeded_fit_matches_reference_seed(dtype):
     rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, scale_lam=True, niter=3, nthreads=2, reset_values=True,
                                        seed=13, w_item=2.0, I_coo=(ir, ic, iv, n, 12))
     assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and frob(mdl.D_, rr["D"]) < t
+    # dense side information under scale_lam_sideinfo: the bias start values count the attributes of the rows that have
+    # them on top of their entries (wsumA / wsumB, collective.c:8071-8104); U covers fewer users than X
+    U = rng.standard_normal((m - 60, 5)).astype(dtype); II = rng.standard_normal((n, 4)).astype(dtype)
+    mdl = CMF(k=k, lambda_=0.05, scale_lam_sideinfo=True, niter=2, random_state=17, use_float=uf, nthreads=1, use_cg=False,
+              w_user=2.0).fit((row, col, val), U=U, I=II, shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+    rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, scale_lam_sideinfo=True, niter=2, nthreads=2,
+                                       reset_values=True, seed=17, use_cg=False, finalize_chol=False, w_user=2.0, U=U, II=II)
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and frob(mdl.C_, rr["C"]) < t
+    assert frob(mdl.user_bias_, rr["biasA"]) < t and frob(mdl.item_bias_, rr["biasB"]) < t
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

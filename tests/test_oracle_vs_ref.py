@@ -309,3 +309,22 @@ def test_nan_side_info_live(oracles, refs, dtype):
         exp = gc.nan_side_reference(refs[dtype], d, implicit, which, sl, sls, nthreads=3, solver=solver)
         got = gc.nan_side_oracle(oracles[dtype], d, implicit, which, sl, sls, nthreads=1, solver=solver)
         assert gc.compare_fits(got, exp) < tol, name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_bias_start_values_count_side_information(oracles, refs, dtype):
+    """Bias initialisation under scale_lam_sideinfo with dense side information: rows / columns that have attributes scale
+    lambda by (entries + attributes) (wsumA / wsumB, collective.c:8071-8104 into common.c:4655-4665, :4812-4823)."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-4
+    d = gc.nonneg_problem(dtype, seed=71)
+    for sls, side in ((True, True), (True, False), (False, True)):
+        U, II = (d["U"][:120], d["I"]) if side else (None, None)
+        kw = dict(lam=0.3, U=U, II=II, nthreads=1, use_cg=False, finalize_chol=False, scale_lam=not sls, scale_lam_sideinfo=sls)
+        r0 = refs[dtype].fit_collective_explicit_als(d["A0"].copy(), d["B0"].copy(), d["row"], d["col"], d["ratings"], d["k"], niter=0,
+                                                     reset_values=True, seed=3, **kw)
+        exp = refs[dtype].fit_collective_explicit_als(d["A0"].copy(), d["B0"].copy(), d["row"], d["col"], d["ratings"], d["k"], niter=2,
+                                                      reset_values=True, seed=3, **kw)
+        got = oracles[dtype].fit_explicit_als(r0["A"].copy(), r0["B"].copy(), d["row"], d["col"], d["ratings"], d["k"], niter=2,
+                                              init_biases=True, **kw)
+        assert np.abs(r0["biasA"]).max() > 0 and gc.compare_fits(got, exp) < tol, (sls, side)
