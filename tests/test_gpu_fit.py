@@ -264,6 +264,21 @@ def test_seeded_fit_matches_reference_seed(dtype):
                                        reset_values=True, seed=17, use_cg=False, finalize_chol=False, w_user=2.0, U=U, II=II)
     assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and frob(mdl.C_, rr["C"]) < t
     assert frob(mdl.user_bias_, rr["biasA"]) < t and frob(mdl.item_bias_, rr["biasB"]) < t
+    # the same data with the CG solver (C, D start at zero, B is seeded because there is item side information, :8243-8273)
+    mdl = CMF(k=k, lambda_=0.05, scale_lam=True, niter=3, random_state=19, use_float=uf, nthreads=1, use_cg=True, finalize_chol=True,
+              w_user=2.0, k_user=2).fit((row, col, val), U=U, I=II, shape=(m, n))
+    Ar, Br = np.zeros((m, k + 2), dtype), np.zeros((n, k), dtype)
+    rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, scale_lam=True, niter=3, nthreads=2, reset_values=True,
+                                       seed=19, use_cg=True, finalize_chol=True, w_user=2.0, k_user=2, U=U, II=II)
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and frob(mdl.C_, rr["C"]) < t and frob(mdl.D_, rr["D"]) < t
+    # implicit model with dense side information, seeded (uniform start values, B seeded too, collective.c:9756-9785)
+    cnt = np.ceil(np.abs(val) * 3 + 1).astype(dtype)
+    mdl = CMF_implicit(k=k, lambda_=2., niter=3, random_state=23, use_float=uf, w_user=3.0, w_item=0.5, k_item=1).fit(
+        (row, col, cnt), U=U, I=II, shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k + 1), dtype)
+    rr = R.fit_collective_implicit_als(Ar, Br, row, col, cnt, k, lam=2., niter=3, nthreads=2, reset_values=True, seed=23, w_user=3.0,
+                                       w_item=0.5, k_item=1, U=U, II=II)
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t and frob(mdl.C_, rr["C"]) < t and frob(mdl.D_, rr["D"]) < t
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
