@@ -327,7 +327,6 @@ int_t fit_collective_explicit_als(
     real_t *precomputedBtXbias, real_t *precomputedBeTBeChol, real_t *precomputedBiTBi,
     real_t *precomputedTransCtCinvCt, real_t *precomputedCtCw, real_t *precomputedCtUbias)
 {
-    (void)scaling_biasA; (void)scaling_biasB;
     (void)handle_interrupt; (void)max_cd_steps;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // with add_implicit_features the prediction matrices are not produced here
@@ -381,7 +380,6 @@ int_t fit_collective_explicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (scale_bias_const) return fail(verbose, "cmfrec_hip: scale_bias_const is not implemented.");
     if ((l1_lam != 0 || l1_lam_unique) && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
     if (nonneg || l1_lam != 0 || l1_lam_unique) use_cg = false;           // collective.c:7474-7479
@@ -410,6 +408,29 @@ int_t fit_collective_explicit_als(
         for (int e = 0; e < 6; e++) { lam6[e] /= w_main; l16[e] /= w_main; }
     }
     const bool has_bias = user_bias || item_bias;
+    // scale_bias_const: the biases' lambda is scaled by one constant -- the mean over the rows of (entries + attributes
+    // counted under scale_lam_sideinfo) -- instead of row by row (collective.c:7555-7556, :8026-8048, :8071-8160)
+    if (!scale_lam || !has_bias) scale_bias_const = false;
+    if (scale_bias_const) {
+        if (add_implicit_features || spU || spI || nan_side)
+            return fail(verbose, "cmfrec_hip: scale_bias_const with implicit features / sparse or NaN side information is not implemented.");
+        if (item_bias && !user_bias && !use_cg)
+            return fail(verbose, "cmfrec_hip: scale_bias_const with only an item bias and the Cholesky solver: the reference leaves "
+                                 "scaling_biasB unset (collective.c:7934).");
+        if (!scaling_biasA || !scaling_biasB) return fail(verbose, "cmfrec_hip: scale_bias_const needs the scaling_biasA / scaling_biasB outputs.");
+        auto mean_count = [&](const int_t *ix, int_t rows, int_t extra, int_t extra_rows) {
+            std::vector<size_t> cnt((size_t)rows, 0);
+            for (size_t e = 0; e < nnz; e++) cnt[ix[e]]++;
+            double wmean = 0;
+            for (int_t r = 0; r < rows; r++) {
+                const real_t w = (real_t)(cnt[r] + (cnt[r] == 0)) + (real_t)((scale_lam_sideinfo && r < extra_rows) ? extra : 0);
+                wmean += ((double)w - wmean) / (double)(r + 1);
+            }
+            return (real_t)wmean;
+        };
+        if (user_bias) { *scaling_biasA = mean_count(ixA, m, U ? p : 0, m_u); lam6[0] *= *scaling_biasA; l16[0] *= *scaling_biasA; }
+        if (item_bias) { *scaling_biasB = mean_count(ixB, n, II ? q : 0, n_i); lam6[1] *= *scaling_biasB; l16[1] *= *scaling_biasB; }
+    }
     const int k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
     const int_t m_max = std::max(m, m_u), n_max = std::max(n, n_i);      // rows of A / B (collective.c:7332-7335)
 
@@ -480,8 +501,10 @@ int_t fit_collective_explicit_als(
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
-    if (!rc && (lam_unique || l1_lam_unique))
-        rc = cmfrec_hip_session_set_lam_unique(s, lam_unique ? lam6 : nullptr, l1_lam_unique ? l16 : nullptr, (int)max_cd_steps);
+    if (!rc && (lam_unique || l1_lam_unique || scale_bias_const))
+        rc = cmfrec_hip_session_set_lam_unique(s, (lam_unique || scale_bias_const) ? lam6 : nullptr,
+                                               (l1_lam_unique || (scale_bias_const && l1_lam != 0)) ? l16 : nullptr, (int)max_cd_steps);
+    if (!rc && scale_bias_const) rc = cmfrec_hip_session_set_scale_bias_const(s, 1);
     if (!rc) rc = cmfrec_hip_session_set_factors(s, A, B, reset_values ? nullptr : biasA, reset_values ? nullptr : biasB, C, D);
     // Ai / Bi need no start values: their first update is a closed-form solve (collective.c:8236-8240)
     if (!rc && add_implicit_features) rc = cmfrec_hip_session_set_implicit_features(s, w_implicit, nullptr, nullptr);

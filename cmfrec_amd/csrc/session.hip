@@ -247,6 +247,7 @@ struct cmfrec_hip_session {
     // per-matrix penalties, the reference's lam_unique / l1_lam_unique order (collective.c:430): user bias, item bias, A, B,
     // C, D -- after the w_main rescaling.  Scalar lam / l1_lam fill all six.
     real_t lam6[6] = {0, 0, 0, 0, 0, 0}, l16[6] = {0, 0, 0, 0, 0, 0};
+    bool scale_bias_const = false;   // explicit model: the bias' lambda is not scaled row by row (lam6[0], [1] carry a constant factor)
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
@@ -653,6 +654,12 @@ int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, 
     });
 }
 
+int cmfrec_hip_session_set_scale_bias_const(cmfrec_hip_session *s, int on)
+{
+    s->scale_bias_const = on != 0;
+    return 0;
+}
+
 int cmfrec_hip_session_set_lam_unique(cmfrec_hip_session *s, const real_t *lam_unique, const real_t *l1_lam_unique, int max_cd_steps)
 {
     if (lam_unique) for (int e = 0; e < 6; e++) s->lam6[e] = lam_unique[e];
@@ -743,6 +750,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const bool opp_bias = isA ? m.item_bias : m.user_bias;
     const int p_self = isA ? m.p : m.q;
     // lam_unique[2] / [3] for A / B; the bias, when fitted, takes lam_unique[0] / [1] (collective.c:8649-8654, :8820-8825)
+    const bool sbc = s->scale_bias_const && !m.implicit;      // rows without side information: common.c:679-723
     const real_t lam_self = s->lam6[isA ? 2 : 3];
     const real_t lam_last_self = (!m.implicit && self_bias) ? s->lam6[isA ? 0 : 1] : lam_self;
     real_t *self_blk = self + (size_t)(begin + (part >= 0 ? s->partBegin[part] : 0)) * ld_self;
@@ -836,7 +844,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
             if (opp_bias) bias_sub_cg = isA ? s->biasB.ptr : s->biasA.ptr;
         }
         CgCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kx, bias_sub_cg, m.implicit ? s->gram.ptr : nullptr,
-                 lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), false, m.max_cg_steps, (bool)m.implicit,
+                 lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), sbc, m.max_cg_steps, (bool)m.implicit,
                  (bool)m.precondition_cg};
         // explicit model: rows beyond X are not part of the block system (solve_sideinfo_only_rows)
         const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
@@ -930,7 +938,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
         const int local_u_main = std::min(local_u, local_x);              // rows beyond X: solve_sideinfo_only_rows
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, s->ctc.ptr, kc, local_u_main,
-                   p_self, lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false,
+                   p_self, lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, sbc,
                    CHOL_COLLECTIVE};
         add_implicit_term(c);
         int rc = launch_chol(dev, c, &X);
@@ -948,11 +956,11 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     }
     if (chol) {
         CholCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, 0, bias_sub, nullptr, 0, 0, 0,
-                   lam_self, lam_last_self, scale_lam, false, false, CHOL_EXPLICIT};
+                   lam_self, lam_last_self, scale_lam, false, sbc, CHOL_EXPLICIT};
         return launch_chol(dev, c, &X);
     }
     CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, ksolve, bias_sub, nullptr,
-             lam_self, lam_last_self, scale_lam, false, m.max_cg_steps, false, (bool)m.precondition_cg};
+             lam_self, lam_last_self, scale_lam, sbc, m.max_cg_steps, false, (bool)m.precondition_cg};
     if (s->implicit_feats) {
         // block CG with the implicit-features term (collective_block_cg without side information on this side,
         // collective.c:2624-2643, :2862-2868): generic kernel; rows without entries are zeroed (:1258-1268)

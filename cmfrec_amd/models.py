@@ -249,8 +249,9 @@ class CMF(_Base):
                  n_jobs=None):
         if method != "als":
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
-        if NA_as_zero or NA_as_zero_user or NA_as_zero_item or scale_bias_const:
-            raise NotImplementedError("NA_as_zero / scale_bias_const are not implemented in cmfrec_amd")
+        if NA_as_zero or NA_as_zero_user or NA_as_zero_item:
+            raise NotImplementedError("NA_as_zero is not implemented in cmfrec_amd")
+        self.scale_bias_const = bool(scale_bias_const)
         if add_implicit_features and (nonneg or not np.isscalar(l1_lambda) or l1_lambda):
             raise NotImplementedError("add_implicit_features together with nonneg / l1_lambda is not implemented in "
                                       "cmfrec_amd (the reference itself crashes on it)")
@@ -319,7 +320,7 @@ class CMF(_Base):
             _lib.ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
             C.c_size_t(len(val)), None, None, C.c_bool(self.user_bias), C.c_bool(self.item_bias),
             C.c_bool(self.center), R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16), C.c_bool(self.scale_lam),
-            C.c_bool(self.scale_lam_sideinfo), C.c_bool(False), _lib.ptr(sbA), _lib.ptr(sbB),
+            C.c_bool(self.scale_lam_sideinfo), C.c_bool(self.scale_bias_const), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
@@ -340,6 +341,7 @@ class CMF(_Base):
         self._BeTBeChol = BeChol if BeChol is not None else e
         self._TransCtCinvCt = TCt if TCt is not None else e
         self._CtCw = CtCw if CtCw is not None else e
+        self._scaling_biasA, self._scaling_biasB = float(sbA[0]), float(sbB[0])    # cmfrec/__init__.py: scaling_biasA_ / _B_
         self.A_, self.B_ = A, B
         self.Ai_ = Ai if imp else e                      # cmfrec/__init__.py:3195-3196
         self.Bi_ = Bi if imp else e
@@ -384,7 +386,8 @@ class CMF(_Base):
             None, C.c_int(n), None, _lib.ptr(self.B_), None, C.c_bool(False),
             C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
             R(self.lambda_), _lib.ptr(lam6), R(0.), None, C.c_bool(self.scale_lam), C.c_bool(self.scale_lam_sideinfo),
-            C.c_bool(False), R(1.), R(self.w_main), R(self.w_user), R(self.w_implicit),
+            C.c_bool(self.scale_bias_const), R(self._scaling_biasA if self.scale_bias_const else 1.), R(self.w_main), R(self.w_user),
+            R(self.w_implicit),
             C.c_int(n), C.c_bool(True),
             None, None, None, None, None,
             _lib.ptr(self._TransCtCinvCt) if (p and has(self._TransCtCinvCt)) else None, None, None, None,

@@ -90,8 +90,8 @@ int_t fit_collective_implicit_als(
  * lam_unique / l1_lam_unique (user bias, item bias, A, B, C, D; :8178-8219, :8367-8423, :8649-8654, :8820-8825, :9066-9238);
  * add_implicit_features with Ai, Bi, w_implicit (:8448-8534, :1704-1771, :2301-2304, :2624-2643, :2862-2868; Cholesky or
  * CG / PCG, dense or no side information inside X, not with nonneg / L1 / precompute_for_predictions); dense U / II with
- * NaN (= missing) under the Cholesky solver with unscaled lambda.  Not built: NA_as_zero_*, dense X, weights,
- * scale_bias_const.  Anything else returns 2. */
+ * NaN (= missing) under the Cholesky solver with unscaled lambda; scale_bias_const (scaling_biasA / scaling_biasB are
+ * outputs).  Not built: NA_as_zero_*, dense X, weights.  Anything else returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,
@@ -353,6 +353,11 @@ int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_
  * the model.  Whole-matrix sessions, dense or no side information. */
 int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_implicit, const real_t *Ai, const real_t *Bi);
 int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, real_t *Bi);
+
+/* scale_bias_const of the explicit model (/root/reference/src/collective.c:7555, :8110-8160): rows solved without side
+ * information keep the bias' lambda as given (lam_unique[0] / [1], which the caller has multiplied by scaling_biasA /
+ * scaling_biasB) instead of scaling it by the row's count (common.c:679-723). */
+int cmfrec_hip_session_set_scale_bias_const(cmfrec_hip_session *s, int on);
 
 /* Per-matrix penalties (lam_unique / l1_lam_unique of the fit entry points, /root/reference/src/collective.c:430):
  * six values each in the order user bias, item bias, A, B, C, D, already divided by w_main.  Either pointer may be NULL

@@ -90,6 +90,10 @@ class Oracle:
         self._lam6, self._l16 = cv(lam_unique), cv(l1_lam_unique)
         self.lib.oracle_set_lam_unique(_ptr(self._lam6), _ptr(self._l16))
 
+    def set_scale_bias_const(self, on):
+        """scale_bias_const of the following explicit fits."""
+        self.lib.oracle_set_scale_bias_const(C.c_bool(on))
+
     def set_nonneg_now(self, on, max_cd_steps=100):
         """The same for operator-level calls outside a fit."""
         self.lib.oracle_set_nonneg_now(C.c_bool(on), C.c_int(max_cd_steps))
@@ -714,7 +718,7 @@ class Reference:
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
                                     l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
-                                    l1_lam_unique=None):
+                                    l1_lam_unique=None, scale_bias_const=False):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
@@ -753,7 +757,7 @@ class Reference:
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             None, None, C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
             self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),
-            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(False), _ptr(sbA), _ptr(sbB),
+            C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_bool(False),
@@ -765,4 +769,4 @@ class Reference:
             C.c_bool(precompute), C.c_bool(True), pp("B_plus_bias"), pp("BtB"), pp("TransBtBinvBt"), pp("BtXbias"),
             pp("BeTBeChol"), pp("BiTBi"), pp("TransCtCinvCt"), pp("CtCw"), pp("CtUbias"))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, biasA=biasA, biasB=biasB, glob_mean=glob_mean[0],
-                    U_colmeans=Ucm, I_colmeans=Icm, pre=pre, Ai=Ai, Bi=Bi)
+                    U_colmeans=Ucm, I_colmeans=Icm, pre=pre, Ai=Ai, Bi=Bi, scaling_biasA=sbA[0], scaling_biasB=sbB[0])

@@ -193,6 +193,10 @@ void oracle_set_lam_unique(const real_t *lam6, const real_t *l16)
     g_has_lam6 = lam6 != NULL; g_has_l16 = l16 != NULL;
     for (int i = 0; i < 6; i++) { g_lam6[i] = lam6 ? lam6[i] : 0; g_l16[i] = l16 ? l16[i] : 0; }
 }
+/* scale_bias_const of the explicit fit (collective.c:7555, :8110-8160); rows solved without side information then keep the
+ * bias' lambda unscaled (common.c:679-723), rows of the block system scale it anyway (collective.c:1347-1348) */
+static bool g_scale_bias_const = false;
+void oracle_set_scale_bias_const(bool on) { g_scale_bias_const = on; }
 static bool g_l1_last_set = false;       /* the last unknown (a fitted bias) carries its own L1 penalty */
 static real_t g_l1_last = 0;
 static void solve_sym_(int_t k, real_t *M, int_t ld, real_t *b)
@@ -700,7 +704,7 @@ static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t 
             if (nnz == 0) mult = 1;                                            /* :1332-1336 */
             if (scale_lam_sideinfo && has_u) mult += (real_t)p;                /* :1338-1346 */
             lam_i *= mult;
-            lam_last_i *= mult;
+            if (has_u || !g_scale_bias_const) lam_last_i *= mult;             /* rows >= m_u: plain optimizeA (:4832-4965) */
             t_l1_mult = mult;
         } else t_l1_mult = 1;
         real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
@@ -794,7 +798,7 @@ static void collective_cg_impl(real_t *A, size_t lda, const real_t *B, size_t ld
                     if (scale_lam_sideinfo) mult += sparse_u ? (real_t)(ue - us) : (real_t)p;
                     lam_i *= mult; lam_last_i *= mult;
                 }
-            } else if (scale_lam) { lam_i *= (real_t)nnz; lam_last_i *= (real_t)nnz; }   /* common.c:679-723 */
+            } else if (scale_lam) { lam_i *= (real_t)nnz; if (!g_scale_bias_const) lam_last_i *= (real_t)nnz; }   /* common.c:679-723 */
         }
         real_t r[512], pp[512], Ap[512], z[512], PC[512], ctu[512];
         /* Ap-type product: out = [BtB v_x] + sum_j w_j(B_j.v_x) B_j + w CtC v_u  (no lambda) */
@@ -1221,10 +1225,12 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
      * C / D (:8367, :8418), [3] / [2] for Bi / Ai (:8469, :8510) */
     const real_t lamA = g_has_lam6 ? g_lam6[2] : lam, lamB = g_has_lam6 ? g_lam6[3] : lam;
     const real_t lamC = g_has_lam6 ? g_lam6[4] : lam, lamD = g_has_lam6 ? g_lam6[5] : lam;
-    const real_t lamAl = (g_has_lam6 && user_bias) ? g_lam6[0] : lamA, lamBl = (g_has_lam6 && item_bias) ? g_lam6[1] : lamB;
+    real_t lamAl = (g_has_lam6 && user_bias) ? g_lam6[0] : lamA, lamBl = (g_has_lam6 && item_bias) ? g_lam6[1] : lamB;
     const real_t l1A = g_has_l16 ? g_l16[2] : l1f, l1B = g_has_l16 ? g_l16[3] : l1f;
     const real_t l1C = g_has_l16 ? g_l16[4] : l1f, l1D = g_has_l16 ? g_l16[5] : l1f;
-    const real_t l1Al = (g_has_l16 && user_bias) ? g_l16[0] : l1A, l1Bl = (g_has_l16 && item_bias) ? g_l16[1] : l1B;
+    real_t l1Al = (g_has_l16 && user_bias) ? g_l16[0] : l1A, l1Bl = (g_has_l16 && item_bias) ? g_l16[1] : l1B;
+    bool sbc = g_scale_bias_const && scale_lam && (user_bias || item_bias);    /* :7555-7556 */
+    if (sbc && (imp || (item_bias && !user_bias && !use_cg))) return 2;        /* not restated / scaling_biasB unset in the reference */
     if (!use_cg) finalize_chol = false;                                        /* :7481 */
     int_t has_bias = (user_bias || item_bias) ? 1 : 0;
     int_t k_totA = k_user + k + k_main, k_totB = k_item + k + k_main;
@@ -1250,10 +1256,30 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         if (item_bias) { csr_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csr_orig, csr_v, nnz * sizeof(real_t)); }
         if (user_bias) { csc_orig = (real_t *)malloc(nnz * sizeof(real_t)); memcpy(csc_orig, csc_v, nnz * sizeof(real_t)); }
     }
+    if (sbc) {                                                                 /* :8026-8048, :8071-8160 */
+        if (user_bias) {
+            double wmean = 0;
+            for (int_t r = 0; r < m_x; r++) {
+                size_t cnt = csr_p[(size_t)r + 1] - csr_p[r];
+                real_t w = (real_t)(cnt + (cnt == 0)) + (real_t)((scale_lam_sideinfo && U != NULL && r < m_u) ? p : 0);
+                wmean += ((double)w - wmean) / (double)(r + 1);
+            }
+            lamAl *= (real_t)wmean; l1Al *= (real_t)wmean;
+        }
+        if (item_bias) {
+            double wmean = 0;
+            for (int_t c = 0; c < n_x; c++) {
+                size_t cnt = csc_p[(size_t)c + 1] - csc_p[c];
+                real_t w = (real_t)(cnt + (cnt == 0)) + (real_t)((scale_lam_sideinfo && II != NULL && c < n_i) ? q : 0);
+                wmean += ((double)w - wmean) / (double)(c + 1);
+            }
+            lamBl *= (real_t)wmean; l1Bl *= (real_t)wmean;
+        }
+    }
     if (scale_lam_sideinfo) { g_init_p = (U != NULL) ? p : 0; g_init_rows_u = m_u; g_init_q = (II != NULL) ? q : 0; g_init_cols_i = n_i; }
     if (has_bias && init_biases)                                               /* :8164-8226 */
         oracle_initialize_biases_twosided(m, n, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v,
-                                          g_has_lam6 ? g_lam6[0] : lam, g_has_lam6 ? g_lam6[1] : lam, scale_lam, biasA, biasB);
+                                          user_bias ? lamAl : lam, item_bias ? lamBl : lam, scale_lam, biasA, biasB);
     g_init_p = g_init_q = 0; g_init_rows_u = g_init_cols_i = 0;
     if (has_bias) {                                                            /* :8283-8317 */
         for (int_t r = 0; r < m; r++) {
@@ -1302,7 +1328,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         else                                                                   /* :8680-8717 */
             oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
                                       k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
-                                      lamB, lamBl, scale_lam, false, nthreads,
+                                      lamB, lamBl, scale_lam, sbc, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
         if (II != NULL) {
         if (n_i > n_x) {                                            /* rows known from side information only */
@@ -1333,7 +1359,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         else                                                                   /* :8847-8876 */
             oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,
                                       k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
-                                      lamA, lamAl, scale_lam, false, nthreads,
+                                      lamA, lamAl, scale_lam, sbc, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
         if (U != NULL) {
         if (m_u > m_x) {                                            /* rows known from side information only */

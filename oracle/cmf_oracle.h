@@ -146,6 +146,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                             int_t niter, int nthreads,
                             bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
                             bool init_biases);
+void oracle_set_scale_bias_const(bool on);
 void oracle_set_lam_unique(const real_t *lam6, const real_t *l16);
 int oracle_fit_explicit_als(real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                             real_t *glob_mean, real_t *U_colmeans, real_t *I_colmeans,

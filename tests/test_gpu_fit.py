@@ -282,6 +282,37 @@ def test_seeded_fit_matches_reference_seed(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_scale_bias_const_matches_reference(dtype):
+    """scale_bias_const through the estimator, seeded like the reference (the scaling constants are outputs of the fit):
+    Cholesky and CG, with and without dense side information (fewer users in U than in X), single biases."""
+    from oracle.bindings import Reference, ref_available
+    if not ref_available(dtype):
+        pytest.skip("oracle/_ref not built")
+    from cmfrec_amd import CMF
+    from test_oracle_vs_ref import SCALE_BIAS_CONST_CASES
+    R = Reference(dtype)
+    uf = dtype is np.float32
+    m, n, k = 700, 500, 24
+    row, col, val = make_coo(m, n, 20000, 35, counts=False, dtype=dtype)
+    rng = np.random.default_rng(8)
+    Ud = rng.standard_normal((m - 60, 5)).astype(dtype); Id = rng.standard_normal((n, 4)).astype(dtype)
+    t = 1e-6 if dtype is np.float64 else 1e-2
+    for name, side, o in SCALE_BIAS_CONST_CASES:
+        o = dict(o); U, II = (Ud, Id) if side else (None, None)
+        kw = dict(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+        mdl = CMF(k=k, lambda_=0.05, niter=2, random_state=29, use_float=uf, nthreads=1, scale_bias_const=True,
+                  precompute_for_predictions=False, **kw).fit((row, col, val), U=U, I=II, shape=(m, n))
+        Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+        rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, niter=2, nthreads=2, reset_values=True, seed=29,
+                                           scale_bias_const=True, U=U, II=II, **kw)
+        assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t, name
+        if mdl.user_bias:
+            assert frob(mdl.user_bias_, rr["biasA"]) < t and abs(mdl._scaling_biasA - rr["scaling_biasA"]) < 1e-5 * rr["scaling_biasA"], name
+        if mdl.item_bias:
+            assert frob(mdl.item_bias_, rr["biasB"]) < t and abs(mdl._scaling_biasB - rr["scaling_biasB"]) < 1e-5 * rr["scaling_biasB"], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("side", [False, True])
 def test_factors_multiple_after_fit(oracles, dtype, side):
     """``factors_multiple`` of the estimators (factors_collective_*_multiple underneath).  A fit that ends on a Cholesky

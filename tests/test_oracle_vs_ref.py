@@ -328,3 +328,36 @@ def test_bias_start_values_count_side_information(oracles, refs, dtype):
         got = oracles[dtype].fit_explicit_als(r0["A"].copy(), r0["B"].copy(), d["row"], d["col"], d["ratings"], d["k"], niter=2,
                                               init_biases=True, **kw)
         assert np.abs(r0["biasA"]).max() > 0 and gc.compare_fits(got, exp) < tol, (sls, side)
+
+
+SCALE_BIAS_CONST_CASES = [("sl chol", False, dict(scale_lam=True)), ("sl cg", False, dict(scale_lam=True, use_cg=True, finalize_chol=True)),
+                          ("sls side chol", True, dict(scale_lam_sideinfo=True)), ("sl side cg m_u<m", True, dict(scale_lam=True, use_cg=True)),
+                          ("user bias only", False, dict(scale_lam=True, item_bias=False)),
+                          ("item bias only cg", False, dict(scale_lam=True, user_bias=False, use_cg=True))]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_scale_bias_const_live(oracles, refs, dtype):
+    """scale_bias_const: the biases' lambda takes one constant factor -- the mean over the rows of (entries + attributes counted
+    under scale_lam_sideinfo), collective.c:8026-8048, :8071-8160 -- while rows solved without side information stop scaling it
+    by their own count (common.c:679-723); the bias start values still multiply by the row's count (:4655-4665)."""
+    import golden_cases as gc
+    tol = 1e-11 if dtype is np.float64 else 2e-3          # whole fits, CG among them: the single-precision fit tolerance
+    d = gc.nonneg_problem(dtype, seed=73)
+    for name, side, o in SCALE_BIAS_CONST_CASES:
+        o = dict(o)
+        U, II = (d["U"][:120], d["I"]) if side else (None, None)
+        kw = dict(lam=0.3, U=U, II=II, nthreads=1, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+        args = (d["row"], d["col"], d["ratings"], d["k"])
+        r0 = refs[dtype].fit_collective_explicit_als(d["A0"].copy(), d["B0"].copy(), *args, niter=0, reset_values=True, seed=3,
+                                                     scale_bias_const=True, **kw)
+        exp = refs[dtype].fit_collective_explicit_als(d["A0"].copy(), d["B0"].copy(), *args, niter=2, reset_values=True, seed=3,
+                                                      scale_bias_const=True, **kw)
+        oracles[dtype].set_scale_bias_const(True)
+        try:
+            both = kw.get("user_bias", True) == kw.get("item_bias", True)
+            got = oracles[dtype].fit_explicit_als(r0["A"].copy(), r0["B"].copy(), *args, niter=2, init_biases=both,
+                                                  biasA=r0["biasA"].copy(), biasB=r0["biasB"].copy(), **kw)
+        finally:
+            oracles[dtype].set_scale_bias_const(False)
+        assert max(exp["scaling_biasA"], exp["scaling_biasB"]) > 1 and gc.compare_fits(got, exp) < tol, name
