@@ -310,6 +310,14 @@ def test_scale_bias_const_matches_reference(dtype):
             assert frob(mdl.user_bias_, rr["biasA"]) < t and abs(mdl._scaling_biasA - rr["scaling_biasA"]) < 1e-5 * rr["scaling_biasA"], name
         if mdl.item_bias:
             assert frob(mdl.item_bias_, rr["biasB"]) < t and abs(mdl._scaling_biasB - rr["scaling_biasB"]) < 1e-5 * rr["scaling_biasB"], name
+        if name == "sl chol":
+            # the scaling constant travels to the new-row function: a fit that ends on a Cholesky A-step leaves the closed-form
+            # factors of its own rows, so the training data handed back reproduces A_ and the user biases
+            import scipy.sparse as sp
+            A2, b2 = mdl.factors_multiple(sp.csr_matrix((val, (row, col)), shape=(m, n)), return_bias=True)
+            ne = np.bincount(row, minlength=m) > 0
+            t2 = 1e-8 if dtype is np.float64 else 5e-3
+            assert np.abs(A2[ne] - mdl.A_[ne]).max() < t2 * max(1.0, np.abs(mdl.A_).max()) and np.abs(b2[ne] - mdl.user_bias_[ne]).max() < t2 * 10
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
