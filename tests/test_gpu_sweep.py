@@ -101,3 +101,33 @@ def test_nonneg_width_sweep(oracles, dtype, k):
         O.set_nonneg(False, False, False, 100)
     tol = 1e-6 if dtype is np.float64 else 1e-2
     assert rel_err(mdl.A_, a2) < tol and rel_err(mdl.B_, b2) < tol and (mdl.A_ >= 0).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k,use_cg", [(40, True), (70, True), (70, False), (130, False)])
+def test_implicit_features_long_rows(oracles, dtype, k, use_cg):
+    """Implicit features on a matrix with long item rows (one beyond 1024 entries, most beyond 128): the sixteen- and
+    four-wavefront teams of the generic CG kernel with the Bi gather term, the wide tile counts of the shared-matrix
+    (CHOL_NAZ, right-hand sides only + library triangular solves) and two-source Cholesky launches -- against the oracle."""
+    from cmfrec_amd import CMF
+    rng = np.random.default_rng(91)
+    m, n = 1500, 30
+    lin = rng.choice(m * n, size=19000, replace=False)
+    row = (lin // n).astype(np.int32); col = (lin % n).astype(np.int32)
+    extra = np.setdiff1d(np.arange(m, dtype=np.int32), row[col == 0])[:900]          # item 0: > 1024 entries
+    row = np.concatenate([row, extra]); col = np.concatenate([col, np.zeros(len(extra), np.int32)])
+    assert np.bincount(col, minlength=n)[0] > 1024
+    val = (0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    bA = np.zeros(m, dtype); bB = np.zeros(n, dtype)
+    kw = dict(use_cg=use_cg, finalize_chol=False)
+    mdl = CMF(k=k, lambda_=2.0, niter=2, use_float=dtype is np.float32, add_implicit_features=True, w_implicit=0.7,
+              precompute_for_predictions=False, **kw)
+    mdl.fit((row, col, val), shape=(m, n), A0=A0, B0=B0, biasA0=bA, biasB0=bB)
+    o = oracles[dtype].fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), lam=2.0, niter=2,
+                                        nthreads=4, add_implicit_features=True, w_implicit=0.7, **kw)
+    assert o["ret"] == 0
+    tol = 1e-7 if dtype is np.float64 else 1e-2
+    for got, exp in ((mdl.A_, o["A"]), (mdl.B_, o["B"]), (mdl.Ai_, o["Ai"]), (mdl.Bi_, o["Bi"]), (mdl.user_bias_, o["biasA"]),
+                     (mdl.item_bias_, o["biasB"])):
+        assert np.isfinite(got).all() and np.abs(got - exp).max() <= tol * max(1.0, np.abs(exp).max())
