@@ -131,3 +131,38 @@ def test_implicit_features_long_rows(oracles, dtype, k, use_cg):
     for got, exp in ((mdl.A_, o["A"]), (mdl.B_, o["B"]), (mdl.Ai_, o["Ai"]), (mdl.Bi_, o["Bi"]), (mdl.user_bias_, o["biasA"]),
                      (mdl.item_bias_, o["biasB"])):
         assert np.isfinite(got).all() and np.abs(got - exp).max() <= tol * max(1.0, np.abs(exp).max())
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("implicit,pcg", [(True, False), (True, True), (False, False), (False, True)])
+def test_block_cg_long_rows(oracles, dtype, implicit, pcg):
+    """The block CG / PCG with dense side information on long rows (one item beyond 1024 entries: the sixteen-wavefront team
+    of the generic kernel, most items beyond 128: the four-wavefront one) against the oracle, both models."""
+    from cmfrec_amd import CMF, CMF_implicit
+    rng = np.random.default_rng(93)
+    m, n, k = 1500, 30, 24
+    lin = rng.choice(m * n, size=19000, replace=False)
+    row = (lin // n).astype(np.int32); col = (lin % n).astype(np.int32)
+    extra = np.setdiff1d(np.arange(m, dtype=np.int32), row[col == 0])[:900]
+    row = np.concatenate([row, extra]); col = np.concatenate([col, np.zeros(len(extra), np.int32)])
+    val = (0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    U = rng.standard_normal((m, 6)).astype(dtype); II = rng.standard_normal((n, 4)).astype(dtype)
+    A0 = (rng.standard_normal((m, k + 1)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    kw = dict(use_cg=True, precondition_cg=pcg, finalize_chol=False, k_user=1, w_user=2.0, w_item=0.5)
+    O = oracles[dtype]
+    tol = 1e-7 if dtype is np.float64 else 1e-2
+    if implicit:
+        mdl = CMF_implicit(k=k, lambda_=3.0, niter=2, use_float=dtype is np.float32, precompute_for_predictions=False, **kw)
+        mdl.fit((row, col, val), U=U, I=II, shape=(m, n), A0=A0, B0=B0)
+        A1, B1 = A0.copy(), B0.copy()
+        o = O.fit_implicit_als_sideinfo(A1, B1, row, col, val, k, lam=3.0, niter=2, U=U, II=II, nthreads=4, **kw)
+        pairs = ((mdl.A_, A1), (mdl.B_, B1), (mdl.C_, o["C"]), (mdl.D_, o["D"]))
+    else:
+        bA = np.zeros(m, dtype); bB = np.zeros(n, dtype)
+        mdl = CMF(k=k, lambda_=3.0, niter=2, use_float=dtype is np.float32, precompute_for_predictions=False, **kw)
+        mdl.fit((row, col, val), U=U, I=II, shape=(m, n), A0=A0, B0=B0, biasA0=bA, biasB0=bB)
+        o = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), lam=3.0, niter=2, U=U, II=II,
+                               nthreads=4, **kw)
+        pairs = ((mdl.A_, o["A"]), (mdl.B_, o["B"]), (mdl.C_, o["C"]), (mdl.D_, o["D"]), (mdl.user_bias_, o["biasA"]))
+    for got, exp in pairs:
+        assert np.isfinite(got).all() and np.abs(got - exp).max() <= tol * max(1.0, np.abs(exp).max())
