@@ -329,6 +329,65 @@ __global__ void embed_block_kernel(const T *__restrict__ G, int kb, int ks, int 
     }
 }
 
+// Right-hand sides of the shared-matrix update (optimizeA Case 3 on the binary indicator, tgemm_sp_dense with unit values,
+// common.c:3145-3151): out[row, :] = sum over the row's entries j of F[idx_j, :].  Two stages so that a row of tens of
+// thousands of entries is not one wavefront's chain and the sum order stays fixed: (1) one wavefront per segment of up to
+// GSUM_SEG entries, lane <-> column, four entries in flight; (2) one wavefront per row adds its segments in order.
+constexpr int GSUM_SEG = 256;
+constexpr int GSUM_MAXC = 5;                 // columns per lane: k + k_main <= 320
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_sum_segments_kernel(const size_t *__restrict__ indptr, const int *__restrict__ indices, const T *__restrict__ F, size_t ldf,
+                           int kk, const int *__restrict__ seg_row, const int *__restrict__ seg_off, int nseg, T *__restrict__ partial)
+{
+    const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (seg >= nseg) return;
+    const int row = seg_row[seg];
+    const size_t st = indptr[row] + (size_t)seg_off[seg];
+    const int len = (int)min((size_t)GSUM_SEG, indptr[row + 1] - st);
+    T acc[GSUM_MAXC];
+#pragma unroll
+    for (int c = 0; c < GSUM_MAXC; c++) acc[c] = T(0);
+    for (int j0 = 0; j0 < len; j0 += 4) {
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) idx[u] = indices[st + min(j0 + u, len - 1)];
+        T v[4][GSUM_MAXC];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < GSUM_MAXC; c++) {
+                const int f = lane + 64 * c;
+                v[u][c] = (f < kk && j0 + u < len) ? F[(size_t)idx[u] * ldf + f] : T(0);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < GSUM_MAXC; c++) acc[c] += v[u][c];
+    }
+#pragma unroll
+    for (int c = 0; c < GSUM_MAXC; c++) {
+        const int f = lane + 64 * c;
+        if (f < kk) partial[(size_t)seg * kk + f] = acc[c];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+gather_sum_rows_kernel(const T *__restrict__ partial, const int *__restrict__ row_seg_first, int rows, int kk, T *__restrict__ out,
+                       size_t ldo)
+{
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int s0 = row_seg_first[row], s1 = row_seg_first[row + 1];
+    for (int f = lane; f < kk; f += 64) {
+        T acc = T(0);
+        for (int sg = s0; sg < s1; sg++) acc += partial[(size_t)sg * kk + f];
+        out[(size_t)row * ldo + f] = acc;
+    }
+}
+
 // U[r, c] -= colmeans[c]  (preprocess_vec on the rows of new side information, collective.c:6337-6349)
 template <typename T>
 __global__ void sub_colmeans_kernel(T *__restrict__ U, size_t rows, int p, const T *__restrict__ colmeans)

@@ -244,6 +244,9 @@ struct cmfrec_hip_session {
     bool implicit_feats = false;
     real_t w_implicit = 1;
     DevBuf<real_t> Ai, Bi, bitbi, bitbi_full, ones;
+    // segment tables of the two-stage right-hand-side gather of the Ai / Bi updates ([0]: rows of X, [1]: columns)
+    struct GatherSegs { DevBuf<int> seg_row, seg_off, row_first; int nseg = 0; } gsegs[2];
+    DevBuf<real_t> gpartial;
     // per-matrix penalties, the reference's lam_unique / l1_lam_unique order (collective.c:430): user bias, item bias, A, B,
     // C, D -- after the w_main rescaling.  Scalar lam / l1_lam fill all six.
     real_t lam6[6] = {0, 0, 0, 0, 0, 0}, l16[6] = {0, 0, 0, 0, 0, 0};
@@ -634,6 +637,28 @@ int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_imp
         if (Bi) HIP_CHECK(hipMemcpyAsync(s->Bi.ptr, Bi, (size_t)m.n * kk * sizeof(real_t), hipMemcpyHostToDevice, s->dev.stream));
         else HIP_CHECK(hipMemsetAsync(s->Bi.ptr, 0, (size_t)m.n * kk * sizeof(real_t), s->dev.stream));
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        // segments of up to GSUM_SEG entries per row, in row order
+        size_t max_seg = 0;
+        for (int o = 0; o < 2; o++) {
+            const SparseShard &X = o == 0 ? s->Xr : s->Xc;
+            std::vector<size_t> hp((size_t)X.nrows + 1);
+            X.p.download(hp.data(), hp.size(), s->dev.stream);
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+            std::vector<int> srow, soff, rfirst((size_t)X.nrows + 1, 0);
+            for (int r = 0; r < X.nrows; r++) {
+                rfirst[r] = (int)srow.size();
+                for (size_t off = 0; off < hp[r + 1] - hp[r]; off += GSUM_SEG) { srow.push_back(r); soff.push_back((int)off); }
+            }
+            rfirst[X.nrows] = (int)srow.size();
+            auto &G = s->gsegs[o];
+            G.nseg = (int)srow.size();
+            G.seg_row.upload(srow.data(), std::max<size_t>(srow.size(), 1), s->dev.stream);
+            G.seg_off.upload(soff.data(), std::max<size_t>(soff.size(), 1), s->dev.stream);
+            G.row_first.upload(rfirst.data(), rfirst.size(), s->dev.stream);
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+            max_seg = std::max(max_seg, srow.size());
+        }
+        s->gpartial.alloc(std::max<size_t>(max_seg, 1) * kk);
         s->w_implicit = w_implicit;
         s->implicit_feats = true;
         return 0;
@@ -993,9 +1018,21 @@ static int update_implicit_feats(cmfrec_hip_session *s, bool isAi)
         return launch_chol(dev, c, &X);             // coordinate descent: per row on the assembled system
     // one factorisation of the shared matrix, the row kernel only gathers the right-hand sides (first version: the
     // matrix factorised once per row -- c1 + implicit features 8 ms for Bi + Ai)
-    c.rhs_only = true;
-    int rc = launch_chol(dev, c, &X);
-    if (rc) return rc;
+    // ... first by the row kernel itself (rhs_only: CMFREC_HIP_NAZ_ROWKERNEL=1), whose staging loop made the longest
+    // row the critical path (Bi at the C1 shape 4.5 ms); now a two-stage segmented gather-sum
+    auto &G = s->gsegs[isAi ? 0 : 1];
+    if (kk <= 64 * GSUM_MAXC && getenv("CMFREC_HIP_NAZ_ROWKERNEL") == nullptr) {
+        if (G.nseg > 0)
+            hipLaunchKernelGGL(gather_sum_segments_kernel<real_t>, dim3((G.nseg + 3) / 4), dim3(256), 0, dev.stream, X.p.ptr, X.i.ptr, F, ldf,
+                               kk, G.seg_row.ptr, G.seg_off.ptr, G.nseg, s->gpartial.ptr);
+        hipLaunchKernelGGL(gather_sum_rows_kernel<real_t>, dim3((rows_self + 3) / 4), dim3(256), 0, dev.stream, s->gpartial.ptr,
+                           G.row_first.ptr, rows_self, kk, self, (size_t)kk);
+        HIP_CHECK(hipGetLastError());
+    } else {
+        c.rhs_only = true;
+        int rc = launch_chol(dev, c, &X);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, dev.stream, s->gram.ptr, kk);
     HIP_CHECK(hipGetLastError());
     launch_potrs_rows(dev, rows_self, kk, s->gram.ptr, self, (size_t)kk);
