@@ -71,6 +71,8 @@ struct CholParams {
     int koff2 = 0;
     int w2_syr_zero = 0;
     int rows_src2 = -1;                   // rows that have second-source entries (default: rows_with_u)
+    int rhs_prefilled_all = 0;            // every row's right-hand side starts from what the caller left in A (collective modes:
+                                          // not only the rows with side information) -- the implicit-features term
     int rhs_only = 0;                     // CHOL_NAZ: store the gathered right-hand side and stop (the shared matrix is
                                           // factorised once by the caller, the solve is one triangular-solve pair)
     const T *values_override = nullptr;   // read the entries' values from here instead of `values` (all-ones indicator)
@@ -354,7 +356,7 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
         for (int tt = 0; tt < TPW; tt++) acc[tt] = vec{0, 0, 0, 0};
         // right-hand side: thread t owns unknown t
-        T racc = (has_u && tid < kt) ? arow[tid] : T(0);               // w*U*C prefilled (collective.c:5768-5773)
+        T racc = ((has_u || P.rhs_prefilled_all) && tid < kt) ? arow[tid] : T(0);   // w*U*C prefilled (collective.c:5768-5773)
         // software pipeline over chunks of CHOL_CHUNK gathered rows:
         //   indices (+ x values) of chunk c+2  ->  rows (+ bias of x) of chunk c+1  ->  LDS slot / MFMAs of chunk c
         // loads are unconditional on clamped addresses, padding is selected to zero afterwards

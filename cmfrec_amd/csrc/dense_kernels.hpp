@@ -388,6 +388,17 @@ gather_sum_rows_kernel(const T *__restrict__ partial, const int *__restrict__ ro
     }
 }
 
+// dst[r, off + f] += scale * src[r, f]  for f < kk: the gathered implicit-features term joins the prefilled right-hand sides
+template <typename T>
+__global__ void add_cols_scaled_kernel(T *__restrict__ dst, size_t ldd, int off, const T *__restrict__ src, int kk, T scale, size_t rows)
+{
+    const size_t total = rows * (size_t)kk;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / (size_t)kk; const int f = (int)(e % (size_t)kk);
+        dst[r * ldd + off + f] += scale * src[e];
+    }
+}
+
 // U[r, c] -= colmeans[c]  (preprocess_vec on the rows of new side information, collective.c:6337-6349)
 template <typename T>
 __global__ void sub_colmeans_kernel(T *__restrict__ U, size_t rows, int p, const T *__restrict__ colmeans)
