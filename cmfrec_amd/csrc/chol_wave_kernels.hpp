@@ -1,0 +1,400 @@
+// chol_wave_kernels.hpp -- closed-form (Cholesky) ALS row updates, one WAVEFRONT per row (gfx950).
+//
+// Same arithmetic as chol_rows_kernel (chol_kernels.hpp) -- factors_closed_form /root/reference/src/common.c:978-1070,
+// factors_implicit_chol :2063-2126, collective_closed_form_block /root/reference/src/collective.c:1534-1846,
+// collective_closed_form_block_implicit :1849-2131 -- but a different mapping for rows of up to ~1k entries, where the
+// workgroup-per-row kernel is bound by its per-row chain of barriers and LDS exchanges (one row in flight per CU):
+//   * one wavefront owns a row from the gather to the solution; the four wavefronts of a workgroup sit on the four
+//     SIMDs of a CU and never synchronise with each other (no s_barrier in the row loop), so 4 (k_t <= 129) to 8
+//     (k_t <= 65) rows are in flight per CU;
+//   * the whole upper triangle of the k_t x k_t normal matrix lives in this wave's registers as 16x16 tiles in the C/D
+//     layout of v_mfma_{f64,f32}_16x16x4 (NB (NB+1)/2 tiles: 36 tiles = 288 registers in double for k_t = 128);
+//   * gathered rows go straight from HBM / L2 into MFMA operand registers: lane (g, c) = (lane >> 4, lane & 15) reads
+//     element 16 b + c of gathered row g of a 4-row step, which is exactly the A / B operand of the 16x16x4 step for
+//     block b -- NB loads (+ one for a border column) feed NB (NB+1)/2 MFMAs; PD steps are in flight;
+//   * the blocked factorisation needs no exchange at all: panel and trailing updates are MFMAs whose operands are the
+//     tiles' own C/D registers (chol_kernels.hpp, step 3); right-hand side and border column ride along as one more
+//     tile column E (two live columns), so the forward substitution is MFMA work too;
+//   * k_t = 16 n + 1 (k + a bias column: 129, 257, 65) does not pay for a whole extra block row: the last unknown is a
+//     border  [G g; g^T gamma]:  r = R^-T g comes out of the factorisation as the second column of E,
+//     rho^2 = gamma - r.r, and the last unknown is solved first in the backward substitution.
+// Rows longer than the launch's limit stay with chol_rows_kernel (their rank-k update dominates and is shared by 8
+// waves there); both launches of a half-step run side by side.
+#pragma once
+#include "chol_kernels.hpp"
+#include "cg_kernels.hpp"
+
+namespace cmfhip {
+
+#define CMF_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// tile (bi, bj), bj >= bi, of the packed upper triangle of an NB x NB grid
+__host__ __device__ constexpr int wtix(int bi, int bj, int NB) { return bi * NB - (bi * (bi - 1)) / 2 + (bj - bi); }
+
+// LDS elements per wavefront: inv(R_kk) of every block, two vectors of 16 NB (+16), the solution
+template <typename T>
+__host__ __device__ constexpr size_t chol_wave_lds_elems(int NB)
+{
+    return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 16 * (size_t)NB + 16;
+}
+
+// NB: 16-blocks of the compiled tile grid; BORDER: the last unknown is kept outside the tiles; PD: 4-row gather steps
+// in flight; WPS: wavefronts per SIMD the register budget is set for (workgroups per CU).
+// NOV: at one wavefront per SIMD hipcc emits the accumulator-file form of every MFMA (destination and C operand in
+// AGPRs), so at most 256 registers can be MFMA destinations -- 32 tiles in double, and k_t = 128 has 36 (+ 8 of E).
+// The last NOV tiles of the packed order (and E, when NOV > 0) are therefore kept as ordinary values and updated as
+// tile += mfma(a, b, 0): the product lands in a short-lived accumulator, the sum is a vector add (12 more vector
+// instructions per update, hidden behind the 64-cycle MFMAs), and the register allocator is free to place them.
+template <typename T, int NB, bool BORDER, int PD, int WPS, int NOV = 0>
+__global__ void __launch_bounds__(256, WPS)
+chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
+{
+    using Mf = CholMfma<T>;
+    using vec = typename Mf::vec;
+    constexpr int NT = NB * (NB + 1) / 2;
+    constexpr int NRES = NT - NOV;           // tiles [0, NRES) are MFMA accumulators, [NRES, NT) overflow tiles
+    constexpr int LDR = Mf::LDR, RSZ = 16 * LDR;
+    constexpr int NV = 16 * NB + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lm = lane & 15, g = lane >> 4;
+    T *wbase = reinterpret_cast<T *>(smem_raw) + (size_t)wave * chol_wave_lds_elems<T>(NB);
+    T *rinv = wbase;                         // [NB][16][LDR]
+    T *yv0 = rinv + (size_t)NB * RSZ;        // [NV]  right-hand side -> y -> z
+    T *yv1 = yv0 + NV;                       // [NV]  border column g -> R^-T g
+    T *xall = yv1 + NV;                      // [NV]  solution
+
+    const int kt = P.kt, koff = P.koff;
+    const int kq = kt - (BORDER ? 1 : 0);    // unknowns inside the tiles
+    const int nb = (kq + 15) >> 4;
+    const int kbcols = kt - koff;            // columns of B that are used
+    // this lane's column of B for block b (clamped) and whether the unknown 16 b + lm takes a gathered value
+    int colb[NB];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int u = 16 * b + lm;
+        const bool ok = (u >= koff) && (u < kq);
+        colb[b] = min(max(u - koff, 0), kbcols - 1);
+        vmask |= ok ? (1u << b) : 0u;
+    }
+    const int bcol = kbcols - 1;             // border column of B
+
+    const bool coll = (P.mode == CHOL_COLLECTIVE || P.mode == CHOL_COLLECTIVE_IMPLICIT);
+    const bool impl_w = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_COLLECTIVE_IMPLICIT);
+    const bool full = (P.mode == CHOL_IMPLICIT);
+    const bool add_lam = (P.mode == CHOL_EXPLICIT || P.mode == CHOL_COLLECTIVE);
+
+    const int nwaves = gridDim.x * 4;
+    int rix = P.row_first + blockIdx.x * 4 + wave;
+    for (;;) {
+        if (rix >= P.nrows) break;
+        // the next position is claimed now and read when this row is done
+        int claim = 0;
+        if (lane == 0) claim = atomicAdd(P.counter, 1);
+        RowDesc d = desc[rix];
+        const int row = __builtin_amdgcn_readfirstlane(d.row);
+        const int nnz = __builtin_amdgcn_readfirstlane(d.nnz);
+        const size_t st = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.st >> 32)) << 32) |
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)(d.st & 0xffffffffu));
+        T *arow = P.A + (size_t)row * P.lda;
+        const bool has_u = coll && row < P.rows_with_u;
+        if (coll && nnz == 0 && !has_u) {                               // collective.c:1258-1268, :1876-1885
+            for (int e = lane; e < kt; e += 64) arow[e] = T(0);
+            rix = P.row_first + nwaves + __builtin_amdgcn_readfirstlane(claim);
+            continue;
+        }
+        T lam = P.lam, lam_last = P.lam_last;
+        if (P.mode == CHOL_EXPLICIT) {
+            if (P.scale_lam) {                                           // common.c:679-723
+                lam *= (T)nnz;
+                if (!P.scale_bias_const) lam_last *= (T)nnz;
+            }
+        } else if (P.mode == CHOL_COLLECTIVE) {
+            if (P.scale_lam || P.scale_lam_sideinfo) {                   // collective.c:1285-1355
+                T mult = (nnz > 0) ? (T)nnz : T(1);
+                if (P.scale_lam_sideinfo && has_u) mult += (T)P.p_side;  // :1338-1346
+                lam *= mult;
+                if (has_u || !P.scale_bias_const) lam_last *= mult;
+            }
+        }
+        // ---- the initial matrix in the accumulator layout (padding: identity) ----
+        // (the lane coordinates are made opaque per row: otherwise every address of the initial matrices -- loop
+        //  invariant over the rows -- is hoisted out of the row loop and pinned in registers / spilled)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int lm_o = lane_o & 15;
+        const T *M1 = full ? P.Minit : P.Mfull;                    // [kt, kt], every row
+        const T *M2 = (!full && has_u) ? P.Minit : nullptr;        // [kc, kc], rows with side information
+        const int kc = P.kc;
+        vec acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = vec{0, 0, 0, 0};
+        auto add_matrix = [&](const T *Mi, int lim) {              // collective.c:1566-1571
+            static_for<0, NB>([&](auto bic) {
+                constexpr int bi = decltype(bic)::value;
+                static_for<bi, NB>([&](auto bjc) {
+                    constexpr int bj = decltype(bjc)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int gi = 16 * bi + Mf::row_of(lane_o, r), gj = 16 * bj + lm_o;
+                        const int lo = min(gi, gj), hi = max(gi, gj);
+                        const T q = Mi[(size_t)min(lo, lim - 1) * lim + min(hi, lim - 1)];
+                        acc[wtix(bi, bj, NB)][r] += (hi < lim) ? q : T(0);
+                    }
+                });
+            });
+        };
+        if (M1 != nullptr) add_matrix(M1, kt);
+        if (M2 != nullptr && kc > 0) add_matrix(M2, kc);
+        // element (gi, kt - 1) of the initial matrices: the border column
+        auto border_init = [&](int gi) -> T {
+            T v = T(0);
+            if (M1 != nullptr) v += M1[(size_t)min(gi, kt - 1) * kt + (kt - 1)];
+            if (M2 != nullptr && kc > 0) { const T q = M2[(size_t)min(gi, kc - 1) * kc + (kc - 1)]; v += (kt - 1 < kc) ? q : T(0); }
+            return v;
+        };
+        static_for<0, NB>([&](auto bic) {
+            constexpr int bi = decltype(bic)::value;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gi = 16 * bi + Mf::row_of(lane, r), gj = 16 * bi + lm;
+                T dv = T(0);
+                if (gi == gj) dv = (gi >= kq) ? T(1) : (!add_lam ? T(0) : ((gi == kt - 1) ? lam_last : lam));   // common.c:1060-1062, collective.c:1819
+                acc[wtix(bi, bi, NB)][r] += dv;
+            }
+        });
+        // right-hand side, border column: per lane the partial sum of its 4-row group g for the unknown 16 b + lm
+        // (summed over the groups when the block becomes the pivot); prefilled values enter through group 0
+        const bool pre_rhs = has_u || P.rhs_prefilled_all;              // w*U*C prefilled (collective.c:5768-5773)
+        T rp[NB], gp[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int u = 16 * b + lm;
+            rp[b] = (pre_rhs && g == 0 && u < kq) ? arow[min(u, kt - 1)] : T(0);
+            gp[b] = T(0);
+            if (BORDER) { const T q = border_init(16 * b + lm_o); gp[b] = (g == 0 && u < kq) ? q : T(0); }
+        }
+        T gam = T(0), rbs = T(0);            // border diagonal and border right-hand side (partial over g, equal over lm)
+        if (BORDER) {
+            if (g == 0) {
+                gam = (add_lam ? lam_last : T(0));
+                gam += border_init(kt - 1);
+                rbs = pre_rhs ? arow[kt - 1] : T(0);
+            }
+        }
+        // ---- 1. rank-k update: PD steps of 4 gathered rows in flight ----
+        const int nsteps = (nnz + 3) >> 2;
+        const int niter = (nsteps + PD - 1) / PD;
+        {
+            T opb[PD][NB], bvb[PD], xraw[PD], bsv[PD];
+            bool vld[PD];
+            int idxn[PD]; T xn[PD]; bool vn[PD];
+            auto load_entry = [&](int s, int step) {
+                const int e = 4 * step + g;
+                vn[s] = e < nnz;
+                const int ec = min(e, nnz - 1);
+                idxn[s] = P.indices[st + ec];
+                xn[s] = P.values[st + ec];
+            };
+            auto issue_rows = [&](int s) {
+                const T *rowp = P.B + (size_t)idxn[s] * P.ldb;
+#pragma unroll
+                for (int b = 0; b < NB; b++) opb[s][b] = rowp[colb[b]];
+                bvb[s] = BORDER ? rowp[bcol] : T(0);
+                bsv[s] = (P.bias_sub != nullptr) ? P.bias_sub[idxn[s]] : T(0);
+                xraw[s] = xn[s]; vld[s] = vn[s];
+            };
+            if (nnz > 0) {
+#pragma unroll
+                for (int s = 0; s < PD; s++) load_entry(s, s);
+#pragma unroll
+                for (int s = 0; s < PD; s++) { issue_rows(s); load_entry(s, PD + s); }
+            }
+            for (int it = 0; it < niter; it++) {
+#pragma unroll
+                for (int s = 0; s < PD; s++) {
+                    const T x = xraw[s] - bsv[s];
+                    T ws = impl_w ? x : T(1);               // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
+                    T xw = impl_w ? x + T(1) : x;           // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
+                    if (!vld[s]) { ws = T(0); xw = T(0); }
+                    T o[NB], a[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; b++) {
+                        o[b] = ((vmask >> b) & 1u) ? opb[s][b] : T(0);
+                        a[b] = o[b] * ws;
+                    }
+                    const T bv = bvb[s];
+                    // the next use of this buffer: step (it + 1) PD + s
+                    if (it + 1 < niter) { issue_rows(s); load_entry(s, (it + 2) * PD + s); }
+                    static_for<0, NB>([&](auto bic) {
+                        constexpr int bi = decltype(bic)::value;
+                        static_for<bi, NB>([&](auto bjc) {
+                            constexpr int bj = decltype(bjc)::value;
+                            constexpr int t = wtix(bi, bj, NB);
+                            if constexpr (t < NRES) acc[t] = Mf::mma(a[bi], o[bj], acc[t]);
+                            else acc[t] += Mf::mma(a[bi], o[bj], vec{0, 0, 0, 0});
+                        });
+                    });
+#pragma unroll
+                    for (int b = 0; b < NB; b++) rp[b] += xw * o[b];
+                    if (BORDER) {
+                        const T bw = ws * bv;
+#pragma unroll
+                        for (int b = 0; b < NB; b++) gp[b] += bw * o[b];
+                        gam += bw * bv;
+                        rbs += xw * bv;
+                    }
+                }
+            }
+        }
+        // ---- 2. right-hand side and border column become the tile column E (columns 0 and 1) ----
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            T v = lanes::tswap16_add(rp[b], rp[b]);
+            v = lanes::tswap32_add(v, v);
+            if (lane < 16) yv0[16 * b + lane] = v;
+            if (BORDER) {
+                T w = lanes::tswap16_add(gp[b], gp[b]);
+                w = lanes::tswap32_add(w, w);
+                if (lane < 16) yv1[16 * b + lane] = w;
+            }
+        }
+        if (BORDER) {
+            gam = lanes::tswap16_add(gam, gam); gam = lanes::tswap32_add(gam, gam);
+            rbs = lanes::tswap16_add(rbs, rbs); rbs = lanes::tswap32_add(rbs, rbs);
+        }
+        CMF_LDS_FENCE();
+        vec E[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int u = 16 * b + Mf::row_of(lane, r);
+                const T v0 = yv0[u];
+                const T v1 = BORDER ? yv1[u] : T(0);
+                E[b][r] = (lm == 0) ? v0 : ((BORDER && lm == 1) ? v1 : T(0));
+            }
+        }
+        CMF_LDS_FENCE();
+        // ---- 3. blocked Cholesky  M = R^T R, in this wave's registers ----
+        for (int kb = 0; kb < nb; kb++) {
+            T *rslot = rinv + (size_t)kb * RSZ;
+            vec dd = vec{0, 0, 0, 0};
+            static_for<0, NB>([&](auto kc_) {
+                constexpr int KB = decltype(kc_)::value;
+                if (kb == KB) dd = acc[wtix(KB, KB, NB)];
+            });
+            chol_diag_block<T>(dd, rslot, lane, min(16, kq - 16 * kb));
+            CMF_LDS_FENCE();
+            T ainv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) ainv[r] = rslot[Mf::row_of(lane, r) * LDR + lm];
+            static_for<0, NB>([&](auto kc_) {
+                constexpr int KB = decltype(kc_)::value;
+                if (kb == KB) {
+                    // panel:  X = inv(R_kk)^T * tile  (one chain per tile; the tiles of a block row interleave)
+                    auto panel = [&](vec tIn) -> vec {
+                        vec x = Mf::mma(ainv[0], tIn[0], vec{0, 0, 0, 0});
+                        x = Mf::mma(ainv[1], tIn[1], x);
+                        x = Mf::mma(ainv[2], tIn[2], x);
+                        x = Mf::mma(ainv[3], tIn[3], x);
+                        return x;
+                    };
+                    static_for<KB + 1, NB>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        acc[wtix(KB, j, NB)] = panel(acc[wtix(KB, j, NB)]);
+                    });
+                    E[KB] = panel(E[KB]);
+                    // trailing:  tile(bi, bj) -= X_bi^T X_bj ;  E_bi -= X_bi^T E_k  (forward substitution)
+                    static_for<KB + 1, NB>([&](auto bic) {
+                        constexpr int bi = decltype(bic)::value;
+                        T na[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) na[r] = -acc[wtix(KB, bi, NB)][r];
+                        static_for<bi, NB>([&](auto bjc) {
+                            constexpr int bj = decltype(bjc)::value;
+                            constexpr int t = wtix(bi, bj, NB);
+                            if constexpr (t < NRES) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) acc[t] = Mf::mma(na[r], acc[wtix(KB, bj, NB)][r], acc[t]);
+                            } else {
+                                vec tmp = Mf::mma(na[0], acc[wtix(KB, bj, NB)][0], vec{0, 0, 0, 0});
+#pragma unroll
+                                for (int r = 1; r < 4; r++) tmp = Mf::mma(na[r], acc[wtix(KB, bj, NB)][r], tmp);
+                                acc[t] += tmp;
+                            }
+                        });
+                        if constexpr (NOV == 0) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) E[bi] = Mf::mma(na[r], E[KB][r], E[bi]);
+                        } else {
+                            vec tmp = Mf::mma(na[0], E[KB][0], vec{0, 0, 0, 0});
+#pragma unroll
+                            for (int r = 1; r < 4; r++) tmp = Mf::mma(na[r], E[KB][r], tmp);
+                            E[bi] += tmp;
+                        }
+                    });
+                }
+            });
+        }
+        // y (column 0 of E) and R^-T g (column 1) back to LDS
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int u = 16 * b + Mf::row_of(lane, r);
+                if (lm == 0) yv0[u] = E[b][r];
+                if (BORDER && lm == 1) yv1[u] = E[b][r];
+            }
+        }
+        CMF_LDS_FENCE();
+        T xlast = T(0);
+        if (BORDER) {
+            // rho^2 = gamma - r.r ;  y_last = (rhs_last - r.y) / rho ;  x_last = y_last / rho ;  z = y - r x_last
+            T s1 = T(0), s2 = T(0);
+            for (int u = lane; u < 16 * nb; u += 64) { const T rv = yv1[u]; s1 += rv * rv; s2 += rv * yv0[u]; }
+            s1 = lanes::wave_sum(s1); s2 = lanes::wave_sum(s2);
+            const T rho2 = gam - s1;
+            xlast = (rbs - s2) / rho2;
+            CMF_LDS_FENCE();
+            for (int u = lane; u < 16 * nb; u += 64) yv0[u] -= yv1[u] * xlast;
+            CMF_LDS_FENCE();
+        }
+        // ---- 4. backward substitution R x = z, one block column per step ----
+        for (int bjk = nb - 1; bjk >= 0; bjk--) {
+            const T *rslot = rinv + (size_t)bjk * RSZ;
+            T xm = T(0);                          // x[16 bjk + lm], computed redundantly by every 16-lane group
+#pragma unroll
+            for (int n2 = 0; n2 < 16; n2++) xm += rslot[lm * LDR + n2] * yv0[16 * bjk + n2];
+            if (lane < 16) xall[16 * bjk + lane] = xm;
+            CMF_LDS_FENCE();
+            static_for<0, NB>([&](auto jc) {
+                constexpr int BJ = decltype(jc)::value;
+                if (bjk == BJ) {
+                    static_for<0, BJ>([&](auto ic) {
+                        constexpr int bi = decltype(ic)::value;
+                        const vec tl = acc[wtix(bi, BJ, NB)];
+                        // sum over the 16 lanes of a row for the four registers at once: after two select-and-exchange
+                        // steps lane l carries register (l & 3), then two plain butterflies
+                        const T p0 = tl[0] * xm, p1 = tl[1] * xm, p2 = tl[2] * xm, p3 = tl[3] * xm;
+                        const bool o1 = (lm & 1) != 0, o2 = (lm & 2) != 0;
+                        const T s01 = (o1 ? p1 : p0) + lanes::xor1(o1 ? p0 : p1);
+                        const T s23 = (o1 ? p3 : p2) + lanes::xor1(o1 ? p2 : p3);
+                        T sr = (o2 ? s23 : s01) + lanes::xor2(o2 ? s01 : s23);
+                        sr += lanes::xor4(sr);
+                        sr += lanes::xor8(sr);
+                        if (lm < 4) yv0[16 * bi + Mf::row_of(lane, lm)] -= sr;
+                    });
+                }
+            });
+            CMF_LDS_FENCE();
+        }
+        for (int e = lane; e < kq; e += 64) arow[e] = xall[e];
+        if (BORDER && lane == 0) arow[kt - 1] = xlast;
+        CMF_LDS_FENCE();                     // this wave's LDS is reused by its next row
+        rix = P.row_first + nwaves + __builtin_amdgcn_readfirstlane(claim);
+    }
+}
+
+}  // namespace cmfhip

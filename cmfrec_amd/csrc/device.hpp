@@ -74,6 +74,7 @@ struct DevBuf {
 // stride over the sorted list, which balances the heavy-tailed row lengths the reference handles
 // with `omp schedule(dynamic)` (common.c:3259,3349).  A row of a bin with W waves per row keeps its
 // gathered tiles in registers when it has <= 64*W non-zeros.
+constexpr int MAX_DEVICES = 16;   // per-device caches of launch attributes
 constexpr int NBINS = 6;
 constexpr int BIN_VHEAVY = 0;   // > 1024 nnz : every CG pass split over many workgroups (vh_* kernels); measured on C2: 2048 -> 5.05, 1024 -> 4.93, 512 -> 5.11 ms
 constexpr int BIN_HEAVY = 1;    // 257..1024  : 8 waves / row (register-resident up to 512 nnz, else re-streamed)
@@ -124,6 +125,19 @@ struct SparseShard {
         return bin_rows[0] > 0 && n_chunks <= 4 * num_cus && getenv("CMFREC_HIP_VH_INLINE") == nullptr;
     }
     static constexpr int LONG_ROW = 1024;
+    // rows (they lead the processing order) with more than `maxlen` entries, for the nnz-bin boundaries 32 .. 1024
+    int rows_longer_than(int maxlen, int cap) const
+    {
+        int n;
+        if (maxlen >= max_nnz) n = 0;
+        else if (maxlen >= LONG_ROW) n = n_long;
+        else if (maxlen >= 256) n = bin_first[BIN_MED4];
+        else if (maxlen >= 128) n = bin_first[BIN_MED2];
+        else if (maxlen >= 64) n = bin_first[BIN_LIGHT];
+        else if (maxlen >= 32) n = bin_first[BIN_TINY];
+        else n = n_nonempty;
+        return std::min(n, cap);
+    }
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
     int n_chunks = 0;
     DevBuf<int> vh_chunk_row, vh_chunk_start, vh_chunk_cnt, vh_chunk_off, vh_launch, vh_done;
@@ -391,7 +405,9 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     constexpr int threads = 64 * W * RPB;
     size_t smem = ((IMPLICIT ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
     auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB>;
-    static thread_local int blocks_per_cu = 0;
+    // per device: the dynamic-LDS attribute and the occupancy belong to the device the kernel was loaded on
+    static thread_local int bpc_dev[MAX_DEVICES] = {0};
+    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
     if (blocks_per_cu == 0) {
         if (smem > 48 * 1024)
             HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -425,7 +441,8 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     P.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
     size_t smem = (IMPLICIT ? (size_t)64 * gram_ld(S) : 0) * sizeof(real_t);
     auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT>;
-    static thread_local int blocks_per_cu = 0;
+    static thread_local int bpc_dev[MAX_DEVICES] = {0};
+    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
     if (blocks_per_cu == 0) {
         int nb = 0;
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));

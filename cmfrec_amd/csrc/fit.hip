@@ -165,11 +165,11 @@ int_t fit_collective_implicit_als(
 
     (void)nthreads;
     (void)precomputedCtUbias;            // only written with sparse U + NA_as_zero_U (collective.c:10111), not supported
-    (void)handle_interrupt;
     // collective.c:9406-9435
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
+    if (nnz == 0) return fail(verbose, "cmfrec_hip: the implicit model needs at least one entry of X.");
     // dense side information with NaN -> the sparse route on its centred present entries
     DenseNanSide nanU, nanI;
     const bool hadU = (U != nullptr);
@@ -226,7 +226,7 @@ int_t fit_collective_implicit_als(
 
     PhaseTimer tm;
     tm.lap("validate");
-    SigGuard sig(true);
+    SigGuard sig(handle_interrupt);
     std::vector<real_t> Xs;                                              // X is copied before edits (:9578-9599)
     if (apply_log_transf) {
         Xs.assign(X, X + nnz);
@@ -270,7 +270,7 @@ int_t fit_collective_implicit_als(
     mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
-    if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
+    if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("session create");
     // X := alpha * X and COO -> CSR + CSC happen on the device (coo_device.hpp), same entry order as helpers.c:1375-1491
     int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, (real_t)0, alpha);
@@ -307,7 +307,7 @@ int_t fit_collective_implicit_als(
     cmfrec_hip_session_destroy(s);
     tm.lap("session destroy");
     if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
-    return rc_loop > 3 ? 1 : rc_loop;
+    return rc_loop;
 }
 
 int_t fit_collective_explicit_als(
@@ -327,7 +327,7 @@ int_t fit_collective_explicit_als(
     real_t *precomputedBtXbias, real_t *precomputedBeTBeChol, real_t *precomputedBiTBi,
     real_t *precomputedTransCtCinvCt, real_t *precomputedCtCw, real_t *precomputedCtUbias)
 {
-    (void)handle_interrupt; (void)max_cd_steps;
+    (void)max_cd_steps;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // with add_implicit_features the prediction matrices are not produced here
     (void)precomputedCtUbias;      // only with sparse U + NA_as_zero_U, not supported
@@ -397,7 +397,7 @@ int_t fit_collective_explicit_als(
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
 
-    SigGuard sig(true);
+    SigGuard sig(handle_interrupt);
     scale_lam = scale_lam || scale_lam_sideinfo;                          // :7465
     if (!use_cg) finalize_chol = false;                                   // :7481
     // per-matrix penalties, order: user bias, item bias, A, B, C, D (collective.c:430)
@@ -491,7 +491,7 @@ int_t fit_collective_explicit_als(
     mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
-    if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); return 1; }
+    if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("start values + session");
     // X - mean, COO -> CSR + CSC and the bias start values are computed on the device (coo_device.hpp)
     int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, X, nnz, gm, (real_t)1);
@@ -549,7 +549,7 @@ int_t fit_collective_explicit_als(
     cmfrec_hip_session_destroy(s);
     tm.lap("get_factors + precompute + destroy");
     if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
-    return rc_loop > 3 ? 1 : rc_loop;
+    return rc_loop;
 }
 
 // ---- factors of new rows (the step after the path) -----------------------------------------------------

@@ -7,6 +7,7 @@
 // the small k x k work matrices -- all resident in HBM for the whole fit.
 #include "device.hpp"
 #include "coo_device.hpp"
+#include "chol_wave_kernels.hpp"
 #include <functional>
 #include <memory>
 #include <new>
@@ -14,6 +15,7 @@
 namespace cmfhip {
 
 thread_local std::string g_last_error;
+thread_local int g_last_rc = 0;      // return code that goes with g_last_error where the entry point returns a pointer
 
 CgVariant cg_variant_from_env()
 {
@@ -56,6 +58,9 @@ struct CholCall {
     bool rhs_prefilled_all = false;          // every row starts from the right-hand side left in A
 };
 
+static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, CholParams<real_t> P, bool two_src,
+                            size_t smem_nonneg);
+
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
 static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, int nrows_prefilled = 0)
 {
@@ -96,10 +101,79 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         return 2;
     }
     if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
-    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 2 * sizeof(int), dev.stream));
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 4 * sizeof(int), dev.stream));
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
     const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ;      // CHOL_NAZ is part of that build only
+    // Rows of up to WAVE_ROW_MAX entries: one wavefront per row, the matrix in its registers (chol_wave_kernels.hpp).
+    // The rows beyond (they lead the processing order) stay with the workgroup-per-row kernel below; the two launches
+    // run side by side on two streams.  CMFREC_HIP_CHOL=rows keeps everything on the workgroup-per-row kernel (A/B
+    // switch and on-device cross-check).
+    {
+        static const char *chol_env = getenv("CMFREC_HIP_CHOL");
+        const bool border = (c.kt > 16) && ((c.kt - 1) % 16 == 0);
+        const int nbw = (c.kt - (border ? 1 : 0) + 15) / 16;
+        const bool wave_ok = X != nullptr && !two_src && !nonneg && !l1on && !c.rhs_only && nbw <= 8 &&
+                             (c.mode == CHOL_EXPLICIT || c.mode == CHOL_IMPLICIT || c.mode == CHOL_COLLECTIVE ||
+                              c.mode == CHOL_COLLECTIVE_IMPLICIT) &&
+                             !(chol_env != nullptr && strcmp(chol_env, "rows") == 0);
+        if (wave_ok) {
+            static const int wave_row_max = getenv("CMFREC_HIP_CHOL_WAVE_MAX") ? atoi(getenv("CMFREC_HIP_CHOL_WAVE_MAX")) : SparseShard::LONG_ROW;
+            const int n_heavy = (wave_row_max == SparseShard::LONG_ROW) ? std::min(X->n_long, P.nrows) : X->rows_longer_than(wave_row_max, P.nrows);
+            const int total = P.nrows;
+            DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+            const bool two = n_heavy > 0 && total > n_heavy;
+            if (two) {
+                d.ensure_aux();
+                HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
+                HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
+            }
+            if (total > n_heavy) {
+                CholParams<real_t> W = P;
+                W.row_first = n_heavy; W.nrows = total; W.counter = dev.row_counter.ptr + 2;
+                auto wlaunch = [&](auto kern, int nb_, int wps) {
+                    const size_t smem = 4 * chol_wave_lds_elems<real_t>(nb_) * sizeof(real_t);
+                    const int grid = std::min((total - n_heavy + 3) / 4, dev.num_cus * wps);
+                    if (smem > 48 * 1024)
+                        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, two ? d.aux_stream : dev.stream, W, X->desc.ptr);
+                };
+                // <16-blocks, border, gather steps in flight, wavefronts per SIMD>
+#define WAVE_KERN(nb_, pd, wps, nov) (border ? chol_wave_kernel<real_t, nb_, true, pd, wps, nov> : chol_wave_kernel<real_t, nb_, false, pd, wps, nov>)
+#ifdef CMFREC_HIP_FLOAT
+                if (nbw <= 2) wlaunch(WAVE_KERN(2, 4, 4, 0), 2, 4);
+                else if (nbw <= 4) wlaunch(WAVE_KERN(4, 4, 2, 0), 4, 2);
+                else if (nbw <= 6) wlaunch(WAVE_KERN(6, 3, 2, 0), 6, 2);
+                else wlaunch(WAVE_KERN(8, 2, 1, 0), 8, 1);
+#else
+                // 7 and 8 blocks in double: 28 / 36 tiles of 8 registers exceed the 256 accumulator registers, the last 8 tiles
+                // are overflow tiles (chol_wave_kernels.hpp, NOV); one gather step in flight is a microsecond of MFMAs there
+                if (nbw <= 2) wlaunch(WAVE_KERN(2, 4, 3, 0), 2, 3);
+                else if (nbw <= 4) wlaunch(WAVE_KERN(4, 3, 2, 0), 4, 2);
+                else if (nbw <= 6) wlaunch(WAVE_KERN(6, 2, 1, 0), 6, 1);
+                else wlaunch(WAVE_KERN(8, 1, 1, 8), 8, 1);
+#endif
+#undef WAVE_KERN
+                HIP_CHECK(hipGetLastError());
+                if (two) {
+                    HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
+                }
+            }
+            P.nrows = n_heavy;          // what is left for the kernel below
+            if (n_heavy <= 0) return 0;
+            int rc_heavy = launch_chol_rows(dev, c, X, P, two_src, smem_nonneg);
+            if (two) HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
+            return rc_heavy;
+        }
+    }
+    return launch_chol_rows(dev, c, X, P, two_src, smem_nonneg);
+}
+
+// the workgroup-per-row kernel over the positions [P.row_first, P.nrows) of the processing order
+static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, CholParams<real_t> P, bool two_src,
+                            size_t smem_nonneg)
+{
+    const int T = chol_tiles(c.kt);
     // the two-source build (sparse side information) only where it is asked for
 #define CHOL_KERN(a, b, c_, d) (two_src ? chol_rows_kernel<real_t, a, b, c_, d, true> : chol_rows_kernel<real_t, a, b, c_, d, false>)
     hipStream_t run_on = dev.stream;
@@ -141,7 +215,11 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         }
     }
     else if (T <= 6) launch(CHOL_KERN(6, 8, 32, 1), 6, 8, 32, 1);
-    else if (T <= 9) launch(CHOL_KERN(9, 8, 32, 1), 9, 8, 32, 1);
+    else if (T <= 9) {
+        static const bool alt9 = getenv("CMFREC_HIP_CHOL_ROWS9") != nullptr;     // experiment: 4 waves per row, 2 rows per CU
+        if (alt9) launch(CHOL_KERN(9, 4, 16, 2), 9, 4, 16, 2);
+        else launch(CHOL_KERN(9, 8, 32, 1), 9, 8, 32, 1);
+    }
 #ifdef CMFREC_HIP_FLOAT
     else if (T <= 12) launch(CHOL_KERN(12, 8, 32, 1), 12, 8, 32, 1);
     else if (T <= 16) launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
@@ -278,6 +356,14 @@ struct cmfrec_hip_session {
     }
 };
 
+static void trim_events(std::vector<EventPair> &v)
+{
+    constexpr size_t CAP = 2048;
+    if (v.size() < CAP) return;
+    for (size_t e = 0; e < CAP / 2; e++) { (void)hipEventDestroy(v[e].a); (void)hipEventDestroy(v[e].b); }
+    v.erase(v.begin(), v.begin() + CAP / 2);
+}
+
 static int guarded(const std::function<int()> &f)
 {
     try {
@@ -355,12 +441,14 @@ cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int
         if (m.q > 0 && m.use_cg) s->ucB.alloc((size_t)std::max(1, m.n_i) * (m.k_item + m.k));
         return 0;
     });
+    g_last_rc = rc;
     if (rc != 0) {
         delete s;
         return nullptr;
     }
     return s;
 }
+int cmfrec_hip_last_error_code(void) { return g_last_rc; }
 
 void cmfrec_hip_session_destroy(cmfrec_hip_session *s)
 {
@@ -1255,6 +1343,9 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
             }
             HIP_CHECK(hipEventRecord(ev.b, s->dev.stream));
             (which == 'A' ? s->evA : s->evB).push_back(ev);
+            // long-lived sessions: the timing events are a window over the most recent updates, not an unbounded log
+            trim_events(which == 'A' ? s->evA : s->evB);
+            for (auto &v : (which == 'A' ? s->binA : s->binB).ev) trim_events(v);
             return rc;
         }
         if (which == 'C' || which == 'D') return update_sideinfo(s, which == 'C', chol);
@@ -1645,6 +1736,31 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
             return 2;
         }
         if (!(p > 0 && (U || spU))) { p = 0; m_u = 0; }
+        // index validation on the host, before anything reaches the device (the fit entry points do the same,
+        // fit.hip): a row id outside [0, m_x) or an item id outside [0, n) would corrupt device memory silently
+        {
+            auto bad = [](const char *what) { g_last_error = std::string("cmfrec_hip_factors_multiple: ") + what; return 2; };
+            if (Xcsr_p) {
+                const size_t nz = Xcsr_p[m_x];
+                for (int r = 0; r < m_x; r++) if (Xcsr_p[r] > Xcsr_p[r + 1]) return bad("Xcsr_p is not non-decreasing");
+                if (nz > 0 && (!Xcsr_i || !Xcsr)) return bad("Xcsr_i / Xcsr missing");
+                for (size_t e = 0; e < nz; e++) if (Xcsr_i[e] < 0 || Xcsr_i[e] >= n) return bad("item index of X outside [0, n)");
+            } else {
+                for (size_t e = 0; e < nnz; e++)
+                    if (ixA[e] < 0 || ixA[e] >= m_x || ixB[e] < 0 || ixB[e] >= n) return bad("row / item index of X outside [0, m_x) x [0, n)");
+            }
+            if (spU) {
+                if (U_csr_p) {
+                    const size_t nz = U_csr_p[m_u];
+                    for (int r = 0; r < m_u; r++) if (U_csr_p[r] > U_csr_p[r + 1]) return bad("U_csr_p is not non-decreasing");
+                    if (nz > 0 && (!U_csr_i || !U_csr)) return bad("U_csr_i / U_csr missing");
+                    for (size_t e = 0; e < nz; e++) if (U_csr_i[e] < 0 || U_csr_i[e] >= p) return bad("attribute index of U outside [0, p)");
+                } else {
+                    for (size_t e = 0; e < nnz_U; e++)
+                        if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return bad("row / attribute index of U outside [0, m_u) x [0, p)");
+                }
+            }
+        }
         DeviceInfo dev;
         init_device(dev, -1);
         hipStream_t st = dev.stream;

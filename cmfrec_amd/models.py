@@ -71,6 +71,11 @@ def _new_rows(X, n, dt):
         return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, dt), 0
     if isinstance(X, tuple):
         row, col, val = X
+        row = np.asarray(row); col = np.asarray(col)
+        if len(row) and (row.min() < 0 or col.min() < 0):
+            raise ValueError("'X' has negative indices")
+        if len(col) and col.max() >= n:
+            raise ValueError("'X' has more columns than the model has items")
         m_x = int(np.max(row)) + 1 if len(row) else 0
     else:
         X = X.tocoo()
@@ -114,6 +119,8 @@ class CMF_implicit(_Base):
                  precompute_for_predictions=True, use_float=True, max_cg_steps=3,
                  precondition_cg=False, finalize_chol=False, random_state=1, verbose=False,
                  produce_dicts=False, handle_interrupt=True, nthreads=-1, n_jobs=None):
+        if NA_as_zero_user or NA_as_zero_item:
+            raise NotImplementedError("NA_as_zero_user / NA_as_zero_item are not implemented in cmfrec_amd")
         self.k = int(k); self.alpha = float(alpha); self.use_cg = bool(use_cg)
         self.lambda_, self._lam6 = _penalty(lambda_, "lambda_")
         self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
@@ -177,7 +184,9 @@ class CMF_implicit(_Base):
             C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg), C.c_bool(self.finalize_chol),
             C.c_bool(self.nonneg), C.c_int(self.max_cd_steps), C.c_bool(self.nonneg_C), C.c_bool(self.nonneg_D),
             C.c_bool(pre), _lib.ptr(BtB), _lib.ptr(BeTBe), _lib.ptr(BeTBeChol), None)
-        _lib.check(rc, lib, "fit_collective_implicit_als")
+        # an interrupted fit returns 3 with usable factors; like the reference's wrapper, raise only when the caller did
+        # not ask for the interrupt to be handled (cmfrec/wrapper_untyped.pxi: `if ret_code == 3 and not handle_interrupt`)
+        _lib.check(rc, lib, "fit_collective_implicit_als", interrupt_ok=self.handle_interrupt)
         self.A_, self.B_ = A, B
         self.C_ = Cm if Cm is not None else np.empty((0, 0), dt)
         self.D_ = Dm if Dm is not None else np.empty((0, 0), dt)
@@ -332,7 +341,7 @@ class CMF(_Base):
             C.c_bool(self.nonneg_D),
             C.c_bool(pre), C.c_bool(True), _lib.ptr(Bpb), _lib.ptr(BtB), _lib.ptr(TBt), None, _lib.ptr(BeChol), None,
             _lib.ptr(TCt), _lib.ptr(CtCw), None)
-        _lib.check(rc, lib, "fit_collective_explicit_als")
+        _lib.check(rc, lib, "fit_collective_explicit_als", interrupt_ok=self.handle_interrupt)
         # precomputed matrices for predictions on new data, reference attribute names (cmfrec/__init__.py:3211-3247)
         e = np.empty((0, 0), dt)
         self._B_plus_bias = Bpb if Bpb is not None else e

@@ -298,6 +298,8 @@ typedef struct cmfrec_hip_model {
 cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int device);
 void cmfrec_hip_session_destroy(cmfrec_hip_session *s);
 const char *cmfrec_hip_last_error(void);
+/* return code (1 out of memory, 2 invalid input, 4 HIP failure) that goes with the last NULL from cmfrec_hip_session_create */
+int cmfrec_hip_last_error_code(void);
 
 /* CSR of the local user rows [row_begin,row_end) (indptr rebased to 0, column ids global) and CSC
  * of the local item columns [col_begin,col_end) (row ids global).  Host buffers; copied to HBM. */
