@@ -9,9 +9,13 @@ synthetic implicit-feedback matrix with the shape/nnz of LastFM-360K (BASELINE.j
 CMF_implicit, ALS-CG, k=50, fp64, lambda=5, max_cg_steps=3), factors and CSR/CSC resident in HBM
 when the timed region starts.  value = rows/s = (users + items) / iteration time.
 
-N > 1: weak scaling.  Every rank owns one LastFM-sized user block (358,858 users, 17.3M nnz, own
-seed) and 1/N of the 160,112 items; each half-step updates the local block and is followed by an
-all-gather of the updated factor matrix over RCCL (torch.distributed, backend nccl).
+N > 1: BASELINE.json configs[3] -- CMF_implicit ALS-CG k=64 fp32 on a synthetic 10M users x 1M items
+matrix with 5e8 entries, STRONG scaling: the problem is fixed, every rank generates its user block
+(10M / N users, 5e8 / N entries) on its own GPU, item blocks are cut nnz-balanced, the entries of a
+rank's items arrive through one all-to-all, and every half-step updates the local block and is
+followed by an all-gather of the updated factor rows over RCCL (torch.distributed, backend nccl),
+enqueued on the session's stream (no host synchronisation inside the loop; the A-step's all-gather
+runs part by part beside the kernels of the following parts).
 
 Prints ONE JSON line (rank 0) with the contract fields + "roofline" + "cpu_baseline".
 """
@@ -97,6 +101,8 @@ def main():
 
     from cmfrec_amd.session import AlsSession
     from cmfrec_amd.distributed import ShardedAls, GpuEngine
+    if use_dist and args.workload == "c2":
+        return c4_distributed(args, rank, world, local_rank)
     if args.workload == "fit":
         return whole_fit(args)
     if args.workload == "c4shard":
@@ -129,18 +135,7 @@ def main():
         def sync():
             sess.sync()
     else:
-        # the A-step finishes in parts so that each part's all-gather overlaps the kernels of the next ones
-        a_parts = int(os.environ.get("CMFREC_HIP_AG_PARTS", "4"))
-        eng = GpuEngine.from_user_block(m_blk, n, K, row, col, val, A0_blk, lam=LAM, max_cg_steps=MAX_CG_STEPS,
-                                        rank=rank, world=world, device=local_rank, a_parts=a_parts)
-        engine = ShardedAls(eng, rank, world)
-        sess = eng.session
-
-        def step():
-            engine.iteration()
-
-        def sync():
-            sess.sync(); torch.cuda.synchronize()
+        raise SystemExit("multi-rank runs take the c4_distributed path")
 
     for _ in range(args.warmup):
         step()
@@ -237,6 +232,130 @@ def main():
         final_line = None
     if use_dist:
         dist.destroy_process_group()
+    emit_last_line(final_line)
+
+
+C4_M, C4_N, C4_NNZ, C4_K = 10_000_000, 1_000_000, 500_000_000, 64     # BASELINE.json configs[3] / SURVEY.md 8d "C4"
+
+
+def synth_block_torch(m, n, nnz, seed, item_seed, device):
+    """The SURVEY.md 8d generator on the GPU (torch), for blocks too large to draw on the host in the bench's time
+    budget: lognormal row weights, 1/rank^0.8 column weights in a permuted order that is COMMON to all ranks
+    (item_seed), 1.35 nnz draws, unique, random subset of nnz; values ceil(lognormal(3, 1.5)).  Returns int32 row
+    (local), int32 col, float32 val, all resident on `device`."""
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    gi = torch.Generator(device=device); gi.manual_seed(item_seed)
+    rcdf = torch.cumsum(torch.exp(torch.randn(m, generator=g, device=device, dtype=torch.float64)), 0)
+    rcdf /= rcdf[-1].clone()
+    cw = 1.0 / torch.arange(1, n + 1, device=device, dtype=torch.float64) ** 0.8
+    ccdf = torch.cumsum(cw[torch.randperm(n, generator=gi, device=device)], 0)
+    ccdf /= ccdf[-1].clone()
+    draws = int(1.35 * nnz)
+    r = torch.searchsorted(rcdf, torch.rand(draws, generator=g, device=device, dtype=torch.float64)).clamp_(max=m - 1)
+    c = torch.searchsorted(ccdf, torch.rand(draws, generator=g, device=device, dtype=torch.float64)).clamp_(max=n - 1)
+    lin = torch.unique(r * n + c)
+    del r, c
+    if lin.numel() < nnz:
+        raise RuntimeError("generator produced too few unique pairs")
+    lin = lin[torch.randperm(lin.numel(), generator=g, device=device)[:nnz]]
+    row = (lin // n).to(torch.int32); col = (lin % n).to(torch.int32)
+    del lin
+    val = torch.ceil(torch.exp(3.0 + 1.5 * torch.randn(nnz, generator=g, device=device, dtype=torch.float32)))
+    return row, col, val
+
+
+def c4_distributed(args, rank, world, local_rank):
+    """BASELINE.json configs[3]: CMF_implicit ALS-CG k=64 fp32, synthetic 10M users x 1M items, 5e8 entries, row-partitioned
+    over the ranks with an all-gather of the updated factor rows after every half-step.  Strong scaling: the problem
+    does not change with N (--scale shrinks it for tests only and marks the line invalid)."""
+    import torch
+    import torch.distributed as dist
+    from cmfrec_amd.distributed import ShardedAls, GpuEngine
+    dev = torch.device("cuda", local_rank)
+    m_blk = int(C4_M * args.scale) // world
+    n = int(C4_N * args.scale)
+    nnz_blk = int(C4_NNZ * args.scale) // world
+    m = m_blk * world
+    t0 = time.time()
+    row, col, val = synth_block_torch(m_blk, n, nnz_blk, seed=40 + rank, item_seed=4, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    row_ranges = [(r * m_blk, (r + 1) * m_blk) for r in range(world)]
+    a_parts = int(os.environ.get("CMFREC_HIP_AG_PARTS", "4")) if world > 1 else 1
+    t0 = time.time()
+    eng = GpuEngine.from_device_coo(m, n, C4_K, row, col, val, row_ranges, rank, world, local_rank, dtype=np.float32, lam=LAM,
+                                    max_cg_steps=MAX_CG_STEPS, a_parts=a_parts)
+    del row, col, val
+    t_setup = time.time() - t0
+    g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+    fullA = eng.full("A")
+    fullA[rank * m_blk:(rank + 1) * m_blk].copy_(torch.rand((m_blk, fullA.shape[1]), generator=g, device=dev, dtype=torch.float32) * 2.0 ** -7)
+    eng.full("B").zero_()
+    torch.cuda.synchronize()
+    engine = ShardedAls(eng, rank, world)
+    engine.allgather("A")
+    sess = eng.session
+
+    def sync():
+        sess.sync(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.iteration()
+    sync()
+    sess.reset_timers()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        engine.iteration()
+    sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    rows_per_s = (m + n) / (elapsed / args.steps)
+    # roofline of rank 0's dominant launch + the whole job's algorithmic bytes per iteration
+    names = {0: "split rows (> 1024 nnz)", 1: "cg_rows_kernel<W=8> (257..1024 nnz)", 2: "cg_rows_kernel<W=4> (129..256 nnz)",
+             3: "cg_rows_kernel<W=2> (65..128 nnz)", 4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel (<= 32 nnz)"}
+    kernels = []
+    for which in ("B", "A"):
+        for b in range(6):
+            ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
+            if cnt:
+                kernels.append(dict(step=which, kernel=names[b], avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, C4_K, 4),
+                                    overlapped=sess.bin_overlaps(which, b)))
+    job_bytes = torch.tensor([float(sum(d["alg_bytes"] for d in kernels))], device="cuda", dtype=torch.float64)
+    dist.all_reduce(job_bytes)
+    roofline = None
+    cand = [d for d in kernels if not d["overlapped"]]
+    if cand:
+        dom = max(cand, key=lambda d: d["avg_ms"])
+        ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="%s, %s-step (rank 0; with A-step parts a bin is launched once per part)" % (dom["kernel"], dom["step"]),
+                        achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                        alg_bytes_per_launch=dom["alg_bytes"], avg_launch_ms=round(dom["avg_ms"], 4),
+                        iteration={"alg_GB_whole_job": round(float(job_bytes.item()) / 1e9, 3),
+                                   "frac_of_hbm_peak": round(float(job_bytes.item()) / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)})
+    final_line = None
+    if rank == 0:
+        out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=64 fp32",
+               "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "CMF_implicit ALS-CG k=64 fp32, synthetic %d users x %d items, %d nnz (BASELINE.json configs[3]); "
+                                      "lambda=5, max_cg_steps=3" % (m, n, nnz_blk * world),
+                          "parallelism": "user / item row blocks x%d (items nnz-balanced), RCCL all-gather of the updated rows after every "
+                                         "half-step, A-step in %d parts" % (world, a_parts),
+                          "gen_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1)},
+               "roofline": roofline, "cpu_baseline": None}
+        if args.scale != 1.0:
+            out["config"]["INVALID_scaled_down"] = args.scale
+        final_line = json.dumps(out)
+    dist.destroy_process_group()
     emit_last_line(final_line)
 
 

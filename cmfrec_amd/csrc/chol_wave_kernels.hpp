@@ -18,8 +18,10 @@
 //   * k_t = 16 n + 1 (k + a bias column: 129, 257, 65) does not pay for a whole extra block row: the last unknown is a
 //     border  [G g; g^T gamma]:  r = R^-T g comes out of the factorisation as the second column of E,
 //     rho^2 = gamma - r.r, and the last unknown is solved first in the backward substitution.
-// Rows longer than the launch's limit stay with chol_rows_kernel (their rank-k update dominates and is shared by 8
-// waves there); both launches of a half-step run side by side.
+// Rows beyond 1024 entries (a popular item holds tens of thousands) are cut into slices of <= 2048 entries
+// (SparseShard::sl_*): the same kernel, PRODUCER build, runs the rank-k update of one slice per wavefront and leaves
+// the raw tiles + right-hand-side partials in HBM (NT x 2 KB per slice in double); the row's owner then adds its
+// slices in slice order (fixed summation order, no atomics) instead of gathering, and factorises as usual.
 #pragma once
 #include "chol_kernels.hpp"
 #include "cg_kernels.hpp"
@@ -28,6 +30,13 @@ namespace cmfhip {
 
 #define CMF_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// does any of the tiles [T0, T1) of the packed order touch block b?
+__host__ __device__ constexpr bool wave_block_needed(int b, int T0, int T1, int NB)
+{
+    for (int t = T0; t < T1; t++)
+        if (tile_bi(t, NB) == b || tile_bj(t, NB) == b) return true;
+    return false;
+}
 // tile (bi, bj), bj >= bi, of the packed upper triangle of an NB x NB grid
 __host__ __device__ constexpr int wtix(int bi, int bj, int NB) { return bi * NB - (bi * (bi - 1)) / 2 + (bj - bi); }
 
@@ -38,6 +47,20 @@ __host__ __device__ constexpr size_t chol_wave_lds_elems(int NB)
     return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 16 * (size_t)NB + 16;
 }
 
+// slices of the rows that lead the processing order (positions < n_heavy): slice s covers entries
+// [first[s], first[s] + count[s]) of the row at position vrow[s]; row_off[v] .. row_off[v + 1] are the slices of position v
+template <typename T>
+struct CholSlices {
+    const int *vrow = nullptr, *first = nullptr, *count = nullptr, *row_off = nullptr;
+    T *part = nullptr;               // partials of the work items [part_base, ..): item - part_base selects the slot
+    int n_slices = 0, n_heavy = 0;
+    // Work items of a producer launch: items [0, n_slices) are the slices above; item n_slices + i is the WHOLE row at
+    // position n_heavy + i (two-kernel mode: every row's rank-k update is done by the producer build).
+    int part_base = 0;
+};
+// elements of one slice's partial: NT tiles in lane-linear order, right-hand side, border column, two scalars
+__host__ __device__ constexpr size_t chol_wave_part_elems(int NB) { return (size_t)(NB * (NB + 1) / 2) * 256 + 2 * 16 * (size_t)NB + 64; }
+
 // NB: 16-blocks of the compiled tile grid; BORDER: the last unknown is kept outside the tiles; PD: 4-row gather steps
 // in flight; WPS: wavefronts per SIMD the register budget is set for (workgroups per CU).
 // NOV: at one wavefront per SIMD hipcc emits the accumulator-file form of every MFMA (destination and C operand in
@@ -45,9 +68,14 @@ __host__ __device__ constexpr size_t chol_wave_lds_elems(int NB)
 // The last NOV tiles of the packed order (and E, when NOV > 0) are therefore kept as ordinary values and updated as
 // tile += mfma(a, b, 0): the product lands in a short-lived accumulator, the sum is a vector add (12 more vector
 // instructions per update, hidden behind the 64-cycle MFMAs), and the register allocator is free to place them.
-template <typename T, int NB, bool BORDER, int PD, int WPS, int NOV = 0>
+// WMODE 0: a row per work item.  WMODE 1 (producer): work items are slices, the kernel stops after the rank-k update and
+// stores the partials.  WMODE 2: rows whose rank-k update is the sum of their slices' partials.  (Separate builds: the
+// register allocation of the plain build must not pay for the other two.)
+// EV: right-hand side and border column are forward-substituted on the vector ALU after the factorisation (their
+// per-group partial sums stay in registers, 2 NB values) instead of riding as the tile column E (NB more tiles).
+template <typename T, int NB, bool BORDER, int PD, int WPS, int NOV = 0, int WMODE = 0, bool EV = false>
 __global__ void __launch_bounds__(256, WPS)
-chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
+chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const CholSlices<T> SL)
 {
     using Mf = CholMfma<T>;
     using vec = typename Mf::vec;
@@ -55,6 +83,8 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
     constexpr int NRES = NT - NOV;           // tiles [0, NRES) are MFMA accumulators, [NRES, NT) overflow tiles
     constexpr int LDR = Mf::LDR, RSZ = 16 * LDR;
     constexpr int NV = 16 * NB + 16;
+    constexpr size_t PART = chol_wave_part_elems(NB);
+    constexpr bool PRODUCER = (WMODE == 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lm = lane & 15, g = lane >> 4;
@@ -92,14 +122,25 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
         // the next position is claimed now and read when this row is done
         int claim = 0;
         if (lane == 0) claim = atomicAdd(P.counter, 1);
-        RowDesc d = desc[rix];
+        int ritem = rix;                      // position of the row in the processing order
+        int sfirst = 0, scount = 0;
+        if (PRODUCER) {
+            if (rix < SL.n_slices) { ritem = SL.vrow[rix]; sfirst = SL.first[rix]; scount = SL.count[rix]; }
+            else { ritem = SL.n_heavy + (rix - SL.n_slices); scount = -1; }
+        }
+        RowDesc d = desc[ritem];
         const int row = __builtin_amdgcn_readfirstlane(d.row);
-        const int nnz = __builtin_amdgcn_readfirstlane(d.nnz);
-        const size_t st = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.st >> 32)) << 32) |
-                          (unsigned)__builtin_amdgcn_readfirstlane((int)(d.st & 0xffffffffu));
+        const int nnz_row = __builtin_amdgcn_readfirstlane(d.nnz);
+        const size_t st_row = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.st >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)(d.st & 0xffffffffu));
+        // what the rank-k loop walks over: the whole row, or this slice of it
+        const int nnz = (PRODUCER && scount >= 0) ? __builtin_amdgcn_readfirstlane(scount) : nnz_row;
+        const size_t st = PRODUCER ? st_row + (size_t)__builtin_amdgcn_readfirstlane(sfirst) : st_row;
+        // rows whose rank-k update was done slice by slice: add the partials instead of gathering
+        constexpr bool from_slices = (WMODE == 2);
         T *arow = P.A + (size_t)row * P.lda;
         const bool has_u = coll && row < P.rows_with_u;
-        if (coll && nnz == 0 && !has_u) {                               // collective.c:1258-1268, :1876-1885
+        if (!PRODUCER && coll && nnz_row == 0 && !has_u) {              // collective.c:1258-1268, :1876-1885
             for (int e = lane; e < kt; e += 64) arow[e] = T(0);
             rix = P.row_first + nwaves + __builtin_amdgcn_readfirstlane(claim);
             continue;
@@ -107,12 +148,12 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
         T lam = P.lam, lam_last = P.lam_last;
         if (P.mode == CHOL_EXPLICIT) {
             if (P.scale_lam) {                                           // common.c:679-723
-                lam *= (T)nnz;
-                if (!P.scale_bias_const) lam_last *= (T)nnz;
+                lam *= (T)nnz_row;
+                if (!P.scale_bias_const) lam_last *= (T)nnz_row;
             }
         } else if (P.mode == CHOL_COLLECTIVE) {
             if (P.scale_lam || P.scale_lam_sideinfo) {                   // collective.c:1285-1355
-                T mult = (nnz > 0) ? (T)nnz : T(1);
+                T mult = (nnz_row > 0) ? (T)nnz_row : T(1);
                 if (P.scale_lam_sideinfo && has_u) mult += (T)P.p_side;  // :1338-1346
                 lam *= mult;
                 if (has_u || !P.scale_bias_const) lam_last *= mult;
@@ -130,23 +171,29 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
         vec acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = vec{0, 0, 0, 0};
+        // (four tiles of loads in flight at a time: left to itself the scheduler issues all NT x 4 loads first and the
+        //  register allocation of the whole kernel pays for it)
         auto add_matrix = [&](const T *Mi, int lim) {              // collective.c:1566-1571
-            static_for<0, NB>([&](auto bic) {
-                constexpr int bi = decltype(bic)::value;
-                static_for<bi, NB>([&](auto bjc) {
-                    constexpr int bj = decltype(bjc)::value;
+            static_for<0, (NT + 3) / 4>([&](auto qc) {
+                constexpr int q4 = decltype(qc)::value;
+                static_for<4 * q4, (4 * q4 + 4 < NT ? 4 * q4 + 4 : NT)>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int bi = tile_bi(t, NB), bj = tile_bj(t, NB);
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int gi = 16 * bi + Mf::row_of(lane_o, r), gj = 16 * bj + lm_o;
                         const int lo = min(gi, gj), hi = max(gi, gj);
                         const T q = Mi[(size_t)min(lo, lim - 1) * lim + min(hi, lim - 1)];
-                        acc[wtix(bi, bj, NB)][r] += (hi < lim) ? q : T(0);
+                        acc[t][r] += (hi < lim) ? q : T(0);
                     }
                 });
+                __builtin_amdgcn_sched_barrier(0);
             });
         };
-        if (M1 != nullptr) add_matrix(M1, kt);
-        if (M2 != nullptr && kc > 0) add_matrix(M2, kc);
+        if (!PRODUCER) {
+            if (M1 != nullptr) add_matrix(M1, kt);
+            if (M2 != nullptr && kc > 0) add_matrix(M2, kc);
+        }
         // element (gi, kt - 1) of the initial matrices: the border column
         auto border_init = [&](int gi) -> T {
             T v = T(0);
@@ -154,29 +201,31 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
             if (M2 != nullptr && kc > 0) { const T q = M2[(size_t)min(gi, kc - 1) * kc + (kc - 1)]; v += (kt - 1 < kc) ? q : T(0); }
             return v;
         };
-        static_for<0, NB>([&](auto bic) {
-            constexpr int bi = decltype(bic)::value;
+        if (!PRODUCER) {
+            static_for<0, NB>([&](auto bic) {
+                constexpr int bi = decltype(bic)::value;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int gi = 16 * bi + Mf::row_of(lane, r), gj = 16 * bi + lm;
-                T dv = T(0);
-                if (gi == gj) dv = (gi >= kq) ? T(1) : (!add_lam ? T(0) : ((gi == kt - 1) ? lam_last : lam));   // common.c:1060-1062, collective.c:1819
-                acc[wtix(bi, bi, NB)][r] += dv;
-            }
-        });
+                for (int r = 0; r < 4; r++) {
+                    const int gi = 16 * bi + Mf::row_of(lane, r), gj = 16 * bi + lm;
+                    T dv = T(0);
+                    if (gi == gj) dv = (gi >= kq) ? T(1) : (!add_lam ? T(0) : ((gi == kt - 1) ? lam_last : lam));   // common.c:1060-1062, collective.c:1819
+                    acc[wtix(bi, bi, NB)][r] += dv;
+                }
+            });
+        }
         // right-hand side, border column: per lane the partial sum of its 4-row group g for the unknown 16 b + lm
         // (summed over the groups when the block becomes the pivot); prefilled values enter through group 0
-        const bool pre_rhs = has_u || P.rhs_prefilled_all;              // w*U*C prefilled (collective.c:5768-5773)
+        const bool pre_rhs = !PRODUCER && (has_u || P.rhs_prefilled_all);   // w*U*C prefilled (collective.c:5768-5773)
         T rp[NB], gp[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             const int u = 16 * b + lm;
             rp[b] = (pre_rhs && g == 0 && u < kq) ? arow[min(u, kt - 1)] : T(0);
             gp[b] = T(0);
-            if (BORDER) { const T q = border_init(16 * b + lm_o); gp[b] = (g == 0 && u < kq) ? q : T(0); }
+            if (BORDER && !PRODUCER) { const T q = border_init(16 * b + lm_o); gp[b] = (g == 0 && u < kq) ? q : T(0); }
         }
         T gam = T(0), rbs = T(0);            // border diagonal and border right-hand side (partial over g, equal over lm)
-        if (BORDER) {
+        if (BORDER && !PRODUCER) {
             if (g == 0) {
                 gam = (add_lam ? lam_last : T(0));
                 gam += border_init(kt - 1);
@@ -185,79 +234,133 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
         }
         // ---- 1. rank-k update: PD steps of 4 gathered rows in flight ----
         const int nsteps = (nnz + 3) >> 2;
-        const int niter = (nsteps + PD - 1) / PD;
-        {
-            T opb[PD][NB], bvb[PD], xraw[PD], bsv[PD];
-            bool vld[PD];
-            int idxn[PD]; T xn[PD]; bool vn[PD];
-            auto load_entry = [&](int s, int step) {
-                const int e = 4 * step + g;
-                vn[s] = e < nnz;
-                const int ec = min(e, nnz - 1);
-                idxn[s] = P.indices[st + ec];
-                xn[s] = P.values[st + ec];
-            };
-            auto issue_rows = [&](int s) {
-                const T *rowp = P.B + (size_t)idxn[s] * P.ldb;
+        const int niter = from_slices ? 0 : (nsteps + PD - 1) / PD;
+        if constexpr (from_slices) {
+            // the rank-k update of this row was done slice by slice: add the partials in slice order
+            const bool hv = rix < SL.n_heavy;
+            const int s0 = hv ? SL.row_off[rix] : SL.n_slices + (rix - SL.n_heavy), s1 = hv ? SL.row_off[rix + 1] : s0 + 1;
+            for (int sl = s0; sl < s1; sl++) {
+                const T *pp = SL.part + (size_t)(sl - SL.part_base) * PART;
+                static_for<0, (NT + 3) / 4>([&](auto qc) {
+                    constexpr int q4 = decltype(qc)::value;
+                    static_for<4 * q4, (4 * q4 + 4 < NT ? 4 * q4 + 4 : NT)>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
 #pragma unroll
-                for (int b = 0; b < NB; b++) opb[s][b] = rowp[colb[b]];
-                bvb[s] = BORDER ? rowp[bcol] : T(0);
-                bsv[s] = (P.bias_sub != nullptr) ? P.bias_sub[idxn[s]] : T(0);
-                xraw[s] = xn[s]; vld[s] = vn[s];
-            };
-            if (nnz > 0) {
-#pragma unroll
-                for (int s = 0; s < PD; s++) load_entry(s, s);
-#pragma unroll
-                for (int s = 0; s < PD; s++) { issue_rows(s); load_entry(s, PD + s); }
-            }
-            for (int it = 0; it < niter; it++) {
-#pragma unroll
-                for (int s = 0; s < PD; s++) {
-                    const T x = xraw[s] - bsv[s];
-                    T ws = impl_w ? x : T(1);               // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
-                    T xw = impl_w ? x + T(1) : x;           // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
-                    if (!vld[s]) { ws = T(0); xw = T(0); }
-                    T o[NB], a[NB];
-#pragma unroll
-                    for (int b = 0; b < NB; b++) {
-                        o[b] = ((vmask >> b) & 1u) ? opb[s][b] : T(0);
-                        a[b] = o[b] * ws;
-                    }
-                    const T bv = bvb[s];
-                    // the next use of this buffer: step (it + 1) PD + s
-                    if (it + 1 < niter) { issue_rows(s); load_entry(s, (it + 2) * PD + s); }
-                    static_for<0, NB>([&](auto bic) {
-                        constexpr int bi = decltype(bic)::value;
-                        static_for<bi, NB>([&](auto bjc) {
-                            constexpr int bj = decltype(bjc)::value;
-                            constexpr int t = wtix(bi, bj, NB);
-                            if constexpr (t < NRES) acc[t] = Mf::mma(a[bi], o[bj], acc[t]);
-                            else acc[t] += Mf::mma(a[bi], o[bj], vec{0, 0, 0, 0});
-                        });
+                        for (int r = 0; r < 4; r++) acc[t][r] += pp[t * 256 + r * 64 + lane];
                     });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                const T *pv = pp + (size_t)NT * 256;
 #pragma unroll
-                    for (int b = 0; b < NB; b++) rp[b] += xw * o[b];
-                    if (BORDER) {
-                        const T bw = ws * bv;
+                for (int b = 0; b < NB; b++) {
+                    const T q = pv[16 * b + lm];
+                    rp[b] += (g == 0) ? q : T(0);
+                    if (BORDER) { const T q2 = pv[16 * NB + 16 * b + lm]; gp[b] += (g == 0) ? q2 : T(0); }
+                }
+                if (BORDER) {
+                    const T q3 = pv[32 * NB], q4 = pv[32 * NB + 1];
+                    gam += (g == 0) ? q3 : T(0);
+                    rbs += (g == 0) ? q4 : T(0);
+                }
+            }
+        } else {
+            // one sweep over the row's (or slice's) entries for the tiles [T0, T1) of the packed order; VEC: the
+            // right-hand side and border column partials ride along
+            auto rank_pass = [&](auto t0c, auto t1c, auto vecc) {
+                constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+                constexpr bool VEC = decltype(vecc)::value;
+                T opb[PD][NB], bvb[PD], xraw[PD], bsv[PD];
+                bool vld[PD];
+                int idxn[PD]; T xn[PD]; bool vn[PD];
+                auto load_entry = [&](int s, int step) {
+                    const int e = 4 * step + g;
+                    vn[s] = e < nnz;
+                    const int ec = min(e, nnz - 1);
+                    idxn[s] = P.indices[st + ec];
+                    xn[s] = P.values[st + ec];
+                };
+                auto issue_rows = [&](int s) {
+                    const T *rowp = P.B + (size_t)idxn[s] * P.ldb;
+                    static_for<0, NB>([&](auto bc) {
+                        constexpr int b = decltype(bc)::value;
+                        if constexpr (VEC || wave_block_needed(b, T0, T1, NB)) opb[s][b] = rowp[colb[b]];
+                        else opb[s][b] = T(0);
+                    });
+                    bvb[s] = (BORDER && VEC) ? rowp[bcol] : T(0);
+                    bsv[s] = (P.bias_sub != nullptr) ? P.bias_sub[idxn[s]] : T(0);
+                    xraw[s] = xn[s]; vld[s] = vn[s];
+                };
+                if (nnz > 0 && niter > 0) {
 #pragma unroll
-                        for (int b = 0; b < NB; b++) gp[b] += bw * o[b];
-                        gam += bw * bv;
-                        rbs += xw * bv;
+                    for (int s = 0; s < PD; s++) load_entry(s, s);
+#pragma unroll
+                    for (int s = 0; s < PD; s++) { issue_rows(s); load_entry(s, PD + s); }
+                }
+                for (int it = 0; it < niter; it++) {
+#pragma unroll
+                    for (int s = 0; s < PD; s++) {
+                        const T x = xraw[s] - bsv[s];
+                        T ws = impl_w ? x : T(1);               // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
+                        T xw = impl_w ? x + T(1) : x;           // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
+                        if (!vld[s]) { ws = T(0); xw = T(0); }
+                        T o[NB], a[NB];
+#pragma unroll
+                        for (int b = 0; b < NB; b++) {
+                            o[b] = ((vmask >> b) & 1u) ? opb[s][b] : T(0);
+                            a[b] = o[b] * ws;
+                        }
+                        const T bv = bvb[s];
+                        // the next use of this buffer: step (it + 1) PD + s
+                        if (it + 1 < niter) { issue_rows(s); load_entry(s, (it + 2) * PD + s); }
+                        static_for<0, NB>([&](auto bic) {
+                            constexpr int bi = decltype(bic)::value;
+                            static_for<bi, NB>([&](auto bjc) {
+                                constexpr int bj = decltype(bjc)::value;
+                                constexpr int t = wtix(bi, bj, NB);
+                                if constexpr (t >= T0 && t < T1) acc[t] = Mf::mma(a[bi], o[bj], acc[t]);
+                            });
+                        });
+                        if constexpr (VEC) {
+#pragma unroll
+                            for (int b = 0; b < NB; b++) rp[b] += xw * o[b];
+                            if (BORDER) {
+                                const T bw = ws * bv;
+#pragma unroll
+                                for (int b = 0; b < NB; b++) gp[b] += bw * o[b];
+                                gam += bw * bv;
+                                rbs += xw * bv;
+                            }
+                        }
                     }
                 }
+            };
+            if constexpr (PRODUCER && NOV > 0) {
+                // 36 tiles of 8 registers do not fit the 256 accumulator registers: the first NT - NOV tiles in one sweep,
+                // stored, then the last NOV tiles in a second sweep over the same entries (only the blocks they touch are
+                // read again, from L1 / L2)
+                rank_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NRES>{}, std::true_type{});
+                T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
+#pragma unroll
+                for (int t = 0; t < NRES; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) pp[t * 256 + r * 64 + lane] = acc[t][r];
+                rank_pass(std::integral_constant<int, NRES>{}, std::integral_constant<int, NT>{}, std::false_type{});
+            } else {
+                rank_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{}, std::true_type{});
             }
         }
         // ---- 2. right-hand side and border column become the tile column E (columns 0 and 1) ----
+        if (PRODUCER || !EV) {
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-            T v = lanes::tswap16_add(rp[b], rp[b]);
-            v = lanes::tswap32_add(v, v);
-            if (lane < 16) yv0[16 * b + lane] = v;
-            if (BORDER) {
-                T w = lanes::tswap16_add(gp[b], gp[b]);
-                w = lanes::tswap32_add(w, w);
-                if (lane < 16) yv1[16 * b + lane] = w;
+            for (int b = 0; b < NB; b++) {
+                T v = lanes::tswap16_add(rp[b], rp[b]);
+                v = lanes::tswap32_add(v, v);
+                if (lane < 16) yv0[16 * b + lane] = v;
+                if (BORDER) {
+                    T w = lanes::tswap16_add(gp[b], gp[b]);
+                    w = lanes::tswap32_add(w, w);
+                    if (lane < 16) yv1[16 * b + lane] = w;
+                }
             }
         }
         if (BORDER) {
@@ -265,18 +368,36 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
             rbs = lanes::tswap16_add(rbs, rbs); rbs = lanes::tswap32_add(rbs, rbs);
         }
         CMF_LDS_FENCE();
-        vec E[NB];
+        if constexpr (PRODUCER) {
+            T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
+            for (int t = (NOV > 0 ? NRES : 0); t < NT; t++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int u = 16 * b + Mf::row_of(lane, r);
-                const T v0 = yv0[u];
-                const T v1 = BORDER ? yv1[u] : T(0);
-                E[b][r] = (lm == 0) ? v0 : ((BORDER && lm == 1) ? v1 : T(0));
+                for (int r = 0; r < 4; r++) pp[t * 256 + r * 64 + lane] = acc[t][r];
+            T *pv = pp + (size_t)NT * 256;
+            for (int u = lane; u < 16 * NB; u += 64) {
+                pv[u] = yv0[u];
+                if (BORDER) pv[16 * NB + u] = yv1[u];
             }
+            if (BORDER && lane == 0) { pv[32 * NB] = gam; pv[32 * NB + 1] = rbs; }
+            CMF_LDS_FENCE();
+            rix = P.row_first + nwaves + __builtin_amdgcn_readfirstlane(claim);
+            continue;
         }
-        CMF_LDS_FENCE();
+        vec E[EV ? 1 : NB];
+        if constexpr (!EV) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int u = 16 * b + Mf::row_of(lane, r);
+                    const T v0 = yv0[u];
+                    const T v1 = BORDER ? yv1[u] : T(0);
+                    E[b][r] = (lm == 0) ? v0 : ((BORDER && lm == 1) ? v1 : T(0));
+                }
+            }
+            CMF_LDS_FENCE();
+        }
         // ---- 3. blocked Cholesky  M = R^T R, in this wave's registers ----
         for (int kb = 0; kb < nb; kb++) {
             T *rslot = rinv + (size_t)kb * RSZ;
@@ -305,7 +426,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
                         constexpr int j = decltype(jc)::value;
                         acc[wtix(KB, j, NB)] = panel(acc[wtix(KB, j, NB)]);
                     });
-                    E[KB] = panel(E[KB]);
+                    if constexpr (!EV) E[KB] = panel(E[KB]);
                     // trailing:  tile(bi, bj) -= X_bi^T X_bj ;  E_bi -= X_bi^T E_k  (forward substitution)
                     static_for<KB + 1, NB>([&](auto bic) {
                         constexpr int bi = decltype(bic)::value;
@@ -325,7 +446,8 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
                                 acc[t] += tmp;
                             }
                         });
-                        if constexpr (NOV == 0) {
+                        if constexpr (EV) {
+                        } else if constexpr (NOV == 0) {
 #pragma unroll
                             for (int r = 0; r < 4; r++) E[bi] = Mf::mma(na[r], E[KB][r], E[bi]);
                         } else {
@@ -338,17 +460,59 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc)
                 }
             });
         }
-        // y (column 0 of E) and R^-T g (column 1) back to LDS
+        if constexpr (EV) {
+            // forward substitution after the factorisation, on the vector ALU:  y_k = inv(R_kk)^T (v_k - sum_{i<k} R_ik^T y_i)
+            // for the right-hand side and the border column at once.  rp / gp still hold the per-group partials of v; a
+            // lane adds the products of its four rows of every tile (i, k), the groups are summed, one 16 x 16
+            // matrix-vector product per block through LDS.
+            for (int kb = 0; kb < nb; kb++) {
+                const T *rslot = rinv + (size_t)kb * RSZ;
+                T vk = T(0), wk = T(0);
+                static_for<0, NB>([&](auto kc_) {
+                    constexpr int KB = decltype(kc_)::value;
+                    if (kb == KB) {
+                        T s0 = T(0), s1 = T(0);
+                        static_for<0, KB>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
+                            for (int r = 0; r < 4; r++) {
+                                const T tv = acc[wtix(i, KB, NB)][r];
+                                s0 += tv * yv0[16 * i + Mf::row_of(lane, r)];
+                                if (BORDER) s1 += tv * yv1[16 * i + Mf::row_of(lane, r)];
+                            }
+                        });
+                        vk = rp[KB] - s0; wk = gp[KB] - s1;
+                    }
+                });
+                vk = lanes::tswap16_add(vk, vk); vk = lanes::tswap32_add(vk, vk);
+                if (BORDER) { wk = lanes::tswap16_add(wk, wk); wk = lanes::tswap32_add(wk, wk); }
+                if (lane < 16) { yv0[16 * kb + lane] = vk; if (BORDER) yv1[16 * kb + lane] = wk; }
+                CMF_LDS_FENCE();
+                T y0 = T(0), y1 = T(0);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int u = 16 * b + Mf::row_of(lane, r);
-                if (lm == 0) yv0[u] = E[b][r];
-                if (BORDER && lm == 1) yv1[u] = E[b][r];
+                for (int c = 0; c < 16; c++) {
+                    const T ic = rslot[c * LDR + lm];
+                    y0 += ic * yv0[16 * kb + c];
+                    if (BORDER) y1 += ic * yv1[16 * kb + c];
+                }
+                CMF_LDS_FENCE();
+                if (lane < 16) { yv0[16 * kb + lane] = y0; if (BORDER) yv1[16 * kb + lane] = y1; }
+                CMF_LDS_FENCE();
             }
         }
-        CMF_LDS_FENCE();
+        // y (column 0 of E) and R^-T g (column 1) back to LDS
+        if constexpr (!EV) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int u = 16 * b + Mf::row_of(lane, r);
+                    if (lm == 0) yv0[u] = E[b][r];
+                    if (BORDER && lm == 1) yv1[u] = E[b][r];
+                }
+            }
+            CMF_LDS_FENCE();
+        }
         T xlast = T(0);
         if (BORDER) {
             // rho^2 = gamma - r.r ;  y_last = (rhs_last - r.y) / rho ;  x_last = y_last / rho ;  z = y - r x_last

@@ -59,6 +59,10 @@ struct DevBuf {
         owned = true;
         if (count) HIP_CHECK(hipMalloc((void **)&ptr, count * sizeof(T)));
     }
+    void alloc_at_least(size_t count)
+    {
+        if (n < count) alloc(count);
+    }
     void upload(const T *host, size_t count, hipStream_t st)
     {
         if (count > n) alloc(count);
@@ -147,7 +151,9 @@ struct SparseShard {
     static constexpr int GRAM_SLICE = 2048;
     int n_slices = 0;
     DevBuf<int> sl_vrow, sl_first, sl_count, row_sl_off;
+    std::vector<int> h_row_sl_off;       // host copy of row_sl_off (batching of the two-kernel Cholesky mode)
     DevBuf<real_t> gram_part;
+    mutable DevBuf<real_t> chol_part;    // partial normal matrices of the slices (wave-per-row Cholesky kernel), sized on first use
 
     void upload(int nrows_, const size_t *hp, const int *hi, const real_t *hv, hipStream_t st)
     {
@@ -196,7 +202,7 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0; n_long = 0;
+        n_empty = 0; n_long = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         for (int q = 0; q < nrows; q++) {
@@ -234,6 +240,7 @@ struct SparseShard {
             sl_first.upload(s_first.data(), s_first.size(), st);
             sl_count.upload(s_count.data(), s_count.size(), st);
             row_sl_off.upload(s_off.data(), s_off.size(), st);
+            h_row_sl_off = s_off;
             gram_part.alloc((size_t)n_slices * GRAM_PART);
         }
         HIP_CHECK(hipStreamSynchronize(st));
@@ -249,6 +256,14 @@ struct DeviceInfo {
     // first use, owned here
     hipStream_t aux_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // third stream for the eigen-decomposition of the low-rank path (one workgroup, overlaps the row kernels of both other streams)
+    hipStream_t eig_stream_ = nullptr;
+    hipEvent_t eig_ev = nullptr, eig_fork = nullptr;
+    hipStream_t eig_stream()
+    {
+        if (!eig_stream_) HIP_CHECK(hipStreamCreateWithFlags(&eig_stream_, hipStreamNonBlocking));
+        return eig_stream_;
+    }
     // rocBLAS handle for the plain dense contractions of the side-information path (U C, U^T A, A^T A for k > 64);
     // created on first use, bound to `stream`, atomics off (bit-reproducible results)
     rocblas_handle blas = nullptr;
@@ -265,6 +280,9 @@ struct DeviceInfo {
     ~DeviceInfo()
     {
         if (blas) (void)rocblas_destroy_handle(blas);
+        if (eig_ev) (void)hipEventDestroy(eig_ev);
+        if (eig_fork) (void)hipEventDestroy(eig_fork);
+        if (eig_stream_) (void)hipStreamDestroy(eig_stream_);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (join_ev) (void)hipEventDestroy(join_ev);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);

@@ -8,6 +8,7 @@
 #include "device.hpp"
 #include "coo_device.hpp"
 #include "chol_wave_kernels.hpp"
+#include "lowrank_kernels.hpp"
 #include <functional>
 #include <memory>
 #include <new>
@@ -56,6 +57,7 @@ struct CholCall {
     const real_t *values_override = nullptr; // values of the first source (default: X's own)
     bool rhs_only = false;                   // CHOL_NAZ: gather the right-hand sides only
     bool rhs_prefilled_all = false;          // every row starts from the right-hand side left in A
+    int row_limit = -1;                      // only the first row_limit positions of the processing order (the others are solved elsewhere)
 };
 
 static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, CholParams<real_t> P, bool two_src,
@@ -72,6 +74,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
     else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT) P.nrows = X->nrows;   // empty rows too
     else P.nrows = X->n_nonempty;                                                // non-empty rows
+    if (c.row_limit >= 0) P.nrows = std::min(P.nrows, c.row_limit);
     P.Minit = c.Minit; P.Mfull = c.Mfull; P.kc = c.kc; P.rows_with_u = c.rows_with_u; P.p_side = c.p_side;
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_lam_sideinfo = c.scale_lam_sideinfo; P.scale_bias_const = c.scale_bias_const;
@@ -101,7 +104,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         return 2;
     }
     if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
-    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 4 * sizeof(int), dev.stream));
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 4 * sizeof(int), dev.stream));   // [0, 4): first launches of this call
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
     const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ;      // CHOL_NAZ is part of that build only
@@ -118,51 +121,117 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                               c.mode == CHOL_COLLECTIVE_IMPLICIT) &&
                              !(chol_env != nullptr && strcmp(chol_env, "rows") == 0);
         if (wave_ok) {
-            static const int wave_row_max = getenv("CMFREC_HIP_CHOL_WAVE_MAX") ? atoi(getenv("CMFREC_HIP_CHOL_WAVE_MAX")) : SparseShard::LONG_ROW;
-            const int n_heavy = (wave_row_max == SparseShard::LONG_ROW) ? std::min(X->n_long, P.nrows) : X->rows_longer_than(wave_row_max, P.nrows);
+            // rows beyond 1024 entries: sliced (their slice tables are the ones of the split-row CG path, SparseShard::sl_*);
+            // CMFREC_HIP_CHOL=noslices leaves them to the workgroup-per-row kernel (A/B switch)
+            const bool sliced = !(chol_env != nullptr && strcmp(chol_env, "noslices") == 0);
+            const int n_heavy = std::min(X->bin_rows[BIN_VHEAVY], P.nrows);
             const int total = P.nrows;
             DeviceInfo &d = const_cast<DeviceInfo &>(dev);
-            const bool two = n_heavy > 0 && total > n_heavy;
-            if (two) {
-                d.ensure_aux();
-                HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
-                HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
-            }
-            if (total > n_heavy) {
+            // one launch of the wave kernel over the positions [first, last) of the processing order (or over work items)
+            auto wave_launch = [&](int wmode, int first, int last, int counter, const CholSlices<real_t> &SL, hipStream_t st) {
+                if (last <= first) return;
                 CholParams<real_t> W = P;
-                W.row_first = n_heavy; W.nrows = total; W.counter = dev.row_counter.ptr + 2;
+                W.row_first = first; W.nrows = last; W.counter = dev.row_counter.ptr + counter;
                 auto wlaunch = [&](auto kern, int nb_, int wps) {
                     const size_t smem = 4 * chol_wave_lds_elems<real_t>(nb_) * sizeof(real_t);
-                    const int grid = std::min((total - n_heavy + 3) / 4, dev.num_cus * wps);
+                    const int grid = std::min((last - first + 3) / 4, dev.num_cus * wps);
                     if (smem > 48 * 1024)
                         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, two ? d.aux_stream : dev.stream, W, X->desc.ptr);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, W, X->desc.ptr, SL);
                 };
-                // <16-blocks, border, gather steps in flight, wavefronts per SIMD>
-#define WAVE_KERN(nb_, pd, wps, nov) (border ? chol_wave_kernel<real_t, nb_, true, pd, wps, nov> : chol_wave_kernel<real_t, nb_, false, pd, wps, nov>)
+                // <16-blocks, border, gather steps in flight, wavefronts per SIMD, overflow tiles, mode>
+#define WAVE_KERN_M(nb_, pd, wps, nov, wm) (border ? chol_wave_kernel<real_t, nb_, true, pd, wps, nov, wm, false> : chol_wave_kernel<real_t, nb_, false, pd, wps, nov, wm, false>)
+#define WAVE_KERN(nb_, pd, wps, nov) \
+    (wmode == 1 ? WAVE_KERN_M(nb_, pd, wps, nov, 1) : wmode == 2 ? WAVE_KERN_M(nb_, pd, wps, nov, 2) : WAVE_KERN_M(nb_, pd, wps, nov, 0))
 #ifdef CMFREC_HIP_FLOAT
                 if (nbw <= 2) wlaunch(WAVE_KERN(2, 4, 4, 0), 2, 4);
                 else if (nbw <= 4) wlaunch(WAVE_KERN(4, 4, 2, 0), 4, 2);
                 else if (nbw <= 6) wlaunch(WAVE_KERN(6, 3, 2, 0), 6, 2);
                 else wlaunch(WAVE_KERN(8, 2, 1, 0), 8, 1);
 #else
-                // 7 and 8 blocks in double: 28 / 36 tiles of 8 registers exceed the 256 accumulator registers, the last 8 tiles
-                // are overflow tiles (chol_wave_kernels.hpp, NOV); one gather step in flight is a microsecond of MFMAs there
                 if (nbw <= 2) wlaunch(WAVE_KERN(2, 4, 3, 0), 2, 3);
                 else if (nbw <= 4) wlaunch(WAVE_KERN(4, 3, 2, 0), 4, 2);
                 else if (nbw <= 6) wlaunch(WAVE_KERN(6, 2, 1, 0), 6, 1);
-                else wlaunch(WAVE_KERN(8, 1, 1, 8), 8, 1);
+                // 7 and 8 blocks in double: two kernels, see below
+                else if (wmode == 1) wlaunch(WAVE_KERN_M(8, 3, 1, 4, 1), 8, 1);
+                else wlaunch((border ? chol_wave_kernel<real_t, 8, true, 1, 1, 6, 2, true> : chol_wave_kernel<real_t, 8, false, 1, 1, 6, 2, true>), 8, 1);
 #endif
 #undef WAVE_KERN
+#undef WAVE_KERN_M
                 HIP_CHECK(hipGetLastError());
-                if (two) {
-                    HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
-                }
+            };
+            const int nb_inst = nbw <= 2 ? 2 : nbw <= 4 ? 4 : nbw <= 6 ? 6 : 8;
+            const size_t part_elems = chol_wave_part_elems(nb_inst);
+            CholSlices<real_t> SLT;
+            if (n_heavy > 0) {
+                SLT.vrow = X->sl_vrow.ptr; SLT.first = X->sl_first.ptr; SLT.count = X->sl_count.ptr; SLT.row_off = X->row_sl_off.ptr;
+                SLT.n_slices = X->n_slices;
             }
-            P.nrows = n_heavy;          // what is left for the kernel below
-            if (n_heavy <= 0) return 0;
-            int rc_heavy = launch_chol_rows(dev, c, X, P, two_src, smem_nonneg);
-            if (two) HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
+            SLT.n_heavy = n_heavy;
+            if (sizeof(real_t) == 8 && nbw > 6) {
+                // Two kernels (7 and 8 blocks in double: 28 / 36 tiles of 8 registers + the factorisation's temporaries exceed
+                // what one kernel can keep in registers -- hipcc emits the accumulator-file form of the MFMAs at one wave per
+                // SIMD, 256 registers for all MFMA destinations).  The producer build runs every row's rank-k update at full
+                // MFMA rate (no spills, three gather steps in flight) and leaves the raw tiles in HBM, the second build adds the
+                // initial matrix and factorises.  76 KB per work item each way; batches bound the scratch buffer.
+                static const int batch_env = getenv("CMFREC_HIP_CHOL_BATCH") ? atoi(getenv("CMFREC_HIP_CHOL_BATCH")) : 0;
+                const int BATCH = batch_env > 0 ? batch_env : 32768;
+                const std::vector<int> &ho = X->h_row_sl_off;
+                int max_row_items = 1;
+                for (int r = 0; r < n_heavy; r++) max_row_items = std::max(max_row_items, ho[r + 1] - ho[r]);
+                const int nsl = n_heavy > 0 ? X->n_slices : 0;
+                const size_t cap_items = (size_t)std::min<long long>((long long)nsl + (total - n_heavy), std::max(BATCH, max_row_items));
+                if (X->chol_part.n < cap_items * part_elems) X->chol_part.alloc(cap_items * part_elems);
+                SLT.part = X->chol_part.ptr;
+                int ctr = 4;
+                auto run_batch = [&](int item0, int item1, int row0, int row1) {
+                    if (ctr + 2 > 60) ctr = 4;
+                    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr + ctr, 0, 2 * sizeof(int), dev.stream));
+                    CholSlices<real_t> SL = SLT;
+                    SL.part_base = item0;
+                    wave_launch(1, item0, item1, ctr, SL, dev.stream);
+                    wave_launch(2, row0, row1, ctr + 1, SL, dev.stream);
+                    ctr += 2;
+                };
+                for (int r = 0; r < n_heavy;) {                 // heavy rows: whole rows per batch
+                    int r1 = r + 1;
+                    while (r1 < n_heavy && ho[r1 + 1] - ho[r] <= (int)cap_items) r1++;
+                    run_batch(ho[r], ho[r1], r, r1);
+                    r = r1;
+                }
+                for (int r = n_heavy; r < total; r += (int)cap_items) {   // the others: item n_slices + i <-> position n_heavy + i
+                    const int r1 = (int)std::min<long long>(total, (long long)r + (long long)cap_items);
+                    run_batch(nsl + (r - n_heavy), nsl + (r1 - n_heavy), r, r1);
+                }
+                return 0;
+            }
+            const bool two = n_heavy > 0 && total > n_heavy;
+            if (two) {
+                d.ensure_aux();
+                HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
+                HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
+            }
+            hipStream_t heavy_stream = two ? d.aux_stream : dev.stream;
+            CholSlices<real_t> none;
+            int rc_heavy = 0;
+            if (n_heavy > 0 && sliced) {
+                CholSlices<real_t> SL = SLT;
+                const size_t need = (size_t)X->n_slices * part_elems;
+                if (X->chol_part.n < need) X->chol_part.alloc(need);
+                SL.part = X->chol_part.ptr;
+                wave_launch(1, 0, X->n_slices, 1, SL, heavy_stream);       // partial Gramians of the slices
+                wave_launch(2, 0, n_heavy, 3, SL, heavy_stream);           // their rows: sum, factorise, solve
+            }
+            wave_launch(0, n_heavy, total, 2, none, dev.stream);          // everything up to 1024 entries
+            if (n_heavy > 0 && !sliced) {
+                CholParams<real_t> H = P;
+                H.nrows = n_heavy;
+                // (on the stream the call was issued on: the k_t <= 64 variant of the row kernel forks onto the auxiliary one itself)
+                rc_heavy = launch_chol_rows(dev, c, X, H, two_src, smem_nonneg);
+            } else if (two) {
+                HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
+                HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
+            }
             return rc_heavy;
         }
     }
@@ -222,10 +291,20 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
     }
 #ifdef CMFREC_HIP_FLOAT
     else if (T <= 12) launch(CHOL_KERN(12, 8, 32, 1), 12, 8, 32, 1);
-    else if (T <= 16) launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
+    else if (T <= 16) {
+        static const char *w16t = getenv("CMFREC_HIP_CHOL_ROWS16");
+        if (w16t != nullptr && w16t[0] == '8') launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
+        else launch(CHOL_KERN(16, 16, 16, 1), 16, 16, 16, 1);
+    }
     // k = 256 + bias (BASELINE config 5).  Two workgroups per CU do not pay here: at the 128 VGPRs that allows the
     // kernel spills (c5 share 1.6 -> 4.0 s per A-step; the same on 9 tiles in double: 22.6 -> 25.6 ms).
-    else launch(CHOL_KERN(17, 8, 16, 1), 17, 8, 16, 1);
+    else {
+        // 16 wavefronts per row (10 tile slots per wave instead of 20: the 8-wave build spills ~500 registers):
+        // c5 shard B-step 377 -> 274 ms.  CMFREC_HIP_CHOL_ROWS17=8 brings the 8-wave build back (A/B switch).
+        static const char *w17 = getenv("CMFREC_HIP_CHOL_ROWS17");
+        if (w17 != nullptr && w17[0] == '8') launch(CHOL_KERN(17, 8, 16, 1), 17, 8, 16, 1);
+        else launch(CHOL_KERN(17, 16, 16, 1), 17, 16, 16, 1);
+    }
 #else
     else if (T <= 12) launch(CHOL_KERN(12, 8, 16, 1), 12, 8, 16, 1);
     else launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
@@ -284,6 +363,108 @@ static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real
     if (r1 != rocblas_status_success || r2 != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS trsm failed"; throw HipError{1}; }
 }
 
+// Low-rank row updates (lowrank_kernels.hpp): eigenvectors / values of w C^T C, rotated C and opposing factors, rotated
+// right-hand sides and solutions.
+struct LowRankScratch {
+    DevBuf<double> W, V;
+    DevBuf<real_t> Q, Qt, Lam, Ct, Bt, R, T;
+};
+
+// Collective Cholesky half-step (mode CHOL_COLLECTIVE, dense side information on every row of the block) with the rows of
+// few entries solved by the low-rank update of a diagonalised shared matrix instead of a k_t^3 / 3 factorisation per row
+// (config 5's users: 20 entries against k_t = 257 unknowns).  c: the call as launch_chol would take it (right-hand sides
+// w U C already in the rows, c.Minit = w C^T C); Um: the block's rows of U; k: the factors shared with X; rows_b: rows of
+// the opposing matrix.  Returns -1 when the path does not apply (the caller launches as usual), else the return code.
+// CMFREC_HIP_LOWRANK=0 switches it off, =1 forces it whenever the shapes allow (tests).
+static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, CholCall c, const SparseShard &X, const real_t *Cm,
+                                     const real_t *Um, int p_self, real_t w, int k, int rows_b)
+{
+    const char *lr_env = getenv("CMFREC_HIP_LOWRANK");
+    const int kt = c.kt, kc = c.kc, k_side_self = c.koff;
+    // rows of up to lr_max entries: the s x s system is at most half the k_t x k_t one (and 8 blocks in single, 4 in double)
+    const int lr_type_max = (sizeof(real_t) == 4) ? 128 : 64;
+    const int lr_max = (kt >= 256 && lr_type_max >= 128) ? 128 : (kt >= 128 ? 64 : 32);
+    const int n_full = X.rows_longer_than(lr_max, X.nrows);          // positions [0, n_full): full factorisation
+    const int n_light = X.nrows - n_full;
+    const bool lr_ok = !(lr_env != nullptr && lr_env[0] == '0') && c.mode == CHOL_COLLECTIVE && c.Mfull == nullptr && c.X2 == nullptr &&
+                       !c.scale_bias_const && !dev.nonneg_now && !c.nonneg && dev.l1_now == (real_t)0 && dev.l1_last_now == (real_t)0 &&
+                       c.rows_with_u >= X.nrows && !c.rhs_prefilled_all && kt <= 320 && kt >= 64 && kc > 0 && p_self > 0 &&
+                       // the penalty must be a multiple of the identity on the rotated block: the last unknown's own lambda
+                       // (a bias) has to sit outside of it
+                       (kt - 1 >= kc || c.lam_last == c.lam) &&
+                       ((lr_env != nullptr && lr_env[0] == '1') || (n_light >= 32768 && kt >= 96));
+    if (!lr_ok || n_light <= 0) return -1;
+    hipStream_t st = dev.stream;
+    const int ngr = (kt + 15) / 16;
+    const size_t ldbt = (size_t)16 * ngr;
+    S.W.alloc_at_least((size_t)kc * kc); S.V.alloc_at_least((size_t)kc * kc);
+    S.Q.alloc_at_least((size_t)kc * kc); S.Qt.alloc_at_least((size_t)kc * kc); S.Lam.alloc_at_least((size_t)kc);
+    S.Ct.alloc_at_least((size_t)p_self * kc);
+    S.Bt.alloc_at_least((size_t)rows_b * ldbt + 64);
+    S.R.alloc_at_least((size_t)X.nrows * kc);
+    S.T.alloc_at_least((size_t)n_light * kc);
+    // w C^T C = Q L Q^T: one workgroup on the auxiliary stream, beside the full factorisations of the longer rows (which do
+    // not need it)
+    {
+        DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+        d.ensure_aux();
+        if (!d.eig_ev) HIP_CHECK(hipEventCreateWithFlags(&d.eig_ev, hipEventDisableTiming));
+        if (!d.eig_fork) HIP_CHECK(hipEventCreateWithFlags(&d.eig_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(d.eig_fork, st));
+        HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), d.eig_fork, 0));
+        hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), c.Minit, kc, S.W.ptr, S.V.ptr, S.Q.ptr, S.Qt.ptr,
+                           (size_t)kc, S.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(d.eig_ev, d.eig_stream()));
+        c.row_limit = n_full;
+        const int rc = (n_full > 0) ? launch_chol(dev, c, &X) : 0;
+        if (rc) return rc;
+        HIP_CHECK(hipStreamWaitEvent(st, d.eig_ev, 0));
+    }
+    // C~ = C Q ;  B~ = [B(:, :k) Q(k_side:, :) | B(:, k:)] ;  R = w U C~ (natural row order)
+    launch_gemm<false>(dev, p_self, kc, kc, (real_t)1, Cm, (size_t)kc, S.Q.ptr, (size_t)kc, S.Ct.ptr, (size_t)kc);
+    launch_gemm<false>(dev, rows_b, kc, k, (real_t)1, c.B, c.ldb, S.Q.ptr + (size_t)k_side_self * kc, (size_t)kc, S.Bt.ptr, ldbt);
+    if (kt > kc)
+        hipLaunchKernelGGL(copy_cols_kernel<real_t>, grid1d((size_t)rows_b * (kt - kc)), dim3(256), 0, st, S.Bt.ptr, ldbt, kc, c.B, c.ldb, k,
+                           kt - kc, (size_t)rows_b);
+    launch_gemm<false>(dev, X.nrows, kc, p_self, w, Um, (size_t)p_self, S.Ct.ptr, (size_t)kc, S.R.ptr, (size_t)kc);
+    LrParams<real_t> L;
+    L.A = c.A; L.lda = c.lda; L.pre = S.R.ptr; L.ldpre = (size_t)kc;
+    L.Tc = S.T.ptr; L.ldt = (size_t)kc; L.pos0 = n_full;
+    L.Bt = S.Bt.ptr; L.ldbt = ldbt; L.lam_eig = S.Lam.ptr;
+    L.kt = kt; L.kc = kc; L.koff = k_side_self; L.rotated = 1;
+    L.indptr = X.p.ptr; L.indices = X.i.ptr; L.values = X.v.ptr; L.bias_sub = c.bias_sub;
+    L.lam = c.lam; L.lam_last = c.lam_last;
+    L.scale_lam = c.scale_lam ? 1 : 0; L.scale_lam_sideinfo = c.scale_lam_sideinfo ? 1 : 0;
+    L.scale_bias_const = 0; L.p_side = p_self; L.collective = 1;
+    if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr + 8, 0, 4 * sizeof(int), st));
+    // rows sorted by length: (64, 128] entries -> 8 blocks (single precision only), (32, 64] -> 4, the rest -> 2
+    const int n_gt64 = X.rows_longer_than(64, X.nrows), n_gt32 = X.rows_longer_than(32, X.nrows);
+    auto lr_launch = [&](auto kern, int nb_, int wps, int first, int last, int counter) {
+        if (last <= first) return;
+        LrParams<real_t> Lc = L;
+        Lc.row_first = first; Lc.nrows = last; Lc.counter = dev.row_counter.ptr + 8 + counter;
+        const size_t smem = 4 * lowrank_lds_elems<real_t>(nb_) * sizeof(real_t);
+        if (smem > 48 * 1024)
+            HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int grid = std::min((last - first + 3) / 4, dev.num_cus * wps);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, Lc, X.desc.ptr);
+    };
+#ifdef CMFREC_HIP_FLOAT
+    lr_launch(lowrank_rows_kernel<real_t, 8, 1>, 8, 1, n_full, std::max(n_full, n_gt64), 0);
+#endif
+    lr_launch(lowrank_rows_kernel<real_t, 4, 2>, 4, 2, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
+    lr_launch(lowrank_rows_kernel<real_t, 2, 3>, 2, 3, std::max(n_full, n_gt32), X.nrows, 2);
+    HIP_CHECK(hipGetLastError());
+    // x[:kc] = Q x~[:kc]: one GEMM over the light rows (in processing order), then back to their rows
+    launch_gemm<false>(dev, n_light, kc, kc, (real_t)1, S.T.ptr, (size_t)kc, S.Qt.ptr, (size_t)kc, S.R.ptr, (size_t)kc);
+    hipLaunchKernelGGL(scatter_rows_kernel<real_t>, grid1d((size_t)n_light * kc), dim3(256), 0, st, c.A, c.lda, X.desc.ptr, n_full, S.R.ptr,
+                       (size_t)kc, kc, (size_t)n_light);
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 static void init_device(DeviceInfo &dev, int device)
 {
     int count = 0;
@@ -337,6 +518,9 @@ struct cmfrec_hip_session {
     std::vector<int> partBegin;          // nparts + 1 local row offsets
     std::vector<hipEvent_t> partEv;
     DevBuf<real_t> gram, ctc, betbe, ucA, ucB;
+    // low-rank row updates (lowrank_kernels.hpp): eigenvectors / values of w C^T C, rotated C and opposing factors,
+    // rotated right-hand sides and solutions
+    LowRankScratch lr;
     GramWorkspace gws;
     std::vector<EventPair> evA, evB;     // whole half-steps
     BinTimers binA, binB;                // row-update kernel launches per nnz bin
@@ -479,6 +663,17 @@ int cmfrec_hip_session_set_A_parts(cmfrec_hip_session *s, const size_t *csr_p, c
         s->partEv.clear();
         if (nparts <= 1) return 0;
         if (s->mdl.p > 0) { g_last_error = "cmfrec_hip_session_set_A_parts: not with user side information"; return 2; }
+        // no host CSR given: cut the resident one (shards built on the device)
+        std::vector<size_t> hp; std::vector<int_t> hi; std::vector<real_t> hv;
+        if (csr_p == nullptr) {
+            if (s->Xr.nrows != nrows) { g_last_error = "cmfrec_hip_session_set_A_parts: set X first"; return 2; }
+            hp.resize((size_t)nrows + 1); hi.resize(std::max<size_t>(s->Xr.nnz, 1)); hv.resize(std::max<size_t>(s->Xr.nnz, 1));
+            s->Xr.p.download(hp.data(), (size_t)nrows + 1, s->dev.stream);
+            s->Xr.i.download(hi.data(), s->Xr.nnz, s->dev.stream);
+            s->Xr.v.download(hv.data(), s->Xr.nnz, s->dev.stream);
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+            csr_p = hp.data(); csr_i = hi.data(); csr_v = hv.data();
+        }
         nparts = std::min(nparts, std::max(1, nrows));
         const int step = (nrows + nparts - 1) / nparts;
         for (int c = 0; c <= nparts; c++) s->partBegin.push_back(std::min(c * step, nrows));
@@ -532,6 +727,24 @@ int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const 
         dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
         shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
         shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
+// One shard from a COO triplet that already lives in HBM (multi-GPU set-up: the triplets come out of the
+// all-to-all exchange of the ranks' blocks, distributed.py): which = 'r' -> CSR of the local rows (d_key = row - row_begin,
+// d_other = global column), 'c' -> CSC of the local columns (d_key = column - col_begin, d_other = global row).
+// x := (x - subtract) * alpha as in cmfrec_hip_session_set_X_coo.  The pointers are device pointers.
+int cmfrec_hip_session_set_X_coo_device(cmfrec_hip_session *s, int which, const int_t *d_key, const int_t *d_other,
+                                        const real_t *d_val, size_t nnz, real_t subtract, real_t alpha)
+{
+    return guarded([&]() {
+        const cmfrec_hip_model &m = s->mdl;
+        if (which != 'r' && which != 'c') { g_last_error = "cmfrec_hip_session_set_X_coo_device: which must be 'r' or 'c'"; return 2; }
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        if (which == 'r') shard_from_coo(s->Xr, m.row_end - m.row_begin, m.n, d_key, d_other, d_val, nnz, subtract, alpha, s->dev.stream);
+        else shard_from_coo(s->Xc, m.col_end - m.col_begin, m.m, d_key, d_other, d_val, nnz, subtract, alpha, s->dev.stream);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
@@ -1071,6 +1284,11 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
                    p_self, lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, sbc,
                    CHOL_COLLECTIVE};
         add_implicit_term(c);
+        // rows with few entries against many unknowns: low-rank path (lowrank_kernels.hpp)
+        if (Fi == nullptr && !sbc && local_u_main == X.nrows && part < 0) {
+            const int rc_lr = launch_collective_lowrank(dev, s->lr, c, X, Cm, Um + (size_t)begin * p_self, p_self, w, m.k, isA ? m.n : m.m);
+            if (rc_lr >= 0) return rc_lr;
+        }
         int rc = launch_chol(dev, c, &X);
         if (rc) return rc;
         return solve_sideinfo_only_rows(s, isA, true, local_u_main, local_u - local_u_main);
@@ -1634,7 +1852,9 @@ int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size
         launch_gemm<false>(dev, m_u, kc, p, w_user, dU.ptr, (size_t)p, dC.ptr, (size_t)kc, dA.ptr, lda);
         CholCall c{dA.ptr, lda, dB.ptr + k_item, ldb, kt, k_user, bias_sub ? dbias.ptr : nullptr, dG.ptr, kc, m_u, p,
                    lam, lam_last, (bool)(scale_lam || scale_lam_sideinfo), scale_lam_sideinfo, false, CHOL_COLLECTIVE};
-        int rc = launch_chol(dev, c, &X);
+        LowRankScratch lrs;
+        int rc = (m_u >= m) ? launch_collective_lowrank(dev, lrs, c, X, dC.ptr, dU.ptr, p, w_user, k, n) : -1;
+        if (rc < 0) rc = launch_chol(dev, c, &X);
         dA.download(A, (size_t)m * lda, dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
         return rc;

@@ -35,6 +35,39 @@ def equal_boundaries(n, parts):
     return [min(i * step, n) for i in range(parts)] + [n]
 
 
+def shard_coo_by_items(row_global, col, val, n, rank, world, group=None, col_bounds=None):
+    """Set-up of the item side of a row-block run without ever holding the whole matrix on one rank: every rank brings
+    the entries of ITS user block (global row ids, global column ids); item blocks are cut nnz-balanced from the
+    all-reduced per-item counts, and every entry travels to the rank that owns its column in one
+    all-to-all (variable splits).  Entries arrive ordered by source rank and, inside a source, in their original order,
+    i.e. in the order of the concatenated COO -- the order the reference's stable counting sort would see.
+    Tensors may live on any device (gloo on CPU in the tests, RCCL on the GPUs).
+    Returns (col_bounds [world+1], rows_of_my_items (global), cols_of_my_items (global), vals)."""
+    import torch
+    import torch.distributed as dist
+    if col_bounds is None:
+        counts = torch.bincount(col.long(), minlength=n)
+        if world > 1:
+            dist.all_reduce(counts, group=group)
+        col_bounds = balanced_boundaries(counts.cpu().numpy(), world)
+    if world == 1:
+        return col_bounds, row_global, col, val
+    inner = torch.as_tensor(col_bounds[1:-1], device=col.device, dtype=col.dtype)
+    dest = torch.bucketize(col, inner, right=True)          # owner of the column: number of inner boundaries <= col
+    order = torch.argsort(dest, stable=True)
+    send = torch.bincount(dest, minlength=world)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    in_splits, out_splits = send.tolist(), recv.tolist()
+
+    def xchg(t):
+        out = t.new_empty(int(sum(out_splits)))
+        dist.all_to_all_single(out, t[order].contiguous(), out_splits, in_splits, group=group)
+        return out
+
+    return col_bounds, xchg(row_global), xchg(col), xchg(val)
+
+
 class ShardedAls:
     """ALS loop over row-block shards.  engine protocol:
         engine.update(which, use_cholesky=False)   -- recompute the LOCAL block of 'A' or 'B'
@@ -52,6 +85,7 @@ class ShardedAls:
         self._stage = {}
 
     def allgather(self, which):
+        import contextlib
         import torch
         import torch.distributed as dist
         eng = self.engine
@@ -59,28 +93,36 @@ class ShardedAls:
         ranges = eng.ranges(which)
         b0, b1 = ranges[self.rank]
         sizes = [e - b for b, e in ranges]
-        eng.pre_collective()
+        # Engines that expose their stream (GpuEngine) get the collective ENQUEUED on it: kernels -> all-gather -> next
+        # half-step are ordered by the stream, the host never waits inside the loop.  Others (the CPU test engine) keep
+        # the pre / post hooks.
+        ordered = eng.ordered_stream() if hasattr(eng, "ordered_stream") else None
+        if ordered is None:
+            eng.pre_collective()
         if self.world == 1 and not dist.is_initialized():
-            eng.post_collective()
+            if ordered is None:
+                eng.post_collective()
             return
         ld = full.shape[1]
-        if len(set(sizes)) == 1 and sizes[0] * self.world == full.shape[0]:
-            # equal blocks tiling the matrix exactly: gather straight into the replica
-            local = full[b0:b1].clone()
-            dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=self.group)
-        else:
-            mx = max(sizes)
-            key = (which, mx, ld)
-            if key not in self._stage:
-                self._stage[key] = (torch.zeros((self.world, mx, ld), dtype=full.dtype, device=full.device),
-                                    torch.zeros((mx, ld), dtype=full.dtype, device=full.device))
-            stage, local = self._stage[key]
-            local[: b1 - b0].copy_(full[b0:b1])
-            dist.all_gather_into_tensor(stage.view(-1), local.view(-1), group=self.group)
-            for r, (rb, re) in enumerate(ranges):
-                if r != self.rank and re > rb:
-                    full[rb:re].copy_(stage[r, : re - rb])
-        eng.post_collective()
+        with (torch.cuda.stream(ordered) if ordered is not None else contextlib.nullcontext()):
+            if len(set(sizes)) == 1 and sizes[0] * self.world == full.shape[0]:
+                # equal blocks tiling the matrix exactly: gather straight into the replica
+                local = full[b0:b1].clone()
+                dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=self.group)
+            else:
+                mx = max(sizes)
+                key = (which, mx, ld)
+                if key not in self._stage:
+                    self._stage[key] = (torch.zeros((self.world, mx, ld), dtype=full.dtype, device=full.device),
+                                        torch.zeros((mx, ld), dtype=full.dtype, device=full.device))
+                stage, local = self._stage[key]
+                local[: b1 - b0].copy_(full[b0:b1])
+                dist.all_gather_into_tensor(stage.view(-1), local.view(-1), group=self.group)
+                for r, (rb, re) in enumerate(ranges):
+                    if r != self.rank and re > rb:
+                        full[rb:re].copy_(stage[r, : re - rb])
+        if ordered is None:
+            eng.post_collective()
 
     def allgather_parts(self, which, parts):
         """All-gather of a block that its engine completes part by part (engine.parts): the collective of part c is
@@ -199,11 +241,42 @@ class GpuEngine:
         ShardedAls(eng, rank, world).allgather("A")
         return eng
 
+    @classmethod
+    def from_device_coo(cls, m, n, k, row_local, col, val, row_ranges, rank, world, device, dtype=np.float32, lam=5.0,
+                        max_cg_steps=3, a_parts=1, group=None):
+        """Implicit model from a COO block that lives in HBM (torch CUDA tensors; BASELINE config 4 is generated shard-wise
+        on the device): this rank's USER block (rows local to row_ranges[rank], global item ids).  Item blocks are cut
+        nnz-balanced, the entries of a rank's items arrive through one all-to-all (shard_coo_by_items), CSR and CSC are
+        built on the device.  No rank ever holds the whole matrix."""
+        import torch
+        from .session import AlsSession
+        r0, r1 = row_ranges[rank]
+        row_local = row_local.to(torch.int32); col = col.to(torch.int32)
+        col_bounds, crow, ccol, cval = shard_coo_by_items(row_local + r0, col, val, n, rank, world, group=group)
+        col_ranges = [(int(col_bounds[r]), int(col_bounds[r + 1])) for r in range(world)]
+        c0, c1 = col_ranges[rank]
+        sess = AlsSession(m, n, k, implicit=True, dtype=dtype, lam=lam, use_cg=True, max_cg_steps=max_cg_steps,
+                          row_range=row_ranges[rank], col_range=col_ranges[rank], device=device)
+        sess.set_X_coo_device("r", row_local, col, val)
+        sess.set_X_coo_device("c", (ccol - c0).to(torch.int32), crow.to(torch.int32), cval)
+        del crow, ccol, cval
+        if a_parts > 1:
+            sess.set_A_parts_resident(a_parts)
+        return cls(sess, row_ranges, col_ranges)
+
     def full(self, which):
         return self._full[which]
 
     def ranges(self, which):
         return self._ranges[which]
+
+    def ordered_stream(self):
+        """The session's own HIP stream as a torch stream: collectives enqueued on it are ordered after the kernels of the
+        half-step before them and before those of the next one without any host synchronisation."""
+        import torch
+        if getattr(self, "_ext", None) is None:
+            self._ext = torch.cuda.ExternalStream(int(self.session.stream()))
+        return self._ext
 
     def update(self, which, use_cholesky=False):
         self.session.update(which, use_cholesky)
@@ -224,10 +297,9 @@ class GpuEngine:
         self.session.stream_wait_part(part, stream.cuda_stream)
 
     def join_comm(self, stream):
-        # the last part's collective was issued after that part's event, so once the communication stream has
-        # drained the session's stream has nothing of this half-step left either
-        stream.synchronize()
-        self.session.sync()
+        # the next half-step (enqueued on the session's stream) must see every part's gathered rows: the session's
+        # stream waits for the communication stream, the host does not
+        self.ordered_stream().wait_stream(stream)
 
     def pre_collective(self):
         # the session launches on its own stream; RCCL runs on torch's

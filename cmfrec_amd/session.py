@@ -118,6 +118,25 @@ class AlsSession:
         _lib.check(self.lib.cmfrec_hip_session_set_X_coo(self.handle, *[_lib.ptr(a) for a in keep],
                                                          C.c_size_t(len(keep[2])), R(subtract), R(alpha)), self.lib, "set_X_coo")
 
+    def set_X_coo_device(self, which, key, other, val, alpha=1.0, subtract=0.0):
+        """One shard from a COO triplet resident in HBM (torch CUDA tensors, int32 / int32 / values): which = 'r' builds
+        the CSR of the local rows (key = row - row_begin, other = global column), 'c' the CSC of the local columns
+        (key = column - col_begin, other = global row).  Multi-GPU set-up path (distributed.py)."""
+        import torch
+        R = _lib.real(self.dtype)
+        tdt = torch.float64 if self.dtype is np.float64 else torch.float32
+        assert key.is_cuda and other.is_cuda and val.is_cuda and key.dtype == torch.int32 and other.dtype == torch.int32 and val.dtype == tdt
+        key, other, val = key.contiguous(), other.contiguous(), val.contiguous()
+        torch.cuda.current_stream().synchronize()      # the tensors were produced on torch's stream, the session has its own
+        _lib.check(self.lib.cmfrec_hip_session_set_X_coo_device(
+            self.handle, C.c_int(ord(which)), C.c_void_p(key.data_ptr()), C.c_void_p(other.data_ptr()), C.c_void_p(val.data_ptr()),
+            C.c_size_t(val.numel()), R(subtract), R(alpha)), self.lib, "set_X_coo_device")
+
+    def set_A_parts_resident(self, nparts):
+        """set_A_parts on the CSR already resident in the session (shards built on the device)."""
+        _lib.check(self.lib.cmfrec_hip_session_set_A_parts(self.handle, None, None, None, C.c_int(int(nparts))), self.lib,
+                   "set_A_parts")
+
     def get_X(self, which):
         """(indptr uint64, indices int32, values, order int32) of the resident CSR ('r') / CSC ('c')."""
         rows = self.m if which == "r" else self.n

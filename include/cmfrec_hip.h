@@ -323,6 +323,12 @@ int cmfrec_hip_session_stream_wait_part(cmfrec_hip_session *s, int part, void *s
 
 int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
                                  size_t nnz, real_t subtract, real_t alpha);
+/* One shard from a COO triplet already resident in HBM (device pointers): which = 'r': CSR of the local rows, d_key = row -
+   row_begin, d_other = global column; 'c': CSC of the local columns, d_key = column - col_begin, d_other = global row.
+   Multi-GPU set-up path (the triplets come out of an all-to-all between the ranks); no reference counterpart: the
+   reference converts on the host (src/helpers.c:1375-1491). */
+int cmfrec_hip_session_set_X_coo_device(cmfrec_hip_session *s, int which, const int_t *d_key, const int_t *d_other,
+                                        const real_t *d_val, size_t nnz, real_t subtract, real_t alpha);
 /* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
  * _onesided (src/common.c:4410-4909, 4265-4289; call sites src/collective.c:8166-8220): written to the
  * session's bias vectors and the bias columns of A / B.  Call after set_X* and set_factors. */

@@ -166,3 +166,75 @@ def test_two_rank_partwise_allgather(tmp_path, oracles):
     assert np.array_equal(r0["A"], r1["A"]) and np.array_equal(r0["B"], r1["B"])
     assert np.array_equal(r0["A"], A) and np.array_equal(r0["B"], B)
     assert int(r0["joined"]) == 3 and int(r1["joined"]) == 3          # the part-wise path was really taken, once per iteration
+
+
+def _worker_exchange(rank, world, port, out_dir, m=300):
+    """Set-up path of bench.py --gpus N: every rank holds ONLY the entries of its user block; nnz-balanced item blocks
+    come from the all-reduced counts and the CSC shard from the all-to-all (shard_coo_by_items)."""
+    from conftest import make_coo
+    from oracle.bindings import Oracle
+    from cmfrec_amd.distributed import ShardedAls, shard_coo_by_items, balanced_boundaries
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = Oracle(np.float64)
+    n, k = 200, 8
+    row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
+    m_blk = m // world
+    r0, r1 = rank * m_blk, (rank + 1) * m_blk
+    mine = (row >= r0) & (row < r1)                    # this rank's block, in the global COO order
+    lrow, lcol, lval = row[mine], col[mine], val[mine]
+    cb, crow, ccol, cval = shard_coo_by_items(torch.from_numpy(lrow.astype(np.int64)), torch.from_numpy(lcol.astype(np.int64)),
+                                              torch.from_numpy(lval), n, rank, world)
+    # the boundaries are the nnz-balanced ones of the whole matrix
+    assert cb == balanced_boundaries(np.bincount(col, minlength=n), world)
+    c0, c1 = cb[rank], cb[rank + 1]
+    crow, ccol, cval = crow.numpy(), ccol.numpy(), cval.numpy()
+    assert ((ccol >= c0) & (ccol < c1)).all()
+    # exactly the entries of my item block, ordered by source rank and, inside a source, in COO order
+    want = (col >= c0) & (col < c1)
+    src = row[want] // m_blk
+    order = np.argsort(src, kind="stable")
+    assert np.array_equal(crow, row[want][order]) and np.array_equal(ccol, col[want][order]) and np.array_equal(cval, val[want][order])
+    # local CSR / CSC shards from the local triplets only
+    csr_l, _ = O.coo_to_csr_and_csc((lrow - r0).astype(np.int32), lcol.astype(np.int32), lval, m_blk, n)
+    _, csc_l = O.coo_to_csr_and_csc(crow.astype(np.int32), (ccol - c0).astype(np.int32), cval, m, c1 - c0)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((m, k)) * 0.01
+    B = np.zeros((n, k))
+    rr = [(i * m_blk, (i + 1) * m_blk) for i in range(world)]
+    cr = [(cb[i], cb[i + 1]) for i in range(world)]
+
+    class LocalShardEngine(OracleEngine):
+        def __init__(self):
+            self.O, self.rank, self.lam = O, rank, 4.0
+            self.A, self.B = A, B
+            self.tA, self.tB = torch.from_numpy(A), torch.from_numpy(B)
+            self._ranges = {"A": rr, "B": cr}
+            self.csr, self.csc = csr_l, csc_l
+
+    als = ShardedAls(LocalShardEngine(), rank, world)
+    for _ in range(3):
+        als.iteration()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B)
+    dist.destroy_process_group()
+
+
+def test_two_rank_alltoall_setup(tmp_path, oracles):
+    """No rank ever sees the whole matrix, item blocks are nnz-balanced: the three iterations still equal the
+    single-process fit.  (Sums inside an item's column follow the exchanged order = the global COO order here,
+    because user blocks are contiguous and arrive in rank order.)"""
+    from conftest import make_coo
+    world, m = 2, 300
+    mp.spawn(_worker_exchange, args=(world, _free_port(), str(tmp_path), m), nprocs=world, join=True)
+    O = oracles[np.float64]
+    n, k = 200, 8
+    row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
+    A = np.random.default_rng(3).standard_normal((m, k)) * 0.01
+    B = np.zeros((n, k))
+    O.fit_implicit_als(A, B, row, col, val, lam=4.0, niter=3)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    assert np.array_equal(r0["A"], r1["A"]) and np.array_equal(r0["B"], r1["B"])
+    # the entries of a column arrive grouped by source block instead of interleaved as in the global COO: the same sums
+    # in another order
+    assert np.abs(r0["A"] - A).max() < 1e-12 and np.abs(r0["B"] - B).max() < 1e-12

@@ -128,3 +128,41 @@ def test_c4_width_implicit_single(oracles, mode):
     ops.optimizeA_implicit(Ah, B, csr, 4.0, **kw)
     O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, **kw)
     assert rel_err(Ah, Ao) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,k,p,ku", [(np.float32, 256, 512, 0), (np.float32, 100, 40, 3), (np.float64, 128, 64, 0),
+                                          (np.float64, 72, 24, 2)])
+@pytest.mark.parametrize("scale_lam", [True, False])
+def test_lowrank_rows(oracles, dtype, k, p, ku, scale_lam, monkeypatch):
+    """Rows with few entries against many unknowns take the low-rank path (lowrank_kernels.hpp: the shared matrix
+    w C^T C diagonalised once, an s x s system per row); CMFREC_HIP_LOWRANK=1 forces it on this small problem.  Row r
+    has r entries (0 .. 159): every block count of the s x s kernel, the hand-over to the full factorisation, empty
+    rows.  Same system as the reference's (collective.c:1534-1846), different arithmetic: tolerance-based."""
+    from cmfrec_amd import ops
+    monkeypatch.setenv("CMFREC_HIP_LOWRANK", "1")
+    O = oracles[dtype]
+    m, n = 160, 3000
+    rng = np.random.default_rng(k + p)
+    rows, cols = [], []
+    for r in range(m):
+        rows.append(np.full(r, r, np.int32)); cols.append(rng.choice(n, r, replace=False).astype(np.int32))
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
+    val = (0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    # one k_main factor stands in for the bias column: the last unknown has its own lambda and lies outside the block that
+    # the side information couples (what fit() launches with a user bias)
+    kA = ku + k + 1
+    Bm = (rng.standard_normal((n, k + 1)) * 0.3).astype(dtype); Bm[:, k] = 1
+    Cm = (rng.standard_normal((p, ku + k)) * (0.3 / np.sqrt(p / 12.0))).astype(dtype)
+    U = rng.standard_normal((m, p)).astype(dtype)
+    A0 = rng.standard_normal((m, kA)).astype(dtype)
+    bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+    Ah, A64 = A0.copy(), A0.astype(np.float64)
+    kw = dict(w_user=0.5, lam_last=0.1, k=k, k_user=ku, k_main=1, scale_lam=scale_lam)
+    ops.optimizeA_collective(Ah, Bm, Cm, csr, U, 0.05, bias_sub=bias, **kw)
+    csr_sub = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(np.float64))
+    oracles[np.float64].optimizeA_collective_chol(A64, Bm.astype(np.float64), Cm.astype(np.float64), csr_sub, U.astype(np.float64),
+                                                  0.05, nthreads=4, **kw)
+    tol = 1e-9 if dtype is np.float64 else 2e-4
+    assert rel_err(Ah, A64) < tol

@@ -50,3 +50,44 @@ def test_one_rank_engine_matches_session(parts):
         dist.destroy_process_group()
     # the parts change which rows share a launch, not the arithmetic of a row
     assert np.array_equal(B, Br) and np.array_equal(A, Ar)
+
+
+@pytest.mark.parametrize("parts", [1, 4])
+def test_one_rank_device_coo_engine(parts):
+    """The set-up path of `bench.py --gpus N` (BASELINE config 4): COO generated on the device, item blocks from the
+    all-reduced counts, CSR / CSC built from device triplets, collectives enqueued on the session's stream (no host
+    synchronisation in the loop), A-step in parts.  One rank through RCCL against a plain session on the same data."""
+    import torch
+    import torch.distributed as dist
+    from cmfrec_amd.session import AlsSession
+    from cmfrec_amd.distributed import GpuEngine, ShardedAls
+    m, n, k, nnz = 24000, 7000, 64, 700000
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    row, col, val = bench.synth_block_torch(m, n, nnz, seed=41, item_seed=4, device=dev)
+    hrow, hcol, hval = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    assert len(np.unique(hrow.astype(np.int64) * n + hcol)) == nnz and hval.min() >= 1
+    A0 = (np.random.default_rng(1).random((m, k)) * 2.0 ** -7).astype(np.float32)
+    ref = AlsSession(m, n, k, implicit=True, dtype=np.float32, lam=5.0, use_cg=True, max_cg_steps=3)
+    ref.set_X_coo(hrow, hcol, hval)
+    ref.set_factors(A=A0, B=np.zeros((n, k), np.float32))
+    for _ in range(3):
+        ref.update("B"); ref.update("A")
+    f = ref.get_factors(); Ar, Br = f["A"], f["B"]
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        eng = GpuEngine.from_device_coo(m, n, k, row, col, val, [(0, m)], 0, 1, 0, dtype=np.float32, lam=5.0, max_cg_steps=3,
+                                        a_parts=parts)
+        assert len(eng.parts("A")) == (parts if parts > 1 else 0)
+        eng.full("A").copy_(torch.as_tensor(A0, device=dev)); eng.full("B").zero_()
+        torch.cuda.synchronize()
+        als = ShardedAls(eng, 0, 1)
+        for _ in range(3):
+            als.iteration()
+        eng.session.sync(); torch.cuda.synchronize()
+        f = eng.session.get_factors(); A, B = f["A"], f["B"]
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(B, Br) and np.array_equal(A, Ar)
