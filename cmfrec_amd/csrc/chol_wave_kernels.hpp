@@ -241,9 +241,11 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
             const int s0 = hv ? SL.row_off[rix] : SL.n_slices + (rix - SL.n_heavy), s1 = hv ? SL.row_off[rix + 1] : s0 + 1;
             for (int sl = s0; sl < s1; sl++) {
                 const T *pp = SL.part + (size_t)(sl - SL.part_base) * PART;
-                static_for<0, (NT + 3) / 4>([&](auto qc) {
+                // LB tiles of loads in flight at a time (a partial is NT x 2 KB from HBM: every batch is a round trip)
+                constexpr int LB = (sizeof(T) == 8) ? 9 : 12;
+                static_for<0, (NT + LB - 1) / LB>([&](auto qc) {
                     constexpr int q4 = decltype(qc)::value;
-                    static_for<4 * q4, (4 * q4 + 4 < NT ? 4 * q4 + 4 : NT)>([&](auto tc) {
+                    static_for<LB * q4, (LB * q4 + LB < NT ? LB * q4 + LB : NT)>([&](auto tc) {
                         constexpr int t = decltype(tc)::value;
 #pragma unroll
                         for (int r = 0; r < 4; r++) acc[t][r] += pp[t * 256 + r * 64 + lane];

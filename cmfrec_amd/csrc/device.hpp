@@ -259,6 +259,19 @@ struct DeviceInfo {
     // third stream for the eigen-decomposition of the low-rank path (one workgroup, overlaps the row kernels of both other streams)
     hipStream_t eig_stream_ = nullptr;
     hipEvent_t eig_ev = nullptr, eig_fork = nullptr;
+    rocblas_handle blas_eig = nullptr;      // own handle (own workspace) for library calls on the eigen-decomposition's stream
+    rocblas_handle ensure_blas_eig()
+    {
+        if (!blas_eig) {
+            if (rocblas_create_handle(&blas_eig) != rocblas_status_success) {
+                blas_eig = nullptr;
+                g_last_error = "cmfrec_hip: rocblas_create_handle failed";
+                throw HipError{1};
+            }
+        }
+        (void)rocblas_set_stream(blas_eig, eig_stream());
+        return blas_eig;
+    }
     hipStream_t eig_stream()
     {
         if (!eig_stream_) HIP_CHECK(hipStreamCreateWithFlags(&eig_stream_, hipStreamNonBlocking));
@@ -280,6 +293,7 @@ struct DeviceInfo {
     ~DeviceInfo()
     {
         if (blas) (void)rocblas_destroy_handle(blas);
+        if (blas_eig) (void)rocblas_destroy_handle(blas_eig);
         if (eig_ev) (void)hipEventDestroy(eig_ev);
         if (eig_fork) (void)hipEventDestroy(eig_fork);
         if (eig_stream_) (void)hipStreamDestroy(eig_stream_);

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <vector>
+#include <hip/hip_runtime.h>
 
 #include "../../include/cmfrec_hip.h"
 #include "rng_host.hpp"
@@ -132,6 +133,155 @@ int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool
         if ((rc = cmfrec_hip_session_after_gather(s, 'A'))) return rc;
         if (verbose) { cmfrec_hip_session_sync(s); printf(" done\n\tCompleted ALS iteration %2d\n\n", it + 1); fflush(stdout); }
     }
+    return 0;
+}
+
+// ---- several GPUs of one node behind the unchanged C signature ----------------------------------
+// CMFREC_HIP_DEVICES="0,1,2,3" (HIP device ordinals, comma separated; an ordinal may repeat, which shards one device --
+// that is how the path is tested on a single-GPU box).  One entry: that device instead of the current one.  Several:
+// users are cut into equal contiguous blocks and items into nnz-balanced ones, every device owns one block of each, holds
+// full replicas of A and B, updates its own rows, and the updated rows travel to the peers over xGMI
+// (hipMemcpyPeerAsync, ordered by events; no host synchronisation inside the loop) -- the all-gather of distributed.py
+// without torch.  Rows are independent given the opposing matrix and every device computes B^T B from identical
+// replicas, so the factors are bit-for-bit those of the single-device fit.
+std::vector<int> devices_from_env()
+{
+    std::vector<int> out;
+    const char *e = getenv("CMFREC_HIP_DEVICES");
+    if (e == nullptr) return out;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return out;
+    const char *q = e;
+    while (*q) {
+        char *end = nullptr;
+        const long v = strtol(q, &end, 10);
+        if (end == q) break;
+        if (v >= 0 && v < count) out.push_back((int)v);
+        q = end;
+        while (*q == ',' || *q == ' ') q++;
+    }
+    return out;
+}
+
+struct MultiDev {
+    std::vector<cmfrec_hip_session *> sess;
+    std::vector<int> dev;
+    std::vector<int> rb, cb;               // block boundaries of users / items (D + 1 each)
+    std::vector<hipEvent_t> ev;            // per device: "my block has reached every peer"
+    ~MultiDev()
+    {
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto s : sess) if (s) cmfrec_hip_session_destroy(s);
+    }
+    // block d of matrix `which` (updated on device d) is copied into every other replica; every stream then waits for all blocks
+    int exchange(int which)
+    {
+        const int D = (int)sess.size();
+        const std::vector<int> &bb = (which == 'A') ? rb : cb;
+        for (int d = 0; d < D; d++) {
+            size_t rows = 0, ld = 0;
+            real_t *src = (real_t *)cmfrec_hip_session_device_ptr(sess[d], which, &rows, &ld);
+            hipStream_t st = (hipStream_t)cmfrec_hip_session_stream(sess[d]);
+            if (hipSetDevice(dev[d]) != hipSuccess) return 4;
+            const size_t off = (size_t)bb[d] * ld, bytes = (size_t)(bb[d + 1] - bb[d]) * ld * sizeof(real_t);
+            for (int e = 0; e < D && bytes; e++) {
+                if (e == d) continue;
+                size_t r2 = 0, l2 = 0;
+                real_t *dst = (real_t *)cmfrec_hip_session_device_ptr(sess[e], which, &r2, &l2);
+                if (hipMemcpyPeerAsync(dst + off, dev[e], src + off, dev[d], bytes, st) != hipSuccess) return 4;
+            }
+            if (hipEventRecord(ev[d], st) != hipSuccess) return 4;
+        }
+        for (int e = 0; e < D; e++) {
+            hipStream_t st = (hipStream_t)cmfrec_hip_session_stream(sess[e]);
+            if (hipSetDevice(dev[e]) != hipSuccess) return 4;
+            for (int d = 0; d < D; d++)
+                if (d != e && hipStreamWaitEvent(st, ev[d], 0) != hipSuccess) return 4;
+        }
+        return 0;
+    }
+};
+
+// plain implicit model (no side information) on the devices of `devs`; same results as the single-device driver
+int fit_implicit_multi(const std::vector<int> &devs, real_t *A, real_t *B, int_t m, int_t n, int_t k_tot, const int_t *ixA, const int_t *ixB,
+                       const real_t *X, size_t nnz, cmfrec_hip_model mdl, const real_t *lam6, real_t alpha, int niter, bool finalize_chol,
+                       bool verbose, cmfrec_hip_session **first_out, MultiDev &md)
+{
+    const int D = (int)devs.size();
+    md.dev = devs;
+    // users: equal contiguous blocks; items: nnz-balanced contiguous blocks
+    md.rb.assign(D + 1, 0); md.cb.assign(D + 1, 0);
+    const int step = (m + D - 1) / D;
+    for (int d = 0; d <= D; d++) md.rb[d] = std::min(d * step, (int)m);
+    {
+        std::vector<size_t> cnt((size_t)n + 1, 0);
+        for (size_t e = 0; e < nnz; e++) cnt[(size_t)ixB[e] + 1]++;
+        for (int j = 0; j < n; j++) cnt[j + 1] += cnt[j];
+        int j = 0;
+        for (int d = 1; d < D; d++) {
+            const double target = (double)nnz * d / D;
+            while (j < n && (double)cnt[j] < target) j++;
+            md.cb[d] = std::max(md.cb[d - 1], j);
+        }
+        md.cb[D] = n;
+    }
+    for (int d = 0; d < D; d++)
+        for (int e = 0; e < D; e++)
+            if (devs[d] != devs[e] && hipSetDevice(devs[d]) == hipSuccess) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devs[d], devs[e]) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(devs[e], 0);
+                    if (pe != hipSuccess) (void)hipGetLastError();            // already enabled
+                }
+            }
+    md.sess.assign(D, nullptr); md.ev.assign(D, nullptr);
+    std::vector<int_t> key, oth; std::vector<real_t> val;
+    for (int d = 0; d < D; d++) {
+        cmfrec_hip_model md_d = mdl;
+        md_d.row_begin = md.rb[d]; md_d.row_end = md.rb[d + 1]; md_d.col_begin = md.cb[d]; md_d.col_end = md.cb[d + 1];
+        md.sess[d] = cmfrec_hip_session_create(&md_d, devs[d]);
+        if (!md.sess[d]) { const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
+        if (hipEventCreateWithFlags(&md.ev[d], hipEventDisableTiming) != hipSuccess) return 4;
+        // the block's entries in COO order (the order the stable device sort keeps inside a row), staged through device buffers
+        for (int side = 0; side < 2; side++) {
+            const int lo = side == 0 ? md.rb[d] : md.cb[d], hi = side == 0 ? md.rb[d + 1] : md.cb[d + 1];
+            const int_t *kk = side == 0 ? ixA : ixB, *oo = side == 0 ? ixB : ixA;
+            key.clear(); oth.clear(); val.clear();
+            for (size_t e = 0; e < nnz; e++)
+                if (kk[e] >= lo && kk[e] < hi) { key.push_back(kk[e] - lo); oth.push_back(oo[e]); val.push_back(X[e]); }
+            int_t *dk = nullptr, *d_o = nullptr; real_t *dv = nullptr;
+            const size_t cntE = key.size();
+            if (hipSetDevice(devs[d]) != hipSuccess) return 4;
+            if (hipMalloc((void **)&dk, std::max<size_t>(cntE, 1) * sizeof(int_t)) != hipSuccess) return 1;
+            if (hipMalloc((void **)&d_o, std::max<size_t>(cntE, 1) * sizeof(int_t)) != hipSuccess) { (void)hipFree(dk); return 1; }
+            if (hipMalloc((void **)&dv, std::max<size_t>(cntE, 1) * sizeof(real_t)) != hipSuccess) { (void)hipFree(dk); (void)hipFree(d_o); return 1; }
+            (void)hipMemcpy(dk, key.data(), cntE * sizeof(int_t), hipMemcpyHostToDevice);
+            (void)hipMemcpy(d_o, oth.data(), cntE * sizeof(int_t), hipMemcpyHostToDevice);
+            (void)hipMemcpy(dv, val.data(), cntE * sizeof(real_t), hipMemcpyHostToDevice);
+            const int rc = cmfrec_hip_session_set_X_coo_device(md.sess[d], side == 0 ? 'r' : 'c', dk, d_o, dv, cntE, (real_t)0, alpha);
+            (void)hipFree(dk); (void)hipFree(d_o); (void)hipFree(dv);
+            if (rc) return rc;
+        }
+        int rc = cmfrec_hip_session_set_lam_unique(md.sess[d], lam6, nullptr, 100);
+        if (!rc) rc = cmfrec_hip_session_set_factors(md.sess[d], A, B, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    if (verbose) { printf("Starting ALS optimization routine (%d device shards)\n\n", D); fflush(stdout); }
+    for (int it = 0; it < niter; it++) {
+        if (g_stop) return 3;
+        const int chol = (finalize_chol && mdl.use_cg && it == niter - 1) ? 1 : 0;
+        for (int pass = 0; pass < 2; pass++) {                                // B then A (collective.c:9924-10022)
+            const int which = pass == 0 ? 'B' : 'A';
+            for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_update(md.sess[d], which, chol); if (rc) return rc; }
+            const int rc = md.exchange(which);
+            if (rc) return rc;
+            if (g_stop) return 3;
+        }
+        if (verbose) { for (int d = 0; d < D; d++) cmfrec_hip_session_sync(md.sess[d]); printf("\tCompleted ALS iteration %2d\n\n", it + 1); fflush(stdout); }
+    }
+    for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sync(md.sess[d]); if (rc) return rc; }
+    *first_out = md.sess[0];
+    (void)k_tot;
     return 0;
 }
 
@@ -269,7 +419,32 @@ int_t fit_collective_implicit_als(
     mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.lam = lam;
     mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
-    cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
+    // device selection without touching the signature: CMFREC_HIP_DEVICES (one ordinal: that device; several: row-block shards)
+    const std::vector<int> devs = devices_from_env();
+    const bool multi_ok = devs.size() > 1 && p == 0 && q == 0 && !nonneg && l1_lam == 0 && !l1_lam_unique && m >= (int_t)devs.size() &&
+                          n >= (int_t)devs.size();
+    if (devs.size() > 1 && !multi_ok && verbose)
+        printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (side information / constraints) runs on the first\n",
+               (int)devs.size());
+    if (multi_ok) {
+        MultiDev md;
+        cmfrec_hip_session *s0 = nullptr;
+        int rc_loop = fit_implicit_multi(devs, A, B, m_max, n_max, k_totA, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, mdl, lam6, alpha,
+                                         niter, finalize_chol, verbose, &s0, md);
+        if ((rc_loop == 0 || rc_loop == 3) && s0 == nullptr && !md.sess.empty()) s0 = md.sess[0];
+        if ((rc_loop == 0 || rc_loop == 3) && s0) {
+            int rc2 = cmfrec_hip_session_get_factors(s0, A, B, nullptr, nullptr, nullptr, nullptr);
+            if (rc2) rc_loop = rc2;
+        }
+        if ((rc_loop == 0 || rc_loop == 3) && s0 && precompute_for_predictions) {
+            const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
+            int rc2 = cmfrec_hip_session_precompute(s0, last_chol, 0, precomputedBtB, nullptr, nullptr, nullptr, nullptr, nullptr);
+            if (rc2) rc_loop = rc2;
+        }
+        if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
+        return rc_loop;
+    }
+    cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, devs.empty() ? -1 : devs[0]);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("session create");
     // X := alpha * X and COO -> CSR + CSC happen on the device (coo_device.hpp), same entry order as helpers.c:1375-1491
@@ -490,7 +665,8 @@ int_t fit_collective_explicit_als(
     mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i;
     mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
-    cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, -1);
+    const std::vector<int> devs = devices_from_env();                  // CMFREC_HIP_DEVICES: the first listed device (row-block shards: implicit model)
+    cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, devs.empty() ? -1 : devs[0]);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("start values + session");
     // X - mean, COO -> CSR + CSC and the bias start values are computed on the device (coo_device.hpp)

@@ -9,6 +9,7 @@
 #include "coo_device.hpp"
 #include "chol_wave_kernels.hpp"
 #include "lowrank_kernels.hpp"
+#include <dlfcn.h>
 #include <functional>
 #include <memory>
 #include <new>
@@ -366,9 +367,53 @@ static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real
 // Low-rank row updates (lowrank_kernels.hpp): eigenvectors / values of w C^T C, rotated C and opposing factors, rotated
 // right-hand sides and solutions.
 struct LowRankScratch {
-    DevBuf<double> W, V;
+    DevBuf<double> W, V, D, E;
+    DevBuf<int> info;
     DevBuf<real_t> Q, Qt, Lam, Ct, Bt, R, T;
 };
+
+// The symmetric eigen-decomposition of the k x k matrix w C^T C (once per half-step of the low-rank path) is a plain dense
+// library operation like the side-information GEMMs: rocSOLVER's divide-and-conquer syevd when the library can be loaded
+// (6 ms at k = 256 on this part), the built-in one-workgroup Jacobi kernel of lowrank_kernels.hpp otherwise (91 ms; also
+// CMFREC_HIP_EIG=jacobi, the on-device cross-check).  Both run on the GPU; the library is bound at run time so that the
+// shared objects do not depend on it.
+struct RocSolverApi {
+    typedef rocblas_status (*dsyevd_t)(rocblas_handle, int /*rocblas_evect*/, rocblas_fill, int, double *, int, double *, double *, int *);
+    dsyevd_t dsyevd = nullptr;
+    RocSolverApi()
+    {
+        const char *e = getenv("CMFREC_HIP_EIG");
+        if (e != nullptr && strcmp(e, "jacobi") == 0) return;
+        void *lib = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_LOCAL);
+        if (lib) dsyevd = (dsyevd_t)dlsym(lib, "rocsolver_dsyevd");
+    }
+};
+static const RocSolverApi &rocsolver_api()
+{
+    static const RocSolverApi api;
+    return api;
+}
+
+// W (double, n x n) := A ;  after syevd (column-major eigenvectors in W, eigenvalues in D): Q[i][c] = W[c n + i], Qt = its transpose
+template <typename T>
+__global__ void eig_pack_kernel(const T *__restrict__ A, double *__restrict__ W, int n)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n) W[e] = (double)A[e];
+}
+template <typename T>
+__global__ void eig_unpack_kernel(const double *__restrict__ W, const double *__restrict__ D, int n, T *__restrict__ Q, T *__restrict__ Qt,
+                                  T *__restrict__ lam)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * n) {
+        const int c = e / n, i = e % n;
+        Qt[(size_t)c * n + i] = (T)W[e];
+        Q[(size_t)i * n + c] = (T)W[e];
+    }
+    if (e < n) lam[e] = (T)fmax(D[e], 0.0);
+}
 
 // Collective Cholesky half-step (mode CHOL_COLLECTIVE, dense side information on every row of the block) with the rows of
 // few entries solved by the low-rank update of a diagonalised shared matrix instead of a k_t^3 / 3 factorisation per row
@@ -412,8 +457,21 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
         if (!d.eig_fork) HIP_CHECK(hipEventCreateWithFlags(&d.eig_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(d.eig_fork, st));
         HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), d.eig_fork, 0));
-        hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), c.Minit, kc, S.W.ptr, S.V.ptr, S.Q.ptr, S.Qt.ptr,
-                           (size_t)kc, S.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
+        const RocSolverApi &rs = rocsolver_api();
+        bool done = false;
+        if (rs.dsyevd != nullptr) {
+            S.D.alloc_at_least((size_t)kc); S.E.alloc_at_least((size_t)kc); S.info.alloc_at_least(1);
+            hipLaunchKernelGGL(eig_pack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), c.Minit, S.W.ptr, kc);
+            rocblas_handle he = d.ensure_blas_eig();
+            done = rs.dsyevd(he, 211 /* rocblas_evect_original (rocsolver-extra-types.h) */, rocblas_fill_upper, kc, S.W.ptr, kc, S.D.ptr, S.E.ptr, S.info.ptr) ==
+                   rocblas_status_success;
+            if (done)
+                hipLaunchKernelGGL(eig_unpack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), S.W.ptr, S.D.ptr, kc, S.Q.ptr,
+                                   S.Qt.ptr, S.Lam.ptr);
+        }
+        if (!done)
+            hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), c.Minit, kc, S.W.ptr, S.V.ptr, S.Q.ptr, S.Qt.ptr,
+                               (size_t)kc, S.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(d.eig_ev, d.eig_stream()));
         c.row_limit = n_full;
@@ -521,6 +579,11 @@ struct cmfrec_hip_session {
     // low-rank row updates (lowrank_kernels.hpp): eigenvectors / values of w C^T C, rotated C and opposing factors,
     // rotated right-hand sides and solutions
     LowRankScratch lr;
+    // row-block shards of the explicit / collective model (distributed.py): U / I hold only the rows of this
+    // rank's block, and the C / D update is split into partial sums over the local rows (side_part: [kc x kc | p x kc]),
+    // an all-reduce by the caller, and the identical small solve on every rank
+    bool side_local = false;
+    DevBuf<real_t> side_part;
     GramWorkspace gws;
     std::vector<EventPair> evA, evB;     // whole half-steps
     BinTimers binA, binB;                // row-update kernel launches per nnz bin
@@ -896,6 +959,83 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
     });
 }
 
+// Row-block shards: U holds the rows [row_begin, min(row_end, m_u)) only, I the rows [col_begin, min(col_end, n_i)).
+int cmfrec_hip_session_set_sideinfo_local(cmfrec_hip_session *s, const real_t *U_local, const real_t *I_local)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        const int ru = std::max(0, std::min(m.row_end, m.m_u) - m.row_begin), ri = std::max(0, std::min(m.col_end, m.n_i) - m.col_begin);
+        if (U_local && m.p > 0 && ru > 0) s->U.upload(U_local, (size_t)ru * m.p, s->dev.stream);
+        if (I_local && m.q > 0 && ri > 0) s->II.upload(I_local, (size_t)ri * m.q, s->dev.stream);
+        s->side_local = true;
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
+// C / D update of a row-block shard, first half (optimizeA Case 1, common.c:2793-2991, split over the ranks): the partial
+// sums over the LOCAL rows of the factor matrix F (A for 'C', B for 'D') that carry side information,
+//   side_part = [ F_loc^T F_loc  (kc x kc) | U_loc^T F_loc  (p x kc) ],
+// for the caller to all-reduce (cmfrec_hip_session_device_ptr(s, 'P')).  Dense side information only.
+int cmfrec_hip_session_sideinfo_partial(cmfrec_hip_session *s, int which)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        const DeviceInfo &dev = s->dev;
+        const bool isC = (which == 'C');
+        const int p = isC ? m.p : m.q;
+        if ((which != 'C' && which != 'D') || p <= 0 || (isC ? s->sparseU : s->sparseI)) {
+            g_last_error = "cmfrec_hip_session_sideinfo_partial: dense side information on that side is required";
+            return 2;
+        }
+        const int rows_u = isC ? m.m_u : m.n_i, begin = isC ? m.row_begin : m.col_begin, end = isC ? m.row_end : m.col_end;
+        const int local = std::max(0, std::min(end, rows_u) - begin);
+        const int kc = (isC ? m.k_user : m.k_item) + m.k;
+        const real_t *F = (isC ? s->A.ptr : s->B.ptr) + (size_t)begin * (isC ? s->ldA : s->ldB);
+        const size_t ldF = isC ? s->ldA : s->ldB;
+        const real_t *Um = (isC ? s->U.ptr : s->II.ptr) + (s->side_local ? (size_t)0 : (size_t)begin * p);
+        s->side_part.alloc_at_least((size_t)kc * kc + (size_t)p * kc);
+        HIP_CHECK(hipMemsetAsync(s->side_part.ptr, 0, ((size_t)kc * kc + (size_t)p * kc) * sizeof(real_t), dev.stream));
+        if (local > 0) {
+            launch_gram(dev, s->gws, F, ldF, local, kc, s->side_part.ptr, (real_t)1, (real_t)0);
+            launch_gemm<true>(dev, p, kc, local, (real_t)1, Um, (size_t)p, F, ldF, s->side_part.ptr + (size_t)kc * kc, (size_t)kc);
+        }
+        return 0;
+    });
+}
+
+// ... second half, on the all-reduced sums: C := (U^T F) (F^T F + lam I)^-1, the same on every rank
+int cmfrec_hip_session_sideinfo_finish(cmfrec_hip_session *s, int which)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        const cmfrec_hip_model &m = s->mdl;
+        const DeviceInfo &dev = s->dev;
+        const bool isC = (which == 'C');
+        const int p = isC ? m.p : m.q;
+        if ((which != 'C' && which != 'D') || p <= 0) return 2;
+        const int rows_u = isC ? m.m_u : m.n_i;
+        const int kc = (isC ? m.k_user : m.k_item) + m.k;
+        real_t *Cm = isC ? s->C.ptr : s->D.ptr;
+        const real_t w = isC ? m.w_user : m.w_item;
+        const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
+        const real_t lam = s->lam6[isC ? 4 : 5] / w;                                               // collective.c:8367, :8418
+        const real_t diag = scale_lam ? lam * (real_t)rows_u : lam;                                // common.c:2832
+        HIP_CHECK(hipMemcpyAsync(s->gram.ptr, s->side_part.ptr, (size_t)kc * kc * sizeof(real_t), hipMemcpyDeviceToDevice, dev.stream));
+        hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3((kc + 255) / 256), dim3(256), 0, dev.stream, s->gram.ptr, kc, 0, kc, diag);
+        HIP_CHECK(hipMemcpyAsync(Cm, s->side_part.ptr + (size_t)kc * kc, (size_t)p * kc * sizeof(real_t), hipMemcpyDeviceToDevice, dev.stream));
+        struct Scope {                                            // nonneg_C / nonneg_D, L1 on C / D as in cmfrec_hip_session_update
+            const DeviceInfo &d;
+            Scope(const DeviceInfo &d_, bool nn, int steps, real_t l1, real_t sc) : d(d_) { d.nonneg_now = nn; d.max_cd_steps = steps; d.l1_now = l1; d.l1_last_now = l1; d.l1_scale = sc; }
+            ~Scope() { d.nonneg_now = false; d.l1_now = 0; d.l1_last_now = 0; d.l1_scale = 1; }
+        } scope(dev, isC ? s->nonneg_C : s->nonneg_D, s->max_cd_steps, s->l16[isC ? 4 : 5] / w, scale_lam ? (real_t)rows_u : (real_t)1);
+        CholCall c{Cm, (size_t)kc, nullptr, 0, kc, 0, nullptr, s->gram.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+        return launch_chol(dev, c, nullptr, p);                                                    // common.c:2872-2875
+    });
+}
+
 int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps)
 {
     s->nonneg = nonneg != 0; s->nonneg_C = nonneg_C != 0; s->nonneg_D = nonneg_D != 0;
@@ -1055,7 +1195,7 @@ static int solve_sideinfo_only_rows(cmfrec_hip_session *s, bool isA, bool chol, 
     if (chol) HIP_CHECK(hipMemsetAsync(rows, 0, (size_t)count * ld_self * sizeof(real_t), dev.stream));
     launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->betbe.ptr, (real_t)1,
                 (s->lam6[isA ? 2 : 3] / w) * (real_t)(scale_lam ? p_self : 1));                                   // common.c:2824-2832
-    launch_gemm<false>(dev, count, kc, p_self, (real_t)1, Um + (size_t)(begin + first) * p_self, (size_t)p_self, Cm,
+    launch_gemm<false>(dev, count, kc, p_self, (real_t)1, Um + (size_t)((s->side_local ? 0 : begin) + first) * p_self, (size_t)p_self, Cm,
                        (size_t)kc, rows, ld_self);                                                 // common.c:2847-2855
     CholCall c{rows, ld_self, nullptr, 0, kc, 0, nullptr, s->betbe.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
     return launch_chol(dev, c, nullptr, count);                                                    // common.c:2872-2875
@@ -1155,7 +1295,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
         real_t *uc = isA ? s->ucA.ptr : s->ucB.ptr;
         launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, (real_t)1, (real_t)0);   // C^T C, unweighted
-        launch_gemm<false>(dev, local_u, kc, p_self, (real_t)1, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
+        launch_gemm<false>(dev, local_u, kc, p_self, (real_t)1, Um + (size_t)(s->side_local ? 0 : begin) * p_self, (size_t)p_self, Cm, (size_t)kc,
                            uc, (size_t)kc);                                                        // U C
         const real_t *bias_sub_cg = nullptr;
         int kx = kk;
@@ -1201,7 +1341,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);            // :6138-6160
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :6018-6019
         const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
-        launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
+        launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)(s->side_local ? 0 : begin) * p_self, (size_t)p_self, Cm, (size_t)kc,
                            self_blk, ld_self);                                                      // :6163-6168
         CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, nullptr, s->ctc.ptr, kc, local_u,
                    p_self, lam_self, lam_last_self, false, false, false, CHOL_COLLECTIVE_IMPLICIT, s->betbe.ptr};
@@ -1276,7 +1416,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);            // :5658-5668
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822
         const int local_u = std::max(0, std::min(rows_u - begin, X.nrows));
-        launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)begin * p_self, (size_t)p_self, Cm, (size_t)kc,
+        launch_gemm<false>(dev, local_u, kc, p_self, w, Um + (size_t)(s->side_local ? 0 : begin) * p_self, (size_t)p_self, Cm, (size_t)kc,
                            self_blk, ld_self);                                                      // :5768-5773
         const int local_x = std::max(0, std::min(rows_x_self - begin, X.nrows));
         const int local_u_main = std::min(local_u, local_x);              // rows beyond X: solve_sideinfo_only_rows
@@ -1286,7 +1426,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         add_implicit_term(c);
         // rows with few entries against many unknowns: low-rank path (lowrank_kernels.hpp)
         if (Fi == nullptr && !sbc && local_u_main == X.nrows && part < 0) {
-            const int rc_lr = launch_collective_lowrank(dev, s->lr, c, X, Cm, Um + (size_t)begin * p_self, p_self, w, m.k, isA ? m.n : m.m);
+            const int rc_lr = launch_collective_lowrank(dev, s->lr, c, X, Cm, Um + (size_t)(s->side_local ? 0 : begin) * p_self, p_self, w, m.k, isA ? m.n : m.m);
             if (rc_lr >= 0) return rc_lr;
         }
         int rc = launch_chol(dev, c, &X);
@@ -1615,6 +1755,7 @@ void *cmfrec_hip_session_device_ptr(cmfrec_hip_session *s, int which, size_t *ro
         case 'D': if (rows) *rows = s->mdl.q; if (ld) *ld = s->mdl.k_item + s->mdl.k; return s->D.ptr;
         case 'a': if (rows) *rows = s->mdl.m; if (ld) *ld = 1; return s->biasA.ptr;
         case 'b': if (rows) *rows = s->mdl.n; if (ld) *ld = 1; return s->biasB.ptr;
+        case 'P': if (rows) *rows = s->side_part.n; if (ld) *ld = 1; return s->side_part.ptr;   // partial sums of the C / D update
     }
     return nullptr;
 }

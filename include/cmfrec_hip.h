@@ -351,6 +351,14 @@ int cmfrec_hip_session_set_sideinfo(cmfrec_hip_session *s, const real_t *U, cons
  * row systems are then solved by the reference's cyclic coordinate descent (solve_nonneg, src/common.c:2131-2179,
  * at most max_cd_steps sweeps, 0 = until converged) and the CG is switched off for that matrix (common.c:725, :2781).
  * The k_t x k_t system lives in LDS: k_t <= 140 (double) / 199 (single). */
+/* Row-block shards of the explicit / collective model (one session per GPU): side information restricted to
+   the rows of the block -- U_local = rows [row_begin, min(row_end, m_u)) of U, I_local = rows [col_begin, min(col_end, n_i))
+   of I (already centred) -- and the C / D update (optimizeA Case 1, src/common.c:2793-2991) cut in two:
+   _partial leaves [F_loc^T F_loc | U_loc^T F_loc] in a device buffer (cmfrec_hip_session_device_ptr(s, 'P', &elems, NULL)),
+   the caller all-reduces it over the ranks, _finish adds lambda and solves -- the same small system on every rank. */
+int cmfrec_hip_session_set_sideinfo_local(cmfrec_hip_session *s, const real_t *U_local, const real_t *I_local);
+int cmfrec_hip_session_sideinfo_partial(cmfrec_hip_session *s, int which /* 'C' | 'D' */);
+int cmfrec_hip_session_sideinfo_finish(cmfrec_hip_session *s, int which /* 'C' | 'D' */);
 int cmfrec_hip_session_set_nonneg(cmfrec_hip_session *s, int nonneg, int nonneg_C, int nonneg_D, int max_cd_steps);
 /* Implicit features of the explicit model (add_implicit_features of fit_collective_explicit_als,
  * /root/reference/src/collective.c:7269, :8448-8534): Ai [m, k+k_main] and Bi [n, k+k_main] factorise the binary

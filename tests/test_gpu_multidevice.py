@@ -1,0 +1,40 @@
+"""GPU: several device shards behind the unchanged C signature: CMFREC_HIP_DEVICES lists HIP device
+ordinals; fit_collective_implicit_als then cuts users / items into row blocks, one session per entry, and moves the updated
+rows between the replicas with peer copies ordered by events (cmfrec_amd/csrc/fit.hip, fit_implicit_multi).  An ordinal may
+repeat, which shards ONE device -- the only way to run the path on a single-GPU box, and it exercises everything but the
+xGMI hop: block boundaries (equal users, nnz-balanced items), shard construction from the COO, the exchange and its event
+ordering, the epilogue on the first replica.  Rows are independent given the opposing matrix, so the result must be the
+single-device fit bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import make_coo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+@pytest.mark.parametrize("use_cg", [True, False])
+@pytest.mark.parametrize("use_float", [False, True])
+def test_devices_env_matches_single_device(devices, use_cg, use_float, monkeypatch):
+    from cmfrec_amd import CMF_implicit
+    m, n = 900, 700
+    row, col, val = make_coo(m, n, 30000, 3, heavy_row=(5, 600), empty_rows=(7, 11))
+    kw = dict(k=20, lambda_=3.0, niter=3, use_cg=use_cg, use_float=use_float, finalize_chol=use_cg, random_state=7)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF_implicit(**kw).fit((row, col, val), shape=(m, n))
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", devices)
+    shard = CMF_implicit(**kw).fit((row, col, val), shape=(m, n))
+    assert np.isfinite(shard.A_).all() and np.abs(shard.A_).max() > 0
+    assert np.array_equal(shard.A_, base.A_) and np.array_equal(shard.B_, base.B_)
+    assert np.array_equal(shard._BtB, base._BtB)
+
+
+def test_devices_env_ignores_bad_ordinals(monkeypatch):
+    """Ordinals outside the visible devices are dropped; an empty list falls back to the current device."""
+    from cmfrec_amd import CMF_implicit
+    m, n = 300, 200
+    row, col, val = make_coo(m, n, 5000, 4)
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", "99,-1")
+    mdl = CMF_implicit(k=8, niter=1, use_float=False).fit((row, col, val), shape=(m, n))
+    assert np.isfinite(mdl.A_).all()
