@@ -30,6 +30,60 @@ namespace cmfhip {
 
 #define CMF_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+// Sixteen values of a lane-linear tile array (4 tiles: element [t][r][lane], t = -2 .. 1 around `mid`, r = 0 .. 3) with all
+// sixteen loads in flight and one wait (loads and their wait in one statement, early-clobber outputs: the compiler neither
+// counts nor reorders what is inside).
+__device__ __forceinline__ void wave_load16(const double *mid, double (&v)[16])
+{
+    asm volatile(
+        "global_load_dwordx2 %0, %16, off offset:-4096\n\t"
+        "global_load_dwordx2 %1, %16, off offset:-3584\n\t"
+        "global_load_dwordx2 %2, %16, off offset:-3072\n\t"
+        "global_load_dwordx2 %3, %16, off offset:-2560\n\t"
+        "global_load_dwordx2 %4, %16, off offset:-2048\n\t"
+        "global_load_dwordx2 %5, %16, off offset:-1536\n\t"
+        "global_load_dwordx2 %6, %16, off offset:-1024\n\t"
+        "global_load_dwordx2 %7, %16, off offset:-512\n\t"
+        "global_load_dwordx2 %8, %16, off\n\t"
+        "global_load_dwordx2 %9, %16, off offset:512\n\t"
+        "global_load_dwordx2 %10, %16, off offset:1024\n\t"
+        "global_load_dwordx2 %11, %16, off offset:1536\n\t"
+        "global_load_dwordx2 %12, %16, off offset:2048\n\t"
+        "global_load_dwordx2 %13, %16, off offset:2560\n\t"
+        "global_load_dwordx2 %14, %16, off offset:3072\n\t"
+        "global_load_dwordx2 %15, %16, off offset:3584\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+          "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+        : "v"(mid)
+        : "memory");
+}
+__device__ __forceinline__ void wave_load16(const float *mid, float (&v)[16])
+{
+    asm volatile(
+        "global_load_dword %0, %16, off offset:-2048\n\t"
+        "global_load_dword %1, %16, off offset:-1792\n\t"
+        "global_load_dword %2, %16, off offset:-1536\n\t"
+        "global_load_dword %3, %16, off offset:-1280\n\t"
+        "global_load_dword %4, %16, off offset:-1024\n\t"
+        "global_load_dword %5, %16, off offset:-768\n\t"
+        "global_load_dword %6, %16, off offset:-512\n\t"
+        "global_load_dword %7, %16, off offset:-256\n\t"
+        "global_load_dword %8, %16, off\n\t"
+        "global_load_dword %9, %16, off offset:256\n\t"
+        "global_load_dword %10, %16, off offset:512\n\t"
+        "global_load_dword %11, %16, off offset:768\n\t"
+        "global_load_dword %12, %16, off offset:1024\n\t"
+        "global_load_dword %13, %16, off offset:1280\n\t"
+        "global_load_dword %14, %16, off offset:1536\n\t"
+        "global_load_dword %15, %16, off offset:1792\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+          "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11]), "=&v"(v[12]), "=&v"(v[13]), "=&v"(v[14]), "=&v"(v[15])
+        : "v"(mid)
+        : "memory");
+}
+
 // does any of the tiles [T0, T1) of the packed order touch block b?
 __host__ __device__ constexpr bool wave_block_needed(int b, int T0, int T1, int NB)
 {
@@ -44,7 +98,7 @@ __host__ __device__ constexpr int wtix(int bi, int bj, int NB) { return bi * NB 
 template <typename T>
 __host__ __device__ constexpr size_t chol_wave_lds_elems(int NB)
 {
-    return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 16 * (size_t)NB + 16;
+    return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 16 * (size_t)NB + 16 + 2 * 64 * (size_t)NB;
 }
 
 // slices of the rows that lead the processing order (positions < n_heavy): slice s covers entries
@@ -57,6 +111,7 @@ struct CholSlices {
     // Work items of a producer launch: items [0, n_slices) are the slices above; item n_slices + i is the WHOLE row at
     // position n_heavy + i (two-kernel mode: every row's rank-k update is done by the producer build).
     int part_base = 0;
+    int dbg_skip = 0;                // timing experiments only (CMFREC_HIP_WAVE_SKIP): 1 partial loads, 2 factorisation, 4 forward pass, 8 backward pass
 };
 // elements of one slice's partial: NT tiles in lane-linear order, right-hand side, border column, two scalars
 __host__ __device__ constexpr size_t chol_wave_part_elems(int NB) { return (size_t)(NB * (NB + 1) / 2) * 256 + 2 * 16 * (size_t)NB + 64; }
@@ -93,6 +148,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
     T *yv0 = rinv + (size_t)NB * RSZ;        // [NV]  right-hand side -> y -> z
     T *yv1 = yv0 + NV;                       // [NV]  border column g -> R^-T g
     T *xall = yv1 + NV;                      // [NV]  solution
+    T *stash = xall + NV;                    // [2][NB][64]  per-lane partials of right-hand side / border column (EV builds)
 
     const int kt = P.kt, koff = P.koff;
     const int kq = kt - (BORDER ? 1 : 0);    // unknowns inside the tiles
@@ -173,7 +229,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
         for (int t = 0; t < NT; t++) acc[t] = vec{0, 0, 0, 0};
         // (four tiles of loads in flight at a time: left to itself the scheduler issues all NT x 4 loads first and the
         //  register allocation of the whole kernel pays for it)
-        auto add_matrix = [&](const T *Mi, int lim) {              // collective.c:1566-1571
+        auto add_matrix = [&](const T *Mi, int lim) __attribute__((always_inline)) {              // collective.c:1566-1571
             static_for<0, (NT + 3) / 4>([&](auto qc) {
                 constexpr int q4 = decltype(qc)::value;
                 static_for<4 * q4, (4 * q4 + 4 < NT ? 4 * q4 + 4 : NT)>([&](auto tc) {
@@ -190,18 +246,9 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
-        if (!PRODUCER) {
+        auto apply_init = [&]() __attribute__((always_inline)) {
             if (M1 != nullptr) add_matrix(M1, kt);
             if (M2 != nullptr && kc > 0) add_matrix(M2, kc);
-        }
-        // element (gi, kt - 1) of the initial matrices: the border column
-        auto border_init = [&](int gi) -> T {
-            T v = T(0);
-            if (M1 != nullptr) v += M1[(size_t)min(gi, kt - 1) * kt + (kt - 1)];
-            if (M2 != nullptr && kc > 0) { const T q = M2[(size_t)min(gi, kc - 1) * kc + (kc - 1)]; v += (kt - 1 < kc) ? q : T(0); }
-            return v;
-        };
-        if (!PRODUCER) {
             static_for<0, NB>([&](auto bic) {
                 constexpr int bi = decltype(bic)::value;
 #pragma unroll
@@ -212,7 +259,15 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
                     acc[wtix(bi, bi, NB)][r] += dv;
                 }
             });
-        }
+        };
+        if constexpr (!PRODUCER) apply_init();
+        // element (gi, kt - 1) of the initial matrices: the border column
+        auto border_init = [&](int gi) -> T {
+            T v = T(0);
+            if (M1 != nullptr) v += M1[(size_t)min(gi, kt - 1) * kt + (kt - 1)];
+            if (M2 != nullptr && kc > 0) { const T q = M2[(size_t)min(gi, kc - 1) * kc + (kc - 1)]; v += (kt - 1 < kc) ? q : T(0); }
+            return v;
+        };
         // right-hand side, border column: per lane the partial sum of its 4-row group g for the unknown 16 b + lm
         // (summed over the groups when the block becomes the pivot); prefilled values enter through group 0
         const bool pre_rhs = !PRODUCER && (has_u || P.rhs_prefilled_all);   // w*U*C prefilled (collective.c:5768-5773)
@@ -239,18 +294,24 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
             // the rank-k update of this row was done slice by slice: add the partials in slice order
             const bool hv = rix < SL.n_heavy;
             const int s0 = hv ? SL.row_off[rix] : SL.n_slices + (rix - SL.n_heavy), s1 = hv ? SL.row_off[rix + 1] : s0 + 1;
-            for (int sl = s0; sl < s1; sl++) {
+            for (int sl = s0; sl < ((SL.dbg_skip & 1) ? s0 : s1); sl++) {
                 const T *pp = SL.part + (size_t)(sl - SL.part_base) * PART;
-                // LB tiles of loads in flight at a time (a partial is NT x 2 KB from HBM: every batch is a round trip)
-                constexpr int LB = (sizeof(T) == 8) ? 9 : 12;
-                static_for<0, (NT + LB - 1) / LB>([&](auto qc) {
-                    constexpr int q4 = decltype(qc)::value;
-                    static_for<LB * q4, (LB * q4 + LB < NT ? LB * q4 + LB : NT)>([&](auto tc) {
-                        constexpr int t = decltype(tc)::value;
+                // 16 values (4 tiles) per round trip, through wave_load16: left to the compiler every value waits for its own
+                // load (with the factorisation's registers live it finds one free pair and serialises 144 round trips per
+                // partial: 8 of 24 ms at the config-3 shape)
+                static_for<0, NT / 4>([&](auto qc) {
+                    constexpr int t0 = 4 * decltype(qc)::value;
+                    T v16[16];
+                    wave_load16(pp + (size_t)(t0 + 2) * 256 + lane, v16);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) acc[t][r] += pp[t * 256 + r * 64 + lane];
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[t0 + u][r] += v16[4 * u + r];
+                });
+                static_for<(NT / 4) * 4, NT>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[t][r] += pp[t * 256 + r * 64 + lane];
                 });
                 const T *pv = pp + (size_t)NT * 256;
 #pragma unroll
@@ -268,7 +329,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
         } else {
             // one sweep over the row's (or slice's) entries for the tiles [T0, T1) of the packed order; VEC: the
             // right-hand side and border column partials ride along
-            auto rank_pass = [&](auto t0c, auto t1c, auto vecc) {
+            auto rank_pass = [&](auto t0c, auto t1c, auto vecc) __attribute__((always_inline)) {
                 constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
                 constexpr bool VEC = decltype(vecc)::value;
                 T opb[PD][NB], bvb[PD], xraw[PD], bsv[PD];
@@ -400,8 +461,13 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
             }
             CMF_LDS_FENCE();
         }
+        if constexpr (EV) {
+            // the partials are not touched by the factorisation: out of the registers until the forward substitution
+#pragma unroll
+            for (int b = 0; b < NB; b++) { stash[b * 64 + lane] = rp[b]; if (BORDER) stash[(NB + b) * 64 + lane] = gp[b]; }
+        }
         // ---- 3. blocked Cholesky  M = R^T R, in this wave's registers ----
-        for (int kb = 0; kb < nb; kb++) {
+        for (int kb = 0; kb < ((WMODE == 2 && (SL.dbg_skip & 2)) ? 0 : nb); kb++) {
             T *rslot = rinv + (size_t)kb * RSZ;
             vec dd = vec{0, 0, 0, 0};
             static_for<0, NB>([&](auto kc_) {
@@ -467,7 +533,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
             // for the right-hand side and the border column at once.  rp / gp still hold the per-group partials of v; a
             // lane adds the products of its four rows of every tile (i, k), the groups are summed, one 16 x 16
             // matrix-vector product per block through LDS.
-            for (int kb = 0; kb < nb; kb++) {
+            for (int kb = 0; kb < ((WMODE == 2 && (SL.dbg_skip & 4)) ? 0 : nb); kb++) {
                 const T *rslot = rinv + (size_t)kb * RSZ;
                 T vk = T(0), wk = T(0);
                 static_for<0, NB>([&](auto kc_) {
@@ -483,7 +549,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
                                 if (BORDER) s1 += tv * yv1[16 * i + Mf::row_of(lane, r)];
                             }
                         });
-                        vk = rp[KB] - s0; wk = gp[KB] - s1;
+                        vk = stash[KB * 64 + lane] - s0; wk = BORDER ? stash[(NB + KB) * 64 + lane] - s1 : T(0);
                     }
                 });
                 vk = lanes::tswap16_add(vk, vk); vk = lanes::tswap32_add(vk, vk);
@@ -528,7 +594,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
             CMF_LDS_FENCE();
         }
         // ---- 4. backward substitution R x = z, one block column per step ----
-        for (int bjk = nb - 1; bjk >= 0; bjk--) {
+        for (int bjk = ((WMODE == 2 && (SL.dbg_skip & 8)) ? -1 : nb - 1); bjk >= 0; bjk--) {
             const T *rslot = rinv + (size_t)bjk * RSZ;
             T xm = T(0);                          // x[16 bjk + lm], computed redundantly by every 16-lane group
 #pragma unroll

@@ -169,6 +169,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 SLT.n_slices = X->n_slices;
             }
             SLT.n_heavy = n_heavy;
+            { static const int skip = getenv("CMFREC_HIP_WAVE_SKIP") ? atoi(getenv("CMFREC_HIP_WAVE_SKIP")) : 0; SLT.dbg_skip = skip; }
             if (sizeof(real_t) == 8 && nbw > 6) {
                 // Two kernels (7 and 8 blocks in double: 28 / 36 tiles of 8 registers + the factorisation's temporaries exceed
                 // what one kernel can keep in registers -- hipcc emits the accumulator-file form of the MFMAs at one wave per

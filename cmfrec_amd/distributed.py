@@ -171,6 +171,34 @@ class ShardedAls:
         self.half_step("B", use_cholesky)
         self.half_step("A", use_cholesky)
 
+    # ---- explicit / collective model: side information sharded with the rows ----
+    def sideinfo_step(self, which):
+        """C ('C') or D ('D') update of the collective model (optimizeA Case 1, src/common.c:2793-2991) with U / I cut
+        into the same row blocks as A / B: every rank adds up  F_loc^T F_loc  and  U_loc^T F_loc  over ITS rows
+        (engine.sideinfo_partial), one all-reduce makes the sums global, and every rank solves the same small system
+        (engine.sideinfo_finish) -- C / D stay identical replicas without ever being communicated."""
+        import contextlib
+        import torch
+        import torch.distributed as dist
+        eng = self.engine
+        buf = eng.sideinfo_partial(which)              # flat tensor, updated in place
+        ordered = eng.ordered_stream() if hasattr(eng, "ordered_stream") else None
+        if self.world > 1 or dist.is_initialized():
+            with (torch.cuda.stream(ordered) if ordered is not None else contextlib.nullcontext()):
+                dist.all_reduce(buf, group=self.group)
+        eng.sideinfo_finish(which)
+
+    def iteration_collective(self, use_cholesky=True):
+        """One ALS iteration of the explicit model with side information, reference order C, D, B, A
+        (src/collective.c:8334-8898).  Bias columns ride in the gathered rows (engine.after_gather splits them off)."""
+        eng = self.engine
+        if eng.has_sideinfo("C"):
+            self.sideinfo_step("C")
+        if eng.has_sideinfo("D"):
+            self.sideinfo_step("D")
+        self.half_step("B", use_cholesky)
+        self.half_step("A", use_cholesky)
+
 
 class _DevArray:
     """Zero-copy view of session-owned HBM for torch (``__cuda_array_interface__``)."""
@@ -269,6 +297,42 @@ class GpuEngine:
 
     def ranges(self, which):
         return self._ranges[which]
+
+    @classmethod
+    def from_collective_block(cls, m, n, k, row_local, col, val, row_ranges, rank, world, device, U_local=None, I_local=None,
+                              p=0, q=0, m_u=0, n_i=0, dtype=np.float64, lam=1.0, w_user=1.0, w_item=1.0, user_bias=False,
+                              item_bias=False, scale_lam=False, group=None):
+        """Explicit model with dense side information, sharded: this rank's user block of X (device COO, rows local), its
+        rows of U and -- after the item blocks are known -- its rows of I (a callable ``I_local(c0, c1)`` or the array).
+        X is expected centred (and the bias start values set through the replicas) by the caller."""
+        import torch
+        from .session import AlsSession
+        r0, r1 = row_ranges[rank]
+        row_local = row_local.to(torch.int32); col = col.to(torch.int32)
+        col_bounds, crow, ccol, cval = shard_coo_by_items(row_local + r0, col, val, n, rank, world, group=group)
+        col_ranges = [(int(col_bounds[r]), int(col_bounds[r + 1])) for r in range(world)]
+        c0, c1 = col_ranges[rank]
+        sess = AlsSession(m, n, k, implicit=False, dtype=dtype, lam=lam, use_cg=False, user_bias=user_bias, item_bias=item_bias,
+                          scale_lam=scale_lam, p=p, q=q, m_u=m_u, n_i=n_i, w_user=w_user, w_item=w_item,
+                          row_range=row_ranges[rank], col_range=col_ranges[rank], device=device)
+        sess.set_X_coo_device("r", row_local, col, val)
+        sess.set_X_coo_device("c", (ccol - c0).to(torch.int32), crow.to(torch.int32), cval)
+        Il = I_local(c0, c1) if callable(I_local) else I_local
+        sess.set_sideinfo_local(U_local, Il)
+        eng = cls(sess, row_ranges, col_ranges)
+        eng._side = {"C": p > 0, "D": q > 0}
+        return eng
+
+    def has_sideinfo(self, which):
+        return bool(getattr(self, "_side", {}).get(which, False))
+
+    def sideinfo_partial(self, which):
+        import torch
+        ptr, elems = self.session.sideinfo_partial(which)
+        return torch.as_tensor(_DevArray(ptr, (elems,), self.session.dtype), device="cuda")
+
+    def sideinfo_finish(self, which):
+        self.session.sideinfo_finish(which)
 
     def ordered_stream(self):
         """The session's own HIP stream as a torch stream: collectives enqueued on it are ordered after the kernels of the

@@ -170,6 +170,23 @@ class AlsSession:
         _lib.check(self.lib.cmfrec_hip_session_set_sideinfo(self.handle, *[_lib.ptr(a) for a in keep]), self.lib,
                    "set_sideinfo")
 
+    def set_sideinfo_local(self, U=None, II=None):
+        """Row-block shards: only the block's rows of the (centred) side information -- U rows [row_begin, min(row_end, m_u)),
+        I rows [col_begin, min(col_end, n_i))."""
+        keep = [self._c(U), self._c(II)]
+        _lib.check(self.lib.cmfrec_hip_session_set_sideinfo_local(self.handle, *[_lib.ptr(a) for a in keep]), self.lib,
+                   "set_sideinfo_local")
+
+    def sideinfo_partial(self, which):
+        """First half of the C / D update of a shard: partial sums over the local rows; returns (device pointer, elements) of
+        the buffer [F_loc^T F_loc | U_loc^T F_loc] for the caller's all-reduce."""
+        _lib.check(self.lib.cmfrec_hip_session_sideinfo_partial(self.handle, C.c_int(ord(which))), self.lib, "sideinfo_partial")
+        p, elems, _ = self.device_ptr("P")
+        return p, elems
+
+    def sideinfo_finish(self, which):
+        _lib.check(self.lib.cmfrec_hip_session_sideinfo_finish(self.handle, C.c_int(ord(which))), self.lib, "sideinfo_finish")
+
     def update(self, which, use_cholesky=False):
         _lib.check(self.lib.cmfrec_hip_session_update(self.handle, C.c_int(ord(which)), C.c_int(int(use_cholesky))),
                    self.lib, "update(%s)" % which)

@@ -238,3 +238,107 @@ def test_two_rank_alltoall_setup(tmp_path, oracles):
     # the entries of a column arrive grouped by source block instead of interleaved as in the global COO: the same sums
     # in another order
     assert np.abs(r0["A"] - A).max() < 1e-12 and np.abs(r0["B"] - B).max() < 1e-12
+
+
+# ---- explicit / collective model: side information sharded with the rows --------------------------------------------
+def _collective_problem():
+    from conftest import make_coo
+    m, n, k, p, q = 120, 90, 6, 5, 4
+    row, col, val = make_coo(m, n, 2400, 21, counts=False, heavy_row=(3, 70), empty_rows=(9,))
+    rng = np.random.default_rng(8)
+    U = rng.standard_normal((m, p)); II = rng.standard_normal((n, q))
+    U -= U.mean(0); II -= II.mean(0)           # the fit centres the side information by columns (common.c:4911-4997): done up front here
+    A0 = rng.standard_normal((m, k)) * 0.1; B0 = rng.standard_normal((n, k)) * 0.1
+    return m, n, k, p, q, row, col, val, U, II, A0, B0
+
+
+class CollectiveOracleEngine(OracleEngine):
+    """CPU engine of ShardedAls.iteration_collective: the local rows of A / B through the oracle's collective Cholesky
+    operator (optimizeA_collective), the C / D update as partial sums over the local rows + the small solve."""
+
+    def __init__(self, O, A, B, Cm, Dm, csr_l, csc_l, U_l, I_l, rr, cr, rank, lam, w_user, w_item, k):
+        self.O, self.rank, self.lam, self.w_user, self.w_item, self.k = O, rank, lam, w_user, w_item, k
+        self.A, self.B, self.Cm, self.Dm = A, B, Cm, Dm
+        self.tA, self.tB = torch.from_numpy(A), torch.from_numpy(B)
+        self._ranges = {"A": rr, "B": cr}
+        self.csr, self.csc, self.U_l, self.I_l = csr_l, csc_l, U_l, I_l
+        self._part = {}
+
+    def has_sideinfo(self, which):
+        return True
+
+    def update(self, which, use_cholesky=True):
+        b, e = self._ranges[which][self.rank]
+        if which == "A":
+            blk = np.ascontiguousarray(self.A[b:e])
+            self.O.optimizeA_collective_chol(blk, self.B, self.Cm, self.csr, self.U_l, self.lam, w_user=self.w_user, k=self.k)
+            self.A[b:e] = blk
+        else:
+            blk = np.ascontiguousarray(self.B[b:e])
+            self.O.optimizeA_collective_chol(blk, self.A, self.Dm, self.csc, self.I_l, self.lam, w_user=self.w_item, k=self.k)
+            self.B[b:e] = blk
+
+    def sideinfo_partial(self, which):
+        b, e = self._ranges["A" if which == "C" else "B"][self.rank]
+        F = (self.A if which == "C" else self.B)[b:e]
+        Ul = self.U_l if which == "C" else self.I_l
+        buf = torch.from_numpy(np.concatenate([(F.T @ F).ravel(), (Ul.T @ F).ravel()]))
+        self._part[which] = buf
+        return buf
+
+    def sideinfo_finish(self, which):
+        kc = self.k
+        buf = self._part[which].numpy()
+        G = buf[:kc * kc].reshape(kc, kc); R = buf[kc * kc:].reshape(-1, kc)
+        w = self.w_user if which == "C" else self.w_item
+        M = (self.Cm if which == "C" else self.Dm)
+        M[:] = np.linalg.solve(G + (self.lam / w) * np.eye(kc), R.T).T            # collective.c:8367, common.c:2824-2875
+
+
+def _worker_collective(rank, world, port, out_dir):
+    from oracle.bindings import Oracle
+    from cmfrec_amd.distributed import ShardedAls, shard_coo_by_items
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    O = Oracle(np.float64)
+    m, n, k, p, q, row, col, val, U, II, A0, B0 = _collective_problem()
+    m_blk = m // world
+    r0, r1 = rank * m_blk, (rank + 1) * m_blk
+    mine = (row >= r0) & (row < r1)
+    lrow, lcol, lval = row[mine], col[mine], val[mine]
+    cb, crow, ccol, cval = shard_coo_by_items(torch.from_numpy(lrow.astype(np.int64)), torch.from_numpy(lcol.astype(np.int64)),
+                                              torch.from_numpy(lval), n, rank, world)
+    c0, c1 = cb[rank], cb[rank + 1]
+    csr_l, _ = O.coo_to_csr_and_csc((lrow - r0).astype(np.int32), lcol.astype(np.int32), lval, m_blk, n)
+    _, csc_l = O.coo_to_csr_and_csc(crow.numpy().astype(np.int32), (ccol.numpy() - c0).astype(np.int32), cval.numpy(), m, c1 - c0)
+    A, B = A0.copy(), B0.copy()
+    Cm, Dm = np.zeros((p, k)), np.zeros((q, k))
+    rr = [(i * m_blk, (i + 1) * m_blk) for i in range(world)]
+    cr = [(cb[i], cb[i + 1]) for i in range(world)]
+    eng = CollectiveOracleEngine(O, A, B, Cm, Dm, csr_l, csc_l, np.ascontiguousarray(U[r0:r1]), np.ascontiguousarray(II[c0:c1]),
+                                 rr, cr, rank, 0.7, 0.5, 2.0, k)
+    als = ShardedAls(eng, rank, world)
+    for _ in range(3):
+        als.iteration_collective()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B, C=Cm, D=Dm)
+    dist.destroy_process_group()
+
+
+def test_two_rank_collective_model(tmp_path, oracles):
+    """Explicit model with dense side information on both sides, U / I sharded with the rows (a config-3-shaped toy):
+    partial sums + all-reduce for C / D, all-gathers for A / B.  The two ranks end with identical replicas of everything;
+    against the single-process fit only the summation order of the C / D partials differs."""
+    world = 2
+    mp.spawn(_worker_collective, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    O = oracles[np.float64]
+    m, n, k, p, q, row, col, val, U, II, A0, B0 = _collective_problem()
+    A, B = A0.copy(), B0.copy()
+    Cm, Dm = np.zeros((p, k)), np.zeros((q, k))
+    O.fit_explicit_als(A, B, row, col, val, k, Cm=Cm, Dm=Dm, U=U, II=II, user_bias=False, item_bias=False, center=False,
+                       lam=0.7, w_user=0.5, w_item=2.0, niter=3, use_cg=False, finalize_chol=False)
+    r0 = np.load(tmp_path / "rank0.npz"); r1 = np.load(tmp_path / "rank1.npz")
+    for key in ("A", "B", "C", "D"):
+        assert np.array_equal(r0[key], r1[key]), key
+    for key, ref in (("A", A), ("B", B), ("C", Cm), ("D", Dm)):
+        assert np.abs(r0[key] - ref).max() / np.abs(ref).max() < 1e-10, key

@@ -91,3 +91,52 @@ def test_one_rank_device_coo_engine(parts):
     finally:
         dist.destroy_process_group()
     assert np.array_equal(B, Br) and np.array_equal(A, Ar)
+
+
+@pytest.mark.parametrize("biases", [False, True])
+def test_one_rank_collective_engine(biases):
+    """Explicit model with dense side information on both sides as ONE row-block shard (U / I local, C / D update split into
+    partial sums + all-reduce + finish, bias columns riding in the gathered rows): with one rank the partial sums are the
+    whole sums, so three iterations must equal the plain session's bit for bit.  (Two ranks: tests/test_distributed_gloo.py.)"""
+    import torch
+    import torch.distributed as dist
+    from cmfrec_amd.session import AlsSession
+    from cmfrec_amd.distributed import GpuEngine, ShardedAls
+    from conftest import make_coo
+    m, n, k, p, q = 3000, 1800, 24, 10, 7
+    row, col, val = make_coo(m, n, 90000, 9, counts=False, heavy_row=(4, 1500), empty_rows=(8,))
+    val = val - val.mean()
+    rng = np.random.default_rng(2)
+    U = rng.standard_normal((m, p)); U -= U.mean(0)
+    II = rng.standard_normal((n, q)); II -= II.mean(0)
+    A0 = rng.standard_normal((m, k)) * 0.05; B0 = rng.standard_normal((n, k)) * 0.05
+    kw = dict(implicit=False, dtype=np.float64, lam=0.3, use_cg=False, user_bias=biases, item_bias=biases, scale_lam=True, p=p, m_u=m,
+              q=q, n_i=n, w_user=0.5, w_item=2.0)
+    ref = AlsSession(m, n, k, **kw)
+    ref.set_X_coo(row, col, val)
+    ref.set_sideinfo(U=U, II=II)
+    fac = dict(A=A0, B=B0, biasA=np.zeros(m) if biases else None, biasB=np.zeros(n) if biases else None, Cm=np.zeros((p, k)),
+               Dm=np.zeros((q, k)))
+    ref.set_factors(**fac)
+    ref.iterate(3)
+    fr = ref.get_factors()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        eng = GpuEngine.from_collective_block(m, n, k, torch.as_tensor(row, device=dev), torch.as_tensor(col, device=dev),
+                                              torch.as_tensor(val, device=dev), [(0, m)], 0, 1, 0, U_local=U, I_local=lambda c0, c1: II[c0:c1],
+                                              p=p, q=q, m_u=m, n_i=n, dtype=np.float64, lam=0.3, w_user=0.5, w_item=2.0,
+                                              user_bias=biases, item_bias=biases, scale_lam=True)
+        eng.session.set_factors(**fac)
+        als = ShardedAls(eng, 0, 1)
+        for _ in range(3):
+            als.iteration_collective()
+        eng.session.sync(); torch.cuda.synchronize()
+        fs = eng.session.get_factors()
+    finally:
+        dist.destroy_process_group()
+    for key in ("A", "B", "C", "D") + (("biasA", "biasB") if biases else ()):
+        assert np.array_equal(fs[key], fr[key]), key
