@@ -200,6 +200,7 @@ def main():
                         round((d["avg_ms"] + (other[0]["avg_ms"] if other else 0.0)) / (2 if other else 1), 4)}
     roofline = dict(bound="hbm", kernel="%s, %s-step" % (dom["kernel"], dom["step"]), achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    traffic_source=pmc_meta() if traffic is not None else None,
                     alg_bytes_per_launch=dom["alg_bytes"],
                     avg_launch_ms=round(dom["avg_ms"], 4), rocprof=dom["rocprof"],
                     iteration={"alg_GB": round(iter_bytes / 1e9, 3), "halfstep_ms": halfstep_ms,
@@ -531,6 +532,24 @@ def side_workload(args, device):
                       "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "k": k, "m": m, "n": n, "nnz": nnz, **extra,
                       "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
                       "note": "side measurement, not the headline metric"}))
+
+
+def pmc_meta():
+    """Where roofline.traffic comes from: the committed counter file, the round / step it was taken in, the FETCH_SIZE
+    correction it used, and whether the CG kernel sources have changed since (stale)."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    h = hashlib.sha1()
+    for f in ("cmfrec_amd/csrc/cg_kernels.hpp", "cmfrec_amd/csrc/gram_cg_kernels.hpp", "cmfrec_amd/csrc/lanes.hpp"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    cur = h.hexdigest()[:16]
+    return {"file": "profiles/pmc_latest.json", "round": d.get("round", "r01_f"), "fetch_factor": d.get("fetch_factor", 2.0),
+            "fetch_factor_source": d.get("fetch_factor_source", "x2 (guide; uncalibrated for this pattern)"),
+            "kernel_source_hash": d.get("kernel_source_hash"), "current_source_hash": cur,
+            "stale": d.get("kernel_source_hash") != cur}
 
 
 def pmc_traffic(dom):

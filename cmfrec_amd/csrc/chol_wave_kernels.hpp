@@ -111,10 +111,30 @@ struct CholSlices {
     // Work items of a producer launch: items [0, n_slices) are the slices above; item n_slices + i is the WHOLE row at
     // position n_heavy + i (two-kernel mode: every row's rank-k update is done by the producer build).
     int part_base = 0;
+    // initial matrices of the launch in the tile-linear layout of the partials (tile_pack_kernel), added like one more
+    // partial; null: read from the row-major matrices element by element
+    const T *init1 = nullptr, *init2 = nullptr;
     int dbg_skip = 0;                // timing experiments only (CMFREC_HIP_WAVE_SKIP): 1 partial loads, 2 factorisation, 4 forward pass, 8 backward pass
 };
 // elements of one slice's partial: NT tiles in lane-linear order, right-hand side, border column, two scalars
 __host__ __device__ constexpr size_t chol_wave_part_elems(int NB) { return (size_t)(NB * (NB + 1) / 2) * 256 + 2 * 16 * (size_t)NB + 64; }
+
+// out[t][r][lane] = M[gi][gj] of the symmetric lim x lim matrix M (upper triangle referenced, zero beyond lim) for the tile
+// grid of an NB-block wave kernel: the initial matrix of a launch, once, in the layout the row kernels add partials in
+template <typename T>
+__global__ void tile_pack_kernel(const T *__restrict__ M, int lim, int NB, T *__restrict__ out)
+{
+    const int NT = NB * (NB + 1) / 2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NT * 256) return;
+    const int t = e >> 8, r = (e >> 6) & 3, lane = e & 63;
+    int bi = 0, rem = t;
+    while (rem >= NB - bi) { rem -= NB - bi; bi++; }
+    const int bj = bi + rem;
+    const int gi = 16 * bi + CholMfma<T>::row_of(lane, r), gj = 16 * bj + (lane & 15);
+    const int lo = min(gi, gj), hi = max(gi, gj);
+    out[e] = (hi < lim) ? M[(size_t)lo * lim + hi] : T(0);
+}
 
 // NB: 16-blocks of the compiled tile grid; BORDER: the last unknown is kept outside the tiles; PD: 4-row gather steps
 // in flight; WPS: wavefronts per SIMD the register budget is set for (workgroups per CU).
@@ -246,9 +266,25 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
+        auto add_tiles = [&](const T *pp) __attribute__((always_inline)) {    // a tile-linear array, 16 values per round trip
+            static_for<0, NT / 4>([&](auto qc) {
+                constexpr int t0 = 4 * decltype(qc)::value;
+                T v16[16];
+                wave_load16(pp + (size_t)(t0 + 2) * 256 + lane, v16);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[t0 + u][r] += v16[4 * u + r];
+            });
+            static_for<(NT / 4) * 4, NT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[t][r] += pp[t * 256 + r * 64 + lane];
+            });
+        };
         auto apply_init = [&]() __attribute__((always_inline)) {
-            if (M1 != nullptr) add_matrix(M1, kt);
-            if (M2 != nullptr && kc > 0) add_matrix(M2, kc);
+            if (M1 != nullptr) { if (WMODE == 2 && SL.init1 != nullptr) add_tiles(SL.init1); else add_matrix(M1, kt); }
+            if (M2 != nullptr && kc > 0) { if (WMODE == 2 && SL.init2 != nullptr) add_tiles(SL.init2); else add_matrix(M2, kc); }
             static_for<0, NB>([&](auto bic) {
                 constexpr int bi = decltype(bic)::value;
 #pragma unroll
@@ -299,20 +335,7 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
                 // 16 values (4 tiles) per round trip, through wave_load16: left to the compiler every value waits for its own
                 // load (with the factorisation's registers live it finds one free pair and serialises 144 round trips per
                 // partial: 8 of 24 ms at the config-3 shape)
-                static_for<0, NT / 4>([&](auto qc) {
-                    constexpr int t0 = 4 * decltype(qc)::value;
-                    T v16[16];
-                    wave_load16(pp + (size_t)(t0 + 2) * 256 + lane, v16);
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc[t0 + u][r] += v16[4 * u + r];
-                });
-                static_for<(NT / 4) * 4, NT>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) acc[t][r] += pp[t * 256 + r * 64 + lane];
-                });
+                add_tiles(pp);
                 const T *pv = pp + (size_t)NT * 256;
 #pragma unroll
                 for (int b = 0; b < NB; b++) {

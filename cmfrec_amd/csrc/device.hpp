@@ -251,6 +251,7 @@ struct DeviceInfo {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    DevBuf<real_t> tile_init;       // initial matrices of a Cholesky launch in tile-linear layout (chol_wave_kernels.hpp, tile_pack_kernel)
     DevBuf<int> row_counter;        // work counters of the dynamically scheduled row kernels (zeroed before each launch)
     // second stream + events for two row kernels that may overlap (heavy-row teams beside light-row teams); created on
     // first use, owned here

@@ -185,6 +185,22 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 const size_t cap_items = (size_t)std::min<long long>((long long)nsl + (total - n_heavy), std::max(BATCH, max_row_items));
                 if (X->chol_part.n < cap_items * part_elems) X->chol_part.alloc(cap_items * part_elems);
                 SLT.part = X->chol_part.ptr;
+                // the launch's initial matrices once, in the tile layout of the partials (the row kernel then adds them like a
+                // partial, 16 values per round trip, instead of 144 dependent loads per row)
+                {
+                    const bool fullm = (c.mode == CHOL_IMPLICIT);
+                    const real_t *M1 = fullm ? c.Minit : c.Mfull, *M2 = fullm ? nullptr : c.Minit;
+                    const size_t tl = (size_t)36 * 256;
+                    if (M1 != nullptr || (M2 != nullptr && c.kc > 0)) d.tile_init.alloc_at_least(2 * tl);
+                    if (M1 != nullptr) {
+                        hipLaunchKernelGGL(tile_pack_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, M1, c.kt, 8, d.tile_init.ptr);
+                        SLT.init1 = d.tile_init.ptr;
+                    }
+                    if (M2 != nullptr && c.kc > 0) {
+                        hipLaunchKernelGGL(tile_pack_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, M2, c.kc, 8, d.tile_init.ptr + tl);
+                        SLT.init2 = d.tile_init.ptr + tl;
+                    }
+                }
                 int ctr = 4;
                 auto run_batch = [&](int item0, int item1, int row0, int row1) {
                     if (ctr + 2 > 60) ctr = 4;

@@ -106,3 +106,98 @@ def test_full_size_explicit_cg_reaches_closed_form():
         out[use_cg] = s.get_factors()["A"]
     err = np.abs(out[True] - out[False]).max() / np.abs(out[False]).max()
     assert err < 1e-3, err                       # CG stops at |r|^2 <= 1e-8 (absolute, common.c:1180)
+
+
+def test_c4_shard_properties():
+    """One GPU's share of configuration 4 (1.25 M x 1 M, 62.5 M entries, implicit ALS-CG k = 64 in SINGLE precision, the data
+    generated on the device as `bench.py --gpus 8` does): two independent runs are bit-identical (no floating-point
+    atomics, fixed summation orders -- also with 64-bit CSR offsets at this size) and the implicit objective never
+    increases over the iterations."""
+    import torch
+    import bench
+    from cmfrec_amd.session import AlsSession
+    dev = torch.device("cuda", 0)
+    m, n, nnz, k = 1_250_000, 1_000_000, 62_500_000, 64
+    row, col, val = bench.synth_block_torch(m, n, nnz, seed=40, item_seed=4, device=dev)
+    hrow, hcol, hval = row.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    del row, col, val
+    torch.cuda.empty_cache()
+    A0 = (np.random.default_rng(7).random((m, k), dtype=np.float32) * np.float32(2.0 ** -7))
+
+    def run(niter):
+        s = AlsSession(m, n, k, implicit=True, dtype=np.float32, lam=LAM, use_cg=True, max_cg_steps=3)
+        s.set_X_coo(hrow, hcol, hval)
+        s.set_factors(A=A0, B=np.zeros((n, k), np.float32))
+        out = []
+        for _ in range(niter):
+            s.iterate(1)
+            out.append(s.get_factors())
+        return out
+
+    r1, r2 = run(3), run(2)
+    assert np.array_equal(r1[1]["A"], r2[1]["A"]) and np.array_equal(r1[1]["B"], r2[1]["B"])
+    assert np.isfinite(r1[2]["A"]).all() and np.isfinite(r1[2]["B"]).all()
+    v64 = hval.astype(np.float64)
+    obj = [_objective(f["A"].astype(np.float64), f["B"].astype(np.float64), hrow, hcol, v64, LAM) for f in r1]
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(obj, obj[1:])), obj
+
+
+def test_c3_shape_normal_equations():
+    """Configuration 3's shape (69,878 x 10,677, 10 M ratings, k = 128 + biases, dense item side information q = 64, double
+    precision, Cholesky): sampled ITEM rows -- the heaviest (sliced over several wavefronts), single-entry ones, random
+    ones -- satisfy the collective normal equations
+        (sum_j a_j a_j^T + w D^T D (+) 0 + lam n_i I) b = w D^T i_row (+) 0 + sum_j (x_ij - bias_j) a_j
+    with the user-bias column of A fixed to 1 (collective_closed_form_block, collective.c:1534-1846), and sampled USER rows
+    the plain ones (factors_closed_form, common.c:978-1070)."""
+    import bench
+    from cmfrec_amd.session import AlsSession
+    m, n, nnz, k, q = 69_878, 10_677, 10_000_054, 128, 64
+    row, col, _ = bench.synth_block(m, n, nnz, seed=1)
+    rng = np.random.default_rng(1)
+    val = 0.5 * rng.integers(1, 11, nnz); val = val - val.mean()
+    II = rng.standard_normal((n, q)); II -= II.mean(0)
+    lam, w = 0.05, 1.0
+    s = AlsSession(m, n, k, implicit=False, dtype=np.float64, lam=lam, use_cg=False, user_bias=True, item_bias=True, scale_lam=True,
+                   q=q, n_i=n, w_item=w)
+    s.set_X_coo(row, col, val)
+    s.set_sideinfo(II=II)
+    A0 = rng.standard_normal((m, k)) * 0.1
+    biasA0 = rng.standard_normal(m) * 0.1
+    Dm0 = rng.standard_normal((q, k)) * 0.1
+    s.set_factors(A=A0, B=np.zeros((n, k)), biasA=biasA0, biasB=np.zeros(n), Dm=Dm0)
+    s.update("B"); s.after_gather("B")
+    f = s.get_factors()
+    B, biasB = f["B"], f["biasB"]
+    cnt = np.bincount(col, minlength=n)
+    order = np.argsort(col, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(cnt)])
+    kt = k + 1
+    items = np.concatenate([np.argsort(-cnt)[:4], np.nonzero(cnt == 1)[0][:4], rng.choice(np.nonzero(cnt > 0)[0], 24, replace=False)])
+    assert cnt[items[0]] > 2048
+    Ab = np.concatenate([A0, np.ones((m, 1))], axis=1)             # unknowns of an item: [b (k) | bias], gathered rows [a_j | 1]
+    DtD = w * Dm0.T @ Dm0
+    for i in items:
+        e = order[ptr[i]:ptr[i + 1]]
+        Aj = Ab[row[e]]; x = val[e] - biasA0[row[e]]
+        M = Aj.T @ Aj + lam * cnt[i] * np.eye(kt)
+        M[:k, :k] += DtD
+        rhs = Aj.T @ x
+        rhs[:k] += w * (II[i] @ Dm0)
+        sol = np.concatenate([B[i], [biasB[i]]])
+        assert np.abs(M @ sol - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max()), (i, cnt[i])
+    # user side: plain explicit rows with the item biases just computed
+    s.update("A"); s.after_gather("A")
+    f2 = s.get_factors()
+    A, biasA = f2["A"], f2["biasA"]
+    ucnt = np.bincount(row, minlength=m)
+    uorder = np.argsort(row, kind="stable")
+    uptr = np.concatenate([[0], np.cumsum(ucnt)])
+    Bb = np.concatenate([B, np.ones((n, 1))], axis=1)
+    users = np.concatenate([np.argsort(-ucnt)[:4], rng.choice(np.nonzero(ucnt > 0)[0], 24, replace=False)])
+    for u in users:
+        e = uorder[uptr[u]:uptr[u + 1]]
+        Bj = Bb[col[e]]; x = val[e] - biasB[col[e]]
+        M = Bj.T @ Bj + lam * ucnt[u] * np.eye(kt)
+        rhs = Bj.T @ x
+        sol = np.concatenate([A[u], [biasA[u]]])
+        assert np.abs(M @ sol - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max()), (u, ucnt[u])

@@ -12,15 +12,39 @@ import argparse
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """sha1 over the sources of the CG row kernels: bench.py compares it with the tree it runs from, so that counter
+    files taken from older kernels are visible as stale in the bench line."""
+    h = hashlib.sha1()
+    for f in ("cmfrec_amd/csrc/cg_kernels.hpp", "cmfrec_amd/csrc/gram_cg_kernels.hpp", "cmfrec_amd/csrc/lanes.hpp"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dirs", nargs="+")
     ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("--round", default="", help="round / step tag of the passes (e.g. r02_m)")
+    ap.add_argument("--calibration", default=os.path.join(ROOT, "profiles", "fetch_calibration.json"),
+                    help="output of tools/fetch_calibration.py: FETCH_SIZE correction measured on the gather's access pattern")
     args = ap.parse_args()
+    # FETCH_SIZE -> bytes: the guide's x2 holds for 16 B / lane coalesced reads; the CG kernels gather 8 B / lane in 64 B
+    # segments, for which the factor is measured (tools/microbench/fetch_calib.hip)
+    fetch_factor, fetch_note = 2.0, "x2 (guide, 16 B / lane coalesced; uncalibrated for this pattern)"
+    if os.path.exists(args.calibration):
+        cal = json.load(open(args.calibration))
+        g = cal.get("gather_8B_per_lane_64B_segments")
+        if g:
+            fetch_factor = float(g["factor_vs_64B_sectors"])
+            fetch_note = "x%.3f measured on the gather pattern (known 64 B sectors / FETCH_SIZE, %s)" % (fetch_factor, os.path.basename(args.calibration))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in args.dirs:
         for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
@@ -46,12 +70,13 @@ def main():
                       "per_halfstep_A": sum(halves[1::2]) / max(len(halves[1::2]), 1)}
         for step in ("A", "B"):
             if "FETCH_SIZE" in ent:
-                ent["hbm_read_bytes_%s" % step] = ent["FETCH_SIZE"]["per_halfstep_" + step] * 1024 * 2
+                ent["hbm_read_bytes_%s" % step] = ent["FETCH_SIZE"]["per_halfstep_" + step] * 1024 * fetch_factor
             if "WRITE_SIZE" in ent:
                 ent["hbm_write_bytes_%s" % step] = ent["WRITE_SIZE"]["per_halfstep_" + step] * 1024
         out[kname] = ent
-    json.dump({"note": "counter sums per half-step (bench.py order: B-step then A-step); FETCH_SIZE/WRITE_SIZE in KiB, "
-                       "FETCH_SIZE x2 gfx950 correction applied in hbm_read_bytes_*", "kernels": out},
+    json.dump({"note": "counter sums per half-step (bench.py order: B-step then A-step); FETCH_SIZE/WRITE_SIZE in KiB; "
+                       "hbm_read_bytes_* = FETCH_SIZE x 1024 x fetch_factor", "fetch_factor": fetch_factor, "fetch_factor_source": fetch_note,
+               "round": args.round, "kernel_source_hash": kernel_source_hash(), "kernels": out},
               open(args.out, "w"), indent=1, sort_keys=True)
     print("wrote", args.out, len(out), "kernels")
 
