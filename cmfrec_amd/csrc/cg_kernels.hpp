@@ -89,6 +89,11 @@ struct CgParams {
     const T *BiTBi = nullptr;
     int ki = 0;
     T w_imp = 0;
+    // tiled kernels, explicit model with a block term (GRAMX builds): the weighted Gramian of the block system --
+    // w C^T C and / or w_i Bi^T Bi, embedded in k x k -- arrives through BtB like the implicit model's, and the row's
+    // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
+    const T *rconst = nullptr;
+    size_t ldr = 0;
 };
 
 template <typename T>
@@ -230,14 +235,18 @@ __device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane)
 
 // Persistent kernel: W waves cooperate on one row (W = waves per row, blockDim.x = 64*W*RPB where
 // RPB rows are processed concurrently by one workgroup).
-template <typename T, int S, bool IMPLICIT, int W, int RPB>
+// GRAMX (explicit model only): block systems under CG (collective_block_cg with dense side information on every row and /
+// or implicit features, src/collective.c:2134-2903, no k_user offset): out -= / += G v on top of the gathered part, G staged
+// in LDS exactly like the implicit model's B^T B, and a per-row constant in the first residual.
+template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
 __global__ void __launch_bounds__(64 * W * RPB, CMF_CG_WAVES_PER_SIMD)
 cg_rows_kernel(const CgParams<T> P)
 {
     constexpr int LD = gram_ld(S);
+    constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *G = reinterpret_cast<T *>(smem_raw);                                  // [64][LD] (implicit)
-    T *red = G + (IMPLICIT ? 64 * LD : 0);                                   // [RPB][2][W][64]
+    T *G = reinterpret_cast<T *>(smem_raw);                                  // [64][LD] (implicit / block systems)
+    T *red = G + (GRAM ? 64 * LD : 0);                                       // [RPB][2][W][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -274,13 +283,13 @@ cg_rows_kernel(const CgParams<T> P)
         s_claim[2] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
         s_claim[3] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
     }
-    if (IMPLICIT) {
+    if (GRAM) {
         for (int e = tid; e < 64 * LD; e += blockDim.x) {
             int r = e / LD, c = e % LD;
             G[e] = (r < k && c < k) ? P.BtB[(size_t)r * k + c] : T(0);
         }
     }
-    if (IMPLICIT || W > 1) __syncthreads();
+    if (GRAM || W > 1) __syncthreads();
     if (W > 1) { rnxt = s_claim[2]; rnn = s_claim[3]; }
     T *myred = red + (size_t)grp * 2 * W * 64;
 
@@ -326,7 +335,13 @@ cg_rows_kernel(const CgParams<T> P)
         const bool resident = my_ntiles <= 1;
 
         T lam = P.lam, lam_last = P.lam_last;
-        if (!IMPLICIT && P.scale_lam) {                       // common.c:679-723
+        if (GRAMX && P.kc > 0) {                              // rows of the block system: collective.c:1285-1355
+            if (P.scale_lam || P.scale_lam_sideinfo) {
+                T mult = (T)nnz;
+                if (P.scale_lam_sideinfo) mult += (T)P.p_side;
+                lam *= mult; lam_last *= mult;
+            }
+        } else if (!IMPLICIT && P.scale_lam) {                // common.c:679-723
             lam *= (T)nnz;
             if (!P.scale_bias_const) lam_last *= (T)nnz;
         }
@@ -368,8 +383,8 @@ cg_rows_kernel(const CgParams<T> P)
                 }
                 tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
             }
-            if (IMPLICIT)
-                gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, out, lane, wr);   // common.c:1932 / :1958
+            if (GRAM)
+                gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, out, lane, wr);   // common.c:1932 / :1958; collective.c:2609-2643
             T tot = treduce8_high<T>(out, lane);                              // lane f <- element f
             if (W > 1) {
                 T *rb = myred + (size_t)buf * W * 64;
@@ -388,6 +403,7 @@ cg_rows_kernel(const CgParams<T> P)
         T r_d = run_pass(a_d, std::integral_constant<int, 0>{}, true);
         r_d -= lam * a_d;
         if (!IMPLICIT && lam != lam_last && lane == k - 1) r_d -= (lam_last - lam) * a_d;
+        if (GRAMX && P.rconst != nullptr && lane < k) r_d += P.rconst[(size_t)row * P.ldr + lane];
         if (lane >= k) r_d = T(0);
         T p_d = r_d;
         T r_old = wave_sum(r_d * r_d);
@@ -504,17 +520,18 @@ __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (
 #define CMF_TINY_WAVES_PER_SIMD 4     // 4: single tile buffer in a 128-VGPR budget (measured 10 % faster than
                                       // 2: double-buffered tiles, 2 x 56 VGPRs, 2 waves/SIMD)
 #endif
-template <typename T, int S, bool IMPLICIT>
+template <typename T, int S, bool IMPLICIT, bool GRAMX = false>
 __global__ void __launch_bounds__(256, CMF_TINY_WAVES_PER_SIMD)
 cg_rows_tiny_kernel(const CgParams<T> P)
 {
     constexpr int LD = gram_ld(S);
+    constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int k = P.k;
-    if (IMPLICIT) {
+    if (GRAM) {
         for (int e = tid; e < 64 * LD; e += blockDim.x) {
             int r = e / LD, c = e % LD;
             G[e] = (r < k && c < k) ? P.BtB[(size_t)r * k + c] : T(0);
@@ -547,7 +564,13 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     auto solve = [&](const RowDesc &d, const Pre &pr, const RegTile4<T, S> &tile) {
         const int nnz = d.nnz;
         T lam = P.lam, lam_last = P.lam_last;
-        if (!IMPLICIT && P.scale_lam) {
+        if (GRAMX && P.kc > 0) {
+            if (P.scale_lam || P.scale_lam_sideinfo) {
+                T mult = (T)nnz;
+                if (P.scale_lam_sideinfo) mult += (T)P.p_side;
+                lam *= mult; lam_last *= mult;
+            }
+        } else if (!IMPLICIT && P.scale_lam) {
             lam *= (T)nnz;
             if (!P.scale_bias_const) lam_last *= (T)nnz;
         }
@@ -562,12 +585,13 @@ cg_rows_tiny_kernel(const CgParams<T> P)
 #pragma unroll
             for (int s = 0; s < 8; s++) out[s] = T(0);
             tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, out, lane);
-            if (IMPLICIT) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, out, lane, 0);
+            if (GRAM) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, out, lane, 0);
             return treduce8_high<T>(out, lane);
         };
         T r_d = run_pass(a_d, std::integral_constant<int, 0>{});
         r_d -= lam * a_d;
         if (!IMPLICIT && lam != lam_last && lane == k - 1) r_d -= (lam_last - lam) * a_d;
+        if (GRAMX && P.rconst != nullptr && lane < k) r_d += P.rconst[(size_t)d.row * P.ldr + lane];
         if (lane >= k) r_d = T(0);
         T p_d = r_d;
         T r_old = wave_sum(r_d * r_d);
@@ -716,7 +740,7 @@ vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
 
 constexpr int VH_UPD_WAVES = 4;
 
-template <typename T, bool IMPLICIT, int MODE>
+template <typename T, bool IMPLICIT, int MODE, bool GRAMX = false>
 __global__ void __launch_bounds__(64 * VH_UPD_WAVES)
 vh_update_kernel(const CgParams<T> P, const VhState<T> V)
 {
@@ -749,14 +773,20 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
 #pragma unroll
     for (int w = 0; w < VH_UPD_WAVES; w++) tot += psum[w][lane];
     T lam = P.lam, lam_last = P.lam_last;
-    if (!IMPLICIT && P.scale_lam) {
+    if (GRAMX && P.kc > 0) {
+        if (P.scale_lam || P.scale_lam_sideinfo) {
+            T mult = (T)nnz;
+            if (P.scale_lam_sideinfo) mult += (T)P.p_side;
+            lam *= mult; lam_last *= mult;
+        }
+    } else if (!IMPLICIT && P.scale_lam) {
         lam *= (T)nnz;
         if (!P.scale_bias_const) lam_last *= (T)nnz;
     }
     T *arow = P.A + (size_t)row * P.lda;
     T a_d = (lane < k) ? arow[lane] : T(0);
     T v = (MODE == 0) ? a_d : V.p[(size_t)vi * 64 + lane];
-    if (IMPLICIT) {                                    // + (+-) BtB v   (common.c:1932 / :1958)
+    if (IMPLICIT || GRAMX) {                           // + (+-) BtB v   (common.c:1932 / :1958; block systems: collective.c:2609-2643)
         T g = T(0);
         for (int j = 0; j < k; j++) {
             T vj = __shfl(v, j);
@@ -767,6 +797,7 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
     if (MODE == 0) {
         T r_d = tot - lam * a_d;
         if (!IMPLICIT && lam != lam_last && lane == k - 1) r_d -= (lam_last - lam) * a_d;
+        if (GRAMX && P.rconst != nullptr && lane < k) r_d += P.rconst[(size_t)row * P.ldr + lane];
         if (lane >= k) r_d = T(0);
         T r_old = wave_sum(r_d * r_d);
         V.r[(size_t)vi * 64 + lane] = r_d;

@@ -155,7 +155,8 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
     using Mf = CholMfma<T>;
     using vec = typename Mf::vec;
     constexpr int NT = NB * (NB + 1) / 2;
-    constexpr int NRES = NT - NOV;           // tiles [0, NRES) are MFMA accumulators, [NRES, NT) overflow tiles
+    constexpr int NRES = (WMODE == 1) ? NT : NT - NOV;   // tiles [0, NRES) are MFMA accumulators, [NRES, NT) overflow tiles
+                                                         // (producer build: NOV = tiles per sweep instead)
     constexpr int LDR = Mf::LDR, RSZ = 16 * LDR;
     constexpr int NV = 16 * NB + 16;
     constexpr size_t PART = chol_wave_part_elems(NB);
@@ -421,16 +422,20 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
                 }
             };
             if constexpr (PRODUCER && NOV > 0) {
-                // 36 tiles of 8 registers do not fit the 256 accumulator registers: the first NT - NOV tiles in one sweep,
-                // stored, then the last NOV tiles in a second sweep over the same entries (only the blocks they touch are
-                // read again, from L1 / L2)
-                rank_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NRES>{}, std::true_type{});
+                // The tiles do not fit the 256 accumulator registers (36 x 8 in double at 8 blocks, 153 x 4 in single at 17):
+                // NOV tiles per sweep, stored, then the next NOV tiles in another sweep over the same entries (a sweep reads
+                // only the blocks its tiles touch; the first one carries the right-hand side and border partials).
+                constexpr int TP = NOV, NP = (NT + TP - 1) / TP;
                 T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
+                static_for<0, NP>([&](auto pc) {
+                    constexpr int T0 = decltype(pc)::value * TP, T1 = (T0 + TP < NT) ? T0 + TP : NT;
+                    rank_pass(std::integral_constant<int, T0>{}, std::integral_constant<int, T1>{}, std::integral_constant<bool, T0 == 0>{});
+                    static_for<T0, T1>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
 #pragma unroll
-                for (int t = 0; t < NRES; t++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) pp[t * 256 + r * 64 + lane] = acc[t][r];
-                rank_pass(std::integral_constant<int, NRES>{}, std::integral_constant<int, NT>{}, std::false_type{});
+                        for (int r = 0; r < 4; r++) pp[t * 256 + r * 64 + lane] = acc[t][r];
+                    });
+                });
             } else {
                 rank_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NT>{}, std::true_type{});
             }
@@ -456,10 +461,12 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
         CMF_LDS_FENCE();
         if constexpr (PRODUCER) {
             T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
+            if constexpr (NOV == 0) {
 #pragma unroll
-            for (int t = (NOV > 0 ? NRES : 0); t < NT; t++)
+                for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) pp[t * 256 + r * 64 + lane] = acc[t][r];
+                    for (int r = 0; r < 4; r++) pp[t * 256 + r * 64 + lane] = acc[t][r];
+            }
             T *pv = pp + (size_t)NT * 256;
             for (int u = lane; u < 16 * NB; u += 64) {
                 pv[u] = yv0[u];

@@ -419,4 +419,31 @@ __global__ void cold_select_kernel(T *__restrict__ A, size_t lda, int kt, int kc
     for (int e = threadIdx.x; e < kt; e += blockDim.x) A[(size_t)r * lda + e] = (e < kc) ? cold[(size_t)r * kc + e] : T(0);
 }
 
+// Block systems on the tiled CG kernels (cg_kernels.hpp, GRAMX): the weighted Gramian  w C^T C (+) 0 + w_i Bi^T Bi (+) 0  as one
+// k x k matrix, and the per-row constants  w (U C)_row (+) 0 + w_i gsum_row (+) 0.
+template <typename T>
+__global__ void block_gram_kernel(const T *__restrict__ CtC, int kc, T w_side, const T *__restrict__ BiTBi, int ki, T w_imp, int k,
+                                  T *__restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * k) return;
+    const int i = e / k, j = e % k;
+    T v = T(0);
+    if (CtC != nullptr && i < kc && j < kc) v += w_side * CtC[(size_t)i * kc + j];
+    if (BiTBi != nullptr && i < ki && j < ki) v += w_imp * BiTBi[(size_t)i * ki + j];
+    out[e] = v;
+}
+template <typename T>
+__global__ void block_rconst_kernel(const T *__restrict__ UC, int kc, T w_side, const T *__restrict__ gsum, int ki, T w_imp, int k, size_t rows,
+                                    T *__restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * (size_t)k) return;
+    const size_t r = e / k; const int f = (int)(e % k);
+    T v = T(0);
+    if (UC != nullptr && f < kc) v += w_side * UC[r * kc + f];
+    if (gsum != nullptr && f < ki) v += w_imp * gsum[r * ki + f];
+    out[e] = v;
+}
+
 }  // namespace cmfhip

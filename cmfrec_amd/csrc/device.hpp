@@ -251,6 +251,7 @@ struct DeviceInfo {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    DevBuf<real_t> cg_gfull, cg_rconst;   // block systems on the tiled CG kernels: weighted Gramian (k x k) and per-row constants
     DevBuf<real_t> tile_init;       // initial matrices of a Cholesky launch in tile-linear layout (chol_wave_kernels.hpp, tile_pack_kernel)
     DevBuf<int> row_counter;        // work counters of the dynamically scheduled row kernels (zeroed before each launch)
     // second stream + events for two row kernels that may overlap (heavy-row teams beside light-row teams); created on
@@ -412,6 +413,7 @@ struct CgCall {
     const real_t *Bi = nullptr, *BiTBi = nullptr;
     int ki = 0;
     real_t w_imp = 0;
+    const real_t *gsum = nullptr;     // [rows, ki]: sum of the rows of Bi at each row's observed positions (segmented gather-sum), or null
 };
 
 enum class CgVariant { Auto, Generic };
@@ -421,7 +423,7 @@ CgVariant cg_variant_from_env();
 constexpr size_t ROW_COUNTER_INTS = 64 + (size_t)NBINS * CG_NCOUNTERS * CG_COUNTER_STRIDE;
 inline size_t cg_counter_offset(int bin) { return 64 + (size_t)bin * CG_NCOUNTERS * CG_COUNTER_STRIDE; }
 
-template <int S, bool IMPLICIT, int W, int RPB>
+template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
 inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
 {
     if (count <= 0) return;
@@ -436,8 +438,8 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     P.nrows = count;
     P.counter = dev.row_counter.ptr + cg_counter_offset(bin);          // zeroed by launch_cg_S
     constexpr int threads = 64 * W * RPB;
-    size_t smem = ((IMPLICIT ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
-    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB>;
+    size_t smem = (((IMPLICIT || GRAMX) ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
+    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB, GRAMX>;
     // per device: the dynamic-LDS attribute and the occupancy belong to the device the kernel was loaded on
     static thread_local int bpc_dev[MAX_DEVICES] = {0};
     int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
@@ -458,7 +460,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
-template <int S, bool IMPLICIT>
+template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st)
 {
     if (count <= 0) return;
@@ -472,8 +474,8 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     P.desc += first;
     P.nrows = count;
     P.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
-    size_t smem = (IMPLICIT ? (size_t)64 * gram_ld(S) : 0) * sizeof(real_t);
-    auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT>;
+    size_t smem = ((IMPLICIT || GRAMX) ? (size_t)64 * gram_ld(S) : 0) * sizeof(real_t);
+    auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX>;
     static thread_local int bpc_dev[MAX_DEVICES] = {0};
     int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
     if (blocks_per_cu == 0) {
@@ -491,7 +493,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
 }
 
 // very heavy rows: one (pass, update) launch pair per CG pass
-template <int S, bool IMPLICIT>
+template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const SparseShard &X, BinTimers *tm, hipStream_t st)
 {
     const int nvh = X.bin_rows[BIN_VHEAVY];
@@ -508,7 +510,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     // 107-141 cycles on this part, no faster than the FP64 VALU, so 6x the flops do not pay for 4x fewer bytes.
     // Kept as an option (and as an on-device cross-check of the split-row path); default: stream.
     const char *vh_env = getenv("CMFREC_HIP_VH");
-    const bool use_gram = (vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram();     // "stream" / "gram" force one
+    const bool use_gram = !GRAMX && ((vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram());     // "stream" / "gram" force one
     if (P.k <= 16 * GRAM_NTT && use_gram) {
         // one gather: Gramian slices on the matrix cores, then CG on the k x k system (gram_cg_kernels.hpp)
         GramParams<real_t> G;
@@ -533,10 +535,10 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     P.nrows = nvh;
     const dim3 gp(X.n_launch), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64 * VH_UPD_WAVES);
     hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 0>), gp, bp, 0, dev.stream, P, V);
-    hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0>), gu, bu, 0, dev.stream, P, V);
+    hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0, GRAMX>), gu, bu, 0, dev.stream, P, V);
     for (int step = 0; step < P.max_cg_steps; step++) {
         hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 1>), gp, bp, 0, dev.stream, P, V);
-        hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 1>), gu, bu, 0, dev.stream, P, V);
+        hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 1, GRAMX>), gu, bu, 0, dev.stream, P, V);
     }
     HIP_CHECK(hipGetLastError());
     if (tm) {
@@ -545,7 +547,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     }
 }
 
-template <int S, bool IMPLICIT>
+template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm)
 {
     // Few split rows (less than about one round of workgroups per pass: the users of C2) make their launch sequence --
@@ -566,13 +568,13 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
         HIP_CHECK(hipStreamWaitEvent(d.aux_stream, d.fork_ev, 0));
     }
     hipStream_t s0 = dev.stream, s1 = alt ? d.aux_stream : dev.stream;
-    launch_cg_vheavy<S, IMPLICIT>(dev, P, X, tm, (vh_aside || (alt && X.is_part)) ? d.aux_stream : dev.stream);
+    launch_cg_vheavy<S, IMPLICIT, GRAMX>(dev, P, X, tm, (vh_aside || (alt && X.is_part)) ? d.aux_stream : dev.stream);
     // then longest rows first: they are the longest-running teams
-    launch_cg_bin<S, IMPLICIT, 8, 1>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY, s0);
-    launch_cg_bin<S, IMPLICIT, 4, 1>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4, s1);
-    launch_cg_bin<S, IMPLICIT, 2, 1>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2, s0);
-    launch_cg_bin<S, IMPLICIT, 1, 4>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT, s1);
-    launch_cg_tiny<S, IMPLICIT>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, s0);
+    launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY, s0);
+    launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4, s1);
+    launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2, s0);
+    launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT, s1);
+    launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, s0);
     if (vh_aside || alt) {
         HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
         HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));
@@ -622,8 +624,48 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     if (c.X2) { P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr; P.C2 = c.C2; }
     P.Bi = c.Bi; P.BiTBi = c.BiTBi; P.ki = c.ki; P.w_imp = c.w_imp;
     const int S = (c.k + 7) / 8;
-    // the Jacobi-preconditioned variants (not a default anywhere in the reference) and the block systems with side
-    // information run on the generic kernel
+    // Block systems (dense side information on EVERY row of the launch and / or implicit features, no k_user offset) on the
+    // tiled kernels: the weighted Gramian w C^T C + w_i Bi^T Bi acts on the unknowns like the implicit model's B^T B, the row's
+    // constant w (U C)_row + w_i sum Bi_j joins the first residual (GRAMX builds, cg_kernels.hpp).  Rows without entries
+    // (still solved from their side information / zeroed) go through the generic kernel afterwards.
+    static const bool block_generic = getenv("CMFREC_HIP_BLOCK_CG_GENERIC") != nullptr;      // A/B switch and cross-check
+    const bool block = (c.kc > 0 || c.Bi != nullptr);
+    const bool tiled_block = block && !block_generic && cg_variant_from_env() != CgVariant::Generic && !c.implicit && c.koff == 0 && !c.precond &&
+                             S <= 8 && c.X2 == nullptr && (c.kc == 0 || (c.rows_with_u >= X.nrows && c.CtC != nullptr && c.UC != nullptr)) &&
+                             (c.Bi == nullptr || (c.gsum != nullptr && c.BiTBi != nullptr)) && c.kc <= c.k && c.ki <= c.k;
+    if (tiled_block) {
+        DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+        d.cg_gfull.alloc_at_least((size_t)c.k * c.k);
+        d.cg_rconst.alloc_at_least((size_t)std::max(X.nrows, 1) * c.k);
+        hipLaunchKernelGGL(block_gram_kernel<real_t>, dim3((c.k * c.k + 255) / 256), dim3(256), 0, dev.stream, c.CtC, c.kc, c.w_side, c.BiTBi,
+                           c.ki, c.w_imp, c.k, d.cg_gfull.ptr);
+        hipLaunchKernelGGL(block_rconst_kernel<real_t>, dim3((unsigned)(((size_t)X.nrows * c.k + 255) / 256)), dim3(256), 0, dev.stream, c.UC, c.kc,
+                           c.w_side, c.gsum, c.ki, c.w_imp, c.k, (size_t)X.nrows, d.cg_rconst.ptr);
+        P.BtB = d.cg_gfull.ptr; P.rconst = d.cg_rconst.ptr; P.ldr = (size_t)c.k;
+#define CMF_BCASE(SS) case SS: launch_cg_S<SS, false, true>(dev, P, X, tm); break;
+        switch (S) {
+            CMF_BCASE(1) CMF_BCASE(2) CMF_BCASE(3) CMF_BCASE(4)
+            CMF_BCASE(5) CMF_BCASE(6) CMF_BCASE(7) CMF_BCASE(8)
+        }
+#undef CMF_BCASE
+        if (X.nrows > X.n_nonempty) {
+            // rows without entries: solved from their side information alone / zeroed (collective.c:1258-1268), one wavefront per row
+            CgParams<real_t> Pe = P;
+            Pe.BtB = c.BtB; Pe.rconst = nullptr;
+            Pe.row_first = X.n_nonempty; Pe.nrows = X.nrows;
+            const int cnt = X.nrows - X.n_nonempty;
+            const int NFe = (c.koff + c.k + 63) / 64;
+            const int grid = std::min((cnt + 3) / 4, dev.num_cus * 8);
+            switch (NFe) {
+                case 1: hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, 1, false, 1>), dim3(grid), dim3(256), 0, dev.stream, Pe); break;
+                default: hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, 2, false, 1>), dim3(grid), dim3(256), 0, dev.stream, Pe); break;
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // the Jacobi-preconditioned variants (not a default anywhere in the reference) and the remaining block systems run on the
+    // generic kernel
     const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond || c.kc > 0 || c.Bi != nullptr;
     if (!generic) {
 #define CMF_CASE(SS)                                                        \

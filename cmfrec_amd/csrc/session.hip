@@ -154,7 +154,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 else if (nbw <= 4) wlaunch(WAVE_KERN(4, 3, 2, 0), 4, 2);
                 else if (nbw <= 6) wlaunch(WAVE_KERN(6, 2, 1, 0), 6, 1);
                 // 7 and 8 blocks in double: two kernels, see below
-                else if (wmode == 1) wlaunch(WAVE_KERN_M(8, 3, 1, 4, 1), 8, 1);
+                else if (wmode == 1) wlaunch(WAVE_KERN_M(8, 3, 1, 32, 1), 8, 1);      // 32 tiles per sweep
                 else wlaunch((border ? chol_wave_kernel<real_t, 8, true, 1, 1, 6, 2, true> : chol_wave_kernel<real_t, 8, false, 1, 1, 6, 2, true>), 8, 1);
 #endif
 #undef WAVE_KERN
@@ -1218,6 +1218,22 @@ static int solve_sideinfo_only_rows(cmfrec_hip_session *s, bool isA, bool chol, 
     return launch_chol(dev, c, nullptr, count);                                                    // common.c:2872-2875
 }
 
+// sum of the rows of F (Bi / Ai) at every row's observed positions, by the two-stage segmented gather-sum; result in s->grhs
+// [X.nrows, kk].  Returns false when the tables / widths do not allow it (the caller then gathers inside the row kernel).
+static bool launch_gsum(cmfrec_hip_session *s, bool isA, const SparseShard &X, const real_t *Fi, int kk)
+{
+    auto &G = s->gsegs[isA ? 0 : 1];
+    if (kk > 64 * GSUM_MAXC || s->grhs.ptr == nullptr) return false;
+    hipStream_t st = s->dev.stream;
+    if (G.nseg > 0)
+        hipLaunchKernelGGL(gather_sum_segments_kernel<real_t>, dim3((G.nseg + 3) / 4), dim3(256), 0, st, X.p.ptr, X.i.ptr, Fi, (size_t)kk, kk,
+                           G.seg_row.ptr, G.seg_off.ptr, G.nseg, s->gpartial.ptr);
+    hipLaunchKernelGGL(gather_sum_rows_kernel<real_t>, dim3((X.nrows + 3) / 4), dim3(256), 0, st, s->gpartial.ptr, G.row_first.ptr, X.nrows, kk,
+                       s->grhs.ptr, (size_t)kk);
+    HIP_CHECK(hipGetLastError());
+    return true;
+}
+
 static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = -1)
 {
     const cmfrec_hip_model &m = s->mdl;
@@ -1340,6 +1356,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
             const real_t *Fi = isA ? s->Bi.ptr : s->Ai.ptr;
             launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, (real_t)1, (real_t)0);
             c.Bi = Fi; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
+            if (part < 0 && launch_gsum(s, isA, X, Fi, kk)) c.gsum = s->grhs.ptr;
         }
         int rc = launch_cg(dev, c, X, nullptr);
         if (rc) return rc;
@@ -1472,6 +1489,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         const real_t *Fc = isA ? s->Bi.ptr : s->Ai.ptr;
         launch_gram(dev, s->gws, Fc, (size_t)kk, rows_opp, kk, s->bitbi.ptr, (real_t)1, (real_t)0);
         c.Bi = Fc; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
+        if (part < 0 && launch_gsum(s, isA, X, Fc, kk)) c.gsum = s->grhs.ptr;
     }
     return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
 }
