@@ -142,41 +142,144 @@ __device__ __forceinline__ T treduce8_high(const T (&v)[8], int lane)
 // LDS leading dimension for the staged Gramian: odd, so that the jj-groups of a lane group land on
 // distinct banks both for ds_read_b64 (32 lanes, 64 banks) and ds_read2_b64 (16 lanes, 32 banks).
 __host__ __device__ constexpr int gram_ld(int S) { return 8 * S + 1; }
+// Single precision keeps the Gramian's rows 2q and 2q+1 interleaved -- element (r, c) at 2 ((r >> 1) LD2 + c) + (r & 1),
+// LD2 = 8 S + 2 -- so that one ds_read_b64 brings the register pair a v_pk_fma_f32 wants; 4 LD2 = 8 (mod 32) keeps the
+// four jj-groups of a half-wave on distinct banks.
+__host__ __device__ constexpr int gram_ld2(int S) { return 8 * S + 2; }
+template <typename T> __host__ __device__ constexpr int gram_elems(int S) { return sizeof(T) == 4 ? 64 * gram_ld2(S) : 64 * gram_ld(S); }
+template <typename T, int S> __device__ __forceinline__ int gram_index(int r, int c)
+{
+    if constexpr (sizeof(T) == 4) return 2 * ((r >> 1) * gram_ld2(S) + c) + (r & 1);
+    else return r * gram_ld(S) + c;
+}
+// stage the k x k Gramian (row-major, ld = k) of a launch in LDS, zero-padded to 64 x 8 S
+template <typename T, int S>
+__device__ __forceinline__ void stage_gramian(T *__restrict__ G, const T *__restrict__ BtB, int k, int tid, int nthreads)
+{
+    for (int e = tid; e < 64 * 8 * S; e += nthreads) {
+        const int r = e / (8 * S), c = e % (8 * S);
+        G[gram_index<T, S>(r, c)] = (r < k && c < k) ? BtB[(size_t)r * k + c] : T(0);
+    }
+}
 
 template <typename T, int S>
 struct RegTile {
     T v[8][S];
+    __device__ __forceinline__ void set(int t, int s, T x) { v[t][s] = x; }
+};
+// Single precision: the entries 2q and 2q+1 of a lane's tile sit in one aligned register pair, so that both products of
+// the tile pass (c_j = B_j . v with v broadcast; out += w_j B_j with one partial sum per entry parity) and the Gramian
+// product issue as v_pk_fma_f32 -- two FMAs per lane and instruction, the f32 VALU peak of this part.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int S>
+struct RegTile<float, S> {
+    f32x2 v[4][S];
+    __device__ __forceinline__ void set(int t, int s, float x) { v[t >> 1][s][t & 1] = x; }
 };
 
+// accumulators of one pass, out[s] for the factor columns ll + 8 s (float: two partial sums per column, added by close())
+template <typename T>
+struct PassAcc {
+    T v[8];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = T(0);
+    }
+    __device__ __forceinline__ void close(T (&out)[8]) const
+    {
+#pragma unroll
+        for (int s = 0; s < 8; s++) out[s] = v[s];
+    }
+};
+template <>
+struct PassAcc<float> {
+    f32x2 v[8];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = f32x2{0.f, 0.f};
+    }
+    __device__ __forceinline__ void close(float (&out)[8]) const
+    {
+#pragma unroll
+        for (int s = 0; s < 8; s++) out[s] = v[s][0] + v[s][1];
+    }
+};
+
+// Branch-free (like load_tile4 below): slots past the end of the tile re-read the row of the tile's first entry (their
+// weight w_j is forced to zero by `valid`), factor columns past k re-read column k-1 (their vrep / Gramian entries are
+// zero and the result lanes >= k are cleared).  One v_mad_u64_u32 per gathered row forms its address.
 template <typename T, int S>
 __device__ __forceinline__ void load_tile(RegTile<T, S> &tile, const T *__restrict__ Bm, size_t ldb,
                                           int k, int my_idx, int cnt, int lane)
 {
     const int jj = lane >> 3, ll = lane & 7;
-    const bool last_ok = (ll + 8 * (S - 1)) < k;
     int its[8];
     its[0] = lanes::bcast8<0>(my_idx); its[1] = lanes::bcast8<1>(my_idx); its[2] = lanes::bcast8<2>(my_idx);
     its[3] = lanes::bcast8<3>(my_idx); its[4] = lanes::bcast8<4>(my_idx); its[5] = lanes::bcast8<5>(my_idx);
     its[6] = lanes::bcast8<6>(my_idx); its[7] = lanes::bcast8<7>(my_idx);
+    const int first_idx = __builtin_amdgcn_readfirstlane(my_idx);
+    const int col_last = min(ll + 8 * (S - 1), k - 1) - ll;
+    const char *base = reinterpret_cast<const char *>(Bm + ll);
+    const unsigned ldb_bytes = (unsigned)(ldb * sizeof(T));
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        int it = its[t];
-        bool valid = (jj * 8 + t) < cnt;
-        const T *rp = Bm + (size_t)it * ldb + ll;
+        const unsigned it = (unsigned)(((jj * 8 + t) < cnt) ? its[t] : first_idx);
+        const T *rp = reinterpret_cast<const T *>(base + (unsigned long long)it * ldb_bytes);
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            bool ok = valid && (s < S - 1 || last_ok);
-            tile.v[t][s] = ok ? rp[8 * s] : T(0);
-        }
+        for (int s = 0; s < S; s++) tile.set(t, s, rp[(s < S - 1) ? 8 * s : col_last]);
     }
 }
 
 // One tile contribution:  c_j = B_j . vrep ; w_j = f(c_j, x_j) ; out[s] += sum_t w_j B_j[s]
 // MODE 0: residual pass, MODE 1: A*p pass.
+template <typename T, bool IMPLICIT, int MODE>
+__device__ __forceinline__ T pass_weight(T coef, T x, bool valid)
+{
+    T w;
+    if (IMPLICIT) {
+        if (MODE == 0) w = -(coef - T(1)) * x - coef;     // common.c:1939
+        else           w = coef * (x - T(1)) + coef;      // common.c:1965
+    } else {
+        if (MODE == 0) w = -(coef - x);                   // common.c:1121-1123
+        else           w = coef;                          // common.c:1158-1159
+    }
+    return valid ? w : T(0);
+}
+
+template <int S, bool IMPLICIT, int MODE>
+__device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, const float (&vrep)[S], float x, bool valid,
+                                          PassAcc<float> &out, int lane)
+{
+    float c[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; s++) acc += tile.v[q][s] * f32x2{vrep[s], vrep[s]};
+        c[2 * q] = acc[0]; c[2 * q + 1] = acc[1];
+    }
+    float coef = treduce8_low<float>(c, lane);
+    const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid);
+    float wts[8];
+    wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
+    wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += w2 * tile.v[q][s];
+    }
+}
+
 template <typename T, int S, bool IMPLICIT, int MODE>
 __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid,
-                                          T (&out)[8], int lane)
+                                          PassAcc<T> &out, int lane)
 {
+    if constexpr (std::is_same<T, float>::value) {
+        tile_pass_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+    } else {
     T c[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
@@ -186,29 +289,22 @@ __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&v
         c[t] = acc;
     }
     T coef = treduce8_low<T>(c, lane);           // lane j now holds B_j . v
-    T w;
-    if (IMPLICIT) {
-        if (MODE == 0) w = -(coef - T(1)) * x - coef;     // common.c:1939
-        else           w = coef * (x - T(1)) + coef;      // common.c:1965
-    } else {
-        if (MODE == 0) w = -(coef - x);                   // common.c:1121-1123
-        else           w = coef;                          // common.c:1158-1159
-    }
-    if (!valid) w = T(0);
+    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid);
     T wts[8];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
     wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
 #pragma unroll
     for (int t = 0; t < 8; t++) {
 #pragma unroll
-        for (int s = 0; s < S; s++) out[s] += wts[t] * tile.v[t][s];
+        for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
+    }
     }
 }
 
 // out[s] += sum_j wdist_j * G[j][ll+8s]  with the Gramian staged in LDS (rows padded to 64).
 // The 8 row-slices t are dealt to the W waves of the team (wave wr takes t = wr, wr+W, ...).
 template <typename T, int S, int W>
-__device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, T (&out)[8], int lane, int wr)
+__device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, PassAcc<T> &out, int lane, int wr)
 {
     constexpr int LD = gram_ld(S);
     const int jj = lane >> 3, ll = lane & 7;
@@ -216,12 +312,26 @@ __device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, T (&
     wts[0] = lanes::bcast8<0>(wdist); wts[1] = lanes::bcast8<1>(wdist); wts[2] = lanes::bcast8<2>(wdist);
     wts[3] = lanes::bcast8<3>(wdist); wts[4] = lanes::bcast8<4>(wdist); wts[5] = lanes::bcast8<5>(wdist);
     wts[6] = lanes::bcast8<6>(wdist); wts[7] = lanes::bcast8<7>(wdist);
+    if constexpr (std::is_same<T, float>::value && W <= 4) {
+        // row pairs (2q, 2q+1) of the lane's eight Gramian rows, dealt to the waves; one ds_read2_b32 fetches both
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        if (W > 1 && (t % W) != wr) continue;
-        const T *g = G + (jj * 8 + t) * LD + ll;
+        for (int q = 0; q < 4; q++) {
+            if (W > 1 && (q % W) != wr) continue;
+            const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (jj * 4 + q) * gram_ld2(S) + ll;
+            const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
 #pragma unroll
-        for (int s = 0; s < S; s++) out[s] += wts[t] * g[8 * s];
+            for (int s = 0; s < S; s++) out.v[s] += w2 * g[8 * s];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (W > 1 && (t % W) != wr) continue;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
+                else out.v[s] += wts[t] * G[(jj * 8 + t) * LD + ll + 8 * s];
+            }
+        }
     }
 }
 
@@ -242,11 +352,10 @@ template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
 __global__ void __launch_bounds__(64 * W * RPB, CMF_CG_WAVES_PER_SIMD)
 cg_rows_kernel(const CgParams<T> P)
 {
-    constexpr int LD = gram_ld(S);
     constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);                                  // [64][LD] (implicit / block systems)
-    T *red = G + (GRAM ? 64 * LD : 0);                                       // [RPB][2][W][64]
+    T *red = G + (GRAM ? gram_elems<T>(S) : 0);                              // [RPB][2][W][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -283,12 +392,7 @@ cg_rows_kernel(const CgParams<T> P)
         s_claim[2] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
         s_claim[3] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
     }
-    if (GRAM) {
-        for (int e = tid; e < 64 * LD; e += blockDim.x) {
-            int r = e / LD, c = e % LD;
-            G[e] = (r < k && c < k) ? P.BtB[(size_t)r * k + c] : T(0);
-        }
-    }
+    if (GRAM) stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
     if (GRAM || W > 1) __syncthreads();
     if (W > 1) { rnxt = s_claim[2]; rnn = s_claim[3]; }
     T *myred = red + (size_t)grp * 2 * W * 64;
@@ -364,9 +468,8 @@ cg_rows_kernel(const CgParams<T> P)
             asm volatile("" ::: "memory");
             T vrep[S];
             replicate<T, S>(vdist, vrep, lane);
-            T out[8];
-#pragma unroll
-            for (int s = 0; s < 8; s++) out[s] = T(0);
+            PassAcc<T> acc;
+            acc.zero();
             for (int tl = wr; tl < ntiles; tl += W) {
                 T x; bool valid;
                 const bool have = (tl == wr) && (resident || first);   // still in registers
@@ -381,10 +484,12 @@ cg_rows_kernel(const CgParams<T> P)
                 } else {
                     x = x_res; valid = valid_res;
                 }
-                tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+                tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
             }
             if (GRAM)
-                gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, out, lane, wr);   // common.c:1932 / :1958; collective.c:2609-2643
+                gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, acc, lane, wr);   // common.c:1932 / :1958; collective.c:2609-2643
+            T out[8];
+            acc.close(out);
             T tot = treduce8_high<T>(out, lane);                              // lane f <- element f
             if (W > 1) {
                 T *rb = myred + (size_t)buf * W * 64;
@@ -443,6 +548,12 @@ constexpr int TILE4 = 32;
 template <typename T, int S>
 struct RegTile4 {
     T v[4][S];
+    __device__ __forceinline__ void set(int t, int s, T x) { v[t][s] = x; }
+};
+template <int S>
+struct RegTile4<float, S> {
+    f32x2 v[2][S];
+    __device__ __forceinline__ void set(int t, int s, float x) { v[t >> 1][s][t & 1] = x; }
 };
 
 // lanes 2t and 2t+1 of every 8-lane group carry non-zero jj*4+t (my_idx / x are loaded with
@@ -464,7 +575,7 @@ __device__ __forceinline__ void load_tile4(RegTile4<T, S> &tile, const T *__rest
         const int it = ((jj * 4 + t) < cnt) ? its[t] : first_idx;
         const T *rp = Bm + (size_t)it * ldb + ll;
 #pragma unroll
-        for (int s = 0; s < S; s++) tile.v[t][s] = rp[(s < S - 1) ? 8 * s : col_last];
+        for (int s = 0; s < S; s++) tile.set(t, s, rp[(s < S - 1) ? 8 * s : col_last]);
     }
 }
 
@@ -485,10 +596,37 @@ __device__ __forceinline__ T treduce4_low(const T (&v)[4], int lane)
     return q + lanes::xor1(q);          // lanes 2t, 2t+1 both hold the total of v[t]
 }
 
+template <int S, bool IMPLICIT, int MODE>
+__device__ __forceinline__ void tile_pass4_f32(const RegTile4<float, S> &tile, const float (&vrep)[S], float x, bool valid,
+                                           PassAcc<float> &out, int lane)
+{
+    float c[4];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; s++) acc += tile.v[q][s] * f32x2{vrep[s], vrep[s]};
+        c[2 * q] = acc[0]; c[2 * q + 1] = acc[1];
+    }
+    float coef = treduce4_low<float>(c, lane);
+    const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid);
+    float wts[4];
+    wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<2>(w); wts[2] = lanes::bcast8<4>(w); wts[3] = lanes::bcast8<6>(w);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += w2 * tile.v[q][s];
+    }
+}
+
 template <typename T, int S, bool IMPLICIT, int MODE>
 __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (&vrep)[S], T x, bool valid,
-                                           T (&out)[8], int lane)
+                                           PassAcc<T> &out, int lane)
 {
+    if constexpr (std::is_same<T, float>::value) {
+        tile_pass4_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+    } else {
     T c[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -498,21 +636,14 @@ __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (
         c[t] = acc;
     }
     T coef = treduce4_low<T>(c, lane);
-    T w;
-    if (IMPLICIT) {
-        if (MODE == 0) w = -(coef - T(1)) * x - coef;     // common.c:1939
-        else           w = coef * (x - T(1)) + coef;      // common.c:1965
-    } else {
-        if (MODE == 0) w = -(coef - x);                   // common.c:1121-1123
-        else           w = coef;                          // common.c:1158-1159
-    }
-    if (!valid) w = T(0);
+    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid);
     T wts[4];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<2>(w); wts[2] = lanes::bcast8<4>(w); wts[3] = lanes::bcast8<6>(w);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
 #pragma unroll
-        for (int s = 0; s < S; s++) out[s] += wts[t] * tile.v[t][s];
+        for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
+    }
     }
 }
 
@@ -524,7 +655,6 @@ template <typename T, int S, bool IMPLICIT, bool GRAMX = false>
 __global__ void __launch_bounds__(256, CMF_TINY_WAVES_PER_SIMD)
 cg_rows_tiny_kernel(const CgParams<T> P)
 {
-    constexpr int LD = gram_ld(S);
     constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);
@@ -532,10 +662,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     const int lane = tid & 63;
     const int k = P.k;
     if (GRAM) {
-        for (int e = tid; e < 64 * LD; e += blockDim.x) {
-            int r = e / LD, c = e % LD;
-            G[e] = (r < k && c < k) ? P.BtB[(size_t)r * k + c] : T(0);
-        }
+        stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
         __syncthreads();
     }
     const int nwaves = gridDim.x * 4;
@@ -581,11 +708,12 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             asm volatile("" ::: "memory");
             T vrep[S];
             replicate<T, S>(vdist, vrep, lane);
+            PassAcc<T> acc;
+            acc.zero();
+            tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane);
+            if (GRAM) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
-#pragma unroll
-            for (int s = 0; s < 8; s++) out[s] = T(0);
-            tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, out, lane);
-            if (GRAM) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, out, lane, 0);
+            acc.close(out);
             return treduce8_high<T>(out, lane);
         };
         T r_d = run_pass(a_d, std::integral_constant<int, 0>{});
@@ -679,6 +807,18 @@ cg_rows_tiny_kernel(const CgParams<T> P)
 // pass; kernel boundaries are the grid-wide synchronisation.
 constexpr int VH_CHUNK_TILES = 4;
 
+// One workgroup of the pass kernel, in launch order: everything it needs to find its non-zeros in ONE 32-byte (scalar)
+// load -- the chain launch[] -> chunk_row[] -> order[] -> indptr[] -> indices[] -> gather was six dependent round trips
+// per workgroup, and a pass is a few rounds of short-lived workgroups.
+struct VhWork {
+    int vi;                 // index of the very heavy row (position in `order`), -1: no chunk at this launch position
+    int row;                // its row id
+    int cnt;                // non-zeros of the chunk
+    int chunk;              // chunk id (where its partial goes)
+    unsigned long long st;  // CSR position of the chunk's first non-zero
+    unsigned long long pad_;
+};
+
 template <typename T>
 struct VhState {
     T *r, *p;               // [nvh][64] distributed CG vectors (a lives in the factor matrix itself)
@@ -690,6 +830,7 @@ struct VhState {
     const int *chunk_cnt;   // [nchunks] non-zeros of the chunk (<= 64 * VH_CHUNK_TILES)
     const int *chunk_off;   // [nvh+1] chunk range of every row
     const int *launch;      // [nlaunch] workgroup -> chunk (-1: none): chunks of one range of gathered rows share an XCD
+    const VhWork *work;     // [nlaunch] the same map with the chunk's row, length and CSR position resolved
     int nvh, nchunks, nlaunch;
 };
 
@@ -699,21 +840,21 @@ vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
 {
     __shared__ T red[VH_CHUNK_TILES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = V.launch[blockIdx.x];
-    if (c < 0) return;
-    const int vi = V.chunk_row[c];
+    const VhWork wk = V.work[blockIdx.x];
+    const int vi = wk.vi;
+    if (vi < 0) return;
     if (MODE == 1 && V.done[vi]) return;
-    const int row = P.order[vi];
-    const size_t st = P.indptr[row] + (size_t)V.chunk_start[c];
-    const int nnz = V.chunk_cnt[c];          // of this chunk
+    const int c = wk.chunk;
+    const int row = wk.row;
+    const size_t st = (size_t)wk.st;
+    const int nnz = wk.cnt;                  // of this chunk
     const int tl = wave;
     const int k = P.k;
     T vdist;
     if (MODE == 0) vdist = (lane < k) ? P.A[(size_t)row * P.lda + lane] : T(0);
     else           vdist = V.p[(size_t)vi * 64 + lane];
-    T out[8];
-#pragma unroll
-    for (int s = 0; s < 8; s++) out[s] = T(0);
+    PassAcc<T> acc;
+    acc.zero();
     if (tl * TILE < nnz) {
         const int cnt = min(TILE, nnz - tl * TILE);
         const bool valid = lane < cnt;
@@ -725,8 +866,10 @@ vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
         load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
         T vrep[S];
         replicate<T, S>(vdist, vrep, lane);
-        tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+        tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
     }
+    T out[8];
+    acc.close(out);
     T tot = treduce8_high<T>(out, lane);
     red[wave][lane] = tot;
     __syncthreads();

@@ -145,6 +145,7 @@ struct SparseShard {
     // split-row work list and CG state of the very heavy rows (cg_kernels.hpp, VhState)
     int n_chunks = 0;
     DevBuf<int> vh_chunk_row, vh_chunk_start, vh_chunk_cnt, vh_chunk_off, vh_launch, vh_done;
+    DevBuf<VhWork> vh_work;
     int n_launch = 0;
     DevBuf<real_t> vh_r, vh_p, vh_r_old, vh_part;
     // Gramian path of the very heavy rows (gram_cg_kernels.hpp): slices of <= GRAM_SLICE non-zeros
@@ -195,6 +196,21 @@ struct SparseShard {
         vh_chunk_off.upload(c_off.data(), c_off.size(), st);
         vh_launch.upload(launch.data(), launch.size(), st);
         vh_part.alloc((size_t)n_chunks * 64);
+        // resolved work items of the pass kernel (the split rows lead the processing order: desc[vi] is row vi of them)
+        const int nvh = (int)c_off.size() - 1;
+        std::vector<RowDesc> hd((size_t)std::max(nvh, 1));
+        HIP_CHECK(hipMemcpyAsync(hd.data(), desc.ptr, (size_t)nvh * sizeof(RowDesc), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<VhWork> work(launch.size());
+        for (size_t b = 0; b < launch.size(); b++) {
+            VhWork &w = work[b];
+            const int c = launch[b];
+            w.pad_ = 0;
+            if (c < 0) { w.vi = -1; w.row = 0; w.cnt = 0; w.chunk = 0; w.st = 0; continue; }
+            w.vi = c_row[c]; w.row = hd[w.vi].row; w.cnt = c_cnt[c]; w.chunk = c;
+            w.st = hd[w.vi].st + (unsigned long long)c_start[c];
+        }
+        vh_work.upload(work.data(), work.size(), st);
         HIP_CHECK(hipStreamSynchronize(st));
     }
 
@@ -438,7 +454,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     P.nrows = count;
     P.counter = dev.row_counter.ptr + cg_counter_offset(bin);          // zeroed by launch_cg_S
     constexpr int threads = 64 * W * RPB;
-    size_t smem = (((IMPLICIT || GRAMX) ? (size_t)64 * gram_ld(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
+    size_t smem = (((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
     auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB, GRAMX>;
     // per device: the dynamic-LDS attribute and the occupancy belong to the device the kernel was loaded on
     static thread_local int bpc_dev[MAX_DEVICES] = {0};
@@ -474,7 +490,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     P.desc += first;
     P.nrows = count;
     P.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
-    size_t smem = ((IMPLICIT || GRAMX) ? (size_t)64 * gram_ld(S) : 0) * sizeof(real_t);
+    size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX>;
     static thread_local int bpc_dev[MAX_DEVICES] = {0};
     int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
@@ -530,7 +546,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     VhState<real_t> V;
     V.r = X.vh_r.ptr; V.p = X.vh_p.ptr; V.r_old = X.vh_r_old.ptr; V.done = X.vh_done.ptr; V.part = X.vh_part.ptr;
     V.chunk_row = X.vh_chunk_row.ptr; V.chunk_start = X.vh_chunk_start.ptr; V.chunk_cnt = X.vh_chunk_cnt.ptr;
-    V.chunk_off = X.vh_chunk_off.ptr; V.launch = X.vh_launch.ptr;
+    V.chunk_off = X.vh_chunk_off.ptr; V.launch = X.vh_launch.ptr; V.work = X.vh_work.ptr;
     V.nvh = nvh; V.nchunks = X.n_chunks; V.nlaunch = X.n_launch;
     P.nrows = nvh;
     const dim3 gp(X.n_launch), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64 * VH_UPD_WAVES);

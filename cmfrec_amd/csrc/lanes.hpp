@@ -19,6 +19,13 @@ __device__ __forceinline__ int dpp(int old, int src)
 {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, BANK, false);
 }
+// same without a previous value: every lane the bank mask enables is written (all sources lie inside the row), the other
+// lanes are left undefined -- the caller overwrites them with a second move.  Saves the register copy update_dpp needs.
+template <int CTRL, int BANK>
+__device__ __forceinline__ int dpp_new(int src)
+{
+    return __builtin_amdgcn_mov_dpp(src, CTRL, 0xF, BANK, false);
+}
 
 // ---- apply a dword -> dword lane operation to float / double / int ---------------------------
 template <typename F> __device__ __forceinline__ int map(int x, F f) { return f(x); }
@@ -37,22 +44,22 @@ template <typename F> __device__ __forceinline__ double map2(double a, double b,
     return __hiloint2double(f(__double2hiint(a), __double2hiint(b)), f(__double2loint(a), __double2loint(b)));
 }
 
-template <typename T> __device__ __forceinline__ T xor1(T x) { return map(x, [](int v) { return dpp<QP_XOR1, 0xF>(v, v); }); }
-template <typename T> __device__ __forceinline__ T xor2(T x) { return map(x, [](int v) { return dpp<QP_XOR2, 0xF>(v, v); }); }
+template <typename T> __device__ __forceinline__ T xor1(T x) { return map(x, [](int v) { return dpp_new<QP_XOR1, 0xF>(v); }); }
+template <typename T> __device__ __forceinline__ T xor2(T x) { return map(x, [](int v) { return dpp_new<QP_XOR2, 0xF>(v); }); }
 template <typename T> __device__ __forceinline__ T xor4(T x)
 {
-    return map(x, [](int v) { int t = dpp<ROW_SHL4, 0x5>(v, v); return dpp<ROW_SHR4, 0xA>(t, v); });
+    return map(x, [](int v) { int t = dpp_new<ROW_SHL4, 0x5>(v); return dpp<ROW_SHR4, 0xA>(t, v); });
 }
-template <typename T> __device__ __forceinline__ T xor8(T x) { return map(x, [](int v) { return dpp<ROW_ROR8, 0xF>(v, v); }); }
+template <typename T> __device__ __forceinline__ T xor8(T x) { return map(x, [](int v) { return dpp_new<ROW_ROR8, 0xF>(v); }); }
 
 // lanes with (lane & M) == 0 receive a[lane ^ M], the others b[lane ^ M]  (M = 4 or 8)
 template <typename T> __device__ __forceinline__ T recv_xor4(T a, T b)
 {
-    return map2(a, b, [](int x, int y) { int t = dpp<ROW_SHL4, 0x5>(x, x); return dpp<ROW_SHR4, 0xA>(t, y); });
+    return map2(a, b, [](int x, int y) { int t = dpp_new<ROW_SHL4, 0x5>(x); return dpp<ROW_SHR4, 0xA>(t, y); });
 }
 template <typename T> __device__ __forceinline__ T recv_xor8(T a, T b)
 {
-    return map2(a, b, [](int x, int y) { int t = dpp<ROW_ROR8, 0x3>(x, x); return dpp<ROW_ROR8, 0xC>(t, y); });
+    return map2(a, b, [](int x, int y) { int t = dpp_new<ROW_ROR8, 0x3>(x); return dpp<ROW_ROR8, 0xC>(t, y); });
 }
 
 // result: lanes < 32 : a[l] + a[l+32] ;  lanes >= 32 : b[l-32] + b[l]
@@ -88,7 +95,7 @@ template <int t, typename T> __device__ __forceinline__ T bcast8(T x)
     constexpr int q = t & 3;
     constexpr int QP = q | (q << 2) | (q << 4) | (q << 6);
     return map(x, [](int v) {
-        int y = dpp<QP, 0xF>(v, v);
+        int y = dpp_new<QP, 0xF>(v);
         if (t < 4) return dpp<ROW_SHR4, 0xA>(y, y);      // odd quads fetch from the even quad
         else       return dpp<ROW_SHL4, 0x5>(y, y);      // even quads fetch from the odd quad
     });
