@@ -170,7 +170,7 @@ def main():
             if cnt:
                 name_b = names[b]
                 if b == 0 and sess.vh_mode(which) == 2:
-                    name_b = "gram_slice+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"
+                    name_b = "gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"
                 kernels.append(dict(step=which, kernel=name_b, ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
                                     avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, K),
                                     overlapped=sess.bin_overlaps(which, b)))
@@ -188,8 +188,8 @@ def main():
                   3: ["cg_rows_kernel<double, 7, true, 2, 1>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4>"],
                   5: ["cg_rows_tiny_kernel<double, 7, true>"]}
     inv = {v: b for b, v in names.items()}
-    inv["gram_slice+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
-    prof_names[6] = ["gram_slice_kernel<double, true>", "gram_cg_kernel<double, true>"]
+    inv["gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
+    prof_names[6] = ["gram_wave_kernel<double, true>", "gram_cg_kernel<double, true>"]
     for d in kernels:
         other = [e for e in kernels if e["kernel"] == d["kernel"] and e["step"] != d["step"]]
         # (a launch that runs beside other kernels has no duration of its own, and rocprof's average mixes it in:
@@ -328,7 +328,7 @@ def c4_distributed(args, rank, world, local_rank):
             ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
             if cnt:
                 kernels.append(dict(step=which, kernel=names[b], avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, C4_K, 4),
-                                    overlapped=sess.bin_overlaps(which, b)))
+                                    overlapped=sess.bin_overlaps(which, b), rows=rows_b, nnz=nnz_b, launches=cnt))
     job_bytes = torch.tensor([float(sum(d["alg_bytes"] for d in kernels))], device="cuda", dtype=torch.float64)
     dist.all_reduce(job_bytes)
     roofline = None
@@ -340,7 +340,10 @@ def c4_distributed(args, rank, world, local_rank):
                         achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                         alg_bytes_per_launch=dom["alg_bytes"], avg_launch_ms=round(dom["avg_ms"], 4),
                         iteration={"alg_GB_whole_job": round(float(job_bytes.item()) / 1e9, 3),
-                                   "frac_of_hbm_peak": round(float(job_bytes.item()) / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)})
+                                   "frac_of_hbm_peak": round(float(job_bytes.item()) / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)},
+                        per_kernel_rank0=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4), rows=d["rows"], nnz=d["nnz"],
+                                               launches_timed=d["launches"], GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1))
+                                          for d in kernels])
     final_line = None
     if rank == 0:
         out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=64 fp32",
@@ -424,10 +427,18 @@ def c4_shard(args, device):
     msA, cA = sess.kernel_time("A"); msB, cB = sess.kernel_time("B")
     f = sess.get_factors()
     alg = algorithmic_bytes(nnz, m, k, 4) + algorithmic_bytes(nnz, n, k, 4)
+    bins = {}
+    for which in ("B", "A"):
+        for b in range(6):
+            ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
+            if cnt:
+                bins["%s%d" % (which, b)] = {"ms": round(ms / cnt, 3), "rows": rows_b, "nnz": nnz_b,
+                                             "GBps": round(algorithmic_bytes(nnz_b, rows_b, k, 4) / (ms / cnt * 1e-3) / 1e9, 1)}
     print(json.dumps({"workload": "c4 shard (1/8 of 10M x 1M, nnz 5e8), implicit ALS-CG k=64 fp32, one GPU",
                       "ms_per_iteration": round(dt * 1e3, 3), "rows_per_s": round((m + n) / dt, 1),
                       "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)}, "alg_GB": round(alg / 1e9, 2),
                       "frac_of_hbm_peak": round(alg / dt / 8e12, 3), "m": m, "n": n, "nnz": nnz,
+                      "bins (0: split rows > 1024 nnz, 1: 257..1024, 2: 129..256, 3: 65..128, 4: 33..64, 5: <= 32)": bins,
                       "gen_seconds": round(t_gen, 1), "set_X_coo_seconds": round(t_setx, 2),
                       "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all()),
                       "note": "side measurement, not the headline metric"}))
@@ -562,7 +573,7 @@ def pmc_traffic(dom):
     ks = json.load(open(path))["kernels"]
     tags = {"cg_rows_kernel<W=8>": [", 8, 1>"], "cg_rows_kernel<W=4>": [", 4, 1>"], "cg_rows_kernel<W=2>": [", 2, 1>"],
             "cg_rows_kernel<W=1>": [", 1, 4>"], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel"],
-            "vh_pass": ["vh_pass_kernel", "vh_update_kernel"], "gram_slice": ["gram_slice_kernel", "gram_cg_kernel"]}
+            "vh_pass": ["vh_pass_kernel", "vh_update_kernel"], "gram_wave": ["gram_wave_kernel", "gram_cg_kernel"]}
     want = next(v for k, v in tags.items() if dom["kernel"].startswith(k))
     tot, found = 0.0, False
     for name, ent in ks.items():

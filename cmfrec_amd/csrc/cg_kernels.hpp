@@ -94,7 +94,24 @@ struct CgParams {
     // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
     const T *rconst = nullptr;
     size_t ldr = 0;
+#ifdef CMF_CG_DEBUG
+    int dbg = 0;   // phase skipping for timing experiments (results are wrong): 1 gathers, 2 Gramian product, 4 tile products, 8 dot products
+#endif
 };
+// Timing experiments (tools/gpu/r02_o.sh): a build with -DCMF_CG_DEBUG reads CMFREC_HIP_CG_SKIP and leaves phases out.
+#ifdef CMF_CG_DEBUG
+#define CMF_DBG(P, bit) (((P).dbg & (bit)) != 0)
+#else
+#define CMF_DBG(P, bit) false
+#endif
+template <int NT, int S, typename TILE, typename T>
+__device__ __forceinline__ void dbg_fill_tile(TILE &tile, T val)
+{
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int s = 0; s < S; s++) tile.set(t, s, val);
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return lanes::wave_sum(v); }
@@ -457,7 +474,8 @@ cg_rows_kernel(const CgParams<T> P)
         const int cnt0 = min(TILE, nnz - wr * TILE);
         T x_res = pcur.x;
         bool valid_res = lane < cnt0;
-        if (cnt0 > 0) load_tile<T, S>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
+        if (CMF_DBG(P, 1)) dbg_fill_tile<8, S>(tile, (T)(pcur.idx & 3) * (T)0.001);
+        else if (cnt0 > 0) load_tile<T, S>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
         const RowDesc dnn = load_desc(rnn);
         const Pre pnxt = load_pre(dnxt);
 
@@ -480,13 +498,13 @@ cg_rows_kernel(const CgParams<T> P)
                     int my_idx = valid ? P.indices[pos] : 0;
                     x = valid ? P.values[pos] : T(0);
                     if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
-                    load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
+                    if (!CMF_DBG(P, 1)) load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
                 } else {
                     x = x_res; valid = valid_res;
                 }
-                tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
+                if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
             }
-            if (GRAM)
+            if (GRAM && !CMF_DBG(P, 2))
                 gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, acc, lane, wr);   // common.c:1932 / :1958; collective.c:2609-2643
             T out[8];
             acc.close(out);
@@ -511,7 +529,7 @@ cg_rows_kernel(const CgParams<T> P)
         if (GRAMX && P.rconst != nullptr && lane < k) r_d += P.rconst[(size_t)row * P.ldr + lane];
         if (lane >= k) r_d = T(0);
         T p_d = r_d;
-        T r_old = wave_sum(r_d * r_d);
+        T r_old = CMF_DBG(P, 8) ? T(1) : wave_sum(r_d * r_d);
         // r_old / r_new are bit-identical on every wave of the team (same LDS partials summed in
         // the same order), so the data-dependent exits below are uniform over the workgroup.
         bool done = (r_old <= (T)1e-12);            // common.c:1952 / :1147
@@ -520,10 +538,10 @@ cg_rows_kernel(const CgParams<T> P)
             Ap_d += lam * p_d;
             if (!IMPLICIT && lam != lam_last && lane == k - 1) Ap_d += (lam_last - lam) * p_d;
             if (lane >= k) Ap_d = T(0);
-            T alpha = r_old / wave_sum(Ap_d * p_d);
+            T alpha = CMF_DBG(P, 8) ? T(0.001) : r_old / wave_sum(Ap_d * p_d);
             a_d += alpha * p_d;
             r_d -= alpha * Ap_d;
-            T r_new = wave_sum(r_d * r_d);
+            T r_new = CMF_DBG(P, 8) ? T(0.5) : wave_sum(r_d * r_d);
             if (r_new <= (T)1e-8) done = true;      // common.c:1979 / :1180
             else {
                 p_d = p_d * (r_new / r_old) + r_d;
@@ -710,8 +728,8 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
-            tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane);
-            if (GRAM) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
+            if (!CMF_DBG(P, 4)) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane);
+            if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
             acc.close(out);
             return treduce8_high<T>(out, lane);
@@ -762,7 +780,8 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         RegTile4<T, S> tA;
         int pend = issue_claim();
         while (rix < P.nrows) {
-            load_tile4<T, S>(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
+            if (CMF_DBG(P, 1)) dbg_fill_tile<4, S>(tA, (T)(p0.idx & 3) * (T)0.001);
+            else load_tile4<T, S>(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
             RowDesc d2 = load_desc(rnn);
             Pre p1 = load_pre(d1);
             solve(d0, p0, tA);
@@ -863,10 +882,11 @@ vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
         T x = valid ? P.values[pos] : T(0);
         if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
         RegTile<T, S> tile;
-        load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
+        if (CMF_DBG(P, 1)) dbg_fill_tile<8, S>(tile, (T)(my_idx & 3) * (T)0.001);
+        else load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
         T vrep[S];
         replicate<T, S>(vdist, vrep, lane);
-        tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
+        if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
     }
     T out[8];
     acc.close(out);

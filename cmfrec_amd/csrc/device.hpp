@@ -116,12 +116,14 @@ struct SparseShard {
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
-    // Split rows: stream their gathered rows once per CG pass (default) or read them once and run the CG on the row's
-    // own Gramian (gram_cg_kernels.hpp).  Streaming lives on the rows being shared between the split rows of a launch
-    // -- sorted entries, one slice of the opposing matrix per XCD --: with 15 references per opposing row and pass (C2's
-    // items) it takes 0.89 ms against 1.23 ms; a rank's item block of an 8-GPU run has 2.8 (the opposing matrix is 8
-    // times taller) and streaming costs 2.13 ms against 1.80 ms (tools/microbench/weak_scaling_bstep.py).
-    bool prefer_gram() const { return n_other > 0 && (double)bin_nnz[0] < 3.5 * (double)n_other; }
+    // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
+    // per slice: c4shard's item rows 2.31 -> 1.57 ms, BASELINE config 4 on one GPU 40.6 -> 21.8 ms, C2's items 0.89 ->
+    // 0.73 ms), or stream them once per CG pass (sorted entries, one slice of the opposing matrix per XCD).  Single
+    // precision always takes the Gramian (the matrix cores outrun any gather).  In double precision v_mfma_f64_16x16x4 is no
+    // faster than the VALU, and streaming wins once the split rows of a launch share their opposing rows often enough to live
+    // in L2: 15 references per opposing row (C2's items) still favour the Gramian, 143 (C1, MovieLens-10M-shaped: 1.30
+    // against 1.06 ms for its A-step) do not.  CMFREC_HIP_VH=gram / stream force one.
+    bool prefer_gram() const { return sizeof(real_t) == 4 || (n_other > 0 && (double)bin_nnz[0] < 40.0 * (double)n_other); }
     // few split rows (less than about one round of workgroups per CG pass): their launch sequence is a chain of
     // latencies and runs on the second stream beside the other bins
     bool vh_runs_aside(int num_cus) const
@@ -521,10 +523,9 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         HIP_CHECK(hipEventCreate(&ev.b));
         HIP_CHECK(hipEventRecord(ev.a, dev.stream));
     }
-    // CMFREC_HIP_VH=gram: read the gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp).
-    // Measured on C2 (fp64): 1.53 ms against 1.28 ms for the streaming path below -- v_mfma_f64_16x16x4 issues at
-    // 107-141 cycles on this part, no faster than the FP64 VALU, so 6x the flops do not pay for 4x fewer bytes.
-    // Kept as an option (and as an on-device cross-check of the split-row path); default: stream.
+    // Default: read the gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp); CMFREC_HIP_VH=stream
+    // takes the launch pair per CG pass below (also the on-device cross-check of the Gramian path, and the only path for
+    // k > 64 and for block systems).
     const char *vh_env = getenv("CMFREC_HIP_VH");
     const bool use_gram = !GRAMX && ((vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram());     // "stream" / "gram" force one
     if (P.k <= 16 * GRAM_NTT && use_gram) {
@@ -533,9 +534,17 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         G.sl_vrow = X.sl_vrow.ptr; G.sl_first = X.sl_first.ptr; G.sl_count = X.sl_count.ptr; G.row_sl_off = X.row_sl_off.ptr;
         G.part = X.gram_part.ptr; G.n_slices = X.n_slices; G.nvh = nvh;
         P.nrows = nvh;
-        hipLaunchKernelGGL((gram_slice_kernel<real_t, IMPLICIT>), dim3(std::min(X.n_slices, dev.num_cus * 2)), dim3(64 * GRAM_NW), 0,
+        // slice partials: one wavefront per slice straight from the gather (gram_wave_kernel), or the LDS-staged workgroup
+        // kernel (CMFREC_HIP_GRAM_KERNEL=slice)
+        const char *gk_env = getenv("CMFREC_HIP_GRAM_KERNEL");
+        const bool slice_kernel = gk_env != nullptr && strcmp(gk_env, "slice") == 0;
+        if (slice_kernel)
+            hipLaunchKernelGGL((gram_slice_kernel<real_t, IMPLICIT>), dim3(std::min(X.n_slices, dev.num_cus * 2)), dim3(64 * GRAM_NW), 0,
                            dev.stream, P, G);
-        hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 4)), dim3(256), 0, dev.stream, P, G);
+        else
+            hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), dim3(std::min((X.n_slices + 3) / 4, dev.num_cus * 3)), dim3(256), 0,
+                               dev.stream, P, G);
+        hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 8)), dim3(256), 0, dev.stream, P, G);
         HIP_CHECK(hipGetLastError());
         if (tm) {
             HIP_CHECK(hipEventRecord(ev.b, dev.stream));
@@ -639,6 +648,9 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.rows_with_u = c.rows_with_u; P.p_side = c.p_side; P.scale_lam_sideinfo = c.scale_lam_sideinfo ? 1 : 0;
     if (c.X2) { P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr; P.C2 = c.C2; }
     P.Bi = c.Bi; P.BiTBi = c.BiTBi; P.ki = c.ki; P.w_imp = c.w_imp;
+#ifdef CMF_CG_DEBUG
+    if (const char *e = getenv("CMFREC_HIP_CG_SKIP")) P.dbg = atoi(e);
+#endif
     const int S = (c.k + 7) / 8;
     // Block systems (dense side information on EVERY row of the launch and / or implicit features, no k_user offset) on the
     // tiled kernels: the weighted Gramian w C^T C + w_i Bi^T Bi acts on the unknowns like the implicit model's B^T B, the row's

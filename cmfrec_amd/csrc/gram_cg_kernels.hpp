@@ -169,6 +169,127 @@ gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
     }
 }
 
+// The same slice partial from ONE WAVEFRONT per slice, without LDS and without barriers: the 4 x 16 operand of
+// v_mfma_*_16x16x4 (lane l: row l / 16 of the slab, column l % 16 of the block) is exactly what a coalesced gather delivers
+// -- 16 lanes read 16 consecutive columns of one gathered row, 4 rows per instruction -- so a slab of 4 gathered rows x 64
+// columns lands in 4 VGPRs and feeds all 10 tiles of the upper triangle (A operand: the slab scaled by the row weights, B
+// operand: the slab itself).  Per slab: 4 loads, ~25 VALU instructions (B_j . a for the residual's weights, the weighted
+// row sum v, the scaling), 10 MFMAs -- the matrix pipe is the limit (single precision: 320 of its cycles per 4 non-zeros,
+// 20 cycles per non-zero and CU), and the rows are read once instead of max_cg_steps + 1 times.  Groups of 8 slabs are
+// double-buffered in registers.  Output layout = gram_slice_kernel's, so gram_cg_kernel consumes either.
+template <typename T> constexpr int gw_slabs() { return sizeof(T) == 4 ? 8 : 4; }     // slabs per prefetch group (32 / 16 non-zeros)
+
+template <typename T, bool IMPLICIT>
+__global__ void __launch_bounds__(256, 2)
+gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
+{
+    using Mf = CholMfma<T>;
+    using vec = typename Mf::vec;
+    constexpr int NTT = GRAM_NTT, NTALL = GRAM_NTILES, NS = gw_slabs<T>(), GRP = 4 * NS;
+    const int kt = P.k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kc = lane >> 4, lm = lane & 15;                // slab row of this lane, column inside a 16-column block
+    // column 16 cb + lm; past kt: column kt - 1 again (finite values; gram_cg_kernel ignores those rows / columns of G and v)
+    size_t coff[NTT];
+    bool cok[NTT];
+#pragma unroll
+    for (int cb = 0; cb < NTT; cb++) { cok[cb] = (16 * cb + lm) < kt; coff[cb] = (size_t)min(16 * cb + lm, kt - 1); }
+    const unsigned ldb_bytes = (unsigned)(P.ldb * sizeof(T));
+
+    for (int sl = blockIdx.x * 4 + wave; sl < Gp.n_slices; sl += gridDim.x * 4) {
+        const RowDesc d = P.desc[Gp.sl_vrow[sl]];
+        const size_t st = d.st + (size_t)Gp.sl_first[sl];
+        const int nnz = Gp.sl_count[sl];
+        T a_c[NTT];
+#pragma unroll
+        for (int cb = 0; cb < NTT; cb++) a_c[cb] = (IMPLICIT && cok[cb]) ? P.A[(size_t)d.row * P.lda + coff[cb]] : T(0);
+        vec acc[NTALL];
+#pragma unroll
+        for (int t = 0; t < NTALL; t++) acc[t] = vec{0, 0, 0, 0};
+        T racc[NTT];
+#pragma unroll
+        for (int cb = 0; cb < NTT; cb++) racc[cb] = T(0);
+
+        // entry (lane & 31) of a group: index, value (explicit: minus the fused bias), 1 / 0 for entries past the slice
+        auto load_entries = [&](int c0, int &idx, T &x, T &okf) {
+            const int e = c0 + (lane & (GRP - 1));
+            const bool ok = e < nnz;
+            const size_t pos = st + (size_t)max(min(e, nnz - 1), 0);
+            idx = P.indices[pos];
+            x = P.values[pos];
+            if (!IMPLICIT && P.bias_sub != nullptr) x -= P.bias_sub[idx];
+            okf = ok ? T(1) : T(0);
+        };
+        auto load_slabs = [&](int idx, T (&slab)[NS][NTT]) {
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const unsigned it = (unsigned)__shfl(idx, 4 * q + kc);
+                const T *rp = reinterpret_cast<const T *>(reinterpret_cast<const char *>(P.B) + (unsigned long long)it * ldb_bytes);
+#pragma unroll
+                for (int cb = 0; cb < NTT; cb++) slab[q][cb] = rp[coff[cb]];
+            }
+        };
+        int idx_c, idx_n;
+        T x_c, ok_c, x_n, ok_n;
+        T cur[NS][NTT], nxt[NS][NTT];
+        // (every load below is unconditional -- entries past the slice re-read its last one with weight 0 -- so that the
+        //  loop-carried registers are plain copies: conditional loads into live registers make the compiler keep both sets)
+        load_entries(0, idx_c, x_c, ok_c);
+        load_slabs(idx_c, cur);
+        load_entries(GRP, idx_n, x_n, ok_n);
+        for (int c0 = 0; c0 < nnz; c0 += GRP) {
+            load_slabs(idx_n, nxt);                                            // lands behind this group's MFMAs
+            int idx_nn; T x_nn, ok_nn;
+            load_entries(c0 + 2 * GRP, idx_nn, x_nn, ok_nn);
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const T x = __shfl(x_c, 4 * q + kc), okf = __shfl(ok_c, 4 * q + kc);
+                T wG, wv;
+                if (IMPLICIT) {
+                    T dp = T(0);
+#pragma unroll
+                    for (int cb = 0; cb < NTT; cb++) dp += cur[q][cb] * a_c[cb];
+                    dp += lanes::xor1(dp); dp += lanes::xor2(dp); dp += lanes::xor4(dp); dp += lanes::xor8(dp);   // B_j . a, 16 lanes
+                    wG = x * okf;                                              // common.c:1965
+                    wv = (x - dp) * okf;                                       // common.c:1936-1943 (quirk Q1)
+                } else {
+                    wG = okf;
+                    wv = x * okf;
+                }
+                T sa[NTT];
+#pragma unroll
+                for (int cb = 0; cb < NTT; cb++) {
+                    racc[cb] += wv * cur[q][cb];
+                    sa[cb] = wG * cur[q][cb];
+                }
+                static_for<0, NTALL>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value, bi = tile_bi(t, NTT), bj = tile_bj(t, NTT);
+                    acc[t] = Mf::mma(sa[bi], cur[q][bj], acc[t]);
+                });
+            }
+#pragma unroll
+            for (int q = 0; q < NS; q++)
+#pragma unroll
+                for (int cb = 0; cb < NTT; cb++) cur[q][cb] = nxt[q][cb];
+            idx_c = idx_n; x_c = x_n; ok_c = ok_n;
+            idx_n = idx_nn; x_n = x_nn; ok_n = ok_nn;
+        }
+        T *out = Gp.part + (size_t)sl * GRAM_PART;
+#pragma unroll
+        for (int t = 0; t < NTALL; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[t][r];
+        }
+        // v: the four slab rows of a column sit 16 lanes apart
+#pragma unroll
+        for (int cb = 0; cb < NTT; cb++) {
+            T v = lanes::tswap32_add(racc[cb], racc[cb]);
+            v = lanes::tswap16_add(v, v);
+            if (kc == 0) out[NTALL * 256 + 16 * cb + lm] = cok[cb] ? v : T(0);
+        }
+    }
+}
+
 // one workgroup (256 threads) per very heavy row; wave 0 runs the CG
 template <typename T, bool IMPLICIT>
 __global__ void __launch_bounds__(256)
@@ -190,6 +311,10 @@ gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
             if (!P.scale_bias_const) lam_last *= (T)d.nnz;
         }
         __syncthreads();                      // previous row's CG is done with M
+        // columns kt .. 63 of M stay zero: the dense products below run over all 64 columns, four partial sums at a time
+        if (kt < 64)
+            for (int e = tid; e < 64 * LDM; e += 256) M[e] = T(0);
+        if (kt < 64) __syncthreads();
         // G = sum of the slice partials, in slice order;  M = G + (BtB + lam I | diag(lam .. lam_last)), both triangles
         for (int e = tid; e < NTALL * 256; e += 256) {
             T s = T(0);
@@ -216,14 +341,18 @@ gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
         if (tid < 64) {                       // one wavefront: lane e <-> unknown e
             const bool live = lane < kt;
             T a = live ? arow[lane] : T(0);
-            auto mul = [&](T x) {             // (M x)[lane]
+            auto mul = [&](T x) {             // (M x)[lane];  x is zero on the lanes >= kt
                 vec_s[lane] = x;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                T y = T(0);
-                if (live)
-                    for (int c = 0; c < kt; c++) y += M[lane * LDM + c] * vec_s[c];
+                T y0 = T(0), y1 = T(0), y2 = T(0), y3 = T(0);
+                const T *mrow = M + lane * LDM;
+#pragma unroll
+                for (int c = 0; c < 64; c += 4) {
+                    y0 += mrow[c] * vec_s[c]; y1 += mrow[c + 1] * vec_s[c + 1];
+                    y2 += mrow[c + 2] * vec_s[c + 2]; y3 += mrow[c + 3] * vec_s[c + 3];
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                return y;
+                return (y0 + y1) + (y2 + y3);
             };
             T r = live ? v - mul(a) : T(0);   // common.c:1932-1943 / :1128-1139
             T p = r;

@@ -95,13 +95,16 @@ def test_optimizeA_collective(oracles, dtype, ku, ki, km, sls, m_u):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("implicit", [True, False])
-@pytest.mark.parametrize("vh", ["stream", "gram"])
+@pytest.mark.parametrize("vh", ["stream", "gram", "gram-slice"])
 def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, monkeypatch):
     """Rows above 1024 nnz take the split-row path (one launch pair per CG pass) or, with
-    CMFREC_HIP_VH=gram, the single-gather Gramian path (gram_cg_kernels.hpp); 257..1024 the 8-wave
+    CMFREC_HIP_VH=gram, the single-gather Gramian path (gram_cg_kernels.hpp: one wavefront per slice, or the
+    LDS-staged workgroup kernel with CMFREC_HIP_GRAM_KERNEL=slice); 257..1024 the 8-wave
     team with re-streamed tiles; all must agree with the sequential reference sums."""
     from cmfrec_amd import ops
-    monkeypatch.setenv("CMFREC_HIP_VH", vh)
+    monkeypatch.setenv("CMFREC_HIP_VH", vh.split("-")[0])
+    if vh == "gram-slice":
+        monkeypatch.setenv("CMFREC_HIP_GRAM_KERNEL", "slice")
     O = oracles[dtype]
     m, n, k = 60, 5000, 50
     row, col, val = make_coo(m, n, 12000, 41, counts=implicit, dtype=dtype, heavy_row=(3, 4500), empty_rows=(8,))
