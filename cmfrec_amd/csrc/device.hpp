@@ -121,9 +121,16 @@ struct SparseShard {
     // 0.73 ms), or stream them once per CG pass (sorted entries, one slice of the opposing matrix per XCD).  Single
     // precision always takes the Gramian (the matrix cores outrun any gather).  In double precision v_mfma_f64_16x16x4 is no
     // faster than the VALU, and streaming wins once the split rows of a launch share their opposing rows often enough to live
-    // in L2: 15 references per opposing row (C2's items) still favour the Gramian, 143 (C1, MovieLens-10M-shaped: 1.30
-    // against 1.06 ms for its A-step) do not.  CMFREC_HIP_VH=gram / stream force one.
-    bool prefer_gram() const { return sizeof(real_t) == 4 || (n_other > 0 && (double)bin_nnz[0] < 40.0 * (double)n_other); }
+    // in cache: C2's items (15 references per opposing row, a 144 MB opposing matrix) still favour the Gramian; C1
+    // (MovieLens-10M-shaped: 4 / 28 MB opposing matrices, 100+ references) does not -- 1.29 against 1.06 ms for its A-step.
+    // `opp_bytes_per_row` = k x sizeof(real_t) of the launch.  CMFREC_HIP_VH=gram / stream force one.
+    bool prefer_gram(size_t opp_bytes_per_row) const
+    {
+        if (sizeof(real_t) == 4) return true;
+        if (n_other <= 0) return false;
+        const double refs = (double)bin_nnz[0] / (double)n_other;
+        return refs < 3.5 || (refs < 40.0 && (double)n_other * (double)opp_bytes_per_row > 100e6);
+    }
     // few split rows (less than about one round of workgroups per CG pass): their launch sequence is a chain of
     // latencies and runs on the second stream beside the other bins
     bool vh_runs_aside(int num_cus) const
@@ -527,7 +534,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     // takes the launch pair per CG pass below (also the on-device cross-check of the Gramian path, and the only path for
     // k > 64 and for block systems).
     const char *vh_env = getenv("CMFREC_HIP_VH");
-    const bool use_gram = !GRAMX && ((vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram());     // "stream" / "gram" force one
+    const bool use_gram = !GRAMX && ((vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram((size_t)P.k * sizeof(real_t)));     // "stream" / "gram" force one
     if (P.k <= 16 * GRAM_NTT && use_gram) {
         // one gather: Gramian slices on the matrix cores, then CG on the k x k system (gram_cg_kernels.hpp)
         GramParams<real_t> G;

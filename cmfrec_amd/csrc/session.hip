@@ -1850,7 +1850,7 @@ int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which)
     const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
     if (X.bin_rows[BIN_VHEAVY] <= 0) return 0;
     const char *e = getenv("CMFREC_HIP_VH");
-    const bool gram = (e != nullptr) ? strcmp(e, "gram") == 0 : X.prefer_gram();
+    const bool gram = (e != nullptr) ? strcmp(e, "gram") == 0 : X.prefer_gram((size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t));
     return (gram && s->mdl.k + s->mdl.k_main <= 16 * GRAM_NTT) ? 2 : 1;
 }
 
