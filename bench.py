@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 M_USERS, N_ITEMS, NNZ, K = 358_858, 160_112, 17_309_518, 50
 LAM, MAX_CG_STEPS = 5.0, int(os.environ.get("BENCH_CG_STEPS", "3"))   # env override: experiments only
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GATHER_CEILING_GBS = 6000.0    # measured: random 400-byte rows into register tiles, matrix resident in the Infinity Cache
 
 
 def synth_block(m, n, nnz, seed):
@@ -203,6 +204,10 @@ def main():
                     traffic_source=pmc_meta() if traffic is not None else None,
                     alg_bytes_per_launch=dom["alg_bytes"],
                     avg_launch_ms=round(dom["avg_ms"], 4), rocprof=dom["rocprof"],
+                    # what a gather of 400-byte rows at random positions reaches on this part with nothing else to do
+                    # (tools/microbench/gather_rate.hip: 6.0 TB/s out of the 256 MiB Infinity Cache, 5.1 TB/s from HBM)
+                    gather_ceiling={"GBps": GATHER_CEILING_GBS, "frac": round(achieved / GATHER_CEILING_GBS, 4),
+                                    "source": "profiles/r02_q_gather_rate.txt (opposing matrices of C2: 144 MB / 64 MB, cache resident)"},
                     iteration={"alg_GB": round(iter_bytes / 1e9, 3), "halfstep_ms": halfstep_ms,
                                "frac_of_hbm_peak": round(iter_bytes / 1e9 / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * world), 4)},
                     per_kernel=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4),

@@ -81,7 +81,7 @@ struct DevBuf {
 constexpr int MAX_DEVICES = 16;   // per-device caches of launch attributes
 constexpr int NBINS = 6;
 constexpr int BIN_VHEAVY = 0;   // > 1024 nnz : every CG pass split over many workgroups (vh_* kernels); measured on C2: 2048 -> 5.05, 1024 -> 4.93, 512 -> 5.11 ms
-constexpr int BIN_HEAVY = 1;    // 257..1024  : 8 waves / row (register-resident up to 512 nnz, else re-streamed)
+constexpr int BIN_HEAVY = 1;    // 257..1024  : 8 waves / row (double: register-resident up to 512 nnz, else re-streamed; single: two tiles per wave, resident)
 constexpr int BIN_MED4 = 2;     // 129..256   : 4 waves / row
 constexpr int BIN_MED2 = 3;     // 65..128    : 2 waves / row
 constexpr int BIN_LIGHT = 4;    // 33..64     : 1 wave / row, 4 rows / workgroup
@@ -89,7 +89,10 @@ constexpr int BIN_TINY = 5;     // 1..32      : 1 wave / row, half-size tiles, d
 constexpr int BIN_MIN_NNZ[NBINS] = {1025, 257, 129, 65, 33, 1};
 inline int vheavy_min_nnz()
 {
-    static const int v = getenv("CMFREC_HIP_VH_MIN") ? std::max(258, atoi(getenv("CMFREC_HIP_VH_MIN"))) : BIN_MIN_NNZ[BIN_VHEAVY];
+    // (single precision: the 8-wave kernel keeps two tiles per wave and nothing else, so the boundary cannot move up)
+    static const int v = getenv("CMFREC_HIP_VH_MIN")
+                             ? std::min(sizeof(real_t) == 4 ? BIN_MIN_NNZ[BIN_VHEAVY] : (1 << 30), std::max(258, atoi(getenv("CMFREC_HIP_VH_MIN"))))
+                             : BIN_MIN_NNZ[BIN_VHEAVY];
     return v;
 }
 inline int bin_of(long long nnz)

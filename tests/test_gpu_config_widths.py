@@ -119,7 +119,18 @@ def test_c4_width_implicit_single(oracles, mode):
     O = oracles[dtype]
     m, n, k = 300, 5000, 64
     row, col, val = make_coo(m, n, 16000, 13, dtype=dtype, heavy_row=(3, 3000), empty_rows=(5, 17))
+    # rows of 513..1024 entries: in single precision the 8-wave team keeps two tiles per wave (one gather for all passes);
+    # 1024 fills both tiles of every wave, 577 leaves the second tile of the first wave with one entry
+    rng0 = np.random.default_rng(99)
+    keep = ~np.isin(row, (20, 21, 22))
+    er, ec = [], []
+    for r, cnt in ((20, 1024), (21, 577), (22, 700)):
+        er.append(np.full(cnt, r, np.int32)); ec.append(rng0.choice(n, cnt, replace=False).astype(np.int32))
+    ev = np.ceil(rng0.lognormal(1, 1, sum(len(e) for e in er))).astype(dtype)
+    row = np.concatenate([row[keep]] + er); col = np.concatenate([col[keep]] + ec); val = np.concatenate([val[keep], ev])
     csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    lens = np.diff(csr[0].astype(np.int64))
+    assert lens[20] == 1024 and lens[21] == 577
     rng = np.random.default_rng(k)
     A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
     B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)

@@ -12,7 +12,7 @@ def main():
     ap.add_argument("dir"); ap.add_argument("known"); ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
     known = json.loads([l for l in open(a.known) if l.startswith("{")][-1])
-    vals = {"calib_stream_kernel": [], "calib_gather_kernel": []}
+    vals = {"calib_stream_kernel": [], "calib_gather_kernel": [], "calib_gather128_kernel": []}
     for f in glob.glob(os.path.join(a.dir, "**", "*counter_collection.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
@@ -22,7 +22,7 @@ def main():
             per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
         for (_, name), v in per.items():
             for k in vals:
-                if k in name:
+                if name.strip().endswith(k) or (k + "<") in name or name.strip() == k:
                     vals[k].append(v * 1024.0)                      # FETCH_SIZE is in KiB
     out = {"known": known, "note": "factor = known bytes / FETCH_SIZE bytes; the last launch of three is used (warm TLBs, cold data: "
                                    "both buffers exceed the 256 MiB Infinity Cache)"}
@@ -35,6 +35,12 @@ def main():
                                                   "factor_vs_64B_sectors": known["gather_sector64_bytes"] / c,
                                                   "factor_vs_128B_lines": known["gather_line128_bytes"] / c,
                                                   "all_launches_bytes": vals["calib_gather_kernel"]}
+    if vals["calib_gather128_kernel"]:
+        c = vals["calib_gather128_kernel"][-1]
+        out["gather_8B_per_lane_128B_segments"] = {"fetch_size_bytes": c, "factor_vs_logical": known["gather_logical_bytes"] / c,
+                                                   "factor_vs_64B_sectors": known["gather_sector64_bytes"] / c,
+                                                   "factor_vs_128B_lines": known["gather_line128_bytes"] / c,
+                                                   "all_launches_bytes": vals["calib_gather128_kernel"]}
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

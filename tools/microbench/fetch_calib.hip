@@ -44,6 +44,26 @@ __global__ void calib_gather_kernel(const double *__restrict__ B, size_t ldb, in
     if (acc == 1.2345e300) sink[0] = acc;
 }
 
+// one wavefront per 4 rows: lane = kc * 16 + lm reads row idx[4 w + kc], columns lm + 16 cb (gram_wave_kernel's slab:
+// 16 lanes x 8 B = 128 contiguous bytes per row and instruction)
+__global__ void calib_gather128_kernel(const double *__restrict__ B, size_t ldb, int k, const int *__restrict__ idx, size_t nrows,
+                                       double *__restrict__ sink)
+{
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, kc = lane >> 4, lm = lane & 15;
+    const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    double acc = 0;
+    for (size_t g = wave; g * 4 < nrows; g += nw) {
+        const size_t r = g * 4 + kc;
+        if (r < nrows) {
+            const double *rp = B + (size_t)idx[r] * ldb;
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) acc += rp[min(lm + 16 * cb, k - 1)];
+        }
+    }
+    if (acc == 1.2345e300) sink[0] = acc;
+}
+
 int main()
 {
     const size_t stream_bytes = (size_t)2 << 30;
@@ -71,6 +91,8 @@ int main()
         hipLaunchKernelGGL(calib_stream_kernel, dim3(4096), dim3(256), 0, 0, (const double2 *)dS, stream_bytes / 16, sink);
         hipDeviceSynchronize();
         hipLaunchKernelGGL(calib_gather_kernel, dim3(4096), dim3(256), 0, 0, dB, (size_t)k, k, dIdx, N, sink);
+        hipDeviceSynchronize();
+        hipLaunchKernelGGL(calib_gather128_kernel, dim3(4096), dim3(256), 0, 0, dB, (size_t)k, k, dIdx, N, sink);
         hipDeviceSynchronize();
     }
     printf("{\"stream_bytes\": %zu, \"gather_logical_bytes\": %zu, \"gather_sector64_bytes\": %zu, \"gather_line128_bytes\": %zu, \"launches_each\": 3}\n",

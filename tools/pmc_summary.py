@@ -39,12 +39,17 @@ def main():
     # FETCH_SIZE -> bytes: the guide's x2 holds for 16 B / lane coalesced reads; the CG kernels gather 8 B / lane in 64 B
     # segments, for which the factor is measured (tools/microbench/fetch_calib.hip)
     fetch_factor, fetch_note = 2.0, "x2 (guide, 16 B / lane coalesced; uncalibrated for this pattern)"
+    factor128 = None
     if os.path.exists(args.calibration):
         cal = json.load(open(args.calibration))
         g = cal.get("gather_8B_per_lane_64B_segments")
         if g:
             fetch_factor = float(g["factor_vs_64B_sectors"])
             fetch_note = "x%.3f measured on the gather pattern (known 64 B sectors / FETCH_SIZE, %s)" % (fetch_factor, os.path.basename(args.calibration))
+        g = cal.get("gather_8B_per_lane_128B_segments")
+        if g:       # gram_wave_kernel: 16 lanes x 8 B per gathered row and instruction
+            factor128 = float(g["factor_vs_64B_sectors"])
+            fetch_note += "; gram_wave_kernel x%.3f (16 lanes x 8 B segments)" % factor128
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in args.dirs:
         for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
@@ -68,9 +73,10 @@ def main():
             ent[c] = {"mean": sum(v) / len(v), "launches": len(v),
                       "per_halfstep_B": sum(halves[0::2]) / max(len(halves[0::2]), 1),
                       "per_halfstep_A": sum(halves[1::2]) / max(len(halves[1::2]), 1)}
+        ff = factor128 if (factor128 is not None and "gram_wave_kernel" in kname) else fetch_factor
         for step in ("A", "B"):
             if "FETCH_SIZE" in ent:
-                ent["hbm_read_bytes_%s" % step] = ent["FETCH_SIZE"]["per_halfstep_" + step] * 1024 * fetch_factor
+                ent["hbm_read_bytes_%s" % step] = ent["FETCH_SIZE"]["per_halfstep_" + step] * 1024 * ff
             if "WRITE_SIZE" in ent:
                 ent["hbm_write_bytes_%s" % step] = ent["WRITE_SIZE"]["per_halfstep_" + step] * 1024
         out[kname] = ent
