@@ -315,16 +315,28 @@ gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
         if (kt < 64)
             for (int e = tid; e < 64 * LDM; e += 256) M[e] = T(0);
         if (kt < 64) __syncthreads();
-        // G = sum of the slice partials, in slice order;  M = G + (BtB + lam I | diag(lam .. lam_last)), both triangles
-        for (int e = tid; e < NTALL * 256; e += 256) {
-            T s = T(0);
-            for (int sl = s0; sl < s1; sl += 8) {
-                T t8[8];
+        // G = sum of the slice partials, in slice order;  M = G + (BtB + lam I | diag(lam .. lam_last)), both triangles.
+        // Slices outermost, the thread's ten elements inside: 80 independent loads per round, so that the most popular rows
+        // (hundreds of slices: a chain of hundreds of round trips per element otherwise) do not become the tail of the launch.
+        constexpr int EPT = NTALL * 256 / 256, SB = 4;     // slices per round (40 loads in flight per thread; more would cost resident workgroups)
+        T sacc[EPT];
 #pragma unroll
-                for (int u = 0; u < 8; u++) t8[u] = (sl + u < s1) ? Gp.part[(size_t)(sl + u) * GRAM_PART + e] : T(0);
+        for (int q = 0; q < EPT; q++) sacc[q] = T(0);
+        for (int sl = s0; sl < s1; sl += SB) {
+            T t8[EPT][SB];
 #pragma unroll
-                for (int u = 0; u < 8; u++) s += t8[u];
-            }
+            for (int q = 0; q < EPT; q++)
+#pragma unroll
+                for (int u = 0; u < SB; u++) t8[q][u] = (sl + u < s1) ? Gp.part[(size_t)(sl + u) * GRAM_PART + tid + 256 * q] : T(0);
+#pragma unroll
+            for (int q = 0; q < EPT; q++)
+#pragma unroll
+                for (int u = 0; u < SB; u++) sacc[q] += t8[q][u];
+        }
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const int e = tid + 256 * q;
+            T s = sacc[q];
             const int t = e >> 8, r = (e >> 6) & 3, l = e & 63;
             const int i = 16 * tile_bi(t, NTT) + Mf::row_of(l, r), j = 16 * tile_bj(t, NTT) + (l & 15);
             if (j >= i && j < kt) {           // diagonal tiles: the upper half only, mirrored
@@ -335,8 +347,15 @@ gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
             }
         }
         T v = T(0);
-        if (tid < 64)
-            for (int sl = s0; sl < s1; sl++) v += Gp.part[(size_t)sl * GRAM_PART + NTALL * 256 + tid];
+        if (tid < 64) {
+            for (int sl = s0; sl < s1; sl += 8) {
+                T t8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t8[u] = (sl + u < s1) ? Gp.part[(size_t)(sl + u) * GRAM_PART + NTALL * 256 + tid] : T(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += t8[u];
+            }
+        }
         __syncthreads();
         if (tid < 64) {                       // one wavefront: lane e <-> unknown e
             const bool live = lane < kt;

@@ -52,7 +52,7 @@ def main():
             fetch_note += "; gram_wave_kernel x%.3f (16 lanes x 8 B segments)" % factor128
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in args.dirs:
-        for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             per_dispatch = collections.defaultdict(float)
             names = {}
             for r in csv.DictReader(open(f)):
