@@ -614,10 +614,12 @@ __device__ __forceinline__ void load_tile4(RegTile4<T, S> &tile, const T *__rest
     its[2] = lanes::bcast8<4>(my_idx); its[3] = lanes::bcast8<6>(my_idx);
     const int first_idx = __builtin_amdgcn_readfirstlane(my_idx);
     const int col_last = min(ll + 8 * (S - 1), k - 1) - ll;
+    const char *base = reinterpret_cast<const char *>(Bm + ll);
+    const unsigned ldb_bytes = (unsigned)(ldb * sizeof(T));
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const int it = ((jj * 4 + t) < cnt) ? its[t] : first_idx;
-        const T *rp = Bm + (size_t)it * ldb + ll;
+        const unsigned it = (unsigned)(((jj * 4 + t) < cnt) ? its[t] : first_idx);
+        const T *rp = reinterpret_cast<const T *>(base + (unsigned long long)it * ldb_bytes);     // one v_mad_u64_u32
 #pragma unroll
         for (int s = 0; s < S; s++) tile.set(t, s, rp[(s < S - 1) ? 8 * s : col_last]);
     }
