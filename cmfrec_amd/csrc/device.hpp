@@ -552,7 +552,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
             hipLaunchKernelGGL((gram_slice_kernel<real_t, IMPLICIT>), dim3(std::min(X.n_slices, dev.num_cus * 2)), dim3(64 * GRAM_NW), 0,
                            dev.stream, P, G);
         else
-            hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), dim3(std::min((X.n_slices + 3) / 4, dev.num_cus * 3)), dim3(256), 0,
+            hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), dim3(std::min((X.n_slices + 3) / 4, dev.num_cus * 4)), dim3(256), 0,
                                dev.stream, P, G);
         hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 8)), dim3(256), 0, dev.stream, P, G);
         HIP_CHECK(hipGetLastError());

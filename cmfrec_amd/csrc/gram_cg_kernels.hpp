@@ -177,7 +177,13 @@ gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
 // row sum v, the scaling), 10 MFMAs -- the matrix pipe is the limit (single precision: 320 of its cycles per 4 non-zeros,
 // 20 cycles per non-zero and CU), and the rows are read once instead of max_cg_steps + 1 times.  Groups of 8 slabs are
 // double-buffered in registers.  Output layout = gram_slice_kernel's, so gram_cg_kernel consumes either.
-template <typename T> constexpr int gw_slabs() { return sizeof(T) == 4 ? 8 : 4; }     // slabs per prefetch group (32 / 16 non-zeros)
+#ifndef GW_SLABS_F32
+#define GW_SLABS_F32 4      // 120 VGPRs: four wavefronts per SIMD (8: 168 VGPRs, three; 16: 202, two -- measured 1.30 / 1.39 / 1.95 ms on c4shard's item rows)
+#endif
+#ifndef GW_SLABS_F64
+#define GW_SLABS_F64 4
+#endif
+template <typename T> constexpr int gw_slabs() { return sizeof(T) == 4 ? GW_SLABS_F32 : GW_SLABS_F64; }     // slabs per prefetch group
 
 template <typename T, bool IMPLICIT>
 __global__ void __launch_bounds__(256, 2)
