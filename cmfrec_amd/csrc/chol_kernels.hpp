@@ -90,6 +90,10 @@ struct CholParams {
     int scale_lam, scale_lam_sideinfo, scale_bias_const;
     int mode;
     int *counter;              // zero-initialised: rows are handed out to the workgroups in `order` (heaviest first)
+#ifdef CMF_CHOL_DEBUG
+    int dbg = 0;               // timing experiments (results are wrong): 1 gather + rank-k update, 2 rank-k MFMAs only, 4 factorisation,
+                               // 8 backward substitution, 16 initial matrix
+#endif
     int row_first;             // positions row_first .. nrows-1 of the processing order are handled
 };
 
@@ -240,6 +244,11 @@ __device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *
 // CHOL_CHUNK gathered rows of a round);  WGS = workgroups per CU the register budget is set for.
 // TWO_SRC compiles the second gather source in (sparse side information); the single-source build carries none of its
 // selects (they cost 4-19 % on the plain Cholesky configurations when they were unconditional).
+#ifdef CMF_CHOL_DEBUG
+#define CMF_CDBG(P, bit) (((P).dbg & (bit)) != 0)
+#else
+#define CMF_CDBG(P, bit) false
+#endif
 template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS, bool TWO_SRC = false>
 __global__ void __launch_bounds__(64 * NW, WGS)
 chol_rows_kernel(const CholParams<T> P)
@@ -403,7 +412,7 @@ chol_rows_kernel(const CholParams<T> P)
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
         __syncthreads();          // previous row's LDS readers (backward substitution) are done
-        for (int c0 = 0, slot = 0; c0 < nnz; c0 += CHOL_CHUNK, slot ^= 1) {
+        for (int c0 = 0, slot = 0; c0 < (CMF_CDBG(P, 1) ? 0 : nnz); c0 += CHOL_CHUNK, slot ^= 1) {
             T *Bs = ring + (size_t)slot * CHOL_CHUNK * ldc;
 #pragma unroll
             for (int i = 0; i < RPW; i++)
@@ -424,7 +433,7 @@ chol_rows_kernel(const CholParams<T> P)
                 for (int r = 0; r < CHOL_CHUNK; r++) racc += wrh[slot * CHOL_CHUNK + r] * Bs[r * ldc + tid];   // padded rows: weight 0, row 0
             }
             // chunks whose rank-1 weights are all zero contribute to the right-hand side only
-            const bool skip_mma = TWO_SRC && (naz || (two_src && P.w2_syr_zero && c0 >= nnz1));
+            const bool skip_mma = (TWO_SRC && (naz || (two_src && P.w2_syr_zero && c0 >= nnz1))) || CMF_CDBG(P, 2);
             // straight-line: operand reads of every slot, weights, MFMAs (idle slots run on tile 0 and are ignored)
             if (!skip_mma) {
 #pragma unroll
@@ -454,7 +463,7 @@ chol_rows_kernel(const CholParams<T> P)
             for (int pass = 0; pass < 2; pass++) {                     // unconditional loads on clamped addresses
                 const T *Mi = pass ? M2 : M1;
                 const int lim = pass ? P.kc : kt;
-                if (Mi == nullptr || lim <= 0) continue;
+                if (Mi == nullptr || lim <= 0 || CMF_CDBG(P, 16)) continue;
 #pragma unroll
                 for (int tt = 0; tt < TPW; tt++) {
 #pragma unroll
@@ -590,7 +599,7 @@ chol_rows_kernel(const CholParams<T> P)
         if (tid < 16 * NTT) rhs[tid] = (tid < kt) ? racc : T(0);
         __syncthreads();                      // ring fully consumed (X tiles alias it), rhs visible
         // ---- 3. blocked Cholesky  M = R^T R ----
-        for (int kbk = 0; kbk < nb; kbk++) {
+        for (int kbk = 0; kbk < (CMF_CDBG(P, 4) ? 0 : nb); kbk++) {
             T *rslot = rinv + (size_t)kbk * RSZ;
             {   // a. diagonal block, by its owner wave
                 vec d = vec{0, 0, 0, 0};
@@ -664,7 +673,7 @@ chol_rows_kernel(const CholParams<T> P)
         }
         __syncthreads();
         // ---- 4. backward substitution R x = y, one block column per step ----
-        for (int bjk = nb - 1; bjk >= 0; bjk--) {
+        for (int bjk = (CMF_CDBG(P, 8) ? -1 : nb - 1); bjk >= 0; bjk--) {
             const T *rslot = rinv + (size_t)bjk * RSZ;
             T xm = T(0);                          // x[16 bjk + lm], computed redundantly by every 16-lane group
 #pragma unroll

@@ -261,6 +261,9 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
                             size_t smem_nonneg)
 {
     const int T = chol_tiles(c.kt);
+#ifdef CMF_CHOL_DEBUG
+    if (const char *e = getenv("CMFREC_HIP_CHOL_SKIP")) P.dbg = atoi(e);
+#endif
     // the two-source build (sparse side information) only where it is asked for
 #define CHOL_KERN(a, b, c_, d) (two_src ? chol_rows_kernel<real_t, a, b, c_, d, true> : chol_rows_kernel<real_t, a, b, c_, d, false>)
     hipStream_t run_on = dev.stream;
@@ -320,8 +323,12 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
         // 16 wavefronts per row (10 tile slots per wave instead of 20: the 8-wave build spills ~500 registers):
         // c5 shard B-step 377 -> 274 ms.  CMFREC_HIP_CHOL_ROWS17=8 brings the 8-wave build back (A/B switch).
         static const char *w17 = getenv("CMFREC_HIP_CHOL_ROWS17");
+        // 32 gathered rows per round instead of 16 (half the barriers and staging rounds of the rank-k update, which is
+        // 56 % of this kernel's time on the c5 shard -- phase skipping, profiles/r02_ag_*): item step 272 -> 219 ms.
+        // The build is register-starved either way (128 VGPRs at 16 waves, ~1 KB of scratch per lane).
         if (w17 != nullptr && w17[0] == '8') launch(CHOL_KERN(17, 8, 16, 1), 17, 8, 16, 1);
-        else launch(CHOL_KERN(17, 16, 16, 1), 17, 16, 16, 1);
+        else if (w17 != nullptr && w17[0] == 'c') launch(CHOL_KERN(17, 16, 16, 1), 17, 16, 16, 1);      // "c16": the 16-row rounds
+        else launch(CHOL_KERN(17, 16, 32, 1), 17, 16, 32, 1);
     }
 #else
     else if (T <= 12) launch(CHOL_KERN(12, 8, 16, 1), 12, 8, 16, 1);
