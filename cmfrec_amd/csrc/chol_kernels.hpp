@@ -293,6 +293,16 @@ chol_rows_kernel(const CholParams<T> P)
 #define T_BI(tt) (offa[tt] >> 4)
 #define T_BJ(tt) (offb[tt] >> 4)
 #define T_REAL(tt) (offa[tt] <= offb[tt])
+    // the same offsets in LDS for the rank-k loop of the widest builds, where the register copies above end up in scratch
+    // (17 tiles / 16 waves: 26 scratch loads per round of the hottest loop): one broadcast ds_read per tile and k-step
+    constexpr bool OFF_LDS = (NTT >= 16);
+    __shared__ unsigned s_otab[OFF_LDS ? NW * TPW : 1];
+    if (OFF_LDS) {
+#pragma unroll
+        for (int tt = 0; tt < TPW; tt++)
+            if (lane == 0) s_otab[wave * TPW + tt] = (unsigned)offa[tt] | ((unsigned)offb[tt] << 16);
+        __syncthreads();
+    }
 
     // staging: wave w gathers rows RPW*w .. RPW*w + RPW-1 of a chunk, lane l the unknowns l, l+64, ...
     int scol[NCJ];                             // column of B to read (clamped); valid <=> svalid bit
@@ -436,6 +446,27 @@ chol_rows_kernel(const CholParams<T> P)
             const bool skip_mma = (TWO_SRC && (naz || (two_src && P.w2_syr_zero && c0 >= nnz1))) || CMF_CDBG(P, 2);
             // straight-line: operand reads of every slot, weights, MFMAs (idle slots run on tile 0 and are ignored)
             if (!skip_mma) {
+                if constexpr (OFF_LDS) {
+                    // element addresses of this lane's operand column in slab row (lane >> 4), once per round; the k-step
+                    // (4 q rows further down) is an immediate offset of the ds_read
+                    const T *pa[TPW], *pb[TPW];
+#pragma unroll
+                    for (int tt = 0; tt < TPW; tt++) {
+                        const unsigned o = s_otab[wave * TPW + tt];
+                        pa[tt] = Bs + (lane >> 4) * ldc + lm + (o & 0xffffu);
+                        pb[tt] = Bs + (lane >> 4) * ldc + lm + (o >> 16);
+                    }
+#pragma unroll
+                    for (int q = 0; q < CHOL_CHUNK / 4; q++) {
+                        const T w = wsc[slot * CHOL_CHUNK + 4 * q + (lane >> 4)];
+                        T opa[TPW], opb[TPW];
+#pragma unroll
+                        for (int tt = 0; tt < TPW; tt++) { opa[tt] = pa[tt][4 * q * ldc]; opb[tt] = pb[tt][4 * q * ldc]; }
+#pragma unroll
+                        for (int tt = 0; tt < TPW; tt++) acc[tt] = Mf::mma(opa[tt] * w, opb[tt], acc[tt]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < CHOL_CHUNK / 4; q++) {
                     const int rr = 4 * q + (lane >> 4);
@@ -447,6 +478,7 @@ chol_rows_kernel(const CholParams<T> P)
 #pragma unroll
                     for (int tt = 0; tt < TPW; tt++) acc[tt] = Mf::mma(opa[tt] * w, opb[tt], acc[tt]);
                     __builtin_amdgcn_sched_barrier(0);       // one k-step of operands in registers at a time
+                }
                 }
             }
         }
