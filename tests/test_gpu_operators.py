@@ -96,7 +96,8 @@ def test_optimizeA_collective(oracles, dtype, ku, ki, km, sls, m_u):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("vh", ["stream", "gram", "gram-slice"])
-def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, monkeypatch):
+@pytest.mark.parametrize("k", [50, 7, 33])
+def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, k, monkeypatch):
     """Rows above 1024 nnz take the split-row path (one launch pair per CG pass) or, with
     CMFREC_HIP_VH=gram, the single-gather Gramian path (gram_cg_kernels.hpp: one wavefront per slice, or the
     LDS-staged workgroup kernel with CMFREC_HIP_GRAM_KERNEL=slice); 257..1024 the 8-wave
@@ -106,7 +107,7 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, monkeypatch):
     if vh == "gram-slice":
         monkeypatch.setenv("CMFREC_HIP_GRAM_KERNEL", "slice")
     O = oracles[dtype]
-    m, n, k = 60, 5000, 50
+    m, n = 60, 5000            # k = 7: one 16-column block, mostly padding; 33: two blocks and one live column of the third
     row, col, val = make_coo(m, n, 12000, 41, counts=implicit, dtype=dtype, heavy_row=(3, 4500), empty_rows=(8,))
     # a second very heavy row and a 257..1024 one
     rng = np.random.default_rng(4)
