@@ -1,4 +1,7 @@
 #!/bin/bash
+# (First attempt: its counter pass put FETCH_SIZE and WRITE_SIZE into one rocprofv3 run, which this part cannot collect together;
+# rocprofv3 aborted and then hung until the call's limit.  Only the calibration of step 1 comes from this script; the rest of the
+# end-of-round data was taken by r02_final2.sh / r02_final3.sh / r02_final4.sh.)
 # round 2, end-of-round measurement: FETCH_SIZE calibration (three access patterns), counter passes and kernel trace of the
 # default `python bench.py`, the bench line itself (with the CPU baseline), the side workloads and BASELINE config 4 on one GPU
 export TMPDIR=/tmp
