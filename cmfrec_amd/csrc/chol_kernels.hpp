@@ -93,6 +93,9 @@ struct CholParams {
 #ifdef CMF_CHOL_DEBUG
     int dbg = 0;               // timing experiments (results are wrong): 1 gather + rank-k update, 2 rank-k MFMAs only, 4 factorisation,
                                // 8 backward substitution, 16 initial matrix
+    unsigned long long *tstamp = nullptr;   // [8]: shader-clock ticks summed over the rows of the launch -- 0 row claim + set-up,
+                                            // 1 rank-k loop, 2 initial matrix + diagonal, 3 factorisation, 4 backward substitution
+                                            // + store, 5 rows, 6 non-zeros
 #endif
     int row_first;             // positions row_first .. nrows-1 of the processing order are handled
 };
@@ -246,8 +249,17 @@ __device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *
 // selects (they cost 4-19 % on the plain Cholesky configurations when they were unconditional).
 #ifdef CMF_CHOL_DEBUG
 #define CMF_CDBG(P, bit) (((P).dbg & (bit)) != 0)
+#define CMF_CTICK(P, slot)                                                                   \
+    do {                                                                                     \
+        if ((P).tstamp != nullptr && tid == 0) {                                             \
+            const unsigned long long now_ = __builtin_readcyclecounter();                    \
+            atomicAdd(&(P).tstamp[slot], now_ - tick_);                                      \
+            tick_ = now_;                                                                    \
+        }                                                                                    \
+    } while (0)
 #else
 #define CMF_CDBG(P, bit) false
+#define CMF_CTICK(P, slot) do { } while (0)
 #endif
 template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS, bool TWO_SRC = false>
 __global__ void __launch_bounds__(64 * NW, WGS)
@@ -327,6 +339,9 @@ chol_rows_kernel(const CholParams<T> P)
     }
 
     __shared__ int s_rix;
+#ifdef CMF_CHOL_DEBUG
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
     for (;;) {
         if (tid == 0) s_rix = P.row_first + atomicAdd(P.counter, 1);
         __syncthreads();
@@ -422,6 +437,10 @@ chol_rows_kernel(const CholParams<T> P)
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
         __syncthreads();          // previous row's LDS readers (backward substitution) are done
+        CMF_CTICK(P, 0);
+#ifdef CMF_CHOL_DEBUG
+        if (P.tstamp != nullptr && tid == 0) { atomicAdd(&P.tstamp[5], 1ull); atomicAdd(&P.tstamp[6], (unsigned long long)nnz); }
+#endif
         for (int c0 = 0, slot = 0; c0 < (CMF_CDBG(P, 1) ? 0 : nnz); c0 += CHOL_CHUNK, slot ^= 1) {
             T *Bs = ring + (size_t)slot * CHOL_CHUNK * ldc;
 #pragma unroll
@@ -482,6 +501,7 @@ chol_rows_kernel(const CholParams<T> P)
                 }
             }
         }
+        CMF_CTICK(P, 1);
         if (TWO_SRC && P.rhs_only) {
             if (tid < kt) arow[tid] = racc;
             continue;                     // the loop head's barrier orders the staging ring against the next row
@@ -630,6 +650,7 @@ chol_rows_kernel(const CholParams<T> P)
         }
         if (tid < 16 * NTT) rhs[tid] = (tid < kt) ? racc : T(0);
         __syncthreads();                      // ring fully consumed (X tiles alias it), rhs visible
+        CMF_CTICK(P, 2);
         // ---- 3. blocked Cholesky  M = R^T R ----
         for (int kbk = 0; kbk < (CMF_CDBG(P, 4) ? 0 : nb); kbk++) {
             T *rslot = rinv + (size_t)kbk * RSZ;
@@ -704,6 +725,7 @@ chol_rows_kernel(const CholParams<T> P)
             }
         }
         __syncthreads();
+        CMF_CTICK(P, 3);
         // ---- 4. backward substitution R x = y, one block column per step ----
         for (int bjk = (CMF_CDBG(P, 8) ? -1 : nb - 1); bjk >= 0; bjk--) {
             const T *rslot = rinv + (size_t)bjk * RSZ;
@@ -730,7 +752,7 @@ chol_rows_kernel(const CholParams<T> P)
         }
         if (wave == 0)
             for (int e = lane; e < kt; e += 64) arow[e] = xall[e];
-
+        CMF_CTICK(P, 4);
     }
 }
 

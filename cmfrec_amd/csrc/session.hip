@@ -263,6 +263,22 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
     const int T = chol_tiles(c.kt);
 #ifdef CMF_CHOL_DEBUG
     if (const char *e = getenv("CMFREC_HIP_CHOL_SKIP")) P.dbg = atoi(e);
+    if (getenv("CMFREC_HIP_CHOL_TICKS") != nullptr && T >= 16) {
+        // phase timers of the widest kernel: printed (and reset) by the launch that follows, i.e. per half-step
+        static unsigned long long *d_ticks = nullptr;
+        unsigned long long h[8];
+        if (d_ticks == nullptr) { HIP_CHECK(hipMalloc((void **)&d_ticks, sizeof(h))); HIP_CHECK(hipMemset(d_ticks, 0, sizeof(h))); }
+        else {
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(h, d_ticks, sizeof(h), hipMemcpyDeviceToHost));
+            if (h[5] > 0)
+                fprintf(stderr, "chol_rows ticks/row: setup %.0f rank-k %.0f init %.0f factor %.0f back %.0f  (rows %llu, nnz/row %.0f)\n",
+                        (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[5],
+                        (double)h[6] / h[5]);
+            HIP_CHECK(hipMemset(d_ticks, 0, sizeof(h)));
+        }
+        P.tstamp = d_ticks;
+    }
 #endif
     // the two-source build (sparse side information) only where it is asked for
 #define CHOL_KERN(a, b, c_, d) (two_src ? chol_rows_kernel<real_t, a, b, c_, d, true> : chol_rows_kernel<real_t, a, b, c_, d, false>)
