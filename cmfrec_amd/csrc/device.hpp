@@ -544,6 +544,22 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         G.sl_vrow = X.sl_vrow.ptr; G.sl_first = X.sl_first.ptr; G.sl_count = X.sl_count.ptr; G.row_sl_off = X.row_sl_off.ptr;
         G.part = X.gram_part.ptr; G.n_slices = X.n_slices; G.nvh = nvh;
         P.nrows = nvh;
+#ifdef CMF_CG_DEBUG
+        if (getenv("CMFREC_HIP_GRAM_TICKS") != nullptr) {
+            static unsigned long long *d_t = nullptr;
+            unsigned long long h[4];
+            if (d_t == nullptr) { HIP_CHECK(hipMalloc((void **)&d_t, sizeof(h))); HIP_CHECK(hipMemset(d_t, 0, sizeof(h))); }
+            else {
+                HIP_CHECK(hipDeviceSynchronize());
+                HIP_CHECK(hipMemcpy(h, d_t, sizeof(h), hipMemcpyDeviceToHost));
+                if (h[1] > 0)
+                    fprintf(stderr, "gram_wave: %.0f ticks per wave, %llu waves, %llu slices, %llu nnz: %.1f ticks per nnz and wave\n",
+                            (double)h[0] / h[1], h[1], h[2], h[3], (double)h[0] / (double)h[3]);
+                HIP_CHECK(hipMemset(d_t, 0, sizeof(h)));
+            }
+            G.ticks = d_t;
+        }
+#endif
         // slice partials: one wavefront per slice straight from the gather (gram_wave_kernel), or the LDS-staged workgroup
         // kernel (CMFREC_HIP_GRAM_KERNEL=slice)
         const char *gk_env = getenv("CMFREC_HIP_GRAM_KERNEL");

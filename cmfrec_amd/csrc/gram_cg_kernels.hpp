@@ -38,6 +38,9 @@ struct GramParams {
     const int *row_sl_off;     // [nvh + 1] slices of a row are contiguous
     T *part;                   // [n_slices][GRAM_PART]
     int n_slices, nvh;
+#ifdef CMF_CG_DEBUG
+    unsigned long long *ticks = nullptr;   // [4] timing experiment: shader-clock ticks of lane 0 of every wave summed, waves, slices, non-zeros
+#endif
 };
 
 // sums of c[0..7] over the 64 lanes in 10 exchanges: afterwards lane l holds the total of c[l >> 3]
@@ -201,11 +204,18 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
 #pragma unroll
     for (int cb = 0; cb < NTT; cb++) { cok[cb] = (16 * cb + lm) < kt; coff[cb] = (size_t)min(16 * cb + lm, kt - 1); }
     const unsigned ldb_bytes = (unsigned)(P.ldb * sizeof(T));
+#ifdef CMF_CG_DEBUG
+    const unsigned long long tick0 = __builtin_readcyclecounter();
+    unsigned long long nsl_ = 0, nnz_ = 0;
+#endif
 
     for (int sl = blockIdx.x * 4 + wave; sl < Gp.n_slices; sl += gridDim.x * 4) {
         const RowDesc d = P.desc[Gp.sl_vrow[sl]];
         const size_t st = d.st + (size_t)Gp.sl_first[sl];
         const int nnz = Gp.sl_count[sl];
+#ifdef CMF_CG_DEBUG
+        nsl_++; nnz_ += nnz;
+#endif
         T a_c[NTT];
 #pragma unroll
         for (int cb = 0; cb < NTT; cb++) a_c[cb] = (IMPLICIT && cok[cb]) ? P.A[(size_t)d.row * P.lda + coff[cb]] : T(0);
@@ -294,6 +304,12 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
             if (kc == 0) out[NTALL * 256 + 16 * cb + lm] = cok[cb] ? v : T(0);
         }
     }
+#ifdef CMF_CG_DEBUG
+    if (Gp.ticks != nullptr && lane == 0) {
+        atomicAdd(&Gp.ticks[0], __builtin_readcyclecounter() - tick0);
+        atomicAdd(&Gp.ticks[1], 1ull); atomicAdd(&Gp.ticks[2], nsl_); atomicAdd(&Gp.ticks[3], nnz_);
+    }
+#endif
 }
 
 // one workgroup (256 threads) per very heavy row; wave 0 runs the CG
