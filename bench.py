@@ -215,6 +215,13 @@ def main():
                                      **({"runs_beside_other_kernels": True} if d["overlapped"] else {}))
                                 for d in kernels])
 
+    if dom["kernel"].startswith("gram_wave"):
+        # the Gramian path reads its rows once; what limits it in double precision is v_mfma_f64_16x16x4:
+        # 10 tiles of the upper triangle per 4 entries, 2 x 16 x 16 x 4 flops each
+        mf = 10 * 2 * 16 * 16 * dom["nnz"] / (dom["avg_ms"] * 1e-3) / 1e12
+        roofline["matrix_pipe"] = {"executed_TFLOPs": round(mf, 1), "peak_fp64_TFLOPs": 78.6, "frac": round(mf / 78.6, 3),
+                                   "note": "flops the kernel issues (16-wide tiles over k = 50 and full diagonal tiles included); "
+                                           "tools/microbench/mfma_rate.hip measures 47 TFLOP/s for this instruction on the part"}
     # ---- CPU baseline: the reference itself (oracle/_ref) on this host, rank 0 / N=1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
