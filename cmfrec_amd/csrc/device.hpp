@@ -117,6 +117,7 @@ struct SparseShard {
     int n_nonempty = 0, n_empty = 0;
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
+    int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
     // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
@@ -162,6 +163,7 @@ struct SparseShard {
     DevBuf<real_t> vh_r, vh_p, vh_r_old, vh_part;
     // Gramian path of the very heavy rows (gram_cg_kernels.hpp): slices of <= GRAM_SLICE non-zeros
     static constexpr int GRAM_SLICE = 2048;
+    int slice_len = GRAM_SLICE;          // entries per slice of this shard (build_bins)
     int n_slices = 0;
     DevBuf<int> sl_vrow, sl_first, sl_count, row_sl_off;
     std::vector<int> h_row_sl_off;       // host copy of row_sl_off (batching of the two-kernel Cholesky mode)
@@ -230,12 +232,18 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0; n_long = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
+        n_empty = 0; n_long = 0; n_gt16 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
+        // few split rows (C2's users: 50 rows, 65 k entries): short slices, so that their Gramian kernels -- which run in line
+        // with the other bins, see launch_cg_S -- have a few hundred wavefronts to spread over instead of a few dozen
+        long long vh_total = 0;
+        for (int q = 0; q < nrows && (long long)lens_sorted[q] >= vheavy_min_nnz(); q++) vh_total += (long long)lens_sorted[q];
+        slice_len = (vh_total < (long long)GRAM_SLICE * 1024) ? 256 : GRAM_SLICE;
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
+            if (l > 16) n_gt16++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -245,7 +253,7 @@ struct SparseShard {
                 }
                 c_off.push_back((int)c_row.size());
                 // equal slices, multiples of 16 non-zeros (one staging round)
-                const int nsl = (int)((l + GRAM_SLICE - 1) / GRAM_SLICE);
+                const int nsl = (int)((l + slice_len - 1) / slice_len);
                 const int per = (int)((((l + nsl - 1) / nsl) + 15) / 16 * 16);
                 for (long long f = 0; f < l; f += per) {
                     s_row.push_back(bin_rows[b]); s_first.push_back((int)f); s_count.push_back((int)std::min<long long>(per, l - f));
@@ -489,7 +497,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
 }
 
 template <int S, bool IMPLICIT, bool GRAMX = false>
-inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st)
+inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st, int n_gt16)
 {
     if (count <= 0) return;
     EventPair ev{nullptr, nullptr};
@@ -498,21 +506,49 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         HIP_CHECK(hipEventCreate(&ev.b));
         HIP_CHECK(hipEventRecord(ev.a, st));
     }
-    P.order += first;
-    P.desc += first;
-    P.nrows = count;
-    P.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
+    // rows of at most 16 entries (the tail of the bin): two per wavefront (cg_rows_tiny2_kernel); CMFREC_HIP_TINY2=0 keeps them
+    // on the one-row kernel (A/B switch and cross-check)
+    static const bool tiny2_off = getenv("CMFREC_HIP_TINY2") != nullptr && getenv("CMFREC_HIP_TINY2")[0] == '0';
+    const int count2 = (GRAMX || tiny2_off) ? 0 : std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
+    const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
-    auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX>;
-    static thread_local int bpc_dev[MAX_DEVICES] = {0};
-    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
-    if (blocks_per_cu == 0) {
-        int nb = 0;
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
-        blocks_per_cu = std::max(1, nb);
+    const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
+    if (count1 > 0) {
+        CgParams<real_t> P1 = P;
+        P1.order += first;
+        P1.desc += first;
+        P1.nrows = count1;
+        P1.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
+        auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX>;
+        static thread_local int bpc_dev[MAX_DEVICES] = {0};
+        int &blocks_per_cu = bpc_dev[di];
+        if (blocks_per_cu == 0) {
+            int nb = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
+            blocks_per_cu = std::max(1, nb);
+        }
+        int grid = std::min((count1 + 3) / 4, dev.num_cus * blocks_per_cu);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, P1);
     }
-    int grid = std::min((count + 3) / 4, dev.num_cus * blocks_per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, P);
+    if constexpr (!GRAMX) {
+        if (count2 > 0) {
+            CgParams<real_t> P2 = P;
+            P2.order += first + count1;
+            P2.desc += first + count1;
+            P2.nrows = count2;
+            auto kern2 = cg_rows_tiny2_kernel<real_t, S, IMPLICIT>;
+            static thread_local int bpc2_dev[MAX_DEVICES] = {0};
+            int &blocks_per_cu = bpc2_dev[di];
+            if (blocks_per_cu == 0) {
+                int nb = 0;
+                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern2, 256, IMPLICIT ? smem : 0));
+                blocks_per_cu = std::max(1, nb);
+            }
+            const int npairs = (count2 + 1) / 2;
+            int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
+            hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), IMPLICIT ? smem : 0, st, P2);
+        }
+    }
     HIP_CHECK(hipGetLastError());
     if (tm) {
         HIP_CHECK(hipEventRecord(ev.b, st));
@@ -521,6 +557,15 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
 }
 
 // very heavy rows: one (pass, update) launch pair per CG pass
+// split rows of this launch on the Gramian path?  (CMFREC_HIP_VH=stream / gram force one; k > 64 and block systems stream)
+template <bool GRAMX>
+inline bool vh_takes_gram(int k, const SparseShard &X)
+{
+    if (GRAMX || k > 16 * GRAM_NTT) return false;
+    const char *vh_env = getenv("CMFREC_HIP_VH");
+    return (vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram((size_t)k * sizeof(real_t));
+}
+
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const SparseShard &X, BinTimers *tm, hipStream_t st)
 {
@@ -536,9 +581,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     // Default: read the gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp); CMFREC_HIP_VH=stream
     // takes the launch pair per CG pass below (also the on-device cross-check of the Gramian path, and the only path for
     // k > 64 and for block systems).
-    const char *vh_env = getenv("CMFREC_HIP_VH");
-    const bool use_gram = !GRAMX && ((vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram((size_t)P.k * sizeof(real_t)));     // "stream" / "gram" force one
-    if (P.k <= 16 * GRAM_NTT && use_gram) {
+    if (vh_takes_gram<GRAMX>(P.k, X)) {
         // one gather: Gramian slices on the matrix cores, then CG on the k x k system (gram_cg_kernels.hpp)
         GramParams<real_t> G;
         G.sl_vrow = X.sl_vrow.ptr; G.sl_first = X.sl_first.ptr; G.sl_count = X.sl_count.ptr; G.row_sl_off = X.row_sl_off.ptr;
@@ -606,7 +649,9 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     // beside the other bins.  Many split rows (the items of C2) fill the chip by themselves and stay in line.
     if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, ROW_COUNTER_INTS * sizeof(int), dev.stream));   // work counters of the bins
-    const bool vh_aside = X.bin_rows[BIN_VHEAVY] > 0 && X.vh_runs_aside(dev.num_cus);
+    // (The Gramian path is two launches, not two per pass, and its slices are short when the rows are few: it stays in line.)
+    const bool vh_aside = X.bin_rows[BIN_VHEAVY] > 0 && X.vh_runs_aside(dev.num_cus) &&
+                          (!vh_takes_gram<GRAMX>(P.k, X) || getenv("CMFREC_HIP_VH_GRAM_ASIDE") != nullptr);
     // A shard that is one of several parts of a block (multi-GPU overlap, session.hip) has a quarter of the rows per
     // launch, so ramp-up and tail of every bin weigh four times as much: its bins alternate between the two streams,
     // the next bin fills the CUs the previous one is vacating.  (Not for whole blocks: there the per-bin event timings
@@ -625,7 +670,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4, s1);
     launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2, s0);
     launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT, s1);
-    launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, s0);
+    launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, s0, X.n_gt16);
     if (vh_aside || alt) {
         HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));
         HIP_CHECK(hipStreamWaitEvent(dev.stream, d.join_ev, 0));

@@ -134,6 +134,51 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, k, monkeypatch
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("implicit", [True, False])
+@pytest.mark.parametrize("k", [50, 8, 64])
+def test_two_rows_per_wave(oracles, dtype, implicit, k):
+    """Rows of at most 16 entries are solved two per wavefront (cg_rows_tiny2_kernel): every length 0 .. 16 several times, an
+    odd number of such rows (the last wavefront holds one), rows that take the first exit (warm start = zero in the implicit
+    model with unit counts does not; a row whose start already solves its system does), next to rows of 17 .. 40 entries on
+    the one-row kernels."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n = 91, 600
+    rng = np.random.default_rng(k + 3)
+    rows, cols = [], []
+    for r in range(m):
+        cnt = r % 17 if r < 85 else 17 + 4 * (r - 85)
+        rows.append(np.full(cnt, r, np.int32)); cols.append(rng.choice(n, cnt, replace=False).astype(np.int32))
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
+    val = (np.ceil(rng.lognormal(1, 1, len(row))) if implicit else 0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    if implicit:
+        ops.optimizeA_implicit(Ah, B, csr, 4.0)
+        O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4)
+    else:
+        bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True, bias_sub=bias)
+        csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+        O.optimizeA_explicit(Ao, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    for r in (0, 17, 34):                                   # rows without entries are untouched
+        assert np.array_equal(Ah[r], A0[r])
+    # a second call starts from the first one's result: after enough calls rows converge and take the early exits
+    Ah2, Ao2 = Ah.copy(), Ao.copy()
+    for _ in range(6):
+        if implicit:
+            ops.optimizeA_implicit(Ah2, B, csr, 4.0); O.optimizeA_implicit(Ao2, B, csr, 4.0, nthreads=4)
+        else:
+            ops.optimizeA_explicit(Ah2, B, csr, 0.05, lam_last=0.3, scale_lam=True, bias_sub=bias)
+            O.optimizeA_explicit(Ao2, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
+    assert rel_err(Ah2, Ao2) < 10 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_lane_primitives_selftest(dtype):
     """DPP / permlane-swap shuffles, broadcasts and the transposed butterflies, checked lane by lane."""
     from cmfrec_amd import _lib

@@ -1,0 +1,48 @@
+"""Hunts the rare gross mismatch of the heavy-row parity case: repeats one configuration N times in one process and reports the rows
+that differ from the oracle.  python tools/microbench/heavy_rows_flake.py gram|stream [slice] k implicit(0/1) N"""
+import os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+os.environ["CMFREC_HIP_VH"] = sys.argv[1]
+args = sys.argv[2:]
+if args and args[0] == "slice":
+    os.environ["CMFREC_HIP_GRAM_KERNEL"] = "slice"; args = args[1:]
+k, implicit, N = int(args[0]), bool(int(args[1])), int(args[2])
+from conftest import make_coo, rel_err
+from oracle.bindings import Oracle
+from cmfrec_amd import ops
+dtype = np.float32
+O = Oracle(dtype)
+m, n = 60, 5000
+row, col, val = make_coo(m, n, 12000, 41, counts=implicit, dtype=dtype, heavy_row=(3, 4500), empty_rows=(8,))
+rng = np.random.default_rng(4)
+extra_r = np.concatenate([np.full(2500, 10, np.int32), np.full(900, 11, np.int32)])
+keep = (row != 10) & (row != 11)
+extra_c = np.concatenate([rng.choice(n, 2500, replace=False), rng.choice(n, 900, replace=False)]).astype(np.int32)
+extra_v = (np.ceil(rng.lognormal(1, 1, 3400)) if implicit else 0.5 * rng.integers(1, 11, 3400)).astype(dtype)
+row = np.concatenate([row[keep], extra_r]); col = np.concatenate([col[keep], extra_c]); val = np.concatenate([val[keep], extra_v])
+csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+lens = np.diff(csr[0].astype(np.int64))
+A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+Ao = A0.copy()
+if implicit:
+    O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4)
+else:
+    csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+    O.optimizeA_explicit(Ao, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
+bad = 0
+for it in range(N):
+    Ah = A0.copy()
+    if implicit:
+        ops.optimizeA_implicit(Ah, B, csr, 4.0)
+    else:
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True, bias_sub=bias)
+    e = rel_err(Ah, Ao)
+    if e > 2e-4:
+        bad += 1
+        per = np.abs(Ah - Ao).max(axis=1)
+        rows = np.flatnonzero(per > 1e-3 * np.abs(Ao).max())
+        print("iteration %d: rel_err %.3e, rows off: %s (lengths %s)" % (it, e, rows.tolist(), lens[rows].tolist()), flush=True)
+print("%s k=%d implicit=%d: %d of %d runs off" % (" ".join(sys.argv[1:3]), k, implicit, bad, N))
