@@ -163,7 +163,7 @@ def main():
     # ---- roofline of the dominant kernel (per nnz-bin launch of the CG row kernel) ----
     names = {0: "vh_pass+vh_update x4 (rows > 1024 nnz, split rows)", 1: "cg_rows_kernel<W=8> (257..1024 nnz)",
              2: "cg_rows_kernel<W=4> (129..256 nnz)", 3: "cg_rows_kernel<W=2> (65..128 nnz)",
-             4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel (<= 32 nnz)"}
+             4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel + cg_rows_tiny2_kernel (<= 32 nnz)"}
     kernels = []
     for which in ("B", "A"):
         for b in range(6):
@@ -187,7 +187,7 @@ def main():
                       "vh_update_kernel<..., 0> x1 + vh_update_kernel<..., 1> x%d" % MAX_CG_STEPS],
                   1: ["cg_rows_kernel<double, 7, true, 8, 1>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1>"],
                   3: ["cg_rows_kernel<double, 7, true, 2, 1>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4>"],
-                  5: ["cg_rows_tiny_kernel<double, 7, true>"]}
+                  5: ["cg_rows_tiny_kernel<double, 7, true>", "cg_rows_tiny2_kernel<double, 7, true> (rows of <= 16 nnz, two per wavefront)"]}
     inv = {v: b for b, v in names.items()}
     inv["gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
     prof_names[6] = ["gram_wave_kernel<double, true>", "gram_cg_kernel<double, true>"]
@@ -584,7 +584,7 @@ def pmc_traffic(dom):
         return None
     ks = json.load(open(path))["kernels"]
     tags = {"cg_rows_kernel<W=8>": [", 8, 1>"], "cg_rows_kernel<W=4>": [", 4, 1>"], "cg_rows_kernel<W=2>": [", 2, 1>"],
-            "cg_rows_kernel<W=1>": [", 1, 4>"], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel"],
+            "cg_rows_kernel<W=1>": [", 1, 4>"], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel", "cg_rows_tiny2_kernel"],
             "vh_pass": ["vh_pass_kernel", "vh_update_kernel"], "gram_wave": ["gram_wave_kernel", "gram_cg_kernel"]}
     want = next(v for k, v in tags.items() if dom["kernel"].startswith(k))
     tot, found = 0.0, False

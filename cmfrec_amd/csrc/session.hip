@@ -1865,7 +1865,9 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
 {
     const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
     if (which == 'A' && !s->XrParts.empty()) return 1;                    // the bins of a part alternate between two streams
-    return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus)) ? 1 : 0;
+    // (the Gramian path stays in line, launch_cg_S)
+    const bool gram_in_line = cmfrec_hip_session_vh_mode(s, which) == 2 && getenv("CMFREC_HIP_VH_GRAM_ASIDE") == nullptr;
+    return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus) && !gram_in_line) ? 1 : 0;
 }
 
 int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which)
