@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBDIR = os.path.join(_HERE, "lib")
+# CMFREC_HIP_LIBDIR: load the two libraries from another directory (a second build kept beside the default one)
+LIBDIR = os.environ.get("CMFREC_HIP_LIBDIR") or os.path.join(_HERE, "lib")
 
 RETURN_CODES = {0: "ok", 1: "out of memory", 2: "invalid or unsupported input", 3: "interrupted",
                 4: "HIP runtime failure"}

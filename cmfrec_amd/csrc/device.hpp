@@ -240,6 +240,7 @@ struct SparseShard {
         long long vh_total = 0;
         for (int q = 0; q < nrows && (long long)lens_sorted[q] >= vheavy_min_nnz(); q++) vh_total += (long long)lens_sorted[q];
         slice_len = (vh_total < (long long)GRAM_SLICE * 1024) ? 256 : GRAM_SLICE;
+        if (const char *e = getenv("CMFREC_HIP_GRAM_SLICE_LEN")) slice_len = std::min(GRAM_SLICE, std::max(16, atoi(e) / 16 * 16));   // A/B measurements
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
@@ -459,6 +460,28 @@ CgVariant cg_variant_from_env();
 constexpr size_t ROW_COUNTER_INTS = 64 + (size_t)NBINS * CG_NCOUNTERS * CG_COUNTER_STRIDE;
 inline size_t cg_counter_offset(int bin) { return 64 + (size_t)bin * CG_NCOUNTERS * CG_COUNTER_STRIDE; }
 
+// Test hook (CMFREC_HIP_POISON_LDS=1, tests/test_gpu_operators.py): fill the LDS of every CU with NaN patterns in front of the
+// launches of the CG row update, so that a kernel that reads LDS it has not written -- found once in gram_cg_kernel: 0 x stale
+// LDS, NaN only when the previous tenant left a NaN pattern there, i.e. on some boxes in some runs -- fails every time.
+__global__ void __launch_bounds__(256) poison_lds_kernel(int words)
+{
+    extern __shared__ unsigned int poison_words[];
+    volatile unsigned int *w = poison_words;
+    for (int e = threadIdx.x; e < words; e += 256) w[e] = 0xFFFFFFFFu;       // NaN as float and as either half of a double
+}
+inline void poison_lds(hipStream_t st, int num_cus)
+{
+    if (getenv("CMFREC_HIP_POISON_LDS") == nullptr) return;
+    constexpr int BYTES = 80 * 1024;                                         // two workgroups cover the 160 KB of a CU
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(num_cus * 4), dim3(256), BYTES, st, BYTES / 4);
+    HIP_CHECK(hipGetLastError());
+}
+
 template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
 inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
 {
@@ -469,6 +492,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
         HIP_CHECK(hipEventCreate(&ev.b));
         HIP_CHECK(hipEventRecord(ev.a, st));
     }
+    poison_lds(st, dev.num_cus);
     P.order += first;
     P.desc += first;
     P.nrows = count;
@@ -508,6 +532,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     }
     // rows of at most 16 entries (the tail of the bin): two per wavefront (cg_rows_tiny2_kernel); CMFREC_HIP_TINY2=0 keeps them
     // on the one-row kernel (A/B switch and cross-check)
+    poison_lds(st, dev.num_cus);
     static const bool tiny2_off = getenv("CMFREC_HIP_TINY2") != nullptr && getenv("CMFREC_HIP_TINY2")[0] == '0';
     const int count2 = (GRAMX || tiny2_off) ? 0 : std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
     const int count1 = count - count2;
@@ -605,6 +630,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
 #endif
         // slice partials: one wavefront per slice straight from the gather (gram_wave_kernel), or the LDS-staged workgroup
         // kernel (CMFREC_HIP_GRAM_KERNEL=slice)
+        poison_lds(dev.stream, dev.num_cus);
         const char *gk_env = getenv("CMFREC_HIP_GRAM_KERNEL");
         const bool slice_kernel = gk_env != nullptr && strcmp(gk_env, "slice") == 0;
         if (slice_kernel)
@@ -613,6 +639,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         else
             hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), dim3(std::min((X.n_slices + 3) / 4, dev.num_cus * 4)), dim3(256), 0,
                                dev.stream, P, G);
+        poison_lds(dev.stream, dev.num_cus);
         hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 8)), dim3(256), 0, dev.stream, P, G);
         HIP_CHECK(hipGetLastError());
         if (tm) {
@@ -627,6 +654,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     V.chunk_off = X.vh_chunk_off.ptr; V.launch = X.vh_launch.ptr; V.work = X.vh_work.ptr;
     V.nvh = nvh; V.nchunks = X.n_chunks; V.nlaunch = X.n_launch;
     P.nrows = nvh;
+    poison_lds(dev.stream, dev.num_cus);
     const dim3 gp(X.n_launch), bp(64 * VH_CHUNK_TILES), gu(nvh), bu(64 * VH_UPD_WAVES);
     hipLaunchKernelGGL((vh_pass_kernel<real_t, S, IMPLICIT, 0>), gp, bp, 0, dev.stream, P, V);
     hipLaunchKernelGGL((vh_update_kernel<real_t, IMPLICIT, 0, GRAMX>), gu, bu, 0, dev.stream, P, V);
@@ -687,6 +715,7 @@ inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const S
     // 31 -> 13 ms), four for the others; the rest: a wavefront per row
     const int nteam = std::min(count, X.bin_first[BIN_MED2]);
     const int nvh = std::min(nteam, X.bin_rows[BIN_VHEAVY]);
+    poison_lds(dev.stream, dev.num_cus);
     if (nvh > 0) {
         P.row_first = 0; P.nrows = nvh;
         hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 16>), dim3(std::min(nvh, dev.num_cus * 2)), dim3(1024), 0,

@@ -395,12 +395,17 @@ gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 return (y0 + y1) + (y2 + y3);
             };
-            T r = live ? v - mul(a) : T(0);   // common.c:1932-1943 / :1128-1139
+            // (every lane takes part in `mul`: the lanes >= kt hand in zeros, so that no element of vec_s is ever read before
+            //  it was written -- 0 x whatever the LDS held is NaN when that happens to be a NaN pattern, and a NaN residual
+            //  skips the CG below and leaves the row at its start value)
+            const T Ma = mul(a);
+            T r = live ? v - Ma : T(0);       // common.c:1932-1943 / :1128-1139
             T p = r;
             T r_old = lanes::wave_sum(r * r);
             if (r_old > (T)1e-12) {           // :1952 / :1147
                 for (int step = 0; step < P.max_cg_steps; step++) {
-                    const T Ap = live ? mul(p) : T(0);
+                    const T Mp = mul(p);
+                    const T Ap = live ? Mp : T(0);
                     const T alpha = r_old / lanes::wave_sum(Ap * p);
                     a += alpha * p; r -= alpha * Ap;
                     const T r_new = lanes::wave_sum(r * r);

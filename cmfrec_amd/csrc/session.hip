@@ -134,6 +134,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 CholParams<real_t> W = P;
                 W.row_first = first; W.nrows = last; W.counter = dev.row_counter.ptr + counter;
                 auto wlaunch = [&](auto kern, int nb_, int wps) {
+                    poison_lds(st, dev.num_cus);      // test hook, device.hpp
                     const size_t smem = 4 * chol_wave_lds_elems<real_t>(nb_) * sizeof(real_t);
                     const int grid = std::min((last - first + 3) / 4, dev.num_cus * wps);
                     if (smem > 48 * 1024)
@@ -289,6 +290,7 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
         if (grid <= 0) return;
         if (smem > 48 * 1024)
             HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        poison_lds(run_on, dev.num_cus);          // test hook, device.hpp
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, run_on, P);
     };
     // <16-blocks per dimension, wavefronts per workgroup, gathered rows per round, waves per SIMD>

@@ -45,4 +45,8 @@ for it in range(N):
         per = np.abs(Ah - Ao).max(axis=1)
         rows = np.flatnonzero(per > 1e-3 * np.abs(Ao).max())
         print("iteration %d: rel_err %.3e, rows off: %s (lengths %s)" % (it, e, rows.tolist(), lens[rows].tolist()), flush=True)
+        if bad <= 2:
+            for r in rows[:2]:
+                print("   row %d got      %s\n   row %d expected %s" % (r, np.array2string(Ah[r][:8], precision=4), r,
+                                                                        np.array2string(Ao[r][:8], precision=4)), flush=True)
 print("%s k=%d implicit=%d: %d of %d runs off" % (" ".join(sys.argv[1:3]), k, implicit, bad, N))
