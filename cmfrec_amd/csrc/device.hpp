@@ -58,6 +58,10 @@ struct DevBuf {
         n = count;
         owned = true;
         if (count) HIP_CHECK(hipMalloc((void **)&ptr, count * sizeof(T)));
+        if (count && getenv("CMFREC_HIP_POISON_LDS") != nullptr) {          // test hook (poison_lds below): device buffers too
+            HIP_CHECK(hipMemset(ptr, 0xFF, count * sizeof(T)));
+            HIP_CHECK(hipDeviceSynchronize());
+        }
     }
     void alloc_at_least(size_t count)
     {
