@@ -54,8 +54,14 @@ def frob(a, b):
 
 
 def maxrel(a, b):
+    dt = np.asarray(a).dtype
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+    e = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+    log = os.environ.get("CMFREC_TEST_RELERR_LOG")       # same log as conftest.rel_err
+    if log:
+        with open(log, "a") as f:
+            f.write("%s %s %.3e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], dt, e))
+    return e
 
 
 # ---- result metrics of the reference's benchmarks (SURVEY.md 8c G7, 8d "results parity") ----

@@ -7,7 +7,7 @@ import golden_cases as gc
 
 pytestmark = pytest.mark.gpu
 DT = [np.float64, np.float32]
-TOL = {np.float64: 1e-10, np.float32: 2e-4}
+TOL = {np.float64: 1e-10, np.float32: 1e-4}      # measured worst cases: profiles/r02_ao_relerr_maxima.txt
 TOL_FIT = {np.float64: 1e-6, np.float32: 1e-2}
 
 

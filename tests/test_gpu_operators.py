@@ -1,13 +1,13 @@
 """GPU parity: every operator of the HIP path (through the C ABI, host-buffer level) against the
 oracle on the same seeded inputs.  Tolerances: SURVEY.md 8d -- single operator call, fp64 1e-10
-relative (max-abs / max-abs), fp32 1e-4."""
+relative (max-abs / max-abs), fp32 1e-4 (worst case measured over this file: 2.7e-5, profiles/r02_ao_relerr_maxima.txt)."""
 import numpy as np
 import pytest
 
 from conftest import make_coo, rel_err
 
 pytestmark = pytest.mark.gpu
-TOL = {np.float64: 1e-10, np.float32: 2e-4}
+TOL = {np.float64: 1e-10, np.float32: 1e-4}      # measured worst cases: profiles/r02_ao_relerr_maxima.txt
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
