@@ -128,14 +128,7 @@ __host__ __device__ inline size_t chol_lds_elems(int NTT, int CH)
     return 2 * (size_t)CH * ldc + (size_t)NTT * 16 * CholMfma<T>::LDR + 2 * 16 * (size_t)NTT + 4 * CH + 8;
 }
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
+// (static_for lives in lanes.hpp)
 // tile t of the packed upper triangle of an NTT x NTT tile grid -> (bi, bj), bj >= bi
 __host__ __device__ constexpr int tile_bi(int t, int NTT)
 {

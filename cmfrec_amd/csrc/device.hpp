@@ -13,6 +13,7 @@
 
 #include "../../include/cmfrec_hip.h"
 #include "cg_kernels.hpp"
+#include "cg2_kernels.hpp"
 #include "chol_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gram_cg_kernels.hpp"
@@ -91,12 +92,17 @@ constexpr int BIN_MED2 = 3;     // 65..128    : 2 waves / row
 constexpr int BIN_LIGHT = 4;    // 33..64     : 1 wave / row, 4 rows / workgroup
 constexpr int BIN_TINY = 5;     // 1..32      : 1 wave / row, half-size tiles, double-buffered gather
 constexpr int BIN_MIN_NNZ[NBINS] = {1025, 257, 129, 65, 33, 1};
+// Double precision: an 8-wave team keeps 512 entries in registers, longer rows re-stream their second tile on every pass
+// (1.7x the algorithmic bytes measured on that bin in round 2).  Since the split rows' Gramian kernel does the last column
+// block of k = 50 on the vector ALU (round 3), cutting at 513 instead of 1025 is the faster split: C2 4.36 -> 4.16 ms
+// (513), 4.24 (769), 4.34 (385) -- profiles/r03_c.  CMFREC_HIP_VH_MIN overrides.
+constexpr int VH_MIN_DEFAULT = (sizeof(real_t) == 8) ? 513 : 1025;
 inline int vheavy_min_nnz()
 {
     // (single precision: the 8-wave kernel keeps two tiles per wave and nothing else, so the boundary cannot move up)
     static const int v = getenv("CMFREC_HIP_VH_MIN")
                              ? std::min(sizeof(real_t) == 4 ? BIN_MIN_NNZ[BIN_VHEAVY] : (1 << 30), std::max(258, atoi(getenv("CMFREC_HIP_VH_MIN"))))
-                             : BIN_MIN_NNZ[BIN_VHEAVY];
+                             : VH_MIN_DEFAULT;
     return v;
 }
 inline int bin_of(long long nnz)
@@ -342,6 +348,10 @@ struct DeviceInfo {
         if (eig_stream_) (void)hipStreamDestroy(eig_stream_);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
         if (join_ev) (void)hipEventDestroy(join_ev);
+        for (int i = 0; i < MAX_BIN_STREAMS; i++) {
+            if (bin_join[i]) (void)hipEventDestroy(bin_join[i]);
+            if (i > 0 && bin_streams[i]) (void)hipStreamDestroy(bin_streams[i]);
+        }
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -365,6 +375,20 @@ struct DeviceInfo {
         HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    }
+    // further streams for the nnz bins of a half-step running side by side (launch_cg_S): bin_streams[0] is aux_stream
+    static constexpr int MAX_BIN_STREAMS = 5;
+    hipStream_t bin_streams[MAX_BIN_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t bin_join[MAX_BIN_STREAMS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void ensure_bin_streams(int n)
+    {
+        ensure_aux();
+        bin_streams[0] = aux_stream;
+        if (!bin_join[0]) HIP_CHECK(hipEventCreateWithFlags(&bin_join[0], hipEventDisableTiming));
+        for (int i = 1; i < n && i < MAX_BIN_STREAMS; i++) {
+            if (!bin_streams[i]) HIP_CHECK(hipStreamCreateWithFlags(&bin_streams[i], hipStreamNonBlocking));
+            if (!bin_join[i]) HIP_CHECK(hipEventCreateWithFlags(&bin_join[i], hipEventDisableTiming));
+        }
     }
 };
 
@@ -524,6 +548,64 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
+// Second-generation tiled kernels (cg2_kernels.hpp): slots in use only, vectors redistributed through LDS, cheaper Gramian
+// product.  CMFREC_HIP_CG2=0 / 1 forces the first / second generation (A/B measurements and on-device cross-check); the
+// default is the second generation in double precision.
+inline bool cg2_enabled()
+{
+    static const int v = [] {
+        const char *e = getenv("CMFREC_HIP_CG2");
+        if (e != nullptr) return (e[0] != '0') ? 1 : 0;
+        return (sizeof(real_t) == 8) ? 1 : 0;
+    }();
+    return v != 0;
+}
+// rows of at most 16 entries: two per wavefront on the first-generation kernel (default) or the NT = 4 kernel with one or two
+// slots in use (CMFREC_HIP_CG2_TINY=all)
+inline bool cg2_tiny_all()
+{
+    static const bool v = getenv("CMFREC_HIP_CG2_TINY") != nullptr && strcmp(getenv("CMFREC_HIP_CG2_TINY"), "all") == 0;
+    return v;
+}
+
+template <int S, int NT, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
+inline void launch_cg2_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st,
+                           bool own_events = true)
+{
+    if (count <= 0) return;
+    EventPair ev{nullptr, nullptr};
+    if (tm && own_events) {
+        HIP_CHECK(hipEventCreate(&ev.a));
+        HIP_CHECK(hipEventCreate(&ev.b));
+        HIP_CHECK(hipEventRecord(ev.a, st));
+    }
+    poison_lds(st, dev.num_cus);
+    P.order += first;
+    P.desc += first;
+    P.nrows = count;
+    P.counter = dev.row_counter.ptr + cg_counter_offset(bin);          // zeroed by launch_cg_S
+    constexpr int threads = 64 * W * RPB;
+    const size_t smem = (((IMPLICIT || GRAMX) ? (size_t)gram2_elems(S) : 0) + (size_t)W * RPB * 64 + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
+    auto kern = cg2_rows_kernel<real_t, S, NT, IMPLICIT, W, RPB, GRAMX>;
+    static thread_local int bpc_dev[MAX_DEVICES] = {0};
+    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
+    if (blocks_per_cu == 0) {
+        if (smem > 48 * 1024)
+            HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int nb = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, smem));
+        blocks_per_cu = std::max(1, nb);
+    }
+    const int teams_needed = (count + RPB - 1) / RPB;
+    const int grid = std::min(teams_needed, dev.num_cus * blocks_per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, st, P);
+    HIP_CHECK(hipGetLastError());
+    if (tm && own_events) {
+        HIP_CHECK(hipEventRecord(ev.b, st));
+        tm->ev[bin].push_back(ev);
+    }
+}
+
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st, int n_gt16)
 {
@@ -542,6 +624,38 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
+    if (cg2_enabled()) {
+        // second generation: NT = 4 tiles for the rows above 16 entries (or the whole bin), the two-rows-per-wavefront kernel below
+        // for the rest; one event pair around both launches
+        const int c1 = cg2_tiny_all() ? count : count1;
+        launch_cg2_bin<S, 4, IMPLICIT, 1, 4, GRAMX>(dev, P, first, c1, nullptr, BIN_TINY, st, false);
+        if constexpr (!GRAMX) {
+            const int c2 = count - c1;
+            if (c2 > 0) {
+                CgParams<real_t> P2 = P;
+                P2.order += first + c1;
+                P2.desc += first + c1;
+                P2.nrows = c2;
+                auto kern2 = cg_rows_tiny2_kernel<real_t, S, IMPLICIT>;
+                static thread_local int bpc3_dev[MAX_DEVICES] = {0};
+                int &blocks_per_cu = bpc3_dev[di];
+                if (blocks_per_cu == 0) {
+                    int nb = 0;
+                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern2, 256, IMPLICIT ? smem : 0));
+                    blocks_per_cu = std::max(1, nb);
+                }
+                const int npairs = (c2 + 1) / 2;
+                int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
+                hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), IMPLICIT ? smem : 0, st, P2);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        if (tm) {
+            HIP_CHECK(hipEventRecord(ev.b, st));
+            tm->ev[BIN_TINY].push_back(ev);
+        }
+        return;
+    }
     if (count1 > 0) {
         CgParams<real_t> P1 = P;
         P1.order += first;
@@ -640,9 +754,20 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         if (slice_kernel)
             hipLaunchKernelGGL((gram_slice_kernel<real_t, IMPLICIT>), dim3(std::min(X.n_slices, dev.num_cus * 2)), dim3(64 * GRAM_NW), 0,
                            dev.stream, P, G);
-        else
-            hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), dim3(std::min((X.n_slices + 3) / 4, dev.num_cus * 4)), dim3(256), 0,
-                               dev.stream, P, G);
+        else {
+            // double precision, 48 < k <= 52 (k = 50): the two to four columns of the last block as vector products instead of
+            // four matrix-core tiles per slab (CMFREC_HIP_GRAM_REMV=0: all ten tiles, A/B and cross-check)
+            static const bool remv_off = getenv("CMFREC_HIP_GRAM_REMV") != nullptr && getenv("CMFREC_HIP_GRAM_REMV")[0] == '0';
+            const dim3 gw(std::min((X.n_slices + 3) / 4, dev.num_cus * 4));
+            const int rem = (sizeof(real_t) == 8 && !remv_off) ? P.k - 16 * (GRAM_NTT - 1) : 0;
+            switch (rem) {
+                case 1: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 1>), gw, dim3(256), 0, dev.stream, P, G); break;
+                case 2: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 2>), gw, dim3(256), 0, dev.stream, P, G); break;
+                case 3: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 3>), gw, dim3(256), 0, dev.stream, P, G); break;
+                case 4: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 4>), gw, dim3(256), 0, dev.stream, P, G); break;
+                default: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), gw, dim3(256), 0, dev.stream, P, G); break;
+            }
+        }
         poison_lds(dev.stream, dev.num_cus);
         hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 8)), dim3(256), 0, dev.stream, P, G);
         HIP_CHECK(hipGetLastError());
@@ -673,6 +798,44 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     }
 }
 
+// number of streams the nnz bins of a half-step are spread over (CMFREC_HIP_BINS_PAR; 1 = one after the other)
+inline int cg_bin_streams()
+{
+    static const int v = [] {
+        const char *e = getenv("CMFREC_HIP_BINS_PAR");
+        const int n = e ? atoi(e) : 1;
+        return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
+    }();
+    return v;
+}
+
+// one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row) on the kernel generation in use
+template <int S, bool IMPLICIT, bool GRAMX>
+inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm, int bin, hipStream_t st)
+{
+    const int first = X.bin_first[bin], count = X.bin_rows[bin];
+    const bool v2 = cg2_enabled();
+    switch (bin) {
+        case BIN_HEAVY:
+            // (single precision: the first-generation 8-wave kernel keeps two resident tiles per wave, the second generation one)
+            if (v2 && sizeof(real_t) == 8) launch_cg2_bin<S, 8, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st);
+            else launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st);
+            break;
+        case BIN_MED4:
+            if (v2) launch_cg2_bin<S, 8, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st);
+            else launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st);
+            break;
+        case BIN_MED2:
+            if (v2) launch_cg2_bin<S, 8, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st);
+            else launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st);
+            break;
+        default:
+            if (v2) launch_cg2_bin<S, 8, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
+            else launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
+            break;
+    }
+}
+
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm)
 {
@@ -690,6 +853,34 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     // feed the roofline report and must not overlap.)
     const bool alt = (X.is_part && getenv("CMFREC_HIP_PART_SERIAL") == nullptr) || getenv("CMFREC_HIP_BINS_ALT") != nullptr;
     DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+    // Round 3: the bins of a half-step side by side.  Every bin is a persistent launch whose teams claim rows from a counter, so
+    // a launch that shares the chip with its neighbours just takes its rows as workgroups become resident; what disappears are
+    // the ramp-up and the tail of six launches per half-step, during which most CUs idle (C2: 4.36 -> 4.09 ms with two streams).
+    // CMFREC_HIP_BINS_PAR = number of streams (1: in line as before; default cg_bin_streams()).  The per-bin events then
+    // measure overlapping spans.
+    const int npar = cg_bin_streams();
+    if (npar > 1 && !(vh_aside || alt)) {
+        d.ensure_bin_streams(npar - 1);
+        hipStream_t ss[DeviceInfo::MAX_BIN_STREAMS + 1];
+        ss[0] = dev.stream;
+        for (int i = 1; i < npar; i++) ss[i] = d.bin_streams[i - 1];
+        HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
+        for (int i = 1; i < npar; i++) HIP_CHECK(hipStreamWaitEvent(ss[i], d.fork_ev, 0));
+        int nx = 0;
+        auto next = [&]() { hipStream_t st = ss[nx]; nx = (nx + 1) % npar; return st; };
+        // longest-running first; the split rows' two launches stay on one stream
+        launch_cg_vheavy<S, IMPLICIT, GRAMX>(dev, P, X, tm, next());
+        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_HEAVY, next());
+        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_MED2, next());
+        launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, next(), X.n_gt16);
+        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_MED4, next());
+        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_LIGHT, next());
+        for (int i = 1; i < npar; i++) {
+            HIP_CHECK(hipEventRecord(d.bin_join[i - 1], ss[i]));
+            HIP_CHECK(hipStreamWaitEvent(dev.stream, d.bin_join[i - 1], 0));
+        }
+        return;
+    }
     if (vh_aside || alt) {
         d.ensure_aux();
         HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
@@ -698,10 +889,10 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     hipStream_t s0 = dev.stream, s1 = alt ? d.aux_stream : dev.stream;
     launch_cg_vheavy<S, IMPLICIT, GRAMX>(dev, P, X, tm, (vh_aside || (alt && X.is_part)) ? d.aux_stream : dev.stream);
     // then longest rows first: they are the longest-running teams
-    launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, X.bin_first[BIN_HEAVY], X.bin_rows[BIN_HEAVY], tm, BIN_HEAVY, s0);
-    launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, X.bin_first[BIN_MED4], X.bin_rows[BIN_MED4], tm, BIN_MED4, s1);
-    launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, X.bin_first[BIN_MED2], X.bin_rows[BIN_MED2], tm, BIN_MED2, s0);
-    launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, X.bin_first[BIN_LIGHT], X.bin_rows[BIN_LIGHT], tm, BIN_LIGHT, s1);
+    launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_HEAVY, s0);
+    launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_MED4, s1);
+    launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_MED2, s0);
+    launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_LIGHT, s1);
     launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, s0, X.n_gt16);
     if (vh_aside || alt) {
         HIP_CHECK(hipEventRecord(d.join_ev, d.aux_stream));

@@ -31,7 +31,10 @@ struct SigGuard {
     bool armed = false;
     explicit SigGuard(bool arm) : armed(arm)
     {
-        if (arm) { g_stop = 0; old = signal(SIGINT, on_sigint); }
+        // the flag is cleared for every fit, armed or not: the loops test it unconditionally, and a Ctrl-C handled by an
+        // earlier fit must not end the next one at iteration 0 (the reference resets should_stop_procedure in its cleanup)
+        g_stop = 0;
+        if (arm) old = signal(SIGINT, on_sigint);
     }
     ~SigGuard() { if (armed) signal(SIGINT, old); }
 };

@@ -188,13 +188,23 @@ gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
 #endif
 template <typename T> constexpr int gw_slabs() { return sizeof(T) == 4 ? GW_SLABS_F32 : GW_SLABS_F64; }     // slabs per prefetch group
 
-template <typename T, bool IMPLICIT>
+// REM > 0 (round 3, double precision): only the first NTF = NTT - 1 column blocks go through the matrix cores; the REM columns
+// 16 NTF .. kt - 1 (at most GW_REM of them: k = 50 has two) are VALU products -- lane (kc, lm) takes the column's element of its
+// slab row from lane (kc, column - 16 NTF) with one row_newbcast move and adds  w e_j B_j[16 cb + lm]  for its four blocks.
+// In double precision an MFMA occupies the pipe as long as ~30 vector FMAs and the last column block of k = 50 holds 2 live
+// columns of 16: 4 of the 10 tiles per slab are replaced by 12 vector instructions.  Their sums land in the partial at the
+// positions gram_cg_kernel reads (tile (cb, NTT - 1), column j - 16 (NTT - 1)); the rest of those tiles stays unwritten and unread.
+constexpr int GW_REM = 4;
+template <typename T, bool IMPLICIT, int REM = 0>
 __global__ void __launch_bounds__(256, 2)
 gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
 {
     using Mf = CholMfma<T>;
     using vec = typename Mf::vec;
     constexpr int NTT = GRAM_NTT, NTALL = GRAM_NTILES, NS = gw_slabs<T>(), GRP = 4 * NS;
+    constexpr bool REMV = REM > 0;
+    constexpr int NTF = REMV ? NTT - 1 : NTT;                 // the host launches REM = kt - 16 (NTT - 1)
+    static_assert(REM >= 0 && REM <= GW_REM, "remainder columns");
     const int kt = P.k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kc = lane >> 4, lm = lane & 15;                // slab row of this lane, column inside a 16-column block
@@ -225,6 +235,11 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
         T racc[NTT];
 #pragma unroll
         for (int cb = 0; cb < NTT; cb++) racc[cb] = T(0);
+        T cacc[REMV ? REM : 1][NTT];                          // remainder columns: G[16 cb + lm][16 NTF + c], this lane's slab rows
+#pragma unroll
+        for (int c = 0; c < (REMV ? REM : 1); c++)
+#pragma unroll
+            for (int cb = 0; cb < NTT; cb++) cacc[c][cb] = T(0);
 
         // entry (lane & 31) of a group: index, value (explicit: minus the fused bias), 1 / 0 for entries past the slice
         auto load_entries = [&](int c0, int &idx, T &x, T &okf) {
@@ -280,8 +295,16 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
                 }
                 static_for<0, NTALL>([&](auto tc) {
                     constexpr int t = decltype(tc)::value, bi = tile_bi(t, NTT), bj = tile_bj(t, NTT);
-                    acc[t] = Mf::mma(sa[bi], cur[q][bj], acc[t]);
+                    if constexpr (bj < NTF) acc[t] = Mf::mma(sa[bi], cur[q][bj], acc[t]);
                 });
+                if constexpr (REMV) {
+                    static_for<0, REM>([&](auto cc) {
+                        constexpr int c = decltype(cc)::value;
+                        const T we = wG * lanes::row_bcast16<c>(cur[q][NTT - 1]);
+#pragma unroll
+                        for (int cb = 0; cb < NTT; cb++) cacc[c][cb] += we * cur[q][cb];
+                    });
+                }
             }
 #pragma unroll
             for (int q = 0; q < NS; q++)
@@ -291,10 +314,26 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
             idx_n = idx_nn; x_n = x_nn; ok_n = ok_nn;
         }
         T *out = Gp.part + (size_t)sl * GRAM_PART;
+        static_for<0, NTALL>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (tile_bj(t, NTT) < NTF) {
 #pragma unroll
-        for (int t = 0; t < NTALL; t++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[t][r];
+                for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[t][r];
+            }
+        });
+        if constexpr (REMV) {
+            // element (16 cb + lm, 16 NTF + c): summed over the four slab rows (16 lanes apart), stored where tile (cb, NTT - 1) keeps it
+            static_for<0, REM>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                static_for<0, NTT>([&](auto cbc) {
+                    constexpr int cb = decltype(cbc)::value;
+                    // packed index of tile (cb, NTT - 1): sum_{b < cb} (NTT - b) + (NTT - 1 - cb)
+                    constexpr int t = cb * NTT - cb * (cb - 1) / 2 + (NTT - 1 - cb);
+                    T v = lanes::tswap32_add(cacc[c][cb], cacc[c][cb]);
+                    v = lanes::tswap16_add(v, v);
+                    if (kc == 0) out[t * 256 + Mf::cidx(lm, c)] = v;
+                });
+            });
         }
         // v: the four slab rows of a column sit 16 lanes apart
 #pragma unroll

@@ -4,8 +4,20 @@
 // (doubles are moved as two dwords).  Verified on device by cmfrec_hip_selftest_lanes().
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace cmfhip {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = I0 .. N-1
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 namespace lanes {
 
 constexpr int QP_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
@@ -13,6 +25,8 @@ constexpr int QP_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
 constexpr int ROW_SHL4 = 0x104;    // lane i <- lane i+4 (inside a 16-lane row)
 constexpr int ROW_SHR4 = 0x114;    // lane i <- lane i-4
 constexpr int ROW_ROR8 = 0x128;    // lane i <- lane (i+8)%16
+constexpr int ROW_HALF_MIRROR = 0x141;   // lane i <- lane 7 - i inside each group of 8 lanes
+constexpr int ROW_NEWBCAST = 0x150;      // + n: every lane of a 16-lane row <- lane n of the row (gfx90a+; also as v_mov_b64_dpp)
 
 template <int CTRL, int BANK>
 __device__ __forceinline__ int dpp(int old, int src)
@@ -89,17 +103,26 @@ template <> __device__ __forceinline__ double tswap16_add(double a, double b)
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
-// value of lane ((lane & ~7) | t) for every lane (t compile-time)
-template <int t, typename T> __device__ __forceinline__ T bcast8(T x)
+// value of lane ((lane & ~7) | t) for every lane (t compile-time): two row_newbcast moves, one per half of the 16-lane row
+// (bank masks 0x3 / 0xC).  A double moves as ONE v_mov_b64_dpp per half -- row_newbcast is the one DPP control the 64-bit move
+// has on this part -- instead of two 32-bit moves per half.
+template <int t> __device__ __forceinline__ int bcast8(int x)
 {
-    constexpr int q = t & 3;
-    constexpr int QP = q | (q << 2) | (q << 4) | (q << 6);
-    return map(x, [](int v) {
-        int y = dpp_new<QP, 0xF>(v);
-        if (t < 4) return dpp<ROW_SHR4, 0xA>(y, y);      // odd quads fetch from the even quad
-        else       return dpp<ROW_SHL4, 0x5>(y, y);      // even quads fetch from the odd quad
-    });
+    int y = __builtin_amdgcn_mov_dpp(x, ROW_NEWBCAST + t, 0xF, 0x3, false);
+    return __builtin_amdgcn_update_dpp(y, x, ROW_NEWBCAST + 8 + t, 0xF, 0xC, false);
 }
+template <int t> __device__ __forceinline__ float bcast8(float x) { return __int_as_float(bcast8<t>(__float_as_int(x))); }
+template <int t> __device__ __forceinline__ double bcast8(double x)
+{
+    double y = __builtin_amdgcn_mov_dpp(x, ROW_NEWBCAST + t, 0xF, 0x3, false);
+    return __builtin_amdgcn_update_dpp(y, x, ROW_NEWBCAST + 8 + t, 0xF, 0xC, false);
+}
+// value of lane ((lane & ~15) | t): lane t of the lane's 16-lane row (one v_mov_b64_dpp for a double)
+template <int t> __device__ __forceinline__ int row_bcast16(int x) { return __builtin_amdgcn_mov_dpp(x, ROW_NEWBCAST + t, 0xF, 0xF, false); }
+template <int t> __device__ __forceinline__ float row_bcast16(float x) { return __int_as_float(row_bcast16<t>(__float_as_int(x))); }
+template <int t> __device__ __forceinline__ double row_bcast16(double x) { return __builtin_amdgcn_mov_dpp(x, ROW_NEWBCAST + t, 0xF, 0xF, false); }
+// value of lane (lane ^ 7) (the mirror image inside the lane's group of 8)
+template <typename T> __device__ __forceinline__ T half_mirror(T x) { return map(x, [](int v) { return dpp_new<ROW_HALF_MIRROR, 0xF>(v); }); }
 
 // full wave sum, identical on every lane
 template <typename T> __device__ __forceinline__ T wave_sum(T v)

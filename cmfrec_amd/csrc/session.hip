@@ -1057,7 +1057,10 @@ int cmfrec_hip_session_sideinfo_finish(cmfrec_hip_session *s, int which)
         const DeviceInfo &dev = s->dev;
         const bool isC = (which == 'C');
         const int p = isC ? m.p : m.q;
-        if ((which != 'C' && which != 'D') || p <= 0) return 2;
+        if ((which != 'C' && which != 'D') || p <= 0 || (isC ? s->sparseU : s->sparseI)) {
+            g_last_error = "cmfrec_hip_session_sideinfo_finish: dense side information on that side is required";
+            return 2;
+        }
         const int rows_u = isC ? m.m_u : m.n_i;
         const int kc = (isC ? m.k_user : m.k_item) + m.k;
         real_t *Cm = isC ? s->C.ptr : s->D.ptr;
@@ -1766,7 +1769,16 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
             for (auto &v : (which == 'A' ? s->binA : s->binB).ev) trim_events(v);
             return rc;
         }
-        if (which == 'C' || which == 'D') return update_sideinfo(s, which == 'C', chol);
+        if (which == 'C' || which == 'D') {
+            if (s->side_local) {
+                // the session holds the side information of its row block only: the whole-matrix update would read rows it
+                // does not have -- the sharded form is sideinfo_partial + all-reduce + sideinfo_finish
+                g_last_error = "cmfrec_hip_session_update: C / D of a session with local side information go through "
+                               "cmfrec_hip_session_sideinfo_partial / _finish";
+                return 2;
+            }
+            return update_sideinfo(s, which == 'C', chol);
+        }
         if ((which == 'a' || which == 'b') && s->implicit_feats) return update_implicit_feats(s, which == 'a');
         g_last_error = "cmfrec_hip: unknown update target";
         return 2;
@@ -2352,6 +2364,8 @@ __global__ void lanes_selftest_kernel(real_t *out)
     for (int i = 0; i < 8; i++) v[i] = (real_t)(lane + 100 * i);
     o[13 * 64] = treduce8_low<real_t>(v, lane);
     o[14 * 64] = treduce8_high<real_t>(v, lane);
+    o[15 * 64] = lanes::half_mirror(x);
+    o[16 * 64] = (real_t)lanes::bcast8<6>(lane * 5 + 2);
 }
 }  // namespace cmfhip
 
@@ -2362,17 +2376,17 @@ extern "C" int cmfrec_hip_selftest_lanes(void)
         DeviceInfo dev;
         init_device(dev, -1);
         DevBuf<real_t> d;
-        d.alloc(15 * 64);
+        d.alloc(17 * 64);
         hipLaunchKernelGGL(lanes_selftest_kernel, dim3(1), dim3(64), 0, dev.stream, d.ptr);
         HIP_CHECK(hipGetLastError());
-        std::vector<real_t> h(15 * 64);
+        std::vector<real_t> h(17 * 64);
         d.download(h.data(), h.size(), dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
         auto X = [](int l) { return (double)(l * 3 + 1); };
         auto Y = [](int l) { return (double)(1000 + l); };
         bad = 0;
         for (int l = 0; l < 64; l++) {
-            double e[15];
+            double e[17];
             e[0] = X(l ^ 1); e[1] = X(l ^ 2); e[2] = X(l ^ 4); e[3] = X(l ^ 8);
             e[4] = (l & 4) ? Y(l ^ 4) : X(l ^ 4);
             e[5] = (l & 8) ? Y(l ^ 8) : X(l ^ 8);
@@ -2383,7 +2397,9 @@ extern "C" int cmfrec_hip_selftest_lanes(void)
             e[12] = s;
             { int b = l & 7; double t = 0; for (int j = 0; j < 8; j++) t += (double)(((l & ~7) | j) + 100 * b); e[13] = t; }
             { int b = l >> 3; double t = 0; for (int j = 0; j < 8; j++) t += (double)(((l & 7) | (j << 3)) + 100 * b); e[14] = t; }
-            for (int c = 0; c < 15; c++)
+            e[15] = X(l ^ 7);
+            e[16] = (double)(((l & ~7) | 6) * 5 + 2);
+            for (int c = 0; c < 17; c++)
                 if ((double)h[c * 64 + l] != e[c]) {
                     if (bad < 8) fprintf(stderr, "lanes selftest: case %d lane %d got %g expected %g\n", c, l, (double)h[c * 64 + l], e[c]);
                     bad++;

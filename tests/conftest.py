@@ -48,6 +48,23 @@ def rel_err(a, b):
     return e
 
 
+def row_rel_err(a, b, floor=1e-6):
+    """Per-row criterion: for every row, max-abs error over the row's max-abs value; rows whose entries are all
+    below `floor` x the matrix maximum are measured against that floor instead (a row of zeros has no scale of its own).
+    Returns (worst ratio, index of the worst row).  The global rel_err above lets a row whose entries are 1e-3 of the matrix
+    maximum be 10 % off at a 1e-4 tolerance; this one does not."""
+    a = np.asarray(a, np.float64).reshape(len(a), -1)
+    b = np.asarray(b, np.float64).reshape(len(b), -1)
+    scale = np.maximum(np.abs(b).max(axis=1), floor * max(float(np.abs(b).max()), 1e-300))
+    e = np.abs(a - b).max(axis=1) / scale
+    worst = int(np.argmax(e))
+    log = os.environ.get("CMFREC_TEST_RELERR_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("%s %s row %.3e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], np.asarray(a).dtype, e[worst]))
+    return float(e[worst]), worst
+
+
 @pytest.fixture(scope="session")
 def oracles():
     from oracle.bindings import Oracle

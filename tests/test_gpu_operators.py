@@ -4,10 +4,16 @@ relative (max-abs / max-abs), fp32 1e-4 (worst case measured over this file: 2.7
 import numpy as np
 import pytest
 
-from conftest import make_coo, rel_err
+from conftest import make_coo, rel_err, row_rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = {np.float64: 1e-10, np.float32: 1e-4}      # measured worst cases: profiles/r02_ao_relerr_maxima.txt
+ROW_TOL = {np.float64: 1e-9, np.float32: 1e-3}   # per-row criterion (row max-abs error / row max-abs), SURVEY.md 8d
+
+
+def check_rows(got, exp, dtype):
+    e, r = row_rel_err(got, exp)
+    assert e < ROW_TOL[dtype], "row %d: per-row relative error %.3e" % (r, e)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -28,6 +34,7 @@ def test_optimizeA_implicit(oracles, dtype, k, mode):
     Go = O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, return_BtB=True, **kw)
     assert rel_err(Gh, Go) < TOL[dtype]
     assert rel_err(Ah, Ao) < TOL[dtype]
+    check_rows(Ah, Ao, dtype)
     if mode != "chol":   # empty rows are left untouched by the CG path (common.c:3354)
         assert np.array_equal(Ah[5], A0[5]) and np.array_equal(Ah[17], A0[17])
     else:              # and zeroed by the Cholesky path (common.c:3334)
@@ -53,6 +60,7 @@ def test_optimizeA_explicit(oracles, dtype, k, pad, mode):
     csr_sub = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))   # what the reference's host sweep does
     O.optimizeA_explicit(Ao, B, csr_sub, 0.05, nthreads=4, **kw)
     assert rel_err(Ah, Ao) < TOL[dtype]
+    check_rows(Ah[:, :k], Ao[:, :k], dtype)
     assert np.array_equal(Ah[2], A0[2])            # empty rows untouched in Case 4 (common.c:3270)
     if pad:
         assert np.array_equal(Ah[:, k:], A0[:, k:])   # padding columns never written
@@ -130,6 +138,7 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, k, monkeypatch
         csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
         O.optimizeA_explicit(Ao, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
     assert rel_err(Ah, Ao) < TOL[dtype]
+    check_rows(Ah, Ao, dtype)
     assert np.array_equal(Ah[8], A0[8])
 
 
@@ -176,6 +185,41 @@ def test_two_rows_per_wave(oracles, dtype, implicit, k):
             ops.optimizeA_explicit(Ah2, B, csr, 0.05, lam_last=0.3, scale_lam=True, bias_sub=bias)
             O.optimizeA_explicit(Ao2, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
     assert rel_err(Ah2, Ao2) < 10 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("implicit", [True, False])
+@pytest.mark.parametrize("k", [50, 64, 9])
+def test_every_slot_count(oracles, dtype, implicit, k):
+    """The second-generation tiled kernels (cg2_kernels.hpp) run the gather and the tile products over the slots in use
+    only: rows of EVERY length 1 .. 150 (all slot counts 1 .. 8 of a 64-entry tile and 1 .. 4 of a 32-entry one, full and
+    partly filled last slots, one-, two- and four-wave teams), a few of 250 .. 1000 (four- and eight-wave teams, the
+    re-streamed second tile in double precision), checked row by row."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    lens = list(range(0, 151)) + [250, 256, 257, 300, 511, 512, 513, 640, 777, 1000, 1024]
+    m, n = len(lens), 2200
+    rng = np.random.default_rng(100 + k)
+    rows = [np.full(c, r, np.int32) for r, c in enumerate(lens)]
+    cols = [rng.choice(n, c, replace=False).astype(np.int32) for c in lens]
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
+    val = (np.ceil(rng.lognormal(1, 1, len(row))) if implicit else 0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    if implicit:
+        ops.optimizeA_implicit(Ah, B, csr, 4.0)
+        O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4)
+    else:
+        bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True, bias_sub=bias)
+        csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+        O.optimizeA_explicit(Ao, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    check_rows(Ah, Ao, dtype)
+    assert np.array_equal(Ah[0], A0[0])
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
