@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-point", action="store_true", help="skip the N = 1 point of the scaling series (config 4 on one GPU)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
     ap.add_argument("--implicit-features", action="store_true", help="side workloads c1 / c3: add the implicit-features matrices Ai, Bi")
@@ -175,13 +176,28 @@ def main():
                 kernels.append(dict(step=which, kernel=name_b, ms_total=ms, launches=cnt, rows=rows_b, nnz=nnz_b,
                                     avg_ms=ms / cnt, alg_bytes=algorithmic_bytes(nnz_b, rows_b, K),
                                     overlapped=sess.bin_overlaps(which, b)))
-    # launches that run beside other kernels (few split rows on the second stream) have no duration of their own
-    dom = max([d for d in kernels if not d["overlapped"]], key=lambda d: d["ms_total"])
-    achieved = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
-    traffic = pmc_traffic(dom) if args.scale == 1.0 and world == 1 else None
     msA, cntA = sess.kernel_time("A"); msB, cntB = sess.kernel_time("B")
     halfstep_ms = {"A": msA / max(cntA, 1), "B": msB / max(cntB, 1)}
     iter_bytes = sum(d["alg_bytes"] for d in kernels)
+    side_by_side = all(d["overlapped"] for d in kernels)
+    if side_by_side:
+        # Round 3: the nnz bins of a half-step run side by side on several streams (cmfrec_amd/csrc/device.hpp, launch_cg_S), so
+        # a bin's event pair spans a time in which it shares the chip -- it has no duration of its own.  The unit that does is the
+        # half-step: ONE group of launches forked from and joined on the session's stream, timed by the event pair around it on
+        # that stream.  The dominant launch group is the longer half-step; its algorithmic bytes are the sum over its bins.
+        w_dom = max(("A", "B"), key=lambda w: halfstep_ms[w])
+        grp = [d for d in kernels if d["step"] == w_dom]
+        dom = dict(step=w_dom, kernel="%s half-step: %d nnz-bin launches side by side on %s streams (%s)" % (
+            w_dom, len(grp), os.environ.get("CMFREC_HIP_BINS_PAR", "2"), " | ".join(d["kernel"].split(" (")[0] for d in grp)),
+                   avg_ms=halfstep_ms[w_dom], alg_bytes=sum(d["alg_bytes"] for d in grp), nnz=sum(d["nnz"] for d in grp),
+                   overlapped=False, group=grp)
+        tr = [pmc_traffic(d) for d in grp] if args.scale == 1.0 and world == 1 else [None]
+        traffic = round(sum(tr)) if all(t is not None for t in tr) else None
+    else:
+        # launches that run beside other kernels (few split rows on the second stream) have no duration of their own
+        dom = max([d for d in kernels if not d["overlapped"]], key=lambda d: d["ms_total"])
+        traffic = pmc_traffic(dom) if args.scale == 1.0 and world == 1 else None
+    achieved = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
     # how a per-bin figure maps onto `rocprofv3 --kernel-trace --stats` rows (those average over BOTH half-steps)
     prof_names = {0: ["vh_pass_kernel<..., 0> x1 + vh_pass_kernel<..., 1> x%d" % MAX_CG_STEPS,
                       "vh_update_kernel<..., 0> x1 + vh_update_kernel<..., 1> x%d" % MAX_CG_STEPS],
@@ -199,7 +215,12 @@ def main():
         d["rocprof"] = {"kernels": prof_names[inv[d["kernel"]]],
                         "avg_ms_over_both_halfsteps": None if mixed else
                         round((d["avg_ms"] + (other[0]["avg_ms"] if other else 0.0)) / (2 if other else 1), 4)}
-    roofline = dict(bound="hbm", kernel="%s, %s-step" % (dom["kernel"], dom["step"]), achieved=round(achieved, 1),
+    if side_by_side:
+        dom["rocprof"] = {"kernels": sorted({n for d in dom["group"] for n in d["rocprof"]["kernels"]}),
+                          "avg_ms_over_both_halfsteps": None,
+                          "note": "kernels of one half-step overlap: rocprofv3's per-kernel durations are spans, their sum exceeds the "
+                                  "half-step; CMFREC_HIP_BINS_PAR=1 puts the bins in line again for a per-kernel cross-check (profiles/README.md)"}
+    roofline = dict(bound="hbm", kernel=dom["kernel"] if side_by_side else "%s, %s-step" % (dom["kernel"], dom["step"]), achieved=round(achieved, 1),
                     peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     traffic_source=pmc_meta() if traffic is not None else None,
                     alg_bytes_per_launch=dom["alg_bytes"],
@@ -215,7 +236,7 @@ def main():
                                      **({"runs_beside_other_kernels": True} if d["overlapped"] else {}))
                                 for d in kernels])
 
-    if dom["kernel"].startswith("gram_wave"):
+    if not side_by_side and dom["kernel"].startswith("gram_wave"):
         # the Gramian path reads its rows once; what limits it in double precision is v_mfma_f64_16x16x4:
         # 10 tiles of the upper triangle per 4 entries, 2 x 16 x 16 x 4 flops each
         mf = 10 * 2 * 16 * 16 * dom["nnz"] / (dom["avg_ms"] * 1e-3) / 1e12
@@ -227,17 +248,33 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(row, col, val, m_blk, n, A0_blk)
 
+    # ---- the N = 1 point of the scaling series: BASELINE.json configs[3] on this one GPU, through the distributed engine ----
+    scale_point = None
+    if rank == 0 and world == 1 and not use_dist and args.scale == 1.0 and not args.no_scale_point:
+        try:
+            del sess
+            torch.cuda.empty_cache()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            sp = c4_run(args, 0, 1, local_rank, steps=5, warmup=2)
+            dist.destroy_process_group()
+            scale_point = {k: sp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config")}
+            scale_point["iteration_frac_of_hbm_peak"] = (sp.get("roofline") or {}).get("iteration", {}).get("frac_of_hbm_peak")
+        except Exception as e:        # the headline above must not depend on it
+            scale_point = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=50 fp64",
                "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "CMF_implicit ALS-CG k=50 fp64, LastFM-360K shape (synthetic): %d users x %d items, "
                                       "%d nnz%s; lambda=5, max_cg_steps=3" % (m, n, nnz_blk * world,
                                                                                " (1 LastFM-sized user block per GPU)" if world > 1 else ""),
                           "parallelism": "row-block x%d + all-gather" % world if world > 1 else "single GPU",
                           "gen_seconds": round(t_gen, 1)},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "scale_point": scale_point}
         if args.scale != 1.0:
             out["config"]["INVALID_scaled_down"] = args.scale
         final_line = json.dumps(out)
@@ -279,6 +316,13 @@ def synth_block_torch(m, n, nnz, seed, item_seed, device):
 
 
 def c4_distributed(args, rank, world, local_rank):
+    import torch.distributed as dist
+    out = c4_run(args, rank, world, local_rank, args.steps, args.warmup)
+    dist.destroy_process_group()
+    emit_last_line(json.dumps(out) if out is not None else None)
+
+
+def c4_run(args, rank, world, local_rank, steps, warmup):
     """BASELINE.json configs[3]: CMF_implicit ALS-CG k=64 fp32, synthetic 10M users x 1M items, 5e8 entries, row-partitioned
     over the ranks with an all-gather of the updated factor rows after every half-step.  Strong scaling: the problem
     does not change with N (--scale shrinks it for tests only and marks the line invalid)."""
@@ -313,14 +357,14 @@ def c4_distributed(args, rank, world, local_rank):
     def sync():
         sess.sync(); torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         engine.iteration()
     sync()
     sess.reset_timers()
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         engine.iteration()
     sync()
     dist.barrier()
@@ -329,8 +373,8 @@ def c4_distributed(args, rank, world, local_rank):
     t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    rows_per_s = (m + n) / (elapsed / args.steps)
+    ms_per_step = elapsed / steps * 1e3
+    rows_per_s = (m + n) / (elapsed / steps)
     # roofline of rank 0's dominant launch + the whole job's algorithmic bytes per iteration
     names = {0: "split rows (> 1024 nnz)", 1: "cg_rows_kernel<W=8> (257..1024 nnz)", 2: "cg_rows_kernel<W=4> (129..256 nnz)",
              3: "cg_rows_kernel<W=2> (65..128 nnz)", 4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel (<= 32 nnz)"}
@@ -345,6 +389,14 @@ def c4_distributed(args, rank, world, local_rank):
     dist.all_reduce(job_bytes)
     roofline = None
     cand = [d for d in kernels if not d["overlapped"]]
+    if not cand and kernels:
+        # the bins of a half-step run side by side (see main()): the half-step is the unit with a duration of its own
+        msA, cntA = sess.kernel_time("A"); msB, cntB = sess.kernel_time("B")
+        hs = {"A": msA / max(cntA, 1), "B": msB / max(cntB, 1)}
+        w_dom = max(("A", "B"), key=lambda w: hs[w])
+        grp = [d for d in kernels if d["step"] == w_dom]
+        cand = [dict(step=w_dom, kernel="%s half-step: %d nnz-bin launches side by side" % (w_dom, len(grp)), avg_ms=hs[w_dom],
+                     alg_bytes=sum(d["alg_bytes"] for d in grp))]
     if cand:
         dom = max(cand, key=lambda d: d["avg_ms"])
         ach = dom["alg_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
@@ -356,10 +408,10 @@ def c4_distributed(args, rank, world, local_rank):
                         per_kernel_rank0=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4), rows=d["rows"], nnz=d["nnz"],
                                                launches_timed=d["launches"], GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1))
                                           for d in kernels])
-    final_line = None
+    out = None
     if rank == 0:
         out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=64 fp32",
-               "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "CMF_implicit ALS-CG k=64 fp32, synthetic %d users x %d items, %d nnz (BASELINE.json configs[3]); "
@@ -368,11 +420,14 @@ def c4_distributed(args, rank, world, local_rank):
                                          "half-step, A-step in %d parts" % (world, a_parts),
                           "gen_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1)},
                "roofline": roofline, "cpu_baseline": None}
+        out["config"]["scaling_series"] = ("BASELINE.json configs[3] at N = 1, 2, 4, 8: every --gpus N > 1 line runs THIS workload; its N = 1 point "
+                                           "is the \"scale_point\" object of the --gpus 1 line (the same engine and collectives on one rank), which is "
+                                           "what a per-N value is to be divided by -- not the headline of --gpus 1 (C2, double precision)")
         if args.scale != 1.0:
             out["config"]["INVALID_scaled_down"] = args.scale
-        final_line = json.dumps(out)
-    dist.destroy_process_group()
-    emit_last_line(final_line)
+    del engine, eng, sess
+    torch.cuda.empty_cache()
+    return out
 
 
 def emit_last_line(line):
@@ -613,10 +668,15 @@ def cpu_baseline(row, col, val, m, n, A0):
         path = os.path.join(td, "w.npz")
         np.savez(path, row=row, col=col, val=val, A0=A0, m=m, n=n)
         tried = []
-        for nthreads in sorted({min(cores, 32), min(cores, 64), min(cores, 16), min(cores, 128)}, key=lambda t: abs(t - 32)):
-            if time.time() - t_start > 75 and best is not None:
+        # pinned threads (one per core, neighbours first: the row loop shares the opposing matrix through the last-level cache,
+        # and unpinned teams of 32+ threads on this host ran SLOWER than 16: 6.6 s / 14 s / 26 s at 32 / 64 / 128 in round 2);
+        # 8, 4, 16 threads first (round 3, pinned: 0.82 s / iteration at 8, 1.76 at 16, 3.97 at 32, 8.1 at 64), then others while
+        # the time budget lasts
+        for nthreads in [t for t in (8, 4, 16, 2, 32) if t <= cores] or [cores]:
+            if time.time() - t_start > 60 and best is not None:
                 break
-            env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS=str(nthreads))
+            env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS=str(nthreads), OMP_PROC_BIND="close", OMP_PLACES="cores",
+                       OMP_DYNAMIC="false")
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(nthreads)],
                                    env=env, capture_output=True, text=True, timeout=300)
@@ -645,18 +705,27 @@ def cpu_worker(path, nthreads):
     else:
         eng, kind = O, "port"
     A = A0.copy(); B = np.zeros((n, K))
+    # one untimed warm-up iteration (page faults, thread start-up, and the first iteration's rows take the early exits less
+    # often than later ones), then up to two timed ones
+    t0 = time.perf_counter()
+    eng.optimizeA_implicit(B, A, csc, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
+    eng.optimizeA_implicit(A, B, csr, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
+    t_warm = time.perf_counter() - t0
     iters, t_tot = 0, 0.0
-    while iters < 2 and t_tot < 12.0:
+    while iters < 2 and t_tot + t_warm < 14.0:
         t0 = time.perf_counter()
         eng.optimizeA_implicit(B, A, csc, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
         eng.optimizeA_implicit(A, B, csr, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
         t_tot += time.perf_counter() - t0
         iters += 1
+    if iters == 0:
+        iters, t_tot = 1, t_warm       # a team too slow for a second iteration: its warm-up is its sample
     s_per_iter = t_tot / iters
     print(json.dumps({"value": round((m + n) / s_per_iter, 1), "unit": "rows/s", "cores": nthreads, "kind": kind,
                       "s_per_iteration": round(s_per_iter, 3),
-                      "sample": "%d full ALS iteration(s) (optimizeA_implicit B-step + A-step, the reference's OpenMP row "
-                                "loop) of the same workload, nthreads=%d of %d host cpus, BLAS = SciPy OpenBLAS"
+                      "sample": "%d full ALS iteration(s) after one warm-up iteration (optimizeA_implicit B-step + A-step, the "
+                                "reference's OpenMP row loop) of the same workload, nthreads=%d of %d host cpus pinned "
+                                "(OMP_PROC_BIND=close, OMP_PLACES=cores), BLAS = SciPy OpenBLAS"
                                 % (iters, nthreads, os.cpu_count() or 1)}))
 
 

@@ -53,14 +53,14 @@ __device__ __forceinline__ void stage_gramian2(T *__restrict__ G, const T *__res
 template <int NT>
 __device__ __forceinline__ int entry_of_lane(int lane)
 {
-    if constexpr (NT == 8) return (lane & 7) * 8 + (lane >> 3);
-    else return ((lane & 7) >> 1) * 8 + (lane >> 3);
+    if constexpr (NT == 4) return ((lane & 7) >> 1) * 8 + (lane >> 3);
+    else return ((lane & 7) < NT) ? (lane & 7) * 8 + (lane >> 3) : 8 * NT;       // NT = 5 .. 7: the last lanes of a group own no slot
 }
 template <int NT, int t, typename T>
 __device__ __forceinline__ T slot_bcast(T x)
 {
-    if constexpr (NT == 8) return lanes::bcast8<t>(x);
-    else return lanes::bcast8<2 * t>(x);
+    if constexpr (NT == 4) return lanes::bcast8<2 * t>(x);
+    else return lanes::bcast8<t>(x);
 }
 
 // gather of the slots in use (nt of NT, wave-uniform: scalar branches): entries past the end of the tile re-read the row of the
@@ -96,7 +96,12 @@ __device__ __forceinline__ void load_tile2(Tile2<T, S, NT> &tile, const T *__res
 template <typename T, int NT, bool LOW>
 __device__ __forceinline__ T treduce_slots(const T (&c)[NT], int lane)
 {
-    if constexpr (NT == 8) {
+    if constexpr (NT > 4 && NT < 8) {
+        T c8[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) c8[t] = (t < NT) ? c[t] : T(0);
+        return treduce_slots<T, 8, LOW>(c8, lane);
+    } else if constexpr (NT == 8) {
         T u[4], q[2];
         bool h = (lane & 4) != 0;
 #pragma unroll
@@ -147,10 +152,10 @@ __device__ __forceinline__ void tile_pass2(const Tile2<T, S, NT> &tile, const T 
     T c[NT];
     asm volatile("" : "+s"(nt));
     // two slots per scalar branch: two independent FMA chains
-    static_for<0, NT / 2>([&](auto qc) {
-        constexpr int t0 = 2 * decltype(qc)::value, t1 = t0 + 1;
+    static_for<0, (NT + 1) / 2>([&](auto qc) {
+        constexpr int t0 = 2 * decltype(qc)::value, t1 = (t0 + 1 < NT) ? t0 + 1 : t0;
         c[t0] = T(0); c[t1] = T(0);
-        if (t1 < nt) {
+        if (t1 > t0 && t1 < nt) {
             T a0 = tile.v[t0][0] * vrep[0], a1 = tile.v[t1][0] * vrep[0];
 #pragma unroll
             for (int s = 1; s < S; s++) { a0 += tile.v[t0][s] * vrep[s]; a1 += tile.v[t1][s] * vrep[s]; }
@@ -163,7 +168,7 @@ __device__ __forceinline__ void tile_pass2(const Tile2<T, S, NT> &tile, const T 
         }
     });
     T coef;
-    if (2 * nt <= NT) coef = treduce_slots<T, NT, true>(c, lane);
+    if (nt <= (NT == 4 ? 2 : 4)) coef = treduce_slots<T, NT, true>(c, lane);
     else coef = treduce_slots<T, NT, false>(c, lane);
     const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid);
     asm volatile("" : "+s"(nt));
@@ -197,6 +202,9 @@ __device__ __forceinline__ void gram_pass2(const T *__restrict__ G, const T *__r
 #ifndef CMF_CG2_WAVES_NT8
 #define CMF_CG2_WAVES_NT8 2
 #endif
+#ifndef CMF_CG2_WAVES_NT7
+#define CMF_CG2_WAVES_NT7 3     // 5 .. 7 slots per lane: the tile leaves room for a third wavefront per SIMD in double precision
+#endif
 #ifndef CMF_CG2_WAVES_NT4
 #define CMF_CG2_WAVES_NT4 4
 #endif
@@ -204,7 +212,7 @@ __device__ __forceinline__ void gram_pass2(const T *__restrict__ G, const T *__r
 // Persistent kernel, W wavefronts per row, RPB rows per workgroup (W == 1 only); the row loop, the dynamic claiming of rows
 // and the software pipeline over rows are those of cg_rows_kernel.
 template <typename T, int S, int NT, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
-__global__ void __launch_bounds__(64 * W * RPB, (NT == 4 ? CMF_CG2_WAVES_NT4 : CMF_CG2_WAVES_NT8))
+__global__ void __launch_bounds__(64 * W * RPB, (NT == 4 ? CMF_CG2_WAVES_NT4 : (NT < 8 ? CMF_CG2_WAVES_NT7 : CMF_CG2_WAVES_NT8)))
 cg2_rows_kernel(const CgParams<T> P)
 {
     constexpr bool GRAM = IMPLICIT || GRAMX;

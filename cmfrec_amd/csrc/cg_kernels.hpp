@@ -116,10 +116,11 @@ __device__ __forceinline__ void dbg_fill_tile(TILE &tile, T val)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return lanes::wave_sum(v); }
 
-// Reads of the staged Gramian go through a volatile LDS pointer: the load / store optimiser then leaves them as single
-// ds_read_b64 (256 B per clock and CU) instead of pairing them into ds_read2_b64 -- two reads for the price of 3.5 on this part
-// (tools/microbench/valu_costs.hip: 26 against 7.3 ticks per instruction and SIMD) -- and cannot hoist them out of the pass
-// loops into registers either.
+// A volatile LDS pointer: the load / store optimiser leaves reads through it as single ds_read_b64 (256 B per clock and CU)
+// instead of pairing them into ds_read2_b64 -- two reads for the price of 3.5 on this part (tools/microbench/valu_costs.hip:
+// 26 against 7.3 ticks per instruction and SIMD) -- and cannot hoist them out of the pass loops into registers either.  Used
+// by the second-generation kernels (cg2_kernels.hpp: 6 % on their 32-entry-tile kernel); on the first-generation kernels the
+// same change measured 2.5 % SLOWER (the tiny bins are not bound by the LDS pipe), so they read the Gramian plainly.
 template <typename T> using lds_cv = const volatile T __attribute__((address_space(3)));
 
 // Transposed butterfly over the lane bits 0..2 (the 8 lanes of one non-zero group): 8 values per
@@ -340,20 +341,19 @@ __device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, Pass
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (W > 1 && (q % W) != wr) continue;
-            lds_cv<f32x2> *g = (lds_cv<f32x2> *)(reinterpret_cast<const f32x2 *>(G) + (jj * 4 + q) * gram_ld2(S) + ll);
+            const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (jj * 4 + q) * gram_ld2(S) + ll;
             const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
 #pragma unroll
-            for (int s = 0; s < S; s++) { const f32x2 gv = g[8 * s]; out.v[s] += w2 * gv; }
+            for (int s = 0; s < S; s++) out.v[s] += w2 * g[8 * s];
         }
     } else {
-        lds_cv<T> *Gv = (lds_cv<T> *)G;
 #pragma unroll
         for (int t = 0; t < 8; t++) {
             if (W > 1 && (t % W) != wr) continue;
 #pragma unroll
             for (int s = 0; s < S; s++) {
-                if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * Gv[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
-                else out.v[s] += wts[t] * Gv[(jj * 8 + t) * LD + ll + 8 * s];
+                if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
+                else out.v[s] += wts[t] * G[(jj * 8 + t) * LD + ll + 8 * s];
             }
         }
     }
@@ -963,15 +963,15 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
                     if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
                         for (int qq = 0; qq < 4; qq++) {       // row pairs (2 qq, 2 qq + 1) of the group's eight rows
-                            lds_cv<f32x2> *g = (lds_cv<f32x2> *)(reinterpret_cast<const f32x2 *>(G) + (16 * a + 4 * jq + qq) * gram_ld2(S) + ll);
+                            const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (16 * a + 4 * jq + qq) * gram_ld2(S) + ll;
                             const f32x2 w2 = f32x2{w[2 * qq], w[2 * qq + 1]};
 #pragma unroll
-                            for (int s = 0; s < S; s++) { const f32x2 gv = g[8 * s]; acc.v[s] += w2 * gv; }
+                            for (int s = 0; s < S; s++) acc.v[s] += w2 * g[8 * s];
                         }
                     } else {
 #pragma unroll
                         for (int t = 0; t < 8; t++) {
-                            lds_cv<T> *g = (lds_cv<T> *)(G + (32 * a + 8 * jq + t) * LD + ll);
+                            const T *g = G + (32 * a + 8 * jq + t) * LD + ll;
 #pragma unroll
                             for (int s = 0; s < S; s++) acc.v[s] += w[t] * g[8 * s];
                         }

@@ -122,7 +122,7 @@ inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st);
 inline void shard_from_coo(SparseShard &S, int nrows, int n_other, const int *d_key, const int *d_other, const real_t *d_val,
                            size_t nnz, real_t subtract, real_t alpha, hipStream_t st)
 {
-    S.nrows = nrows; S.nnz = nnz;
+    S.nrows = nrows; S.nnz = nnz; S.n_other = n_other;
     const int grid_e = (int)std::min<size_t>(4096, (nnz + 255) / 256 + 1), grid_r = std::min(2048, (nrows + 255) / 256 + 1);
     DevBuf<unsigned> counts; counts.alloc((size_t)nrows + 1);
     HIP_CHECK(hipMemsetAsync(counts.ptr, 0, ((size_t)nrows + 1) * sizeof(unsigned), st));
@@ -271,6 +271,7 @@ inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st)
 inline void shard_from_csr(SparseShard &S, int nrows, const size_t *hp, const int *hi, const real_t *hv, int n_other,
                            hipStream_t st)
 {
+    S.n_other = n_other;
     S.upload(nrows, hp, hi, hv, st);
     finalize_vheavy(S, n_other, st);
 }

@@ -92,30 +92,40 @@ constexpr int BIN_MED2 = 3;     // 65..128    : 2 waves / row
 constexpr int BIN_LIGHT = 4;    // 33..64     : 1 wave / row, 4 rows / workgroup
 constexpr int BIN_TINY = 5;     // 1..32      : 1 wave / row, half-size tiles, double-buffered gather
 constexpr int BIN_MIN_NNZ[NBINS] = {1025, 257, 129, 65, 33, 1};
-// Double precision: an 8-wave team keeps 512 entries in registers, longer rows re-stream their second tile on every pass
-// (1.7x the algorithmic bytes measured on that bin in round 2).  Since the split rows' Gramian kernel does the last column
-// block of k = 50 on the vector ALU (round 3), cutting at 513 instead of 1025 is the faster split: C2 4.36 -> 4.16 ms
-// (513), 4.24 (769), 4.34 (385) -- profiles/r03_c.  CMFREC_HIP_VH_MIN overrides.
-constexpr int VH_MIN_DEFAULT = (sizeof(real_t) == 8) ? 513 : 1025;
-inline int vheavy_min_nnz()
+// The boundary of the split rows is a property of the shard (SparseShard::vh_min).  Single precision: 1025 -- the 8-wave kernel
+// keeps two tiles per wave and nothing else, so the boundary cannot move up.  Double precision: an 8-wave team keeps 512
+// entries in registers and re-streams the second tile of longer rows on every pass (1.7x the algorithmic bytes measured on
+// that bin in round 2); since the split rows' Gramian kernel does the last column block of k = 50 on the vector ALU (round 3),
+// cutting at 513 is the faster split WHERE THE GRAMIAN PATH TAKES THE SPLIT ROWS: C2 4.36 -> 4.16 ms (513), 4.24 (769), 4.34
+// (385) -- profiles/r03_c; where they are streamed (C1: small opposing matrices, many references) 1025 stays better (2.48
+// against 2.65 ms).  CMFREC_HIP_VH_MIN overrides.
+inline int vh_min_env()
 {
-    // (single precision: the 8-wave kernel keeps two tiles per wave and nothing else, so the boundary cannot move up)
     static const int v = getenv("CMFREC_HIP_VH_MIN")
                              ? std::min(sizeof(real_t) == 4 ? BIN_MIN_NNZ[BIN_VHEAVY] : (1 << 30), std::max(258, atoi(getenv("CMFREC_HIP_VH_MIN"))))
-                             : VH_MIN_DEFAULT;
+                             : 0;
     return v;
-}
-inline int bin_of(long long nnz)
-{
-    if (nnz >= vheavy_min_nnz()) return BIN_VHEAVY;
-    for (int b = 1; b < NBINS; b++)
-        if (nnz >= BIN_MIN_NNZ[b]) return b;
-    return -1;   // empty row
 }
 
 struct SparseShard {
     int nrows = 0;
     size_t nnz = 0;
+    int vh_min = BIN_MIN_NNZ[BIN_VHEAVY];       // rows of at least this many entries are split rows (build_bins)
+    size_t opp_row_bytes_hint = 50 * sizeof(real_t);   // bytes of a gathered row (k x sizeof), for the choice of vh_min; set before the build
+    int bin_of(long long l) const
+    {
+        if (l >= vh_min) return BIN_VHEAVY;
+        for (int b = 1; b < NBINS; b++)
+            if (l >= BIN_MIN_NNZ[b]) return b;
+        return -1;   // empty row
+    }
+    static bool gram_pays(double vh_nnz, int n_other_, size_t opp_bytes_per_row)
+    {
+        if (sizeof(real_t) == 4) return true;
+        if (n_other_ <= 0) return false;
+        const double refs = vh_nnz / (double)n_other_;
+        return refs < 3.5 || (refs < 40.0 && (double)n_other_ * (double)opp_bytes_per_row > 100e6);
+    }
     DevBuf<size_t> p;
     DevBuf<int> i;
     DevBuf<real_t> v;
@@ -128,6 +138,7 @@ struct SparseShard {
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
     int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
+    int n_gt48 = 0;          // rows with more than 48 entries: the rest of the 33..64 bin fits 6-slot tiles (three wavefronts per SIMD)
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
     // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
@@ -138,13 +149,7 @@ struct SparseShard {
     // in cache: C2's items (15 references per opposing row, a 144 MB opposing matrix) still favour the Gramian; C1
     // (MovieLens-10M-shaped: 4 / 28 MB opposing matrices, 100+ references) does not -- 1.29 against 1.06 ms for its A-step.
     // `opp_bytes_per_row` = k x sizeof(real_t) of the launch.  CMFREC_HIP_VH=gram / stream force one.
-    bool prefer_gram(size_t opp_bytes_per_row) const
-    {
-        if (sizeof(real_t) == 4) return true;
-        if (n_other <= 0) return false;
-        const double refs = (double)bin_nnz[0] / (double)n_other;
-        return refs < 3.5 || (refs < 40.0 && (double)n_other * (double)opp_bytes_per_row > 100e6);
-    }
+    bool prefer_gram(size_t opp_bytes_per_row) const { return gram_pays((double)bin_nnz[0], n_other, opp_bytes_per_row); }
     // few split rows (less than about one round of workgroups per CG pass): their launch sequence is a chain of
     // latencies and runs on the second stream beside the other bins
     bool vh_runs_aside(int num_cus) const
@@ -242,19 +247,31 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0; n_long = 0; n_gt16 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
+        n_empty = 0; n_long = 0; n_gt16 = 0; n_gt48 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         // few split rows (C2's users: 50 rows, 65 k entries): short slices, so that their Gramian kernels -- which run in line
         // with the other bins, see launch_cg_S -- have a few hundred wavefronts to spread over instead of a few dozen
+        // where the split rows begin (see vh_min_env above): double precision cuts at 513 when the rows above that go through
+        // their Gramian, at 1025 otherwise
+        vh_min = BIN_MIN_NNZ[BIN_VHEAVY];
+        if (vh_min_env() > 0) vh_min = vh_min_env();
+        else if (sizeof(real_t) == 8) {
+            double nnz513 = 0;
+            for (int q = 0; q < nrows && lens_sorted[q] >= 513u; q++) nnz513 += (double)lens_sorted[q];
+            const char *vh_env = getenv("CMFREC_HIP_VH");
+            const bool gram = (vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : gram_pays(nnz513, n_other, opp_row_bytes_hint);
+            if (gram && opp_row_bytes_hint <= 16 * 4 * sizeof(real_t)) vh_min = 513;
+        }
         long long vh_total = 0;
-        for (int q = 0; q < nrows && (long long)lens_sorted[q] >= vheavy_min_nnz(); q++) vh_total += (long long)lens_sorted[q];
+        for (int q = 0; q < nrows && (long long)lens_sorted[q] >= vh_min; q++) vh_total += (long long)lens_sorted[q];
         slice_len = (vh_total < (long long)GRAM_SLICE * 1024) ? 256 : GRAM_SLICE;
         if (const char *e = getenv("CMFREC_HIP_GRAM_SLICE_LEN")) slice_len = std::min(GRAM_SLICE, std::max(16, atoi(e) / 16 * 16));   // A/B measurements
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
             if (l > 16) n_gt16++;
+            if (l > 48) n_gt48++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -485,7 +502,8 @@ enum class CgVariant { Auto, Generic };
 CgVariant cg_variant_from_env();
 
 // layout of DeviceInfo::row_counter: [0, 64) the Cholesky kernels' counters, then CG_NCOUNTERS padded counters per nnz bin
-constexpr size_t ROW_COUNTER_INTS = 64 + (size_t)NBINS * CG_NCOUNTERS * CG_COUNTER_STRIDE;
+constexpr int NCOUNTER_SETS = NBINS + 2;   // one set per nnz bin + spares for bins that run as two launches
+constexpr size_t ROW_COUNTER_INTS = 64 + (size_t)NCOUNTER_SETS * CG_NCOUNTERS * CG_COUNTER_STRIDE;
 inline size_t cg_counter_offset(int bin) { return 64 + (size_t)bin * CG_NCOUNTERS * CG_COUNTER_STRIDE; }
 
 // Test hook (CMFREC_HIP_POISON_LDS=1, tests/test_gpu_operators.py): fill the LDS of every CU with NaN patterns in front of the
@@ -549,28 +567,29 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
 }
 
 // Second-generation tiled kernels (cg2_kernels.hpp): slots in use only, vectors redistributed through LDS, cheaper Gramian
-// product.  CMFREC_HIP_CG2=0 / 1 forces the first / second generation (A/B measurements and on-device cross-check); the
-// default is the second generation in double precision.
-inline bool cg2_enabled()
+// product -- a third fewer vector instructions per row, and no faster: the register-resident bins turned out to be bound by
+// the bytes they keep in flight (two wavefronts per SIMD), not by the vector ALU (profiles/r03_b, r03_d).  CMFREC_HIP_CG2=1
+// selects them (tests/test_gpu_cg2.py runs the operator cases on them); the default is the first generation.
+// (These switches select kernels, so they are read at every launch -- a test can set them per case -- not cached.)
+inline bool env_flag(const char *name, bool dflt)
 {
-    static const int v = [] {
-        const char *e = getenv("CMFREC_HIP_CG2");
-        if (e != nullptr) return (e[0] != '0') ? 1 : 0;
-        return (sizeof(real_t) == 8) ? 1 : 0;
-    }();
-    return v != 0;
+    const char *e = getenv(name);
+    return e != nullptr ? (e[0] != '0') : dflt;
 }
+inline bool cg2_enabled() { return env_flag("CMFREC_HIP_CG2", false); }
+// rows of 33 .. 48 entries of the second generation on 6-slot tiles, three wavefronts per SIMD (CMFREC_HIP_CG2_NT6=1)
+inline bool cg2_nt6() { return env_flag("CMFREC_HIP_CG2_NT6", false); }
 // rows of at most 16 entries: two per wavefront on the first-generation kernel (default) or the NT = 4 kernel with one or two
 // slots in use (CMFREC_HIP_CG2_TINY=all)
 inline bool cg2_tiny_all()
 {
-    static const bool v = getenv("CMFREC_HIP_CG2_TINY") != nullptr && strcmp(getenv("CMFREC_HIP_CG2_TINY"), "all") == 0;
-    return v;
+    const char *e = getenv("CMFREC_HIP_CG2_TINY");
+    return e != nullptr && strcmp(e, "all") == 0;
 }
 
 template <int S, int NT, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
 inline void launch_cg2_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st,
-                           bool own_events = true)
+                           bool own_events = true, size_t counter_shift = 0)
 {
     if (count <= 0) return;
     EventPair ev{nullptr, nullptr};
@@ -583,7 +602,7 @@ inline void launch_cg2_bin(const DeviceInfo &dev, CgParams<real_t> P, int first,
     P.order += first;
     P.desc += first;
     P.nrows = count;
-    P.counter = dev.row_counter.ptr + cg_counter_offset(bin);          // zeroed by launch_cg_S
+    P.counter = dev.row_counter.ptr + cg_counter_offset(bin) + counter_shift;          // zeroed by launch_cg_S
     constexpr int threads = 64 * W * RPB;
     const size_t smem = (((IMPLICIT || GRAMX) ? (size_t)gram2_elems(S) : 0) + (size_t)W * RPB * 64 + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
     auto kern = cg2_rows_kernel<real_t, S, NT, IMPLICIT, W, RPB, GRAMX>;
@@ -801,12 +820,9 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
 // number of streams the nnz bins of a half-step are spread over (CMFREC_HIP_BINS_PAR; 1 = one after the other)
 inline int cg_bin_streams()
 {
-    static const int v = [] {
-        const char *e = getenv("CMFREC_HIP_BINS_PAR");
-        const int n = e ? atoi(e) : 1;
-        return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
-    }();
-    return v;
+    const char *e = getenv("CMFREC_HIP_BINS_PAR");
+    const int n = e ? atoi(e) : 2;      // C2: 4.19 (1) / 3.99 (2) / 4.21 (3) / 4.11 (4) / 4.30 (6) ms per iteration, profiles/r03_d
+    return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
 }
 
 // one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row) on the kernel generation in use
@@ -830,7 +846,24 @@ inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, 
             else launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st);
             break;
         default:
-            if (v2) launch_cg2_bin<S, 8, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
+            if (v2 && cg2_nt6()) {
+                // rows of 33 .. 48 entries (the tail of the bin) on 6-slot tiles: 84 tile registers leave room for a third
+                // wavefront per SIMD in double precision -- more rows, i.e. more bytes of the gather, in flight per CU
+                const int c8 = std::min(count, std::max(0, X.n_gt48 - first));
+                EventPair ev{nullptr, nullptr};
+                if (tm && count > 0) {
+                    HIP_CHECK(hipEventCreate(&ev.a));
+                    HIP_CHECK(hipEventCreate(&ev.b));
+                    HIP_CHECK(hipEventRecord(ev.a, st));
+                }
+                launch_cg2_bin<S, 8, IMPLICIT, 1, 4, GRAMX>(dev, P, first, c8, tm, bin, st, false);
+                launch_cg2_bin<S, 6, IMPLICIT, 1, 4, GRAMX>(dev, P, first + c8, count - c8, tm, bin, st, false,
+                                                            cg_counter_offset(NBINS) - cg_counter_offset(bin));
+                if (tm && count > 0) {
+                    HIP_CHECK(hipEventRecord(ev.b, st));
+                    tm->ev[bin].push_back(ev);
+                }
+            } else if (v2) launch_cg2_bin<S, 8, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
             else launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
             break;
     }
@@ -866,15 +899,28 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
         for (int i = 1; i < npar; i++) ss[i] = d.bin_streams[i - 1];
         HIP_CHECK(hipEventRecord(d.fork_ev, dev.stream));
         for (int i = 1; i < npar; i++) HIP_CHECK(hipStreamWaitEvent(ss[i], d.fork_ev, 0));
-        int nx = 0;
-        auto next = [&]() { hipStream_t st = ss[nx]; nx = (nx + 1) % npar; return st; };
-        // longest-running first; the split rows' two launches stay on one stream
-        launch_cg_vheavy<S, IMPLICIT, GRAMX>(dev, P, X, tm, next());
-        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_HEAVY, next());
-        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_MED2, next());
-        launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, next(), X.n_gt16);
-        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_MED4, next());
-        launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, BIN_LIGHT, next());
+        // Bins onto streams: longest estimated bin first, each to the stream with the least work so far (LPT), so that the
+        // streams end together and no bin's tail runs alone.  Estimate = entries + a per-row share in entry equivalents, fitted
+        // to the in-line times of the bins of C2 (profiles/r03_f, both half-steps: ~10.5 M entries per ms everywhere, plus ~12 ns
+        // per row of an 8-wave team, ~1 ns per row of the tiny bin, < 1 ns elsewhere).
+        static const double row_equiv[NBINS] = {0.0, 126.0, 7.0, 7.0, 0.0, 11.5};
+        double cost[NBINS], load[DeviceInfo::MAX_BIN_STREAMS + 1] = {0, 0, 0, 0, 0, 0};
+        int order_b[NBINS];
+        for (int b = 0; b < NBINS; b++) {
+            cost[b] = (double)X.bin_nnz[b] + row_equiv[b] * (double)X.bin_rows[b];
+            order_b[b] = b;
+        }
+        std::sort(order_b, order_b + NBINS, [&](int a, int b2) { return cost[a] > cost[b2]; });
+        for (int q = 0; q < NBINS; q++) {
+            const int b = order_b[q];
+            if (X.bin_rows[b] <= 0) continue;
+            int si = 0;
+            for (int i = 1; i < npar; i++) if (load[i] < load[si]) si = i;
+            load[si] += cost[b];
+            if (b == BIN_VHEAVY) launch_cg_vheavy<S, IMPLICIT, GRAMX>(dev, P, X, tm, ss[si]);
+            else if (b == BIN_TINY) launch_cg_tiny<S, IMPLICIT, GRAMX>(dev, P, X.bin_first[BIN_TINY], X.bin_rows[BIN_TINY], tm, ss[si], X.n_gt16);
+            else launch_cg_any_bin<S, IMPLICIT, GRAMX>(dev, P, X, tm, b, ss[si]);
+        }
         for (int i = 1; i < npar; i++) {
             HIP_CHECK(hipEventRecord(d.bin_join[i - 1], ss[i]));
             HIP_CHECK(hipStreamWaitEvent(dev.stream, d.bin_join[i - 1], 0));

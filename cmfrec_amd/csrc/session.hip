@@ -751,6 +751,7 @@ int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const i
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
+        s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t);
         shard_from_csr(s->Xr, s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->mdl.n, s->dev.stream);
         shard_from_csr(s->Xc, s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->mdl.m, s->dev.stream);
         return 0;
@@ -789,6 +790,7 @@ int cmfrec_hip_session_set_A_parts(cmfrec_hip_session *s, const size_t *csr_p, c
             for (int r = r0; r <= r1; r++) pp[r - r0] = csr_p[r] - csr_p[r0];
             s->XrParts.emplace_back(new SparseShard());
             s->XrParts.back()->is_part = true;
+            s->XrParts.back()->opp_row_bytes_hint = (size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t);
             shard_from_csr(*s->XrParts.back(), r1 - r0, pp.data(), csr_i + csr_p[r0], csr_v + csr_p[r0], s->mdl.n, s->dev.stream);
             HIP_CHECK(hipStreamSynchronize(s->dev.stream));              // pp is reused
             hipEvent_t e;
@@ -830,6 +832,7 @@ int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const 
         HIP_CHECK(hipSetDevice(s->dev.device));
         DevBuf<int> dr, dc; DevBuf<real_t> dv;
         dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
+        s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(m.k + m.k_main) * sizeof(real_t);
         shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
         shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
@@ -848,6 +851,7 @@ int cmfrec_hip_session_set_X_coo_device(cmfrec_hip_session *s, int which, const 
         const cmfrec_hip_model &m = s->mdl;
         if (which != 'r' && which != 'c') { g_last_error = "cmfrec_hip_session_set_X_coo_device: which must be 'r' or 'c'"; return 2; }
         HIP_CHECK(hipSetDevice(s->dev.device));
+        s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(m.k + m.k_main) * sizeof(real_t);
         if (which == 'r') shard_from_coo(s->Xr, m.row_end - m.row_begin, m.n, d_key, d_other, d_val, nnz, subtract, alpha, s->dev.stream);
         else shard_from_coo(s->Xc, m.col_end - m.col_begin, m.m, d_key, d_other, d_val, nnz, subtract, alpha, s->dev.stream);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
@@ -1879,9 +1883,17 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
 {
     const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
     if (which == 'A' && !s->XrParts.empty()) return 1;                    // the bins of a part alternate between two streams
+    if (cg_bin_streams() > 1) return 1;                                    // the bins of a half-step run side by side (launch_cg_S)
     // (the Gramian path stays in line, launch_cg_S)
     const bool gram_in_line = cmfrec_hip_session_vh_mode(s, which) == 2 && getenv("CMFREC_HIP_VH_GRAM_ASIDE") == nullptr;
     return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus) && !gram_in_line) ? 1 : 0;
+}
+
+// rows of the CSR ('A') / CSC ('B') shard with at least this many entries are split rows (their entries are kept sorted by
+// opposing index, SparseShard::vh_min)
+int cmfrec_hip_session_vh_min(cmfrec_hip_session *s, int which)
+{
+    return ((which == 'A') ? s->Xr : s->Xc).vh_min;
 }
 
 int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which)
@@ -1918,6 +1930,7 @@ int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t
         dA.upload(A, (size_t)m * lda, dev.stream);
         dB.upload(B, (size_t)n * ldb, dev.stream);
         dG.alloc((size_t)k * k);
+        X.opp_row_bytes_hint = (size_t)k * sizeof(real_t);
         shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         launch_gram(dev, gws, dB.ptr, ldb, n, k, dG.ptr, (real_t)1, use_cg ? (real_t)0 : lam);
         int rc;
@@ -1950,6 +1963,7 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
         dA.upload(A, (size_t)m * lda, dev.stream);
         dB.upload(B, (size_t)n * ldb, dev.stream);
         if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
+        X.opp_row_bytes_hint = (size_t)k * sizeof(real_t);
         shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         int rc;
         if (use_cg) {
@@ -2060,6 +2074,7 @@ int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size
         dU.upload(U, (size_t)m_u * p, dev.stream);
         if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
         dG.alloc((size_t)kc * kc);
+        X.opp_row_bytes_hint = (size_t)k * sizeof(real_t);
         shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         launch_gram(dev, gws, dC.ptr, (size_t)kc, p, kc, dG.ptr, w_user, (real_t)0);
         // collective.c:4817-4822 zeroes max(m,m_u)*lda - (lda-k_totA) elements
@@ -2102,6 +2117,7 @@ int cmfrec_hip_optimizeA_collective_sparse(real_t *A, size_t lda, const real_t *
         dB.upload(B, (size_t)n * ldb, dev.stream);
         dC.upload(C, (size_t)p * kc, dev.stream);
         if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
+        X.opp_row_bytes_hint = (size_t)k * sizeof(real_t);
         shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
         std::vector<size_t> up((size_t)m + 1);
         for (int r = 0; r <= m; r++) up[r] = Ucsr_p[std::min(r, m_u)];

@@ -226,6 +226,10 @@ class AlsSession:
         """True when the launches of that bin run beside other kernels, so that bin_stats' time is not a kernel duration."""
         return bool(self.lib.cmfrec_hip_session_bin_overlaps(self.handle, C.c_int(ord(which)), C.c_int(bin_)))
 
+    def vh_min(self, which):
+        """Rows of X's CSR ('A') / CSC ('B') shard with at least this many entries are split rows (entries sorted by opposing index)."""
+        return int(self.lib.cmfrec_hip_session_vh_min(self.handle, C.c_int(ord(which))))
+
     def vh_mode(self, which):
         """0: no split rows on that side; 1: streamed per CG pass; 2: single gather + CG on the row's Gramian."""
         return int(self.lib.cmfrec_hip_session_vh_mode(self.handle, C.c_int(ord(which))))

@@ -439,6 +439,10 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin);
 /* How the split rows (> 1024 entries) of that side are solved: 0 none, 1 streamed once per CG pass, 2 read once, CG on the
  * row's own Gramian (chosen when few split rows share an opposing row, e.g. a rank's item block of a multi-GPU run). */
 int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which);
+/* rows of X's CSR ('A') / CSC ('B') shard with at least this many entries are "split rows": their entries are stored sorted
+   by the opposing index (a permutation of the row's sums) and take the split-row kernels (1025; double precision: 513 where
+   the split rows go through their own Gramian) */
+int cmfrec_hip_session_vh_min(cmfrec_hip_session *s, int which);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
 /* Batched top-N (the step after the path; the reference ranks one user per call: topN, src/common.c:5127-5380).

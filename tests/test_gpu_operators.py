@@ -249,7 +249,9 @@ def test_coo_device_matches_host(dtype, m, n, nnz):
         perm = np.argsort(key, kind="stable")
         cnt = np.bincount(key, minlength=rows)
         ptr = np.concatenate([[0], np.cumsum(cnt)])
-        for r in np.nonzero(cnt > 1024)[0]:                 # very heavy rows: entries by opposing index (stable), the
+        vh_min = s.vh_min("A" if which == "r" else "B")     # 1025; double precision: 513 where the split rows take the Gramian path
+        assert vh_min in (513, 1025)
+        for r in np.nonzero(cnt >= vh_min)[0]:              # very heavy rows: entries by opposing index (stable), the
             seg = perm[ptr[r]:ptr[r + 1]]                   # XCD-aware split-row schedule (coo_device.hpp)
             perm[ptr[r]:ptr[r + 1]] = seg[np.argsort(other[seg], kind="stable")]
         assert np.array_equal(p, ptr.astype(np.uint64))
@@ -302,9 +304,10 @@ def test_bias_init_device_matches_oracle(oracles, dtype, scale_lam, long_rows):
     s.set_X_coo(row, col, val, subtract=float(gm))
     p, i, v, _ = s.get_X("r")
     ptr = csr[0].astype(np.int64)
-    for r in range(m):                                      # rows > 1024 entries are re-ordered by column (coo_device.hpp)
+    vh_min = s.vh_min("A")
+    for r in range(m):                                      # split rows (>= vh_min entries) are re-ordered by column (coo_device.hpp)
         a, b = ptr[r], ptr[r + 1]
-        o = np.argsort(csr[1][a:b], kind="stable") if b - a > 1024 else np.arange(b - a)
+        o = np.argsort(csr[1][a:b], kind="stable") if b - a >= vh_min else np.arange(b - a)
         assert np.array_equal(i[a:b], csr[1][a:b][o]) and np.array_equal(v[a:b], csr[2][a:b][o])
     s.set_factors(A=np.zeros((m, k), dtype), B=np.zeros((n, k), dtype))
     s.init_biases(lam, lam)
