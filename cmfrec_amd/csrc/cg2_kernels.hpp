@@ -68,7 +68,7 @@ __device__ __forceinline__ T slot_bcast(T x)
 // are zero)
 template <typename T, int S, int NT>
 __device__ __forceinline__ void load_tile2(Tile2<T, S, NT> &tile, const T *__restrict__ Bm, size_t ldb, int k, int my_idx,
-                                           int cnt, int nt, int lane)
+                                           int cnt, int nt, int lane, int t_first = 0)
 {
     const int jj = lane >> 3, ll = lane & 7;
     const int first_idx = __builtin_amdgcn_readfirstlane(my_idx);
@@ -78,9 +78,10 @@ __device__ __forceinline__ void load_tile2(Tile2<T, S, NT> &tile, const T *__res
     // (the slot count is made opaque at every use: otherwise the compiler keeps one lane mask per `t < nt` alive across the
     //  whole row -- SGPR pairs it then spills into VGPR lanes -- instead of one scalar compare in front of each branch)
     asm volatile("" : "+s"(nt));
+    asm volatile("" : "+s"(t_first));
     static_for<0, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        if (t < nt) {
+        if (t >= t_first && t < nt) {
             const int its = slot_bcast<NT, t>(my_idx);
             const unsigned it = (unsigned)(((8 * t + jj) < cnt) ? its : first_idx);
             const T *rp = reinterpret_cast<const T *>(base + (unsigned long long)it * ldb_bytes);
@@ -199,6 +200,75 @@ __device__ __forceinline__ void gram_pass2(const T *__restrict__ G, const T *__r
     }
 }
 
+// ---- the next row's tile by LDS-DMA (PF builds, one wavefront per row) -----------------------------------------------------
+// The register-tiled bins are bound by what they keep in flight: halving the resident teams of the 33..64 bin costs 1.57x, the
+// fit T(w) = 0.16 + 0.22 / w ms says a third more bytes in flight would be worth ~20 % (profiles/r03_h) -- and the registers of
+// a wavefront hold ONE tile.  So the gathered rows of the NEXT row of a wavefront travel into LDS while the current row is being
+// solved: global_load_lds_dwordx4 moves 64 x 16 bytes per instruction from per-lane addresses to M0 + 16 lane -- chunk c of a
+// tile is bytes 16 (c % cpr) .. of entry c / cpr (cpr = k sizeof / 16 chunks per gathered row), so the LDS image is the dense
+// [entry][k] array -- no VGPRs, no waiting.  The DMAs are issued after the row's first pass (by then every load the compiler
+// counts has been consumed: vmcnt is in order, and a wait for an older load would otherwise wait for the DMAs too) and land
+// during the remaining passes; at the next row an s_waitcnt vmcnt(0), 7 ds_read_b64 per slot and lane, and the row starts
+// without its gather.  Entries past the prefetched ones (P.pf_entries per tile, what fits the CU's LDS) are gathered as before.
+typedef __attribute__((address_space(3))) void cg2_lds_void;
+typedef __attribute__((address_space(1))) const void cg2_glb_void;
+
+// issue the DMAs of the first `pfe` entries (whole slots) of a tile: idx = the tile's indices (lane <-> entry as entry_of_lane),
+// cnt = entries of the tile (slots past them re-read the first entry's row), dst = this wave's LDS buffer
+template <typename T, int NT>
+__device__ __forceinline__ void prefetch_tile_lds(const CgParams<T> &P, unsigned char *dst, int idx, int cnt, int pfe, int lane)
+{
+    const int cpr = P.pf_cpr;
+    int nchunks = pfe * cpr;
+    const int first_idx = __builtin_amdgcn_readfirstlane(idx);
+    const char *base = reinterpret_cast<const char *>(P.B);
+    const unsigned ldb_bytes = (unsigned)(P.ldb * sizeof(T));
+    // groups of 8 DMA instructions: the 8 index look-ups (ds_bpermute) of a group are issued together -- one LDS round trip per
+    // group instead of one per instruction (a rolled loop with a look-up, its wait and the address arithmetic per trip cost
+    // ~200 cycles per instruction, 16 instructions per row: 20 % of the bin's time, profiles/r03_i)
+    constexpr int GQ = 8;
+    for (int g0 = 0; g0 < nchunks; g0 += 64 * GQ) {
+        int it[GQ], part[GQ];
+#pragma unroll
+        for (int u = 0; u < GQ; u++) {
+            const int c = g0 + 64 * u + lane;
+            const int e = (c * P.pf_magic) >> 16;                          // entry and 16-byte chunk of its row
+            part[u] = c - e * cpr;
+            // entry e = 8 t + jj lives in lane (jj, t) of the tile's index register (NT = 4: lanes (jj, 2t), (jj, 2t + 1))
+            const int src = ((e & 7) << 3) | (NT == 4 ? ((e >> 3) << 1) : (e >> 3));
+            const int v = __builtin_amdgcn_ds_bpermute(src << 2, idx);
+            it[u] = (e < cnt) ? v : first_idx;
+        }
+#pragma unroll
+        for (int u = 0; u < GQ; u++) {
+            const int c0 = g0 + 64 * u;                                    // wave-uniform
+            if (c0 < nchunks) {
+                const char *g = base + (unsigned long long)(unsigned)it[u] * ldb_bytes + (part[u] << 4);
+                if (c0 + lane < nchunks)
+                    __builtin_amdgcn_global_load_lds((cg2_glb_void *)g, (cg2_lds_void *)(dst + (size_t)c0 * 16), 16, 0, 0);
+            }
+        }
+    }
+}
+
+// the prefetched slots [0, nslots) of a tile from the wave's LDS buffer into the register tile
+template <typename T, int S, int NT>
+__device__ __forceinline__ void tile_from_lds(Tile2<T, S, NT> &tile, const unsigned char *src, int k, int nslots, int lane)
+{
+    const int jj = lane >> 3, ll = lane & 7;
+    const int col_last = min(ll + 8 * (S - 1), k - 1);
+    const T *row0 = reinterpret_cast<const T *>(src) + (size_t)jj * k;
+    asm volatile("" : "+s"(nslots));
+    static_for<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if (t < nslots) {
+            const T *rp = row0 + (size_t)(8 * t) * k;
+#pragma unroll
+            for (int s = 0; s < S; s++) tile.v[t][s] = rp[(s < S - 1) ? ll + 8 * s : col_last];
+        }
+    });
+}
+
 #ifndef CMF_CG2_WAVES_NT8
 #define CMF_CG2_WAVES_NT8 2
 #endif
@@ -211,16 +281,19 @@ __device__ __forceinline__ void gram_pass2(const T *__restrict__ G, const T *__r
 
 // Persistent kernel, W wavefronts per row, RPB rows per workgroup (W == 1 only); the row loop, the dynamic claiming of rows
 // and the software pipeline over rows are those of cg_rows_kernel.
-template <typename T, int S, int NT, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
+template <typename T, int S, int NT, bool IMPLICIT, int W, int RPB, bool GRAMX = false, bool PF = false>
 __global__ void __launch_bounds__(64 * W * RPB, (NT == 4 ? CMF_CG2_WAVES_NT4 : (NT < 8 ? CMF_CG2_WAVES_NT7 : CMF_CG2_WAVES_NT8)))
 cg2_rows_kernel(const CgParams<T> P)
 {
     constexpr bool GRAM = IMPLICIT || GRAMX;
     constexpr int TE = 8 * NT;                                               // entries per tile
+    static_assert(!PF || W == 1, "the LDS prefetch is built for one wavefront per row");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);                                  // [8 S][LD] (implicit / block systems)
     T *vbuf = G + (GRAM ? gram2_elems(S) : 0);                               // [W RPB][64] the vector of the current pass, per wave
-    T *red = vbuf + W * RPB * 64;                                            // [RPB][2][W][64]
+    T *red = vbuf + W * RPB * 64;                                            // [RPB][2][W][64] (W > 1)
+    // PF: per wave a buffer of P.pf_entries gathered rows (k elements each), behind the vectors
+    unsigned char *pfbuf = reinterpret_cast<unsigned char *>(W > 1 ? red + RPB * 2 * W * 64 : red);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,6 +302,8 @@ cg2_rows_kernel(const CgParams<T> P)
     const int jj = lane >> 3, ll = lane & 7;
     const int k = P.k;
     T *vb = vbuf + wave * 64;
+    unsigned char *pfb = pfbuf + (size_t)wave * (size_t)P.pf_entries * (size_t)k * sizeof(T);
+    int pf_slots = 0;              // slots of the CURRENT row's tile that wait in this wave's LDS buffer (PF)
 
     const int nteams = gridDim.x * RPB;
     __shared__ int s_claim[4];
@@ -313,7 +388,14 @@ cg2_rows_kernel(const CgParams<T> P)
         const int nt0 = (cnt0 + 7) >> 3;                       // slots in use (wave-uniform)
         const T x_res = pcur.x;
         const bool valid_res = my_e < cnt0;
-        if (cnt0 > 0 && !CMF_DBG(P, 1)) load_tile2<T, S, NT>(tile, P.B, P.ldb, k, pcur.idx, cnt0, nt0, lane);
+        if constexpr (PF) {
+            if (pf_slots > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMAs (and everything older) have landed
+            // the slots the buffer had no room for: gathered as before, in flight while the others move from LDS to registers
+            if (cnt0 > 0 && nt0 > pf_slots) load_tile2<T, S, NT>(tile, P.B, P.ldb, k, pcur.idx, cnt0, nt0, lane, pf_slots);
+            if (pf_slots > 0) tile_from_lds<T, S, NT>(tile, pfb, k, pf_slots, lane);
+        } else {
+            if (cnt0 > 0 && !CMF_DBG(P, 1)) load_tile2<T, S, NT>(tile, P.B, P.ldb, k, pcur.idx, cnt0, nt0, lane);
+        }
         const RowDesc dnn = load_desc(rnn);
         const Pre pnxt = load_pre(dnxt);
 
@@ -331,6 +413,12 @@ cg2_rows_kernel(const CgParams<T> P)
             T out[8];
 #pragma unroll
             for (int s = 0; s < 8; s++) out[s] = T(0);
+            if constexpr (PF) {
+                // one resident tile per row by construction (the bin holds rows of at most 8 NT entries): no gather code inside
+                // the passes -- a load the compiler counts anywhere in them would put an s_waitcnt vmcnt(0) in front of its use,
+                // and with it the DMAs of the next row, issued after the first pass, back on the critical path
+                if (cnt0 > 0) tile_pass2<T, S, NT, IMPLICIT, MODE>(tile, vrep, x_res, valid_res, nt0, out, lane);
+            } else
             for (int tl = wr; tl < ntiles; tl += W) {
                 T x; bool valid; int nt;
                 const bool have = (tl == wr) && (resident || first);   // still in registers
@@ -365,6 +453,14 @@ cg2_rows_kernel(const CgParams<T> P)
 
         // ---- residual (common.c:1932-1943 / :1112-1139) ----
         T r_d = run_pass(a_d, std::integral_constant<int, 0>{}, true);
+        if constexpr (PF) {
+            // the next row's first slots set out for LDS now: the tile of this row is in registers, the buffer is free, and every
+            // load the compiler counts has been consumed (see prefetch_tile_lds)
+            const int cnt_n = min(TE, dnxt.nnz);
+            const int nt_n = (cnt_n + 7) >> 3;
+            pf_slots = (rnxt < P.nrows) ? min(nt_n, P.pf_entries >> 3) : 0;
+            if (pf_slots > 0) prefetch_tile_lds<T, NT>(P, pfb, pnxt.idx, cnt_n, 8 * pf_slots, lane);
+        }
         r_d -= lam * a_d;
         if (!IMPLICIT && lam != lam_last && lane == k - 1) r_d -= (lam_last - lam) * a_d;
         if (GRAMX && P.rconst != nullptr && lane < k) r_d += P.rconst[(size_t)row * P.ldr + lane];

@@ -94,6 +94,10 @@ struct CgParams {
     // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
     const T *rconst = nullptr;
     size_t ldr = 0;
+    // second-generation kernels with the next row's tile prefetched into LDS (cg2_kernels.hpp, PF builds): entries of a tile
+    // that travel by LDS-DMA (a multiple of 8, 0: none), 16-byte chunks per gathered row (k x sizeof / 16) and the multiplier of
+    // the division by it (ceil(65536 / chunks))
+    int pf_entries = 0, pf_cpr = 0, pf_magic = 0;
 #ifdef CMF_CG_DEBUG
     int dbg = 0;   // phase skipping for timing experiments (results are wrong): 1 gathers, 2 Gramian product, 4 tile products, 8 dot products
 #endif

@@ -558,6 +558,8 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
     int teams_needed = (count + RPB - 1) / RPB;
     int grid = std::min(teams_needed, dev.num_cus * blocks_per_cu);
+    if (const char *e = getenv("CMFREC_HIP_CG_GRID_PCT"))       // occupancy experiments: a fraction of the resident grid
+        grid = std::max(1, std::min(grid, dev.num_cus * blocks_per_cu * atoi(e) / 100));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, st, P);
     HIP_CHECK(hipGetLastError());
     if (tm) {
@@ -577,6 +579,9 @@ inline bool env_flag(const char *name, bool dflt)
     return e != nullptr ? (e[0] != '0') : dflt;
 }
 inline bool cg2_enabled() { return env_flag("CMFREC_HIP_CG2", false); }
+// second generation with the next row's tile prefetched into LDS by DMA (33 .. 64 bin; CMFREC_HIP_CG2_PF=1, implies the second
+// generation for that bin)
+inline bool cg2_pf() { return env_flag("CMFREC_HIP_CG2_PF", false); }
 // rows of 33 .. 48 entries of the second generation on 6-slot tiles, three wavefronts per SIMD (CMFREC_HIP_CG2_NT6=1)
 inline bool cg2_nt6() { return env_flag("CMFREC_HIP_CG2_NT6", false); }
 // rows of at most 16 entries: two per wavefront on the first-generation kernel (default) or the NT = 4 kernel with one or two
@@ -817,6 +822,45 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     }
 }
 
+// One wavefront per row with the next row's tile travelling into LDS while the current one is solved (cg2_kernels.hpp, PF
+// builds): a workgroup of 8 wavefronts per CU, the Gramian once, and per wavefront as many gathered rows as the CU's LDS holds
+// (40 of the 64 entries of a tile at k = 50 in double precision).  Returns false when the layout does not allow the 16-byte DMAs.
+template <int S, bool IMPLICIT, bool GRAMX>
+inline bool launch_cg2_pf_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
+{
+    if (count <= 0) return true;
+    constexpr int RPB = 8;
+    const size_t rowbytes = (size_t)P.k * sizeof(real_t);
+    if (rowbytes % 16 != 0 || (P.ldb * sizeof(real_t)) % 16 != 0 || ((uintptr_t)P.B) % 16 != 0 || rowbytes / 16 > 64) return false;
+    const size_t fixed = (((IMPLICIT || GRAMX) ? (size_t)gram2_elems(S) : 0) + (size_t)RPB * 64) * sizeof(real_t);
+    const size_t lds_cu = 160 * 1024 - 256;                     // the CU's LDS minus the static words of the kernel
+    if (fixed + (size_t)RPB * 16 * rowbytes > lds_cu) return false;
+    const int pfe = (int)std::min<size_t>(64, ((lds_cu - fixed) / ((size_t)RPB * rowbytes)) & ~(size_t)7);
+    EventPair ev{nullptr, nullptr};
+    if (tm) {
+        HIP_CHECK(hipEventCreate(&ev.a));
+        HIP_CHECK(hipEventCreate(&ev.b));
+        HIP_CHECK(hipEventRecord(ev.a, st));
+    }
+    poison_lds(st, dev.num_cus);
+    P.order += first;
+    P.desc += first;
+    P.nrows = count;
+    P.counter = dev.row_counter.ptr + cg_counter_offset(bin);
+    P.pf_entries = pfe; P.pf_cpr = (int)(rowbytes / 16); P.pf_magic = (65536 + P.pf_cpr - 1) / P.pf_cpr;
+    const size_t smem = fixed + (size_t)RPB * pfe * rowbytes;
+    auto kern = cg2_rows_kernel<real_t, S, 8, IMPLICIT, 1, RPB, GRAMX, true>;
+    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int grid = std::min((count + RPB - 1) / RPB, dev.num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RPB), smem, st, P);
+    HIP_CHECK(hipGetLastError());
+    if (tm) {
+        HIP_CHECK(hipEventRecord(ev.b, st));
+        tm->ev[bin].push_back(ev);
+    }
+    return true;
+}
+
 // number of streams the nnz bins of a half-step are spread over (CMFREC_HIP_BINS_PAR; 1 = one after the other)
 inline int cg_bin_streams()
 {
@@ -846,6 +890,7 @@ inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, 
             else launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st);
             break;
         default:
+            if (cg2_pf() && launch_cg2_pf_bin<S, IMPLICIT, GRAMX>(dev, P, first, count, tm, bin, st)) break;
             if (v2 && cg2_nt6()) {
                 // rows of 33 .. 48 entries (the tail of the bin) on 6-slot tiles: 84 tile registers leave room for a third
                 // wavefront per SIMD in double precision -- more rows, i.e. more bytes of the gather, in flight per CU

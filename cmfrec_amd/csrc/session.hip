@@ -412,6 +412,9 @@ struct LowRankScratch {
     DevBuf<double> W, V, D, E;
     DevBuf<int> info;
     DevBuf<real_t> Q, Qt, Lam, Ct, Bt, R, T;
+    int last_rows = 0;            // rows the low-rank kernels solved in the most recent launch (0: path not taken)
+    int last_eig = 0;             // its eigen-decomposition: 1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel
+    int checked_kc = 0;           // dsyevd's info word has been read back for this matrix size (once per size and session)
 };
 
 // The symmetric eigen-decomposition of the k x k matrix w C^T C (once per half-step of the low-rank path) is a plain dense
@@ -424,8 +427,6 @@ struct RocSolverApi {
     dsyevd_t dsyevd = nullptr;
     RocSolverApi()
     {
-        const char *e = getenv("CMFREC_HIP_EIG");
-        if (e != nullptr && strcmp(e, "jacobi") == 0) return;
         void *lib = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_LOCAL);
         if (lib) dsyevd = (dsyevd_t)dlsym(lib, "rocsolver_dsyevd");
@@ -480,6 +481,7 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
                        // (a bias) has to sit outside of it
                        (kt - 1 >= kc || c.lam_last == c.lam) &&
                        ((lr_env != nullptr && lr_env[0] == '1') || (n_light >= 32768 && kt >= 96));
+    S.last_rows = 0; S.last_eig = 0;
     if (!lr_ok || n_light <= 0) return -1;
     hipStream_t st = dev.stream;
     const int ngr = (kt + 15) / 16;
@@ -500,13 +502,25 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
         HIP_CHECK(hipEventRecord(d.eig_fork, st));
         HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), d.eig_fork, 0));
         const RocSolverApi &rs = rocsolver_api();
+        // CMFREC_HIP_EIG=jacobi (read at every launch: a test can set it per case) takes the built-in kernel
+        const char *eig_env = getenv("CMFREC_HIP_EIG");
+        static bool dsyevd_bad = false;       // the library reported a failed decomposition once: the built-in kernel from then on
         bool done = false;
-        if (rs.dsyevd != nullptr) {
+        if (rs.dsyevd != nullptr && !dsyevd_bad && !(eig_env != nullptr && strcmp(eig_env, "jacobi") == 0)) {
             S.D.alloc_at_least((size_t)kc); S.E.alloc_at_least((size_t)kc); S.info.alloc_at_least(1);
             hipLaunchKernelGGL(eig_pack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), c.Minit, S.W.ptr, kc);
             rocblas_handle he = d.ensure_blas_eig();
             done = rs.dsyevd(he, 211 /* rocblas_evect_original (rocsolver-extra-types.h) */, rocblas_fill_upper, kc, S.W.ptr, kc, S.D.ptr, S.E.ptr, S.info.ptr) ==
                    rocblas_status_success;
+            if (done && S.checked_kc != kc) {
+                // the return status only covers the launch: the device-side `info` (off-diagonals that did not converge) is read
+                // back the first time a matrix of this size goes through the library in this session
+                int h_info = 0;
+                HIP_CHECK(hipMemcpyAsync(&h_info, S.info.ptr, sizeof(int), hipMemcpyDeviceToHost, d.eig_stream()));
+                HIP_CHECK(hipStreamSynchronize(d.eig_stream()));
+                S.checked_kc = kc;
+                if (h_info != 0) { dsyevd_bad = true; done = false; }
+            }
             if (done)
                 hipLaunchKernelGGL(eig_unpack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), S.W.ptr, S.D.ptr, kc, S.Q.ptr,
                                    S.Qt.ptr, S.Lam.ptr);
@@ -514,6 +528,8 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
         if (!done)
             hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), c.Minit, kc, S.W.ptr, S.V.ptr, S.Q.ptr, S.Qt.ptr,
                                (size_t)kc, S.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
+        S.last_eig = done ? 1 : 2;
+        S.last_rows = n_light;
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(d.eig_ev, d.eig_stream()));
         c.row_limit = n_full;
@@ -1887,6 +1903,15 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
     // (the Gramian path stays in line, launch_cg_S)
     const bool gram_in_line = cmfrec_hip_session_vh_mode(s, which) == 2 && getenv("CMFREC_HIP_VH_GRAM_ASIDE") == nullptr;
     return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus) && !gram_in_line) ? 1 : 0;
+}
+
+// The most recent collective Cholesky half-step of the session: rows solved by the low-rank kernels (0: the path was not taken)
+// and the eigen-decomposition behind them (1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel)
+int cmfrec_hip_session_lowrank_info(cmfrec_hip_session *s, int *rows, int *eig)
+{
+    if (rows) *rows = s->lr.last_rows;
+    if (eig) *eig = s->lr.last_eig;
+    return 0;
 }
 
 // rows of the CSR ('A') / CSC ('B') shard with at least this many entries are split rows (their entries are kept sorted by

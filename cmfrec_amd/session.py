@@ -230,6 +230,13 @@ class AlsSession:
         """Rows of X's CSR ('A') / CSC ('B') shard with at least this many entries are split rows (entries sorted by opposing index)."""
         return int(self.lib.cmfrec_hip_session_vh_min(self.handle, C.c_int(ord(which))))
 
+    def lowrank_info(self):
+        """(rows, eig) of the most recent collective Cholesky half-step: rows solved by the low-rank kernels (0: path not taken),
+        eigen-decomposition 1 = rocSOLVER dsyevd, 2 = built-in Jacobi kernel."""
+        rows, eig = C.c_int(0), C.c_int(0)
+        self.lib.cmfrec_hip_session_lowrank_info(self.handle, C.byref(rows), C.byref(eig))
+        return int(rows.value), int(eig.value)
+
     def vh_mode(self, which):
         """0: no split rows on that side; 1: streamed per CG pass; 2: single gather + CG on the row's Gramian."""
         return int(self.lib.cmfrec_hip_session_vh_mode(self.handle, C.c_int(ord(which))))

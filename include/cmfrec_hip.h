@@ -443,6 +443,9 @@ int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which);
    by the opposing index (a permutation of the row's sums) and take the split-row kernels (1025; double precision: 513 where
    the split rows go through their own Gramian) */
 int cmfrec_hip_session_vh_min(cmfrec_hip_session *s, int which);
+/* the most recent collective Cholesky half-step: rows solved by the low-rank kernels (0: path not taken) and the
+   eigen-decomposition behind them (1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel; CMFREC_HIP_EIG=jacobi forces 2) */
+int cmfrec_hip_session_lowrank_info(cmfrec_hip_session *s, int *rows, int *eig);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
 /* Batched top-N (the step after the path; the reference ranks one user per call: topN, src/common.c:5127-5380).

@@ -11,9 +11,12 @@ pytestmark = pytest.mark.gpu
 DT = [np.float64, np.float32]
 
 
-@pytest.fixture(params=["cg2", "cg2-nt6", "cg2-tinyall"])
+@pytest.fixture(params=["cg2", "cg2-nt6", "cg2-tinyall", "cg2-pf", "pf-only"])
 def second_generation(request, monkeypatch):
-    monkeypatch.setenv("CMFREC_HIP_CG2", "1")
+    if request.param != "pf-only":
+        monkeypatch.setenv("CMFREC_HIP_CG2", "1")
+    if request.param in ("cg2-pf", "pf-only"):        # the 33 .. 64 bin with the next row's tile prefetched into LDS by DMA
+        monkeypatch.setenv("CMFREC_HIP_CG2_PF", "1")
     if request.param == "cg2-nt6":
         monkeypatch.setenv("CMFREC_HIP_CG2_NT6", "1")
     if request.param == "cg2-tinyall":

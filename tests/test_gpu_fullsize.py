@@ -201,3 +201,94 @@ def test_c3_shape_normal_equations():
         rhs = Bj.T @ x
         sol = np.concatenate([A[u], [biasA[u]]])
         assert np.abs(M @ sol - rhs).max() <= 1e-9 * max(1.0, np.abs(rhs).max()), (u, ucnt[u])
+
+
+@pytest.mark.parametrize("eig", ["library", "jacobi"])
+def test_c5_shard_properties(eig, monkeypatch):
+    """A quarter of `bench.py --workload c5shard` (BASELINE config 5's shape per GPU: k = 256 + biases in SINGLE precision, 512
+    dense side-information columns on both sides, Cholesky, 20 entries per user): 390,625 users x 31,250 items, 7.8 M entries --
+    the size at which the dispatch of the benchmark is taken, not just its instantiations: the automatic low-rank selection for
+    the users (asserted), the eigen-decomposition chain (rocSOLVER where the box has it, the built-in Jacobi kernel when forced),
+    the 17-tile 16-wave row kernel for the items, 64-bit offsets, the library GEMMs at production width.  Sampled user rows
+    (s <= 128 entries: low-rank path) and item rows satisfy the collective normal equations in float64 arithmetic
+        (sum_j b_j b_j^T + w C^T C (+) 0 + lam max(n_row, 1) I) a = w C^T u_row (+) 0 + sum_j (x_j - bias_j) b_j
+    (collective_closed_form_block, collective.c:1534-1846) to 2e-4, two runs are bit-identical, C and D are finite."""
+    import bench
+    from cmfrec_amd.session import AlsSession
+    if eig == "jacobi":
+        monkeypatch.setenv("CMFREC_HIP_EIG", "jacobi")
+    sc = 0.25
+    m, n, nnz = int(1_562_500 * sc), int(125_000 * sc), int(31_250_000 * sc)
+    k, p, q = 256, 512, 512
+    row, col, _ = bench.synth_block(m, n, nnz, seed=5)
+    rng = np.random.default_rng(5)
+    val = (0.5 * rng.integers(1, 11, nnz)).astype(np.float32); val -= val.mean()
+    U = rng.standard_normal((m, p), dtype=np.float32)
+    II = rng.standard_normal((n, q), dtype=np.float32)
+    lam, w = 0.05, 1.0
+    A0 = rng.standard_normal((m, k), dtype=np.float32) * np.float32(0.1)
+    B0 = rng.standard_normal((n, k), dtype=np.float32) * np.float32(0.1)
+    bA0 = rng.standard_normal(m).astype(np.float32) * np.float32(0.1)
+    bB0 = rng.standard_normal(n).astype(np.float32) * np.float32(0.1)
+    C0 = rng.standard_normal((p, k), dtype=np.float32) * np.float32(0.05)
+    D0 = rng.standard_normal((q, k), dtype=np.float32) * np.float32(0.05)
+
+    def run():
+        s = AlsSession(m, n, k, implicit=False, dtype=np.float32, lam=lam, use_cg=False, user_bias=True, item_bias=True, scale_lam=True,
+                       p=p, m_u=m, q=q, n_i=n)
+        s.set_X_coo(row, col, val)
+        s.set_sideinfo(U=U, II=II)
+        s.set_factors(A=A0, B=B0, biasA=bA0, biasB=bB0, Cm=C0, Dm=D0)
+        s.update("B"); s.after_gather("B")
+        fB = s.get_factors()
+        s.update("A"); s.after_gather("A")
+        info = s.lowrank_info()
+        fA = s.get_factors()
+        s.update("C"); s.update("D")
+        fC = s.get_factors()
+        return fB, fA, fC, info
+
+    fB, fA, fC, info = run()
+    # the users go through the low-rank kernels by themselves (>= 32 k qualifying rows), on the eigen-decomposition asked for
+    ucnt = np.bincount(row, minlength=m)
+    assert info[0] >= 32768 and info[0] == int((ucnt <= 128).sum()), info
+    assert info[1] == 2 if eig == "jacobi" else info[1] in (1, 2), info
+    assert np.isfinite(fC["C"]).all() and np.isfinite(fC["D"]).all() and np.isfinite(fA["A"]).all() and np.isfinite(fB["B"]).all()
+    kt = k + 1
+    f64 = lambda a: np.asarray(a, np.float64)
+    # ---- item rows after the B-step (17-tile row kernel; the heaviest are sliced) ----
+    B, biasB = f64(fB["B"]), f64(fB["biasB"])
+    ccnt = np.bincount(col, minlength=n)
+    order = np.argsort(col, kind="stable"); ptr = np.concatenate([[0], np.cumsum(ccnt)])
+    Ab = np.concatenate([f64(A0), np.ones((m, 1))], axis=1)
+    DtD = w * f64(D0).T @ f64(D0)
+    items = np.concatenate([np.argsort(-ccnt)[:3], rng.choice(np.nonzero(ccnt > 0)[0], 12, replace=False)])
+    for i in items:
+        e = order[ptr[i]:ptr[i + 1]]
+        Aj = Ab[row[e]]; x = f64(val[e]) - f64(bA0)[row[e]]
+        M = Aj.T @ Aj + lam * (ccnt[i] + 0) * np.eye(kt)
+        M[:k, :k] += DtD
+        rhs = Aj.T @ x
+        rhs[:k] += w * (f64(II[i]) @ f64(D0))
+        sol = np.concatenate([B[i], [biasB[i]]])
+        assert np.abs(M @ sol - rhs).max() <= 2e-4 * max(1.0, np.abs(rhs).max(), np.abs(M).max() * np.abs(sol).max()), (i, ccnt[i])
+    # ---- user rows after the A-step (low-rank path for s <= 128, full factorisation above) ----
+    A, biasA = f64(fA["A"]), f64(fA["biasA"])
+    uorder = np.argsort(row, kind="stable"); uptr = np.concatenate([[0], np.cumsum(ucnt)])
+    Bb = np.concatenate([B, np.ones((n, 1))], axis=1)
+    CtC = w * f64(C0).T @ f64(C0)
+    light = np.nonzero((ucnt > 0) & (ucnt <= 128))[0]
+    users = np.concatenate([np.argsort(-ucnt)[:3], rng.choice(light, 24, replace=False), np.nonzero(ucnt == 0)[0][:2]])
+    for u in users:
+        e = uorder[uptr[u]:uptr[u + 1]]
+        Bj = Bb[col[e]]; x = f64(val[e]) - biasB[col[e]]
+        M = Bj.T @ Bj + lam * max(ucnt[u], 1) * np.eye(kt)             # rows without entries: multiplier 1 (collective.c:1285-1355)
+        M[:k, :k] += CtC
+        rhs = Bj.T @ x
+        rhs[:k] += w * (f64(U[u]) @ f64(C0))
+        sol = np.concatenate([A[u], [biasA[u]]])
+        assert np.abs(M @ sol - rhs).max() <= 2e-4 * max(1.0, np.abs(rhs).max(), np.abs(M).max() * np.abs(sol).max()), (u, ucnt[u])
+    # ---- bit reproducibility of the whole sequence ----
+    gB, gA, gC, _ = run()
+    for a, b in ((fB["B"], gB["B"]), (fA["A"], gA["A"]), (fC["C"], gC["C"]), (fC["D"], gC["D"])):
+        assert np.array_equal(a, b)
