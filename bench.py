@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
     ap.add_argument("--implicit-features", action="store_true", help="side workloads c1 / c3: add the implicit-features matrices Ai, Bi")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard", "c5shard"],
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard", "c5shard", "c5"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
                          "MovieLens10M-shaped configs of BASELINE.json (single GPU, side measurements)")
     args = ap.parse_args()
@@ -103,6 +103,12 @@ def main():
 
     from cmfrec_amd.session import AlsSession
     from cmfrec_amd.distributed import ShardedAls, GpuEngine
+    if args.workload == "c5":
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        return c5_distributed(args, rank, world, local_rank)
     if use_dist and args.workload == "c2":
         return c4_distributed(args, rank, world, local_rank)
     if args.workload == "fit":
@@ -428,6 +434,120 @@ def c4_run(args, rank, world, local_rank, steps, warmup):
     del engine, eng, sess
     torch.cuda.empty_cache()
     return out
+
+
+C5_M, C5_N, C5_NNZ, C5_K, C5_P = 100_000_000, 1_000_000, 2_000_000_000, 256, 512     # BASELINE.json configs[4] / SURVEY.md 8d "C5"
+
+
+def c5_shard_data(scale, rank, world, dev, seed=50):
+    """This rank's share of the data of BASELINE.json configs[4], drawn on `dev` (a GPU in the bench, the CPU in the gloo test of
+    the set-up path): its user block of X as COO (rows local to the block, global item ids; ratings 0.5 .. 5 minus their mean),
+    its rows of U, and a function that returns the rows [c0, c1) of I -- the item side information is a function of the item id
+    alone, so every rank can draw the rows of whatever item block the nnz-balanced cut assigns to it."""
+    import torch
+    m_blk = max(int(C5_M * scale) // world, 64)
+    n = max(int(C5_N * scale), 1024)                   # (tiny test scales: enough items for 20 distinct ones per user)
+    nnz_blk = (C5_NNZ // C5_M) * m_blk                 # 20 entries per user at every scale
+    p = q = C5_P
+    row, col, _ = synth_block_torch(m_blk, n, nnz_blk, seed=seed + rank, item_seed=5, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(500 + rank)
+    val = 0.5 * torch.randint(1, 11, (len(row),), generator=g, device=dev).to(torch.float32) - 2.75
+    U = torch.randn((m_blk, p), generator=g, device=dev, dtype=torch.float32)
+
+    def item_rows(c0, c1):
+        gi = torch.Generator(device=dev); gi.manual_seed(7)
+        return torch.randn((n, q), generator=gi, device=dev, dtype=torch.float32)[c0:c1].contiguous()
+
+    return dict(m_blk=m_blk, m=m_blk * world, n=n, nnz=nnz_blk * world, row=row, col=col, val=val, U=U, item_rows=item_rows,
+                row_ranges=[(r * m_blk, (r + 1) * m_blk) for r in range(world)])
+
+
+def c5_setup(scale, rank, world, local_rank):
+    """The sharded engine of BASELINE.json configs[4] (CMF_explicit ALS-Chol k=256 fp32, 100M x 1M, 2e9 entries, 512 dense
+    side-information columns on both sides, user and item biases) for this rank: GpuEngine.from_collective_block on the
+    device-generated shard (U / I local, C / D by partial sums + all-reduce), start values set."""
+    import torch
+    from cmfrec_amd.distributed import GpuEngine
+    dev = torch.device("cuda", local_rank)
+    d = c5_shard_data(scale, rank, world, dev)
+    m, n, k = d["m"], d["n"], C5_K
+    eng = GpuEngine.from_collective_block(m, n, k, d["row"], d["col"], d["val"], d["row_ranges"], rank, world, local_rank,
+                                          U_local=d["U"], I_local=d["item_rows"], p=C5_P, q=C5_P, m_u=m, n_i=n, dtype=np.float32,
+                                          lam=0.05, w_user=1.0, w_item=1.0, user_bias=True, item_bias=True, scale_lam=True)
+    fA, fB = eng.full("A"), eng.full("B")
+    fA.zero_(); fB.zero_()
+    r0, r1 = d["row_ranges"][rank]
+    c0, c1 = eng.ranges("B")[rank]
+    g = torch.Generator(device=dev); g.manual_seed(900 + rank)
+    fA[r0:r1, :k].copy_(torch.randn((r1 - r0, k), generator=g, device=dev, dtype=torch.float32) * 2.0 ** -7)
+    gb = torch.Generator(device=dev); gb.manual_seed(9)
+    fB[c0:c1, :k].copy_((torch.randn((n, k), generator=gb, device=dev, dtype=torch.float32) * 2.0 ** -7)[c0:c1])
+    torch.cuda.synchronize()
+    nnz = d["nnz"]
+    del d
+    return eng, m, n, nnz
+
+
+def c5_distributed(args, rank, world, local_rank):
+    """`--workload c5 --gpus N`: BASELINE.json configs[4] on N ranks through ShardedAls.iteration_collective (C, D by partial sums
+    and one all-reduce each; B- and A-step with an all-gather of the updated rows incl. their bias columns).  The whole problem
+    needs N >= 8 (A alone is 103 GB per replica, U 205 GB in total); --scale shrinks it for tests and marks the line invalid."""
+    import torch
+    import torch.distributed as dist
+    from cmfrec_amd.distributed import ShardedAls
+    t0 = time.time()
+    eng, m, n, nnz = c5_setup(args.scale, rank, world, local_rank)
+    t_setup = time.time() - t0
+    als = ShardedAls(eng, rank, world)
+    als.allgather("A"); als.allgather("B")
+    sess = eng.session
+    steps, warmup = max(1, min(args.steps, 3)), min(args.warmup, 1)
+
+    def sync():
+        sess.sync(); torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        als.iteration_collective()
+    sync(); sess.reset_timers()
+    dist.barrier(); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        als.iteration_collective()
+    sync()
+    dist.barrier(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms = elapsed / steps * 1e3
+    msA, cA = sess.kernel_time("A"); msB, cB = sess.kernel_time("B")
+    lr_rows, lr_eig = sess.lowrank_info()
+    kt = C5_K + 1
+    # flops per half-step (SURVEY 8d): Gramians nnz kt (kt + 1) + factorisation kt^3 / 3 + 2 kt^2 per row
+    flA = nnz * kt * (kt + 1) + m * (kt ** 3 / 3 + 2 * kt * kt)
+    flB = nnz * kt * (kt + 1) + n * (kt ** 3 / 3 + 2 * kt * kt)
+    f = sess.get_factors() if m * (kt + 1) < 2e8 else None
+    out = None
+    if rank == 0:
+        out = {"metric": "ALS rows/sec ((users+items)/iteration time), explicit ALS-Chol k=256 fp32 + 512-dim side information",
+               "value": round((m + n) / (elapsed / steps), 1), "unit": "rows/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": "CMF_explicit ALS-Chol k=256 fp32, synthetic %d users x %d items, %d nnz, 512-dim dense side "
+                                      "information on both sides, user + item biases (BASELINE.json configs[4])" % (m, n, nnz),
+                          "parallelism": "user / item row blocks x%d (items nnz-balanced), U / I sharded with the rows, C / D by partial "
+                                         "sums + one all-reduce each, all-gather of the updated rows after every half-step" % world,
+                          "setup_seconds": round(t_setup, 1)},
+               "halfstep_ms_rank0": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)},
+               "halfstep_TFLOPs_rank0_share": {"A": round(flA / world / (msA / max(cA, 1) * 1e-3) / 1e12, 1) if cA else None,
+                                               "B": round(flB / world / (msB / max(cB, 1) * 1e-3) / 1e12, 1) if cB else None},
+               "lowrank_rows_rank0": lr_rows, "lowrank_eig": {0: "not taken", 1: "rocSOLVER dsyevd", 2: "built-in Jacobi"}[lr_eig],
+               "finite": None if f is None else bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all() and np.isfinite(f["C"]).all()),
+               "roofline": None, "cpu_baseline": None}
+        if args.scale != 1.0:
+            out["config"]["INVALID_scaled_down"] = args.scale
+    dist.destroy_process_group()
+    emit_last_line(json.dumps(out) if out is not None else None)
 
 
 def emit_last_line(line):

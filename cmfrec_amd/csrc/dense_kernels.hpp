@@ -211,63 +211,176 @@ __global__ void fill_kernel(T *__restrict__ p, size_t n, T value)
     if (e < n) p[e] = value;
 }
 
-// C[M,N] = alpha * op(A) * B  (row-major; op(A) = A[M,K] or, TRANSA, A stored as [K,M]).
-// Side-information contractions of the collective model: U*C (cblas_tgemm, reference
-// src/collective.c:5770-5773) and U^T*A (src/common.c:2852-2855).  64x64 output tile per
-// workgroup, 4x4 per thread, operands staged through LDS.
+// ---- dense contractions of the side-information path on the matrix cores (round 3) ------------------------------------------
+// C[M,N] (+)= alpha * op(A) * B, row-major, op(A) = A[M,K] or (TRANSA) A stored as [K,M]: the w U C / I D products (tall M,
+// K = p, N = k_user + k), U^T A / A^T A (short M and N, K = the rows of the factor matrix: split over gridDim.z, partial
+// products summed in split order by gemm_splitk_reduce_kernel -- bit-reproducible, no floating-point atomics).
+// Workgroup: 128 x 128 output tile, four wavefronts in a 2 x 2 grid, each a 64 x 64 tile = 4 x 4 accumulator tiles of
+// v_mfma_{f32,f64}_16x16x4; the K dimension in steps of BK = 16 staged through LDS (k-major, so that both MFMA operands are 16
+// consecutive elements of 4 consecutive rows), the next step's global loads in flight during the MFMAs of the current one.
+// 64 MFMAs per wave and step against 16 operand reads: the matrix pipe is the limit.
+template <typename T> struct GemmMfma;
+template <> struct GemmMfma<double> {
+    typedef double vec __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vec mma(double a, double b, vec c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct GemmMfma<float> {
+    typedef float vec __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ vec mma(float a, float b, vec c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+constexpr int GEMM_BM = 128, GEMM_BN = 128;
+constexpr int GEMM_BK = 32;                   // K-chunks of the split are multiples of this (the kernel's own step: 32 / 16)
+template <typename T> struct GemmVec;
+template <> struct GemmVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct GemmVec<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
 template <typename T, bool TRANSA>
-__global__ void __launch_bounds__(256)
-gemm_kernel(int M, int N, int K, T alpha, const T *__restrict__ A, size_t lda,
-            const T *__restrict__ B, size_t ldb, T *__restrict__ C, size_t ldc)
+__global__ void __launch_bounds__(256, 2)
+gemm_mfma_kernel(int M, int N, int K, int kchunk, T alpha, const T *__restrict__ A, size_t lda, const T *__restrict__ B, size_t ldb,
+                 T *__restrict__ C, size_t ldc, size_t split_stride)
 {
-    constexpr int BM = 64, BN = 64, BK = 16;
-    __shared__ T As[BK][BM + 4];
-    __shared__ T Bs[BK][BN + 4];
-    const int tid = threadIdx.x;
-    const int tx = tid % 16, ty = tid / 16;
+    using Mf = GemmMfma<T>;
+    using vec = typename Mf::vec;
+    using lvec = typename GemmVec<T>::type;                    // 16 bytes of operand per load
+    constexpr int BM = GEMM_BM, BN = GEMM_BN;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int BK = (sizeof(T) == 4) ? 32 : 16;             // 16 KB of each operand per step
+    constexpr int NV = BM * BK / 256 / VEC;                    // 16-byte loads per thread, operand and step (4)
+    // LDS images are k-major ([BK][row stride]): both MFMA operands are 16 consecutive elements of 4 consecutive k-rows.
+    // Row stride 144 == 16 (mod 32): conflict-free operand reads and aligned vector stores where the global layout is k-major
+    // too (B always, A when TRANSA).  A[M, K] arrives m-major: its 16-byte loads run along k and are stored as scalars down a
+    // column -- stride 130, so that the 8 k-groups of a wave spread over the banks (2-way on stores and reads instead of 8-way).
+    constexpr int LSA = TRANSA ? 144 : 130, LSB = 144;
+    __shared__ __attribute__((aligned(16))) T As[BK * LSA];
+    __shared__ __attribute__((aligned(16))) T Bs[BK * LSB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    T acc[4][4];
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    // whole tiles at 16-byte aligned addresses take the vector path; edges (and odd leading dimensions) the clamped scalar one
+    const bool a_vec_ok = ((size_t)A % 16 == 0) && ((lda * sizeof(T)) % 16 == 0) && (m0 + BM <= M);
+    const bool b_vec_ok = ((size_t)B % 16 == 0) && ((ldb * sizeof(T)) % 16 == 0) && (n0 + BN <= N);
+    vec acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) acc[a][b] = T(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        for (int e = tid; e < BK * BM; e += 256) {
-            int kk, mm;
-            if (TRANSA) { kk = e / BM; mm = e % BM; }
-            else        { mm = e / BK; kk = e % BK; }
-            int gm = m0 + mm, gk = k0 + kk;
-            T v = T(0);
-            if (gm < M && gk < K) v = TRANSA ? A[(size_t)gk * lda + gm] : A[(size_t)gm * lda + gk];
-            As[kk][mm] = v;
-        }
-        for (int e = tid; e < BK * BN; e += 256) {
-            int kk = e / BN, nn = e % BN;
-            int gk = k0 + kk, gn = n0 + nn;
-            Bs[kk][nn] = (gk < K && gn < N) ? B[(size_t)gk * ldb + gn] : T(0);
-        }
-        __syncthreads();
+        for (int b = 0; b < 4; b++) acc[a][b] = vec{0, 0, 0, 0};
+    lvec ra[NV], rb[NV];
+    // thread -> (row, 16-byte group) of a tile whose rows are RL elements long
+    auto load_step = [&](int k0) {
+        const bool full_k = k0 + BK <= kend;
+        if (a_vec_ok && full_k) {
+            if (TRANSA) {                                      // A[k][m]: groups along m
+                constexpr int GPR = BM / VEC;                  // groups per k-row
 #pragma unroll
-        for (int kk = 0; kk < BK; kk++) {
+                for (int i = 0; i < NV; i++) {
+                    const int kk = tid / GPR + (256 / GPR) * i, mq = tid % GPR;
+                    ra[i] = *reinterpret_cast<const lvec *>(A + (size_t)(k0 + kk) * lda + m0 + mq * VEC);
+                }
+            } else {                                           // A[m][k]: groups along k
+                constexpr int GPR = BK / VEC;
+#pragma unroll
+                for (int i = 0; i < NV; i++) {
+                    const int mm = tid / GPR + (256 / GPR) * i, kq = tid % GPR;
+                    ra[i] = *reinterpret_cast<const lvec *>(A + (size_t)(m0 + mm) * lda + k0 + kq * VEC);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    int kk, mm;
+                    if (TRANSA) { constexpr int GPR = BM / VEC; kk = tid / GPR + (256 / GPR) * i; mm = (tid % GPR) * VEC + j; }
+                    else        { constexpr int GPR = BK / VEC; mm = tid / GPR + (256 / GPR) * i; kk = (tid % GPR) * VEC + j; }
+                    const int gm = m0 + mm, gk = k0 + kk;
+                    const size_t off = TRANSA ? (size_t)min(gk, kend - 1) * lda + (size_t)min(gm, M - 1)
+                                              : (size_t)min(gm, M - 1) * lda + (size_t)min(gk, kend - 1);
+                    const T v = A[off];
+                    ra[i][j] = (gm < M && gk < kend) ? v : T(0);
+                }
+        }
+        constexpr int GPRB = BN / VEC;
+        if (b_vec_ok && full_k) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const int kk = tid / GPRB + (256 / GPRB) * i, nq = tid % GPRB;
+                rb[i] = *reinterpret_cast<const lvec *>(B + (size_t)(k0 + kk) * ldb + n0 + nq * VEC);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const int kk = tid / GPRB + (256 / GPRB) * i, nn = (tid % GPRB) * VEC + j;
+                    const int gk = k0 + kk, gn = n0 + nn;
+                    const T v = B[(size_t)min(gk, kend - 1) * ldb + (size_t)min(gn, N - 1)];
+                    rb[i][j] = (gk < kend && gn < N) ? v : T(0);
+                }
+        }
+    };
+    auto store_step = [&]() {
+        if (TRANSA) {
+            constexpr int GPR = BM / VEC;
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                *reinterpret_cast<lvec *>(As + (tid / GPR + (256 / GPR) * i) * LSA + (tid % GPR) * VEC) = ra[i];
+        } else {
+            constexpr int GPR = BK / VEC;
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+#pragma unroll
+                for (int j = 0; j < VEC; j++) As[((tid % GPR) * VEC + j) * LSA + tid / GPR + (256 / GPR) * i] = ra[i][j];
+        }
+        constexpr int GPRB = BN / VEC;
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+            *reinterpret_cast<lvec *>(Bs + (tid / GPRB + (256 / GPRB) * i) * LSB + (tid % GPRB) * VEC) = rb[i];
+    };
+    if (kbeg < kend) load_step(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                                       // the previous step's operand reads are done
+        store_step();
+        __syncthreads();
+        if (k0 + BK < kend) load_step(k0 + BK);                // lands behind the MFMAs below
+        const T *ap = As + (lane >> 4) * LSA + 64 * wy + (lane & 15);
+        const T *bp = Bs + (lane >> 4) * LSB + 64 * wx + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < BK / 4; q++) {
             T av[4], bv[4];
 #pragma unroll
-            for (int a = 0; a < 4; a++) av[a] = As[kk][ty * 4 + a];
+            for (int a = 0; a < 4; a++) av[a] = ap[(4 * q) * LSA + 16 * a];
 #pragma unroll
-            for (int b = 0; b < 4; b++) bv[b] = Bs[kk][tx * 4 + b];
+            for (int b = 0; b < 4; b++) bv[b] = bp[(4 * q) * LSB + 16 * b];
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
-                for (int b = 0; b < 4; b++) acc[a][b] += av[a] * bv[b];
+                for (int b = 0; b < 4; b++) acc[a][b] = Mf::mma(av[a], bv[b], acc[a][b]);
         }
-        __syncthreads();
     }
+    T *Cz = C + (size_t)blockIdx.z * split_stride;
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            int gm = m0 + ty * 4 + a, gn = n0 + tx * 4 + b;
-            if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = alpha * acc[a][b];
-        }
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gm = m0 + 64 * wy + 16 * a + Mf::row_of(lane, r), gn = n0 + 64 * wx + 16 * b + (lane & 15);
+                if (gm < M && gn < N) Cz[(size_t)gm * ldc + gn] = alpha * acc[a][b][r];
+            }
+}
+
+// C[e] = sum_z partial[z][e], z ascending (a fixed order: the result does not depend on how the blocks were scheduled)
+template <typename T>
+__global__ void gemm_splitk_reduce_kernel(const T *__restrict__ partial, size_t split_stride, int nsplit, int M, int N, T *__restrict__ C, size_t ldc)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)M * N) return;
+    T s = T(0);
+    for (int z = 0; z < nsplit; z++) s += partial[(size_t)z * split_stride + e];
+    C[(e / N) * ldc + (e % N)] = s;
 }
 
 // In-place Cholesky of one small matrix, M = R^T R, upper triangle of the row-major matrix (what LAPACK's

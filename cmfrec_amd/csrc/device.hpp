@@ -71,7 +71,8 @@ struct DevBuf {
     void upload(const T *host, size_t count, hipStream_t st)
     {
         if (count > n) alloc(count);
-        if (count) HIP_CHECK(hipMemcpyAsync(ptr, host, count * sizeof(T), hipMemcpyHostToDevice, st));
+        // (hipMemcpyDefault: the source may also be device memory -- side information generated shard-wise in HBM, bench.py)
+        if (count) HIP_CHECK(hipMemcpyAsync(ptr, host, count * sizeof(T), hipMemcpyDefault, st));
     }
     void download(T *host, size_t count, hipStream_t st) const
     {
@@ -318,6 +319,7 @@ struct DeviceInfo {
     DevBuf<real_t> cg_gfull, cg_rconst;   // block systems on the tiled CG kernels: weighted Gramian (k x k) and per-row constants
     DevBuf<real_t> tile_init;       // initial matrices of a Cholesky launch in tile-linear layout (chol_wave_kernels.hpp, tile_pack_kernel)
     DevBuf<int> row_counter;        // work counters of the dynamically scheduled row kernels (zeroed before each launch)
+    DevBuf<real_t> gemm_ws;         // partial products of the split-K GEMMs (session.hip, launch_gemm)
     // second stream + events for two row kernels that may overlap (heavy-row teams beside light-row teams); created on
     // first use, owned here
     hipStream_t aux_stream = nullptr;
@@ -424,6 +426,55 @@ struct BinTimers {
 };
 
 // ------------------------------------------------------------------------------------------
+// dense contractions
+template <bool TRANSA>
+inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha, const real_t *A, size_t lda,
+                        const real_t *B, size_t ldb, real_t *C, size_t ldc)
+{
+    if (M <= 0 || N <= 0) return;
+    // C[M, N] = alpha * op(A) B, all row-major: the dense contractions of the side-information path (w U C, U^T A, I D, the
+    // rotations of the low-rank path).  Round 3: the library's own MFMA kernel (dense_kernels.hpp, gemm_mfma_kernel) -- the
+    // matrix cores under an LDS-staged 128 x 128 tile, split over K with an ordered reduction where M x N alone would leave
+    // CUs idle (U^T A: 512 x 256 outputs over 1.5 M rows).  CMFREC_HIP_GEMM_OWN=0 calls rocBLAS instead (A/B timing and
+    // cross-check; row-major C is the column-major C^T = B^T op(A)^T, so: first operand B, second operand A with the
+    // transposition flag inverted).
+    const char *own_env = getenv("CMFREC_HIP_GEMM_OWN");
+    if (!(own_env != nullptr && own_env[0] == '0')) {
+        DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+        const int bm = (M + GEMM_BM - 1) / GEMM_BM, bn = (N + GEMM_BN - 1) / GEMM_BN;
+        int nsplit = 1;
+        if ((long long)bm * bn < 2LL * dev.num_cus && K >= 4096)
+            nsplit = (int)std::min<long long>((K + 1023) / 1024, std::max<long long>(1, (4LL * dev.num_cus) / ((long long)bm * bn)));
+        int kchunk = (std::max(K, 1) + nsplit - 1) / nsplit;
+        kchunk = (kchunk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+        nsplit = (std::max(K, 1) + kchunk - 1) / kchunk;
+        const dim3 grid(bn, bm, nsplit);
+        if (nsplit == 1) {
+            hipLaunchKernelGGL((gemm_mfma_kernel<real_t, TRANSA>), grid, dim3(256), 0, dev.stream, M, N, K, kchunk, alpha, A, lda, B, ldb, C, ldc,
+                               (size_t)0);
+        } else {
+            const size_t ss = (size_t)M * N;
+            d.gemm_ws.alloc_at_least(ss * nsplit);
+            hipLaunchKernelGGL((gemm_mfma_kernel<real_t, TRANSA>), grid, dim3(256), 0, dev.stream, M, N, K, kchunk, alpha, A, lda, B, ldb,
+                               d.gemm_ws.ptr, (size_t)N, ss);
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel<real_t>, dim3((unsigned)((ss + 255) / 256)), dim3(256), 0, dev.stream, d.gemm_ws.ptr, ss,
+                               nsplit, M, N, C, ldc);
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
+    const real_t zero = 0;
+    const rocblas_operation opA = TRANSA ? rocblas_operation_transpose : rocblas_operation_none;
+#ifdef CMFREC_HIP_FLOAT
+    rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
+#else
+    rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
+#endif
+    if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm failed"; throw HipError{1}; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Gramian  out[k,k] = scale * B[:, :k]^T B[:, :k] + add_diag * I
 struct GramWorkspace {
     DevBuf<real_t> partial;
@@ -451,18 +502,9 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
         hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 3) / 4), dim3(256), 0, dev.stream,
                            ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
     } else {
-        // k > 64: out = scale * B^T B as one library GEMM (row-major B[n, ldb] is the column-major [ldb, n] whose
-        // first k rows are B^T), then the diagonal shift; both triangles are filled
-        rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
-        const real_t zero = 0;
-#ifdef CMFREC_HIP_FLOAT
-        rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, k, k, n, &scale, B, (int)ldb, B,
-                                          (int)ldb, &zero, out, k);
-#else
-        rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, k, k, n, &scale, B, (int)ldb, B,
-                                          (int)ldb, &zero, out, k);
-#endif
-        if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm (Gramian) failed"; throw HipError{1}; }
+        // k > 64: out = scale * B^T B through the split-K GEMM (both operands the same matrix: 4 x the triangle's flops in
+        // the rare k > 64 set-ups, no extra kernel), then the diagonal shift; both triangles are filled
+        launch_gemm<true>(dev, k, k, n, scale, B, ldb, B, ldb, out, (size_t)k);
         if (add_diag != 0)
             hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3((k + 255) / 256), dim3(256), 0, dev.stream, out, k, 0, k, add_diag);
     }

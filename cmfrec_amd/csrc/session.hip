@@ -357,32 +357,7 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
     return 0;
 }
 
-template <bool TRANSA>
-static void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha, const real_t *A, size_t lda,
-                        const real_t *B, size_t ldb, real_t *C, size_t ldc)
-{
-    if (M <= 0 || N <= 0) return;
-    // C[M, N] = alpha * op(A) B, all row-major.  These are the plain dense contractions of the side-information path
-    // (U C, U^T A, I D ...): a library GEMM.  Row-major C is the column-major C^T = B^T op(A)^T, and a row-major matrix
-    // is its own transpose in column-major storage, so: first operand B (no transpose), second operand A with the
-    // transposition flag inverted.
-    static const bool own = getenv("CMFREC_HIP_GEMM_OWN") != nullptr;        // A/B switch: the LDS-tiled kernel of dense_kernels.hpp
-    if (own || K <= 0) {
-        dim3 grid((N + 63) / 64, (M + 63) / 64);
-        hipLaunchKernelGGL((gemm_kernel<real_t, TRANSA>), grid, dim3(256), 0, dev.stream, M, N, K, alpha, A, lda, B, ldb, C, ldc);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
-    rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
-    const real_t zero = 0;
-    const rocblas_operation opA = TRANSA ? rocblas_operation_transpose : rocblas_operation_none;
-#ifdef CMFREC_HIP_FLOAT
-    rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
-#else
-    rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
-#endif
-    if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm failed"; throw HipError{1}; }
-}
+// (launch_gemm: device.hpp)
 
 // X := X (R^T R)^-1 for the row-major [rows, k] block X (ld = ldx) and the row-major upper Cholesky factor R [k, k] of a
 // shared matrix: the multi-right-hand-side posv of optimizeA Case 3 (common.c:3171-3175) as two library triangular
@@ -2409,6 +2384,54 @@ __global__ void lanes_selftest_kernel(real_t *out)
     o[16 * 64] = (real_t)lanes::bcast8<6>(lane * 5 + 2);
 }
 }  // namespace cmfhip
+
+// Timing probe of the dense contraction C[M, N] = op(A) B on the device (tools/microbench/gemm_probe.py): milliseconds per call of
+// the library's own MFMA kernel and of rocBLAS on the same operands, and the largest difference between their results relative
+// to the largest entry.  transa != 0: A is stored [K, M].
+extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, double *ms_own, double *ms_rocblas, double *max_rel_diff)
+{
+    return guarded([&]() {
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> A, B, C1, C2;
+        A.alloc((size_t)M * K); B.alloc((size_t)K * N); C1.alloc((size_t)M * N); C2.alloc((size_t)M * N);
+        std::vector<real_t> ha((size_t)M * K), hb((size_t)K * N);
+        unsigned long long x = 88172645463325252ull;
+        auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (real_t)((double)(x >> 11) / 9007199254740992.0 - 0.5); };
+        for (auto &v : ha) v = rnd();
+        for (auto &v : hb) v = rnd();
+        A.upload(ha.data(), ha.size(), dev.stream); B.upload(hb.data(), hb.size(), dev.stream);
+        const size_t lda = transa ? (size_t)M : (size_t)K;
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        auto run = [&](bool own, real_t *C, double *ms) {
+            if (own) unsetenv("CMFREC_HIP_GEMM_OWN"); else setenv("CMFREC_HIP_GEMM_OWN", "0", 1);
+            for (int r = 0; r < reps + 1; r++) {
+                if (r == 1) HIP_CHECK(hipEventRecord(e0, dev.stream));
+                if (transa) launch_gemm<true>(dev, M, N, K, (real_t)1, A.ptr, lda, B.ptr, (size_t)N, C, (size_t)N);
+                else launch_gemm<false>(dev, M, N, K, (real_t)1, A.ptr, lda, B.ptr, (size_t)N, C, (size_t)N);
+            }
+            HIP_CHECK(hipEventRecord(e1, dev.stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float t = 0;
+            HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+            if (ms) *ms = (double)t / std::max(reps, 1);
+        };
+        const char *keep = getenv("CMFREC_HIP_GEMM_OWN");
+        const std::string keep_s = keep ? keep : "";
+        run(true, C1.ptr, ms_own);
+        run(false, C2.ptr, ms_rocblas);
+        if (keep) setenv("CMFREC_HIP_GEMM_OWN", keep_s.c_str(), 1); else unsetenv("CMFREC_HIP_GEMM_OWN");
+        std::vector<real_t> h1((size_t)M * N), h2((size_t)M * N);
+        C1.download(h1.data(), h1.size(), dev.stream); C2.download(h2.data(), h2.size(), dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        double mx = 0, df = 0;
+        for (size_t e = 0; e < h1.size(); e++) { mx = std::max(mx, std::fabs((double)h2[e])); df = std::max(df, std::fabs((double)h1[e] - (double)h2[e])); }
+        if (max_rel_diff) *max_rel_diff = df / std::max(mx, 1e-300);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return 0;
+    });
+}
 
 extern "C" int cmfrec_hip_selftest_lanes(void)
 {

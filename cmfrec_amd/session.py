@@ -172,10 +172,20 @@ class AlsSession:
 
     def set_sideinfo_local(self, U=None, II=None):
         """Row-block shards: only the block's rows of the (centred) side information -- U rows [row_begin, min(row_end, m_u)),
-        I rows [col_begin, min(col_end, n_i))."""
-        keep = [self._c(U), self._c(II)]
-        _lib.check(self.lib.cmfrec_hip_session_set_sideinfo_local(self.handle, *[_lib.ptr(a) for a in keep]), self.lib,
-                   "set_sideinfo_local")
+        I rows [col_begin, min(col_end, n_i)).  Arrays on the host, or contiguous torch tensors of the session's dtype that
+        already live in HBM (their device pointers are handed over; the session copies them)."""
+        keep, ptrs = [], []
+        for a in (U, II):
+            if a is not None and hasattr(a, "data_ptr"):           # torch tensor (device or host)
+                if not a.is_contiguous() or np.dtype(str(a.dtype).replace("torch.", "")) != np.dtype(self.dtype):
+                    raise ValueError("device side information must be contiguous and of the session's dtype")
+                keep.append(a); ptrs.append(C.c_void_p(a.data_ptr()))
+            else:
+                b = self._c(a)
+                keep.append(b); ptrs.append(_lib.ptr(b))
+        _lib.check(self.lib.cmfrec_hip_session_set_sideinfo_local(self.handle, *ptrs), self.lib, "set_sideinfo_local")
+        if any(hasattr(a, "data_ptr") for a in keep if a is not None):
+            self.sync()                                            # the copies out of the caller's tensors are done
 
     def sideinfo_partial(self, which):
         """First half of the C / D update of a shard: partial sums over the local rows; returns (device pointer, elements) of

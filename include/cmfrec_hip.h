@@ -461,6 +461,9 @@ int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B
 /* Runs the on-device self-test of the cross-lane primitives (DPP / permlane swaps) the row kernels
  * are built on; returns the number of mismatching lanes (0 = ok), negative = HIP failure. */
 int cmfrec_hip_selftest_lanes(void);
+/* timing / agreement probe of the dense contraction C[M, N] = op(A) B (transa: A stored [K, M]) on random operands: ms per call of
+   the library's own MFMA kernel and of rocBLAS, largest difference of the two results relative to the largest entry */
+int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, double *ms_own, double *ms_rocblas, double *max_rel_diff);
 
 /* Start values as the reference's random_parallel draws them (src/helpers.c:927-1043; xoshiro256++
  * seeded by splitmix64, truncated ziggurat normals or uniforms, scaled 2^-7): A <- stream(seed),

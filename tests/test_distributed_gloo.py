@@ -342,3 +342,50 @@ def test_two_rank_collective_model(tmp_path, oracles):
         assert np.array_equal(r0[key], r1[key]), key
     for key, ref in (("A", A), ("B", B), ("C", Cm), ("D", Dm)):
         assert np.abs(r0[key] - ref).max() / np.abs(ref).max() < 1e-10, key
+
+
+def _worker_c5_setup(rank, world, port, out_dir, scale):
+    """The set-up path of `bench.py --workload c5 --gpus N` (BASELINE.json configs[4]) on the CPU: this rank's shard drawn by
+    bench.c5_shard_data, the item side through shard_coo_by_items (all-reduced item counts, nnz-balanced cut, one all-to-all)."""
+    import bench
+    from cmfrec_amd.distributed import shard_coo_by_items
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = bench.c5_shard_data(scale, rank, world, torch.device("cpu"))
+    r0, r1 = d["row_ranges"][rank]
+    cb, crow, ccol, cval = shard_coo_by_items(d["row"] + r0, d["col"], d["val"], d["n"], rank, world)
+    c0, c1 = int(cb[rank]), int(cb[rank + 1])
+    Il = d["item_rows"](c0, c1)
+    np.savez(os.path.join(out_dir, "c5_rank%d.npz" % rank), cb=np.asarray(cb), crow=crow.numpy(), ccol=ccol.numpy(), cval=cval.numpy(),
+             row=(d["row"] + r0).numpy(), col=d["col"].numpy(), val=d["val"].numpy(), U=d["U"].numpy(), Il=Il.numpy(),
+             dims=np.array([d["m"], d["n"], d["nnz"], d["m_blk"]]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_c5_setup(tmp_path):
+    """World 2, gloo: every rank's user block keeps its entries, every entry reaches the rank that owns its item exactly once
+    and in the order of the concatenated COO (source rank, then position), the item blocks are the same on both ranks and
+    nnz-balanced, U rows are local, and the rows of I a rank draws are the rows of its item block."""
+    import bench
+    world, scale = 2, 2e-5                       # 2000 users x 1024 items, 40 k entries
+    mp.spawn(_worker_c5_setup, args=(world, _free_port(), str(tmp_path), scale), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("c5_rank%d.npz" % i)) for i in range(world)]
+    m, n, nnz, m_blk = [int(v) for v in r[0]["dims"]]
+    assert np.array_equal(r[0]["cb"], r[1]["cb"]) and r[0]["cb"][0] == 0 and r[0]["cb"][-1] == n
+    cb = r[0]["cb"]
+    row = np.concatenate([r[i]["row"] for i in range(world)]); col = np.concatenate([r[i]["col"] for i in range(world)])
+    val = np.concatenate([r[i]["val"] for i in range(world)])
+    assert len(row) == nnz and row.min() >= 0 and row.max() < m
+    for i in range(world):
+        assert r[i]["row"].min() >= i * m_blk and r[i]["row"].max() < (i + 1) * m_blk          # the user block is local
+        mine = (col >= cb[i]) & (col < cb[i + 1])
+        # the entries of this rank's items, in the order of the concatenated COO
+        assert np.array_equal(r[i]["crow"], row[mine]) and np.array_equal(r[i]["ccol"], col[mine]) and np.array_equal(r[i]["cval"], val[mine])
+        assert r[i]["U"].shape == (m_blk, bench.C5_P)
+        full_I = bench.c5_shard_data(scale, i, world, torch.device("cpu"))["item_rows"](0, n).numpy()
+        assert np.array_equal(r[i]["Il"], full_I[cb[i]:cb[i + 1]])
+    counts = np.bincount(col, minlength=n)
+    share = counts[cb[0]:cb[1]].sum() / counts.sum()
+    assert 0.35 < share < 0.65                                                                  # nnz-balanced item blocks
+    assert abs(val.mean()) < 0.2 and set(np.unique(val + 2.75)) <= set(0.5 * np.arange(1, 11))
