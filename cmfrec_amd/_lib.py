@@ -36,10 +36,10 @@ class ModelF(C.Structure):
 EXPORTED = [
     "fit_collective_implicit_als", "fit_collective_explicit_als",
     "factors_collective_explicit_multiple", "factors_collective_implicit_multiple", "cmfrec_hip_factors_multiple",
-    "cmfrec_hip_optimizeA_implicit", "cmfrec_hip_optimizeA_explicit",
+    "cmfrec_hip_optimizeA_implicit", "cmfrec_hip_optimizeA_explicit", "cmfrec_hip_optimizeA_explicit_weighted",
     "cmfrec_hip_optimizeA_dense_full", "cmfrec_hip_optimizeA_collective", "cmfrec_hip_optimizeA_collective_sparse", "cmfrec_hip_topN_batch",
     "cmfrec_hip_session_create", "cmfrec_hip_session_destroy", "cmfrec_hip_last_error", "cmfrec_hip_last_error_code",
-    "cmfrec_hip_session_set_X", "cmfrec_hip_session_set_A_parts", "cmfrec_hip_session_nparts", "cmfrec_hip_session_part_range", "cmfrec_hip_session_stream_wait_part", "cmfrec_hip_session_set_X_coo", "cmfrec_hip_session_set_X_coo_device", "cmfrec_hip_session_precompute", "cmfrec_hip_session_init_biases", "cmfrec_hip_session_get_X", "cmfrec_hip_session_set_factors", "cmfrec_hip_session_get_factors",
+    "cmfrec_hip_session_set_X", "cmfrec_hip_session_set_A_parts", "cmfrec_hip_session_nparts", "cmfrec_hip_session_part_range", "cmfrec_hip_session_stream_wait_part", "cmfrec_hip_session_set_X_coo", "cmfrec_hip_session_set_X_coo_weighted", "cmfrec_hip_session_set_X_weighted", "cmfrec_hip_session_set_X_coo_device", "cmfrec_hip_session_precompute", "cmfrec_hip_session_init_biases", "cmfrec_hip_session_get_X", "cmfrec_hip_session_set_factors", "cmfrec_hip_session_get_factors",
     "cmfrec_hip_session_set_sideinfo", "cmfrec_hip_session_set_sideinfo_local", "cmfrec_hip_session_sideinfo_partial", "cmfrec_hip_session_sideinfo_finish", "cmfrec_hip_session_set_nonneg", "cmfrec_hip_session_set_l1", "cmfrec_hip_session_set_lam_unique", "cmfrec_hip_session_set_scale_bias_const", "cmfrec_hip_session_set_implicit_features", "cmfrec_hip_session_get_implicit_features", "cmfrec_hip_session_set_sideinfo_sparse", "cmfrec_hip_session_update", "cmfrec_hip_session_iterate",
     "cmfrec_hip_session_sync", "cmfrec_hip_session_device_ptr", "cmfrec_hip_session_stream",
     "cmfrec_hip_session_after_gather", "cmfrec_hip_session_kernel_time",

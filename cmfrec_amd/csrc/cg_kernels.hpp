@@ -57,6 +57,11 @@ struct CgParams {
     const int *indices;
     const T *values;
     const T *bias_sub;    // explicit: x_j := x_j - bias_sub[idx_j] (fused "X - bias" sweep), or null
+    // explicit model with observation weights (factors_explicit_cg weighted branches, common.c:1126-1135, :1162-1171): one
+    // weight per entry in the order of `values`, and the row's lambda multiplier under scale_lam -- the driver's wsumA /
+    // wsumB (collective.c:7978-8008: the sum of the row's weights, 1 for a row without entries) instead of its length
+    const T *weights = nullptr;
+    const T *wsum = nullptr;
     const int *order;     // row ids to process
     const RowDesc *desc;  // same rows, same order, with length and CSR offset
     int nrows;
@@ -262,23 +267,38 @@ __device__ __forceinline__ void load_tile(RegTile<T, S> &tile, const T *__restri
 
 // One tile contribution:  c_j = B_j . vrep ; w_j = f(c_j, x_j) ; out[s] += sum_t w_j B_j[s]
 // MODE 0: residual pass, MODE 1: A*p pass.
+// g: the entry's observation weight (explicit model; 1 without weights -- an exact multiplication)
 template <typename T, bool IMPLICIT, int MODE>
-__device__ __forceinline__ T pass_weight(T coef, T x, bool valid)
+__device__ __forceinline__ T pass_weight(T coef, T x, bool valid, T g = T(1))
 {
     T w;
     if (IMPLICIT) {
         if (MODE == 0) w = -(coef - T(1)) * x - coef;     // common.c:1939
         else           w = coef * (x - T(1)) + coef;      // common.c:1965
     } else {
-        if (MODE == 0) w = -(coef - x);                   // common.c:1121-1123
-        else           w = coef;                          // common.c:1158-1159
+        if (MODE == 0) w = -((coef - x) * g);             // common.c:1121-1123, :1130-1133
+        else           w = coef * g;                      // common.c:1158-1159, :1166-1169
     }
     return valid ? w : T(0);
 }
 
+// lambda multiplier of a row under scale_lam: its number of entries, or the sum of its weights (common.c:679-723)
+template <typename T>
+__device__ __forceinline__ T row_lam_mult(const CgParams<T> &P, int row, int nnz)
+{
+    return (P.wsum != nullptr) ? P.wsum[row] : (T)nnz;
+}
+// the weight of the entry at CSR position `pos`
+template <typename T, bool IMPLICIT>
+__device__ __forceinline__ T entry_weight(const CgParams<T> &P, size_t pos)
+{
+    if (IMPLICIT) return T(1);
+    return (P.weights != nullptr) ? P.weights[pos] : T(1);
+}
+
 template <int S, bool IMPLICIT, int MODE>
 __device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, const float (&vrep)[S], float x, bool valid,
-                                          PassAcc<float> &out, int lane)
+                                          PassAcc<float> &out, int lane, float g = 1.f)
 {
     float c[8];
 #pragma unroll
@@ -289,7 +309,7 @@ __device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, con
         c[2 * q] = acc[0]; c[2 * q + 1] = acc[1];
     }
     float coef = treduce8_low<float>(c, lane);
-    const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid);
+    const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid, g);
     float wts[8];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
     wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
@@ -303,10 +323,10 @@ __device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, con
 
 template <typename T, int S, bool IMPLICIT, int MODE>
 __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid,
-                                          PassAcc<T> &out, int lane)
+                                          PassAcc<T> &out, int lane, T g = T(1))
 {
     if constexpr (std::is_same<T, float>::value) {
-        tile_pass_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+        tile_pass_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane, g);
     } else {
     T c[8];
 #pragma unroll
@@ -317,7 +337,7 @@ __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&v
         c[t] = acc;
     }
     T coef = treduce8_low<T>(c, lane);           // lane j now holds B_j . v
-    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid);
+    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid, g);
     T wts[8];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
     wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
@@ -435,7 +455,7 @@ cg_rows_kernel(const CgParams<T> P)
     // of this launch -- are gathered once instead of once per pass (config 4: the bin ran at 2.9 TB/s against 4.5-5.2 for
     // the bins that already were resident).  The register budget goes from three to two wavefronts per SIMD.
     constexpr int NRES = (std::is_same<T, float>::value && W == 8) ? 2 : 1;
-    struct Pre { int idx; T x; T a; int idx2; T x2; };
+    struct Pre { int idx; T x; T a; int idx2; T x2; T g; T g2; };
     auto load_desc = [&](int rix_) -> RowDesc {
         RowDesc d; d.row = 0; d.nnz = 0; d.st = 0;
         if (rix_ < P.nrows) d = P.desc[rix_];
@@ -446,12 +466,13 @@ cg_rows_kernel(const CgParams<T> P)
         return d;
     };
     auto load_pre = [&](const RowDesc &d) -> Pre {
-        Pre q; q.idx = 0; q.x = T(0); q.a = T(0); q.idx2 = 0; q.x2 = T(0);
+        Pre q; q.idx = 0; q.x = T(0); q.a = T(0); q.idx2 = 0; q.x2 = T(0); q.g = T(1); q.g2 = T(1);
         const int cnt = min(TILE, d.nnz - wr * TILE);
         if (lane < cnt) {
             const size_t pos = d.st + (size_t)wr * TILE + lane;
             q.idx = P.indices[pos];
             q.x = P.values[pos];
+            q.g = entry_weight<T, IMPLICIT>(P, pos);
             if (!IMPLICIT && P.bias_sub != nullptr) q.x -= P.bias_sub[q.idx];
         }
         if (NRES == 2) {
@@ -460,6 +481,7 @@ cg_rows_kernel(const CgParams<T> P)
                 const size_t pos = d.st + (size_t)(wr + W) * TILE + lane;
                 q.idx2 = P.indices[pos];
                 q.x2 = P.values[pos];
+                q.g2 = entry_weight<T, IMPLICIT>(P, pos);
                 if (!IMPLICIT && P.bias_sub != nullptr) q.x2 -= P.bias_sub[q.idx2];
             }
         }
@@ -482,13 +504,14 @@ cg_rows_kernel(const CgParams<T> P)
         T lam = P.lam, lam_last = P.lam_last;
         if (GRAMX && P.kc > 0) {                              // rows of the block system: collective.c:1285-1355
             if (P.scale_lam || P.scale_lam_sideinfo) {
-                T mult = (T)nnz;
+                T mult = row_lam_mult(P, row, nnz);
                 if (P.scale_lam_sideinfo) mult += (T)P.p_side;
                 lam *= mult; lam_last *= mult;
             }
         } else if (!IMPLICIT && P.scale_lam) {                // common.c:679-723
-            lam *= (T)nnz;
-            if (!P.scale_bias_const) lam_last *= (T)nnz;
+            const T mult = row_lam_mult(P, row, nnz);
+            lam *= mult;
+            if (!P.scale_bias_const) lam_last *= mult;
         }
         T *arow = P.A + (size_t)row * P.lda;
         T a_d = pcur.a;
@@ -497,12 +520,13 @@ cg_rows_kernel(const CgParams<T> P)
         RegTile<T, S> tile;
         const int cnt0 = min(TILE, nnz - wr * TILE);
         T x_res = pcur.x;
+        const T g_res = pcur.g;
         bool valid_res = lane < cnt0;
         if (CMF_DBG(P, 1)) dbg_fill_tile<8, S>(tile, (T)(pcur.idx & 3) * (T)0.001);
         else if (cnt0 > 0) load_tile<T, S>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
         RegTile<T, (NRES == 2) ? S : 1> tile2;       // second resident tile (entries (wr + W) * 64 ...)
         const int cnt1 = (NRES == 2) ? min(TILE, nnz - (wr + W) * TILE) : 0;
-        const T x2_res = pcur.x2;
+        const T x2_res = pcur.x2, g2_res = pcur.g2;
         const bool valid2_res = lane < cnt1;
         if constexpr (NRES == 2) {
             if (cnt1 > 0 && !CMF_DBG(P, 1)) load_tile<T, S>(tile2, P.B, P.ldb, k, pcur.idx2, cnt1, lane);
@@ -522,11 +546,11 @@ cg_rows_kernel(const CgParams<T> P)
             if constexpr (NRES == 2) {
                 // both tiles of the wave are resident: the launch holds rows of at most 2 * W * 64 = 1024 entries (the host
                 // keeps the split-row boundary at or below that in single precision)
-                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x_res, valid_res, acc, lane);
-                if (cnt1 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile2, vrep, x2_res, valid2_res, acc, lane);
+                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x_res, valid_res, acc, lane, g_res);
+                if (cnt1 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile2, vrep, x2_res, valid2_res, acc, lane, g2_res);
             } else
             for (int tl = wr; tl < ntiles; tl += W) {
-                T x; bool valid;
+                T x, g; bool valid;
                 const bool have = (tl == wr) && (resident || first);   // still in registers
                 if (!have) {
                     const int cnt = min(TILE, nnz - tl * TILE);
@@ -534,12 +558,13 @@ cg_rows_kernel(const CgParams<T> P)
                     const size_t pos = st + (size_t)tl * TILE + lane;
                     int my_idx = valid ? P.indices[pos] : 0;
                     x = valid ? P.values[pos] : T(0);
+                    g = valid ? entry_weight<T, IMPLICIT>(P, pos) : T(1);
                     if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
                     if (!CMF_DBG(P, 1)) load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
                 } else {
-                    x = x_res; valid = valid_res;
+                    x = x_res; g = g_res; valid = valid_res;
                 }
-                if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
+                if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane, g);
             }
             if (GRAM && !CMF_DBG(P, 2))
                 gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, acc, lane, wr);   // common.c:1932 / :1958; collective.c:2609-2643
@@ -655,7 +680,7 @@ __device__ __forceinline__ T treduce4_low(const T (&v)[4], int lane)
 
 template <int S, bool IMPLICIT, int MODE>
 __device__ __forceinline__ void tile_pass4_f32(const RegTile4<float, S> &tile, const float (&vrep)[S], float x, bool valid,
-                                           PassAcc<float> &out, int lane)
+                                           PassAcc<float> &out, int lane, float g = 1.f)
 {
     float c[4];
 #pragma unroll
@@ -666,7 +691,7 @@ __device__ __forceinline__ void tile_pass4_f32(const RegTile4<float, S> &tile, c
         c[2 * q] = acc[0]; c[2 * q + 1] = acc[1];
     }
     float coef = treduce4_low<float>(c, lane);
-    const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid);
+    const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid, g);
     float wts[4];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<2>(w); wts[2] = lanes::bcast8<4>(w); wts[3] = lanes::bcast8<6>(w);
 #pragma unroll
@@ -679,10 +704,10 @@ __device__ __forceinline__ void tile_pass4_f32(const RegTile4<float, S> &tile, c
 
 template <typename T, int S, bool IMPLICIT, int MODE>
 __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (&vrep)[S], T x, bool valid,
-                                           PassAcc<T> &out, int lane)
+                                           PassAcc<T> &out, int lane, T g = T(1))
 {
     if constexpr (std::is_same<T, float>::value) {
-        tile_pass4_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane);
+        tile_pass4_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane, g);
     } else {
     T c[4];
 #pragma unroll
@@ -693,7 +718,7 @@ __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (
         c[t] = acc;
     }
     T coef = treduce4_low<T>(c, lane);
-    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid);
+    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid, g);
     T wts[4];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<2>(w); wts[2] = lanes::bcast8<4>(w); wts[3] = lanes::bcast8<6>(w);
 #pragma unroll
@@ -723,7 +748,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         __syncthreads();
     }
     const int nwaves = gridDim.x * 4;
-    struct Pre { int idx; T x; T a; };
+    struct Pre { int idx; T x; T a; T g; };
     auto load_desc = [&](int rix_) -> RowDesc {
         RowDesc d; d.row = 0; d.nnz = 0; d.st = 0;
         if (rix_ < P.nrows) d = P.desc[rix_];
@@ -734,11 +759,12 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         return d;
     };
     auto load_pre = [&](const RowDesc &d) -> Pre {
-        Pre q; q.idx = 0; q.x = T(0); q.a = T(0);
+        Pre q; q.idx = 0; q.x = T(0); q.a = T(0); q.g = T(1);
         if ((lane >> 1) < d.nnz) {
             const size_t pos = d.st + (size_t)(lane >> 1);
             q.idx = P.indices[pos];
             q.x = P.values[pos];
+            q.g = entry_weight<T, IMPLICIT>(P, pos);
             if (!IMPLICIT && P.bias_sub != nullptr) q.x -= P.bias_sub[q.idx];
         }
         if (d.nnz > 0 && lane < k) q.a = P.A[(size_t)d.row * P.lda + lane];
@@ -750,13 +776,14 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         T lam = P.lam, lam_last = P.lam_last;
         if (GRAMX && P.kc > 0) {
             if (P.scale_lam || P.scale_lam_sideinfo) {
-                T mult = (T)nnz;
+                T mult = row_lam_mult(P, d.row, nnz);
                 if (P.scale_lam_sideinfo) mult += (T)P.p_side;
                 lam *= mult; lam_last *= mult;
             }
         } else if (!IMPLICIT && P.scale_lam) {
-            lam *= (T)nnz;
-            if (!P.scale_bias_const) lam_last *= (T)nnz;
+            const T mult = row_lam_mult(P, d.row, nnz);
+            lam *= mult;
+            if (!P.scale_bias_const) lam_last *= mult;
         }
         const bool valid = (lane >> 1) < nnz;
         T a_d = pr.a;
@@ -767,7 +794,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
-            if (!CMF_DBG(P, 4)) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane);
+            if (!CMF_DBG(P, 4)) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
             if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
             acc.close(out);
@@ -896,9 +923,9 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
     const int npairs = (P.nrows + 1) / 2;
     // elements of this lane: e0 = q, e1 = q + 32
     const bool live0 = q < k, live1 = q + 32 < k;
-    struct Pre { int row, nnz; int idx; T x; T a0, a1; };
+    struct Pre { int row, nnz; int idx; T x; T a0, a1; T g; };
     auto load_pre = [&](int pair) -> Pre {
-        Pre r; r.row = 0; r.nnz = 0; r.idx = 0; r.x = T(0); r.a0 = T(0); r.a1 = T(0);
+        Pre r; r.row = 0; r.nnz = 0; r.idx = 0; r.x = T(0); r.a0 = T(0); r.a1 = T(0); r.g = T(1);
         const int pos = 2 * pair + h;
         if (pair < npairs && pos < P.nrows) {
             const RowDesc d = P.desc[pos];
@@ -907,6 +934,7 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
             if (e < d.nnz) {
                 r.idx = P.indices[d.st + e];
                 r.x = P.values[d.st + e];
+                r.g = entry_weight<T, IMPLICIT>(P, d.st + e);
                 if (!IMPLICIT && P.bias_sub != nullptr) r.x -= P.bias_sub[r.idx];
             }
             if (d.nnz > 0) {
@@ -942,8 +970,9 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
         const bool valid = (q >> 1) < nnz;
         T lam = P.lam, lam_last = P.lam_last;
         if (!IMPLICIT && P.scale_lam) {                        // common.c:679-723
-            lam *= (T)nnz;
-            if (!P.scale_bias_const) lam_last *= (T)nnz;
+            const T mult = (P.wsum != nullptr && nnz > 0) ? P.wsum[cur.row] : (T)nnz;
+            lam *= mult;
+            if (!P.scale_bias_const) lam_last *= mult;
         }
         // diagonal term of the operator for this lane's two elements
         const T d0 = (!IMPLICIT && q == k - 1) ? lam_last : lam, d1 = (!IMPLICIT && q + 32 == k - 1) ? lam_last : lam;
@@ -956,7 +985,7 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
             for (int s = 0; s < S; s++) vrep[s] = __shfl((s >> 2) ? v1 : v0, (lane & 32) | (ll + 8 * (s & 3)));
             PassAcc<T> acc;
             acc.zero();
-            tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, cur.x, valid, acc, lane);
+            tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, cur.x, valid, acc, lane, cur.g);
             if (IMPLICIT) {                                     // + (+-) BtB v: rows 8 jq + t (weights in register 0), 32 + 8 jq + t (register 1)
 #pragma unroll
                 for (int a = 0; a < 2; a++) {
@@ -1095,13 +1124,14 @@ vh_pass_kernel(const CgParams<T> P, const VhState<T> V)
         const size_t pos = st + (size_t)tl * TILE + lane;
         int my_idx = valid ? P.indices[pos] : 0;
         T x = valid ? P.values[pos] : T(0);
+        const T g = valid ? entry_weight<T, IMPLICIT>(P, pos) : T(1);
         if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
         RegTile<T, S> tile;
         if (CMF_DBG(P, 1)) dbg_fill_tile<8, S>(tile, (T)(my_idx & 3) * (T)0.001);
         else load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
         T vrep[S];
         replicate<T, S>(vdist, vrep, lane);
-        if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane);
+        if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane, g);
     }
     T out[8];
     acc.close(out);
@@ -1153,13 +1183,14 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
     T lam = P.lam, lam_last = P.lam_last;
     if (GRAMX && P.kc > 0) {
         if (P.scale_lam || P.scale_lam_sideinfo) {
-            T mult = (T)nnz;
+            T mult = row_lam_mult(P, row, nnz);
             if (P.scale_lam_sideinfo) mult += (T)P.p_side;
             lam *= mult; lam_last *= mult;
         }
     } else if (!IMPLICIT && P.scale_lam) {
-        lam *= (T)nnz;
-        if (!P.scale_bias_const) lam_last *= (T)nnz;
+        const T mult = row_lam_mult(P, row, nnz);
+        lam *= mult;
+        if (!P.scale_bias_const) lam_last *= mult;
     }
     T *arow = P.A + (size_t)row * P.lda;
     T a_d = (lane < k) ? arow[lane] : T(0);
@@ -1247,13 +1278,14 @@ cg_rows_generic_kernel(const CgParams<T> P)
         if (!IMPLICIT) {
             if (has_u) {
                 if (P.scale_lam || P.scale_lam_sideinfo) {    // collective.c:1285-1355
-                    T mult = (nnz > 0) ? (T)nnz : T(1);
+                    T mult = (P.wsum != nullptr) ? P.wsum[row] : ((nnz > 0) ? (T)nnz : T(1));
                     if (P.scale_lam_sideinfo) mult += sparse_u ? (T)nnz2 : (T)P.p_side;
                     lam *= mult; lam_last *= mult;
                 }
             } else if (P.scale_lam) {                         // common.c:679-723
-                lam *= (T)nnz;
-                if (!P.scale_bias_const) lam_last *= (T)nnz;
+                const T mult = row_lam_mult(P, row, nnz);
+                lam *= mult;
+                if (!P.scale_bias_const) lam_last *= mult;
             }
         }
         T *arow = P.A + (size_t)row * P.lda;
@@ -1328,13 +1360,14 @@ cg_rows_generic_kernel(const CgParams<T> P)
             // gat keeps the entry order (so the sums are the ones of the one-at-a-time loop)
             constexpr int UNR = 4;
             for (int j0 = (TEAM == 1 ? 0 : wv); j0 < nnz; j0 += TEAM * UNR) {
-                int idx[UNR]; T x[UNR]; T bv[UNR][NF]; T part[UNR];
+                int idx[UNR]; T x[UNR]; T gw[UNR]; T bv[UNR][NF]; T part[UNR];
 #pragma unroll
                 for (int u = 0; u < UNR; u++) {
                     const int j = j0 + u * TEAM;
                     const bool ok = j < nnz;
                     idx[u] = ok ? P.indices[st + j] : 0;
                     x[u] = ok ? P.values[st + j] : T(0);
+                    gw[u] = ok ? entry_weight<T, IMPLICIT>(P, st + j) : T(1);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; u++) {
@@ -1353,7 +1386,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     const T coef = part[u];
                     T w;
                     if (IMPLICIT) w = (mode == 0) ? (-(coef - T(1)) * x[u] - coef) : (coef * (x[u] - T(1)) + coef);
-                    else          w = (mode == 0) ? -(coef - x[u]) : coef;
+                    else          w = (mode == 0) ? -((coef - x[u]) * gw[u]) : coef * gw[u];   // common.c:1121-1133, :1158-1169
 #pragma unroll
                     for (int c = 0; c < NF; c++) gat[c] += w * bv[u][c];
                     if (!IMPLICIT && mode == 0 && P.Bi != nullptr) {              // + w_i Bi_j (tgemv_dense_sp on ones, collective.c:2638-2643)
@@ -1416,12 +1449,13 @@ cg_rows_generic_kernel(const CgParams<T> P)
             for (int j = (TEAM == 1 ? 0 : wv); j < nnz; j += TEAM) {
                 const int idx = P.indices[st + j];
                 T x = P.values[st + j];
+                const T gwt = entry_weight<T, IMPLICIT>(P, st + j);
                 const T *b = P.B + (size_t)idx * P.ldb;
 #pragma unroll
                 for (int c = 0; c < NF; c++) {
                     int f = lane + 64 * c;
                     T bv = (f >= koff && f < kt) ? b[f - koff] : T(0);
-                    PC[c] += IMPLICIT ? x * (bv * bv) : bv * bv;                 // :2009-2014 / :1238-1243
+                    PC[c] += IMPLICIT ? x * (bv * bv) : gwt * (bv * bv);         // :2009-2014 / :1238-1254
                 }
             }
             for (int j = (TEAM == 1 ? 0 : wv); j < nnz2; j += TEAM) {            // C_j^2, unweighted (collective.c:2292-2298, :2993-2999)

@@ -51,6 +51,11 @@ struct CholParams {
     int koff;                  // offset of the X-block inside the unknowns (k_user), 0 otherwise
     const size_t *indptr; const int *indices; const T *values;
     const T *bias_sub;         // x_j := x_j - bias_sub[idx_j], or null
+    // explicit model with observation weights (common.c:985-1012: tgemv_dense_sp_weighted, syr with weight[ix]): one weight
+    // per entry of X in the order of `values`, and the row's lambda multiplier under scale_lam (the driver's wsumA / wsumB,
+    // collective.c:7978-8008).  Workgroup-per-row kernel only (launch_chol keeps weighted calls off the wave kernel).
+    const T *weights = nullptr;
+    const T *wsum = nullptr;
     const int *order; int nrows;
     const T *Minit;            // implicit: BtB + lam*I [kt,kt];  collective (both): w*CtC [kc,kc];  explicit: null
     const T *Mfull;            // collective implicit: [kt,kt] matrix every solved row starts from;  else null
@@ -364,12 +369,13 @@ chol_rows_kernel(const CholParams<T> P)
         T l1 = P.l1, l1_last = P.l1_last;
         if (P.mode == CHOL_EXPLICIT) {
             if (P.scale_lam) {                                           // common.c:679-723
-                lam *= (T)nnz1; l1 *= (T)nnz1;
-                if (!P.scale_bias_const) { lam_last *= (T)nnz1; l1_last *= (T)nnz1; }
+                const T mult = (P.wsum != nullptr) ? P.wsum[row] : (T)nnz1;
+                lam *= mult; l1 *= mult;
+                if (!P.scale_bias_const) { lam_last *= mult; l1_last *= mult; }
             }
         } else if (P.mode == CHOL_COLLECTIVE) {
             if (P.scale_lam || P.scale_lam_sideinfo) {                   // collective.c:1285-1355
-                T mult = (nnz1 > 0) ? (T)nnz1 : T(1);
+                T mult = (P.wsum != nullptr) ? P.wsum[row] : ((nnz1 > 0) ? (T)nnz1 : T(1));
                 if (P.scale_lam_sideinfo && has_u) mult += (two_src && !P.w2_syr_zero) ? (T)nnz2 : (T)P.p_side;   // :1338-1346
                 lam *= mult;
                 // rows without side information are plain factors_closed_form rows when new rows are fitted
@@ -389,7 +395,7 @@ chol_rows_kernel(const CholParams<T> P)
         // loads are unconditional on clamped addresses, padding is selected to zero afterwards
         T pre[RPW][NCJ];
         int idn[RPW];
-        int widx = 0; T wx = T(0);
+        int widx = 0; T wx = T(0), wg = T(1);
         T pre_wsyr = T(0), pre_wrhs = T(0);
         int nr_rows = 0, nr_idx = 0;
         unsigned src_idx = 0, src_rows = 0;       // bit i: staged row i of this wave comes from the second source
@@ -409,6 +415,7 @@ chol_rows_kernel(const CholParams<T> P)
             wsrc2 = e >= nnz1;
             widx = wsrc2 ? 0 : P.indices[st + e];
             wx = wsrc2 ? P.values2[st2 + (e - nnz1)] : xvals[st + e];
+            wg = (!wsrc2 && P.weights != nullptr) ? P.weights[st + e] : T(1);
         };
         auto load_rows = [&]() {
             nr_rows = nr_idx;
@@ -422,8 +429,8 @@ chol_rows_kernel(const CholParams<T> P)
             }
             T x = wx;
             if (P.bias_sub != nullptr && !wsrc2) x -= P.bias_sub[widx];
-            pre_wsyr = impl_w ? x : T(1);           // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
-            pre_wrhs = impl_w ? x + T(1) : x;       // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
+            pre_wsyr = impl_w ? x : wg;             // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
+            pre_wrhs = impl_w ? x + T(1) : x * wg;  // common.c:2082-2085, collective.c:2097-2101 vs common.c:985-996
             if (naz) pre_wsyr = T(0);               // the matrix is shared (common.c:3130-3140)
             if (wsrc2) { pre_wsyr = P.w2_syr_zero ? T(0) : P.w2; pre_wrhs = P.w2 * wx; }   // collective.c:1636-1653, :1719-1731
         };

@@ -29,9 +29,11 @@ __global__ void coo_iota_kernel(unsigned *__restrict__ out, size_t n)
         out[e] = (unsigned)e;
 }
 
+// wt / w_out: the observation weights travel with the values (null: none)
 __global__ void coo_gather_kernel(const unsigned *__restrict__ perm, const int *__restrict__ other,
                                   const real_t *__restrict__ val, real_t subtract, real_t alpha,
-                                  int *__restrict__ i_out, real_t *__restrict__ v_out, size_t nnz)
+                                  int *__restrict__ i_out, real_t *__restrict__ v_out, size_t nnz,
+                                  const real_t *__restrict__ wt = nullptr, real_t *__restrict__ w_out = nullptr)
 {
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < nnz; e += (size_t)gridDim.x * blockDim.x) {
         const unsigned src = perm[e];
@@ -40,7 +42,74 @@ __global__ void coo_gather_kernel(const unsigned *__restrict__ perm, const int *
         if (subtract != real_t(0)) x -= subtract;          // centring, common.c:3603-3613
         if (alpha != real_t(1)) x *= alpha;                // collective.c:9606-9611
         v_out[e] = x;
+        if (wt != nullptr) w_out[e] = wt[src];
     }
+}
+
+// lambda multiplier of every row under scale_lam with observation weights: the sum of its weights in double, entry by entry
+// in CSR order; 1 for a row without entries (wsumA / wsumB, collective.c:7978-8008)
+__global__ void row_weight_sum_kernel(const size_t *__restrict__ p, const real_t *__restrict__ w, int nrows, real_t *__restrict__ wsum)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    double acc = 0;
+    for (size_t e = p[r]; e < p[r + 1]; e++) acc += (double)w[e];
+    wsum[r] = (p[r + 1] > p[r]) ? (real_t)acc : (real_t)1;
+}
+
+// The same sweep with observation weights (initialize_biases_onesided / _twosided, weighted branches without NA_as_zero:
+// common.c:4180-4205, :4672-4692, :4826-4847): a weighted running mean in double, then the shrinkage
+// wsum / (wsum + lam * mult), mult = the driver's wsumA / wsumB under scale_lam (SparseShard::wsum), else 1.  Rows beyond
+// LONG_ROW entries: weighted sums over the lanes of a wavefront (the same quantity up to rounding, as in the unweighted sweep).
+__device__ __forceinline__ double bias_scale_weighted(double wsum_run, bool nonempty, real_t lam_b, const real_t *wsum_drv, int r, int onesided)
+{
+#pragma clang fp contract(off)
+    const double mult = (wsum_drv != nullptr) ? (double)wsum_drv[r] : 1.;
+    if (onesided) {                       // common.c:4196-4203
+        const double ws = nonempty ? wsum_run : 0.;
+        return ws / (ws + (double)lam_b * mult);
+    }
+    return nonempty ? wsum_run / (wsum_run + (double)lam_b * mult) : 1.;
+}
+
+__global__ void bias_sweep_weighted_kernel(const size_t *__restrict__ p, const int *__restrict__ idx, const real_t *__restrict__ v,
+                                           const real_t *__restrict__ w, const real_t *__restrict__ other, const int *__restrict__ order,
+                                           int first_q, int rows, real_t lam_b, const real_t *__restrict__ wsum_drv, int onesided,
+                                           real_t *__restrict__ bias)
+{
+#pragma clang fp contract(off)
+    const int q = first_q + blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= rows) return;
+    const int r = order[q];
+    const size_t st = p[r], en = p[r + 1];
+    double bm = 0, ws = 2.220446049250313e-16;      // DBL_EPSILON
+    if (other != nullptr) {
+        for (size_t e = st; e < en; e++) { ws += (double)w[e]; bm += ((double)w[e] * ((double)(v[e] - other[idx[e]]) - bm)) / ws; }
+    } else {
+        for (size_t e = st; e < en; e++) { ws += (double)w[e]; bm += ((((double)v[e]) - bm) * (double)w[e]) / ws; }
+    }
+    bm *= bias_scale_weighted(ws, en > st, lam_b, wsum_drv, r, onesided);
+    bias[r] = (real_t)bm;
+}
+
+__global__ void __launch_bounds__(64)
+bias_sweep_weighted_long_kernel(const size_t *__restrict__ p, const int *__restrict__ idx, const real_t *__restrict__ v,
+                                const real_t *__restrict__ w, const real_t *__restrict__ other, const int *__restrict__ order, int n_long,
+                                real_t lam_b, const real_t *__restrict__ wsum_drv, int onesided, real_t *__restrict__ bias)
+{
+#pragma clang fp contract(off)
+    const int q = blockIdx.x;
+    if (q >= n_long) return;
+    const int r = order[q];
+    const size_t st = p[r], en = p[r + 1];
+    double sum = 0, ws = 0;
+    if (other != nullptr) {
+        for (size_t e = st + threadIdx.x; e < en; e += 64) { sum += (double)w[e] * (double)(v[e] - other[idx[e]]); ws += (double)w[e]; }
+    } else {
+        for (size_t e = st + threadIdx.x; e < en; e += 64) { sum += (double)w[e] * (double)v[e]; ws += (double)w[e]; }
+    }
+    sum = lanes::wave_sum(sum); ws = lanes::wave_sum(ws) + 2.220446049250313e-16;
+    if (threadIdx.x == 0) bias[r] = (real_t)((sum / ws) * bias_scale_weighted(ws, en > st, lam_b, wsum_drv, r, onesided));
 }
 
 // One sweep of the bias start values over the rows of one orientation (initialize_biases_twosided /
@@ -120,7 +189,7 @@ struct u32_to_size {
 inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st);
 
 inline void shard_from_coo(SparseShard &S, int nrows, int n_other, const int *d_key, const int *d_other, const real_t *d_val,
-                           size_t nnz, real_t subtract, real_t alpha, hipStream_t st)
+                           size_t nnz, real_t subtract, real_t alpha, hipStream_t st, const real_t *d_wt = nullptr)
 {
     S.nrows = nrows; S.nnz = nnz; S.n_other = n_other;
     const int grid_e = (int)std::min<size_t>(4096, (nnz + 255) / 256 + 1), grid_r = std::min(2048, (nrows + 255) / 256 + 1);
@@ -137,6 +206,8 @@ inline void shard_from_coo(SparseShard &S, int nrows, int n_other, const int *d_
         HIP_CHECK(rocprim::exclusive_scan(tmp.ptr, bytes, in, S.p.ptr, (size_t)0, (size_t)nrows + 1, rocprim::plus<size_t>(), st));
     }
     S.i.alloc(nnz); S.v.alloc(nnz);
+    S.w.release(); S.wsum.release();
+    if (d_wt != nullptr && nnz) { S.w.alloc(nnz); S.wsum.alloc((size_t)nrows); }
     if (nnz) {
         DevBuf<int> keys_out; DevBuf<unsigned> pos, perm;
         keys_out.alloc(nnz); pos.alloc(nnz); perm.alloc(nnz);
@@ -147,7 +218,10 @@ inline void shard_from_coo(SparseShard &S, int nrows, int n_other, const int *d_
         HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, d_key, keys_out.ptr, pos.ptr, perm.ptr, nnz, 0u, bits, st));
         DevBuf<unsigned char> tmp2; tmp2.alloc(bytes + 16);
         HIP_CHECK(rocprim::radix_sort_pairs(tmp2.ptr, bytes, d_key, keys_out.ptr, pos.ptr, perm.ptr, nnz, 0u, bits, st));
-        hipLaunchKernelGGL(coo_gather_kernel, dim3(grid_e), dim3(256), 0, st, perm.ptr, d_other, d_val, subtract, alpha, S.i.ptr, S.v.ptr, nnz);
+        hipLaunchKernelGGL(coo_gather_kernel, dim3(grid_e), dim3(256), 0, st, perm.ptr, d_other, d_val, subtract, alpha, S.i.ptr, S.v.ptr, nnz,
+                           d_wt, S.w.ptr);
+        if (S.w.ptr != nullptr)       // (before finalize_vheavy re-orders the split rows: the driver sums in CSR order)
+            hipLaunchKernelGGL(row_weight_sum_kernel, dim3(grid_r), dim3(256), 0, st, S.p.ptr, S.w.ptr, nrows, S.wsum.ptr);
         HIP_CHECK(hipStreamSynchronize(st));       // temporaries are released here
     }
     // processing order: rows by length, descending, ties by row id (stable)
@@ -227,6 +301,14 @@ inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st)
         DevBuf<unsigned char> tmp; tmp.alloc(bytes + 16);
         HIP_CHECK(rocprim::segmented_radix_sort_pairs(tmp.ptr, bytes, ki.ptr, S.i.ptr, kv.ptr, S.v.ptr, S.nnz, (unsigned)nvh,
                                                       db.ptr, de.ptr, 0u, bits, st));
+        if (S.w.ptr != nullptr) {
+            // the weights take the same (stable) permutation: the same sort once more, on the saved keys
+            DevBuf<int> ki2; ki2.alloc(S.nnz);
+            HIP_CHECK(hipMemcpyAsync(kv.ptr, S.w.ptr, S.nnz * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+            HIP_CHECK(rocprim::segmented_radix_sort_pairs(tmp.ptr, bytes, ki.ptr, ki2.ptr, kv.ptr, S.w.ptr, S.nnz, (unsigned)nvh,
+                                                          db.ptr, de.ptr, 0u, bits, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         HIP_CHECK(hipStreamSynchronize(st));
     }
     // 2. where the index ranges start inside each row
@@ -269,10 +351,10 @@ inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st)
 
 // host CSR -> shard (SparseShard::upload) + the very-heavy-row schedule
 inline void shard_from_csr(SparseShard &S, int nrows, const size_t *hp, const int *hi, const real_t *hv, int n_other,
-                           hipStream_t st)
+                           hipStream_t st, const real_t *hw = nullptr)
 {
     S.n_other = n_other;
-    S.upload(nrows, hp, hi, hv, st);
+    S.upload(nrows, hp, hi, hv, st, hw);
     finalize_vheavy(S, n_other, st);
 }
 

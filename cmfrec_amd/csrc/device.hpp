@@ -130,6 +130,11 @@ struct SparseShard {
     DevBuf<size_t> p;
     DevBuf<int> i;
     DevBuf<real_t> v;
+    // observation weights of the explicit model (empty: none): one per entry in the order of `v`, and per row the multiplier
+    // of lambda under scale_lam -- the sum of the row's weights, 1 for a row without entries (wsumA / wsumB of the driver,
+    // collective.c:7978-8008; summed in double, entry by entry, as there)
+    DevBuf<real_t> w, wsum;
+    bool weighted() const { return w.ptr != nullptr && nnz > 0; }
     DevBuf<int> order;       // row ids sorted by nnz descending: [bin 0 | bin 1 | ... | bin 4 | empty rows]
     DevBuf<RowDesc> desc;    // same order: {row, nnz, CSR offset}
     int bin_rows[NBINS] = {0, 0, 0, 0, 0, 0};
@@ -186,7 +191,7 @@ struct SparseShard {
     DevBuf<real_t> gram_part;
     mutable DevBuf<real_t> chol_part;    // partial normal matrices of the slices (wave-per-row Cholesky kernel), sized on first use
 
-    void upload(int nrows_, const size_t *hp, const int *hi, const real_t *hv, hipStream_t st)
+    void upload(int nrows_, const size_t *hp, const int *hi, const real_t *hv, hipStream_t st, const real_t *hw = nullptr)
     {
         nrows = nrows_;
         nnz = hp[nrows] - hp[0];
@@ -195,6 +200,18 @@ struct SparseShard {
         p.upload(p0.data(), nrows + 1, st);
         i.upload(hi + hp[0], nnz, st);
         v.upload(hv + hp[0], nnz, st);
+        w.release(); wsum.release();
+        if (hw != nullptr && nnz > 0) {
+            w.upload(hw + hp[0], nnz, st);
+            std::vector<real_t> ws((size_t)nrows);
+            for (int r = 0; r < nrows; r++) {
+                double acc_w = 0;
+                for (size_t e = hp[r]; e < hp[r + 1]; e++) acc_w += hw[e];
+                ws[r] = (hp[r + 1] > hp[r]) ? (real_t)acc_w : (real_t)1;
+            }
+            wsum.upload(ws.data(), (size_t)nrows, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         std::vector<int> ord(nrows);
         std::iota(ord.begin(), ord.end(), 0);
         auto len = [&](int r) { return (long long)(p0[r + 1] - p0[r]); };
@@ -690,7 +707,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
-    if (cg2_enabled()) {
+    if (cg2_enabled() && P.weights == nullptr) {
         // second generation: NT = 4 tiles for the rows above 16 entries (or the whole bin), the two-rows-per-wavefront kernel below
         // for the rest; one event pair around both launches
         const int c1 = cg2_tiny_all() ? count : count1;
@@ -916,7 +933,7 @@ template <int S, bool IMPLICIT, bool GRAMX>
 inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm, int bin, hipStream_t st)
 {
     const int first = X.bin_first[bin], count = X.bin_rows[bin];
-    const bool v2 = cg2_enabled();
+    const bool v2 = cg2_enabled() && P.weights == nullptr;     // (the second generation has no observation weights)
     switch (bin) {
         case BIN_HEAVY:
             // (single precision: the first-generation 8-wave kernel keeps two resident tiles per wave, the second generation one)
@@ -1068,6 +1085,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.k = c.k;
     P.indptr = X.p.ptr; P.indices = X.i.ptr; P.values = X.v.ptr;
     P.bias_sub = c.bias_sub; P.order = X.order.ptr; P.desc = X.desc.ptr; P.nrows = 0; P.BtB = c.BtB;
+    if (!c.implicit && X.weighted()) { P.weights = X.w.ptr; P.wsum = X.wsum.ptr; }
     P.lam = c.lam; P.lam_last = c.lam_last;
     P.scale_lam = c.scale_lam; P.scale_bias_const = c.scale_bias_const;
     P.max_cg_steps = c.max_cg_steps;

@@ -354,7 +354,6 @@ int_t fit_collective_implicit_als(
         if (U_row[e] < 0 || U_row[e] >= m_u || U_col[e] < 0 || U_col[e] >= p) return fail(verbose, "cmfrec_hip: U index out of range.");
     for (size_t e = 0; spI && e < nnz_I; e++)
         if (I_row[e] < 0 || I_row[e] >= n_i || I_col[e] < 0 || I_col[e] >= q) return fail(verbose, "cmfrec_hip: I index out of range.");
-    if (adjust_weight) return fail(verbose, "cmfrec_hip: adjust_weight is not implemented.");
     if ((l1_lam != 0 || l1_lam_unique) && (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n)))
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
     if (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique) use_cg = false;    // collective.c:9568-9571 (any of them, unlike the explicit model)
@@ -368,7 +367,12 @@ int_t fit_collective_implicit_als(
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
     for (size_t e = 0; e < nnz; e++)
         if (ixA[e] < 0 || ixA[e] >= m || ixB[e] < 0 || ixB[e] >= n) return fail(verbose, "cmfrec_hip: X index out of range.");
-    if (w_main_multiplier) *w_main_multiplier = 1;
+    real_t w_mult = 1;
+    if (adjust_weight) {                                                  // collective.c:9776-9783
+        w_mult = (real_t)((long double)nnz / (long double)((size_t)m * (size_t)n));
+        w_main *= w_mult;
+    }
+    if (w_main_multiplier) *w_main_multiplier = w_mult;
     // per-matrix penalties: entries 2..5 = A, B, C, D (the bias slots are unused by this model, collective.c:9793-9809)
     real_t lam6[6], l16[6];
     for (int e = 0; e < 6; e++) { lam6[e] = lam_unique ? lam_unique[e] : lam; l16[e] = l1_lam_unique ? l1_lam_unique[e] : l1_lam; }
@@ -513,8 +517,8 @@ int_t fit_collective_explicit_als(
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (Xfull || weight || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I)
-        return fail(verbose, "cmfrec_hip: dense X / weights / NA_as_zero are not implemented.");
+    if (Xfull || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I)
+        return fail(verbose, "cmfrec_hip: dense X / NA_as_zero are not implemented.");
     // dense side information with NaN -> the sparse route on its centred present entries
     DenseNanSide nanU, nanI;
     const bool hadU = (U != nullptr);
@@ -569,6 +573,13 @@ int_t fit_collective_explicit_als(
         return fail(verbose, "cmfrec_hip: NaN in dense side information: only the Cholesky solver with unscaled lambda is implemented.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
+    // observation weights (one per entry of X): every row solver and the start values of the biases take them; the lambda
+    // multipliers of scale_lam become sums of weights (collective.c:7931-8008).  Not together with the options whose weight
+    // bookkeeping is not restated: implicit features, sparse / NaN side information, scale_lam_sideinfo, scale_bias_const.
+    if (weight && (add_implicit_features || spU || spI || nan_side || scale_lam_sideinfo ||
+                   (scale_bias_const && scale_lam && (user_bias || item_bias))))
+        return fail(verbose, "cmfrec_hip: observation weights together with implicit features / sparse or NaN side information / "
+                             "scale_lam_sideinfo / scale_bias_const are not implemented.");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
     if (II == nullptr && !spI) { n_i = 0; q = 0; }
     if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
@@ -616,7 +627,15 @@ int_t fit_collective_explicit_als(
     //      subtraction itself happens on the device while the CSR / CSC are built ----
     PhaseTimer tm;
     real_t gm = 0;
-    if (center) {
+    if (center && weight) {
+        // weighted running mean, common.c:3574-3584.  (With 8 threads or more the reference divides the UNWEIGHTED sum of X by
+        // the sum of the weights, :3561-3571 -- not a mean; that branch is not followed.)
+        double xsum = 0, wsum = 2.220446049250313e-16;
+        for (size_t e = 0; e < nnz; e++) { wsum += (double)weight[e]; xsum += (((double)X[e] - xsum) * (double)weight[e]) / wsum; }
+        gm = (real_t)xsum;
+        if (nonneg) gm = std::max(gm, (real_t)0);                         // :3604-3605
+        if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
+    } else if (center) {
         double xsum = 0;
         if (nthreads >= 8) {
             for (size_t e = 0; e < nnz; e++) xsum += X[e];
@@ -626,6 +645,7 @@ int_t fit_collective_explicit_als(
             for (size_t e = 0; e < nnz; e++) xsum += (X[e] - xsum) / (double)(++cnt);
             gm = (real_t)xsum;
         }
+        if (nonneg) gm = std::max(gm, (real_t)0);                         // common.c:3604-3605
         if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
     }
     *glob_mean = gm;
@@ -673,7 +693,7 @@ int_t fit_collective_explicit_als(
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("start values + session");
     // X - mean, COO -> CSR + CSC and the bias start values are computed on the device (coo_device.hpp)
-    int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, X, nnz, gm, (real_t)1);
+    int rc = cmfrec_hip_session_set_X_coo_weighted(s, ixA, ixB, X, weight, nnz, gm, (real_t)1);
     tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);

@@ -99,14 +99,15 @@ gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
         T racc = T(0);                                        // v[lane], this wave's rows only
         T pre[RPW];
         int idn[RPW];
-        int idx_l = 0; T x_l = T(0), xw_l = T(0);
+        int idx_l = 0; T x_l = T(0), xw_l = T(0), g_l = T(1);   // g_l: observation weight of the entry (explicit model)
+        T gw_l = T(1);
         int nr_rows = 0, nr_idx = 0;
         auto load_idx = [&](int c0) {
             nr_idx = min(CH, nnz - c0);
 #pragma unroll
             for (int i = 0; i < RPW; i++) idn[i] = P.indices[st + c0 + min(RPW * wave + i, nr_idx - 1)];
             const size_t e = st + c0 + min(RPW * wave + myrow, nr_idx - 1);
-            idx_l = P.indices[e]; x_l = P.values[e];
+            idx_l = P.indices[e]; x_l = P.values[e]; g_l = entry_weight<T, IMPLICIT>(P, e);
         };
         auto load_rows = [&]() {
             nr_rows = nr_idx;
@@ -114,6 +115,8 @@ gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
             for (int i = 0; i < RPW; i++) pre[i] = P.B[(size_t)idn[i] * P.ldb + scol];
             xw_l = x_l;
             if (!IMPLICIT && P.bias_sub != nullptr) xw_l -= P.bias_sub[idx_l];
+            gw_l = g_l;
+            if (!IMPLICIT) xw_l *= g_l;                                   // right-hand side weight g x (tgemv_dense_sp_weighted)
         };
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CH) load_idx(CH);
@@ -132,7 +135,7 @@ gram_slice_kernel(const CgParams<T> P, const GramParams<T> Gp)
             const bool live_l = (RPW * wave + myrow < nr_rows);
             T wv = live_l ? xw_l : T(0);
             if (IMPLICIT) wv -= treduce8_rows(prod, lane);                // common.c:1936-1943 (0 for padded rows)
-            if ((lane & 7) == 0) wsc[slot * CH + RPW * wave + myrow] = live_l ? (IMPLICIT ? xw_l : T(1)) : T(0);
+            if ((lane & 7) == 0) wsc[slot * CH + RPW * wave + myrow] = live_l ? (IMPLICIT ? xw_l : gw_l) : T(0);
 #pragma unroll
             for (int i = 0; i < RPW; i++) racc += bcast_lane(wv, 8 * i) * bv[i];
             __syncthreads();
@@ -242,6 +245,8 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
             for (int cb = 0; cb < NTT; cb++) cacc[c][cb] = T(0);
 
         // entry (lane & 31) of a group: index, value (explicit: minus the fused bias), 1 / 0 for entries past the slice
+        // (explicit model with observation weights: okf carries the entry's weight g, so G = sum g B_j B_j^T and
+        //  v = sum g x B_j -- common.c:1007-1012, tgemv_dense_sp_weighted)
         auto load_entries = [&](int c0, int &idx, T &x, T &okf) {
             const int e = c0 + (lane & (GRP - 1));
             const bool ok = e < nnz;
@@ -249,7 +254,7 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
             idx = P.indices[pos];
             x = P.values[pos];
             if (!IMPLICIT && P.bias_sub != nullptr) x -= P.bias_sub[idx];
-            okf = ok ? T(1) : T(0);
+            okf = ok ? entry_weight<T, IMPLICIT>(P, pos) : T(0);
         };
         auto load_slabs = [&](int idx, T (&slab)[NS][NTT]) {
 #pragma unroll
@@ -368,8 +373,9 @@ gram_cg_kernel(const CgParams<T> P, const GramParams<T> Gp)
         const int s0 = Gp.row_sl_off[vr], s1 = Gp.row_sl_off[vr + 1];
         T lam = P.lam, lam_last = P.lam_last;
         if (!IMPLICIT && P.scale_lam) {                       // common.c:679-723
-            lam *= (T)d.nnz;
-            if (!P.scale_bias_const) lam_last *= (T)d.nnz;
+            const T mult = row_lam_mult(P, d.row, d.nnz);
+            lam *= mult;
+            if (!P.scale_bias_const) lam_last *= mult;
         }
         __syncthreads();                      // previous row's CG is done with M
         // columns kt .. 63 of M stay zero: the dense products below run over all 64 columns, four partial sums at a time

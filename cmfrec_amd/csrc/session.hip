@@ -71,6 +71,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.kt = c.kt; P.koff = c.koff;
     P.indptr = X ? X->p.ptr : nullptr; P.indices = X ? X->i.ptr : nullptr; P.values = X ? X->v.ptr : nullptr;
     P.bias_sub = c.bias_sub;
+    // observation weights of the explicit model ride on the shard (SparseShard::w / wsum)
+    const bool weighted = X != nullptr && X->weighted() && (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && c.values_override == nullptr;
+    if (weighted) { P.weights = X->w.ptr; P.wsum = X->wsum.ptr; }
     P.order = X ? X->order.ptr : nullptr;
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
     else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT) P.nrows = X->nrows;   // empty rows too
@@ -117,7 +120,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         static const char *chol_env = getenv("CMFREC_HIP_CHOL");
         const bool border = (c.kt > 16) && ((c.kt - 1) % 16 == 0);
         const int nbw = (c.kt - (border ? 1 : 0) + 15) / 16;
-        const bool wave_ok = X != nullptr && !two_src && !nonneg && !l1on && !c.rhs_only && nbw <= 8 &&
+        const bool wave_ok = X != nullptr && !two_src && !nonneg && !l1on && !c.rhs_only && nbw <= 8 && !weighted &&
                              (c.mode == CHOL_EXPLICIT || c.mode == CHOL_IMPLICIT || c.mode == CHOL_COLLECTIVE ||
                               c.mode == CHOL_COLLECTIVE_IMPLICIT) &&
                              !(chol_env != nullptr && strcmp(chol_env, "rows") == 0);
@@ -450,6 +453,7 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
     const int n_full = X.rows_longer_than(lr_max, X.nrows);          // positions [0, n_full): full factorisation
     const int n_light = X.nrows - n_full;
     const bool lr_ok = !(lr_env != nullptr && lr_env[0] == '0') && c.mode == CHOL_COLLECTIVE && c.Mfull == nullptr && c.X2 == nullptr &&
+                       !X.weighted() &&
                        !c.scale_bias_const && !dev.nonneg_now && !c.nonneg && dev.l1_now == (real_t)0 && dev.l1_last_now == (real_t)0 &&
                        c.rows_with_u >= X.nrows && !c.rhs_prefilled_all && kt <= 320 && kt >= 64 && kc > 0 && p_self > 0 &&
                        // the penalty must be a multiple of the identity on the rotated block: the last unknown's own lambda
@@ -737,16 +741,31 @@ void cmfrec_hip_session_destroy(cmfrec_hip_session *s)
     delete s;
 }
 
+static int weights_allowed(const cmfrec_hip_session *s, const char *fn)
+{
+    if (s->mdl.implicit) { g_last_error = std::string(fn) + ": observation weights belong to the explicit model"; return 2; }
+    return 0;
+}
+
+int cmfrec_hip_session_set_X_weighted(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
+                                      const real_t *csr_w, const size_t *csc_p, const int_t *csc_i, const real_t *csc_v,
+                                      const real_t *csc_w)
+{
+    return guarded([&]() {
+        if ((csr_w != nullptr) != (csc_w != nullptr)) { g_last_error = "cmfrec_hip_session_set_X_weighted: weights for both orientations or none"; return 2; }
+        if (csr_w != nullptr) { const int rc = weights_allowed(s, "cmfrec_hip_session_set_X_weighted"); if (rc) return rc; }
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t);
+        shard_from_csr(s->Xr, s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->mdl.n, s->dev.stream, csr_w);
+        shard_from_csr(s->Xc, s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->mdl.m, s->dev.stream, csc_w);
+        return 0;
+    });
+}
+
 int cmfrec_hip_session_set_X(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
                              const size_t *csc_p, const int_t *csc_i, const real_t *csc_v)
 {
-    return guarded([&]() {
-        HIP_CHECK(hipSetDevice(s->dev.device));
-        s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t);
-        shard_from_csr(s->Xr, s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->mdl.n, s->dev.stream);
-        shard_from_csr(s->Xc, s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->mdl.m, s->dev.stream);
-        return 0;
-    });
+    return cmfrec_hip_session_set_X_weighted(s, csr_p, csr_i, csr_v, nullptr, csc_p, csc_i, csc_v, nullptr);
 }
 
 int cmfrec_hip_session_set_A_parts(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
@@ -760,6 +779,7 @@ int cmfrec_hip_session_set_A_parts(cmfrec_hip_session *s, const size_t *csr_p, c
         s->partEv.clear();
         if (nparts <= 1) return 0;
         if (s->mdl.p > 0) { g_last_error = "cmfrec_hip_session_set_A_parts: not with user side information"; return 2; }
+        if (s->Xr.weighted()) { g_last_error = "cmfrec_hip_session_set_A_parts: not with observation weights"; return 2; }
         // no host CSR given: cut the resident one (shards built on the device)
         std::vector<size_t> hp; std::vector<int_t> hi; std::vector<real_t> hv;
         if (csr_p == nullptr) {
@@ -811,8 +831,9 @@ int cmfrec_hip_session_stream_wait_part(cmfrec_hip_session *s, int part, void *s
     });
 }
 
-int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
-                                 size_t nnz, real_t subtract, real_t alpha)
+// weight: one observation weight per entry (explicit model), or null
+int cmfrec_hip_session_set_X_coo_weighted(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
+                                          const real_t *weight, size_t nnz, real_t subtract, real_t alpha)
 {
     return guarded([&]() {
         const cmfrec_hip_model &m = s->mdl;
@@ -820,15 +841,23 @@ int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const 
             g_last_error = "cmfrec_hip_session_set_X_coo: only for sessions that own all rows and columns";
             return 2;
         }
+        if (weight != nullptr) { const int rc = weights_allowed(s, "cmfrec_hip_session_set_X_coo_weighted"); if (rc) return rc; }
         HIP_CHECK(hipSetDevice(s->dev.device));
-        DevBuf<int> dr, dc; DevBuf<real_t> dv;
+        DevBuf<int> dr, dc; DevBuf<real_t> dv, dw;
         dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
+        if (weight != nullptr) dw.upload(weight, nnz, s->dev.stream);
         s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(m.k + m.k_main) * sizeof(real_t);
-        shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
-        shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream);
+        shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream, dw.ptr);
+        shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream, dw.ptr);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
+}
+
+int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
+                                 size_t nnz, real_t subtract, real_t alpha)
+{
+    return cmfrec_hip_session_set_X_coo_weighted(s, row, col, val, nullptr, nnz, subtract, alpha);
 }
 
 // One shard from a COO triplet that already lives in HBM (multi-GPU set-up: the triplets come out of the
@@ -864,12 +893,27 @@ int cmfrec_hip_session_init_biases(cmfrec_hip_session *s, real_t lam_user, real_
         // under scale_lam_sideinfo the rows that have side information count its attributes too (wsumA / wsumB,
         // collective.c:8071-8104).  For sparse side information the reference adds `U_csr_p[row+1] - U_csr[row]` there -- an
         // index minus a value (:8086): nothing to pin, so that combination is refused
+        if ((s->Xr.weighted() || s->Xc.weighted()) && (m.scale_lam_sideinfo || s->scale_bias_const)) {
+            g_last_error = "cmfrec_hip: bias start values with observation weights and scale_lam_sideinfo / scale_bias_const are not implemented";
+            return 2;
+        }
         if (m.scale_lam_sideinfo && ((s->sparseU && m.user_bias) || (s->sparseI && m.item_bias))) {
             g_last_error = "cmfrec_hip: bias start values with scale_lam_sideinfo and sparse side information are not defined by the reference";
             return 2;
         }
         auto sweep = [&](const SparseShard &X, const real_t *other, real_t lam_b, int user_rule, real_t *bias) {
             const bool users = (&X == &s->Xr);
+            if (X.weighted()) {                                           // common.c:4180-4205, :4672-4692, :4826-4847
+                const int onesided = (m.user_bias != m.item_bias) ? 1 : 0;
+                const real_t *wd = m.scale_lam ? X.wsum.ptr : nullptr;
+                if (X.n_long > 0)
+                    hipLaunchKernelGGL(bias_sweep_weighted_long_kernel, dim3(X.n_long), dim3(64), 0, st, X.p.ptr, X.i.ptr, X.v.ptr, X.w.ptr,
+                                       other, X.order.ptr, X.n_long, lam_b, wd, onesided, bias);
+                if (X.nrows > X.n_long)
+                    hipLaunchKernelGGL(bias_sweep_weighted_kernel, dim3((X.nrows - X.n_long + 63) / 64), dim3(64), 0, st, X.p.ptr, X.i.ptr,
+                                       X.v.ptr, X.w.ptr, other, X.order.ptr, X.n_long, X.nrows, lam_b, wd, onesided, bias);
+                return;
+            }
             const int extra = m.scale_lam_sideinfo ? (users ? m.p : m.q) : 0, extra_rows = users ? m.m_u : m.n_i;
             if (X.n_long > 0)
                 hipLaunchKernelGGL(bias_sweep_long_kernel, dim3(X.n_long), dim3(64), 0, st, X.p.ptr, X.i.ptr, X.v.ptr, other,
@@ -1955,6 +1999,15 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
                                   const real_t *bias_sub, real_t lam, real_t lam_last, bool scale_lam,
                                   bool scale_bias_const, bool use_cg, bool precondition_cg, int_t max_cg_steps)
 {
+    return cmfrec_hip_optimizeA_explicit_weighted(A, lda, B, ldb, m, n, k, Xcsr_p, Xcsr_i, Xcsr, nullptr, nullptr, bias_sub, lam, lam_last,
+                                                  scale_lam, scale_bias_const, use_cg, precondition_cg, max_cg_steps);
+}
+
+int cmfrec_hip_optimizeA_explicit_weighted(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                                           const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr, const real_t *weight,
+                                           const real_t *wsum, const real_t *bias_sub, real_t lam, real_t lam_last, bool scale_lam,
+                                           bool scale_bias_const, bool use_cg, bool precondition_cg, int_t max_cg_steps)
+{
     return guarded([&]() {
         DeviceInfo dev;
         init_device(dev, -1);
@@ -1964,7 +2017,11 @@ int cmfrec_hip_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t
         dB.upload(B, (size_t)n * ldb, dev.stream);
         if (bias_sub) dbias.upload(bias_sub, n, dev.stream);
         X.opp_row_bytes_hint = (size_t)k * sizeof(real_t);
-        shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream);
+        shard_from_csr(X, m, Xcsr_p, Xcsr_i, Xcsr, n, dev.stream, weight);
+        if (weight != nullptr && wsum != nullptr && X.weighted()) {      // the driver's multipliers instead of the rows' own sums
+            X.wsum.upload(wsum, (size_t)m, dev.stream);
+            HIP_CHECK(hipStreamSynchronize(dev.stream));
+        }
         int rc;
         if (use_cg) {
             CgCall c{dA.ptr, lda, dB.ptr, ldb, k, bias_sub ? dbias.ptr : nullptr, nullptr, lam, lam_last, scale_lam,

@@ -39,8 +39,9 @@ def optimizeA_implicit(A, B, csr, lam, k=None, use_cg=True, precondition_cg=Fals
 
 
 def optimizeA_explicit(A, B, csr, lam, lam_last=None, k=None, bias_sub=None, scale_lam=False,
-                       scale_bias_const=False, use_cg=True, precondition_cg=False, max_cg_steps=3):
-    """In-place explicit half-step on sparse X (reference optimizeA, Case 4)."""
+                       scale_bias_const=False, use_cg=True, precondition_cg=False, max_cg_steps=3, weight=None, wsum=None):
+    """In-place explicit half-step on sparse X (reference optimizeA, Case 4).  weight: observation weights in the entry
+    order of ``csr``; wsum: the per-row lambda multipliers of scale_lam (default: every row's own sum of weights)."""
     lib, R = _prep(A, B)
     m, lda = A.shape
     n, ldb = B.shape
@@ -48,6 +49,17 @@ def optimizeA_explicit(A, B, csr, lam, lam_last=None, k=None, bias_sub=None, sca
     lam_last = lam if lam_last is None else lam_last
     p, i, v = _csr(csr, A.dtype)
     bs = None if bias_sub is None else np.ascontiguousarray(bias_sub, A.dtype)
+    if weight is not None:
+        w = np.ascontiguousarray(weight, A.dtype)
+        ws = None if wsum is None else np.ascontiguousarray(wsum, A.dtype)
+        assert len(w) == len(v) and (ws is None or len(ws) == m)
+        rc = lib.cmfrec_hip_optimizeA_explicit_weighted(_lib.ptr(A), C.c_size_t(lda), _lib.ptr(B), C.c_size_t(ldb), C.c_int(m),
+                                                        C.c_int(n), C.c_int(k), _lib.ptr(p), _lib.ptr(i), _lib.ptr(v), _lib.ptr(w),
+                                                        _lib.ptr(ws), _lib.ptr(bs), R(lam), R(lam_last), C.c_bool(scale_lam),
+                                                        C.c_bool(scale_bias_const), C.c_bool(use_cg), C.c_bool(precondition_cg),
+                                                        C.c_int(max_cg_steps))
+        _lib.check(rc, lib, "optimizeA_explicit_weighted")
+        return
     rc = lib.cmfrec_hip_optimizeA_explicit(_lib.ptr(A), C.c_size_t(lda), _lib.ptr(B), C.c_size_t(ldb), C.c_int(m),
                                            C.c_int(n), C.c_int(k), _lib.ptr(p), _lib.ptr(i), _lib.ptr(v), _lib.ptr(bs),
                                            R(lam), R(lam_last), C.c_bool(scale_lam), C.c_bool(scale_bias_const),

@@ -49,7 +49,12 @@ class AlsSession:
         return None if a is None else np.ascontiguousarray(a, self.dtype if dt is None else dt)
 
     def set_X(self, csr, csc):
-        """csr / csc = (indptr uint64 rebased to the local block, indices int32 global, values)."""
+        """csr / csc = (indptr uint64 rebased to the local block, indices int32 global, values[, observation weights])."""
+        if len(csr) > 3 or len(csc) > 3:
+            keep = [self._c(csr[0], np.uint64), self._c(csr[1], np.int32), self._c(csr[2]), self._c(csr[3]),
+                    self._c(csc[0], np.uint64), self._c(csc[1], np.int32), self._c(csc[2]), self._c(csc[3])]
+            _lib.check(self.lib.cmfrec_hip_session_set_X_weighted(self.handle, *[_lib.ptr(a) for a in keep]), self.lib, "set_X")
+            return
         keep = [self._c(csr[0], np.uint64), self._c(csr[1], np.int32), self._c(csr[2]),
                 self._c(csc[0], np.uint64), self._c(csc[1], np.int32), self._c(csc[2])]
         _lib.check(self.lib.cmfrec_hip_session_set_X(self.handle, *[_lib.ptr(a) for a in keep]), self.lib, "set_X")
@@ -110,13 +115,16 @@ class AlsSession:
         R = _lib.real(self.dtype)
         _lib.check(self.lib.cmfrec_hip_session_init_biases(self.handle, R(lam_user), R(lam_item)), self.lib, "init_biases")
 
-    def set_X_coo(self, row, col, val, alpha=1.0, subtract=0.0):
+    def set_X_coo(self, row, col, val, alpha=1.0, subtract=0.0, weight=None):
         """COO triplet (int32 row / col ids, values); CSR and CSC are built on the device with the
-        reference's entry order (stable in COO order, src/helpers.c:1375-1491)."""
+        reference's entry order (stable in COO order, src/helpers.c:1375-1491).  weight: one observation weight per entry
+        (explicit model), or None."""
         R = _lib.real(self.dtype)
-        keep = [self._c(row, np.int32), self._c(col, np.int32), self._c(val)]
-        _lib.check(self.lib.cmfrec_hip_session_set_X_coo(self.handle, *[_lib.ptr(a) for a in keep],
-                                                         C.c_size_t(len(keep[2])), R(subtract), R(alpha)), self.lib, "set_X_coo")
+        keep = [self._c(row, np.int32), self._c(col, np.int32), self._c(val), self._c(weight)]
+        if weight is not None and len(keep[3]) != len(keep[2]):
+            raise ValueError("weight must have one entry per entry of X")
+        _lib.check(self.lib.cmfrec_hip_session_set_X_coo_weighted(self.handle, *[_lib.ptr(a) for a in keep],
+                                                                  C.c_size_t(len(keep[2])), R(subtract), R(alpha)), self.lib, "set_X_coo")
 
     def set_X_coo_device(self, which, key, other, val, alpha=1.0, subtract=0.0):
         """One shard from a COO triplet resident in HBM (torch CUDA tensors, int32 / int32 / values): which = 'r' builds

@@ -157,6 +157,18 @@ int cmfrec_hip_optimizeA_explicit(
     real_t lam, real_t lam_last, bool scale_lam, bool scale_bias_const,
     bool use_cg, bool precondition_cg, int_t max_cg_steps);
 
+/* The same with observation weights (optimizeA Case 4 with weight != NULL, src/common.c:3268-3299 -> the weighted branches
+ * of factors_closed_form :985-1012 and factors_explicit_cg / _pcg :1126-1135, :1162-1171, :1222-1254): weight[nnz] in the
+ * entry order of Xcsr; wsum[m] (optional) = the lambda multipliers of scale_lam the driver passes (wsumA,
+ * src/collective.c:7978-8008), NULL = every row's own sum of weights.  weight == NULL: cmfrec_hip_optimizeA_explicit. */
+int cmfrec_hip_optimizeA_explicit_weighted(
+    real_t *A, size_t lda, const real_t *B, size_t ldb,
+    int_t m, int_t n, int_t k,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr, const real_t *weight, const real_t *wsum,
+    const real_t *bias_sub,
+    real_t lam, real_t lam_last, bool scale_lam, bool scale_bias_const,
+    bool use_cg, bool precondition_cg, int_t max_cg_steps);
+
 /* Dense full side-information update (the C / D step); replaces optimizeA Case 1,
  * src/common.c:2793-2991.  do_B: Xfull is [n, ldX] and used transposed (common.c:2852-2855). */
 int cmfrec_hip_optimizeA_dense_full(
@@ -323,6 +335,17 @@ int cmfrec_hip_session_stream_wait_part(cmfrec_hip_session *s, int part, void *s
 
 int cmfrec_hip_session_set_X_coo(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
                                  size_t nnz, real_t subtract, real_t alpha);
+/* The same with observation weights (explicit model): weight[nnz], one per entry, travels through the same stable sort as
+ * the values (weightR / weightC of coo_to_csr_and_csc, src/helpers.c:1375-1491).  Every row solver then weights the entry's
+ * rank-1 term and right-hand side (src/common.c:985-1012, :1126-1135, :1162-1171, :1246-1254), scale_lam multiplies lambda by
+ * the row's sum of weights (:679-723; src/collective.c:7978-8008) and init_biases takes weighted means (src/common.c:4180-4205,
+ * :4672-4692, :4826-4847).  weight == NULL: as cmfrec_hip_session_set_X_coo.  Returns 2 for the implicit model.
+ * cmfrec_hip_session_set_X_weighted: the same from host CSR + CSC with their weights in the same entry order. */
+int cmfrec_hip_session_set_X_coo_weighted(cmfrec_hip_session *s, const int_t *row, const int_t *col, const real_t *val,
+                                          const real_t *weight, size_t nnz, real_t subtract, real_t alpha);
+int cmfrec_hip_session_set_X_weighted(cmfrec_hip_session *s,
+                                      const size_t *csr_p, const int_t *csr_i, const real_t *csr_v, const real_t *csr_w,
+                                      const size_t *csc_p, const int_t *csc_i, const real_t *csc_v, const real_t *csc_w);
 /* One shard from a COO triplet already resident in HBM (device pointers): which = 'r': CSR of the local rows, d_key = row -
    row_begin, d_other = global column; 'c': CSC of the local columns, d_key = column - col_begin, d_other = global row.
    Multi-GPU set-up path (the triplets come out of an all-to-all between the ranks); no reference counterpart: the

@@ -127,13 +127,19 @@ class Oracle:
 
     def optimizeA_explicit(self, A, B, csr, lam, lam_last=None, k=None, scale_lam=False,
                            scale_bias_const=False, nthreads=1, use_cg=True, precondition_cg=False,
-                           max_cg_steps=3):
+                           max_cg_steps=3, weight=None, wsum=None):
+        """weight: observation weights in the entry order of ``csr``; wsum: per-row lambda multipliers under scale_lam (the
+        driver's wsumA; None: the row's own sum, common.c:696-707)."""
         assert A.dtype == self.dtype and B.dtype == self.dtype and A.flags.c_contiguous and B.flags.c_contiguous
         m, lda = A.shape
         n, ldb = B.shape
         k = min(lda, ldb) if k is None else k
         lam_last = lam if lam_last is None else lam_last
         p, i, v = csr
+        if weight is not None:
+            weight = np.ascontiguousarray(weight, self.dtype)
+            wsum = None if wsum is None else np.ascontiguousarray(wsum, self.dtype)
+            self.lib.oracle_set_row_weights(_ptr(weight), _ptr(wsum))
         self.lib.oracle_optimizeA_explicit(_ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb),
                                            C.c_int(m), C.c_int(n), C.c_int(k), _ptr(p), _ptr(i), _ptr(v),
                                            self._r(lam), self._r(lam_last), C.c_bool(scale_lam),
@@ -353,8 +359,12 @@ class Oracle:
                          scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,
                          w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=True, max_cg_steps=3,
                          precondition_cg=False, finalize_chol=True, init_biases=False, m=None, n=None,
-                         add_implicit_features=False, w_implicit=1.0, w_main=1.0):
+                         add_implicit_features=False, w_implicit=1.0, w_main=1.0, weight=None):
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
+        if weight is not None:
+            weight = np.ascontiguousarray(weight, self.dtype)
+            assert len(weight) == len(val)
+            self.lib.oracle_set_fit_weights(_ptr(weight))
         if w_main != 1.0:                                                            # collective.c:7497-7521
             lam, w_user, w_item, w_implicit = lam / w_main, w_user / w_main, w_item / w_main, w_implicit / w_main
         Ai = np.zeros((A.shape[0], k + k_main), self.dtype) if add_implicit_features else None
@@ -439,8 +449,11 @@ class Reference:
 
     def optimizeA(self, A, B, csr=None, Xfull=None, lam=1.0, lam_last=None, k=None, scale_lam=False,
                   scale_bias_const=False, do_B=False, nthreads=1, use_cg=True, precondition_cg=False,
-                  max_cg_steps=3, full_dense=False):
-        """Case 4 (csr given) or Case 1 (Xfull given, full_dense=True) of optimizeA."""
+                  max_cg_steps=3, full_dense=False, weight=None, wsum=None):
+        """Case 4 (csr given) or Case 1 (Xfull given, full_dense=True) of optimizeA.  weight (entry order of csr) / wsum: the
+        observation weights and the driver's lambda multipliers (wsumA)."""
+        weight = None if weight is None else np.ascontiguousarray(weight, self.dtype)
+        wsum = None if wsum is None else np.ascontiguousarray(wsum, self.dtype)
         m, lda = A.shape
         n, ldb = B.shape
         k = min(lda, ldb) if k is None else k
@@ -453,9 +466,9 @@ class Reference:
         self.lib.optimizeA(_ptr(A), C.c_int(lda), _ptr(B), C.c_int(ldb), C.c_int(m), C.c_int(n), C.c_int(k),
                            _ptr(p), _ptr(i), _ptr(v), _ptr(Xfull), C.c_int(ldX),
                            C.c_bool(full_dense), C.c_bool(False), C.c_bool(full_dense),
-                           _ptr(cnt_NA), None, C.c_bool(False),
+                           _ptr(cnt_NA), _ptr(weight), C.c_bool(False),
                            self._r(lam), self._r(lam_last), self._r(0.), self._r(0.),
-                           C.c_bool(scale_lam), C.c_bool(scale_bias_const), None,
+                           C.c_bool(scale_lam), C.c_bool(scale_bias_const), _ptr(wsum),
                            C.c_bool(do_B), C.c_int(nthreads), C.c_bool(False),
                            C.c_bool(use_cg), C.c_bool(precondition_cg), C.c_int(max_cg_steps),
                            C.c_bool(False), C.c_int(100),
@@ -718,9 +731,11 @@ class Reference:
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
                                     l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
-                                    l1_lam_unique=None, scale_bias_const=False):
-        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
+                                    l1_lam_unique=None, scale_bias_const=False, weight=None):
+        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II.
+        weight: observation weights, one per entry of X."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
+        weight = None if weight is None else np.ascontiguousarray(weight, self.dtype)
         lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
         l16 = None if l1_lam_unique is None else np.ascontiguousarray(l1_lam_unique, self.dtype)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -755,7 +770,7 @@ class Reference:
             C.c_bool(add_implicit_features), C.c_bool(reset_values), C.c_int(seed),
             _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
-            None, None, C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
+            None, _ptr(weight), C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
             self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),

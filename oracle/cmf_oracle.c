@@ -403,17 +403,18 @@ void oracle_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t ld
 /* ------------------------------------------------------------------------------------------ */
 /* explicit-feedback per-row solvers                                                            */
 /* ------------------------------------------------------------------------------------------ */
-/* common.c:1098-1188 (weight == NULL) */
+/* common.c:1098-1188; wt: the row's observation weights (weighted branches :1126-1135, :1162-1171) or NULL */
 static void explicit_cg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
-                            const real_t *Xa, const int_t *ixB, size_t nnz,
+                            const real_t *Xa, const int_t *ixB, size_t nnz, const real_t *wt,
                             real_t lam, real_t lam_last, int_t max_cg_steps, real_t *buf)
 {
     real_t *Ap = buf, *p = Ap + k, *r = p + k;
     memset(r, 0, (size_t)k * sizeof(real_t));
-    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1119-1124 */
+    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1119-1124 / :1128-1134 */
         const real_t *b = B + (size_t)ixB[ix] * ldb;
         real_t coef = dot_(k, b, a);
         coef -= Xa[ix];
+        if (wt != NULL) coef *= wt[ix];
         axpy_(k, -coef, b, r);
     }
     axpy_(k, -lam, a, r);                                                      /* :1138 */
@@ -423,9 +424,10 @@ static void explicit_cg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
     memcpy(p, r, (size_t)k * sizeof(real_t));
     for (int_t step = 0; step < max_cg_steps; step++) {
         memset(Ap, 0, (size_t)k * sizeof(real_t));
-        for (size_t ix = 0; ix < nnz; ix++) {                                  /* :1157-1160 */
+        for (size_t ix = 0; ix < nnz; ix++) {                                  /* :1157-1160 / :1164-1170 */
             const real_t *b = B + (size_t)ixB[ix] * ldb;
             real_t coef = dot_(k, b, p);
+            if (wt != NULL) coef *= wt[ix];
             axpy_(k, coef, b, Ap);
         }
         axpy_(k, lam, p, Ap);
@@ -441,9 +443,9 @@ static void explicit_cg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
     }
 }
 
-/* common.c:1190-1291 (weight == NULL) */
+/* common.c:1190-1291; wt: the row's observation weights or NULL */
 static void explicit_pcg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
-                             const real_t *Xa, const int_t *ixB, size_t nnz,
+                             const real_t *Xa, const int_t *ixB, size_t nnz, const real_t *wt,
                              real_t lam, real_t lam_last, int_t max_cg_steps, real_t *buf)
 {
     real_t *Ap = buf, *p = Ap + k, *r = p + k, *z = r + k, *PC = z + k;
@@ -452,14 +454,16 @@ static void explicit_pcg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
         const real_t *b = B + (size_t)ixB[ix] * ldb;
         real_t coef = dot_(k, b, a);
         coef -= Xa[ix];
+        if (wt != NULL) coef *= wt[ix];                                        /* :1222-1229 */
         axpy_(k, -coef, b, r);
     }
     axpy_(k, -lam, a, r);
     if (lam != lam_last) r[k - 1] -= (lam_last - lam) * a[k - 1];
     memset(PC, 0, (size_t)k * sizeof(real_t));
-    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1238-1243 */
+    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1238-1243 / :1246-1254 */
         const real_t *b = B + (size_t)ixB[ix] * ldb;
-        for (int_t i = 0; i < k; i++) PC[i] += b[i] * b[i];
+        const real_t w_this = (wt != NULL) ? wt[ix] : (real_t)1;
+        for (int_t i = 0; i < k; i++) PC[i] += w_this * (b[i] * b[i]);
     }
     for (int_t i = 0; i < k; i++) PC[i] += lam;
     if (lam != lam_last) PC[k - 1] += (lam_last - lam);
@@ -472,6 +476,7 @@ static void explicit_pcg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
         for (size_t ix = 0; ix < nnz; ix++) {
             const real_t *b = B + (size_t)ixB[ix] * ldb;
             real_t coef = dot_(k, b, p);
+            if (wt != NULL) coef *= wt[ix];
             axpy_(k, coef, b, Ap);
         }
         axpy_(k, lam, p, Ap);
@@ -487,21 +492,30 @@ static void explicit_pcg_row(real_t *a, int_t k, const real_t *B, size_t ldb,
     }
 }
 
-/* common.c:978-1013 + :1060-1070 */
+/* common.c:978-1013 + :1060-1070; wt: the row's observation weights or NULL */
 static void explicit_chol_row(real_t *a, int_t k, const real_t *B, size_t ldb,
-                              const real_t *Xa, const int_t *ixB, size_t nnz,
+                              const real_t *Xa, const int_t *ixB, size_t nnz, const real_t *wt,
                               real_t lam, real_t lam_last, real_t *buf)
 {
     memset(a, 0, (size_t)k * sizeof(real_t));
-    for (size_t ix = 0; ix < nnz; ix++)                      /* tgemv_dense_sp, helpers.c:1175 */
-        axpy_(k, Xa[ix], B + (size_t)ixB[ix] * ldb, a);
+    for (size_t ix = 0; ix < nnz; ix++)                      /* tgemv_dense_sp / _weighted, helpers.c:1175-1203 */
+        axpy_(k, (wt != NULL) ? wt[ix] * Xa[ix] : Xa[ix], B + (size_t)ixB[ix] * ldb, a);
     real_t *M = buf;
     memset(M, 0, (size_t)k * k * sizeof(real_t));
-    for (size_t ix = 0; ix < nnz; ix++)
-        syr_upper_(k, (real_t)1, B + (size_t)ixB[ix] * ldb, M, k);
+    for (size_t ix = 0; ix < nnz; ix++)                      /* common.c:1007-1012 */
+        syr_upper_(k, (wt != NULL) ? wt[ix] : (real_t)1, B + (size_t)ixB[ix] * ldb, M, k);
     for (int_t i = 0; i < k - 1; i++) M[(size_t)i * k + i] += lam;            /* add_to_diag2 */
     M[(size_t)(k - 1) * k + (k - 1)] += lam_last;
     solve_sym_(k, M, k, a);
+}
+
+/* observation weights of the call that follows (optimizeA Case 4 with weight != NULL, common.c:3268-3299): one per entry in
+ * the order of Xcsr, and the per-row lambda multipliers of scale_lam (wsumA / wsumB of the driver, or NULL: the row's sum in
+ * real_t, common.c:696-712).  Cleared by the call. */
+static const real_t *g_row_weights = NULL, *g_row_wsum = NULL;
+void oracle_set_row_weights(const real_t *weights_csr_order, const real_t *wsum)
+{
+    g_row_weights = weights_csr_order; g_row_wsum = wsum;
 }
 
 void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
@@ -513,6 +527,8 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
                                bool use_cg, bool precondition_cg, int_t max_cg_steps)
 {
     (void)n;
+    const real_t *wts = g_row_weights, *wsums = g_row_wsum;
+    g_row_weights = NULL; g_row_wsum = NULL;
     if (nthreads < 1) nthreads = 1;
     size_t szbuf = (size_t)k * k;                                              /* :3244-3249 */
     if (use_cg) szbuf = (size_t)(precondition_cg ? 5 : 3) * k;
@@ -524,19 +540,26 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
         size_t nnz = en - st;
         real_t lam_i = lam, lam_last_i = lam_last;
         t_l1_mult = 1;
+        const real_t *wt = (wts != NULL) ? wts + st : NULL;
         if (scale_lam) {                                                       /* :679-723 */
-            lam_i *= (real_t)nnz;
-            if (!scale_bias_const) lam_last_i *= (real_t)nnz;
-            t_l1_mult = (real_t)nnz;
+            real_t mult = (real_t)nnz;
+            if (wt != NULL) {
+                real_t wsum = (wsums != NULL) ? wsums[ix] : (real_t)0;
+                if (wsum <= 0) { wsum = 0; for (size_t e = 0; e < nnz; e++) wsum += wt[e]; }   /* :696-707 */
+                mult = wsum;
+            }
+            lam_i *= mult;
+            if (!scale_bias_const) lam_last_i *= mult;
+            t_l1_mult = mult;
         }
         real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
         real_t *a = A + (size_t)ix * lda;
         if (use_cg && !precondition_cg)
-            explicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, lam_i, lam_last_i, max_cg_steps, buf);
+            explicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, max_cg_steps, buf);
         else if (use_cg)
-            explicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, lam_i, lam_last_i, max_cg_steps, buf);
+            explicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, max_cg_steps, buf);
         else
-            explicit_chol_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, lam_i, lam_last_i, buf);
+            explicit_chol_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, buf);
     }
     free(bufs);
 }
@@ -1017,6 +1040,57 @@ real_t oracle_calc_mean_and_center(real_t *X, size_t nnz, int nthreads)
     return glob_mean;
 }
 
+/* weighted mean of the entries, running form (common.c:3574-3584; with 8 threads or more the reference divides the unweighted
+ * sum by the sum of the weights, :3561-3571 -- not restated), then centring as above */
+real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz)
+{
+    double xsum = 0, wsum = DBL_EPSILON;
+    for (size_t ix = 0; ix < nnz; ix++)
+        xsum += ((X[ix] - xsum) * weight[ix]) / (wsum += weight[ix]);
+    real_t glob_mean = (real_t)xsum;
+    if (g_nn_AB) glob_mean = (glob_mean > 0) ? glob_mean : (real_t)0;          /* :3604-3605 */
+    if (fabs_t(glob_mean) < sqrt_t(EPSILON_T)) glob_mean = 0;
+    if (glob_mean != 0)
+        for (size_t ix = 0; ix < nnz; ix++) X[ix] -= glob_mean;
+    return glob_mean;
+}
+
+/* initialize_biases_twosided, weighted branches without NA_as_zero (common.c:4672-4692 items, :4826-4847 users); wsumA / wsumB:
+ * the driver's lambda multipliers under scale_lam (NULL without scale_lam: the penalty is not scaled) */
+void oracle_initialize_biases_twosided_weighted(int_t m, int_t n,
+                                                const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *weightR,
+                                                const size_t *Xcsc_p, const int_t *Xcsc_i, const real_t *Xcsc, const real_t *weightC,
+                                                real_t lam_user, real_t lam_item, const real_t *wsumA, const real_t *wsumB,
+                                                real_t *biasA, real_t *biasB)
+{
+    if (fabs_t(lam_user) < EPSILON_T) lam_user = EPSILON_T;
+    if (fabs_t(lam_item) < EPSILON_T) lam_item = EPSILON_T;
+    memset(biasA, 0, (size_t)m * sizeof(real_t));
+    memset(biasB, 0, (size_t)n * sizeof(real_t));
+    for (int iter = 0; iter < 5; iter++) {
+        for (int_t col = 0; col < n; col++) {
+            double bmean = 0, wsum = DBL_EPSILON;
+            for (size_t ix = Xcsc_p[col]; ix < Xcsc_p[(size_t)col + 1]; ix++)
+                bmean += (weightC[ix] * (Xcsc[ix] - biasA[Xcsc_i[ix]] - bmean)) / (wsum += weightC[ix]);
+            if (Xcsc_p[(size_t)col + 1] > Xcsc_p[col])
+                bmean *= wsum / (wsum + lam_item * ((wsumB != NULL) ? wsumB[col] : 1.));
+            biasB[col] = (real_t)bmean;
+        }
+        for (int_t row = 0; row < m; row++) {
+            double bmean = 0, wsum = DBL_EPSILON;
+            for (size_t ix = Xcsr_p[row]; ix < Xcsr_p[(size_t)row + 1]; ix++)
+                bmean += (weightR[ix] * (Xcsr[ix] - biasB[Xcsr_i[ix]] - bmean)) / (wsum += weightR[ix]);
+            if (Xcsr_p[(size_t)row + 1] > Xcsr_p[row])
+                bmean *= wsum / (wsum + lam_user * ((wsumA != NULL) ? wsumA[row] : 1.));
+            biasA[row] = (real_t)bmean;
+        }
+    }
+}
+
+/* observation weights of the next oracle_fit_explicit_als call (COO order; cleared by the call) */
+static const real_t *g_fit_weight = NULL;
+void oracle_set_fit_weights(const real_t *weight) { g_fit_weight = weight; }
+
 /* rows < g_init_rows_u / columns < g_init_cols_i count g_init_p / g_init_q attributes on top of their entries: wsumA /
  * wsumB under scale_lam_sideinfo with dense side information (collective.c:8071-8104), set by the fit around its call */
 static int_t g_init_p = 0, g_init_rows_u = 0, g_init_q = 0, g_init_cols_i = 0;
@@ -1206,9 +1280,14 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                             bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol,
                             bool init_biases)
 {
+    const real_t *weight = g_fit_weight;
+    g_fit_weight = NULL;
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
+    /* weights: restated for the model without side information (the row solvers of common.c); the collective solvers with
+     * weights are checked against the reference build itself (tests/test_gpu_fit.py) */
+    if (weight != NULL && (U != NULL || II != NULL || (Ai != NULL && Bi != NULL) || g_scale_bias_const)) return 2;
     /* side information may cover more users / items than X: A, B have max(m, m_u) / max(n, n_i) rows
      * (collective.c:7332-7335); X is padded with empty rows / columns.  The rows beyond X are fitted to their
      * side information alone by a separate dense solve (optimizeA Case 1, collective.c:4967-5101). */
@@ -1238,6 +1317,8 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
 
     real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
     memcpy(Xc, X, nnz * sizeof(real_t));
+    if (weight != NULL) *glob_mean = center ? oracle_calc_mean_and_center_weighted(Xc, weight, nnz) : (real_t)0;
+    else
     *glob_mean = center ? oracle_calc_mean_and_center(Xc, nnz, nthreads) : (real_t)0;  /* :7552-7568 */
     size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));
     size_t *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
@@ -1245,6 +1326,29 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     real_t *csr_v = (real_t *)malloc(nnz * sizeof(real_t)), *csc_v = (real_t *)malloc(nnz * sizeof(real_t));
     oracle_coo_to_csr_and_csc(ixA, ixB, Xc, m, n, nnz, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v);
     free(Xc);
+    /* weights in CSR / CSC order (weightR / weightC, helpers.c:1419-1446) and, under scale_lam, the lambda multipliers
+     * wsumA / wsumB: the row's sum of weights in double, 1 for a row without entries (collective.c:7978-8008) */
+    real_t *weightR = NULL, *weightC = NULL, *wsumA = NULL, *wsumB = NULL;
+    if (weight != NULL) {
+        weightR = (real_t *)malloc(nnz * sizeof(real_t)); weightC = (real_t *)malloc(nnz * sizeof(real_t));
+        size_t *tp_r = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t)), *tp_c = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
+        int_t *ti_r = (int_t *)malloc(nnz * sizeof(int_t)), *ti_c = (int_t *)malloc(nnz * sizeof(int_t));
+        oracle_coo_to_csr_and_csc(ixA, ixB, weight, m, n, nnz, tp_r, ti_r, weightR, tp_c, ti_c, weightC);
+        free(tp_r); free(tp_c); free(ti_r); free(ti_c);
+        if (scale_lam) {
+            wsumA = (real_t *)malloc((size_t)m * sizeof(real_t)); wsumB = (real_t *)malloc((size_t)n * sizeof(real_t));
+            for (int_t r = 0; r < m; r++) {
+                double ws = 0;
+                for (size_t ix = csr_p[r]; ix < csr_p[(size_t)r + 1]; ix++) ws += weightR[ix];
+                wsumA[r] = (csr_p[(size_t)r + 1] > csr_p[r]) ? (real_t)ws : (real_t)1;
+            }
+            for (int_t c = 0; c < n; c++) {
+                double ws = 0;
+                for (size_t ix = csc_p[c]; ix < csc_p[(size_t)c + 1]; ix++) ws += weightC[ix];
+                wsumB[c] = (csc_p[(size_t)c + 1] > csc_p[c]) ? (real_t)ws : (real_t)1;
+            }
+        }
+    }
     real_t *Uc = NULL, *Ic = NULL;
     if (U != NULL) Uc = center_by_cols_dense(U, m_u, p, U_colmeans);           /* :7850ff preprocess_sideinfo_matrix */
     if (II != NULL) Ic = center_by_cols_dense(II, n_i, q, I_colmeans);
@@ -1277,6 +1381,10 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         }
     }
     if (scale_lam_sideinfo) { g_init_p = (U != NULL) ? p : 0; g_init_rows_u = m_u; g_init_q = (II != NULL) ? q : 0; g_init_cols_i = n_i; }
+    if (has_bias && init_biases && weight != NULL)
+        oracle_initialize_biases_twosided_weighted(m, n, csr_p, csr_i, csr_v, weightR, csc_p, csc_i, csc_v, weightC,
+                                                   user_bias ? lamAl : lam, item_bias ? lamBl : lam, wsumA, wsumB, biasA, biasB);
+    else
     if (has_bias && init_biases)                                               /* :8164-8226 */
         oracle_initialize_biases_twosided(m, n, csr_p, csr_i, csr_v, csc_p, csc_i, csc_v,
                                           user_bias ? lamAl : lam, item_bias ? lamBl : lam, scale_lam, biasA, biasB);
@@ -1325,11 +1433,13 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                              k, k_main + (int_t)item_bias, k_item, k_user,
                                              csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Ai : NULL, k_main, w_implicit);
-        else                                                                   /* :8680-8717 */
+        else {                                                                 /* :8680-8717 */
+            oracle_set_row_weights(weightC, wsumB);
             oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
                                       k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
                                       lamB, lamBl, scale_lam, sbc, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
+        }
         if (II != NULL) {
         if (n_i > n_x) {                                            /* rows known from side information only */
             if (!use_cg)
@@ -1356,11 +1466,13 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                              k, k_main + (int_t)user_bias, k_user, k_item,
                                              csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Bi : NULL, k_main, w_implicit);
-        else                                                                   /* :8847-8876 */
+        else {                                                                 /* :8847-8876 */
+            oracle_set_row_weights(weightR, wsumA);
             oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,
                                       k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
                                       lamA, lamAl, scale_lam, sbc, nthreads,
                                       use_cg, precondition_cg, max_cg_steps);
+        }
         if (U != NULL) {
         if (m_u > m_x) {                                            /* rows known from side information only */
             if (!use_cg)
@@ -1386,6 +1498,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     g_nonneg = false; g_l1 = 0; t_l1_mult = 1; g_l1_last_set = false;
     free(csr_orig); free(csc_orig); free(Uc); free(Ic);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
+    free(weightR); free(weightC); free(wsumA); free(wsumB);
     return 0;
 }
 
@@ -1475,7 +1588,7 @@ void oracle_factors_explicit_multiple(real_t *A, real_t *biasA, int_t m,
                 lam_i *= (real_t)nnz;
                 if (ub && !scale_bias_const) lam_last_i *= (real_t)nnz;
             }
-            explicit_chol_row(sol, kb, Bp + k_item, ldb, x, Xcsr_i + st, nnz, lam_i, lam_last_i, M);
+            explicit_chol_row(sol, kb, Bp + k_item, ldb, x, Xcsr_i + st, nnz, NULL, lam_i, lam_last_i, M);
             memcpy(a + k_user, sol, (size_t)(k + k_main) * sizeof(real_t));
             if (ub) biasA[ix] = sol[k + k_main];
             continue;

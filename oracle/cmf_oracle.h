@@ -66,6 +66,22 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
                                int nthreads,
                                bool use_cg, bool precondition_cg, int_t max_cg_steps);
 
+/* Observation weights of the oracle_optimizeA_explicit call that follows (optimizeA Case 4 with weight != NULL: the weighted
+ * branches of common.c:985-1012, :1126-1135, :1162-1171, :1222-1254): weights_csr_order[nnz] in the entry order of Xcsr and
+ * wsum[m] = the driver's lambda multipliers under scale_lam (wsumA, collective.c:7978-8008), or NULL: the row's own sum
+ * (common.c:696-707).  Cleared by the call. */
+void oracle_set_row_weights(const real_t *weights_csr_order, const real_t *wsum);
+/* Observation weights (COO order) of the oracle_fit_explicit_als call that follows: weighted mean (common.c:3574-3584),
+ * weightR / weightC, wsumA / wsumB, weighted bias start values (common.c:4672-4692, :4826-4847), weighted row solvers.  Model
+ * without side information only (returns 2 otherwise).  Cleared by the call. */
+void oracle_set_fit_weights(const real_t *weight);
+real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz);
+void oracle_initialize_biases_twosided_weighted(int_t m, int_t n,
+                                                const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *weightR,
+                                                const size_t *Xcsc_p, const int_t *Xcsc_i, const real_t *Xcsc, const real_t *weightC,
+                                                real_t lam_user, real_t lam_item, const real_t *wsumA, const real_t *wsumB,
+                                                real_t *biasA, real_t *biasB);
+
 /* common.c:2793-2991 (optimizeA, Case 1: dense full X, no weights) -- the C / D update.
  * do_B=false: A[m,k] = Xfull[m,n] B[n,k] (BtB+diag)^-1 ; do_B=true: Xfull is [n, ldX>=m] and is
  * used transposed (:2852-2855). */

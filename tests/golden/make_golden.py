@@ -273,6 +273,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g16_nan_side_" + tag, **out)
 
+        # ---- G17: observation weights of the explicit model ----
+        out = {}
+        d = gc.weights_problem(dt)
+        for ci, (name, side, opts) in enumerate(gc.WEIGHT_CASES):
+            r = gc.weights_reference(R, d, side, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g17_weights_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -721,3 +721,110 @@ def nan_side_hip(d, implicit, which, sl, sls, dtype, solver=None):
     if U is not None: out["U_colmeans"] = mdl._U_colmeans
     if I is not None: out["I_colmeans"] = mdl._I_colmeans
     return out
+
+
+# ---- observation weights of the explicit model (fit(..., W=...); fit_collective_explicit_als with weight != NULL) ------------
+def weights_problem(dtype, seed=81):
+    """A ratings problem with one weight per entry.  The entries are ordered by column: the reference hands its B-step the
+    weights in COO order where the CSC order is meant (collective.c:8642, :8689 pass `weight`, not `weightC`, for sparse X,
+    while its wsumB and its bias start values read weightC), so only for input sorted by column does it compute what it
+    documents -- the ordering its own docs ask for (cmfrec/__init__.py:3095-3099).  The oracle and the HIP path use the
+    CSC-ordered weights throughout."""
+    d = nonneg_problem(dtype, seed)
+    rng = np.random.default_rng(seed + 1)
+    # one long row and one long column (more than a 64-entry tile; the split-row path has its own test)
+    extra_c = rng.choice(d["n"], 70, replace=False); extra_r = rng.choice(d["m"], 90, replace=False)
+    extra_r = extra_r[~np.isin(extra_r, (4, 120))]
+    row = np.concatenate([d["row"], np.full(len(extra_c), 9, np.int32), extra_r.astype(np.int32)])
+    col = np.concatenate([d["col"], extra_c.astype(np.int32), np.full(len(extra_r), 11, np.int32)])
+    lin = row.astype(np.int64) * d["n"] + col
+    _, first = np.unique(lin, return_index=True)
+    first.sort()
+    row, col = row[first], col[first]
+    o = np.argsort(col, kind="stable")
+    d["row"], d["col"] = row[o], col[o]
+    d["ratings"] = (0.5 * rng.integers(1, 11, len(o))).astype(dtype)
+    d["W"] = (0.2 + 2.5 * rng.random(len(o)) ** 2).astype(dtype)
+    d.pop("counts")
+    d["A0"] = (rng.standard_normal((d["m"], d["k"])) * 0.1).astype(dtype); d["B0"] = (rng.standard_normal((d["n"], d["k"])) * 0.1).astype(dtype)
+    d["U"] = rng.standard_normal((d["m"], 5)).astype(dtype); d["I"] = rng.standard_normal((d["n"], 4)).astype(dtype)
+    return d
+
+
+# (name, side information, options).  seed: the reference's own random start + its weighted bias start values (reset_values).
+WEIGHT_CASES = [
+    ("cg", False, dict(use_cg=True, finalize_chol=False)),
+    ("cg scale_lam finalize", False, dict(use_cg=True, finalize_chol=True, scale_lam=True)),
+    ("pcg scale_lam", False, dict(use_cg=True, precondition_cg=True, finalize_chol=False, scale_lam=True)),
+    ("chol", False, dict(use_cg=False)),
+    ("chol scale_lam no bias", False, dict(use_cg=False, scale_lam=True, user_bias=False, item_bias=False)),
+    ("cg seeded, both biases", False, dict(use_cg=True, finalize_chol=False, scale_lam=True, seed=5)),
+    ("chol seeded, both biases", False, dict(use_cg=False, seed=6)),
+    ("cg seeded, user bias", False, dict(use_cg=True, finalize_chol=False, item_bias=False, scale_lam=True, seed=7)),
+    ("cg seeded, item bias", False, dict(use_cg=True, finalize_chol=False, user_bias=False, seed=8)),
+    # side information + weights, closed form: without centring.  The reference's collective closed form subtracts
+    # (w - 1) x glob_mean from every weighted entry of the right-hand side whether or not X is missing-as-zero
+    # (collective.c:1744-1753 lacks the NA_as_zero_X condition its twin common.c:826-845 has), so with centring its Cholesky
+    # and its CG solvers minimise different objectives; tests/test_oracle_vs_ref.py::test_reference_weight_defects shows it.
+    ("side info chol", True, dict(use_cg=False, k_user=1, k_item=2, center=False)),
+    ("side info chol scale_lam", True, dict(use_cg=False, scale_lam=True, k_main=1, center=False)),
+    ("side info cg", True, dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    ("side info pcg finalize", True, dict(use_cg=True, precondition_cg=True, finalize_chol=True, center=False)),
+    ("nonneg", False, dict(nonneg=True, scale_lam=True, use_cg=False)),
+    ("l1", False, dict(l1_lam=0.02, use_cg=False)),
+]
+
+
+def weights_reference(R, d, side, opts, nthreads=2):
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    A0, B0 = _impf_start(d, o)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    kw = dict(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+    if seed is not None:
+        A0[:] = 0; B0[:] = 0
+        r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], lam=0.3, niter=3, U=U, II=II, w_user=2.0,
+                                          w_item=0.5, nthreads=nthreads, weight=d["W"], reset_values=True, seed=seed, **kw)
+    else:
+        r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                          lam=0.3, niter=3, U=U, II=II, w_user=2.0, w_item=0.5, nthreads=nthreads, weight=d["W"], **kw)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def weights_oracle(O, d, side, opts, nthreads=2):
+    """None where the oracle has no restatement (side information, a one-sided or seeded start, nonneg / L1 with weights)."""
+    o = dict(opts)
+    if side or "seed" in o or o.get("nonneg") or o.get("l1_lam"):
+        return None
+    A0, B0 = _impf_start(d, o)
+    r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                           niter=3, w_user=2.0, w_item=0.5, nthreads=nthreads, weight=d["W"], use_cg=o.pop("use_cg", False),
+                           finalize_chol=o.pop("finalize_chol", False), **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if opts.get("user_bias", True): out["biasA"] = r["biasA"]
+    if opts.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def weights_hip(d, side, opts, dtype, weights=True):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    if "l1_lam" in o:
+        o["l1_lambda"] = o.pop("l1_lam")
+    A0, B0 = _impf_start(d, o)
+    U, II = (d["U"], d["I"]) if side else (None, None)
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1,
+              **(dict(random_state=seed) if seed is not None else {}), **o)
+    start = {} if seed is not None else dict(A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), W=d["W"] if weights else None, **start)
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out

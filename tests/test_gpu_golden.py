@@ -262,3 +262,28 @@ def test_sparse_side_info_colmeans(dtype):
     mdl.fit((d["row"], d["col"], d["counts"]), U=U, shape=(d["m"], d["n"]))
     exp = np.bincount(c[1], weights=c[2].astype(np.float64), minlength=c[4]) / np.bincount(c[1], minlength=c[4])
     assert np.allclose(mdl._U_colmeans, exp, rtol=1e-5 if dtype is np.float32 else 1e-12, atol=1e-6 if dtype is np.float32 else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_observation_weights(oracles, dtype):
+    """G17 through the estimator (CMF.fit(..., W=...)): weighted row solvers in every kernel family the cases reach (register
+    tiles, Jacobi-preconditioned and block CG, the workgroup-per-row Cholesky kernel with and without side information,
+    coordinate descent), sums of weights under scale_lam, weighted mean and weighted one- / two-sided bias start values on the
+    reference's own seeded start."""
+    g = gc.load("g17_weights", dtype)
+    d = gc.weights_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, side, opts) in enumerate(gc.WEIGHT_CASES):
+        got = gc.weights_hip(d, side, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        ref = gc.weights_oracle(oracles[dtype], d, side, opts)
+        if ref is not None:
+            assert gc.compare_fits(got, ref) < tol, name
+    # ... and they are not ignored
+    name, side, opts = gc.WEIGHT_CASES[0]
+    assert gc.compare_fits(gc.weights_hip(d, side, opts, dtype, weights=False), {k[3:]: g[k] for k in g.files if k.startswith("c0_")}) > 1e-2
+    # combinations whose weight bookkeeping is not restated are refused
+    for bad in (dict(scale_lam_sideinfo=True), dict(add_implicit_features=True, use_cg=False), dict(scale_lam=True, scale_bias_const=True)):
+        with pytest.raises(RuntimeError):
+            gc.weights_hip(d, True, bad, dtype)

@@ -400,3 +400,90 @@ def test_collective_sparse_sideinfo(oracles, dtype, k, ku, ki, km):
             O.optimizeA_collective_sparse(a2, B, Cm, csr_b, ucsr, 0.7, nthreads=4, **kw)
             assert rel_err(a1, a2) < tol, (implicit, sl, sls)
             assert not a1[3].any() and not a1[650].any()          # neither observations nor attributes
+
+
+def _driver_wsum(csr_p, w_csr, dtype):
+    """wsumA of the driver: the row's weights summed in double, 1 for a row without entries (collective.c:7988-7998)."""
+    p = csr_p.astype(np.int64)
+    # (np.cumsum adds entry by entry like the driver's loop; np.sum adds pairwise)
+    return np.array([np.cumsum(w_csr[p[r]:p[r + 1]].astype(np.float64))[-1] if p[r + 1] > p[r] else 1.0 for r in range(len(p) - 1)]).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("mode", ["cg", "pcg", "chol"])
+@pytest.mark.parametrize("k", [50, 9, 64, 100])
+def test_observation_weights_every_row_length(oracles, dtype, mode, k):
+    """Observation weights in every row kernel of the explicit model: rows of every length 0 .. 150 (two-rows-per-wavefront,
+    32- and 64-entry tiles, all team sizes), 250 .. 1024 (four- and eight-wave teams, re-streamed tiles), split rows (2500 and
+    4500 entries), k = 100 on the one-wavefront-per-row kernel; the fused bias subtraction, lambda scaled by the driver's sums
+    of weights (scale_lam) with its own value on the last unknown.  Row by row against the oracle."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    lens = list(range(0, 151)) + [250, 257, 300, 511, 512, 513, 640, 777, 1000, 1024, 2500, 4500]
+    m, n = len(lens), 5000
+    rng = np.random.default_rng(300 + k)
+    rows = [np.full(c, r, np.int32) for r, c in enumerate(lens)]
+    cols = [rng.choice(n, c, replace=False).astype(np.int32) for c in lens]
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
+    val = (0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    w = (0.2 + 2.5 * rng.random(len(row)) ** 2).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    w_csr = O.coo_to_csr_and_csc(row, col, w, m, n)[0][2]
+    wsum = _driver_wsum(csr[0], w_csr, dtype)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+    kw = dict(lam_last=0.3, scale_lam=True, use_cg=mode != "chol", precondition_cg=mode == "pcg")
+    Ah, Ao, Au = A0.copy(), A0.copy(), A0.copy()
+    ops.optimizeA_explicit(Ah, B, csr, 0.05, bias_sub=bias, weight=w_csr, wsum=wsum, **kw)
+    csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+    O.optimizeA_explicit(Ao, B, csr_b, 0.05, nthreads=4, weight=w_csr, wsum=wsum, **kw)
+    # (the preconditioned variant runs its three steps without exits: in single precision the 4500-entry rows of the k = 100
+    #  case end 1.2e-4 from the oracle's sequential sums)
+    assert rel_err(Ah, Ao) < TOL[dtype] * (3 if (mode == "pcg" and dtype is np.float32) else 1)
+    check_rows(Ah, Ao, dtype)
+    assert np.array_equal(Ah[0], A0[0])
+    # without `wsum` the rows' own sums are taken: the same numbers here
+    Ah2 = A0.copy()
+    ops.optimizeA_explicit(Ah2, B, csr, 0.05, bias_sub=bias, weight=w_csr, **kw)
+    assert np.array_equal(Ah2, Ah)
+    # unit weights reproduce the unweighted kernels bit for bit (a multiplication by one), other weights do not
+    ops.optimizeA_explicit(Au, B, csr, 0.05, bias_sub=bias, **kw)
+    A1 = A0.copy()
+    ops.optimizeA_explicit(A1, B, csr, 0.05, bias_sub=bias, weight=np.ones_like(w_csr), **kw)
+    if mode == "chol":       # (weighted Cholesky launches stay on the workgroup-per-row kernel: another summation order)
+        assert rel_err(A1, Au) < TOL[dtype]
+    else:
+        assert np.array_equal(A1, Au)
+    assert rel_err(Ah, Au) > 1e-3
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("vh", ["stream", "gram", "gram-slice"])
+def test_observation_weights_split_rows(oracles, dtype, vh, monkeypatch):
+    """The split rows' weights on each of their three paths: streamed per CG pass (entries re-sorted by index, the weights
+    with them), Gramian per slice from one wavefront, Gramian per slice from the LDS-staged workgroup kernel."""
+    from cmfrec_amd import ops
+    monkeypatch.setenv("CMFREC_HIP_VH", vh.split("-")[0])
+    if vh == "gram-slice":
+        monkeypatch.setenv("CMFREC_HIP_GRAM_KERNEL", "slice")
+    O = oracles[dtype]
+    m, n, k = 40, 6000, 33
+    row, col, val = make_coo(m, n, 9000, 43, counts=False, dtype=dtype, heavy_row=(3, 5200), empty_rows=(8,))
+    rng = np.random.default_rng(12)
+    extra_c = rng.choice(n, 2100, replace=False).astype(np.int32)
+    keep = row != 10
+    row = np.concatenate([row[keep], np.full(2100, 10, np.int32)]); col = np.concatenate([col[keep], extra_c])
+    val = np.concatenate([val[keep], (0.5 * rng.integers(1, 11, 2100)).astype(dtype)])
+    w = (0.2 + 2.5 * rng.random(len(row)) ** 2).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    w_csr = O.coo_to_csr_and_csc(row, col, w, m, n)[0][2]
+    wsum = _driver_wsum(csr[0], w_csr, dtype)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    ops.optimizeA_explicit(Ah, B, csr, 0.05, lam_last=0.3, scale_lam=True, weight=w_csr, wsum=wsum)
+    O.optimizeA_explicit(Ao, B, csr, 0.05, lam_last=0.3, scale_lam=True, nthreads=4, weight=w_csr, wsum=wsum)
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    check_rows(Ah, Ao, dtype)

@@ -183,3 +183,20 @@ def test_nan_side_info(oracles, dtype):
         got = gc.nan_side_oracle(oracles[dtype], d, implicit, which, sl, sls, solver=solver)
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_observation_weights(oracles, dtype):
+    """G17: fit_collective_explicit_als with weight != NULL (column-sorted entries, see golden_cases.weights_problem) -- the
+    cases the oracle restates (no side information, given start values)."""
+    g = gc.load("g17_weights", dtype)
+    d = gc.weights_problem(dtype)
+    seen = 0
+    for ci, (name, side, opts) in enumerate(gc.WEIGHT_CASES):
+        got = gc.weights_oracle(oracles[dtype], d, side, opts)
+        if got is None:
+            continue
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+        seen += 1
+    assert seen >= 5
