@@ -171,6 +171,41 @@ __global__ void gram_naive_kernel(const T *__restrict__ B, size_t ldb, int n, in
     out[ent] = s;
 }
 
+// out_part[b][c] = sum over the rows r of block b of (bias[r] + add) * M[r, c]  (rows in order, one thread per column):
+// first stage of the right-hand-side constant of the missing-as-zero half-steps (collective.c:8573-8600, :8756-8787)
+constexpr int COLSUM_ROWS = 256;
+template <typename T>
+__global__ void __launch_bounds__(256)
+weighted_colsum_partial_kernel(const T *__restrict__ M, size_t ld, int rows, int cols, const T *__restrict__ bias, T add,
+                               T *__restrict__ out_part)
+{
+    const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(rows, r0 + COLSUM_ROWS);
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        T acc = T(0);
+        for (int r = r0; r < r1; r++) acc += ((bias != nullptr ? bias[r] : T(0)) + add) * M[(size_t)r * ld + c];
+        out_part[(size_t)blockIdx.x * cols + c] = acc;
+    }
+}
+// out[c] = scale * sum_b part[b][c], blocks in order
+template <typename T>
+__global__ void colsum_finish_kernel(const T *__restrict__ part, int nblocks, int cols, T scale, T *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    T acc = T(0);
+    for (int b = 0; b < nblocks; b++) acc += part[(size_t)b * cols + c];
+    out[c] = scale * acc;
+}
+// M[r, c] += v[c] for the first `cols` columns of every row
+template <typename T>
+__global__ void add_rowvec_kernel(T *__restrict__ M, size_t ld, size_t rows, int cols, const T *__restrict__ v)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= rows * (size_t)cols) return;
+    const size_t r = e / cols; const int c = (int)(e % cols);
+    M[r * ld + c] += v[c];
+}
+
 template <typename T>
 __global__ void col_fill_kernel(T *__restrict__ M, size_t ld, int rows, int col, T value)
 {

@@ -517,8 +517,14 @@ int_t fit_collective_explicit_als(
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (Xfull || NA_as_zero_X || NA_as_zero_U || NA_as_zero_I)
-        return fail(verbose, "cmfrec_hip: dense X / NA_as_zero are not implemented.");
+    if (Xfull || NA_as_zero_U || NA_as_zero_I)
+        return fail(verbose, "cmfrec_hip: dense X / NA_as_zero_U / NA_as_zero_I are not implemented.");
+    // NA_as_zero_X (sparse X whose absent entries are zeros): the plain explicit model -- every half-step is optimizeA
+    // Case 3 (common.c:3118-3205: one shared matrix, closed form whatever use_cg says)
+    if (NA_as_zero_X && (weight || U || II || nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
+                         precompute_for_predictions || (scale_bias_const && (scale_lam || scale_lam_sideinfo) && (user_bias || item_bias))))
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without side information, weights, implicit "
+                             "features, nonneg / L1, scale_bias_const and without precompute_for_predictions.");
     // dense side information with NaN -> the sparse route on its centred present entries
     DenseNanSide nanU, nanI;
     const bool hadU = (U != nullptr);
@@ -627,7 +633,21 @@ int_t fit_collective_explicit_als(
     //      subtraction itself happens on the device while the CSR / CSC are built ----
     PhaseTimer tm;
     real_t gm = 0;
-    if (center && weight) {
+    if (center && NA_as_zero_X) {
+        // mean over all m x n cells: the mean of the entries x nnz / (m n) (common.c:3494-3523); the stored values stay as
+        // they are (:3600-3607), the mean enters every right-hand side instead (collective.c:8573-8600, :8756-8787)
+        double xsum = 0;
+        if (nthreads >= 8) {
+            for (size_t e = 0; e < nnz; e++) xsum += X[e];
+            gm = (real_t)(xsum / (double)nnz);
+        } else {
+            size_t cnt = 0;
+            for (size_t e = 0; e < nnz; e++) xsum += (X[e] - xsum) / (double)(++cnt);
+            gm = (real_t)xsum;
+        }
+        gm = (real_t)((long double)gm * ((long double)nnz / ((long double)m * (long double)n)));
+        if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
+    } else if (center && weight) {
         // weighted running mean, common.c:3574-3584.  (With 8 threads or more the reference divides the UNWEIGHTED sum of X by
         // the sum of the weights, :3561-3571 -- not a mean; that branch is not followed.)
         double xsum = 0, wsum = 2.220446049250313e-16;
@@ -693,7 +713,8 @@ int_t fit_collective_explicit_als(
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("start values + session");
     // X - mean, COO -> CSR + CSC and the bias start values are computed on the device (coo_device.hpp)
-    int rc = cmfrec_hip_session_set_X_coo_weighted(s, ixA, ixB, X, weight, nnz, gm, (real_t)1);
+    int rc = cmfrec_hip_session_set_X_coo_weighted(s, ixA, ixB, X, weight, nnz, NA_as_zero_X ? (real_t)0 : gm, (real_t)1);
+    if (!rc && NA_as_zero_X) rc = cmfrec_hip_session_set_NA_as_zero_X(s, 1, center ? 1 : 0, gm);
     tm.lap("set_X_coo (upload, sort, bins)");
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
@@ -709,6 +730,57 @@ int_t fit_collective_explicit_als(
     if (!rc && add_implicit_features) rc = cmfrec_hip_session_set_implicit_features(s, w_implicit, nullptr, nullptr);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("side info + factors upload");
+    if (!rc && has_bias && reset_values && NA_as_zero_X) {
+        // bias start values, missing-as-zero branches (common.c:4207-4237 one-sided; :4453-4476, :4693-4710, :4849-4868
+        // two-sided): O(nnz) running means per row and column, computed here on the host and handed over
+        real_t lam_u = lam6[0], lam_i = lam6[1];
+        if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
+        if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
+        auto scaled_means = [&](const int_t *ix, int_t rows, int_t other) {       // running mean of the row's entries (COO order) x cnt / other
+            std::vector<double> mean((size_t)rows, 0.); std::vector<size_t> cnt((size_t)rows, 0);
+            for (size_t e = 0; e < nnz; e++) { const size_t r = (size_t)ix[e]; mean[r] += ((double)X[e] - mean[r]) / (double)(++cnt[r]); }
+            std::vector<double> raw = mean;
+            for (int_t r = 0; r < rows; r++) mean[r] *= (double)cnt[r] / (double)other;
+            return std::make_tuple(mean, raw, cnt);
+        };
+        std::vector<real_t> bA((size_t)m_max, 0), bB((size_t)n_max, 0);
+        if (user_bias && item_bias) {
+            auto [meanA, rawA, cntA] = scaled_means(ixA, m, n);
+            auto [meanB, rawB, cntB] = scaled_means(ixB, n, m);
+            (void)rawA; (void)rawB; (void)cntA; (void)cntB;
+            const double fB = (double)m / ((double)m + (double)lam_i * (scale_lam ? (double)m : 1.));
+            const double fA = (double)n / ((double)n + (double)lam_u * (scale_lam ? (double)n : 1.));
+            for (int iter = 0; iter < 5; iter++) {
+                double bmean = 0;
+                // (the reference averages biasA over `row < n` here, common.c:4697-4698; past m it reads beyond the array)
+                if (iter > 0) for (int_t r = 0; r < std::min(m, n); r++) bmean += ((double)bA[r] - bmean) / (double)(r + 1);
+                for (int_t c = 0; c < n; c++) bB[c] = (real_t)((meanB[c] - bmean - (double)gm) * fB);
+                bmean = 0;
+                if (iter > 0) for (int_t c = 0; c < n; c++) bmean += ((double)bB[c] - bmean) / (double)(c + 1);
+                for (int_t r = 0; r < m; r++) bA[r] = (real_t)((meanA[r] - bmean - (double)gm) * fA);
+            }
+        } else if (user_bias || use_cg) {                                  // collective.c:8166-8204 (item bias alone: only with use_cg)
+            const bool users = user_bias;
+            const int_t rows = users ? m : n, other = users ? n : m;
+            auto [mean, raw, cnt] = scaled_means(users ? ixA : ixB, rows, other);
+            (void)mean;
+            const double lam_b = users ? (double)lam_u : (double)lam_i;
+            const double den = (double)other + lam_b * (scale_lam ? (double)other : 1.);
+            std::vector<real_t> &b = users ? bA : bB;
+            for (int_t r = 0; r < rows; r++) {
+                if (cnt[r] > 0) {
+                    double bm = raw[r];
+                    bm -= (double)gm / ((double)cnt[r] / (double)other);
+                    bm *= (double)cnt[r] / den;
+                    b[r] = (real_t)bm;
+                } else b[r] = (real_t)(-(double)gm / ((double)other / den));
+            }
+        }
+        if (user_bias || item_bias) {
+            memcpy(biasA, bA.data(), (size_t)m_max * sizeof(real_t)); memcpy(biasB, bB.data(), (size_t)n_max * sizeof(real_t));
+            rc = cmfrec_hip_session_set_factors(s, nullptr, nullptr, user_bias ? biasA : nullptr, item_bias ? biasB : nullptr, nullptr, nullptr);
+        }
+    } else
     if (!rc && has_bias && reset_values) {                                // common.c:4410-4909; lambdas clipped like :4449-4452
         real_t lam_u = lam6[0], lam_i = lam6[1];                          // collective.c:8178, :8197, :8218-8219
         if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;

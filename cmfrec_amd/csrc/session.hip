@@ -606,6 +606,12 @@ struct cmfrec_hip_session {
     // C, D -- after the w_main rescaling.  Scalar lam / l1_lam fill all six.
     real_t lam6[6] = {0, 0, 0, 0, 0, 0}, l16[6] = {0, 0, 0, 0, 0, 0};
     bool scale_bias_const = false;   // explicit model: the bias' lambda is not scaled row by row (lam6[0], [1] carry a constant factor)
+    // NA_as_zero for the main matrix (explicit model without side information): absent entries of X are zeros.  Every
+    // half-step is optimizeA Case 3 (common.c:3118-3205): one shared matrix, the stored values uncentred, and the constant
+    // -sum over all opposing rows of (their bias + naz_mean) x row on every right-hand side (collective.c:8573-8600, :8756-8787)
+    bool naz_X = false, naz_center = false;
+    real_t naz_mean = 0;
+    DevBuf<real_t> naz_part, naz_vec;
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
@@ -1206,6 +1212,13 @@ int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, 
     });
 }
 
+int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int center, real_t glob_mean)
+{
+    if (on && s->mdl.implicit) { g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: explicit model only"; return 2; }
+    s->naz_X = on != 0; s->naz_center = center != 0; s->naz_mean = glob_mean;
+    return 0;
+}
+
 int cmfrec_hip_session_set_scale_bias_const(cmfrec_hip_session *s, int on)
 {
     s->scale_bias_const = on != 0;
@@ -1301,8 +1314,64 @@ static bool launch_gsum(cmfrec_hip_session *s, bool isA, const SparseShard &X, c
     return true;
 }
 
+// One half-step of the explicit model with the main matrix missing-as-zero (see cmfrec_hip_session::naz_X)
+static int update_factor_naz(cmfrec_hip_session *s, bool isA)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    hipStream_t st = dev.stream;
+    if (m.p > 0 || m.q > 0 || s->implicit_feats || s->scale_bias_const || dev.nonneg_now || dev.l1_now != (real_t)0 ||
+        dev.l1_last_now != (real_t)0 || m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n ||
+        s->Xr.weighted() || m.k_user != 0 || m.k_item != 0) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X: only the plain explicit model on one device (no side information, weights, "
+                       "implicit features, nonneg / L1, scale_bias_const)";
+        return 2;
+    }
+    real_t *self = isA ? s->A.ptr : s->B.ptr;
+    real_t *opp = isA ? s->B.ptr : s->A.ptr;
+    const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
+    const int rows_opp = isA ? m.n : m.m, rows_self = isA ? m.m : m.n;
+    const SparseShard &X = isA ? s->Xr : s->Xc;
+    const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
+    const real_t lam_self = s->lam6[isA ? 2 : 3];
+    const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
+    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0);
+    if (self_bias) {                          // the opposing bias column is fixed to 1 (collective.c:8538-8543, :8728-8732)
+        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA,
+                           (real_t)1);
+    }
+    // shared matrix: opp^T opp + diag(lam .. lam, lam_last), x rows_opp under scale_lam (common.c:3128-3138)
+    const real_t mult = (m.scale_lam || m.scale_lam_sideinfo) ? (real_t)rows_opp : (real_t)1;
+    launch_gram(dev, s->gws, opp, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, lam_self * mult);
+    if (lam_last_self != lam_self)
+        hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3(1), dim3(64), 0, st, s->gram.ptr, ks, ks - 1, ks, (lam_last_self - lam_self) * mult);
+    // right-hand sides: sum_j x_j opp_j over the row's entries (tgemm_sp_dense, :3145-3151) ...
+    HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)ks * sizeof(real_t), (size_t)rows_self, st));
+    CholCall c{self, ld_self, opp, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
+    c.rhs_only = true;
+    int rc = launch_chol(dev, c, &X);
+    if (rc) return rc;
+    // ... plus the constant of the opposing biases and the mean (:3152-3157)
+    if (opp_bias || s->naz_center) {
+        const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
+        s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
+        const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
+        hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, opp, ld_opp, rows_opp, ks, bias,
+                           s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
+        hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
+        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self, ld_self, (size_t)rows_self, ks,
+                           s->naz_vec.ptr);
+    }
+    // one factorisation, all rows (with and without entries) through the triangular solves (:3171-3175)
+    hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, st, s->gram.ptr, ks);
+    HIP_CHECK(hipGetLastError());
+    launch_potrs_rows(dev, rows_self, ks, s->gram.ptr, self, ld_self);
+    return 0;
+}
+
 static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = -1)
 {
+    if (s->naz_X && !s->mdl.implicit) return update_factor_naz(s, isA);
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;

@@ -178,7 +178,7 @@ class CMF_implicit(_Base):
             *spU, *spI,
             C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), _lib.ptr(wmm),
-            R(self.alpha), C.c_bool(False),        # adjust_weight is always False (__init__.py:4753)
+            R(self.alpha), C.c_bool(bool(getattr(self, "_adjust_weight", False))),   # the reference's estimator always passes False (__init__.py:4753)
             C.c_bool(self.apply_log_transf), C.c_int(self.niter), C.c_int(self.nthreads),
             C.c_bool(self.verbose), C.c_bool(self.handle_interrupt), C.c_bool(self.use_cg),
             C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg), C.c_bool(self.finalize_chol),
@@ -258,8 +258,13 @@ class CMF(_Base):
                  n_jobs=None):
         if method != "als":
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
-        if NA_as_zero or NA_as_zero_user or NA_as_zero_item:
-            raise NotImplementedError("NA_as_zero is not implemented in cmfrec_amd")
+        if NA_as_zero_user or NA_as_zero_item:
+            raise NotImplementedError("NA_as_zero_user / NA_as_zero_item are not implemented in cmfrec_amd")
+        # NA_as_zero (absent entries of a sparse X are zeros): the model without side information; the matrices for predictions
+        # on new data are not produced (pass precompute_for_predictions=False)
+        self.NA_as_zero = bool(NA_as_zero)
+        if self.NA_as_zero and precompute_for_predictions:
+            raise NotImplementedError("NA_as_zero: precompute_for_predictions is not implemented in cmfrec_amd (pass False)")
         self.scale_bias_const = bool(scale_bias_const)
         if add_implicit_features and (nonneg or not np.isscalar(l1_lambda) or l1_lambda):
             raise NotImplementedError("add_implicit_features together with nonneg / l1_lambda is not implemented in "
@@ -339,7 +344,7 @@ class CMF(_Base):
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(self.scale_bias_const), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
-            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            C.c_bool(self.NA_as_zero), C.c_bool(False), C.c_bool(False),
             C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), R(self.w_implicit),
             C.c_int(self.niter), C.c_int(self.nthreads), C.c_bool(self.verbose), C.c_bool(self.handle_interrupt),

@@ -352,6 +352,12 @@ int cmfrec_hip_session_set_X_weighted(cmfrec_hip_session *s,
    reference converts on the host (src/helpers.c:1375-1491). */
 int cmfrec_hip_session_set_X_coo_device(cmfrec_hip_session *s, int which, const int_t *d_key, const int_t *d_other,
                                         const real_t *d_val, size_t nnz, real_t subtract, real_t alpha);
+/* NA_as_zero for the main matrix (explicit model, sparse X whose absent entries are zeros; plain model on one device): from
+ * here on every update('A' / 'B') is optimizeA Case 3 (src/common.c:3118-3205) -- one shared matrix opp^T opp + lambda (x rows
+ * under scale_lam), right-hand sides sum_j x_j opp_j over the row's entries plus the constant -sum over ALL opposing rows of
+ * (their bias + glob_mean [when center]) x row (src/collective.c:8573-8600, :8756-8787), one factorisation and a triangular
+ * solve for every row, with or without entries.  X must have been set uncentred. */
+int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int center, real_t glob_mean);
 /* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
  * _onesided (src/common.c:4410-4909, 4265-4289; call sites src/collective.c:8166-8220): written to the
  * session's bias vectors and the bias columns of A / B.  Call after set_X* and set_factors. */

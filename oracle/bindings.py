@@ -359,8 +359,10 @@ class Oracle:
                          scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,
                          w_user=1.0, w_item=1.0, niter=10, nthreads=1, use_cg=True, max_cg_steps=3,
                          precondition_cg=False, finalize_chol=True, init_biases=False, m=None, n=None,
-                         add_implicit_features=False, w_implicit=1.0, w_main=1.0, weight=None):
+                         add_implicit_features=False, w_implicit=1.0, w_main=1.0, weight=None, NA_as_zero_X=False):
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
+        if NA_as_zero_X:
+            self.lib.oracle_set_fit_NA_as_zero_X(C.c_bool(True))
         if weight is not None:
             weight = np.ascontiguousarray(weight, self.dtype)
             assert len(weight) == len(val)
@@ -684,7 +686,7 @@ class Reference:
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
                                     precompute=False, m=None, n=None, U_coo=None, I_coo=None, nonneg=False,
                                     nonneg_C=False, nonneg_D=False, max_cd_steps=100, l1_lam=0.0, lam_unique=None,
-                                    l1_lam_unique=None):
+                                    l1_lam_unique=None, adjust_weight=False):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
@@ -713,15 +715,15 @@ class Reference:
             *su[:4], *si[:4],
             C.c_bool(False), C.c_bool(False), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             self._r(w_main), self._r(w_user), self._r(w_item), _ptr(wmm),
-            self._r(alpha), C.c_bool(False), C.c_bool(apply_log_transf),
+            self._r(alpha), C.c_bool(adjust_weight), C.c_bool(apply_log_transf),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol),
             C.c_bool(nonneg), C.c_int(max_cd_steps), C.c_bool(nonneg_C), C.c_bool(nonneg_D),
             C.c_bool(precompute), _ptr(pre["BtB"]) if pre else None, _ptr(pre["BeTBe"]) if pre else None,
             _ptr(pre["BeTBeChol"]) if pre else None, _ptr(pre["CtUbias"]) if pre else None)
-        if U is None and II is None and not precompute and U_coo is None and I_coo is None:
+        if U is None and II is None and not precompute and U_coo is None and I_coo is None and not adjust_weight:
             return ret
-        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm, pre=pre)
+        return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm, pre=pre, w_main_multiplier=wmm[0])
 
     def fit_collective_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None,
                                     Dm=None, U=None, II=None, user_bias=True, item_bias=True,
@@ -731,7 +733,7 @@ class Reference:
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
                                     l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
-                                    l1_lam_unique=None, scale_bias_const=False, weight=None):
+                                    l1_lam_unique=None, scale_bias_const=False, weight=None, NA_as_zero_X=False):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II.
         weight: observation weights, one per entry of X."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
@@ -775,7 +777,7 @@ class Reference:
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],
-            C.c_bool(False), C.c_bool(False), C.c_bool(False),
+            C.c_bool(NA_as_zero_X), C.c_bool(False), C.c_bool(False),
             C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             self._r(w_main), self._r(w_user), self._r(w_item), self._r(w_implicit),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),

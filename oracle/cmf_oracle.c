@@ -613,10 +613,18 @@ void oracle_optimizeA_dense_full(real_t *A, size_t lda, const real_t *B, size_t 
 /* Missing-as-zero rows on an unweighted sparse matrix (optimizeA Case 3, common.c:3116-3205): one matrix
  * B^T B + lam (x n under scale_lam) for every row, right-hand sides X B (tgemm_sp_dense).  Xcsr == NULL: unit values
  * (the binary indicator the Ai / Bi updates of add_implicit_features run on, collective.c:8448-8534). */
+/* bias_BtX [k] (or NULL): the constant every row's right-hand side receives when the main matrix itself is missing-as-zero --
+ * minus the sum over ALL rows of B of (their bias + the global mean) x the row (common.c:3152-3157; built by the driver,
+ * collective.c:8573-8600, :8756-8787).  Cleared by the call. */
+static const real_t *g_naz_bias_BtX = NULL;
+void oracle_set_naz_bias_BtX(const real_t *bias_BtX) { g_naz_bias_BtX = bias_BtX; }
+
 void oracle_optimizeA_naz(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
                           const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
                           real_t lam, real_t lam_last, bool scale_lam, int nthreads)
 {
+    const real_t *bias_BtX = g_naz_bias_BtX;
+    g_naz_bias_BtX = NULL;
     if (nthreads < 1) nthreads = 1;
     real_t *BtB = (real_t *)malloc((size_t)k * k * sizeof(real_t));
     oracle_gram(B, ldb, n, k, BtB, nthreads);                                  /* :3128-3131 */
@@ -631,6 +639,7 @@ void oracle_optimizeA_naz(real_t *A, size_t lda, const real_t *B, size_t ldb, in
         memset(a, 0, (size_t)k * sizeof(real_t));                              /* :3139-3144 */
         for (size_t jx = Xcsr_p[ix]; jx < Xcsr_p[(size_t)ix + 1]; jx++)       /* :3145-3151 */
             axpy_(k, Xcsr ? Xcsr[jx] : (real_t)1, B + (size_t)Xcsr_i[jx] * ldb, a);
+        if (bias_BtX != NULL) axpy_(k, (real_t)1, bias_BtX, a);               /* :3152-3157 (multiplier_bias_BtX = 1) */
         if (cd) {
             real_t *Mc = (real_t *)malloc((size_t)k * k * sizeof(real_t));
             memcpy(Mc, BtB, (size_t)k * k * sizeof(real_t));
@@ -1087,6 +1096,70 @@ void oracle_initialize_biases_twosided_weighted(int_t m, int_t n,
     }
 }
 
+/* NA_as_zero_X of the next oracle_fit_explicit_als call (sparse X whose absent entries are zeros; model without side
+ * information, without weights; cleared by the call): the mean over all m x n cells (common.c:3517-3523), no centring of the
+ * stored values, bias start values of the missing-as-zero branches, every half-step through optimizeA Case 3 (one shared
+ * matrix, closed form whatever use_cg says) with the bias / mean correction of the right-hand side. */
+static bool g_fit_naz = false;
+void oracle_set_fit_NA_as_zero_X(bool on) { g_fit_naz = on; }
+
+/* initialize_biases_onesided, missing-as-zero without weights (common.c:4207-4237); mult: wsumA[row] = n under scale_lam
+ * (collective.c:8033-8036), else 1 */
+static void naz_biases_onesided(int_t m, int_t n, const size_t *p, const real_t *v, real_t glob_mean, real_t lam, bool scale_lam,
+                                real_t *bias)
+{
+    if (fabs_t(lam) < EPSILON_T) lam = EPSILON_T;
+    const double mult = scale_lam ? (double)n : 1.;
+    for (int_t row = 0; row < m; row++) {
+        double bmean = 0;
+        const size_t st = p[row], en = p[(size_t)row + 1];
+        for (size_t ix = st; ix < en; ix++) bmean += (v[ix] - bmean) / (double)(ix - st + 1);
+        bmean -= glob_mean / ((double)(en - st) / (double)n);
+        bmean *= (double)(en - st) / ((double)n + lam * mult);
+        bias[row] = (en > st) ? (real_t)bmean : (real_t)(-glob_mean / ((double)n / ((double)n + lam * mult)));
+    }
+}
+
+/* initialize_biases_twosided, missing-as-zero without weights (common.c:4453-4476, :4693-4710, :4849-4868).  The item sweep
+ * averages biasA over `row < n` (:4697-4698: the bound of the OTHER dimension); restated as written for n <= m, over the m
+ * users for n > m (where the reference reads past the array). */
+static void naz_biases_twosided(int_t m, int_t n, const size_t *pr, const real_t *vr, const size_t *pc, const real_t *vc,
+                                real_t glob_mean, real_t lam_user, real_t lam_item, bool scale_lam, bool nonneg,
+                                real_t *biasA, real_t *biasB)
+{
+    if (fabs_t(lam_user) < EPSILON_T) lam_user = EPSILON_T;
+    if (fabs_t(lam_item) < EPSILON_T) lam_item = EPSILON_T;
+    double *meanA = (double *)malloc((size_t)m * sizeof(double)), *meanB = (double *)malloc((size_t)n * sizeof(double));
+    for (int_t row = 0; row < m; row++) {
+        double xmean = 0;
+        for (size_t ix = pr[row]; ix < pr[(size_t)row + 1]; ix++) xmean += (vr[ix] - xmean) / (double)(ix - pr[row] + 1);
+        meanA[row] = xmean * ((double)(pr[(size_t)row + 1] - pr[row]) / (double)n);
+    }
+    for (int_t col = 0; col < n; col++) {
+        double xmean = 0;
+        for (size_t ix = pc[col]; ix < pc[(size_t)col + 1]; ix++) xmean += (vc[ix] - xmean) / (double)(ix - pc[col] + 1);
+        meanB[col] = xmean * ((double)(pc[(size_t)col + 1] - pc[col]) / (double)m);
+    }
+    memset(biasA, 0, (size_t)m * sizeof(real_t));
+    memset(biasB, 0, (size_t)n * sizeof(real_t));
+    const int niter = nonneg ? 15 : 5;
+    for (int iter = 0; iter < niter; iter++) {
+        double bmean = 0;
+        if (iter > 0) for (int_t row = 0; row < ((n < m) ? n : m); row++) bmean += (biasA[row] - bmean) / (double)(row + 1);
+        for (int_t col = 0; col < n; col++) {
+            biasB[col] = (real_t)((meanB[col] - bmean - glob_mean) * ((double)m / ((double)m + lam_item * (scale_lam ? (double)m : 1.))));
+            if (nonneg && !(biasB[col] >= 0)) biasB[col] = 0;
+        }
+        bmean = 0;
+        if (iter > 0) for (int_t col = 0; col < n; col++) bmean += (biasB[col] - bmean) / (double)(col + 1);
+        for (int_t row = 0; row < m; row++) {
+            biasA[row] = (real_t)((meanA[row] - bmean - glob_mean) * ((double)n / ((double)n + lam_user * (scale_lam ? (double)n : 1.))));
+            if (nonneg && !(biasA[row] >= 0)) biasA[row] = 0;
+        }
+    }
+    free(meanA); free(meanB);
+}
+
 /* observation weights of the next oracle_fit_explicit_als call (COO order; cleared by the call) */
 static const real_t *g_fit_weight = NULL;
 void oracle_set_fit_weights(const real_t *weight) { g_fit_weight = weight; }
@@ -1282,6 +1355,9 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
 {
     const real_t *weight = g_fit_weight;
     g_fit_weight = NULL;
+    const bool naz = g_fit_naz;
+    g_fit_naz = false;
+    if (naz && (U != NULL || II != NULL || (Ai != NULL && Bi != NULL) || weight != NULL || g_scale_bias_const)) return 2;
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
@@ -1294,7 +1370,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     const int_t m_x = m, n_x = n;
     if (m_u > m) m = m_u;
     if (n_i > n) n = n_i;
-    if (init_biases && (user_bias != item_bias)) return 2;
+    if (init_biases && (user_bias != item_bias) && !naz) return 2;
     const bool imp = (Ai != NULL && Bi != NULL);
     if (imp && (m_u > m_x || n_i > n_x)) return 2;
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
@@ -1317,7 +1393,18 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
 
     real_t *Xc = (real_t *)malloc(nnz * sizeof(real_t));
     memcpy(Xc, X, nnz * sizeof(real_t));
-    if (weight != NULL) *glob_mean = center ? oracle_calc_mean_and_center_weighted(Xc, weight, nnz) : (real_t)0;
+    if (naz) {                                                                 /* common.c:3494-3523, :3600-3607: X stays as it is */
+        *glob_mean = 0;
+        if (center) {
+            double xsum = 0;
+            if (nthreads >= 8) { for (size_t ix = 0; ix < nnz; ix++) xsum += Xc[ix]; *glob_mean = (real_t)(xsum / (double)nnz); }
+            else { size_t cnt = 0; for (size_t ix = 0; ix < nnz; ix++) xsum += (Xc[ix] - xsum) / (double)(++cnt); *glob_mean = (real_t)xsum; }
+            *glob_mean = (real_t)((long double)(*glob_mean) * ((long double)nnz / ((long double)m * (long double)n)));
+            if (g_nn_AB) *glob_mean = (*glob_mean > 0) ? *glob_mean : (real_t)0;
+            if (fabs_t(*glob_mean) < sqrt_t(EPSILON_T)) *glob_mean = 0;
+        }
+    }
+    else if (weight != NULL) *glob_mean = center ? oracle_calc_mean_and_center_weighted(Xc, weight, nnz) : (real_t)0;
     else
     *glob_mean = center ? oracle_calc_mean_and_center(Xc, nnz, nthreads) : (real_t)0;  /* :7552-7568 */
     size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));
@@ -1381,6 +1468,17 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         }
     }
     if (scale_lam_sideinfo) { g_init_p = (U != NULL) ? p : 0; g_init_rows_u = m_u; g_init_q = (II != NULL) ? q : 0; g_init_cols_i = n_i; }
+    if (has_bias && init_biases && naz) {                                      /* :8164-8226, missing-as-zero branches */
+        if (user_bias && item_bias)
+            naz_biases_twosided(m, n, csr_p, csr_v, csc_p, csc_v, *glob_mean, lamAl, lamBl, scale_lam, g_nn_AB, biasA, biasB);
+        else if (user_bias) naz_biases_onesided(m, n, csr_p, csr_v, *glob_mean, lamAl, scale_lam, biasA);
+        else if (use_cg) naz_biases_onesided(n, m, csc_p, csc_v, *glob_mean, lamBl, scale_lam, biasB);   /* :8187 only with use_cg_B */
+        if (g_nn_AB && (user_bias != item_bias)) {
+            if (user_bias) for (int_t r = 0; r < m; r++) biasA[r] = (biasA[r] >= 0) ? biasA[r] : 0;
+            else for (int_t c = 0; c < n; c++) biasB[c] = (biasB[c] >= 0) ? biasB[c] : 0;
+        }
+    }
+    else
     if (has_bias && init_biases && weight != NULL)
         oracle_initialize_biases_twosided_weighted(m, n, csr_p, csr_i, csr_v, weightR, csc_p, csc_i, csc_v, weightC,
                                                    user_bias ? lamAl : lam, item_bias ? lamBl : lam, wsumA, wsumB, biasA, biasB);
@@ -1421,7 +1519,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         g_nonneg = g_nn_AB; g_l1 = l1B; g_l1_last = l1Bl; g_l1_last_set = true;
         if (item_bias)                                                         /* :8538-8543 */
             for (int_t r = 0; r < m; r++) A_bias[(size_t)r * ldA + k_totA] = 1;
-        if (user_bias)                                                         /* :8566-8570 */
+        if (user_bias && !naz)                                                 /* :8566-8570 */
             for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
         g_cg_Bi = imp ? Ai : NULL; g_cg_ki = k + k_main; g_cg_wimp = w_implicit;
         if ((II != NULL || imp) && use_cg)                                     /* :8634-8678 */
@@ -1433,6 +1531,18 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                              k, k_main + (int_t)item_bias, k_item, k_user,
                                              csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Ai : NULL, k_main, w_implicit);
+        else if (naz) {                                                        /* :8573-8600 + optimizeA Case 3 */
+            const int_t ks = k + k_main + (int_t)item_bias;
+            real_t *btx = NULL;
+            if (user_bias || center) {
+                btx = (real_t *)calloc((size_t)ks, sizeof(real_t));
+                for (int_t r = 0; r < m; r++)
+                    axpy_(ks, -((user_bias ? biasA[r] : (real_t)0) + (center ? *glob_mean : (real_t)0)), A_bias + k_user + (size_t)r * ldA, btx);
+            }
+            oracle_set_naz_bias_BtX(btx);
+            oracle_optimizeA_naz(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m, ks, csc_p, csc_i, csc_v, lamB, lamBl, scale_lam, nthreads);
+            free(btx);
+        }
         else {                                                                 /* :8680-8717 */
             oracle_set_row_weights(weightC, wsumB);
             oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
@@ -1454,7 +1564,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         if (user_bias)                                                         /* :8728-8732 */
             for (int_t c = 0; c < n; c++) B_bias[(size_t)c * ldB + k_totB] = 1;
         g_l1 = l1A; g_l1_last = l1Al;
-        if (item_bias)                                                         /* :8750-8754 */
+        if (item_bias && !naz)                                                 /* :8750-8754 */
             for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
         g_cg_Bi = imp ? Bi : NULL;
         if ((U != NULL || imp) && use_cg)                                      /* :8805-8845 */
@@ -1466,6 +1576,18 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                              k, k_main + (int_t)user_bias, k_user, k_item,
                                              csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Bi : NULL, k_main, w_implicit);
+        else if (naz) {                                                        /* :8756-8787 + optimizeA Case 3 */
+            const int_t ks = k + k_main + (int_t)user_bias;
+            real_t *btx = NULL;
+            if (item_bias || center) {
+                btx = (real_t *)calloc((size_t)ks, sizeof(real_t));
+                for (int_t c = 0; c < n; c++)
+                    axpy_(ks, -((item_bias ? biasB[c] : (real_t)0) + (center ? *glob_mean : (real_t)0)), B_bias + k_item + (size_t)c * ldB, btx);
+            }
+            oracle_set_naz_bias_BtX(btx);
+            oracle_optimizeA_naz(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n, ks, csr_p, csr_i, csr_v, lamA, lamAl, scale_lam, nthreads);
+            free(btx);
+        }
         else {                                                                 /* :8847-8876 */
             oracle_set_row_weights(weightR, wsumA);
             oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,

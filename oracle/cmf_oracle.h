@@ -71,6 +71,14 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
  * wsum[m] = the driver's lambda multipliers under scale_lam (wsumA, collective.c:7978-8008), or NULL: the row's own sum
  * (common.c:696-707).  Cleared by the call. */
 void oracle_set_row_weights(const real_t *weights_csr_order, const real_t *wsum);
+/* NA_as_zero_X of the oracle_fit_explicit_als call that follows (sparse X, absent = zero; model without side information and
+ * without weights, returns 2 otherwise): mean over all m x n cells (common.c:3517-3523), missing-as-zero bias start values
+ * (common.c:4207-4237, :4453-4476, :4693-4710, :4849-4868), half-steps through optimizeA Case 3 (common.c:3118-3205) with the
+ * right-hand-side constant of the driver (collective.c:8573-8600, :8756-8787).  Cleared by the call. */
+void oracle_set_fit_NA_as_zero_X(bool on);
+/* bias_BtX[k] of the oracle_optimizeA_naz call that follows (common.c:3152-3157).  Cleared by the call. */
+void oracle_set_naz_bias_BtX(const real_t *bias_BtX);
+
 /* Observation weights (COO order) of the oracle_fit_explicit_als call that follows: weighted mean (common.c:3574-3584),
  * weightR / weightC, wsumA / wsumB, weighted bias start values (common.c:4672-4692, :4826-4847), weighted row solvers.  Model
  * without side information only (returns 2 otherwise).  Cleared by the call. */

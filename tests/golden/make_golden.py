@@ -283,6 +283,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g17_weights_" + tag, **out)
 
+        # ---- G18: NA_as_zero for the main matrix ----
+        out = {}
+        d = gc.naz_problem(dt)
+        for ci, (name, opts) in enumerate(gc.NAZ_CASES):
+            r = gc.naz_reference(R, d, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g18_na_as_zero_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -828,3 +828,90 @@ def weights_hip(d, side, opts, dtype, weights=True):
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     return out
+
+
+# ---- NA_as_zero for the main matrix (CMF(NA_as_zero=True); fit_collective_explicit_als with NA_as_zero_X) -------------------
+def naz_problem(dtype, seed=91):
+    d = nonneg_problem(dtype, seed)
+    rng = np.random.default_rng(seed + 1)
+    keep = d["col"] != 7                                  # a column without entries next to the rows (4, 120) without
+    d["row"], d["col"], d["ratings"] = d["row"][keep], d["col"][keep], d["ratings"][keep]
+    d["A0"] = (rng.standard_normal((d["m"], d["k"])) * 0.1).astype(dtype); d["B0"] = (rng.standard_normal((d["n"], d["k"])) * 0.1).astype(dtype)
+    return d
+
+
+# (name, options).  seed: the reference's own random start + its missing-as-zero bias start values (m > n here, where the
+# item sweep's average over the wrong bound stays inside the array)
+NAZ_CASES = [
+    ("chol, biases", dict(use_cg=False)),
+    ("cg asked for, scale_lam", dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    ("no biases", dict(use_cg=False, user_bias=False, item_bias=False)),
+    ("no centring, user bias, scale_lam", dict(use_cg=False, center=False, item_bias=False, scale_lam=True)),
+    ("item bias, k_main", dict(use_cg=False, user_bias=False, k_main=2)),
+    ("no biases, no centring", dict(use_cg=False, user_bias=False, item_bias=False, center=False)),
+    ("per-matrix lambdas", dict(use_cg=False, lam_unique=LAM6)),
+    ("seeded, both biases", dict(use_cg=False, scale_lam=True, seed=5)),
+    ("seeded, user bias", dict(use_cg=False, item_bias=False, seed=6)),
+    ("seeded, item bias (cg asked for)", dict(use_cg=True, finalize_chol=False, user_bias=False, scale_lam=True, seed=7)),
+]
+
+
+def naz_reference(R, d, opts, nthreads=2):
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    A0, B0 = _impf_start(d, o)
+    kw = dict(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+    if seed is not None:
+        A0[:] = 0; B0[:] = 0
+        r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], lam=0.3, niter=3, nthreads=nthreads,
+                                          NA_as_zero_X=True, reset_values=True, seed=seed, **kw)
+    else:
+        r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                          lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, **kw)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_oracle(O, d, opts, nthreads=2):
+    """None for the seeded cases (the oracle has no random start)."""
+    o = dict(opts)
+    if "seed" in o:
+        return None
+    lam6 = o.pop("lam_unique", None)
+    if lam6 is not None:
+        O.set_lam_unique(np.asarray(lam6, np.float64), None)
+    try:
+        A0, B0 = _impf_start(d, o)
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                               niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
+                               finalize_chol=o.pop("finalize_chol", False), **o)
+    finally:
+        O.set_lam_unique(None, None)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if opts.get("user_bias", True): out["biasA"] = r["biasA"]
+    if opts.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_hip(d, opts, dtype, NA_as_zero=True):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    if "lam_unique" in o:
+        o["lambda_"] = o.pop("lam_unique")
+    else:
+        o["lambda_"] = 0.3
+    A0, B0 = _impf_start(d, o)
+    mdl = CMF(k=d["k"], niter=3, use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=NA_as_zero,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1,
+              **(dict(random_state=seed) if seed is not None else {}), **o)
+    start = {} if seed is not None else dict(A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    mdl.fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]), **start)
+    out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out

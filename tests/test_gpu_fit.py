@@ -365,3 +365,33 @@ def test_factors_multiple_after_fit(oracles, dtype, side):
     if side:
         kw.update(Cm=mi.C_, U=U2, U_colmeans=mi._U_colmeans)
     assert gc.maxrel(A, O.factors_implicit_multiple(**kw)) < t
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("side", [False, True])
+def test_implicit_adjust_weight_matches_reference(dtype, side):
+    """adjust_weight of the implicit model (collective.c:9776-9811): w_main is multiplied by nnz / (m n), which rescales lambda
+    and the side-information weights; the multiplier is an output.  Seeded like the reference."""
+    from oracle.bindings import Reference, ref_available
+    if not ref_available(dtype):
+        pytest.skip("oracle/_ref not built")
+    from cmfrec_amd import CMF_implicit
+    R = Reference(dtype)
+    m, n, k = 600, 400, 16
+    row, col, val = make_coo(m, n, 15000, 37, counts=True, dtype=dtype)
+    rng = np.random.default_rng(9)
+    U = rng.standard_normal((m, 5)).astype(dtype) if side else None
+    II = rng.standard_normal((n, 4)).astype(dtype) if side else None
+    mdl = CMF_implicit(k=k, lambda_=2.0, niter=2, random_state=31, use_float=dtype is np.float32, nthreads=1, use_cg=False,
+                       w_user=3.0, w_item=0.5, precompute_for_predictions=False)
+    mdl._adjust_weight = True
+    mdl.fit((row, col, val), U=U, I=II, shape=(m, n))
+    Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+    rr = R.fit_collective_implicit_als(Ar, Br, row, col, val, k, lam=2.0, niter=2, nthreads=2, reset_values=True, seed=31, use_cg=False,
+                                       U=U, II=II, w_user=3.0, w_item=0.5, adjust_weight=True)
+    t = 1e-6 if dtype is np.float64 else 1e-2
+    assert abs(mdl._w_main_multiplier - len(val) / (m * n)) < 1e-6 and abs(mdl._w_main_multiplier - float(rr["w_main_multiplier"])) < 1e-7
+    assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t
+    plain = CMF_implicit(k=k, lambda_=2.0, niter=2, random_state=31, use_float=dtype is np.float32, nthreads=1, use_cg=False,
+                         w_user=3.0, w_item=0.5, precompute_for_predictions=False).fit((row, col, val), U=U, I=II, shape=(m, n))
+    assert frob(plain.A_, Ar) > 1e-2

@@ -287,3 +287,30 @@ def test_observation_weights(oracles, dtype):
     for bad in (dict(scale_lam_sideinfo=True), dict(add_implicit_features=True, use_cg=False), dict(scale_lam=True, scale_bias_const=True)):
         with pytest.raises(RuntimeError):
             gc.weights_hip(d, True, bad, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X(oracles, dtype):
+    """G18 through the estimator (CMF(NA_as_zero=True)): the mean over all cells, one shared matrix per half-step, the
+    right-hand-side constant of the opposing biases and the mean, rows and columns without entries solved like the others,
+    the missing-as-zero bias start values on the reference's seeded start."""
+    g = gc.load("g18_na_as_zero", dtype)
+    d = gc.naz_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, opts) in enumerate(gc.NAZ_CASES):
+        got = gc.naz_hip(d, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        ref = gc.naz_oracle(oracles[dtype], d, opts)
+        if ref is not None:
+            assert gc.compare_fits(got, ref) < tol, name
+    # rows / columns without entries are solved too (the reference's Case 3 runs over all of them)
+    got = gc.naz_hip(d, gc.NAZ_CASES[0][1], dtype)
+    assert np.abs(got["A"][4]).max() > 0 and np.abs(got["B"][7]).max() > 0
+    # ... and the option changes the model
+    assert gc.compare_fits(gc.naz_hip(d, gc.NAZ_CASES[0][1], dtype, NA_as_zero=False), {k[3:]: g[k] for k in g.files if k.startswith("c0_")}) > 1e-2
+    from cmfrec_amd import CMF
+    with pytest.raises(NotImplementedError):
+        CMF(NA_as_zero=True)                          # precompute_for_predictions defaults to True
+    with pytest.raises(RuntimeError):
+        CMF(k=4, NA_as_zero=True, precompute_for_predictions=False, nonneg=True).fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]))

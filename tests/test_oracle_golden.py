@@ -200,3 +200,19 @@ def test_observation_weights(oracles, dtype):
         assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
         seen += 1
     assert seen >= 5
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_X(oracles, dtype):
+    """G18: fit_collective_explicit_als with NA_as_zero_X on sparse X -- the cases with given start values."""
+    g = gc.load("g18_na_as_zero", dtype)
+    d = gc.naz_problem(dtype)
+    seen = 0
+    for ci, (name, opts) in enumerate(gc.NAZ_CASES):
+        got = gc.naz_oracle(oracles[dtype], d, opts)
+        if got is None:
+            continue
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+        seen += 1
+    assert seen >= 6

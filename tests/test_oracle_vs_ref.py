@@ -476,3 +476,52 @@ def test_reference_weight_defects(refs):
         b = fit(row, col, (x - a["glob_mean"]).astype(x.dtype), w, use_cg=use_cg, finalize_chol=False, center=False, **side)
         e = rel_err(a["A"], b["A"])
         assert (e > 1e-2) if differs else (e < 1e-10), (use_cg, e)
+
+
+# ---- NA_as_zero for the main matrix (sparse X whose absent entries are zeros), model without side information ----------------
+NAZ_CASES = [
+    ("chol, biases", dict(use_cg=False)),
+    ("cg asked for (closed form all the same), scale_lam", dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    ("no biases", dict(use_cg=False, user_bias=False, item_bias=False)),
+    ("no centring, user bias", dict(use_cg=False, center=False, item_bias=False, scale_lam=True)),
+    ("item bias, k_main", dict(use_cg=False, user_bias=False, k_main=2)),
+    ("no biases, no centring", dict(use_cg=False, user_bias=False, item_bias=False, center=False)),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(310, 190), (150, 230)])
+def test_NA_as_zero_fit_live(oracles, refs, dtype, shape):
+    """fit_collective_explicit_als with NA_as_zero_X on sparse X: mean over all cells, optimizeA Case 3 (one shared matrix) with
+    the bias / mean constant of the right-hand side, rows and columns without entries solved like the others; the bias start
+    values (one- and two-sided, missing-as-zero branches) after zero iterations of a seeded reference fit.  Both m > n and
+    n > m (the item sweep of the two-sided start values averages the user biases over the wrong bound: see the oracle)."""
+    O, R = oracles[dtype], refs[dtype]
+    m, n = shape
+    row, col, val = make_coo(m, n, 5000, 75, counts=False, dtype=dtype, heavy_row=(3, 120), empty_rows=(5, 17))
+    keep = col != 11                                     # a column without entries
+    row, col, val = row[keep], col[keep], val[keep]
+    k = 12
+    rng = np.random.default_rng(11)
+    for name, o in NAZ_CASES:
+        o = dict(o)
+        km = o.get("k_main", 0)
+        A0 = (rng.standard_normal((m, k + km)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k + km)) * 0.1).astype(dtype)
+        bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+        ro = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), lam=0.4, niter=3, nthreads=2,
+                                NA_as_zero_X=True, **o)
+        rr = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), lam=0.4, niter=3,
+                                           nthreads=2, NA_as_zero_X=True, **o)
+        assert ro["ret"] == 0 and rr["ret"] == 0, name
+        keys = ("A", "B") + (("biasA",) if o.get("user_bias", True) else ()) + (("biasB",) if o.get("item_bias", True) else ())
+        for key in keys:
+            assert rel_err(ro[key], rr[key]) < 100 * TOL[dtype], (name, key)
+        assert abs(ro["glob_mean"] - rr["glob_mean"]) < 1e-6 * max(1.0, abs(rr["glob_mean"])), name
+        ub, ib = o.get("user_bias", True), o.get("item_bias", True)
+        if (ub or ib) and not (ib and not ub and not o["use_cg"]) and not (ub and ib and n > m):
+            r0 = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, lam=0.4, niter=0, nthreads=2, NA_as_zero_X=True,
+                                               reset_values=True, seed=3, **o)
+            o0 = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, lam=0.4, niter=0, nthreads=2, NA_as_zero_X=True,
+                                    init_biases=True, **o)
+            for key in (("biasA",) if ub else ()) + (("biasB",) if ib else ()):
+                assert np.abs(o0[key]).max() > 1e-3 and rel_err(o0[key], r0[key]) < 100 * TOL[dtype], (name, key)
