@@ -675,6 +675,15 @@ def c5_shard(args, device):
                       "ms_per_iteration": round(dt * 1e3, 2), "rows_per_s": round((m + n) / dt, 1),
                       "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)},
                       "alg_TFLOP": round(flops / 1e12, 2), "TFLOPs": round(flops / dt / 1e12, 1),
+                      # the item step on its own flops (every item row is a full k_t x k_t system: rank-k update + factorisation);
+                      # the user step runs the low-rank path and does far fewer flops than the formula above charges it
+                      "item_step": (lambda fl, ms: {"TFLOP": round(fl / 1e12, 3), "ms": round(ms, 2), "TFLOPs": round(fl / ms / 1e9, 1),
+                                                    "frac_of_fp32_matrix_peak_157": round(fl / ms / 1e9 / 157.0, 3)})(
+                          nnz * kt * (kt + 1) + n * (kt ** 3 / 3.0), msB / max(cB, 1)),
+                      "user_step_ms": round(msA / max(cA, 1), 2),
+                      # how the item rows split between the low-rank kernels (<= 128 entries) and the full factorisation
+                      "item_rows": (lambda cnt: {"le128": int((cnt <= 128).sum()), "full": int((cnt > 128).sum()),
+                                                 "nnz_full": int(cnt[cnt > 128].sum()), "max": int(cnt.max())})(np.bincount(col, minlength=n)),
                       "gen_seconds": round(t_gen, 1), "steps": steps,
                       "finite": bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all() and np.isfinite(f["C"]).all()),
                       "note": "side measurement, not the headline metric"}))

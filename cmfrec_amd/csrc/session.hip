@@ -8,6 +8,7 @@
 #include "device.hpp"
 #include "coo_device.hpp"
 #include "chol_wave_kernels.hpp"
+#include "gramk_kernels.hpp"
 #include "lowrank_kernels.hpp"
 #include <dlfcn.h>
 #include <functional>
@@ -257,6 +258,85 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             return rc_heavy;
         }
     }
+#ifdef CMFREC_HIP_FLOAT
+    {
+        // 17-block rows (k_t = 257 .. 272, config 5's item step): the rank-k update by gramk_producer_kernel (four independent
+        // wavefronts per row or slice, operands straight from the gather), the partial matrices through HBM, the factorisation
+        // by the row kernel below.  CMFREC_HIP_GRAMK=0 keeps the row kernel's own LDS-staged rank-k loop (A/B switch and
+        // cross-check).
+        const char *gk_env = getenv("CMFREC_HIP_GRAMK");
+        const bool gk_ok = X != nullptr && T == 17 && !two_src && c.koff == 0 && !weighted && !c.rhs_only && c.values_override == nullptr &&
+                           (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && !nonneg && !l1on && !(gk_env != nullptr && gk_env[0] == '0');
+        if (gk_ok) {
+            DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+            const int total = P.nrows;
+            const int n_heavy = std::min(X->bin_rows[BIN_VHEAVY], total);
+            const int nsl = n_heavy > 0 ? X->n_slices : 0;
+            CholSlices<real_t> SLT;
+            if (n_heavy > 0) {
+                SLT.vrow = X->sl_vrow.ptr; SLT.first = X->sl_first.ptr; SLT.count = X->sl_count.ptr; SLT.row_off = X->row_sl_off.ptr;
+            }
+            SLT.n_slices = nsl; SLT.n_heavy = n_heavy;
+            const std::vector<int> &ho = X->h_row_sl_off;
+            int max_row_items = 1;
+            for (int r = 0; r < n_heavy; r++) max_row_items = std::max(max_row_items, ho[r + 1] - ho[r]);
+            const int batch_env = getenv("CMFREC_HIP_GRAMK_BATCH") ? atoi(getenv("CMFREC_HIP_GRAMK_BATCH")) : 0;
+            const int BATCH = batch_env > 0 ? batch_env : 32768;                      // x 158 KB = 5.2 GB of partials
+            const size_t cap_items = (size_t)std::min<long long>((long long)nsl + (total - n_heavy), std::max(BATCH, max_row_items));
+            if (X->chol_part.n < cap_items * GK_PART) X->chol_part.alloc(cap_items * GK_PART);
+            SLT.part = X->chol_part.ptr;
+            // the launch's initial matrices once, in the tile layout of the partials (the consumer adds them like a partial)
+            const real_t *init1 = nullptr, *init2 = nullptr;
+            {
+                const size_t tl = (size_t)GK_NT * 256;
+                if (c.Mfull != nullptr || (c.Minit != nullptr && c.kc > 0)) d.tile_init.alloc_at_least(2 * tl);
+                if (c.Mfull != nullptr) {
+                    hipLaunchKernelGGL(tile_pack_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, c.Mfull, c.kt, GK_NB,
+                                       d.tile_init.ptr);
+                    init1 = d.tile_init.ptr;
+                }
+                if (c.Minit != nullptr && c.kc > 0) {
+                    hipLaunchKernelGGL(tile_pack_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, c.Minit, c.kc, GK_NB,
+                                       d.tile_init.ptr + tl);
+                    init2 = d.tile_init.ptr + tl;
+                }
+            }
+            int ctr = 4, rc_all = 0;
+            auto run_batch = [&](int item0, int item1, int row0, int row1) {
+                if (ctr + 2 > 60) ctr = 4;
+                HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr + ctr, 0, 2 * sizeof(int), dev.stream));
+                CholSlices<real_t> SL = SLT;
+                SL.part_base = item0;
+                CholParams<real_t> W = P;
+                W.row_first = item0; W.nrows = item1; W.counter = dev.row_counter.ptr + ctr;
+                if (item1 > item0) {
+                    poison_lds(dev.stream, dev.num_cus);
+                    hipLaunchKernelGGL(gramk_producer_kernel<real_t>, dim3(std::min(item1 - item0, dev.num_cus)), dim3(256), 0, dev.stream, W,
+                                       X->desc.ptr, SL);
+                    HIP_CHECK(hipGetLastError());
+                }
+                CholParams<real_t> H = P;
+                H.row_first = row0; H.nrows = row1; H.counter = dev.row_counter.ptr + ctr + 1;
+                H.gk_part = X->chol_part.ptr; H.gk_row_off = X->row_sl_off.ptr; H.gk_n_heavy = n_heavy; H.gk_n_slices = nsl; H.gk_base = item0;
+                H.gk_stride = (size_t)GK_PART; H.gk_init1 = init1; H.gk_init2 = init2;
+                const int rc1 = launch_chol_rows(dev, c, X, H, two_src, smem_nonneg);
+                if (rc1) rc_all = rc1;
+                ctr += 2;
+            };
+            for (int r = 0; r < n_heavy;) {                 // split rows: whole rows per batch
+                int r1 = r + 1;
+                while (r1 < n_heavy && ho[r1 + 1] - ho[r] <= (int)cap_items) r1++;
+                run_batch(ho[r], ho[r1], r, r1);
+                r = r1;
+            }
+            for (int r = n_heavy; r < total; r += (int)cap_items) {   // the others: item n_slices + i <-> position n_heavy + i
+                const int r1 = (int)std::min<long long>(total, (long long)r + (long long)cap_items);
+                run_batch(nsl + (r - n_heavy), nsl + (r1 - n_heavy), r, r1);
+            }
+            return rc_all;
+        }
+    }
+#endif
     return launch_chol_rows(dev, c, X, P, two_src, smem_nonneg);
 }
 
@@ -276,8 +356,8 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
             HIP_CHECK(hipDeviceSynchronize());
             HIP_CHECK(hipMemcpy(h, d_ticks, sizeof(h), hipMemcpyDeviceToHost));
             if (h[5] > 0)
-                fprintf(stderr, "chol_rows ticks/row: setup %.0f rank-k %.0f init %.0f factor %.0f back %.0f  (rows %llu, nnz/row %.0f)\n",
-                        (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], h[5],
+                fprintf(stderr, "chol_rows ticks/row: setup %.0f rank-k|trailing %.0f init %.0f diag+wait %.0f panel %.0f back %.0f  (rows %llu, nnz/row %.0f)\n",
+                        (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[7] / h[5], (double)h[4] / h[5], h[5],
                         (double)h[6] / h[5]);
             HIP_CHECK(hipMemset(d_ticks, 0, sizeof(h)));
         }
@@ -296,6 +376,18 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
         poison_lds(run_on, dev.num_cus);          // test hook, device.hpp
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, run_on, P);
     };
+#ifdef CMFREC_HIP_FLOAT
+    if (P.gk_part != nullptr) {
+        // consumer of the producer's partial matrices (launch_chol, 17 blocks): initial matrix, factorisation, solve.
+        // CMFREC_HIP_GRAMK_CONS: 16 (sixteen wavefronts, one row per CU), 8 (eight wavefronts, two rows per CU)
+        const char *ce = getenv("CMFREC_HIP_GRAMK_CONS");
+        const int cons = ce ? atoi(ce) : 16;
+        if (cons == 8) launch(chol_rows_kernel<real_t, 17, 8, 16, 2, false, true>, 17, 8, 16, 2);
+        else launch(chol_rows_kernel<real_t, 17, 16, 16, 1, false, true>, 17, 16, 16, 1);
+        HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+#endif
     // <16-blocks per dimension, wavefronts per workgroup, gathered rows per round, waves per SIMD>
     if (T <= 4) {
         // k_t <= 64: the whole system is 10 tiles.  Rows of 129 non-zeros and more (they lead the processing order) get

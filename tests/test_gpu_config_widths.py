@@ -82,10 +82,17 @@ def test_c3_width_explicit_double(oracles):
 
 
 @pytest.mark.parametrize("side", ["users", "items"])
-def test_c5_width_collective_single(oracles, side):
+@pytest.mark.parametrize("gramk", ["default", "off", "batch7"])
+def test_c5_width_collective_single(oracles, side, gramk, monkeypatch):
     """k = 256 + bias, 512-dimensional side information, fp32.  users: ~20 entries per row (nnz << k_t);
-    items: hundreds to thousands of entries per row."""
+    items: hundreds to thousands of entries per row.  gramk: the rank-k update by the four-wavefront producer kernel with
+    the partial matrices through HBM (default; split rows arrive as several partials), by the row kernel's own LDS-staged
+    loop (off), and the producer in batches of 7 work items."""
     from cmfrec_amd import ops
+    if gramk == "off":
+        monkeypatch.setenv("CMFREC_HIP_GRAMK", "0")
+    elif gramk == "batch7":
+        monkeypatch.setenv("CMFREC_HIP_GRAMK_BATCH", "7")
     dtype = np.float32
     O = oracles[dtype]
     k, p = 256, 512
