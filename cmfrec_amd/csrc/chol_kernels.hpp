@@ -103,15 +103,15 @@ struct CholParams {
                                             // + store, 5 rows, 6 non-zeros
 #endif
     int row_first;             // positions row_first .. nrows-1 of the processing order are handled
-    // Rank-k update done beforehand by gramk_producer_kernel (gramk_kernels.hpp; 17-block rows in single precision): the row's
-    // tiles and right-hand side are the sum of its work items' partials [item - gk_base][gk_stride] -- the split rows
-    // (positions < gk_n_heavy) own the items gk_row_off[pos] .. gk_row_off[pos + 1], position pos >= gk_n_heavy the item
-    // gk_n_slices + pos - gk_n_heavy -- and the gather loop below is skipped.
+    // gramk_consumer_kernel (gramk_kernels.hpp; 17-block rows in single precision) only: the rank-k update was done beforehand
+    // by gramk_producer_kernel, the row's tiles and right-hand side are the sum of its work items' partials
+    // [item - gk_base][gk_stride] -- the split rows (positions < gk_n_heavy) own the items gk_row_off[pos] ..
+    // gk_row_off[pos + 1], position pos >= gk_n_heavy the item gk_n_slices + pos - gk_n_heavy.
     const T *gk_part = nullptr;
     const int *gk_row_off = nullptr;
     int gk_n_heavy = 0, gk_n_slices = 0, gk_base = 0;
     size_t gk_stride = 0;
-    // ... and the launch's initial matrices in the same tile-linear layout (tile_pack_kernel): gk_init1 for every row (Mfull),
+    // ... and the launch's initial matrices in the same tile-linear layout (tile_pack_lane_kernel): gk_init1 for every row (Mfull),
     // gk_init2 for the rows with side information (Minit = w C^T C); null: none
     const T *gk_init1 = nullptr, *gk_init2 = nullptr;
 };
@@ -270,9 +270,7 @@ __device__ __forceinline__ void chol_diag_block(typename CholMfma<T>::vec d, T *
 #define CMF_CDBG(P, bit) false
 #define CMF_CTICK(P, slot) do { } while (0)
 #endif
-// FROM_PART: the build that takes its rank-k update from gramk_producer_kernel's partials (P.gk_part) and carries no gather
-// code (and none of its registers)
-template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS, bool TWO_SRC = false, bool FROM_PART = false>
+template <typename T, int NTT, int NW, int CHOL_CHUNK, int WGS, bool TWO_SRC = false>
 __global__ void __launch_bounds__(64 * NW, WGS)
 chol_rows_kernel(const CholParams<T> P)
 {
@@ -447,39 +445,14 @@ chol_rows_kernel(const CholParams<T> P)
             if (naz) pre_wsyr = T(0);               // the matrix is shared (common.c:3130-3140)
             if (wsrc2) { pre_wsyr = P.w2_syr_zero ? T(0) : P.w2; pre_wrhs = P.w2 * wx; }   // collective.c:1636-1653, :1719-1731
         };
-        constexpr bool from_part = FROM_PART;
-        if (!from_part) {
         if (nnz > 0) { load_idx(0); load_rows(); }
         if (nnz > CHOL_CHUNK) load_idx(CHOL_CHUNK);
-        }
         __syncthreads();          // previous row's LDS readers (backward substitution) are done
         CMF_CTICK(P, 0);
 #ifdef CMF_CHOL_DEBUG
         if (P.tstamp != nullptr && tid == 0) { atomicAdd(&P.tstamp[5], 1ull); atomicAdd(&P.tstamp[6], (unsigned long long)nnz); }
 #endif
-        if (FROM_PART && nnz1 > 0) {
-            // the producer's partials: tile t = wave + NW tt of the packed upper triangle in the accumulator layout, then the
-            // right-hand side; the items of a split row are added in order
-            int i0, i1;
-            if (rix < P.gk_n_heavy) { i0 = P.gk_row_off[rix]; i1 = P.gk_row_off[rix + 1]; }
-            else { i0 = P.gk_n_slices + (rix - P.gk_n_heavy); i1 = i0 + 1; }
-            for (int item = i0; item < i1; item++) {
-                const T *pp = P.gk_part + (size_t)(item - P.gk_base) * P.gk_stride;
-#pragma unroll
-                for (int tt = 0; tt < TPW; tt++) {
-                    const int t = min(wave + NW * tt, NTALL - 1);
-                    T v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = pp[(size_t)t * 256 + r * 64 + lane];
-                    if (T_REAL(tt)) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) acc[tt][r] += v[r];
-                    }
-                }
-                if (tid < kt) racc += pp[(size_t)NTALL * 256 + tid];
-            }
-        }
-        for (int c0 = 0, slot = 0; c0 < ((CMF_CDBG(P, 1) || from_part) ? 0 : nnz); c0 += CHOL_CHUNK, slot ^= 1) {
+        for (int c0 = 0, slot = 0; c0 < (CMF_CDBG(P, 1) ? 0 : nnz); c0 += CHOL_CHUNK, slot ^= 1) {
             T *Bs = ring + (size_t)slot * CHOL_CHUNK * ldc;
 #pragma unroll
             for (int i = 0; i < RPW; i++)
@@ -549,26 +522,6 @@ chol_rows_kernel(const CholParams<T> P)
             const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED || P.mode == CHOL_NAZ);
             const T *M1 = full ? P.Minit : P.Mfull;                    // [kt, kt], every row
             const T *M2 = (!full && has_u) ? P.Minit : nullptr;        // [kc, kc], rows with side information
-            if constexpr (FROM_PART) {
-                // packed once per launch into the accumulator layout: coalesced loads, no index arithmetic (which is what
-                // fills this kernel's registers in the row-major form below)
-#pragma unroll 1
-                for (int pass = 0; pass < 2; pass++) {
-                    const T *Ti = pass ? (has_u ? P.gk_init2 : nullptr) : P.gk_init1;
-                    if (Ti == nullptr) continue;
-#pragma unroll
-                    for (int tt = 0; tt < TPW; tt++) {
-                        const int t = min(wave + NW * tt, NTALL - 1);
-                        T v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] = Ti[(size_t)t * 256 + r * 64 + lane];
-                        if (T_REAL(tt)) {
-#pragma unroll
-                            for (int r = 0; r < 4; r++) acc[tt][r] += v[r];
-                        }
-                    }
-                }
-            } else
 #pragma unroll 1
             for (int pass = 0; pass < 2; pass++) {                     // unconditional loads on clamped addresses
                 const T *Mi = pass ? M2 : M1;
@@ -597,7 +550,7 @@ chol_rows_kernel(const CholParams<T> P)
                 }
             }
         }
-        if (!FROM_PART && (P.nonneg || P.l1 != T(0) || P.l1_last != T(0))) {   // (the producer / consumer pair is not launched for them)
+        if (P.nonneg || P.l1 != T(0) || P.l1_last != T(0)) {
             // ---- 3'. non-negative solution by cyclic coordinate descent (solve_nonneg, common.c:2131-2179):
             //   a = 0, g = rhs;  sweep ix = 0..kt-1:  new = max(a_ix + g_ix / M_ix,ix, 0);  if |new - a_ix| > 1e-8:
             //   g -= (new - a_ix) M[ix, :], a_ix = new;  stop after a sweep that moved less than 1e-8 in total.
@@ -757,23 +710,6 @@ chol_rows_kernel(const CholParams<T> P)
             // the suffix are updated too: nothing reads them.
             const int ft1 = (kbk + 1) * NTT - ((kbk + 1) * kbk) / 2;            // first tile of block row kbk + 1
             const int tt0 = max(0, (ft1 - __builtin_amdgcn_readfirstlane(wave) + NW - 1) / NW);
-            if constexpr (FROM_PART) {
-                // one k-step of operands at a time (20 registers instead of 40: this build has four wavefronts per SIMD to
-                // cover the latency of the reads)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    T xa[TPW], xb[TPW];
-#pragma unroll
-                    for (int tt = 0; tt < TPW; tt++) {
-                        xa[tt] = -Xt[offa[tt] * 16 + q4 * 64 + lane];
-                        xb[tt] = Xt[offb[tt] * 16 + q4 * 64 + lane];
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < TPW; tt++)
-                        if (tt >= tt0) acc[tt] = Mf::mma(xa[tt], xb[tt], acc[tt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 T xa[TPW][2], xb[TPW][2];

@@ -133,8 +133,7 @@ __device__ __forceinline__ void gk_quarter(const CholParams<T> &P, size_t st, in
     static_for<0, NTQ>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int t = gk_packed(gk_bi(Q, i), gk_bj(Q, i));
-#pragma unroll
-        for (int r = 0; r < 4; r++) out[t * 256 + r * 64 + lane] = acc[i][r];
+        *reinterpret_cast<vec *>(out + t * 256 + lane * 4) = acc[i];       // [tile][lane][register]: one 16-byte store
     });
     static_for<0, NRB>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -174,6 +173,305 @@ gramk_producer_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, c
             default: gk_quarter<T, 3>(P, st, nnz, out, lane); break;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The consumer: initial matrix + the producer's partials, blocked Cholesky, both substitutions, for one row per workgroup of
+// FOUR wavefronts, two workgroups per CU (collective_closed_form_block's tposv, /root/reference/src/collective.c:1819-1846;
+// factors_closed_form, common.c:1060-1075).
+//
+// The 16-wavefront row kernel spent ~870 k cycles on a 257 x 257 system whose matrix-pipe time is ~30 k: 51 barriers of 16
+// waves, two LDS reads per MFMA, every phase a latency chain with nothing else on the CU.  Here
+//  * a wave owns whole tile COLUMNS of the upper triangle -- {Q, 7 - Q, 9 + Q, 16 - Q} plus two or three tiles of column 8,
+//    38-39 tiles, all indices compile-time (one instantiation per wave, as in the producer) -- so the panel tiles of a block
+//    row are spread over the four waves, and the 17 panel tiles X_b of a step, read once per wave (one ds_read_b128 each, the
+//    register of k-step q is A operand of tile row b and B operand of tile column b), feed all of its trailing MFMAs;
+//  * the accumulators hold the NEGATED matrix, so the trailing update is a plain  N += X_bi^T X_bj  without a sign flip per
+//    operand (the diagonal block and inv(R) are negated where they are read: 8 instructions per step);
+//  * the panel tiles are double-buffered and inv(R_kk) has a slot per block: two barriers per block step;
+//  * the backward substitution runs by block ROWS (every wave multiplies its tiles of row i by the x_j it keeps for its own
+//    columns, one cross-lane reduction and one barrier per step) instead of one wave per block column;
+//  * the second workgroup of the CU fills the diagonal-block and barrier latencies of the first.
+// LDS per workgroup: 2 x 17 KB of panel tiles, 21.3 KB of inv(R), right-hand side / solution / partial sums.
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int gc_col_of(int Q, int s) { return s == 0 ? Q : s == 1 ? 7 - Q : s == 2 ? 9 + Q : 16 - Q; }
+__host__ __device__ constexpr int gc_count(int Q) { return 36 + (Q == 0 ? 3 : 2); }
+__host__ __device__ constexpr int gc8_first(int Q) { return Q == 0 ? 0 : 1 + 2 * Q; }
+__host__ __device__ constexpr int gc_bj(int Q, int i)
+{
+    int rem = i;
+    for (int s = 0; s < 4; s++) {
+        const int c = gc_col_of(Q, s);
+        if (rem <= c) return c;
+        rem -= c + 1;
+    }
+    return 8;
+}
+__host__ __device__ constexpr int gc_bi(int Q, int i)
+{
+    int rem = i;
+    for (int s = 0; s < 4; s++) {
+        const int c = gc_col_of(Q, s);
+        if (rem <= c) return rem;
+        rem -= c + 1;
+    }
+    return gc8_first(Q) + rem;
+}
+// owner of the diagonal tile (and of the solution block) b
+__host__ __device__ constexpr int gc_diag_owner(int b) { return b < 4 ? b : b < 8 ? 7 - b : b == 8 ? 3 : b < 13 ? b - 9 : 16 - b; }
+// register slot of x_b in the wave that keeps it for its column b (columns {Q, 7 - Q, 9 + Q, 16 - Q} -> 0..3, column 8 -> 4)
+__host__ __device__ constexpr int gc_xslot(int Q, int b) { return b == 8 ? 4 : b == Q ? 0 : b == 7 - Q ? 1 : b == 9 + Q ? 2 : 3; }
+__host__ __device__ constexpr bool gc_has_col(int Q, int b) { return b == 8 || b == Q || b == 7 - Q || b == 9 + Q || b == 16 - Q; }
+
+template <typename T> struct GcShared {
+    __attribute__((aligned(16))) T Xt[2][GK_NB * 256];                      // panel tiles of a block step, [b][lane][k-step]
+    T rinv[GK_NB * 16 * CholMfma<T>::LDR];     // inv(R_kk) of every block
+    T rhs[GK_NB * 16];                         // right-hand side -> y (in place)
+    T xall[GK_NB * 16];                        // solution
+    T psum[2][4][16];                          // backward substitution: the waves' partial sums of a block row
+    int rix;
+};
+
+struct GcRow {                                 // what the workgroup's four instantiations share about the row
+    int item0, item1;                          // the producer's work items of this row (item0 == item1: none)
+    bool has_u;
+    int kt;
+};
+
+template <typename T, int Q>
+__device__ __forceinline__ void gc_row(const CholParams<T> &P, GcShared<T> &S, const GcRow &R, T lam, T lam_last, T *__restrict__ arow, int lane)
+{
+    using Mf = CholMfma<T>;
+    using vec = typename Mf::vec;
+    constexpr int NTQ = gc_count(Q);
+    constexpr int LDR = Mf::LDR, RSZ = 16 * LDR;
+    const int lm = lane & 15, kt = R.kt;
+    const int tid = 64 * Q + lane;
+    vec acc[NTQ];
+#pragma unroll
+    for (int i = 0; i < NTQ; i++) acc[i] = vec{0, 0, 0, 0};
+    // ---- 1. N = -(initial matrix + partials + diagonal);  right-hand side ----
+    T r0 = T(0), r1 = T(0);                    // unknowns tid and 256 + tid
+    if (R.has_u || P.rhs_prefilled_all) {      // w U C prefilled (collective.c:5768-5773)
+        if (tid < kt) r0 = arow[tid];
+        if (256 + tid < kt) r1 = arow[256 + tid];
+    }
+    auto add_tiles = [&](const T *__restrict__ pp) {           // thirteen 16-byte loads in flight
+        static_for<0, 3>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            vec ld[13];
+            static_for<0, 13>([&](auto jc) {
+                constexpr int i = 13 * g + decltype(jc)::value;
+                if constexpr (i < NTQ) ld[i - 13 * g] = *reinterpret_cast<const vec *>(pp + gk_packed(gc_bi(Q, i), gc_bj(Q, i)) * 256 + lane * 4);
+            });
+            static_for<0, 13>([&](auto jc) {
+                constexpr int i = 13 * g + decltype(jc)::value;
+                if constexpr (i < NTQ) acc[i] -= ld[i - 13 * g];
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    for (int item = R.item0; item < R.item1; item++) {
+        const T *pp = P.gk_part + (size_t)(item - P.gk_base) * P.gk_stride;
+        add_tiles(pp);
+        r0 += pp[GK_NT * 256 + tid];
+        if (tid < 16) r1 += pp[GK_NT * 256 + 256 + tid];
+    }
+    if (P.gk_init1 != nullptr) add_tiles(P.gk_init1);
+    if (R.has_u && P.gk_init2 != nullptr) add_tiles(P.gk_init2);
+    static_for<0, NTQ>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (gc_bi(Q, i) == gc_bj(Q, i)) {
+            constexpr int b = gc_bi(Q, i);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gi = 16 * b + Mf::row_of(lane, r), gj = 16 * b + lm;
+                if (gi == gj) acc[i][r] -= (gi >= kt) ? T(1) : ((gi == kt - 1) ? lam_last : lam);   // add_to_diag2: common.c:1060-1062, collective.c:1819
+            }
+        }
+    });
+    S.rhs[tid] = r0;
+    if (tid < 16) S.rhs[256 + tid] = r1;
+    // ---- 2. blocked Cholesky  M = R^T R  of M = -N ----
+    for (int kbk = 0; kbk < GK_NB; kbk++) {
+        T *rslot = S.rinv + kbk * RSZ;
+        T *Xw = S.Xt[kbk & 1];
+        // a. diagonal block, by its owner
+        {
+            vec d = vec{0, 0, 0, 0};
+            bool mine = false;
+            static_for<0, NTQ>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (gc_bi(Q, i) == gc_bj(Q, i)) {
+                    if (kbk == gc_bi(Q, i)) { d = -acc[i]; mine = true; }
+                }
+            });
+            if (mine) chol_diag_block<T>(d, rslot, lane, min(16, kt - 16 * kbk));
+        }
+        __syncthreads();
+        // b. panel tiles of block row kbk:  X = inv(R_kk)^T tile  (tile = -N: the A operand carries the sign)
+        {
+            T ainv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) ainv[r] = -rslot[Mf::row_of(lane, r) * LDR + lm];
+            if (Q == ((kbk + 1) & 3)) {           // y_k = inv(R_kk)^T rhs_k, in place (a wave that is not the next diagonal's owner... any wave)
+                T yv = T(0);
+#pragma unroll
+                for (int l = 0; l < 16; l++) yv += rslot[l * LDR + lm] * S.rhs[16 * kbk + l];
+                if (lane < 16) S.rhs[16 * kbk + lane] = yv;
+            }
+            static_for<0, NTQ>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int bi = gc_bi(Q, i), bj = gc_bj(Q, i);
+                if constexpr (bi < bj) {
+                    if (kbk == bi) {
+                        vec x = Mf::mma(ainv[0], acc[i][0], vec{0, 0, 0, 0});          // two independent chains
+                        vec x2 = Mf::mma(ainv[2], acc[i][2], vec{0, 0, 0, 0});
+                        x = Mf::mma(ainv[1], acc[i][1], x);
+                        x2 = Mf::mma(ainv[3], acc[i][3], x2);
+                        x += x2;
+                        acc[i] = x;                                                   // R(bi, bj), kept for the backward pass
+                        *reinterpret_cast<vec *>(Xw + bj * 256 + lane * 4) = x;
+                    }
+                }
+            });
+        }
+        __syncthreads();
+        // c. trailing tiles  N(bi, bj) += X_bi^T X_bj  (bi > kbk), forward substitution of the later blocks
+        if (kbk + 1 < GK_NB) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                typedef T vec2 __attribute__((ext_vector_type(2)));
+                vec2 xo[GK_NB];
+#pragma unroll
+                for (int b = 1; b < GK_NB; b++) xo[b] = *reinterpret_cast<const vec2 *>(Xw + b * 256 + lane * 4 + 2 * h);
+                static_for<0, NTQ>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    constexpr int bi = gc_bi(Q, i), bj = gc_bj(Q, i);
+                    if constexpr (bi > 0) {
+                        if (kbk < bi) {
+                            acc[i] = Mf::mma(xo[bi][0], xo[bj][0], acc[i]);
+                            acc[i] = Mf::mma(xo[bi][1], xo[bj][1], acc[i]);
+                        }
+                    }
+                });
+            }
+            // rhs_j -= X_j^T y_k  for the later blocks: thread <-> unknown (element (k2, c) of tile b sits at
+            // [b][16 (k2 >> 2) + c][k2 & 3])
+#pragma unroll
+            for (int rep = 0; rep < 2; rep++) {
+                const int jg = tid + 256 * rep;
+                if (jg >= 16 * (kbk + 1) && jg < 16 * GK_NB) {
+                    T sacc = S.rhs[jg];
+                    const T *xt = Xw + (jg >> 4) * 256 + (jg & 15) * 4;
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; k2++) sacc -= xt[(k2 >> 2) * 64 + (k2 & 3)] * S.rhs[16 * kbk + k2];
+                    S.rhs[jg] = sacc;
+                }
+            }
+        }
+    }
+    // ---- 3. backward substitution  R x = y  by block rows:  x_i = inv(R_ii) (y_i - sum_{j > i} R_ij x_j) ----
+    T xs[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) xs[c] = T(0);
+    static_for<0, GK_NB>([&](auto sc) {
+        constexpr int bi = GK_NB - 1 - decltype(sc)::value;
+        T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
+        static_for<0, NTQ>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (gc_bi(Q, i) == bi && gc_bj(Q, i) > bi) {
+                const T xv = xs[gc_xslot(Q, gc_bj(Q, i))];
+                p0 += acc[i][0] * xv; p1 += acc[i][1] * xv; p2 += acc[i][2] * xv; p3 += acc[i][3] * xv;
+            }
+        });
+        // sum over the 16 lanes of a row for the four registers at once: after two select-and-exchange steps lane l carries
+        // register (l & 3), then two plain butterflies
+        const bool o1 = (lm & 1) != 0, o2 = (lm & 2) != 0;
+        const T s01 = (o1 ? p1 : p0) + lanes::xor1(o1 ? p0 : p1);
+        const T s23 = (o1 ? p3 : p2) + lanes::xor1(o1 ? p2 : p3);
+        T sr = (o2 ? s23 : s01) + lanes::xor2(o2 ? s01 : s23);
+        sr += lanes::xor4(sr);
+        sr += lanes::xor8(sr);
+        T *ps = &S.psum[bi & 1][0][0];
+        if (lm < 4) ps[Q * 16 + Mf::row_of(lane, lm)] = sr;
+        __syncthreads();
+        const T *rslot = S.rinv + bi * RSZ;
+        T xm = T(0);                              // x[16 bi + lm], computed redundantly by every 16-lane group of every wave
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++)
+            xm += rslot[lm * LDR + n2] * (S.rhs[16 * bi + n2] - ((ps[n2] + ps[16 + n2]) + (ps[32 + n2] + ps[48 + n2])));
+        if constexpr (gc_has_col(Q, bi)) xs[gc_xslot(Q, bi)] = xm;
+        if (Q == 0 && lane < 16) S.xall[16 * bi + lane] = xm;
+    });
+    if (Q == 0)
+        for (int e = lane; e < kt; e += 64) arow[e] = S.xall[e];
+}
+
+// One workgroup of four wavefronts per row; rows [P.row_first, P.nrows) of the processing order handed out by P.counter.
+template <typename T>
+__global__ void __launch_bounds__(256, 2)
+gramk_consumer_kernel(const CholParams<T> P)
+{
+    __shared__ GcShared<T> S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kt = P.kt;
+    for (;;) {
+        if (tid == 0) S.rix = P.row_first + atomicAdd(P.counter, 1);
+        __syncthreads();
+        const int rix = S.rix;
+        __syncthreads();                            // S.rix may be rewritten; the previous row's LDS readers are done
+        if (rix >= P.nrows) break;
+        const int row = (P.order != nullptr) ? P.order[rix] : rix;
+        const int nnz1 = (int)(P.indptr[row + 1] - P.indptr[row]);
+        T *arow = P.A + (size_t)row * P.lda;
+        const bool coll = (P.mode == CHOL_COLLECTIVE);
+        GcRow R;
+        R.kt = kt;
+        R.has_u = coll && row < P.rows_with_u;
+        if (coll && nnz1 == 0 && !R.has_u) {                            // collective.c:1258-1268, :1876-1885
+            for (int e = tid; e < kt; e += 256) arow[e] = T(0);
+            continue;
+        }
+        T lam = P.lam, lam_last = P.lam_last;
+        if (P.mode == CHOL_EXPLICIT) {
+            if (P.scale_lam) {                                           // common.c:679-723
+                const T mult = (P.wsum != nullptr) ? P.wsum[row] : (T)nnz1;
+                lam *= mult;
+                if (!P.scale_bias_const) lam_last *= mult;
+            }
+        } else if (P.scale_lam || P.scale_lam_sideinfo) {               // collective.c:1285-1355
+            T mult = (P.wsum != nullptr) ? P.wsum[row] : ((nnz1 > 0) ? (T)nnz1 : T(1));
+            if (P.scale_lam_sideinfo && R.has_u) mult += (T)P.p_side;    // :1338-1346
+            lam *= mult;
+            if (R.has_u || !P.scale_bias_const) lam_last *= mult;
+        }
+        if (nnz1 <= 0) { R.item0 = R.item1 = 0; }                       // rows without entries have no partial
+        else if (rix < P.gk_n_heavy) { R.item0 = P.gk_row_off[rix]; R.item1 = P.gk_row_off[rix + 1]; }
+        else { R.item0 = P.gk_n_slices + (rix - P.gk_n_heavy); R.item1 = R.item0 + 1; }
+        switch (wave) {
+            case 0: gc_row<T, 0>(P, S, R, lam, lam_last, arow, lane); break;
+            case 1: gc_row<T, 1>(P, S, R, lam, lam_last, arow, lane); break;
+            case 2: gc_row<T, 2>(P, S, R, lam, lam_last, arow, lane); break;
+            default: gc_row<T, 3>(P, S, R, lam, lam_last, arow, lane); break;
+        }
+    }
+}
+
+// out[t][lane][r]: the [lane][register] form of tile_pack_kernel's output (the layout of the producer's partials)
+template <typename T>
+__global__ void tile_pack_lane_kernel(const T *__restrict__ M, int lim, int NB, T *__restrict__ out)
+{
+    const int NT = NB * (NB + 1) / 2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NT * 256) return;
+    const int t = e >> 8, lane = (e >> 2) & 63, r = e & 3;
+    int bi = 0, rem = t;
+    while (rem >= NB - bi) { rem -= NB - bi; bi++; }
+    const int bj = bi + rem;
+    const int gi = 16 * bi + CholMfma<T>::row_of(lane, r), gj = 16 * bj + (lane & 15);
+    const int lo = min(gi, gj), hi = max(gi, gj);
+    out[e] = (hi < lim) ? M[(size_t)lo * lim + hi] : T(0);
 }
 
 }  // namespace cmfhip

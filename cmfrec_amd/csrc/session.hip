@@ -262,8 +262,8 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     {
         // 17-block rows (k_t = 257 .. 272, config 5's item step): the rank-k update by gramk_producer_kernel (four independent
         // wavefronts per row or slice, operands straight from the gather), the partial matrices through HBM, the factorisation
-        // by the row kernel below.  CMFREC_HIP_GRAMK=0 keeps the row kernel's own LDS-staged rank-k loop (A/B switch and
-        // cross-check).
+        // and the substitutions by gramk_consumer_kernel (four wavefronts per row, two rows per CU).  CMFREC_HIP_GRAMK=0 keeps
+        // the 16-wavefront row kernel with its own LDS-staged rank-k loop (A/B switch and cross-check).
         const char *gk_env = getenv("CMFREC_HIP_GRAMK");
         const bool gk_ok = X != nullptr && T == 17 && !two_src && c.koff == 0 && !weighted && !c.rhs_only && c.values_override == nullptr &&
                            (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && !nonneg && !l1on && !(gk_env != nullptr && gk_env[0] == '0');
@@ -291,12 +291,12 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 const size_t tl = (size_t)GK_NT * 256;
                 if (c.Mfull != nullptr || (c.Minit != nullptr && c.kc > 0)) d.tile_init.alloc_at_least(2 * tl);
                 if (c.Mfull != nullptr) {
-                    hipLaunchKernelGGL(tile_pack_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, c.Mfull, c.kt, GK_NB,
+                    hipLaunchKernelGGL(tile_pack_lane_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, c.Mfull, c.kt, GK_NB,
                                        d.tile_init.ptr);
                     init1 = d.tile_init.ptr;
                 }
                 if (c.Minit != nullptr && c.kc > 0) {
-                    hipLaunchKernelGGL(tile_pack_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, c.Minit, c.kc, GK_NB,
+                    hipLaunchKernelGGL(tile_pack_lane_kernel<real_t>, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, dev.stream, c.Minit, c.kc, GK_NB,
                                        d.tile_init.ptr + tl);
                     init2 = d.tile_init.ptr + tl;
                 }
@@ -319,8 +319,11 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 H.row_first = row0; H.nrows = row1; H.counter = dev.row_counter.ptr + ctr + 1;
                 H.gk_part = X->chol_part.ptr; H.gk_row_off = X->row_sl_off.ptr; H.gk_n_heavy = n_heavy; H.gk_n_slices = nsl; H.gk_base = item0;
                 H.gk_stride = (size_t)GK_PART; H.gk_init1 = init1; H.gk_init2 = init2;
-                const int rc1 = launch_chol_rows(dev, c, X, H, two_src, smem_nonneg);
-                if (rc1) rc_all = rc1;
+                if (row1 > row0) {
+                    poison_lds(dev.stream, dev.num_cus);
+                    hipLaunchKernelGGL(gramk_consumer_kernel<real_t>, dim3(std::min(row1 - row0, 2 * dev.num_cus)), dim3(256), 0, dev.stream, H);
+                    HIP_CHECK(hipGetLastError());
+                }
                 ctr += 2;
             };
             for (int r = 0; r < n_heavy;) {                 // split rows: whole rows per batch
@@ -376,18 +379,6 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
         poison_lds(run_on, dev.num_cus);          // test hook, device.hpp
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * nw), smem, run_on, P);
     };
-#ifdef CMFREC_HIP_FLOAT
-    if (P.gk_part != nullptr) {
-        // consumer of the producer's partial matrices (launch_chol, 17 blocks): initial matrix, factorisation, solve.
-        // CMFREC_HIP_GRAMK_CONS: 16 (sixteen wavefronts, one row per CU), 8 (eight wavefronts, two rows per CU)
-        const char *ce = getenv("CMFREC_HIP_GRAMK_CONS");
-        const int cons = ce ? atoi(ce) : 16;
-        if (cons == 8) launch(chol_rows_kernel<real_t, 17, 8, 16, 2, false, true>, 17, 8, 16, 2);
-        else launch(chol_rows_kernel<real_t, 17, 16, 16, 1, false, true>, 17, 16, 16, 1);
-        HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-#endif
     // <16-blocks per dimension, wavefronts per workgroup, gathered rows per round, waves per SIMD>
     if (T <= 4) {
         // k_t <= 64: the whole system is 10 tiles.  Rows of 129 non-zeros and more (they lead the processing order) get
