@@ -207,12 +207,12 @@ def main():
     # how a per-bin figure maps onto `rocprofv3 --kernel-trace --stats` rows (those average over BOTH half-steps)
     prof_names = {0: ["vh_pass_kernel<..., 0> x1 + vh_pass_kernel<..., 1> x%d" % MAX_CG_STEPS,
                       "vh_update_kernel<..., 0> x1 + vh_update_kernel<..., 1> x%d" % MAX_CG_STEPS],
-                  1: ["cg_rows_kernel<double, 7, true, 8, 1>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1>"],
-                  3: ["cg_rows_kernel<double, 7, true, 2, 1>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4>"],
-                  5: ["cg_rows_tiny_kernel<double, 7, true>", "cg_rows_tiny2_kernel<double, 7, true> (rows of <= 16 nnz, two per wavefront)"]}
+                  1: ["cg_rows_kernel<double, 7, true, 8, 1, false>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1, false>"],
+                  3: ["cg_rows_kernel<double, 7, true, 2, 1, false>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4, false>"],
+                  5: ["cg_rows_tiny_kernel<double, 7, true, false>", "cg_rows_tiny2_kernel<double, 7, true> (rows of <= 16 nnz, two per wavefront)"]}
     inv = {v: b for b, v in names.items()}
     inv["gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
-    prof_names[6] = ["gram_wave_kernel<double, true>", "gram_cg_kernel<double, true>"]
+    prof_names[6] = ["gram_wave_kernel<double, true, 2>", "gram_cg_kernel<double, true>"]
     for d in kernels:
         other = [e for e in kernels if e["kernel"] == d["kernel"] and e["step"] != d["step"]]
         # (a launch that runs beside other kernels has no duration of its own, and rocprof's average mixes it in:
@@ -767,13 +767,16 @@ def pmc_traffic(dom):
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
-    tags = {"cg_rows_kernel<W=8>": [", 8, 1>"], "cg_rows_kernel<W=4>": [", 4, 1>"], "cg_rows_kernel<W=2>": [", 2, 1>"],
-            "cg_rows_kernel<W=1>": [", 1, 4>"], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel", "cg_rows_tiny2_kernel"],
+    # (the row kernel's template arguments are <T, slots, implicit, waves per row, rows per workgroup, weighted>)
+    tags = {"cg_rows_kernel<W=8>": [", 8, 1, "], "cg_rows_kernel<W=4>": [", 4, 1, "], "cg_rows_kernel<W=2>": [", 2, 1, "],
+            "cg_rows_kernel<W=1>": [", 1, 4, "], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel", "cg_rows_tiny2_kernel"],
             "vh_pass": ["vh_pass_kernel", "vh_update_kernel"], "gram_wave": ["gram_wave_kernel", "gram_cg_kernel"]}
     want = next(v for k, v in tags.items() if dom["kernel"].startswith(k))
     tot, found = 0.0, False
     for name, ent in ks.items():
         head = name.split("(")[0]
+        if "<double" not in head:                     # the counter passes also see the single-precision scale point
+            continue
         if any(t in head for t in want) and ("cg_rows_kernel<" in head) == dom["kernel"].startswith("cg_rows_kernel"):
             r = ent.get("hbm_read_bytes_" + dom["step"]); w = ent.get("hbm_write_bytes_" + dom["step"])
             if r is not None and w is not None:

@@ -106,7 +106,10 @@ void sparse_colmeans(const int_t *col, const real_t *val, size_t nnz, int_t cols
     for (int_t c = 0; c < cols; c++) means[c] = (real_t)(sum[c] / (double)cnt[c]);
 }
 
-int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose, bool implicit_feats = false)
+// chol_A / chol_B: that half-step is a closed-form solve whatever use_cg says (dense X without weights whose rows / columns are
+// all or nearly all complete: optimizeA Case 1, common.c:2787-2993)
+int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose, bool implicit_feats = false,
+             bool chol_A = false, bool chol_B = false)
 {
     for (int it = 0; it < niter; it++) {
         if (g_stop) return 3;
@@ -127,17 +130,56 @@ int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool
             if (g_stop) return 3;
         }
         if (verbose) { printf("Updating B..."); fflush(stdout); }
-        if ((rc = cmfrec_hip_session_update(s, 'B', chol))) return rc;
+        if ((rc = cmfrec_hip_session_update(s, 'B', (chol || chol_B) ? 1 : 0))) return rc;
         if ((rc = cmfrec_hip_session_after_gather(s, 'B'))) return rc;
         if (verbose) { cmfrec_hip_session_sync(s); printf(" done\n"); }
         if (g_stop) return 3;
         if (verbose) { printf("Updating A..."); fflush(stdout); }
-        if ((rc = cmfrec_hip_session_update(s, 'A', chol))) return rc;
+        if ((rc = cmfrec_hip_session_update(s, 'A', (chol || chol_A) ? 1 : 0))) return rc;
         if ((rc = cmfrec_hip_session_after_gather(s, 'A'))) return rc;
         if (verbose) { cmfrec_hip_session_sync(s); printf(" done\n\tCompleted ALS iteration %2d\n\n", it + 1); fflush(stdout); }
     }
     return 0;
 }
+
+// Dense X (Xfull [m, n] row-major, NaN = missing; weight, if given, dense too) -> the COO of its present entries in row-major
+// order, which is the order every running mean of the reference's dense branches takes them in (common.c:3463-3490,
+// :4152-4180), plus what optimizeA's case selection needs (helpers.c:151-250): a half-step is "full" when no row (column) has
+// a missing entry and "near dense" when at least 75 % of them have none.
+struct DenseX {
+    std::vector<int_t> row, col;
+    std::vector<real_t> val, w;
+    bool full = false, near_row = false, near_col = false;
+    std::vector<int_t> na_row, na_col;          // missing entries per row / column
+    void convert(const real_t *Xfull, const real_t *weight, int_t m, int_t n)
+    {
+        na_row.assign((size_t)m, 0); na_col.assign((size_t)n, 0);
+        size_t present = 0;
+        for (int_t r = 0; r < m; r++)
+            for (int_t c = 0; c < n; c++) {
+                const bool na = std::isnan(Xfull[(size_t)r * n + c]);
+                na_row[r] += na; na_col[c] += na; present += !na;
+            }
+        row.reserve(present); col.reserve(present); val.reserve(present);
+        if (weight) w.reserve(present);
+        for (int_t r = 0; r < m; r++)
+            for (int_t c = 0; c < n; c++) {
+                const real_t x = Xfull[(size_t)r * n + c];
+                if (std::isnan(x)) continue;
+                row.push_back(r); col.push_back(c); val.push_back(x);
+                if (weight) w.push_back(weight[(size_t)r * n + c]);
+            }
+        full = (present == (size_t)m * (size_t)n);
+        if (!full) {
+            int_t with_na = 0;
+            for (int_t r = 0; r < m; r++) with_na += (na_row[r] > 0);
+            near_row = (m - with_na) >= (int)(0.75 * (double)m);
+            with_na = 0;
+            for (int_t c = 0; c < n; c++) with_na += (na_col[c] > 0);
+            near_col = (n - with_na) >= (int_t)((real_t)0.75 * (real_t)n);
+        }
+    }
+};
 
 // ---- several GPUs of one node behind the unchanged C signature ----------------------------------
 // CMFREC_HIP_DEVICES="0,1,2,3" (HIP device ordinals, comma separated; an ordinal may repeat, which shards one device --
@@ -146,7 +188,11 @@ int run_loop(cmfrec_hip_session *s, const cmfrec_hip_model &mdl, int niter, bool
 // full replicas of A and B, updates its own rows, and the updated rows travel to the peers over xGMI
 // (hipMemcpyPeerAsync, ordered by events; no host synchronisation inside the loop) -- the all-gather of distributed.py
 // without torch.  Rows are independent given the opposing matrix and every device computes B^T B from identical
-// replicas, so the factors are bit-for-bit those of the single-device fit.
+// replicas, so the factors are bit-for-bit those of the single-device fit as long as every row takes the same kernel path on
+// the shard as on the whole matrix.  That holds for rows of at most 1024 entries (512 in double precision); for split rows the
+// choice between the streaming and the Gramian path, and the slice length, follow the SHARD's statistics (device.hpp,
+// prefer_gram / slice_len), so their sums may be taken in another order: equal to rounding, not to the bit
+// (tests/test_gpu_multidevice.py has both cases).
 std::vector<int> devices_from_env()
 {
     std::vector<int> out;
@@ -517,8 +563,52 @@ int_t fit_collective_explicit_als(
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (Xfull || NA_as_zero_U || NA_as_zero_I)
-        return fail(verbose, "cmfrec_hip: dense X / NA_as_zero_U / NA_as_zero_I are not implemented.");
+    if (NA_as_zero_U || NA_as_zero_I)
+        return fail(verbose, "cmfrec_hip: NA_as_zero_U / NA_as_zero_I are not implemented.");
+    // Dense X: the rows of the present entries go through the same row kernels as a sparse X (a row's system is the sum over
+    // its present entries either way: factors_closed_form, common.c:762-1075; factors_explicit_cg_dense, :1615-1749).  What the
+    // reference's dense cases add is the CHOICE of solver (optimizeA Cases 1-2, common.c:2787-3116), followed here per
+    // half-step.  Without weights: a half-step whose rows are all or nearly all complete is a closed-form solve whatever
+    // use_cg says (Case 1; its rows with many missing entries run k CG steps from zero there, :2944-2983 -- the exact solution
+    // in exact arithmetic -- and the closed form here); otherwise (Case 2) a row that misses fewer than twice as many entries
+    // as its system has unknowns is solved in closed form from the precomputed B^T B (factors_closed_form, :662, :759-790:
+    // that branch comes before the CG one), the others by the solver asked for.  A half-step that has rows of both kinds under
+    // use_cg is refused.  With weights every row takes the solver asked for.  Plain model only (no side information /
+    // implicit features).
+    DenseX dx;
+    bool dense_chol_A = false, dense_chol_B = false;
+    if (Xfull) {
+        if (U || II || nnz_U || nnz_I || add_implicit_features || NA_as_zero_X)
+            return fail(verbose, "cmfrec_hip: dense X is implemented for the model without side information and implicit features.");
+        if (m <= 0 || n <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
+        dx.convert(Xfull, weight, m, n);
+        if (dx.val.empty()) return fail(verbose, "cmfrec_hip: 'X' has all entries missing.");
+        const int_t fewA = 2 * (k + k_main + (user_bias ? 1 : 0)), fewB = 2 * (k + k_main + (item_bias ? 1 : 0));
+        // Under scale_lam such a row's precomputed matrix carries n lam (that of a complete row), not lam times its number of
+        // present entries (common.c:3031-3032): a per-row rule that is not restated.
+        if (!weight && (scale_lam || scale_lam_sideinfo)) {
+            for (int_t r = 0; r < m; r++) if (dx.na_row[r] > 0 && dx.na_row[r] < fewA) return fail(verbose, "cmfrec_hip: dense X: scale_lam with rows that miss only a few entries is not implemented.");
+            for (int_t c = 0; c < n; c++) if (dx.na_col[c] > 0 && dx.na_col[c] < fewB) return fail(verbose, "cmfrec_hip: dense X: scale_lam with columns that miss only a few entries is not implemented.");
+        }
+        ixA = dx.row.data(); ixB = dx.col.data(); X = dx.val.data(); nnz = dx.val.size();
+        if (weight) weight = dx.w.data();
+        else {
+            // Case 2 under use_cg: closed form for the rows that miss few entries, CG for the others (rows without any entry are zero)
+            auto case2_chol = [&](const std::vector<int_t> &na, int_t other, int_t few, bool &mixed) {
+                size_t n_few = 0, n_many = 0;
+                for (int_t v : na) { if (v < few) n_few++; else if (v < other) n_many++; }
+                mixed = (n_few > 0 && n_many > 0);
+                return n_many == 0;
+            };
+            bool mixA = false, mixB = false;
+            dense_chol_A = dx.full || dx.near_row || case2_chol(dx.na_row, n, fewA, mixA);
+            dense_chol_B = dx.full || dx.near_col || case2_chol(dx.na_col, m, fewB, mixB);
+            if (use_cg && !nonneg && l1_lam == 0 && !l1_lam_unique && ((!(dx.full || dx.near_row) && mixA) || (!(dx.full || dx.near_col) && mixB)))
+                return fail(verbose, "cmfrec_hip: dense X with use_cg: a half-step whose rows partly miss few and partly many entries mixes two "
+                                     "solvers in the reference; not implemented (use_cg=False is).");
+        }
+        Xfull = nullptr;
+    }
     // NA_as_zero_X (sparse X whose absent entries are zeros): the plain explicit model -- every half-step is optimizeA
     // Case 3 (common.c:3118-3205: one shared matrix, closed form whatever use_cg says)
     if (NA_as_zero_X && (weight || U || II || nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
@@ -700,6 +790,14 @@ int_t fit_collective_explicit_als(
         }
     }
 
+    // dense X: rows / columns without a present entry are zero in the reference (optimizeA, common.c:2925-2929; factors_closed_form,
+    // :667-677) -- factors and bias -- whereas the sparse path leaves such rows at their start values
+    auto zero_empty_dense = [&]() {
+        if (dx.na_row.empty()) return;
+        for (int_t r = 0; r < m; r++) if (dx.na_row[r] == n) { memset(A + (size_t)r * k_totA, 0, (size_t)k_totA * sizeof(real_t)); if (biasA) biasA[r] = 0; }
+        for (int_t c = 0; c < n; c++) if (dx.na_col[c] == m) { memset(B + (size_t)c * k_totB, 0, (size_t)k_totB * sizeof(real_t)); if (biasB) biasB[c] = 0; }
+    };
+    if (niter > 0) zero_empty_dense();
     cmfrec_hip_model mdl;
     memset(&mdl, 0, sizeof mdl);
     mdl.implicit = 0; mdl.m = m_max; mdl.n = n_max; mdl.m_x = m; mdl.n_x = n;
@@ -790,7 +888,7 @@ int_t fit_collective_explicit_als(
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("bias init");
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
-    int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose, add_implicit_features);
+    int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose, add_implicit_features, dense_chol_A, dense_chol_B);
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("ALS iterations");
     if (rc_loop == 0 || rc_loop == 3) {
@@ -801,6 +899,7 @@ int_t fit_collective_explicit_als(
     if (rc_loop == 0 || rc_loop == 3) {                                   // no bias beyond the shape of X (collective.c:8296, :8923-8925)
         if (user_bias) for (int_t r = m; r < m_max; r++) biasA[r] = 0;
         if (item_bias) for (int_t c = n; c < n_max; c++) biasB[c] = 0;
+        if (niter > 0) zero_empty_dense();
     }
     if ((rc_loop == 0 || rc_loop == 3) && precompute_for_predictions) {   // collective.c:8936-9249
         if (verbose) { printf("Finishing precomputed matrices..."); fflush(stdout); }

@@ -24,7 +24,19 @@ namespace cmfhip {
 constexpr int GK_NB = 17;                               // blocks of 16 unknowns
 constexpr int GK_NT = GK_NB * (GK_NB + 1) / 2;          // 153 tiles of the upper triangle, packed as tile_bi / tile_bj do
 constexpr int GK_PART = GK_NT * 256 + GK_NB * 16;       // elements of one work item's partial: the tiles, then the right-hand side
-constexpr int GK_PD = 3;                                // k-steps of operands in flight (17 loads each; the counter tracks 63)
+constexpr int GK_PD = 2;                                // k-steps of operands in flight (5 loads each; the counter tracks 63)
+
+// ORDER OF THE UNKNOWNS INSIDE THE TILES.  The operand register of block b holds, for lane l (l & 15 = position, l >> 4 = entry
+// of the k-step), one number of the gathered row.  Reading "position p of block b = column 16 b + p" costs one 4-byte load per
+// block, lane and k-step: 17 load instructions per k-step and wave, each of them 64 scattered 4-byte reads -- the texture
+// addresser, not the matrix pipe, then sets the pace, and the 63-entry load counter allows only three k-steps in flight against
+// a gather that goes to HBM (the opposing matrix of config 5's item step is 1.6 GB).  The Gramian does not care which unknown
+// sits where, so the blocks take the order that 16-byte loads deliver: lane position p reads columns 64 q + 4 p .. + 3
+// (q = 0..3) and register r of that load is the operand of block 4 q + r.  Position t = 16 b + p of the tile order therefore
+// holds unknown  64 (b >> 2) + 4 p + (b & 3)  for b < 16; block 16 (columns 256 .. k_t - 1, one 4-byte load) keeps 256 + p.
+// Five loads per k-step, six k-steps in flight.  The consumer factorises in this order (a symmetric permutation of the system)
+// and puts the solution back; the initial matrices are packed in it (tile_pack_lane_kernel).
+__host__ __device__ constexpr int gk_unknown(int t) { return (t < 256) ? 64 * (t >> 6) + 4 * (t & 15) + ((t >> 4) & 3) : t; }
 
 // tile rows of quarter Q: {Q, 7 - Q, 9 + Q, 16 - Q} -- 36 tiles each -- and two or three tiles of row 8
 __host__ __device__ constexpr int gk_row_of(int Q, int s) { return s == 0 ? Q : s == 1 ? 7 - Q : s == 2 ? 9 + Q : 16 - Q; }
@@ -72,10 +84,11 @@ __device__ __forceinline__ void gk_quarter(const CholParams<T> &P, size_t st, in
     const bool v16 = (256 + lm) < kt;                  // block 16: the live columns 256 .. kt - 1
     const int col16 = v16 ? 256 + lm : 256;
     const unsigned long long ldb_bytes = (unsigned long long)P.ldb * sizeof(T);
-    const char *base = reinterpret_cast<const char *>(P.B + lm);
+    const char *base = reinterpret_cast<const char *>(P.B);
     const int nsteps = (nnz + 3) >> 2;
+    typedef T vec4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));     // rows start at any multiple of 4 bytes
 
-    T op[GK_PD][GK_NB], xw[GK_PD], okf[GK_PD];
+    vec op4[GK_PD][4]; T op16[GK_PD], xw[GK_PD], okf[GK_PD];
     int idxn[GK_PD]; T xn[GK_PD], okn[GK_PD];
     auto load_entry = [&](int s, int step) {
         const int e = 4 * step + kc;
@@ -87,8 +100,8 @@ __device__ __forceinline__ void gk_quarter(const CholParams<T> &P, size_t st, in
     auto issue_rows = [&](int s) {
         const T *rowp = reinterpret_cast<const T *>(base + (unsigned long long)(unsigned)idxn[s] * ldb_bytes);
 #pragma unroll
-        for (int b = 0; b < 16; b++) op[s][b] = rowp[16 * b];
-        op[s][16] = rowp[col16 - lm];
+        for (int q = 0; q < 4; q++) op4[s][q] = *reinterpret_cast<const vec4u *>(rowp + 64 * q + 4 * lm);
+        op16[s] = rowp[col16];
         T x = xn[s];
         if (P.bias_sub != nullptr) x -= P.bias_sub[idxn[s]];
         xw[s] = x * okn[s];                              // common.c:991-996 (0 for the padding of the last k-step)
@@ -108,8 +121,8 @@ __device__ __forceinline__ void gk_quarter(const CholParams<T> &P, size_t st, in
             const T ok = (it * GK_PD + s < nsteps) ? okf[s] : T(0);
             T o[GK_NB], a[GK_NB];
 #pragma unroll
-            for (int b = 0; b < GK_NB; b++) o[b] = op[s][b];
-            if (!v16) o[16] = T(0);
+            for (int b = 0; b < 16; b++) o[b] = op4[s][b >> 2][b & 3];
+            o[16] = v16 ? op16[s] : T(0);
             const T xws = (it * GK_PD + s < nsteps) ? xw[s] : T(0);
             static_for<0, GK_NB>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
@@ -147,7 +160,7 @@ __device__ __forceinline__ void gk_quarter(const CholParams<T> &P, size_t st, in
 // One workgroup of four wavefronts per work item (CholSlices: slices of the split rows first, then whole rows in processing
 // order), items handed out by a counter.  W.row_first / W.nrows = the range of work items, SL.part_base the item of slot 0.
 template <typename T>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
 gramk_producer_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const CholSlices<T> SL)
 {
     __shared__ int s_item;
@@ -253,7 +266,7 @@ __device__ __forceinline__ void gc_row(const CholParams<T> &P, GcShared<T> &S, c
     // ---- 1. N = -(initial matrix + partials + diagonal);  right-hand side ----
     T r0 = T(0), r1 = T(0);                    // unknowns tid and 256 + tid
     if (R.has_u || P.rhs_prefilled_all) {      // w U C prefilled (collective.c:5768-5773)
-        if (tid < kt) r0 = arow[tid];
+        r0 = arow[gk_unknown(tid)];                // (tile-order position tid < 256 <-> an unknown < 256 <= kt - 1)
         if (256 + tid < kt) r1 = arow[256 + tid];
     }
     auto add_tiles = [&](const T *__restrict__ pp) {           // thirteen 16-byte loads in flight
@@ -405,7 +418,8 @@ __device__ __forceinline__ void gc_row(const CholParams<T> &P, GcShared<T> &S, c
         if (Q == 0 && lane < 16) S.xall[16 * bi + lane] = xm;
     });
     if (Q == 0)
-        for (int e = lane; e < kt; e += 64) arow[e] = S.xall[e];
+        for (int t = lane; t < GK_NB * 16; t += 64)
+            if (gk_unknown(t) < kt) arow[gk_unknown(t)] = S.xall[t];
 }
 
 // One workgroup of four wavefronts per row; rows [P.row_first, P.nrows) of the processing order handed out by P.counter.
@@ -458,7 +472,8 @@ gramk_consumer_kernel(const CholParams<T> P)
     }
 }
 
-// out[t][lane][r]: the [lane][register] form of tile_pack_kernel's output (the layout of the producer's partials)
+// out[t][lane][r]: the [lane][register] form of tile_pack_kernel's output, in the producer's order of the unknowns (gk_unknown):
+// the layout of its partials
 template <typename T>
 __global__ void tile_pack_lane_kernel(const T *__restrict__ M, int lim, int NB, T *__restrict__ out)
 {
@@ -469,7 +484,7 @@ __global__ void tile_pack_lane_kernel(const T *__restrict__ M, int lim, int NB, 
     int bi = 0, rem = t;
     while (rem >= NB - bi) { rem -= NB - bi; bi++; }
     const int bj = bi + rem;
-    const int gi = 16 * bi + CholMfma<T>::row_of(lane, r), gj = 16 * bj + (lane & 15);
+    const int gi = gk_unknown(16 * bi + CholMfma<T>::row_of(lane, r)), gj = gk_unknown(16 * bj + (lane & 15));
     const int lo = min(gi, gj), hi = max(gi, gj);
     out[e] = (hi < lim) ? M[(size_t)lo * lim + hi] : T(0);
 }

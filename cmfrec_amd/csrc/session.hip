@@ -283,8 +283,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             const int batch_env = getenv("CMFREC_HIP_GRAMK_BATCH") ? atoi(getenv("CMFREC_HIP_GRAMK_BATCH")) : 0;
             const int BATCH = batch_env > 0 ? batch_env : 32768;                      // x 158 KB = 5.2 GB of partials
             const size_t cap_items = (size_t)std::min<long long>((long long)nsl + (total - n_heavy), std::max(BATCH, max_row_items));
+            // (Tried: two half-size buffers with the consumer of a batch on the second stream beside the producer of the next
+            // one -- c5 shard 146.3 against 145.8 ms / iteration in line, profiles/r03: not kept.)
             if (X->chol_part.n < cap_items * GK_PART) X->chol_part.alloc(cap_items * GK_PART);
-            SLT.part = X->chol_part.ptr;
             // the launch's initial matrices once, in the tile layout of the partials (the consumer adds them like a partial)
             const real_t *init1 = nullptr, *init2 = nullptr;
             {
@@ -304,20 +305,22 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             int ctr = 4, rc_all = 0;
             auto run_batch = [&](int item0, int item1, int row0, int row1) {
                 if (ctr + 2 > 60) ctr = 4;
+                real_t *part = X->chol_part.ptr;
                 HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr + ctr, 0, 2 * sizeof(int), dev.stream));
                 CholSlices<real_t> SL = SLT;
+                SL.part = part;
                 SL.part_base = item0;
                 CholParams<real_t> W = P;
                 W.row_first = item0; W.nrows = item1; W.counter = dev.row_counter.ptr + ctr;
                 if (item1 > item0) {
                     poison_lds(dev.stream, dev.num_cus);
-                    hipLaunchKernelGGL(gramk_producer_kernel<real_t>, dim3(std::min(item1 - item0, dev.num_cus)), dim3(256), 0, dev.stream, W,
+                    hipLaunchKernelGGL(gramk_producer_kernel<real_t>, dim3(std::min(item1 - item0, 2 * dev.num_cus)), dim3(256), 0, dev.stream, W,
                                        X->desc.ptr, SL);
                     HIP_CHECK(hipGetLastError());
                 }
                 CholParams<real_t> H = P;
                 H.row_first = row0; H.nrows = row1; H.counter = dev.row_counter.ptr + ctr + 1;
-                H.gk_part = X->chol_part.ptr; H.gk_row_off = X->row_sl_off.ptr; H.gk_n_heavy = n_heavy; H.gk_n_slices = nsl; H.gk_base = item0;
+                H.gk_part = part; H.gk_row_off = X->row_sl_off.ptr; H.gk_n_heavy = n_heavy; H.gk_n_slices = nsl; H.gk_base = item0;
                 H.gk_stride = (size_t)GK_PART; H.gk_init1 = init1; H.gk_init2 = init2;
                 if (row1 > row0) {
                     poison_lds(dev.stream, dev.num_cus);

@@ -289,15 +289,26 @@ class CMF(_Base):
         self._setup(use_float, nthreads, n_jobs)
 
     def fit(self, X, U=None, I=None, shape=None, A0=None, B0=None, biasA0=None, biasB0=None, W=None):
-        """``W``: observation weights, one per entry of ``X`` in its COO order (reference ``CMF.fit(X, ..., W=...)``,
-        cmfrec/__init__.py:3066; an array(nnz,) for sparse ``X``)."""
-        row, col, val, m, n = _coo_triplet(X, shape)
+        """``X``: SciPy sparse matrix / COO triplet, or a dense 2-D array with NaN for the missing entries (the plain model:
+        no side information).  ``W``: observation weights, one per entry of ``X`` in its COO order (reference
+        ``CMF.fit(X, ..., W=...)``, cmfrec/__init__.py:3066; an array(nnz,) for sparse ``X``, an array(m, n) for dense ``X``)."""
         lib, R = self._lib()
         dt = self.dtype_
+        Xfull = None
+        if isinstance(X, np.ndarray):
+            if X.ndim != 2:
+                raise ValueError("a dense 'X' must be a 2-D array")
+            if self.NA_as_zero:
+                raise ValueError("'NA_as_zero' is for a sparse 'X'.")
+            Xfull = np.ascontiguousarray(X, dt)
+            m, n = Xfull.shape
+            row = col = np.empty(0, np.int32); val = np.empty(0, dt)
+        else:
+            row, col, val, m, n = _coo_triplet(X, shape)
         Wv = None
         if W is not None:
             Wv = np.ascontiguousarray(np.asarray(W).reshape(-1), dt)
-            if Wv.shape[0] != len(val):
+            if Wv.shape[0] != (len(val) if Xfull is None else Xfull.size):
                 raise ValueError("'W' must have the same number of entries as 'X'.")
         lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, dt)
         l16 = None if self._l16 is None else np.ascontiguousarray(self._l16, dt)
@@ -339,7 +350,7 @@ class CMF(_Base):
             _lib.ptr(biasA), _lib.ptr(biasB), _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), _lib.ptr(Ai), _lib.ptr(Bi),
             C.c_bool(imp), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean), _lib.ptr(Ucm),
             _lib.ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
-            C.c_size_t(len(val)), None, _lib.ptr(Wv), C.c_bool(self.user_bias), C.c_bool(self.item_bias),
+            C.c_size_t(len(val)), _lib.ptr(Xfull), _lib.ptr(Wv), C.c_bool(self.user_bias), C.c_bool(self.item_bias),
             C.c_bool(self.center), R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16), C.c_bool(self.scale_lam),
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(self.scale_bias_const), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),

@@ -19,6 +19,7 @@ class AlsSession:
         M = _lib.Model if self.dtype is np.float64 else _lib.ModelF
         rb, re = (0, m) if row_range is None else row_range
         cb, ce = (0, n) if col_range is None else col_range
+        self._row_range, self._col_range = (int(rb), int(re)), (int(cb), int(ce))
         self.model = M(implicit=int(implicit), m=m, n=n, k=k, k_main=k_main, k_user=k_user, k_item=k_item,
                        user_bias=int(user_bias), item_bias=int(item_bias), scale_lam=int(scale_lam),
                        scale_lam_sideinfo=int(scale_lam_sideinfo), use_cg=int(use_cg), precondition_cg=int(precondition_cg),
@@ -135,6 +136,15 @@ class AlsSession:
         tdt = torch.float64 if self.dtype is np.float64 else torch.float32
         assert key.is_cuda and other.is_cuda and val.is_cuda and key.dtype == torch.int32 and other.dtype == torch.int32 and val.dtype == tdt
         key, other, val = key.contiguous(), other.contiguous(), val.contiguous()
+        if val.numel():
+            # the device build counts with atomics on counts[key] and sizes its sort from the row count: an index outside the
+            # shard would corrupt HBM silently (the host entry points validate theirs the same way)
+            lo, hi = (self._row_range if which == "r" else self._col_range)
+            n_other = self.n if which == "r" else self.m
+            kmin, kmax = torch.aminmax(key)
+            omin, omax = torch.aminmax(other)
+            if int(kmin) < 0 or int(kmax) >= hi - lo or int(omin) < 0 or int(omax) >= n_other:
+                raise ValueError("set_X_coo_device: index outside the shard (key in [0, %d), other in [0, %d))" % (hi - lo, n_other))
         torch.cuda.current_stream().synchronize()      # the tensors were produced on torch's stream, the session has its own
         _lib.check(self.lib.cmfrec_hip_session_set_X_coo_device(
             self.handle, C.c_int(ord(which)), C.c_void_p(key.data_ptr()), C.c_void_p(other.data_ptr()), C.c_void_p(val.data_ptr()),

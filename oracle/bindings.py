@@ -733,11 +733,15 @@ class Reference:
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
                                     l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
-                                    l1_lam_unique=None, scale_bias_const=False, weight=None, NA_as_zero_X=False):
+                                    l1_lam_unique=None, scale_bias_const=False, weight=None, NA_as_zero_X=False, Xfull=None):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II.
-        weight: observation weights, one per entry of X."""
+        weight: observation weights, one per entry of X.  Xfull: dense X [m, n] with NaN for the missing entries instead
+        of the triplet (row / col / val are then ignored; weight, if given, is [m, n] too)."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
         weight = None if weight is None else np.ascontiguousarray(weight, self.dtype)
+        if Xfull is not None:
+            Xfull = np.array(Xfull, self.dtype, order="C", copy=True)        # the reference centres it in place
+            row = col = np.empty(0, np.int32); val = np.empty(0, self.dtype)
         lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
         l16 = None if l1_lam_unique is None else np.ascontiguousarray(l1_lam_unique, self.dtype)
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -772,7 +776,7 @@ class Reference:
             C.c_bool(add_implicit_features), C.c_bool(reset_values), C.c_int(seed),
             _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
-            None, _ptr(weight), C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
+            _ptr(Xfull), _ptr(weight), C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
             self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),

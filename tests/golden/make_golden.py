@@ -21,7 +21,12 @@ import golden_cases as gc              # noqa: E402
 from oracle.bindings import Reference  # noqa: E402
 
 
+ONLY = sys.argv[1:]          # e.g. `make_golden.py g19`: write only the fixtures whose name starts with one of these
+
+
 def save(name, **arrs):
+    if ONLY and not any(name.startswith(o + "_") for o in ONLY):
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrs)
     print("%-40s %7.1f KB" % (name, os.path.getsize(path) / 1024))
@@ -292,6 +297,15 @@ def main():
                 if v is not None:
                     out["c%d_%s" % (ci, key)] = v
         save("g18_na_as_zero_" + tag, **out)
+
+        # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
+        out = {}
+        for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):
+            r = gc.dense_reference(R, gc.dense_problem(dt, variant), opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g19_dense_X_" + tag, **out)
 
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}

@@ -915,3 +915,116 @@ def naz_hip(d, opts, dtype, NA_as_zero=True):
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     return out
+
+
+# ---- dense X (NaN = missing): optimizeA Cases 1-2, common.c:2787-3116 ------------------------------------------------
+def dense_problem(dtype, variant, seed=131):
+    """variant: 'full' no missing entry; 'near' 13 % of the rows and 10 % of the columns have missing entries (both half-steps
+    are Case 1); 'holes' half of the cells missing, one row and one column entirely (Case 2, every row misses many entries: the
+    solver asked for); 'mixed' 10 % of the rows miss half of their cells, so the rows are near dense (Case 1) and the columns are
+    not (Case 2) -- but every column misses fewer than 2 k entries, which the reference solves in closed form from the
+    precomputed B^T B whatever use_cg says (factors_closed_form, common.c:662, :759-790)."""
+    rng = np.random.default_rng(seed)
+    m, n, k = 90, 60, 6
+    X = (0.5 * rng.integers(1, 11, (m, n))).astype(dtype)
+    if variant == "near":
+        rows = rng.choice(m, 12, replace=False); cols = rng.choice(n, 6, replace=False)
+        for r in rows:
+            X[r, rng.choice(cols, 3, replace=False)] = np.nan
+    elif variant == "holes":
+        X[rng.random((m, n)) < 0.5] = np.nan
+        X[4, :] = np.nan; X[:, 7] = np.nan
+    elif variant == "mixed":
+        for r in rng.choice(m, 9, replace=False):
+            X[r, rng.random(n) < 0.5] = np.nan
+    d = dict(m=m, n=n, k=k, X=X)
+    d["row"], d["col"] = [a.astype(np.int32) for a in np.nonzero(~np.isnan(X))]     # row-major order of the present entries
+    d["ratings"] = X[d["row"], d["col"]]
+    d["Wfull"] = (0.25 * rng.integers(1, 9, (m, n))).astype(dtype)
+    d["W"] = d["Wfull"][d["row"], d["col"]]
+    d["A0"] = (rng.standard_normal((m, k)) * 0.1).astype(dtype); d["B0"] = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    d["bA"] = (rng.standard_normal(m) * 0.1).astype(dtype); d["bB"] = (rng.standard_normal(n) * 0.1).astype(dtype)
+    return d
+
+
+# (name, variant, options).  weights: dense weights (Case 2 whatever the pattern).  seed: the reference's own random start and
+# its dense bias start values.
+DENSE_CASES = [
+    ("full, cg asked for", "full", dict(use_cg=True, finalize_chol=True)),
+    ("full, chol, scale_lam", "full", dict(use_cg=False, scale_lam=True)),
+    ("near dense, chol", "near", dict(use_cg=False)),
+    ("near dense, cg asked for", "near", dict(use_cg=True, finalize_chol=False)),
+    ("holes, cg", "holes", dict(use_cg=True, finalize_chol=True, scale_lam=True)),
+    ("holes, chol, no biases", "holes", dict(use_cg=False, user_bias=False, item_bias=False)),
+    ("mixed, cg", "mixed", dict(use_cg=True, finalize_chol=False)),
+    ("holes, weights, cg", "holes", dict(use_cg=True, finalize_chol=False, weights=True)),
+    ("full, weights, chol", "full", dict(use_cg=False, weights=True, scale_lam=True)),
+    ("near dense, nonneg", "near", dict(use_cg=False, nonneg=True, user_bias=False, item_bias=False, center=False)),
+    ("holes, seeded", "holes", dict(use_cg=True, finalize_chol=True, seed=5)),
+    ("near dense, seeded, user bias", "near", dict(use_cg=False, item_bias=False, seed=6)),
+    ("full, seeded", "full", dict(use_cg=True, finalize_chol=False, seed=7)),
+]
+
+
+def dense_reference(R, d, opts, nthreads=2):
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    W = d["Wfull"] if o.pop("weights", False) else None
+    kw = dict(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+    A0, B0 = d["A0"].copy(), d["B0"].copy()
+    if seed is not None:
+        A0[:] = 0; B0[:] = 0
+        r = R.fit_collective_explicit_als(A0, B0, None, None, None, d["k"], lam=0.3, niter=3, nthreads=nthreads, Xfull=d["X"], weight=W,
+                                          reset_values=True, seed=seed, **kw)
+    else:
+        r = R.fit_collective_explicit_als(A0, B0, None, None, None, d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3, niter=3,
+                                          nthreads=nthreads, Xfull=d["X"], weight=W, **kw)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def dense_oracle(O, d, variant, opts, nthreads=2):
+    """The present entries as a sparse X.  Without weights the 'full' / 'near' / 'mixed' patterns are closed-form solves
+    whatever use_cg says (Case 1, and Case 2 with few missing entries per row).  None for seeded starts and non-negative factors."""
+    o = dict(opts)
+    if "seed" in o or o.get("nonneg"):
+        return None
+    W = d["W"] if o.pop("weights", False) else None
+    use_cg, fin = o.pop("use_cg", False), o.pop("finalize_chol", False)
+    if W is None and variant in ("full", "near", "mixed"):
+        use_cg = fin = False
+    # rows / columns without a present entry: zero in the dense reference (factors and bias), left alone by the sparse path
+    A0, B0, bA, bB = d["A0"].copy(), d["B0"].copy(), d["bA"].copy(), d["bB"].copy()
+    er = np.bincount(d["row"], minlength=d["m"]) == 0; ec = np.bincount(d["col"], minlength=d["n"]) == 0
+    A0[er] = 0; bA[er] = 0; B0[ec] = 0; bB[ec] = 0
+    r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=bA, biasB=bB,
+                           lam=0.3, niter=3, nthreads=nthreads, weight=W, use_cg=use_cg, finalize_chol=fin, **o)
+    assert r["ret"] == 0
+    r["biasA"][er] = 0; r["biasB"][ec] = 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if opts.get("user_bias", True): out["biasA"] = r["biasA"]
+    if opts.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def dense_hip(d, opts, dtype, as_sparse=False):
+    """as_sparse: the same entries as a COO triplet (the solver then follows use_cg in both half-steps)."""
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    weights = o.pop("weights", False)
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, use_float=dtype is np.float32, precompute_for_predictions=False,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1,
+              **(dict(random_state=seed) if seed is not None else {}), **o)
+    start = {} if seed is not None else dict(A0=d["A0"], B0=d["B0"], biasA0=d["bA"], biasB0=d["bB"])
+    if as_sparse:
+        mdl.fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]), W=d["W"] if weights else None, **start)
+    else:
+        mdl.fit(d["X"], W=d["Wfull"] if weights else None, **start)
+    out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out

@@ -314,3 +314,45 @@ def test_NA_as_zero_X(oracles, dtype):
         CMF(NA_as_zero=True)                          # precompute_for_predictions defaults to True
     with pytest.raises(RuntimeError):
         CMF(k=4, NA_as_zero=True, precompute_for_predictions=False, nonneg=True).fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dense_X(oracles, dtype):
+    """G19 through the estimator (CMF.fit(X = 2-D array with NaN)): every pattern of the reference's dense cases -- complete,
+    nearly complete (closed form whatever use_cg says), half missing with an empty row and column (the solver asked for),
+    rows nearly complete but columns not (every column misses few entries: closed form as well), dense weights, non-negative
+    factors, the reference's seeded start with its dense bias start values."""
+    g = gc.load("g19_dense_X", dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):
+        d = gc.dense_problem(dtype, variant)
+        got = gc.dense_hip(d, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        ref = gc.dense_oracle(oracles[dtype], d, variant, opts)
+        if ref is not None:
+            assert gc.compare_fits(got, ref) < tol, name
+    # the closed form of Case 1 is a different model from three CG steps on the same entries
+    d = gc.dense_problem(dtype, "near")
+    opts = dict(use_cg=True, finalize_chol=False)
+    assert gc.compare_fits(gc.dense_hip(d, opts, dtype, as_sparse=True), gc.dense_hip(d, opts, dtype)) > 1e-3
+    # an empty row / column is zero (the sparse path leaves it at its start values)
+    d = gc.dense_problem(dtype, "holes")
+    got = gc.dense_hip(d, dict(use_cg=False), dtype)
+    assert not got["A"][4].any() and not got["B"][7].any() and got["biasA"][4] == 0 and got["biasB"][7] == 0
+    # refused: scale_lam with rows that miss only a few entries (the reference's multiplier there is not the entry count),
+    # side information, NA_as_zero
+    from cmfrec_amd import CMF
+    dn = gc.dense_problem(dtype, "near")
+    with pytest.raises(RuntimeError):
+        CMF(k=4, scale_lam=True, precompute_for_predictions=False).fit(dn["X"])
+    with pytest.raises(RuntimeError):
+        CMF(k=4, precompute_for_predictions=False).fit(dn["X"], U=np.ones((dn["m"], 2), dtype))
+    # ... and under use_cg a half-step whose rows partly miss few and partly many entries (two solvers in one half-step there)
+    dm = gc.dense_problem(dtype, "holes")["X"].copy()
+    dm[:20, :] = 1.0; dm[:20, :3] = np.nan
+    with pytest.raises(RuntimeError):
+        CMF(k=4, use_cg=True, precompute_for_predictions=False).fit(dm)
+    CMF(k=4, use_cg=False, precompute_for_predictions=False).fit(dm)
+    with pytest.raises(ValueError):
+        CMF(k=4, NA_as_zero=True, precompute_for_predictions=False).fit(dn["X"])

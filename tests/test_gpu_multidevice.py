@@ -4,7 +4,8 @@ rows between the replicas with peer copies ordered by events (cmfrec_amd/csrc/fi
 repeat, which shards ONE device -- the only way to run the path on a single-GPU box, and it exercises everything but the
 xGMI hop: block boundaries (equal users, nnz-balanced items), shard construction from the COO, the exchange and its event
 ordering, the epilogue on the first replica.  Rows are independent given the opposing matrix, so the result must be the
-single-device fit bit for bit."""
+single-device fit bit for bit -- for rows that take the same kernel path on the shard as on the whole matrix (at most 1024
+entries); split rows choose their path and slice length from the shard's statistics and agree to rounding."""
 import numpy as np
 import pytest
 
@@ -28,6 +29,28 @@ def test_devices_env_matches_single_device(devices, use_cg, use_float, monkeypat
     assert np.isfinite(shard.A_).all() and np.abs(shard.A_).max() > 0
     assert np.array_equal(shard.A_, base.A_) and np.array_equal(shard.B_, base.B_)
     assert np.array_equal(shard._BtB, base._BtB)
+
+
+@pytest.mark.parametrize("use_float", [False, True])
+def test_devices_env_split_rows_agree_to_rounding(use_float, monkeypatch):
+    """A user and an item above the split-row boundary (> 1024 entries): the shards may pick the other split-row path or slice
+    length than the single-device run (per-shard statistics), so the sums may be ordered differently -- equal to rounding."""
+    from cmfrec_amd import CMF_implicit
+    m, n = 2600, 2400
+    row, col, val = make_coo(m, n, 90000, 5, heavy_row=(5, 2000), empty_rows=(7,))
+    hr = np.arange(0, m, 2, dtype=row.dtype)[:1200]                      # a heavy item too: column 3 rated by 1200 users
+    keep = ~((col == 3) & np.isin(row, hr))
+    row = np.concatenate([row[keep], hr]); col = np.concatenate([col[keep], np.full(hr.size, 3, col.dtype)])
+    val = np.concatenate([val[keep], np.ones(hr.size, val.dtype)])
+    kw = dict(k=20, lambda_=3.0, niter=3, use_cg=True, use_float=use_float, finalize_chol=False, random_state=7)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF_implicit(**kw).fit((row, col, val), shape=(m, n))
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", "0,0,0")
+    shard = CMF_implicit(**kw).fit((row, col, val), shape=(m, n))
+    tol = 2e-4 if use_float else 1e-11
+    for a, b in ((shard.A_, base.A_), (shard.B_, base.B_)):
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= tol * np.abs(b).max()
 
 
 def test_devices_env_ignores_bad_ordinals(monkeypatch):

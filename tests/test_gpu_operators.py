@@ -229,6 +229,26 @@ def test_lane_primitives_selftest(dtype):
     assert _lib.load(dtype).cmfrec_hip_selftest_lanes() == 0
 
 
+def test_coo_device_rejects_indices_outside_the_shard():
+    """set_X_coo_device takes caller tensors: a key outside [0, rows) or an opposing index outside [0, n_other) must be refused
+    before the device build counts with atomics on it (the host entry points validate theirs)."""
+    import torch
+    from cmfrec_amd.session import AlsSession
+    dev = torch.device("cuda", 0)
+    s = AlsSession(50, 40, 8, implicit=True, dtype=np.float32)
+    key = torch.tensor([0, 3, 49], dtype=torch.int32, device=dev)
+    oth = torch.tensor([1, 39, 7], dtype=torch.int32, device=dev)
+    val = torch.ones(3, dtype=torch.float32, device=dev)
+    s.set_X_coo_device("r", key, oth, val)                              # in range: accepted
+    for bad_key, bad_oth in ((50, 1), (-1, 1), (3, 40), (3, -2)):
+        k2 = key.clone(); o2 = oth.clone()
+        k2[1] = bad_key; o2[1] = bad_oth
+        with pytest.raises(ValueError, match="outside the shard"):
+            s.set_X_coo_device("r", k2, o2, val)
+    with pytest.raises(ValueError, match="outside the shard"):          # 'c': key is the column, other the row
+        s.set_X_coo_device("c", torch.tensor([40], dtype=torch.int32, device=dev), torch.tensor([0], dtype=torch.int32, device=dev), val[:1])
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("m,n,nnz", [(300, 200, 6000), (5000, 70000, 400000), (7, 3, 0)])
 def test_coo_device_matches_host(dtype, m, n, nnz):

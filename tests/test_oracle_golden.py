@@ -216,3 +216,20 @@ def test_NA_as_zero_X(oracles, dtype):
         assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
         seen += 1
     assert seen >= 6
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_X(oracles, dtype):
+    """G19: fit_collective_explicit_als on a dense X with NaN (the reference's optimizeA Cases 1-2) against the restatement run
+    on the present entries as a sparse X: closed form in the half-steps whose rows are all / nearly all complete (whatever
+    use_cg says), the solver asked for otherwise; rows / columns without a present entry are zero."""
+    g = gc.load("g19_dense_X", dtype)
+    seen = 0
+    for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):
+        got = gc.dense_oracle(oracles[dtype], gc.dense_problem(dtype, variant), variant, opts)
+        if got is None:
+            continue
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+        seen += 1
+    assert seen >= 8
