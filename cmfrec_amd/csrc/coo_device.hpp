@@ -274,9 +274,8 @@ inline void finalize_vheavy(SparseShard &S, int n_other, hipStream_t st)
 {
     const int nvh = S.bin_rows[BIN_VHEAVY];
     S.n_other = n_other;
-    if (nvh <= 0 || n_other <= 0 || getenv("CMFREC_HIP_VH_NOSORT")) return;
-    int VH_NX = 8;                                  // index ranges (a multiple of the XCD count)
-    if (const char *e = getenv("CMFREC_HIP_VH_RANGES")) VH_NX = std::max(VH_XCDS, std::min(VH_NX_MAX, atoi(e) / VH_XCDS * VH_XCDS));
+    if (nvh <= 0 || n_other <= 0) return;
+    const int VH_NX = 8;                            // index ranges (a multiple of the XCD count)
     std::vector<RowDesc> hd(nvh);
     HIP_CHECK(hipMemcpyAsync(hd.data(), S.desc.ptr, (size_t)nvh * sizeof(RowDesc), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));

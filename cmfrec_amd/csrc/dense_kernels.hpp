@@ -10,52 +10,6 @@
 
 namespace cmfhip {
 
-// Stage 1: each workgroup reduces a contiguous chunk of rows into a private k x k partial (upper
-// and lower computed alike, the result is symmetric by construction: entry (i,j) and (j,i) are
-// the same products summed in the same order).  Stage 2 sums the partials in block order, so the
-// result is deterministic (no floating-point atomics).
-template <typename T>
-__global__ void __launch_bounds__(256)
-gram_partial_kernel(const T *__restrict__ B, size_t ldb, int n, int k, int rows_per_block,
-                    T *__restrict__ partial)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *Bs = reinterpret_cast<T *>(smem_raw);          // [32][k]
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(n, r0 + rows_per_block);
-    const int nent = k * k;
-    constexpr int MAXE = 16;                          // entries per thread (k <= 64 -> 16)
-    T acc[MAXE];
-#pragma unroll
-    for (int e = 0; e < MAXE; e++) acc[e] = T(0);
-    for (int rb = r0; rb < r1; rb += 32) {
-        const int nr = min(32, r1 - rb);
-        __syncthreads();
-        for (int e = tid; e < nr * k; e += 256) {
-            int r = e / k, c = e % k;
-            Bs[r * k + c] = B[(size_t)(rb + r) * ldb + c];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < MAXE; e++) {
-            int ent = tid + 256 * e;
-            if (ent < nent) {
-                int i = ent / k, j = ent % k;
-                int lo = min(i, j), hi = max(i, j);   // same operand order for (i,j) and (j,i)
-                T s = acc[e];
-                for (int r = 0; r < nr; r++) s += Bs[r * k + lo] * Bs[r * k + hi];
-                acc[e] = s;
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < MAXE; e++) {
-        int ent = tid + 256 * e;
-        if (ent < nent) partial[(size_t)ent * gridDim.x + blockIdx.x] = acc[e];     // [entry][block]
-    }
-}
-
 // one wavefront per entry: lane l adds blocks l, l+64, ... in order, then a fixed butterfly --
 // the summation order depends only on (n, k), never on scheduling.
 template <typename T>

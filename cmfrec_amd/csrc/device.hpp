@@ -284,7 +284,6 @@ struct SparseShard {
         long long vh_total = 0;
         for (int q = 0; q < nrows && (long long)lens_sorted[q] >= vh_min; q++) vh_total += (long long)lens_sorted[q];
         slice_len = (vh_total < (long long)GRAM_SLICE * 1024) ? 256 : GRAM_SLICE;
-        if (const char *e = getenv("CMFREC_HIP_GRAM_SLICE_LEN")) slice_len = std::min(GRAM_SLICE, std::max(16, atoi(e) / 16 * 16));   // A/B measurements
         for (int q = 0; q < nrows; q++) {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
@@ -507,15 +506,8 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
         if (nblocks < 1) nblocks = 1;
         size_t need = (size_t)nblocks * k * k;
         if (ws.partial.n < need) ws.partial.alloc(need);
-        static const bool use_valu = getenv("CMFREC_HIP_GRAM_VALU") != nullptr;    // A/B switch, MFMA is the default
-        if (use_valu) {
-            size_t smem = (size_t)32 * k * sizeof(real_t);
-            hipLaunchKernelGGL(gram_partial_kernel<real_t>, dim3(nblocks), dim3(256), smem, dev.stream,
-                               B, ldb, n, k, rpb, ws.partial.ptr);
-        } else {
-            hipLaunchKernelGGL(gram_mfma_partial_kernel<real_t>, dim3(nblocks), dim3(256), 0, dev.stream,
-                               B, ldb, n, k, rpb, ws.partial.ptr);
-        }
+        hipLaunchKernelGGL(gram_mfma_partial_kernel<real_t>, dim3(nblocks), dim3(256), 0, dev.stream,
+                           B, ldb, n, k, rpb, ws.partial.ptr);
         hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 3) / 4), dim3(256), 0, dev.stream,
                            ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
     } else {
@@ -617,8 +609,6 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
     int teams_needed = (count + RPB - 1) / RPB;
     int grid = std::min(teams_needed, dev.num_cus * blocks_per_cu);
-    if (const char *e = getenv("CMFREC_HIP_CG_GRID_PCT"))       // occupancy experiments: a fraction of the resident grid
-        grid = std::max(1, std::min(grid, dev.num_cus * blocks_per_cu * atoi(e) / 100));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, st, P);
     HIP_CHECK(hipGetLastError());
     if (tm) {
@@ -839,10 +829,9 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
                            dev.stream, P, G);
         else {
             // double precision, 48 < k <= 52 (k = 50): the two to four columns of the last block as vector products instead of
-            // four matrix-core tiles per slab (CMFREC_HIP_GRAM_REMV=0: all ten tiles, A/B and cross-check)
-            static const bool remv_off = getenv("CMFREC_HIP_GRAM_REMV") != nullptr && getenv("CMFREC_HIP_GRAM_REMV")[0] == '0';
+            // four matrix-core tiles per slab
             const dim3 gw(std::min((X.n_slices + 3) / 4, dev.num_cus * 4));
-            const int rem = (sizeof(real_t) == 8 && !remv_off) ? P.k - 16 * (GRAM_NTT - 1) : 0;
+            const int rem = (sizeof(real_t) == 8) ? P.k - 16 * (GRAM_NTT - 1) : 0;
             switch (rem) {
                 case 1: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 1>), gw, dim3(256), 0, dev.stream, P, G); break;
                 case 2: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 2>), gw, dim3(256), 0, dev.stream, P, G); break;
@@ -988,7 +977,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     // launch, so ramp-up and tail of every bin weigh four times as much: its bins alternate between the two streams,
     // the next bin fills the CUs the previous one is vacating.  (Not for whole blocks: there the per-bin event timings
     // feed the roofline report and must not overlap.)
-    const bool alt = (X.is_part && getenv("CMFREC_HIP_PART_SERIAL") == nullptr) || getenv("CMFREC_HIP_BINS_ALT") != nullptr;
+    const bool alt = X.is_part;
     DeviceInfo &d = const_cast<DeviceInfo &>(dev);
     // Round 3: the bins of a half-step side by side.  Every bin is a persistent launch whose teams claim rows from a counter, so
     // a launch that shares the chip with its neighbours just takes its rows as workgroups become resident; what disappears are
@@ -1102,9 +1091,8 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     // tiled kernels: the weighted Gramian w C^T C + w_i Bi^T Bi acts on the unknowns like the implicit model's B^T B, the row's
     // constant w (U C)_row + w_i sum Bi_j joins the first residual (GRAMX builds, cg_kernels.hpp).  Rows without entries
     // (still solved from their side information / zeroed) go through the generic kernel afterwards.
-    static const bool block_generic = getenv("CMFREC_HIP_BLOCK_CG_GENERIC") != nullptr;      // A/B switch and cross-check
     const bool block = (c.kc > 0 || c.Bi != nullptr);
-    const bool tiled_block = block && !block_generic && cg_variant_from_env() != CgVariant::Generic && !c.implicit && c.koff == 0 && !c.precond &&
+    const bool tiled_block = block && cg_variant_from_env() != CgVariant::Generic && !c.implicit && c.koff == 0 && !c.precond &&
                              S <= 8 && c.X2 == nullptr && (c.kc == 0 || (c.rows_with_u >= X.nrows && c.CtC != nullptr && c.UC != nullptr)) &&
                              (c.Bi == nullptr || (c.gsum != nullptr && c.BiTBi != nullptr)) && c.kc <= c.k && c.ki <= c.k;
     if (tiled_block) {

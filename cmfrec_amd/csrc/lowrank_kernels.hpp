@@ -189,13 +189,14 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lm = lane & 15, g = lane >> 4;
-    constexpr size_t PERW = (size_t)NB * RSZ + 2 * NV + KTMAX + 16 * NB * 2;
+    constexpr size_t PERW = (size_t)NB * RSZ + 2 * NV + 2 * KTMAX + 16 * NB * 2;
     T *wbase = reinterpret_cast<T *>(smem_raw) + (size_t)wave * PERW;
     T *rinv = wbase;                         // [NB][16][LDR]
     T *yv0 = rinv + (size_t)NB * RSZ;        // [NV]  q -> y -> back-substituted
     T *xall = yv0 + NV;                      // [NV]  z
     T *tvec = xall + NV;                     // [KTMAX] t = D^-1 r~
-    int *idxs = reinterpret_cast<int *>(tvec + KTMAX);   // [16 NB] entry -> opposing row
+    T *dtab = tvec + KTMAX;                  // [KTMAX] 1 / D of the row (0 beyond k_t)
+    int *idxs = reinterpret_cast<int *>(dtab + KTMAX);   // [16 NB] entry -> opposing row
     T *xent = reinterpret_cast<T *>(idxs + 16 * NB);     // [16 NB] entry values (x_j - bias_j)
 
     const int kt = P.kt, kc = P.kc;
@@ -231,6 +232,13 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
             T x = ok ? P.values[st + a] : T(0);
             if (ok && P.bias_sub != nullptr) x -= P.bias_sub[ix];
             idxs[a] = ix; xent[a] = x;
+        }
+        // 1 / D_u once per row (round 2 divided in every 16-column group of both sweeps: 136 IEEE divisions per lane and row, a
+        // third of the kernel's instructions)
+        for (int u = lane; u < 16 * ngroups; u += 64) {
+            T dd = (u == kt - 1) ? lam_last : lam;
+            if (P.lam_eig != nullptr && u < kc) dd += P.lam_eig[u];
+            dtab[u] = (u < kt) ? T(1) / dd : T(0);
         }
         CMF_LDS_FENCE();
         int my_idx[NB]; T xl[NB]; unsigned amask = 0;
@@ -270,13 +278,11 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
                     }
                 }
                 T dinv[4], pre[4];
+                const vec4 dq = *reinterpret_cast<const vec4 *>(dtab + c0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int u = c0 + r;
-                    const int uc = min(u, kt - 1);
-                    T dd = (u == kt - 1) ? lam_last : lam;
-                    if (P.lam_eig != nullptr && uc < kc) dd += P.lam_eig[uc];
-                    dinv[r] = (u < kt) ? T(1) / dd : T(0);
+                    dinv[r] = dq[r];
                     if (PASS == 0) pre[r] = (P.pre != nullptr && u < kc) ? P.pre[(size_t)row * P.ldpre + min(u, kc - 1)] : T(0);
                     else pre[r] = T(0);
                 }
@@ -432,7 +438,7 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
 template <typename T>
 __host__ __device__ constexpr size_t lowrank_lds_elems(int NB)
 {
-    return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 320 + 16 * (size_t)NB * 2;
+    return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 2 * 320 + 16 * (size_t)NB * 2;
 }
 
 }  // namespace cmfhip

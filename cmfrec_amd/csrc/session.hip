@@ -181,8 +181,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 // SIMD, 256 registers for all MFMA destinations).  The producer build runs every row's rank-k update at full
                 // MFMA rate (no spills, three gather steps in flight) and leaves the raw tiles in HBM, the second build adds the
                 // initial matrix and factorises.  76 KB per work item each way; batches bound the scratch buffer.
-                static const int batch_env = getenv("CMFREC_HIP_CHOL_BATCH") ? atoi(getenv("CMFREC_HIP_CHOL_BATCH")) : 0;
-                const int BATCH = batch_env > 0 ? batch_env : 32768;
+                const int BATCH = 32768;
                 const std::vector<int> &ho = X->h_row_sl_off;
                 int max_row_items = 1;
                 for (int r = 0; r < n_heavy; r++) max_row_items = std::max(max_row_items, ho[r + 1] - ho[r]);
@@ -412,30 +411,18 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
         }
     }
     else if (T <= 6) launch(CHOL_KERN(6, 8, 32, 1), 6, 8, 32, 1);
-    else if (T <= 9) {
-        static const bool alt9 = getenv("CMFREC_HIP_CHOL_ROWS9") != nullptr;     // experiment: 4 waves per row, 2 rows per CU
-        if (alt9) launch(CHOL_KERN(9, 4, 16, 2), 9, 4, 16, 2);
-        else launch(CHOL_KERN(9, 8, 32, 1), 9, 8, 32, 1);
-    }
+    else if (T <= 9) launch(CHOL_KERN(9, 8, 32, 1), 9, 8, 32, 1);
 #ifdef CMFREC_HIP_FLOAT
     else if (T <= 12) launch(CHOL_KERN(12, 8, 32, 1), 12, 8, 32, 1);
-    else if (T <= 16) {
-        static const char *w16t = getenv("CMFREC_HIP_CHOL_ROWS16");
-        if (w16t != nullptr && w16t[0] == '8') launch(CHOL_KERN(16, 8, 16, 1), 16, 8, 16, 1);
-        else launch(CHOL_KERN(16, 16, 16, 1), 16, 16, 16, 1);
-    }
+    else if (T <= 16) launch(CHOL_KERN(16, 16, 16, 1), 16, 16, 16, 1);
     // k = 256 + bias (BASELINE config 5).  Two workgroups per CU do not pay here: at the 128 VGPRs that allows the
     // kernel spills (c5 share 1.6 -> 4.0 s per A-step; the same on 9 tiles in double: 22.6 -> 25.6 ms).
     else {
-        // 16 wavefronts per row (10 tile slots per wave instead of 20: the 8-wave build spills ~500 registers):
-        // c5 shard B-step 377 -> 274 ms.  CMFREC_HIP_CHOL_ROWS17=8 brings the 8-wave build back (A/B switch).
-        static const char *w17 = getenv("CMFREC_HIP_CHOL_ROWS17");
-        // 32 gathered rows per round instead of 16 (half the barriers and staging rounds of the rank-k update, which is
-        // 56 % of this kernel's time on the c5 shard -- phase skipping, profiles/r02_ag_*): item step 272 -> 219 ms.
+        // The rows the producer / consumer pair of launch_chol does not take (weights, non-negativity, L1, a second gather
+        // source): 16 wavefronts per row (10 tile slots per wave; the 8-wave build spilled ~500 registers: c5 shard B-step
+        // 377 -> 274 ms), 32 gathered rows per round (half the barriers and staging rounds of the rank-k update: 272 -> 219 ms).
         // The build is register-starved either way (128 VGPRs at 16 waves, ~1 KB of scratch per lane).
-        if (w17 != nullptr && w17[0] == '8') launch(CHOL_KERN(17, 8, 16, 1), 17, 8, 16, 1);
-        else if (w17 != nullptr && w17[0] == 'c') launch(CHOL_KERN(17, 16, 16, 1), 17, 16, 16, 1);      // "c16": the 16-row rounds
-        else launch(CHOL_KERN(17, 16, 32, 1), 17, 16, 32, 1);
+        launch(CHOL_KERN(17, 16, 32, 1), 17, 16, 32, 1);
     }
 #else
     else if (T <= 12) launch(CHOL_KERN(12, 8, 16, 1), 12, 8, 16, 1);
@@ -632,10 +619,13 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
         const int grid = std::min((last - first + 3) / 4, dev.num_cus * wps);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, Lc, X.desc.ptr);
     };
+    // (two wavefronts per SIMD at least: a single wave cannot keep the matrix pipe issuing, see gramk_kernels.hpp)
 #ifdef CMFREC_HIP_FLOAT
-    lr_launch(lowrank_rows_kernel<real_t, 8, 1>, 8, 1, n_full, std::max(n_full, n_gt64), 0);
-#endif
+    lr_launch(lowrank_rows_kernel<real_t, 8, 2>, 8, 2, n_full, std::max(n_full, n_gt64), 0);
+    lr_launch(lowrank_rows_kernel<real_t, 4, 3>, 4, 3, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
+#else
     lr_launch(lowrank_rows_kernel<real_t, 4, 2>, 4, 2, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
+#endif
     lr_launch(lowrank_rows_kernel<real_t, 2, 3>, 2, 3, std::max(n_full, n_gt32), X.nrows, 2);
     HIP_CHECK(hipGetLastError());
     // x[:kc] = Q x~[:kc]: one GEMM over the light rows (in processing order), then back to their rows
@@ -1645,7 +1635,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         if (Fi == nullptr) return;
         c.Mfull = s->bitbi_full.ptr;
         auto &G = s->gsegs[isA ? 0 : 1];
-        if (kk <= 64 * GSUM_MAXC && part < 0 && getenv("CMFREC_HIP_IMPF_SECOND_SOURCE") == nullptr) {
+        if (kk <= 64 * GSUM_MAXC && part < 0) {
             // the right-hand-side term by the segmented gather-sum, added to the (zeroed / w U C) rows the launch then starts
             // from: the row kernel gathers X only (first version: Bi as a second gather source of the same launch, c3 +
             // implicit features A-step 34.4 ms, B-step 20.5 ms)
@@ -1734,14 +1724,14 @@ static int update_implicit_feats(cmfrec_hip_session *s, bool isAi)
     HIP_CHECK(hipMemsetAsync(self, 0, (size_t)rows_self * kk * sizeof(real_t), dev.stream));
     CholCall c{self, (size_t)kk, F, ldf, kk, 0, nullptr, s->gram.ptr, 0, 0, 0, lam, lam, false, false, false, CHOL_NAZ};
     c.values_override = s->ones.ptr;
-    if (dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || getenv("CMFREC_HIP_NAZ_PER_ROW") != nullptr)
+    if (dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0)
         return launch_chol(dev, c, &X);             // coordinate descent: per row on the assembled system
     // one factorisation of the shared matrix, the row kernel only gathers the right-hand sides (first version: the
     // matrix factorised once per row -- c1 + implicit features 8 ms for Bi + Ai)
-    // ... first by the row kernel itself (rhs_only: CMFREC_HIP_NAZ_ROWKERNEL=1), whose staging loop made the longest
+    // ... first by the row kernel itself (rhs_only, still the path of wider systems), whose staging loop made the longest
     // row the critical path (Bi at the C1 shape 4.5 ms); now a two-stage segmented gather-sum
     auto &G = s->gsegs[isAi ? 0 : 1];
-    if (kk <= 64 * GSUM_MAXC && getenv("CMFREC_HIP_NAZ_ROWKERNEL") == nullptr) {
+    if (kk <= 64 * GSUM_MAXC) {
         if (G.nseg > 0)
             hipLaunchKernelGGL(gather_sum_segments_kernel<real_t>, dim3((G.nseg + 3) / 4), dim3(256), 0, dev.stream, X.p.ptr, X.i.ptr, F, ldf,
                                kk, G.seg_row.ptr, G.seg_off.ptr, G.nseg, s->gpartial.ptr);

@@ -80,7 +80,7 @@ int_t fit_collective_implicit_als(
 
 /* Replaces fit_collective_explicit_als, /root/reference/src/cmfrec.h:1851-1892 (body
  * src/collective.c:7263-9370; include/cmfrec.h.in:885-926).
- * Supported in this round: sparse X with missing-as-NA, no weights, biases/centering/scale_lam,
+ * Supported: sparse X with missing-as-NA, biases/centering/scale_lam,
  * CG / PCG or Cholesky, optional DENSE side information U[m_u, p] / II[n_i, q] without NaN (m_u, n_i may exceed
  * m, n: rows known from side information only are fitted to it alone and get a zero bias, :4967-5101, :8296)
  * (Cholesky: collective_closed_form_block, src/collective.c:1223-1847; CG: collective_block_cg, :2134-2903),
@@ -91,7 +91,11 @@ int_t fit_collective_implicit_als(
  * add_implicit_features with Ai, Bi, w_implicit (:8448-8534, :1704-1771, :2301-2304, :2624-2643, :2862-2868; Cholesky or
  * CG / PCG, dense or no side information inside X, not with nonneg / L1 / precompute_for_predictions); dense U / II with
  * NaN (= missing) under the Cholesky solver with unscaled lambda; scale_bias_const (scaling_biasA / scaling_biasB are
- * outputs).  Not built: NA_as_zero_*, dense X, weights.  Anything else returns 2. */
+ * outputs); observation weights (weight, one per entry of X; src/common.c:1098-1291, :679-723); NA_as_zero_X on sparse X for
+ * the model without side information (optimizeA Case 3, src/common.c:3118-3205; src/collective.c:8573-8600); dense X
+ * (Xfull [m, n], NaN = missing, weight [m, n]) for the model without side information, with the reference's choice of solver
+ * per half-step (optimizeA Cases 1-2, src/common.c:2787-3116).  Not built: NA_as_zero_U / NA_as_zero_I.  Anything else
+ * returns 2. */
 int_t fit_collective_explicit_als(
     real_t *biasA, real_t *biasB,
     real_t *A, real_t *B,

@@ -1,0 +1,68 @@
+"""GPU: the kernel-selecting environment switches that are read once per process -- the generic CG kernel, the
+workgroup-per-row Cholesky kernel, one row per wavefront for the shortest rows, the split-row boundary, the library GEMMs.
+Each runs the same three small fits in a child process with the switch set; the factors must agree with the default paths'
+to rounding (the switches select another kernel for the same row systems, never another model)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+from conftest import make_coo
+from cmfrec_amd import CMF, CMF_implicit
+out = {}
+for uf, tag in ((False, "f64"), (True, "f32")):
+    dt = np.float32 if uf else np.float64
+    m, n = 900, 700
+    row, col, val = make_coo(m, n, 30000, 3, heavy_row=(5, 600), empty_rows=(7, 11), dtype=dt)
+    a = CMF_implicit(k=20, lambda_=3.0, niter=3, use_cg=True, finalize_chol=False, use_float=uf, random_state=7).fit((row, col, val), shape=(m, n))
+    out["icg_A_" + tag] = a.A_; out["icg_B_" + tag] = a.B_
+    rng = np.random.default_rng(2)
+    II = rng.standard_normal((n, 6)).astype(dt)
+    row, col, val = make_coo(m, n, 30000, 4, counts=False, heavy_row=(5, 600), dtype=dt)
+    b = CMF(k=20, lambda_=0.5, niter=2, use_cg=False, use_float=uf, random_state=9, nthreads=1, precompute_for_predictions=False).fit(
+        (row, col, val), I=II, shape=(m, n))
+    out["ech_A_" + tag] = b.A_; out["ech_B_" + tag] = b.B_; out["ech_D_" + tag] = b.D_
+    c = CMF(k=20, lambda_=0.5, niter=2, use_cg=True, finalize_chol=False, use_float=uf, random_state=9, nthreads=1,
+            precompute_for_predictions=False).fit((row, col, val), shape=(m, n))
+    out["ecg_A_" + tag] = c.A_; out["ecg_B_" + tag] = c.B_
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _run(tmp_path, name, env):
+    path = str(tmp_path / (name + ".npz"))
+    e = dict(os.environ)
+    for k in ("CMFREC_HIP_CG_KERNEL", "CMFREC_HIP_CHOL", "CMFREC_HIP_TINY2", "CMFREC_HIP_VH_MIN", "CMFREC_HIP_GEMM_OWN"):
+        e.pop(k, None)
+    e.update(env)
+    code = CHILD % dict(root=ROOT, tests=os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(path)
+
+
+@pytest.fixture(scope="module")
+def default_fits(tmp_path_factory):
+    return _run(tmp_path_factory.mktemp("switches"), "default", {})
+
+
+@pytest.mark.parametrize("env", [{"CMFREC_HIP_CG_KERNEL": "generic"}, {"CMFREC_HIP_CHOL": "rows"}, {"CMFREC_HIP_TINY2": "0"},
+                                 {"CMFREC_HIP_VH_MIN": "400"}, {"CMFREC_HIP_GEMM_OWN": "0"}],
+                         ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
+def test_process_wide_switch_agrees_with_default(default_fits, tmp_path, env):
+    got = _run(tmp_path, "alt", env)
+    assert set(got.files) == set(default_fits.files)
+    for key in got.files:
+        a, b = got[key], default_fits[key]
+        tol = 2e-4 if key.endswith("f32") else 1e-10
+        assert np.isfinite(a).all(), key
+        assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30), (key, float(np.abs(a - b).max()), float(np.abs(b).max()))
