@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-scale-point", action="store_true", help="skip the N = 1 point of the scaling series (config 4 on one GPU)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
+    ap.add_argument("--item-blocks", default="dealt", choices=["dealt", "contiguous"],
+                    help="config 4 on N ranks: item blocks equal in rows and balanced in nnz (items renumbered; B's all-gather lands in the "
+                         "replica directly) or contiguous nnz-balanced blocks of unequal size (padded staging all-gather)")
     ap.add_argument("--implicit-features", action="store_true", help="side workloads c1 / c3: add the implicit-features matrices Ai, Bi")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard", "c5shard", "c5"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
@@ -348,7 +351,8 @@ def c4_run(args, rank, world, local_rank, steps, warmup):
     a_parts = int(os.environ.get("CMFREC_HIP_AG_PARTS", "4")) if world > 1 else 1
     t0 = time.time()
     eng = GpuEngine.from_device_coo(m, n, C4_K, row, col, val, row_ranges, rank, world, local_rank, dtype=np.float32, lam=LAM,
-                                    max_cg_steps=MAX_CG_STEPS, a_parts=a_parts)
+                                    max_cg_steps=MAX_CG_STEPS, a_parts=a_parts, item_blocks=args.item_blocks)
+    b_sizes = sorted({e - b for b, e in eng.ranges("B")})
     del row, col, val
     t_setup = time.time() - t0
     g = torch.Generator(device=dev); g.manual_seed(100 + rank)
@@ -422,8 +426,9 @@ def c4_run(args, rank, world, local_rank, steps, warmup):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "CMF_implicit ALS-CG k=64 fp32, synthetic %d users x %d items, %d nnz (BASELINE.json configs[3]); "
                                       "lambda=5, max_cg_steps=3" % (m, n, nnz_blk * world),
-                          "parallelism": "user / item row blocks x%d (items nnz-balanced), RCCL all-gather of the updated rows after every "
-                                         "half-step, A-step in %d parts" % (world, a_parts),
+                          "parallelism": "user / item row blocks x%d (items nnz-balanced, %s: %s rows per block), RCCL all-gather of the "
+                                         "updated rows after every half-step, A-step in %d parts" % (
+                                             world, args.item_blocks if world > 1 else "one block", "/".join(map(str, b_sizes)), a_parts),
                           "gen_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1)},
                "roofline": roofline, "cpu_baseline": None}
         out["config"]["scaling_series"] = ("BASELINE.json configs[3] at N = 1, 2, 4, 8: every --gpus N > 1 line runs THIS workload; its N = 1 point "

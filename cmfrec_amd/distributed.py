@@ -35,6 +35,26 @@ def equal_boundaries(n, parts):
     return [min(i * step, n) for i in range(parts)] + [n]
 
 
+def dealt_item_order(counts, parts):
+    """Item blocks that are EQUAL in rows and balanced in nnz at once: the items in descending order of their entry count
+    (stable) are dealt to the ranks like cards, in snake order (0 .. parts-1, parts-1 .. 0, ...), and rank r's items get the
+    new ids r * blk + 0, 1, 2, ... in the order dealt.  Contiguous nnz-balanced blocks (balanced_boundaries) are unequal in
+    rows, which forces the all-gather of B through a padded staging buffer and world - 1 strided copies per half-step
+    (ShardedAls.allgather); with equal blocks it lands in the replica directly, like A's.
+    Returns (new_id [n] int64, blk): new_id[item] in [0, parts * blk); the ids no item maps to (parts * blk - n of them, the
+    last slots of some blocks) are rows of B without entries."""
+    counts = np.asarray(counts, np.int64)
+    n = len(counts)
+    blk = -(-n // parts)
+    order = np.argsort(-counts, kind="stable")
+    pos = np.arange(n)
+    rnd, j = pos // parts, pos % parts
+    rank = np.where(rnd % 2 == 0, j, parts - 1 - j)
+    new_id = np.empty(n, np.int64)
+    new_id[order] = rank * blk + rnd
+    return new_id, blk
+
+
 def shard_coo_by_items(row_global, col, val, n, rank, world, group=None, col_bounds=None):
     """Set-up of the item side of a row-block run without ever holding the whole matrix on one rank: every rank brings
     the entries of ITS user block (global row ids, global column ids); item blocks are cut nnz-balanced from the
@@ -271,16 +291,30 @@ class GpuEngine:
 
     @classmethod
     def from_device_coo(cls, m, n, k, row_local, col, val, row_ranges, rank, world, device, dtype=np.float32, lam=5.0,
-                        max_cg_steps=3, a_parts=1, group=None):
+                        max_cg_steps=3, a_parts=1, group=None, item_blocks="contiguous"):
         """Implicit model from a COO block that lives in HBM (torch CUDA tensors; BASELINE config 4 is generated shard-wise
         on the device): this rank's USER block (rows local to row_ranges[rank], global item ids).  Item blocks are cut
         nnz-balanced, the entries of a rank's items arrive through one all-to-all (shard_coo_by_items), CSR and CSC are
-        built on the device.  No rank ever holds the whole matrix."""
+        built on the device.  No rank ever holds the whole matrix.
+        item_blocks: "contiguous" -- blocks of consecutive item ids, balanced in nnz, unequal in rows; "dealt" -- the items are
+        renumbered (dealt_item_order) so that the blocks are equal in rows AND balanced: B then has world * blk >= n rows in
+        the new numbering, engine.item_ids maps an item to its row (engine.items_in_order(B) puts a replica back)."""
         import torch
+        import torch.distributed as dist
         from .session import AlsSession
         r0, r1 = row_ranges[rank]
         row_local = row_local.to(torch.int32); col = col.to(torch.int32)
-        col_bounds, crow, ccol, cval = shard_coo_by_items(row_local + r0, col, val, n, rank, world, group=group)
+        item_ids, col_bounds_in = None, None
+        if item_blocks == "dealt" and world > 1:
+            counts = torch.bincount(col.long(), minlength=n)
+            dist.all_reduce(counts, group=group)
+            item_ids, blk = dealt_item_order(counts.cpu().numpy(), world)
+            col = torch.as_tensor(item_ids, device=col.device)[col.long()].to(torch.int32)
+            n = blk * world
+            col_bounds_in = [r * blk for r in range(world + 1)]
+        elif item_blocks not in ("contiguous", "dealt"):
+            raise ValueError("item_blocks must be 'contiguous' or 'dealt'")
+        col_bounds, crow, ccol, cval = shard_coo_by_items(row_local + r0, col, val, n, rank, world, group=group, col_bounds=col_bounds_in)
         col_ranges = [(int(col_bounds[r]), int(col_bounds[r + 1])) for r in range(world)]
         c0, c1 = col_ranges[rank]
         sess = AlsSession(m, n, k, implicit=True, dtype=dtype, lam=lam, use_cg=True, max_cg_steps=max_cg_steps,
@@ -290,7 +324,15 @@ class GpuEngine:
         del crow, ccol, cval
         if a_parts > 1:
             sess.set_A_parts_resident(a_parts)
-        return cls(sess, row_ranges, col_ranges)
+        eng = cls(sess, row_ranges, col_ranges)
+        eng.item_ids = item_ids
+        return eng
+
+    item_ids = None         # "dealt" item blocks: item -> row of B (numpy int64 [n_items]); None: the identity
+
+    def items_in_order(self, B):
+        """Rows of a replica of B (array [rows, ...]) in the caller's item numbering."""
+        return B if self.item_ids is None else B[self.item_ids]
 
     def full(self, which):
         return self._full[which]

@@ -63,3 +63,27 @@ def test_bench_generator_and_bytes():
     # 6.92 GB gather + 0.21 GB CSR per half-step at LastFM size
     b = bench.algorithmic_bytes(bench.NNZ, bench.M_USERS, bench.K)
     assert abs(bench.NNZ * bench.K * 8 / 1e9 - 6.92) < 0.01 and 7.3e9 < b < 7.6e9
+
+
+def test_dealt_item_order():
+    """Item blocks equal in rows and balanced in entries (cmfrec_amd/distributed.py, dealt_item_order): a bijection into
+    [0, parts * blk), every block within one row of the others, entry counts within a fraction of a per cent of each other on a
+    heavily skewed popularity (contiguous nnz-balanced blocks would be far from equal in rows there), deterministic."""
+    from cmfrec_amd.distributed import balanced_boundaries, dealt_item_order
+    rng = np.random.default_rng(3)
+    for n, parts in ((1000003, 8), (5001, 2), (7, 4), (64, 8)):
+        counts = (rng.zipf(1.2, size=n) % 100000).astype(np.int64)
+        ids, blk = dealt_item_order(counts, parts)
+        assert blk == -(-n // parts) and ids.min() >= 0 and ids.max() < parts * blk and len(np.unique(ids)) == n
+        rows = np.bincount(ids // blk, minlength=parts)
+        assert rows.max() - rows.min() <= 1
+        nnz = np.bincount(ids // blk, weights=counts, minlength=parts)
+        if n > 1000:
+            assert nnz.max() - nnz.min() <= 0.005 * nnz.sum()
+            cb = np.diff(balanced_boundaries(counts, parts))
+            assert cb.max() > 1.01 * cb.min() or parts == 1          # what the renumbering is for
+        ids2, _ = dealt_item_order(counts, parts)
+        assert np.array_equal(ids, ids2)
+        # the most popular items lead their blocks
+        top = np.argsort(-counts, kind="stable")[:parts]
+        assert sorted(ids[top] % blk) == [0] * parts
