@@ -262,79 +262,108 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
         // opposing rows of the entries 16 b + lm (16-byte loads, 64-byte segments per row).
         //   pass 0:  tot_c = sum_a x_a V~[a][c] ;  t_c = (pre_c + tot_c) / D_c ;  G += MFMA ;  q_a += V~[a][c] t_c
         //   pass 1:  tot_c = sum_a z_a V~[a][c] ;  x~_c = t_c - tot_c / D_c
-        auto sweep = [&](auto pass_tag, const T (&wl)[NB]) {
+        // FULL: the group lies inside [0, min(k_t, k_c)) of the rotated basis -- every group but the last one or two of a row:
+        // no column masks, the prefilled right-hand side, t and x~ move as 16-byte vectors
+        typedef T vec4u __attribute__((ext_vector_type(4), aligned(sizeof(T))));
+        // (only in the build for the shortest rows, which is most rows: with both forms of the group in one kernel the wider
+        // builds spill)
+        const int full_lim = (NB <= 2 && P.rotated) ? min(kt, kc) : 0;
+        auto group = [&](auto pass_tag, auto full_tag, int qg, const T (&wl)[NB]) {
             constexpr int PASS = decltype(pass_tag)::value;
-            for (int qg = 0; qg < ngroups; qg++) {
-                const int c0 = 16 * qg + 4 * g;              // this lane's four columns (unknowns)
-                vec4 val[NB];
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int c0 = 16 * qg + 4 * g;              // this lane's four columns (unknowns)
+            vec4 val[NB];
 #pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    // (the last group may hang over the row's end: the load stays inside the padded leading dimension)
-                    const T *src = P.Bt + (size_t)my_idx[b] * P.ldbt + (P.rotated ? c0 : c0 - P.koff);
-                    if (P.rotated) val[b] = *reinterpret_cast<const vec4 *>(src);
-                    else {
+            for (int b = 0; b < NB; b++) {
+                // (the last group may hang over the row's end: the load stays inside the padded leading dimension)
+                const bool rot = FULL || P.rotated;
+                const T *src = P.Bt + (size_t)my_idx[b] * P.ldbt + (rot ? c0 : c0 - P.koff);
+                if (rot) val[b] = *reinterpret_cast<const vec4 *>(src);
+                else {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) { const int u = c0 + r; val[b][r] = (u >= P.koff && u < kt) ? src[r] : T(0); }
-                    }
+                    for (int r = 0; r < 4; r++) { const int u = c0 + r; val[b][r] = (u >= P.koff && u < kt) ? src[r] : T(0); }
                 }
-                T dinv[4], pre[4];
-                const vec4 dq = *reinterpret_cast<const vec4 *>(dtab + c0);
+            }
+            T dinv[4], pre[4];
+            const vec4 dq = *reinterpret_cast<const vec4 *>(dtab + c0);
+            if (FULL && PASS == 0 && P.pre != nullptr) {
+                const vec4 pq = *reinterpret_cast<const vec4u *>(P.pre + (size_t)row * P.ldpre + c0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) pre[r] = pq[r];
+            } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int u = c0 + r;
-                    dinv[r] = dq[r];
-                    if (PASS == 0) pre[r] = (P.pre != nullptr && u < kc) ? P.pre[(size_t)row * P.ldpre + min(u, kc - 1)] : T(0);
-                    else pre[r] = T(0);
+                    pre[r] = (!FULL && PASS == 0 && P.pre != nullptr && u < kc) ? P.pre[(size_t)row * P.ldpre + min(u, kc - 1)] : T(0);
                 }
-                T o[NB][4], part[4] = {T(0), T(0), T(0), T(0)};
+            }
 #pragma unroll
-                for (int b = 0; b < NB; b++)
+            for (int r = 0; r < 4; r++) dinv[r] = dq[r];
+            T o[NB][4], part[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        o[b][r] = (((amask >> b) & 1u) && (c0 + r < kt)) ? val[b][r] : T(0);
-                        part[r] += o[b][r] * wl[b];
-                    }
-                // sum over the 16 lanes of the group (all 16 end with the total)
+            for (int b = 0; b < NB; b++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    T v = part[r];
-                    v += lanes::xor1(v); v += lanes::xor2(v); v += lanes::xor4(v); v += lanes::xor8(v);
-                    part[r] = v;
+                    o[b][r] = (((amask >> b) & 1u) && (FULL || c0 + r < kt)) ? val[b][r] : T(0);
+                    part[r] += o[b][r] * wl[b];
                 }
-                if (PASS == 0) {
-                    T tt[4];
+            // sum over the 16 lanes of the group (all 16 end with the total)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) tt[r] = (pre[r] + part[r]) * dinv[r];
-                    if (lm == 0) {
+            for (int r = 0; r < 4; r++) {
+                T v = part[r];
+                v += lanes::xor1(v); v += lanes::xor2(v); v += lanes::xor4(v); v += lanes::xor8(v);
+                part[r] = v;
+            }
+            if (PASS == 0) {
+                vec4 tt;
+#pragma unroll
+                for (int r = 0; r < 4; r++) tt[r] = (pre[r] + part[r]) * dinv[r];
+                if (lm == 0) {
+                    if (FULL) *reinterpret_cast<vec4 *>(tvec + c0) = tt;
+                    else {
 #pragma unroll
                         for (int r = 0; r < 4; r++) if (c0 + r < kt) tvec[c0 + r] = tt[r];
                     }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    T ao[NB];
+#pragma unroll
+                    for (int b = 0; b < NB; b++) { ao[b] = o[b][r] * dinv[r]; qp[b] += o[b][r] * tt[r]; }
+                    static_for<0, NB>([&](auto bic) {
+                        constexpr int bi = decltype(bic)::value;
+                        static_for<bi, NB>([&](auto bjc) {
+                            constexpr int bj = decltype(bjc)::value;
+                            acc[wtix(bi, bj, NB)] = Mf::mma(ao[bi], o[bj][r], acc[wtix(bi, bj, NB)]);
+                        });
+                    });
+                }
+            } else if (lm == 0) {
+                if (FULL) {
+                    const vec4 tv = *reinterpret_cast<const vec4 *>(tvec + c0);
+                    vec4 xv;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) xv[r] = tv[r] - part[r] * dinv[r];
+                    *reinterpret_cast<vec4u *>(P.Tc + (size_t)(rix - P.pos0) * P.ldt + c0) = xv;
+                } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        T ao[NB];
-#pragma unroll
-                        for (int b = 0; b < NB; b++) { ao[b] = o[b][r] * dinv[r]; qp[b] += o[b][r] * tt[r]; }
-                        static_for<0, NB>([&](auto bic) {
-                            constexpr int bi = decltype(bic)::value;
-                            static_for<bi, NB>([&](auto bjc) {
-                                constexpr int bj = decltype(bjc)::value;
-                                acc[wtix(bi, bj, NB)] = Mf::mma(ao[bi], o[bj][r], acc[wtix(bi, bj, NB)]);
-                            });
-                        });
-                    }
-                } else {
-                    if (lm == 0) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int u = c0 + r;
-                            if (u < kt) {
-                                const T xv = tvec[u] - part[r] * dinv[r];
-                                if (P.rotated && u < kc) P.Tc[(size_t)(rix - P.pos0) * P.ldt + u] = xv;
-                                else arow[u] = xv;
-                            }
+                        const int u = c0 + r;
+                        if (u < kt) {
+                            const T xv = tvec[u] - part[r] * dinv[r];
+                            if (P.rotated && u < kc) P.Tc[(size_t)(rix - P.pos0) * P.ldt + u] = xv;
+                            else arow[u] = xv;
                         }
                     }
                 }
+            }
+        };
+        auto sweep = [&](auto pass_tag, const T (&wl)[NB]) {
+            for (int qg = 0; qg < ngroups; qg++) {
+                if constexpr (NB <= 2) {
+                    if (16 * qg + 16 <= full_lim) { group(pass_tag, std::true_type{}, qg, wl); continue; }
+                }
+                group(pass_tag, std::false_type{}, qg, wl);
             }
         };
         sweep(std::integral_constant<int, 0>{}, xl);

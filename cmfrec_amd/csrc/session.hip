@@ -626,7 +626,11 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
 #else
     lr_launch(lowrank_rows_kernel<real_t, 4, 2>, 4, 2, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
 #endif
+#ifdef CMFREC_HIP_FLOAT
+    lr_launch(lowrank_rows_kernel<real_t, 2, 4>, 2, 4, std::max(n_full, n_gt32), X.nrows, 2);
+#else
     lr_launch(lowrank_rows_kernel<real_t, 2, 3>, 2, 3, std::max(n_full, n_gt32), X.nrows, 2);
+#endif
     HIP_CHECK(hipGetLastError());
     // x[:kc] = Q x~[:kc]: one GEMM over the light rows (in processing order), then back to their rows
     launch_gemm<false>(dev, n_light, kc, kc, (real_t)1, S.T.ptr, (size_t)kc, S.Qt.ptr, (size_t)kc, S.R.ptr, (size_t)kc);
