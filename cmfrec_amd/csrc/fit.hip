@@ -15,6 +15,7 @@
 #include <cstring>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <vector>
 #include <hip/hip_runtime.h>
 
@@ -251,14 +252,15 @@ struct MultiDev {
     }
 };
 
-// plain implicit model (no side information) on the devices of `devs`; same results as the single-device driver
-int fit_implicit_multi(const std::vector<int> &devs, real_t *A, real_t *B, int_t m, int_t n, int_t k_tot, const int_t *ixA, const int_t *ixB,
-                       const real_t *X, size_t nnz, cmfrec_hip_model mdl, const real_t *lam6, real_t alpha, int niter, bool finalize_chol,
-                       bool verbose, cmfrec_hip_session **first_out, MultiDev &md)
+// One session per entry of `devs`, each owning a block of users and a block of items and holding the block's entries of X
+// ((x - subtract) * alpha): users in equal contiguous blocks, items in nnz-balanced contiguous ones.
+// `configure` is called on every new session once its shards are built.
+int build_shards(MultiDev &md, const std::vector<int> &devs, const cmfrec_hip_model &mdl, int_t m, int_t n, const int_t *ixA,
+                 const int_t *ixB, const real_t *X, size_t nnz, real_t subtract, real_t alpha,
+                 const std::function<int(cmfrec_hip_session *)> &configure)
 {
     const int D = (int)devs.size();
     md.dev = devs;
-    // users: equal contiguous blocks; items: nnz-balanced contiguous blocks
     md.rb.assign(D + 1, 0); md.cb.assign(D + 1, 0);
     const int step = (m + D - 1) / D;
     for (int d = 0; d <= D; d++) md.rb[d] = std::min(d * step, (int)m);
@@ -307,12 +309,28 @@ int fit_implicit_multi(const std::vector<int> &devs, real_t *A, real_t *B, int_t
             (void)hipMemcpy(dk, key.data(), cntE * sizeof(int_t), hipMemcpyHostToDevice);
             (void)hipMemcpy(d_o, oth.data(), cntE * sizeof(int_t), hipMemcpyHostToDevice);
             (void)hipMemcpy(dv, val.data(), cntE * sizeof(real_t), hipMemcpyHostToDevice);
-            const int rc = cmfrec_hip_session_set_X_coo_device(md.sess[d], side == 0 ? 'r' : 'c', dk, d_o, dv, cntE, (real_t)0, alpha);
+            const int rc = cmfrec_hip_session_set_X_coo_device(md.sess[d], side == 0 ? 'r' : 'c', dk, d_o, dv, cntE, subtract, alpha);
             (void)hipFree(dk); (void)hipFree(d_o); (void)hipFree(dv);
             if (rc) return rc;
         }
-        int rc = cmfrec_hip_session_set_lam_unique(md.sess[d], lam6, nullptr, 100);
-        if (!rc) rc = cmfrec_hip_session_set_factors(md.sess[d], A, B, nullptr, nullptr, nullptr, nullptr);
+        const int rc = configure(md.sess[d]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// plain implicit model (no side information) on the devices of `devs`; same results as the single-device driver
+int fit_implicit_multi(const std::vector<int> &devs, real_t *A, real_t *B, int_t m, int_t n, int_t k_tot, const int_t *ixA, const int_t *ixB,
+                       const real_t *X, size_t nnz, cmfrec_hip_model mdl, const real_t *lam6, real_t alpha, int niter, bool finalize_chol,
+                       bool verbose, cmfrec_hip_session **first_out, MultiDev &md)
+{
+    const int D = (int)devs.size();
+    {
+        const int rc = build_shards(md, devs, mdl, m, n, ixA, ixB, X, nnz, (real_t)0, alpha, [&](cmfrec_hip_session *sd) {
+            int rc2 = cmfrec_hip_session_set_lam_unique(sd, lam6, nullptr, 100);
+            if (!rc2) rc2 = cmfrec_hip_session_set_factors(sd, A, B, nullptr, nullptr, nullptr, nullptr);
+            return rc2;
+        });
         if (rc) return rc;
     }
     if (verbose) { printf("Starting ALS optimization routine (%d device shards)\n\n", D); fflush(stdout); }
@@ -331,6 +349,30 @@ int fit_implicit_multi(const std::vector<int> &devs, real_t *A, real_t *B, int_t
     for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sync(md.sess[d]); if (rc) return rc; }
     *first_out = md.sess[0];
     (void)k_tot;
+    return 0;
+}
+
+// plain explicit model (biases, centring, no side information / weights) on the devices of `devs`: the same half-steps as run_loop,
+// every device on its block, the updated rows (bias column included: it rides in the factor rows, collective.c:8538-8543) copied
+// to the peers, then every replica splits the opposing bias off again (cmfrec_hip_session_after_gather)
+int explicit_multi_loop(MultiDev &md, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose)
+{
+    const int D = (int)md.sess.size();
+    if (verbose) { printf("Starting ALS optimization routine (%d device shards)\n\n", D); fflush(stdout); }
+    for (int it = 0; it < niter; it++) {
+        if (g_stop) return 3;
+        const int chol = (finalize_chol && mdl.use_cg && it == niter - 1) ? 1 : 0;
+        for (int pass = 0; pass < 2; pass++) {                                // B then A (collective.c:8640-8898)
+            const int which = pass == 0 ? 'B' : 'A';
+            for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_update(md.sess[d], which, chol); if (rc) return rc; }
+            int rc = md.exchange(which);
+            for (int d = 0; d < D && !rc; d++) rc = cmfrec_hip_session_after_gather(md.sess[d], which);
+            if (rc) return rc;
+            if (g_stop) return 3;
+        }
+        if (verbose) { for (int d = 0; d < D; d++) cmfrec_hip_session_sync(md.sess[d]); printf("\tCompleted ALS iteration %2d\n\n", it + 1); fflush(stdout); }
+    }
+    for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sync(md.sess[d]); if (rc) return rc; }
     return 0;
 }
 
@@ -806,7 +848,69 @@ int_t fit_collective_explicit_als(
     mdl.use_cg = use_cg; mdl.max_cg_steps = max_cg_steps; mdl.precondition_cg = precondition_cg; mdl.p = p; mdl.q = q; mdl.m_u = m_u; mdl.n_i = n_i;
     mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
-    const std::vector<int> devs = devices_from_env();                  // CMFREC_HIP_DEVICES: the first listed device (row-block shards: implicit model)
+    const std::vector<int> devs = devices_from_env();                  // CMFREC_HIP_DEVICES: one ordinal = that device, several = row-block shards
+    // Several devices: the plain model (biases, centring, CG / Cholesky, non-negativity, L1, per-matrix penalties) as row-block
+    // shards with peer copies of the updated rows, like fit_implicit_multi.  The bias start values are those of the single-device
+    // driver: they are computed by a temporary session that holds the whole X on the first device (the sweeps alternate over
+    // all rows and all columns, common.c:4410-4909), then handed to every shard.
+    const bool multi_ok = devs.size() > 1 && !U && !II && !spU && !spI && !add_implicit_features && !NA_as_zero_X && !weight &&
+                          m >= (int_t)devs.size() && n >= (int_t)devs.size();
+    if (devs.size() > 1 && !multi_ok && verbose)
+        printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (side information / weights / implicit features / "
+               "NA_as_zero) runs on the first\n", (int)devs.size());
+    if (multi_ok) {
+        auto configure = [&](cmfrec_hip_session *sd) {
+            int rc2 = 0;
+            if (nonneg) rc2 = cmfrec_hip_session_set_nonneg(sd, nonneg, false, false, (int)max_cd_steps);
+            if (!rc2 && l1_lam != 0) rc2 = cmfrec_hip_session_set_l1(sd, l1_lam, (int)max_cd_steps);
+            if (!rc2 && (lam_unique || l1_lam_unique || scale_bias_const))
+                rc2 = cmfrec_hip_session_set_lam_unique(sd, (lam_unique || scale_bias_const) ? lam6 : nullptr,
+                                                        (l1_lam_unique || (scale_bias_const && l1_lam != 0)) ? l16 : nullptr, (int)max_cd_steps);
+            if (!rc2 && scale_bias_const) rc2 = cmfrec_hip_session_set_scale_bias_const(sd, 1);
+            return rc2;
+        };
+        int rc = 0;
+        if (has_bias && reset_values) {
+            cmfrec_hip_session *t = cmfrec_hip_session_create(&mdl, devs[0]);
+            if (!t) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
+            rc = cmfrec_hip_session_set_X_coo_weighted(t, ixA, ixB, X, nullptr, nnz, gm, (real_t)1);
+            if (!rc) rc = configure(t);
+            if (!rc) rc = cmfrec_hip_session_set_factors(t, A, B, nullptr, nullptr, nullptr, nullptr);
+            real_t lam_u = lam6[0], lam_i = lam6[1];                      // collective.c:8178, :8197, :8218-8219
+            if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
+            if (std::fabs(lam_i) < EPS_T) lam_i = EPS_T;
+            if (!rc) rc = cmfrec_hip_session_init_biases(t, lam_u, lam_i);
+            if (!rc) rc = cmfrec_hip_session_get_factors(t, nullptr, nullptr, biasA, biasB, nullptr, nullptr);
+            cmfrec_hip_session_destroy(t);
+            if (rc) return rc;
+        }
+        MultiDev md;
+        rc = build_shards(md, devs, mdl, m, n, ixA, ixB, X, nnz, gm, (real_t)1, [&](cmfrec_hip_session *sd) {
+            int rc2 = configure(sd);
+            if (!rc2) rc2 = cmfrec_hip_session_set_factors(sd, A, B, has_bias ? biasA : nullptr, has_bias ? biasB : nullptr, nullptr, nullptr);
+            return rc2;
+        });
+        int rc_loop = rc ? rc : explicit_multi_loop(md, mdl, (int)niter, finalize_chol, verbose);
+        cmfrec_hip_session *s0 = md.sess.empty() ? nullptr : md.sess[0];
+        if ((rc_loop == 0 || rc_loop == 3) && s0) {
+            const int rc2 = cmfrec_hip_session_get_factors(s0, A, B, biasA, biasB, nullptr, nullptr);
+            if (rc2) rc_loop = rc2;
+        }
+        if ((rc_loop == 0 || rc_loop == 3) && s0 && precompute_for_predictions) {   // collective.c:8936-9249
+            const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
+            int rc2 = cmfrec_hip_session_precompute(s0, last_chol, include_all_X ? 1 : 0, precomputedBtB, precomputedTransBtBinvBt, nullptr,
+                                                    nullptr, nullptr, nullptr);
+            if (rc2) rc_loop = rc2;
+            if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
+                for (int_t c = 0; c < n_max; c++) {
+                    memcpy(B_plus_bias + (size_t)c * (k_totB + 1), B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));
+                    B_plus_bias[(size_t)c * (k_totB + 1) + k_totB] = 1;
+                }
+            }
+        }
+        if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
+        return rc_loop;
+    }
     cmfrec_hip_session *s = cmfrec_hip_session_create(&mdl, devs.empty() ? -1 : devs[0]);
     if (!s) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
     tm.lap("start values + session");

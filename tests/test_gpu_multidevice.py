@@ -53,6 +53,48 @@ def test_devices_env_split_rows_agree_to_rounding(use_float, monkeypatch):
         assert np.abs(a - b).max() <= tol * np.abs(b).max()
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("opts", [dict(use_cg=True, finalize_chol=True), dict(use_cg=False, scale_lam=True),
+                                  dict(use_cg=True, finalize_chol=False, user_bias=False, center=False),
+                                  dict(use_cg=False, item_bias=False, lambda_=[0.5, 0.4, 3.0, 2.0, 1.0, 1.0]),
+                                  dict(use_cg=False, nonneg=True, user_bias=False, item_bias=False, center=False),
+                                  dict(use_cg=False, l1_lambda=0.05)],
+                         ids=["cg+fin", "chol-scale_lam", "cg-item_bias-only", "chol-lam6-user_bias-only", "nonneg", "l1"])
+@pytest.mark.parametrize("use_float", [False, True])
+def test_devices_env_explicit_model(devices, opts, use_float, monkeypatch):
+    """fit_collective_explicit_als behind CMFREC_HIP_DEVICES (plain model: biases, centring, CG / Cholesky, scale_lam, per-matrix
+    penalties, non-negative / L1): row-block shards, the bias columns riding in the exchanged rows, bias start values from the
+    temporary whole-X session, the precomputed matrices from the first replica.  No split rows here (at most 600 entries), so
+    every row takes the same kernel as on one device: bit for bit, including the seeded start."""
+    from cmfrec_amd import CMF
+    m, n = 900, 700
+    row, col, val = make_coo(m, n, 30000, 3, counts=False, heavy_row=(5, 600), empty_rows=(7, 11))
+    o = dict(opts)
+    kw = dict(k=12, lambda_=o.pop("lambda_", 2.0), niter=3, use_float=use_float, random_state=7, nthreads=1, **o)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF(**kw).fit((row, col, val), shape=(m, n))
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", devices)
+    shard = CMF(**kw).fit((row, col, val), shape=(m, n))
+    assert np.isfinite(shard.A_).all() and np.abs(shard.A_).max() > 0
+    for name in ("A_", "B_", "user_bias_", "item_bias_", "_BtB", "_TransBtBinvBt", "_B_plus_bias"):
+        assert np.array_equal(getattr(shard, name), getattr(base, name)), name
+    assert shard.glob_mean_ == base.glob_mean_
+
+
+def test_devices_env_explicit_falls_back_with_side_information(monkeypatch):
+    """Configurations the sharded driver does not take (side information, weights, ...) run on the first listed device."""
+    from cmfrec_amd import CMF
+    m, n = 300, 200
+    row, col, val = make_coo(m, n, 5000, 4, counts=False)
+    II = np.random.default_rng(1).standard_normal((n, 3))
+    kw = dict(k=6, niter=2, use_float=False, random_state=3, nthreads=1)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF(**kw).fit((row, col, val), I=II, shape=(m, n))
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", "0,0")
+    two = CMF(**kw).fit((row, col, val), I=II, shape=(m, n))
+    assert np.array_equal(two.A_, base.A_) and np.array_equal(two.D_, base.D_)
+
+
 def test_devices_env_ignores_bad_ordinals(monkeypatch):
     """Ordinals outside the visible devices are dropped; an empty list falls back to the current device."""
     from cmfrec_amd import CMF_implicit
