@@ -395,3 +395,34 @@ def test_implicit_adjust_weight_matches_reference(dtype, side):
     plain = CMF_implicit(k=k, lambda_=2.0, niter=2, random_state=31, use_float=dtype is np.float32, nthreads=1, use_cg=False,
                          w_user=3.0, w_item=0.5, precompute_for_predictions=False).fit((row, col, val), U=U, I=II, shape=(m, n))
     assert frob(plain.A_, Ar) > 1e-2
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("pattern,use_cg", [("full", True), ("sparse-ish", True), ("sparse-ish", False)])
+def test_fit_dense_X_medium(oracles, dtype, pattern, use_cg):
+    """Dense X at a size where rows fall into every length bin (1600 x 1200: complete rows of 1200 entries are split rows, the
+    70 %-missing pattern has rows of ~360): CMF.fit(X = array with NaN) against the oracle on the present entries -- closed form
+    for the complete matrix whatever use_cg says (optimizeA Case 1), the solver asked for where every row misses many entries
+    (Case 2).  (Small patterns against the reference itself: tests/test_gpu_golden.py::test_dense_X.)"""
+    from cmfrec_amd import CMF
+    O = oracles[dtype]
+    m, n, k = 1600, 1200, 16
+    rng = np.random.default_rng(8)
+    X = (0.5 * rng.integers(1, 11, (m, n))).astype(dtype)
+    if pattern != "full":
+        X[rng.random((m, n)) < 0.7] = np.nan
+    row, col = [a.astype(np.int32) for a in np.nonzero(~np.isnan(X))]
+    val = X[row, col]
+    A0 = (rng.standard_normal((m, k)) * 0.01).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.01).astype(dtype)
+    bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+    mdl = CMF(k=k, lambda_=2.0, niter=2, use_cg=use_cg, finalize_chol=False, use_float=dtype is np.float32, nthreads=1,
+              precompute_for_predictions=False).fit(X, A0=A0, B0=B0, biasA0=bA, biasB0=bB)
+    Ao, Bo = A0.copy(), B0.copy()
+    cg_o = use_cg and pattern != "full"
+    ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), lam=2.0, niter=2, nthreads=2, use_cg=cg_o,
+                            finalize_chol=False)
+    assert ro["ret"] == 0
+    t = tol(dtype, "cg" if cg_o else "chol")
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    assert frob(mdl.user_bias_, ro["biasA"]) < t and frob(mdl.item_bias_, ro["biasB"]) < t
+    assert abs(mdl.glob_mean_ - ro["glob_mean"]) <= 1e-6 * abs(ro["glob_mean"])
