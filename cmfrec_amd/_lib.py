@@ -66,6 +66,14 @@ def load(dtype=np.float64):
         raise ImportError(
             "%s is missing: the HIP extension has not been built (run __graft_entry__.build() or "
             "`make -C cmfrec_amd/csrc`). cmfrec_amd has no CPU fallback." % path)
+    # PyTorch ships its own HIP runtime under the same soname as /opt/rocm's.  Whichever is mapped first serves the whole
+    # process; if this library's copy came first, a later `import torch` would run on a runtime its other libraries were not
+    # built against ("No HIP GPUs are available").  The package uses torch for device memory and streams anyway, so it goes
+    # first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.cmfrec_hip_last_error.restype = C.c_char_p
     lib.cmfrec_hip_build_info.restype = C.c_char_p

@@ -7,27 +7,47 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lanes.hpp"
 
 namespace cmfhip {
 
-// one wavefront per entry: lane l adds blocks l, l+64, ... in order, then a fixed butterfly --
-// the summation order depends only on (n, k), never on scheduling.
+// Second stage of the Gramian: partial[b][i * k + j] holds block b's sum for the entries of the UPPER triangle (i <= j; a block's
+// k x k values are contiguous, so the first stage writes them in runs and this stage reads 128-byte runs).  A workgroup owns
+// 16 consecutive entries; thread (ph, e) adds the blocks ph, ph + 16, ... of entry e in order, thread (0, e) the sixteen
+// phase sums in order: the summation order depends only on (n, k), never on scheduling.  Both triangles of `out` are written.
+constexpr int GRAM_RED_ENT = 16;
 template <typename T>
 __global__ void __launch_bounds__(256)
 gram_reduce_kernel(const T *__restrict__ partial, int nblocks, int nent,
                    T *__restrict__ out, T scale, T add_diag, int k)
 {
-    const int lane = threadIdx.x & 63;
-    const int ent = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ent >= nent) return;
-    const T *src = partial + (size_t)ent * nblocks;
+    __shared__ T ph_sum[16][GRAM_RED_ENT];
+    const int e = threadIdx.x & (GRAM_RED_ENT - 1), ph = threadIdx.x / GRAM_RED_ENT;
+    const int ent = blockIdx.x * GRAM_RED_ENT + e;
+    const int i = ent / k, j = ent % k;
+    const bool live = ent < nent && i <= j;
     T s = T(0);
-    for (int b = lane; b < nblocks; b += 64) s += src[b];
+    if (live) {
+        const T *src = partial + ent;
+        int b = ph;
+        for (; b + 48 < nblocks; b += 64) {
+            const T v0 = src[(size_t)b * nent], v1 = src[(size_t)(b + 16) * nent], v2 = src[(size_t)(b + 32) * nent],
+                    v3 = src[(size_t)(b + 48) * nent];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; b < nblocks; b += 16) s += src[(size_t)b * nent];
+    }
+    ph_sum[ph][e] = s;
+    __syncthreads();
+    if (ph == 0 && live) {
+        T tot = ph_sum[0][e];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    s *= scale;
-    if (ent / k == ent % k) s += add_diag;
-    if (lane == 0) out[ent] = s;
+        for (int q = 1; q < 16; q++) tot += ph_sum[q][e];
+        tot *= scale;
+        if (i == j) tot += add_diag;
+        out[(size_t)i * k + j] = tot;
+        if (i != j) out[(size_t)j * k + i] = tot;
+    }
 }
 
 // MFMA Gramian (k <= 64): the dense B^T B precompute on the matrix cores.
@@ -36,8 +56,8 @@ gram_reduce_kernel(const T *__restrict__ partial, int nblocks, int nent,
 // One MFMA step consumes 4 rows of B: every lane loads B[row0 + (l>>4)][16*cb + (l&15)] for the
 // (up to 4) column blocks -- 4 rows x 128 B per block, coalesced -- and the 10 upper 16x16 tiles
 // are updated with tile(bi,bj) += val[bi]^T val[bj].  A workgroup (4 waves) owns a slab of rows,
-// its waves' accumulators are added in wave order through LDS and written as [entry][block]
-// partials for the same deterministic second stage as the VALU version.
+// its waves' accumulators are added in wave order through LDS and written as [block][entry]
+// partials (upper triangle) for the deterministic second stage above.
 template <typename T> struct MfmaAcc;
 template <> struct MfmaAcc<double> {
     typedef double vec __attribute__((ext_vector_type(4)));
@@ -50,21 +70,36 @@ template <> struct MfmaAcc<float> {
     static __device__ __forceinline__ int row_of(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-template <typename T>
+// REM > 0 (double precision, 48 < k <= 52: k = 50 of the headline configuration): the last column block holds REM live columns,
+// so its four tiles would run the matrix pipe at REM / 16 of its width -- 4 of the 10 MFMAs of a step, in the precision whose
+// MFMA rate is the limit of this kernel.  Those REM columns go through the vector ALU instead: column 48 + q of the step's row
+// is lane q of the lane's 16-lane row (one v_mov_b64_dpp row_newbcast), times the lane's own four values, per-lane partial sums
+// over the rows the lane sees, added over the four row groups and the four waves in a fixed order at the end.  6 MFMAs + 5 REM
+// vector instructions per step instead of 10 MFMAs (C2: 0.105 / 0.050 -> see profiles/r03 for the two matrices).
+template <typename T, int REM = 0>
 __global__ void __launch_bounds__(256)
 gram_mfma_partial_kernel(const T *__restrict__ B, size_t ldb, int n, int k, int rows_per_block,
                          T *__restrict__ partial)
 {
     using Acc = MfmaAcc<T>;
     using vec = typename Acc::vec;
-    __shared__ T red[4][10][4][64];                       // [wave][tile][reg][lane]
+    constexpr int NB = REM ? 3 : 4;                       // column blocks on the matrix pipe
+    constexpr int NTL = NB * (NB + 1) / 2;                // their upper-triangle tiles
+    constexpr int NX = REM ? REM : 1;
+    __shared__ T red[4][NTL][4][64];                      // [wave][tile][reg][lane]
+    __shared__ T redx[REM ? 4 : 1][NX][4][64];            // [wave][column 48 + q][column block][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(n, r0 + rows_per_block);
     const int kk = lane >> 4, cc = lane & 15;
-    vec acc[10];
+    vec acc[NTL];
+    T ex[NX][4];
 #pragma unroll
-    for (int t = 0; t < 10; t++) acc[t] = vec{0, 0, 0, 0};
+    for (int t = 0; t < NTL; t++) acc[t] = vec{0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < NX; q++)
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) ex[q][cb] = T(0);
     // four steps (16 rows of this wave) per trip: their 16 loads are in flight together (one step at a time exposed a full
     // memory latency per 10 MFMAs: 0.065 ms for the 359 k x 50 matrix of C2, twice what streaming it takes)
     constexpr int UNR = 4;
@@ -83,28 +118,58 @@ gram_mfma_partial_kernel(const T *__restrict__ B, size_t ldb, int n, int k, int 
         for (int u = 0; u < UNR; u++) {
             int t = 0;
 #pragma unroll
-            for (int bi = 0; bi < 4; bi++)
+            for (int bi = 0; bi < NB; bi++)
 #pragma unroll
-                for (int bj = bi; bj < 4; bj++) { acc[t] = Acc::mma(val[u][bi], val[u][bj], acc[t]); t++; }
+                for (int bj = bi; bj < NB; bj++) { acc[t] = Acc::mma(val[u][bi], val[u][bj], acc[t]); t++; }
+            if constexpr (REM > 0) {
+                static_for<0, REM>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    const T b = lanes::row_bcast16<q>(val[u][3]);
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++) ex[q][cb] += val[u][cb] * b;
+                });
+            }
         }
     }
 #pragma unroll
-    for (int t = 0; t < 10; t++)
+    for (int t = 0; t < NTL; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) red[wave][t][r][lane] = acc[t][r];
+    if constexpr (REM > 0) {
+#pragma unroll
+        for (int q = 0; q < REM; q++)
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) redx[wave][q][cb][lane] = ex[q][cb];
+    }
     __syncthreads();
+    T *__restrict__ pblk = partial + (size_t)blockIdx.x * k * k;          // this block's k x k values (upper triangle written)
     // entry (i,j) with i in tile-row bi, j in tile-col bj: thread -> (tile, reg, lane)
-    for (int e = threadIdx.x; e < 10 * 4 * 64; e += 256) {
+    for (int e = threadIdx.x; e < NTL * 4 * 64; e += 256) {
         const int t = e / 256, r = (e / 64) % 4, l = e % 64;
         int bi = 0, rem = t;
-        while (rem >= 4 - bi) { rem -= 4 - bi; bi++; }
+        while (rem >= NB - bi) { rem -= NB - bi; bi++; }
         const int bj = bi + rem;
         const int i = 16 * bi + Acc::row_of(l, r), j = 16 * bj + (l & 15);
-        if (i < k && j < k) {
+        if (i <= j && j < k) {                             // (a diagonal tile holds both triangles: the upper one is kept)
             T sum = red[0][t][r][l];
             sum += red[1][t][r][l]; sum += red[2][t][r][l]; sum += red[3][t][r][l];
-            partial[(size_t)(i * k + j) * gridDim.x + blockIdx.x] = sum;
-            if (bi != bj || i != j) partial[(size_t)(j * k + i) * gridDim.x + blockIdx.x] = sum;
+            pblk[i * k + j] = sum;
+        }
+    }
+    if constexpr (REM > 0) {
+        // entry (48 + q, 16 cb + c): row groups in order inside a wave, waves in order
+        for (int e = threadIdx.x; e < REM * 4 * 16; e += 256) {
+            const int q = e / 64, cb = (e / 16) % 4, c = e % 16;
+            const int i = 16 * NB + q, j = 16 * cb + c;
+            if (j < k && (cb < NB || j >= i)) {                // entry (j, i) of the upper triangle, or (i, j) inside the last block
+                T sum = T(0);
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) sum += redx[w][q][cb][16 * g + c];
+                if (cb < NB) pblk[j * k + i] = sum;
+                else pblk[i * k + j] = sum;
+            }
         }
     }
 }

@@ -506,9 +506,15 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
         if (nblocks < 1) nblocks = 1;
         size_t need = (size_t)nblocks * k * k;
         if (ws.partial.n < need) ws.partial.alloc(need);
-        hipLaunchKernelGGL(gram_mfma_partial_kernel<real_t>, dim3(nblocks), dim3(256), 0, dev.stream,
-                           B, ldb, n, k, rpb, ws.partial.ptr);
-        hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + 3) / 4), dim3(256), 0, dev.stream,
+        // double precision, 48 < k <= 52: the live columns of the last block on the vector ALU (dense_kernels.hpp)
+        const int rem = (sizeof(real_t) == 8 && k > 48 && k <= 52) ? k - 48 : 0;
+        switch (rem) {
+#define CMF_GRAM_REM(R) case R: hipLaunchKernelGGL((gram_mfma_partial_kernel<real_t, R>), dim3(nblocks), dim3(256), 0, dev.stream, B, ldb, n, k, rpb, ws.partial.ptr); break;
+            CMF_GRAM_REM(1) CMF_GRAM_REM(2) CMF_GRAM_REM(3) CMF_GRAM_REM(4)
+#undef CMF_GRAM_REM
+            default: hipLaunchKernelGGL((gram_mfma_partial_kernel<real_t, 0>), dim3(nblocks), dim3(256), 0, dev.stream, B, ldb, n, k, rpb, ws.partial.ptr); break;
+        }
+        hipLaunchKernelGGL(gram_reduce_kernel<real_t>, dim3((k * k + GRAM_RED_ENT - 1) / GRAM_RED_ENT), dim3(256), 0, dev.stream,
                            ws.partial.ptr, nblocks, k * k, out, scale, add_diag, k);
     } else {
         // k > 64: out = scale * B^T B through the split-K GEMM (both operands the same matrix: 4 x the triangle's flops in
