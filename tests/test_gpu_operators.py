@@ -41,6 +41,31 @@ def test_optimizeA_implicit(oracles, dtype, k, mode):
         assert not Ah[5].any()
 
 
+@pytest.mark.parametrize("k", [49, 50, 51, 52, 53])
+def test_gramian_last_block_widths(oracles, k):
+    """Double precision, 48 < k <= 52: the Gramian kernel takes the last column block's live columns through the vector ALU
+    (gram_mfma_partial_kernel<double, REM>, REM = 1 .. 4), k = 53 is back on four matrix-core blocks; several row blocks,
+    both triangles of the result, and the half-step that uses it."""
+    from cmfrec_amd import ops
+    dtype = np.float64
+    O = oracles[dtype]
+    m, n = 300, 5000
+    row, col, val = make_coo(m, n, 30000, 70 + k, dtype=dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(k)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    Ah, Ao = A0.copy(), A0.copy()
+    Gh = ops.optimizeA_implicit(Ah, B, csr, 4.0, return_BtB=True, use_cg=True, max_cg_steps=3)
+    Go = O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, return_BtB=True, use_cg=True, max_cg_steps=3)
+    assert np.array_equal(Gh, Gh.T)
+    assert rel_err(Gh, Go) < 1e-13
+    dg = np.sqrt(np.diag(Go))
+    assert np.max(np.abs(Gh - Go) / np.outer(dg, dg)) < 1e-13    # every entry on the scale of its two columns, the last block's too
+    assert rel_err(Ah, Ao) < TOL[dtype]
+    check_rows(Ah, Ao, dtype)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("k,pad", [(51, 1), (16, 0), (33, 2)])
 @pytest.mark.parametrize("mode", ["cg", "chol", "pcg"])
