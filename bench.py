@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--item-blocks", default="dealt", choices=["dealt", "contiguous"],
                     help="config 4 on N ranks: item blocks equal in rows and balanced in nnz (items renumbered; B's all-gather lands in the "
                          "replica directly) or contiguous nnz-balanced blocks of unequal size (padded staging all-gather)")
+    ap.add_argument("--allgather", default=None, choices=["collective", "p2p"],
+                    help="N ranks: how the updated row blocks travel -- RCCL all-gathers (default; or CMFREC_ALLGATHER) or direct "
+                         "placement, every rank sending its block to each peer over their own xGMI link in one group of "
+                         "point-to-point transfers (cmfrec_amd/distributed.py, ShardedAls)")
     ap.add_argument("--implicit-features", action="store_true", help="side workloads c1 / c3: add the implicit-features matrices Ai, Bi")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "fit", "c4shard", "c5shard", "c5"],
                     help="c2 (default, the metric's config): implicit CG LastFM shape; c1 / c3: the explicit "
@@ -360,7 +364,7 @@ def c4_run(args, rank, world, local_rank, steps, warmup):
     fullA[rank * m_blk:(rank + 1) * m_blk].copy_(torch.rand((m_blk, fullA.shape[1]), generator=g, device=dev, dtype=torch.float32) * 2.0 ** -7)
     eng.full("B").zero_()
     torch.cuda.synchronize()
-    engine = ShardedAls(eng, rank, world)
+    engine = ShardedAls(eng, rank, world, exchange=args.allgather)
     engine.allgather("A")
     sess = eng.session
 
@@ -426,9 +430,11 @@ def c4_run(args, rank, world, local_rank, steps, warmup):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "CMF_implicit ALS-CG k=64 fp32, synthetic %d users x %d items, %d nnz (BASELINE.json configs[3]); "
                                       "lambda=5, max_cg_steps=3" % (m, n, nnz_blk * world),
-                          "parallelism": "user / item row blocks x%d (items nnz-balanced, %s: %s rows per block), RCCL all-gather of the "
+                          "parallelism": "user / item row blocks x%d (items nnz-balanced, %s: %s rows per block), %s of the "
                                          "updated rows after every half-step, A-step in %d parts" % (
-                                             world, args.item_blocks if world > 1 else "one block", "/".join(map(str, b_sizes)), a_parts),
+                                             world, args.item_blocks if world > 1 else "one block", "/".join(map(str, b_sizes)),
+                                             "direct placement (point-to-point group over RCCL)" if engine.exchange == "p2p" else "RCCL all-gather",
+                                             a_parts),
                           "gen_seconds": round(t_gen, 1), "setup_seconds": round(t_setup, 1)},
                "roofline": roofline, "cpu_baseline": None}
         out["config"]["scaling_series"] = ("BASELINE.json configs[3] at N = 1, 2, 4, 8: every --gpus N > 1 line runs THIS workload; its N = 1 point "
@@ -503,7 +509,7 @@ def c5_distributed(args, rank, world, local_rank):
     t0 = time.time()
     eng, m, n, nnz = c5_setup(args.scale, rank, world, local_rank)
     t_setup = time.time() - t0
-    als = ShardedAls(eng, rank, world)
+    als = ShardedAls(eng, rank, world, exchange=args.allgather)
     als.allgather("A"); als.allgather("B")
     sess = eng.session
     steps, warmup = max(1, min(args.steps, 3)), min(args.warmup, 1)
@@ -541,7 +547,8 @@ def c5_distributed(args, rank, world, local_rank):
                "config": {"workload": "CMF_explicit ALS-Chol k=256 fp32, synthetic %d users x %d items, %d nnz, 512-dim dense side "
                                       "information on both sides, user + item biases (BASELINE.json configs[4])" % (m, n, nnz),
                           "parallelism": "user / item row blocks x%d (items nnz-balanced), U / I sharded with the rows, C / D by partial "
-                                         "sums + one all-reduce each, all-gather of the updated rows after every half-step" % world,
+                                         "sums + one all-reduce each, %s of the updated rows after every half-step" % (
+                                             world, "direct placement (point-to-point group)" if als.exchange == "p2p" else "all-gather"),
                           "setup_seconds": round(t_setup, 1)},
                "halfstep_ms_rank0": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)},
                "halfstep_TFLOPs_rank0_share": {"A": round(flA / world / (msA / max(cA, 1) * 1e-3) / 1e12, 1) if cA else None,

@@ -100,9 +100,50 @@ class ShardedAls:
         engine.wait_part(which, part, stream), engine.join_comm(stream)
     """
 
-    def __init__(self, engine, rank, world, group=None):
+    def __init__(self, engine, rank, world, group=None, exchange=None):
+        """exchange: how the updated row blocks travel after a half-step --
+          "collective" (default): `all_gather_into_tensor` (RCCL picks ring / tree), through a padded staging buffer when the
+                                  blocks are unequal;
+          "p2p"                 : every rank sends its block to each peer and receives each peer's block STRAIGHT INTO its
+                                  rows of the replica, all 2 (world - 1) transfers in one `batch_isend_irecv` group -- on an
+                                  xGMI node every pair of GPUs has a link of its own, so the group is one hop on seven links at
+                                  once (2.1 ms against the ring's 14.6 ms bound for config 4's A), and unequal
+                                  blocks need neither padding nor copy kernels.
+        Default from CMFREC_ALLGATHER.  Which one wins on an 8-GPU node is a measurement this repository could not take (one
+        GPU per call); both give bit-identical replicas (tests/test_distributed_gloo.py, tests/test_gpu_two_ranks.py)."""
+        import os
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
         self._stage = {}
+        self.exchange = exchange or os.environ.get("CMFREC_ALLGATHER", "collective")
+        if self.exchange not in ("collective", "p2p"):
+            raise ValueError("exchange must be 'collective' or 'p2p'")
+
+    def _p2p_exchange(self, full, ranges, r0=None, r1=None):
+        """Direct placement: rows [b + r0, b + r1) of every rank's block (the whole block when r0 is None) from their owner
+        into this rank's replica.  Peers are visited in the order rank + 1, rank + 2, ... so that no two ranks start on the
+        same peer."""
+        import torch.distributed as dist
+        me, world = self.rank, self.world
+
+        def rows(r):
+            b, e = ranges[r]
+            return (b, e) if r0 is None else (b + r0, min(b + r1, e))
+
+        def peer(r):
+            return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+        ops = []
+        sb, se = rows(me)
+        for off in range(1, world):
+            dst, src = (me + off) % world, (me - off) % world
+            if se > sb:
+                ops.append(dist.P2POp(dist.isend, full[sb:se], peer(dst), self.group))
+            rb, re = rows(src)
+            if re > rb:
+                ops.append(dist.P2POp(dist.irecv, full[rb:re], peer(src), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()          # RCCL: the current stream waits (no host wait); gloo: the host does
 
     def allgather(self, which):
         import contextlib
@@ -125,7 +166,9 @@ class ShardedAls:
             return
         ld = full.shape[1]
         with (torch.cuda.stream(ordered) if ordered is not None else contextlib.nullcontext()):
-            if len(set(sizes)) == 1 and sizes[0] * self.world == full.shape[0]:
+            if self.exchange == "p2p":
+                self._p2p_exchange(full, ranges)
+            elif len(set(sizes)) == 1 and sizes[0] * self.world == full.shape[0]:
                 # equal blocks tiling the matrix exactly: gather straight into the replica
                 local = full[b0:b1].clone()
                 dist.all_gather_into_tensor(full.view(-1), local.view(-1), group=self.group)
@@ -161,6 +204,11 @@ class ShardedAls:
         view = full.view(self.world, blk, ld)
         cs = eng.comm_stream()
         for c, (r0, r1) in enumerate(parts):
+            if self.exchange == "p2p":
+                eng.wait_part(which, c, cs)
+                with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
+                    self._p2p_exchange(full, ranges, r0, r1)
+                continue
             key = (which, "part", c, r1 - r0, ld)
             if key not in self._stage:
                 self._stage[key] = torch.empty((self.world, r1 - r0, ld), dtype=full.dtype, device=full.device)

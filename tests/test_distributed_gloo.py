@@ -112,7 +112,7 @@ def _worker(rank, world, port, balanced, out_dir, m=301, nparts=0):
         assert len(eng.parts("A")) == nparts
     for _ in range(3):
         als.iteration()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B, joined=eng.joined)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), A=A, B=B, joined=eng.joined, exchange=als.exchange)
     dist.destroy_process_group()
 
 
@@ -121,10 +121,12 @@ def _free_port():
     return p
 
 
+@pytest.mark.parametrize("exchange", ["collective", "p2p"])
 @pytest.mark.parametrize("balanced", [False, True])
-def test_two_rank_als_matches_single_process(tmp_path, balanced, oracles):
+def test_two_rank_als_matches_single_process(tmp_path, balanced, exchange, oracles, monkeypatch):
     from conftest import make_coo
     world = 2
+    monkeypatch.setenv("CMFREC_ALLGATHER", exchange)      # (inherited by the spawned ranks; "p2p": direct placement, no staging)
     mp.spawn(_worker, args=(world, _free_port(), balanced, str(tmp_path)), nprocs=world, join=True)
     O = oracles[np.float64]
     m, n, k = 301, 200, 8
@@ -136,6 +138,26 @@ def test_two_rank_als_matches_single_process(tmp_path, balanced, oracles):
     # replicas agree bit-for-bit across ranks and equal the single-process fit exactly
     assert np.array_equal(r0["A"], r1["A"]) and np.array_equal(r0["B"], r1["B"])
     assert np.array_equal(r0["A"], A) and np.array_equal(r0["B"], B)
+    assert str(r0["exchange"]) == exchange and str(r1["exchange"]) == exchange
+
+
+def test_three_rank_p2p_unequal_blocks(tmp_path, oracles, monkeypatch):
+    """Direct placement with three ranks and nnz-balanced (unequal) blocks: every rank sends to / receives from two peers in
+    one group, no padding; replicas bit-identical to the single-process fit."""
+    from conftest import make_coo
+    world = 3
+    monkeypatch.setenv("CMFREC_ALLGATHER", "p2p")
+    mp.spawn(_worker, args=(world, _free_port(), True, str(tmp_path)), nprocs=world, join=True)
+    O = oracles[np.float64]
+    m, n, k = 301, 200, 8
+    row, col, val = make_coo(m, n, 5000, 77, heavy_row=(2, 150))
+    A = np.random.default_rng(3).standard_normal((m, k)) * 0.01
+    B = np.zeros((n, k))
+    O.fit_implicit_als(A, B, row, col, val, lam=4.0, niter=3)
+    for r in range(world):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert str(z["exchange"]) == "p2p"
+        assert np.array_equal(z["A"], A) and np.array_equal(z["B"], B)
 
 
 def test_boundaries():
@@ -150,11 +172,13 @@ def test_boundaries():
     assert balanced_boundaries(np.zeros(5, int), 3)[-1] == 5
 
 
-def test_two_rank_partwise_allgather(tmp_path, oracles):
+@pytest.mark.parametrize("exchange", ["collective", "p2p"])
+def test_two_rank_partwise_allgather(tmp_path, oracles, exchange, monkeypatch):
     """The overlap path of the multi-GPU bench: equal user blocks, the A block gathered in three parts
     (ShardedAls.allgather_parts); must still be the single-process fit, bit for bit."""
     from conftest import make_coo
     world, m = 2, 300
+    monkeypatch.setenv("CMFREC_ALLGATHER", exchange)
     mp.spawn(_worker, args=(world, _free_port(), False, str(tmp_path), m, 3), nprocs=world, join=True)
     O = oracles[np.float64]
     n, k = 200, 8

@@ -68,7 +68,33 @@ def _host_staged_collectives():
         assert res.shape[0] == int(sum(outs))
         out.copy_(res.to(out.dtype))
 
+    real_batch = dist.batch_isend_irecv
+
+    def batch_isend_irecv(ops):
+        """ShardedAls' direct placement (exchange="p2p"): sends from / receives into device rows, staged through the host."""
+        if not any(op.tensor.is_cuda for op in ops):
+            return real_batch(ops)
+        host_ops, landed = [], []
+        for op in ops:
+            if op.op is dist.isend:
+                host_ops.append(dist.P2POp(dist.isend, op.tensor.detach().cpu().contiguous(), op.peer, op.group))
+            else:
+                h = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+                host_ops.append(dist.P2POp(dist.irecv, h, op.peer, op.group))
+                landed.append((op.tensor, h))
+        reqs = real_batch(host_ops)
+
+        class Done:
+            def wait(self):
+                for r in reqs:
+                    r.wait()
+                for dst, h in landed:
+                    dst.copy_(h)
+
+        return [Done()]
+
     dist.all_gather_into_tensor, dist.all_reduce, dist.all_to_all_single = all_gather_into_tensor, all_reduce, all_to_all_single
+    dist.batch_isend_irecv = batch_isend_irecv
 
 
 def _worker(rank, world, port, case, path):
@@ -144,9 +170,13 @@ def _run_two_ranks(case, payload):
         return [dict(np.load(path + ".rank%d.npz" % r)) for r in range(2)]
 
 
+@pytest.mark.parametrize("exchange", ["collective", "p2p"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_two_rank_implicit_hip_sessions(dtype):
+def test_two_rank_implicit_hip_sessions(dtype, exchange, monkeypatch):
+    """exchange="p2p": the updated blocks (B: unequal blocks; A: in four parts on the communication stream) travel by direct
+    placement -- one batch of sends / receives per half-step or part, no staging buffer -- instead of all-gathers."""
     from cmfrec_amd.session import AlsSession
+    monkeypatch.setenv("CMFREC_ALLGATHER", exchange)         # read by ShardedAls in the spawned ranks
     from conftest import make_coo
     m, n, k, nnz = 16000, 5001, 50, 500000
     row, col, val = make_coo(m, n, nnz, 7, heavy_row=(3, 450))      # uniform: ~31 entries per user, ~100 per item, one long row
