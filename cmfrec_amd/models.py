@@ -273,11 +273,10 @@ class CMF(_Base):
         self.l1_lambda, self._l16 = _penalty(l1_lambda, "l1_lambda")
         self.nonneg = bool(nonneg); self.nonneg_C = bool(nonneg_C); self.nonneg_D = bool(nonneg_D)
         self.max_cd_steps = int(max_cd_steps)
-        if not (center_U and center_I):
-            raise NotImplementedError("center_U / center_I = False are not implemented in cmfrec_amd")
         self.k = int(k); self.use_cg = bool(use_cg)
         self.lambda_, self._lam6 = _penalty(lambda_, "lambda_")
         self.user_bias = bool(user_bias); self.item_bias = bool(item_bias); self.center = bool(center)
+        self.center_U = bool(center_U); self.center_I = bool(center_I)
         self.scale_lam = bool(scale_lam); self.scale_lam_sideinfo = bool(scale_lam_sideinfo)
         self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
         self.w_main = float(w_main); self.w_user = float(w_user); self.w_item = float(w_item)
@@ -348,8 +347,10 @@ class CMF(_Base):
         CtCw = np.zeros((kc, kc), dt) if (pre and p) else None
         rc = lib.fit_collective_explicit_als(
             _lib.ptr(biasA), _lib.ptr(biasB), _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), _lib.ptr(Ai), _lib.ptr(Bi),
-            C.c_bool(imp), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean), _lib.ptr(Ucm),
-            _lib.ptr(Icm), C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
+            C.c_bool(imp), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean),
+            # no column means = the side information is used as given (cmfrec/__init__.py passes an empty array for center_U=False)
+            _lib.ptr(Ucm) if (p and self.center_U) else None, _lib.ptr(Icm) if (q and self.center_I) else None,
+            C.c_int(m), C.c_int(n), C.c_int(self.k), _lib.ptr(row), _lib.ptr(col), _lib.ptr(val),
             C.c_size_t(len(val)), _lib.ptr(Xfull), _lib.ptr(Wv), C.c_bool(self.user_bias), C.c_bool(self.item_bias),
             C.c_bool(self.center), R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16), C.c_bool(self.scale_lam),
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(self.scale_bias_const), _lib.ptr(sbA), _lib.ptr(sbB),
@@ -382,7 +383,8 @@ class CMF(_Base):
         self.user_bias_ = biasA if self.user_bias else np.empty(0, dt)
         self.item_bias_ = biasB if self.item_bias else np.empty(0, dt)
         self.glob_mean_ = float(glob_mean[0])
-        self._U_colmeans, self._I_colmeans = Ucm[:p], Icm[:q]
+        self._U_colmeans = Ucm[:p] if self.center_U else Ucm[:0]
+        self._I_colmeans = Icm[:q] if self.center_I else Icm[:0]
         self.is_fitted_ = True
         return self
 

@@ -733,8 +733,10 @@ class Reference:
                                     finalize_chol=True, reset_values=False, seed=1, precompute=False, m=None, n=None,
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
                                     l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
-                                    l1_lam_unique=None, scale_bias_const=False, weight=None, NA_as_zero_X=False, Xfull=None):
+                                    l1_lam_unique=None, scale_bias_const=False, weight=None, NA_as_zero_X=False, Xfull=None,
+                                    center_U=True, center_I=True):
         """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II.
+        center_U / center_I = False: no column means are handed over, the reference then uses U / II as given.
         weight: observation weights, one per entry of X.  Xfull: dense X [m, n] with NaN for the missing entries instead
         of the triplet (row / col / val are then ignored; weight, if given, is [m, n] too)."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n
@@ -774,7 +776,7 @@ class Reference:
         ret = self.lib.fit_collective_explicit_als(
             _ptr(biasA), _ptr(biasB), _ptr(A), _ptr(B), _ptr(Cm), _ptr(Dm), _ptr(Ai), _ptr(Bi),
             C.c_bool(add_implicit_features), C.c_bool(reset_values), C.c_int(seed),
-            _ptr(glob_mean), _ptr(Ucm), _ptr(Icm),
+            _ptr(glob_mean), _ptr(Ucm) if center_U else None, _ptr(Icm) if center_I else None,
             C.c_int(m), C.c_int(n), C.c_int(k), _ptr(row), _ptr(col), _ptr(val), C.c_size_t(len(val)),
             _ptr(Xfull), _ptr(weight), C.c_bool(user_bias), C.c_bool(item_bias), C.c_bool(center),
             self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),

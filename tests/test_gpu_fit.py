@@ -321,6 +321,39 @@ def test_scale_bias_const_matches_reference(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("cu,ci", [(False, False), (False, True), (True, False)])
+def test_fit_explicit_uncentred_sideinfo(dtype, cu, ci):
+    """center_U / center_I = False: the side information is used as given (no column means are handed to the C function, as the
+    reference's estimator does); seeded fit against the compiled reference, Cholesky and CG, on matrices whose columns are far
+    from zero mean; the new-row function afterwards works without the means."""
+    from oracle.bindings import Reference, ref_available
+    if not ref_available(dtype):
+        pytest.skip("oracle/_ref not built")
+    from cmfrec_amd import CMF
+    R = Reference(dtype)
+    m, n, k, p, q = 420, 300, 16, 6, 5
+    row, col, val = make_coo(m, n, 9000, 41, counts=False, dtype=dtype)
+    rng = np.random.default_rng(5)
+    U = (rng.standard_normal((m, p)) + 1.5).astype(dtype); II = (rng.standard_normal((n, q)) - 2.0).astype(dtype)
+    t = 1e-6 if dtype is np.float64 else 1e-2
+    for use_cg in (False, True):
+        kw = dict(niter=2, use_cg=use_cg, finalize_chol=False, w_user=0.5, w_item=2.0)
+        mdl = CMF(k=k, lambda_=0.05, random_state=17, use_float=dtype is np.float32, nthreads=1, center_U=cu, center_I=ci,
+                  precompute_for_predictions=False, **kw).fit((row, col, val), U=U, I=II, shape=(m, n))
+        Ar, Br = np.zeros((m, k), dtype), np.zeros((n, k), dtype)
+        rr = R.fit_collective_explicit_als(Ar, Br, row, col, val, k, lam=0.05, nthreads=2, reset_values=True, seed=17, U=U, II=II,
+                                           center_U=cu, center_I=ci, **kw)
+        assert rr["ret"] == 0
+        assert frob(mdl.A_, Ar) < t and frob(mdl.B_, Br) < t, use_cg
+        assert frob(mdl.C_, rr["C"]) < t and frob(mdl.D_, rr["D"]) < t, use_cg
+        assert len(mdl._U_colmeans) == (p if cu else 0) and len(mdl._I_colmeans) == (q if ci else 0)
+        # and it matters: the centred fit of the same data is a different model
+        ctr = CMF(k=k, lambda_=0.05, random_state=17, use_float=dtype is np.float32, nthreads=1, precompute_for_predictions=False,
+                  **kw).fit((row, col, val), U=U, I=II, shape=(m, n))
+        assert frob(mdl.C_ if not cu else mdl.D_, ctr.C_ if not cu else ctr.D_) > 1e-2
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("side", [False, True])
 def test_factors_multiple_after_fit(oracles, dtype, side):
     """``factors_multiple`` of the estimators (factors_collective_*_multiple underneath).  A fit that ends on a Cholesky
