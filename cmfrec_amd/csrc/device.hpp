@@ -778,6 +778,9 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     }
 }
 
+// (gram_wave_tu.hip)
+void launch_gram_wave(dim3 grid, hipStream_t st, const CgParams<real_t> &P, const GramParams<real_t> &G, bool implicit, int rem);
+
 // very heavy rows: one (pass, update) launch pair per CG pass
 // split rows of this launch on the Gramian path?  (CMFREC_HIP_VH=stream / gram force one; k > 64 and block systems stream)
 template <bool GRAMX>
@@ -838,13 +841,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
             // four matrix-core tiles per slab
             const dim3 gw(std::min((X.n_slices + 3) / 4, dev.num_cus * 4));
             const int rem = (sizeof(real_t) == 8) ? P.k - 16 * (GRAM_NTT - 1) : 0;
-            switch (rem) {
-                case 1: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 1>), gw, dim3(256), 0, dev.stream, P, G); break;
-                case 2: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 2>), gw, dim3(256), 0, dev.stream, P, G); break;
-                case 3: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 3>), gw, dim3(256), 0, dev.stream, P, G); break;
-                case 4: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT, 4>), gw, dim3(256), 0, dev.stream, P, G); break;
-                default: hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPLICIT>), gw, dim3(256), 0, dev.stream, P, G); break;
-            }
+            launch_gram_wave(gw, dev.stream, P, G, IMPLICIT, rem);       // gram_wave_tu.hip: built with its own scheduler
         }
         poison_lds(dev.stream, dev.num_cus);
         hipLaunchKernelGGL((gram_cg_kernel<real_t, IMPLICIT>), dim3(std::min(nvh, dev.num_cus * 8)), dim3(256), 0, dev.stream, P, G);
