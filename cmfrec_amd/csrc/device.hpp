@@ -500,7 +500,9 @@ inline void launch_gram(const DeviceInfo &dev, GramWorkspace &ws, const real_t *
                         real_t *out, real_t scale, real_t add_diag)
 {
     if (k <= 64) {
-        int nblocks = std::max(1, std::min(dev.num_cus * 4, (n + 127) / 128));
+        // two workgroups per CU: 27.9 + 7.1 us for the two stages on C2's 359 k x 50 / 160 k x 50 matrices, against 35.8 + 5.1 (one),
+        // 33.0 + 12.3 (four), 36.5 + 17.6 (eight) -- profiles/r03/r03_bo_gram_blocks.txt
+        int nblocks = std::max(1, std::min(dev.num_cus * 2, (n + 127) / 128));
         int rpb = (n + nblocks - 1) / nblocks;
         nblocks = (n + rpb - 1) / rpb;
         if (nblocks < 1) nblocks = 1;
