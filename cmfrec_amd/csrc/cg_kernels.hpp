@@ -99,10 +99,6 @@ struct CgParams {
     // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
     const T *rconst = nullptr;
     size_t ldr = 0;
-    // second-generation kernels with the next row's tile prefetched into LDS (cg2_kernels.hpp, PF builds): entries of a tile
-    // that travel by LDS-DMA (a multiple of 8, 0: none), 16-byte chunks per gathered row (k x sizeof / 16) and the multiplier of
-    // the division by it (ceil(65536 / chunks))
-    int pf_entries = 0, pf_cpr = 0, pf_magic = 0;
 #ifdef CMF_CG_DEBUG
     int dbg = 0;   // phase skipping for timing experiments (results are wrong): 1 gathers, 2 Gramian product, 4 tile products, 8 dot products
 #endif
@@ -124,13 +120,6 @@ __device__ __forceinline__ void dbg_fill_tile(TILE &tile, T val)
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) { return lanes::wave_sum(v); }
-
-// A volatile LDS pointer: the load / store optimiser leaves reads through it as single ds_read_b64 (256 B per clock and CU)
-// instead of pairing them into ds_read2_b64 -- two reads for the price of 3.5 on this part (tools/microbench/valu_costs.hip:
-// 26 against 7.3 ticks per instruction and SIMD) -- and cannot hoist them out of the pass loops into registers either.  Used
-// by the second-generation kernels (cg2_kernels.hpp: 6 % on their 32-entry-tile kernel); on the first-generation kernels the
-// same change measured 2.5 % SLOWER (the tiny bins are not bound by the LDS pipe), so they read the Gramian plainly.
-template <typename T> using lds_cv = const volatile T __attribute__((address_space(3)));
 
 // Transposed butterfly over the lane bits 0..2 (the 8 lanes of one non-zero group): 8 values per
 // lane in, the lane whose low bits are b ends with the 8-lane total of v[b].

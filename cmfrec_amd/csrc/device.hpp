@@ -13,7 +13,6 @@
 
 #include "../../include/cmfrec_hip.h"
 #include "cg_kernels.hpp"
-#include "cg2_kernels.hpp"
 #include "chol_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gram_cg_kernels.hpp"
@@ -144,7 +143,6 @@ struct SparseShard {
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
     int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
-    int n_gt48 = 0;          // rows with more than 48 entries: the rest of the 33..64 bin fits 6-slot tiles (three wavefronts per SIMD)
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
     // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
@@ -265,7 +263,7 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0; n_long = 0; n_gt16 = 0; n_gt48 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
+        n_empty = 0; n_long = 0; n_gt16 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         // few split rows (C2's users: 50 rows, 65 k entries): short slices, so that their Gramian kernels -- which run in line
@@ -288,7 +286,6 @@ struct SparseShard {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
             if (l > 16) n_gt16++;
-            if (l > 48) n_gt48++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -625,66 +622,15 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
-// Second-generation tiled kernels (cg2_kernels.hpp): slots in use only, vectors redistributed through LDS, cheaper Gramian
-// product -- a third fewer vector instructions per row, and no faster: the register-resident bins turned out to be bound by
-// the bytes they keep in flight (two wavefronts per SIMD), not by the vector ALU (profiles/r03_b, r03_d).  CMFREC_HIP_CG2=1
-// selects them (tests/test_gpu_cg2.py runs the operator cases on them); the default is the first generation.
-// (These switches select kernels, so they are read at every launch -- a test can set them per case -- not cached.)
-inline bool env_flag(const char *name, bool dflt)
+// (cg_mm_tu.hip)
+bool launch_cg_tiny_mm(int num_cus, hipStream_t st, const CgParams<real_t> &P);
+// CMFREC_HIP_MM: 0 = off, 1 (default) = rows of 17 .. 32 entries, all = the whole tiny bin
+inline int mm_mode()
 {
-    const char *e = getenv(name);
-    return e != nullptr ? (e[0] != '0') : dflt;
-}
-inline bool cg2_enabled() { return env_flag("CMFREC_HIP_CG2", false); }
-// second generation with the next row's tile prefetched into LDS by DMA (33 .. 64 bin; CMFREC_HIP_CG2_PF=1, implies the second
-// generation for that bin)
-inline bool cg2_pf() { return env_flag("CMFREC_HIP_CG2_PF", false); }
-// rows of 33 .. 48 entries of the second generation on 6-slot tiles, three wavefronts per SIMD (CMFREC_HIP_CG2_NT6=1)
-inline bool cg2_nt6() { return env_flag("CMFREC_HIP_CG2_NT6", false); }
-// rows of at most 16 entries: two per wavefront on the first-generation kernel (default) or the NT = 4 kernel with one or two
-// slots in use (CMFREC_HIP_CG2_TINY=all)
-inline bool cg2_tiny_all()
-{
-    const char *e = getenv("CMFREC_HIP_CG2_TINY");
-    return e != nullptr && strcmp(e, "all") == 0;
-}
-
-template <int S, int NT, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
-inline void launch_cg2_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st,
-                           bool own_events = true, size_t counter_shift = 0)
-{
-    if (count <= 0) return;
-    EventPair ev{nullptr, nullptr};
-    if (tm && own_events) {
-        HIP_CHECK(hipEventCreate(&ev.a));
-        HIP_CHECK(hipEventCreate(&ev.b));
-        HIP_CHECK(hipEventRecord(ev.a, st));
-    }
-    poison_lds(st, dev.num_cus);
-    P.order += first;
-    P.desc += first;
-    P.nrows = count;
-    P.counter = dev.row_counter.ptr + cg_counter_offset(bin) + counter_shift;          // zeroed by launch_cg_S
-    constexpr int threads = 64 * W * RPB;
-    const size_t smem = (((IMPLICIT || GRAMX) ? (size_t)gram2_elems(S) : 0) + (size_t)W * RPB * 64 + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
-    auto kern = cg2_rows_kernel<real_t, S, NT, IMPLICIT, W, RPB, GRAMX>;
-    static thread_local int bpc_dev[MAX_DEVICES] = {0};
-    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
-    if (blocks_per_cu == 0) {
-        if (smem > 48 * 1024)
-            HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        int nb = 0;
-        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, smem));
-        blocks_per_cu = std::max(1, nb);
-    }
-    const int teams_needed = (count + RPB - 1) / RPB;
-    const int grid = std::min(teams_needed, dev.num_cus * blocks_per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, st, P);
-    HIP_CHECK(hipGetLastError());
-    if (tm && own_events) {
-        HIP_CHECK(hipEventRecord(ev.b, st));
-        tm->ev[bin].push_back(ev);
-    }
+    const char *e = getenv("CMFREC_HIP_MM");
+    if (e == nullptr) return 1;
+    if (strcmp(e, "all") == 0) return 2;
+    return e[0] != '0' ? 1 : 0;
 }
 
 template <int S, bool IMPLICIT, bool GRAMX = false>
@@ -705,38 +651,25 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
-    if (cg2_enabled() && P.weights == nullptr) {
-        // second generation: NT = 4 tiles for the rows above 16 entries (or the whole bin), the two-rows-per-wavefront kernel below
-        // for the rest; one event pair around both launches
-        const int c1 = cg2_tiny_all() ? count : count1;
-        launch_cg2_bin<S, 4, IMPLICIT, 1, 4, GRAMX>(dev, P, first, c1, nullptr, BIN_TINY, st, false);
-        if constexpr (!GRAMX) {
-            const int c2 = count - c1;
-            if (c2 > 0) {
-                CgParams<real_t> P2 = P;
-                P2.order += first + c1;
-                P2.desc += first + c1;
-                P2.nrows = c2;
-                auto kern2 = cg_rows_tiny2_kernel<real_t, S, IMPLICIT>;
-                static thread_local int bpc3_dev[MAX_DEVICES] = {0};
-                int &blocks_per_cu = bpc3_dev[di];
-                if (blocks_per_cu == 0) {
-                    int nb = 0;
-                    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern2, 256, IMPLICIT ? smem : 0));
-                    blocks_per_cu = std::max(1, nb);
-                }
-                const int npairs = (c2 + 1) / 2;
-                int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
-                hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), IMPLICIT ? smem : 0, st, P2);
-            }
+    // implicit model: sixteen rows in lock step per workgroup, the Gramian product of all sixteen on the matrix pipe
+    // (cg_mm_kernels.hpp); CMFREC_HIP_MM=0 keeps the bin on the one-row-per-wavefront kernels (A/B switch and cross-check),
+    // CMFREC_HIP_MM=all sends the rows of at most 16 entries through it as well
+    int mm_rows = 0;
+    if constexpr (IMPLICIT && !GRAMX) {
+        const int mode = mm_mode();
+        mm_rows = (mode == 2) ? count : (mode == 1 ? count1 : 0);
+        if (mm_rows > 0) {
+            CgParams<real_t> Pm = P;
+            Pm.order += first;
+            Pm.desc += first;
+            Pm.nrows = mm_rows;
+            Pm.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
+            if (!launch_cg_tiny_mm(dev.num_cus, st, Pm)) mm_rows = 0;
         }
-        HIP_CHECK(hipGetLastError());
-        if (tm) {
-            HIP_CHECK(hipEventRecord(ev.b, st));
-            tm->ev[BIN_TINY].push_back(ev);
-        }
-        return;
     }
+    if (mm_rows >= count1 && count1 > 0) {
+        // (done above)
+    } else
     if (count1 > 0) {
         CgParams<real_t> P1 = P;
         P1.order += first;
@@ -755,7 +688,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, P1);
     }
     if constexpr (!GRAMX) {
-        if (count2 > 0) {
+        if (count2 > 0 && mm_rows < count) {
             CgParams<real_t> P2 = P;
             P2.order += first + count1;
             P2.desc += first + count1;
@@ -875,45 +808,6 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
     }
 }
 
-// One wavefront per row with the next row's tile travelling into LDS while the current one is solved (cg2_kernels.hpp, PF
-// builds): a workgroup of 8 wavefronts per CU, the Gramian once, and per wavefront as many gathered rows as the CU's LDS holds
-// (40 of the 64 entries of a tile at k = 50 in double precision).  Returns false when the layout does not allow the 16-byte DMAs.
-template <int S, bool IMPLICIT, bool GRAMX>
-inline bool launch_cg2_pf_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
-{
-    if (count <= 0) return true;
-    constexpr int RPB = 8;
-    const size_t rowbytes = (size_t)P.k * sizeof(real_t);
-    if (rowbytes % 16 != 0 || (P.ldb * sizeof(real_t)) % 16 != 0 || ((uintptr_t)P.B) % 16 != 0 || rowbytes / 16 > 64) return false;
-    const size_t fixed = (((IMPLICIT || GRAMX) ? (size_t)gram2_elems(S) : 0) + (size_t)RPB * 64) * sizeof(real_t);
-    const size_t lds_cu = 160 * 1024 - 256;                     // the CU's LDS minus the static words of the kernel
-    if (fixed + (size_t)RPB * 16 * rowbytes > lds_cu) return false;
-    const int pfe = (int)std::min<size_t>(64, ((lds_cu - fixed) / ((size_t)RPB * rowbytes)) & ~(size_t)7);
-    EventPair ev{nullptr, nullptr};
-    if (tm) {
-        HIP_CHECK(hipEventCreate(&ev.a));
-        HIP_CHECK(hipEventCreate(&ev.b));
-        HIP_CHECK(hipEventRecord(ev.a, st));
-    }
-    poison_lds(st, dev.num_cus);
-    P.order += first;
-    P.desc += first;
-    P.nrows = count;
-    P.counter = dev.row_counter.ptr + cg_counter_offset(bin);
-    P.pf_entries = pfe; P.pf_cpr = (int)(rowbytes / 16); P.pf_magic = (65536 + P.pf_cpr - 1) / P.pf_cpr;
-    const size_t smem = fixed + (size_t)RPB * pfe * rowbytes;
-    auto kern = cg2_rows_kernel<real_t, S, 8, IMPLICIT, 1, RPB, GRAMX, true>;
-    HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int grid = std::min((count + RPB - 1) / RPB, dev.num_cus);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * RPB), smem, st, P);
-    HIP_CHECK(hipGetLastError());
-    if (tm) {
-        HIP_CHECK(hipEventRecord(ev.b, st));
-        tm->ev[bin].push_back(ev);
-    }
-    return true;
-}
-
 // number of streams the nnz bins of a half-step are spread over (CMFREC_HIP_BINS_PAR; 1 = one after the other)
 inline int cg_bin_streams()
 {
@@ -922,48 +816,16 @@ inline int cg_bin_streams()
     return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
 }
 
-// one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row) on the kernel generation in use
+// one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row)
 template <int S, bool IMPLICIT, bool GRAMX>
 inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm, int bin, hipStream_t st)
 {
     const int first = X.bin_first[bin], count = X.bin_rows[bin];
-    const bool v2 = cg2_enabled() && P.weights == nullptr;     // (the second generation has no observation weights)
     switch (bin) {
-        case BIN_HEAVY:
-            // (single precision: the first-generation 8-wave kernel keeps two resident tiles per wave, the second generation one)
-            if (v2 && sizeof(real_t) == 8) launch_cg2_bin<S, 8, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st);
-            else launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st);
-            break;
-        case BIN_MED4:
-            if (v2) launch_cg2_bin<S, 8, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st);
-            else launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st);
-            break;
-        case BIN_MED2:
-            if (v2) launch_cg2_bin<S, 8, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st);
-            else launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st);
-            break;
-        default:
-            if (cg2_pf() && launch_cg2_pf_bin<S, IMPLICIT, GRAMX>(dev, P, first, count, tm, bin, st)) break;
-            if (v2 && cg2_nt6()) {
-                // rows of 33 .. 48 entries (the tail of the bin) on 6-slot tiles: 84 tile registers leave room for a third
-                // wavefront per SIMD in double precision -- more rows, i.e. more bytes of the gather, in flight per CU
-                const int c8 = std::min(count, std::max(0, X.n_gt48 - first));
-                EventPair ev{nullptr, nullptr};
-                if (tm && count > 0) {
-                    HIP_CHECK(hipEventCreate(&ev.a));
-                    HIP_CHECK(hipEventCreate(&ev.b));
-                    HIP_CHECK(hipEventRecord(ev.a, st));
-                }
-                launch_cg2_bin<S, 8, IMPLICIT, 1, 4, GRAMX>(dev, P, first, c8, tm, bin, st, false);
-                launch_cg2_bin<S, 6, IMPLICIT, 1, 4, GRAMX>(dev, P, first + c8, count - c8, tm, bin, st, false,
-                                                            cg_counter_offset(NBINS) - cg_counter_offset(bin));
-                if (tm && count > 0) {
-                    HIP_CHECK(hipEventRecord(ev.b, st));
-                    tm->ev[bin].push_back(ev);
-                }
-            } else if (v2) launch_cg2_bin<S, 8, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
-            else launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st);
-            break;
+        case BIN_HEAVY: launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
+        case BIN_MED4: launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
+        case BIN_MED2: launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
+        default: launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st); break;
     }
 }
 

@@ -853,11 +853,13 @@ int_t fit_collective_explicit_als(
     // shards with peer copies of the updated rows, like fit_implicit_multi.  The bias start values are those of the single-device
     // driver: they are computed by a temporary session that holds the whole X on the first device (the sweeps alternate over
     // all rows and all columns, common.c:4410-4909), then handed to every shard.
+    // (a dense X keeps to one device: its half-steps follow the reference's per-half-step choice of solver, dense_chol_A / _B,
+    // and its empty rows are zeroed afterwards -- neither is part of explicit_multi_loop)
     const bool multi_ok = devs.size() > 1 && !U && !II && !spU && !spI && !add_implicit_features && !NA_as_zero_X && !weight &&
-                          m >= (int_t)devs.size() && n >= (int_t)devs.size();
+                          dx.na_row.empty() && m >= (int_t)devs.size() && n >= (int_t)devs.size();
     if (devs.size() > 1 && !multi_ok && verbose)
         printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (side information / weights / implicit features / "
-               "NA_as_zero) runs on the first\n", (int)devs.size());
+               "NA_as_zero / dense X) runs on the first\n", (int)devs.size());
     if (multi_ok) {
         auto configure = [&](cmfrec_hip_session *sd) {
             int rc2 = 0;

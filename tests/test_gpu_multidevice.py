@@ -103,3 +103,24 @@ def test_devices_env_ignores_bad_ordinals(monkeypatch):
     monkeypatch.setenv("CMFREC_HIP_DEVICES", "99,-1")
     mdl = CMF_implicit(k=8, niter=1, use_float=False).fit((row, col, val), shape=(m, n))
     assert np.isfinite(mdl.A_).all()
+
+
+@pytest.mark.parametrize("use_cg", [True, False])
+def test_devices_env_dense_X_stays_on_one_device(use_cg, monkeypatch):
+    """A dense X (NaN = missing) follows the reference's per-half-step choice of solver (optimizeA Cases 1-2, common.c:2787-3116) and
+    has its empty rows zeroed after the loop; the row-block loop knows neither, so such a fit keeps to the first listed device
+    and must return exactly what the single-device call returns (it used to run max_cg_steps CG steps instead)."""
+    from cmfrec_amd import CMF
+    rng = np.random.default_rng(11)
+    m, n = 120, 90
+    X = rng.integers(1, 11, size=(m, n)).astype(np.float64) * 0.5
+    X[rng.random((m, n)) < 0.7] = np.nan
+    X[5, :] = np.nan                                                     # an empty row
+    kw = dict(k=6, lambda_=1.5, niter=3, use_cg=use_cg, finalize_chol=False, use_float=False, random_state=3, nthreads=1)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF(**kw).fit(X)
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", "0,0")
+    shard = CMF(**kw).fit(X)
+    for name in ("A_", "B_", "user_bias_", "item_bias_"):
+        assert np.array_equal(getattr(shard, name), getattr(base, name)), name
+    assert np.all(shard.A_[5] == 0)

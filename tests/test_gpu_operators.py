@@ -216,8 +216,7 @@ def test_two_rows_per_wave(oracles, dtype, implicit, k):
 @pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("k", [50, 64, 9])
 def test_every_slot_count(oracles, dtype, implicit, k):
-    """The second-generation tiled kernels (cg2_kernels.hpp) run the gather and the tile products over the slots in use
-    only: rows of EVERY length 1 .. 150 (all slot counts 1 .. 8 of a 64-entry tile and 1 .. 4 of a 32-entry one, full and
+    """Rows of EVERY length 1 .. 150 (all slot counts 1 .. 8 of a 64-entry tile and 1 .. 4 of a 32-entry one, full and
     partly filled last slots, one-, two- and four-wave teams), a few of 250 .. 1000 (four- and eight-wave teams, the
     re-streamed second tile in double precision), checked row by row."""
     from cmfrec_amd import ops
