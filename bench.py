@@ -249,6 +249,26 @@ def main():
                                      **({"runs_beside_other_kernels": True} if d["overlapped"] else {}))
                                 for d in kernels])
 
+    # ---- the same kernels with the bins in line: every bin's own duration (what rocprofv3's per-kernel averages show) ----
+    if side_by_side and os.environ.get("CMFREC_HIP_BINS_PAR") is None:
+        def _name(which, b):
+            return ("gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"
+                    if b == 0 and sess.vh_mode(which) == 2 else names[b])
+        tab, hs_inline = inline_bin_leg(sess, step, sync, 5, _name, K, 8)
+        by_key = {(r["step"], r["kernel"]): r for r in tab}
+        for e in roofline["per_kernel"]:
+            r = by_key.get((e["step"], e["kernel"]))
+            if r is None:
+                continue
+            o = by_key.get(("A" if e["step"] == "B" else "B", e["kernel"]))
+            e["inline_ms"] = r["inline_ms"]; e["inline_GBps"] = r["GBps"]; e["inline_frac"] = r["frac"]
+            e["rocprof"]["avg_ms_over_both_halfsteps"] = round((r["inline_ms"] + (o["inline_ms"] if o else 0.0)) / (2 if o else 1), 4)
+            e["rocprof"]["mode"] = "bins in line (CMFREC_HIP_BINS_PAR=1): the run profiles/r04/*_kernel_stats_inline.csv is taken from"
+        worst = min(tab, key=lambda r: r["frac"])
+        roofline["inline"] = {"halfstep_ms": hs_inline, "iteration_ms": round(hs_inline["A"] + hs_inline["B"], 4),
+                              "worst_bin": {k2: worst[k2] for k2 in ("step", "kernel", "inline_ms", "GBps", "frac")},
+                              "note": "5 iterations after the timed region with the nnz bins one after the other; not part of `value`"}
+
     if not side_by_side and dom["kernel"].startswith("gram_wave"):
         # the Gramian path reads its rows once; what limits it in double precision is v_mfma_f64_16x16x4:
         # 10 tiles of the upper triangle per 4 entries, 2 x 16 x 16 x 4 flops each
@@ -273,7 +293,10 @@ def main():
             sp = c4_run(args, 0, 1, local_rank, steps=5, warmup=2)
             dist.destroy_process_group()
             scale_point = {k: sp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config")}
-            scale_point["iteration_frac_of_hbm_peak"] = (sp.get("roofline") or {}).get("iteration", {}).get("frac_of_hbm_peak")
+            rf = sp.get("roofline") or {}
+            scale_point["iteration_frac_of_hbm_peak"] = rf.get("iteration", {}).get("frac_of_hbm_peak")
+            scale_point["per_bin_inline"] = rf.get("per_bin_inline")
+            scale_point["inline"] = rf.get("inline")
         except Exception as e:        # the headline above must not depend on it
             scale_point = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -296,6 +319,39 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     emit_last_line(final_line)
+
+
+def inline_bin_leg(sess, step_fn, sync_fn, nsteps, names, k, itemsize):
+    """A few more iterations with the nnz bins of a half-step IN LINE (CMFREC_HIP_BINS_PAR=1, read by the library at every
+    launch): only then a bin's HIP-event pair -- recorded on the stream the kernel is launched on -- brackets that kernel alone, and
+    only then `rocprofv3 --kernel-trace --stats` of the same kernels has durations of their own to compare with
+    (profiles/r04/*_kernel_stats_inline.csv).  Returns one row per (half-step, bin): its own duration, algorithmic GB/s and
+    fraction of the HBM peak -- the per-kernel roofline the side-by-side default cannot show."""
+    keep = os.environ.get("CMFREC_HIP_BINS_PAR")
+    os.environ["CMFREC_HIP_BINS_PAR"] = "1"
+    try:
+        step_fn(); sync_fn()
+        sess.reset_timers()
+        for _ in range(nsteps):
+            step_fn()
+        sync_fn()
+        rows = []
+        for which in ("B", "A"):
+            for b in range(6):
+                ms, cnt, rows_b, nnz_b = sess.bin_stats(which, b)
+                if cnt:
+                    by = algorithmic_bytes(nnz_b, rows_b, k, itemsize)
+                    rows.append(dict(step=which, bin=b, kernel=names[b] if not callable(names) else names(which, b), rows=rows_b, nnz=nnz_b,
+                                     inline_ms=round(ms / cnt, 4), GBps=round(by / (ms / cnt * 1e-3) / 1e9, 1),
+                                     frac=round(by / (ms / cnt * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)))
+        msA, cntA = sess.kernel_time("A"); msB, cntB = sess.kernel_time("B")
+        return rows, {"A": round(msA / max(cntA, 1), 4), "B": round(msB / max(cntB, 1), 4)}
+    finally:
+        if keep is None:
+            os.environ.pop("CMFREC_HIP_BINS_PAR", None)
+        else:
+            os.environ["CMFREC_HIP_BINS_PAR"] = keep
+        sess.reset_timers()
 
 
 C4_M, C4_N, C4_NNZ, C4_K = 10_000_000, 1_000_000, 500_000_000, 64     # BASELINE.json configs[3] / SURVEY.md 8d "C4"
@@ -422,6 +478,13 @@ def c4_run(args, rank, world, local_rank, steps, warmup):
                         per_kernel_rank0=[dict(step=d["step"], kernel=d["kernel"], avg_ms=round(d["avg_ms"], 4), rows=d["rows"], nnz=d["nnz"],
                                                launches_timed=d["launches"], GBps=round(d["alg_bytes"] / (d["avg_ms"] * 1e-3) / 1e9, 1))
                                           for d in kernels])
+    if world == 1 and roofline is not None and os.environ.get("CMFREC_HIP_BINS_PAR") is None:
+        tab, hs_inline = inline_bin_leg(sess, engine.iteration, sync, 2, names, C4_K, 4)
+        worst = min(tab, key=lambda r: r["frac"])
+        roofline["per_bin_inline"] = tab
+        roofline["inline"] = {"halfstep_ms": hs_inline, "iteration_ms": round(hs_inline["A"] + hs_inline["B"], 4),
+                              "worst_bin": {k2: worst[k2] for k2 in ("step", "kernel", "inline_ms", "GBps", "frac")},
+                              "note": "2 iterations after the timed region with the nnz bins one after the other; not part of `value`"}
     out = None
     if rank == 0:
         out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=64 fp32",

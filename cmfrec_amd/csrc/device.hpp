@@ -622,17 +622,6 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
-// (cg_mm_tu.hip)
-bool launch_cg_tiny_mm(int num_cus, hipStream_t st, const CgParams<real_t> &P);
-// CMFREC_HIP_MM: 0 = off, 1 (default) = rows of 17 .. 32 entries, all = the whole tiny bin
-inline int mm_mode()
-{
-    const char *e = getenv("CMFREC_HIP_MM");
-    if (e == nullptr) return 1;
-    if (strcmp(e, "all") == 0) return 2;
-    return e[0] != '0' ? 1 : 0;
-}
-
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st, int n_gt16)
 {
@@ -651,25 +640,6 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
-    // implicit model: sixteen rows in lock step per workgroup, the Gramian product of all sixteen on the matrix pipe
-    // (cg_mm_kernels.hpp); CMFREC_HIP_MM=0 keeps the bin on the one-row-per-wavefront kernels (A/B switch and cross-check),
-    // CMFREC_HIP_MM=all sends the rows of at most 16 entries through it as well
-    int mm_rows = 0;
-    if constexpr (IMPLICIT && !GRAMX) {
-        const int mode = mm_mode();
-        mm_rows = (mode == 2) ? count : (mode == 1 ? count1 : 0);
-        if (mm_rows > 0) {
-            CgParams<real_t> Pm = P;
-            Pm.order += first;
-            Pm.desc += first;
-            Pm.nrows = mm_rows;
-            Pm.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
-            if (!launch_cg_tiny_mm(dev.num_cus, st, Pm)) mm_rows = 0;
-        }
-    }
-    if (mm_rows >= count1 && count1 > 0) {
-        // (done above)
-    } else
     if (count1 > 0) {
         CgParams<real_t> P1 = P;
         P1.order += first;
@@ -688,7 +658,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, P1);
     }
     if constexpr (!GRAMX) {
-        if (count2 > 0 && mm_rows < count) {
+        if (count2 > 0) {
             CgParams<real_t> P2 = P;
             P2.order += first + count1;
             P2.desc += first + count1;

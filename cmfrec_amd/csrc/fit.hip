@@ -17,7 +17,11 @@
 #include <cstdlib>
 #include <functional>
 #include <vector>
+#include <dlfcn.h>
+#include <set>
+#include <string>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is bound at run time, when a fit spans several devices
 
 #include "../../include/cmfrec_hip.h"
 #include "rng_host.hpp"
@@ -213,21 +217,132 @@ std::vector<int> devices_from_env()
     return out;
 }
 
+// RCCL for the exchange between the devices of one fit ("ncclAllGather ... or direct placement").  Bound with
+// dlopen when the first multi-device fit asks for it -- a single-device caller never maps the library -- through the prototypes
+// of <rccl/rccl.h> (decltype: nothing is declared by hand).
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load()
+    {
+        if (handle) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) return false;
+#define CMF_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(handle, #sym)); if (!field) { handle = nullptr; return false; }
+        CMF_SYM(CommInitAll, ncclCommInitAll) CMF_SYM(CommDestroy, ncclCommDestroy) CMF_SYM(GroupStart, ncclGroupStart)
+        CMF_SYM(GroupEnd, ncclGroupEnd) CMF_SYM(Send, ncclSend) CMF_SYM(Recv, ncclRecv) CMF_SYM(AllReduce, ncclAllReduce)
+        CMF_SYM(GetErrorString, ncclGetErrorString)
+#undef CMF_SYM
+        return true;
+    }
+};
+RcclApi &rccl() { static RcclApi api; return api; }
+#ifdef CMFREC_HIP_FLOAT
+const ncclDataType_t NCCL_REAL = ncclFloat;
+#else
+const ncclDataType_t NCCL_REAL = ncclDouble;
+#endif
+
+// acc[i] += x[i]: the partial sums of the C / D update when the shards exchange by copies (fixed order: shard 0, 1, 2 ...)
+__global__ void add_into_kernel(real_t *__restrict__ acc, const real_t *__restrict__ x, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+
+// The shards of one fit and what travels between them.  Two transports:
+//   RCCL   (distinct devices; the default there): the updated row blocks go by DIRECT PLACEMENT -- one ncclGroup of
+//          ncclSend / ncclRecv per half-step, every device sends its block to each peer and receives the peers' blocks straight
+//          into its replica, all pairs at once (on an xGMI node every pair of GPUs has a link of its own: one hop on D - 1 links
+//          instead of a ring's D - 1 steps on one); the partial sums of the C / D update by ncclAllReduce.  Every call is
+//          enqueued on the owning session's stream: kernels -> exchange -> next kernels are ordered by the stream, the host
+//          thread never waits inside the loop.
+//   copies (an ordinal repeats, i.e. several shards on one device -- how the path runs on a single-GPU box -- or
+//          CMFREC_HIP_EXCHANGE=copy): hipMemcpyPeerAsync ordered by events; the C / D partial sums are added on the first
+//          shard's device in shard order and copied back.
 struct MultiDev {
     std::vector<cmfrec_hip_session *> sess;
     std::vector<int> dev;
     std::vector<int> rb, cb;               // block boundaries of users / items (D + 1 each)
     std::vector<hipEvent_t> ev;            // per device: "my block has reached every peer"
+    std::vector<ncclComm_t> comm;          // RCCL transport: one communicator per shard (empty: copies)
+    real_t *stage = nullptr, *stage2 = nullptr;   // copies transport: partial sums on the first shard's device
+    size_t stage_n = 0;
+    std::string error;
     ~MultiDev()
     {
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
+        if (!comm.empty()) for (auto c : comm) if (c) (void)rccl().CommDestroy(c);
+        if (stage) { (void)hipSetDevice(dev.empty() ? 0 : dev[0]); (void)hipFree(stage); (void)hipFree(stage2); }
         for (auto s : sess) if (s) cmfrec_hip_session_destroy(s);
     }
-    // block d of matrix `which` (updated on device d) is copied into every other replica; every stream then waits for all blocks
+    bool use_rccl() const { return !comm.empty(); }
+    // CMFREC_HIP_EXCHANGE = rccl | copy (default: rccl where the ordinals are distinct and librccl can be bound)
+    int init_transport(bool verbose)
+    {
+        const char *e = getenv("CMFREC_HIP_EXCHANGE");
+        const bool want_copy = e != nullptr && strcmp(e, "copy") == 0, want_rccl = e != nullptr && strcmp(e, "rccl") == 0;
+        const bool distinct = std::set<int>(dev.begin(), dev.end()).size() == dev.size();
+        if (want_copy || !distinct) {
+            if (want_rccl) { error = "cmfrec_hip: CMFREC_HIP_EXCHANGE=rccl needs distinct device ordinals in CMFREC_HIP_DEVICES"; return 2; }
+            return 0;
+        }
+        if (!rccl().load()) {
+            if (want_rccl) { error = "cmfrec_hip: librccl could not be loaded"; return 4; }
+            if (verbose) printf("cmfrec_hip: librccl not found, the shards exchange by peer copies\n");
+            return 0;
+        }
+        comm.assign(dev.size(), nullptr);
+        const ncclResult_t r = rccl().CommInitAll(comm.data(), (int)dev.size(), dev.data());
+        if (r != ncclSuccess) {
+            comm.clear();
+            error = std::string("cmfrec_hip: ncclCommInitAll failed: ") + rccl().GetErrorString(r);
+            if (want_rccl) return 4;
+            if (verbose) printf("%s; the shards exchange by peer copies\n", error.c_str());
+            error.clear();
+        }
+        return 0;
+    }
+    // block d of matrix `which` (updated on device d) reaches every other replica; every stream then holds all blocks
     int exchange(int which)
     {
         const int D = (int)sess.size();
         const std::vector<int> &bb = (which == 'A') ? rb : cb;
+        if (use_rccl()) {
+            if (D == 1) return 0;
+            std::vector<real_t *> base(D); std::vector<size_t> ld(D); std::vector<hipStream_t> st(D);
+            for (int d = 0; d < D; d++) {
+                size_t rows = 0;
+                base[d] = (real_t *)cmfrec_hip_session_device_ptr(sess[d], which, &rows, &ld[d]);
+                st[d] = (hipStream_t)cmfrec_hip_session_stream(sess[d]);
+            }
+            ncclResult_t r = rccl().GroupStart();
+            for (int d = 0; d < D && r == ncclSuccess; d++) {
+                const size_t cnt_d = (size_t)(bb[d + 1] - bb[d]) * ld[d];
+                for (int o = 1; o < D && r == ncclSuccess; o++) {            // peers in the order d + 1, d + 2, ...: no two start on the same one
+                    const int e = (d + o) % D;
+                    const size_t cnt_e = (size_t)(bb[e + 1] - bb[e]) * ld[d];
+                    if (cnt_d) r = rccl().Send(base[d] + (size_t)bb[d] * ld[d], cnt_d, NCCL_REAL, e, comm[d], st[d]);
+                    if (cnt_e && r == ncclSuccess) r = rccl().Recv(base[d] + (size_t)bb[e] * ld[d], cnt_e, NCCL_REAL, e, comm[d], st[d]);
+                }
+            }
+            const ncclResult_t r2 = rccl().GroupEnd();
+            if (r != ncclSuccess || r2 != ncclSuccess) {
+                error = std::string("cmfrec_hip: RCCL exchange failed: ") + rccl().GetErrorString(r != ncclSuccess ? r : r2);
+                return 4;
+            }
+            return 0;
+        }
         for (int d = 0; d < D; d++) {
             size_t rows = 0, ld = 0;
             real_t *src = (real_t *)cmfrec_hip_session_device_ptr(sess[d], which, &rows, &ld);
@@ -250,6 +365,49 @@ struct MultiDev {
         }
         return 0;
     }
+    // the shards' partial sums [F_loc^T F_loc | U_loc^T F_loc] of a C / D update (cmfrec_hip_session_sideinfo_partial) become
+    // their total on every shard -- the same numbers everywhere, so that every replica solves the same small system
+    int allreduce_partials(size_t count)
+    {
+        const int D = (int)sess.size();
+        if (use_rccl()) {
+            ncclResult_t r = rccl().GroupStart();
+            for (int d = 0; d < D && r == ncclSuccess; d++) {
+                size_t rows = 0, ld = 0;
+                real_t *part = (real_t *)cmfrec_hip_session_device_ptr(sess[d], 'P', &rows, &ld);
+                r = rccl().AllReduce(part, part, count, NCCL_REAL, ncclSum, comm[d], (hipStream_t)cmfrec_hip_session_stream(sess[d]));
+            }
+            const ncclResult_t r2 = rccl().GroupEnd();
+            if (r != ncclSuccess || r2 != ncclSuccess) {
+                error = std::string("cmfrec_hip: RCCL all-reduce failed: ") + rccl().GetErrorString(r != ncclSuccess ? r : r2);
+                return 4;
+            }
+            return 0;
+        }
+        if (D == 1) return 0;
+        // copies: everything through the first shard's stream, between two host synchronisations (the test transport)
+        for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sync(sess[d]); if (rc) return rc; }
+        if (hipSetDevice(dev[0]) != hipSuccess) return 4;
+        if (stage_n < count) {
+            if (stage) { (void)hipFree(stage); (void)hipFree(stage2); stage = stage2 = nullptr; }
+            if (hipMalloc((void **)&stage, count * sizeof(real_t)) != hipSuccess || hipMalloc((void **)&stage2, count * sizeof(real_t)) != hipSuccess) return 1;
+            stage_n = count;
+        }
+        hipStream_t st0 = (hipStream_t)cmfrec_hip_session_stream(sess[0]);
+        for (int d = 0; d < D; d++) {
+            size_t rows = 0, ld = 0;
+            const real_t *part = (const real_t *)cmfrec_hip_session_device_ptr(sess[d], 'P', &rows, &ld);
+            if (hipMemcpyPeerAsync(d == 0 ? stage : stage2, dev[0], part, dev[d], count * sizeof(real_t), st0) != hipSuccess) return 4;
+            if (d > 0) hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st0, stage, stage2, count);
+        }
+        for (int d = 0; d < D; d++) {
+            size_t rows = 0, ld = 0;
+            real_t *part = (real_t *)cmfrec_hip_session_device_ptr(sess[d], 'P', &rows, &ld);
+            if (hipMemcpyPeerAsync(part, dev[d], stage, dev[0], count * sizeof(real_t), st0) != hipSuccess) return 4;
+        }
+        if (hipStreamSynchronize(st0) != hipSuccess) return 4;
+        return 0;
+    }
 };
 
 // One session per entry of `devs`, each owning a block of users and a block of items and holding the block's entries of X
@@ -257,10 +415,14 @@ struct MultiDev {
 // `configure` is called on every new session once its shards are built.
 int build_shards(MultiDev &md, const std::vector<int> &devs, const cmfrec_hip_model &mdl, int_t m, int_t n, const int_t *ixA,
                  const int_t *ixB, const real_t *X, size_t nnz, real_t subtract, real_t alpha,
-                 const std::function<int(cmfrec_hip_session *)> &configure)
+                 const std::function<int(cmfrec_hip_session *, int)> &configure)
 {
     const int D = (int)devs.size();
     md.dev = devs;
+    {
+        const int rc = md.init_transport(false);
+        if (rc) { fprintf(stderr, "%s\n", md.error.c_str()); return rc; }
+    }
     md.rb.assign(D + 1, 0); md.cb.assign(D + 1, 0);
     const int step = (m + D - 1) / D;
     for (int d = 0; d <= D; d++) md.rb[d] = std::min(d * step, (int)m);
@@ -313,59 +475,47 @@ int build_shards(MultiDev &md, const std::vector<int> &devs, const cmfrec_hip_mo
             (void)hipFree(dk); (void)hipFree(d_o); (void)hipFree(dv);
             if (rc) return rc;
         }
-        const int rc = configure(md.sess[d]);
+        const int rc = configure(md.sess[d], d);
         if (rc) return rc;
     }
     return 0;
 }
 
-// plain implicit model (no side information) on the devices of `devs`; same results as the single-device driver
-int fit_implicit_multi(const std::vector<int> &devs, real_t *A, real_t *B, int_t m, int_t n, int_t k_tot, const int_t *ixA, const int_t *ixB,
-                       const real_t *X, size_t nnz, cmfrec_hip_model mdl, const real_t *lam6, real_t alpha, int niter, bool finalize_chol,
-                       bool verbose, cmfrec_hip_session **first_out, MultiDev &md)
-{
-    const int D = (int)devs.size();
-    {
-        const int rc = build_shards(md, devs, mdl, m, n, ixA, ixB, X, nnz, (real_t)0, alpha, [&](cmfrec_hip_session *sd) {
-            int rc2 = cmfrec_hip_session_set_lam_unique(sd, lam6, nullptr, 100);
-            if (!rc2) rc2 = cmfrec_hip_session_set_factors(sd, A, B, nullptr, nullptr, nullptr, nullptr);
-            return rc2;
-        });
-        if (rc) return rc;
-    }
-    if (verbose) { printf("Starting ALS optimization routine (%d device shards)\n\n", D); fflush(stdout); }
-    for (int it = 0; it < niter; it++) {
-        if (g_stop) return 3;
-        const int chol = (finalize_chol && mdl.use_cg && it == niter - 1) ? 1 : 0;
-        for (int pass = 0; pass < 2; pass++) {                                // B then A (collective.c:9924-10022)
-            const int which = pass == 0 ? 'B' : 'A';
-            for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_update(md.sess[d], which, chol); if (rc) return rc; }
-            const int rc = md.exchange(which);
-            if (rc) return rc;
-            if (g_stop) return 3;
-        }
-        if (verbose) { for (int d = 0; d < D; d++) cmfrec_hip_session_sync(md.sess[d]); printf("\tCompleted ALS iteration %2d\n\n", it + 1); fflush(stdout); }
-    }
-    for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sync(md.sess[d]); if (rc) return rc; }
-    *first_out = md.sess[0];
-    (void)k_tot;
-    return 0;
-}
-
-// plain explicit model (biases, centring, no side information / weights) on the devices of `devs`: the same half-steps as run_loop,
-// every device on its block, the updated rows (bias column included: it rides in the factor rows, collective.c:8538-8543) copied
-// to the peers, then every replica splits the opposing bias off again (cmfrec_hip_session_after_gather)
-int explicit_multi_loop(MultiDev &md, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose)
+// C ('C') or D ('D') update of the collective model over the shards (optimizeA Case 1, common.c:2793-2991, with U / I cut into the
+// same row blocks as A / B): every shard adds up  F_loc^T F_loc  and  U_loc^T F_loc  over ITS rows, the sums are made global
+// (ncclAllReduce, or added in shard order by the copies transport), and every shard solves the same small system -- C / D stay
+// identical replicas without ever being exchanged.
+int multi_sideinfo_step(MultiDev &md, const cmfrec_hip_model &mdl, int which)
 {
     const int D = (int)md.sess.size();
-    if (verbose) { printf("Starting ALS optimization routine (%d device shards)\n\n", D); fflush(stdout); }
+    const size_t pp = (size_t)(which == 'C' ? mdl.p : mdl.q), kc = (size_t)((which == 'C' ? mdl.k_user : mdl.k_item) + mdl.k);
+    for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sideinfo_partial(md.sess[d], which); if (rc) return rc; }
+    const int rc = md.allreduce_partials(kc * kc + pp * kc);
+    if (rc) return rc;
+    for (int d = 0; d < D; d++) { const int rc2 = cmfrec_hip_session_sideinfo_finish(md.sess[d], which); if (rc2) return rc2; }
+    return 0;
+}
+
+// The ALS loop over the shards, both models: C, D (dense side information), then B, then A (collective.c:8334-8898, :9855-10022) --
+// every device updates its block, the updated rows (a bias column rides in them, collective.c:8538-8543) reach the peers
+// (MultiDev::exchange), and every replica splits the opposing bias off again (cmfrec_hip_session_after_gather).
+int multi_loop(MultiDev &md, const cmfrec_hip_model &mdl, int niter, bool finalize_chol, bool verbose)
+{
+    const int D = (int)md.sess.size();
+    if (verbose) {
+        printf("Starting ALS optimization routine (%d device shards, exchange by %s)\n\n", D, md.use_rccl() ? "RCCL" : "peer copies");
+        fflush(stdout);
+    }
     for (int it = 0; it < niter; it++) {
         if (g_stop) return 3;
         const int chol = (finalize_chol && mdl.use_cg && it == niter - 1) ? 1 : 0;
-        for (int pass = 0; pass < 2; pass++) {                                // B then A (collective.c:8640-8898)
+        if (mdl.p > 0) { const int rc = multi_sideinfo_step(md, mdl, 'C'); if (rc) return rc; }
+        if (mdl.q > 0) { const int rc = multi_sideinfo_step(md, mdl, 'D'); if (rc) return rc; }
+        for (int pass = 0; pass < 2; pass++) {
             const int which = pass == 0 ? 'B' : 'A';
             for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_update(md.sess[d], which, chol); if (rc) return rc; }
             int rc = md.exchange(which);
+            if (rc == 4 && !md.error.empty()) fprintf(stderr, "%s\n", md.error.c_str());
             for (int d = 0; d < D && !rc; d++) rc = cmfrec_hip_session_after_gather(md.sess[d], which);
             if (rc) return rc;
             if (g_stop) return 3;
@@ -374,6 +524,24 @@ int explicit_multi_loop(MultiDev &md, const cmfrec_hip_model &mdl, int niter, bo
     }
     for (int d = 0; d < D; d++) { const int rc = cmfrec_hip_session_sync(md.sess[d]); if (rc) return rc; }
     return 0;
+}
+
+// the rows of the (centred) dense side information that belong to shard d: U rows [rb[d], min(rb[d+1], m_u)), I likewise
+int set_sideinfo_shard(const MultiDev &md, cmfrec_hip_session *sd, int d, const real_t *Uc, int_t m_u, int_t p, const real_t *Ic, int_t n_i, int_t q)
+{
+    const real_t *Ul = (Uc && p > 0 && md.rb[d] < m_u) ? Uc + (size_t)md.rb[d] * p : nullptr;
+    const real_t *Il = (Ic && q > 0 && md.cb[d] < n_i) ? Ic + (size_t)md.cb[d] * q : nullptr;
+    if ((Uc && p > 0) || (Ic && q > 0)) return cmfrec_hip_session_set_sideinfo_local(sd, Ul, Il);
+    return 0;
+}
+
+// several entries in CMFREC_HIP_DEVICES, or one entry together with CMFREC_HIP_SHARDED=1 (the sharded driver on a single
+// shard: what a one-GPU box can run of the RCCL transport -- communicator, all-reduce -- tests/test_gpu_multidevice.py)
+bool sharded_fit_wanted(const std::vector<int> &devs)
+{
+    if (devs.size() > 1) return true;
+    const char *e = getenv("CMFREC_HIP_SHARDED");
+    return devs.size() == 1 && e != nullptr && e[0] == '1';
 }
 
 }  // namespace
@@ -516,24 +684,35 @@ int_t fit_collective_implicit_als(
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
     // device selection without touching the signature: CMFREC_HIP_DEVICES (one ordinal: that device; several: row-block shards)
     const std::vector<int> devs = devices_from_env();
-    const bool multi_ok = devs.size() > 1 && p == 0 && q == 0 && !nonneg && l1_lam == 0 && !l1_lam_unique && m >= (int_t)devs.size() &&
+    // Sharded: the plain model and the one with DENSE side information (C / D by partial sums + all-reduce, multi_sideinfo_step),
+    // all solvers, constraints and penalties; sparse side information and side information beyond the shape of X keep to the
+    // first listed device.
+    const bool multi_ok = sharded_fit_wanted(devs) && !spU && !spI && m_u <= m && n_i <= n && m >= (int_t)devs.size() &&
                           n >= (int_t)devs.size();
     if (devs.size() > 1 && !multi_ok && verbose)
-        printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (side information / constraints) runs on the first\n",
-               (int)devs.size());
+        printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (sparse side information / side information beyond X) "
+               "runs on the first\n", (int)devs.size());
     if (multi_ok) {
         MultiDev md;
-        cmfrec_hip_session *s0 = nullptr;
-        int rc_loop = fit_implicit_multi(devs, A, B, m_max, n_max, k_totA, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, mdl, lam6, alpha,
-                                         niter, finalize_chol, verbose, &s0, md);
-        if ((rc_loop == 0 || rc_loop == 3) && s0 == nullptr && !md.sess.empty()) s0 = md.sess[0];
+        int rc_loop = build_shards(md, devs, mdl, m_max, n_max, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, (real_t)0, alpha,
+                                   [&](cmfrec_hip_session *sd, int d) {
+            int rc2 = set_sideinfo_shard(md, sd, d, U ? Uc.data() : nullptr, m_u, p, II ? Ic.data() : nullptr, n_i, q);
+            if (!rc2 && (nonneg || nonneg_C || nonneg_D)) rc2 = cmfrec_hip_session_set_nonneg(sd, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
+            if (!rc2 && l1_lam != 0) rc2 = cmfrec_hip_session_set_l1(sd, l1_lam, (int)max_cd_steps);
+            if (!rc2) rc2 = cmfrec_hip_session_set_lam_unique(sd, lam6, l1_lam_unique ? l16 : nullptr, (int)max_cd_steps);
+            if (!rc2) rc2 = cmfrec_hip_session_set_factors(sd, A, B, nullptr, nullptr, C, D);
+            return rc2;
+        });
+        if (!rc_loop) rc_loop = multi_loop(md, mdl, (int)niter, finalize_chol, verbose);
+        cmfrec_hip_session *s0 = md.sess.empty() ? nullptr : md.sess[0];
         if ((rc_loop == 0 || rc_loop == 3) && s0) {
-            int rc2 = cmfrec_hip_session_get_factors(s0, A, B, nullptr, nullptr, nullptr, nullptr);
+            int rc2 = cmfrec_hip_session_get_factors(s0, A, B, nullptr, nullptr, C, D);
             if (rc2) rc_loop = rc2;
         }
         if ((rc_loop == 0 || rc_loop == 3) && s0 && precompute_for_predictions) {
             const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
-            int rc2 = cmfrec_hip_session_precompute(s0, last_chol, 0, precomputedBtB, nullptr, nullptr, nullptr, nullptr, nullptr);
+            int rc2 = cmfrec_hip_session_precompute(s0, last_chol, 0, precomputedBtB, nullptr, hadU ? precomputedBeTBe : nullptr,
+                                                    hadU ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
             if (rc2) rc_loop = rc2;
         }
         if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
@@ -849,21 +1028,21 @@ int_t fit_collective_explicit_als(
     mdl.lam = lam; mdl.w_user = w_user; mdl.w_item = w_item;
     mdl.row_begin = 0; mdl.row_end = m_max; mdl.col_begin = 0; mdl.col_end = n_max;
     const std::vector<int> devs = devices_from_env();                  // CMFREC_HIP_DEVICES: one ordinal = that device, several = row-block shards
-    // Several devices: the plain model (biases, centring, CG / Cholesky, non-negativity, L1, per-matrix penalties) as row-block
-    // shards with peer copies of the updated rows, like fit_implicit_multi.  The bias start values are those of the single-device
-    // driver: they are computed by a temporary session that holds the whole X on the first device (the sweeps alternate over
-    // all rows and all columns, common.c:4410-4909), then handed to every shard.
+    // Several devices: the plain model and the one with DENSE side information (biases, centring, CG / Cholesky, non-negativity,
+    // L1, per-matrix penalties) as row-block shards that exchange the updated rows (MultiDev).  The bias start values are those
+    // of the single-device driver: they are computed by a temporary session that holds the whole X on the first device (the
+    // sweeps alternate over all rows and all columns, common.c:4410-4909), then handed to every shard.
     // (a dense X keeps to one device: its half-steps follow the reference's per-half-step choice of solver, dense_chol_A / _B,
-    // and its empty rows are zeroed afterwards -- neither is part of explicit_multi_loop)
-    const bool multi_ok = devs.size() > 1 && !U && !II && !spU && !spI && !add_implicit_features && !NA_as_zero_X && !weight &&
-                          dx.na_row.empty() && m >= (int_t)devs.size() && n >= (int_t)devs.size();
+    // and its empty rows are zeroed afterwards -- neither is part of multi_loop)
+    const bool multi_ok = sharded_fit_wanted(devs) && !spU && !spI && m_u <= m && n_i <= n && !add_implicit_features && !NA_as_zero_X &&
+                          !weight && dx.na_row.empty() && m >= (int_t)devs.size() && n >= (int_t)devs.size();
     if (devs.size() > 1 && !multi_ok && verbose)
-        printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (side information / weights / implicit features / "
-               "NA_as_zero / dense X) runs on the first\n", (int)devs.size());
+        printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (sparse side information / side information beyond X / "
+               "weights / implicit features / NA_as_zero / dense X) runs on the first\n", (int)devs.size());
     if (multi_ok) {
         auto configure = [&](cmfrec_hip_session *sd) {
             int rc2 = 0;
-            if (nonneg) rc2 = cmfrec_hip_session_set_nonneg(sd, nonneg, false, false, (int)max_cd_steps);
+            if (nonneg || nonneg_C || nonneg_D) rc2 = cmfrec_hip_session_set_nonneg(sd, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
             if (!rc2 && l1_lam != 0) rc2 = cmfrec_hip_session_set_l1(sd, l1_lam, (int)max_cd_steps);
             if (!rc2 && (lam_unique || l1_lam_unique || scale_bias_const))
                 rc2 = cmfrec_hip_session_set_lam_unique(sd, (lam_unique || scale_bias_const) ? lam6 : nullptr,
@@ -876,7 +1055,7 @@ int_t fit_collective_explicit_als(
             cmfrec_hip_session *t = cmfrec_hip_session_create(&mdl, devs[0]);
             if (!t) { if (verbose) fprintf(stderr, "%s\n", cmfrec_hip_last_error()); const int ec = cmfrec_hip_last_error_code(); return ec ? ec : 1; }
             rc = cmfrec_hip_session_set_X_coo_weighted(t, ixA, ixB, X, nullptr, nnz, gm, (real_t)1);
-            if (!rc) rc = configure(t);
+            if (!rc) rc = configure(t);          // (the sweeps need the attribute COUNTS under scale_lam_sideinfo, mdl.p / mdl.q, not U / I)
             if (!rc) rc = cmfrec_hip_session_set_factors(t, A, B, nullptr, nullptr, nullptr, nullptr);
             real_t lam_u = lam6[0], lam_i = lam6[1];                      // collective.c:8178, :8197, :8218-8219
             if (std::fabs(lam_u) < EPS_T) lam_u = EPS_T;
@@ -887,21 +1066,23 @@ int_t fit_collective_explicit_als(
             if (rc) return rc;
         }
         MultiDev md;
-        rc = build_shards(md, devs, mdl, m, n, ixA, ixB, X, nnz, gm, (real_t)1, [&](cmfrec_hip_session *sd) {
-            int rc2 = configure(sd);
-            if (!rc2) rc2 = cmfrec_hip_session_set_factors(sd, A, B, has_bias ? biasA : nullptr, has_bias ? biasB : nullptr, nullptr, nullptr);
+        if (!rc) rc = build_shards(md, devs, mdl, m_max, n_max, ixA, ixB, X, nnz, gm, (real_t)1, [&](cmfrec_hip_session *sd, int d) {
+            int rc2 = set_sideinfo_shard(md, sd, d, U ? Uc.data() : nullptr, m_u, p, II ? Ic.data() : nullptr, n_i, q);
+            if (!rc2) rc2 = configure(sd);
+            if (!rc2) rc2 = cmfrec_hip_session_set_factors(sd, A, B, has_bias ? biasA : nullptr, has_bias ? biasB : nullptr, C, D);
             return rc2;
         });
-        int rc_loop = rc ? rc : explicit_multi_loop(md, mdl, (int)niter, finalize_chol, verbose);
+        int rc_loop = rc ? rc : multi_loop(md, mdl, (int)niter, finalize_chol, verbose);
         cmfrec_hip_session *s0 = md.sess.empty() ? nullptr : md.sess[0];
         if ((rc_loop == 0 || rc_loop == 3) && s0) {
-            const int rc2 = cmfrec_hip_session_get_factors(s0, A, B, biasA, biasB, nullptr, nullptr);
+            const int rc2 = cmfrec_hip_session_get_factors(s0, A, B, biasA, biasB, C, D);
             if (rc2) rc_loop = rc2;
         }
         if ((rc_loop == 0 || rc_loop == 3) && s0 && precompute_for_predictions) {   // collective.c:8936-9249
             const int last_chol = (!use_cg || (finalize_chol && niter > 0)) ? 1 : 0;
             int rc2 = cmfrec_hip_session_precompute(s0, last_chol, include_all_X ? 1 : 0, precomputedBtB, precomputedTransBtBinvBt, nullptr,
-                                                    nullptr, nullptr, nullptr);
+                                                    hadU ? precomputedBeTBeChol : nullptr, hadU ? precomputedCtCw : nullptr,
+                                                    hadU ? precomputedTransCtCinvCt : nullptr);
             if (rc2) rc_loop = rc2;
             if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
                 for (int_t c = 0; c < n_max; c++) {

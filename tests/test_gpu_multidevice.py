@@ -124,3 +124,81 @@ def test_devices_env_dense_X_stays_on_one_device(use_cg, monkeypatch):
     for name in ("A_", "B_", "user_bias_", "item_bias_"):
         assert np.array_equal(getattr(shard, name), getattr(base, name)), name
     assert np.all(shard.A_[5] == 0)
+
+
+def _side_problem(seed=5, m=700, n=500, nnz=24000, p=9, q=7, counts=False):
+    rng = np.random.default_rng(seed)
+    row, col, val = make_coo(m, n, nnz, seed, counts=counts, heavy_row=(5, 400), empty_rows=(7, 11))
+    U = rng.standard_normal((m, p)) + 0.5
+    I = rng.standard_normal((n, q)) - 1.0
+    return m, n, row, col, val, U, I
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("opts", [dict(use_cg=False), dict(use_cg=True, finalize_chol=True), dict(use_cg=False, scale_lam=True, scale_lam_sideinfo=True),
+                                  dict(use_cg=False, k_user=2, k_item=1, k_main=1, w_user=0.5, w_item=2.0)],
+                         ids=["chol", "cg+fin", "chol-scale_lam_sideinfo", "chol-k_user-k_item-k_main"])
+@pytest.mark.parametrize("sides", ["U", "I", "UI"])
+@pytest.mark.parametrize("use_float", [False, True])
+def test_devices_env_collective_model(devices, opts, sides, use_float, monkeypatch):
+    """The explicit model WITH dense side information behind CMFREC_HIP_DEVICES (BASELINE configs 3 and 5 are of
+    this kind): U / I cut into the shards' row blocks, the C / D update as partial sums per shard + their total on every shard +
+    the same small solve everywhere (multi_sideinfo_step, fit.hip), bias columns riding in the exchanged rows.  Against the
+    single-device fit: the partial sums are added in another order, nothing else differs."""
+    from cmfrec_amd import CMF
+    m, n, row, col, val, U, I = _side_problem()
+    kw = dict(k=10, lambda_=1.5, niter=3, use_float=use_float, random_state=7, nthreads=1, **opts)
+    side = dict(U=U if "U" in sides else None, I=I if "I" in sides else None)
+    if "U" not in sides: kw.pop("k_user", None)
+    if "I" not in sides: kw.pop("k_item", None)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF(**kw).fit((row, col, val), shape=(m, n), **side)
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", devices)
+    shard = CMF(**kw).fit((row, col, val), shape=(m, n), **side)
+    tol = 2e-3 if use_float else 1e-10
+    names = ["A_", "B_", "user_bias_", "item_bias_"] + (["C_"] if "U" in sides else []) + (["D_"] if "I" in sides else [])
+    for name in names:
+        a, b = getattr(shard, name), getattr(base, name)
+        assert np.isfinite(a).all() and np.abs(b).max() > 0, name
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), name
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("use_cg", [False, True])
+@pytest.mark.parametrize("use_float", [False, True])
+def test_devices_env_implicit_with_side_information(devices, use_cg, use_float, monkeypatch):
+    from cmfrec_amd import CMF_implicit
+    m, n, row, col, val, U, I = _side_problem(seed=6, counts=True)
+    kw = dict(k=10, lambda_=2.0, niter=3, use_cg=use_cg, finalize_chol=False, use_float=use_float, random_state=7, k_user=1, k_item=2)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = CMF_implicit(**kw).fit((row, col, val), shape=(m, n), U=U, I=I)
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", devices)
+    shard = CMF_implicit(**kw).fit((row, col, val), shape=(m, n), U=U, I=I)
+    tol = 2e-3 if use_float else 1e-10
+    for name in ("A_", "B_", "C_", "D_"):
+        a, b = getattr(shard, name), getattr(base, name)
+        assert np.isfinite(a).all() and np.abs(b).max() > 0, name
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), name
+
+
+@pytest.mark.parametrize("model", ["explicit", "implicit"])
+def test_single_shard_through_rccl(model, monkeypatch):
+    """What a one-GPU box can run of the RCCL transport of the C host (fit.hip, MultiDev): CMFREC_HIP_SHARDED=1 sends a fit on ONE
+    listed device through the sharded driver, CMFREC_HIP_EXCHANGE=rccl makes the library bind librccl, build a communicator
+    (ncclCommInitAll over the one device) and all-reduce the C / D partial sums through it (a one-rank ncclAllReduce is the
+    identity).  The N > 1 exchange (ncclSend / ncclRecv group) needs N devices and is covered by construction only."""
+    from cmfrec_amd import CMF, CMF_implicit
+    m, n, row, col, val, U, I = _side_problem(seed=8, counts=(model == "implicit"))
+    if model == "explicit":
+        mk = lambda: CMF(k=8, lambda_=1.5, niter=2, use_cg=False, use_float=False, random_state=3, nthreads=1)
+    else:
+        mk = lambda: CMF_implicit(k=8, lambda_=1.5, niter=2, use_cg=True, use_float=False, random_state=3)
+    monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
+    base = mk().fit((row, col, val), shape=(m, n), U=U, I=I)
+    monkeypatch.setenv("CMFREC_HIP_DEVICES", "0")
+    monkeypatch.setenv("CMFREC_HIP_SHARDED", "1")
+    monkeypatch.setenv("CMFREC_HIP_EXCHANGE", "rccl")
+    one = mk().fit((row, col, val), shape=(m, n), U=U, I=I)
+    for name in ("A_", "B_", "C_", "D_"):
+        a, b = getattr(one, name), getattr(base, name)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), name
