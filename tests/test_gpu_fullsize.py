@@ -2,10 +2,13 @@
 where the CPU oracle would take minutes per call: size-independent properties of the ALS half-steps instead
 (run-to-run bit reproducibility, the normal equations of sampled rows, monotone objective, invariance to the order
 of the COO entries, CG -> closed form)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 K, LAM = 50, 5.0
 
@@ -292,3 +295,31 @@ def test_c5_shard_properties(eig, monkeypatch):
     gB, gA, gC, _ = run()
     for a, b in ((fB["B"], gB["B"]), (fA["A"], gA["A"]), (fC["C"], gC["C"]), (fC["D"], gC["D"])):
         assert np.array_equal(a, b)
+
+
+def test_c5_rank_true_share():
+    """ONE rank of BASELINE config 5 on 8 GPUs at its TRUE share: rank 0's shard built as
+    GpuEngine.from_collective_block builds it -- the 100 M x 257 replica of A (102.8 GB), 12.5 M users with 250 M entries, its
+    nnz-balanced item block with the entries of all eight user blocks, 25.6 GB of U drawn on the device -- through
+    tools/microbench/c5_rank_of_n.py.  Size-independent properties: the factors are finite, sampled user rows (the three heaviest
+    and random ones) satisfy the collective normal equations in float64 arithmetic to 2e-4, and one iteration run twice from the
+    same state is bit-identical.  Needs most of the part's 288 GB; skipped where less than 230 GB are free."""
+    import importlib.util
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 230e9:
+        pytest.skip("needs 230 GB of free HBM, %.0f GB are free" % (free / 1e9))
+    spec = importlib.util.spec_from_file_location("c5_rank_of_n", os.path.join(ROOT, "tools", "microbench", "c5_rank_of_n.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        res = mod.run(N=8, scale=1.0, timed_iters=1, n_check=12, verbose=False)
+    finally:
+        os.chdir(cwd)
+    assert res["users_in_block"] == 12_500_000 and res["replica_rows"]["A"] == 100_000_000
+    assert res["lowrank_rows"] >= 12_000_000                          # 20 entries per user: the low-rank path takes (nearly) all of them
+    c = res["checks"]
+    assert c["finite"] and c["reproducible"]
+    assert c["user_rows_normal_equations_relres"] <= 2e-4, c
+    assert res["memory_GB"]["high_water_used"] < 280

@@ -81,18 +81,19 @@ def test_devices_env_explicit_model(devices, opts, use_float, monkeypatch):
     assert shard.glob_mean_ == base.glob_mean_
 
 
-def test_devices_env_explicit_falls_back_with_side_information(monkeypatch):
-    """Configurations the sharded driver does not take (side information, weights, ...) run on the first listed device."""
+def test_devices_env_explicit_falls_back(monkeypatch):
+    """Configurations the sharded driver does not take (observation weights, sparse side information, ...) run on the first
+    listed device: exactly the single-device result."""
     from cmfrec_amd import CMF
     m, n = 300, 200
     row, col, val = make_coo(m, n, 5000, 4, counts=False)
-    II = np.random.default_rng(1).standard_normal((n, 3))
+    W = np.random.default_rng(1).random(len(val)) + 0.5
     kw = dict(k=6, niter=2, use_float=False, random_state=3, nthreads=1)
     monkeypatch.delenv("CMFREC_HIP_DEVICES", raising=False)
-    base = CMF(**kw).fit((row, col, val), I=II, shape=(m, n))
+    base = CMF(**kw).fit((row, col, val), W=W, shape=(m, n))
     monkeypatch.setenv("CMFREC_HIP_DEVICES", "0,0")
-    two = CMF(**kw).fit((row, col, val), I=II, shape=(m, n))
-    assert np.array_equal(two.A_, base.A_) and np.array_equal(two.D_, base.D_)
+    two = CMF(**kw).fit((row, col, val), W=W, shape=(m, n))
+    assert np.array_equal(two.A_, base.A_) and np.array_equal(two.B_, base.B_)
 
 
 def test_devices_env_ignores_bad_ordinals(monkeypatch):
