@@ -494,6 +494,41 @@ __global__ void betbe_base_kernel(const T *__restrict__ G, int kk, int ks, T lam
     }
 }
 
+// Linv [n, n] row-major := (R^T)^-1 for the row-major upper Cholesky factor R (M = R^T R): lower triangular, zeros above the
+// diagonal.  One workgroup; thread j solves R x = e_j by back substitution (x = column j of R^-1 = row j of Linv): the
+// elements of R it reads are the same for every thread (broadcast loads), its own x stays in its row of the output.
+template <typename T>
+__global__ void __launch_bounds__(256) trtri_from_upper_kernel(const T *__restrict__ R, int n, T *__restrict__ Linv)
+{
+    for (int j = threadIdx.x; j < n; j += 256) {
+        T *x = Linv + (size_t)j * n;
+        for (int i = j + 1; i < n; i++) x[i] = T(0);
+        x[j] = T(1) / R[(size_t)j * n + j];
+        for (int i = j - 1; i >= 0; i--) {
+            T acc = T(0);
+            for (int l = i + 1; l <= j; l++) acc += R[(size_t)i * n + l] * x[l];
+            x[i] = -acc / R[(size_t)i * n + i];
+        }
+    }
+}
+
+// out[kt, kt] = blockdiag(lam I [ks, ks], G [kb, kb]) + CtC [kc, kc] in the upper-left corner, kt = ks + kb: the matrix every row of
+// a missing-as-zero half-step with dense side information shares (collective.c:5700-5716; G = B^T B with its own diagonal
+// already added, CtC already times w)
+template <typename T>
+__global__ void naz_block_matrix_kernel(const T *__restrict__ G, int kb, const T *__restrict__ CtC, int kc, int ks, T lam, T *__restrict__ out)
+{
+    const int kt = ks + kb;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < kt * kt; e += gridDim.x * blockDim.x) {
+        const int i = e / kt, j = e % kt;
+        T v = T(0);
+        if (i >= ks && j >= ks) v = G[(size_t)(i - ks) * kb + (j - ks)];
+        else if (i == j) v = lam;
+        if (i < kc && j < kc) v += CtC[(size_t)i * kc + j];
+        out[e] = v;
+    }
+}
+
 // out[kt, kt] = 0 except the [kb, kb] block at (ks, ks), which takes G  (sum_mat of BiTBi into the X block of the row's
 // system, collective.c:1704-1707)
 template <typename T>

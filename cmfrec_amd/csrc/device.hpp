@@ -332,6 +332,7 @@ struct DeviceInfo {
     DevBuf<real_t> cg_gfull, cg_rconst;   // block systems on the tiled CG kernels: weighted Gramian (k x k) and per-row constants
     DevBuf<real_t> tile_init;       // initial matrices of a Cholesky launch in tile-linear layout (chol_wave_kernels.hpp, tile_pack_kernel)
     DevBuf<int> row_counter;        // work counters of the dynamically scheduled row kernels (zeroed before each launch)
+    DevBuf<real_t> potrs_inv, potrs_tmp;   // launch_potrs_rows: L^-1 and M^-1 of the shared matrix; the product before it replaces the rows
     DevBuf<real_t> gemm_ws;         // partial products of the split-K GEMMs (session.hip, launch_gemm)
     // second stream + events for two row kernels that may overlap (heavy-row teams beside light-row teams); created on
     // first use, owned here
@@ -339,7 +340,7 @@ struct DeviceInfo {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     // third stream for the eigen-decomposition of the low-rank path (one workgroup, overlaps the row kernels of both other streams)
     hipStream_t eig_stream_ = nullptr;
-    hipEvent_t eig_ev = nullptr, eig_fork = nullptr;
+    hipEvent_t eig_fork = nullptr;
     rocblas_handle blas_eig = nullptr;      // own handle (own workspace) for library calls on the eigen-decomposition's stream
     rocblas_handle ensure_blas_eig()
     {
@@ -375,7 +376,6 @@ struct DeviceInfo {
     {
         if (blas) (void)rocblas_destroy_handle(blas);
         if (blas_eig) (void)rocblas_destroy_handle(blas_eig);
-        if (eig_ev) (void)hipEventDestroy(eig_ev);
         if (eig_fork) (void)hipEventDestroy(eig_fork);
         if (eig_stream_) (void)hipStreamDestroy(eig_stream_);
         if (fork_ev) (void)hipEventDestroy(fork_ev);

@@ -100,6 +100,41 @@ struct DenseNanSide {
     }
 };
 
+// NA_as_zero_U / NA_as_zero_I: a sparse side-information matrix whose absent entries are ZEROS is the dense matrix holding those
+// zeros, on every row of X (rows of X beyond the last row of the triplets are zero rows: the column means divide by all of
+// them).  The reference reaches the same numbers by other operations -- optimizeA Case 3 for C / D with the column means as a
+// rank-one correction (collective.c:8354-8386, common.c:3116-3205), the full w C^T C block plus a constant -w C^T colmeans on
+// every right-hand side (collective.c:1277-1457, :5790-5800, :5823-5836; block CG: :2292-2298) -- and agrees with the dense
+// route on the zero-filled matrix to 1e-15, closed form and CG, both models (tests/test_oracle_vs_ref.py).  So that is what the
+// fit runs: the triplets are scattered into a [rows of X, cols] matrix here and take the dense path, GEMMs and all.  Cost: rows x
+// cols numbers of host and device memory instead of the triplets.  More rows of side information than X has: refused (the
+// reference treats the rows beyond X differently from its dense branch, nothing pins them).
+struct ZeroFilledSide {
+    std::vector<real_t> dense;
+    // 0 ok, 1 triplets missing / out of range, 2 more rows than X
+    int build(int_t rows_x, int_t rows_side, int_t cols, const int_t *r, const int_t *c, const real_t *v, size_t nnz)
+    {
+        if (rows_side > rows_x) return 2;
+        if (!r || !c || !v || cols <= 0) return 1;
+        dense.assign((size_t)rows_x * (size_t)cols, (real_t)0);
+        for (size_t e = 0; e < nnz; e++) {
+            if (r[e] < 0 || r[e] >= rows_side || c[e] < 0 || c[e] >= cols) return 1;
+            dense[(size_t)r[e] * (size_t)cols + (size_t)c[e]] += v[e];
+        }
+        return 0;
+    }
+};
+// precomputedCtUbias of the reference's epilogue (collective.c:9244-9252, :10115-10123): -w C^T colmeans
+static void fill_CtUbias(real_t *out, const real_t *C, const real_t *colmeans, int_t p, int_t kc, real_t w)
+{
+    if (!out || !C || !colmeans) return;
+    for (int_t f = 0; f < kc; f++) {
+        double acc = 0;
+        for (int_t j = 0; j < p; j++) acc += (double)C[(size_t)j * kc + f] * (double)colmeans[j];
+        out[f] = (real_t)(-(double)w * acc);
+    }
+}
+
 // column means of sparse side information are reported like the reference does (common.c:4976-4990); the fit itself runs on
 // the values as given (the centred copy center_by_cols makes is not the one coo_to_csr_and_csc reads, collective.c:6541-6558)
 void sparse_colmeans(const int_t *col, const real_t *val, size_t nnz, int_t cols, real_t *means)
@@ -573,12 +608,24 @@ int_t fit_collective_implicit_als(
 {
 
     (void)nthreads;
-    (void)precomputedCtUbias;            // only written with sparse U + NA_as_zero_U (collective.c:10111), not supported
     // collective.c:9406-9435
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
     if (nnz == 0) return fail(verbose, "cmfrec_hip: the implicit model needs at least one entry of X.");
+    // sparse side information whose absent entries are zeros -> the dense route on the zero-filled matrix (ZeroFilledSide)
+    ZeroFilledSide zfU, zfI;
+    const bool naz_U = NA_as_zero_U && U == nullptr && nnz_U > 0, naz_I = NA_as_zero_I && II == nullptr && nnz_I > 0;
+    if (naz_U) {
+        const int e = zfU.build(m, m_u, p, U_row, U_col, U_sp, nnz_U);
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented." : "cmfrec_hip: U index out of range.");
+        U = zfU.dense.data(); m_u = m; nnz_U = 0; U_row = U_col = nullptr; U_sp = nullptr;
+    }
+    if (naz_I) {
+        const int e = zfI.build(n, n_i, q, I_row, I_col, I_sp, nnz_I);
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented." : "cmfrec_hip: I index out of range.");
+        II = zfI.dense.data(); n_i = n; nnz_I = 0; I_row = I_col = nullptr; I_sp = nullptr;
+    }
     // dense side information with NaN -> the sparse route on its centred present entries
     DenseNanSide nanU, nanI;
     const bool hadU = (U != nullptr);
@@ -601,7 +648,6 @@ int_t fit_collective_implicit_als(
         return fail(verbose, "cmfrec_hip: U has no present entries.");
     // side information: dense or sparse COO (missing = absent).  Sparse: rows within X.
     const bool spU = (U == nullptr && nnz_U > 0), spI = (II == nullptr && nnz_I > 0);
-    if (NA_as_zero_U || NA_as_zero_I) return fail(verbose, "cmfrec_hip: NA_as_zero_U / NA_as_zero_I are not implemented.");
     if ((spU && (m_u > m || !U_row || !U_col || !U_sp)) || (spI && (n_i > n || !I_row || !I_col || !I_sp)))
         return fail(verbose, "cmfrec_hip: sparse side information must be COO triplets with rows inside X.");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
@@ -714,6 +760,7 @@ int_t fit_collective_implicit_als(
             int rc2 = cmfrec_hip_session_precompute(s0, last_chol, 0, precomputedBtB, nullptr, hadU ? precomputedBeTBe : nullptr,
                                                     hadU ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
             if (rc2) rc_loop = rc2;
+            if (naz_U && !rc2) fill_CtUbias(precomputedCtUbias, C, U_colmeans, p, k_user + k, w_user);   // collective.c:9244-9252, :10115-10123
         }
         if (verbose && rc_loop == 0) printf("ALS procedure terminated successfully\n");
         return rc_loop;
@@ -750,6 +797,7 @@ int_t fit_collective_implicit_als(
         int rc2 = cmfrec_hip_session_precompute(s, last_chol, 0, precomputedBtB, nullptr, hadU ? precomputedBeTBe : nullptr,
                                                 hadU ? precomputedBeTBeChol : nullptr, nullptr, nullptr);
         if (rc2) rc_loop = rc2;
+        if (naz_U && !rc2) fill_CtUbias(precomputedCtUbias, C, U_colmeans, p, k_user + k, w_user);   // collective.c:9244-9252, :10115-10123
         if (verbose) printf("  done\n");
         tm.lap("precompute epilogue");
     }
@@ -779,13 +827,23 @@ int_t fit_collective_explicit_als(
     (void)max_cd_steps;
     (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // with add_implicit_features the prediction matrices are not produced here
-    (void)precomputedCtUbias;      // only with sparse U + NA_as_zero_U, not supported
     // collective.c:7308-7329
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
     if (k_item && II == nullptr && nnz_I == 0) return fail(verbose, "Cannot pass 'k_item' without I data.");
     if (k_main && Xfull == nullptr && nnz == 0) return fail(verbose, "Cannot pass 'k_main' without X data.");
-    if (NA_as_zero_U || NA_as_zero_I)
-        return fail(verbose, "cmfrec_hip: NA_as_zero_U / NA_as_zero_I are not implemented.");
+    // sparse side information whose absent entries are zeros -> the dense route on the zero-filled matrix (ZeroFilledSide)
+    ZeroFilledSide zfU, zfI;
+    const bool naz_U = NA_as_zero_U && U == nullptr && nnz_U > 0, naz_I = NA_as_zero_I && II == nullptr && nnz_I > 0;
+    if (naz_U) {
+        const int e = zfU.build(m, m_u, p, U_row, U_col, U_sp, nnz_U);
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented." : "cmfrec_hip: U index out of range.");
+        U = zfU.dense.data(); m_u = m; nnz_U = 0; U_row = U_col = nullptr; U_sp = nullptr;
+    }
+    if (naz_I) {
+        const int e = zfI.build(n, n_i, q, I_row, I_col, I_sp, nnz_I);
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented." : "cmfrec_hip: I index out of range.");
+        II = zfI.dense.data(); n_i = n; nnz_I = 0; I_row = I_col = nullptr; I_sp = nullptr;
+    }
     // Dense X: the rows of the present entries go through the same row kernels as a sparse X (a row's system is the sum over
     // its present entries either way: factors_closed_form, common.c:762-1075; factors_explicit_cg_dense, :1615-1749).  What the
     // reference's dense cases add is the CHOICE of solver (optimizeA Cases 1-2, common.c:2787-3116), followed here per
@@ -830,12 +888,24 @@ int_t fit_collective_explicit_als(
         }
         Xfull = nullptr;
     }
-    // NA_as_zero_X (sparse X whose absent entries are zeros): the plain explicit model -- every half-step is optimizeA
-    // Case 3 (common.c:3118-3205: one shared matrix, closed form whatever use_cg says)
-    if (NA_as_zero_X && (weight || U || II || nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
+    // NA_as_zero_X (sparse X whose absent entries are zeros): every half-step shares one matrix over its rows -- optimizeA Case 3
+    // without side information on that side (common.c:3118-3205: closed form whatever use_cg says), optimizeA_collective with
+    // the factorised shared block matrix (collective.c:5607-5617, :5700-5716) with dense complete side information
+    if (NA_as_zero_X && (weight || nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
                          precompute_for_predictions || (scale_bias_const && (scale_lam || scale_lam_sideinfo) && (user_bias || item_bias))))
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without side information, weights, implicit "
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without weights, sparse side information, implicit "
                              "features, nonneg / L1, scale_bias_const and without precompute_for_predictions.");
+    if (NA_as_zero_X && (U || II)) {
+        if (use_cg)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: the block CG on a missing-as-zero main matrix "
+                                 "(collective.c:2134-2903) is not implemented (use_cg=False is).");
+        if ((U && m_u != m) || (II && n_i != n))
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: U / I must have exactly the rows / columns of X.");
+        for (size_t e = 0; U && e < (size_t)m_u * (size_t)p; e++)
+            if (std::isnan(U[e])) return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: NaN in U is not implemented.");
+        for (size_t e = 0; II && e < (size_t)n_i * (size_t)q; e++)
+            if (std::isnan(II[e])) return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: NaN in I is not implemented.");
+    }
     // dense side information with NaN -> the sparse route on its centred present entries
     DenseNanSide nanU, nanI;
     const bool hadU = (U != nullptr);
@@ -1084,6 +1154,7 @@ int_t fit_collective_explicit_als(
                                                     hadU ? precomputedBeTBeChol : nullptr, hadU ? precomputedCtCw : nullptr,
                                                     hadU ? precomputedTransCtCinvCt : nullptr);
             if (rc2) rc_loop = rc2;
+            if (naz_U && !rc2) fill_CtUbias(precomputedCtUbias, C, U_colmeans, p, k_user + k, w_user);   // collective.c:9244-9252, :10115-10123
             if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
                 for (int_t c = 0; c < n_max; c++) {
                     memcpy(B_plus_bias + (size_t)c * (k_totB + 1), B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));
@@ -1195,6 +1266,7 @@ int_t fit_collective_explicit_als(
                                                 hadU ? precomputedBeTBeChol : nullptr, hadU ? precomputedCtCw : nullptr,
                                                 hadU ? precomputedTransCtCinvCt : nullptr);
         if (rc2) rc_loop = rc2;
+        if (naz_U && !rc2) fill_CtUbias(precomputedCtUbias, C, U_colmeans, p, k_user + k, w_user);   // collective.c:9244-9252, :10115-10123
         if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
             for (int_t c = 0; c < n_max; c++) {
                 memcpy(B_plus_bias + (size_t)c * (k_totB + 1), B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));

@@ -24,6 +24,9 @@ namespace cmfhip {
 constexpr int GK_NB = 17;                               // blocks of 16 unknowns
 constexpr int GK_NT = GK_NB * (GK_NB + 1) / 2;          // 153 tiles of the upper triangle, packed as tile_bi / tile_bj do
 constexpr int GK_PART = GK_NT * 256 + GK_NB * 16;       // elements of one work item's partial: the tiles, then the right-hand side
+#ifndef GK_OPEN_SLOTS
+#define GK_OPEN_SLOTS 32                                  // workgroup slots of the 2 x CUs a launch leaves to other streams: one per shader engine (session.hip; 24: no effect, 32-40: best, profiles/r04)
+#endif
 constexpr int GK_PD = 2;                                // k-steps of operands in flight (5 loads each; the counter tracks 63)
 
 // ORDER OF THE UNKNOWNS INSIDE THE TILES.  The operand register of block b holds, for lane l (l & 15 = position, l >> 4 = entry

@@ -302,6 +302,11 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 }
             }
             int ctr = 4, rc_all = 0;
+            // two persistent workgroups per CU fill the register file; a few slots stay open so that the small launches of
+            // another stream (the eigen-decomposition chain of the low-rank rows, EigCache) are dispatched beside a batch
+            // instead of behind it
+            const int gk_open = getenv("CMFREC_HIP_GK_OPEN") ? atoi(getenv("CMFREC_HIP_GK_OPEN")) : GK_OPEN_SLOTS;
+            const int gk_grid = std::max(2 * dev.num_cus - gk_open, dev.num_cus / 2);
             auto run_batch = [&](int item0, int item1, int row0, int row1) {
                 if (ctr + 2 > 60) ctr = 4;
                 real_t *part = X->chol_part.ptr;
@@ -313,7 +318,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 W.row_first = item0; W.nrows = item1; W.counter = dev.row_counter.ptr + ctr;
                 if (item1 > item0) {
                     poison_lds(dev.stream, dev.num_cus);
-                    hipLaunchKernelGGL(gramk_producer_kernel<real_t>, dim3(std::min(item1 - item0, 2 * dev.num_cus)), dim3(256), 0, dev.stream, W,
+                    hipLaunchKernelGGL(gramk_producer_kernel<real_t>, dim3(std::min(item1 - item0, gk_grid)), dim3(256), 0, dev.stream, W,
                                        X->desc.ptr, SL);
                     HIP_CHECK(hipGetLastError());
                 }
@@ -323,7 +328,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 H.gk_stride = (size_t)GK_PART; H.gk_init1 = init1; H.gk_init2 = init2;
                 if (row1 > row0) {
                     poison_lds(dev.stream, dev.num_cus);
-                    hipLaunchKernelGGL(gramk_consumer_kernel<real_t>, dim3(std::min(row1 - row0, 2 * dev.num_cus)), dim3(256), 0, dev.stream, H);
+                    hipLaunchKernelGGL(gramk_consumer_kernel<real_t>, dim3(std::min(row1 - row0, gk_grid)), dim3(256), 0, dev.stream, H);
                     HIP_CHECK(hipGetLastError());
                 }
                 ctr += 2;
@@ -436,36 +441,47 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
 // (launch_gemm: device.hpp)
 
 // X := X (R^T R)^-1 for the row-major [rows, k] block X (ld = ldx) and the row-major upper Cholesky factor R [k, k] of a
-// shared matrix: the multi-right-hand-side posv of optimizeA Case 3 (common.c:3171-3175) as two library triangular
-// solves.  In the library's column-major reading X is [k, rows] and R's memory is the lower factor L = R^T: L y = b, L^T x = y.
+// shared matrix: the multi-right-hand-side posv of optimizeA Case 3 (common.c:3171-3175).  Round 4: no library call -- the
+// inverse of the shared matrix once (L^-1 = R^-T by one workgroup, column per thread; M^-1 = L^-T L^-1 by the library's own
+// GEMM), then the rows times it as one tall GEMM on the matrix cores (rounds 1-3: two rocBLAS trsm over all rows).
 static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real_t *R, real_t *X, size_t ldx)
 {
     if (rows <= 0 || k <= 0) return;
-    rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
-    const real_t one = 1;
-#ifdef CMFREC_HIP_FLOAT
-    rocblas_status r1 = rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
-                                      k, rows, &one, R, k, X, (int)ldx);
-    rocblas_status r2 = rocblas_strsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
-                                      k, rows, &one, R, k, X, (int)ldx);
-#else
-    rocblas_status r1 = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
-                                      k, rows, &one, R, k, X, (int)ldx);
-    rocblas_status r2 = rocblas_dtrsm(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
-                                      k, rows, &one, R, k, X, (int)ldx);
-#endif
-    if (r1 != rocblas_status_success || r2 != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS trsm failed"; throw HipError{1}; }
+    DeviceInfo &d = const_cast<DeviceInfo &>(dev);
+    d.potrs_inv.alloc_at_least((size_t)2 * k * k);
+    d.potrs_tmp.alloc_at_least((size_t)rows * k);
+    real_t *Linv = d.potrs_inv.ptr, *Minv = d.potrs_inv.ptr + (size_t)k * k;
+    hipLaunchKernelGGL(trtri_from_upper_kernel<real_t>, dim3(1), dim3(256), 0, dev.stream, R, k, Linv);
+    HIP_CHECK(hipGetLastError());
+    launch_gemm<true>(dev, k, k, k, (real_t)1, Linv, (size_t)k, Linv, (size_t)k, Minv, (size_t)k);
+    launch_gemm<false>(dev, rows, k, k, (real_t)1, X, ldx, Minv, (size_t)k, d.potrs_tmp.ptr, (size_t)k);
+    HIP_CHECK(hipMemcpy2DAsync(X, ldx * sizeof(real_t), d.potrs_tmp.ptr, (size_t)k * sizeof(real_t), (size_t)k * sizeof(real_t), (size_t)rows,
+                               hipMemcpyDeviceToDevice, dev.stream));
 }
 
-// Low-rank row updates (lowrank_kernels.hpp): eigenvectors / values of w C^T C, rotated C and opposing factors, rotated
-// right-hand sides and solutions.
-struct LowRankScratch {
+// Eigenvectors / values of one side's shared matrix w C^T C.  The decomposition is a chain of some four thousand small
+// launches (rocSOLVER's tridiagonalisation is launch-bound: ~4.5 ms of host time, ~6 ms on an idle device at k = 256), so
+//  * inside a half-step it is enqueued BEHIND the launches of the rows that do not need it (the producer / consumer batches of
+//    the long rows), on the eigen stream, waiting only for an event recorded in front of them;
+//  * a half-step also enqueues the decomposition the NEXT half-step of the other side will ask for (`wanted`: that side took
+//    the low-rank path before), since C and D are final once their own updates have run (cmfrec's order C, D, B, A):
+//    `fresh` says the cached vectors belong to the side matrix as it stands; every update / upload of C or D clears it.
+struct EigCache {
     DevBuf<double> W, V, D, E;
     DevBuf<int> info;
-    DevBuf<real_t> Q, Qt, Lam, Ct, Bt, R, T;
+    DevBuf<real_t> Q, Qt, Lam, M;     // M: the matrix a prefetch decomposes (the half-step's own one lives in the session's ctc)
+    hipEvent_t ev = nullptr;          // recorded behind the chain on the eigen stream
+    bool fresh = false, wanted = false;
+    int kind = 0;                     // 1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel
+    int checked_kc = 0;               // dsyevd's info word has been read back for this matrix size (once per size and cache)
+    ~EigCache() { if (ev) (void)hipEventDestroy(ev); }
+};
+
+struct LowRankScratch {
+    DevBuf<real_t> Ct, Bt, R, T;
+    EigCache own;                 // callers without a cache per side (the stand-alone operator)
     int last_rows = 0;            // rows the low-rank kernels solved in the most recent launch (0: path not taken)
     int last_eig = 0;             // its eigen-decomposition: 1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel
-    int checked_kc = 0;           // dsyevd's info word has been read back for this matrix size (once per size and session)
 };
 
 // The symmetric eigen-decomposition of the k x k matrix w C^T C (once per half-step of the low-rank path) is a plain dense
@@ -509,14 +525,57 @@ __global__ void eig_unpack_kernel(const double *__restrict__ W, const double *__
     if (e < n) lam[e] = (T)fmax(D[e], 0.0);
 }
 
+// Enqueues the decomposition of the kc x kc matrix Minit on the eigen stream, behind `after` (an event of the main stream:
+// what produced Minit), and records E.ev behind it.
+static void issue_eig(DeviceInfo &d, EigCache &E, const real_t *Minit, int kc, hipEvent_t after)
+{
+    E.W.alloc_at_least((size_t)kc * kc); E.V.alloc_at_least((size_t)kc * kc);
+    E.Q.alloc_at_least((size_t)kc * kc); E.Qt.alloc_at_least((size_t)kc * kc); E.Lam.alloc_at_least((size_t)kc);
+    if (!E.ev) HIP_CHECK(hipEventCreateWithFlags(&E.ev, hipEventDisableTiming));
+    HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), after, 0));
+    const RocSolverApi &rs = rocsolver_api();
+    // CMFREC_HIP_EIG=jacobi (read at every launch: a test can set it per case) takes the built-in kernel
+    const char *eig_env = getenv("CMFREC_HIP_EIG");
+    static bool dsyevd_bad = false;       // the library reported a failed decomposition once: the built-in kernel from then on
+    bool done = false;
+    if (rs.dsyevd != nullptr && !dsyevd_bad && !(eig_env != nullptr && strcmp(eig_env, "jacobi") == 0)) {
+        E.D.alloc_at_least((size_t)kc); E.E.alloc_at_least((size_t)kc); E.info.alloc_at_least(1);
+        hipLaunchKernelGGL(eig_pack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), Minit, E.W.ptr, kc);
+        rocblas_handle he = d.ensure_blas_eig();
+        done = rs.dsyevd(he, 211 /* rocblas_evect_original (rocsolver-extra-types.h) */, rocblas_fill_upper, kc, E.W.ptr, kc, E.D.ptr, E.E.ptr, E.info.ptr) ==
+               rocblas_status_success;
+        if (done && E.checked_kc != kc) {
+            // the return status only covers the launch: the device-side `info` (off-diagonals that did not converge) is read
+            // back the first time a matrix of this size goes through the library in this cache
+            int h_info = 0;
+            HIP_CHECK(hipMemcpyAsync(&h_info, E.info.ptr, sizeof(int), hipMemcpyDeviceToHost, d.eig_stream()));
+            HIP_CHECK(hipStreamSynchronize(d.eig_stream()));
+            E.checked_kc = kc;
+            if (h_info != 0) { dsyevd_bad = true; done = false; }
+        }
+        if (done)
+            hipLaunchKernelGGL(eig_unpack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), E.W.ptr, E.D.ptr, kc, E.Q.ptr,
+                               E.Qt.ptr, E.Lam.ptr);
+    }
+    if (!done)
+        hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), Minit, kc, E.W.ptr, E.V.ptr, E.Q.ptr, E.Qt.ptr,
+                           (size_t)kc, E.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
+    E.kind = done ? 1 : 2;
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(E.ev, d.eig_stream()));
+}
+
 // Collective Cholesky half-step (mode CHOL_COLLECTIVE, dense side information on every row of the block) with the rows of
 // few entries solved by the low-rank update of a diagonalised shared matrix instead of a k_t^3 / 3 factorisation per row
 // (config 5's users: 20 entries against k_t = 257 unknowns).  c: the call as launch_chol would take it (right-hand sides
 // w U C already in the rows, c.Minit = w C^T C); Um: the block's rows of U; k: the factors shared with X; rows_b: rows of
 // the opposing matrix.  Returns -1 when the path does not apply (the caller launches as usual), else the return code.
 // CMFREC_HIP_LOWRANK=0 switches it off, =1 forces it whenever the shapes allow (tests).
+// mine: this side's cache (NULL: the scratch's own, never fresh); next / kc_next: the other side's cache with its matrix in
+// next->M, decomposed behind this one for the half-step that follows (NULL: nothing to prefetch).
 static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, CholCall c, const SparseShard &X, const real_t *Cm,
-                                     const real_t *Um, int p_self, real_t w, int k, int rows_b)
+                                     const real_t *Um, int p_self, real_t w, int k, int rows_b, EigCache *mine = nullptr,
+                                     EigCache *next = nullptr, int kc_next = 0)
 {
     const char *lr_env = getenv("CMFREC_HIP_LOWRANK");
     const int kt = c.kt, kc = c.kc, k_side_self = c.koff;
@@ -538,60 +597,41 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
     hipStream_t st = dev.stream;
     const int ngr = (kt + 15) / 16;
     const size_t ldbt = (size_t)16 * ngr;
-    S.W.alloc_at_least((size_t)kc * kc); S.V.alloc_at_least((size_t)kc * kc);
-    S.Q.alloc_at_least((size_t)kc * kc); S.Qt.alloc_at_least((size_t)kc * kc); S.Lam.alloc_at_least((size_t)kc);
     S.Ct.alloc_at_least((size_t)p_self * kc);
     S.Bt.alloc_at_least((size_t)rows_b * ldbt + 64);
     S.R.alloc_at_least((size_t)X.nrows * kc);
     S.T.alloc_at_least((size_t)n_light * kc);
-    // w C^T C = Q L Q^T: one workgroup on the auxiliary stream, beside the full factorisations of the longer rows (which do
-    // not need it)
+    EigCache &E = mine ? *mine : S.own;
+    if (mine) mine->wanted = true;
+    // w C^T C = Q L Q^T on the eigen stream, beside the full factorisations of the longer rows (which do not need it and are
+    // enqueued first: see EigCache)
     {
         DeviceInfo &d = const_cast<DeviceInfo &>(dev);
         d.ensure_aux();
-        if (!d.eig_ev) HIP_CHECK(hipEventCreateWithFlags(&d.eig_ev, hipEventDisableTiming));
-        if (!d.eig_fork) HIP_CHECK(hipEventCreateWithFlags(&d.eig_fork, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(d.eig_fork, st));
-        HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), d.eig_fork, 0));
-        const RocSolverApi &rs = rocsolver_api();
-        // CMFREC_HIP_EIG=jacobi (read at every launch: a test can set it per case) takes the built-in kernel
-        const char *eig_env = getenv("CMFREC_HIP_EIG");
-        static bool dsyevd_bad = false;       // the library reported a failed decomposition once: the built-in kernel from then on
-        bool done = false;
-        if (rs.dsyevd != nullptr && !dsyevd_bad && !(eig_env != nullptr && strcmp(eig_env, "jacobi") == 0)) {
-            S.D.alloc_at_least((size_t)kc); S.E.alloc_at_least((size_t)kc); S.info.alloc_at_least(1);
-            hipLaunchKernelGGL(eig_pack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), c.Minit, S.W.ptr, kc);
-            rocblas_handle he = d.ensure_blas_eig();
-            done = rs.dsyevd(he, 211 /* rocblas_evect_original (rocsolver-extra-types.h) */, rocblas_fill_upper, kc, S.W.ptr, kc, S.D.ptr, S.E.ptr, S.info.ptr) ==
-                   rocblas_status_success;
-            if (done && S.checked_kc != kc) {
-                // the return status only covers the launch: the device-side `info` (off-diagonals that did not converge) is read
-                // back the first time a matrix of this size goes through the library in this session
-                int h_info = 0;
-                HIP_CHECK(hipMemcpyAsync(&h_info, S.info.ptr, sizeof(int), hipMemcpyDeviceToHost, d.eig_stream()));
-                HIP_CHECK(hipStreamSynchronize(d.eig_stream()));
-                S.checked_kc = kc;
-                if (h_info != 0) { dsyevd_bad = true; done = false; }
-            }
-            if (done)
-                hipLaunchKernelGGL(eig_unpack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), S.W.ptr, S.D.ptr, kc, S.Q.ptr,
-                                   S.Qt.ptr, S.Lam.ptr);
+        const bool have = mine != nullptr && mine->fresh && mine->ev != nullptr;
+        const bool ahead = next != nullptr && kc_next > 0;
+        if (!have || ahead) {
+            if (!d.eig_fork) HIP_CHECK(hipEventCreateWithFlags(&d.eig_fork, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(d.eig_fork, st));
         }
-        if (!done)
-            hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), c.Minit, kc, S.W.ptr, S.V.ptr, S.Q.ptr, S.Qt.ptr,
-                               (size_t)kc, S.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
-        S.last_eig = done ? 1 : 2;
-        S.last_rows = n_light;
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipEventRecord(d.eig_ev, d.eig_stream()));
         c.row_limit = n_full;
         const int rc = (n_full > 0) ? launch_chol(dev, c, &X) : 0;
         if (rc) return rc;
-        HIP_CHECK(hipStreamWaitEvent(st, d.eig_ev, 0));
+        if (!have) {
+            issue_eig(d, E, c.Minit, kc, d.eig_fork);
+            if (mine) mine->fresh = true;          // (c.Minit is the session's w C^T C of this side as it stands)
+        }
+        if (ahead) {
+            issue_eig(d, *next, next->M.ptr, kc_next, d.eig_fork);
+            next->fresh = true;
+        }
+        S.last_eig = E.kind;
+        S.last_rows = n_light;
+        HIP_CHECK(hipStreamWaitEvent(st, E.ev, 0));
     }
     // C~ = C Q ;  B~ = [B(:, :k) Q(k_side:, :) | B(:, k:)] ;  R = w U C~ (natural row order)
-    launch_gemm<false>(dev, p_self, kc, kc, (real_t)1, Cm, (size_t)kc, S.Q.ptr, (size_t)kc, S.Ct.ptr, (size_t)kc);
-    launch_gemm<false>(dev, rows_b, kc, k, (real_t)1, c.B, c.ldb, S.Q.ptr + (size_t)k_side_self * kc, (size_t)kc, S.Bt.ptr, ldbt);
+    launch_gemm<false>(dev, p_self, kc, kc, (real_t)1, Cm, (size_t)kc, E.Q.ptr, (size_t)kc, S.Ct.ptr, (size_t)kc);
+    launch_gemm<false>(dev, rows_b, kc, k, (real_t)1, c.B, c.ldb, E.Q.ptr + (size_t)k_side_self * kc, (size_t)kc, S.Bt.ptr, ldbt);
     if (kt > kc)
         hipLaunchKernelGGL(copy_cols_kernel<real_t>, grid1d((size_t)rows_b * (kt - kc)), dim3(256), 0, st, S.Bt.ptr, ldbt, kc, c.B, c.ldb, k,
                            kt - kc, (size_t)rows_b);
@@ -599,7 +639,7 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
     LrParams<real_t> L;
     L.A = c.A; L.lda = c.lda; L.pre = S.R.ptr; L.ldpre = (size_t)kc;
     L.Tc = S.T.ptr; L.ldt = (size_t)kc; L.pos0 = n_full;
-    L.Bt = S.Bt.ptr; L.ldbt = ldbt; L.lam_eig = S.Lam.ptr;
+    L.Bt = S.Bt.ptr; L.ldbt = ldbt; L.lam_eig = E.Lam.ptr;
     L.kt = kt; L.kc = kc; L.koff = k_side_self; L.rotated = 1;
     L.indptr = X.p.ptr; L.indices = X.i.ptr; L.values = X.v.ptr; L.bias_sub = c.bias_sub;
     L.lam = c.lam; L.lam_last = c.lam_last;
@@ -633,7 +673,7 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
 #endif
     HIP_CHECK(hipGetLastError());
     // x[:kc] = Q x~[:kc]: one GEMM over the light rows (in processing order), then back to their rows
-    launch_gemm<false>(dev, n_light, kc, kc, (real_t)1, S.T.ptr, (size_t)kc, S.Qt.ptr, (size_t)kc, S.R.ptr, (size_t)kc);
+    launch_gemm<false>(dev, n_light, kc, kc, (real_t)1, S.T.ptr, (size_t)kc, E.Qt.ptr, (size_t)kc, S.R.ptr, (size_t)kc);
     hipLaunchKernelGGL(scatter_rows_kernel<real_t>, grid1d((size_t)n_light * kc), dim3(256), 0, st, c.A, c.lda, X.desc.ptr, n_full, S.R.ptr,
                        (size_t)kc, kc, (size_t)n_light);
     HIP_CHECK(hipGetLastError());
@@ -691,7 +731,7 @@ struct cmfrec_hip_session {
     // -sum over all opposing rows of (their bias + naz_mean) x row on every right-hand side (collective.c:8573-8600, :8756-8787)
     bool naz_X = false, naz_center = false;
     real_t naz_mean = 0;
-    DevBuf<real_t> naz_part, naz_vec;
+    DevBuf<real_t> naz_part, naz_vec, naz_M, naz_rhs;
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
@@ -702,6 +742,7 @@ struct cmfrec_hip_session {
     // low-rank row updates (lowrank_kernels.hpp): eigenvectors / values of w C^T C, rotated C and opposing factors,
     // rotated right-hand sides and solutions
     LowRankScratch lr;
+    EigCache eigA, eigB;          // eigenvectors of w_user C^T C (A-steps) / w_item D^T D (B-steps), see EigCache
     // row-block shards of the explicit / collective model (distributed.py): U / I hold only the rows of this
     // rank's block, and the C / D update is split into partial sums over the local rows (side_part: [kc x kc | p x kc]),
     // an all-reduce by the caller, and the identical small solve on every rank
@@ -1073,6 +1114,7 @@ int cmfrec_hip_session_set_factors(cmfrec_hip_session *s, const real_t *A, const
         HIP_CHECK(hipSetDevice(s->dev.device));
         const cmfrec_hip_model &m = s->mdl;
         hipStream_t st = s->dev.stream;
+        s->eigA.fresh = false; s->eigB.fresh = false;
         upload_padded(s, A, m.m, s->k_totA, s->A.ptr, s->ldA);
         upload_padded(s, B, m.n, s->k_totB, s->B.ptr, s->ldB);
         if (s->has_bias) {
@@ -1189,6 +1231,7 @@ int cmfrec_hip_session_sideinfo_finish(cmfrec_hip_session *s, int which)
         const int rows_u = isC ? m.m_u : m.n_i;
         const int kc = (isC ? m.k_user : m.k_item) + m.k;
         real_t *Cm = isC ? s->C.ptr : s->D.ptr;
+        (isC ? s->eigA : s->eigB).fresh = false;
         const real_t w = isC ? m.w_user : m.w_item;
         const bool scale_lam = m.scale_lam || m.scale_lam_sideinfo;
         const real_t lam = s->lam6[isC ? 4 : 5] / w;                                               // collective.c:8367, :8418
@@ -1394,64 +1437,109 @@ static bool launch_gsum(cmfrec_hip_session *s, bool isA, const SparseShard &X, c
     return true;
 }
 
-// One half-step of the explicit model with the main matrix missing-as-zero (see cmfrec_hip_session::naz_X)
-static int update_factor_naz(cmfrec_hip_session *s, bool isA)
+// One half-step of the explicit model with the main matrix missing-as-zero (see cmfrec_hip_session::naz_X).
+// Without side information on this side: optimizeA Case 3 (common.c:3116-3205).  With dense, complete side information that
+// covers exactly the rows of X: optimizeA_collective with bufferBeTBeChol (collective.c:5566-5968, :5607-5617) -- every row
+// shares  blockdiag(0, B^T B) + w C^T C + lam mult I  (mult = n + p | n | 1, :4787-4799, :5700-5716), right-hand sides
+// X B + w U C + the bias / mean constant on the columns behind k_user (:5753-5770, :5815-5821), one factorisation (:5715) and
+// the substitutions of collective_closed_form_block's first branch (:1364-1460).
+static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
 {
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
-    if (m.p > 0 || m.q > 0 || s->implicit_feats || s->scale_bias_const || dev.nonneg_now || dev.l1_now != (real_t)0 ||
+    const int p_self = isA ? m.p : m.q;
+    const int rows_u = isA ? m.m_u : m.n_i;
+    const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
+    if (s->implicit_feats || s->scale_bias_const || dev.nonneg_now || dev.l1_now != (real_t)0 ||
         dev.l1_last_now != (real_t)0 || m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n ||
-        s->Xr.weighted() || m.k_user != 0 || m.k_item != 0) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X: only the plain explicit model on one device (no side information, weights, "
-                       "implicit features, nonneg / L1, scale_bias_const)";
+        s->Xr.weighted() || s->sparseU || s->sparseI || s->side_local) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X: the explicit model on one device without weights, implicit features, nonneg / L1, "
+                       "scale_bias_const, sparse or incomplete side information";
+        return 2;
+    }
+    if (p_self > 0 && (rows_u != rows_self || !chol)) {
+        // (m > m_u takes optimizeA Case 3 for the rows beyond in the reference -- its build corrupts the heap there, so nothing
+        //  pins that branch; the block CG with a missing-as-zero main matrix, collective.c:2134-2903, is not built)
+        g_last_error = "cmfrec_hip: NA_as_zero_X with side information: closed form only (use_cg = false), side information on "
+                       "exactly the rows / columns of X";
+        return 2;
+    }
+    if (p_self == 0 && (isA ? m.k_user : m.k_item) != 0) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X: k_user / k_item without side information on that side";
         return 2;
     }
     real_t *self = isA ? s->A.ptr : s->B.ptr;
     real_t *opp = isA ? s->B.ptr : s->A.ptr;
     const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
-    const int rows_opp = isA ? m.n : m.m, rows_self = isA ? m.m : m.n;
+    const int k_side_self = isA ? m.k_user : m.k_item, k_side_opp = isA ? m.k_item : m.k_user;
     const SparseShard &X = isA ? s->Xr : s->Xc;
     const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
     const real_t lam_self = s->lam6[isA ? 2 : 3];
     const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
-    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0);
+    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0), kc = k_side_self + m.k, kt = k_side_self + ks;
+    const real_t *oppx = opp + k_side_opp;                        // the columns X refers to
     if (self_bias) {                          // the opposing bias column is fixed to 1 (collective.c:8538-8543, :8728-8732)
         hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA,
                            (real_t)1);
     }
-    // shared matrix: opp^T opp + diag(lam .. lam, lam_last), x rows_opp under scale_lam (common.c:3128-3138)
-    const real_t mult = (m.scale_lam || m.scale_lam_sideinfo) ? (real_t)rows_opp : (real_t)1;
-    launch_gram(dev, s->gws, opp, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, lam_self * mult);
+    // shared matrix: opp^T opp + diag(lam .. lam, lam_last), x rows_opp (+ p with side information on this side under
+    // scale_lam_sideinfo) under scale_lam (common.c:3128-3138; collective.c:4787-4799)
+    const real_t mult = (p_self > 0 && m.scale_lam_sideinfo) ? (real_t)(rows_opp + p_self)
+                        : ((m.scale_lam || m.scale_lam_sideinfo) ? (real_t)rows_opp : (real_t)1);
+    launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, lam_self * mult);
     if (lam_last_self != lam_self)
         hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3(1), dim3(64), 0, st, s->gram.ptr, ks, ks - 1, ks, (lam_last_self - lam_self) * mult);
-    // right-hand sides: sum_j x_j opp_j over the row's entries (tgemm_sp_dense, :3145-3151) ...
-    HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)ks * sizeof(real_t), (size_t)rows_self, st));
-    CholCall c{self, ld_self, opp, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
+    real_t *Msh = s->gram.ptr;                // the matrix the rows share, [kt, kt]
+    real_t *rhs_x = self;                     // where the row kernel leaves sum_j x_j opp_j: [rows, ks], ld
+    size_t ld_rhs = ld_self;
+    if (p_self > 0) {
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const real_t w = isA ? m.w_user : m.w_item;
+        launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);            // :5658-5668
+        s->naz_M.alloc_at_least((size_t)kt * kt);
+        hipLaunchKernelGGL(naz_block_matrix_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, st, s->gram.ptr, ks, s->ctc.ptr, kc, k_side_self,
+                           lam_self * mult, s->naz_M.ptr);
+        Msh = s->naz_M.ptr;
+        s->naz_rhs.alloc_at_least((size_t)rows_self * ks);
+        rhs_x = s->naz_rhs.ptr; ld_rhs = (size_t)ks;
+    }
+    // right-hand sides: sum_j x_j opp_j over the row's entries (tgemm_sp_dense, :3145-3151 / :5753-5762) ...
+    HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
+    if (p_self > 0) HIP_CHECK(hipMemsetAsync(rhs_x, 0, (size_t)rows_self * ks * sizeof(real_t), st));
+    CholCall c{rhs_x, ld_rhs, oppx, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
     c.rhs_only = true;
     int rc = launch_chol(dev, c, &X);
     if (rc) return rc;
-    // ... plus the constant of the opposing biases and the mean (:3152-3157)
+    if (p_self > 0) {
+        // ... w U C on the first k_side + k columns, the gathered part behind k_side
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+        launch_gemm<false>(dev, rows_self, kc, p_self, isA ? m.w_user : m.w_item, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
+        hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self, ld_self, k_side_self, rhs_x, ks,
+                           (real_t)1, (size_t)rows_self);
+    }
+    // ... plus the constant of the opposing biases and the mean (:3152-3157 / :5815-5821)
     if (opp_bias || s->naz_center) {
         const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
         s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
         const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
-        hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, opp, ld_opp, rows_opp, ks, bias,
+        hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, oppx, ld_opp, rows_opp, ks, bias,
                            s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
         hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
-        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self, ld_self, (size_t)rows_self, ks,
+        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self + k_side_self, ld_self, (size_t)rows_self, ks,
                            s->naz_vec.ptr);
     }
-    // one factorisation, all rows (with and without entries) through the triangular solves (:3171-3175)
-    hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, st, s->gram.ptr, ks);
+    // one factorisation, all rows (with and without entries) through the triangular solves (:3171-3175 / :5715, :1455-1458)
+    hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, st, Msh, kt);
     HIP_CHECK(hipGetLastError());
-    launch_potrs_rows(dev, rows_self, ks, s->gram.ptr, self, ld_self);
+    launch_potrs_rows(dev, rows_self, kt, Msh, self, ld_self);
     return 0;
 }
 
 static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = -1)
 {
-    if (s->naz_X && !s->mdl.implicit) return update_factor_naz(s, isA);
+    if (s->naz_X && !s->mdl.implicit) return update_factor_naz(s, isA, chol);
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
@@ -1676,7 +1764,19 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         add_implicit_term(c);
         // rows with few entries against many unknowns: low-rank path (lowrank_kernels.hpp)
         if (Fi == nullptr && !sbc && local_u_main == X.nrows && part < 0) {
-            const int rc_lr = launch_collective_lowrank(dev, s->lr, c, X, Cm, Um + (size_t)(s->side_local ? 0 : begin) * p_self, p_self, w, m.k, isA ? m.n : m.m);
+            // the other side's w D^T D, if its next half-step will want the eigenvectors and they are not there yet: decomposed
+            // behind this side's (EigCache)
+            EigCache *mine = isA ? &s->eigA : &s->eigB, *next = isA ? &s->eigB : &s->eigA;
+            const int p_next = isA ? m.q : m.p, kc_next = (isA ? m.k_item : m.k_user) + m.k;
+            if (next->wanted && !next->fresh && p_next > 0 && !(isA ? s->sparseI : s->sparseU)) {
+                next->M.alloc_at_least((size_t)kc_next * kc_next);
+                launch_gram(dev, s->gws, isA ? s->D.ptr : s->C.ptr, (size_t)kc_next, p_next, kc_next, next->M.ptr, isA ? m.w_item : m.w_user,
+                            (real_t)0);
+            } else {
+                next = nullptr;
+            }
+            const int rc_lr = launch_collective_lowrank(dev, s->lr, c, X, Cm, Um + (size_t)(s->side_local ? 0 : begin) * p_self, p_self, w, m.k,
+                                                        isA ? m.n : m.m, mine, next, kc_next);
             if (rc_lr >= 0) return rc_lr;
         }
         int rc = launch_chol(dev, c, &X);
@@ -1760,6 +1860,7 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol)
     const DeviceInfo &dev = s->dev;
     const int p = isC ? m.p : m.q;
     if (p <= 0) return 0;
+    (isC ? s->eigA : s->eigB).fresh = false;
     const int rows_u = isC ? m.m_u : m.n_i;
     const int kc = (isC ? m.k_user : m.k_item) + m.k;
     real_t *Cm = isC ? s->C.ptr : s->D.ptr;
@@ -2011,8 +2112,9 @@ void *cmfrec_hip_session_device_ptr(cmfrec_hip_session *s, int which, size_t *ro
     switch (which) {
         case 'A': if (rows) *rows = s->mdl.m; if (ld) *ld = s->ldA; return s->A.ptr;
         case 'B': if (rows) *rows = s->mdl.n; if (ld) *ld = s->ldB; return s->B.ptr;
-        case 'C': if (rows) *rows = s->mdl.p; if (ld) *ld = s->mdl.k_user + s->mdl.k; return s->C.ptr;
-        case 'D': if (rows) *rows = s->mdl.q; if (ld) *ld = s->mdl.k_item + s->mdl.k; return s->D.ptr;
+        // (whoever asks for C / D may write to it: the cached eigenvectors are not trusted afterwards)
+        case 'C': if (rows) *rows = s->mdl.p; if (ld) *ld = s->mdl.k_user + s->mdl.k; s->eigA.fresh = false; return s->C.ptr;
+        case 'D': if (rows) *rows = s->mdl.q; if (ld) *ld = s->mdl.k_item + s->mdl.k; s->eigB.fresh = false; return s->D.ptr;
         case 'a': if (rows) *rows = s->mdl.m; if (ld) *ld = 1; return s->biasA.ptr;
         case 'b': if (rows) *rows = s->mdl.n; if (ld) *ld = 1; return s->biasB.ptr;
         case 'P': if (rows) *rows = s->side_part.n; if (ld) *ld = 1; return s->side_part.ptr;   // partial sums of the C / D update

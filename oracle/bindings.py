@@ -686,8 +686,9 @@ class Reference:
                                     k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0, w_item=1.0,
                                     precompute=False, m=None, n=None, U_coo=None, I_coo=None, nonneg=False,
                                     nonneg_C=False, nonneg_D=False, max_cd_steps=100, l1_lam=0.0, lam_unique=None,
-                                    l1_lam_unique=None, adjust_weight=False):
-        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II."""
+                                    l1_lam_unique=None, adjust_weight=False, NA_as_zero_U=False, NA_as_zero_I=False):
+        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II (NA_as_zero_U / _I: its
+        absent entries are zeros instead of missing)."""
         m = A.shape[0] if m is None else m; n = B.shape[0] if n is None else n       # shape of X (A, B may have more rows)
         lam6 = None if lam_unique is None else np.ascontiguousarray(lam_unique, self.dtype)
         l16 = None if l1_lam_unique is None else np.ascontiguousarray(l1_lam_unique, self.dtype)
@@ -713,7 +714,7 @@ class Reference:
             self._r(lam), _ptr(lam6), self._r(l1_lam), _ptr(l16),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],
-            C.c_bool(False), C.c_bool(False), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
+            C.c_bool(NA_as_zero_U), C.c_bool(NA_as_zero_I), C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             self._r(w_main), self._r(w_user), self._r(w_item), _ptr(wmm),
             self._r(alpha), C.c_bool(adjust_weight), C.c_bool(apply_log_transf),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),
@@ -734,8 +735,9 @@ class Reference:
                                     U_coo=None, I_coo=None, nonneg=False, nonneg_C=False, nonneg_D=False, max_cd_steps=100,
                                     l1_lam=0.0, add_implicit_features=False, w_implicit=1.0, w_main=1.0, lam_unique=None,
                                     l1_lam_unique=None, scale_bias_const=False, weight=None, NA_as_zero_X=False, Xfull=None,
-                                    center_U=True, center_I=True):
-        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II.
+                                    center_U=True, center_I=True, NA_as_zero_U=False, NA_as_zero_I=False):
+        """U_coo / I_coo = (row, col, val, rows, cols): sparse side information instead of dense U / II (NA_as_zero_U / _I:
+        its absent entries are zeros instead of missing).
         center_U / center_I = False: no column means are handed over, the reference then uses U / II as given.
         weight: observation weights, one per entry of X.  Xfull: dense X [m, n] with NaN for the missing entries instead
         of the triplet (row / col / val are then ignored; weight, if given, is [m, n] too)."""
@@ -783,7 +785,7 @@ class Reference:
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), _ptr(sbA), _ptr(sbB),
             _ptr(U), C.c_int(m_u), C.c_int(p), _ptr(II), C.c_int(n_i), C.c_int(q),
             *su[:4], *si[:4],
-            C.c_bool(NA_as_zero_X), C.c_bool(False), C.c_bool(False),
+            C.c_bool(NA_as_zero_X), C.c_bool(NA_as_zero_U), C.c_bool(NA_as_zero_I),
             C.c_int(k_main), C.c_int(k_user), C.c_int(k_item),
             self._r(w_main), self._r(w_user), self._r(w_item), self._r(w_implicit),
             C.c_int(niter), C.c_int(nthreads), C.c_bool(False), C.c_bool(False),

@@ -1202,6 +1202,56 @@ void oracle_initialize_biases_twosided(int_t m, int_t n,
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* optimizeA_collective with the main matrix missing-as-zero and dense, complete side information, closed form
+ * (collective.c:5566-5968 with bufferBeTBeChol, :5607-5617): every row with side information shares ONE matrix
+ *     blockdiag(0, B^T B) + w C^T C (upper-left block) + lam mult I,   mult = n + p | n | 1   (:4787-4799, :5700-5716)
+ * factorised once (:5715); right-hand sides  X B (tgemm_sp_dense, :5753-5762)  +  w U C (gemm with beta 1, :5764-5770)
+ * +  bias_BtX on the k + k_main columns behind k_user (:5815-5821); rows go through the tpotrs branch of
+ * collective_closed_form_block (:1364-1460).  Rows of X beyond the side information (m > m_u, :4832-4908): optimizeA Case 3
+ * on the columns behind k_user, lam x n under scale_lam; their first k_user entries stay zero (:4817-4822). */
+static void collective_naz_chol(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
+                                int_t m, int_t m_u, int_t n, int_t p, int_t k, int_t k_main, int_t k_user, int_t k_item,
+                                const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *U,
+                                real_t lam, real_t w_user, real_t lam_last, bool scale_lam, bool scale_lam_sideinfo,
+                                const real_t *bias_BtX, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (m_u > m) m_u = m;
+    const int_t kt = k_user + k + k_main, kc = k_user + k, kb = k + k_main;
+    for (int_t r = 0; r < m; r++) memset(A + (size_t)r * lda, 0, (size_t)kt * sizeof(real_t));   /* :4817-4822 */
+    const real_t mult = scale_lam_sideinfo ? (real_t)(n + p) : (scale_lam ? (real_t)n : (real_t)1);
+    real_t *M = (real_t *)calloc((size_t)kt * kt, sizeof(real_t));
+    real_t *BtB = (real_t *)malloc((size_t)kb * kb * sizeof(real_t)), *CtC = (real_t *)malloc((size_t)kc * kc * sizeof(real_t));
+    oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
+    oracle_gram(C, (size_t)kc, p, kc, CtC, nthreads);
+    for (int_t i = 0; i < kc; i++) for (int_t j = 0; j < kc; j++) M[(size_t)i * kt + j] = w_user * CtC[(size_t)i * kc + j];
+    for (int_t i = 0; i < kb; i++) for (int_t j = 0; j < kb; j++) M[(size_t)(k_user + i) * kt + (k_user + j)] += BtB[(size_t)i * kb + j];
+    for (int_t i = 0; i < kt - 1; i++) M[(size_t)i * kt + i] += lam * mult;
+    M[(size_t)(kt - 1) * kt + (kt - 1)] += lam_last * mult;
+    const int bad = chol_upper_(kt, M, kt);
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m_u; ix++) {
+        real_t *a = A + (size_t)ix * lda;
+        for (size_t jx = Xcsr_p[ix]; jx < Xcsr_p[(size_t)ix + 1]; jx++)
+            axpy_(kb, Xcsr[jx], B + k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+        for (int_t c = 0; c < kc; c++) {
+            double acc = 0;
+            for (int_t j = 0; j < p; j++) acc += (double)U[(size_t)ix * p + j] * (double)C[(size_t)j * kc + c];
+            a[c] += w_user * (real_t)acc;
+        }
+        if (bias_BtX != NULL) axpy_(kb, (real_t)1, bias_BtX, a + k_user);
+        if (!bad) chol_solve_upper_(kt, M, kt, a);
+        else for (int_t c = 0; c < kt; c++) a[c] = NAN;
+    }
+    free(M); free(BtB); free(CtC);
+    if (m > m_u) {
+        oracle_set_naz_bias_BtX(bias_BtX);
+        oracle_optimizeA_naz(A + k_user + (size_t)m_u * lda, lda, B + k_item, ldb, m - m_u, n, kb, Xcsr_p + m_u, Xcsr_i, Xcsr,
+                             lam, lam_last, scale_lam || scale_lam_sideinfo, nthreads);
+    }
+}
+
 /* column means + centering of a dense side-info matrix, common.c:4911-4997 (dense, no NaN) */
 static real_t *center_by_cols_dense(const real_t *U, int_t m_u, int_t p, real_t *colmeans)
 {
@@ -1357,7 +1407,10 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     g_fit_weight = NULL;
     const bool naz = g_fit_naz;
     g_fit_naz = false;
-    if (naz && (U != NULL || II != NULL || (Ai != NULL && Bi != NULL) || weight != NULL || g_scale_bias_const)) return 2;
+    /* missing-as-zero with side information: dense complete U / I, closed form, side information on exactly the rows / columns of X
+     * (with fewer the reference's own build corrupts its heap, so nothing pins the m > m_u branch restated in collective_naz_chol) */
+    if (naz && ((Ai != NULL && Bi != NULL) || weight != NULL || g_scale_bias_const)) return 2;
+    if (naz && (U != NULL || II != NULL) && (use_cg || g_nn_AB || g_l1_base != 0 || g_has_l16 || (U != NULL && m_u != m) || (II != NULL && n_i != n))) return 2;
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
@@ -1526,6 +1579,18 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
             oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
+        else if (II != NULL && naz) {                                          /* :8573-8600 + :8612 with NA_as_zero_X */
+            const int_t ks = k + k_main + (int_t)item_bias;
+            real_t *btx = NULL;
+            if (user_bias || center) {
+                btx = (real_t *)calloc((size_t)ks, sizeof(real_t));
+                for (int_t r = 0; r < m; r++)
+                    axpy_(ks, -((user_bias ? biasA[r] : (real_t)0) + (center ? *glob_mean : (real_t)0)), A_bias + k_user + (size_t)r * ldA, btx);
+            }
+            collective_naz_chol(B_bias, ldB, A_bias, ldA, D, n_x, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
+                                csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, btx, nthreads);
+            free(btx);
+        }
         else if (II != NULL || imp)                                            /* :8612 */
             collective_chol_impl(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q,
                                              k, k_main + (int_t)item_bias, k_item, k_user,
@@ -1571,6 +1636,18 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
             oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                            csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
+        else if (U != NULL && naz) {                                           /* :8756-8787 + :8783 with NA_as_zero_X */
+            const int_t ks = k + k_main + (int_t)user_bias;
+            real_t *btx = NULL;
+            if (item_bias || center) {
+                btx = (real_t *)calloc((size_t)ks, sizeof(real_t));
+                for (int_t c = 0; c < n; c++)
+                    axpy_(ks, -((item_bias ? biasB[c] : (real_t)0) + (center ? *glob_mean : (real_t)0)), B_bias + k_item + (size_t)c * ldB, btx);
+            }
+            collective_naz_chol(A_bias, ldA, B_bias, ldB, C, m_x, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
+                                csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, btx, nthreads);
+            free(btx);
+        }
         else if (U != NULL || imp)                                             /* :8783 */
             collective_chol_impl(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p,
                                              k, k_main + (int_t)user_bias, k_user, k_item,

@@ -307,6 +307,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g19_dense_X_" + tag, **out)
 
+        # ---- G20: NA_as_zero_X together with dense side information (shared block matrix, collective.c:5607-5617) ----
+        out = {}
+        d = gc.naz_problem(dt)
+        for ci, (name, sides, opts) in enumerate(gc.NAZ_SIDE_CASES):
+            r = gc.naz_side_reference(R, d, sides, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g20_na_as_zero_sideinfo_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -917,6 +917,93 @@ def naz_hip(d, opts, dtype, NA_as_zero=True):
     return out
 
 
+# ---- NA_as_zero for the main matrix together with dense side information (optimizeA_collective with the factorised shared
+# block matrix, collective.c:5566-5968 / :5607-5617, :5700-5716) ---------------------------------------------------------------
+# (name, which sides carry side information, options).  Closed form only (the block CG on a missing-as-zero main matrix is not
+# built); side information on exactly the rows / columns of X (the reference's own build corrupts its heap with fewer).
+NAZ_SIDE_CASES = [
+    ("both sides, biases", "UI", dict()),
+    ("both sides, scale_lam", "UI", dict(scale_lam=True)),
+    ("both sides, scale_lam_sideinfo", "UI", dict(scale_lam_sideinfo=True)),
+    ("k_user / k_item / k_main, weights of the sides, user bias", "UI", dict(center=False, item_bias=False, k_user=2, k_item=1, k_main=2,
+                                                                               w_user=0.7, w_item=1.3)),
+    ("no biases, no centring", "UI", dict(user_bias=False, item_bias=False, center=False)),
+    ("user side only", "U", dict()),
+    ("item side only, scale_lam", "I", dict(scale_lam=True)),
+    ("per-matrix lambdas", "UI", dict(lam_unique=LAM6)),
+    ("seeded, both biases", "UI", dict(scale_lam=True, seed=5)),
+]
+
+
+def _naz_side(d, sides):
+    return (d["U"] if "U" in sides else None), (d["I"] if "I" in sides else None)
+
+
+def naz_side_reference(R, d, sides, opts, nthreads=2):
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    A0, B0 = _impf_start(d, o)
+    U, II = _naz_side(d, sides)
+    kw = dict(U=U, II=II, lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=False, **o)
+    if seed is not None:
+        A0[:] = 0; B0[:] = 0
+        r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], reset_values=True, seed=seed, **kw)
+    else:
+        r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), **kw)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if U is not None: out["C"] = r["C"]
+    if II is not None: out["D"] = r["D"]
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_side_oracle(O, d, sides, opts, nthreads=2):
+    """None for the seeded cases (the oracle has no random start)."""
+    o = dict(opts)
+    if "seed" in o:
+        return None
+    lam6 = o.pop("lam_unique", None)
+    if lam6 is not None:
+        O.set_lam_unique(np.asarray(lam6, np.float64), None)
+    U, II = _naz_side(d, sides)
+    try:
+        A0, B0 = _impf_start(d, o)
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), U=U, II=II,
+                               lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=False, **o)
+    finally:
+        O.set_lam_unique(None, None)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if U is not None: out["C"] = r["C"]
+    if II is not None: out["D"] = r["D"]
+    if opts.get("user_bias", True): out["biasA"] = r["biasA"]
+    if opts.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_side_hip(d, sides, opts, dtype, **ctor):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    seed = o.pop("seed", None)
+    o["lambda_"] = o.pop("lam_unique") if "lam_unique" in o else 0.3
+    A0, B0 = _impf_start(d, o)
+    U, II = _naz_side(d, sides)
+    args = dict(k=d["k"], niter=3, use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=True, use_cg=False, nthreads=1)
+    args.update(dict(random_state=seed) if seed is not None else {})
+    args.update(o); args.update(ctor)
+    mdl = CMF(**args)
+    start = {} if seed is not None else dict(A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), **start)
+    out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
+    if U is not None: out["C"] = mdl.C_
+    if II is not None: out["D"] = mdl.D_
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- dense X (NaN = missing): optimizeA Cases 1-2, common.c:2787-3116 ------------------------------------------------
 def dense_problem(dtype, variant, seed=131):
     """variant: 'full' no missing entry; 'near' 13 % of the rows and 10 % of the columns have missing entries (both half-steps

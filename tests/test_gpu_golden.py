@@ -317,6 +317,31 @@ def test_NA_as_zero_X(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_sideinfo(oracles, dtype):
+    """G20 through the estimator (CMF(NA_as_zero=True).fit(X, U=, I=)): the half-steps with dense side information share one
+    block matrix (blockdiag(0, B^T B) + w C^T C + lam mult I, mult = n + p | n | 1), factorised once; right-hand sides
+    X B + w U C + the constant of the opposing biases and the mean; k_user / k_item / k_main, per-matrix lambdas, the reference's
+    seeded start."""
+    g = gc.load("g20_na_as_zero_sideinfo", dtype)
+    d = gc.naz_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, sides, opts) in enumerate(gc.NAZ_SIDE_CASES):
+        got = gc.naz_side_hip(d, sides, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        ref = gc.naz_side_oracle(oracles[dtype], d, sides, opts)
+        if ref is not None:
+            assert gc.compare_fits(got, ref) < tol, name
+    # the side information changes the model, and the combinations that are not built are refused
+    assert gc.compare_fits(gc.naz_side_hip(d, "", gc.NAZ_SIDE_CASES[0][2], dtype), {k[3:]: g[k] for k in g.files if k.startswith("c0_") and k[3:] not in ("C", "D")}) > 1e-3
+    with pytest.raises(RuntimeError):
+        gc.naz_side_hip(d, "UI", dict(), dtype, use_cg=True)
+    d2 = dict(d); d2["U"] = d["U"][:100]
+    with pytest.raises(RuntimeError):
+        gc.naz_side_hip(d2, "U", dict(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_dense_X(oracles, dtype):
     """G19 through the estimator (CMF.fit(X = 2-D array with NaN)): every pattern of the reference's dense cases -- complete,
     nearly complete (closed form whatever use_cg says), half missing with an empty row and column (the solver asked for),

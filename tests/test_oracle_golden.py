@@ -219,6 +219,23 @@ def test_NA_as_zero_X(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_X_sideinfo(oracles, dtype):
+    """G20: NA_as_zero_X together with dense side information -- one factorised block matrix per half-step
+    (collective.c:5607-5617, :5700-5716), right-hand sides X B + w U C + the bias / mean constant."""
+    g = gc.load("g20_na_as_zero_sideinfo", dtype)
+    d = gc.naz_problem(dtype)
+    seen = 0
+    for ci, (name, sides, opts) in enumerate(gc.NAZ_SIDE_CASES):
+        got = gc.naz_side_oracle(oracles[dtype], d, sides, opts)
+        if got is None:
+            continue
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+        seen += 1
+    assert seen >= 8
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dense_X(oracles, dtype):
     """G19: fit_collective_explicit_als on a dense X with NaN (the reference's optimizeA Cases 1-2) against the restatement run
     on the present entries as a sparse X: closed form in the half-steps whose rows are all / nearly all complete (whatever

@@ -525,3 +525,44 @@ def test_NA_as_zero_fit_live(oracles, refs, dtype, shape):
                                     init_biases=True, **o)
             for key in (("biasA",) if ub else ()) + (("biasB",) if ib else ()):
                 assert np.abs(o0[key]).max() > 1e-3 and rel_err(o0[key], r0[key]) < 100 * TOL[dtype], (name, key)
+
+
+# ---- NA_as_zero for the main matrix together with dense side information -------------------------------------------------------
+NAZ_SIDE_LIVE = [
+    dict(), dict(scale_lam=True), dict(scale_lam_sideinfo=True),
+    dict(center=False, item_bias=False, k_user=2, k_item=1, k_main=2, w_user=0.7, w_item=1.3),
+    dict(user_bias=False, item_bias=False, center=False), dict(U_only=True), dict(I_only=True, scale_lam=True),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(310, 190), (150, 230)])
+def test_NA_as_zero_sideinfo_fit_live(oracles, refs, dtype, shape):
+    """fit_collective_explicit_als with NA_as_zero_X AND dense side information, closed form: optimizeA_collective's factorised
+    shared block matrix (collective.c:5607-5617, :5700-5716), right-hand sides X B + w U C + the bias / mean constant
+    (:5753-5770, :5815-5821); side information on one or both sides, k_user / k_item / k_main, both lambda scalings."""
+    O, R = oracles[dtype], refs[dtype]
+    m, n = shape
+    rng = np.random.default_rng(5)
+    row, col, val = make_coo(m, n, 5000, 75, counts=False, dtype=dtype, heavy_row=(3, 120), empty_rows=(5, 17))
+    keep = col != 11
+    row, col, val = row[keep], col[keep], val[keep]
+    k, p, q = 10, 7, 5
+    U = rng.standard_normal((m, p)).astype(dtype); II = rng.standard_normal((n, q)).astype(dtype)
+    for o in NAZ_SIDE_LIVE:
+        o = dict(o); U_only = o.pop("U_only", False); I_only = o.pop("I_only", False)
+        ku, ki, km = o.get("k_user", 0), o.get("k_item", 0), o.get("k_main", 0)
+        A0 = (rng.standard_normal((m, ku + k + km)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, ki + k + km)) * 0.1).astype(dtype)
+        bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+        kw = dict(U=None if I_only else U, II=None if U_only else II, lam=0.4, niter=3, nthreads=2, NA_as_zero_X=True, use_cg=False, **o)
+        ro = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        rr = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        assert ro["ret"] == 0 and rr["ret"] == 0, o
+        keys = ("A", "B") + (() if I_only else ("C",)) + (() if U_only else ("D",)) + (("biasA",) if o.get("user_bias", True) else ()) + \
+               (("biasB",) if o.get("item_bias", True) else ())
+        for key in keys:
+            assert rel_err(ro[key], rr[key]) < 100 * TOL[dtype], (o, key)
+    # what the restatement does not cover is refused: the block CG, side information on fewer rows than X
+    A0 = np.zeros((m, k), dtype); B0 = np.zeros((n, k), dtype)
+    assert O.fit_explicit_als(A0, B0, row, col, val, k, U=U, II=II, niter=1, NA_as_zero_X=True, use_cg=True)["ret"] == 2
+    assert O.fit_explicit_als(A0, B0, row, col, val, k, U=U[:m - 9], niter=1, NA_as_zero_X=True, use_cg=False)["ret"] == 2
