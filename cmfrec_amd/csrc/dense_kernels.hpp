@@ -494,6 +494,24 @@ __global__ void betbe_base_kernel(const T *__restrict__ G, int kk, int ks, T lam
     }
 }
 
+// M[r, :] := keep[r, :] for the rows whose mask byte is zero (both [rows, ld])
+template <typename T>
+__global__ void restore_rows_kernel(T *__restrict__ M, const T *__restrict__ keep, size_t ld, size_t rows, const unsigned char *__restrict__ mask)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= rows * ld) return;
+    if (!mask[e / ld]) M[e] = keep[e];
+}
+
+// M[rows[e], 0 .. ncols) := 0
+template <typename T>
+__global__ void zero_rows_kernel(T *__restrict__ M, size_t ld, int ncols, const int *__restrict__ rows, int count)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= (size_t)count * ncols) return;
+    M[(size_t)rows[e / ncols] * ld + (e % ncols)] = T(0);
+}
+
 // Linv [n, n] row-major := (R^T)^-1 for the row-major upper Cholesky factor R (M = R^T R): lower triangular, zeros above the
 // diagonal.  One workgroup; thread j solves R x = e_j by back substitution (x = column j of R^-1 = row j of Linv): the
 // elements of R it reads are the same for every thread (broadcast loads), its own x stays in its row of the output.

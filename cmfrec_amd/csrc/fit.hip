@@ -124,6 +124,18 @@ struct ZeroFilledSide {
         return 0;
     }
 };
+// ... with one exception the reference makes: a row with neither an entry of X nor an entry of the side information is not solved
+// but set to zero, bias included (collective_closed_form_block, collective.c:1262-1271; _implicit: :1876-1884).  The list of
+// those rows, for cmfrec_hip_session_set_zero_rows.
+static std::vector<int_t> rows_without_data(int_t rows, const int_t *ix_x, size_t nnz, const int_t *ix_side, size_t nnz_side)
+{
+    std::vector<char> has((size_t)rows, 0);
+    for (size_t e = 0; e < nnz; e++) if (ix_x[e] >= 0 && ix_x[e] < rows) has[(size_t)ix_x[e]] = 1;
+    for (size_t e = 0; e < nnz_side; e++) if (ix_side[e] >= 0 && ix_side[e] < rows) has[(size_t)ix_side[e]] = 1;
+    std::vector<int_t> out;
+    for (int_t r = 0; r < rows; r++) if (!has[(size_t)r]) out.push_back(r);
+    return out;
+}
 // precomputedCtUbias of the reference's epilogue (collective.c:9244-9252, :10115-10123): -w C^T colmeans
 static void fill_CtUbias(real_t *out, const real_t *C, const real_t *colmeans, int_t p, int_t kc, real_t w)
 {
@@ -616,12 +628,15 @@ int_t fit_collective_implicit_als(
     // sparse side information whose absent entries are zeros -> the dense route on the zero-filled matrix (ZeroFilledSide)
     ZeroFilledSide zfU, zfI;
     const bool naz_U = NA_as_zero_U && U == nullptr && nnz_U > 0, naz_I = NA_as_zero_I && II == nullptr && nnz_I > 0;
+    std::vector<int_t> zero_rows_A, zero_rows_B;
     if (naz_U) {
+        zero_rows_A = rows_without_data(m, ixA, nnz, U_row, nnz_U);
         const int e = zfU.build(m, m_u, p, U_row, U_col, U_sp, nnz_U);
         if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented." : "cmfrec_hip: U index out of range.");
         U = zfU.dense.data(); m_u = m; nnz_U = 0; U_row = U_col = nullptr; U_sp = nullptr;
     }
     if (naz_I) {
+        zero_rows_B = rows_without_data(n, ixB, nnz, I_row, nnz_I);
         const int e = zfI.build(n, n_i, q, I_row, I_col, I_sp, nnz_I);
         if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented." : "cmfrec_hip: I index out of range.");
         II = zfI.dense.data(); n_i = n; nnz_I = 0; I_row = I_col = nullptr; I_sp = nullptr;
@@ -734,7 +749,7 @@ int_t fit_collective_implicit_als(
     // all solvers, constraints and penalties; sparse side information and side information beyond the shape of X keep to the
     // first listed device.
     const bool multi_ok = sharded_fit_wanted(devs) && !spU && !spI && m_u <= m && n_i <= n && m >= (int_t)devs.size() &&
-                          n >= (int_t)devs.size();
+                          n >= (int_t)devs.size() && zero_rows_A.empty() && zero_rows_B.empty();
     if (devs.size() > 1 && !multi_ok && verbose)
         printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (sparse side information / side information beyond X) "
                "runs on the first\n", (int)devs.size());
@@ -772,6 +787,8 @@ int_t fit_collective_implicit_als(
     int rc = cmfrec_hip_session_set_X_coo(s, ixA, ixB, apply_log_transf ? Xs.data() : X, nnz, (real_t)0, alpha);
     std::vector<real_t>().swap(Xs);
     tm.lap("set_X_coo (upload, sort, bins)");
+    if (!rc && !zero_rows_A.empty()) rc = cmfrec_hip_session_set_zero_rows(s, 'A', zero_rows_A.data(), (int)zero_rows_A.size());
+    if (!rc && !zero_rows_B.empty()) rc = cmfrec_hip_session_set_zero_rows(s, 'B', zero_rows_B.data(), (int)zero_rows_B.size());
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
@@ -834,12 +851,15 @@ int_t fit_collective_explicit_als(
     // sparse side information whose absent entries are zeros -> the dense route on the zero-filled matrix (ZeroFilledSide)
     ZeroFilledSide zfU, zfI;
     const bool naz_U = NA_as_zero_U && U == nullptr && nnz_U > 0, naz_I = NA_as_zero_I && II == nullptr && nnz_I > 0;
+    std::vector<int_t> zero_rows_A, zero_rows_B;
     if (naz_U) {
+        zero_rows_A = rows_without_data(m, ixA, nnz, U_row, nnz_U);
         const int e = zfU.build(m, m_u, p, U_row, U_col, U_sp, nnz_U);
         if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented." : "cmfrec_hip: U index out of range.");
         U = zfU.dense.data(); m_u = m; nnz_U = 0; U_row = U_col = nullptr; U_sp = nullptr;
     }
     if (naz_I) {
+        zero_rows_B = rows_without_data(n, ixB, nnz, I_row, nnz_I);
         const int e = zfI.build(n, n_i, q, I_row, I_col, I_sp, nnz_I);
         if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented." : "cmfrec_hip: I index out of range.");
         II = zfI.dense.data(); n_i = n; nnz_I = 0; I_row = I_col = nullptr; I_sp = nullptr;
@@ -852,10 +872,11 @@ int_t fit_collective_explicit_als(
     // in exact arithmetic -- and the closed form here); otherwise (Case 2) a row that misses fewer than twice as many entries
     // as its system has unknowns is solved in closed form from the precomputed B^T B (factors_closed_form, :662, :759-790:
     // that branch comes before the CG one), the others by the solver asked for.  A half-step that has rows of both kinds under
-    // use_cg is refused.  With weights every row takes the solver asked for.  Plain model only (no side information /
+    // use_cg runs both solvers (dense_cf_A / _B).  With weights every row takes the solver asked for.  Plain model only (no side information /
     // implicit features).
     DenseX dx;
     bool dense_chol_A = false, dense_chol_B = false;
+    std::vector<unsigned char> dense_cf_A, dense_cf_B;
     if (Xfull) {
         if (U || II || nnz_U || nnz_I || add_implicit_features || NA_as_zero_X)
             return fail(verbose, "cmfrec_hip: dense X is implemented for the model without side information and implicit features.");
@@ -882,9 +903,12 @@ int_t fit_collective_explicit_als(
             bool mixA = false, mixB = false;
             dense_chol_A = dx.full || dx.near_row || case2_chol(dx.na_row, n, fewA, mixA);
             dense_chol_B = dx.full || dx.near_col || case2_chol(dx.na_col, m, fewB, mixB);
-            if (use_cg && !nonneg && l1_lam == 0 && !l1_lam_unique && ((!(dx.full || dx.near_row) && mixA) || (!(dx.full || dx.near_col) && mixB)))
-                return fail(verbose, "cmfrec_hip: dense X with use_cg: a half-step whose rows partly miss few and partly many entries mixes two "
-                                     "solvers in the reference; not implemented (use_cg=False is).");
+            // a half-step with rows of both kinds under use_cg: the rows that miss few entries are marked for the closed form
+            // (cmfrec_hip_session_set_closed_form_rows), the update runs both solvers
+            if (use_cg && !nonneg && l1_lam == 0 && !l1_lam_unique) {
+                if (!(dx.full || dx.near_row) && mixA) { dense_cf_A.resize((size_t)m); for (int_t r = 0; r < m; r++) dense_cf_A[r] = dx.na_row[r] < fewA; }
+                if (!(dx.full || dx.near_col) && mixB) { dense_cf_B.resize((size_t)n); for (int_t c = 0; c < n; c++) dense_cf_B[c] = dx.na_col[c] < fewB; }
+            }
         }
         Xfull = nullptr;
     }
@@ -1105,7 +1129,8 @@ int_t fit_collective_explicit_als(
     // (a dense X keeps to one device: its half-steps follow the reference's per-half-step choice of solver, dense_chol_A / _B,
     // and its empty rows are zeroed afterwards -- neither is part of multi_loop)
     const bool multi_ok = sharded_fit_wanted(devs) && !spU && !spI && m_u <= m && n_i <= n && !add_implicit_features && !NA_as_zero_X &&
-                          !weight && dx.na_row.empty() && m >= (int_t)devs.size() && n >= (int_t)devs.size();
+                          !weight && dx.na_row.empty() && m >= (int_t)devs.size() && n >= (int_t)devs.size() && zero_rows_A.empty() &&
+                          zero_rows_B.empty();
     if (devs.size() > 1 && !multi_ok && verbose)
         printf("cmfrec_hip: CMFREC_HIP_DEVICES lists %d devices; this configuration (sparse side information / side information beyond X / "
                "weights / implicit features / NA_as_zero / dense X) runs on the first\n", (int)devs.size());
@@ -1172,6 +1197,10 @@ int_t fit_collective_explicit_als(
     int rc = cmfrec_hip_session_set_X_coo_weighted(s, ixA, ixB, X, weight, nnz, NA_as_zero_X ? (real_t)0 : gm, (real_t)1);
     if (!rc && NA_as_zero_X) rc = cmfrec_hip_session_set_NA_as_zero_X(s, 1, center ? 1 : 0, gm);
     tm.lap("set_X_coo (upload, sort, bins)");
+    if (!rc && !dense_cf_A.empty()) rc = cmfrec_hip_session_set_closed_form_rows(s, 'A', dense_cf_A.data());
+    if (!rc && !dense_cf_B.empty()) rc = cmfrec_hip_session_set_closed_form_rows(s, 'B', dense_cf_B.data());
+    if (!rc && !zero_rows_A.empty()) rc = cmfrec_hip_session_set_zero_rows(s, 'A', zero_rows_A.data(), (int)zero_rows_A.size());
+    if (!rc && !zero_rows_B.empty()) rc = cmfrec_hip_session_set_zero_rows(s, 'B', zero_rows_B.data(), (int)zero_rows_B.size());
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);

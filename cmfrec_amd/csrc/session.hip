@@ -732,6 +732,11 @@ struct cmfrec_hip_session {
     bool naz_X = false, naz_center = false;
     real_t naz_mean = 0;
     DevBuf<real_t> naz_part, naz_vec, naz_M, naz_rhs;
+    DevBuf<int> zrowsA, zrowsB;   // rows every update of A / B leaves at zero (cmfrec_hip_session_set_zero_rows)
+    int n_zrowsA = 0, n_zrowsB = 0;
+    DevBuf<unsigned char> cfmaskA, cfmaskB;   // rows that take the closed form inside a CG update (cmfrec_hip_session_set_closed_form_rows)
+    bool has_cfA = false, has_cfB = false;
+    DevBuf<real_t> cf_keep;
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
     // optional split of the local rows of A into contiguous parts, each with its own processing order: an A-step then
     // finishes part by part (one event each), so the all-gather of a finished part overlaps the rest of the step
@@ -1340,6 +1345,43 @@ int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int cente
     if (on && s->mdl.implicit) { g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: explicit model only"; return 2; }
     s->naz_X = on != 0; s->naz_center = center != 0; s->naz_mean = glob_mean;
     return 0;
+}
+
+int cmfrec_hip_session_set_zero_rows(cmfrec_hip_session *s, int which, const int_t *rows, int count)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        if (which != 'A' && which != 'B') { g_last_error = "cmfrec_hip_session_set_zero_rows: which must be 'A' or 'B'"; return 2; }
+        const int limit = which == 'A' ? s->mdl.m : s->mdl.n;
+        for (int e = 0; e < count; e++)
+            if (rows == nullptr || rows[e] < 0 || rows[e] >= limit) { g_last_error = "cmfrec_hip_session_set_zero_rows: row out of range"; return 2; }
+        DevBuf<int> &buf = which == 'A' ? s->zrowsA : s->zrowsB;
+        (which == 'A' ? s->n_zrowsA : s->n_zrowsB) = std::max(count, 0);
+        if (count > 0) {
+            std::vector<int> h(rows, rows + count);
+            buf.alloc_at_least((size_t)count);
+            HIP_CHECK(hipMemcpyAsync(buf.ptr, h.data(), (size_t)count * sizeof(int), hipMemcpyHostToDevice, s->dev.stream));
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        }
+        return 0;
+    });
+}
+
+int cmfrec_hip_session_set_closed_form_rows(cmfrec_hip_session *s, int which, const unsigned char *mask)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        if (which != 'A' && which != 'B') { g_last_error = "cmfrec_hip_session_set_closed_form_rows: which must be 'A' or 'B'"; return 2; }
+        const size_t rows = (size_t)(which == 'A' ? s->mdl.m : s->mdl.n);
+        (which == 'A' ? s->has_cfA : s->has_cfB) = (mask != nullptr);
+        if (mask != nullptr) {
+            DevBuf<unsigned char> &buf = which == 'A' ? s->cfmaskA : s->cfmaskB;
+            buf.alloc_at_least(rows);
+            HIP_CHECK(hipMemcpyAsync(buf.ptr, mask, rows, hipMemcpyHostToDevice, s->dev.stream));
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        }
+        return 0;
+    });
 }
 
 int cmfrec_hip_session_set_scale_bias_const(cmfrec_hip_session *s, int on)
@@ -2050,6 +2092,29 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
                 }
             } else {
                 rc = update_factor(s, which == 'A', chol);
+                if (rc == 0 && !chol && (which == 'A' ? s->has_cfA : s->has_cfB)) {
+                    // rows of this half-step that the reference solves in closed form next to the CG rows
+                    // (cmfrec_hip_session_set_closed_form_rows): CG results aside, closed form over all rows, CG rows back
+                    const bool isA = which == 'A';
+                    real_t *self = isA ? s->A.ptr : s->B.ptr;
+                    const size_t ld = isA ? s->ldA : s->ldB, rows = (size_t)(isA ? s->mdl.m : s->mdl.n);
+                    s->cf_keep.alloc_at_least(rows * ld);
+                    HIP_CHECK(hipMemcpyAsync(s->cf_keep.ptr, self, rows * ld * sizeof(real_t), hipMemcpyDeviceToDevice, s->dev.stream));
+                    rc = update_factor(s, isA, true);
+                    hipLaunchKernelGGL(restore_rows_kernel<real_t>, grid1d(rows * ld), dim3(256), 0, s->dev.stream, self, s->cf_keep.ptr, ld, rows,
+                                       (isA ? s->cfmaskA : s->cfmaskB).ptr);
+                    HIP_CHECK(hipGetLastError());
+                }
+            }
+            if (rc == 0 && (which == 'A' ? s->n_zrowsA : s->n_zrowsB) > 0) {
+                // rows the reference does not solve under NA_as_zero_U / _I (cmfrec_hip_session_set_zero_rows): the unknowns of
+                // the row, its own bias included; a bias column fixed to 1 stays
+                const bool isA = which == 'A';
+                const bool self_bias = !s->mdl.implicit && (isA ? s->mdl.user_bias : s->mdl.item_bias);
+                const int ncols = (isA ? s->k_totA : s->k_totB) + (self_bias ? 1 : 0), cnt = isA ? s->n_zrowsA : s->n_zrowsB;
+                hipLaunchKernelGGL(zero_rows_kernel<real_t>, grid1d((size_t)cnt * ncols), dim3(256), 0, s->dev.stream, isA ? s->A.ptr : s->B.ptr,
+                                   isA ? s->ldA : s->ldB, ncols, (isA ? s->zrowsA : s->zrowsB).ptr, cnt);
+                HIP_CHECK(hipGetLastError());
             }
             HIP_CHECK(hipEventRecord(ev.b, s->dev.stream));
             (which == 'A' ? s->evA : s->evB).push_back(ev);

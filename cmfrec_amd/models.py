@@ -119,8 +119,9 @@ class CMF_implicit(_Base):
                  precompute_for_predictions=True, use_float=True, max_cg_steps=3,
                  precondition_cg=False, finalize_chol=False, random_state=1, verbose=False,
                  produce_dicts=False, handle_interrupt=True, nthreads=-1, n_jobs=None):
-        if NA_as_zero_user or NA_as_zero_item:
-            raise NotImplementedError("NA_as_zero_user / NA_as_zero_item are not implemented in cmfrec_amd")
+        # sparse side information whose absent entries are zeros (not missing): cmfrec/__init__.py:4688-4690.  The C library
+        # runs it as the zero-filled dense matrix it denotes (fit.hip, ZeroFilledSide)
+        self.NA_as_zero_user = bool(NA_as_zero_user); self.NA_as_zero_item = bool(NA_as_zero_item)
         self.k = int(k); self.alpha = float(alpha); self.use_cg = bool(use_cg)
         self.lambda_, self._lam6 = _penalty(lambda_, "lambda_")
         self.k_user = int(k_user); self.k_item = int(k_item); self.k_main = int(k_main)
@@ -169,6 +170,7 @@ class CMF_implicit(_Base):
         BtB = np.zeros((self.k + self.k_main,) * 2, dt) if pre else None
         BeTBe = np.zeros((kq, kq), dt) if (pre and p) else None
         BeTBeChol = np.zeros((kq, kq), dt) if (pre and p) else None
+        CtUbias = np.zeros(self.k_user + self.k, dt) if (pre and p and Us is not None and self.NA_as_zero_user) else None
         rc = lib.fit_collective_implicit_als(
             _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), C.c_bool(reset), C.c_int(self.random_state),
             _lib.ptr(Ucm) if (p and self.center_U) else None, _lib.ptr(Icm) if (q and self.center_I) else None,
@@ -176,14 +178,14 @@ class CMF_implicit(_Base):
             C.c_size_t(len(val)), R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
-            C.c_bool(False), C.c_bool(False), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
+            C.c_bool(self.NA_as_zero_user), C.c_bool(self.NA_as_zero_item), C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), _lib.ptr(wmm),
             R(self.alpha), C.c_bool(bool(getattr(self, "_adjust_weight", False))),   # the reference's estimator always passes False (__init__.py:4753)
             C.c_bool(self.apply_log_transf), C.c_int(self.niter), C.c_int(self.nthreads),
             C.c_bool(self.verbose), C.c_bool(self.handle_interrupt), C.c_bool(self.use_cg),
             C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg), C.c_bool(self.finalize_chol),
             C.c_bool(self.nonneg), C.c_int(self.max_cd_steps), C.c_bool(self.nonneg_C), C.c_bool(self.nonneg_D),
-            C.c_bool(pre), _lib.ptr(BtB), _lib.ptr(BeTBe), _lib.ptr(BeTBeChol), None)
+            C.c_bool(pre), _lib.ptr(BtB), _lib.ptr(BeTBe), _lib.ptr(BeTBeChol), _lib.ptr(CtUbias))
         # an interrupted fit returns 3 with usable factors; like the reference's wrapper, raise only when the caller did
         # not ask for the interrupt to be handled (cmfrec/wrapper_untyped.pxi: `if ret_code == 3 and not handle_interrupt`)
         _lib.check(rc, lib, "fit_collective_implicit_als", interrupt_ok=self.handle_interrupt)
@@ -197,6 +199,7 @@ class CMF_implicit(_Base):
         self._BtB = BtB if BtB is not None else e
         self._BeTBe = BeTBe if BeTBe is not None else e
         self._BeTBeChol = BeTBeChol if BeTBeChol is not None else e
+        self._CtUbias = CtUbias if CtUbias is not None else np.empty(0, dt)
         self.is_fitted_ = True
         return self
 
@@ -258,10 +261,12 @@ class CMF(_Base):
                  n_jobs=None):
         if method != "als":
             raise NotImplementedError("only method='als' is implemented in cmfrec_amd")
-        if NA_as_zero_user or NA_as_zero_item:
-            raise NotImplementedError("NA_as_zero_user / NA_as_zero_item are not implemented in cmfrec_amd")
-        # NA_as_zero (absent entries of a sparse X are zeros): the model without side information; the matrices for predictions
-        # on new data are not produced (pass precompute_for_predictions=False)
+        # sparse side information whose absent entries are zeros (not missing): cmfrec/__init__.py:2903-2905.  The C library
+        # runs it as the zero-filled dense matrix it denotes (fit.hip, ZeroFilledSide)
+        self.NA_as_zero_user = bool(NA_as_zero_user); self.NA_as_zero_item = bool(NA_as_zero_item)
+        # NA_as_zero (absent entries of a sparse X are zeros): without side information or with dense complete side information on
+        # exactly the rows / columns of X (closed form); the matrices for predictions on new data are not produced (pass
+        # precompute_for_predictions=False)
         self.NA_as_zero = bool(NA_as_zero)
         if self.NA_as_zero and precompute_for_predictions:
             raise NotImplementedError("NA_as_zero: precompute_for_predictions is not implemented in cmfrec_amd (pass False)")
@@ -345,6 +350,7 @@ class CMF(_Base):
         BeChol = np.zeros((kq, kq), dt) if (pre and p) else None
         TCt = np.zeros((p, kc), dt) if (pre and p) else None
         CtCw = np.zeros((kc, kc), dt) if (pre and p) else None
+        CtUbias = np.zeros(kc, dt) if (pre and p and Us is not None and self.NA_as_zero_user) else None
         rc = lib.fit_collective_explicit_als(
             _lib.ptr(biasA), _lib.ptr(biasB), _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), _lib.ptr(Ai), _lib.ptr(Bi),
             C.c_bool(imp), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean),
@@ -356,7 +362,7 @@ class CMF(_Base):
             C.c_bool(self.scale_lam_sideinfo), C.c_bool(self.scale_bias_const), _lib.ptr(sbA), _lib.ptr(sbB),
             _lib.ptr(Uc), C.c_int(m_u), C.c_int(p), _lib.ptr(Ic), C.c_int(n_i), C.c_int(q),
             *spU, *spI,
-            C.c_bool(self.NA_as_zero), C.c_bool(False), C.c_bool(False),
+            C.c_bool(self.NA_as_zero), C.c_bool(self.NA_as_zero_user), C.c_bool(self.NA_as_zero_item),
             C.c_int(self.k_main), C.c_int(self.k_user), C.c_int(self.k_item),
             R(self.w_main), R(self.w_user), R(self.w_item), R(self.w_implicit),
             C.c_int(self.niter), C.c_int(self.nthreads), C.c_bool(self.verbose), C.c_bool(self.handle_interrupt),
@@ -364,7 +370,7 @@ class CMF(_Base):
             C.c_bool(self.finalize_chol), C.c_bool(self.nonneg), C.c_int(self.max_cd_steps), C.c_bool(self.nonneg_C),
             C.c_bool(self.nonneg_D),
             C.c_bool(pre), C.c_bool(True), _lib.ptr(Bpb), _lib.ptr(BtB), _lib.ptr(TBt), None, _lib.ptr(BeChol), None,
-            _lib.ptr(TCt), _lib.ptr(CtCw), None)
+            _lib.ptr(TCt), _lib.ptr(CtCw), _lib.ptr(CtUbias))
         _lib.check(rc, lib, "fit_collective_explicit_als", interrupt_ok=self.handle_interrupt)
         # precomputed matrices for predictions on new data, reference attribute names (cmfrec/__init__.py:3211-3247)
         e = np.empty((0, 0), dt)
@@ -373,6 +379,7 @@ class CMF(_Base):
         self._TransBtBinvBt = TBt if TBt is not None else e
         self._BeTBeChol = BeChol if BeChol is not None else e
         self._TransCtCinvCt = TCt if TCt is not None else e
+        self._CtUbias = CtUbias if CtUbias is not None else np.empty(0, dt)
         self._CtCw = CtCw if CtCw is not None else e
         self._scaling_biasA, self._scaling_biasB = float(sbA[0]), float(sbB[0])    # cmfrec/__init__.py: scaling_biasA_ / _B_
         self.A_, self.B_ = A, B

@@ -360,8 +360,21 @@ int cmfrec_hip_session_set_X_coo_device(cmfrec_hip_session *s, int which, const 
  * here on every update('A' / 'B') is optimizeA Case 3 (src/common.c:3118-3205) -- one shared matrix opp^T opp + lambda (x rows
  * under scale_lam), right-hand sides sum_j x_j opp_j over the row's entries plus the constant -sum over ALL opposing rows of
  * (their bias + glob_mean [when center]) x row (src/collective.c:8573-8600, :8756-8787), one factorisation and a triangular
- * solve for every row, with or without entries.  X must have been set uncentred. */
+ * solve for every row, with or without entries.  A side with dense complete side information on exactly the rows of X:
+ * optimizeA_collective's factorised block matrix (src/collective.c:5607-5617, :5700-5716), closed form only.  X must have been
+ * set uncentred. */
 int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int center, real_t glob_mean);
+/* Rows of A (which = 'A') or B ('B') that every update of that matrix leaves at ZERO, bias included, instead of solving them:
+ * with NA_as_zero_U / NA_as_zero_I the reference does not solve a row that has neither an entry of X nor an entry of the side
+ * information (collective_closed_form_block, src/collective.c:1262-1271; _implicit: :1876-1884), while the zero-filled dense
+ * matrix the fit runs on (fit.hip, ZeroFilledSide) would.  count = 0 clears the list. */
+int cmfrec_hip_session_set_zero_rows(cmfrec_hip_session *s, int which, const int_t *rows, int count);
+/* Rows of A ('A') or B ('B') that take the CLOSED FORM in every update of that matrix, also when the update runs CG for the
+ * others: a dense X whose half-step (optimizeA Case 2, src/common.c:2992-3116) has rows missing fewer than 2 k entries (closed form
+ * from the precomputed B^T B, factors_closed_form :662, :759-790) next to rows missing more (the solver asked for).  mask: one byte
+ * per row of the matrix, non-zero = closed form; NULL clears it.  A CG update then solves every row by CG, keeps a copy, solves
+ * every row in closed form and puts the copy back for the rows whose byte is zero. */
+int cmfrec_hip_session_set_closed_form_rows(cmfrec_hip_session *s, int which, const unsigned char *mask);
 /* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
  * _onesided (src/common.c:4410-4909, 4265-4289; call sites src/collective.c:8166-8220): written to the
  * session's bias vectors and the bias columns of A / B.  Call after set_X* and set_factors. */

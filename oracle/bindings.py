@@ -354,6 +354,21 @@ class Oracle:
             C.c_bool(use_cg), C.c_int(max_cg_steps), C.c_bool(precondition_cg), C.c_bool(finalize_chol))
         return dict(ret=ret, A=A, B=B, C=Cm, D=Dm, U_colmeans=Ucm, I_colmeans=Icm)
 
+    def set_closed_form_rows(self, maskA=None, maskB=None):
+        """Per-row solver choice of the NEXT explicit fit (dense X, optimizeA Case 2): non-zero = closed form inside a CG
+        half-step.  The arrays must stay alive until that fit returns."""
+        self._cfA = None if maskA is None else np.ascontiguousarray(maskA, np.uint8)
+        self._cfB = None if maskB is None else np.ascontiguousarray(maskB, np.uint8)
+        self.lib.oracle_set_closed_form_rows(_ptr(self._cfA), _ptr(self._cfB))
+
+    def set_zero_rows(self, rowsA=None, rowsB=None):
+        """Rows of A / B the NEXT fit sets to zero after their update (NA_as_zero_U / _I: rows with neither an entry of X nor of
+        the side information, which the reference does not solve).  The arrays must stay alive until that fit returns."""
+        self._zrA = None if rowsA is None else np.ascontiguousarray(rowsA, np.int32)
+        self._zrB = None if rowsB is None else np.ascontiguousarray(rowsB, np.int32)
+        self.lib.oracle_set_zero_rows(_ptr(self._zrA), C.c_int(0 if self._zrA is None else len(self._zrA)),
+                                      _ptr(self._zrB), C.c_int(0 if self._zrB is None else len(self._zrB)))
+
     def fit_explicit_als(self, A, B, row, col, val, k, biasA=None, biasB=None, Cm=None, Dm=None,
                          U=None, II=None, user_bias=True, item_bias=True, center=True, lam=10.0,
                          scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0,

@@ -518,6 +518,13 @@ void oracle_set_row_weights(const real_t *weights_csr_order, const real_t *wsum)
     g_row_weights = weights_csr_order; g_row_wsum = wsum;
 }
 
+/* Dense X, optimizeA Case 2 (common.c:2992-3116): a row that misses fewer than 2 k entries is solved in closed form from the
+ * precomputed B^T B whatever use_cg says (factors_closed_form, :662, :759-790), the others by the solver asked for.  The masks
+ * (one byte per row / column, non-zero = closed form) of the next oracle_fit_explicit_als call; g_cf_now: the one of the
+ * half-step about to run (consumed by oracle_optimizeA_explicit). */
+static const unsigned char *g_cf_rows_A = NULL, *g_cf_rows_B = NULL, *g_cf_now = NULL;
+void oracle_set_closed_form_rows(const unsigned char *maskA, const unsigned char *maskB) { g_cf_rows_A = maskA; g_cf_rows_B = maskB; }
+
 void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
                                int_t m, int_t n, int_t k,
                                const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr,
@@ -529,9 +536,11 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
     (void)n;
     const real_t *wts = g_row_weights, *wsums = g_row_wsum;
     g_row_weights = NULL; g_row_wsum = NULL;
+    const unsigned char *cf = g_cf_now;
+    g_cf_now = NULL;
     if (nthreads < 1) nthreads = 1;
     size_t szbuf = (size_t)k * k;                                              /* :3244-3249 */
-    if (use_cg) szbuf = (size_t)(precondition_cg ? 5 : 3) * k;
+    if (use_cg && cf == NULL) szbuf = (size_t)(precondition_cg ? 5 : 3) * k;
     real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
     #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
     for (int_t ix = 0; ix < m; ix++) {                                         /* :3268-3299 */
@@ -554,9 +563,10 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
         }
         real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
         real_t *a = A + (size_t)ix * lda;
-        if (use_cg && !precondition_cg)
+        const bool row_cg = use_cg && !(cf != NULL && cf[ix]);
+        if (row_cg && !precondition_cg)
             explicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, max_cg_steps, buf);
-        else if (use_cg)
+        else if (row_cg)
             explicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, max_cg_steps, buf);
         else
             explicit_chol_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, buf);
@@ -1202,6 +1212,22 @@ void oracle_initialize_biases_twosided(int_t m, int_t n,
     }
 }
 
+/* NA_as_zero_U / NA_as_zero_I (sparse side information whose absent entries are zeros): restated as the dense route on the
+ * zero-filled matrix -- equal to the reference's sparse branches to 1e-15 (tests/test_oracle_vs_ref.py) -- with ONE exception the
+ * reference makes: a row with neither an entry of X nor an entry of U is not solved but set to zero, bias included
+ * (collective_closed_form_block's first check, collective.c:1262-1271; _implicit: :1876-1884).  The rows / columns this applies to
+ * are handed to the next fit call here (consumed by it). */
+static const int_t *g_zero_rows_A = NULL, *g_zero_rows_B = NULL;
+static int_t g_n_zero_rows_A = 0, g_n_zero_rows_B = 0;
+void oracle_set_zero_rows(const int_t *rowsA, int_t nA, const int_t *rowsB, int_t nB)
+{
+    g_zero_rows_A = rowsA; g_n_zero_rows_A = rowsA ? nA : 0; g_zero_rows_B = rowsB; g_n_zero_rows_B = rowsB ? nB : 0;
+}
+static void zero_rows_(real_t *M, size_t ld, int_t ncols, const int_t *rows, int_t cnt)
+{
+    for (int_t e = 0; e < cnt; e++) memset(M + (size_t)rows[e] * ld, 0, (size_t)ncols * sizeof(real_t));
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* optimizeA_collective with the main matrix missing-as-zero and dense, complete side information, closed form
  * (collective.c:5566-5968 with bufferBeTBeChol, :5607-5617): every row with side information shares ONE matrix
@@ -1285,6 +1311,9 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
     if (II == NULL) { n_i = 0; q = 0; }
     /* side information may cover more users / items than X: A, B have max(m, m_u) / max(n, n_i) rows
      * (collective.c:9437-9440); X is padded with empty rows / columns, the Gramians keep X's own shape */
+    const int_t *zrA = g_zero_rows_A, *zrB = g_zero_rows_B;                    /* see oracle_set_zero_rows */
+    const int_t nzrA = g_n_zero_rows_A, nzrB = g_n_zero_rows_B;
+    g_zero_rows_A = g_zero_rows_B = NULL; g_n_zero_rows_A = g_n_zero_rows_B = 0;
     const int_t m_x = m, n_x = n;
     if (m_u > m) m = m_u;
     if (n_i > n) n = n_i;
@@ -1333,6 +1362,7 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
         else                                                                      /* :9965-9981 */
             oracle_optimizeA_implicit(B + k_item, (size_t)k_totB, A + k_user, (size_t)k_totA, n, m_x, k + k_main,
                                       csc_p, csc_i, csc_v, lamB, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+        zero_rows_(B, (size_t)k_totB, k_totB, zrB, nzrB);
         g_l1 = l1A;
         if (U != NULL && use_cg)                                                  /* :9985-10022 */
             oracle_optimizeA_collective_cg(A, (size_t)k_totA, B, (size_t)k_totB, C, m, m_u, n_x, p, k, k_main, k_user, k_item,
@@ -1345,6 +1375,7 @@ int oracle_fit_implicit_als_sideinfo(real_t *A, real_t *B, real_t *C, real_t *D,
         else
             oracle_optimizeA_implicit(A + k_user, (size_t)k_totA, B + k_item, (size_t)k_totB, m, n_x, k + k_main,
                                       csr_p, csr_i, csr_v, lamA, nthreads, use_cg, precondition_cg, max_cg_steps, NULL);
+        zero_rows_(A, (size_t)k_totA, k_totA, zrA, nzrA);
     }
     g_nonneg = false; g_l1 = 0; t_l1_mult = 1;
     free(Uc); free(Ic);
@@ -1407,6 +1438,11 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     g_fit_weight = NULL;
     const bool naz = g_fit_naz;
     g_fit_naz = false;
+    const unsigned char *cfA = g_cf_rows_A, *cfB = g_cf_rows_B;                 /* see oracle_set_closed_form_rows */
+    g_cf_rows_A = g_cf_rows_B = NULL;
+    const int_t *zrA = g_zero_rows_A, *zrB = g_zero_rows_B;                    /* see oracle_set_zero_rows */
+    const int_t nzrA = g_n_zero_rows_A, nzrB = g_n_zero_rows_B;
+    g_zero_rows_A = g_zero_rows_B = NULL; g_n_zero_rows_A = g_n_zero_rows_B = 0;
     /* missing-as-zero with side information: dense complete U / I, closed form, side information on exactly the rows / columns of X
      * (with fewer the reference's own build corrupts its heap, so nothing pins the m > m_u branch restated in collective_naz_chol) */
     if (naz && ((Ai != NULL && Bi != NULL) || weight != NULL || g_scale_bias_const)) return 2;
@@ -1610,6 +1646,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         }
         else {                                                                 /* :8680-8717 */
             oracle_set_row_weights(weightC, wsumB);
+            g_cf_now = use_cg ? cfB : NULL;
             oracle_optimizeA_explicit(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m,
                                       k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v,
                                       lamB, lamBl, scale_lam, sbc, nthreads,
@@ -1624,6 +1661,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                         scale_lam, nthreads);
         }
         }
+        zero_rows_(B_bias, ldB, k_totB + (int_t)item_bias, zrB, nzrB);
         if (item_bias)                                                         /* :8723-8725 */
             for (int_t c = 0; c < n; c++) biasB[c] = B_bias[(size_t)c * ldB + k_totB];
         if (user_bias)                                                         /* :8728-8732 */
@@ -1667,6 +1705,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         }
         else {                                                                 /* :8847-8876 */
             oracle_set_row_weights(weightR, wsumA);
+            g_cf_now = use_cg ? cfA : NULL;
             oracle_optimizeA_explicit(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n,
                                       k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
                                       lamA, lamAl, scale_lam, sbc, nthreads,
@@ -1682,6 +1721,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         }
         }
         g_cg_Bi = NULL;
+        zero_rows_(A_bias, ldA, k_totA + (int_t)user_bias, zrA, nzrA);
         if (user_bias)                                                         /* :8882-8884 */
             for (int_t r = 0; r < m; r++) biasA[r] = A_bias[(size_t)r * ldA + k_totA];
     }

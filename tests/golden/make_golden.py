@@ -317,6 +317,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g20_na_as_zero_sideinfo_" + tag, **out)
 
+        # ---- G21: NA_as_zero_U / NA_as_zero_I (sparse side information whose absent entries are zeros) ----
+        out = {}
+        d = gc.sparse_sideinfo_problem(dt)
+        for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.NAZ_UI_CASES):
+            r = gc.naz_ui_reference(R, d, implicit, which, sl, sls, solver)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g21_na_as_zero_UI_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -363,6 +363,101 @@ def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
     return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, biasA=mdl.user_bias_, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_)
 
 
+# ---- NA_as_zero_U / NA_as_zero_I: sparse side information whose absent entries are zeros (collective.c:1277-1457, :5790-5836,
+# C / D by optimizeA Case 3 with the column means as a rank-one correction, :8354-8441) ----------------------------------------
+# (name, implicit, sides, scale_lam, scale_lam_sideinfo, solver kwargs); the problem of G12 (U covers 80 of the 90 users)
+NAZ_UI_CASES = [("implicit UI", True, "UI", False, False, dict()),
+                ("implicit UI cg", True, "UI", False, False, dict(use_cg=True)),
+                ("explicit UI", False, "UI", False, False, dict()),
+                ("explicit UI scaled, cg + finalize", False, "UI", True, True, dict(use_cg=True, finalize_chol=True)),
+                ("explicit U scaled", False, "U", True, False, dict()),
+                ("explicit I cg", False, "I", False, False, dict(use_cg=True)),
+                ("implicit I", True, "I", False, False, dict())]
+
+
+def zero_filled(coo, rows):
+    """The dense matrix a COO tuple (row, col, val, rows, cols) with absent = 0 denotes, on `rows` rows."""
+    M = np.zeros((rows, coo[4]), coo[2].dtype)
+    np.add.at(M, (coo[0], coo[1]), coo[2])
+    return M
+
+
+def naz_ui_reference(R, d, implicit, which, sl, sls, solver, nthreads=2):
+    """The real reference on G12's problem with NA_as_zero_U / NA_as_zero_I on the sides that are given."""
+    solver = dict(solver or {})
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver)
+    cz = 0 if sv["use_cg"] else 1
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, **sv,
+              U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
+              NA_as_zero_U="U" in which, NA_as_zero_I="I" in which,
+              Cm=(d["C0"][:, d["ku"] - ku:] * cz).copy() if "U" in which else None,
+              Dm=(d["D0"][:, d["ki"] - ki:] * cz).copy() if "I" in which else None)
+    if implicit:
+        r = R.fit_collective_implicit_als(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, w_main=0.5, **kw)
+        assert r["ret"] == 0
+        return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"])
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **kw)
+    assert r["ret"] == 0
+    return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+
+
+def naz_ui_oracle(O, d, implicit, which, sl, sls, solver, nthreads=2):
+    """The restatement: the dense route on the zero-filled matrices (rows / columns of X)."""
+    solver = dict(solver or {})
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver)
+    cz = 0 if sv["use_cg"] else 1
+    U = zero_filled(d["U_coo"], d["m"]) if "U" in which else None
+    II = zero_filled(d["I_coo"], d["n"]) if "I" in which else None
+    # ... except that a row with neither an entry of X nor of the side information is set to zero, not solved
+    def neither(ix, coo, rows):
+        has = np.zeros(rows, bool); has[ix] = True; has[coo[0]] = True
+        return np.nonzero(~has)[0]
+    O.set_zero_rows(neither(d["row"], d["U_coo"], d["m"]) if "U" in which else None,
+                    neither(d["col"], d["I_coo"], d["n"]) if "I" in which else None)
+    kw = dict(k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, U=U, II=II, **sv,
+              Cm=(d["C0"][:, d["ku"] - ku:] * cz).copy() if "U" in which else None,
+              Dm=(d["D0"][:, d["ki"] - ki:] * cz).copy() if "I" in which else None)
+    if implicit:
+        r = O.fit_implicit_als_sideinfo(A0, B0, d["row"], d["col"], d["counts"], d["k"], lam=2.0, alpha=1.5, w_main=0.5, **kw)
+        assert r["ret"] == 0
+        return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"])
+    r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                           scale_lam=sl, scale_lam_sideinfo=sls, **kw)
+    assert r["ret"] == 0
+    return dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], biasA=r["biasA"], biasB=r["biasB"], glob_mean=r["glob_mean"])
+
+
+def naz_ui_hip(d, implicit, which, sl, sls, solver, dtype, flags=True, precompute=False):
+    """The product: the estimators with SciPy sparse side information and NA_as_zero_user / NA_as_zero_item."""
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF, CMF_implicit
+    solver = dict(solver or {})
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    U = mk(d["U_coo"]) if "U" in which else None; I = mk(d["I_coo"]) if "I" in which else None
+    sv = dict(use_cg=False, finalize_chol=False); sv.update(solver)
+    common = dict(k=d["k"], k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, use_float=dtype is np.float32,
+                  precompute_for_predictions=precompute, NA_as_zero_user=flags and "U" in which, NA_as_zero_item=flags and "I" in which, **sv)
+    shape = (d["m"], d["n"])
+    if implicit:
+        mdl = CMF_implicit(lambda_=2.0, alpha=1.5, w_main=0.5, **common)
+        mdl.fit((d["row"], d["col"], d["counts"]), U=U, I=I, shape=shape, A0=A0, B0=B0)
+        out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_)
+    else:
+        mdl = CMF(lambda_=0.3, scale_lam=sl, scale_lam_sideinfo=sls, **common)
+        mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=I, shape=shape, A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+        out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, biasA=mdl.user_bias_, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_)
+    if precompute:
+        out["_model"] = mdl
+    return out
+
+
 def compare_fits(got, exp):
     """Largest relative error over the factor matrices / biases both sides carry."""
     err = 0.0
@@ -1024,6 +1119,16 @@ def dense_problem(dtype, variant, seed=131):
     elif variant == "mixed":
         for r in rng.choice(m, 9, replace=False):
             X[r, rng.random(n) < 0.5] = np.nan
+    elif variant in ("split", "split2"):
+        # half of the rows miss 4 entries, the other half 30 of 60: neither complete nor near dense, and one half-step holds rows on
+        # both sides of the 2 k boundary (closed form next to the solver asked for).  split2: ten columns miss 3 entries only, so the
+        # columns split as well
+        for r in range(m):
+            X[r, rng.choice(n, 4 if r % 2 == 0 else 30, replace=False)] = np.nan
+        if variant == "split2":
+            for c in rng.choice(n, 10, replace=False):
+                X[:, c] = (0.5 * rng.integers(1, 11, m)).astype(dtype)
+                X[rng.choice(m, 3, replace=False), c] = np.nan
     d = dict(m=m, n=n, k=k, X=X)
     d["row"], d["col"] = [a.astype(np.int32) for a in np.nonzero(~np.isnan(X))]     # row-major order of the present entries
     d["ratings"] = X[d["row"], d["col"]]
@@ -1050,6 +1155,9 @@ DENSE_CASES = [
     ("holes, seeded", "holes", dict(use_cg=True, finalize_chol=True, seed=5)),
     ("near dense, seeded, user bias", "near", dict(use_cg=False, item_bias=False, seed=6)),
     ("full, seeded", "full", dict(use_cg=True, finalize_chol=False, seed=7)),
+    ("rows on both sides of the 2 k boundary, cg", "split", dict(use_cg=True, finalize_chol=False)),
+    ("rows and columns on both sides, cg + finalize, user bias", "split2", dict(use_cg=True, finalize_chol=True, item_bias=False)),
+    ("rows and columns on both sides, chol", "split2", dict(use_cg=False)),
 ]
 
 
@@ -1083,6 +1191,11 @@ def dense_oracle(O, d, variant, opts, nthreads=2):
     use_cg, fin = o.pop("use_cg", False), o.pop("finalize_chol", False)
     if W is None and variant in ("full", "near", "mixed"):
         use_cg = fin = False
+    if W is None and use_cg and variant in ("split", "split2"):
+        # Case 2 with rows on both sides of the boundary: closed form below 2 k missing entries, the solver asked for above
+        na_r = np.isnan(d["X"]).sum(1); na_c = np.isnan(d["X"]).sum(0)
+        few_r = 2 * (d["k"] + o.get("k_main", 0) + int(o.get("user_bias", True))); few_c = 2 * (d["k"] + o.get("k_main", 0) + int(o.get("item_bias", True)))
+        O.set_closed_form_rows(na_r < few_r, na_c < few_c)
     # rows / columns without a present entry: zero in the dense reference (factors and bias), left alone by the sparse path
     A0, B0, bA, bB = d["A0"].copy(), d["B0"].copy(), d["bA"].copy(), d["bB"].copy()
     er = np.bincount(d["row"], minlength=d["m"]) == 0; ec = np.bincount(d["col"], minlength=d["n"]) == 0

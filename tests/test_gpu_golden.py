@@ -342,6 +342,34 @@ def test_NA_as_zero_X_sideinfo(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_UI(oracles, dtype):
+    """G21 through the estimators (NA_as_zero_user / NA_as_zero_item with SciPy sparse U / I): the fits of the reference's
+    sparse missing-as-zero branches; the flag changes the model; the constant the reference keeps for new rows
+    (precomputedCtUbias = -w C^T colmeans, collective.c:9244-9252) is produced; more rows of U than X are refused."""
+    g = gc.load("g21_na_as_zero_UI", dtype)
+    d = gc.sparse_sideinfo_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.NAZ_UI_CASES):
+        got = gc.naz_ui_hip(d, implicit, which, sl, sls, solver, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        got = {key: v for key, v in got.items() if key in exp}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        ref = gc.naz_ui_oracle(oracles[dtype], d, implicit, which, sl, sls, solver)
+        assert gc.compare_fits(got, {key: v for key, v in ref.items() if key in exp}) < tol, name
+    name, implicit, which, sl, sls, solver = gc.NAZ_UI_CASES[2]
+    exp = {key[3:]: g[key] for key in g.files if key.startswith("c2_")}
+    plain = gc.naz_ui_hip(d, implicit, which, sl, sls, solver, dtype, flags=False)
+    assert gc.compare_fits({key: v for key, v in plain.items() if key in exp}, exp) > 1e-2
+    r = gc.naz_ui_hip(d, implicit, which, sl, sls, solver, dtype, precompute=True)
+    mdl = r["_model"]
+    want = -mdl.w_user * (mdl.C_.astype(np.float64).T @ mdl._U_colmeans.astype(np.float64))
+    assert mdl._CtUbias.shape == want.shape and np.abs(mdl._CtUbias - want).max() <= (1e-12 if dtype is np.float64 else 1e-5) * max(1.0, np.abs(want).max())
+    d2 = dict(d); c = d["U_coo"]; d2["U_coo"] = (c[0], c[1], c[2], d["m"] + 5, c[4])
+    with pytest.raises(RuntimeError):
+        gc.naz_ui_hip(d2, implicit, "U", sl, sls, solver, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_dense_X(oracles, dtype):
     """G19 through the estimator (CMF.fit(X = 2-D array with NaN)): every pattern of the reference's dense cases -- complete,
     nearly complete (closed form whatever use_cg says), half missing with an empty row and column (the solver asked for),
@@ -373,11 +401,11 @@ def test_dense_X(oracles, dtype):
         CMF(k=4, scale_lam=True, precompute_for_predictions=False).fit(dn["X"])
     with pytest.raises(RuntimeError):
         CMF(k=4, precompute_for_predictions=False).fit(dn["X"], U=np.ones((dn["m"], 2), dtype))
-    # ... and under use_cg a half-step whose rows partly miss few and partly many entries (two solvers in one half-step there)
-    dm = gc.dense_problem(dtype, "holes")["X"].copy()
-    dm[:20, :] = 1.0; dm[:20, :3] = np.nan
-    with pytest.raises(RuntimeError):
-        CMF(k=4, use_cg=True, precompute_for_predictions=False).fit(dm)
-    CMF(k=4, use_cg=False, precompute_for_predictions=False).fit(dm)
+    # under use_cg a half-step whose rows partly miss few and partly many entries runs both solvers (the 'split' cases above): the
+    # result is neither the all-CG nor the all-closed-form fit of the same entries
+    ds = gc.dense_problem(dtype, "split")
+    both = gc.dense_hip(ds, dict(use_cg=True, finalize_chol=False), dtype)
+    assert gc.compare_fits(gc.dense_hip(ds, dict(use_cg=True, finalize_chol=False), dtype, as_sparse=True), both) > 1e-4
+    assert gc.compare_fits(gc.dense_hip(ds, dict(use_cg=False), dtype), both) > 1e-4
     with pytest.raises(ValueError):
         CMF(k=4, NA_as_zero=True, precompute_for_predictions=False).fit(dn["X"])

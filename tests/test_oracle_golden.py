@@ -236,6 +236,20 @@ def test_NA_as_zero_X_sideinfo(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_UI(oracles, dtype):
+    """G21: NA_as_zero_U / NA_as_zero_I (the reference's sparse branches, collective.c:1277-1457, :5790-5836, C / D by optimizeA
+    Case 3 with the column means as a rank-one correction) against the restatement: the dense route on the zero-filled
+    matrices -- both models, closed form and CG, U on fewer rows than X."""
+    g = gc.load("g21_na_as_zero_UI", dtype)
+    d = gc.sparse_sideinfo_problem(dtype)
+    for ci, (name, implicit, which, sl, sls, solver) in enumerate(gc.NAZ_UI_CASES):
+        got = gc.naz_ui_oracle(oracles[dtype], d, implicit, which, sl, sls, solver)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        got = {key: v for key, v in got.items() if key in exp}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dense_X(oracles, dtype):
     """G19: fit_collective_explicit_als on a dense X with NaN (the reference's optimizeA Cases 1-2) against the restatement run
     on the present entries as a sparse X: closed form in the half-steps whose rows are all / nearly all complete (whatever

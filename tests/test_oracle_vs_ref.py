@@ -566,3 +566,21 @@ def test_NA_as_zero_sideinfo_fit_live(oracles, refs, dtype, shape):
     A0 = np.zeros((m, k), dtype); B0 = np.zeros((n, k), dtype)
     assert O.fit_explicit_als(A0, B0, row, col, val, k, U=U, II=II, niter=1, NA_as_zero_X=True, use_cg=True)["ret"] == 2
     assert O.fit_explicit_als(A0, B0, row, col, val, k, U=U[:m - 9], niter=1, NA_as_zero_X=True, use_cg=False)["ret"] == 2
+
+
+# ---- NA_as_zero_U / NA_as_zero_I: sparse side information whose absent entries are zeros ------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed", [77, 78])
+def test_NA_as_zero_UI_fit_live(oracles, refs, dtype, seed):
+    """The reference's sparse missing-as-zero branches for the side information (collective.c:1277-1457, :5790-5836; C / D by
+    optimizeA Case 3 with the column means as a rank-one correction, :8354-8441) against the restatement -- the dense route on the
+    zero-filled matrices, rows with neither an entry of X nor of the side information set to zero -- on fresh problems of G21's
+    shape (U on 80 of the 90 users, rows without entries on either side): both models, closed form and CG."""
+    import golden_cases as gc
+    d = gc.sparse_sideinfo_problem(dtype, seed=seed)
+    for name, implicit, which, sl, sls, solver in gc.NAZ_UI_CASES:
+        ref = gc.naz_ui_reference(refs[dtype], d, implicit, which, sl, sls, solver)
+        got = gc.naz_ui_oracle(oracles[dtype], d, implicit, which, sl, sls, solver)
+        for key, v in ref.items():
+            if v is not None and np.size(v) > 1:
+                assert rel_err(got[key], v) < 100 * TOL[dtype], (name, key)
