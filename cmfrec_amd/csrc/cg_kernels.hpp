@@ -385,7 +385,11 @@ __device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane)
 // GRAMX (explicit model only): block systems under CG (collective_block_cg with dense side information on every row and /
 // or implicit features, src/collective.c:2134-2903, no k_user offset): out -= / += G v on top of the gathered part, G staged
 // in LDS exactly like the implicit model's B^T B, and a per-row constant in the first residual.
-template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
+// NRES_: resident tiles per wavefront (0: two for the 8-wave teams of the single-precision build, one otherwise).  Round 4: the
+// single-precision rows of 257..512 entries run on FOUR waves with two tiles each instead of eight waves of which three to
+// five only take part in the barriers (config 4: the 257..1024 bin ran at 0.43-0.46 of the HBM peak against 0.55-0.62 for the
+// 4-wave bin below it).
+template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0>
 __global__ void __launch_bounds__(64 * W * RPB, CMF_CG_WAVES_PER_SIMD)
 cg_rows_kernel(const CgParams<T> P)
 {
@@ -443,7 +447,8 @@ cg_rows_kernel(const CgParams<T> P)
     // Single precision, 8-wave teams: a wavefront keeps TWO tiles (2 x 64 VGPRs), so rows up to 1024 entries -- the whole bin
     // of this launch -- are gathered once instead of once per pass (config 4: the bin ran at 2.9 TB/s against 4.5-5.2 for
     // the bins that already were resident).  The register budget goes from three to two wavefronts per SIMD.
-    constexpr int NRES = (std::is_same<T, float>::value && W == 8) ? 2 : 1;
+    constexpr int NRES = NRES_ > 0 ? NRES_ : ((std::is_same<T, float>::value && W == 8) ? 2 : 1);
+    static_assert(NRES == 1 || std::is_same<T, float>::value, "two resident tiles: single precision");
     struct Pre { int idx; T x; T a; int idx2; T x2; T g; T g2; };
     auto load_desc = [&](int rix_) -> RowDesc {
         RowDesc d; d.row = 0; d.nnz = 0; d.st = 0;
@@ -722,8 +727,44 @@ __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (
 #define CMF_TINY_WAVES_PER_SIMD 4     // 4: single tile buffer in a 128-VGPR budget (measured 10 % faster than
                                       // 2: double-buffered tiles, 2 x 56 VGPRs, 2 waves/SIMD)
 #endif
+// CMF_TINY_GREG (experiment, round 4): the lane's 8 x S Gramian elements live in REGISTERS for the whole launch instead of being
+// read from LDS in every pass (28 ds_read2_b64 per pass and wavefront in double precision: with four wavefronts per SIMD the
+// LDS pipe of the CU is ~70 % busy with them).  Costs 16 S registers (double), i.e. two wavefronts per SIMD instead of four.
+#ifdef CMF_TINY_GREG
+#define CMF_TINY_LB 2
+#else
+#define CMF_TINY_LB CMF_TINY_WAVES_PER_SIMD
+#endif
+template <typename T, int S>
+struct GramRegs {
+    T v[8][S];
+    __device__ __forceinline__ void load(const T *__restrict__ G, int lane)
+    {
+        const int jj = lane >> 3, ll = lane & 7;
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+#pragma unroll
+            for (int s = 0; s < S; s++) v[t][s] = G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
+    }
+};
+template <typename T, int S>
+__device__ __forceinline__ void gram_pass_regs(const GramRegs<T, S> &R, T wdist, PassAcc<T> &out)
+{
+    T wts[8];
+    wts[0] = lanes::bcast8<0>(wdist); wts[1] = lanes::bcast8<1>(wdist); wts[2] = lanes::bcast8<2>(wdist);
+    wts[3] = lanes::bcast8<3>(wdist); wts[4] = lanes::bcast8<4>(wdist); wts[5] = lanes::bcast8<5>(wdist);
+    wts[6] = lanes::bcast8<6>(wdist); wts[7] = lanes::bcast8<7>(wdist);
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * R.v[t][s];
+            else out.v[s] += wts[t] * R.v[t][s];
+        }
+}
+
 template <typename T, int S, bool IMPLICIT, bool GRAMX = false>
-__global__ void __launch_bounds__(256, CMF_TINY_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(256, CMF_TINY_LB)
 cg_rows_tiny_kernel(const CgParams<T> P)
 {
     constexpr bool GRAM = IMPLICIT || GRAMX;
@@ -736,6 +777,10 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
         __syncthreads();
     }
+#ifdef CMF_TINY_GREG
+    GramRegs<T, S> greg;
+    if (GRAM) greg.load(G, lane);
+#endif
     const int nwaves = gridDim.x * 4;
     struct Pre { int idx; T x; T a; T g; };
     auto load_desc = [&](int rix_) -> RowDesc {
@@ -784,7 +829,11 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             PassAcc<T> acc;
             acc.zero();
             if (!CMF_DBG(P, 4)) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
+#ifdef CMF_TINY_GREG
+            if (GRAM && !CMF_DBG(P, 2)) gram_pass_regs<T, S>(greg, (MODE == 0) ? -vdist : vdist, acc);
+#else
             if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
+#endif
             T out[8];
             acc.close(out);
             return treduce8_high<T>(out, lane);

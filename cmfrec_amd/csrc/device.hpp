@@ -143,6 +143,7 @@ struct SparseShard {
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
     int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
+    int n_gt512 = 0;         // rows with more than 512 entries (single precision: the 257..512 part of the heavy bin runs on 4-wave teams)
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
     // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
@@ -263,7 +264,7 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0; n_long = 0; n_gt16 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
+        n_empty = 0; n_long = 0; n_gt16 = 0; n_gt512 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         // few split rows (C2's users: 50 rows, 65 k entries): short slices, so that their Gramian kernels -- which run in line
@@ -286,6 +287,7 @@ struct SparseShard {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
             if (l > 16) n_gt16++;
+            if (l > 512) n_gt512++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -584,8 +586,8 @@ inline void poison_lds(hipStream_t st, int num_cus)
     HIP_CHECK(hipGetLastError());
 }
 
-template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false>
-inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st)
+template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0>
+inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st, int counter_set = -1)
 {
     if (count <= 0) return;
     EventPair ev{nullptr, nullptr};
@@ -598,10 +600,10 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     P.order += first;
     P.desc += first;
     P.nrows = count;
-    P.counter = dev.row_counter.ptr + cg_counter_offset(bin);          // zeroed by launch_cg_S
+    P.counter = dev.row_counter.ptr + cg_counter_offset(counter_set >= 0 ? counter_set : bin);          // zeroed by launch_cg_S
     constexpr int threads = 64 * W * RPB;
     size_t smem = (((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
-    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB, GRAMX>;
+    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB, GRAMX, NRES_>;
     // per device: the dynamic-LDS attribute and the occupancy belong to the device the kernel was loaded on
     static thread_local int bpc_dev[MAX_DEVICES] = {0};
     int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
@@ -786,13 +788,34 @@ inline int cg_bin_streams()
     return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
 }
 
+// CMFREC_HIP_HEAVY_SPLIT=0: the whole 257..1024 bin on eight-wave teams in single precision too (A/B switch, cross-check)
+inline bool heavy_split_off()
+{
+    static const bool off = getenv("CMFREC_HIP_HEAVY_SPLIT") != nullptr && getenv("CMFREC_HIP_HEAVY_SPLIT")[0] == '0';
+    return off;
+}
+
 // one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row)
 template <int S, bool IMPLICIT, bool GRAMX>
 inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm, int bin, hipStream_t st)
 {
     const int first = X.bin_first[bin], count = X.bin_rows[bin];
     switch (bin) {
-        case BIN_HEAVY: launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
+        case BIN_HEAVY:
+#ifdef CMFREC_HIP_FLOAT
+            if (!heavy_split_off()) {
+                // single precision: rows of 257..512 entries on four waves with two resident tiles each (cg_rows_kernel, NRES_),
+                // the longer ones on eight; one event pair around both launches, the second on a spare counter set
+                const int n_long8 = std::min(count, std::max(0, X.n_gt512 - first));
+                EventPair ev{nullptr, nullptr};
+                if (tm) { HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); HIP_CHECK(hipEventRecord(ev.a, st)); }
+                launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, n_long8, nullptr, bin, st);
+                launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX, 2>(dev, P, first + n_long8, count - n_long8, nullptr, bin, st, NBINS);
+                if (tm) { HIP_CHECK(hipEventRecord(ev.b, st)); tm->ev[bin].push_back(ev); }
+                break;
+            }
+#endif
+            launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
         case BIN_MED4: launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
         case BIN_MED2: launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
         default: launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st); break;
