@@ -727,14 +727,16 @@ __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (
 #define CMF_TINY_WAVES_PER_SIMD 4     // 4: single tile buffer in a 128-VGPR budget (measured 10 % faster than
                                       // 2: double-buffered tiles, 2 x 56 VGPRs, 2 waves/SIMD)
 #endif
-// CMF_TINY_GREG (experiment, round 4): the lane's 8 x S Gramian elements live in REGISTERS for the whole launch instead of being
-// read from LDS in every pass (28 ds_read2_b64 per pass and wavefront in double precision: with four wavefronts per SIMD the
-// LDS pipe of the CU is ~70 % busy with them).  Costs 16 S registers (double), i.e. two wavefronts per SIMD instead of four.
-#ifdef CMF_TINY_GREG
-#define CMF_TINY_LB 2
-#else
-#define CMF_TINY_LB CMF_TINY_WAVES_PER_SIMD
+// Round 4: in double precision the lane's 8 x S Gramian elements of the tiny kernel live in REGISTERS for the whole launch instead
+// of being read from LDS in every pass (28 ds_read2_b64 per pass and wavefront: with four wavefronts per SIMD the LDS pipe of the CU
+// was ~70 % busy with them).  Costs 16 S registers, i.e. two wavefronts per SIMD instead of four for the kernels that carry a
+// Gramian (C2: tiny bin 0.502 -> 0.476 ms users, 0.166 -> 0.148 ms items, iteration 3.70 -> 3.65 ms; profiles/r04).  The
+// two-rows-per-wavefront kernel below would need 32 S registers and keeps its Gramian in LDS.
+#ifndef CMF_TINY_GREG_F32
+#define CMF_TINY_GREG_F32 1          // single precision: 8 S registers more per lane, three wavefronts per SIMD (c4shard 8.03-8.17 -> 7.91-7.92 ms; 0 = Gramian in LDS)
 #endif
+template <typename T, bool GRAM> constexpr bool tiny_greg() { return GRAM && (sizeof(T) == 8 || CMF_TINY_GREG_F32 != 0); }
+template <typename T, bool GRAM> constexpr int tiny_waves_per_simd() { return tiny_greg<T, GRAM>() ? (sizeof(T) == 8 ? 2 : 3) : CMF_TINY_WAVES_PER_SIMD; }
 template <typename T, int S>
 struct GramRegs {
     T v[8][S];
@@ -747,6 +749,35 @@ struct GramRegs {
             for (int s = 0; s < S; s++) v[t][s] = G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
     }
 };
+// single precision: the row pairs (2q, 2q+1) as the register pairs a v_pk_fma_f32 wants (the LDS layout of gram_index)
+template <int S>
+struct GramRegs<float, S> {
+    f32x2 v[4][S];
+    __device__ __forceinline__ void load(const float *__restrict__ G, int lane)
+    {
+        const int jj = lane >> 3, ll = lane & 7;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (jj * 4 + q) * gram_ld2(S) + ll;
+#pragma unroll
+            for (int s = 0; s < S; s++) v[q][s] = g[8 * s];
+        }
+    }
+};
+template <int S>
+__device__ __forceinline__ void gram_pass_regs(const GramRegs<float, S> &R, float wdist, PassAcc<float> &out)
+{
+    float wts[8];
+    wts[0] = lanes::bcast8<0>(wdist); wts[1] = lanes::bcast8<1>(wdist); wts[2] = lanes::bcast8<2>(wdist);
+    wts[3] = lanes::bcast8<3>(wdist); wts[4] = lanes::bcast8<4>(wdist); wts[5] = lanes::bcast8<5>(wdist);
+    wts[6] = lanes::bcast8<6>(wdist); wts[7] = lanes::bcast8<7>(wdist);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += w2 * R.v[q][s];
+    }
+}
 template <typename T, int S>
 __device__ __forceinline__ void gram_pass_regs(const GramRegs<T, S> &R, T wdist, PassAcc<T> &out)
 {
@@ -757,14 +788,11 @@ __device__ __forceinline__ void gram_pass_regs(const GramRegs<T, S> &R, T wdist,
 #pragma unroll
     for (int t = 0; t < 8; t++)
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * R.v[t][s];
-            else out.v[s] += wts[t] * R.v[t][s];
-        }
+        for (int s = 0; s < S; s++) out.v[s] += wts[t] * R.v[t][s];
 }
 
 template <typename T, int S, bool IMPLICIT, bool GRAMX = false>
-__global__ void __launch_bounds__(256, CMF_TINY_LB)
+__global__ void __launch_bounds__(256, (tiny_waves_per_simd<T, IMPLICIT || GRAMX>()))
 cg_rows_tiny_kernel(const CgParams<T> P)
 {
     constexpr bool GRAM = IMPLICIT || GRAMX;
@@ -777,10 +805,9 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
         __syncthreads();
     }
-#ifdef CMF_TINY_GREG
-    GramRegs<T, S> greg;
-    if (GRAM) greg.load(G, lane);
-#endif
+    constexpr bool GREG = tiny_greg<T, GRAM>();
+    GramRegs<T, GREG ? S : 1> greg;
+    if constexpr (GREG) greg.load(G, lane);
     const int nwaves = gridDim.x * 4;
     struct Pre { int idx; T x; T a; T g; };
     auto load_desc = [&](int rix_) -> RowDesc {
@@ -829,11 +856,8 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             PassAcc<T> acc;
             acc.zero();
             if (!CMF_DBG(P, 4)) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
-#ifdef CMF_TINY_GREG
-            if (GRAM && !CMF_DBG(P, 2)) gram_pass_regs<T, S>(greg, (MODE == 0) ? -vdist : vdist, acc);
-#else
-            if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
-#endif
+            if constexpr (GREG) { if (!CMF_DBG(P, 2)) gram_pass_regs(greg, (MODE == 0) ? -vdist : vdist, acc); }
+            else if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
             acc.close(out);
             return treduce8_high<T>(out, lane);

@@ -554,6 +554,7 @@ struct CgCall {
     int ki = 0;
     real_t w_imp = 0;
     const real_t *gsum = nullptr;     // [rows, ki]: sum of the rows of Bi at each row's observed positions (segmented gather-sum), or null
+    int skip_first = 0;               // generic kernel: the first positions of the processing order are solved elsewhere (session.hip, launch_cg_wide)
 };
 
 enum class CgVariant { Auto, Generic };
@@ -900,29 +901,29 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
 }
 
 template <int NF, bool IMPLICIT>
-inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X)
+inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, int first = 0)
 {
     int count = (P.kc > 0 || P.Bi != nullptr) ? X.nrows : X.n_nonempty;   // rows without entries still have side information / get zeroed
-    if (count <= 0) return;
+    if (count <= first) return;
     // rows of 129 non-zeros and more (they lead the processing order): a workgroup per row -- sixteen wavefronts for the
     // rows beyond 1024 non-zeros (the longest row is the critical path of the launch: C1's items with implicit features
     // 31 -> 13 ms), four for the others; the rest: a wavefront per row
     const int nteam = std::min(count, X.bin_first[BIN_MED2]);
     const int nvh = std::min(nteam, X.bin_rows[BIN_VHEAVY]);
     poison_lds(dev.stream, dev.num_cus);
-    if (nvh > 0) {
-        P.row_first = 0; P.nrows = nvh;
-        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 16>), dim3(std::min(nvh, dev.num_cus * 2)), dim3(1024), 0,
+    if (nvh > first) {
+        P.row_first = first; P.nrows = nvh;
+        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 16>), dim3(std::min(nvh - first, dev.num_cus * 2)), dim3(1024), 0,
                            dev.stream, P);
     }
-    if (nteam > nvh) {
-        P.row_first = nvh; P.nrows = nteam;
-        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 4>), dim3(std::min(nteam - nvh, dev.num_cus * 8)), dim3(256), 0,
+    if (nteam > std::max(nvh, first)) {
+        P.row_first = std::max(nvh, first); P.nrows = nteam;
+        hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 4>), dim3(std::min(nteam - P.row_first, dev.num_cus * 8)), dim3(256), 0,
                            dev.stream, P);
     }
-    if (count > nteam) {
-        P.row_first = nteam; P.nrows = count;
-        int grid = std::min((count - nteam + 3) / 4, dev.num_cus * 8);
+    if (count > std::max(nteam, first)) {
+        P.row_first = std::max(nteam, first); P.nrows = count;
+        int grid = std::min((count - P.row_first + 3) / 4, dev.num_cus * 8);
         hipLaunchKernelGGL((cg_rows_generic_kernel<real_t, NF, IMPLICIT, 1>), dim3(grid), dim3(256), 0, dev.stream, P);
     }
     HIP_CHECK(hipGetLastError());
@@ -952,7 +953,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     // constant w (U C)_row + w_i sum Bi_j joins the first residual (GRAMX builds, cg_kernels.hpp).  Rows without entries
     // (still solved from their side information / zeroed) go through the generic kernel afterwards.
     const bool block = (c.kc > 0 || c.Bi != nullptr);
-    const bool tiled_block = block && cg_variant_from_env() != CgVariant::Generic && !c.implicit && c.koff == 0 && !c.precond &&
+    const bool tiled_block = block && cg_variant_from_env() != CgVariant::Generic && !c.implicit && c.koff == 0 && !c.precond && c.skip_first == 0 &&
                              S <= 8 && c.X2 == nullptr && (c.kc == 0 || (c.rows_with_u >= X.nrows && c.CtC != nullptr && c.UC != nullptr)) &&
                              (c.Bi == nullptr || (c.gsum != nullptr && c.BiTBi != nullptr)) && c.kc <= c.k && c.ki <= c.k;
     if (tiled_block) {
@@ -988,7 +989,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     }
     // the Jacobi-preconditioned variants (not a default anywhere in the reference) and the remaining block systems run on the
     // generic kernel
-    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond || c.kc > 0 || c.Bi != nullptr;
+    const bool generic = cg_variant_from_env() == CgVariant::Generic || S > 8 || c.precond || c.kc > 0 || c.Bi != nullptr || c.skip_first > 0;
     if (!generic) {
 #define CMF_CASE(SS)                                                        \
     case SS:                                                                \
@@ -1004,8 +1005,8 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     const int NF = (c.koff + c.k + 63) / 64;
 #define CMF_GCASE(NN)                                                       \
     case NN:                                                                \
-        if (c.implicit) launch_cg_generic<NN, true>(dev, P, X);             \
-        else            launch_cg_generic<NN, false>(dev, P, X);            \
+        if (c.implicit) launch_cg_generic<NN, true>(dev, P, X, c.skip_first);  \
+        else            launch_cg_generic<NN, false>(dev, P, X, c.skip_first); \
         return 0;
     switch (NF) {
         CMF_GCASE(1) CMF_GCASE(2) CMF_GCASE(3) CMF_GCASE(4) CMF_GCASE(5)

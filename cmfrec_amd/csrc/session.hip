@@ -10,6 +10,7 @@
 #include "chol_wave_kernels.hpp"
 #include "gramk_kernels.hpp"
 #include "lowrank_kernels.hpp"
+#include "gram_cg_wide_kernels.hpp"
 #include <dlfcn.h>
 #include <functional>
 #include <memory>
@@ -60,6 +61,9 @@ struct CholCall {
     bool rhs_only = false;                   // CHOL_NAZ: gather the right-hand sides only
     bool rhs_prefilled_all = false;          // every row starts from the right-hand side left in A
     int row_limit = -1;                      // only the first row_limit positions of the processing order (the others are solved elsewhere)
+    // CG on the row's Gramian instead of the factorisation (gram_cg_wide_kernels.hpp): the producer build of the wave kernel runs
+    // every row's rank-k update, gram_cg_wide_kernel takes the partials; the parameters of the CG (explicit model)
+    const CgParams<real_t> *cg_wide = nullptr;
 };
 
 static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, CholParams<real_t> P, bool two_src,
@@ -175,7 +179,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             }
             SLT.n_heavy = n_heavy;
             { static const int skip = getenv("CMFREC_HIP_WAVE_SKIP") ? atoi(getenv("CMFREC_HIP_WAVE_SKIP")) : 0; SLT.dbg_skip = skip; }
-            if (sizeof(real_t) == 8 && nbw > 6) {
+            const bool cg_wide = c.cg_wide != nullptr;
+            if ((sizeof(real_t) == 8 && nbw > 6) || cg_wide) {
+                // (cg_wide: the second kernel is the CG on the summed partials, gram_cg_wide_kernels.hpp -- every precision and width)
                 // Two kernels (7 and 8 blocks in double: 28 / 36 tiles of 8 registers + the factorisation's temporaries exceed
                 // what one kernel can keep in registers -- hipcc emits the accumulator-file form of the MFMAs at one wave per
                 // SIMD, 256 registers for all MFMA destinations).  The producer build runs every row's rank-k update at full
@@ -191,7 +197,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 SLT.part = X->chol_part.ptr;
                 // the launch's initial matrices once, in the tile layout of the partials (the row kernel then adds them like a
                 // partial, 16 values per round trip, instead of 144 dependent loads per row)
-                {
+                if (!cg_wide) {
                     const bool fullm = (c.mode == CHOL_IMPLICIT);
                     const real_t *M1 = fullm ? c.Minit : c.Mfull, *M2 = fullm ? nullptr : c.Minit;
                     const size_t tl = (size_t)36 * 256;
@@ -212,6 +218,19 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                     CholSlices<real_t> SL = SLT;
                     SL.part_base = item0;
                     wave_launch(1, item0, item1, ctr, SL, dev.stream);
+                    if (cg_wide) {
+                        WideCgParams<real_t> Wp;
+                        Wp.part = SL.part; Wp.part_base = item0; Wp.NB = nb_inst; Wp.border = border ? 1 : 0;
+                        Wp.row_off = X->row_sl_off.ptr; Wp.n_heavy = n_heavy; Wp.n_slices = nsl;
+                        Wp.row_first = row0; Wp.row_last = row1;
+                        const size_t smem = gcw_lds_elems<real_t>(c.kt) * sizeof(real_t);
+                        auto kern = gram_cg_wide_kernel<real_t>;
+                        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                        const int per_cu = std::max(1, (int)((size_t)160 * 1024 / smem));
+                        poison_lds(dev.stream, dev.num_cus);
+                        hipLaunchKernelGGL(kern, dim3(std::min(row1 - row0, dev.num_cus * per_cu)), dim3(64 * GCW_NW), smem, dev.stream, *c.cg_wide, Wp);
+                        HIP_CHECK(hipGetLastError());
+                    } else
                     wave_launch(2, row0, row1, ctr + 1, SL, dev.stream);
                     ctr += 2;
                 };
@@ -457,6 +476,49 @@ static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real
     launch_gemm<false>(dev, rows, k, k, (real_t)1, X, ldx, Minv, (size_t)k, d.potrs_tmp.ptr, (size_t)k);
     HIP_CHECK(hipMemcpy2DAsync(X, ldx * sizeof(real_t), d.potrs_tmp.ptr, (size_t)k * sizeof(real_t), (size_t)k * sizeof(real_t), (size_t)rows,
                                hipMemcpyDeviceToDevice, dev.stream));
+}
+
+// CG of the explicit model beyond 64 unknowns (k_t <= 129): through the row's Gramian (gram_cg_wide_kernels.hpp) instead of the
+// lane <-> unknown kernel.  -1: not applicable (the caller takes launch_cg).  CMFREC_HIP_CG_KERNEL=generic keeps the generic kernel
+// (A/B switch and on-device cross-check).
+static int launch_cg_wide(const DeviceInfo &dev, const CgCall &c, const SparseShard &X)
+{
+    const bool border = (c.k > 16) && ((c.k - 1) % 16 == 0);
+    const int nbw = (c.k - (border ? 1 : 0) + 15) / 16;
+    static const char *chol_env = getenv("CMFREC_HIP_CHOL");
+    if (c.implicit || c.k <= 64 || nbw > 8 || c.precond || c.X2 != nullptr || c.Bi != nullptr || c.koff != 0 || X.weighted() ||
+        cg_variant_from_env() == CgVariant::Generic || (chol_env != nullptr && strcmp(chol_env, "rows") == 0) ||
+        (c.kc > 0 && (c.CtC == nullptr || c.UC == nullptr || c.kc > c.k)) || gcw_lds_elems<real_t>(c.k) * sizeof(real_t) > (size_t)160 * 1024)
+        return -1;
+    CgParams<real_t> P;
+    P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.k = c.k;
+    P.indptr = X.p.ptr; P.indices = X.i.ptr; P.values = X.v.ptr;
+    P.bias_sub = c.bias_sub; P.order = X.order.ptr; P.desc = X.desc.ptr; P.nrows = 0; P.BtB = nullptr;
+    P.lam = c.lam; P.lam_last = c.lam_last;
+    P.scale_lam = c.scale_lam; P.scale_bias_const = c.scale_bias_const;
+    P.max_cg_steps = c.max_cg_steps; P.precond = 0;
+    P.koff = 0; P.kc = c.kc; P.CtC = c.CtC; P.UC = c.UC; P.w_side = c.w_side;
+    P.rows_with_u = c.rows_with_u; P.p_side = c.p_side; P.scale_lam_sideinfo = c.scale_lam_sideinfo ? 1 : 0;
+    // The Gramian costs k_t / 8 times the products of the CG's four passes per entry and saves three of the four gathers and the
+    // generic kernel's wave-wide reduction per gathered row: it pays on the long rows (config 3's items under CG: 18.1 -> 6.8 ms)
+    // and loses on the short ones (its users, 143 entries per row on average: 8.6 -> 15.8 ms).  So the rows beyond 256 entries --
+    // they lead the processing order -- take it, the others stay on the lane <-> unknown kernel (CgCall::skip_first).
+    const int n_wide = X.rows_longer_than(256, X.n_nonempty);
+    if (n_wide <= 0) return -1;
+    CholCall cc{c.A, c.lda, c.B, c.ldb, c.k, 0, c.bias_sub, nullptr, 0, 0, 0, c.lam, c.lam_last, c.scale_lam, c.scale_lam_sideinfo,
+                c.scale_bias_const, CHOL_EXPLICIT};
+    cc.cg_wide = &P;
+    cc.row_limit = n_wide;
+    int rc = launch_chol(dev, cc, &X);                    // positions [0, n_wide)
+    if (rc) return rc;
+    CgCall rest = c;
+    rest.skip_first = n_wide;
+    return launch_cg(dev, rest, X, nullptr);              // the shorter rows, and a block system's rows without entries
+}
+static int launch_cg_any(const DeviceInfo &dev, const CgCall &c, const SparseShard &X, BinTimers *tm = nullptr)
+{
+    const int rc = launch_cg_wide(dev, c, X);
+    return rc >= 0 ? rc : launch_cg(dev, c, X, tm);
 }
 
 // Eigenvectors / values of one side's shared matrix w C^T C.  The decomposition is a chain of some four thousand small
@@ -1638,7 +1700,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
                      (bool)m.precondition_cg};
             c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
             c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo; c.X2 = &Us; c.C2 = Cm;
-            return launch_cg(dev, c, X, nullptr);
+            return launch_cg_any(dev, c, X, nullptr);
         }
         if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822, :6018-6019
         if (m.implicit) {
@@ -1704,7 +1766,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
             c.Bi = Fi; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
             if (part < 0 && launch_gsum(s, isA, X, Fi, kk)) c.gsum = s->grhs.ptr;
         }
-        int rc = launch_cg(dev, c, X, nullptr);
+        int rc = launch_cg_any(dev, c, X, nullptr);
         if (rc) return rc;
         return solve_sideinfo_only_rows(s, isA, false, local_u_main, local_u - local_u_main);
     }
@@ -1739,7 +1801,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         }
         CgCall c{self_blk + k_side_self, ld_self, opp + k_side_opp, ld_opp, kk, nullptr, s->gram.ptr,
                  lam_self, lam_last_self, false, false, m.max_cg_steps, true, (bool)m.precondition_cg};
-        return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
+        return launch_cg_any(dev, c, X, isA ? &s->binA : &s->binB);
     }
 
     // ---- explicit ----
@@ -1849,7 +1911,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         c.Bi = Fc; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
         if (part < 0 && launch_gsum(s, isA, X, Fc, kk)) c.gsum = s->grhs.ptr;
     }
-    return launch_cg(dev, c, X, isA ? &s->binA : &s->binB);
+    return launch_cg_any(dev, c, X, isA ? &s->binA : &s->binB);
 }
 
 // Ai / Bi update: optimizeA Case 3 on the binary indicator of X (collective.c:8448-8534; common.c:3116-3205): one
@@ -1919,7 +1981,7 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol)
         if (!chol) {
             CgCall cg{Cm, (size_t)kc, F, ldF, kc, nullptr, nullptr, lam, lam, scale_lam, false, m.max_cg_steps, false,
                       (bool)m.precondition_cg};
-            return launch_cg(dev, cg, Uc);
+            return launch_cg_any(dev, cg, Uc);
         }
         CholCall c{Cm, (size_t)kc, F, ldF, kc, 0, nullptr, nullptr, 0, 0, 0, lam, lam, scale_lam, false, false, CHOL_EXPLICIT};
         return launch_chol(dev, c, &Uc);
@@ -2296,7 +2358,7 @@ int cmfrec_hip_optimizeA_implicit(real_t *A, size_t lda, const real_t *B, size_t
         int rc;
         if (use_cg) {
             CgCall c{dA.ptr, lda, dB.ptr, ldb, k, nullptr, dG.ptr, lam, lam, false, false, max_cg_steps, true, precondition_cg};
-            rc = launch_cg(dev, c, X);
+            rc = launch_cg_any(dev, c, X);
         } else {
             // common.c:3334 zeroes m*k - (lda-k) elements from A
             HIP_CHECK(hipMemsetAsync(dA.ptr, 0, ((size_t)m * lda - (lda - (size_t)k)) * sizeof(real_t), dev.stream));
@@ -2342,7 +2404,7 @@ int cmfrec_hip_optimizeA_explicit_weighted(real_t *A, size_t lda, const real_t *
         if (use_cg) {
             CgCall c{dA.ptr, lda, dB.ptr, ldb, k, bias_sub ? dbias.ptr : nullptr, nullptr, lam, lam_last, scale_lam,
                      scale_bias_const, max_cg_steps, false, precondition_cg};
-            rc = launch_cg(dev, c, X);
+            rc = launch_cg_any(dev, c, X);
         } else {
             CholCall c{dA.ptr, lda, dB.ptr, ldb, k, 0, bias_sub ? dbias.ptr : nullptr, nullptr, 0, 0, 0, lam, lam_last,
                        scale_lam, false, scale_bias_const, CHOL_EXPLICIT};

@@ -161,6 +161,31 @@ def test_fit_sideinfo_block_cg(oracles, dtype, implicit, pcg, ku, ki, km, m_u, f
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k,km", [(96, 0), (127, 1)])
+def test_fit_sideinfo_block_cg_beyond_64_unknowns(oracles, dtype, k, km):
+    """The block CG of the collective system with more than 64 unknowns per row (config 3's shape under use_cg): rank-k update by
+    the Cholesky producer, CG on the row's Gramian + w C^T C (gram_cg_wide_kernels.hpp), dense side information on both sides, biases,
+    both lambda scalings; rows without entries are solved from their side information alone."""
+    from cmfrec_amd import CMF
+    O = oracles[dtype]
+    m, n, p, q = 260, 200, 12, 9
+    row, col, val = make_coo(m, n, 9000, 31, counts=False, dtype=dtype, empty_rows=(3, 250))
+    rng = np.random.default_rng(6)
+    U = (rng.standard_normal((m, p)) + 1).astype(dtype); II = (rng.standard_normal((n, q)) - 2).astype(dtype)
+    A0 = (rng.standard_normal((m, k + km)) * 0.01).astype(dtype); B0 = (rng.standard_normal((n, k + km)) * 0.01).astype(dtype)
+    Ao, Bo = A0.copy(), B0.copy()
+    kw = dict(niter=3, use_cg=True, finalize_chol=False, k_main=km, w_user=0.5, w_item=2.0, scale_lam=True, scale_lam_sideinfo=km > 0)
+    mdl = CMF(k=k, lambda_=0.05, use_float=dtype is np.float32, nthreads=1, **kw).fit((row, col, val), shape=(m, n), U=U, I=II, A0=A0, B0=B0)
+    ro = O.fit_explicit_als(Ao, Bo, row, col, val, k, lam=0.05, U=U, II=II, nthreads=1, **kw)
+    t = tol(dtype, "cg")
+    assert ro["ret"] == 0
+    assert frob(mdl.A_, Ao) < t and frob(mdl.B_, Bo) < t
+    assert frob(mdl.C_, ro["C"]) < t and frob(mdl.D_, ro["D"]) < t
+    assert frob(mdl.user_bias_, ro["biasA"]) < t and frob(mdl.item_bias_, ro["biasB"]) < t
+    assert np.abs(mdl.A_[3]).max() > 0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("implicit", [False, True])
 @pytest.mark.parametrize("cg,ku,ki,km", [(False, 0, 0, 0), (False, 2, 3, 1), (True, 1, 0, 2)])
 def test_fit_sideinfo_beyond_X(oracles, dtype, implicit, cg, ku, ki, km):

@@ -496,7 +496,9 @@ def test_observation_weights_every_row_length(oracles, dtype, mode, k):
     ops.optimizeA_explicit(Au, B, csr, 0.05, bias_sub=bias, **kw)
     A1 = A0.copy()
     ops.optimizeA_explicit(A1, B, csr, 0.05, bias_sub=bias, weight=np.ones_like(w_csr), **kw)
-    if mode == "chol":       # (weighted Cholesky launches stay on the workgroup-per-row kernel: another summation order)
+    if mode == "chol" or (mode == "cg" and k > 64):
+        # (weighted Cholesky launches stay on the workgroup-per-row kernel, weighted CG beyond 64 unknowns on the lane <-> unknown
+        #  kernel while the unweighted one goes through the row's Gramian: other summation orders)
         assert rel_err(A1, Au) < TOL[dtype]
     else:
         assert np.array_equal(A1, Au)
@@ -531,3 +533,37 @@ def test_observation_weights_split_rows(oracles, dtype, vh, monkeypatch):
     O.optimizeA_explicit(Ao, B, csr, 0.05, lam_last=0.3, scale_lam=True, nthreads=4, weight=w_csr, wsum=wsum)
     assert rel_err(Ah, Ao) < TOL[dtype]
     check_rows(Ah, Ao, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("k", [65, 80, 97, 100, 128, 129])
+def test_explicit_cg_beyond_64_unknowns(oracles, dtype, k):
+    """Explicit-model CG with 64 < k <= 129 unknowns (round 4): the Cholesky path's producer builds the row's Gramian on the matrix
+    cores, gram_cg_wide_kernel runs the reference's CG steps on it (gram_cg_wide_kernels.hpp) -- every tile grid of the producer
+    (4 / 6 / 8 blocks, with and without the border column), rows of every length 0 .. 150, four- and eight-wave lengths, split rows
+    (2500 and 4500 entries: partials summed in slice order), the fused bias subtraction, scale_lam with its own lambda on the last
+    unknown.  The rows beyond 256 entries take this path, the shorter ones the lane <-> unknown kernel.  Row by row against the
+    oracle."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    lens = list(range(0, 151)) + [250, 257, 512, 513, 777, 1024, 2500, 4500]
+    m, n = len(lens), 5000
+    rng = np.random.default_rng(900 + k)
+    rows = [np.full(c, r, np.int32) for r, c in enumerate(lens)]
+    cols = [rng.choice(n, c, replace=False).astype(np.int32) for c in lens]
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
+    val = (0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+    for scale_lam in (True, False):
+        kw = dict(lam_last=0.3, scale_lam=scale_lam, use_cg=True)
+        Ah, Ao = A0.copy(), A0.copy()
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, bias_sub=bias, **kw)
+        csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+        O.optimizeA_explicit(Ao, B, csr_b, 0.05, nthreads=4, **kw)
+        assert rel_err(Ah, Ao) < TOL[dtype]
+        check_rows(Ah, Ao, dtype)
+        assert np.array_equal(Ah[0], A0[0])                  # a row without entries stays as it is
