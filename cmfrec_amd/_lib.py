@@ -70,10 +70,13 @@ def load(dtype=np.float64):
     # process; if this library's copy came first, a later `import torch` would run on a runtime its other libraries were not
     # built against ("No HIP GPUs are available").  The package uses torch for device memory and streams anyway, so it goes
     # first whenever it is installed.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # A process that will never import torch can skip this (seconds of import time, torch's HIP runtime initialised):
+    # CMFREC_AMD_NO_TORCH_PRELOAD=1.  The ordering requirement then is the caller's: torch, if it comes at all, before this library.
+    if os.environ.get("CMFREC_AMD_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     lib.cmfrec_hip_last_error.restype = C.c_char_p
     lib.cmfrec_hip_build_info.restype = C.c_char_p

@@ -442,6 +442,9 @@ struct BinTimers {
 
 // ------------------------------------------------------------------------------------------
 // dense contractions
+// per-thread override of CMFREC_HIP_GEMM_OWN (-1: follow the environment; 0 rocBLAS; 1 the library's own kernel): what
+// cmfrec_hip_gemm_probe switches between its two timings instead of mutating the process environment
+inline thread_local int g_gemm_force = -1;
 template <bool TRANSA>
 inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha, const real_t *A, size_t lda,
                         const real_t *B, size_t ldb, real_t *C, size_t ldc)
@@ -454,7 +457,8 @@ inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
     // cross-check; row-major C is the column-major C^T = B^T op(A)^T, so: first operand B, second operand A with the
     // transposition flag inverted).
     const char *own_env = getenv("CMFREC_HIP_GEMM_OWN");
-    if (!(own_env != nullptr && own_env[0] == '0')) {
+    const bool use_own = (g_gemm_force >= 0) ? (g_gemm_force != 0) : !(own_env != nullptr && own_env[0] == '0');
+    if (use_own) {
         DeviceInfo &d = const_cast<DeviceInfo &>(dev);
         const int bm = (M + GEMM_BM - 1) / GEMM_BM, bn = (N + GEMM_BN - 1) / GEMM_BN;
         int nsplit = 1;

@@ -197,8 +197,12 @@ template <typename T> constexpr int gw_slabs() { return sizeof(T) == 4 ? GW_SLAB
 // In double precision an MFMA occupies the pipe as long as ~30 vector FMAs and the last column block of k = 50 holds 2 live
 // columns of 16: 4 of the 10 tiles per slab are replaced by 12 vector instructions.  Their sums land in the partial at the
 // positions gram_cg_kernel reads (tile (cb, NTT - 1), column j - 16 (NTT - 1)); the rest of those tiles stays unwritten and unread.
+// FULLK (round 4): k_t = 16 NTT exactly (config 4: k = 64) -- the four loads of a slab row are one address plus immediate offsets
+// (the clamped column offsets of the general build cost a 64-bit multiply-add per load, quarter rate: 16 of them per group of four
+// slabs, 256 of the ~900 vector cycles beside 1280 matrix cycles).  Both builds keep the two slab buffers in place and swap their
+// roles (the loop body twice per trip) instead of copying `nxt` into `cur`.
 constexpr int GW_REM = 4;
-template <typename T, bool IMPLICIT, int REM = 0>
+template <typename T, bool IMPLICIT, int REM = 0, bool FULLK = false>
 __global__ void __launch_bounds__(256, 2)
 gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
 {
@@ -261,20 +265,27 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
             for (int q = 0; q < NS; q++) {
                 const unsigned it = (unsigned)__shfl(idx, 4 * q + kc);
                 const T *rp = reinterpret_cast<const T *>(reinterpret_cast<const char *>(P.B) + (unsigned long long)it * ldb_bytes);
+                if constexpr (FULLK) {
+                    const T *rl = rp + lm;
 #pragma unroll
-                for (int cb = 0; cb < NTT; cb++) slab[q][cb] = rp[coff[cb]];
+                    for (int cb = 0; cb < NTT; cb++) slab[q][cb] = rl[16 * cb];
+                } else {
+#pragma unroll
+                    for (int cb = 0; cb < NTT; cb++) slab[q][cb] = rp[coff[cb]];
+                }
             }
         };
         int idx_c, idx_n;
         T x_c, ok_c, x_n, ok_n;
-        T cur[NS][NTT], nxt[NS][NTT];
+        T bufA[NS][NTT], bufB[NS][NTT];
         // (every load below is unconditional -- entries past the slice re-read its last one with weight 0 -- so that the
         //  loop-carried registers are plain copies: conditional loads into live registers make the compiler keep both sets)
         load_entries(0, idx_c, x_c, ok_c);
-        load_slabs(idx_c, cur);
+        load_slabs(idx_c, bufA);
         load_entries(GRP, idx_n, x_n, ok_n);
-        for (int c0 = 0; c0 < nnz; c0 += GRP) {
-            load_slabs(idx_n, nxt);                                            // lands behind this group's MFMAs
+        // one group of NS slabs: its products from S_, the next group's rows into N_ (they land behind this group's MFMAs)
+        auto group = [&](int c0, T (&S_)[NS][NTT], T (&N_)[NS][NTT]) {
+            load_slabs(idx_n, N_);
             int idx_nn; T x_nn, ok_nn;
             load_entries(c0 + 2 * GRP, idx_nn, x_nn, ok_nn);
 #pragma unroll
@@ -284,7 +295,7 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
                 if (IMPLICIT) {
                     T dp = T(0);
 #pragma unroll
-                    for (int cb = 0; cb < NTT; cb++) dp += cur[q][cb] * a_c[cb];
+                    for (int cb = 0; cb < NTT; cb++) dp += S_[q][cb] * a_c[cb];
                     dp += lanes::xor1(dp); dp += lanes::xor2(dp); dp += lanes::xor4(dp); dp += lanes::xor8(dp);   // B_j . a, 16 lanes
                     wG = x * okf;                                              // common.c:1965
                     wv = (x - dp) * okf;                                       // common.c:1936-1943 (quirk Q1)
@@ -295,28 +306,28 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
                 T sa[NTT];
 #pragma unroll
                 for (int cb = 0; cb < NTT; cb++) {
-                    racc[cb] += wv * cur[q][cb];
-                    sa[cb] = wG * cur[q][cb];
+                    racc[cb] += wv * S_[q][cb];
+                    sa[cb] = wG * S_[q][cb];
                 }
                 static_for<0, NTALL>([&](auto tc) {
                     constexpr int t = decltype(tc)::value, bi = tile_bi(t, NTT), bj = tile_bj(t, NTT);
-                    if constexpr (bj < NTF) acc[t] = Mf::mma(sa[bi], cur[q][bj], acc[t]);
+                    if constexpr (bj < NTF) acc[t] = Mf::mma(sa[bi], S_[q][bj], acc[t]);
                 });
                 if constexpr (REMV) {
                     static_for<0, REM>([&](auto cc) {
                         constexpr int c = decltype(cc)::value;
-                        const T we = wG * lanes::row_bcast16<c>(cur[q][NTT - 1]);
+                        const T we = wG * lanes::row_bcast16<c>(S_[q][NTT - 1]);
 #pragma unroll
-                        for (int cb = 0; cb < NTT; cb++) cacc[c][cb] += we * cur[q][cb];
+                        for (int cb = 0; cb < NTT; cb++) cacc[c][cb] += we * S_[q][cb];
                     });
                 }
             }
-#pragma unroll
-            for (int q = 0; q < NS; q++)
-#pragma unroll
-                for (int cb = 0; cb < NTT; cb++) cur[q][cb] = nxt[q][cb];
             idx_c = idx_n; x_c = x_n; ok_c = ok_n;
             idx_n = idx_nn; x_n = x_nn; ok_n = ok_nn;
+        };
+        for (int c0 = 0; c0 < nnz; c0 += 2 * GRP) {
+            group(c0, bufA, bufB);
+            if (c0 + GRP < nnz) group(c0 + GRP, bufB, bufA);
         }
         T *out = Gp.part + (size_t)sl * GRAM_PART;
         static_for<0, NTALL>([&](auto tc) {

@@ -15,6 +15,11 @@ namespace cmfhip {
 void launch_gram_wave(dim3 grid, hipStream_t st, const CgParams<real_t> &P, const GramParams<real_t> &G, bool implicit, int rem)
 {
 #define CMF_GW(IMPL, R) hipLaunchKernelGGL((gram_wave_kernel<real_t, IMPL, R>), grid, dim3(256), 0, st, P, G)
+    if (rem == 0 && P.k == 16 * GRAM_NTT) {           // every column block complete (k = 64): compile-time column offsets
+        if (implicit) hipLaunchKernelGGL((gram_wave_kernel<real_t, true, 0, true>), grid, dim3(256), 0, st, P, G);
+        else hipLaunchKernelGGL((gram_wave_kernel<real_t, false, 0, true>), grid, dim3(256), 0, st, P, G);
+        return;
+    }
     if (implicit) {
         switch (rem) {
             case 1: CMF_GW(true, 1); break;

@@ -470,7 +470,14 @@ static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real
     d.potrs_inv.alloc_at_least((size_t)2 * k * k);
     d.potrs_tmp.alloc_at_least((size_t)rows * k);
     real_t *Linv = d.potrs_inv.ptr, *Minv = d.potrs_inv.ptr + (size_t)k * k;
-    hipLaunchKernelGGL(trtri_from_upper_kernel<real_t>, dim3(1), dim3(256), 0, dev.stream, R, k, Linv);
+    const size_t tr_smem = (size_t)2 * k * (k + 1) * sizeof(real_t);
+    if (tr_smem <= 96 * 1024) {
+        auto kern = trtri_from_upper_kernel<real_t, true>;
+        if (tr_smem > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tr_smem));
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), tr_smem, dev.stream, R, k, Linv);
+    } else {
+        hipLaunchKernelGGL((trtri_from_upper_kernel<real_t, false>), dim3(1), dim3(256), 0, dev.stream, R, k, Linv);
+    }
     HIP_CHECK(hipGetLastError());
     launch_gemm<true>(dev, k, k, k, (real_t)1, Linv, (size_t)k, Linv, (size_t)k, Minv, (size_t)k);
     launch_gemm<false>(dev, rows, k, k, (real_t)1, X, ldx, Minv, (size_t)k, d.potrs_tmp.ptr, (size_t)k);
@@ -792,6 +799,7 @@ struct cmfrec_hip_session {
     // half-step is optimizeA Case 3 (common.c:3118-3205): one shared matrix, the stored values uncentred, and the constant
     // -sum over all opposing rows of (their bias + naz_mean) x row on every right-hand side (collective.c:8573-8600, :8756-8787)
     bool naz_X = false, naz_center = false;
+    real_t x_subtract = 0;        // what the most recent set_X_coo* subtracted from the values (cmfrec_hip_session_set_NA_as_zero_X checks it)
     real_t naz_mean = 0;
     DevBuf<real_t> naz_part, naz_vec, naz_M, naz_rhs;
     DevBuf<int> zrowsA, zrowsB;   // rows every update of A / B leaves at zero (cmfrec_hip_session_set_zero_rows)
@@ -1041,6 +1049,7 @@ int cmfrec_hip_session_set_X_coo_weighted(cmfrec_hip_session *s, const int_t *ro
         dr.upload(row, nnz, s->dev.stream); dc.upload(col, nnz, s->dev.stream); dv.upload(val, nnz, s->dev.stream);
         if (weight != nullptr) dw.upload(weight, nnz, s->dev.stream);
         s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(m.k + m.k_main) * sizeof(real_t);
+        s->x_subtract = subtract;
         shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream, dw.ptr);
         shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream, dw.ptr);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
@@ -1404,9 +1413,19 @@ int cmfrec_hip_session_get_implicit_features(cmfrec_hip_session *s, real_t *Ai, 
 
 int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int center, real_t glob_mean)
 {
-    if (on && s->mdl.implicit) { g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: explicit model only"; return 2; }
-    s->naz_X = on != 0; s->naz_center = center != 0; s->naz_mean = glob_mean;
-    return 0;
+    return guarded([&]() {
+        if (on && s->mdl.implicit) { g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: explicit model only"; return 2; }
+        // the mean enters through the right-hand-side constant: an X that was uploaded centred would count it twice; the weighted
+        // and the sharded forms are not built (the updates would refuse them one by one)
+        if (on && (s->x_subtract != (real_t)0 || s->Xr.weighted() || s->mdl.row_begin != 0 || s->mdl.row_end != s->mdl.m ||
+                   s->mdl.col_begin != 0 || s->mdl.col_end != s->mdl.n)) {
+            g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: X must have been set uncentred (subtract = 0), without weights, on the "
+                           "whole row and column range";
+            return 2;
+        }
+        s->naz_X = on != 0; s->naz_center = center != 0; s->naz_mean = glob_mean;
+        return 0;
+    });
 }
 
 int cmfrec_hip_session_set_zero_rows(cmfrec_hip_session *s, int which, const int_t *rows, int count)
@@ -2840,7 +2859,7 @@ extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, 
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         auto run = [&](bool own, real_t *C, double *ms) {
-            if (own) unsetenv("CMFREC_HIP_GEMM_OWN"); else setenv("CMFREC_HIP_GEMM_OWN", "0", 1);
+            g_gemm_force = own ? 1 : 0;
             for (int r = 0; r < reps + 1; r++) {
                 if (r == 1) HIP_CHECK(hipEventRecord(e0, dev.stream));
                 if (transa) launch_gemm<true>(dev, M, N, K, (real_t)1, A.ptr, lda, B.ptr, (size_t)N, C, (size_t)N);
@@ -2852,11 +2871,9 @@ extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, 
             HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
             if (ms) *ms = (double)t / std::max(reps, 1);
         };
-        const char *keep = getenv("CMFREC_HIP_GEMM_OWN");
-        const std::string keep_s = keep ? keep : "";
         run(true, C1.ptr, ms_own);
         run(false, C2.ptr, ms_rocblas);
-        if (keep) setenv("CMFREC_HIP_GEMM_OWN", keep_s.c_str(), 1); else unsetenv("CMFREC_HIP_GEMM_OWN");
+        g_gemm_force = -1;
         std::vector<real_t> h1((size_t)M * N), h2((size_t)M * N);
         C1.download(h1.data(), h1.size(), dev.stream); C2.download(h2.data(), h2.size(), dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
