@@ -270,7 +270,7 @@ def main():
                               "note": "5 iterations after the timed region with the nnz bins one after the other; not part of `value`"}
 
     if not side_by_side and dom["kernel"].startswith("gram_wave"):
-        # the Gramian path reads its rows once; what limits it in double precision is v_mfma_f64_16x16x4:
+        # the Gramian path reads its rows once; what limits it in double precision is v_mfma_f64_16x16x4 (docs/DESIGN_HISTORY.md 3.1):
         # 10 tiles of the upper triangle per 4 entries, 2 x 16 x 16 x 4 flops each
         mf = 10 * 2 * 16 * 16 * dom["nnz"] / (dom["avg_ms"] * 1e-3) / 1e12
         roofline["matrix_pipe"] = {"executed_TFLOPs": round(mf, 1), "peak_fp64_TFLOPs": 78.6, "frac": round(mf / 78.6, 3),

@@ -438,7 +438,7 @@ cg_rows_kernel(const CgParams<T> P)
     if (W > 1) { rnxt = s_claim[2]; rnn = s_claim[3]; }
     T *myred = red + (size_t)grp * 2 * W * 64;
 
-    int buf = 0;   // cross-wave exchange buffer parity; persists across rows
+    int buf = 0;   // cross-wave exchange buffer parity; persists across rows (see docs/DESIGN_HISTORY.md 3.1)
     static_assert(W == 1 || RPB == 1, "multi-wave teams own their workgroup (barriers are per row)");
 
     // Software pipeline over the team's rows: while row i is being solved, the descriptor of row

@@ -793,7 +793,7 @@ inline int cg_bin_streams()
     return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
 }
 
-// CMFREC_HIP_HEAVY_SPLIT=0: the whole 257..1024 bin on eight-wave teams in single precision too (A/B switch, cross-check)
+// CMFREC_HIP_HEAVY_SPLIT=0: the whole 257..1024 bin on eight-wave teams (A/B switch, cross-check)
 inline bool heavy_split_off()
 {
     static const bool off = getenv("CMFREC_HIP_HEAVY_SPLIT") != nullptr && getenv("CMFREC_HIP_HEAVY_SPLIT")[0] == '0';
@@ -819,6 +819,8 @@ inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, 
                 if (tm) { HIP_CHECK(hipEventRecord(ev.b, st)); tm->ev[bin].push_back(ev); }
                 break;
             }
+            // (double precision: rows of 257..384 entries on six-wave teams were measured slower -- 0.245 -> 0.27 ms for C2's items,
+            //  0.184 -> 0.203 for its users, profiles/r04/r04_u -- a second launch per bin costs more than the idle waves)
 #endif
             launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
         case BIN_MED4: launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;

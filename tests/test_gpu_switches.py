@@ -1,4 +1,4 @@
-"""GPU: the kernel-selecting environment switches that are read once per process -- the generic CG kernel, the
+"""GPU: the kernel-selecting environment switches that are read once per process ("Run-time switches") -- the generic CG kernel, the
 workgroup-per-row Cholesky kernel, one row per wavefront for the shortest rows, the split-row boundary, the library GEMMs.
 Each runs the same three small fits in a child process with the switch set; the factors must agree with the default paths'
 to rounding (the switches select another kernel for the same row systems, never another model)."""
