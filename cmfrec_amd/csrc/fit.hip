@@ -877,6 +877,8 @@ int_t fit_collective_explicit_als(
     DenseX dx;
     bool dense_chol_A = false, dense_chol_B = false;
     std::vector<unsigned char> dense_cf_A, dense_cf_B;
+    std::vector<real_t> dense_mult_A, dense_mult_B;
+    bool unit_weights = false;
     if (Xfull) {
         if (U || II || nnz_U || nnz_I || add_implicit_features || NA_as_zero_X)
             return fail(verbose, "cmfrec_hip: dense X is implemented for the model without side information and implicit features.");
@@ -884,15 +886,26 @@ int_t fit_collective_explicit_als(
         dx.convert(Xfull, weight, m, n);
         if (dx.val.empty()) return fail(verbose, "cmfrec_hip: 'X' has all entries missing.");
         const int_t fewA = 2 * (k + k_main + (user_bias ? 1 : 0)), fewB = 2 * (k + k_main + (item_bias ? 1 : 0));
-        // Under scale_lam such a row's precomputed matrix carries n lam (that of a complete row), not lam times its number of
-        // present entries (common.c:3031-3032): a per-row rule that is not restated.
+        // Under scale_lam a row that misses fewer than 2 k entries keeps the n lam of a complete row -- its matrix is the precomputed
+        // B^T B + n lam I minus the missing rows (factors_closed_form, common.c:759-790 with BtB_has_diag; :3031-3032) -- while the
+        // others take lam times their present entries.  Restated through the weighted kernels: unit weights (a multiplication by
+        // one: the unweighted numbers bit for bit) and the per-row multipliers handed over after the bias start values
+        // (cmfrec_hip_session_set_lambda_multipliers).
         if (!weight && (scale_lam || scale_lam_sideinfo)) {
-            for (int_t r = 0; r < m; r++) if (dx.na_row[r] > 0 && dx.na_row[r] < fewA) return fail(verbose, "cmfrec_hip: dense X: scale_lam with rows that miss only a few entries is not implemented.");
-            for (int_t c = 0; c < n; c++) if (dx.na_col[c] > 0 && dx.na_col[c] < fewB) return fail(verbose, "cmfrec_hip: dense X: scale_lam with columns that miss only a few entries is not implemented.");
+            bool any = false;
+            for (int_t r = 0; r < m && !any; r++) any = (dx.na_row[r] > 0 && dx.na_row[r] < fewA);
+            for (int_t c = 0; c < n && !any; c++) any = (dx.na_col[c] > 0 && dx.na_col[c] < fewB);
+            if (any) {
+                dense_mult_A.resize((size_t)m); dense_mult_B.resize((size_t)n);
+                for (int_t r = 0; r < m; r++) dense_mult_A[r] = (dx.na_row[r] < fewA) ? (real_t)n : (dx.na_row[r] < n ? (real_t)(n - dx.na_row[r]) : (real_t)1);
+                for (int_t c = 0; c < n; c++) dense_mult_B[c] = (dx.na_col[c] < fewB) ? (real_t)m : (dx.na_col[c] < m ? (real_t)(m - dx.na_col[c]) : (real_t)1);
+                dx.w.assign(dx.val.size(), (real_t)1);
+                unit_weights = true;
+            }
         }
         ixA = dx.row.data(); ixB = dx.col.data(); X = dx.val.data(); nnz = dx.val.size();
-        if (weight) weight = dx.w.data();
-        else {
+        if (weight || unit_weights) weight = dx.w.data();
+        if (!weight || unit_weights) {
             // Case 2 under use_cg: closed form for the rows that miss few entries, CG for the others (rows without any entry are zero)
             auto case2_chol = [&](const std::vector<int_t> &na, int_t other, int_t few, bool &mixed) {
                 size_t n_few = 0, n_many = 0;
@@ -1274,6 +1287,9 @@ int_t fit_collective_explicit_als(
     }
     if (tm.on) cmfrec_hip_session_sync(s);
     tm.lap("bias init");
+    // dense X under scale_lam: the rows' lambda multipliers (n for a row that misses few entries, its present entries otherwise)
+    if (!rc && !dense_mult_A.empty()) rc = cmfrec_hip_session_set_lambda_multipliers(s, 'A', dense_mult_A.data());
+    if (!rc && !dense_mult_B.empty()) rc = cmfrec_hip_session_set_lambda_multipliers(s, 'B', dense_mult_B.data());
     if (verbose && !rc) { printf("Starting ALS optimization routine\n\n"); fflush(stdout); }
     int rc_loop = rc ? rc : run_loop(s, mdl, niter, finalize_chol, verbose, add_implicit_features, dense_chol_A, dense_chol_B);
     if (tm.on) cmfrec_hip_session_sync(s);

@@ -1465,6 +1465,22 @@ int cmfrec_hip_session_set_closed_form_rows(cmfrec_hip_session *s, int which, co
     });
 }
 
+int cmfrec_hip_session_set_lambda_multipliers(cmfrec_hip_session *s, int which, const real_t *mult)
+{
+    return guarded([&]() {
+        HIP_CHECK(hipSetDevice(s->dev.device));
+        if ((which != 'A' && which != 'B') || mult == nullptr) { g_last_error = "cmfrec_hip_session_set_lambda_multipliers: which must be 'A' or 'B', mult non-null"; return 2; }
+        SparseShard &X = which == 'A' ? s->Xr : s->Xc;
+        if (!X.weighted() || s->mdl.implicit) {
+            g_last_error = "cmfrec_hip_session_set_lambda_multipliers: the explicit model with observation weights on X (unit weights will do)";
+            return 2;
+        }
+        X.wsum.upload(mult, (size_t)X.nrows, s->dev.stream);
+        HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+        return 0;
+    });
+}
+
 int cmfrec_hip_session_set_scale_bias_const(cmfrec_hip_session *s, int on)
 {
     s->scale_bias_const = on != 0;

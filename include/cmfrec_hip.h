@@ -375,6 +375,12 @@ int cmfrec_hip_session_set_zero_rows(cmfrec_hip_session *s, int which, const int
  * per row of the matrix, non-zero = closed form; NULL clears it.  A CG update then solves every row by CG, keeps a copy, solves
  * every row in closed form and puts the copy back for the rows whose byte is zero. */
 int cmfrec_hip_session_set_closed_form_rows(cmfrec_hip_session *s, int which, const unsigned char *mask);
+/* The lambda multipliers of the rows of A ('A') / B ('B') under scale_lam, instead of the rows' own sums of weights: a dense X
+ * under scale_lam, where a row that misses fewer than 2 k entries keeps the n lam of a complete row (its matrix is the precomputed
+ * B^T B + n lam I minus the missing rows, src/common.c:759-790, :3031-3032) while the others take lam times their present entries.
+ * The session must hold X with observation weights (unit weights for this use); call after the bias start values.  mult: one
+ * value per row of the matrix. */
+int cmfrec_hip_session_set_lambda_multipliers(cmfrec_hip_session *s, int which, const real_t *mult);
 /* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
  * _onesided (src/common.c:4410-4909, 4265-4289; call sites src/collective.c:8166-8220): written to the
  * session's bias vectors and the bias columns of A / B.  Call after set_X* and set_factors. */

@@ -361,6 +361,13 @@ class Oracle:
         self._cfB = None if maskB is None else np.ascontiguousarray(maskB, np.uint8)
         self.lib.oracle_set_closed_form_rows(_ptr(self._cfA), _ptr(self._cfB))
 
+    def set_lambda_multipliers(self, multA=None, multB=None):
+        """Per-row lambda multipliers of the NEXT explicit fit under scale_lam (dense X: n for a row that misses few entries, its
+        present entries otherwise); that fit must be given (unit) weights.  The arrays must stay alive until it returns."""
+        self._lmA = None if multA is None else np.ascontiguousarray(multA, self.dtype)
+        self._lmB = None if multB is None else np.ascontiguousarray(multB, self.dtype)
+        self.lib.oracle_set_lambda_multipliers(_ptr(self._lmA), _ptr(self._lmB))
+
     def set_zero_rows(self, rowsA=None, rowsB=None):
         """Rows of A / B the NEXT fit sets to zero after their update (NA_as_zero_U / _I: rows with neither an entry of X nor of
         the side information, which the reference does not solve).  The arrays must stay alive until that fit returns."""

@@ -524,6 +524,12 @@ void oracle_set_row_weights(const real_t *weights_csr_order, const real_t *wsum)
  * half-step about to run (consumed by oracle_optimizeA_explicit). */
 static const unsigned char *g_cf_rows_A = NULL, *g_cf_rows_B = NULL, *g_cf_now = NULL;
 void oracle_set_closed_form_rows(const unsigned char *maskA, const unsigned char *maskB) { g_cf_rows_A = maskA; g_cf_rows_B = maskB; }
+/* ... and under scale_lam such a row keeps the n lam of a complete row (its matrix is the precomputed B^T B + n lam I minus the
+ * missing rows: factors_closed_form :759-790 with BtB_has_diag, the diagonal added at :3031-3032 / :2832), the others lam times
+ * their present entries: the per-row multipliers of the next oracle_fit_explicit_als call, which must carry (unit) weights --
+ * they replace wsumA / wsumB after the bias start values. */
+static const real_t *g_lam_mult_A = NULL, *g_lam_mult_B = NULL;
+void oracle_set_lambda_multipliers(const real_t *multA, const real_t *multB) { g_lam_mult_A = multA; g_lam_mult_B = multB; }
 
 void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ldb,
                                int_t m, int_t n, int_t k,
@@ -1440,6 +1446,8 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     g_fit_naz = false;
     const unsigned char *cfA = g_cf_rows_A, *cfB = g_cf_rows_B;                 /* see oracle_set_closed_form_rows */
     g_cf_rows_A = g_cf_rows_B = NULL;
+    const real_t *lmA = g_lam_mult_A, *lmB = g_lam_mult_B;                      /* see oracle_set_lambda_multipliers */
+    g_lam_mult_A = g_lam_mult_B = NULL;
     const int_t *zrA = g_zero_rows_A, *zrB = g_zero_rows_B;                    /* see oracle_set_zero_rows */
     const int_t nzrA = g_n_zero_rows_A, nzrB = g_n_zero_rows_B;
     g_zero_rows_A = g_zero_rows_B = NULL; g_n_zero_rows_A = g_n_zero_rows_B = 0;
@@ -1587,6 +1595,8 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         }
     }
 
+    if (wsumA != NULL && lmA != NULL) memcpy(wsumA, lmA, (size_t)m * sizeof(real_t));
+    if (wsumB != NULL && lmB != NULL) memcpy(wsumB, lmB, (size_t)n * sizeof(real_t));
     for (int_t iter = 0; iter < niter; iter++) {                               /* :8334-8898 */
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;
         g_nonneg = g_nn_C; g_l1 = l1C / w_user; g_l1_last_set = false;

@@ -77,6 +77,7 @@ void oracle_set_row_weights(const real_t *weights_csr_order, const real_t *wsum)
  * right-hand-side constant of the driver (collective.c:8573-8600, :8756-8787).  Cleared by the call. */
 void oracle_set_fit_NA_as_zero_X(bool on);
 void oracle_set_closed_form_rows(const unsigned char *maskA, const unsigned char *maskB);   /* dense X, Case 2: rows solved in closed form inside a CG half-step */
+void oracle_set_lambda_multipliers(const real_t *multA, const real_t *multB);   /* dense X under scale_lam: per-row lambda multipliers of the next (unit-weighted) fit */
 void oracle_set_zero_rows(const int_t *rowsA, int_t nA, const int_t *rowsB, int_t nB);   /* NA_as_zero_U / _I: rows the next fit zeroes after their update */
 /* bias_BtX[k] of the oracle_optimizeA_naz call that follows (common.c:3152-3157).  Cleared by the call. */
 void oracle_set_naz_bias_BtX(const real_t *bias_BtX);

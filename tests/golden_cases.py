@@ -1158,6 +1158,12 @@ DENSE_CASES = [
     ("rows on both sides of the 2 k boundary, cg", "split", dict(use_cg=True, finalize_chol=False)),
     ("rows and columns on both sides, cg + finalize, user bias", "split2", dict(use_cg=True, finalize_chol=True, item_bias=False)),
     ("rows and columns on both sides, chol", "split2", dict(use_cg=False)),
+    ("near dense, chol, scale_lam", "near", dict(use_cg=False, scale_lam=True)),
+    ("rows and columns on both sides, cg, scale_lam", "split2", dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    # (under use_cg the reference runs k CG steps from zero on the rows of a near-dense half-step that miss many entries, common.c:2944-2983;
+    #  the closed form here is the same solution until that CG leaves through its 1e-8 exit early -- with scale_lam's larger lambda it does,
+    #  1e-5 apart -- so the scaled mixed pattern is pinned with the closed form)
+    ("mixed, chol, scale_lam, no biases", "mixed", dict(use_cg=False, scale_lam=True, user_bias=False, item_bias=False)),
 ]
 
 
@@ -1196,6 +1202,17 @@ def dense_oracle(O, d, variant, opts, nthreads=2):
         na_r = np.isnan(d["X"]).sum(1); na_c = np.isnan(d["X"]).sum(0)
         few_r = 2 * (d["k"] + o.get("k_main", 0) + int(o.get("user_bias", True))); few_c = 2 * (d["k"] + o.get("k_main", 0) + int(o.get("item_bias", True)))
         O.set_closed_form_rows(na_r < few_r, na_c < few_c)
+    if W is None and o.get("scale_lam") and variant != "full":
+        # under scale_lam a row that misses fewer than 2 k entries keeps the n lam of a complete row, the others lam times their
+        # present entries: unit weights + per-row multipliers
+        na_r = np.isnan(d["X"]).sum(1); na_c = np.isnan(d["X"]).sum(0)
+        few_r = 2 * (d["k"] + o.get("k_main", 0) + int(o.get("user_bias", True))); few_c = 2 * (d["k"] + o.get("k_main", 0) + int(o.get("item_bias", True)))
+        if ((na_r > 0) & (na_r < few_r)).any() or ((na_c > 0) & (na_c < few_c)).any():
+            dt = d["X"].dtype
+            mult_r = np.where(na_r < few_r, d["n"], np.where(na_r < d["n"], d["n"] - na_r, 1)).astype(dt)
+            mult_c = np.where(na_c < few_c, d["m"], np.where(na_c < d["m"], d["m"] - na_c, 1)).astype(dt)
+            O.set_lambda_multipliers(mult_r, mult_c)
+            W = np.ones(len(d["ratings"]), dt)
     # rows / columns without a present entry: zero in the dense reference (factors and bias), left alone by the sparse path
     A0, B0, bA, bB = d["A0"].copy(), d["B0"].copy(), d["bA"].copy(), d["bB"].copy()
     er = np.bincount(d["row"], minlength=d["m"]) == 0; ec = np.bincount(d["col"], minlength=d["n"]) == 0

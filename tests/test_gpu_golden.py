@@ -393,12 +393,10 @@ def test_dense_X(oracles, dtype):
     d = gc.dense_problem(dtype, "holes")
     got = gc.dense_hip(d, dict(use_cg=False), dtype)
     assert not got["A"][4].any() and not got["B"][7].any() and got["biasA"][4] == 0 and got["biasB"][7] == 0
-    # refused: scale_lam with rows that miss only a few entries (the reference's multiplier there is not the entry count),
-    # side information, NA_as_zero
+    # refused: side information, NA_as_zero (scale_lam with rows that miss only a few entries -- the reference's multiplier there
+    # is n, not the entry count -- is among the cases above)
     from cmfrec_amd import CMF
     dn = gc.dense_problem(dtype, "near")
-    with pytest.raises(RuntimeError):
-        CMF(k=4, scale_lam=True, precompute_for_predictions=False).fit(dn["X"])
     with pytest.raises(RuntimeError):
         CMF(k=4, precompute_for_predictions=False).fit(dn["X"], U=np.ones((dn["m"], 2), dtype))
     # under use_cg a half-step whose rows partly miss few and partly many entries runs both solvers (the 'split' cases above): the
