@@ -933,9 +933,7 @@ int_t fit_collective_explicit_als(
         return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without weights, sparse side information, implicit "
                              "features, nonneg / L1, scale_bias_const and without precompute_for_predictions.");
     if (NA_as_zero_X && (U || II)) {
-        if (use_cg)
-            return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: the block CG on a missing-as-zero main matrix "
-                                 "(collective.c:2134-2903) is not implemented (use_cg=False is).");
+        // (use_cg is accepted: with a factorised shared block matrix the reference takes the closed form whatever the solver asked for)
         if ((U && m_u != m) || (II && n_i != n))
             return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: U / I must have exactly the rows / columns of X.");
         for (size_t e = 0; U && e < (size_t)m_u * (size_t)p; e++)

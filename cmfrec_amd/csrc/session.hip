@@ -1597,13 +1597,15 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
                        "scale_bias_const, sparse or incomplete side information";
         return 2;
     }
-    if (p_self > 0 && (rows_u != rows_self || !chol)) {
+    if (p_self > 0 && rows_u != rows_self) {
         // (m > m_u takes optimizeA Case 3 for the rows beyond in the reference -- its build corrupts the heap there, so nothing
-        //  pins that branch; the block CG with a missing-as-zero main matrix, collective.c:2134-2903, is not built)
-        g_last_error = "cmfrec_hip: NA_as_zero_X with side information: closed form only (use_cg = false), side information on "
-                       "exactly the rows / columns of X";
+        //  pins that branch)
+        g_last_error = "cmfrec_hip: NA_as_zero_X with side information: side information on exactly the rows / columns of X";
         return 2;
     }
+    // (use_cg changes nothing here, like in Case 3: collective_closed_form_block takes the factorised block matrix before it looks
+    //  at the solver, collective.c:1364-1460 -- the reference's fit with use_cg = true returns the closed-form numbers, g20)
+    (void)chol;
     if (p_self == 0 && (isA ? m.k_user : m.k_item) != 0) {
         g_last_error = "cmfrec_hip: NA_as_zero_X: k_user / k_item without side information on that side";
         return 2;
@@ -1644,7 +1646,9 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
         rhs_x = s->naz_rhs.ptr; ld_rhs = (size_t)ks;
     }
     // right-hand sides: sum_j x_j opp_j over the row's entries (tgemm_sp_dense, :3145-3151 / :5753-5762) ...
-    HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
+    real_t *rhs = self;
+    const size_t ld_r = ld_self;
+    HIP_CHECK(hipMemset2DAsync(rhs, ld_r * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
     if (p_self > 0) HIP_CHECK(hipMemsetAsync(rhs_x, 0, (size_t)rows_self * ks * sizeof(real_t), st));
     CholCall c{rhs_x, ld_rhs, oppx, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
     c.rhs_only = true;
@@ -1654,8 +1658,8 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
         // ... w U C on the first k_side + k columns, the gathered part behind k_side
         const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
         const real_t *Um = isA ? s->U.ptr : s->II.ptr;
-        launch_gemm<false>(dev, rows_self, kc, p_self, isA ? m.w_user : m.w_item, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
-        hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self, ld_self, k_side_self, rhs_x, ks,
+        launch_gemm<false>(dev, rows_self, kc, p_self, isA ? m.w_user : m.w_item, Um, (size_t)p_self, Cm, (size_t)kc, rhs, ld_r);
+        hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, rhs, ld_r, k_side_self, rhs_x, ks,
                            (real_t)1, (size_t)rows_self);
     }
     // ... plus the constant of the opposing biases and the mean (:3152-3157 / :5815-5821)
@@ -1666,7 +1670,7 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
         hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, oppx, ld_opp, rows_opp, ks, bias,
                            s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
         hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
-        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self + k_side_self, ld_self, (size_t)rows_self, ks,
+        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, rhs + k_side_self, ld_r, (size_t)rows_self, ks,
                            s->naz_vec.ptr);
     }
     // one factorisation, all rows (with and without entries) through the triangular solves (:3171-3175 / :5715, :1455-1458)

@@ -1454,7 +1454,8 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     /* missing-as-zero with side information: dense complete U / I, closed form, side information on exactly the rows / columns of X
      * (with fewer the reference's own build corrupts its heap, so nothing pins the m > m_u branch restated in collective_naz_chol) */
     if (naz && ((Ai != NULL && Bi != NULL) || weight != NULL || g_scale_bias_const)) return 2;
-    if (naz && (U != NULL || II != NULL) && (use_cg || g_nn_AB || g_l1_base != 0 || g_has_l16 || (U != NULL && m_u != m) || (II != NULL && n_i != n))) return 2;
+    /* (use_cg changes nothing there: the factorised block matrix is taken before the solver is looked at, collective.c:1364-1460) */
+    if (naz && (U != NULL || II != NULL) && (g_nn_AB || g_l1_base != 0 || g_has_l16 || (U != NULL && m_u != m) || (II != NULL && n_i != n))) return 2;
     if (U == NULL) { m_u = 0; p = 0; }
     if (II == NULL) { n_i = 0; q = 0; }
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
@@ -1621,7 +1622,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         if (user_bias && !naz)                                                 /* :8566-8570 */
             for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
         g_cg_Bi = imp ? Ai : NULL; g_cg_ki = k + k_main; g_cg_wimp = w_implicit;
-        if ((II != NULL || imp) && use_cg)                                     /* :8634-8678 */
+        if ((II != NULL || imp) && use_cg && !naz)                             /* :8634-8678 */
             oracle_optimizeA_collective_cg(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                            csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);
@@ -1680,7 +1681,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
         if (item_bias && !naz)                                                 /* :8750-8754 */
             for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
         g_cg_Bi = imp ? Bi : NULL;
-        if ((U != NULL || imp) && use_cg)                                      /* :8805-8845 */
+        if ((U != NULL || imp) && use_cg && !naz)                              /* :8805-8845 */
             oracle_optimizeA_collective_cg(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                            csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, false,
                                            max_cg_steps, precondition_cg, nthreads);

@@ -1014,8 +1014,8 @@ def naz_hip(d, opts, dtype, NA_as_zero=True):
 
 # ---- NA_as_zero for the main matrix together with dense side information (optimizeA_collective with the factorised shared
 # block matrix, collective.c:5566-5968 / :5607-5617, :5700-5716) ---------------------------------------------------------------
-# (name, which sides carry side information, options).  Closed form only (the block CG on a missing-as-zero main matrix is not
-# built); side information on exactly the rows / columns of X (the reference's own build corrupts its heap with fewer).
+# (name, which sides carry side information, options).  Side information on exactly the rows / columns of X (the reference's own
+# build corrupts its heap with fewer).
 NAZ_SIDE_CASES = [
     ("both sides, biases", "UI", dict()),
     ("both sides, scale_lam", "UI", dict(scale_lam=True)),
@@ -1027,6 +1027,12 @@ NAZ_SIDE_CASES = [
     ("item side only, scale_lam", "I", dict(scale_lam=True)),
     ("per-matrix lambdas", "UI", dict(lam_unique=LAM6)),
     ("seeded, both biases", "UI", dict(scale_lam=True, seed=5)),
+    # use_cg: the reference takes the factorised block matrix before it looks at the solver (collective.c:1364-1460): closed-form numbers
+    ("cg, both sides, biases", "UI", dict(use_cg=True, finalize_chol=False)),
+    ("cg + finalize, scale_lam_sideinfo", "UI", dict(use_cg=True, finalize_chol=True, scale_lam_sideinfo=True)),
+    ("cg, k_user / k_item / k_main, user bias", "UI", dict(use_cg=True, finalize_chol=False, center=False, item_bias=False, k_user=2, k_item=1, k_main=2,
+                                                              w_user=0.7, w_item=1.3)),
+    ("cg, user side only, scale_lam", "U", dict(use_cg=True, finalize_chol=False, scale_lam=True)),
 ]
 
 
@@ -1039,7 +1045,8 @@ def naz_side_reference(R, d, sides, opts, nthreads=2):
     seed = o.pop("seed", None)
     A0, B0 = _impf_start(d, o)
     U, II = _naz_side(d, sides)
-    kw = dict(U=U, II=II, lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=False, **o)
+    kw = dict(U=U, II=II, lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
+              finalize_chol=o.pop("finalize_chol", False), **o)
     if seed is not None:
         A0[:] = 0; B0[:] = 0
         r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], reset_values=True, seed=seed, **kw)
@@ -1066,7 +1073,8 @@ def naz_side_oracle(O, d, sides, opts, nthreads=2):
     try:
         A0, B0 = _impf_start(d, o)
         r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), U=U, II=II,
-                               lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=False, **o)
+                               lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
+                               finalize_chol=o.pop("finalize_chol", False), **o)
     finally:
         O.set_lam_unique(None, None)
     assert r["ret"] == 0
@@ -1085,7 +1093,8 @@ def naz_side_hip(d, sides, opts, dtype, **ctor):
     o["lambda_"] = o.pop("lam_unique") if "lam_unique" in o else 0.3
     A0, B0 = _impf_start(d, o)
     U, II = _naz_side(d, sides)
-    args = dict(k=d["k"], niter=3, use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=True, use_cg=False, nthreads=1)
+    args = dict(k=d["k"], niter=3, use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=True, use_cg=False,
+                finalize_chol=False, nthreads=1)
     args.update(dict(random_state=seed) if seed is not None else {})
     args.update(o); args.update(ctor)
     mdl = CMF(**args)

@@ -334,8 +334,6 @@ def test_NA_as_zero_X_sideinfo(oracles, dtype):
             assert gc.compare_fits(got, ref) < tol, name
     # the side information changes the model, and the combinations that are not built are refused
     assert gc.compare_fits(gc.naz_side_hip(d, "", gc.NAZ_SIDE_CASES[0][2], dtype), {k[3:]: g[k] for k in g.files if k.startswith("c0_") and k[3:] not in ("C", "D")}) > 1e-3
-    with pytest.raises(RuntimeError):
-        gc.naz_side_hip(d, "UI", dict(), dtype, use_cg=True)
     d2 = dict(d); d2["U"] = d["U"][:100]
     with pytest.raises(RuntimeError):
         gc.naz_side_hip(d2, "U", dict(), dtype)

@@ -562,9 +562,14 @@ def test_NA_as_zero_sideinfo_fit_live(oracles, refs, dtype, shape):
                (("biasB",) if o.get("item_bias", True) else ())
         for key in keys:
             assert rel_err(ro[key], rr[key]) < 100 * TOL[dtype], (o, key)
-    # what the restatement does not cover is refused: the block CG, side information on fewer rows than X
+    # use_cg changes nothing (the factorised block matrix is taken before the solver is looked at) ...
+    kw = dict(U=U, II=II, lam=0.4, niter=2, nthreads=2, NA_as_zero_X=True)
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    rc = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, use_cg=True, finalize_chol=False, **kw)
+    oc = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, use_cg=True, finalize_chol=False, **kw)
+    assert rc["ret"] == 0 and oc["ret"] == 0 and rel_err(oc["A"], rc["A"]) < 100 * TOL[dtype] and rel_err(oc["B"], rc["B"]) < 100 * TOL[dtype]
+    # ... and what the restatement does not cover is refused: side information on fewer rows than X
     A0 = np.zeros((m, k), dtype); B0 = np.zeros((n, k), dtype)
-    assert O.fit_explicit_als(A0, B0, row, col, val, k, U=U, II=II, niter=1, NA_as_zero_X=True, use_cg=True)["ret"] == 2
     assert O.fit_explicit_als(A0, B0, row, col, val, k, U=U[:m - 9], niter=1, NA_as_zero_X=True, use_cg=False)["ret"] == 2
 
 
