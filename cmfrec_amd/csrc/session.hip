@@ -69,9 +69,15 @@ struct CholCall {
 static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, CholParams<real_t> P, bool two_src,
                             size_t smem_nonneg);
 
+static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const SparseShard &X);
+
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
 static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, int nrows_prefilled = 0)
 {
+    if (X != nullptr && c.mode == CHOL_EXPLICIT && c.row_limit < 0 && c.cg_wide == nullptr) {
+        const int rc_lr = launch_plain_lowrank(dev, c, *X);      // rows with few entries against many unknowns (-1: not applicable)
+        if (rc_lr >= 0) return rc_lr;
+    }
     CholParams<real_t> P;
     P.A = c.A; P.lda = c.lda; P.B = c.B; P.ldb = c.ldb; P.kt = c.kt; P.koff = c.koff;
     P.indptr = X ? X->p.ptr : nullptr; P.indices = X ? X->i.ptr : nullptr; P.values = X ? X->v.ptr : nullptr;
@@ -745,6 +751,61 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
     launch_gemm<false>(dev, n_light, kc, kc, (real_t)1, S.T.ptr, (size_t)kc, E.Qt.ptr, (size_t)kc, S.R.ptr, (size_t)kc);
     hipLaunchKernelGGL(scatter_rows_kernel<real_t>, grid1d((size_t)n_light * kc), dim3(256), 0, st, c.A, c.lda, X.desc.ptr, n_full, S.R.ptr,
                        (size_t)kc, kc, (size_t)n_light);
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Plain closed-form rows (factors_closed_form, common.c:978-1070: no side information) with few entries against many unknowns: the
+// row's matrix is lam_i I + sum_j B_j B_j^T -- already diagonal plus a rank-s update, so the low-rank kernel applies without any
+// rotation (lowrank_kernels.hpp, !rotated / !collective): an s x s system instead of a k_t^3 / 3 factorisation.  Config 3's users
+// (k_t = 129, double): 38 % of the rows hold at most 64 entries.  -1 when the path does not apply.
+static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const SparseShard &X)
+{
+    const char *lr_env = getenv("CMFREC_HIP_LOWRANK");
+    const int kt = c.kt;
+    const int lr_type_max = (sizeof(real_t) == 4) ? 128 : 64;
+    const int lr_max = (kt >= 256 && lr_type_max >= 128) ? 128 : (kt >= 128 ? 64 : 32);
+    const int n_rows = X.n_nonempty;                                  // rows without entries stay as they are (common.c:3270)
+    const int n_full = X.rows_longer_than(lr_max, n_rows);
+    const int n_light = n_rows - n_full;
+    const bool ok = !(lr_env != nullptr && lr_env[0] == '0') && !X.weighted() && c.koff == 0 && c.X2 == nullptr && !c.rhs_only &&
+                    c.values_override == nullptr && !c.nonneg && !dev.nonneg_now && dev.l1_now == (real_t)0 && dev.l1_last_now == (real_t)0 &&
+                    kt <= 320 && ((lr_env != nullptr && lr_env[0] == '1') ? kt >= 40 : (kt >= 96 && n_light >= 2048));
+    if (!ok || n_light <= 0) return -1;
+    CholCall cf = c;
+    cf.row_limit = n_full;
+    const int rc = (n_full > 0) ? launch_chol(dev, cf, &X) : 0;
+    if (rc) return rc;
+    hipStream_t st = dev.stream;
+    LrParams<real_t> L;
+    L.A = c.A; L.lda = c.lda; L.pre = nullptr; L.ldpre = 0; L.Tc = nullptr; L.ldt = 0; L.pos0 = n_full;
+    L.Bt = c.B; L.ldbt = c.ldb; L.lam_eig = nullptr;
+    L.kt = kt; L.kc = 0; L.koff = 0; L.rotated = 0;
+    L.indptr = X.p.ptr; L.indices = X.i.ptr; L.values = X.v.ptr; L.bias_sub = c.bias_sub;
+    L.lam = c.lam; L.lam_last = c.lam_last;
+    L.scale_lam = c.scale_lam ? 1 : 0; L.scale_lam_sideinfo = 0; L.scale_bias_const = c.scale_bias_const ? 1 : 0; L.p_side = 0; L.collective = 0;
+    if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
+    HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr + 8, 0, 4 * sizeof(int), st));
+    const int n_gt64 = X.rows_longer_than(64, n_rows), n_gt32 = X.rows_longer_than(32, n_rows);
+    auto lr_launch = [&](auto kern, int nb_, int wps, int first, int last, int counter) {
+        if (last <= first) return;
+        LrParams<real_t> Lc = L;
+        Lc.row_first = first; Lc.nrows = last; Lc.counter = dev.row_counter.ptr + 8 + counter;
+        const size_t smem = 4 * lowrank_lds_elems<real_t>(nb_) * sizeof(real_t);
+        if (smem > 48 * 1024)
+            HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int grid = std::min((last - first + 3) / 4, dev.num_cus * wps);
+        poison_lds(st, dev.num_cus);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, Lc, X.desc.ptr);
+    };
+#ifdef CMFREC_HIP_FLOAT
+    lr_launch(lowrank_rows_kernel<real_t, 8, 2>, 8, 2, n_full, std::max(n_full, n_gt64), 0);
+    lr_launch(lowrank_rows_kernel<real_t, 4, 3>, 4, 3, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
+    lr_launch(lowrank_rows_kernel<real_t, 2, 4>, 2, 4, std::max(n_full, n_gt32), n_rows, 2);
+#else
+    lr_launch(lowrank_rows_kernel<real_t, 4, 2>, 4, 2, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
+    lr_launch(lowrank_rows_kernel<real_t, 2, 3>, 2, 3, std::max(n_full, n_gt32), n_rows, 2);
+#endif
     HIP_CHECK(hipGetLastError());
     return 0;
 }

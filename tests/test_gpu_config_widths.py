@@ -184,3 +184,45 @@ def test_lowrank_rows(oracles, dtype, k, p, ku, scale_lam, monkeypatch):
                                                   0.05, nthreads=4, **kw)
     tol = 1e-9 if dtype is np.float64 else 2e-4
     assert rel_err(Ah, A64) < tol
+
+
+@pytest.mark.parametrize("dtype,k", [(np.float64, 129), (np.float64, 100), (np.float32, 257), (np.float32, 129), (np.float64, 48)])
+@pytest.mark.parametrize("scale_lam", [True, False])
+def test_plain_lowrank_rows(oracles, dtype, k, scale_lam, monkeypatch):
+    """Plain closed-form rows (no side information) with few entries against many unknowns take the low-rank kernel without any
+    rotation (round 4: lam_i I + a rank-s update; config 3's users); CMFREC_HIP_LOWRANK=1 forces it on this small problem.  Row r has
+    r entries (0 .. 159): every block count of the s x s kernel, the hand-over to the full factorisation, a row without entries
+    (left as it is), the fused bias subtraction, the last unknown's own lambda.  Same system as the reference's
+    (factors_closed_form, common.c:978-1070), different arithmetic: tolerance-based; and against the full factorisation of every
+    row (CMFREC_HIP_LOWRANK=0)."""
+    from cmfrec_amd import ops
+    O = oracles[dtype]
+    m, n = 160, 3000
+    rng = np.random.default_rng(k)
+    rows, cols = [], []
+    for r in range(m):
+        rows.append(np.full(r, r, np.int32)); cols.append(rng.choice(n, r, replace=False).astype(np.int32))
+    row, col = np.concatenate(rows), np.concatenate(cols)
+    perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
+    val = (0.5 * rng.integers(1, 11, len(row))).astype(dtype)
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    B = (rng.standard_normal((n, k)) * 0.3).astype(dtype); B[:, k - 1] = 1
+    bias = (rng.standard_normal(n) * 0.2).astype(dtype)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    kw = dict(lam_last=0.2, scale_lam=scale_lam, use_cg=False)
+    Ah, Af, Ao = A0.copy(), A0.copy(), A0.copy()
+    monkeypatch.setenv("CMFREC_HIP_LOWRANK", "1")
+    ops.optimizeA_explicit(Ah, B, csr, 0.4, bias_sub=bias, **kw)
+    monkeypatch.setenv("CMFREC_HIP_LOWRANK", "0")
+    ops.optimizeA_explicit(Af, B, csr, 0.4, bias_sub=bias, **kw)
+    csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+    O64 = oracles[np.float64]
+    Ao = A0.astype(np.float64)
+    O64.optimizeA_explicit(Ao, B.astype(np.float64), (csr[0], csr[1], csr_b[2].astype(np.float64)), 0.4, nthreads=4, **kw)
+    tol = 1e-9 if dtype is np.float64 else 2e-4
+    assert rel_err(Ah, Ao) < tol and rel_err(Af, Ao) < tol
+    assert not np.array_equal(Ah, Af)                       # the two paths are different arithmetic ...
+    assert np.array_equal(Ah[0], A0[0])                     # ... and a row without entries is left alone by both
+    lens = np.diff(csr[0].astype(np.int64))
+    big = lens > (128 if (dtype is np.float32 and k >= 256) else 64 if k >= 128 else 32)
+    assert np.array_equal(Ah[big], Af[big])                 # rows beyond the low-rank limit take the same factorisation
