@@ -214,12 +214,12 @@ def main():
     # how a per-bin figure maps onto `rocprofv3 --kernel-trace --stats` rows (those average over BOTH half-steps)
     prof_names = {0: ["vh_pass_kernel<..., 0> x1 + vh_pass_kernel<..., 1> x%d" % MAX_CG_STEPS,
                       "vh_update_kernel<..., 0> x1 + vh_update_kernel<..., 1> x%d" % MAX_CG_STEPS],
-                  1: ["cg_rows_kernel<double, 7, true, 8, 1, false>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1, false>"],
-                  3: ["cg_rows_kernel<double, 7, true, 2, 1, false>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4, false>"],
+                  1: ["cg_rows_kernel<double, 7, true, 8, 1, false, 0>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1, false, 0>"],
+                  3: ["cg_rows_kernel<double, 7, true, 2, 1, false, 0>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4, false, 0>"],
                   5: ["cg_rows_tiny_kernel<double, 7, true, false>", "cg_rows_tiny2_kernel<double, 7, true> (rows of <= 16 nnz, two per wavefront)"]}
     inv = {v: b for b, v in names.items()}
     inv["gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
-    prof_names[6] = ["gram_wave_kernel<double, true, 2>", "gram_cg_kernel<double, true>"]
+    prof_names[6] = ["gram_wave_kernel<double, true, 2, false>", "gram_cg_kernel<double, true>"]
     for d in kernels:
         other = [e for e in kernels if e["kernel"] == d["kernel"] and e["step"] != d["step"]]
         # (a launch that runs beside other kernels has no duration of its own, and rocprof's average mixes it in:
