@@ -639,11 +639,16 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         HIP_CHECK(hipEventCreate(&ev.b));
         HIP_CHECK(hipEventRecord(ev.a, st));
     }
-    // rows of at most 16 entries (the tail of the bin): two per wavefront (cg_rows_tiny2_kernel); CMFREC_HIP_TINY2=0 keeps them
+    // rows of at most 16 entries (the tail of the bin): two per wavefront (cg_rows_tiny2_kernel) or
     // on the one-row kernel (A/B switch and cross-check)
     poison_lds(st, dev.num_cus);
-    static const bool tiny2_off = getenv("CMFREC_HIP_TINY2") != nullptr && getenv("CMFREC_HIP_TINY2")[0] == '0';
-    const int count2 = (GRAMX || tiny2_off) ? 0 : std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
+    // Round 4: with a Gramian (implicit model) the one-row kernel keeps its Gramian elements in registers and is bound by the vector
+    // ALU, the two-rows kernel reads twice as many of them from LDS per pass and is bound by the LDS pipe (80 % busy): C2's tiny bin
+    // 0.480 -> 0.465 ms (users), 0.146 -> 0.130 ms (items) with every row on the one-row kernel (profiles/r04/r04_x).  Without a
+    // Gramian (explicit model) two rows per wavefront stay the default.  CMFREC_HIP_TINY2 = 0 / 1 forces one or the other.
+    static const char *tiny2_env = getenv("CMFREC_HIP_TINY2");
+    const bool tiny2_on = (tiny2_env != nullptr) ? tiny2_env[0] != '0' : !IMPLICIT;
+    const int count2 = (GRAMX || !tiny2_on) ? 0 : std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
     const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
