@@ -623,11 +623,13 @@ template <typename T, int S>
 struct RegTile4 {
     T v[4][S];
     __device__ __forceinline__ void set(int t, int s, T x) { v[t][s] = x; }
+    __device__ __forceinline__ T get(int t, int s) const { return v[t][s]; }
 };
 template <int S>
 struct RegTile4<float, S> {
     f32x2 v[2][S];
     __device__ __forceinline__ void set(int t, int s, float x) { v[t >> 1][s][t & 1] = x; }
+    __device__ __forceinline__ f32x2 pair0(int s) const { return v[0][s]; }      // entries 0 and 1 of the lane group
 };
 
 // lanes 2t and 2t+1 of every 8-lane group carry non-zero jj*4+t (my_idx / x are loaded with
@@ -723,6 +725,90 @@ __device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (
     }
 }
 
+// Rows of at most 16 entries: a 16-slot tile, TWO entries per lane group instead of four -- lanes 4t .. 4t+3 of every 8-lane
+// group carry non-zero jj*2+t (my_idx / x are loaded with position lane>>2).  Half the tile products and one butterfly stage less
+// than the 32-slot tile for the rows that fill at most half of it (more than half of a tiny bin, typically).
+template <typename T, int S>
+struct RegTile2 {
+    T v[2][S];
+    __device__ __forceinline__ void set(int t, int s, T x) { v[t][s] = x; }
+    __device__ __forceinline__ T get(int t, int s) const { return v[t][s]; }
+};
+template <int S>
+struct RegTile2<float, S> {
+    f32x2 v[S];
+    __device__ __forceinline__ void set(int t, int s, float x) { v[s][t] = x; }
+    __device__ __forceinline__ f32x2 pair0(int s) const { return v[s]; }
+};
+
+// (TILE: RegTile2, or a RegTile4 whose first two entries per lane group are used -- the mixed launch of the tiny kernel)
+template <typename T, int S, typename TILE>
+__device__ __forceinline__ void load_tile2(TILE &tile, const T *__restrict__ Bm, size_t ldb,
+                                           int k, int my_idx, int cnt, int lane)
+{
+    const int jj = lane >> 3, ll = lane & 7;
+    int its[2];
+    its[0] = lanes::bcast8<0>(my_idx); its[1] = lanes::bcast8<4>(my_idx);
+    const int first_idx = __builtin_amdgcn_readfirstlane(my_idx);
+    const int col_last = min(ll + 8 * (S - 1), k - 1) - ll;
+    const char *base = reinterpret_cast<const char *>(Bm + ll);
+    const unsigned ldb_bytes = (unsigned)(ldb * sizeof(T));
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const unsigned it = (unsigned)(((jj * 2 + t) < cnt) ? its[t] : first_idx);
+        const T *rp = reinterpret_cast<const T *>(base + (unsigned long long)it * ldb_bytes);
+#pragma unroll
+        for (int s = 0; s < S; s++) tile.set(t, s, rp[(s < S - 1) ? 8 * s : col_last]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T treduce2_low(const T (&v)[2], int lane)
+{
+    const bool h = (lane & 4) != 0;
+    T u = (h ? v[1] : v[0]) + lanes::recv_xor4(v[0], v[1]);
+    u += lanes::xor2(u);
+    return u + lanes::xor1(u);          // lanes 4t .. 4t+3 hold the total of v[t]
+}
+
+template <typename T, int S, bool IMPLICIT, int MODE, typename TILE>
+__device__ __forceinline__ void tile_pass2(const TILE &tile, const T (&vrep)[S], T x, bool valid,
+                                           PassAcc<T> &out, int lane, T g = T(1))
+{
+    T c[2];
+    if constexpr (std::is_same<T, float>::value) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; s++) acc += tile.pair0(s) * f32x2{vrep[s], vrep[s]};
+        c[0] = acc[0]; c[1] = acc[1];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < S; s++) acc += tile.get(t, s) * vrep[s];
+            c[t] = acc;
+        }
+    }
+    const T coef = treduce2_low<T>(c, lane);
+    const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid, g);
+    const T w0 = lanes::bcast8<0>(w), w1 = lanes::bcast8<4>(w);
+    if constexpr (std::is_same<T, float>::value) {
+        const f32x2 w2 = f32x2{w0, w1};
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += w2 * tile.pair0(s);
+    } else {
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += w0 * tile.get(0, s);
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += w1 * tile.get(1, s);
+    }
+}
+
+// the tiny kernel's tile by entries per lane group (NE = 4: 32 slots, NE = 2: 16 slots)
+template <typename T, int S, int NE> struct TinyTile { using type = RegTile4<T, S>; };
+template <typename T, int S> struct TinyTile<T, S, 2> { using type = RegTile2<T, S>; };
+
 #ifndef CMF_TINY_WAVES_PER_SIMD
 #define CMF_TINY_WAVES_PER_SIMD 4     // 4: single tile buffer in a 128-VGPR budget (measured 10 % faster than
                                       // 2: double-buffered tiles, 2 x 56 VGPRs, 2 waves/SIMD)
@@ -791,15 +877,24 @@ __device__ __forceinline__ void gram_pass_regs(const GramRegs<T, S> &R, T wdist,
         for (int s = 0; s < S; s++) out.v[s] += wts[t] * R.v[t][s];
 }
 
-template <typename T, int S, bool IMPLICIT, bool GRAMX = false>
+template <typename T, int S, bool IMPLICIT, bool GRAMX = false, int NE = 4>
 __global__ void __launch_bounds__(256, (tiny_waves_per_simd<T, IMPLICIT || GRAMX>()))
 cg_rows_tiny_kernel(const CgParams<T> P)
 {
+    // NE: entries per lane group -- 4 (32-slot tile), 2 (16-slot tile: rows of <= 16 entries only) or 0: by row, the 16-slot tile
+    // for the rows of <= 16 entries and the 32-slot tile for the others in ONE launch (a second launch for the short rows costs
+    // more in launch tails beside the other bins than the short tile saves)
+    static_assert(NE == 4 || NE == 2 || NE == 0, "entries per lane group");
+    constexpr bool MIX = NE == 0;
+    static_assert(!MIX || CMF_TINY_WAVES_PER_SIMD >= 3, "the mixed launch lives in the dynamically scheduled loop");
+    using Tile = typename TinyTile<T, S, (NE == 2) ? 2 : 4>::type;
     constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    auto short_row = [&](int nnz_) -> bool { return MIX && nnz_ <= 16; };
+    auto entry_of = [&](int nnz_) -> int { return (NE == 2 || short_row(nnz_)) ? (lane >> 2) : (lane >> 1); };
     const int k = P.k;
     if (GRAM) {
         stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
@@ -821,8 +916,9 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     };
     auto load_pre = [&](const RowDesc &d) -> Pre {
         Pre q; q.idx = 0; q.x = T(0); q.a = T(0); q.g = T(1);
-        if ((lane >> 1) < d.nnz) {
-            const size_t pos = d.st + (size_t)(lane >> 1);
+        const int ent = entry_of(d.nnz);
+        if (ent < d.nnz) {
+            const size_t pos = d.st + (size_t)ent;
             q.idx = P.indices[pos];
             q.x = P.values[pos];
             q.g = entry_weight<T, IMPLICIT>(P, pos);
@@ -831,8 +927,13 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         if (d.nnz > 0 && lane < k) q.a = P.A[(size_t)d.row * P.lda + lane];
         return q;
     };
+    auto load_tile_ne = [&](Tile &t_, const T *Bm_, size_t ldb_, int k_, int idx_, int cnt_, int lane_) {
+        if constexpr (NE != 2) load_tile4<T, S>(t_, Bm_, ldb_, k_, idx_, cnt_, lane_);
+        else load_tile2<T, S>(t_, Bm_, ldb_, k_, idx_, cnt_, lane_);
+    };
     // CG on one register-resident 32-nnz tile (same arithmetic as cg_rows_kernel)
-    auto solve = [&](const RowDesc &d, const Pre &pr, const RegTile4<T, S> &tile) {
+    auto solve = [&](const RowDesc &d, const Pre &pr, const Tile &tile, auto short_tag) {
+        constexpr bool T2 = NE == 2 || decltype(short_tag)::value;      // 16-slot tile (the first two entries of a RegTile4 in the mixed launch)
         const int nnz = d.nnz;
         T lam = P.lam, lam_last = P.lam_last;
         if (GRAMX && P.kc > 0) {
@@ -846,7 +947,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             lam *= mult;
             if (!P.scale_bias_const) lam_last *= mult;
         }
-        const bool valid = (lane >> 1) < nnz;
+        const bool valid = (T2 ? (lane >> 2) : (lane >> 1)) < nnz;
         T a_d = pr.a;
         auto run_pass = [&](T vdist, auto mode_tag) -> T {
             constexpr int MODE = decltype(mode_tag)::value;
@@ -855,7 +956,10 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
-            if (!CMF_DBG(P, 4)) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
+            if (!CMF_DBG(P, 4)) {
+                if constexpr (!T2) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
+                else tile_pass2<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
+            }
             if constexpr (GREG) { if (!CMF_DBG(P, 2)) gram_pass_regs(greg, (MODE == 0) ? -vdist : vdist, acc); }
             else if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
@@ -905,14 +1009,22 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         int rnn = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(c2);
         RowDesc d0 = load_desc(rix), d1 = load_desc(rnxt);
         Pre p0 = load_pre(d0);
-        RegTile4<T, S> tA;
+        Tile tA;
         int pend = issue_claim();
         while (rix < P.nrows) {
-            if (CMF_DBG(P, 1)) dbg_fill_tile<4, S>(tA, (T)(p0.idx & 3) * (T)0.001);
-            else load_tile4<T, S>(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
+            const bool shrt = short_row(d0.nnz);
+            if (CMF_DBG(P, 1)) {
+                dbg_fill_tile<(NE == 2) ? 2 : 4, S>(tA, (T)(p0.idx & 3) * (T)0.001);
+            } else if constexpr (MIX) {
+                if (shrt) load_tile2<T, S>(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
+                else load_tile_ne(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
+            } else load_tile_ne(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
             RowDesc d2 = load_desc(rnn);
             Pre p1 = load_pre(d1);
-            solve(d0, p0, tA);
+            if constexpr (MIX) {
+                if (shrt) solve(d0, p0, tA, std::true_type{});
+                else solve(d0, p0, tA, std::false_type{});
+            } else solve(d0, p0, tA, std::false_type{});
             const int r3 = cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(pend);
             d0 = d1; p0 = p1; d1 = d2;
             rix = rnxt; rnxt = rnn; rnn = r3;
@@ -923,22 +1035,22 @@ cg_rows_tiny_kernel(const CgParams<T> P)
 #endif
     RowDesc d0 = load_desc(rix), d1 = load_desc(rix + nwaves), d2 = load_desc(rix + 2 * nwaves);
     Pre p0 = load_pre(d0);
-    RegTile4<T, S> tA, tB;
-    if (d0.nnz > 0) load_tile4<T, S>(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
+    Tile tA, tB;
+    if (d0.nnz > 0) load_tile_ne(tA, P.B, P.ldb, k, p0.idx, d0.nnz, lane);
     Pre p1 = load_pre(d1);
     while (rix < P.nrows) {
         // row i   : buffer A (gather in flight), row i+1: start its gather into buffer B now
-        if (d1.nnz > 0) load_tile4<T, S>(tB, P.B, P.ldb, k, p1.idx, d1.nnz, lane);
+        if (d1.nnz > 0) load_tile_ne(tB, P.B, P.ldb, k, p1.idx, d1.nnz, lane);
         RowDesc d3 = load_desc(rix + 3 * nwaves);
         Pre p2 = load_pre(d2);
-        solve(d0, p0, tA);
+        solve(d0, p0, tA, std::false_type{});
         rix += nwaves;
         if (rix >= P.nrows) break;
         // row i+1 : buffer B, row i+2: gather into buffer A
-        if (d2.nnz > 0) load_tile4<T, S>(tA, P.B, P.ldb, k, p2.idx, d2.nnz, lane);
+        if (d2.nnz > 0) load_tile_ne(tA, P.B, P.ldb, k, p2.idx, d2.nnz, lane);
         RowDesc d4 = load_desc(rix + 3 * nwaves);
         Pre p3 = load_pre(d3);
-        solve(d1, p1, tB);
+        solve(d1, p1, tB, std::false_type{});
         rix += nwaves;
         d0 = d2; p0 = p2; d1 = d3; p1 = p3; d2 = d4;
     }

@@ -645,10 +645,17 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     // Round 4: with a Gramian (implicit model) the one-row kernel keeps its Gramian elements in registers and is bound by the vector
     // ALU, the two-rows kernel reads twice as many of them from LDS per pass and is bound by the LDS pipe (80 % busy): C2's tiny bin
     // 0.480 -> 0.465 ms (users), 0.146 -> 0.130 ms (items) with every row on the one-row kernel (profiles/r04/r04_x).  Without a
-    // Gramian (explicit model) two rows per wavefront stay the default.  CMFREC_HIP_TINY2 = 0 / 1 forces one or the other.
+    // Gramian (explicit model) the two-rows kernel is the faster one in isolation, but as a second launch of the bin it costs more
+    // in tails beside the other bins' launches than it saves (config 4 on one GPU 66.2 -> 64.9 ms with ONE launch for the bin,
+    // profiles/r04/r04_z2).  So by default the bin is one launch of the one-row kernel, which takes a 16-slot tile for the rows of
+    // <= 16 entries and the 32-slot tile for the others (NE = 0); CMFREC_HIP_TINY16=0: the 32-slot tile for every row;
+    // CMFREC_HIP_TINY2=1: the rows of <= 16 entries on the two-rows kernel.
     static const char *tiny2_env = getenv("CMFREC_HIP_TINY2");
-    const bool tiny2_on = (tiny2_env != nullptr) ? tiny2_env[0] != '0' : !IMPLICIT;
-    const int count2 = (GRAMX || !tiny2_on) ? 0 : std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
+    const bool tiny2_on = (tiny2_env != nullptr) && tiny2_env[0] != '0';
+    static const char *tiny16_env = getenv("CMFREC_HIP_TINY16");
+    const bool tiny16_on = (tiny16_env == nullptr) || tiny16_env[0] != '0';
+    const int count_le16 = std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
+    const int count2 = (GRAMX || !tiny2_on) ? 0 : count_le16;
     const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
@@ -658,9 +665,10 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         P1.desc += first;
         P1.nrows = count1;
         P1.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
-        auto kern = cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX>;
-        static thread_local int bpc_dev[MAX_DEVICES] = {0};
-        int &blocks_per_cu = bpc_dev[di];
+        const bool mixed = tiny16_on && count2 == 0 && count_le16 > 0;
+        auto kern = mixed ? cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX, 0> : cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX, 4>;
+        static thread_local int bpc_dev[MAX_DEVICES][2] = {{0}};
+        int &blocks_per_cu = bpc_dev[di][mixed ? 1 : 0];
         if (blocks_per_cu == 0) {
             int nb = 0;
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
