@@ -46,6 +46,23 @@ struct RowDesc {
 constexpr int CG_NCOUNTERS = 64;        // work counters per launch of a tiled CG kernel ...
 constexpr int CG_COUNTER_STRIDE = 32;    // ... each on its own 128-byte line
 
+// Reads of the staged Gramian.  CMF_LDS_B64 = 1: every 8-byte read stays a ds_read_b64 of its own (a volatile access is never
+// paired) -- on this part a ds_read_b64 occupies the LDS for 2 cycles per wavefront (64 banks, 256 B/clk) while the ds_read2_b64
+// the compiler pairs neighbouring reads into takes 8 (two accesses of 4 x 16 lanes, 128 B/clk): half the LDS time per element.
+#ifndef CMF_LDS_B64
+#define CMF_LDS_B64 0
+#endif
+template <typename V>
+__device__ __forceinline__ V lds_g(const V *p)
+{
+#if CMF_LDS_B64
+    typedef const volatile __attribute__((address_space(3))) V *lds_cvp;   // explicit LDS pointer: a volatile generic access would be a flat_load
+    return *(lds_cvp)p;
+#else
+    return *p;
+#endif
+}
+
 template <typename T>
 struct CgParams {
     T *A;                 // [nrows_total, lda] matrix being updated, first solved column
@@ -357,7 +374,7 @@ __device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, Pass
             const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (jj * 4 + q) * gram_ld2(S) + ll;
             const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
 #pragma unroll
-            for (int s = 0; s < S; s++) out.v[s] += w2 * g[8 * s];
+            for (int s = 0; s < S; s++) out.v[s] += w2 * lds_g(g + 8 * s);
         }
     } else {
 #pragma unroll
@@ -366,7 +383,7 @@ __device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, Pass
 #pragma unroll
             for (int s = 0; s < S; s++) {
                 if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
-                else out.v[s] += wts[t] * G[(jj * 8 + t) * LD + ll + 8 * s];
+                else out.v[s] += wts[t] * lds_g(G + (jj * 8 + t) * LD + ll + 8 * s);
             }
         }
     }
@@ -821,7 +838,10 @@ template <typename T, int S> struct TinyTile<T, S, 2> { using type = RegTile2<T,
 #ifndef CMF_TINY_GREG_F32
 #define CMF_TINY_GREG_F32 1          // single precision: 8 S registers more per lane, three wavefronts per SIMD (c4shard 8.03-8.17 -> 7.91-7.92 ms; 0 = Gramian in LDS)
 #endif
-template <typename T, bool GRAM> constexpr bool tiny_greg() { return GRAM && (sizeof(T) == 8 || CMF_TINY_GREG_F32 != 0); }
+#ifndef CMF_TINY_GREG_F64
+#define CMF_TINY_GREG_F64 1          // double precision: 0 = Gramian in LDS, four wavefronts per SIMD
+#endif
+template <typename T, bool GRAM> constexpr bool tiny_greg() { return GRAM && (sizeof(T) == 8 ? CMF_TINY_GREG_F64 != 0 : CMF_TINY_GREG_F32 != 0); }
 template <typename T, bool GRAM> constexpr int tiny_waves_per_simd() { return tiny_greg<T, GRAM>() ? (sizeof(T) == 8 ? 2 : 3) : CMF_TINY_WAVES_PER_SIMD; }
 template <typename T, int S>
 struct GramRegs {
@@ -1173,14 +1193,14 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
                             const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (16 * a + 4 * jq + qq) * gram_ld2(S) + ll;
                             const f32x2 w2 = f32x2{w[2 * qq], w[2 * qq + 1]};
 #pragma unroll
-                            for (int s = 0; s < S; s++) acc.v[s] += w2 * g[8 * s];
+                            for (int s = 0; s < S; s++) acc.v[s] += w2 * lds_g(g + 8 * s);
                         }
                     } else {
 #pragma unroll
                         for (int t = 0; t < 8; t++) {
                             const T *g = G + (32 * a + 8 * jq + t) * LD + ll;
 #pragma unroll
-                            for (int s = 0; s < S; s++) acc.v[s] += w[t] * g[8 * s];
+                            for (int s = 0; s < S; s++) acc.v[s] += w[t] * lds_g(g + 8 * s);
                         }
                     }
                 }
