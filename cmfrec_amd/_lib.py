@@ -35,7 +35,7 @@ class ModelF(C.Structure):
 
 EXPORTED = [
     "fit_collective_implicit_als", "fit_collective_explicit_als",
-    "factors_collective_explicit_multiple", "factors_collective_implicit_multiple", "cmfrec_hip_factors_multiple",
+    "factors_collective_explicit_multiple", "factors_collective_implicit_multiple", "cmfrec_hip_factors_multiple", "cmfrec_hip_factors_multiple_l1",
     "cmfrec_hip_optimizeA_implicit", "cmfrec_hip_optimizeA_explicit", "cmfrec_hip_optimizeA_explicit_weighted",
     "cmfrec_hip_optimizeA_dense_full", "cmfrec_hip_optimizeA_collective", "cmfrec_hip_optimizeA_collective_sparse", "cmfrec_hip_topN_batch",
     "cmfrec_hip_session_create", "cmfrec_hip_session_destroy", "cmfrec_hip_last_error", "cmfrec_hip_last_error_code",

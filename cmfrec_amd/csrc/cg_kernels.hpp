@@ -52,6 +52,20 @@ constexpr int CG_COUNTER_STRIDE = 32;    // ... each on its own 128-byte line
 #ifndef CMF_LDS_B64
 #define CMF_LDS_B64 0
 #endif
+// The two quotients of a CG step (alpha = r.r / p.Ap, beta = r'.r' / r.r).  Single precision: numerator x v_rcp_f32(denominator)
+// -- 1 ulp for the reciprocal, ~2 ulp (1.2e-7) for the quotient against the twelve-instruction IEEE sequence (v_div_scale x 2,
+// v_rcp, four FMAs, v_div_fmas, v_div_fixup), every lane computing the same wave-uniform number; 0 / 0 and x / 0 come out as in
+// the IEEE sequence (NaN, inf).  Double precision keeps the IEEE division.  -DCMF_CG_IEEE_DIV: IEEE in both.
+template <typename T>
+__device__ __forceinline__ T cg_div(T num, T den)
+{
+#ifndef CMF_CG_IEEE_DIV
+    if constexpr (sizeof(T) == 4) return num * __builtin_amdgcn_rcpf(den);
+    else
+#endif
+        return num / den;
+}
+
 template <typename V>
 __device__ __forceinline__ V lds_g(const V *p)
 {
@@ -611,13 +625,13 @@ cg_rows_kernel(const CgParams<T> P)
             Ap_d += lam * p_d;
             if (!IMPLICIT && lam != lam_last && lane == k - 1) Ap_d += (lam_last - lam) * p_d;
             if (lane >= k) Ap_d = T(0);
-            T alpha = CMF_DBG(P, 8) ? T(0.001) : r_old / wave_sum(Ap_d * p_d);
+            T alpha = CMF_DBG(P, 8) ? T(0.001) : cg_div(r_old, wave_sum(Ap_d * p_d));
             a_d += alpha * p_d;
             r_d -= alpha * Ap_d;
             T r_new = CMF_DBG(P, 8) ? T(0.5) : wave_sum(r_d * r_d);
             if (r_new <= (T)1e-8) done = true;      // common.c:1979 / :1180
             else {
-                p_d = p_d * (r_new / r_old) + r_d;
+                p_d = p_d * cg_div(r_new, r_old) + r_d;
                 r_old = r_new;
             }
         }
@@ -999,13 +1013,13 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             Ap_d += lam * p_d;
             if (!IMPLICIT && lam != lam_last && lane == k - 1) Ap_d += (lam_last - lam) * p_d;
             if (lane >= k) Ap_d = T(0);
-            T alpha = r_old / wave_sum(Ap_d * p_d);
+            T alpha = cg_div(r_old, wave_sum(Ap_d * p_d));
             a_d += alpha * p_d;
             r_d -= alpha * Ap_d;
             T r_new = wave_sum(r_d * r_d);
             if (r_new <= (T)1e-8) done = true;
             else {
-                p_d = p_d * (r_new / r_old) + r_d;
+                p_d = p_d * cg_div(r_new, r_old) + r_d;
                 r_old = r_new;
             }
         }
@@ -1093,7 +1107,7 @@ __device__ __forceinline__ T half_sum(T v)
 {
     v += lanes::xor1(v);
     v += lanes::xor2(v);
-    v += lanes::xor4(v);
+    v += lanes::qxor4(v);
     v += lanes::xor8(v);
     return lanes::tswap16_add(v, v);            // lanes l and l + 16 of each half
 }
@@ -1232,14 +1246,14 @@ cg_rows_tiny2_kernel(const CgParams<T> P)
             if (!live0) Ap0 = T(0);
             if (!live1) Ap1 = T(0);
             const T pAp = half_sum(Ap0 * p0 + Ap1 * p1);
-            const T alpha = done ? T(0) : r_old / pAp;
+            const T alpha = done ? T(0) : cg_div(r_old, pAp);
             a0 += alpha * p0; a1 += alpha * p1;
             r0 -= alpha * Ap0; r1 -= alpha * Ap1;
             const T r_new = half_sum(r0 * r0 + r1 * r1);
             if (!done) {
                 if (r_new <= (T)1e-8) done = true;              // common.c:1979 / :1180
                 else {
-                    const T beta = r_new / r_old;
+                    const T beta = cg_div(r_new, r_old);
                     p0 = p0 * beta + r0; p1 = p1 * beta + r1;
                     r_old = r_new;
                 }
@@ -1413,7 +1427,7 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
         T Ap_d = tot + lam * p_d;
         if (!IMPLICIT && lam != lam_last && lane == k - 1) Ap_d += (lam_last - lam) * p_d;
         if (lane >= k) Ap_d = T(0);
-        T alpha = r_old / wave_sum(Ap_d * p_d);
+        T alpha = cg_div(r_old, wave_sum(Ap_d * p_d));
         a_d += alpha * p_d;
         r_d -= alpha * Ap_d;
         T r_new = wave_sum(r_d * r_d);
@@ -1421,7 +1435,7 @@ vh_update_kernel(const CgParams<T> P, const VhState<T> V)
         if (r_new <= (T)1e-8) {
             if (lane == 0) V.done[vi] = 1;
         } else {
-            V.p[(size_t)vi * 64 + lane] = p_d * (r_new / r_old) + r_d;
+            V.p[(size_t)vi * 64 + lane] = p_d * cg_div(r_new, r_old) + r_d;
             V.r[(size_t)vi * 64 + lane] = r_d;
             if (lane == 0) V.r_old[vi] = r_new;
         }
@@ -1699,14 +1713,14 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     if (!IMPLICIT && lam != lam_last && f == kt - 1) Ap[c] += (lam_last - lam) * p[c];
                     if (!live(f)) Ap[c] = T(0);
                 }
-                T alpha = r_old / vdot(Ap, p);
+                T alpha = cg_div(r_old, vdot(Ap, p));
 #pragma unroll
                 for (int c = 0; c < NF; c++) {
                     a[c] += alpha * p[c]; r[c] -= alpha * Ap[c];
                     z[c] = r[c] * PC[c];
                 }
                 T r_new = vdot(z, r);
-                T ratio = r_new / r_old;
+                T ratio = cg_div(r_new, r_old);
 #pragma unroll
                 for (int c = 0; c < NF; c++) p[c] = p[c] * ratio + z[c];
                 r_old = r_new;
@@ -1723,12 +1737,12 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     if (!IMPLICIT && lam != lam_last && f == kt - 1) Ap[c] += (lam_last - lam) * p[c];
                     if (!live(f)) Ap[c] = T(0);
                 }
-                T alpha = r_old / vdot(Ap, p);
+                T alpha = cg_div(r_old, vdot(Ap, p));
 #pragma unroll
                 for (int c = 0; c < NF; c++) { a[c] += alpha * p[c]; r[c] -= alpha * Ap[c]; }
                 T r_new = vdot(r, r);
                 if (r_new <= (T)1e-8) break;
-                T ratio = r_new / r_old;
+                T ratio = cg_div(r_new, r_old);
 #pragma unroll
                 for (int c = 0; c < NF; c++) p[c] = p[c] * ratio + r[c];
                 r_old = r_new;

@@ -1326,7 +1326,7 @@ int_t fit_collective_explicit_als(
 
 // ---- factors of new rows (the step after the path) -----------------------------------------------------
 // Same positional signatures as the reference (src/cmfrec.h:2004-2071).  Supported: sparse X (COO or CSR, missing = not
-// observed), dense U without NaN, no binary side information / weights / implicit features / L1 / non-negativity /
+// observed), dense U without NaN, L1 penalties, non-negativity; no binary side information / weights / implicit features /
 // NA_as_zero.  Anything else returns 2 with a message on stderr.  The precomputed matrices of the reference's
 // signature are optional accelerators there; here the small Gramians are rebuilt on the device from B and C (BtB of the
 // implicit model and TransCtCinvCt are used when given, because they decide the result: collective.c:11270-11280, :3380).
@@ -1373,16 +1373,20 @@ int_t factors_collective_explicit_multiple(
     if (Xfull) return unsupported_multiple("dense X");
     if (weight) return unsupported_multiple("observation weights");
     if (Bi || add_implicit_features) return unsupported_multiple("implicit features");
-    if (l1_lam != 0 || l1_lam_unique) return unsupported_multiple("L1 regularisation");
     if (U == nullptr && !spU) { m_u = 0; }
     if (std::max(m, m_u) <= 0) return 0;
     if (U) for (size_t e = 0; e < (size_t)m_u * (size_t)p; e++) if (std::isnan(U[e])) return unsupported_multiple("missing values in U");
     // factors_collective_explicit_single, collective.c:10611-10630
-    real_t lam_bias = lam;
+    real_t lam_bias = lam, l1_lam_bias = l1_lam;
     if (lam_unique) { lam_bias = lam_unique[biasA ? 0 : 2]; lam = lam_unique[2]; }
+    if (l1_lam_unique) { l1_lam_bias = l1_lam_unique[biasA ? 0 : 2]; l1_lam = l1_lam_unique[2]; }
     if (!biasA) scale_bias_const = false;
-    if ((scale_lam || scale_lam_sideinfo) && scale_bias_const) lam_bias *= scaling_biasA;
-    if (w_main != 1) { w_user /= w_main; lam /= w_main; lam_bias /= w_main; }   // collective_factors_warm, :3694-3702
+    if ((scale_lam || scale_lam_sideinfo) && scale_bias_const) { lam_bias *= scaling_biasA; l1_lam_bias *= scaling_biasA; }
+    if (w_main != 1) {                                                          // collective_factors_warm, :3694-3713
+        w_user /= w_main; lam /= w_main; lam_bias /= w_main; l1_lam /= w_main; l1_lam_bias /= w_main;
+    }
+    const bool l1on = l1_lam != 0 || (biasA && l1_lam_bias != 0);
+    if (l1on && nonneg) return unsupported_multiple("L1 regularisation together with non-negativity");
     // rows without side information and without a bias: the reference passes scale_lam where factors_closed_form
     // expects scale_bias_const (:3789-3799), so the last factor keeps the unscaled lam
     if (!biasA) scale_bias_const = scale_lam || scale_lam_sideinfo;
@@ -1396,11 +1400,12 @@ int_t factors_collective_explicit_multiple(
         vals = shifted.data();
     }
     const int_t n_rows_B = include_all_X ? std::max(n, n_max) : n;
-    int rc = cmfrec_hip_factors_multiple(A, biasA, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
-                                         Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n_rows_B, C, biasB, k, k_user, k_item,
-                                         k_main, lam, lam_bias, lam, w_user, false, scale_lam, scale_lam_sideinfo,
-                                         scale_bias_const, nullptr, nonneg ? nullptr : TransCtCinvCt, U_row, U_col, U_sp, nnz_U,
-                                         U_csr_p, U_csr_i, U_csr, nonneg);
+    // (TransCtCinvCt: not with non-negativity or an L1 penalty, collective.c:3378)
+    int rc = cmfrec_hip_factors_multiple_l1(A, biasA, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
+                                            Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n_rows_B, C, biasB, k, k_user, k_item,
+                                            k_main, lam, lam_bias, lam, w_user, false, scale_lam, scale_lam_sideinfo,
+                                            scale_bias_const, nullptr, (nonneg || l1on) ? nullptr : TransCtCinvCt, U_row, U_col,
+                                            U_sp, nnz_U, U_csr_p, U_csr_i, U_csr, nonneg, l1_lam, l1_lam_bias);
     if (rc == 2) fprintf(stderr, "%s\n", cmfrec_hip_last_error());
     return rc > 3 ? 1 : rc;
 }
@@ -1427,8 +1432,14 @@ int_t factors_collective_implicit_multiple(
     (void)BeTBe; (void)CtUbias; (void)nthreads;
     if (NA_as_zero_U) return unsupported_multiple("NA_as_zero");
     const bool spU = (U == nullptr && (nnz_U || U_csr_p));
-    if (l1_lam != 0) return unsupported_multiple("L1 regularisation");
     if (U == nullptr && !spU) m_u = 0;
+    // L1 penalty: rows with observations keep the l1_lam of the call (collective_factors_warm_implicit rescales lam and w_user by
+    // w_main only, :4000-4004).
+    // With side information the reference's own result is not finite (its elastic-net sweeps diverge on the block system of
+    // collective_closed_form_block_implicit: +-inf in most rows of a seeded problem, tests/golden_cases.py) -- refused.
+    if (l1_lam != 0 && (U || spU))
+        return unsupported_multiple("L1 regularisation together with side information (the reference's result is not finite)");
+    if (l1_lam != 0 && nonneg) return unsupported_multiple("L1 regularisation together with non-negativity");
     if (std::max(m, m_u) <= 0) return 0;                                        // rows out: max(m, m_u), collective.c:11210
     if (U) for (size_t e = 0; e < (size_t)m_u * (size_t)p; e++) if (std::isnan(U[e])) return unsupported_multiple("missing values in U");
     // BtB as the reference builds it when none is passed: + the lam of the call, before the w_main rescaling
@@ -1447,10 +1458,10 @@ int_t factors_collective_implicit_multiple(
     }
     // a precomputed BeTBeChol without BtB means the caller's BtB is unknown: rebuild (equal for consistent inputs)
     (void)BeTBeChol;
-    int rc = cmfrec_hip_factors_multiple(A, nullptr, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
-                                         Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n, C, nullptr, k, k_user, k_item, k_main,
-                                         lam, lam, BtB ? lam : lam_x, w_user, true, false, false, false, BtB, nullptr,
-                                         U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr, nonneg);
+    int rc = cmfrec_hip_factors_multiple_l1(A, nullptr, m, m_u, (U || spU) ? p : 0, U, U_colmeans, ixA, ixB, Xcsr_p ? nullptr : vals, nnz,
+                                            Xcsr_p, Xcsr_i, Xcsr_p ? vals : nullptr, B, n, C, nullptr, k, k_user, k_item, k_main,
+                                            lam, lam, BtB ? lam : lam_x, w_user, true, false, false, false, BtB, nullptr,
+                                            U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr, nonneg, l1_lam, l1_lam);
     return rc > 3 ? 1 : rc;
 }
 

@@ -193,13 +193,13 @@ gram_cg_wide_kernel(const CgParams<T> P, const WideCgParams<T> W)
             for (int step = 0; step < P.max_cg_steps; step++) {
                 T Ap[GCW_NF];
                 mul(p, Ap);
-                const T alpha = r_old / dot(Ap, p);
+                const T alpha = cg_div(r_old, dot(Ap, p));
 #pragma unroll
                 for (int c = 0; c < GCW_NF; c++) { a[c] += alpha * p[c]; r[c] -= alpha * Ap[c]; }
                 const T r_new = dot(r, r);
                 if (r_new <= (T)1e-8) break;                // :1180
 #pragma unroll
-                for (int c = 0; c < GCW_NF; c++) p[c] = p[c] * (r_new / r_old) + r[c];
+                for (int c = 0; c < GCW_NF; c++) p[c] = p[c] * cg_div(r_new, r_old) + r[c];
                 r_old = r_new;
             }
         }

@@ -40,6 +40,17 @@ __device__ __forceinline__ int dpp_new(int src)
 {
     return __builtin_amdgcn_mov_dpp(src, CTRL, 0xF, BANK, false);
 }
+// full-mask permutation inside a row (every lane has a valid source): bound_ctrl with a zero `old` is the form the compiler folds
+// into the consuming 32-bit VALU instruction (v_add_f32_dpp ...) instead of a v_mov_b32_dpp of its own
+template <int CTRL>
+__device__ __forceinline__ int dpp_full(int src)
+{
+#ifndef CMF_DPP_NOFOLD
+    return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xF, 0xF, true);
+#else
+    return __builtin_amdgcn_mov_dpp(src, CTRL, 0xF, 0xF, false);
+#endif
+}
 
 // ---- apply a dword -> dword lane operation to float / double / int ---------------------------
 template <typename F> __device__ __forceinline__ int map(int x, F f) { return f(x); }
@@ -58,13 +69,13 @@ template <typename F> __device__ __forceinline__ double map2(double a, double b,
     return __hiloint2double(f(__double2hiint(a), __double2hiint(b)), f(__double2loint(a), __double2loint(b)));
 }
 
-template <typename T> __device__ __forceinline__ T xor1(T x) { return map(x, [](int v) { return dpp_new<QP_XOR1, 0xF>(v); }); }
-template <typename T> __device__ __forceinline__ T xor2(T x) { return map(x, [](int v) { return dpp_new<QP_XOR2, 0xF>(v); }); }
+template <typename T> __device__ __forceinline__ T xor1(T x) { return map(x, [](int v) { return dpp_full<QP_XOR1>(v); }); }
+template <typename T> __device__ __forceinline__ T xor2(T x) { return map(x, [](int v) { return dpp_full<QP_XOR2>(v); }); }
 template <typename T> __device__ __forceinline__ T xor4(T x)
 {
     return map(x, [](int v) { int t = dpp_new<ROW_SHL4, 0x5>(v); return dpp<ROW_SHR4, 0xA>(t, v); });
 }
-template <typename T> __device__ __forceinline__ T xor8(T x) { return map(x, [](int v) { return dpp_new<ROW_ROR8, 0xF>(v); }); }
+template <typename T> __device__ __forceinline__ T xor8(T x) { return map(x, [](int v) { return dpp_full<ROW_ROR8>(v); }); }
 
 // lanes with (lane & M) == 0 receive a[lane ^ M], the others b[lane ^ M]  (M = 4 or 8)
 template <typename T> __device__ __forceinline__ T recv_xor4(T a, T b)
@@ -122,14 +133,28 @@ template <int t> __device__ __forceinline__ int row_bcast16(int x) { return __bu
 template <int t> __device__ __forceinline__ float row_bcast16(float x) { return __int_as_float(row_bcast16<t>(__float_as_int(x))); }
 template <int t> __device__ __forceinline__ double row_bcast16(double x) { return __builtin_amdgcn_mov_dpp(x, ROW_NEWBCAST + t, 0xF, 0xF, false); }
 // value of lane (lane ^ 7) (the mirror image inside the lane's group of 8)
-template <typename T> __device__ __forceinline__ T half_mirror(T x) { return map(x, [](int v) { return dpp_new<ROW_HALF_MIRROR, 0xF>(v); }); }
+template <typename T> __device__ __forceinline__ T half_mirror(T x) { return map(x, [](int v) { return dpp_full<ROW_HALF_MIRROR>(v); }); }
+
+// x[lane ^ 4] for an x whose four lanes of every quad hold the same bits (the state after the xor1 and xor2 stages of a sum:
+// a + b == b + a bit for bit): the mirror lane 7 - i lies in the partner quad, so ONE full-mask move (folded into the consuming
+// add in single precision) replaces the two masked moves of xor4 -- the same bits in every lane
+template <typename T> __device__ __forceinline__ T qxor4(T x)
+{
+#ifndef CMF_DPP_NOFOLD
+    return half_mirror(x);
+#else
+    return xor4(x);
+#endif
+}
 
 // full wave sum, identical on every lane
+// (tried in round 4: rows 1 / 3 adding lane 15 of the row below, rows 2 / 3 lane 31 -- the row_bcast controls -- and v_readlane 63:
+//  the compiler does not fold the masked move into the add, 801 -> 815 vector instructions in the fp32 tiny kernel; not kept)
 template <typename T> __device__ __forceinline__ T wave_sum(T v)
 {
     v += xor1(v);
     v += xor2(v);
-    v += xor4(v);
+    v += qxor4(v);
     v += xor8(v);
     v = tswap16_add(v, v);
     v = tswap32_add(v, v);

@@ -311,7 +311,7 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 T v = part[r];
-                v += lanes::xor1(v); v += lanes::xor2(v); v += lanes::xor4(v); v += lanes::xor8(v);
+                v += lanes::xor1(v); v += lanes::xor2(v); v += lanes::qxor4(v); v += lanes::xor8(v);
                 part[r] = v;
             }
             if (PASS == 0) {

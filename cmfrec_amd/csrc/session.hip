@@ -2696,15 +2696,19 @@ int cmfrec_hip_optimizeA_collective_sparse(real_t *A, size_t lda, const real_t *
 //                         COLLECTIVE_IMPLICIT; lam_x is what sits on the diagonal of the X block (the reference adds
 //                         the *unscaled* lam there when it builds BtB itself, :11270-11280, and lam / w_main on the
 //                         k_user block), BtB_pre (lam included) replaces B^T B + lam_x I when given.
-int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U,
-                                const real_t *U_colmeans, const int_t ixA[], const int_t ixB[], const real_t *X,
-                                size_t nnz, const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
-                                const real_t *B, int_t n, const real_t *C, const real_t *biasB, int_t k, int_t k_user,
-                                int_t k_item, int_t k_main, real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
-                                bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
-                                const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
-                                const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
-                                const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr, bool nonneg)
+// l1_lam / l1_lam_bias: the L1 penalty of the row systems and of the bias unknown (solve_elasticnet instead of the Cholesky
+// substitution, common.c:2228-2294; collective_factors_warm / _cold hand them down like lam / lam_bias, collective.c:3571-3931,
+// :3321-3400), already divided by w_main.  Rows that only have side information take l1_lam / w_user (:3395).
+static int factors_multiple_impl(real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U,
+                                 const real_t *U_colmeans, const int_t ixA[], const int_t ixB[], const real_t *X,
+                                 size_t nnz, const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                 const real_t *B, int_t n, const real_t *C, const real_t *biasB, int_t k, int_t k_user,
+                                 int_t k_item, int_t k_main, real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
+                                 bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+                                 const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
+                                 const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
+                                 const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr, bool nonneg,
+                                 real_t l1_lam, real_t l1_lam_bias)
 {
     return guarded([&]() {
         // sparse side information (COO or CSR over m_u rows, missing = absent): second gather source of the row kernel
@@ -2755,6 +2759,14 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
         // new rows, 10 x the number of unknowns (collective.c:3401, :3800-3931, :4041-4054)
         dev.nonneg_now = nonneg;
         dev.max_cd_steps = 10 * (k_user + k + k_main + ub);
+        const bool l1on = l1_lam != (real_t)0 || (ub && l1_lam_bias != (real_t)0);
+        if (l1on && TransCtCinvCt_pre) {
+            g_last_error = "cmfrec_hip_factors_multiple: TransCtCinvCt cannot be used with an L1 penalty (collective.c:3378)";
+            return 2;
+        }
+        dev.l1_now = l1_lam;
+        dev.l1_last_now = ub ? l1_lam_bias : l1_lam;
+        dev.l1_scale = 1;
         const int kc = k_user + k, kk = k + k_main, kt = k_user + kk + ub, ktA = k_user + kk;
         const size_t ldb_host = (size_t)(k_item + kk), ldB = ldb_host + ub, ldA = (size_t)kt;
         DevBuf<real_t> dA, dB, dC, dU, dmeans, dbias, dG, dM, dCtC, dcold, dT;
@@ -2866,7 +2878,11 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
                     launch_gemm<false>(dev, m_u, kc, p, (real_t)1, dU.ptr, (size_t)p, dC.ptr, (size_t)kc, dcold.ptr, (size_t)kc);
                     CholCall cc{dcold.ptr, (size_t)kc, nullptr, 0, kc, 0, nullptr, dM.ptr, 0, 0, 0, 0, 0, false, false, false,
                                 CHOL_PREFILLED};
+                    // factors_closed_form on C with l1_lam / w_user, scaled by p like lam except on the last unknown (collective.c:3385-3400)
+                    dev.l1_last_now = l1_lam / w_user;
+                    dev.l1_now = scale_lam_sideinfo ? dev.l1_last_now * (real_t)p : dev.l1_last_now;
                     rc = launch_chol(dev, cc, nullptr, m_u);
+                    dev.l1_now = l1_lam; dev.l1_last_now = ub ? l1_lam_bias : l1_lam;
                 }
                 hipLaunchKernelGGL(cold_select_kernel<real_t>, dim3(m_u), dim3(64), 0, st, dA.ptr, ldA, kt, kc, dcold.ptr,
                                    Xs.p.ptr, m_u);
@@ -2886,6 +2902,39 @@ int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, 
         HIP_CHECK(hipStreamSynchronize(st));
         return 0;
     });
+}
+
+int cmfrec_hip_factors_multiple(real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U,
+                                const real_t *U_colmeans, const int_t ixA[], const int_t ixB[], const real_t *X,
+                                size_t nnz, const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                const real_t *B, int_t n, const real_t *C, const real_t *biasB, int_t k, int_t k_user,
+                                int_t k_item, int_t k_main, real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
+                                bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+                                const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
+                                const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
+                                const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr, bool nonneg)
+{
+    return factors_multiple_impl(A, biasA, m_x, m_u, p, U, U_colmeans, ixA, ixB, X, nnz, Xcsr_p, Xcsr_i, Xcsr, B, n, C, biasB, k,
+                                 k_user, k_item, k_main, lam, lam_bias, lam_x, w_user, implicit, scale_lam, scale_lam_sideinfo,
+                                 scale_bias_const, BtB_pre, TransCtCinvCt_pre, U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr,
+                                 nonneg, (real_t)0, (real_t)0);
+}
+
+int cmfrec_hip_factors_multiple_l1(real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U,
+                                   const real_t *U_colmeans, const int_t ixA[], const int_t ixB[], const real_t *X,
+                                   size_t nnz, const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+                                   const real_t *B, int_t n, const real_t *C, const real_t *biasB, int_t k, int_t k_user,
+                                   int_t k_item, int_t k_main, real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
+                                   bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+                                   const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
+                                   const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
+                                   const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr, bool nonneg,
+                                   real_t l1_lam, real_t l1_lam_bias)
+{
+    return factors_multiple_impl(A, biasA, m_x, m_u, p, U, U_colmeans, ixA, ixB, X, nnz, Xcsr_p, Xcsr_i, Xcsr, B, n, C, biasB, k,
+                                 k_user, k_item, k_main, lam, lam_bias, lam_x, w_user, implicit, scale_lam, scale_lam_sideinfo,
+                                 scale_bias_const, BtB_pre, TransCtCinvCt_pre, U_row, U_col, U_sp, nnz_U, U_csr_p, U_csr_i, U_csr,
+                                 nonneg, l1_lam, l1_lam_bias);
 }
 
 }  // extern "C"

@@ -209,9 +209,8 @@ class CMF_implicit(_Base):
         factors_collective_implicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main]."""
         if X is None and U is None:
             raise ValueError("Must pass at least one of 'X', 'U'.")
-        if self.l1_lambda or self._l16 is not None:
-            raise NotImplementedError("factors_multiple with l1_lambda is not implemented in cmfrec_amd")
         lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, self.dtype_)
+        l1 = self.l1_lambda if self._l16 is None else float(self._l16[2])       # the reference passes l1_lambda[2], like lambda_
         lib, R = self._lib()
         dt = self.dtype_
         n = self.B_.shape[0]
@@ -227,7 +226,7 @@ class CMF_implicit(_Base):
             _lib.ptr(self.B_), C.c_int(n), _lib.ptr(self.C_) if p else None,
             _lib.ptr(self._U_colmeans) if (p and len(self._U_colmeans)) else None,
             C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
-            R(self.lambda_ if lam6 is None else float(lam6[2])), R(0.), R(self.alpha), R(self.w_main), R(self.w_user),
+            R(self.lambda_ if lam6 is None else float(lam6[2])), R(l1), R(self.alpha), R(self.w_main), R(self.w_user),
             R(self._w_main_multiplier),
             C.c_bool(self.apply_log_transf),
             _lib.ptr(self._BeTBe) if has(self._BeTBe) else None, _lib.ptr(self._BtB) if has(self._BtB) else None,
@@ -401,9 +400,8 @@ class CMF(_Base):
         factors_collective_explicit_multiple).  Returns ``A`` [max(m_x, m_u), k_user+k+k_main], or ``(A, bias)``."""
         if X is None and U is None:
             raise ValueError("Must pass at least one of 'X', 'U'.")
-        if self.l1_lambda or self._l16 is not None:
-            raise NotImplementedError("factors_multiple with l1_lambda is not implemented in cmfrec_amd")
         lam6 = None if self._lam6 is None else np.ascontiguousarray(self._lam6, self.dtype_)
+        l16 = None if self._l16 is None else np.ascontiguousarray(self._l16, self.dtype_)
         if self.add_implicit_features:
             raise NotImplementedError("factors_multiple with add_implicit_features is not implemented in cmfrec_amd")
         lib, R = self._lib()
@@ -426,7 +424,7 @@ class CMF(_Base):
             _lib.ptr(val), _lib.ptr(row), _lib.ptr(col), C.c_size_t(len(val)), None, None, None,
             None, C.c_int(n), None, _lib.ptr(self.B_), None, C.c_bool(False),
             C.c_int(self.k), C.c_int(self.k_user), C.c_int(self.k_item), C.c_int(self.k_main),
-            R(self.lambda_), _lib.ptr(lam6), R(0.), None, C.c_bool(self.scale_lam), C.c_bool(self.scale_lam_sideinfo),
+            R(self.lambda_), _lib.ptr(lam6), R(self.l1_lambda), _lib.ptr(l16), C.c_bool(self.scale_lam), C.c_bool(self.scale_lam_sideinfo),
             C.c_bool(self.scale_bias_const), R(self._scaling_biasA if self.scale_bias_const else 1.), R(self.w_main), R(self.w_user),
             R(self.w_implicit),
             C.c_int(n), C.c_bool(True),

@@ -214,6 +214,22 @@ int cmfrec_hip_factors_multiple(
     const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
     const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr,
     bool nonneg /* solve_nonneg instead of the Cholesky solves, 10 (k_user+k+k_main[+1]) sweeps at most */);
+int cmfrec_hip_factors_multiple_l1(
+    real_t *A, real_t *biasA, int_t m_x, int_t m_u, int_t p, const real_t *U, const real_t *U_colmeans,
+    const int_t ixA[], const int_t ixB[], const real_t *X, size_t nnz,
+    const size_t Xcsr_p[], const int_t Xcsr_i[], const real_t *Xcsr,
+    const real_t *B, int_t n, const real_t *C, const real_t *biasB,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t lam_bias, real_t lam_x, real_t w_user,
+    bool implicit, bool scale_lam, bool scale_lam_sideinfo, bool scale_bias_const,
+    const real_t *BtB_pre, const real_t *TransCtCinvCt_pre,
+    /* sparse side information instead of U (NULL): COO triplets or CSR over the m_u rows, missing = absent */
+    const int_t U_row[], const int_t U_col[], const real_t *U_sp, size_t nnz_U,
+    const size_t U_csr_p[], const int_t U_csr_i[], const real_t *U_csr,
+    bool nonneg /* solve_nonneg instead of the Cholesky solves, 10 (k_user+k+k_main[+1]) sweeps at most */,
+    /* L1 penalty of the row systems / of the bias unknown, after the w_main rescaling (solve_elasticnet,
+     * /root/reference/src/common.c:2228-2294; collective.c:3571-3931); TransCtCinvCt_pre must be NULL */
+    real_t l1_lam, real_t l1_lam_bias);
 
 /* Replace factors_collective_explicit_multiple / factors_collective_implicit_multiple,
  * /root/reference/src/cmfrec.h:2004-2047 and :2048-2071 (bodies src/collective.c:10865-11174, :11176-11340): same

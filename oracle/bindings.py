@@ -538,7 +538,7 @@ class Reference:
                                   glob_mean=0.0, user_bias=False, lam=1.0, lam_bias=None, k_main=0, k_user=0,
                                   k_item=0, scale_lam=False, scale_lam_sideinfo=False, scale_bias_const=False,
                                   scaling_biasA=1.0, w_main=1.0, w_user=1.0, nthreads=1, n=None, TransCtCinvCt=None,
-                                  U_coo=None):
+                                  U_coo=None, l1_lam=0.0, l1_lam_bias=None):
         """factors_collective_explicit_multiple (src/cmfrec.h:2004-2047, collective.c:10865-11174): sparse X of the
         new rows as COO, optional dense U.  Returns (A, biasA or None)."""
         n_max, ldb = B.shape
@@ -560,6 +560,9 @@ class Reference:
         lam_unique = None
         if lam_bias is not None and lam_bias != lam:
             lam_unique = np.zeros(6, self.dtype); lam_unique[0] = lam_bias; lam_unique[2] = lam
+        l1_unique = None
+        if l1_lam_bias is not None and l1_lam_bias != l1_lam:
+            l1_unique = np.zeros(6, self.dtype); l1_unique[0] = l1_lam_bias; l1_unique[2] = l1_lam
         Uc = None if U is None else np.ascontiguousarray(U, self.dtype).copy()
         rc = self.lib.factors_collective_explicit_multiple(
             _ptr(A), _ptr(biasA), C.c_int(m),
@@ -574,7 +577,7 @@ class Reference:
             None, C.c_int(n), None,
             _ptr(B), None, C.c_bool(False),
             C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
-            self._r(lam), _ptr(lam_unique), self._r(0.), None,
+            self._r(lam), _ptr(lam_unique), self._r(l1_lam), _ptr(l1_unique),
             C.c_bool(scale_lam), C.c_bool(scale_lam_sideinfo), C.c_bool(scale_bias_const), self._r(scaling_biasA),
             self._r(w_main), self._r(w_user), self._r(1.),
             C.c_int(n_max), C.c_bool(True),
@@ -585,7 +588,7 @@ class Reference:
 
     def factors_implicit_multiple(self, B, row, col, val, m, k, Cm=None, U=None, U_colmeans=None, lam=1.0,
                                   alpha=1.0, k_main=0, k_user=0, k_item=0, w_main=1.0, w_user=1.0,
-                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None, U_coo=None):
+                                  w_main_multiplier=1.0, apply_log_transf=False, nthreads=1, BtB=None, U_coo=None, l1_lam=0.0):
         """factors_collective_implicit_multiple (src/cmfrec.h:2048-2071, collective.c:11176-11340)."""
         n, ldb = B.shape
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
@@ -609,7 +612,7 @@ class Reference:
             None, None, None,
             _ptr(B), C.c_int(n), _ptr(Cm), _ptr(U_colmeans),
             C.c_int(k), C.c_int(k_user), C.c_int(k_item), C.c_int(k_main),
-            self._r(lam), self._r(0.), self._r(alpha), self._r(w_main), self._r(w_user), self._r(w_main_multiplier),
+            self._r(lam), self._r(l1_lam), self._r(alpha), self._r(w_main), self._r(w_user), self._r(w_main_multiplier),
             C.c_bool(apply_log_transf),
             None, _ptr(BtB), None, None,
             C.c_int(nthreads))

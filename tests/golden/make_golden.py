@@ -223,6 +223,18 @@ def main():
                     out["biasA_" + key] = bA
         save("g11_new_rows_" + tag, **out)
 
+        # ---- G22: factors of new rows under an L1 penalty (solve_elasticnet behind factors_collective_*_multiple) ----
+        out = {}
+        for k in (6, 50):
+            d = gc.new_rows_problem(dt, k)
+            for name, kind, kw in gc.new_rows_l1_cases(d):
+                A, bA = gc.run_new_rows(R, kind, dict(kw, nthreads=2))
+                key = "k%d_%s" % (k, name.split()[0])
+                out["A_" + key] = A
+                if bA is not None:
+                    out["biasA_" + key] = bA
+        save("g22_new_rows_l1_" + tag, **out)
+
         # ---- G12: fits with sparse side information (Cholesky updates) ----
         out = {}
         d = gc.sparse_sideinfo_problem(dt)

@@ -426,6 +426,36 @@ def test_factors_multiple_after_fit(oracles, dtype, side):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_factors_multiple_l1_after_fit(dtype):
+    """New rows under an L1 penalty (solve_elasticnet behind factors_collective_*_multiple; the reference's outputs are the
+    g22 fixture, tests/test_gpu_golden.py::test_new_rows_l1): a fit whose last A-step ran the same elastic-net sweeps leaves
+    exactly the factors the new-rows entry point computes for its training rows -- explicit model with biases and both penalties
+    per matrix, implicit model without side information (solved on the symmetric system, see tests/golden_cases.py)."""
+    import scipy.sparse as sp
+    import golden_cases as gc
+    from cmfrec_amd import CMF, CMF_implicit
+    t = 1e-8 if dtype is np.float64 else 2e-3
+    m, n, k = 500, 300, 12
+    rng = np.random.default_rng(15)
+    row, col, val = make_coo(m, n, 12000, 18, counts=False, dtype=dtype, heavy_row=(5, 200))
+    X = sp.coo_matrix((val, (row, col)), shape=(m, n))
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    mdl = CMF(k=k, lambda_=0.5, l1_lambda=[0.01, 0.02, 0.05, 0.04, 0.03, 0.03], niter=3, use_float=dtype is np.float32,
+              scale_lam=True, max_cd_steps=1000, precompute_for_predictions=False).fit(X, A0=A0, B0=B0)
+    A, bias = mdl.factors_multiple(X, return_bias=True)
+    assert (mdl.A_ == 0).mean() > 0.02                       # the penalty is at work
+    assert gc.maxrel(A, mdl.A_) < t and gc.maxrel(bias, mdl.user_bias_) < t
+    row, col, val = make_coo(m, n, 12000, 19, counts=True, dtype=dtype, heavy_row=(5, 200))
+    X = sp.coo_matrix((val, (row, col)), shape=(m, n))
+    mi = CMF_implicit(k=k, lambda_=2.0, l1_lambda=3.0, alpha=1.5, niter=3, use_float=dtype is np.float32,
+                      max_cd_steps=1000).fit(X, A0=A0, B0=B0)
+    A = mi.factors_multiple(X)
+    assert np.isfinite(A).all()
+    assert gc.maxrel(A, mi.A_) < t
+    assert (mi.A_ == 0).mean() > 0.02                         # the penalty is at work
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("side", [False, True])
 def test_implicit_adjust_weight_matches_reference(dtype, side):
     """adjust_weight of the implicit model (collective.c:9776-9811): w_main is multiplied by nnz / (m n), which rescales lambda

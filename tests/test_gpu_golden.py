@@ -148,6 +148,15 @@ def test_result_metrics(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_new_rows_l1(dtype):
+    """G22: new rows under an L1 penalty (solve_elasticnet behind factors_collective_*_multiple; warm rows, rows with side
+    information only, bias with its own penalty, both lambda scalings) against the reference's outputs."""
+    H = gc.HipNewRows(dtype)
+    for label, err in gc.new_rows_l1_vs_golden(H, dtype):
+        assert err < TOL[dtype], (label, err)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_new_rows(oracles, dtype):
     """G11 through the drop-in entry points factors_collective_{explicit,implicit}_multiple (COO input), then the same
     rows handed over as CSR."""
