@@ -177,7 +177,7 @@ def main():
     # ---- roofline of the dominant kernel (per nnz-bin launch of the CG row kernel) ----
     names = {0: "vh_pass+vh_update x4 (rows > 1024 nnz, split rows)", 1: "cg_rows_kernel<W=8> (257..1024 nnz)",
              2: "cg_rows_kernel<W=4> (129..256 nnz)", 3: "cg_rows_kernel<W=2> (65..128 nnz)",
-             4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel + cg_rows_tiny2_kernel (<= 32 nnz)"}
+             4: "cg_rows_kernel<W=1> (33..64 nnz)", 5: "cg_rows_tiny_kernel (<= 32 nnz; 16-slot tile for rows of <= 16)"}
     kernels = []
     for which in ("B", "A"):
         for b in range(6):
@@ -216,7 +216,7 @@ def main():
                       "vh_update_kernel<..., 0> x1 + vh_update_kernel<..., 1> x%d" % MAX_CG_STEPS],
                   1: ["cg_rows_kernel<double, 7, true, 8, 1, false, 0>"], 2: ["cg_rows_kernel<double, 7, true, 4, 1, false, 0>"],
                   3: ["cg_rows_kernel<double, 7, true, 2, 1, false, 0>"], 4: ["cg_rows_kernel<double, 7, true, 1, 4, false, 0>"],
-                  5: ["cg_rows_tiny_kernel<double, 7, true, false>", "cg_rows_tiny2_kernel<double, 7, true> (rows of <= 16 nnz, two per wavefront)"]}
+                  5: ["cg_rows_tiny_kernel<double, 7, true, false, 0>"]}
     inv = {v: b for b, v in names.items()}
     inv["gram_wave+gram_cg (rows > 1024 nnz, single gather, CG on the row's Gramian)"] = 6
     prof_names[6] = ["gram_wave_kernel<double, true, 2, false>", "gram_cg_kernel<double, true>"]
