@@ -192,6 +192,55 @@ __device__ __forceinline__ T treduce8_high(const T (&v)[8], int lane)
     return keep + lanes::recv_xor8(q[0], q[1]);
 }
 
+// The same reduction through LDS (experiment, -DCMF_TREDUCE_LDS=1; measured slower, profiles/r04/r04_zi_*): lane (jj, ll) stores its S column sums into the wavefront's own
+// [64][TR_LD] buffer at [column ll + 8 s][jj], lane f reads the eight partial sums of column f and adds them in the order jj = 0..7
+// -- S stores, the reads of eight consecutive elements and seven adds instead of seven adds behind fourteen cross-lane moves.  A
+// wavefront's LDS instructions execute in issue order, so no barrier is needed inside it.  Strides: 9 doubles / 12 floats keep both
+// the stores (lanes of a 16- / 32-lane group on distinct banks) and the reads free of bank conflicts.
+template <typename T> __host__ __device__ constexpr int tr_ld() { return sizeof(T) == 8 ? 9 : 12; }
+template <typename T, int S>
+__device__ __forceinline__ T treduce8_lds(const T (&v)[8], int lane, T *__restrict__ tb)
+{
+    constexpr int LD = tr_ld<T>();
+    const int jj = lane >> 3, ll = lane & 7;
+#pragma unroll
+    for (int s = 0; s < S; s++) tb[(ll + 8 * s) * LD + jj] = v[s];
+    __builtin_amdgcn_wave_barrier();
+    const T *rp = tb + lane * LD;
+    T tot = rp[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) tot += rp[j];
+    __builtin_amdgcn_wave_barrier();
+    return (lane < 8 * S) ? tot : T(0);
+}
+#ifndef CMF_TREDUCE_LDS
+#define CMF_TREDUCE_LDS 0
+#endif
+// The vector of a pass (lane f holds element f) through the wavefront's own 64-element LDS buffer: one store, then the lane's S
+// replicated elements ll + 8 s (what `replicate` fetches with 2 S ds_bpermute in double precision) and the eight Gramian weights
+// jj 8 + t (what bcast8 builds with sixteen DPP moves) are plain LDS reads of addresses shared by the lanes of a group (broadcast
+// reads, no conflicts) -- fewer vector AND fewer LDS instructions, and the round trip stands where the ds_bpermute one stood.
+// Double precision (round 4): C2 3.62-3.65 -> 3.50-3.54 ms, tiny bin 0.44 -> 0.41.  Single precision measured slower (c4shard
+// 7.31-7.38 -> 7.58-7.65 ms: its moves are single instructions and the register budget of three wavefronts per SIMD is full) and
+// keeps the cross-lane form.  -DCMF_PASS_VECTOR_LDS=0 / =1: neither / both precisions.  profiles/r04/r04_zj_*.
+#ifndef CMF_PASS_VECTOR_LDS
+#define CMF_PASS_VECTOR_LDS 2
+#endif
+template <typename T> constexpr bool pass_vector_in_lds() { return CMF_PASS_VECTOR_LDS == 1 || (CMF_PASS_VECTOR_LDS == 2 && sizeof(T) == 8); }
+template <typename T, int S>
+__device__ __forceinline__ void pass_vector_lds(T vdist, T (&vrep)[S], T (&wts)[8], int lane, T *__restrict__ pv)
+{
+    const int jj = lane >> 3, ll = lane & 7;
+    pv[lane] = vdist;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < S; s++) vrep[s] = pv[ll + 8 * s];
+    const T *wp = pv + 8 * jj;
+#pragma unroll
+    for (int t = 0; t < 8; t++) wts[t] = wp[t];
+    __builtin_amdgcn_wave_barrier();
+}
+
 // LDS leading dimension for the staged Gramian: odd, so that the jj-groups of a lane group land on
 // distinct banks both for ds_read_b64 (32 lanes, 64 banks) and ds_read2_b64 (16 lanes, 32 banks).
 __host__ __device__ constexpr int gram_ld(int S) { return 8 * S + 1; }
@@ -369,6 +418,35 @@ __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&v
     }
 }
 
+// The two halves of tile_pass for the variant that sends the entry weights through LDS (double precision, -DCMF_TILE_W_LDS=1):
+// tile_weight: c_j = B_j . vrep, w_j = f(c_j, x_j) in the entry's lane; tile_accum: out[s] += sum_t wts[t] B_j[s].
+template <typename T, int S, bool IMPLICIT, int MODE>
+__device__ __forceinline__ T tile_weight(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid, int lane, T g = T(1))
+{
+    T c[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        T acc = T(0);
+#pragma unroll
+        for (int s = 0; s < S; s++) acc += tile.v[t][s] * vrep[s];
+        c[t] = acc;
+    }
+    const T coef = treduce8_low<T>(c, lane);
+    return pass_weight<T, IMPLICIT, MODE>(coef, x, valid, g);
+}
+template <typename T, int S>
+__device__ __forceinline__ void tile_accum(const RegTile<T, S> &tile, const T (&wts)[8], PassAcc<T> &out)
+{
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
+    }
+}
+#ifndef CMF_TILE_W_LDS
+#define CMF_TILE_W_LDS 0
+#endif
+
 // out[s] += sum_j wdist_j * G[j][ll+8s]  with the Gramian staged in LDS (rows padded to 64).
 // The 8 row-slices t are dealt to the W waves of the team (wave wr takes t = wr, wr+W, ...).
 template <typename T, int S, int W>
@@ -398,6 +476,39 @@ __device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, Pass
             for (int s = 0; s < S; s++) {
                 if constexpr (std::is_same<T, float>::value) out.v[s][0] += wts[t] * G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
                 else out.v[s] += wts[t] * lds_g(G + (jj * 8 + t) * LD + ll + 8 * s);
+            }
+        }
+    }
+}
+
+// the same with the eight weights already in registers (level 2 of the LDS experiment); NEG: out -= ...
+template <bool NEG, typename T, int S, int W>
+__device__ __forceinline__ void gram_pass_w(const T *__restrict__ G, const T (&wts)[8], PassAcc<T> &out, int lane, int wr)
+{
+    constexpr int LD = gram_ld(S);
+    const int jj = lane >> 3, ll = lane & 7;
+    if constexpr (std::is_same<T, float>::value && W <= 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (W > 1 && (q % W) != wr) continue;
+            const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (jj * 4 + q) * gram_ld2(S) + ll;
+            const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
+#pragma unroll
+            for (int s = 0; s < S; s++) out.v[s] = NEG ? out.v[s] - w2 * lds_g(g + 8 * s) : out.v[s] + w2 * lds_g(g + 8 * s);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            if (W > 1 && (t % W) != wr) continue;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                if constexpr (std::is_same<T, float>::value) {
+                    const float g = G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
+                    out.v[s][0] = NEG ? out.v[s][0] - wts[t] * g : out.v[s][0] + wts[t] * g;
+                } else {
+                    const T g = lds_g(G + (jj * 8 + t) * LD + ll + 8 * s);
+                    out.v[s] = NEG ? out.v[s] - wts[t] * g : out.v[s] + wts[t] * g;
+                }
             }
         }
     }
@@ -447,6 +558,15 @@ cg_rows_kernel(const CgParams<T> P)
     // C2's users -- so a launch has CG_NCOUNTERS counters on separate cache lines; counter j hands out the positions
     // nteams + j + CG_NCOUNTERS * c, and a team uses the counter of its index modulo CG_NCOUNTERS.)
     __shared__ int s_claim[4];
+#if CMF_TREDUCE_LDS
+    __shared__ __attribute__((aligned(16))) T s_tr[W * RPB][64 * tr_ld<T>()];
+#endif
+    constexpr bool PV = pass_vector_in_lds<T>();
+    __shared__ __attribute__((aligned(16))) T s_pv[PV ? W * RPB : 1][PV ? 64 : 1];
+    // entry weights of a tile through LDS too (double precision): one store in the entry's lane, eight broadcast reads instead of
+    // sixteen DPP moves; the Gramian product of the pass is issued between the store and the reads
+    constexpr bool PW = PV && (CMF_TILE_W_LDS != 0) && sizeof(T) == 8;
+    __shared__ __attribute__((aligned(16))) T s_pw[PW ? W * RPB : 1][PW ? 64 : 1];
     const int cslot = (blockIdx.x * RPB + grp) % CG_NCOUNTERS;
     int *const my_counter = P.counter + cslot * CG_COUNTER_STRIDE;
     const int cbase = nteams + cslot;
@@ -565,7 +685,9 @@ cg_rows_kernel(const CgParams<T> P)
             // lane out of the pass / row loops and pins 16*S VGPRs (occupancy 2 -> 1 wave/SIMD)
             asm volatile("" ::: "memory");
             T vrep[S];
-            replicate<T, S>(vdist, vrep, lane);
+            T gw[8];
+            if constexpr (PV) pass_vector_lds<T, S>(vdist, vrep, gw, lane, &s_pv[wave][0]);
+            else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
             if constexpr (NRES == 2) {
@@ -589,13 +711,32 @@ cg_rows_kernel(const CgParams<T> P)
                 } else {
                     x = x_res; g = g_res; valid = valid_res;
                 }
-                if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane, g);
+                if constexpr (PW) {
+                    if (!CMF_DBG(P, 4)) {
+                        T *wb = &s_pw[wave][0];
+                        wb[lane] = tile_weight<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, lane, g);
+                        if (GRAM && tl == wr && !CMF_DBG(P, 2)) gram_pass_w<MODE == 0, T, S, W>(G, gw, acc, lane, wr);
+                        T wts[8];
+                        const T *wp = wb + 8 * (lane >> 3);
+#pragma unroll
+                        for (int t = 0; t < 8; t++) wts[t] = wp[t];
+                        tile_accum<T, S>(tile, wts, acc);
+                    }
+                } else {
+                    if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane, g);
+                }
             }
-            if (GRAM && !CMF_DBG(P, 2))
-                gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, acc, lane, wr);   // common.c:1932 / :1958; collective.c:2609-2643
+            if (GRAM && !CMF_DBG(P, 2) && !(PW && wr < ntiles && !CMF_DBG(P, 4))) {   // common.c:1932 / :1958; collective.c:2609-2643
+                if constexpr (PV) gram_pass_w<MODE == 0, T, S, W>(G, gw, acc, lane, wr);
+                else gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, acc, lane, wr);
+            }
             T out[8];
             acc.close(out);
+#if CMF_TREDUCE_LDS
+            T tot = treduce8_lds<T, S>(out, lane, &s_tr[wave][0]);
+#else
             T tot = treduce8_high<T>(out, lane);                              // lane f <- element f
+#endif
             if (W > 1) {
                 T *rb = myred + (size_t)buf * W * 64;
                 rb[wr * 64 + lane] = tot;
@@ -911,6 +1052,25 @@ __device__ __forceinline__ void gram_pass_regs(const GramRegs<T, S> &R, T wdist,
         for (int s = 0; s < S; s++) out.v[s] += wts[t] * R.v[t][s];
 }
 
+template <bool NEG, int S>
+__device__ __forceinline__ void gram_pass_regs_w(const GramRegs<float, S> &R, const float (&wts)[8], PassAcc<float> &out)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] = NEG ? out.v[s] - w2 * R.v[q][s] : out.v[s] + w2 * R.v[q][s];
+    }
+}
+template <bool NEG, typename T, int S>
+__device__ __forceinline__ void gram_pass_regs_w(const GramRegs<T, S> &R, const T (&wts)[8], PassAcc<T> &out)
+{
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+#pragma unroll
+        for (int s = 0; s < S; s++) out.v[s] = NEG ? out.v[s] - wts[t] * R.v[t][s] : out.v[s] + wts[t] * R.v[t][s];
+}
+
 template <typename T, int S, bool IMPLICIT, bool GRAMX = false, int NE = 4>
 __global__ void __launch_bounds__(256, (tiny_waves_per_simd<T, IMPLICIT || GRAMX>()))
 cg_rows_tiny_kernel(const CgParams<T> P)
@@ -925,6 +1085,11 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);
+#if CMF_TREDUCE_LDS
+    __shared__ __attribute__((aligned(16))) T s_tr[4][64 * tr_ld<T>()];
+#endif
+    constexpr bool PV = pass_vector_in_lds<T>();
+    __shared__ __attribute__((aligned(16))) T s_pv[PV ? 4 : 1][PV ? 64 : 1];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     auto short_row = [&](int nnz_) -> bool { return MIX && nnz_ <= 16; };
@@ -987,18 +1152,29 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             constexpr int MODE = decltype(mode_tag)::value;
             asm volatile("" ::: "memory");
             T vrep[S];
-            replicate<T, S>(vdist, vrep, lane);
+            T gw[8];
+            if constexpr (PV) pass_vector_lds<T, S>(vdist, vrep, gw, lane, &s_pv[tid >> 6][0]);
+            else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
             if (!CMF_DBG(P, 4)) {
                 if constexpr (!T2) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
                 else tile_pass2<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
             }
-            if constexpr (GREG) { if (!CMF_DBG(P, 2)) gram_pass_regs(greg, (MODE == 0) ? -vdist : vdist, acc); }
+            if constexpr (GREG) {
+                if (!CMF_DBG(P, 2)) {
+                    if constexpr (PV) gram_pass_regs_w<MODE == 0>(greg, gw, acc);
+                    else gram_pass_regs(greg, (MODE == 0) ? -vdist : vdist, acc);
+                }
+            }
             else if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
             acc.close(out);
+#if CMF_TREDUCE_LDS
+            return treduce8_lds<T, S>(out, lane, &s_tr[tid >> 6][0]);
+#else
             return treduce8_high<T>(out, lane);
+#endif
         };
         T r_d = run_pass(a_d, std::integral_constant<int, 0>{});
         r_d -= lam * a_d;

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 4, step zi: the reduction over the eight entry groups through LDS (-DCMF_TREDUCE_LDS=1: S stores + 8 reads + 7 adds per pass instead
+# of the transposed butterfly's cross-lane moves; fp64 tiny + one-wave kernels 2116 -> 2019 vector instructions): lib = default, lib_trl = this
+R=$GRAFT_REPO_ROOT; O=gpurun_out/r04_zi; mkdir -p $R/$O; cd $R
+F='^RCCL\|^HIP ver\|^ROCm ver\|^Hostname\|^Librccl\|amdgpu.ids'
+CMFREC_HIP_LIBDIR=$R/cmfrec_amd/lib_trl timeout -k 10 1200 python -m pytest tests/test_gpu_operators.py tests/test_gpu_switches.py tests/test_gpu_golden.py tests/test_gpu_config_widths.py -m gpu -q -x 2>&1 | grep -v "$F" | tail -4 | tee $O/pytest_trl.log
+CMFREC_HIP_POISON_LDS=1 CMFREC_HIP_LIBDIR=$R/cmfrec_amd/lib_trl timeout -k 10 1200 python -m pytest tests/test_gpu_operators.py tests/test_gpu_golden.py -m gpu -q -x 2>&1 | grep -v "$F" | tail -3 | tee $O/pytest_trl_poisoned.log
+c2() { timeout -k 10 600 python bench.py --workload c2 --no-cpu-baseline --no-scale-point --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); r=d["roofline"]; print("c2", d["ms_per_step"], [(e["step"], round(e.get("inline_ms"),3)) for e in r["per_kernel"]])'; }
+side() { timeout -k 10 600 python bench.py --workload $1 --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.readline()); print(sys.argv[1], d.get("ms_per_iteration"), d.get("halfstep_ms"))' $1; }
+{
+for rep in 1 2 3; do for L in lib lib_trl; do export CMFREC_HIP_LIBDIR=$R/cmfrec_amd/$L; echo "$L $(c2)"; done; done
+for L in lib lib_trl lib lib_trl; do export CMFREC_HIP_LIBDIR=$R/cmfrec_amd/$L; echo "$L $(side c4shard)"; done
+for L in lib lib_trl; do export CMFREC_HIP_LIBDIR=$R/cmfrec_amd/$L; echo "$L $(side c1)"; done
+} 2>&1 | tee $O/ab.txt
