@@ -227,17 +227,30 @@ __device__ __forceinline__ T treduce8_lds(const T (&v)[8], int lane, T *__restri
 #define CMF_PASS_VECTOR_LDS 2
 #endif
 template <typename T> constexpr bool pass_vector_in_lds() { return CMF_PASS_VECTOR_LDS == 1 || (CMF_PASS_VECTOR_LDS == 2 && sizeof(T) == 8); }
+// (CMF_PV_PARTS, experiment: bit 0 = the replicated elements, bit 1 = the Gramian weights through LDS; the other part cross-lane)
+#ifndef CMF_PV_PARTS
+#define CMF_PV_PARTS 3
+#endif
+template <typename T, int S>
+__device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane);
 template <typename T, int S>
 __device__ __forceinline__ void pass_vector_lds(T vdist, T (&vrep)[S], T (&wts)[8], int lane, T *__restrict__ pv)
 {
     const int jj = lane >> 3, ll = lane & 7;
     pv[lane] = vdist;
     __builtin_amdgcn_wave_barrier();
+    if constexpr ((CMF_PV_PARTS & 1) != 0) {
 #pragma unroll
-    for (int s = 0; s < S; s++) vrep[s] = pv[ll + 8 * s];
-    const T *wp = pv + 8 * jj;
+        for (int s = 0; s < S; s++) vrep[s] = pv[ll + 8 * s];
+    } else replicate<T, S>(vdist, vrep, lane);
+    if constexpr ((CMF_PV_PARTS & 2) != 0) {
+        const T *wp = pv + 8 * jj;
 #pragma unroll
-    for (int t = 0; t < 8; t++) wts[t] = wp[t];
+        for (int t = 0; t < 8; t++) wts[t] = wp[t];
+    } else {
+        wts[0] = lanes::bcast8<0>(vdist); wts[1] = lanes::bcast8<1>(vdist); wts[2] = lanes::bcast8<2>(vdist); wts[3] = lanes::bcast8<3>(vdist);
+        wts[4] = lanes::bcast8<4>(vdist); wts[5] = lanes::bcast8<5>(vdist); wts[6] = lanes::bcast8<6>(vdist); wts[7] = lanes::bcast8<7>(vdist);
+    }
     __builtin_amdgcn_wave_barrier();
 }
 
