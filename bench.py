@@ -278,8 +278,27 @@ def main():
                                            "tools/microbench/mfma_rate.hip measures 47 TFLOP/s for this instruction on the part"}
     # ---- CPU baseline: the reference itself (oracle/_ref) on this host, rank 0 / N=1 only ----
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(row, col, val, m_blk, n, A0_blk)
+        def compare(ref):
+            # the same iterations from the same start on the GPU, against the CPU run's factors (whole fit 1e-6 in fp64)
+            sess.set_factors(A=A0_blk, B=np.zeros((n, K)))
+            for _ in range(ref["iterations"]):
+                step()
+            sync()
+            f = sess.get_factors()
+            Ag, Bg = f["A"], f["B"]
+            def rel(x, y):
+                return float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300))
+            def worst_row(x, y):
+                d = np.abs(x - y).max(axis=1) / np.maximum(np.abs(y).max(axis=1), 1e-300)
+                return float(d.max())
+            return {"against": "cmfrec's own optimizeA_implicit (oracle/_ref, kind '%s', %d threads)" % (ref["kind"], ref["nthreads"])
+                               if ref["kind"] == "reference" else "the C restatement (oracle/, kind 'port')",
+                    "iterations": ref["iterations"], "rel_frob_A": rel(Ag[:m_blk], ref["A"]), "rel_frob_B": rel(Bg[:n], ref["B"]),
+                    "max_row_rel_A": worst_row(Ag[:m_blk], ref["A"]), "max_row_rel_B": worst_row(Bg[:n], ref["B"]),
+                    "tolerance": 1e-6, "workload": "the full C2 workload of this line, same start (A0 uniform 2^-7, B0 = 0)"}
+        cpu, parity = cpu_baseline(row, col, val, m_blk, n, A0_blk, compare=compare)
 
     # ---- the N = 1 point of the scaling series: BASELINE.json configs[3] on this one GPU, through the distributed engine ----
     scale_point = None
@@ -310,7 +329,7 @@ def main():
                                                                                " (1 LastFM-sized user block per GPU)" if world > 1 else ""),
                           "parallelism": "row-block x%d + all-gather" % world if world > 1 else "single GPU",
                           "gen_seconds": round(t_gen, 1)},
-               "roofline": roofline, "cpu_baseline": cpu, "scale_point": scale_point}
+               "roofline": roofline, "cpu_baseline": cpu, "parity_vs_reference": parity, "scale_point": scale_point}
         if args.scale != 1.0:
             out["config"]["INVALID_scaled_down"] = args.scale
         final_line = json.dumps(out)
@@ -859,7 +878,7 @@ def pmc_traffic(dom):
     return round(tot) if found else None
 
 
-def cpu_baseline(row, col, val, m, n, A0):
+def cpu_baseline(row, col, val, m, n, A0, compare=None):
     """Times the CPU path beside the GPU number in a child process (a BLAS thread-pool failure must
     not take the GPU result down): the real reference (oracle/_ref, kind 'reference') if it
     travelled with the repo, else our C restatement (kind 'port').  Sample: full B+A half-steps of
@@ -870,6 +889,7 @@ def cpu_baseline(row, col, val, m, n, A0):
     import tempfile
     cores = os.cpu_count() or 1
     best = None
+    factors = None       # the first successful worker's factors (the reference is bit-reproducible across thread counts)
     t_start = time.time()
     with tempfile.TemporaryDirectory(dir="/tmp") as td:
         path = os.path.join(td, "w.npz")
@@ -895,10 +915,22 @@ def cpu_baseline(row, col, val, m, n, A0):
                 tried.append((nthreads, res["s_per_iteration"]))
                 if best is None or res["value"] > best["value"]:
                     best = res
+                fpath = path + ".factors_%d.npz" % nthreads
+                if os.path.exists(fpath):
+                    if factors is None and compare is not None:
+                        f = np.load(fpath)
+                        factors = dict(A=f["A"], B=f["B"], iterations=int(f["iterations"]), kind=res["kind"], nthreads=nthreads)
+                    os.remove(fpath)
     if best is None:
-        return {"value": None, "unit": "rows/s", "cores": 0, "kind": "failed", "sample": "CPU baseline child failed"}
+        return {"value": None, "unit": "rows/s", "cores": 0, "kind": "failed", "sample": "CPU baseline child failed"}, None
     best["threads_tried"] = tried
-    return best
+    parity = None
+    if factors is not None:
+        try:
+            parity = compare(factors)
+        except Exception as e:            # the baseline number must not depend on it
+            parity = {"error": "%s: %s" % (type(e).__name__, e)}
+    return best, parity
 
 
 def cpu_worker(path, nthreads):
@@ -925,9 +957,13 @@ def cpu_worker(path, nthreads):
         eng.optimizeA_implicit(A, B, csr, LAM, nthreads=nthreads, use_cg=True, max_cg_steps=MAX_CG_STEPS)
         t_tot += time.perf_counter() - t0
         iters += 1
+    timed = iters
     if iters == 0:
         iters, t_tot = 1, t_warm       # a team too slow for a second iteration: its warm-up is its sample
     s_per_iter = t_tot / iters
+    # the factors after `iters_run` iterations from the shared start: what the GPU run is compared with (parity_vs_reference)
+    iters_run = 1 + timed
+    np.savez(path + ".factors_%d.npz" % nthreads, A=A, B=B, iterations=iters_run)
     print(json.dumps({"value": round((m + n) / s_per_iter, 1), "unit": "rows/s", "cores": nthreads, "kind": kind,
                       "s_per_iteration": round(s_per_iter, 3),
                       "sample": "%d full ALS iteration(s) after one warm-up iteration (optimizeA_implicit B-step + A-step, the "

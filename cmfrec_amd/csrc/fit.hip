@@ -21,10 +21,16 @@
 #include <set>
 #include <string>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>          // types and prototypes only: the library is bound at run time, when a fit spans several devices
+#define CMF_HAVE_RCCL 1
+#else
+#define CMF_HAVE_RCCL 0         // a ROCm install without the RCCL headers: the shards exchange by peer copies only
+#endif
 
 #include "../../include/cmfrec_hip.h"
 #include "rng_host.hpp"
+#include "exchange_plan.hpp"
 
 namespace {
 
@@ -111,11 +117,23 @@ struct DenseNanSide {
 // reference treats the rows beyond X differently from its dense branch, nothing pins them).
 struct ZeroFilledSide {
     std::vector<real_t> dense;
-    // 0 ok, 1 triplets missing / out of range, 2 more rows than X
+    // Size limit of the zero-filled matrix: it exists three times (here, as the centred copy, on the device), so it is refused
+    // -- a controlled "not implemented at this size", not a bad_alloc / hipErrorOutOfMemory late in the fit -- beyond
+    // CMFREC_HIP_ZEROFILL_MAX_GB (default 8 GB per copy; realistic sparse side information of 1e6..1e7 rows x 1e3..1e4 columns
+    // is 8e9..8e11 bytes and belongs on the sparse kernels with the -w C^T colmeans constant, which this route does not build).
+    static double max_bytes()
+    {
+        const char *e = getenv("CMFREC_HIP_ZEROFILL_MAX_GB");
+        const double gb = (e != nullptr && atof(e) > 0) ? atof(e) : 8.0;
+        return gb * 1e9;
+    }
+    // 0 ok, 1 triplets missing / out of range, 2 more rows than X, 3 larger than the limit above.  Triplets that repeat a
+    // position are SUMMED (the reference's COO -> CSR keeps both and its sums add both: the same numbers).
     int build(int_t rows_x, int_t rows_side, int_t cols, const int_t *r, const int_t *c, const real_t *v, size_t nnz)
     {
         if (rows_side > rows_x) return 2;
         if (!r || !c || !v || cols <= 0) return 1;
+        if ((double)rows_x * (double)cols * (double)sizeof(real_t) > max_bytes()) return 3;
         dense.assign((size_t)rows_x * (size_t)cols, (real_t)0);
         for (size_t e = 0; e < nnz; e++) {
             if (r[e] < 0 || r[e] >= rows_side || c[e] < 0 || c[e] >= cols) return 1;
@@ -267,8 +285,25 @@ std::vector<int> devices_from_env()
 // RCCL for the exchange between the devices of one fit ("ncclAllGather ... or direct placement").  Bound with
 // dlopen when the first multi-device fit asks for it -- a single-device caller never maps the library -- through the prototypes
 // of <rccl/rccl.h> (decltype: nothing is declared by hand).
+#if !CMF_HAVE_RCCL
+// no RCCL headers on this install: enough of the interface for the code below to compile; load() never succeeds, so none of these
+// is ever called and every multi-device fit exchanges by peer copies
+typedef void *ncclComm_t;
+enum ncclResult_t { ncclSuccess = 0, ncclSystemError = 2 };
+enum ncclDataType_t { ncclFloat = 7, ncclDouble = 8 };
+enum ncclRedOp_t { ncclSum = 0 };
+ncclResult_t ncclCommInitAll(ncclComm_t *, int, const int *);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclGroupStart();
+ncclResult_t ncclGroupEnd();
+ncclResult_t ncclSend(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclRecv(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+ncclResult_t ncclAllReduce(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+const char *ncclGetErrorString(ncclResult_t);
+#endif
 struct RcclApi {
     void *handle = nullptr;
+    bool failed = false;        // a previous load found the library unusable: do not dlopen it again for every fit
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -280,12 +315,13 @@ struct RcclApi {
     bool load()
     {
         if (handle) return true;
+        if (failed || !CMF_HAVE_RCCL) return false;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (handle) break;
         }
-        if (!handle) return false;
-#define CMF_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(handle, #sym)); if (!field) { handle = nullptr; return false; }
+        if (!handle) { failed = true; return false; }
+#define CMF_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(handle, #sym)); if (!field) { dlclose(handle); handle = nullptr; failed = true; return false; }
         CMF_SYM(CommInitAll, ncclCommInitAll) CMF_SYM(CommDestroy, ncclCommDestroy) CMF_SYM(GroupStart, ncclGroupStart)
         CMF_SYM(GroupEnd, ncclGroupEnd) CMF_SYM(Send, ncclSend) CMF_SYM(Recv, ncclRecv) CMF_SYM(AllReduce, ncclAllReduce)
         CMF_SYM(GetErrorString, ncclGetErrorString)
@@ -374,14 +410,13 @@ struct MultiDev {
                 st[d] = (hipStream_t)cmfrec_hip_session_stream(sess[d]);
             }
             ncclResult_t r = rccl().GroupStart();
-            for (int d = 0; d < D && r == ncclSuccess; d++) {
-                const size_t cnt_d = (size_t)(bb[d + 1] - bb[d]) * ld[d];
-                for (int o = 1; o < D && r == ncclSuccess; o++) {            // peers in the order d + 1, d + 2, ...: no two start on the same one
-                    const int e = (d + o) % D;
-                    const size_t cnt_e = (size_t)(bb[e + 1] - bb[e]) * ld[d];
-                    if (cnt_d) r = rccl().Send(base[d] + (size_t)bb[d] * ld[d], cnt_d, NCCL_REAL, e, comm[d], st[d]);
-                    if (cnt_e && r == ncclSuccess) r = rccl().Recv(base[d] + (size_t)bb[e] * ld[d], cnt_e, NCCL_REAL, e, comm[d], st[d]);
-                }
+            // the schedule is a pure function of the block boundaries (exchange_plan.hpp; tests/test_exchange_plan.py)
+            for (const cmfhip::ExchangeOp &op : cmfhip::direct_placement_plan(bb)) {
+                if (r != ncclSuccess) break;
+                const int d = op.dev;
+                real_t *ptr = base[d] + (size_t)op.first_row * ld[d];
+                const size_t cnt = (size_t)op.rows * ld[d];
+                r = op.send ? rccl().Send(ptr, cnt, NCCL_REAL, op.peer, comm[d], st[d]) : rccl().Recv(ptr, cnt, NCCL_REAL, op.peer, comm[d], st[d]);
             }
             const ncclResult_t r2 = rccl().GroupEnd();
             if (r != ncclSuccess || r2 != ncclSuccess) {
@@ -595,6 +630,18 @@ bool sharded_fit_wanted(const std::vector<int> &devs)
 
 extern "C" {
 
+/* the exchange schedule of MultiDev::exchange as data (include/cmfrec_hip.h); host-only */
+int cmfrec_hip_exchange_plan(int D, const int *bb, int *out, int cap)
+{
+    if (D < 1 || bb == nullptr) return -1;
+    const std::vector<cmfhip::ExchangeOp> ops = cmfhip::direct_placement_plan(std::vector<int>(bb, bb + D + 1));
+    for (size_t i = 0; i < ops.size() && (int)i < cap && out != nullptr; i++) {
+        out[5 * i] = ops[i].dev; out[5 * i + 1] = ops[i].peer; out[5 * i + 2] = ops[i].send;
+        out[5 * i + 3] = ops[i].first_row; out[5 * i + 4] = ops[i].rows;
+    }
+    return (int)ops.size();
+}
+
 /* Start values exactly as the reference's random_parallel (helpers.c:927-1043) draws them. */
 int cmfrec_hip_random_parallel(real_t *A, size_t sizeA, real_t *B, size_t sizeB, int_t seed, bool normal)
 {
@@ -632,13 +679,19 @@ int_t fit_collective_implicit_als(
     if (naz_U) {
         zero_rows_A = rows_without_data(m, ixA, nnz, U_row, nnz_U);
         const int e = zfU.build(m, m_u, p, U_row, U_col, U_sp, nnz_U);
-        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented." : "cmfrec_hip: U index out of range.");
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented."
+                                    : e == 3 ? "cmfrec_hip: NA_as_zero_U runs on the zero-filled dense matrix (rows of X x p), which is larger than "
+                                               "CMFREC_HIP_ZEROFILL_MAX_GB (default 8) here: not implemented at this size."
+                                             : "cmfrec_hip: U index out of range.");
         U = zfU.dense.data(); m_u = m; nnz_U = 0; U_row = U_col = nullptr; U_sp = nullptr;
     }
     if (naz_I) {
         zero_rows_B = rows_without_data(n, ixB, nnz, I_row, nnz_I);
         const int e = zfI.build(n, n_i, q, I_row, I_col, I_sp, nnz_I);
-        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented." : "cmfrec_hip: I index out of range.");
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented."
+                                    : e == 3 ? "cmfrec_hip: NA_as_zero_I runs on the zero-filled dense matrix (columns of X x q), which is larger than "
+                                               "CMFREC_HIP_ZEROFILL_MAX_GB (default 8) here: not implemented at this size."
+                                             : "cmfrec_hip: I index out of range.");
         II = zfI.dense.data(); n_i = n; nnz_I = 0; I_row = I_col = nullptr; I_sp = nullptr;
     }
     // dense side information with NaN -> the sparse route on its centred present entries
@@ -855,13 +908,19 @@ int_t fit_collective_explicit_als(
     if (naz_U) {
         zero_rows_A = rows_without_data(m, ixA, nnz, U_row, nnz_U);
         const int e = zfU.build(m, m_u, p, U_row, U_col, U_sp, nnz_U);
-        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented." : "cmfrec_hip: U index out of range.");
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_U with more rows of U than X is not implemented."
+                                    : e == 3 ? "cmfrec_hip: NA_as_zero_U runs on the zero-filled dense matrix (rows of X x p), which is larger than "
+                                               "CMFREC_HIP_ZEROFILL_MAX_GB (default 8) here: not implemented at this size."
+                                             : "cmfrec_hip: U index out of range.");
         U = zfU.dense.data(); m_u = m; nnz_U = 0; U_row = U_col = nullptr; U_sp = nullptr;
     }
     if (naz_I) {
         zero_rows_B = rows_without_data(n, ixB, nnz, I_row, nnz_I);
         const int e = zfI.build(n, n_i, q, I_row, I_col, I_sp, nnz_I);
-        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented." : "cmfrec_hip: I index out of range.");
+        if (e) return fail(verbose, e == 2 ? "cmfrec_hip: NA_as_zero_I with more rows of I than X has columns is not implemented."
+                                    : e == 3 ? "cmfrec_hip: NA_as_zero_I runs on the zero-filled dense matrix (columns of X x q), which is larger than "
+                                               "CMFREC_HIP_ZEROFILL_MAX_GB (default 8) here: not implemented at this size."
+                                             : "cmfrec_hip: I index out of range.");
         II = zfI.dense.data(); n_i = n; nnz_I = 0; I_row = I_col = nullptr; I_sp = nullptr;
     }
     // Dense X: the rows of the present entries go through the same row kernels as a sparse X (a row's system is the sum over
@@ -899,6 +958,12 @@ int_t fit_collective_explicit_als(
                 dense_mult_A.resize((size_t)m); dense_mult_B.resize((size_t)n);
                 for (int_t r = 0; r < m; r++) dense_mult_A[r] = (dx.na_row[r] < fewA) ? (real_t)n : (dx.na_row[r] < n ? (real_t)(n - dx.na_row[r]) : (real_t)1);
                 for (int_t c = 0; c < n; c++) dense_mult_B[c] = (dx.na_col[c] < fewB) ? (real_t)m : (dx.na_col[c] < m ? (real_t)(m - dx.na_col[c]) : (real_t)1);
+                // (the bias start values of a weighted session do not restate scale_lam_sideinfo / scale_bias_const: say so here,
+                //  before anything is uploaded, and in terms of what the caller passed -- no weights)
+                if ((scale_lam_sideinfo || scale_bias_const) && user_bias && item_bias && reset_values)
+                    return fail(verbose, "cmfrec_hip: dense X whose rows / columns miss only a few entries, under scale_lam together with "
+                                         "scale_lam_sideinfo / scale_bias_const and both biases, is not implemented (its per-row lambda "
+                                         "multipliers ride on the weighted kernels, whose bias start values do not restate those options).");
                 dx.w.assign(dx.val.size(), (real_t)1);
                 unit_weights = true;
             }
@@ -1064,10 +1129,16 @@ int_t fit_collective_explicit_als(
         gm = (real_t)((long double)gm * ((long double)nnz / ((long double)m * (long double)n)));
         if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
     } else if (center && weight) {
-        // weighted running mean, common.c:3574-3584.  (With 8 threads or more the reference divides the UNWEIGHTED sum of X by
-        // the sum of the weights, :3561-3571 -- not a mean; that branch is not followed.)
+        // weighted running mean, common.c:3574-3584.  With 8 threads or more the reference divides the UNWEIGHTED sum of X by
+        // the sum of the weights (:3561-3571) -- not a mean, but the number a caller with nthreads >= 8 receives (Python:
+        // nthreads = -1 on a host of 8 cores or more), so it is reproduced (fixture g23).
         double xsum = 0, wsum = 2.220446049250313e-16;
-        for (size_t e = 0; e < nnz; e++) { wsum += (double)weight[e]; xsum += (((double)X[e] - xsum) * (double)weight[e]) / wsum; }
+        if (nthreads >= 8) {
+            wsum = 0;
+            for (size_t e = 0; e < nnz; e++) { xsum += (double)X[e]; wsum += (double)weight[e]; }
+            xsum = (double)(real_t)(xsum / wsum);
+        } else
+            for (size_t e = 0; e < nnz; e++) { wsum += (double)weight[e]; xsum += (((double)X[e] - xsum) * (double)weight[e]) / wsum; }
         gm = (real_t)xsum;
         if (nonneg) gm = std::max(gm, (real_t)0);                         // :3604-3605
         if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;

@@ -281,6 +281,13 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             }
             return rc_heavy;
         }
+        if (c.cg_wide != nullptr) {
+            // the wide CG (launch_cg_wide) exists only as the second kernel of the wave path above: falling through would hand
+            // its rows a factorisation without a word -- other numbers than the reference's CG
+            g_last_error = "cmfrec_hip: internal: the Gramian CG beyond 64 unknowns needs the wave-per-row producer (weights, nonneg, L1 or "
+                           "CMFREC_HIP_CHOL=rows keep it off)";
+            return 2;
+        }
     }
 #ifdef CMFREC_HIP_FLOAT
     {
@@ -500,6 +507,7 @@ static int launch_cg_wide(const DeviceInfo &dev, const CgCall &c, const SparseSh
     const int nbw = (c.k - (border ? 1 : 0) + 15) / 16;
     static const char *chol_env = getenv("CMFREC_HIP_CHOL");
     if (c.implicit || c.k <= 64 || nbw > 8 || c.precond || c.X2 != nullptr || c.Bi != nullptr || c.koff != 0 || X.weighted() ||
+        dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 ||      // (launch_chol's wave path is off then)
         cg_variant_from_env() == CgVariant::Generic || (chol_env != nullptr && strcmp(chol_env, "rows") == 0) ||
         (c.kc > 0 && (c.CtC == nullptr || c.UC == nullptr || c.kc > c.k)) || gcw_lds_elems<real_t>(c.k) * sizeof(real_t) > (size_t)160 * 1024)
         return -1;
@@ -2263,9 +2271,15 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
                     s->cf_keep.alloc_at_least(rows * ld);
                     HIP_CHECK(hipMemcpyAsync(s->cf_keep.ptr, self, rows * ld * sizeof(real_t), hipMemcpyDeviceToDevice, s->dev.stream));
                     rc = update_factor(s, isA, true);
-                    hipLaunchKernelGGL(restore_rows_kernel<real_t>, grid1d(rows * ld), dim3(256), 0, s->dev.stream, self, s->cf_keep.ptr, ld, rows,
-                                       (isA ? s->cfmaskA : s->cfmaskB).ptr);
-                    HIP_CHECK(hipGetLastError());
+                    if (rc != 0) {
+                        // the closed-form pass failed part-way: put the CG results back whole rather than leave a mix of zeroed
+                        // and half-solved rows behind the error code
+                        HIP_CHECK(hipMemcpyAsync(self, s->cf_keep.ptr, rows * ld * sizeof(real_t), hipMemcpyDeviceToDevice, s->dev.stream));
+                    } else {
+                        hipLaunchKernelGGL(restore_rows_kernel<real_t>, grid1d(rows * ld), dim3(256), 0, s->dev.stream, self, s->cf_keep.ptr, ld, rows,
+                                           (isA ? s->cfmaskA : s->cfmaskB).ptr);
+                        HIP_CHECK(hipGetLastError());
+                    }
                 }
             }
             if (rc == 0 && (which == 'A' ? s->n_zrowsA : s->n_zrowsB) > 0) {

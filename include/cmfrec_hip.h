@@ -539,6 +539,12 @@ int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, double *ms_
  * constants, 0 if they were recomputed (<= 1 ulp apart). */
 int cmfrec_hip_random_parallel(real_t *A, size_t sizeA, real_t *B, size_t sizeB, int_t seed, bool normal);
 
+/* The point-to-point schedule MultiDev::exchange issues for one half-step (direct placement): the operations of all
+ * D devices for the block boundaries bb[0 .. D], five ints each -- {device, peer, send (1) / receive (0), first row, rows} -- in
+ * issue order, at most `cap` of them written to `out`.  Host-only, no device needed: lets a test check that every send has its
+ * matching receive with the same count and that the received blocks tile the replica.  Returns the number of operations. */
+int cmfrec_hip_exchange_plan(int D, const int *bb, int *out, int cap);
+
 /* Build info: sizeof(real_t), and the gfx target the kernels were compiled for. */
 int cmfrec_hip_sizeof_real(void);
 /* sizeof(cmfrec_hip_model) as compiled: lets a binding verify its mirror of the struct before the first call. */

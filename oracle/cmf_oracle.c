@@ -1065,14 +1065,23 @@ real_t oracle_calc_mean_and_center(real_t *X, size_t nnz, int nthreads)
     return glob_mean;
 }
 
-/* weighted mean of the entries, running form (common.c:3574-3584; with 8 threads or more the reference divides the unweighted
- * sum by the sum of the weights, :3561-3571 -- not restated), then centring as above */
-real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz)
+/* weighted mean of the entries: running form below 8 threads (common.c:3574-3584); with 8 threads or more the reference divides
+ * the UNWEIGHTED sum of the entries by the sum of the weights (:3561-3571) -- not a mean, but what a caller with nthreads >= 8
+ * receives, so it is restated as it stands (sums in entry order; the reference's OpenMP reduction adds per-thread partial
+ * sums in an unspecified order: equal to rounding); then centring as above */
+real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz, int nthreads)
 {
     double xsum = 0, wsum = DBL_EPSILON;
-    for (size_t ix = 0; ix < nnz; ix++)
-        xsum += ((X[ix] - xsum) * weight[ix]) / (wsum += weight[ix]);
-    real_t glob_mean = (real_t)xsum;
+    real_t glob_mean;
+    if (nthreads >= 8) {                                                       /* common.c:3561-3571 */
+        wsum = 0;
+        for (size_t ix = 0; ix < nnz; ix++) { xsum += X[ix]; wsum += weight[ix]; }
+        glob_mean = (real_t)(xsum / wsum);
+    } else {
+        for (size_t ix = 0; ix < nnz; ix++)
+            xsum += ((X[ix] - xsum) * weight[ix]) / (wsum += weight[ix]);
+        glob_mean = (real_t)xsum;
+    }
     if (g_nn_AB) glob_mean = (glob_mean > 0) ? glob_mean : (real_t)0;          /* :3604-3605 */
     if (fabs_t(glob_mean) < sqrt_t(EPSILON_T)) glob_mean = 0;
     if (glob_mean != 0)
@@ -1502,7 +1511,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
             if (fabs_t(*glob_mean) < sqrt_t(EPSILON_T)) *glob_mean = 0;
         }
     }
-    else if (weight != NULL) *glob_mean = center ? oracle_calc_mean_and_center_weighted(Xc, weight, nnz) : (real_t)0;
+    else if (weight != NULL) *glob_mean = center ? oracle_calc_mean_and_center_weighted(Xc, weight, nnz, nthreads) : (real_t)0;
     else
     *glob_mean = center ? oracle_calc_mean_and_center(Xc, nnz, nthreads) : (real_t)0;  /* :7552-7568 */
     size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t));

@@ -86,7 +86,7 @@ void oracle_set_naz_bias_BtX(const real_t *bias_BtX);
  * weightR / weightC, wsumA / wsumB, weighted bias start values (common.c:4672-4692, :4826-4847), weighted row solvers.  Model
  * without side information only (returns 2 otherwise).  Cleared by the call. */
 void oracle_set_fit_weights(const real_t *weight);
-real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz);
+real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz, int nthreads);
 void oracle_initialize_biases_twosided_weighted(int_t m, int_t n,
                                                 const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *weightR,
                                                 const size_t *Xcsc_p, const int_t *Xcsc_i, const real_t *Xcsc, const real_t *weightC,

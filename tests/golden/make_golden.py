@@ -339,6 +339,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g21_na_as_zero_UI_" + tag, **out)
 
+        # ---- G23: the global mean under nthreads >= 8 (sum / count; weighted: unweighted sum / sum of weights) ----
+        out = {}
+        d = gc.weights_problem(dt)
+        for ci, (name, weighted, opts) in enumerate(gc.NTHREADS8_CASES):
+            r = gc.nthreads8_reference(R, d, weighted, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g23_nthreads8_mean_" + tag, **out)
+
         # ---- RNG streams of the reference (pins the start-value generator) ----
         out = {}
         for seed in (1, 123):

@@ -945,7 +945,7 @@ def weights_oracle(O, d, side, opts, nthreads=2):
     return out
 
 
-def weights_hip(d, side, opts, dtype, weights=True):
+def weights_hip(d, side, opts, dtype, weights=True, nthreads=1):
     from cmfrec_amd import CMF
     o = dict(opts)
     seed = o.pop("seed", None)
@@ -954,7 +954,7 @@ def weights_hip(d, side, opts, dtype, weights=True):
     A0, B0 = _impf_start(d, o)
     U, II = (d["U"], d["I"]) if side else (None, None)
     mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
-              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=nthreads,
               **(dict(random_state=seed) if seed is not None else {}), **o)
     start = {} if seed is not None else dict(A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
     mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), W=d["W"] if weights else None, **start)
@@ -962,6 +962,40 @@ def weights_hip(d, side, opts, dtype, weights=True):
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     return out
+
+
+# ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
+#      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
+# (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded
+NTHREADS8_CASES = [
+    ("cg, both biases", False, dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    ("chol, both biases", False, dict(use_cg=False)),
+    ("cg seeded", False, dict(use_cg=True, finalize_chol=False, seed=9)),
+    ("weighted cg, both biases", True, dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    ("weighted chol", True, dict(use_cg=False)),
+    ("weighted cg seeded", True, dict(use_cg=True, finalize_chol=False, scale_lam=True, seed=10)),
+]
+
+
+def nthreads8_reference(R, d, weighted, opts):
+    e = dict(d)
+    if not weighted:
+        e["W"] = None
+    return weights_reference(R, e, False, opts, nthreads=8)
+
+
+def nthreads8_oracle(O, d, weighted, opts):
+    """None for the seeded starts (the oracle has no restatement of the weighted random start)."""
+    if "seed" in opts:
+        return None
+    e = dict(d)
+    if not weighted:
+        e["W"] = None
+    return weights_oracle(O, e, False, opts, nthreads=8)
+
+
+def nthreads8_hip(d, weighted, opts, dtype, nthreads=8):
+    return weights_hip(d, False, opts, dtype, weights=weighted, nthreads=nthreads)
 
 
 # ---- NA_as_zero for the main matrix (CMF(NA_as_zero=True); fit_collective_explicit_als with NA_as_zero_X) -------------------

@@ -274,6 +274,29 @@ def test_sparse_side_info_colmeans(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_global_mean_with_eight_threads(oracles, dtype):
+    """G23 through CMF(nthreads=8): the global mean the reference returns at 8 threads or more (sum / count; with W= the unweighted
+    sum over the sum of the weights, common.c:3496-3513, :3561-3571) -- what nthreads = -1 resolves to on any host of 8 cores."""
+    g = gc.load("g23_nthreads8_mean", dtype)
+    d = gc.weights_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, weighted, opts) in enumerate(gc.NTHREADS8_CASES):
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        got = gc.nthreads8_hip(d, weighted, opts, dtype)
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        assert abs(float(got["glob_mean"]) - float(exp["glob_mean"])) <= (1e-12 if dtype is np.float64 else 1e-5), name
+        ref = gc.nthreads8_oracle(oracles[dtype], d, weighted, opts)
+        if ref is not None:
+            assert gc.compare_fits(got, ref) < tol, name
+    # the default thread count of the estimator (-1 -> all host cores) takes the same branch on the GPU box
+    name, weighted, opts = gc.NTHREADS8_CASES[3]
+    got = gc.nthreads8_hip(d, weighted, opts, dtype, nthreads=-1)
+    import multiprocessing
+    if multiprocessing.cpu_count() >= 8:
+        assert abs(float(got["glob_mean"]) - float(g["c3_glob_mean"])) <= (1e-12 if dtype is np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_observation_weights(oracles, dtype):
     """G17 through the estimator (CMF.fit(..., W=...)): weighted row solvers in every kernel family the cases reach (register
     tiles, Jacobi-preconditioned and block CG, the workgroup-per-row Cholesky kernel with and without side information,

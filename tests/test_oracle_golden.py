@@ -203,6 +203,29 @@ def test_observation_weights(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_global_mean_with_eight_threads(oracles, dtype):
+    """G23: the centred explicit fit called with nthreads = 8 -- calc_mean_and_center then takes sum / count instead of the
+    running mean (common.c:3496-3513) and, with weights, the unweighted sum over the sum of the weights (:3561-3571)."""
+    g = gc.load("g23_nthreads8_mean", dtype)
+    d = gc.weights_problem(dtype)
+    seen = 0
+    for ci, (name, weighted, opts) in enumerate(gc.NTHREADS8_CASES):
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        got = gc.nthreads8_oracle(oracles[dtype], d, weighted, opts)
+        if got is None:
+            continue
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+        assert abs(float(got["glob_mean"]) - float(exp["glob_mean"])) <= (1e-13 if dtype is np.float64 else 1e-6), name
+        seen += 1
+    assert seen == 4
+    # the weighted branch is NOT the weighted mean: the fixture's number is sum(x) / sum(w)
+    w = d["W"].astype(np.float64); x = d["ratings"].astype(np.float64)
+    gm8 = float(g["c3_glob_mean"])
+    assert abs(gm8 - x.sum() / w.sum()) < (1e-12 if dtype is np.float64 else 1e-5)
+    assert abs(gm8 - (x * w).sum() / w.sum()) > 1e-2
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_NA_as_zero_X(oracles, dtype):
     """G18: fit_collective_explicit_als with NA_as_zero_X on sparse X -- the cases with given start values."""
     g = gc.load("g18_na_as_zero", dtype)

@@ -448,6 +448,32 @@ def test_weighted_fit_live(oracles, refs, dtype):
         assert abs(ro["glob_mean"] - rr["glob_mean"]) < 1e-5 * max(1.0, abs(rr["glob_mean"]))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_global_mean_eight_threads_live(oracles, refs, dtype):
+    """calc_mean_and_center at nthreads >= 8 (common.c:3496-3513, :3561-3571), live: zero iterations from a given start, so that
+    the mean (and the bias start values computed from the centred entries) is all that happens."""
+    O, R = oracles[dtype], refs[dtype]
+    m, n, row, col, val, w = weights_problem(dtype, seed=75)
+    k = 6
+    rng = np.random.default_rng(12)
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+    for weight in (None, w):
+        got = {}
+        for nt in (2, 8):
+            ro = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, lam=0.4, niter=2, nthreads=nt, weight=weight, use_cg=True)
+            rr = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, lam=0.4, niter=2, nthreads=nt, weight=weight,
+                                               use_cg=True)
+            assert ro["ret"] == 0 and rr["ret"] == 0
+            assert abs(ro["glob_mean"] - rr["glob_mean"]) < (1e-13 if dtype is np.float64 else 1e-6), (weight is None, nt)
+            for key in ("A", "B"):
+                assert rel_err(ro[key], rr[key]) < 50 * TOL[dtype], (weight is None, nt, key)
+            got[nt] = float(rr["glob_mean"])
+        if weight is not None:
+            assert abs(got[2] - got[8]) > 1e-2          # the two branches are different numbers with weights
+        else:
+            assert abs(got[2] - got[8]) < 1e-5
+
+
 def test_reference_weight_defects(refs):
     """Two defects of the reference's weighted fit, shown on the reference alone -- the reason the weighted parity cases use
     entries sorted by column and, for the collective closed form, no centring ("Observation weights").
