@@ -130,10 +130,29 @@ struct CgParams {
     // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
     const T *rconst = nullptr;
     size_t ldr = 0;
+    // two-rows-per-wavefront kernel (cg_pair_kernels.hpp): the first pair_split rows of the launch (more than 16 entries) pair among
+    // themselves on the 32-slot tile, the others on the 16-slot tile -- a row's arithmetic never depends on its partner
+    int pair_split = 0;
 #ifdef CMF_CG_DEBUG
     int dbg = 0;   // phase skipping for timing experiments (results are wrong): 1 gathers, 2 Gramian product, 4 tile products, 8 dot products
 #endif
+#ifdef CMF_CG_TICKS
+    // Where a wavefront's time goes (a -DCMF_CG_TICKS build, tools/microbench/cg_ticks.py): per kernel family four 64-bit sums over
+    // all wavefronts -- s_memtime ticks spent waiting for the row's gather (from the last load issued to s_waitcnt vmcnt(0)), ticks
+    // in the CG passes, rows, total ticks inside the row loop.  Results are unchanged; the explicit wait moves a few instructions.
+    unsigned long long *ticks = nullptr;
+#endif
 };
+#ifdef CMF_CG_TICKS
+#define CMF_TICK() __builtin_amdgcn_s_memtime()
+__device__ __forceinline__ void cg_ticks_flush(unsigned long long *t, int slot, unsigned long long wait, unsigned long long pass, unsigned long long rows,
+                                               unsigned long long total, int lane)
+{
+    if (t != nullptr && lane == 0) {
+        atomicAdd(t + 4 * slot + 0, wait); atomicAdd(t + 4 * slot + 1, pass); atomicAdd(t + 4 * slot + 2, rows); atomicAdd(t + 4 * slot + 3, total);
+    }
+}
+#endif
 // Timing experiments (tools/gpu/r02_o.sh): a build with -DCMF_CG_DEBUG reads CMFREC_HIP_CG_SKIP and leaves phases out.
 #ifdef CMF_CG_DEBUG
 #define CMF_DBG(P, bit) (((P).dbg & (bit)) != 0)
@@ -651,6 +670,10 @@ cg_rows_kernel(const CgParams<T> P)
     RowDesc dnxt = load_desc(rnxt);
     Pre pcur = load_pre(dcur);
     int pend = issue_claim();      // the position after rnn; lands while this row is solved
+#ifdef CMF_CG_TICKS
+    unsigned long long tk_wait = 0, tk_pass = 0, tk_rows = 0;
+    const unsigned long long tk_begin = CMF_TICK();
+#endif
     for (int it = 0; rix < P.nrows; it++) {
         const int row = dcur.row;
         const size_t st = dcur.st;
@@ -691,6 +714,12 @@ cg_rows_kernel(const CgParams<T> P)
         }
         const RowDesc dnn = load_desc(rnn);
         const Pre pnxt = load_pre(dnxt);
+#ifdef CMF_CG_TICKS
+        const unsigned long long tk0 = CMF_TICK();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tk1 = CMF_TICK();
+        tk_wait += tk1 - tk0;
+#endif
 
         auto run_pass = [&](T vdist, auto mode_tag, bool first) -> T {
             constexpr int MODE = decltype(mode_tag)::value;
@@ -790,11 +819,17 @@ cg_rows_kernel(const CgParams<T> P)
             }
         }
         if (wr == 0 && lane < k) arow[lane] = a_d;
+#ifdef CMF_CG_TICKS
+        tk_pass += CMF_TICK() - tk1; tk_rows += (wr == 0);
+#endif
         const int r3 = (W == 1) ? cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(pend) : s_claim[it & 1];
         dcur = dnxt; dnxt = dnn; pcur = pnxt;
         rix = rnxt; rnxt = rnn; rnn = r3;
         pend = issue_claim();
     }
+#ifdef CMF_CG_TICKS
+    cg_ticks_flush(P.ticks, W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : 3, tk_wait, tk_pass, tk_rows, CMF_TICK() - tk_begin, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -859,8 +894,9 @@ __device__ __forceinline__ T treduce4_low(const T (&v)[4], int lane)
     return q + lanes::xor1(q);          // lanes 2t, 2t+1 both hold the total of v[t]
 }
 
-template <int S, bool IMPLICIT, int MODE>
-__device__ __forceinline__ void tile_pass4_f32(const RegTile4<float, S> &tile, const float (&vrep)[S], float x, bool valid,
+// (TILE: a RegTile4, or a RegTile whose first four entries per lane group are used -- the mixed launch of the pair kernel)
+template <int S, bool IMPLICIT, int MODE, typename TILE>
+__device__ __forceinline__ void tile_pass4_f32(const TILE &tile, const float (&vrep)[S], float x, bool valid,
                                            PassAcc<float> &out, int lane, float g = 1.f)
 {
     float c[4];
@@ -883,8 +919,8 @@ __device__ __forceinline__ void tile_pass4_f32(const RegTile4<float, S> &tile, c
     }
 }
 
-template <typename T, int S, bool IMPLICIT, int MODE>
-__device__ __forceinline__ void tile_pass4(const RegTile4<T, S> &tile, const T (&vrep)[S], T x, bool valid,
+template <typename T, int S, bool IMPLICIT, int MODE, typename TILE>
+__device__ __forceinline__ void tile_pass4(const TILE &tile, const T (&vrep)[S], T x, bool valid,
                                            PassAcc<T> &out, int lane, T g = T(1))
 {
     if constexpr (std::is_same<T, float>::value) {
@@ -1279,18 +1315,8 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Rows of at most 16 non-zeros, TWO per wavefront: the tiny kernel's cost per row is mostly fixed (the Gramian product, the
-// reductions, the CG scalars -- its bin is bound by VALU issue, not by the gather), and half of a tiny bin typically holds no
-// more than 16 entries.  Lanes 0..31 solve one row, lanes 32..63 the next one of the processing order; within a half the grid
-// is 4 groups (jq) x 8 lanes (ll), a lane keeps 4 entries x S columns (the same RegTile4 and tile_pass4 as the tiny kernel).
-// Vectors of length <= 64 are distributed over the 32 lanes of a half as two registers: lane q holds elements q and q + 32.
-//   Gramian product : lane (jq, ll) covers the Gramian rows 8 jq + t and 32 + 8 jq + t, t < 8 -- their weights v[row] sit in the
-//                     lanes of the same 8-lane group, registers 0 / 1 -- twice the products per lane, the same per row
-//   reduction over jq: two 4 x 4 transposed butterflies (lane bits 4 and 3), one per register
-//   dot products     : over the 32 lanes of a half (five stages), both rows in the same instructions
-//   CG               : the two rows take their exits independently; a finished half keeps running with step 0
-// One instruction stream serves two rows: 294 -> ~175 VALU instructions per row and pass in double precision.
+// sum over the 32 lanes of each half of the wavefront (the two-rows-per-wavefront kernel, cg_pair_kernels.hpp), identical on
+// every lane of the half
 template <typename T>
 __device__ __forceinline__ T half_sum(T v)
 {
@@ -1299,162 +1325,6 @@ __device__ __forceinline__ T half_sum(T v)
     v += lanes::qxor4(v);
     v += lanes::xor8(v);
     return lanes::tswap16_add(v, v);            // lanes l and l + 16 of each half
-}
-
-template <typename T, int S, bool IMPLICIT>
-__global__ void __launch_bounds__(256, CMF_TINY_WAVES_PER_SIMD)
-cg_rows_tiny2_kernel(const CgParams<T> P)
-{
-    constexpr int LD = gram_ld(S);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *G = reinterpret_cast<T *>(smem_raw);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int h = lane >> 5, q = lane & 31, jq = q >> 3, ll = lane & 7;
-    const int k = P.k;
-    if (IMPLICIT) {
-        stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
-        __syncthreads();
-    }
-    const int nwaves = gridDim.x * 4;
-    const int npairs = (P.nrows + 1) / 2;
-    // elements of this lane: e0 = q, e1 = q + 32
-    const bool live0 = q < k, live1 = q + 32 < k;
-    struct Pre { int row, nnz; int idx; T x; T a0, a1; T g; };
-    auto load_pre = [&](int pair) -> Pre {
-        Pre r; r.row = 0; r.nnz = 0; r.idx = 0; r.x = T(0); r.a0 = T(0); r.a1 = T(0); r.g = T(1);
-        const int pos = 2 * pair + h;
-        if (pair < npairs && pos < P.nrows) {
-            const RowDesc d = P.desc[pos];
-            r.row = d.row; r.nnz = d.nnz;
-            const int e = q >> 1;                               // lanes 2 t, 2 t + 1 of a group carry entry 4 jq + t
-            if (e < d.nnz) {
-                r.idx = P.indices[d.st + e];
-                r.x = P.values[d.st + e];
-                r.g = entry_weight<T, IMPLICIT>(P, d.st + e);
-                if (!IMPLICIT && P.bias_sub != nullptr) r.x -= P.bias_sub[r.idx];
-            }
-            if (d.nnz > 0) {
-                if (live0) r.a0 = P.A[(size_t)d.row * P.lda + q];
-                if (live1) r.a1 = P.A[(size_t)d.row * P.lda + q + 32];
-            }
-        }
-        return r;
-    };
-    int pair = blockIdx.x * 4 + (tid >> 6);
-    Pre cur = load_pre(pair);
-    while (pair < npairs) {
-        // gather: entries past the row's end re-read the row of its first entry (weight zero), columns past k column k - 1
-        RegTile4<T, S> tile;
-        {
-            int its[4];
-            its[0] = lanes::bcast8<0>(cur.idx); its[1] = lanes::bcast8<2>(cur.idx);
-            its[2] = lanes::bcast8<4>(cur.idx); its[3] = lanes::bcast8<6>(cur.idx);
-            const int first_idx = __shfl(cur.idx, lane & 32);
-            const int col_last = min(ll + 8 * (S - 1), k - 1) - ll;
-            const char *base = reinterpret_cast<const char *>(P.B + ll);
-            const unsigned ldb_bytes = (unsigned)(P.ldb * sizeof(T));
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const unsigned it = (unsigned)(((jq * 4 + t) < cur.nnz) ? its[t] : first_idx);
-                const T *rp = reinterpret_cast<const T *>(base + (unsigned long long)it * ldb_bytes);
-#pragma unroll
-                for (int s = 0; s < S; s++) tile.set(t, s, rp[(s < S - 1) ? 8 * s : col_last]);
-            }
-        }
-        const Pre nxt = load_pre(pair + nwaves);
-        const int nnz = cur.nnz;
-        const bool valid = (q >> 1) < nnz;
-        T lam = P.lam, lam_last = P.lam_last;
-        if (!IMPLICIT && P.scale_lam) {                        // common.c:679-723
-            const T mult = (P.wsum != nullptr && nnz > 0) ? P.wsum[cur.row] : (T)nnz;
-            lam *= mult;
-            if (!P.scale_bias_const) lam_last *= mult;
-        }
-        // diagonal term of the operator for this lane's two elements
-        const T d0 = (!IMPLICIT && q == k - 1) ? lam_last : lam, d1 = (!IMPLICIT && q + 32 == k - 1) ? lam_last : lam;
-        T a0 = cur.a0, a1 = cur.a1;
-        auto run_pass = [&](T v0, T v1, auto mode_tag, T &o0, T &o1) {
-            constexpr int MODE = decltype(mode_tag)::value;
-            asm volatile("" ::: "memory");
-            T vrep[S];
-#pragma unroll
-            for (int s = 0; s < S; s++) vrep[s] = __shfl((s >> 2) ? v1 : v0, (lane & 32) | (ll + 8 * (s & 3)));
-            PassAcc<T> acc;
-            acc.zero();
-            tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, cur.x, valid, acc, lane, cur.g);
-            if (IMPLICIT) {                                     // + (+-) BtB v: rows 8 jq + t (weights in register 0), 32 + 8 jq + t (register 1)
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const T sv = (MODE == 0) ? -(a ? v1 : v0) : (a ? v1 : v0);
-                    T w[8];
-                    w[0] = lanes::bcast8<0>(sv); w[1] = lanes::bcast8<1>(sv); w[2] = lanes::bcast8<2>(sv); w[3] = lanes::bcast8<3>(sv);
-                    w[4] = lanes::bcast8<4>(sv); w[5] = lanes::bcast8<5>(sv); w[6] = lanes::bcast8<6>(sv); w[7] = lanes::bcast8<7>(sv);
-                    if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {       // row pairs (2 qq, 2 qq + 1) of the group's eight rows
-                            const f32x2 *g = reinterpret_cast<const f32x2 *>(G) + (16 * a + 4 * jq + qq) * gram_ld2(S) + ll;
-                            const f32x2 w2 = f32x2{w[2 * qq], w[2 * qq + 1]};
-#pragma unroll
-                            for (int s = 0; s < S; s++) acc.v[s] += w2 * lds_g(g + 8 * s);
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 8; t++) {
-                            const T *g = G + (32 * a + 8 * jq + t) * LD + ll;
-#pragma unroll
-                            for (int s = 0; s < S; s++) acc.v[s] += w[t] * lds_g(g + 8 * s);
-                        }
-                    }
-                }
-            }
-            T out[8];
-            acc.close(out);
-            // element ll + 8 s -> lane (s & 3, ll), register s >> 2, summed over the four groups of the half
-            {
-                const bool b3 = (lane & 8) != 0;
-                T u0 = lanes::tswap16_add(out[0], out[2]), u1 = lanes::tswap16_add(out[1], out[3]);
-                o0 = (b3 ? u1 : u0) + lanes::recv_xor8(u0, u1);
-                T u2 = lanes::tswap16_add(out[4], out[6]), u3 = lanes::tswap16_add(out[5], out[7]);
-                o1 = (b3 ? u3 : u2) + lanes::recv_xor8(u2, u3);
-            }
-        };
-        // ---- residual (common.c:1932-1943 / :1112-1139) ----
-        T r0, r1;
-        run_pass(a0, a1, std::integral_constant<int, 0>{}, r0, r1);
-        r0 -= d0 * a0; r1 -= d1 * a1;
-        if (!live0) r0 = T(0);
-        if (!live1) r1 = T(0);
-        T p0 = r0, p1 = r1;
-        T r_old = half_sum(r0 * r0 + r1 * r1);
-        bool done = (r_old <= (T)1e-12) || nnz <= 0;            // common.c:1952 / :1147; a half without a row idles
-        for (int step = 0; step < P.max_cg_steps && __builtin_amdgcn_ballot_w64(!done) != 0ull; step++) {
-            T Ap0, Ap1;
-            run_pass(p0, p1, std::integral_constant<int, 1>{}, Ap0, Ap1);
-            Ap0 += d0 * p0; Ap1 += d1 * p1;
-            if (!live0) Ap0 = T(0);
-            if (!live1) Ap1 = T(0);
-            const T pAp = half_sum(Ap0 * p0 + Ap1 * p1);
-            const T alpha = done ? T(0) : cg_div(r_old, pAp);
-            a0 += alpha * p0; a1 += alpha * p1;
-            r0 -= alpha * Ap0; r1 -= alpha * Ap1;
-            const T r_new = half_sum(r0 * r0 + r1 * r1);
-            if (!done) {
-                if (r_new <= (T)1e-8) done = true;              // common.c:1979 / :1180
-                else {
-                    const T beta = cg_div(r_new, r_old);
-                    p0 = p0 * beta + r0; p1 = p1 * beta + r1;
-                    r_old = r_new;
-                }
-            }
-        }
-        if (nnz > 0) {
-            if (live0) P.A[(size_t)cur.row * P.lda + q] = a0;
-            if (live1) P.A[(size_t)cur.row * P.lda + q + 32] = a1;
-        }
-        cur = nxt;
-        pair += nwaves;
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "chol_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gram_cg_kernels.hpp"
+#include "cg_pair_kernels.hpp"
 #include "topn_kernels.hpp"
 
 namespace cmfhip {
@@ -629,6 +630,16 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
+// CMFREC_HIP_PAIR: how the rows of at most 32 entries run.  1 (default): two rows per wavefront, ONE launch for the bin
+// (cg_pair_kernels.hpp; the 16-slot tile for the pairs of rows of <= 16 entries).  2: two launches -- the rows of 17..32 entries on
+// the 32-slot build, the rows of <= 16 on the build that keeps its Gramian elements in registers.  0: one row per wavefront
+// (cg_rows_tiny_kernel, round 4; A/B switch and on-device cross-check).
+inline int cg_pair_mode()
+{
+    static const int mode = getenv("CMFREC_HIP_PAIR") != nullptr ? atoi(getenv("CMFREC_HIP_PAIR")) : 1;
+    return mode;
+}
+
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st, int n_gt16)
 {
@@ -639,33 +650,51 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         HIP_CHECK(hipEventCreate(&ev.b));
         HIP_CHECK(hipEventRecord(ev.a, st));
     }
-    // rows of at most 16 entries (the tail of the bin): two per wavefront (cg_rows_tiny2_kernel) or
-    // on the one-row kernel (A/B switch and cross-check)
     poison_lds(st, dev.num_cus);
-    // Round 4: with a Gramian (implicit model) the one-row kernel keeps its Gramian elements in registers and is bound by the vector
-    // ALU, the two-rows kernel reads twice as many of them from LDS per pass and is bound by the LDS pipe (80 % busy): C2's tiny bin
-    // 0.480 -> 0.465 ms (users), 0.146 -> 0.130 ms (items) with every row on the one-row kernel (profiles/r04/r04_x).  Without a
-    // Gramian (explicit model) the two-rows kernel is the faster one in isolation, but as a second launch of the bin it costs more
-    // in tails beside the other bins' launches than it saves (config 4 on one GPU 66.2 -> 64.9 ms with ONE launch for the bin,
-    // profiles/r04/r04_z2).  So by default the bin is one launch of the one-row kernel, which takes a 16-slot tile for the rows of
-    // <= 16 entries and the 32-slot tile for the others (NE = 0); CMFREC_HIP_TINY16=0: the 32-slot tile for every row;
-    // CMFREC_HIP_TINY2=1: the rows of <= 16 entries on the two-rows kernel.
-    static const char *tiny2_env = getenv("CMFREC_HIP_TINY2");
-    const bool tiny2_on = (tiny2_env != nullptr) && tiny2_env[0] != '0';
+    // One launch for the bin (a second launch for the rows of <= 16 entries costs more in launch tails beside the other bins than
+    // the shorter tile saves, profiles/r04/r04_z2); the kernels take the 16-slot tile where the rows allow it.
     static const char *tiny16_env = getenv("CMFREC_HIP_TINY16");
     const bool tiny16_on = (tiny16_env == nullptr) || tiny16_env[0] != '0';
     const int count_le16 = std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
-    const int count2 = (GRAMX || !tiny2_on) ? 0 : count_le16;
-    const int count1 = count - count2;
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
-    if (count1 > 0) {
-        CgParams<real_t> P1 = P;
-        P1.order += first;
-        P1.desc += first;
-        P1.nrows = count1;
-        P1.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
-        const bool mixed = tiny16_on && count2 == 0 && count_le16 > 0;
+    CgParams<real_t> P1 = P;
+    P1.order += first;
+    P1.desc += first;
+    P1.nrows = count;
+    P1.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
+    auto pair_launch = [&](auto kern, int cache_slot, CgParams<real_t> Pk, int rows) {
+        static thread_local int bpc_dev[MAX_DEVICES][4] = {{0}};
+        int &blocks_per_cu = bpc_dev[di][cache_slot];
+        if (blocks_per_cu == 0) {
+            int nb = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
+            blocks_per_cu = std::max(1, nb);
+        }
+        const int npairs = (Pk.pair_split + 1) / 2 + (rows - Pk.pair_split + 1) / 2;
+        const int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, Pk);
+    };
+    if (cg_pair_mode() == 2 && tiny16_on && count_le16 > 0) {
+        // two launches (the second on a spare counter set): rows of 17..32 entries, then rows of <= 16 with the Gramian in registers
+        const int n_long = count - count_le16;
+        if (n_long > 0) {
+            CgParams<real_t> Pl = P1;
+            Pl.nrows = n_long; Pl.pair_split = n_long;
+            pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 8, false>, 0, Pl, n_long);
+        }
+        CgParams<real_t> Ps = P1;
+        Ps.order += n_long; Ps.desc += n_long; Ps.nrows = count_le16; Ps.pair_split = 0;
+        Ps.counter = dev.row_counter.ptr + cg_counter_offset(NBINS + 1);
+        pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 4, true>, 1, Ps, count_le16);
+    } else if (cg_pair_mode() != 0) {
+        // two rows per wavefront, paired in processing order inside their length class (round 5)
+        const bool mixed = tiny16_on && count_le16 > 0;
+        P1.pair_split = mixed ? count - count_le16 : count;        // rows of more than 16 entries lead the bin
+        if (mixed) pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 0, false>, 2, P1, count);
+        else pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 8, false>, 0, P1, count);
+    } else {
+        const bool mixed = tiny16_on && count_le16 > 0;
         auto kern = mixed ? cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX, 0> : cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX, 4>;
         static thread_local int bpc_dev[MAX_DEVICES][2] = {{0}};
         int &blocks_per_cu = bpc_dev[di][mixed ? 1 : 0];
@@ -674,27 +703,8 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
             HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
             blocks_per_cu = std::max(1, nb);
         }
-        int grid = std::min((count1 + 3) / 4, dev.num_cus * blocks_per_cu);
+        const int grid = std::min((count + 3) / 4, dev.num_cus * blocks_per_cu);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, P1);
-    }
-    if constexpr (!GRAMX) {
-        if (count2 > 0) {
-            CgParams<real_t> P2 = P;
-            P2.order += first + count1;
-            P2.desc += first + count1;
-            P2.nrows = count2;
-            auto kern2 = cg_rows_tiny2_kernel<real_t, S, IMPLICIT>;
-            static thread_local int bpc2_dev[MAX_DEVICES] = {0};
-            int &blocks_per_cu = bpc2_dev[di];
-            if (blocks_per_cu == 0) {
-                int nb = 0;
-                HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern2, 256, IMPLICIT ? smem : 0));
-                blocks_per_cu = std::max(1, nb);
-            }
-            const int npairs = (count2 + 1) / 2;
-            int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
-            hipLaunchKernelGGL(kern2, dim3(grid), dim3(256), IMPLICIT ? smem : 0, st, P2);
-        }
     }
     HIP_CHECK(hipGetLastError());
     if (tm) {
@@ -948,6 +958,19 @@ inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const S
     HIP_CHECK(hipGetLastError());
 }
 
+#ifdef CMF_CG_TICKS
+// 8 kernel families x 4 sums (cg_kernels.hpp, CgParams::ticks); one buffer per process, read and cleared by cmfrec_hip_debug_cg_ticks
+inline unsigned long long *cg_ticks_buffer()
+{
+    static unsigned long long *buf = nullptr;
+    if (buf == nullptr) {
+        HIP_CHECK(hipMalloc((void **)&buf, 32 * sizeof(unsigned long long)));
+        HIP_CHECK(hipMemset(buf, 0, 32 * sizeof(unsigned long long)));
+    }
+    return buf;
+}
+#endif
+
 inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &X, BinTimers *tm = nullptr)
 {
     CgParams<real_t> P;
@@ -965,6 +988,9 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.Bi = c.Bi; P.BiTBi = c.BiTBi; P.ki = c.ki; P.w_imp = c.w_imp;
 #ifdef CMF_CG_DEBUG
     if (const char *e = getenv("CMFREC_HIP_CG_SKIP")) P.dbg = atoi(e);
+#endif
+#ifdef CMF_CG_TICKS
+    P.ticks = cg_ticks_buffer();
 #endif
     const int S = (c.k + 7) / 8;
     // Block systems (dense side information on EVERY row of the launch and / or implicit features, no k_user offset) on the

@@ -3029,6 +3029,18 @@ extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, 
     });
 }
 
+#ifdef CMF_CG_TICKS
+// (instrumented builds only; not part of include/cmfrec_hip.h) copies the 32 tick sums to `out` and clears them
+extern "C" int cmfrec_hip_debug_cg_ticks(unsigned long long *out)
+{
+    unsigned long long *buf = cg_ticks_buffer();
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, buf, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemset(buf, 0, 32 * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
+
 extern "C" int cmfrec_hip_selftest_lanes(void)
 {
     int bad = -1;

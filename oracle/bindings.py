@@ -146,6 +146,26 @@ class Oracle:
                                            C.c_bool(scale_bias_const), C.c_int(nthreads), C.c_bool(use_cg),
                                            C.c_bool(precondition_cg), C.c_int(max_cg_steps))
 
+    def optimizeA_naz_weighted(self, A, B, csr, weight, lam, lam_last=None, k=None, wsum=None, bias_BtX=None, bias_X=None,
+                               bias_X_glob=0.0, scale_lam=False, scale_bias_const=False, use_cg=False, precondition_cg=False,
+                               max_cg_steps=3, nthreads=1):
+        """optimizeA Case 4 with NA_as_zero and observation weights (common.c:3209-3302 + the NA_as_zero / weight branches of
+        factors_closed_form): weight in the entry order of ``csr``."""
+        m, lda = A.shape
+        n, ldb = B.shape
+        k = min(lda, ldb) if k is None else k
+        lam_last = lam if lam_last is None else lam_last
+        p, i, v = csr
+        weight = np.ascontiguousarray(weight, self.dtype)
+        wsum = None if wsum is None else np.ascontiguousarray(wsum, self.dtype)
+        bias_BtX = None if bias_BtX is None else np.ascontiguousarray(bias_BtX, self.dtype)
+        bias_X = None if bias_X is None else np.ascontiguousarray(bias_X, self.dtype)
+        self.lib.oracle_optimizeA_naz_weighted(_ptr(A), C.c_size_t(lda), _ptr(B), C.c_size_t(ldb), C.c_int(m), C.c_int(n), C.c_int(k),
+                                               _ptr(p), _ptr(i), _ptr(v), _ptr(weight), _ptr(wsum), _ptr(bias_BtX), _ptr(bias_X),
+                                               self._r(bias_X_glob), self._r(lam), self._r(lam_last), C.c_bool(scale_lam),
+                                               C.c_bool(scale_bias_const), C.c_bool(use_cg), C.c_bool(precondition_cg),
+                                               C.c_int(max_cg_steps), C.c_int(nthreads))
+
     def optimizeA_dense_full(self, A, B, Xfull, lam, lam_last=None, k=None, do_B=False,
                              scale_lam=False, nthreads=1):
         m, lda = A.shape
@@ -473,11 +493,15 @@ class Reference:
 
     def optimizeA(self, A, B, csr=None, Xfull=None, lam=1.0, lam_last=None, k=None, scale_lam=False,
                   scale_bias_const=False, do_B=False, nthreads=1, use_cg=True, precondition_cg=False,
-                  max_cg_steps=3, full_dense=False, weight=None, wsum=None):
+                  max_cg_steps=3, full_dense=False, weight=None, wsum=None, NA_as_zero=False, bias_BtX=None, bias_X=None,
+                  bias_X_glob=0.0):
         """Case 4 (csr given) or Case 1 (Xfull given, full_dense=True) of optimizeA.  weight (entry order of csr) / wsum: the
-        observation weights and the driver's lambda multipliers (wsumA)."""
+        observation weights and the driver's lambda multipliers (wsumA).  NA_as_zero (+ bias_BtX [k], bias_X [n], bias_X_glob):
+        sparse X whose absent entries are zeros -- Case 3 without weights, Case 4's weighted branches with them."""
         weight = None if weight is None else np.ascontiguousarray(weight, self.dtype)
         wsum = None if wsum is None else np.ascontiguousarray(wsum, self.dtype)
+        bias_BtX = None if bias_BtX is None else np.ascontiguousarray(bias_BtX, self.dtype)
+        bias_X = None if bias_X is None else np.ascontiguousarray(bias_X, self.dtype)
         m, lda = A.shape
         n, ldb = B.shape
         k = min(lda, ldb) if k is None else k
@@ -490,13 +514,13 @@ class Reference:
         self.lib.optimizeA(_ptr(A), C.c_int(lda), _ptr(B), C.c_int(ldb), C.c_int(m), C.c_int(n), C.c_int(k),
                            _ptr(p), _ptr(i), _ptr(v), _ptr(Xfull), C.c_int(ldX),
                            C.c_bool(full_dense), C.c_bool(False), C.c_bool(full_dense),
-                           _ptr(cnt_NA), _ptr(weight), C.c_bool(False),
+                           _ptr(cnt_NA), _ptr(weight), C.c_bool(NA_as_zero),
                            self._r(lam), self._r(lam_last), self._r(0.), self._r(0.),
                            C.c_bool(scale_lam), C.c_bool(scale_bias_const), _ptr(wsum),
                            C.c_bool(do_B), C.c_int(nthreads), C.c_bool(False),
                            C.c_bool(use_cg), C.c_bool(precondition_cg), C.c_int(max_cg_steps),
                            C.c_bool(False), C.c_int(100),
-                           None, None, None, self._r(0.), None, self._r(1.),
+                           None, _ptr(bias_BtX), _ptr(bias_X), self._r(bias_X_glob), None, self._r(1.),
                            C.c_bool(False), None, C.byref(filled), _ptr(buf), None)
 
     def optimizeA_collective(self, A, B, Cm, csr, U, lam, w_user=1.0, lam_last=None, k=None,

@@ -671,6 +671,146 @@ void oracle_optimizeA_naz(real_t *A, size_t lda, const real_t *B, size_t ldb, in
     free(BtB);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Missing-as-zero rows WITH observation weights (optimizeA Case 4 with NA_as_zero && weight, common.c:3209-3302; per row
+ * factors_closed_form :631-1095 with its NA_as_zero + weight branches): absent entries count as zeros of weight one, so every
+ * row's system is the shared  B^T B  plus the correction of its present entries,
+ *     M_i = B^T B + sum_j (w_j - 1) B_j B_j^T + diag(lam_i .. lam_i, lam_last_i)
+ *     rhs_i = sum_j [ w_j x_j - (w_j - 1) (bias_X_glob + bias_X[j]) ] B_j + bias_BtX
+ * (closed form :846-907; CG factors_explicit_cg_NA_as_zero_weighted :1293-1441, its k < n branch; PCG :1443-1613), with
+ * lam_i = lam x (sum of the row's weights + n - nnz_i) under scale_lam (the driver's wsumA / wsumB, collective.c:7991-8022, or
+ * the row's own sum, common.c:696-712).  Rows are solved when they have entries OR when bias_BtX is given (:3270-3271).
+ * bias_BtX [k]: minus the sum over all rows of B of (their bias + the mean) x the row; bias_X [n]: the opposing biases;
+ * bias_X_glob: the mean (driver: collective.c:8573-8600, :8756-8787, :8701-8706, :8872-8877). */
+static void naz_weighted_cg_row(real_t *a, int_t k, const real_t *B, size_t ldb, const real_t *Xa, const int_t *ixB, size_t nnz,
+                                const real_t *wt, const real_t *BtB, const real_t *bias_BtX, const real_t *bias_X, real_t bias_X_glob,
+                                real_t lam, real_t lam_last, int_t max_cg_steps, bool precond, real_t *buf)
+{
+    real_t *Ap = buf, *p = Ap + k, *r = p + k, *z = r + k, *PC = z + k;
+    if (precond) {                                                             /* :1486-1497 */
+        memset(PC, 0, (size_t)k * sizeof(real_t));
+        for (size_t ix = 0; ix < nnz; ix++) {
+            const real_t *b = B + (size_t)ixB[ix] * ldb;
+            const real_t w_this = wt[ix] - (real_t)1;
+            for (int_t i = 0; i < k; i++) PC[i] += w_this * b[i] * b[i];
+        }
+        for (int_t i = 0; i < k; i++) PC[i] += BtB[(size_t)i * k + i];
+        for (int_t i = 0; i < k; i++) PC[i] += lam;
+        if (lam != lam_last) PC[k - 1] += (lam_last - lam);
+        for (int_t i = 0; i < k; i++) PC[i] = (real_t)1 / PC[i];
+    }
+    symv_(k, (real_t)-1, BtB, k, a, r);                                        /* :1321-1324 */
+    for (size_t ix = 0; ix < nnz; ix++) {                                      /* :1325-1338 */
+        const real_t *b = B + (size_t)ixB[ix] * ldb;
+        const real_t coef = dot_(k, b, a);
+        axpy_(k, -(wt[ix] - (real_t)1.) * (coef + bias_X_glob + ((bias_X == NULL) ? (real_t)0 : bias_X[ixB[ix]])) + (wt[ix] * Xa[ix]), b, r);
+    }
+    if (bias_BtX != NULL) axpy_(k, (real_t)1, bias_BtX, r);                    /* :1368-1371 (multiplier_bias_BtX = 1) */
+    axpy_(k, -lam, a, r);
+    if (lam != lam_last) r[k - 1] -= (lam_last - lam) * a[k - 1];
+    real_t r_old;
+    if (precond) {
+        for (int_t i = 0; i < k; i++) z[i] = r[i] * PC[i];
+        r_old = dot_(k, z, r);
+        memcpy(p, z, (size_t)k * sizeof(real_t));
+    } else {
+        memcpy(p, r, (size_t)k * sizeof(real_t));
+        r_old = dot_(k, r, r);
+        if (r_old <= (real_t)1e-12) return;                                    /* :1384 */
+    }
+    for (int_t step = 0; step < max_cg_steps; step++) {
+        symv_(k, (real_t)1, BtB, k, p, Ap);                                    /* :1391-1394 */
+        for (size_t ix = 0; ix < nnz; ix++) {                                  /* :1395-1403 */
+            const real_t *b = B + (size_t)ixB[ix] * ldb;
+            const real_t coef = dot_(k, b, p);
+            axpy_(k, (wt[ix] - (real_t)1.) * coef, b, Ap);
+        }
+        axpy_(k, lam, p, Ap);
+        if (lam != lam_last) Ap[k - 1] += (lam_last - lam) * p[k - 1];
+        const real_t alpha = r_old / dot_(k, p, Ap);
+        axpy_(k, alpha, p, a);
+        axpy_(k, -alpha, Ap, r);
+        real_t r_new;
+        if (precond) {
+            for (int_t i = 0; i < k; i++) z[i] = r[i] * PC[i];
+            r_new = dot_(k, z, r);
+            const real_t ratio = r_new / r_old;
+            for (int_t i = 0; i < k; i++) p[i] = p[i] * ratio + z[i];
+        } else {
+            r_new = dot_(k, r, r);
+            if (r_new <= (real_t)1e-8) break;                                  /* :1432 */
+            const real_t ratio = r_new / r_old;
+            for (int_t i = 0; i < k; i++) p[i] = p[i] * ratio + r[i];
+        }
+        r_old = r_new;
+    }
+}
+
+void oracle_optimizeA_naz_weighted(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                                   const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *weight,
+                                   const real_t *wsum, const real_t *bias_BtX, const real_t *bias_X, real_t bias_X_glob,
+                                   real_t lam, real_t lam_last, bool scale_lam, bool scale_bias_const,
+                                   bool use_cg, bool precondition_cg, int_t max_cg_steps, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (g_nonneg) use_cg = false;                                              /* common.c:725 */
+    real_t *BtB = (real_t *)malloc((size_t)k * k * sizeof(real_t));
+    oracle_gram(B, ldb, n, k, BtB, nthreads);                                  /* :3233-3236, no diagonal: it is added per row below */
+    const real_t l1_base = g_l1;
+    #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
+    for (int_t ix = 0; ix < m; ix++) {
+        const size_t st = Xcsr_p[ix], nnz = Xcsr_p[(size_t)ix + 1] - st;
+        if (!(nnz > 0 || bias_BtX != NULL)) continue;                          /* :3270-3271: left as it is */
+        real_t *a = A + (size_t)ix * lda;
+        real_t lam_i = lam, lam_last_i = lam_last, l1_i = l1_base;
+        if (scale_lam) {                                                       /* :679-723 */
+            real_t ws = (wsum != NULL) ? wsum[ix] : (real_t)0;
+            if (ws <= 0) {
+                ws = 0;
+                for (size_t jx = 0; jx < nnz; jx++) ws += weight[st + jx];
+                ws += (real_t)(n - (int_t)nnz);
+            }
+            if (fabs_t(ws) < EPSILON_T && bias_BtX == NULL) { memset(a, 0, (size_t)k * sizeof(real_t)); continue; }
+            lam_i *= ws; l1_i *= ws;
+            if (!scale_bias_const) lam_last_i *= ws;
+        }
+        real_t *buf = (real_t *)malloc(((size_t)k * k + 6 * (size_t)k) * sizeof(real_t));
+        if (use_cg) {
+            naz_weighted_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, weight + st, BtB, bias_BtX, bias_X, bias_X_glob,
+                                lam_i, lam_last_i, max_cg_steps, precondition_cg, buf);
+        } else {                                                               /* :846-907, then :1060-1093 */
+            real_t *M = buf;
+            memset(a, 0, (size_t)k * sizeof(real_t));
+            memset(M, 0, (size_t)k * k * sizeof(real_t));
+            for (size_t jx = 0; jx < nnz; jx++) {
+                const real_t *b = B + (size_t)Xcsr_i[st + jx] * ldb;
+                const real_t w = weight[st + jx];
+                syr_upper_(k, w - (real_t)1., b, M, k);
+                axpy_(k, (w * Xcsr[st + jx]) - (w - (real_t)1.) * (bias_X_glob + ((bias_X == NULL) ? (real_t)0 : bias_X[Xcsr_i[st + jx]])), b, a);
+            }
+            for (int_t i = 0; i < k; i++)
+                for (int_t j = i; j < k; j++) M[(size_t)i * k + j] += BtB[(size_t)i * k + j];
+            for (int_t i = 0; i < k - 1; i++) M[(size_t)i * k + i] += lam_i;
+            M[(size_t)(k - 1) * k + (k - 1)] += lam_last_i;
+            if (bias_BtX != NULL) axpy_(k, (real_t)1, bias_BtX, a);
+            if (g_nonneg) {
+                for (int_t i = 0; i < k; i++) for (int_t j = 0; j < i; j++) M[(size_t)i * k + j] = M[(size_t)j * k + i];
+                if (l1_i != 0) for (int_t c = 0; c < k; c++) a[c] -= l1_i;
+                solve_nonneg_(k, M, k, a, g_max_cd);
+            } else if (l1_i != 0) {
+                for (int_t i = 0; i < k; i++) for (int_t j = 0; j < i; j++) M[(size_t)i * k + j] = M[(size_t)j * k + i];
+                solve_elasticnet_(k, M, k, a, l1_i, l1_i, g_max_cd);
+            } else {
+                const int bad = chol_upper_(k, M, k);
+                if (!bad) chol_solve_upper_(k, M, k, a);
+                else for (int_t c = 0; c < k; c++) a[c] = NAN;
+            }
+        }
+        free(buf);
+    }
+    free(BtB);
+}
+
 static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t ldb,
                                       const real_t *C,
                                       int_t m, int_t m_u, int_t n, int_t p,
@@ -1462,7 +1602,10 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     g_zero_rows_A = g_zero_rows_B = NULL; g_n_zero_rows_A = g_n_zero_rows_B = 0;
     /* missing-as-zero with side information: dense complete U / I, closed form, side information on exactly the rows / columns of X
      * (with fewer the reference's own build corrupts its heap, so nothing pins the m > m_u branch restated in collective_naz_chol) */
-    if (naz && ((Ai != NULL && Bi != NULL) || weight != NULL || g_scale_bias_const)) return 2;
+    if (naz && ((Ai != NULL && Bi != NULL) || g_scale_bias_const)) return 2;
+    /* missing-as-zero WITH weights: the model without side information, start values given (the reference's weighted bias start
+     * values under NA_as_zero index biasB by row inside its item sweep, common.c:4727-4731 -- nothing to restate) */
+    if (naz && weight != NULL && (U != NULL || II != NULL || init_biases)) return 2;
     /* (use_cg changes nothing there: the factorised block matrix is taken before the solver is looked at, collective.c:1364-1460) */
     if (naz && (U != NULL || II != NULL) && (g_nn_AB || g_l1_base != 0 || g_has_l16 || (U != NULL && m_u != m) || (II != NULL && n_i != n))) return 2;
     if (U == NULL) { m_u = 0; p = 0; }
@@ -1502,7 +1645,25 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     memcpy(Xc, X, nnz * sizeof(real_t));
     if (naz) {                                                                 /* common.c:3494-3523, :3600-3607: X stays as it is */
         *glob_mean = 0;
-        if (center) {
+        if (center && weight != NULL) {                                        /* common.c:3558-3596 */
+            double xsum = 0, wsum = DBL_EPSILON;
+            if (nthreads >= 8) {
+                wsum = 0;
+                for (size_t ix = 0; ix < nnz; ix++) { xsum += Xc[ix]; wsum += weight[ix]; }
+                *glob_mean = (real_t)(xsum / wsum);
+            } else {
+                for (size_t ix = 0; ix < nnz; ix++) xsum += ((Xc[ix] - xsum) * weight[ix]) / (wsum += weight[ix]);
+                *glob_mean = (real_t)xsum;
+            }
+            double err = 0, res = 0;                                           /* compensated_sum, helpers.c:1691-1707 */
+            for (size_t ix = 0; ix < nnz; ix++) { const double diff = (double)weight[ix] - err, temp = res + diff; err = (temp - res) - diff; res = temp; }
+            const long double wsum_l = (long double)res;
+            /* (the mean is DIVIDED by the weights' share of all cells, as the reference does, :3590-3594) */
+            *glob_mean = (real_t)((long double)(*glob_mean) / (wsum_l / (wsum_l + ((long double)m * (long double)n - (long double)nnz))));
+            if (g_nn_AB) *glob_mean = (*glob_mean > 0) ? *glob_mean : (real_t)0;
+            if (fabs_t(*glob_mean) < sqrt_t(EPSILON_T)) *glob_mean = 0;
+        }
+        else if (center) {
             double xsum = 0;
             if (nthreads >= 8) { for (size_t ix = 0; ix < nnz; ix++) xsum += Xc[ix]; *glob_mean = (real_t)(xsum / (double)nnz); }
             else { size_t cnt = 0; for (size_t ix = 0; ix < nnz; ix++) xsum += (Xc[ix] - xsum) / (double)(++cnt); *glob_mean = (real_t)xsum; }
@@ -1534,12 +1695,14 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
             for (int_t r = 0; r < m; r++) {
                 double ws = 0;
                 for (size_t ix = csr_p[r]; ix < csr_p[(size_t)r + 1]; ix++) ws += weightR[ix];
-                wsumA[r] = (csr_p[(size_t)r + 1] > csr_p[r]) ? (real_t)ws : (real_t)1;
+                wsumA[r] = (naz || csr_p[(size_t)r + 1] > csr_p[r]) ? (real_t)ws : (real_t)1;
+                if (naz) wsumA[r] += (real_t)(n - (int_t)(csr_p[(size_t)r + 1] - csr_p[r]));      /* collective.c:8014-8022 */
             }
             for (int_t c = 0; c < n; c++) {
                 double ws = 0;
                 for (size_t ix = csc_p[c]; ix < csc_p[(size_t)c + 1]; ix++) ws += weightC[ix];
-                wsumB[c] = (csc_p[(size_t)c + 1] > csc_p[c]) ? (real_t)ws : (real_t)1;
+                wsumB[c] = (naz || csc_p[(size_t)c + 1] > csc_p[c]) ? (real_t)ws : (real_t)1;
+                if (naz) wsumB[c] += (real_t)(m - (int_t)(csc_p[(size_t)c + 1] - csc_p[c]));
             }
         }
     }
@@ -1660,8 +1823,14 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                 for (int_t r = 0; r < m; r++)
                     axpy_(ks, -((user_bias ? biasA[r] : (real_t)0) + (center ? *glob_mean : (real_t)0)), A_bias + k_user + (size_t)r * ldA, btx);
             }
+            if (weight != NULL)                                                /* optimizeA Case 4, NA_as_zero + weights (:8680-8717) */
+                oracle_optimizeA_naz_weighted(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m, ks, csc_p, csc_i, csc_v, weightC, wsumB, btx,
+                                              (btx != NULL && user_bias) ? biasA : NULL, *glob_mean, lamB, lamBl, scale_lam, sbc,
+                                              use_cg, precondition_cg, max_cg_steps, nthreads);
+            else {
             oracle_set_naz_bias_BtX(btx);
             oracle_optimizeA_naz(B_bias + k_item, ldB, A_bias + k_user, ldA, n, m, ks, csc_p, csc_i, csc_v, lamB, lamBl, scale_lam, nthreads);
+            }
             free(btx);
         }
         else {                                                                 /* :8680-8717 */
@@ -1719,8 +1888,14 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                 for (int_t c = 0; c < n; c++)
                     axpy_(ks, -((item_bias ? biasB[c] : (real_t)0) + (center ? *glob_mean : (real_t)0)), B_bias + k_item + (size_t)c * ldB, btx);
             }
+            if (weight != NULL)                                                /* :8847-8876 */
+                oracle_optimizeA_naz_weighted(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n, ks, csr_p, csr_i, csr_v, weightR, wsumA, btx,
+                                              (btx != NULL && item_bias) ? biasB : NULL, *glob_mean, lamA, lamAl, scale_lam, sbc,
+                                              use_cg, precondition_cg, max_cg_steps, nthreads);
+            else {
             oracle_set_naz_bias_BtX(btx);
             oracle_optimizeA_naz(A_bias + k_user, ldA, B_bias + k_item, ldB, m, n, ks, csr_p, csr_i, csr_v, lamA, lamAl, scale_lam, nthreads);
+            }
             free(btx);
         }
         else {                                                                 /* :8847-8876 */

@@ -86,6 +86,11 @@ void oracle_set_naz_bias_BtX(const real_t *bias_BtX);
  * weightR / weightC, wsumA / wsumB, weighted bias start values (common.c:4672-4692, :4826-4847), weighted row solvers.  Model
  * without side information only (returns 2 otherwise).  Cleared by the call. */
 void oracle_set_fit_weights(const real_t *weight);
+void oracle_optimizeA_naz_weighted(real_t *A, size_t lda, const real_t *B, size_t ldb, int_t m, int_t n, int_t k,
+                                   const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *weight,
+                                   const real_t *wsum, const real_t *bias_BtX, const real_t *bias_X, real_t bias_X_glob,
+                                   real_t lam, real_t lam_last, bool scale_lam, bool scale_bias_const,
+                                   bool use_cg, bool precondition_cg, int_t max_cg_steps, int nthreads);
 real_t oracle_calc_mean_and_center_weighted(real_t *X, const real_t *weight, size_t nnz, int nthreads);
 void oracle_initialize_biases_twosided_weighted(int_t m, int_t n,
                                                 const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *weightR,

@@ -171,17 +171,17 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, k, monkeypatch
 @pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("k", [50, 8, 64])
 def test_two_rows_per_wave(oracles, dtype, implicit, k):
-    """Rows of at most 16 entries are solved two per wavefront (cg_rows_tiny2_kernel): every length 0 .. 16 several times, an
-    odd number of such rows (the last wavefront holds one), rows that take the first exit (warm start = zero in the implicit
-    model with unit counts does not; a row whose start already solves its system does), next to rows of 17 .. 40 entries on
-    the one-row kernels."""
+    """Rows of at most 32 entries are solved two per wavefront (cg_rows_pair_kernel, cg_pair_kernels.hpp): every length 0 .. 32
+    several times -- pairs of two short rows (16-slot tiles), of two longer ones, and mixed pairs at the boundary -- an odd number
+    of such rows (the last wavefront holds one), rows that take the first exit (warm start = zero in the implicit model with unit
+    counts does not; a row whose start already solves its system does), next to rows of 33 .. 60 entries on the one-row kernels."""
     from cmfrec_amd import ops
     O = oracles[dtype]
-    m, n = 91, 600
+    m, n = 140, 600
     rng = np.random.default_rng(k + 3)
     rows, cols = [], []
     for r in range(m):
-        cnt = r % 17 if r < 85 else 17 + 4 * (r - 85)
+        cnt = r % 33 if r < 133 else 33 + 4 * (r - 133)
         rows.append(np.full(cnt, r, np.int32)); cols.append(rng.choice(n, cnt, replace=False).astype(np.int32))
     row, col = np.concatenate(rows), np.concatenate(cols)
     perm = rng.permutation(len(row)); row, col = row[perm], col[perm]
@@ -199,7 +199,7 @@ def test_two_rows_per_wave(oracles, dtype, implicit, k):
         csr_b = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
         O.optimizeA_explicit(Ao, B, csr_b, 0.05, lam_last=0.3, scale_lam=True, nthreads=4)
     assert rel_err(Ah, Ao) < TOL[dtype]
-    for r in (0, 17, 34):                                   # rows without entries are untouched
+    for r in (0, 33, 66):                                   # rows without entries are untouched
         assert np.array_equal(Ah[r], A0[r])
     # a second call starts from the first one's result: after enough calls rows converge and take the early exits
     Ah2, Ao2 = Ah.copy(), Ao.copy()

@@ -78,7 +78,8 @@ def test_c2_whole_fit_and_precision_at_10(c2):
     Ar = A0.copy(); Br = np.zeros((n, K))
     r = R.fit_collective_implicit_als(Ar, Br, row[tr], col[tr], val[tr], K, lam=5.0, alpha=1.0, niter=15, nthreads=NTHREADS,
                                       use_cg=True, max_cg_steps=3, finalize_chol=False, m=m, n=n)
-    assert r["ret"] == 0
+    assert r == 0                       # (plain model: the binding returns the code, the factors are updated in place)
+    r = dict(A=Ar, B=Br)
     mdl = CMF_implicit(k=K, lambda_=5.0, niter=15, use_float=False, use_cg=True, finalize_chol=False, precompute_for_predictions=False,
                        nthreads=NTHREADS).fit((row[tr], col[tr], val[tr]), shape=(m, n), A0=A0, B0=np.zeros((n, K)))
     eA, eB = _rel(mdl.A_, r["A"]), _rel(mdl.B_, r["B"])
