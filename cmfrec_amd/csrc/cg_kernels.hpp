@@ -34,6 +34,10 @@ constexpr int MAX_W = 8;          // max cooperating waves per row
 #ifndef CMF_CG_WAVES_PER_SIMD
 #define CMF_CG_WAVES_PER_SIMD 2   // register budget of the row kernels: 2 -> 256 VGPRs, 3 -> 168 (spills)
 #endif
+#ifndef CMF_CG_NT_MIN_S
+#define CMF_CG_NT_MIN_S 4         // tiles by row length (cg_rows_kernel, round 5) for k > 8 (S - 1): below, the tile products are a small
+                                  // part of a pass and the extra pass bodies only cost build time.  9 = the 64-entry tile everywhere
+#endif
 
 // One entry per row in processing order: replaces the order[] -> indptr[] pointer chase in the
 // persistent kernels (one 16-byte load gives the row id, its length and its CSR offset).
@@ -46,36 +50,35 @@ struct RowDesc {
 constexpr int CG_NCOUNTERS = 64;        // work counters per launch of a tiled CG kernel ...
 constexpr int CG_COUNTER_STRIDE = 32;    // ... each on its own 128-byte line
 
-// Reads of the staged Gramian.  CMF_LDS_B64 = 1: every 8-byte read stays a ds_read_b64 of its own (a volatile access is never
-// paired) -- on this part a ds_read_b64 occupies the LDS for 2 cycles per wavefront (64 banks, 256 B/clk) while the ds_read2_b64
-// the compiler pairs neighbouring reads into takes 8 (two accesses of 4 x 16 lanes, 128 B/clk): half the LDS time per element.
-#ifndef CMF_LDS_B64
-#define CMF_LDS_B64 0
-#endif
-// The two quotients of a CG step (alpha = r.r / p.Ap, beta = r'.r' / r.r).  Single precision: numerator x v_rcp_f32(denominator)
-// -- 1 ulp for the reciprocal, ~2 ulp (1.2e-7) for the quotient against the twelve-instruction IEEE sequence (v_div_scale x 2,
-// v_rcp, four FMAs, v_div_fmas, v_div_fixup), every lane computing the same wave-uniform number; 0 / 0 and x / 0 come out as in
-// the IEEE sequence (NaN, inf).  Double precision keeps the IEEE division.  -DCMF_CG_IEEE_DIV: IEEE in both.
+// The two quotients of a CG step (alpha = r.r / p.Ap, beta = r'.r' / r.r), every lane computing the same wave-uniform number.
+// Single precision: numerator x v_rcp_f32(denominator) -- 1 ulp for the reciprocal, ~2 ulp (1.2e-7) for the quotient against the
+// twelve-instruction IEEE sequence (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup); 0 / 0 and x / 0 come out as in
+// the IEEE sequence (NaN, inf).  Double precision (round 5): v_rcp_f64, two Newton steps, one correction of the quotient -- the
+// arithmetic core of the IEEE sequence without its scaling and fix-up instructions (eight issue slots instead of twelve beside the
+// quarter-rate reciprocal; the operands are sums of squares between 1e-12 and what a row's data allows, far from the exponent
+// range's ends), <= 1 ulp from the IEEE quotient.  -DCMF_CG_IEEE_DIV: IEEE in both.
 template <typename T>
 __device__ __forceinline__ T cg_div(T num, T den)
 {
 #ifndef CMF_CG_IEEE_DIV
     if constexpr (sizeof(T) == 4) return num * __builtin_amdgcn_rcpf(den);
-    else
+    else {
+        double y = __builtin_amdgcn_rcp(den);
+        double e = __builtin_fma(-den, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        e = __builtin_fma(-den, y, 1.0);
+        y = __builtin_fma(y, e, y);
+        double q = num * y;
+        const double r = __builtin_fma(-den, q, num);
+        return __builtin_fma(r, y, q);
+    }
+#else
+    return num / den;
 #endif
-        return num / den;
 }
 
 template <typename V>
-__device__ __forceinline__ V lds_g(const V *p)
-{
-#if CMF_LDS_B64
-    typedef const volatile __attribute__((address_space(3))) V *lds_cvp;   // explicit LDS pointer: a volatile generic access would be a flat_load
-    return *(lds_cvp)p;
-#else
-    return *p;
-#endif
-}
+__device__ __forceinline__ V lds_g(const V *p) { return *p; }
 
 template <typename T>
 struct CgParams {
@@ -173,15 +176,22 @@ __device__ __forceinline__ T wave_sum(T v) { return lanes::wave_sum(v); }
 
 // Transposed butterfly over the lane bits 0..2 (the 8 lanes of one non-zero group): 8 values per
 // lane in, the lane whose low bits are b ends with the 8-lane total of v[b].
-template <typename T>
+// NT < 8 (round 5, tiles of NT entries per lane group): only v[0 .. NT-1] exist (NT >= 4).  A first-stage pair whose upper
+// member v[i+4] does not exist is a plain sum into the lower half-group -- three instructions instead of the seven of a
+// transposing step in double precision; the lanes b >= NT end with undefined bits nobody reads (their entry is not valid:
+// pass_weight selects zero for it).
+template <typename T, int NT = 8>
 __device__ __forceinline__ T treduce8_low(const T (&v)[8], int lane)
 {
+    static_assert(NT >= 4 && NT <= 8, "entries per lane group");
     T u[4], q[2];
     bool h = (lane & 4) != 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        T keep = h ? v[i + 4] : v[i];
-        u[i] = keep + lanes::recv_xor4(v[i], v[i + 4]);
+        if (i + 4 < NT) {
+            T keep = h ? v[i + 4] : v[i];
+            u[i] = keep + lanes::recv_xor4(v[i], v[i + 4]);
+        } else u[i] = v[i] + lanes::xor4_lower(v[i]);      // (the lanes with bit 2 set stand for entry i + 4: none)
     }
     h = (lane & 2) != 0;
 #pragma unroll
@@ -211,30 +221,6 @@ __device__ __forceinline__ T treduce8_high(const T (&v)[8], int lane)
     return keep + lanes::recv_xor8(q[0], q[1]);
 }
 
-// The same reduction through LDS (experiment, -DCMF_TREDUCE_LDS=1; measured slower, profiles/r04/r04_zi_*): lane (jj, ll) stores its S column sums into the wavefront's own
-// [64][TR_LD] buffer at [column ll + 8 s][jj], lane f reads the eight partial sums of column f and adds them in the order jj = 0..7
-// -- S stores, the reads of eight consecutive elements and seven adds instead of seven adds behind fourteen cross-lane moves.  A
-// wavefront's LDS instructions execute in issue order, so no barrier is needed inside it.  Strides: 9 doubles / 12 floats keep both
-// the stores (lanes of a 16- / 32-lane group on distinct banks) and the reads free of bank conflicts.
-template <typename T> __host__ __device__ constexpr int tr_ld() { return sizeof(T) == 8 ? 9 : 12; }
-template <typename T, int S>
-__device__ __forceinline__ T treduce8_lds(const T (&v)[8], int lane, T *__restrict__ tb)
-{
-    constexpr int LD = tr_ld<T>();
-    const int jj = lane >> 3, ll = lane & 7;
-#pragma unroll
-    for (int s = 0; s < S; s++) tb[(ll + 8 * s) * LD + jj] = v[s];
-    __builtin_amdgcn_wave_barrier();
-    const T *rp = tb + lane * LD;
-    T tot = rp[0];
-#pragma unroll
-    for (int j = 1; j < 8; j++) tot += rp[j];
-    __builtin_amdgcn_wave_barrier();
-    return (lane < 8 * S) ? tot : T(0);
-}
-#ifndef CMF_TREDUCE_LDS
-#define CMF_TREDUCE_LDS 0
-#endif
 // The vector of a pass (lane f holds element f) through the wavefront's own 64-element LDS buffer: one store, then the lane's S
 // replicated elements ll + 8 s (what `replicate` fetches with 2 S ds_bpermute in double precision) and the eight Gramian weights
 // jj 8 + t (what bcast8 builds with sixteen DPP moves) are plain LDS reads of addresses shared by the lanes of a group (broadcast
@@ -246,53 +232,57 @@ __device__ __forceinline__ T treduce8_lds(const T (&v)[8], int lane, T *__restri
 #define CMF_PASS_VECTOR_LDS 2
 #endif
 template <typename T> constexpr bool pass_vector_in_lds() { return CMF_PASS_VECTOR_LDS == 1 || (CMF_PASS_VECTOR_LDS == 2 && sizeof(T) == 8); }
-// (CMF_PV_PARTS, experiment: bit 0 = the replicated elements, bit 1 = the Gramian weights through LDS; the other part cross-lane)
-#ifndef CMF_PV_PARTS
-#define CMF_PV_PARTS 3
-#endif
 template <typename T, int S>
 __device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane);
-template <typename T, int S>
+// GR: rows of the staged Gramian per lane group (gram_rows below) -- the group jj multiplies the rows GR jj + t, t < GR
+template <typename T, int S, int GR = 8>
 __device__ __forceinline__ void pass_vector_lds(T vdist, T (&vrep)[S], T (&wts)[8], int lane, T *__restrict__ pv)
 {
     const int jj = lane >> 3, ll = lane & 7;
     pv[lane] = vdist;
     __builtin_amdgcn_wave_barrier();
-    if constexpr ((CMF_PV_PARTS & 1) != 0) {
 #pragma unroll
-        for (int s = 0; s < S; s++) vrep[s] = pv[ll + 8 * s];
-    } else replicate<T, S>(vdist, vrep, lane);
-    if constexpr ((CMF_PV_PARTS & 2) != 0) {
-        const T *wp = pv + 8 * jj;
+    for (int s = 0; s < S; s++) vrep[s] = pv[ll + 8 * s];
+    const T *wp = pv + GR * jj;
 #pragma unroll
-        for (int t = 0; t < 8; t++) wts[t] = wp[t];
-    } else {
-        wts[0] = lanes::bcast8<0>(vdist); wts[1] = lanes::bcast8<1>(vdist); wts[2] = lanes::bcast8<2>(vdist); wts[3] = lanes::bcast8<3>(vdist);
-        wts[4] = lanes::bcast8<4>(vdist); wts[5] = lanes::bcast8<5>(vdist); wts[6] = lanes::bcast8<6>(vdist); wts[7] = lanes::bcast8<7>(vdist);
-    }
+    for (int t = 0; t < GR; t++) wts[t] = wp[t];
     __builtin_amdgcn_wave_barrier();
 }
 
 // LDS leading dimension for the staged Gramian: odd, so that the jj-groups of a lane group land on
 // distinct banks both for ds_read_b64 (32 lanes, 64 banks) and ds_read2_b64 (16 lanes, 32 banks).
 __host__ __device__ constexpr int gram_ld(int S) { return 8 * S + 1; }
+// Round 5 -- the Gramian's rows follow k like its columns: the k x k matrix needs ceil(k / 8) = S rows per lane group, not 8 (k = 50:
+// 56 padded rows instead of 64, 7 S instead of 8 S products per lane and pass).  Where the vector of a pass travels through LDS
+// (pass_vector_in_lds: double precision) the group's weights are plain reads at any offset, so those kernels take GR = S rows per
+// group; the cross-lane form (single precision: bcast8 moves inside an 8-lane group) keeps 8.  Leading dimension for GR = S: the
+// smallest LD >= 8 S with S LD = 8 or 24 (mod 32), which puts the four lane groups of a half-wavefront 16 banks apart.
+template <typename T> __host__ __device__ constexpr int gram_rows(int S) { return pass_vector_in_lds<T>() ? S : 8; }
+__host__ __device__ constexpr int gram_ld_rows(int S, int GR)
+{
+    if (GR == 8) return gram_ld(S);
+    int ld = 8 * S;
+    while ((S * ld) % 32 != 8 && (S * ld) % 32 != 24) ld++;
+    return ld;
+}
 // Single precision keeps the Gramian's rows 2q and 2q+1 interleaved -- element (r, c) at 2 ((r >> 1) LD2 + c) + (r & 1),
 // LD2 = 8 S + 2 -- so that one ds_read_b64 brings the register pair a v_pk_fma_f32 wants; 4 LD2 = 8 (mod 32) keeps the
 // four jj-groups of a half-wave on distinct banks.
 __host__ __device__ constexpr int gram_ld2(int S) { return 8 * S + 2; }
 template <typename T> __host__ __device__ constexpr int gram_elems(int S) { return sizeof(T) == 4 ? 64 * gram_ld2(S) : 64 * gram_ld(S); }
-template <typename T, int S> __device__ __forceinline__ int gram_index(int r, int c)
+template <typename T, int S, int GR = 8> __device__ __forceinline__ int gram_index(int r, int c)
 {
     if constexpr (sizeof(T) == 4) return 2 * ((r >> 1) * gram_ld2(S) + c) + (r & 1);
-    else return r * gram_ld(S) + c;
+    else return r * gram_ld_rows(S, GR) + c;
 }
-// stage the k x k Gramian (row-major, ld = k) of a launch in LDS, zero-padded to 64 x 8 S
-template <typename T, int S>
+// stage the k x k Gramian (row-major, ld = k) of a launch in LDS, zero-padded to 8 GR x 8 S
+template <typename T, int S, int GR = 8>
 __device__ __forceinline__ void stage_gramian(T *__restrict__ G, const T *__restrict__ BtB, int k, int tid, int nthreads)
 {
-    for (int e = tid; e < 64 * 8 * S; e += nthreads) {
+    static_assert(GR == 8 || sizeof(T) == 8, "rows by k: double precision");
+    for (int e = tid; e < 8 * GR * 8 * S; e += nthreads) {
         const int r = e / (8 * S), c = e % (8 * S);
-        G[gram_index<T, S>(r, c)] = (r < k && c < k) ? BtB[(size_t)r * k + c] : T(0);
+        G[gram_index<T, S, GR>(r, c)] = (r < k && c < k) ? BtB[(size_t)r * k + c] : T(0);
     }
 }
 
@@ -344,22 +334,27 @@ struct PassAcc<float> {
 // Branch-free (like load_tile4 below): slots past the end of the tile re-read the row of the tile's first entry (their
 // weight w_j is forced to zero by `valid`), factor columns past k re-read column k-1 (their vrep / Gramian entries are
 // zero and the result lanes >= k are cleared).  One v_mad_u64_u32 per gathered row forms its address.
-template <typename T, int S>
+// NT entries per lane group (round 5): the tile holds 8 NT entries, entry jj NT + t of the tile in the lane group jj; its index
+// (my_idx) and value sit in lane (jj, t).  NT = 8 is the 64-entry tile of rounds 1-4.
+template <typename T, int S, int NT = 8>
 __device__ __forceinline__ void load_tile(RegTile<T, S> &tile, const T *__restrict__ Bm, size_t ldb,
                                           int k, int my_idx, int cnt, int lane)
 {
     const int jj = lane >> 3, ll = lane & 7;
     int its[8];
     its[0] = lanes::bcast8<0>(my_idx); its[1] = lanes::bcast8<1>(my_idx); its[2] = lanes::bcast8<2>(my_idx);
-    its[3] = lanes::bcast8<3>(my_idx); its[4] = lanes::bcast8<4>(my_idx); its[5] = lanes::bcast8<5>(my_idx);
-    its[6] = lanes::bcast8<6>(my_idx); its[7] = lanes::bcast8<7>(my_idx);
+    its[3] = lanes::bcast8<3>(my_idx);
+    if (NT > 4) its[4] = lanes::bcast8<4>(my_idx);
+    if (NT > 5) its[5] = lanes::bcast8<5>(my_idx);
+    if (NT > 6) its[6] = lanes::bcast8<6>(my_idx);
+    if (NT > 7) its[7] = lanes::bcast8<7>(my_idx);
     const int first_idx = __builtin_amdgcn_readfirstlane(my_idx);
     const int col_last = min(ll + 8 * (S - 1), k - 1) - ll;
     const char *base = reinterpret_cast<const char *>(Bm + ll);
     const unsigned ldb_bytes = (unsigned)(ldb * sizeof(T));
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const unsigned it = (unsigned)(((jj * 8 + t) < cnt) ? its[t] : first_idx);
+    for (int t = 0; t < NT; t++) {
+        const unsigned it = (unsigned)(((jj * NT + t) < cnt) ? its[t] : first_idx);
         const T *rp = reinterpret_cast<const T *>(base + (unsigned long long)it * ldb_bytes);
 #pragma unroll
         for (int s = 0; s < S; s++) tile.set(t, s, rp[(s < S - 1) ? 8 * s : col_last]);
@@ -397,87 +392,63 @@ __device__ __forceinline__ T entry_weight(const CgParams<T> &P, size_t pos)
     return (P.weights != nullptr) ? P.weights[pos] : T(1);
 }
 
-template <int S, bool IMPLICIT, int MODE>
+template <int S, bool IMPLICIT, int MODE, int NT = 8>
 __device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, const float (&vrep)[S], float x, bool valid,
                                           PassAcc<float> &out, int lane, float g = 1.f)
 {
+    static_assert(NT % 2 == 0, "single precision: the entries of a lane group travel in pairs");
     float c[8];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NT / 2; q++) {
         f32x2 acc = f32x2{0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < S; s++) acc += tile.v[q][s] * f32x2{vrep[s], vrep[s]};
         c[2 * q] = acc[0]; c[2 * q + 1] = acc[1];
     }
-    float coef = treduce8_low<float>(c, lane);
+    float coef = treduce8_low<float, NT>(c, lane);
     const float w = pass_weight<float, IMPLICIT, MODE>(coef, x, valid, g);
     float wts[8];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
-    wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
+    if (NT > 4) { wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); }
+    if (NT > 6) { wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w); }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < NT / 2; q++) {
         const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
 #pragma unroll
         for (int s = 0; s < S; s++) out.v[s] += w2 * tile.v[q][s];
     }
 }
 
-template <typename T, int S, bool IMPLICIT, int MODE>
+template <typename T, int S, bool IMPLICIT, int MODE, int NT = 8>
 __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid,
                                           PassAcc<T> &out, int lane, T g = T(1))
 {
     if constexpr (std::is_same<T, float>::value) {
-        tile_pass_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane, g);
+        tile_pass_f32<S, IMPLICIT, MODE, NT>(tile, vrep, x, valid, out, lane, g);
     } else {
     T c[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < NT; t++) {
         T acc = T(0);
 #pragma unroll
         for (int s = 0; s < S; s++) acc += tile.v[t][s] * vrep[s];
         c[t] = acc;
     }
-    T coef = treduce8_low<T>(c, lane);           // lane j now holds B_j . v
+    T coef = treduce8_low<T, NT>(c, lane);       // lane (jj, t) now holds B_j . v of its entry
     const T w = pass_weight<T, IMPLICIT, MODE>(coef, x, valid, g);
     T wts[8];
     wts[0] = lanes::bcast8<0>(w); wts[1] = lanes::bcast8<1>(w); wts[2] = lanes::bcast8<2>(w); wts[3] = lanes::bcast8<3>(w);
-    wts[4] = lanes::bcast8<4>(w); wts[5] = lanes::bcast8<5>(w); wts[6] = lanes::bcast8<6>(w); wts[7] = lanes::bcast8<7>(w);
+    if (NT > 4) wts[4] = lanes::bcast8<4>(w);
+    if (NT > 5) wts[5] = lanes::bcast8<5>(w);
+    if (NT > 6) wts[6] = lanes::bcast8<6>(w);
+    if (NT > 7) wts[7] = lanes::bcast8<7>(w);
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-#pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
-    }
-    }
-}
-
-// The two halves of tile_pass for the variant that sends the entry weights through LDS (double precision, -DCMF_TILE_W_LDS=1):
-// tile_weight: c_j = B_j . vrep, w_j = f(c_j, x_j) in the entry's lane; tile_accum: out[s] += sum_t wts[t] B_j[s].
-template <typename T, int S, bool IMPLICIT, int MODE>
-__device__ __forceinline__ T tile_weight(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid, int lane, T g = T(1))
-{
-    T c[8];
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        T acc = T(0);
-#pragma unroll
-        for (int s = 0; s < S; s++) acc += tile.v[t][s] * vrep[s];
-        c[t] = acc;
-    }
-    const T coef = treduce8_low<T>(c, lane);
-    return pass_weight<T, IMPLICIT, MODE>(coef, x, valid, g);
-}
-template <typename T, int S>
-__device__ __forceinline__ void tile_accum(const RegTile<T, S> &tile, const T (&wts)[8], PassAcc<T> &out)
-{
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < NT; t++) {
 #pragma unroll
         for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
     }
+    }
 }
-#ifndef CMF_TILE_W_LDS
-#define CMF_TILE_W_LDS 0
-#endif
 
 // out[s] += sum_j wdist_j * G[j][ll+8s]  with the Gramian staged in LDS (rows padded to 64).
 // The 8 row-slices t are dealt to the W waves of the team (wave wr takes t = wr, wr+W, ...).
@@ -514,10 +485,10 @@ __device__ __forceinline__ void gram_pass(const T *__restrict__ G, T wdist, Pass
 }
 
 // the same with the eight weights already in registers (level 2 of the LDS experiment); NEG: out -= ...
-template <bool NEG, typename T, int S, int W>
+template <bool NEG, typename T, int S, int W, int GR = 8>
 __device__ __forceinline__ void gram_pass_w(const T *__restrict__ G, const T (&wts)[8], PassAcc<T> &out, int lane, int wr)
 {
-    constexpr int LD = gram_ld(S);
+    constexpr int LD = gram_ld_rows(S, GR);
     const int jj = lane >> 3, ll = lane & 7;
     if constexpr (std::is_same<T, float>::value && W <= 4) {
 #pragma unroll
@@ -530,7 +501,7 @@ __device__ __forceinline__ void gram_pass_w(const T *__restrict__ G, const T (&w
         }
     } else {
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
+        for (int t = 0; t < GR; t++) {
             if (W > 1 && (t % W) != wr) continue;
 #pragma unroll
             for (int s = 0; s < S; s++) {
@@ -538,7 +509,7 @@ __device__ __forceinline__ void gram_pass_w(const T *__restrict__ G, const T (&w
                     const float g = G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
                     out.v[s][0] = NEG ? out.v[s][0] - wts[t] * g : out.v[s][0] + wts[t] * g;
                 } else {
-                    const T g = lds_g(G + (jj * 8 + t) * LD + ll + 8 * s);
+                    const T g = lds_g(G + (jj * GR + t) * LD + ll + 8 * s);
                     out.v[s] = NEG ? out.v[s] - wts[t] * g : out.v[s] + wts[t] * g;
                 }
             }
@@ -590,15 +561,8 @@ cg_rows_kernel(const CgParams<T> P)
     // C2's users -- so a launch has CG_NCOUNTERS counters on separate cache lines; counter j hands out the positions
     // nteams + j + CG_NCOUNTERS * c, and a team uses the counter of its index modulo CG_NCOUNTERS.)
     __shared__ int s_claim[4];
-#if CMF_TREDUCE_LDS
-    __shared__ __attribute__((aligned(16))) T s_tr[W * RPB][64 * tr_ld<T>()];
-#endif
     constexpr bool PV = pass_vector_in_lds<T>();
     __shared__ __attribute__((aligned(16))) T s_pv[PV ? W * RPB : 1][PV ? 64 : 1];
-    // entry weights of a tile through LDS too (double precision): one store in the entry's lane, eight broadcast reads instead of
-    // sixteen DPP moves; the Gramian product of the pass is issued between the store and the reads
-    constexpr bool PW = PV && (CMF_TILE_W_LDS != 0) && sizeof(T) == 8;
-    __shared__ __attribute__((aligned(16))) T s_pw[PW ? W * RPB : 1][PW ? 64 : 1];
     const int cslot = (blockIdx.x * RPB + grp) % CG_NCOUNTERS;
     int *const my_counter = P.counter + cslot * CG_COUNTER_STRIDE;
     const int cbase = nteams + cslot;
@@ -616,7 +580,8 @@ cg_rows_kernel(const CgParams<T> P)
         s_claim[2] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
         s_claim[3] = cbase + CG_NCOUNTERS * atomicAdd(my_counter, 1);
     }
-    if (GRAM) stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
+    constexpr int GR = gram_rows<T>(S);
+    if (GRAM) stage_gramian<T, S, GR>(G, P.BtB, k, tid, blockDim.x);
     if (GRAM || W > 1) __syncthreads();
     if (W > 1) { rnxt = s_claim[2]; rnn = s_claim[3]; }
     T *myred = red + (size_t)grp * 2 * W * 64;
@@ -632,6 +597,19 @@ cg_rows_kernel(const CgParams<T> P)
     // the bins that already were resident).  The register budget goes from three to two wavefronts per SIMD.
     constexpr int NRES = NRES_ > 0 ? NRES_ : ((std::is_same<T, float>::value && W == 8) ? 2 : 1);
     static_assert(NRES == 1 || std::is_same<T, float>::value, "two resident tiles: single precision");
+    // Round 5 -- the tile follows the row: a resident row of nnz entries runs on tiles of 8 NT entries, NT = entries per lane
+    // group = ceil(nnz / (8 W NRES)) in [NT_MIN, 8] (single precision: even, the entries of a lane travel in pairs), instead of
+    // always 8.  A launch holds rows of (W NRES 32, W NRES 64] entries, so with the 64-entry tile a third of all tile slots were
+    // padding (C2: 24.4 M slots for 16.9 M entries; with NT by row 18.7 M) -- padding that costs the full 2 S FMAs per slot and
+    // pass, its share of the reduction over the column lanes, a weight broadcast and S gather instructions.  NT is a function of
+    // the row's length alone, so a row's arithmetic (and its bits) do not depend on the launch, the shard or the neighbours.
+    // Rows that are not resident (more than W NRES 64 entries: launches outside the length bins) keep the 64-entry tile.
+    constexpr int NT_MIN = (S >= CMF_CG_NT_MIN_S) ? (std::is_same<T, float>::value ? 6 : 5) : 8;
+    auto nt_of = [&](int nnz_) -> int {
+        int nt = (nnz_ + 8 * W * NRES - 1) / (8 * W * NRES);
+        if (std::is_same<T, float>::value) nt = (nt + 1) & ~1;
+        return (nt > 8) ? 8 : (nt < NT_MIN ? NT_MIN : nt);
+    };
     struct Pre { int idx; T x; T a; int idx2; T x2; T g; T g2; };
     auto load_desc = [&](int rix_) -> RowDesc {
         RowDesc d; d.row = 0; d.nnz = 0; d.st = 0;
@@ -642,20 +620,24 @@ cg_rows_kernel(const CgParams<T> P)
                (unsigned)__builtin_amdgcn_readfirstlane((int)(d.st & 0xffffffffu));
         return d;
     };
+    // the lane (jj, b) carries entry jj NT + b of its wavefront's tile (b < NT); NT = 8: entry = lane
     auto load_pre = [&](const RowDesc &d) -> Pre {
         Pre q; q.idx = 0; q.x = T(0); q.a = T(0); q.idx2 = 0; q.x2 = T(0); q.g = T(1); q.g2 = T(1);
-        const int cnt = min(TILE, d.nnz - wr * TILE);
-        if (lane < cnt) {
-            const size_t pos = d.st + (size_t)wr * TILE + lane;
+        const int nt = nt_of(d.nnz), tl = 8 * nt;
+        const int b = lane & 7;
+        const int ent = (lane >> 3) * nt + b;
+        const int cnt = min(tl, d.nnz - wr * tl);
+        if (b < nt && ent < cnt) {
+            const size_t pos = d.st + (size_t)wr * tl + ent;
             q.idx = P.indices[pos];
             q.x = P.values[pos];
             q.g = entry_weight<T, IMPLICIT>(P, pos);
             if (!IMPLICIT && P.bias_sub != nullptr) q.x -= P.bias_sub[q.idx];
         }
         if (NRES == 2) {
-            const int cnt2 = min(TILE, d.nnz - (wr + W) * TILE);
-            if (lane < cnt2) {
-                const size_t pos = d.st + (size_t)(wr + W) * TILE + lane;
+            const int cnt2 = min(tl, d.nnz - (wr + W) * tl);
+            if (b < nt && ent < cnt2) {
+                const size_t pos = d.st + (size_t)(wr + W) * tl + ent;
                 q.idx2 = P.indices[pos];
                 q.x2 = P.values[pos];
                 q.g2 = entry_weight<T, IMPLICIT>(P, pos);
@@ -674,13 +656,19 @@ cg_rows_kernel(const CgParams<T> P)
     unsigned long long tk_wait = 0, tk_pass = 0, tk_rows = 0;
     const unsigned long long tk_begin = CMF_TICK();
 #endif
-    for (int it = 0; rix < P.nrows; it++) {
+    int it = 0;
+    RowDesc dnn;
+    Pre pnxt;
+    // one row on tiles of 8 NT entries
+    auto solve_row = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        constexpr int TL = 8 * NT;
         const int row = dcur.row;
         const size_t st = dcur.st;
         const int nnz = dcur.nnz;
-        const int ntiles = (nnz + TILE - 1) / TILE;
+        const int ntiles = (nnz + TL - 1) / TL;
         const int my_ntiles = (ntiles > wr) ? (ntiles - wr + W - 1) / W : 0;
-        const bool resident = my_ntiles <= NRES;
+        const bool resident = NT < 8 || my_ntiles <= NRES;      // (a tile of fewer than 64 entries is only chosen for a row that fits)
 
         T lam = P.lam, lam_last = P.lam_last;
         if (GRAMX && P.kc > 0) {                              // rows of the block system: collective.c:1285-1355
@@ -699,21 +687,23 @@ cg_rows_kernel(const CgParams<T> P)
 
         // first tile of this wave: gather now (critical path), then start the next row's loads
         RegTile<T, S> tile;
-        const int cnt0 = min(TILE, nnz - wr * TILE);
+        const int ent = (lane >> 3) * NT + (lane & 7);     // this lane's entry of the tile (lanes with (lane & 7) >= NT: none)
+        const bool lane_has = (NT == 8) || (lane & 7) < NT;
+        const int cnt0 = min(TL, nnz - wr * TL);
         T x_res = pcur.x;
         const T g_res = pcur.g;
-        bool valid_res = lane < cnt0;
+        bool valid_res = lane_has && ent < cnt0;
         if (CMF_DBG(P, 1)) dbg_fill_tile<8, S>(tile, (T)(pcur.idx & 3) * (T)0.001);
-        else if (cnt0 > 0) load_tile<T, S>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
-        RegTile<T, (NRES == 2) ? S : 1> tile2;       // second resident tile (entries (wr + W) * 64 ...)
-        const int cnt1 = (NRES == 2) ? min(TILE, nnz - (wr + W) * TILE) : 0;
+        else if (cnt0 > 0) load_tile<T, S, NT>(tile, P.B, P.ldb, k, pcur.idx, cnt0, lane);
+        RegTile<T, (NRES == 2) ? S : 1> tile2;       // second resident tile (entries (wr + W) * TL ...)
+        const int cnt1 = (NRES == 2) ? min(TL, nnz - (wr + W) * TL) : 0;
         const T x2_res = pcur.x2, g2_res = pcur.g2;
-        const bool valid2_res = lane < cnt1;
+        const bool valid2_res = lane_has && ent < cnt1;
         if constexpr (NRES == 2) {
-            if (cnt1 > 0 && !CMF_DBG(P, 1)) load_tile<T, S>(tile2, P.B, P.ldb, k, pcur.idx2, cnt1, lane);
+            if (cnt1 > 0 && !CMF_DBG(P, 1)) load_tile<T, S, NT>(tile2, P.B, P.ldb, k, pcur.idx2, cnt1, lane);
         }
-        const RowDesc dnn = load_desc(rnn);
-        const Pre pnxt = load_pre(dnxt);
+        dnn = load_desc(rnn);
+        pnxt = load_pre(dnxt);
 #ifdef CMF_CG_TICKS
         const unsigned long long tk0 = CMF_TICK();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -728,57 +718,43 @@ cg_rows_kernel(const CgParams<T> P)
             asm volatile("" ::: "memory");
             T vrep[S];
             T gw[8];
-            if constexpr (PV) pass_vector_lds<T, S>(vdist, vrep, gw, lane, &s_pv[wave][0]);
+            if constexpr (PV) pass_vector_lds<T, S, GR>(vdist, vrep, gw, lane, &s_pv[wave][0]);
             else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
             if constexpr (NRES == 2) {
                 // both tiles of the wave are resident: the launch holds rows of at most 2 * W * 64 = 1024 entries (the host
                 // keeps the split-row boundary at or below that in single precision)
-                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x_res, valid_res, acc, lane, g_res);
-                if (cnt1 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile2, vrep, x2_res, valid2_res, acc, lane, g2_res);
+                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x_res, valid_res, acc, lane, g_res);
+                if (cnt1 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile2, vrep, x2_res, valid2_res, acc, lane, g2_res);
+            } else if constexpr (NT < 8) {
+                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x_res, valid_res, acc, lane, g_res);
             } else
             for (int tl = wr; tl < ntiles; tl += W) {
                 T x, g; bool valid;
                 const bool have = (tl == wr) && (resident || first);   // still in registers
                 if (!have) {
-                    const int cnt = min(TILE, nnz - tl * TILE);
-                    valid = lane < cnt;
-                    const size_t pos = st + (size_t)tl * TILE + lane;
+                    // (rows beyond the team's registers: NT = 8 by construction, entry = lane)
+                    const int cnt = min(TL, nnz - tl * TL);
+                    valid = lane_has && ent < cnt;
+                    const size_t pos = st + (size_t)tl * TL + ent;
                     int my_idx = valid ? P.indices[pos] : 0;
                     x = valid ? P.values[pos] : T(0);
                     g = valid ? entry_weight<T, IMPLICIT>(P, pos) : T(1);
                     if (!IMPLICIT && P.bias_sub != nullptr && valid) x -= P.bias_sub[my_idx];
-                    if (!CMF_DBG(P, 1)) load_tile<T, S>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
+                    if (!CMF_DBG(P, 1)) load_tile<T, S, NT>(tile, P.B, P.ldb, k, my_idx, cnt, lane);
                 } else {
                     x = x_res; g = g_res; valid = valid_res;
                 }
-                if constexpr (PW) {
-                    if (!CMF_DBG(P, 4)) {
-                        T *wb = &s_pw[wave][0];
-                        wb[lane] = tile_weight<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, lane, g);
-                        if (GRAM && tl == wr && !CMF_DBG(P, 2)) gram_pass_w<MODE == 0, T, S, W>(G, gw, acc, lane, wr);
-                        T wts[8];
-                        const T *wp = wb + 8 * (lane >> 3);
-#pragma unroll
-                        for (int t = 0; t < 8; t++) wts[t] = wp[t];
-                        tile_accum<T, S>(tile, wts, acc);
-                    }
-                } else {
-                    if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE>(tile, vrep, x, valid, acc, lane, g);
-                }
+                if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x, valid, acc, lane, g);
             }
-            if (GRAM && !CMF_DBG(P, 2) && !(PW && wr < ntiles && !CMF_DBG(P, 4))) {   // common.c:1932 / :1958; collective.c:2609-2643
-                if constexpr (PV) gram_pass_w<MODE == 0, T, S, W>(G, gw, acc, lane, wr);
+            if (GRAM && !CMF_DBG(P, 2)) {   // common.c:1932 / :1958; collective.c:2609-2643
+                if constexpr (PV) gram_pass_w<MODE == 0, T, S, W, GR>(G, gw, acc, lane, wr);
                 else gram_pass<T, S, W>(G, (MODE == 0) ? -vdist : vdist, acc, lane, wr);
             }
             T out[8];
             acc.close(out);
-#if CMF_TREDUCE_LDS
-            T tot = treduce8_lds<T, S>(out, lane, &s_tr[wave][0]);
-#else
             T tot = treduce8_high<T>(out, lane);                              // lane f <- element f
-#endif
             if (W > 1) {
                 T *rb = myred + (size_t)buf * W * 64;
                 rb[wr * 64 + lane] = tot;
@@ -822,6 +798,21 @@ cg_rows_kernel(const CgParams<T> P)
 #ifdef CMF_CG_TICKS
         tk_pass += CMF_TICK() - tk1; tk_rows += (wr == 0);
 #endif
+    };
+    for (; rix < P.nrows; it++) {
+        const int nt = nt_of(dcur.nnz);      // uniform over the team
+        if constexpr (NT_MIN == 8) solve_row(std::integral_constant<int, 8>{});
+        else if constexpr (std::is_same<T, float>::value) {
+            if (nt == 6) solve_row(std::integral_constant<int, 6>{});
+            else solve_row(std::integral_constant<int, 8>{});
+        } else {
+            switch (nt) {
+                case 5: solve_row(std::integral_constant<int, 5>{}); break;
+                case 6: solve_row(std::integral_constant<int, 6>{}); break;
+                case 7: solve_row(std::integral_constant<int, 7>{}); break;
+                default: solve_row(std::integral_constant<int, 8>{}); break;
+            }
+        }
         const int r3 = (W == 1) ? cbase + CG_NCOUNTERS * __builtin_amdgcn_readfirstlane(pend) : s_claim[it & 1];
         dcur = dnxt; dnxt = dnn; pcur = pnxt;
         rix = rnxt; rnxt = rnn; rnn = r3;
@@ -1047,21 +1038,21 @@ template <typename T, int S> struct TinyTile<T, S, 2> { using type = RegTile2<T,
 #endif
 template <typename T, bool GRAM> constexpr bool tiny_greg() { return GRAM && (sizeof(T) == 8 ? CMF_TINY_GREG_F64 != 0 : CMF_TINY_GREG_F32 != 0); }
 template <typename T, bool GRAM> constexpr int tiny_waves_per_simd() { return tiny_greg<T, GRAM>() ? (sizeof(T) == 8 ? 2 : 3) : CMF_TINY_WAVES_PER_SIMD; }
-template <typename T, int S>
+template <typename T, int S, int GR = 8>
 struct GramRegs {
-    T v[8][S];
+    T v[GR][S];
     __device__ __forceinline__ void load(const T *__restrict__ G, int lane)
     {
         const int jj = lane >> 3, ll = lane & 7;
 #pragma unroll
-        for (int t = 0; t < 8; t++)
+        for (int t = 0; t < GR; t++)
 #pragma unroll
-            for (int s = 0; s < S; s++) v[t][s] = G[gram_index<T, S>(jj * 8 + t, ll + 8 * s)];
+            for (int s = 0; s < S; s++) v[t][s] = G[gram_index<T, S, GR>(jj * GR + t, ll + 8 * s)];
     }
 };
 // single precision: the row pairs (2q, 2q+1) as the register pairs a v_pk_fma_f32 wants (the LDS layout of gram_index)
 template <int S>
-struct GramRegs<float, S> {
+struct GramRegs<float, S, 8> {
     f32x2 v[4][S];
     __device__ __forceinline__ void load(const float *__restrict__ G, int lane)
     {
@@ -1111,11 +1102,11 @@ __device__ __forceinline__ void gram_pass_regs_w(const GramRegs<float, S> &R, co
         for (int s = 0; s < S; s++) out.v[s] = NEG ? out.v[s] - w2 * R.v[q][s] : out.v[s] + w2 * R.v[q][s];
     }
 }
-template <bool NEG, typename T, int S>
-__device__ __forceinline__ void gram_pass_regs_w(const GramRegs<T, S> &R, const T (&wts)[8], PassAcc<T> &out)
+template <bool NEG, typename T, int S, int GR>
+__device__ __forceinline__ void gram_pass_regs_w(const GramRegs<T, S, GR> &R, const T (&wts)[8], PassAcc<T> &out)
 {
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+    for (int t = 0; t < GR; t++)
 #pragma unroll
         for (int s = 0; s < S; s++) out.v[s] = NEG ? out.v[s] - wts[t] * R.v[t][s] : out.v[s] + wts[t] * R.v[t][s];
 }
@@ -1134,9 +1125,6 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     constexpr bool GRAM = IMPLICIT || GRAMX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *G = reinterpret_cast<T *>(smem_raw);
-#if CMF_TREDUCE_LDS
-    __shared__ __attribute__((aligned(16))) T s_tr[4][64 * tr_ld<T>()];
-#endif
     constexpr bool PV = pass_vector_in_lds<T>();
     __shared__ __attribute__((aligned(16))) T s_pv[PV ? 4 : 1][PV ? 64 : 1];
     const int tid = threadIdx.x;
@@ -1144,12 +1132,13 @@ cg_rows_tiny_kernel(const CgParams<T> P)
     auto short_row = [&](int nnz_) -> bool { return MIX && nnz_ <= 16; };
     auto entry_of = [&](int nnz_) -> int { return (NE == 2 || short_row(nnz_)) ? (lane >> 2) : (lane >> 1); };
     const int k = P.k;
+    constexpr bool GREG = tiny_greg<T, GRAM>();
+    constexpr int GR = GREG ? gram_rows<T>(S) : 8;          // (the LDS form of the product below reads eight rows per group)
     if (GRAM) {
-        stage_gramian<T, S>(G, P.BtB, k, tid, blockDim.x);
+        stage_gramian<T, S, GR>(G, P.BtB, k, tid, blockDim.x);
         __syncthreads();
     }
-    constexpr bool GREG = tiny_greg<T, GRAM>();
-    GramRegs<T, GREG ? S : 1> greg;
+    GramRegs<T, GREG ? S : 1, GREG ? GR : 8> greg;
     if constexpr (GREG) greg.load(G, lane);
     const int nwaves = gridDim.x * 4;
     struct Pre { int idx; T x; T a; T g; };
@@ -1202,7 +1191,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             asm volatile("" ::: "memory");
             T vrep[S];
             T gw[8];
-            if constexpr (PV) pass_vector_lds<T, S>(vdist, vrep, gw, lane, &s_pv[tid >> 6][0]);
+            if constexpr (PV) pass_vector_lds<T, S, GR>(vdist, vrep, gw, lane, &s_pv[tid >> 6][0]);
             else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
             acc.zero();
@@ -1219,11 +1208,7 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             else if (GRAM && !CMF_DBG(P, 2)) gram_pass<T, S, 1>(G, (MODE == 0) ? -vdist : vdist, acc, lane, 0);
             T out[8];
             acc.close(out);
-#if CMF_TREDUCE_LDS
-            return treduce8_lds<T, S>(out, lane, &s_tr[tid >> 6][0]);
-#else
             return treduce8_high<T>(out, lane);
-#endif
         };
         T r_d = run_pass(a_d, std::integral_constant<int, 0>{});
         r_d -= lam * a_d;

@@ -41,7 +41,14 @@ enum CholMode { CHOL_EXPLICIT = 0, CHOL_IMPLICIT = 1, CHOL_COLLECTIVE = 2,
                                       the multi-RHS posv of the C / D update, common.c:2872-2875 */,
                 CHOL_NAZ = 5 /* missing-as-zero, unweighted (optimizeA Case 3, common.c:3100-3205): every row shares
                                 M = Minit[kt,kt] (B^T B + diag), rhs = sum_j x_j B_j over the row's entries
-                                (tgemm_sp_dense); rows without entries are left to the caller (zero) */ };
+                                (tgemm_sp_dense); rows without entries are left to the caller (zero) */,
+                CHOL_NAZ_W = 6 /* missing-as-zero WITH observation weights (optimizeA Case 4 with NA_as_zero && weight,
+                                  common.c:3209-3302; factors_closed_form :846-907): absent entries are zeros of weight one, so
+                                  M_i = Minit[kt,kt] (B^T B, no diagonal) + sum_j (w_j - 1) B_j B_j^T + diag(lam_i .. lam_last_i),
+                                  rhs_i = the prefilled row (bias_BtX or zero) + sum_j [w_j x_j - (w_j - 1)(mean + bias_j)] B_j.
+                                  The caller hands over `weights` = w - 1 and `values` = the bracket, per entry (session.hip,
+                                  naz_entry_transform_kernel); lam_i = lam x wsum[row] under scale_lam (the driver's sum of the
+                                  row's weights + the number of its absent entries, collective.c:7991-8022).  TWO_SRC build. */ };
 
 template <typename T>
 struct CholParams {
@@ -378,7 +385,7 @@ chol_rows_kernel(const CholParams<T> P)
         }
         T lam = P.lam, lam_last = P.lam_last;
         T l1 = P.l1, l1_last = P.l1_last;
-        if (P.mode == CHOL_EXPLICIT) {
+        if (P.mode == CHOL_EXPLICIT || P.mode == CHOL_NAZ_W) {
             if (P.scale_lam) {                                           // common.c:679-723
                 const T mult = (P.wsum != nullptr) ? P.wsum[row] : (T)nnz1;
                 lam *= mult; l1 *= mult;
@@ -443,6 +450,7 @@ chol_rows_kernel(const CholParams<T> P)
             pre_wsyr = impl_w ? x : wg;             // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
             pre_wrhs = impl_w ? x + T(1) : x * wg;  // common.c:2082-2085, collective.c:2097-2101 vs common.c:985-996
             if (naz) pre_wsyr = T(0);               // the matrix is shared (common.c:3130-3140)
+            if (TWO_SRC && P.mode == CHOL_NAZ_W) { pre_wsyr = wg; pre_wrhs = x; }     // common.c:866-885 (w - 1 and the bracket arrive per entry)
             if (wsrc2) { pre_wsyr = P.w2_syr_zero ? T(0) : P.w2; pre_wrhs = P.w2 * wx; }   // collective.c:1636-1653, :1719-1731
         };
         if (nnz > 0) { load_idx(0); load_rows(); }
@@ -519,7 +527,7 @@ chol_rows_kernel(const CholParams<T> P)
         }
         // ---- 2. the initial matrix, in the accumulator layout (padding: identity) ----
         {
-            const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED || P.mode == CHOL_NAZ);
+            const bool full = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_PREFILLED || P.mode == CHOL_NAZ || P.mode == CHOL_NAZ_W);
             const T *M1 = full ? P.Minit : P.Mfull;                    // [kt, kt], every row
             const T *M2 = (!full && has_u) ? P.Minit : nullptr;        // [kc, kc], rows with side information
 #pragma unroll 1
@@ -538,7 +546,7 @@ chol_rows_kernel(const CholParams<T> P)
                     }
                 }
             }
-            const bool add_lam = (P.mode == CHOL_EXPLICIT || P.mode == CHOL_COLLECTIVE);
+            const bool add_lam = (P.mode == CHOL_EXPLICIT || P.mode == CHOL_COLLECTIVE || P.mode == CHOL_NAZ_W);
 #pragma unroll
             for (int tt = 0; tt < TPW; tt++) {
 #pragma unroll

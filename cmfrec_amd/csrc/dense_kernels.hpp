@@ -225,6 +225,97 @@ __global__ void add_rowvec_kernel(T *__restrict__ M, size_t ld, size_t rows, int
     M[r * ld + c] += v[c];
 }
 
+// M[r, c] = v[c] (or zero) for the first `cols` columns of every row
+template <typename T>
+__global__ void set_rowvec_kernel(T *__restrict__ M, size_t ld, size_t rows, int cols, const T *__restrict__ v)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= rows * (size_t)cols) return;
+    const size_t r = e / cols; const int c = (int)(e % cols);
+    M[r * ld + c] = (v != nullptr) ? v[c] : T(0);
+}
+
+// dst[order[i], c] = src[order[i], c] for the first n positions of a processing order
+template <typename T>
+__global__ void copy_rows_by_order_kernel(const T *__restrict__ src, size_t ld_src, T *__restrict__ dst, size_t ld_dst, const int *__restrict__ order,
+                                          int n, int cols)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * cols) return;
+    const int r = order[e / cols]; const int c = (int)(e % cols);
+    dst[(size_t)r * ld_dst + c] = src[(size_t)r * ld_src + c];
+}
+
+// Missing-as-zero main matrix WITH observation weights (optimizeA Case 4, NA_as_zero && weight): per entry e of X (CSR or CSC
+// order) the rank-1 weight of its correction and the bracket of its right-hand side,
+//     g[e] = w[e] - 1,    xt[e] = w[e] x[e] - (w[e] - 1) (mean + bias[idx[e]])
+// (factors_closed_form, /root/reference/src/common.c:866-885; factors_explicit_cg_NA_as_zero_weighted :1325-1338)
+template <typename T>
+__global__ void naz_entry_transform_kernel(const T *__restrict__ x, const T *__restrict__ w, const int *__restrict__ idx, size_t nnz,
+                                           const T *__restrict__ bias, T mean, T *__restrict__ g, T *__restrict__ xt)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const T we = w[e];
+    const T cst = mean + ((bias != nullptr) ? bias[idx[e]] : T(0));
+    g[e] = we - T(1);
+    xt[e] = we * x[e] - (we - T(1)) * cst;
+}
+// the lambda multipliers of those rows under scale_lam: the sum of the row's weights (in double, entry order) plus the number of
+// its absent entries (collective.c:7991-8022)
+template <typename T>
+__global__ void naz_wsum_kernel(const size_t *__restrict__ p, const T *__restrict__ w, int nrows, int others, T *__restrict__ wsum)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    double acc = 0;
+    for (size_t e = p[r]; e < p[r + 1]; e++) acc += (double)w[e];
+    wsum[r] = (T)acc + (T)(others - (int)(p[r + 1] - p[r]));
+}
+// CG on a matrix every row shares, one wavefront per row, for the rows of that model WITHOUT entries (they are solved when the
+// bias / mean constant exists, common.c:3270-3271): (G + diag(lam_i .. lam_last_i)) a = cst from the row's current a --
+// factors_explicit_cg_NA_as_zero_weighted with nnz = 0 (:1321-1324 symv, :1368-1371 constant, the steps :1388-1438).  k <= 64.
+template <typename T>
+__global__ void __launch_bounds__(256)
+cg_shared_matrix_rows_kernel(T *__restrict__ A, size_t lda, const int *__restrict__ rows, int nrows, int k, const T *__restrict__ G,
+                             const T *__restrict__ cst, T lam, T lam_last, const T *__restrict__ mult, int scale_bias_const, int max_cg_steps)
+{
+    const int lane = threadIdx.x & 63;
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pos >= nrows) return;
+    const int row = rows[pos];
+    T li = lam, ll = lam_last;
+    if (mult != nullptr) { li *= mult[row]; if (!scale_bias_const) ll *= mult[row]; }
+    const T dg = (lane == k - 1) ? ll : li;
+    T *arow = A + (size_t)row * lda;
+    T a = (lane < k) ? arow[lane] : T(0);
+    auto mv = [&](T v) -> T {                        // (G v)[lane], G symmetric
+        T acc = T(0);
+        for (int j = 0; j < k; j++) acc += ((lane < k) ? G[(size_t)j * k + lane] : T(0)) * __shfl(v, j);
+        return acc;
+    };
+    T r = -mv(a);
+    if (cst != nullptr && lane < k) r += cst[lane];
+    r -= dg * a;
+    if (lane >= k) r = T(0);
+    T p = r;
+    T r_old = lanes::wave_sum(r * r);
+    if (r_old > (T)1e-12) {
+        for (int step = 0; step < max_cg_steps; step++) {
+            T Ap = mv(p) + dg * p;
+            if (lane >= k) Ap = T(0);
+            const T alpha = r_old / lanes::wave_sum(p * Ap);
+            a += alpha * p;
+            r -= alpha * Ap;
+            const T r_new = lanes::wave_sum(r * r);
+            if (r_new <= (T)1e-8) break;
+            p = p * (r_new / r_old) + r;
+            r_old = r_new;
+        }
+    }
+    if (lane < k) arow[lane] = a;
+}
+
 template <typename T>
 __global__ void col_fill_kernel(T *__restrict__ M, size_t ld, int rows, int col, T value)
 {

@@ -560,6 +560,12 @@ struct CgCall {
     real_t w_imp = 0;
     const real_t *gsum = nullptr;     // [rows, ki]: sum of the rows of Bi at each row's observed positions (segmented gather-sum), or null
     int skip_first = 0;               // generic kernel: the first positions of the processing order are solved elsewhere (session.hip, launch_cg_wide)
+    // explicit model on the tiled kernels with a matrix every row shares and a per-row constant in the first residual (GRAMX builds):
+    // NA_as_zero_X with observation weights (session.hip, update_factor_naz_weighted) -- Gx [k, k], rconst_x [rows, ldr_x], and the
+    // entries' values / weights read from these arrays (CSR order of X) instead of the shard's own
+    const real_t *Gx = nullptr, *rconst_x = nullptr;
+    size_t ldr_x = 0;
+    const real_t *values_override = nullptr, *weights_override = nullptr;
 };
 
 enum class CgVariant { Auto, Generic };
@@ -630,13 +636,15 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
-// CMFREC_HIP_PAIR: how the rows of at most 32 entries run.  1 (default): two rows per wavefront, ONE launch for the bin
-// (cg_pair_kernels.hpp; the 16-slot tile for the pairs of rows of <= 16 entries).  2: two launches -- the rows of 17..32 entries on
-// the 32-slot build, the rows of <= 16 on the build that keeps its Gramian elements in registers.  0: one row per wavefront
-// (cg_rows_tiny_kernel, round 4; A/B switch and on-device cross-check).
+// CMFREC_HIP_PAIR: how the rows of at most 32 entries run.  0 (default): one row per wavefront (cg_rows_tiny_kernel).  1: two rows
+// per wavefront, ONE launch for the bin (cg_pair_kernels.hpp; the 16-slot tile for the pairs of rows of <= 16 entries).  2: two
+// launches -- the rows of 17..32 entries on the 32-slot build, the rows of <= 16 on the build that keeps its Gramian elements in
+// registers.  Measured side by side in round 5 (profiles/r05/r05_e_*): the pair kernel issues 15 % fewer vector instructions per
+// row, but reads its Gramian from LDS in every pass (no room for a register copy beside two rows' tiles) and a pair costs its
+// longer row -- C2 3.375 (1) / 3.384 (2) against 3.348 ms (0); it stays as an A/B switch and on-device cross-check.
 inline int cg_pair_mode()
 {
-    static const int mode = getenv("CMFREC_HIP_PAIR") != nullptr ? atoi(getenv("CMFREC_HIP_PAIR")) : 1;
+    static const int mode = getenv("CMFREC_HIP_PAIR") != nullptr ? atoi(getenv("CMFREC_HIP_PAIR")) : 0;
     return mode;
 }
 
@@ -993,6 +1001,24 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     P.ticks = cg_ticks_buffer();
 #endif
     const int S = (c.k + 7) / 8;
+    if (c.values_override != nullptr) P.values = c.values_override;
+    if (c.weights_override != nullptr) { P.weights = c.weights_override; P.wsum = X.wsum.ptr; }
+    if (c.Gx != nullptr) {
+        // shared matrix + per-row constant on the GRAMX builds (no block structure: the explicit model's own lambda rules apply)
+        if (c.implicit || c.precond || S > 8 || c.kc > 0 || c.Bi != nullptr || c.koff != 0 || c.skip_first != 0) {
+            g_last_error = "cmfrec_hip: CG with a shared matrix: plain explicit rows of at most 64 unknowns, no preconditioner";
+            return 2;
+        }
+        P.BtB = c.Gx; P.rconst = c.rconst_x; P.ldr = c.ldr_x;
+#define CMF_XCASE(SS) case SS: launch_cg_S<SS, false, true>(dev, P, X, tm); break;
+        switch (S) {
+            CMF_XCASE(1) CMF_XCASE(2) CMF_XCASE(3) CMF_XCASE(4)
+            CMF_XCASE(5) CMF_XCASE(6) CMF_XCASE(7) CMF_XCASE(8)
+        }
+#undef CMF_XCASE
+        HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     // Block systems (dense side information on EVERY row of the launch and / or implicit features, no k_user offset) on the
     // tiled kernels: the weighted Gramian w C^T C + w_i Bi^T Bi acts on the unknowns like the implicit model's B^T B, the row's
     // constant w (U C)_row + w_i sum Bi_j joins the first residual (GRAMX builds, cg_kernels.hpp).  Rows without entries

@@ -993,10 +993,22 @@ int_t fit_collective_explicit_als(
     // NA_as_zero_X (sparse X whose absent entries are zeros): every half-step shares one matrix over its rows -- optimizeA Case 3
     // without side information on that side (common.c:3118-3205: closed form whatever use_cg says), optimizeA_collective with
     // the factorised shared block matrix (collective.c:5607-5617, :5700-5716) with dense complete side information
-    if (NA_as_zero_X && (weight || nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
+    if (NA_as_zero_X && (nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
                          precompute_for_predictions || (scale_bias_const && (scale_lam || scale_lam_sideinfo) && (user_bias || item_bias))))
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without weights, sparse side information, implicit "
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without sparse side information, implicit "
                              "features, nonneg / L1, scale_bias_const and without precompute_for_predictions.");
+    // ... with observation weights (round 5): optimizeA Case 4's NA_as_zero + weight branches (common.c:3209-3302, :846-907,
+    // :1293-1441), the model without side information.  Not with start values for the biases: the reference's own
+    // (initialize_biases with NA_as_zero and weights) index the item biases by row inside the item sweep (common.c:4727-4731).
+    if (NA_as_zero_X && weight != nullptr) {
+        if (U || II || k_user || k_item)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights: the model without side information.");
+        if ((user_bias || item_bias) && reset_values)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights: pass start values for the biases (reset_values = false); "
+                                 "the reference's own start values are not defined for this combination.");
+        if (use_cg && (precondition_cg || k + k_main + 1 > 64) )
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights under CG: k + k_main + bias <= 64, no preconditioner.");
+    }
     if (NA_as_zero_X && (U || II)) {
         // (use_cg is accepted: with a factorised shared block matrix the reference takes the closed form whatever the solver asked for)
         if ((U && m_u != m) || (II && n_i != n))
@@ -1114,7 +1126,25 @@ int_t fit_collective_explicit_als(
     //      subtraction itself happens on the device while the CSR / CSC are built ----
     PhaseTimer tm;
     real_t gm = 0;
-    if (center && NA_as_zero_X) {
+    if (center && NA_as_zero_X && weight) {
+        // weighted mean of the entries (common.c:3558-3584; with 8 threads or more the unweighted sum over the sum of the weights,
+        // quirk Q13), then DIVIDED by the weights' share of all cells, wsum / (wsum + m n - nnz), as the reference does
+        // (:3590-3594; the sum of the weights there is a compensated sum, helpers.c:1691-1707)
+        double xsum = 0, wsum = 2.220446049250313e-16;
+        if (nthreads >= 8) {
+            wsum = 0;
+            for (size_t e = 0; e < nnz; e++) { xsum += (double)X[e]; wsum += (double)weight[e]; }
+            gm = (real_t)(xsum / wsum);
+        } else {
+            for (size_t e = 0; e < nnz; e++) { wsum += (double)weight[e]; xsum += (((double)X[e] - xsum) * (double)weight[e]) / wsum; }
+            gm = (real_t)xsum;
+        }
+        double err = 0, res = 0;
+        for (size_t e = 0; e < nnz; e++) { const double diff = (double)weight[e] - err; const double temp = res + diff; err = (temp - res) - diff; res = temp; }
+        const long double wl = (long double)res;
+        gm = (real_t)((long double)gm / (wl / (wl + ((long double)m * (long double)n - (long double)nnz))));
+        if (std::fabs(gm) < std::sqrt(EPS_T)) gm = 0;
+    } else if (center && NA_as_zero_X) {
         // mean over all m x n cells: the mean of the entries x nnz / (m n) (common.c:3494-3523); the stored values stay as
         // they are (:3600-3607), the mean enters every right-hand side instead (collective.c:8573-8600, :8756-8787)
         double xsum = 0;

@@ -75,6 +75,12 @@ template <typename T> __device__ __forceinline__ T xor4(T x)
 {
     return map(x, [](int v) { int t = dpp_new<ROW_SHL4, 0x5>(v); return dpp<ROW_SHR4, 0xA>(t, v); });
 }
+// x[lane ^ 4] for the lanes with (lane & 4) == 0 only -- one masked move per dword; the other lanes are left undefined (callers
+// whose upper half-groups carry nothing they read: treduce8_low with fewer than 8 values)
+template <typename T> __device__ __forceinline__ T xor4_lower(T x)
+{
+    return map(x, [](int v) { return dpp_new<ROW_SHL4, 0x5>(v); });
+}
 template <typename T> __device__ __forceinline__ T xor8(T x) { return map(x, [](int v) { return dpp_full<ROW_ROR8>(v); }); }
 
 // lanes with (lane & M) == 0 receive a[lane ^ M], the others b[lane ^ M]  (M = 4 or 8)

@@ -60,6 +60,8 @@ struct CholCall {
     const real_t *values_override = nullptr; // values of the first source (default: X's own)
     bool rhs_only = false;                   // CHOL_NAZ: gather the right-hand sides only
     bool rhs_prefilled_all = false;          // every row starts from the right-hand side left in A
+    const real_t *weights_override = nullptr; // CHOL_NAZ_W: the entries' rank-1 weights (w - 1), CSR order of X
+    bool all_rows = false;                   // CHOL_NAZ_W: rows without entries are solved too (from the prefilled right-hand side)
     int row_limit = -1;                      // only the first row_limit positions of the processing order (the others are solved elsewhere)
     // CG on the row's Gramian instead of the factorisation (gram_cg_wide_kernels.hpp): the producer build of the wave kernel runs
     // every row's rank-k update, gram_cg_wide_kernel takes the partials; the parameters of the CG (explicit model)
@@ -85,9 +87,10 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     // observation weights of the explicit model ride on the shard (SparseShard::w / wsum)
     const bool weighted = X != nullptr && X->weighted() && (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && c.values_override == nullptr;
     if (weighted) { P.weights = X->w.ptr; P.wsum = X->wsum.ptr; }
+    if (c.mode == CHOL_NAZ_W) { P.weights = c.weights_override; P.wsum = X->wsum.ptr; }
     P.order = X ? X->order.ptr : nullptr;
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
-    else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT) P.nrows = X->nrows;   // empty rows too
+    else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT || (c.mode == CHOL_NAZ_W && c.all_rows)) P.nrows = X->nrows;   // empty rows too
     else P.nrows = X->n_nonempty;                                                // non-empty rows
     if (c.row_limit >= 0) P.nrows = std::min(P.nrows, c.row_limit);
     P.Minit = c.Minit; P.Mfull = c.Mfull; P.kc = c.kc; P.rows_with_u = c.rows_with_u; P.p_side = c.p_side;
@@ -122,7 +125,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 4 * sizeof(int), dev.stream));   // [0, 4): first launches of this call
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
-    const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ;      // CHOL_NAZ is part of that build only
+    const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ || c.mode == CHOL_NAZ_W;      // CHOL_NAZ[_W] are part of that build only
     // Rows of up to WAVE_ROW_MAX entries: one wavefront per row, the matrix in its registers (chol_wave_kernels.hpp).
     // The rows beyond (they lead the processing order) stay with the workgroup-per-row kernel below; the two launches
     // run side by side on two streams.  CMFREC_HIP_CHOL=rows keeps everything on the workgroup-per-row kernel (A/B
@@ -871,6 +874,9 @@ struct cmfrec_hip_session {
     real_t x_subtract = 0;        // what the most recent set_X_coo* subtracted from the values (cmfrec_hip_session_set_NA_as_zero_X checks it)
     real_t naz_mean = 0;
     DevBuf<real_t> naz_part, naz_vec, naz_M, naz_rhs;
+    // ... with observation weights (update_factor_naz_weighted): per entry w - 1 and the right-hand-side bracket, a zero array in
+    // the place of the values for the CG kernels
+    DevBuf<real_t> naz_g, naz_xt, naz_zero;
     DevBuf<int> zrowsA, zrowsB;   // rows every update of A / B leaves at zero (cmfrec_hip_session_set_zero_rows)
     int n_zrowsA = 0, n_zrowsB = 0;
     DevBuf<unsigned char> cfmaskA, cfmaskB;   // rows that take the closed form inside a CG update (cmfrec_hip_session_set_closed_form_rows)
@@ -1486,11 +1492,21 @@ int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int cente
         if (on && s->mdl.implicit) { g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: explicit model only"; return 2; }
         // the mean enters through the right-hand-side constant: an X that was uploaded centred would count it twice; the weighted
         // and the sharded forms are not built (the updates would refuse them one by one)
-        if (on && (s->x_subtract != (real_t)0 || s->Xr.weighted() || s->mdl.row_begin != 0 || s->mdl.row_end != s->mdl.m ||
+        if (on && (s->x_subtract != (real_t)0 || s->mdl.row_begin != 0 || s->mdl.row_end != s->mdl.m ||
                    s->mdl.col_begin != 0 || s->mdl.col_end != s->mdl.n)) {
-            g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: X must have been set uncentred (subtract = 0), without weights, on the "
-                           "whole row and column range";
+            g_last_error = "cmfrec_hip_session_set_NA_as_zero_X: X must have been set uncentred (subtract = 0) on the whole row and "
+                           "column range";
             return 2;
+        }
+        if (on && s->Xr.weighted() && !s->naz_X) {
+            // with observation weights an absent entry is a zero of weight one: the rows' lambda multipliers under scale_lam count
+            // them (wsumA / wsumB, collective.c:7991-8022)
+            hipStream_t st = s->dev.stream;
+            hipLaunchKernelGGL(naz_wsum_kernel<real_t>, grid1d((size_t)s->Xr.nrows), dim3(256), 0, st, s->Xr.p.ptr, s->Xr.w.ptr, s->Xr.nrows,
+                               s->mdl.n, s->Xr.wsum.ptr);
+            hipLaunchKernelGGL(naz_wsum_kernel<real_t>, grid1d((size_t)s->Xc.nrows), dim3(256), 0, st, s->Xc.p.ptr, s->Xc.w.ptr, s->Xc.nrows,
+                               s->mdl.m, s->Xc.wsum.ptr);
+            HIP_CHECK(hipGetLastError());
         }
         s->naz_X = on != 0; s->naz_center = center != 0; s->naz_mean = glob_mean;
         return 0;
@@ -1749,8 +1765,109 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
     return 0;
 }
 
+// The same half-step WITH observation weights and without side information (optimizeA Case 4 with NA_as_zero && weight,
+// common.c:3209-3302; driver collective.c:8573-8600 + :8680-8717, :8756-8787 + :8847-8876): an absent entry is a zero of weight
+// one, so every row's system is the shared opp^T opp plus the correction of its present entries,
+//     M_i   = opp^T opp + sum_j (w_j - 1) opp_j opp_j^T + diag(lam_i .. lam_i, lam_last_i)
+//     rhs_i = sum_j [w_j x_j - (w_j - 1)(mean + bias_j)] opp_j + cst,    cst = - sum over ALL opposing rows of (bias + mean) x row
+// (factors_closed_form :846-907; factors_explicit_cg_NA_as_zero_weighted :1293-1441), lam_i = lam x (sum of the row's weights +
+// number of its absent entries) under scale_lam.  Closed form: the row Cholesky kernel in its CHOL_NAZ_W mode (B^T B as the
+// initial matrix, the corrections on the matrix cores).  CG: the right-hand sides by the gather-only launch, then the tiled CG
+// kernels of the explicit model with the shared matrix in LDS (GRAMX builds), weights w - 1 and zero values --
+//     r = rhs_i - M_i a,   Ap = M_i p
+// are the reference's :1321-1371 / :1391-1406 regrouped.  Rows without entries are solved when cst exists (:3270-3271).
+static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    hipStream_t st = dev.stream;
+    if ((isA ? m.p : m.q) > 0 || m.k_user != 0 || m.k_item != 0 || s->implicit_feats || dev.nonneg_now || dev.l1_now != (real_t)0 ||
+        dev.l1_last_now != (real_t)0 || s->sparseU || s->sparseI || s->side_local || m.p > 0 || m.q > 0) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without side information, implicit features, nonneg / L1";
+        return 2;
+    }
+    const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
+    real_t *self = isA ? s->A.ptr : s->B.ptr;
+    real_t *opp = isA ? s->B.ptr : s->A.ptr;
+    const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
+    const SparseShard &X = isA ? s->Xr : s->Xc;
+    const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
+    const real_t lam_self = s->lam6[isA ? 2 : 3];
+    const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
+    const int ks = m.k + m.k_main + (self_bias ? 1 : 0);
+    if (!chol && (ks > 64 || m.precondition_cg)) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights under CG: at most 64 unknowns per row, no preconditioner";
+        return 2;
+    }
+    if (self_bias)                            // the opposing bias column is fixed to 1 (collective.c:8538-8543, :8728-8732)
+        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
+    launch_gram(dev, s->gws, opp, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);       // :3233-3236, no diagonal
+    // cst (bias_BtX) and the per-entry pairs
+    const bool has_cst = opp_bias || s->naz_center;
+    const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
+    if (has_cst) {
+        const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
+        s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
+        hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, opp, ld_opp, rows_opp, ks, bias,
+                           s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
+        hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
+    }
+    const real_t *cst = has_cst ? s->naz_vec.ptr : nullptr;
+    const size_t nnz = X.nnz;
+    s->naz_g.alloc_at_least(std::max<size_t>(nnz, 1)); s->naz_xt.alloc_at_least(std::max<size_t>(nnz, 1));
+    if (nnz > 0)
+        hipLaunchKernelGGL(naz_entry_transform_kernel<real_t>, grid1d(nnz), dim3(256), 0, st, X.v.ptr, X.w.ptr, X.i.ptr, nnz,
+                           has_cst ? bias : nullptr, s->naz_center ? s->naz_mean : (real_t)0, s->naz_g.ptr, s->naz_xt.ptr);
+    HIP_CHECK(hipGetLastError());
+    if (chol) {
+        // right-hand sides start from cst (or zero), every row that is solved is overwritten
+        const int nsolve = has_cst ? X.nrows : X.n_nonempty;
+        s->naz_rhs.alloc_at_least((size_t)rows_self * ks);
+        hipLaunchKernelGGL(set_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, s->naz_rhs.ptr, (size_t)ks, (size_t)rows_self, ks, cst);
+        // (rows without entries and without cst keep their factors: the kernel solves into naz_rhs, copied back below for the solved rows)
+        CholCall c{s->naz_rhs.ptr, (size_t)ks, opp, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, m.scale_lam != 0, false,
+                   s->scale_bias_const, CHOL_NAZ_W};
+        c.values_override = s->naz_xt.ptr; c.weights_override = s->naz_g.ptr; c.rhs_prefilled_all = true; c.all_rows = has_cst;
+        int rc = launch_chol(dev, c, &X);
+        if (rc) return rc;
+        hipLaunchKernelGGL(copy_rows_by_order_kernel<real_t>, grid1d((size_t)nsolve * ks), dim3(256), 0, st, s->naz_rhs.ptr, (size_t)ks, self, ld_self,
+                           X.order.ptr, nsolve, ks);
+        HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // CG: rhs_i by the gather-only launch (sum_j xt_j opp_j) + cst ...
+    s->naz_rhs.alloc_at_least((size_t)rows_self * ks);
+    HIP_CHECK(hipMemsetAsync(s->naz_rhs.ptr, 0, (size_t)rows_self * ks * sizeof(real_t), st));
+    {
+        CholCall c{s->naz_rhs.ptr, (size_t)ks, opp, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
+        c.rhs_only = true; c.values_override = s->naz_xt.ptr;
+        int rc = launch_chol(dev, c, &X);
+        if (rc) return rc;
+    }
+    if (has_cst)
+        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, s->naz_rhs.ptr, (size_t)ks, (size_t)rows_self, ks, cst);
+    // ... then the tiled kernels: shared matrix in LDS, rank-1 weights w - 1, values zero
+    if (s->naz_zero.n < std::max<size_t>(nnz, 1)) {
+        s->naz_zero.alloc(std::max<size_t>(nnz, 1));
+        HIP_CHECK(hipMemsetAsync(s->naz_zero.ptr, 0, std::max<size_t>(nnz, 1) * sizeof(real_t), st));
+    }
+    CgCall c{self, ld_self, opp, ld_opp, ks, nullptr, nullptr, lam_self, lam_last_self, m.scale_lam != 0, s->scale_bias_const, m.max_cg_steps, false};
+    c.Gx = s->gram.ptr; c.rconst_x = s->naz_rhs.ptr; c.ldr_x = (size_t)ks;
+    c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_g.ptr;
+    int rc = launch_cg(dev, c, X);
+    if (rc) return rc;
+    if (has_cst && X.nrows > X.n_nonempty) {
+        const int cnt = X.nrows - X.n_nonempty;
+        hipLaunchKernelGGL(cg_shared_matrix_rows_kernel<real_t>, dim3((cnt + 3) / 4), dim3(256), 0, st, self, ld_self, X.order.ptr + X.n_nonempty, cnt, ks,
+                           s->gram.ptr, cst, lam_self, lam_last_self, m.scale_lam ? X.wsum.ptr : nullptr, s->scale_bias_const ? 1 : 0, m.max_cg_steps);
+        HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
 static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = -1)
 {
+    if (s->naz_X && !s->mdl.implicit && s->Xr.weighted()) return update_factor_naz_weighted(s, isA, chol);
     if (s->naz_X && !s->mdl.implicit) return update_factor_naz(s, isA, chol);
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;

@@ -310,6 +310,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g18_na_as_zero_" + tag, **out)
 
+        # ---- G24: NA_as_zero for the main matrix WITH observation weights ----
+        out = {}
+        d = gc.naz_weighted_problem(dt)
+        for ci, (name, opts) in enumerate(gc.NAZ_WEIGHTED_CASES):
+            r = gc.naz_weighted_reference(R, d, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g24_na_as_zero_weighted_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

@@ -1085,6 +1085,80 @@ def naz_hip(d, opts, dtype, NA_as_zero=True):
     return out
 
 
+# ---- NA_as_zero for the main matrix WITH observation weights (optimizeA Case 4, NA_as_zero && weight: common.c:3209-3302, per row
+# :846-907 closed form, :1293-1441 CG) -- fixture g24.  Given start values only: the reference's bias start values are not defined
+# for this combination (common.c:4727-4731 index the item biases by row).  Entries ordered by column, like every weighted case.
+def naz_weighted_problem(dtype, seed=93):
+    d = weights_problem(dtype, seed)
+    keep = d["col"] != 7                                  # a column without entries next to the rows (4, 120) without
+    for key in ("row", "col", "ratings", "W"):
+        d[key] = d[key][keep]
+    return d
+
+
+NAZ_WEIGHTED_CASES = [
+    ("chol, biases", dict(use_cg=False)),
+    ("cg, biases", dict(use_cg=True, finalize_chol=False)),
+    ("chol, scale_lam", dict(use_cg=False, scale_lam=True)),
+    ("cg + finalize, scale_lam, item bias", dict(use_cg=True, finalize_chol=True, scale_lam=True, user_bias=False)),
+    ("chol, no centring, user bias", dict(use_cg=False, center=False, item_bias=False)),
+    ("cg, no biases, no centring: rows without entries stay", dict(use_cg=True, finalize_chol=False, user_bias=False, item_bias=False, center=False)),
+    ("chol, no biases, centred, k_main", dict(use_cg=False, user_bias=False, item_bias=False, k_main=2)),
+    ("cg, per-matrix lambdas", dict(use_cg=True, finalize_chol=False, lam_unique=LAM6)),
+]
+
+
+def naz_weighted_reference(R, d, opts, nthreads=2):
+    o = dict(opts)
+    A0, B0 = _impf_start(d, o)
+    kw = dict(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, weight=d["W"], **kw)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_weighted_oracle(O, d, opts, nthreads=2):
+    o = dict(opts)
+    lam6 = o.pop("lam_unique", None)
+    if lam6 is not None:
+        O.set_lam_unique(np.asarray(lam6, np.float64), None)
+    try:
+        A0, B0 = _impf_start(d, o)
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                               niter=3, nthreads=nthreads, NA_as_zero_X=True, weight=d["W"], use_cg=o.pop("use_cg", False),
+                               finalize_chol=o.pop("finalize_chol", False), **o)
+    finally:
+        O.set_lam_unique(None, None)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if opts.get("user_bias", True): out["biasA"] = r["biasA"]
+    if opts.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_weighted_hip(d, opts, dtype, weights=True, **fit_kw):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "lam_unique" in o:
+        o["lambda_"] = o.pop("lam_unique")
+    else:
+        o["lambda_"] = 0.3
+    A0, B0 = _impf_start(d, o)
+    mdl = CMF(k=d["k"], niter=3, use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=True,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1, **o)
+    start = dict(A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    start.update(fit_kw)
+    mdl.fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]), W=d["W"] if weights else None, **start)
+    out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- NA_as_zero for the main matrix together with dense side information (optimizeA_collective with the factorised shared
 # block matrix, collective.c:5566-5968 / :5607-5617, :5700-5716) ---------------------------------------------------------------
 # (name, which sides carry side information, options).  Side information on exactly the rows / columns of X (the reference's own

@@ -349,6 +349,33 @@ def test_NA_as_zero_X(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_weighted(oracles, dtype):
+    """G24 through the estimator (CMF(NA_as_zero=True).fit(X, W=)): every row's system is the shared B^T B plus the (w - 1)-weighted
+    correction of its present entries -- closed form on the row Cholesky kernel (CHOL_NAZ_W), CG on the tiled kernels with the
+    shared matrix in LDS; rows without entries solved when the bias / mean constant exists, left alone otherwise."""
+    g = gc.load("g24_na_as_zero_weighted", dtype)
+    d = gc.naz_weighted_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, opts) in enumerate(gc.NAZ_WEIGHTED_CASES):
+        got = gc.naz_weighted_hip(d, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.naz_weighted_oracle(oracles[dtype], d, opts)) < tol, name
+    # the weights change the model, rows without entries follow the reference's rule (:3270-3271)
+    c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
+    assert gc.compare_fits(gc.naz_weighted_hip(d, gc.NAZ_WEIGHTED_CASES[0][1], dtype, weights=False), c0) > 1e-3
+    got = gc.naz_weighted_hip(d, gc.NAZ_WEIGHTED_CASES[0][1], dtype)
+    assert np.abs(got["A"][4]).max() > 0 and np.abs(got["B"][7]).max() > 0
+    A0, _ = gc._impf_start(d, dict(gc.NAZ_WEIGHTED_CASES[5][1]))
+    got = gc.naz_weighted_hip(d, gc.NAZ_WEIGHTED_CASES[5][1], dtype)
+    assert np.array_equal(got["A"][4], A0[4])
+    # start values for the biases are the caller's: the reference's own are not defined with weights
+    from cmfrec_amd import CMF
+    with pytest.raises(RuntimeError):
+        CMF(k=4, NA_as_zero=True, precompute_for_predictions=False).fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]), W=d["W"])
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_X_sideinfo(oracles, dtype):
     """G20 through the estimator (CMF(NA_as_zero=True).fit(X, U=, I=)): the half-steps with dense side information share one
     block matrix (blockdiag(0, B^T B) + w C^T C + lam mult I, mult = n + p | n | 1), factorised once; right-hand sides

@@ -171,7 +171,8 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, k, monkeypatch
 @pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("k", [50, 8, 64])
 def test_two_rows_per_wave(oracles, dtype, implicit, k):
-    """Rows of at most 32 entries are solved two per wavefront (cg_rows_pair_kernel, cg_pair_kernels.hpp): every length 0 .. 32
+    """Rows of at most 32 entries (one per wavefront by default; two per wavefront -- cg_rows_pair_kernel, cg_pair_kernels.hpp --
+    under CMFREC_HIP_PAIR=1, which tests/test_gpu_switches.py runs on the same kind of rows): every length 0 .. 32
     several times -- pairs of two short rows (16-slot tiles), of two longer ones, and mixed pairs at the boundary -- an odd number
     of such rows (the last wavefront holds one), rows that take the first exit (warm start = zero in the implicit model with unit
     counts does not; a row whose start already solves its system does), next to rows of 33 .. 60 entries on the one-row kernels."""
@@ -217,11 +218,12 @@ def test_two_rows_per_wave(oracles, dtype, implicit, k):
 @pytest.mark.parametrize("k", [50, 64, 9])
 def test_every_slot_count(oracles, dtype, implicit, k):
     """Rows of EVERY length 1 .. 150 (all slot counts 1 .. 8 of a 64-entry tile and 1 .. 4 of a 32-entry one, full and
-    partly filled last slots, one-, two- and four-wave teams), a few of 250 .. 1000 (four- and eight-wave teams, the
-    re-streamed second tile in double precision), checked row by row."""
+    partly filled last slots, one-, two- and four-wave teams; round 5: every tile size 8 NT, NT = 5 .. 8 entries per lane group,
+    of the one- and two-wave teams), the first and last length of every tile size of the four- and eight-wave teams (129 .. 512)
+    and a few up to 1024 (the re-streamed second tile in double precision), checked row by row."""
     from cmfrec_amd import ops
     O = oracles[dtype]
-    lens = list(range(0, 151)) + [250, 256, 257, 300, 511, 512, 513, 640, 777, 1000, 1024]
+    lens = list(range(0, 151)) + [160, 161, 192, 193, 224, 225, 250, 256, 257, 300, 320, 321, 384, 385, 448, 449, 511, 512, 513, 640, 777, 1000, 1024]
     m, n = len(lens), 2200
     rng = np.random.default_rng(100 + k)
     rows = [np.full(c, r, np.int32) for r, c in enumerate(lens)]

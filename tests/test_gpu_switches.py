@@ -55,7 +55,7 @@ def default_fits(tmp_path_factory):
     return _run(tmp_path_factory.mktemp("switches"), "default", {})
 
 
-@pytest.mark.parametrize("env", [{"CMFREC_HIP_CG_KERNEL": "generic"}, {"CMFREC_HIP_CHOL": "rows"}, {"CMFREC_HIP_PAIR": "0"}, {"CMFREC_HIP_PAIR": "2"}, {"CMFREC_HIP_PAIR": "0", "CMFREC_HIP_TINY16": "0"}, {"CMFREC_HIP_TINY16": "0"},
+@pytest.mark.parametrize("env", [{"CMFREC_HIP_CG_KERNEL": "generic"}, {"CMFREC_HIP_CHOL": "rows"}, {"CMFREC_HIP_PAIR": "1"}, {"CMFREC_HIP_PAIR": "2"}, {"CMFREC_HIP_PAIR": "0", "CMFREC_HIP_TINY16": "0"}, {"CMFREC_HIP_TINY16": "0"},
                                  {"CMFREC_HIP_VH_MIN": "400"}, {"CMFREC_HIP_GEMM_OWN": "0"}],
                          ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_process_wide_switch_agrees_with_default(default_fits, tmp_path, env):

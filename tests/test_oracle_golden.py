@@ -242,6 +242,19 @@ def test_NA_as_zero_X(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_X_weighted(oracles, dtype):
+    """G24: fit_collective_explicit_als with NA_as_zero_X AND observation weights (optimizeA Case 4's NA_as_zero + weight branches,
+    common.c:3209-3302; the mean divided by the weights' share of all cells, :3590-3594; wsumA / wsumB counting the absent
+    entries, collective.c:8014-8022)."""
+    g = gc.load("g24_na_as_zero_weighted", dtype)
+    d = gc.naz_weighted_problem(dtype)
+    for ci, (name, opts) in enumerate(gc.NAZ_WEIGHTED_CASES):
+        got = gc.naz_weighted_oracle(oracles[dtype], d, opts)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_NA_as_zero_X_sideinfo(oracles, dtype):
     """G20: NA_as_zero_X together with dense side information -- one factorised block matrix per half-step
     (collective.c:5607-5617, :5700-5716), right-hand sides X B + w U C + the bias / mean constant."""

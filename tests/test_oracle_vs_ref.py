@@ -615,3 +615,61 @@ def test_NA_as_zero_UI_fit_live(oracles, refs, dtype, seed):
         for key, v in ref.items():
             if v is not None and np.size(v) > 1:
                 assert rel_err(got[key], v) < 100 * TOL[dtype], (name, key)
+
+
+# ---- NA_as_zero for the main matrix together with observation weights -----------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_weighted_operator_live(oracles, refs, dtype):
+    """optimizeA Case 4 with NA_as_zero && weight (common.c:3209-3302): per row the shared B^T B plus the correction of the present
+    entries -- closed form (factors_closed_form :846-907), CG (factors_explicit_cg_NA_as_zero_weighted :1293-1441) and PCG
+    (:1443-1613); with and without the bias / mean constants, both lambda scalings, rows without entries (solved only when bias_BtX
+    is given, :3270-3271)."""
+    O, R = oracles[dtype], refs[dtype]
+    m, n, k = 230, 140, 12
+    row, col, val = make_coo(m, n, 4000, 91, counts=False, dtype=dtype, heavy_row=(4, 100), empty_rows=(6, 19))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(17)
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B = (rng.standard_normal((n, k)) * 0.3).astype(dtype)
+    wt = (0.25 + 2.0 * rng.random(len(csr[2]))).astype(dtype)
+    bias_X = (rng.standard_normal(n) * 0.2).astype(dtype)
+    glob = 0.37
+    bias_BtX = (-(B * (bias_X + dtype(glob))[:, None]).sum(axis=0)).astype(dtype)
+    nnz_row = np.diff(csr[0].astype(np.int64))
+    wsum = (np.add.reduceat(np.append(wt, 0), np.minimum(csr[0][:-1].astype(np.int64), len(wt))) * (nnz_row > 0) + (n - nnz_row)).astype(dtype)
+    tol = 100 * TOL[dtype]
+    for mode in ("chol", "cg", "pcg"):
+        for const in (True, False):
+            for sl, ws in ((False, None), (True, wsum), (True, None)):
+                kw = dict(use_cg=mode != "chol", precondition_cg=mode == "pcg", max_cg_steps=3, scale_lam=sl)
+                cst = dict(bias_BtX=bias_BtX, bias_X=bias_X, bias_X_glob=glob) if const else {}
+                Ao, Ar = A0.copy(), A0.copy()
+                O.optimizeA_naz_weighted(Ao, B, csr, wt, 0.3, lam_last=0.7, wsum=ws, nthreads=2, **kw, **cst)
+                R.optimizeA(Ar, B, csr=csr, lam=0.3, lam_last=0.7, weight=wt, wsum=ws, NA_as_zero=True, nthreads=2, **kw, **cst)
+                assert rel_err(Ao, Ar) < tol, (mode, const, sl, ws is not None)
+                if not const:                                   # rows without entries are left as they were
+                    assert np.array_equal(Ao[6], A0[6]) and np.array_equal(Ar[19], A0[19])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_weighted_fit_live(oracles, refs, dtype):
+    """fit_collective_explicit_als with NA_as_zero_X AND observation weights, no side information (collective.c:8680-8717,
+    :8851-8888: optimizeA Case 4 with the bias / mean constants and wsumA / wsumB = sum of the row's weights + the number of its
+    absent entries, :7991-8022): closed form and CG, with and without biases / centring, scale_lam."""
+    O, R = oracles[dtype], refs[dtype]
+    m, n, row, col, val, wt = weights_problem(dtype, seed=92, m=150, n=110, nnz=3000)     # (entries ordered by column, see there)
+    k = 8
+    rng = np.random.default_rng(18)
+    cases = [dict(use_cg=False), dict(use_cg=True, finalize_chol=False), dict(use_cg=False, scale_lam=True),
+             dict(use_cg=True, finalize_chol=False, scale_lam=True, user_bias=False), dict(use_cg=False, center=False, item_bias=False),
+             dict(use_cg=True, user_bias=False, item_bias=False, center=False, finalize_chol=True)]
+    for o in cases:
+        A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+        bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+        kw = dict(lam=0.4, niter=3, nthreads=2, NA_as_zero_X=True, weight=wt, **o)
+        ro = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        rr = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        assert ro["ret"] == 0 and rr["ret"] == 0, o
+        keys = ("A", "B") + (("biasA",) if o.get("user_bias", True) else ()) + (("biasB",) if o.get("item_bias", True) else ())
+        for key in keys:
+            assert rel_err(ro[key], rr[key]) < 100 * TOL[dtype], (o, key)
+        assert abs(ro["glob_mean"] - rr["glob_mean"]) < 1e-6 * max(1.0, abs(rr["glob_mean"])), o
