@@ -223,7 +223,7 @@ def main():
     for d in kernels:
         other = [e for e in kernels if e["kernel"] == d["kernel"] and e["step"] != d["step"]]
         # (a launch that runs beside other kernels has no duration of its own, and rocprof's average mixes it in:
-        #  CMFREC_HIP_VH_INLINE=1 keeps every launch in line for a clean cross-check, profiles/README.md)
+        #  CMFREC_HIP_BINS_PAR=1 keeps every launch in line for a clean cross-check, profiles/README.md)
         mixed = d["overlapped"] or (other and other[0]["overlapped"])
         d["rocprof"] = {"kernels": prof_names[inv[d["kernel"]]],
                         "avg_ms_over_both_halfsteps": None if mixed else
@@ -341,13 +341,14 @@ def main():
 
 
 def inline_bin_leg(sess, step_fn, sync_fn, nsteps, names, k, itemsize):
-    """A few more iterations with the nnz bins of a half-step IN LINE (CMFREC_HIP_BINS_PAR=1, read by the library at every
-    launch): only then a bin's HIP-event pair -- recorded on the stream the kernel is launched on -- brackets that kernel alone, and
+    """A few more iterations with the nnz bins of a half-step IN LINE (CMFREC_HIP_BINS_PAR=1, read again through
+    cmfrec_hip_reload_switches): only then a bin's HIP-event pair -- recorded on the stream the kernel is launched on -- brackets that kernel alone, and
     only then `rocprofv3 --kernel-trace --stats` of the same kernels has durations of their own to compare with
     (profiles/r04/*_kernel_stats_inline.csv).  Returns one row per (half-step, bin): its own duration, algorithmic GB/s and
     fraction of the HBM peak -- the per-kernel roofline the side-by-side default cannot show."""
     keep = os.environ.get("CMFREC_HIP_BINS_PAR")
     os.environ["CMFREC_HIP_BINS_PAR"] = "1"
+    sess.reload_switches()
     try:
         step_fn(); sync_fn()
         sess.reset_timers()
@@ -370,6 +371,7 @@ def inline_bin_leg(sess, step_fn, sync_fn, nsteps, names, k, itemsize):
             os.environ.pop("CMFREC_HIP_BINS_PAR", None)
         else:
             os.environ["CMFREC_HIP_BINS_PAR"] = keep
+        sess.reload_switches()
         sess.reset_timers()
 
 

@@ -257,7 +257,10 @@ __host__ __device__ constexpr int gram_ld(int S) { return 8 * S + 1; }
 // (pass_vector_in_lds: double precision) the group's weights are plain reads at any offset, so those kernels take GR = S rows per
 // group; the cross-lane form (single precision: bcast8 moves inside an 8-lane group) keeps 8.  Leading dimension for GR = S: the
 // smallest LD >= 8 S with S LD = 8 or 24 (mod 32), which puts the four lane groups of a half-wavefront 16 banks apart.
-template <typename T> __host__ __device__ constexpr int gram_rows(int S) { return pass_vector_in_lds<T>() ? S : 8; }
+#ifndef CMF_GRAM_ROWS_BY_K
+#define CMF_GRAM_ROWS_BY_K 1         // 0: eight rows per lane group everywhere (rounds 1-4; A/B build)
+#endif
+template <typename T> __host__ __device__ constexpr int gram_rows(int S) { return (CMF_GRAM_ROWS_BY_K && pass_vector_in_lds<T>()) ? S : 8; }
 __host__ __device__ constexpr int gram_ld_rows(int S, int GR)
 {
     if (GR == 8) return gram_ld(S);

@@ -179,7 +179,6 @@ __global__ void __launch_bounds__(256, (pair_waves_per_simd<T, GREG_>()))
 cg_rows_pair_kernel(const CgParams<T> P)
 {
     static_assert(NE == 0 || NE == 4 || NE == 8, "entries per lane");
-    constexpr bool MIX = NE == 0;
     constexpr bool GRAM = IMPLICIT || GRAMX;
     static_assert(!GREG_ || NE == 4, "the register copy of the Gramian fits beside the 16-slot tile only");
     constexpr bool GREG = GRAM && GREG_;

@@ -38,6 +38,52 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define HIP_CHECK(x) ::cmfhip::hip_check((x), #x, __FILE__, __LINE__)
 
+// Run-time switches: the CMFREC_HIP_* environment variables are read ONCE PER SESSION -- when a session is
+// created (every level-1 / level-2 entry point creates its own) or when cmfrec_hip_reload_switches() is called -- into this
+// process-wide struct, instead of a getenv per launch path.  Each is an A/B switch or an on-device cross-check (another kernel
+// for the same row systems, exercised by tests/test_gpu_switches.py and the tests that name it), a test hook, or a deployment
+// setting (devices, exchange, size limit); none selects another model.
+struct Switches {
+    bool poison_lds = false;        // CMFREC_HIP_POISON_LDS: NaN patterns in LDS and fresh buffers in front of the launches (test hook)
+    int vh_min = 0;                 // CMFREC_HIP_VH_MIN: where the split rows begin (0: by precision and path)
+    int vh = 0;                     // CMFREC_HIP_VH: split rows 1 = stream (launch pair per CG pass), 2 = gram (one gather, CG on the row's Gramian); 0: by shape
+    bool gram_slice = false;        // CMFREC_HIP_GRAM_KERNEL=slice: LDS-staged workgroup kernel for the slice partials
+    bool gemm_library = false;      // CMFREC_HIP_GEMM_OWN=0: rocBLAS instead of the own MFMA GEMM
+    int pair = 0;                   // CMFREC_HIP_PAIR=1: rows of <= 32 entries two per wavefront
+    int bins_par = 2;               // CMFREC_HIP_BINS_PAR: streams the nnz bins of a half-step are spread over (1: in line)
+    bool cg_generic = false;        // CMFREC_HIP_CG_KERNEL=generic: lane <-> unknown CG kernel everywhere
+    int chol = 0;                   // CMFREC_HIP_CHOL: 1 = rows (workgroup-per-row kernel only), 2 = noslices
+    int gramk = -1;                 // CMFREC_HIP_GRAMK: 0 / 1 force the producer / consumer pair off / on (-1: by width)
+    int gramk_batch = 0;            // CMFREC_HIP_GRAMK_BATCH: work items per batch (test hook: several batches on a small problem)
+    int lowrank = -1;               // CMFREC_HIP_LOWRANK: 0 / 1 force the low-rank row kernel off / on (-1: by shape)
+    bool eig_jacobi = false;        // CMFREC_HIP_EIG=jacobi: the built-in eigen-decomposition instead of rocSOLVER's
+    int debug_skip = 0;             // CMFREC_HIP_CG_SKIP / _CHOL_SKIP / _WAVE_SKIP (timing builds only: -DCMF_CG_DEBUG / -DCMF_CHOL_DEBUG)
+    bool debug_ticks = false;       // CMFREC_HIP_GRAM_TICKS / _CHOL_TICKS (timing builds only)
+    void reload()
+    {
+        auto str = [](const char *n) -> const char * { const char *v = getenv(n); return (v != nullptr && v[0] != 0) ? v : nullptr; };
+        auto num = [&](const char *n, int dflt) -> int { const char *v = str(n); return v ? atoi(v) : dflt; };
+        poison_lds = str("CMFREC_HIP_POISON_LDS") != nullptr;
+        vh_min = num("CMFREC_HIP_VH_MIN", 0);
+        const char *v = str("CMFREC_HIP_VH");
+        vh = !v ? 0 : strcmp(v, "stream") == 0 ? 1 : strcmp(v, "gram") == 0 ? 2 : 1;       // (any other value streams, as before)
+        v = str("CMFREC_HIP_GRAM_KERNEL"); gram_slice = v && strcmp(v, "slice") == 0;
+        v = str("CMFREC_HIP_GEMM_OWN"); gemm_library = v && v[0] == '0';
+        pair = num("CMFREC_HIP_PAIR", 0);
+        bins_par = num("CMFREC_HIP_BINS_PAR", 2);
+        v = str("CMFREC_HIP_CG_KERNEL"); cg_generic = v && strcmp(v, "generic") == 0;
+        v = str("CMFREC_HIP_CHOL"); chol = !v ? 0 : strcmp(v, "rows") == 0 ? 1 : strcmp(v, "noslices") == 0 ? 2 : 0;
+        gramk = num("CMFREC_HIP_GRAMK", -1);
+        gramk_batch = num("CMFREC_HIP_GRAMK_BATCH", 0);
+        lowrank = num("CMFREC_HIP_LOWRANK", -1);
+        v = str("CMFREC_HIP_EIG"); eig_jacobi = v && strcmp(v, "jacobi") == 0;
+        debug_skip = num("CMFREC_HIP_CG_SKIP", num("CMFREC_HIP_CHOL_SKIP", num("CMFREC_HIP_WAVE_SKIP", 0)));
+        debug_ticks = str("CMFREC_HIP_GRAM_TICKS") != nullptr || str("CMFREC_HIP_CHOL_TICKS") != nullptr;
+    }
+};
+inline Switches &switches_mut() { static Switches sw; static bool first = (sw.reload(), true); (void)first; return sw; }
+inline const Switches &switches() { return switches_mut(); }
+
 template <typename T>
 struct DevBuf {
     T *ptr = nullptr;
@@ -59,7 +105,7 @@ struct DevBuf {
         n = count;
         owned = true;
         if (count) HIP_CHECK(hipMalloc((void **)&ptr, count * sizeof(T)));
-        if (count && getenv("CMFREC_HIP_POISON_LDS") != nullptr) {          // test hook (poison_lds below): device buffers too
+        if (count && switches().poison_lds) {          // test hook (poison_lds below): device buffers too
             HIP_CHECK(hipMemset(ptr, 0xFF, count * sizeof(T)));
             HIP_CHECK(hipDeviceSynchronize());
         }
@@ -102,10 +148,8 @@ constexpr int BIN_MIN_NNZ[NBINS] = {1025, 257, 129, 65, 33, 1};
 // against 2.65 ms).  CMFREC_HIP_VH_MIN overrides.
 inline int vh_min_env()
 {
-    static const int v = getenv("CMFREC_HIP_VH_MIN")
-                             ? std::min(sizeof(real_t) == 4 ? BIN_MIN_NNZ[BIN_VHEAVY] : (1 << 30), std::max(258, atoi(getenv("CMFREC_HIP_VH_MIN"))))
-                             : 0;
-    return v;
+    const int v = switches().vh_min;
+    return v > 0 ? std::min(sizeof(real_t) == 4 ? BIN_MIN_NNZ[BIN_VHEAVY] : (1 << 30), std::max(258, v)) : 0;
 }
 
 struct SparseShard {
@@ -160,7 +204,7 @@ struct SparseShard {
     // latencies and runs on the second stream beside the other bins
     bool vh_runs_aside(int num_cus) const
     {
-        return bin_rows[0] > 0 && n_chunks <= 4 * num_cus && getenv("CMFREC_HIP_VH_INLINE") == nullptr;
+        return bin_rows[0] > 0 && n_chunks <= 4 * num_cus;
     }
     static constexpr int LONG_ROW = 1024;
     // rows (they lead the processing order) with more than `maxlen` entries, for the nnz-bin boundaries 32 .. 1024
@@ -277,8 +321,7 @@ struct SparseShard {
         else if (sizeof(real_t) == 8) {
             double nnz513 = 0;
             for (int q = 0; q < nrows && lens_sorted[q] >= 513u; q++) nnz513 += (double)lens_sorted[q];
-            const char *vh_env = getenv("CMFREC_HIP_VH");
-            const bool gram = (vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : gram_pays(nnz513, n_other, opp_row_bytes_hint);
+            const bool gram = (switches().vh != 0) ? switches().vh == 2 : gram_pays(nnz513, n_other, opp_row_bytes_hint);
             if (gram && opp_row_bytes_hint <= 16 * 4 * sizeof(real_t)) vh_min = 513;
         }
         long long vh_total = 0;
@@ -457,8 +500,7 @@ inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
     // CUs idle (U^T A: 512 x 256 outputs over 1.5 M rows).  CMFREC_HIP_GEMM_OWN=0 calls rocBLAS instead (A/B timing and
     // cross-check; row-major C is the column-major C^T = B^T op(A)^T, so: first operand B, second operand A with the
     // transposition flag inverted).
-    const char *own_env = getenv("CMFREC_HIP_GEMM_OWN");
-    const bool use_own = (g_gemm_force >= 0) ? (g_gemm_force != 0) : !(own_env != nullptr && own_env[0] == '0');
+    const bool use_own = (g_gemm_force >= 0) ? (g_gemm_force != 0) : !switches().gemm_library;
     if (use_own) {
         DeviceInfo &d = const_cast<DeviceInfo &>(dev);
         const int bm = (M + GEMM_BM - 1) / GEMM_BM, bn = (N + GEMM_BN - 1) / GEMM_BN;
@@ -587,7 +629,7 @@ __global__ void __launch_bounds__(256) poison_lds_kernel(int words)
 }
 inline void poison_lds(hipStream_t st, int num_cus)
 {
-    if (getenv("CMFREC_HIP_POISON_LDS") == nullptr) return;
+    if (!switches().poison_lds) return;
     constexpr int BYTES = 80 * 1024;                                         // two workgroups cover the 160 KB of a CU
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -637,16 +679,12 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
 }
 
 // CMFREC_HIP_PAIR: how the rows of at most 32 entries run.  0 (default): one row per wavefront (cg_rows_tiny_kernel).  1: two rows
-// per wavefront, ONE launch for the bin (cg_pair_kernels.hpp; the 16-slot tile for the pairs of rows of <= 16 entries).  2: two
-// launches -- the rows of 17..32 entries on the 32-slot build, the rows of <= 16 on the build that keeps its Gramian elements in
-// registers.  Measured side by side in round 5 (profiles/r05/r05_e_*): the pair kernel issues 15 % fewer vector instructions per
-// row, but reads its Gramian from LDS in every pass (no room for a register copy beside two rows' tiles) and a pair costs its
-// longer row -- C2 3.375 (1) / 3.384 (2) against 3.348 ms (0); it stays as an A/B switch and on-device cross-check.
-inline int cg_pair_mode()
-{
-    static const int mode = getenv("CMFREC_HIP_PAIR") != nullptr ? atoi(getenv("CMFREC_HIP_PAIR")) : 0;
-    return mode;
-}
+// per wavefront, one launch for the bin (cg_pair_kernels.hpp; the 16-slot tile for the pairs of rows of <= 16 entries).  Measured side
+// by side in round 5 (profiles/r05/r05_e_*): the pair kernel issues 15 % fewer vector instructions per row, but reads its Gramian
+// from LDS in every pass (no room for a register copy beside two rows' tiles) and a pair costs its longer row -- C2 3.375 against
+// 3.348 ms; a second launch for the rows of <= 16 entries with the Gramian in registers: 3.384.  It stays as an A/B switch and
+// on-device cross-check.
+inline int cg_pair_mode() { return switches().pair; }
 
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st, int n_gt16)
@@ -661,8 +699,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     poison_lds(st, dev.num_cus);
     // One launch for the bin (a second launch for the rows of <= 16 entries costs more in launch tails beside the other bins than
     // the shorter tile saves, profiles/r04/r04_z2); the kernels take the 16-slot tile where the rows allow it.
-    static const char *tiny16_env = getenv("CMFREC_HIP_TINY16");
-    const bool tiny16_on = (tiny16_env == nullptr) || tiny16_env[0] != '0';
+    constexpr bool tiny16_on = true;
     const int count_le16 = std::min(count, std::max(0, first + count - std::max(first, n_gt16)));
     size_t smem = ((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) * sizeof(real_t);
     const int di = std::min(std::max(dev.device, 0), MAX_DEVICES - 1);
@@ -683,19 +720,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
         const int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, Pk);
     };
-    if (cg_pair_mode() == 2 && tiny16_on && count_le16 > 0) {
-        // two launches (the second on a spare counter set): rows of 17..32 entries, then rows of <= 16 with the Gramian in registers
-        const int n_long = count - count_le16;
-        if (n_long > 0) {
-            CgParams<real_t> Pl = P1;
-            Pl.nrows = n_long; Pl.pair_split = n_long;
-            pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 8, false>, 0, Pl, n_long);
-        }
-        CgParams<real_t> Ps = P1;
-        Ps.order += n_long; Ps.desc += n_long; Ps.nrows = count_le16; Ps.pair_split = 0;
-        Ps.counter = dev.row_counter.ptr + cg_counter_offset(NBINS + 1);
-        pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 4, true>, 1, Ps, count_le16);
-    } else if (cg_pair_mode() != 0) {
+    if (cg_pair_mode() != 0) {
         // two rows per wavefront, paired in processing order inside their length class (round 5)
         const bool mixed = tiny16_on && count_le16 > 0;
         P1.pair_split = mixed ? count - count_le16 : count;        // rows of more than 16 entries lead the bin
@@ -730,8 +755,7 @@ template <bool GRAMX>
 inline bool vh_takes_gram(int k, const SparseShard &X)
 {
     if (GRAMX || k > 16 * GRAM_NTT) return false;
-    const char *vh_env = getenv("CMFREC_HIP_VH");
-    return (vh_env != nullptr) ? strcmp(vh_env, "gram") == 0 : X.prefer_gram((size_t)k * sizeof(real_t));
+    return (switches().vh != 0) ? switches().vh == 2 : X.prefer_gram((size_t)k * sizeof(real_t));
 }
 
 template <int S, bool IMPLICIT, bool GRAMX = false>
@@ -756,7 +780,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         G.part = X.gram_part.ptr; G.n_slices = X.n_slices; G.nvh = nvh;
         P.nrows = nvh;
 #ifdef CMF_CG_DEBUG
-        if (getenv("CMFREC_HIP_GRAM_TICKS") != nullptr) {
+        if (switches().debug_ticks) {
             static unsigned long long *d_t = nullptr;
             unsigned long long h[4];
             if (d_t == nullptr) { HIP_CHECK(hipMalloc((void **)&d_t, sizeof(h))); HIP_CHECK(hipMemset(d_t, 0, sizeof(h))); }
@@ -774,8 +798,7 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
         // slice partials: one wavefront per slice straight from the gather (gram_wave_kernel), or the LDS-staged workgroup
         // kernel (CMFREC_HIP_GRAM_KERNEL=slice)
         poison_lds(dev.stream, dev.num_cus);
-        const char *gk_env = getenv("CMFREC_HIP_GRAM_KERNEL");
-        const bool slice_kernel = gk_env != nullptr && strcmp(gk_env, "slice") == 0;
+        const bool slice_kernel = switches().gram_slice;
         if (slice_kernel)
             hipLaunchKernelGGL((gram_slice_kernel<real_t, IMPLICIT>), dim3(std::min(X.n_slices, dev.num_cus * 2)), dim3(64 * GRAM_NW), 0,
                            dev.stream, P, G);
@@ -819,16 +842,8 @@ inline void launch_cg_vheavy(const DeviceInfo &dev_, CgParams<real_t> P, const S
 // number of streams the nnz bins of a half-step are spread over (CMFREC_HIP_BINS_PAR; 1 = one after the other)
 inline int cg_bin_streams()
 {
-    const char *e = getenv("CMFREC_HIP_BINS_PAR");
-    const int n = e ? atoi(e) : 2;      // C2: 4.19 (1) / 3.99 (2) / 4.21 (3) / 4.11 (4) / 4.30 (6) ms per iteration, profiles/r03_d
+    const int n = switches().bins_par;  // C2: 4.19 (1) / 3.99 (2) / 4.21 (3) / 4.11 (4) / 4.30 (6) ms per iteration, profiles/r03_d
     return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
-}
-
-// CMFREC_HIP_HEAVY_SPLIT=0: the whole 257..1024 bin on eight-wave teams (A/B switch, cross-check)
-inline bool heavy_split_off()
-{
-    static const bool off = getenv("CMFREC_HIP_HEAVY_SPLIT") != nullptr && getenv("CMFREC_HIP_HEAVY_SPLIT")[0] == '0';
-    return off;
 }
 
 // one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row)
@@ -839,7 +854,7 @@ inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, 
     switch (bin) {
         case BIN_HEAVY:
 #ifdef CMFREC_HIP_FLOAT
-            if (!heavy_split_off()) {
+            {
                 // single precision: rows of 257..512 entries on four waves with two resident tiles each (cg_rows_kernel, NRES_),
                 // the longer ones on eight; one event pair around both launches, the second on a spare counter set
                 const int n_long8 = std::min(count, std::max(0, X.n_gt512 - first));
@@ -869,8 +884,7 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
     if (dev.row_counter.n < ROW_COUNTER_INTS) const_cast<DeviceInfo &>(dev).row_counter.alloc(ROW_COUNTER_INTS);
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, ROW_COUNTER_INTS * sizeof(int), dev.stream));   // work counters of the bins
     // (The Gramian path is two launches, not two per pass, and its slices are short when the rows are few: it stays in line.)
-    const bool vh_aside = X.bin_rows[BIN_VHEAVY] > 0 && X.vh_runs_aside(dev.num_cus) &&
-                          (!vh_takes_gram<GRAMX>(P.k, X) || getenv("CMFREC_HIP_VH_GRAM_ASIDE") != nullptr);
+    const bool vh_aside = X.bin_rows[BIN_VHEAVY] > 0 && X.vh_runs_aside(dev.num_cus) && !vh_takes_gram<GRAMX>(P.k, X);
     // A shard that is one of several parts of a block (multi-GPU overlap, session.hip) has a quarter of the rows per
     // launch, so ramp-up and tail of every bin weigh four times as much: its bins alternate between the two streams,
     // the next bin fills the CUs the previous one is vacating.  (Not for whole blocks: there the per-bin event timings
@@ -995,7 +1009,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     if (c.X2) { P.indptr2 = c.X2->p.ptr; P.indices2 = c.X2->i.ptr; P.values2 = c.X2->v.ptr; P.C2 = c.C2; }
     P.Bi = c.Bi; P.BiTBi = c.BiTBi; P.ki = c.ki; P.w_imp = c.w_imp;
 #ifdef CMF_CG_DEBUG
-    if (const char *e = getenv("CMFREC_HIP_CG_SKIP")) P.dbg = atoi(e);
+    P.dbg = switches().debug_skip;
 #endif
 #ifdef CMF_CG_TICKS
     P.ticks = cg_ticks_buffer();

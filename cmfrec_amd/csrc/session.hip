@@ -21,15 +21,7 @@ namespace cmfhip {
 thread_local std::string g_last_error;
 thread_local int g_last_rc = 0;      // return code that goes with g_last_error where the entry point returns a pointer
 
-CgVariant cg_variant_from_env()
-{
-    static int cached = -1;
-    if (cached < 0) {
-        const char *e = getenv("CMFREC_HIP_CG_KERNEL");
-        cached = (e && strcmp(e, "generic") == 0) ? 1 : 0;
-    }
-    return cached ? CgVariant::Generic : CgVariant::Auto;
-}
+CgVariant cg_variant_from_env() { return switches().cg_generic ? CgVariant::Generic : CgVariant::Auto; }
 
 inline dim3 grid1d(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
@@ -131,17 +123,17 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     // run side by side on two streams.  CMFREC_HIP_CHOL=rows keeps everything on the workgroup-per-row kernel (A/B
     // switch and on-device cross-check).
     {
-        static const char *chol_env = getenv("CMFREC_HIP_CHOL");
+        const int chol_sw = switches().chol;        // 1: rows, 2: noslices
         const bool border = (c.kt > 16) && ((c.kt - 1) % 16 == 0);
         const int nbw = (c.kt - (border ? 1 : 0) + 15) / 16;
         const bool wave_ok = X != nullptr && !two_src && !nonneg && !l1on && !c.rhs_only && nbw <= 8 && !weighted &&
                              (c.mode == CHOL_EXPLICIT || c.mode == CHOL_IMPLICIT || c.mode == CHOL_COLLECTIVE ||
                               c.mode == CHOL_COLLECTIVE_IMPLICIT) &&
-                             !(chol_env != nullptr && strcmp(chol_env, "rows") == 0);
+                             chol_sw != 1;
         if (wave_ok) {
             // rows beyond 1024 entries: sliced (their slice tables are the ones of the split-row CG path, SparseShard::sl_*);
             // CMFREC_HIP_CHOL=noslices leaves them to the workgroup-per-row kernel (A/B switch)
-            const bool sliced = !(chol_env != nullptr && strcmp(chol_env, "noslices") == 0);
+            const bool sliced = chol_sw != 2;
             const int n_heavy = std::min(X->bin_rows[BIN_VHEAVY], P.nrows);
             const int total = P.nrows;
             DeviceInfo &d = const_cast<DeviceInfo &>(dev);
@@ -187,7 +179,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 SLT.n_slices = X->n_slices;
             }
             SLT.n_heavy = n_heavy;
-            { static const int skip = getenv("CMFREC_HIP_WAVE_SKIP") ? atoi(getenv("CMFREC_HIP_WAVE_SKIP")) : 0; SLT.dbg_skip = skip; }
+            SLT.dbg_skip = switches().debug_skip;
             const bool cg_wide = c.cg_wide != nullptr;
             if ((sizeof(real_t) == 8 && nbw > 6) || cg_wide) {
                 // (cg_wide: the second kernel is the CG on the summed partials, gram_cg_wide_kernels.hpp -- every precision and width)
@@ -298,9 +290,9 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
         // wavefronts per row or slice, operands straight from the gather), the partial matrices through HBM, the factorisation
         // and the substitutions by gramk_consumer_kernel (four wavefronts per row, two rows per CU).  CMFREC_HIP_GRAMK=0 keeps
         // the 16-wavefront row kernel with its own LDS-staged rank-k loop (A/B switch and cross-check).
-        const char *gk_env = getenv("CMFREC_HIP_GRAMK");
+        const bool gk_off = switches().gramk == 0;
         const bool gk_ok = X != nullptr && T == 17 && !two_src && c.koff == 0 && !weighted && !c.rhs_only && c.values_override == nullptr &&
-                           (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && !nonneg && !l1on && !(gk_env != nullptr && gk_env[0] == '0');
+                           (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && !nonneg && !l1on && !gk_off;
         if (gk_ok) {
             DeviceInfo &d = const_cast<DeviceInfo &>(dev);
             const int total = P.nrows;
@@ -314,7 +306,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             const std::vector<int> &ho = X->h_row_sl_off;
             int max_row_items = 1;
             for (int r = 0; r < n_heavy; r++) max_row_items = std::max(max_row_items, ho[r + 1] - ho[r]);
-            const int batch_env = getenv("CMFREC_HIP_GRAMK_BATCH") ? atoi(getenv("CMFREC_HIP_GRAMK_BATCH")) : 0;
+            const int batch_env = switches().gramk_batch;
             const int BATCH = batch_env > 0 ? batch_env : 32768;                      // x 158 KB = 5.2 GB of partials
             const size_t cap_items = (size_t)std::min<long long>((long long)nsl + (total - n_heavy), std::max(BATCH, max_row_items));
             // (Tried: two half-size buffers with the consumer of a batch on the second stream beside the producer of the next
@@ -340,7 +332,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
             // two persistent workgroups per CU fill the register file; a few slots stay open so that the small launches of
             // another stream (the eigen-decomposition chain of the low-rank rows, EigCache) are dispatched beside a batch
             // instead of behind it
-            const int gk_open = getenv("CMFREC_HIP_GK_OPEN") ? atoi(getenv("CMFREC_HIP_GK_OPEN")) : GK_OPEN_SLOTS;
+            const int gk_open = GK_OPEN_SLOTS;
             const int gk_grid = std::max(2 * dev.num_cus - gk_open, dev.num_cus / 2);
             auto run_batch = [&](int item0, int item1, int row0, int row1) {
                 if (ctr + 2 > 60) ctr = 4;
@@ -391,8 +383,8 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
 {
     const int T = chol_tiles(c.kt);
 #ifdef CMF_CHOL_DEBUG
-    if (const char *e = getenv("CMFREC_HIP_CHOL_SKIP")) P.dbg = atoi(e);
-    if (getenv("CMFREC_HIP_CHOL_TICKS") != nullptr && T >= 16) {
+    P.dbg = switches().debug_skip;
+    if (switches().debug_ticks && T >= 16) {
         // phase timers of the widest kernel: printed (and reset) by the launch that follows, i.e. per half-step
         static unsigned long long *d_ticks = nullptr;
         unsigned long long h[8];
@@ -508,10 +500,9 @@ static int launch_cg_wide(const DeviceInfo &dev, const CgCall &c, const SparseSh
 {
     const bool border = (c.k > 16) && ((c.k - 1) % 16 == 0);
     const int nbw = (c.k - (border ? 1 : 0) + 15) / 16;
-    static const char *chol_env = getenv("CMFREC_HIP_CHOL");
     if (c.implicit || c.k <= 64 || nbw > 8 || c.precond || c.X2 != nullptr || c.Bi != nullptr || c.koff != 0 || X.weighted() ||
         dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 ||      // (launch_chol's wave path is off then)
-        cg_variant_from_env() == CgVariant::Generic || (chol_env != nullptr && strcmp(chol_env, "rows") == 0) ||
+        cg_variant_from_env() == CgVariant::Generic || switches().chol == 1 ||
         (c.kc > 0 && (c.CtC == nullptr || c.UC == nullptr || c.kc > c.k)) || gcw_lds_elems<real_t>(c.k) * sizeof(real_t) > (size_t)160 * 1024)
         return -1;
     CgParams<real_t> P;
@@ -620,11 +611,10 @@ static void issue_eig(DeviceInfo &d, EigCache &E, const real_t *Minit, int kc, h
     if (!E.ev) HIP_CHECK(hipEventCreateWithFlags(&E.ev, hipEventDisableTiming));
     HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), after, 0));
     const RocSolverApi &rs = rocsolver_api();
-    // CMFREC_HIP_EIG=jacobi (read at every launch: a test can set it per case) takes the built-in kernel
-    const char *eig_env = getenv("CMFREC_HIP_EIG");
+    // CMFREC_HIP_EIG=jacobi takes the built-in kernel
     static bool dsyevd_bad = false;       // the library reported a failed decomposition once: the built-in kernel from then on
     bool done = false;
-    if (rs.dsyevd != nullptr && !dsyevd_bad && !(eig_env != nullptr && strcmp(eig_env, "jacobi") == 0)) {
+    if (rs.dsyevd != nullptr && !dsyevd_bad && !switches().eig_jacobi) {
         E.D.alloc_at_least((size_t)kc); E.E.alloc_at_least((size_t)kc); E.info.alloc_at_least(1);
         hipLaunchKernelGGL(eig_pack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), Minit, E.W.ptr, kc);
         rocblas_handle he = d.ensure_blas_eig();
@@ -663,21 +653,21 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
                                      const real_t *Um, int p_self, real_t w, int k, int rows_b, EigCache *mine = nullptr,
                                      EigCache *next = nullptr, int kc_next = 0)
 {
-    const char *lr_env = getenv("CMFREC_HIP_LOWRANK");
+    const int lr_sw = switches().lowrank;       // CMFREC_HIP_LOWRANK: 0 / 1 force the path off / on
     const int kt = c.kt, kc = c.kc, k_side_self = c.koff;
     // rows of up to lr_max entries: the s x s system is at most half the k_t x k_t one (and 8 blocks in single, 4 in double)
     const int lr_type_max = (sizeof(real_t) == 4) ? 128 : 64;
     const int lr_max = (kt >= 256 && lr_type_max >= 128) ? 128 : (kt >= 128 ? 64 : 32);
     const int n_full = X.rows_longer_than(lr_max, X.nrows);          // positions [0, n_full): full factorisation
     const int n_light = X.nrows - n_full;
-    const bool lr_ok = !(lr_env != nullptr && lr_env[0] == '0') && c.mode == CHOL_COLLECTIVE && c.Mfull == nullptr && c.X2 == nullptr &&
+    const bool lr_ok = lr_sw != 0 && c.mode == CHOL_COLLECTIVE && c.Mfull == nullptr && c.X2 == nullptr &&
                        !X.weighted() &&
                        !c.scale_bias_const && !dev.nonneg_now && !c.nonneg && dev.l1_now == (real_t)0 && dev.l1_last_now == (real_t)0 &&
                        c.rows_with_u >= X.nrows && !c.rhs_prefilled_all && kt <= 320 && kt >= 64 && kc > 0 && p_self > 0 &&
                        // the penalty must be a multiple of the identity on the rotated block: the last unknown's own lambda
                        // (a bias) has to sit outside of it
                        (kt - 1 >= kc || c.lam_last == c.lam) &&
-                       ((lr_env != nullptr && lr_env[0] == '1') || (n_light >= 32768 && kt >= 96));
+                       (lr_sw == 1 || (n_light >= 32768 && kt >= 96));
     S.last_rows = 0; S.last_eig = 0;
     if (!lr_ok || n_light <= 0) return -1;
     hipStream_t st = dev.stream;
@@ -772,16 +762,16 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
 // (k_t = 129, double): 38 % of the rows hold at most 64 entries.  -1 when the path does not apply.
 static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const SparseShard &X)
 {
-    const char *lr_env = getenv("CMFREC_HIP_LOWRANK");
+    const int lr_sw = switches().lowrank;       // CMFREC_HIP_LOWRANK: 0 / 1 force the path off / on
     const int kt = c.kt;
     const int lr_type_max = (sizeof(real_t) == 4) ? 128 : 64;
     const int lr_max = (kt >= 256 && lr_type_max >= 128) ? 128 : (kt >= 128 ? 64 : 32);
     const int n_rows = X.n_nonempty;                                  // rows without entries stay as they are (common.c:3270)
     const int n_full = X.rows_longer_than(lr_max, n_rows);
     const int n_light = n_rows - n_full;
-    const bool ok = !(lr_env != nullptr && lr_env[0] == '0') && !X.weighted() && c.koff == 0 && c.X2 == nullptr && !c.rhs_only &&
+    const bool ok = lr_sw != 0 && !X.weighted() && c.koff == 0 && c.X2 == nullptr && !c.rhs_only &&
                     c.values_override == nullptr && !c.nonneg && !dev.nonneg_now && dev.l1_now == (real_t)0 && dev.l1_last_now == (real_t)0 &&
-                    kt <= 320 && ((lr_env != nullptr && lr_env[0] == '1') ? kt >= 40 : (kt >= 96 && n_light >= 2048));
+                    kt <= 320 && (lr_sw == 1 ? kt >= 40 : (kt >= 96 && n_light >= 2048));
     if (!ok || n_light <= 0) return -1;
     CholCall cf = c;
     cf.row_limit = n_full;
@@ -823,6 +813,7 @@ static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const 
 
 static void init_device(DeviceInfo &dev, int device)
 {
+    switches_mut().reload();           // the environment switches, once per session / operator call (device.hpp, Switches)
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
@@ -950,6 +941,7 @@ const char *cmfrec_hip_build_info(void)
 #endif
 }
 const char *cmfrec_hip_last_error(void) { return g_last_error.c_str(); }
+void cmfrec_hip_reload_switches(void) { switches_mut().reload(); }
 
 cmfrec_hip_session *cmfrec_hip_session_create(const cmfrec_hip_model *model, int device)
 {
@@ -2529,7 +2521,7 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
     if (which == 'A' && !s->XrParts.empty()) return 1;                    // the bins of a part alternate between two streams
     if (cg_bin_streams() > 1) return 1;                                    // the bins of a half-step run side by side (launch_cg_S)
     // (the Gramian path stays in line, launch_cg_S)
-    const bool gram_in_line = cmfrec_hip_session_vh_mode(s, which) == 2 && getenv("CMFREC_HIP_VH_GRAM_ASIDE") == nullptr;
+    const bool gram_in_line = cmfrec_hip_session_vh_mode(s, which) == 2 && true;
     return (bin == BIN_VHEAVY && X.vh_runs_aside(s->dev.num_cus) && !gram_in_line) ? 1 : 0;
 }
 
@@ -2553,8 +2545,7 @@ int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which)
 {
     const SparseShard &X = (which == 'A') ? s->Xr : s->Xc;
     if (X.bin_rows[BIN_VHEAVY] <= 0) return 0;
-    const char *e = getenv("CMFREC_HIP_VH");
-    const bool gram = (e != nullptr) ? strcmp(e, "gram") == 0 : X.prefer_gram((size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t));
+    const bool gram = (switches().vh != 0) ? switches().vh == 2 : X.prefer_gram((size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t));
     return (gram && s->mdl.k + s->mdl.k_main <= 16 * GRAM_NTT) ? 2 : 1;
 }
 

@@ -271,3 +271,7 @@ class AlsSession:
 
     def reset_timers(self):
         self.lib.cmfrec_hip_session_reset_timers(self.handle)
+
+    def reload_switches(self):
+        """Read the CMFREC_HIP_* environment switches again (they are read when a session is created)."""
+        self.lib.cmfrec_hip_reload_switches()

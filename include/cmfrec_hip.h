@@ -550,6 +550,9 @@ int cmfrec_hip_sizeof_real(void);
 /* sizeof(cmfrec_hip_model) as compiled: lets a binding verify its mirror of the struct before the first call. */
 int cmfrec_hip_sizeof_model(void);
 const char *cmfrec_hip_build_info(void);
+/* The CMFREC_HIP_* environment switches are read when a session is created; this reads them again for the
+ * sessions that already exist (bench.py's pass with the nnz bins in line). */
+void cmfrec_hip_reload_switches(void);
 
 #ifdef __cplusplus
 }

@@ -91,7 +91,8 @@ def test_c2_whole_fit_and_precision_at_10(c2):
     p_ref = gc.precision_at_k(r["A"], r["B"], *args)
     p_hip = gc.precision_at_k(mdl.A_, mdl.B_, *args)
     print("C2 15 iterations: rel. Frobenius A %.2e B %.2e; P@10 reference %.6f, HIP %.6f" % (eA, eB, p_ref, p_hip))
-    assert p_ref > 0.01, "the fit must rank held-out items well above chance"
+    chance = 10.0 * keep_te.sum() / len(users) / n            # ten random items against a user's held-out ones
+    assert p_ref > 20 * chance, "the fit must rank held-out items well above chance"
     assert abs(p_ref - p_hip) <= 1e-4
 
 

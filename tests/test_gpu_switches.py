@@ -1,5 +1,5 @@
 """GPU: the kernel-selecting environment switches that are read once per process ("Run-time switches") -- the generic CG kernel, the
-workgroup-per-row Cholesky kernel, one row per wavefront for the shortest rows, the split-row boundary, the library GEMMs.
+workgroup-per-row Cholesky kernel, two rows per wavefront for the shortest rows, the split-row boundary, the library GEMMs.
 Each runs the same three small fits in a child process with the switch set; the factors must agree with the default paths'
 to rounding (the switches select another kernel for the same row systems, never another model)."""
 import os
@@ -41,7 +41,7 @@ np.savez(sys.argv[1], **out)
 def _run(tmp_path, name, env):
     path = str(tmp_path / (name + ".npz"))
     e = dict(os.environ)
-    for k in ("CMFREC_HIP_CG_KERNEL", "CMFREC_HIP_CHOL", "CMFREC_HIP_PAIR", "CMFREC_HIP_TINY16", "CMFREC_HIP_VH_MIN", "CMFREC_HIP_GEMM_OWN"):
+    for k in ("CMFREC_HIP_CG_KERNEL", "CMFREC_HIP_CHOL", "CMFREC_HIP_PAIR", "CMFREC_HIP_VH_MIN", "CMFREC_HIP_GEMM_OWN"):
         e.pop(k, None)
     e.update(env)
     code = CHILD % dict(root=ROOT, tests=os.path.join(ROOT, "tests"))
@@ -55,7 +55,7 @@ def default_fits(tmp_path_factory):
     return _run(tmp_path_factory.mktemp("switches"), "default", {})
 
 
-@pytest.mark.parametrize("env", [{"CMFREC_HIP_CG_KERNEL": "generic"}, {"CMFREC_HIP_CHOL": "rows"}, {"CMFREC_HIP_PAIR": "1"}, {"CMFREC_HIP_PAIR": "2"}, {"CMFREC_HIP_PAIR": "0", "CMFREC_HIP_TINY16": "0"}, {"CMFREC_HIP_TINY16": "0"},
+@pytest.mark.parametrize("env", [{"CMFREC_HIP_CG_KERNEL": "generic"}, {"CMFREC_HIP_CHOL": "rows"}, {"CMFREC_HIP_PAIR": "1"},
                                  {"CMFREC_HIP_VH_MIN": "400"}, {"CMFREC_HIP_GEMM_OWN": "0"}],
                          ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_process_wide_switch_agrees_with_default(default_fits, tmp_path, env):
