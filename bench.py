@@ -263,11 +263,18 @@ def main():
             o = by_key.get(("A" if e["step"] == "B" else "B", e["kernel"]))
             e["inline_ms"] = r["inline_ms"]; e["inline_GBps"] = r["GBps"]; e["inline_frac"] = r["frac"]
             e["rocprof"]["avg_ms_over_both_halfsteps"] = round((r["inline_ms"] + (o["inline_ms"] if o else 0.0)) / (2 if o else 1), 4)
-            e["rocprof"]["mode"] = "bins in line (CMFREC_HIP_BINS_PAR=1): the run profiles/r04/*_kernel_stats_inline.csv is taken from"
+            e["rocprof"]["mode"] = "bins in line (CMFREC_HIP_BINS_PAR=1): the run profiles/r05/*_kernel_stats_inline.csv is taken from"
         worst = min(tab, key=lambda r: r["frac"])
         roofline["inline"] = {"halfstep_ms": hs_inline, "iteration_ms": round(hs_inline["A"] + hs_inline["B"], 4),
                               "worst_bin": {k2: worst[k2] for k2 in ("step", "kernel", "inline_ms", "GBps", "frac")},
                               "note": "5 iterations after the timed region with the nnz bins one after the other; not part of `value`"}
+        # ONE kernel with a duration of its own: the launch that takes the most time when the bins run in line (HIP events around it
+        # on its own stream; rocprofv3's per-kernel average of the in-line run under profiles/ must agree)
+        big = max(tab, key=lambda r: r["inline_ms"])
+        roofline["dominant_inline"] = {"step": big["step"], "kernel": big["kernel"], "rows": big["rows"], "nnz": big["nnz"],
+                                       "avg_launch_ms": big["inline_ms"], "alg_bytes_per_launch": algorithmic_bytes(big["nnz"], big["rows"], K),
+                                       "achieved": big["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": big["frac"],
+                                       "share_of_inline_iteration": round(big["inline_ms"] / (hs_inline["A"] + hs_inline["B"]), 3)}
 
     if not side_by_side and dom["kernel"].startswith("gram_wave"):
         # the Gramian path reads its rows once; what limits it in double precision is v_mfma_f64_16x16x4 (docs/DESIGN_HISTORY.md 3.1):
@@ -770,7 +777,10 @@ def c5_shard(args, device):
                                   % (m, n, nnz),
                       "ms_per_iteration": round(dt * 1e3, 2), "rows_per_s": round((m + n) / dt, 1),
                       "halfstep_ms": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)},
-                      "alg_TFLOP": round(flops / 1e12, 2), "TFLOPs": round(flops / dt / 1e12, 1),
+                      # (the full-Cholesky operation count of SURVEY 8d, NOT executed flops: the user step runs the low-rank path and skips
+                      #  most of them -- the figure says how long the same half-steps would take at a given rate, not how busy the pipes are;
+                      #  the item step below is counted on the flops it executes)
+                      "full_cholesky_TFLOP_surveyed": round(flops / 1e12, 2), "surveyed_TFLOP_per_s_equivalent": round(flops / dt / 1e12, 1),
                       # the item step on its own flops (every item row is a full k_t x k_t system: rank-k update + factorisation);
                       # the user step runs the low-rank path and does far fewer flops than the formula above charges it
                       "item_step": (lambda fl, ms: {"TFLOP": round(fl / 1e12, 3), "ms": round(ms, 2), "TFLOPs": round(fl / ms / 1e9, 1),

@@ -235,6 +235,35 @@ __global__ void set_rowvec_kernel(T *__restrict__ M, size_t ld, size_t rows, int
     M[r * ld + c] = (v != nullptr) ? v[c] : T(0);
 }
 
+// the refinement step of the shared-matrix solve (session.hip, launch_potrs_rows)
+// out = the upper triangle of the row-major k x k factor R, zeros below (the factorisation leaves the lower triangle as it was)
+template <typename T>
+__global__ void upper_only_kernel(const T *__restrict__ R, int k, T *__restrict__ out)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= (size_t)k * k) return;
+    const int r = (int)(e / k), c = (int)(e % k);
+    out[e] = (c >= r) ? R[e] : T(0);
+}
+// res[r, c] = b[r, c] - res[r, c]
+template <typename T>
+__global__ void residual_rows_kernel(T *__restrict__ res, size_t ld_res, const T *__restrict__ b, size_t ld_b, size_t rows, int cols)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= rows * (size_t)cols) return;
+    const size_t r = e / cols; const int c = (int)(e % cols);
+    res[r * ld_res + c] = b[r * ld_b + c] - res[r * ld_res + c];
+}
+// x[r, c] += a[r, c]
+template <typename T>
+__global__ void add_rows_kernel(T *__restrict__ x, size_t ld_x, const T *__restrict__ a, size_t ld_a, size_t rows, int cols)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= rows * (size_t)cols) return;
+    const size_t r = e / cols; const int c = (int)(e % cols);
+    x[r * ld_x + c] += a[r * ld_a + c];
+}
+
 // dst[order[i], c] = src[order[i], c] for the first n positions of a processing order
 template <typename T>
 __global__ void copy_rows_by_order_kernel(const T *__restrict__ src, size_t ld_src, T *__restrict__ dst, size_t ld_dst, const int *__restrict__ order,

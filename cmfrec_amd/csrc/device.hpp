@@ -379,6 +379,7 @@ struct DeviceInfo {
     DevBuf<real_t> tile_init;       // initial matrices of a Cholesky launch in tile-linear layout (chol_wave_kernels.hpp, tile_pack_kernel)
     DevBuf<int> row_counter;        // work counters of the dynamically scheduled row kernels (zeroed before each launch)
     DevBuf<real_t> potrs_inv, potrs_tmp;   // launch_potrs_rows: L^-1 and M^-1 of the shared matrix; the product before it replaces the rows
+    DevBuf<real_t> potrs_ref;              // ... single precision: the matrix itself and the residuals of the refinement step
     DevBuf<real_t> gemm_ws;         // partial products of the split-K GEMMs (session.hip, launch_gemm)
     // second stream + events for two row kernels that may overlap (heavy-row teams beside light-row teams); created on
     // first use, owned here

@@ -269,6 +269,13 @@ gram_wave_kernel(const CgParams<T> P, const GramParams<T> Gp)
                     const T *rl = rp + lm;
 #pragma unroll
                     for (int cb = 0; cb < NTT; cb++) slab[q][cb] = rl[16 * cb];
+                } else if constexpr (REMV) {
+                    // (round 5) 16 NTF <= kt - 1: the full blocks are one address plus immediate offsets like the FULLK build, only
+                    // the remainder block needs its clamped column
+                    const T *rl = rp + lm;
+#pragma unroll
+                    for (int cb = 0; cb < NTF; cb++) slab[q][cb] = rl[16 * cb];
+                    slab[q][NTT - 1] = rp[coff[NTT - 1]];
                 } else {
 #pragma unroll
                     for (int cb = 0; cb < NTT; cb++) slab[q][cb] = rp[coff[cb]];

@@ -489,6 +489,22 @@ static void launch_potrs_rows(const DeviceInfo &dev, int rows, int k, const real
     HIP_CHECK(hipGetLastError());
     launch_gemm<true>(dev, k, k, k, (real_t)1, Linv, (size_t)k, Linv, (size_t)k, Minv, (size_t)k);
     launch_gemm<false>(dev, rows, k, k, (real_t)1, X, ldx, Minv, (size_t)k, d.potrs_tmp.ptr, (size_t)k);
+    if (sizeof(real_t) == 4) {
+        // Single precision: one step of iterative refinement with the matrix itself.  The product with an explicit inverse carries
+        // an error of cond(M) eps where the two triangular solves of the reference's posv are backward stable; x1 = x0 +
+        // (b - x0 M) M^-1 brings the residual back to the level of the solves (the right-hand sides are still in X here).
+        // M = R^T R from the factor; three tall products instead of one, on rows x k x k flops -- nothing beside the half-step's gather.
+        d.potrs_ref.alloc_at_least((size_t)k * k + (size_t)rows * k);
+        real_t *Mfull = d.potrs_ref.ptr, *Res = d.potrs_ref.ptr + (size_t)k * k;
+        hipLaunchKernelGGL(upper_only_kernel<real_t>, grid1d((size_t)k * k), dim3(256), 0, dev.stream, R, k, Linv);       // (Linv is free again)
+        launch_gemm<true>(dev, k, k, k, (real_t)1, Linv, (size_t)k, Linv, (size_t)k, Mfull, (size_t)k);                    // R^T R
+        launch_gemm<false>(dev, rows, k, k, (real_t)1, d.potrs_tmp.ptr, (size_t)k, Mfull, (size_t)k, Res, (size_t)k);      // x0 M
+        hipLaunchKernelGGL(residual_rows_kernel<real_t>, grid1d((size_t)rows * k), dim3(256), 0, dev.stream, Res, (size_t)k, X, ldx, (size_t)rows, k);   // b - x0 M
+        launch_gemm<false>(dev, rows, k, k, (real_t)1, Res, (size_t)k, Minv, (size_t)k, X, ldx);                           // (b - x0 M) M^-1 -> X
+        hipLaunchKernelGGL(add_rows_kernel<real_t>, grid1d((size_t)rows * k), dim3(256), 0, dev.stream, X, ldx, d.potrs_tmp.ptr, (size_t)k, (size_t)rows, k);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     HIP_CHECK(hipMemcpy2DAsync(X, ldx * sizeof(real_t), d.potrs_tmp.ptr, (size_t)k * sizeof(real_t), (size_t)k * sizeof(real_t), (size_t)rows,
                                hipMemcpyDeviceToDevice, dev.stream));
 }

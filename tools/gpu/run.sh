@@ -42,7 +42,15 @@ ab)
   done; done
   for w in c4shard c1; do for L in "$1" "$2"; do
     CMFREC_HIP_LIBDIR=$R/cmfrec_amd/$L $B --workload $w --steps 20 --warmup 3 2>/dev/null | python /tmp/line.py "$w $L" | tee -a $O/lines.txt
-  done; done ;;
+  done; done
+  # config 4 on one GPU (the scale point of the default line), per bin in line
+  for L in "$1" "$2"; do
+    CMFREC_HIP_LIBDIR=$R/cmfrec_amd/$L python $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | python -c "
+import sys, json
+l = [x for x in sys.stdin if x.startswith('{')]
+sp = (json.loads(l[-1]).get('scale_point') or {}) if l else {}
+print('c4 $L', sp.get('ms_per_step'), (sp.get('inline') or {}).get('halfstep_ms'), [(e['step'], e['bin'], e['inline_ms']) for e in sp.get('per_bin_inline', [])])" | tee -a $O/lines.txt
+  done ;;
 env)
   V=$1; shift
   for rep in 1 2; do for x in "$@"; do
