@@ -993,10 +993,26 @@ int_t fit_collective_explicit_als(
     // NA_as_zero_X (sparse X whose absent entries are zeros): every half-step shares one matrix over its rows -- optimizeA Case 3
     // without side information on that side (common.c:3118-3205: closed form whatever use_cg says), optimizeA_collective with
     // the factorised shared block matrix (collective.c:5607-5617, :5700-5716) with dense complete side information
-    if (NA_as_zero_X && (nnz_U || nnz_I || add_implicit_features || nonneg || l1_lam != 0 || l1_lam_unique ||
+    if (NA_as_zero_X && (nonneg || l1_lam != 0 || l1_lam_unique ||
                          precompute_for_predictions || (scale_bias_const && (scale_lam || scale_lam_sideinfo) && (user_bias || item_bias))))
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without sparse side information, implicit "
-                             "features, nonneg / L1, scale_bias_const and without precompute_for_predictions.");
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without "
+                             "nonneg / L1, scale_bias_const and without precompute_for_predictions.");
+    // ... with implicit features (round 5): the model without side information and weights, closed form (optimizeA_collective's
+    // general branch on a matrix all rows share, collective.c:8612 / :8783 -> :1534-1846)
+    if (NA_as_zero_X && add_implicit_features && (U || II || nnz_U || nnz_I || weight != nullptr || use_cg))
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information and weights, closed "
+                             "form (use_cg = false).");
+    // ... with SPARSE side information (round 5): row by row on the shared B^T B plus the rank-1 terms of the row's own attributes
+    // (collective_closed_form_block with prefer_BtB, collective.c:1534-1846) -- closed form, side information on exactly the rows /
+    // columns of X, no weights
+    if (NA_as_zero_X && ((U == nullptr && nnz_U) || (II == nullptr && nnz_I))) {
+        if (use_cg)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with sparse side information: closed form only (use_cg = false).");
+        if (weight != nullptr || NA_as_zero_U || NA_as_zero_I)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with sparse side information: not together with weights or NA_as_zero_U / _I.");
+        if ((U == nullptr && nnz_U && m_u != m) || (II == nullptr && nnz_I && n_i != n))
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: U / I must have exactly the rows / columns of X.");
+    }
     // ... with observation weights (round 5): optimizeA Case 4's NA_as_zero + weight branches (common.c:3209-3302, :846-907,
     // :1293-1441), the model without side information.  Not with start values for the biases: the reference's own
     // (initialize_biases with NA_as_zero and weights) index the item biases by row inside the item sweep (common.c:4727-4731).

@@ -53,6 +53,8 @@ struct CholCall {
     bool rhs_only = false;                   // CHOL_NAZ: gather the right-hand sides only
     bool rhs_prefilled_all = false;          // every row starts from the right-hand side left in A
     const real_t *weights_override = nullptr; // CHOL_NAZ_W: the entries' rank-1 weights (w - 1), CSR order of X
+    bool x_rhs_only = false;                 // the entries of X add to the right-hand sides only (their Gramian is inside Mfull)
+    const real_t *mult_override = nullptr;   // per-row lambda multipliers of the collective modes instead of the rows' lengths
     bool all_rows = false;                   // CHOL_NAZ_W: rows without entries are solved too (from the prefilled right-hand side)
     int row_limit = -1;                      // only the first row_limit positions of the processing order (the others are solved elsewhere)
     // CG on the row's Gramian instead of the factorisation (gram_cg_wide_kernels.hpp): the producer build of the wave kernel runs
@@ -80,6 +82,8 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     const bool weighted = X != nullptr && X->weighted() && (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && c.values_override == nullptr;
     if (weighted) { P.weights = X->w.ptr; P.wsum = X->wsum.ptr; }
     if (c.mode == CHOL_NAZ_W) { P.weights = c.weights_override; P.wsum = X->wsum.ptr; }
+    if (c.mult_override != nullptr) P.wsum = c.mult_override;
+    P.x_rhs_only = c.x_rhs_only ? 1 : 0;
     P.order = X ? X->order.ptr : nullptr;
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
     else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT || (c.mode == CHOL_NAZ_W && c.all_rows)) P.nrows = X->nrows;   // empty rows too
@@ -884,6 +888,7 @@ struct cmfrec_hip_session {
     // ... with observation weights (update_factor_naz_weighted): per entry w - 1 and the right-hand-side bracket, a zero array in
     // the place of the values for the CG kernels
     DevBuf<real_t> naz_g, naz_xt, naz_zero;
+    DevBuf<real_t> naz_mult;            // NA_as_zero_X with sparse side information: the rows' lambda multiplier (every cell counts)
     DevBuf<int> zrowsA, zrowsB;   // rows every update of A / B leaves at zero (cmfrec_hip_session_set_zero_rows)
     int n_zrowsA = 0, n_zrowsB = 0;
     DevBuf<unsigned char> cfmaskA, cfmaskB;   // rows that take the closed form inside a CG update (cmfrec_hip_session_set_closed_form_rows)
@@ -1669,6 +1674,73 @@ static bool launch_gsum(cmfrec_hip_session *s, bool isA, const SparseShard &X, c
     return true;
 }
 
+// NA_as_zero_X on a side with SPARSE side information (missing = absent; round 5): no matrix is shared by the rows any more -- each
+// adds the rank-1 terms of its own attributes -- so the reference solves row by row (collective_closed_form_block's general
+// branch with prefer_BtB, collective.c:1534-1846):
+//     M_i   = blockdiag(0, B^T B) + w sum_u c_u c_u^T + lam mult_i I,   mult_i = n (+ the row's attributes under scale_lam_sideinfo)
+//     rhs_i = [w sum_u u_iu c_u ; sum_j x_j b_j + cst]
+// on the two-source build of the row Cholesky kernel: B^T B embedded as the matrix every row starts from (Mfull), the entries of X
+// right-hand side only, the attributes as the second gather source with their rank-1 terms, the constant prefilled.  Closed
+// form only (the block CG with NA_as_zero_X, collective.c:2134-2903, is not restated).
+static int update_factor_naz_sparse_side(cmfrec_hip_session *s, bool isA, bool chol)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    hipStream_t st = dev.stream;
+    if (!chol) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with sparse side information: closed form only (use_cg = false)";
+        return 2;
+    }
+    const int p_self = isA ? m.p : m.q, rows_u = isA ? m.m_u : m.n_i;
+    const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
+    if (rows_u != rows_self) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with side information: side information on exactly the rows / columns of X";
+        return 2;
+    }
+    real_t *self = isA ? s->A.ptr : s->B.ptr;
+    real_t *opp = isA ? s->B.ptr : s->A.ptr;
+    const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
+    const int k_side_self = isA ? m.k_user : m.k_item, k_side_opp = isA ? m.k_item : m.k_user;
+    const SparseShard &X = isA ? s->Xr : s->Xc;
+    const SparseShard &Us = isA ? s->Usr : s->Isr;
+    const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+    const real_t w = isA ? m.w_user : m.w_item;
+    const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
+    const real_t lam_self = s->lam6[isA ? 2 : 3];
+    const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
+    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0), kc = k_side_self + m.k, kt = k_side_self + ks;
+    const real_t *oppx = opp + k_side_opp;
+    if (self_bias)
+        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
+    launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);
+    s->naz_M.alloc_at_least((size_t)kt * kt);
+    hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, st, s->gram.ptr, ks, k_side_self, (real_t)0, s->naz_M.ptr);
+    // right-hand sides start from [0 ; cst]
+    HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
+    if (opp_bias || s->naz_center) {
+        const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
+        s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
+        const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
+        hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, oppx, ld_opp, rows_opp, ks, bias,
+                           s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
+        hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
+        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self + k_side_self, ld_self, (size_t)rows_self, ks,
+                           s->naz_vec.ptr);
+    }
+    const bool scaled = m.scale_lam || m.scale_lam_sideinfo;
+    if (scaled) {
+        s->naz_mult.alloc_at_least((size_t)rows_self);
+        hipLaunchKernelGGL(fill_kernel<real_t>, grid1d((size_t)rows_self), dim3(256), 0, st, s->naz_mult.ptr, (size_t)rows_self, (real_t)rows_opp);
+    }
+    HIP_CHECK(hipGetLastError());
+    CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, nullptr, kc, rows_u, p_self, lam_self, lam_last_self, scaled,
+               (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE, s->naz_M.ptr};
+    c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
+    c.rhs_prefilled_all = true; c.x_rhs_only = true;
+    if (scaled) c.mult_override = s->naz_mult.ptr;
+    return launch_chol(dev, c, &X);
+}
+
 // One half-step of the explicit model with the main matrix missing-as-zero (see cmfrec_hip_session::naz_X).
 // Without side information on this side: optimizeA Case 3 (common.c:3116-3205).  With dense, complete side information that
 // covers exactly the rows of X: optimizeA_collective with bufferBeTBeChol (collective.c:5566-5968, :5607-5617) -- every row
@@ -1683,13 +1755,22 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
     const int p_self = isA ? m.p : m.q;
     const int rows_u = isA ? m.m_u : m.n_i;
     const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
-    if (s->implicit_feats || s->scale_bias_const || dev.nonneg_now || dev.l1_now != (real_t)0 ||
+    if (s->scale_bias_const || dev.nonneg_now || dev.l1_now != (real_t)0 ||
         dev.l1_last_now != (real_t)0 || m.row_begin != 0 || m.row_end != m.m || m.col_begin != 0 || m.col_end != m.n ||
-        s->Xr.weighted() || s->sparseU || s->sparseI || s->side_local) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X: the explicit model on one device without weights, implicit features, nonneg / L1, "
-                       "scale_bias_const, sparse or incomplete side information";
+        s->Xr.weighted() || s->side_local) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X: the explicit model on one device without weights, nonneg / L1, "
+                       "scale_bias_const, incomplete side information";
         return 2;
     }
+    // implicit features (round 5): the model without side information -- the reference runs those half-steps through
+    // optimizeA_collective's general branch (collective.c:8612 / :8783 -> :1534-1846 with prefer_BtB), which without side
+    // information is ONE matrix for all rows, B^T B + w_i Bi^T Bi + lam mult I, and right-hand sides X B + w_i sum_{observed} Bi_j
+    // + the constant: the shared-matrix half-step below with two more terms.  Closed form (the block CG is not restated).
+    if (s->implicit_feats && (m.p > 0 || m.q > 0 || !chol)) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information, closed form (use_cg = false)";
+        return 2;
+    }
+    if (p_self > 0 && (isA ? s->sparseU : s->sparseI)) return update_factor_naz_sparse_side(s, isA, chol);
     if (p_self > 0 && rows_u != rows_self) {
         // (m > m_u takes optimizeA Case 3 for the rows beyond in the reference -- its build corrupts the heap there, so nothing
         //  pins that branch)
@@ -1724,6 +1805,11 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
     launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, lam_self * mult);
     if (lam_last_self != lam_self)
         hipLaunchKernelGGL(add_diag_kernel<real_t>, dim3(1), dim3(64), 0, st, s->gram.ptr, ks, ks - 1, ks, (lam_last_self - lam_self) * mult);
+    const real_t *Fi = s->implicit_feats ? (isA ? s->Bi.ptr : s->Ai.ptr) : nullptr;      // the opposing side's implicit factors [rows_opp, kk]
+    if (Fi != nullptr) {                                                                   // + w_i Bi^T Bi on the first k + k_main unknowns (:1704-1707)
+        launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, s->w_implicit, (real_t)0);
+        hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kk * kk), dim3(256), 0, st, s->bitbi.ptr, kk, (real_t)1, s->gram.ptr, ks, 0);
+    }
     real_t *Msh = s->gram.ptr;                // the matrix the rows share, [kt, kt]
     real_t *rhs_x = self;                     // where the row kernel leaves sum_j x_j opp_j: [rows, ks], ld
     size_t ld_rhs = ld_self;
@@ -1754,6 +1840,15 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
         launch_gemm<false>(dev, rows_self, kc, p_self, isA ? m.w_user : m.w_item, Um, (size_t)p_self, Cm, (size_t)kc, rhs, ld_r);
         hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, rhs, ld_r, k_side_self, rhs_x, ks,
                            (real_t)1, (size_t)rows_self);
+    }
+    if (Fi != nullptr) {
+        // ... w_i times the sum of the opposing implicit factors at the row's observed positions (:1757-1771)
+        if (!launch_gsum(s, isA, X, Fi, kk)) {
+            g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: k + k_main too wide for the gather-sum";
+            return 2;
+        }
+        hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)X.nrows * kk), dim3(256), 0, st, rhs, ld_r, k_side_self, s->grhs.ptr, kk,
+                           s->w_implicit, (size_t)X.nrows);
     }
     // ... plus the constant of the opposing biases and the mean (:3152-3157 / :5815-5821)
     if (opp_bias || s->naz_center) {

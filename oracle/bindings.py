@@ -253,8 +253,10 @@ class Oracle:
                                 biasA=None, biasB=None, user_bias=False, item_bias=False, center=False, lam=1.0, alpha=1.0,
                                 scale_lam=False, scale_lam_sideinfo=False, k_main=0, k_user=0, k_item=0, w_main=1.0,
                                 w_user=1.0, w_item=1.0, niter=3, nthreads=1, use_cg=False, max_cg_steps=3,
-                                precondition_cg=False, finalize_chol=False):
-        """Whole fit with sparse side information (U_coo / I_coo = (row, col, val, rows, cols))."""
+                                precondition_cg=False, finalize_chol=False, NA_as_zero_X=False):
+        """Whole fit with sparse side information (U_coo / I_coo = (row, col, val, rows, cols)).  NA_as_zero_X: explicit model, closed form."""
+        if NA_as_zero_X:
+            self.lib.oracle_set_sparse_fit_NA_as_zero_X(C.c_bool(True))
         m, n = A.shape[0], B.shape[0]
         row = np.ascontiguousarray(row, np.int32); col = np.ascontiguousarray(col, np.int32)
         val = np.ascontiguousarray(val, self.dtype)

@@ -811,6 +811,13 @@ void oracle_optimizeA_naz_weighted(real_t *A, size_t lda, const real_t *B, size_
     free(BtB);
 }
 
+/* NA_as_zero_X of the collective_chol_impl call that follows (cleared by the call; used for the model with implicit features and no
+ * side information, which the reference runs through optimizeA_collective's general branch, collective.c:8612 / :8783 ->
+ * collective_closed_form_block :1534-1846 with prefer_BtB): the lower-right block is the whole B^T B (:1631-1640), the right-hand
+ * side gains bias_BtX (:1774-1775), the lambda multiplier is n (:1300-1301), rows without entries are solved when bias_BtX exists
+ * (:1258-1268). */
+static bool g_cc_naz = false;
+static const real_t *g_cc_btx = NULL;
 static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t ldb,
                                       const real_t *C,
                                       int_t m, int_t m_u, int_t n, int_t p,
@@ -849,6 +856,14 @@ static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t 
                                       const real_t *Bi, int_t k_main_i, real_t w_implicit)
 {
     if (nthreads < 1) nthreads = 1;
+    const bool naz = g_cc_naz;
+    const real_t *btx = naz ? g_cc_btx : NULL;
+    g_cc_naz = false; g_cc_btx = NULL;
+    real_t *BtBn = NULL;
+    if (naz) {
+        BtBn = (real_t *)malloc((size_t)(k + k_main) * (k + k_main) * sizeof(real_t));
+        oracle_gram(B + k_item, ldb, n, k + k_main, BtBn, nthreads);
+    }
     const int_t kbi = k + k_main_i;
     real_t *BiTBi = NULL;
     if (Bi != NULL) {
@@ -885,11 +900,12 @@ static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t 
         size_t nnz = en - st;
         bool has_u = (U != NULL && p > 0 && ix < m_u);
         real_t *a = A + (size_t)ix * lda;
-        if (nnz == 0 && !has_u) { memset(a, 0, (size_t)k_totA * sizeof(real_t)); continue; } /* :1258-1268 */
+        if (nnz == 0 && !has_u && !(naz && btx != NULL)) { memset(a, 0, (size_t)k_totA * sizeof(real_t)); continue; } /* :1258-1268 */
         real_t lam_i = lam, lam_last_i = lam_last;
         if (scale_lam || scale_lam_sideinfo) {                                 /* :1285-1355 */
             real_t mult = (real_t)nnz;
             if (nnz == 0) mult = 1;                                            /* :1332-1336 */
+            if (naz) mult = (real_t)n;                                         /* :1300-1301 */
             if (scale_lam_sideinfo && has_u) mult += (real_t)p;                /* :1338-1346 */
             lam_i *= mult;
             if (has_u || !g_scale_bias_const) lam_last_i *= mult;             /* rows >= m_u: plain optimizeA (:4832-4965) */
@@ -902,11 +918,16 @@ static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t 
                 for (int_t j = 0; j < k_totC; j++)
                     M[(size_t)i * k_totA + j] = CtCw[(size_t)i * k_totC + j];
         real_t *Mlr = M + (size_t)k_user + (size_t)k_user * k_totA;            /* :1360 */
+        if (naz) {                                                             /* :1631-1640 */
+            for (int_t i = 0; i < kb; i++)
+                for (int_t j = i; j < kb; j++) Mlr[(size_t)i * k_totA + j] += BtBn[(size_t)i * kb + j];
+        } else
         for (size_t jx = st; jx < en; jx++)                                    /* :1694-1699 */
             syr_upper_(kb, (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
         /* :1542-1543 tail already zero; :1738-1742 rhs += B^T x */
         for (size_t jx = st; jx < en; jx++)
             axpy_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+        if (btx != NULL) axpy_(kb, (real_t)1, btx, a + k_user);               /* :1774-1775 */
         if (Bi != NULL) {
             for (int_t i = 0; i < kbi; i++)                                    /* :1704-1707 */
                 for (int_t j = i; j < kbi; j++) Mlr[(size_t)i * k_totA + j] += BiTBi[(size_t)i * kbi + j];
@@ -920,6 +941,7 @@ static void collective_chol_impl(real_t *A, size_t lda, const real_t *B, size_t 
     free(bufs);
     free(CtCw);
     free(BiTBi);
+    free(BtBn);
 }
 
 /* Block CG on the collective system, dense full U without NaN (prefer_CtC branches):
@@ -1602,7 +1624,10 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     g_zero_rows_A = g_zero_rows_B = NULL; g_n_zero_rows_A = g_n_zero_rows_B = 0;
     /* missing-as-zero with side information: dense complete U / I, closed form, side information on exactly the rows / columns of X
      * (with fewer the reference's own build corrupts its heap, so nothing pins the m > m_u branch restated in collective_naz_chol) */
-    if (naz && ((Ai != NULL && Bi != NULL) || g_scale_bias_const)) return 2;
+    if (naz && g_scale_bias_const) return 2;
+    /* NA_as_zero_X with implicit features: the model without side information and weights, closed form (the half-steps then are
+     * optimizeA_collective's general branch on a matrix all rows share; the block CG with NA_as_zero_X is not restated) */
+    if (naz && (Ai != NULL && Bi != NULL) && (U != NULL || II != NULL || weight != NULL || use_cg)) return 2;
     /* missing-as-zero WITH weights: the model without side information, start values given (the reference's weighted bias start
      * values under NA_as_zero index biasB by row inside its item sweep, common.c:4727-4731 -- nothing to restate) */
     if (naz && weight != NULL && (U != NULL || II != NULL || init_biases)) return 2;
@@ -1810,11 +1835,23 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                 csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, btx, nthreads);
             free(btx);
         }
-        else if (II != NULL || imp)                                            /* :8612 */
+        else if (II != NULL || imp) {                                          /* :8612 */
+            real_t *btx = NULL;
+            if (naz) {                                                         /* (imp without side information, see above) :8573-8600 */
+                const int_t ks = k + k_main + (int_t)item_bias;
+                if (user_bias || center) {
+                    btx = (real_t *)calloc((size_t)ks, sizeof(real_t));
+                    for (int_t r = 0; r < m; r++)
+                        axpy_(ks, -((user_bias ? biasA[r] : (real_t)0) + (center ? *glob_mean : (real_t)0)), A_bias + k_user + (size_t)r * ldA, btx);
+                }
+                g_cc_naz = true; g_cc_btx = btx;
+            }
             collective_chol_impl(B_bias, ldB, A_bias, ldA, D, n_x, (n_i < n_x) ? n_i : n_x, m, q,
                                              k, k_main + (int_t)item_bias, k_item, k_user,
                                              csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Ai : NULL, k_main, w_implicit);
+            free(btx);
+        }
         else if (naz) {                                                        /* :8573-8600 + optimizeA Case 3 */
             const int_t ks = k + k_main + (int_t)item_bias;
             real_t *btx = NULL;
@@ -1875,11 +1912,23 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                                 csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, btx, nthreads);
             free(btx);
         }
-        else if (U != NULL || imp)                                             /* :8783 */
+        else if (U != NULL || imp) {                                           /* :8783 */
+            real_t *btx = NULL;
+            if (naz) {                                                         /* :8756-8787 */
+                const int_t ks = k + k_main + (int_t)user_bias;
+                if (item_bias || center) {
+                    btx = (real_t *)calloc((size_t)ks, sizeof(real_t));
+                    for (int_t c = 0; c < n; c++)
+                        axpy_(ks, -((item_bias ? biasB[c] : (real_t)0) + (center ? *glob_mean : (real_t)0)), B_bias + k_item + (size_t)c * ldB, btx);
+                }
+                g_cc_naz = true; g_cc_btx = btx;
+            }
             collective_chol_impl(A_bias, ldA, B_bias, ldB, C, m_x, (m_u < m_x) ? m_u : m_x, n, p,
                                              k, k_main + (int_t)user_bias, k_user, k_item,
                                              csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl,
                                              scale_lam, scale_lam_sideinfo, nthreads, imp ? Bi : NULL, k_main, w_implicit);
+            free(btx);
+        }
         else if (naz) {                                                        /* :8756-8787 + optimizeA Case 3 */
             const int_t ks = k + k_main + (int_t)user_bias;
             real_t *btx = NULL;
@@ -2136,6 +2185,15 @@ void oracle_factors_implicit_multiple(real_t *A, int_t m,
  * optimizeA_collective_implicit (:5971-6244 -> collective_closed_form_block_implicit :1849-2131) with SPARSE side
  * information: u_vec == NULL, u_vec_sp != NULL, !NA_as_zero_U ("add_C" branches :1636-1653 / :2003-2011 and the
  * tgemv_dense_sp right-hand sides :1719-1731 / :2013-2021); Cholesky; U_csr has m_u rows. */
+/* NA_as_zero_X of the oracle_optimizeA_collective_sparse_chol call that follows (explicit model; cleared by the call): the main
+ * matrix's absent entries are zeros, so every row's lower-right block is the whole B^T B (collective_closed_form_block part 2,
+ * collective.c:1631-1640, prefer_BtB), its right-hand side sum_j x_j B_j + bias_BtX (:1738-1742, :1774-1775), its lambda
+ * multiplier n (+ the row's attributes under scale_lam_sideinfo, :1300-1346), and a row without entries is solved like the others
+ * unless it has neither side information nor a constant (:1258-1268). */
+static bool g_csp_naz = false;
+static const real_t *g_csp_btx = NULL;
+void oracle_set_collective_sparse_naz(bool on, const real_t *bias_BtX) { g_csp_naz = on; g_csp_btx = bias_BtX; }
+
 void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
                                              int_t m, int_t m_u, int_t n, int_t p,
                                              int_t k, int_t k_main, int_t k_user, int_t k_item,
@@ -2145,14 +2203,17 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
                                              bool scale_lam, bool scale_lam_sideinfo, bool implicit, int nthreads)
 {
     (void)p;
+    const bool naz = g_csp_naz && !implicit;
+    const real_t *btx = naz ? g_csp_btx : NULL;
+    g_csp_naz = false; g_csp_btx = NULL;
     if (nthreads < 1) nthreads = 1;
     const int_t k_totA = k_user + k + k_main, k_totC = k_user + k, kb = k + k_main;
     for (int_t i = 0; i < m; i++) memset(A + (size_t)i * lda, 0, (size_t)k_totA * sizeof(real_t));  /* :4817-4822, :6018-6019 */
     real_t *BtB = NULL;
-    if (implicit) {                                                            /* :6056-6061 */
+    if (implicit || naz) {                                                     /* :6056-6061; :5650-5668 (build_BtB_CtC) */
         BtB = (real_t *)calloc((size_t)kb * kb + 1, sizeof(real_t));
         oracle_gram(B + k_item, ldb, n, kb, BtB, nthreads);
-        for (int_t i = 0; i < kb; i++) BtB[(size_t)i * kb + i] += lam;
+        if (implicit) for (int_t i = 0; i < kb; i++) BtB[(size_t)i * kb + i] += lam;
     }
     const size_t szbuf = (size_t)k_totA * k_totA;
     real_t *bufs = (real_t *)malloc(szbuf * (size_t)nthreads * sizeof(real_t));
@@ -2161,12 +2222,12 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
         const size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1], nnz = en - st;
         const size_t us = ix < m_u ? Ucsr_p[ix] : 0, ue = ix < m_u ? Ucsr_p[(size_t)ix + 1] : 0, nnz_u = ue - us;
         real_t *a = A + (size_t)ix * lda;
-        if (nnz == 0 && nnz_u == 0) continue;                                  /* :1258-1268, :1876-1885: zeros */
+        if (nnz == 0 && nnz_u == 0 && !(naz && btx != NULL)) continue;         /* :1258-1268, :1876-1885: zeros */
         real_t *M = bufs + szbuf * (size_t)omp_get_thread_num();
         memset(M, 0, szbuf * sizeof(real_t));
         real_t lam_i = lam, lam_last_i = lam_last;
         if (!implicit && (scale_lam || scale_lam_sideinfo)) {                  /* :1285-1355 */
-            real_t mult = nnz ? (real_t)nnz : (real_t)1;
+            real_t mult = naz ? (real_t)n : (nnz ? (real_t)nnz : (real_t)1);   /* :1300-1301 */
             if (scale_lam_sideinfo) mult += (real_t)nnz_u;                     /* :1338-1346 */
             lam_i *= mult; lam_last_i *= mult;
             t_l1_mult = mult;
@@ -2185,10 +2246,15 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
             for (size_t jx = st; jx < en; jx++)
                 syr_upper_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
         } else {
+            if (naz) {                                                         /* :1631-1640 */
+                for (int_t i = 0; i < kb; i++)
+                    for (int_t j = i; j < kb; j++) Mlr[(size_t)i * k_totA + j] += BtB[(size_t)i * kb + j];
+            } else
             for (size_t jx = st; jx < en; jx++)
                 syr_upper_(kb, (real_t)1, B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, Mlr, k_totA);
             for (size_t jx = st; jx < en; jx++)
                 axpy_(kb, Xcsr[jx], B + (size_t)k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
+            if (btx != NULL) axpy_(kb, (real_t)1, btx, a + k_user);           /* :1774-1775 */
             for (int_t i = 0; i < k_totA - 1; i++) M[(size_t)i * k_totA + i] += lam_i;
             M[(size_t)(k_totA - 1) * k_totA + (k_totA - 1)] += lam_last_i;
         }
@@ -2203,6 +2269,13 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
  * m_u <= m, n_i <= n, reset_values = false.  A side without side information is a plain optimizeA / optimizeA_implicit
  * step.  C / D: optimizeA Case 4 on the CSC of U / I with lam / w (:8354-8441, :9834-9917).  Explicit: optional
  * biases (start values passed in) and centring; implicit: alpha scaling, w_main folded into lam / w_user / w_item. */
+/* NA_as_zero_X of the oracle_fit_als_sparse_sideinfo call that follows (explicit model, closed form, sparse side information on
+ * exactly the rows / columns of X where there is any; cleared by the call): the mean over all cells (common.c:3494-3523), the
+ * stored values left as they are, the bias / mean constant on every right-hand side (collective.c:8573-8600, :8756-8787); a side
+ * without side information is optimizeA Case 3. */
+static bool g_spfit_naz = false;
+void oracle_set_sparse_fit_NA_as_zero_X(bool on) { g_spfit_naz = on; }
+
 int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                                    real_t *glob_mean, int_t m, int_t n, int_t k,
                                    const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,
@@ -2214,9 +2287,12 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
                                    real_t w_main, real_t w_user, real_t w_item, int_t niter, int nthreads,
                                    bool use_cg, int_t max_cg_steps, bool precondition_cg, bool finalize_chol)
 {
+    const bool naz = g_spfit_naz && !implicit;
+    g_spfit_naz = false;
     if (nnz_U == 0) { m_u = 0; p = 0; }
     if (nnz_I == 0) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n || (k_user && !p) || (k_item && !q)) return 2;
+    if (naz && (use_cg || (p && m_u != m) || (q && n_i != n) || g_nn_AB || g_l1_base != 0)) return 2;    /* (not restated) */
     if (implicit) { user_bias = item_bias = center = false; scale_lam = scale_lam_sideinfo = false; }
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     const real_t l1f = g_l1_base / ((w_main != (real_t)1.) ? w_main : (real_t)1.);
@@ -2227,6 +2303,17 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
     real_t *Xc = (real_t *)malloc((nnz + 1) * sizeof(real_t));
     memcpy(Xc, X, nnz * sizeof(real_t));
     if (implicit && alpha != (real_t)1.) for (size_t i = 0; i < nnz; i++) Xc[i] *= alpha;
+    real_t gmean = 0;
+    if (naz) {                                                                 /* common.c:3494-3523, :3600-3607: X stays as it is */
+        if (center) {
+            double xsum = 0;
+            if (nthreads >= 8) { for (size_t ix = 0; ix < nnz; ix++) xsum += Xc[ix]; gmean = (real_t)(xsum / (double)nnz); }
+            else { size_t cnt = 0; for (size_t ix = 0; ix < nnz; ix++) xsum += (Xc[ix] - xsum) / (double)(++cnt); gmean = (real_t)xsum; }
+            gmean = (real_t)((long double)gmean * ((long double)nnz / ((long double)m * (long double)n)));
+            if (fabs_t(gmean) < sqrt_t(EPSILON_T)) gmean = 0;
+        }
+        if (glob_mean) *glob_mean = gmean;
+    } else
     if (glob_mean) *glob_mean = center ? oracle_calc_mean_and_center(Xc, nnz, nthreads) : (real_t)0;
     size_t *csr_p = (size_t *)malloc(((size_t)m + 1) * sizeof(size_t)), *csc_p = (size_t *)malloc(((size_t)n + 1) * sizeof(size_t));
     int_t *csr_i = (int_t *)malloc((nnz + 1) * sizeof(int_t)), *csc_i = (int_t *)malloc((nnz + 1) * sizeof(int_t));
@@ -2276,7 +2363,23 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         g_nonneg = g_nn_AB; g_l1 = l1f;
         if (item_bias) for (int_t r = 0; r < m; r++) A_b[(size_t)r * ldA + k_totA] = 1;
-        if (user_bias) for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
+        if (user_bias && !naz) for (size_t ix = 0; ix < nnz; ix++) csc_v[ix] = csc_orig[ix] - biasA[csc_i[ix]];
+        real_t *btxB = NULL;
+        if (naz && (user_bias || center)) {                                    /* collective.c:8573-8600 */
+            const int_t ks = k + k_main + (int_t)item_bias;
+            btxB = (real_t *)calloc((size_t)ks, sizeof(real_t));
+            for (int_t r = 0; r < m; r++) axpy_(ks, -((user_bias ? biasA[r] : (real_t)0) + gmean), A_b + k_user + (size_t)r * ldA, btxB);
+        }
+        if (naz && q) {
+            oracle_set_collective_sparse_naz(true, btxB);
+            oracle_optimizeA_collective_sparse_chol(B_b, ldB, A_b, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
+                                                    csc_p, csc_i, csc_v, Ir_p, Ir_i, Ir_v, lam, w_item, lam, scale_lam,
+                                                    scale_lam_sideinfo, false, nthreads);
+        } else if (naz) {
+            oracle_set_naz_bias_BtX(btxB);
+            oracle_optimizeA_naz(B_b + k_item, ldB, A_b + k_user, ldA, n, m, k + k_main + (int_t)item_bias, csc_p, csc_i, csc_v, lam, lam,
+                                 scale_lam, nthreads);
+        } else
         if (q && use_cg)
             oracle_optimizeA_collective_sparse_cg(B_b, ldB, A_b, ldA, D, n, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                                   csc_p, csc_i, csc_v, Ir_p, Ir_i, Ir_v, lam, w_item, lam, scale_lam,
@@ -2293,7 +2396,24 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
                                       lam, lam, scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         if (item_bias) for (int_t c = 0; c < n; c++) biasB[c] = B_b[(size_t)c * ldB + k_totB];
         if (user_bias) for (int_t c = 0; c < n; c++) B_b[(size_t)c * ldB + k_totB] = 1;
-        if (item_bias) for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
+        free(btxB);
+        if (item_bias && !naz) for (size_t ix = 0; ix < nnz; ix++) csr_v[ix] = csr_orig[ix] - biasB[csr_i[ix]];
+        real_t *btxA = NULL;
+        if (naz && (item_bias || center)) {                                    /* collective.c:8756-8787 */
+            const int_t ks = k + k_main + (int_t)user_bias;
+            btxA = (real_t *)calloc((size_t)ks, sizeof(real_t));
+            for (int_t c = 0; c < n; c++) axpy_(ks, -((item_bias ? biasB[c] : (real_t)0) + gmean), B_b + k_item + (size_t)c * ldB, btxA);
+        }
+        if (naz && p) {
+            oracle_set_collective_sparse_naz(true, btxA);
+            oracle_optimizeA_collective_sparse_chol(A_b, ldA, B_b, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
+                                                    csr_p, csr_i, csr_v, Ur_p, Ur_i, Ur_v, lam, w_user, lam, scale_lam,
+                                                    scale_lam_sideinfo, false, nthreads);
+        } else if (naz) {
+            oracle_set_naz_bias_BtX(btxA);
+            oracle_optimizeA_naz(A_b + k_user, ldA, B_b + k_item, ldB, m, n, k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v, lam, lam,
+                                 scale_lam, nthreads);
+        } else
         if (p && use_cg)
             oracle_optimizeA_collective_sparse_cg(A_b, ldA, B_b, ldB, C, m, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                                   csr_p, csr_i, csr_v, Ur_p, Ur_i, Ur_v, lam, w_user, lam, scale_lam,
@@ -2308,6 +2428,7 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
         else
             oracle_optimizeA_explicit(A_b + k_user, ldA, B_b + k_item, ldB, m, n, k + k_main + (int_t)user_bias, csr_p, csr_i, csr_v,
                                       lam, lam, scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
+        free(btxA);
         if (user_bias) for (int_t r = 0; r < m; r++) biasA[r] = A_b[(size_t)r * ldA + k_totA];
     }
     if (has_bias) {

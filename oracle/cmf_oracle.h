@@ -245,6 +245,9 @@ void oracle_optimizeA_collective_sparse_cg(real_t *A, size_t lda, const real_t *
 
 /* Whole fits with SPARSE side information (COO, missing = absent), Cholesky or CG / PCG updates, m_u <= m, n_i <= n,
  * injected start values: fit_collective_explicit_als (collective.c:7263-9370) / fit_collective_implicit_als (:9375-10207). */
+/* NA_as_zero_X of the next oracle_fit_als_sparse_sideinfo / oracle_optimizeA_collective_sparse_chol call (explicit model, closed form) */
+void oracle_set_sparse_fit_NA_as_zero_X(bool on);
+void oracle_set_collective_sparse_naz(bool on, const real_t *bias_BtX);
 int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                                    real_t *glob_mean, int_t m, int_t n, int_t k,
                                    const int_t *ixA, const int_t *ixB, const real_t *X, size_t nnz,

@@ -320,6 +320,26 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g24_na_as_zero_weighted_" + tag, **out)
 
+        # ---- G25: NA_as_zero for the main matrix together with SPARSE side information ----
+        out = {}
+        d = gc.naz_sparse_side_problem(dt)
+        for ci, (name, which, opts) in enumerate(gc.NAZ_SPARSE_SIDE_CASES):
+            r = gc.naz_sparse_side_reference(R, d, which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g25_na_as_zero_sparse_side_" + tag, **out)
+
+        # ---- G26: NA_as_zero for the main matrix together with implicit features ----
+        out = {}
+        d = gc.naz_problem(dt)
+        for ci, (name, opts) in enumerate(gc.NAZ_IMPF_CASES):
+            r = gc.naz_impf_reference(R, d, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g26_na_as_zero_implicit_features_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

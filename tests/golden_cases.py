@@ -402,6 +402,157 @@ def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
     return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, biasA=mdl.user_bias_, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_)
 
 
+# ---- NA_as_zero_X together with implicit features, no side information (optimizeA_collective's general branch on a matrix all rows
+# share: B^T B + w_i Bi^T Bi + lam mult I; collective.c:8612 / :8783 -> :1534-1846) -- fixture g26, closed form, the problem of g18
+NAZ_IMPF_CASES = [
+    ("biases", dict()),
+    ("scale_lam", dict(scale_lam=True)),
+    ("no biases, no centring", dict(user_bias=False, item_bias=False, center=False)),
+    ("user bias, no centring, k_main, w_implicit", dict(center=False, item_bias=False, k_main=2, w_implicit=0.6)),
+    ("item bias", dict(user_bias=False)),
+    ("per-matrix lambdas", dict(lam_unique=[0.7, 0.2, 0.4, 0.25, 1.5, 0.6])),
+]
+
+
+def naz_impf_reference(R, d, opts, nthreads=2):
+    o = dict(opts)
+    A0, B0 = _impf_start(d, o)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=False, add_implicit_features=True, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], Ai=r["Ai"], Bi=r["Bi"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_impf_oracle(O, d, opts, nthreads=2):
+    o = dict(opts)
+    lam6 = o.pop("lam_unique", None)
+    if lam6 is not None:
+        O.set_lam_unique(np.asarray(lam6, np.float64), None)
+    try:
+        A0, B0 = _impf_start(d, o)
+        r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                               niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=False, add_implicit_features=True, **o)
+    finally:
+        O.set_lam_unique(None, None)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], Ai=r["Ai"], Bi=r["Bi"], glob_mean=r["glob_mean"])
+    if opts.get("user_bias", True): out["biasA"] = r["biasA"]
+    if opts.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_impf_hip(d, opts, dtype, **ctor):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    o.setdefault("w_implicit", 1.0)           # (the estimator's default is 0.5, the C default used by the reference calls above 1)
+    if "lam_unique" in o:
+        o["lambda_"] = o.pop("lam_unique")
+    else:
+        o["lambda_"] = 0.3
+    A0, B0 = _impf_start(d, o)
+    kw = dict(k=d["k"], niter=3, use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=True, use_cg=False,
+              add_implicit_features=True, nthreads=1)
+    kw.update(o); kw.update(ctor)
+    mdl = CMF(**kw)
+    mdl.fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, Ai=mdl.Ai_, Bi=mdl.Bi_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
+# ---- NA_as_zero_X together with SPARSE side information (collective_closed_form_block's general branch with prefer_BtB,
+# collective.c:1534-1846: the shared B^T B plus the rank-1 terms of the row's own attributes) -- fixture g25.  Side information on
+# exactly the rows / columns of X, closed form.
+def naz_sparse_side_problem(dtype, seed=47):
+    d = sparse_sideinfo_problem(dtype, seed)
+    rng = np.random.default_rng(seed + 1)
+    m, n = d["m"], d["n"]
+    p, q = d["U_coo"][4], d["I_coo"][4]
+    def coo(rows, cols, cnt, empty):
+        lin = rng.choice(rows * cols, size=cnt, replace=False)
+        r = (lin // cols).astype(np.int32); c = (lin % cols).astype(np.int32)
+        keep = ~np.isin(r, empty)
+        return r[keep], c[keep]
+    ur, uc = coo(m, p, 300, (3, 5)); ir, ic = coo(n, q, 220, (4,))           # (row 3: neither an entry of X nor an attribute)
+    d["U_coo"] = (ur, uc, rng.standard_normal(len(ur)).astype(dtype), m, p)
+    d["I_coo"] = (ir, ic, rng.standard_normal(len(ir)).astype(dtype), n, q)
+    return d
+
+
+# (name, sides with side information, options)
+NAZ_SPARSE_SIDE_CASES = [
+    ("both sides, biases", "UI", dict()),
+    ("both sides, scale_lam", "UI", dict(scale_lam=True)),
+    ("both sides, scale_lam_sideinfo, item bias", "UI", dict(scale_lam_sideinfo=True, user_bias=False)),
+    ("no biases, no centring", "UI", dict(user_bias=False, item_bias=False, center=False)),
+    ("user side only", "U", dict()),
+    ("item side only, scale_lam, no k_item", "I", dict(scale_lam=True, no_k_side=True)),
+    ("user bias, no centring", "UI", dict(center=False, item_bias=False)),
+]
+
+
+def _naz_sparse_args(d, which, opts):
+    o = dict(opts); nks = o.pop("no_k_side", False)
+    ku = d["ku"] if ("U" in which and not nks) else 0; ki = d["ki"] if ("I" in which and not nks) else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    return o, ku, ki, A0, B0
+
+
+def naz_sparse_side_reference(R, d, which, opts, nthreads=2):
+    o, ku, ki, A0, B0 = _naz_sparse_args(d, which, opts)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
+                                      k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, use_cg=False,
+                                      U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
+                                      NA_as_zero_X=True, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if "U" in which: out["C"] = r["C"]
+    if "I" in which: out["D"] = r["D"]
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_sparse_side_oracle(O, d, which, opts, nthreads=2):
+    o, ku, ki, A0, B0 = _naz_sparse_args(d, which, opts)
+    ub, ib, ce = o.pop("user_bias", True), o.pop("item_bias", True), o.pop("center", True)
+    r = O.fit_als_sparse_sideinfo(A0, B0, d["row"], d["col"], d["ratings"], d["k"], False, biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                  user_bias=ub, item_bias=ib, center=ce, lam=0.3, k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0,
+                                  w_item=0.7, niter=3, nthreads=nthreads, use_cg=False,
+                                  U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
+                                  NA_as_zero_X=True, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], glob_mean=r["glob_mean"])
+    if "U" in which: out["C"] = r["C"]
+    if "I" in which: out["D"] = r["D"]
+    if ub: out["biasA"] = r["biasA"]
+    if ib: out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_sparse_side_hip(d, which, opts, dtype, **ctor):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o, ku, ki, A0, B0 = _naz_sparse_args(d, which, opts)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    U = mk(d["U_coo"]) if "U" in which else None; I = mk(d["I_coo"]) if "I" in which else None
+    kw = dict(k=d["k"], lambda_=0.3, k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, use_cg=False,
+              use_float=dtype is np.float32, precompute_for_predictions=False, NA_as_zero=True, nthreads=1)
+    kw.update(o); kw.update(ctor)
+    mdl = CMF(**kw)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=I, shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
+    if U is not None: out["C"] = mdl.C_
+    if I is not None: out["D"] = mdl.D_
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- NA_as_zero_U / NA_as_zero_I: sparse side information whose absent entries are zeros (collective.c:1277-1457, :5790-5836,
 # C / D by optimizeA Case 3 with the column means as a rank-one correction, :8354-8441) ----------------------------------------
 # (name, implicit, sides, scale_lam, scale_lam_sideinfo, solver kwargs); the problem of G12 (U covers 80 of the 90 users)

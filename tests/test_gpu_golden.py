@@ -376,6 +376,44 @@ def test_NA_as_zero_X_weighted(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_sparse_sideinfo(oracles, dtype):
+    """G25 through the estimator (CMF(NA_as_zero=True).fit(X, U=sparse, I=sparse)): the two-source build of the row Cholesky kernel
+    with the shared B^T B as the matrix every row starts from, the entries of X right-hand side only, the row's attributes with their
+    rank-1 terms; a side without side information takes the shared-matrix half-step."""
+    g = gc.load("g25_na_as_zero_sparse_side", dtype)
+    d = gc.naz_sparse_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, which, opts) in enumerate(gc.NAZ_SPARSE_SIDE_CASES):
+        got = gc.naz_sparse_side_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.naz_sparse_side_oracle(oracles[dtype], d, which, opts)) < tol, name
+    # the option changes the model; CG is refused (the reference's block CG with NA_as_zero_X is not restated)
+    c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
+    assert gc.compare_fits(gc.naz_sparse_side_hip(d, "UI", {}, dtype, NA_as_zero=False), c0) > 1e-2
+    with pytest.raises(RuntimeError):
+        gc.naz_sparse_side_hip(d, "UI", {}, dtype, use_cg=True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_implicit_features(oracles, dtype):
+    """G26 through the estimator (CMF(NA_as_zero=True, add_implicit_features=True)): the shared-matrix half-step with w_i Bi^T Bi in
+    the matrix and the gather-sum of the opposing implicit factors in the right-hand sides."""
+    g = gc.load("g26_na_as_zero_implicit_features", dtype)
+    d = gc.naz_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, opts) in enumerate(gc.NAZ_IMPF_CASES):
+        got = gc.naz_impf_hip(d, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.naz_impf_oracle(oracles[dtype], d, opts)) < tol, name
+    c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
+    assert gc.compare_fits(gc.naz_impf_hip(d, {}, dtype, NA_as_zero=False), c0) > 1e-2
+    with pytest.raises(RuntimeError):
+        gc.naz_impf_hip(d, {}, dtype, use_cg=True)          # the block CG with NA_as_zero_X is not restated
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_X_sideinfo(oracles, dtype):
     """G20 through the estimator (CMF(NA_as_zero=True).fit(X, U=, I=)): the half-steps with dense side information share one
     block matrix (blockdiag(0, B^T B) + w C^T C + lam mult I, mult = n + p | n | 1), factorised once; right-hand sides

@@ -255,6 +255,30 @@ def test_NA_as_zero_X_weighted(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_X_sparse_sideinfo(oracles, dtype):
+    """G25: NA_as_zero_X together with SPARSE side information -- row by row on the shared B^T B plus the rank-1 terms of the row's
+    attributes (collective_closed_form_block's general branch with prefer_BtB, collective.c:1534-1846)."""
+    g = gc.load("g25_na_as_zero_sparse_side", dtype)
+    d = gc.naz_sparse_side_problem(dtype)
+    for ci, (name, which, opts) in enumerate(gc.NAZ_SPARSE_SIDE_CASES):
+        got = gc.naz_sparse_side_oracle(oracles[dtype], d, which, opts)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_X_implicit_features(oracles, dtype):
+    """G26: NA_as_zero_X together with implicit features (no side information): every row of a half-step shares
+    B^T B + w_i Bi^T Bi + lam mult I; right-hand sides X B + w_i sum_{observed} Bi_j + the bias / mean constant."""
+    g = gc.load("g26_na_as_zero_implicit_features", dtype)
+    d = gc.naz_problem(dtype)
+    for ci, (name, opts) in enumerate(gc.NAZ_IMPF_CASES):
+        got = gc.naz_impf_oracle(oracles[dtype], d, opts)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_NA_as_zero_X_sideinfo(oracles, dtype):
     """G20: NA_as_zero_X together with dense side information -- one factorised block matrix per half-step
     (collective.c:5607-5617, :5700-5716), right-hand sides X B + w U C + the bias / mean constant."""

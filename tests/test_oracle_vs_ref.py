@@ -673,3 +673,41 @@ def test_NA_as_zero_weighted_fit_live(oracles, refs, dtype):
         for key in keys:
             assert rel_err(ro[key], rr[key]) < 100 * TOL[dtype], (o, key)
         assert abs(ro["glob_mean"] - rr["glob_mean"]) < 1e-6 * max(1.0, abs(rr["glob_mean"])), o
+
+
+# ---- NA_as_zero for the main matrix together with SPARSE side information --------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed", [51, 52])
+def test_NA_as_zero_sparse_sideinfo_fit_live(oracles, refs, dtype, seed):
+    """fit_collective_explicit_als with NA_as_zero_X and sparse U / I (missing = absent), closed form: collective_closed_form_block's
+    general branch with prefer_BtB (collective.c:1534-1846) row by row; both lambda scalings, k_user / k_item / k_main, one side only."""
+    import golden_cases as gc
+    d = gc.naz_sparse_side_problem(dtype, seed=seed)
+    for name, which, opts in gc.NAZ_SPARSE_SIDE_CASES:
+        ref = gc.naz_sparse_side_reference(refs[dtype], d, which, opts)
+        got = gc.naz_sparse_side_oracle(oracles[dtype], d, which, opts)
+        for key, v in ref.items():
+            if v is not None and np.size(v) > 1:
+                assert rel_err(got[key], v) < 100 * TOL[dtype], (name, key)
+        assert abs(got["glob_mean"] - ref["glob_mean"]) < 1e-6 * max(1.0, abs(ref["glob_mean"])), name
+    # what the restatement does not cover is refused: CG, side information on fewer rows than X
+    O = oracles[dtype]
+    A0, B0 = d["A0"][:, d["ku"]:].copy(), d["B0"][:, d["ki"]:].copy()
+    assert O.fit_als_sparse_sideinfo(A0, B0, d["row"], d["col"], d["ratings"], d["k"], False, k_main=d["km"], U_coo=d["U_coo"], niter=1,
+                                     use_cg=True, NA_as_zero_X=True)["ret"] == 2
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed", [95, 96])
+def test_NA_as_zero_implicit_features_fit_live(oracles, refs, dtype, seed):
+    """fit_collective_explicit_als with NA_as_zero_X and add_implicit_features, no side information, closed form: the half-steps of A
+    and B are optimizeA_collective's general branch (collective.c:8612 / :8783 -> :1534-1846 with prefer_BtB), Ai / Bi optimizeA
+    Case 3 on the indicator (:8448-8534)."""
+    import golden_cases as gc
+    d = gc.naz_problem(dtype, seed=seed)
+    for name, opts in gc.NAZ_IMPF_CASES:
+        ref = gc.naz_impf_reference(refs[dtype], d, opts)
+        got = gc.naz_impf_oracle(oracles[dtype], d, opts)
+        for key, v in ref.items():
+            if v is not None and np.size(v) > 1:
+                assert rel_err(got[key], v) < 100 * TOL[dtype], (name, key)

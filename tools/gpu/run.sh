@@ -94,7 +94,7 @@ final)
   for ag in collective p2p; do
     timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --force-dist --allgather $ag --no-cpu-baseline --steps 5 --warmup 2 2>/dev/null | tail -1 | cut -c1-400 | sed "s/^/force-dist $ag /" | tee -a $O/force_dist.txt
   done
-  timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29572 bench.py --gpus 1 --force-dist --workload c5 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | tail -1 | cut -c1-400 | sed "s/^/force-dist c5 /" | tee -a $O/force_dist.txt
+  timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29572 bench.py --gpus 1 --force-dist --workload c5 --scale 0.125 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | grep "^{" | tail -1 | cut -c1-400 | sed "s/^/force-dist c5 (one rank, an eighth of the problem: the launch path only) /" | tee -a $O/force_dist.txt
   CMFREC_HIP_POISON_LDS=1 suite | tail -3 | tee $O/pytest_gpu_poisoned.log ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
