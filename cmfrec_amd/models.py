@@ -267,7 +267,8 @@ class CMF(_Base):
         # exactly the rows / columns of X (closed form); the matrices for predictions on new data are not produced (pass
         # precompute_for_predictions=False).  With observation weights (fit(..., W=)): the model without side information, closed
         # form or CG (k + k_main + bias <= 64), start values given by the caller (A0 / B0 / biasA0 / biasB0) when the model has
-        # biases -- the reference's own bias start values are not defined for that combination (common.c:4727-4731).
+        # biases -- the reference's own bias start values are not defined for that combination (common.c:4727-4731).  With sparse
+        # side information (on exactly the rows / columns of X) or with add_implicit_features (no side information): use_cg=False.
         self.NA_as_zero = bool(NA_as_zero)
         if self.NA_as_zero and precompute_for_predictions:
             raise NotImplementedError("NA_as_zero: precompute_for_predictions is not implemented in cmfrec_amd (pass False)")
