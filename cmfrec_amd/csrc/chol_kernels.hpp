@@ -88,6 +88,8 @@ struct CholParams {
     int rhs_only = 0;                     // CHOL_NAZ: store the gathered right-hand side and stop (the shared matrix is
                                           // factorised once by the caller, the solve is one triangular-solve pair)
     const T *values_override = nullptr;   // read the entries' values from here instead of `values` (all-ones indicator)
+    int entry_pairs = 0;                  // `weights` / `values` hold the entry's rank-1 weight and right-hand-side weight as they are
+                                          // (NA_as_zero_X with observation weights in the collective modes: w - 1 and the bracket)
     int x_rhs_only = 0;                   // the entries of X add to the right-hand side only (NA_as_zero_X in the collective modes: their
                                           // Gramian is the shared B^T B inside Mfull, collective.c:1631-1640).  TWO_SRC build.
     // non-negative factors: the assembled system is solved by the reference's cyclic coordinate descent instead of the
@@ -452,7 +454,7 @@ chol_rows_kernel(const CholParams<T> P)
             pre_wsyr = impl_w ? x : wg;             // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
             pre_wrhs = impl_w ? x + T(1) : x * wg;  // common.c:2082-2085, collective.c:2097-2101 vs common.c:985-996
             if (naz) pre_wsyr = T(0);               // the matrix is shared (common.c:3130-3140)
-            if (TWO_SRC && P.mode == CHOL_NAZ_W) { pre_wsyr = wg; pre_wrhs = x; }     // common.c:866-885 (w - 1 and the bracket arrive per entry)
+            if (TWO_SRC && (P.mode == CHOL_NAZ_W || P.entry_pairs)) { pre_wsyr = wg; pre_wrhs = x; }     // common.c:866-885 (w - 1 and the bracket arrive per entry)
             if (TWO_SRC && P.x_rhs_only) pre_wsyr = T(0);
             if (wsrc2) { pre_wsyr = P.w2_syr_zero ? T(0) : P.w2; pre_wrhs = P.w2 * wx; }   // collective.c:1636-1653, :1719-1731
         };

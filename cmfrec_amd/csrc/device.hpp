@@ -322,6 +322,9 @@ struct SparseShard {
             double nnz513 = 0;
             for (int q = 0; q < nrows && lens_sorted[q] >= 513u; q++) nnz513 += (double)lens_sorted[q];
             const bool gram = (switches().vh != 0) ? switches().vh == 2 : gram_pays(nnz513, n_other, opp_row_bytes_hint);
+            // (Round 5: 385 / 321 / 258 for a shard whose split rows hold 40 % of the entries -- C2's items -- move the eight-wave bin's rows
+            //  to the slice kernel, 87 against 115-126 ps per entry: in line the two bins gain 0.035 ms together, side by side on two streams
+            //  the half-step does not change, 3.285 / 3.298 against 3.293 / 3.286 ms; profiles/r05/r05_l_split_boundary.txt, r05_m_*)
             if (gram && opp_row_bytes_hint <= 16 * 4 * sizeof(real_t)) vh_min = 513;
         }
         long long vh_total = 0;

@@ -895,7 +895,6 @@ int_t fit_collective_explicit_als(
     real_t *precomputedTransCtCinvCt, real_t *precomputedCtCw, real_t *precomputedCtUbias)
 {
     (void)max_cd_steps;
-    (void)precomputedBtXbias;      // only with NA_as_zero_X (collective.c:8938-8986), not supported
     (void)precomputedBiTBi;        // with add_implicit_features the prediction matrices are not produced here
     // collective.c:7308-7329
     if (k_user && U == nullptr && nnz_U == 0) return fail(verbose, "Cannot pass 'k_user' without U data.");
@@ -994,9 +993,12 @@ int_t fit_collective_explicit_als(
     // without side information on that side (common.c:3118-3205: closed form whatever use_cg says), optimizeA_collective with
     // the factorised shared block matrix (collective.c:5607-5617, :5700-5716) with dense complete side information
     if (NA_as_zero_X && (nonneg || l1_lam != 0 || l1_lam_unique ||
-                         precompute_for_predictions || (scale_bias_const && (scale_lam || scale_lam_sideinfo) && (user_bias || item_bias))))
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without "
-                             "nonneg / L1, scale_bias_const and without precompute_for_predictions.");
+                         (scale_bias_const && (scale_lam || scale_lam_sideinfo) && (user_bias || item_bias))))
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X is implemented for the model without nonneg / L1 and scale_bias_const.");
+    // the matrices for predictions (round 5): for the model without side information -- B_plus_bias, BtB, TransBtBinvBt as ever, plus
+    // BtXbias, the constant every new row's right-hand side receives (collective.c:8938-8986)
+    if (NA_as_zero_X && precompute_for_predictions && (U || II || nnz_U || nnz_I || add_implicit_features))
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X with precompute_for_predictions: the model without side information and implicit features.");
     // ... with implicit features (round 5): the model without side information and weights, closed form (optimizeA_collective's
     // general branch on a matrix all rows share, collective.c:8612 / :8783 -> :1534-1846)
     if (NA_as_zero_X && add_implicit_features && (U || II || nnz_U || nnz_I || weight != nullptr || use_cg))
@@ -1014,11 +1016,13 @@ int_t fit_collective_explicit_als(
             return fail(verbose, "cmfrec_hip: NA_as_zero_X with side information: U / I must have exactly the rows / columns of X.");
     }
     // ... with observation weights (round 5): optimizeA Case 4's NA_as_zero + weight branches (common.c:3209-3302, :846-907,
-    // :1293-1441), the model without side information.  Not with start values for the biases: the reference's own
-    // (initialize_biases with NA_as_zero and weights) index the item biases by row inside the item sweep (common.c:4727-4731).
+    // :1293-1441) without side information; with DENSE complete side information the rows with entries leave the shared
+    // factorisation for collective_closed_form_block's general branch (collective.c:1367-1372, :1534-1846), closed form.  Not
+    // with start values for the biases: the reference's own (initialize_biases with NA_as_zero and weights) index the item biases
+    // by row inside the item sweep (common.c:4727-4731).
     if (NA_as_zero_X && weight != nullptr) {
-        if (U || II || k_user || k_item)
-            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights: the model without side information.");
+        if ((U || II) && use_cg)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights and side information: closed form only (use_cg = false).");
         if ((user_bias || item_bias) && reset_values)
             return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights: pass start values for the biases (reset_values = false); "
                                  "the reference's own start values are not defined for this combination.");
@@ -1427,6 +1431,19 @@ int_t fit_collective_explicit_als(
                                                 hadU ? precomputedTransCtCinvCt : nullptr);
         if (rc2) rc_loop = rc2;
         if (naz_U && !rc2) fill_CtUbias(precomputedCtUbias, C, U_colmeans, p, k_user + k, w_user);   // collective.c:9244-9252, :10115-10123
+        if (!rc2 && NA_as_zero_X && precomputedBtXbias != nullptr) {
+            // minus the sum over the items of (their bias + the mean) x their factors, the bias column as 1 (collective.c:8938-8986)
+            const int_t kp = k + k_main + (user_bias ? 1 : 0);
+            std::vector<double> acc((size_t)kp, 0.);
+            if (item_bias || center)
+                for (int_t c = 0; c < n; c++) {
+                    const double coef = -((item_bias ? (double)biasB[c] : 0.) + (double)gm);
+                    const real_t *b = B + (size_t)c * k_totB + k_item;
+                    for (int_t f = 0; f < k + k_main; f++) acc[(size_t)f] += coef * (double)b[f];
+                    if (user_bias) acc[(size_t)(kp - 1)] += coef;
+                }
+            for (int_t f = 0; f < kp; f++) precomputedBtXbias[f] = (real_t)acc[(size_t)f];
+        }
         if (!rc2 && user_bias && B_plus_bias) {                           // append_ones_last_col, :8908-8920
             for (int_t c = 0; c < n_max; c++) {
                 memcpy(B_plus_bias + (size_t)c * (k_totB + 1), B + (size_t)c * k_totB, (size_t)k_totB * sizeof(real_t));

@@ -54,6 +54,7 @@ struct CholCall {
     bool rhs_prefilled_all = false;          // every row starts from the right-hand side left in A
     const real_t *weights_override = nullptr; // CHOL_NAZ_W: the entries' rank-1 weights (w - 1), CSR order of X
     bool x_rhs_only = false;                 // the entries of X add to the right-hand sides only (their Gramian is inside Mfull)
+    bool entry_pairs = false;                // weights_override / values_override are the entries' rank-1 and right-hand-side weights
     const real_t *mult_override = nullptr;   // per-row lambda multipliers of the collective modes instead of the rows' lengths
     bool all_rows = false;                   // CHOL_NAZ_W: rows without entries are solved too (from the prefilled right-hand side)
     int row_limit = -1;                      // only the first row_limit positions of the processing order (the others are solved elsewhere)
@@ -84,6 +85,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     if (c.mode == CHOL_NAZ_W) { P.weights = c.weights_override; P.wsum = X->wsum.ptr; }
     if (c.mult_override != nullptr) P.wsum = c.mult_override;
     P.x_rhs_only = c.x_rhs_only ? 1 : 0;
+    if (c.entry_pairs) { P.entry_pairs = 1; P.weights = c.weights_override; }
     P.order = X ? X->order.ptr : nullptr;
     if (c.mode == CHOL_PREFILLED) P.nrows = nrows_prefilled;
     else if (c.mode == CHOL_COLLECTIVE || c.mode == CHOL_COLLECTIVE_IMPLICIT || (c.mode == CHOL_NAZ_W && c.all_rows)) P.nrows = X->nrows;   // empty rows too
@@ -121,7 +123,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     HIP_CHECK(hipMemsetAsync(dev.row_counter.ptr, 0, 4 * sizeof(int), dev.stream));   // [0, 4): first launches of this call
     P.counter = dev.row_counter.ptr;
     P.row_first = 0;
-    const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ || c.mode == CHOL_NAZ_W;      // CHOL_NAZ[_W] are part of that build only
+    const bool two_src = c.X2 != nullptr || c.mode == CHOL_NAZ || c.mode == CHOL_NAZ_W || c.x_rhs_only || c.entry_pairs;   // (that build only)
     // Rows of up to WAVE_ROW_MAX entries: one wavefront per row, the matrix in its registers (chol_wave_kernels.hpp).
     // The rows beyond (they lead the processing order) stay with the workgroup-per-row kernel below; the two launches
     // run side by side on two streams.  CMFREC_HIP_CHOL=rows keeps everything on the workgroup-per-row kernel (A/B
@@ -1868,6 +1870,74 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
     return 0;
 }
 
+// ... WITH observation weights on a side that carries DENSE side information (round 5): a row with entries leaves the shared
+// factorisation (collective.c:1367-1372 wants weight == NULL || nnz == 0) for collective_closed_form_block's general branch,
+//     M_i   = w C^T C (+) B^T B + sum_j (w_j - 1) b_j b_j^T + lam mult_i I,   mult_i = sum of the row's weights + absent entries (+ p)
+//     rhs_i = [w U C ; sum_j (w_j x_j - (w_j - 1)(mean + bias_j)) b_j + cst]
+// on the row Cholesky kernel's collective mode: w C^T C for the rows with side information (all of them), blockdiag(0, B^T B) as the
+// matrix every row starts from, the entries' weight pairs as they are (entry_pairs), the right-hand sides prefilled.  Closed form.
+static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool chol)
+{
+    const cmfrec_hip_model &m = s->mdl;
+    const DeviceInfo &dev = s->dev;
+    hipStream_t st = dev.stream;
+    if (!chol) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights and side information: closed form only (use_cg = false)";
+        return 2;
+    }
+    const int p_self = isA ? m.p : m.q, rows_u = isA ? m.m_u : m.n_i;
+    const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
+    if (rows_u != rows_self) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with side information: side information on exactly the rows / columns of X";
+        return 2;
+    }
+    real_t *self = isA ? s->A.ptr : s->B.ptr;
+    real_t *opp = isA ? s->B.ptr : s->A.ptr;
+    const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
+    const int k_side_self = isA ? m.k_user : m.k_item, k_side_opp = isA ? m.k_item : m.k_user;
+    const SparseShard &X = isA ? s->Xr : s->Xc;
+    const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+    const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+    const real_t w = isA ? m.w_user : m.w_item;
+    const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
+    const real_t lam_self = s->lam6[isA ? 2 : 3];
+    const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
+    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0), kc = k_side_self + m.k, kt = k_side_self + ks;
+    const real_t *oppx = opp + k_side_opp;
+    if (self_bias)
+        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
+    launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);
+    s->naz_M.alloc_at_least((size_t)kt * kt);
+    hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, st, s->gram.ptr, ks, k_side_self, (real_t)0, s->naz_M.ptr);
+    launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);
+    // right-hand sides start from [w U C ; cst]
+    HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
+    launch_gemm<false>(dev, rows_self, kc, p_self, w, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
+    const bool has_cst = opp_bias || s->naz_center;
+    const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
+    if (has_cst) {
+        const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
+        s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
+        hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, oppx, ld_opp, rows_opp, ks, bias,
+                           s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
+        hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
+        hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self + k_side_self, ld_self, (size_t)rows_self, ks,
+                           s->naz_vec.ptr);
+    }
+    const size_t nnz = X.nnz;
+    s->naz_g.alloc_at_least(std::max<size_t>(nnz, 1)); s->naz_xt.alloc_at_least(std::max<size_t>(nnz, 1));
+    if (nnz > 0)
+        hipLaunchKernelGGL(naz_entry_transform_kernel<real_t>, grid1d(nnz), dim3(256), 0, st, X.v.ptr, X.w.ptr, X.i.ptr, nnz,
+                           has_cst ? bias : nullptr, s->naz_center ? s->naz_mean : (real_t)0, s->naz_g.ptr, s->naz_xt.ptr);
+    HIP_CHECK(hipGetLastError());
+    const bool scaled = m.scale_lam || m.scale_lam_sideinfo;
+    CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, s->ctc.ptr, kc, rows_u, p_self, lam_self, lam_last_self, scaled,
+               (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE, s->naz_M.ptr};
+    c.rhs_prefilled_all = true; c.entry_pairs = true; c.values_override = s->naz_xt.ptr; c.weights_override = s->naz_g.ptr;
+    if (scaled) c.mult_override = X.wsum.ptr;            // sum of the row's weights + its absent entries (cmfrec_hip_session_set_NA_as_zero_X)
+    return launch_chol(dev, c, &X);
+}
+
 // The same half-step WITH observation weights and without side information (optimizeA Case 4 with NA_as_zero && weight,
 // common.c:3209-3302; driver collective.c:8573-8600 + :8680-8717, :8756-8787 + :8847-8876): an absent entry is a zero of weight
 // one, so every row's system is the shared opp^T opp plus the correction of its present entries,
@@ -1884,14 +1954,16 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
-    if ((isA ? m.p : m.q) > 0 || m.k_user != 0 || m.k_item != 0 || s->implicit_feats || dev.nonneg_now || dev.l1_now != (real_t)0 ||
-        dev.l1_last_now != (real_t)0 || s->sparseU || s->sparseI || s->side_local || m.p > 0 || m.q > 0) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without side information, implicit features, nonneg / L1";
+    const int p_self = isA ? m.p : m.q;
+    if (s->implicit_feats || dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || s->sparseU || s->sparseI ||
+        s->side_local) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without sparse side information, implicit features, nonneg / L1";
         return 2;
     }
+    if (p_self > 0) return update_factor_naz_weighted_side(s, isA, chol);
     const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
     real_t *self = isA ? s->A.ptr : s->B.ptr;
-    real_t *opp = isA ? s->B.ptr : s->A.ptr;
+    real_t *opp = (isA ? s->B.ptr : s->A.ptr) + (isA ? m.k_item : m.k_user);      // the columns X refers to (the other side may carry k_item / k_user)
     const size_t ld_self = isA ? s->ldA : s->ldB, ld_opp = isA ? s->ldB : s->ldA;
     const SparseShard &X = isA ? s->Xr : s->Xc;
     const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
@@ -1903,7 +1975,8 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
         return 2;
     }
     if (self_bias)                            // the opposing bias column is fixed to 1 (collective.c:8538-8543, :8728-8732)
-        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
+        hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, isA ? s->B.ptr : s->A.ptr, ld_opp, rows_opp,
+                           isA ? s->k_totB : s->k_totA, (real_t)1);
     launch_gram(dev, s->gws, opp, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);       // :3233-3236, no diagonal
     // cst (bias_BtX) and the per-entry pairs
     const bool has_cst = opp_bias || s->naz_center;

@@ -264,14 +264,14 @@ class CMF(_Base):
         # runs it as the zero-filled dense matrix it denotes (fit.hip, ZeroFilledSide)
         self.NA_as_zero_user = bool(NA_as_zero_user); self.NA_as_zero_item = bool(NA_as_zero_item)
         # NA_as_zero (absent entries of a sparse X are zeros): without side information or with dense complete side information on
-        # exactly the rows / columns of X (closed form); the matrices for predictions on new data are not produced (pass
-        # precompute_for_predictions=False).  With observation weights (fit(..., W=)): the model without side information, closed
-        # form or CG (k + k_main + bias <= 64), start values given by the caller (A0 / B0 / biasA0 / biasB0) when the model has
-        # biases -- the reference's own bias start values are not defined for that combination (common.c:4727-4731).  With sparse
-        # side information (on exactly the rows / columns of X) or with add_implicit_features (no side information): use_cg=False.
+        # exactly the rows / columns of X (closed form); the matrices for predictions on new data (with BtXbias) for the model
+        # without side information and implicit features only.  With observation weights (fit(..., W=)): the model without side information, closed
+        # form or CG (k + k_main + bias <= 64), or with dense complete side information (closed form); start values given by the
+        # caller (A0 / B0 / biasA0 / biasB0) when the model has biases -- the reference's own bias start values are not defined
+        # for that combination (common.c:4727-4731).  With sparse side information (on exactly the rows / columns of X) or with
+        # add_implicit_features (no side information): use_cg=False.
         self.NA_as_zero = bool(NA_as_zero)
-        if self.NA_as_zero and precompute_for_predictions:
-            raise NotImplementedError("NA_as_zero: precompute_for_predictions is not implemented in cmfrec_amd (pass False)")
+        # (precompute_for_predictions with NA_as_zero: the model without side information -- checked in fit(), where the data is known)
         self.scale_bias_const = bool(scale_bias_const)
         if add_implicit_features and (nonneg or not np.isscalar(l1_lambda) or l1_lambda):
             raise NotImplementedError("add_implicit_features together with nonneg / l1_lambda is not implemented in "
@@ -353,6 +353,10 @@ class CMF(_Base):
         TCt = np.zeros((p, kc), dt) if (pre and p) else None
         CtCw = np.zeros((kc, kc), dt) if (pre and p) else None
         CtUbias = np.zeros(kc, dt) if (pre and p and Us is not None and self.NA_as_zero_user) else None
+        if self.NA_as_zero and pre and (p or q or imp):
+            raise NotImplementedError("NA_as_zero with side information or implicit features: precompute_for_predictions is not "
+                                      "implemented in cmfrec_amd (pass False)")
+        BtXbias = np.zeros(kp, dt) if (pre and self.NA_as_zero) else None       # reference attribute BtXbias_ (cmfrec/__init__.py)
         rc = lib.fit_collective_explicit_als(
             _lib.ptr(biasA), _lib.ptr(biasB), _lib.ptr(A), _lib.ptr(B), _lib.ptr(Cm), _lib.ptr(Dm), _lib.ptr(Ai), _lib.ptr(Bi),
             C.c_bool(imp), C.c_bool(reset), C.c_int(self.random_state), _lib.ptr(glob_mean),
@@ -371,7 +375,7 @@ class CMF(_Base):
             C.c_bool(use_cg), C.c_int(self.max_cg_steps), C.c_bool(self.precondition_cg),
             C.c_bool(self.finalize_chol), C.c_bool(self.nonneg), C.c_int(self.max_cd_steps), C.c_bool(self.nonneg_C),
             C.c_bool(self.nonneg_D),
-            C.c_bool(pre), C.c_bool(True), _lib.ptr(Bpb), _lib.ptr(BtB), _lib.ptr(TBt), None, _lib.ptr(BeChol), None,
+            C.c_bool(pre), C.c_bool(True), _lib.ptr(Bpb), _lib.ptr(BtB), _lib.ptr(TBt), _lib.ptr(BtXbias), _lib.ptr(BeChol), None,
             _lib.ptr(TCt), _lib.ptr(CtCw), _lib.ptr(CtUbias))
         _lib.check(rc, lib, "fit_collective_explicit_als", interrupt_ok=self.handle_interrupt)
         # precomputed matrices for predictions on new data, reference attribute names (cmfrec/__init__.py:3211-3247)
@@ -379,6 +383,7 @@ class CMF(_Base):
         self._B_plus_bias = Bpb if Bpb is not None else e
         self._BtB = BtB if BtB is not None else e
         self._TransBtBinvBt = TBt if TBt is not None else e
+        self._BtXbias = BtXbias if BtXbias is not None else np.empty(0, dt)
         self._BeTBeChol = BeChol if BeChol is not None else e
         self._TransCtCinvCt = TCt if TCt is not None else e
         self._CtUbias = CtUbias if CtUbias is not None else np.empty(0, dt)

@@ -1413,12 +1413,22 @@ static void zero_rows_(real_t *M, size_t ld, int_t ncols, const int_t *rows, int
  * +  bias_BtX on the k + k_main columns behind k_user (:5815-5821); rows go through the tpotrs branch of
  * collective_closed_form_block (:1364-1460).  Rows of X beyond the side information (m > m_u, :4832-4908): optimizeA Case 3
  * on the columns behind k_user, lam x n under scale_lam; their first k_user entries stay zero (:4817-4822). */
+/* Observation weights of the collective_naz_chol call that follows (cleared by the call): with them a row that has entries is no
+ * longer served by the shared factorisation (collective.c:1367-1372: weight == NULL || nnz == 0) but by the general branch --
+ * the shared matrix plus (w_j - 1) B_j B_j^T over its entries (:1659-1665), right-hand side sum_j [w_j x_j - (w_j - 1)(mean +
+ * bias_j)] B_j (:1741-1753), lambda multiplier wsum_i = sum of the row's weights + number of its absent entries (+ p under
+ * scale_lam_sideinfo, :1305-1346).  w in the order of Xcsr. */
+static const real_t *g_cn_w = NULL, *g_cn_wsum = NULL, *g_cn_biasX = NULL;
+static real_t g_cn_glob = 0;
 static void collective_naz_chol(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C,
                                 int_t m, int_t m_u, int_t n, int_t p, int_t k, int_t k_main, int_t k_user, int_t k_item,
                                 const size_t *Xcsr_p, const int_t *Xcsr_i, const real_t *Xcsr, const real_t *U,
                                 real_t lam, real_t w_user, real_t lam_last, bool scale_lam, bool scale_lam_sideinfo,
                                 const real_t *bias_BtX, int nthreads)
 {
+    const real_t *wts = g_cn_w, *wsum = g_cn_wsum, *biasX = g_cn_biasX;
+    const real_t globX = g_cn_glob;
+    g_cn_w = NULL; g_cn_wsum = NULL; g_cn_biasX = NULL; g_cn_glob = 0;
     if (nthreads < 1) nthreads = 1;
     if (m_u > m) m_u = m;
     const int_t kt = k_user + k + k_main, kc = k_user + k, kb = k + k_main;
@@ -1430,12 +1440,45 @@ static void collective_naz_chol(real_t *A, size_t lda, const real_t *B, size_t l
     oracle_gram(C, (size_t)kc, p, kc, CtC, nthreads);
     for (int_t i = 0; i < kc; i++) for (int_t j = 0; j < kc; j++) M[(size_t)i * kt + j] = w_user * CtC[(size_t)i * kc + j];
     for (int_t i = 0; i < kb; i++) for (int_t j = 0; j < kb; j++) M[(size_t)(k_user + i) * kt + (k_user + j)] += BtB[(size_t)i * kb + j];
+    real_t *M0 = NULL;                                                         /* the shared matrix without its diagonal term */
+    if (wts != NULL) { M0 = (real_t *)malloc((size_t)kt * kt * sizeof(real_t)); memcpy(M0, M, (size_t)kt * kt * sizeof(real_t)); }
     for (int_t i = 0; i < kt - 1; i++) M[(size_t)i * kt + i] += lam * mult;
     M[(size_t)(kt - 1) * kt + (kt - 1)] += lam_last * mult;
     const int bad = chol_upper_(kt, M, kt);
     #pragma omp parallel for schedule(dynamic) num_threads(nthreads)
     for (int_t ix = 0; ix < m_u; ix++) {
         real_t *a = A + (size_t)ix * lda;
+        const size_t st = Xcsr_p[ix], en = Xcsr_p[(size_t)ix + 1];
+        if (wts != NULL && en > st) {                                          /* general branch, :1534-1846 */
+            real_t *Mi = (real_t *)malloc((size_t)kt * kt * sizeof(real_t));
+            memcpy(Mi, M0, (size_t)kt * kt * sizeof(real_t));
+            real_t *Mlr = Mi + (size_t)k_user + (size_t)k_user * kt;
+            double ws = 0;
+            for (size_t jx = st; jx < en; jx++) {
+                const real_t *b = B + k_item + (size_t)Xcsr_i[jx] * ldb;
+                const real_t w = wts[jx];
+                syr_upper_(kb, w - (real_t)1, b, Mlr, kt);                     /* :1659-1665 */
+                axpy_(kb, (w * Xcsr[jx]) - (w - (real_t)1) * (globX + ((biasX == NULL) ? (real_t)0 : biasX[Xcsr_i[jx]])), b, a + k_user);
+                ws += (double)w;
+            }
+            for (int_t c = 0; c < kc; c++) {
+                double acc = 0;
+                for (int_t j = 0; j < p; j++) acc += (double)U[(size_t)ix * p + j] * (double)C[(size_t)j * kc + c];
+                a[c] += w_user * (real_t)acc;
+            }
+            if (bias_BtX != NULL) axpy_(kb, (real_t)1, bias_BtX, a + k_user);
+            real_t mi = (real_t)1;
+            if (scale_lam || scale_lam_sideinfo) {                             /* :1285-1355 */
+                mi = (wsum != NULL && wsum[ix] > 0) ? wsum[ix] : (real_t)ws + (real_t)(n - (int_t)(en - st));
+                if (scale_lam_sideinfo) mi += (real_t)p;
+            }
+            for (int_t i = 0; i < kt - 1; i++) Mi[(size_t)i * kt + i] += lam * mi;
+            Mi[(size_t)(kt - 1) * kt + (kt - 1)] += lam_last * mi;
+            for (int_t i = 0; i < kt; i++) for (int_t j = 0; j < i; j++) Mi[(size_t)i * kt + j] = Mi[(size_t)j * kt + i];
+            solve_sym_(kt, Mi, kt, a);
+            free(Mi);
+            continue;
+        }
         for (size_t jx = Xcsr_p[ix]; jx < Xcsr_p[(size_t)ix + 1]; jx++)
             axpy_(kb, Xcsr[jx], B + k_item + (size_t)Xcsr_i[jx] * ldb, a + k_user);
         for (int_t c = 0; c < kc; c++) {
@@ -1447,7 +1490,7 @@ static void collective_naz_chol(real_t *A, size_t lda, const real_t *B, size_t l
         if (!bad) chol_solve_upper_(kt, M, kt, a);
         else for (int_t c = 0; c < kt; c++) a[c] = NAN;
     }
-    free(M); free(BtB); free(CtC);
+    free(M); free(M0); free(BtB); free(CtC);
     if (m > m_u) {
         oracle_set_naz_bias_BtX(bias_BtX);
         oracle_optimizeA_naz(A + k_user + (size_t)m_u * lda, lda, B + k_item, ldb, m - m_u, n, kb, Xcsr_p + m_u, Xcsr_i, Xcsr,
@@ -1630,7 +1673,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     if (naz && (Ai != NULL && Bi != NULL) && (U != NULL || II != NULL || weight != NULL || use_cg)) return 2;
     /* missing-as-zero WITH weights: the model without side information, start values given (the reference's weighted bias start
      * values under NA_as_zero index biasB by row inside its item sweep, common.c:4727-4731 -- nothing to restate) */
-    if (naz && weight != NULL && (U != NULL || II != NULL || init_biases)) return 2;
+    if (naz && weight != NULL && (init_biases || ((U != NULL || II != NULL) && use_cg))) return 2;
     /* (use_cg changes nothing there: the factorised block matrix is taken before the solver is looked at, collective.c:1364-1460) */
     if (naz && (U != NULL || II != NULL) && (g_nn_AB || g_l1_base != 0 || g_has_l16 || (U != NULL && m_u != m) || (II != NULL && n_i != n))) return 2;
     if (U == NULL) { m_u = 0; p = 0; }
@@ -1638,7 +1681,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
     if ((k_user && U == NULL) || (k_item && II == NULL)) return 2;             /* collective.c:7308-7318 */
     /* weights: restated for the model without side information (the row solvers of common.c); the collective solvers with
      * weights are checked against the reference build itself (tests/test_gpu_fit.py) */
-    if (weight != NULL && (U != NULL || II != NULL || (Ai != NULL && Bi != NULL) || g_scale_bias_const)) return 2;
+    if (weight != NULL && (((U != NULL || II != NULL) && !naz) || (Ai != NULL && Bi != NULL) || g_scale_bias_const)) return 2;
     /* side information may cover more users / items than X: A, B have max(m, m_u) / max(n, n_i) rows
      * (collective.c:7332-7335); X is padded with empty rows / columns.  The rows beyond X are fitted to their
      * side information alone by a separate dense solve (optimizeA Case 1, collective.c:4967-5101). */
@@ -1831,6 +1874,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                 for (int_t r = 0; r < m; r++)
                     axpy_(ks, -((user_bias ? biasA[r] : (real_t)0) + (center ? *glob_mean : (real_t)0)), A_bias + k_user + (size_t)r * ldA, btx);
             }
+            if (weight != NULL) { g_cn_w = weightC; g_cn_wsum = wsumB; g_cn_biasX = (btx != NULL && user_bias) ? biasA : NULL; g_cn_glob = *glob_mean; }
             collective_naz_chol(B_bias, ldB, A_bias, ldA, D, n_x, n_i, m, q, k, k_main + (int_t)item_bias, k_item, k_user,
                                 csc_p, csc_i, csc_v, Ic, lamB, w_item, lamBl, scale_lam, scale_lam_sideinfo, btx, nthreads);
             free(btx);
@@ -1908,6 +1952,7 @@ int oracle_fit_explicit_als_implicit_features(real_t *biasA, real_t *biasB, real
                 for (int_t c = 0; c < n; c++)
                     axpy_(ks, -((item_bias ? biasB[c] : (real_t)0) + (center ? *glob_mean : (real_t)0)), B_bias + k_item + (size_t)c * ldB, btx);
             }
+            if (weight != NULL) { g_cn_w = weightR; g_cn_wsum = wsumA; g_cn_biasX = (btx != NULL && item_bias) ? biasB : NULL; g_cn_glob = *glob_mean; }
             collective_naz_chol(A_bias, ldA, B_bias, ldB, C, m_x, m_u, n, p, k, k_main + (int_t)user_bias, k_user, k_item,
                                 csr_p, csr_i, csr_v, Uc, lamA, w_user, lamAl, scale_lam, scale_lam_sideinfo, btx, nthreads);
             free(btx);

@@ -340,6 +340,26 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g26_na_as_zero_implicit_features_" + tag, **out)
 
+        # ---- G27: NA_as_zero for the main matrix with the matrices for predictions ----
+        out = {}
+        d = gc.naz_problem(dt)
+        for ci, (name, opts) in enumerate(gc.NAZ_PRE_CASES):
+            r = gc.naz_pre_reference(R, d, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g27_na_as_zero_precompute_" + tag, **out)
+
+        # ---- G28: NA_as_zero for the main matrix with observation weights AND dense side information ----
+        out = {}
+        d = gc.naz_weighted_problem(dt)
+        for ci, (name, sides, opts) in enumerate(gc.NAZ_WEIGHTED_SIDE_CASES):
+            r = gc.naz_side_reference(R, d, sides, opts, weights=True)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g28_na_as_zero_weighted_sideinfo_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

@@ -402,6 +402,36 @@ def sparse_sideinfo_hip(d, implicit, which, sl, sls, dtype, solver=None):
     return dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, biasA=mdl.user_bias_, biasB=mdl.item_bias_, glob_mean=mdl.glob_mean_)
 
 
+# ---- NA_as_zero_X with precompute_for_predictions (model without side information): fixture g27 -- the fit's factors and the matrices
+# B_plus_bias, BtB, TransBtBinvBt, BtXbias (collective.c:8936-9082)
+NAZ_PRE_CASES = [
+    ("chol, biases", dict(use_cg=False)),
+    ("cg + finalize (the defaults), scale_lam", dict(use_cg=True, finalize_chol=True, scale_lam=True)),
+    ("no centring, item bias only", dict(use_cg=False, center=False, user_bias=False)),
+    ("no biases, centred", dict(use_cg=False, user_bias=False, item_bias=False)),
+]
+
+
+def naz_pre_reference(R, d, opts, nthreads=2):
+    o = dict(opts)
+    A0, B0 = _impf_start(d, o)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, precompute=True, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], BtXbias=r["pre"]["BtXbias"], BtB=r["pre"]["BtB"], TransBtBinvBt=r["pre"]["TransBtBinvBt"])
+    if o.get("user_bias", True): out["B_plus_bias"] = r["pre"]["B_plus_bias"]
+    return out
+
+
+def naz_pre_hip(d, opts, dtype):
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    A0, B0 = _impf_start(d, o)
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, use_float=dtype is np.float32, NA_as_zero=True, nthreads=1, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    return dict(A=mdl.A_, B=mdl.B_, BtXbias=mdl._BtXbias, BtB=mdl._BtB, TransBtBinvBt=mdl._TransBtBinvBt, B_plus_bias=mdl._B_plus_bias)
+
+
 # ---- NA_as_zero_X together with implicit features, no side information (optimizeA_collective's general branch on a matrix all rows
 # share: B^T B + w_i Bi^T Bi + lam mult I; collective.c:8612 / :8783 -> :1534-1846) -- fixture g26, closed form, the problem of g18
 NAZ_IMPF_CASES = [
@@ -1338,13 +1368,30 @@ def _naz_side(d, sides):
     return (d["U"] if "U" in sides else None), (d["I"] if "I" in sides else None)
 
 
-def naz_side_reference(R, d, sides, opts, nthreads=2):
+# ... and with observation weights on top (round 5): the rows with entries leave the shared factorisation for the general branch
+# of collective_closed_form_block (collective.c:1367-1372 -> :1534-1846) -- fixture g28, closed form, the problem of g24 (entries
+# ordered by column, see weights_problem)
+NAZ_WEIGHTED_SIDE_CASES = [
+    ("both sides, biases", "UI", dict()),
+    ("both sides, scale_lam", "UI", dict(scale_lam=True)),
+    ("both sides, scale_lam_sideinfo", "UI", dict(scale_lam_sideinfo=True)),
+    ("no biases, no centring", "UI", dict(user_bias=False, item_bias=False, center=False)),
+    ("k_user / k_item / k_main, weights of the sides, user bias", "UI", dict(center=False, item_bias=False, k_user=2, k_item=1, k_main=2,
+                                                                               w_user=0.7, w_item=1.3)),
+    ("user side only", "U", dict()),
+    ("item side only, scale_lam", "I", dict(scale_lam=True)),
+    ("per-matrix lambdas, item bias", "UI", dict(lam_unique=LAM6, user_bias=False)),
+]
+
+
+def naz_side_reference(R, d, sides, opts, nthreads=2, weights=False):
     o = dict(opts)
     seed = o.pop("seed", None)
     A0, B0 = _impf_start(d, o)
     U, II = _naz_side(d, sides)
     kw = dict(U=U, II=II, lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
               finalize_chol=o.pop("finalize_chol", False), **o)
+    if weights: kw["weight"] = d["W"]
     if seed is not None:
         A0[:] = 0; B0[:] = 0
         r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], reset_values=True, seed=seed, **kw)
@@ -1359,7 +1406,7 @@ def naz_side_reference(R, d, sides, opts, nthreads=2):
     return out
 
 
-def naz_side_oracle(O, d, sides, opts, nthreads=2):
+def naz_side_oracle(O, d, sides, opts, nthreads=2, weights=False):
     """None for the seeded cases (the oracle has no random start)."""
     o = dict(opts)
     if "seed" in o:
@@ -1372,7 +1419,7 @@ def naz_side_oracle(O, d, sides, opts, nthreads=2):
         A0, B0 = _impf_start(d, o)
         r = O.fit_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), U=U, II=II,
                                lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
-                               finalize_chol=o.pop("finalize_chol", False), **o)
+                               finalize_chol=o.pop("finalize_chol", False), weight=d["W"] if weights else None, **o)
     finally:
         O.set_lam_unique(None, None)
     assert r["ret"] == 0
@@ -1384,7 +1431,7 @@ def naz_side_oracle(O, d, sides, opts, nthreads=2):
     return out
 
 
-def naz_side_hip(d, sides, opts, dtype, **ctor):
+def naz_side_hip(d, sides, opts, dtype, weights=False, **ctor):
     from cmfrec_amd import CMF
     o = dict(opts)
     seed = o.pop("seed", None)
@@ -1397,7 +1444,7 @@ def naz_side_hip(d, sides, opts, dtype, **ctor):
     args.update(o); args.update(ctor)
     mdl = CMF(**args)
     start = {} if seed is not None else dict(A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
-    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), **start)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), W=d["W"] if weights else None, **start)
     out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
     if U is not None: out["C"] = mdl.C_
     if II is not None: out["D"] = mdl.D_

@@ -342,10 +342,20 @@ def test_NA_as_zero_X(oracles, dtype):
     # ... and the option changes the model
     assert gc.compare_fits(gc.naz_hip(d, gc.NAZ_CASES[0][1], dtype, NA_as_zero=False), {k[3:]: g[k] for k in g.files if k.startswith("c0_")}) > 1e-2
     from cmfrec_amd import CMF
-    with pytest.raises(NotImplementedError):
-        CMF(NA_as_zero=True)                          # precompute_for_predictions defaults to True
     with pytest.raises(RuntimeError):
         CMF(k=4, NA_as_zero=True, precompute_for_predictions=False, nonneg=True).fit((d["row"], d["col"], d["ratings"]), shape=(d["m"], d["n"]))
+    # the matrices for predictions, default constructor arguments otherwise (fixture g27: BtXbias, collective.c:8938-8986)
+    g27 = gc.load("g27_na_as_zero_precompute", dtype)
+    for ci, (name, opts) in enumerate(gc.NAZ_PRE_CASES):
+        got = gc.naz_pre_hip(d, opts, dtype)
+        for key in ("A", "B", "BtXbias", "BtB", "TransBtBinvBt", "B_plus_bias"):
+            if "c%d_%s" % (ci, key) in g27.files:
+                ref, mine = g27["c%d_%s" % (ci, key)], got[key]
+                if key == "BtB": ref, mine = np.triu(ref), np.triu(mine)       # (the reference fills the upper triangle, syrk 'U')
+                assert np.abs(mine - ref).max() <= tol * max(np.abs(ref).max(), 1e-30), (name, key)
+    with pytest.raises(NotImplementedError):
+        rng = np.random.default_rng(0)
+        CMF(k=4, NA_as_zero=True).fit((d["row"], d["col"], d["ratings"]), U=rng.standard_normal((d["m"], 3)).astype(dtype), shape=(d["m"], d["n"]))
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -434,6 +444,28 @@ def test_NA_as_zero_X_sideinfo(oracles, dtype):
     d2 = dict(d); d2["U"] = d["U"][:100]
     with pytest.raises(RuntimeError):
         gc.naz_side_hip(d2, "U", dict(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_weighted_sideinfo(oracles, dtype):
+    """G28 through the estimator (CMF(NA_as_zero=True).fit(X, U=, I=, W=)): with observation weights the rows that have entries are
+    solved one by one on the row Cholesky kernel's collective mode -- blockdiag(0, B^T B) as the matrix every row starts from,
+    w C^T C on the side-information block, the entries' pairs (w_j - 1, w_j x_j - (w_j - 1)(mean + bias_j)), lambda x (sum of the
+    row's weights + its absent entries (+ p)); the side without side information runs the weighted half-step of G24 on the columns
+    behind k_user / k_item."""
+    g = gc.load("g28_na_as_zero_weighted_sideinfo", dtype)
+    d = gc.naz_weighted_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, sides, opts) in enumerate(gc.NAZ_WEIGHTED_SIDE_CASES):
+        got = gc.naz_side_hip(d, sides, opts, dtype, weights=True)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+        assert gc.compare_fits(got, gc.naz_side_oracle(oracles[dtype], d, sides, opts, weights=True)) < tol, name
+    # the weights change the model, and the CG variant is refused
+    c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
+    assert gc.compare_fits(gc.naz_side_hip(d, "UI", dict(), dtype), c0) > 1e-3
+    with pytest.raises(RuntimeError):
+        gc.naz_side_hip(d, "UI", dict(use_cg=True), dtype, weights=True)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -25,8 +25,7 @@ def test_unsupported_options_raise():
     from cmfrec_amd import CMF, CMF_implicit
     with pytest.raises(NotImplementedError):
         CMF(method="lbfgs")
-    with pytest.raises(NotImplementedError):
-        CMF(NA_as_zero=True)
+    assert CMF(NA_as_zero=True).NA_as_zero          # (its prediction matrices exist for the model without side information: checked in fit())
     assert CMF(scale_bias_const=True, scale_lam=True).scale_bias_const
     six = CMF_implicit(l1_lambda=np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6]), lambda_=[1, 2, 3, 4, 5, 6])
     assert six.l1_lambda == 0.0 and six._l16[5] == 0.6 and six.lambda_ == 0.0 and six._lam6[2] == 3.0   # scalar 0 + array, like the reference

@@ -296,6 +296,19 @@ def test_NA_as_zero_X_sideinfo(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_X_weighted_sideinfo(oracles, dtype):
+    """G28: NA_as_zero_X with observation weights AND dense side information -- the rows with entries leave the factorised block
+    matrix for collective_closed_form_block's general branch (collective.c:1367-1372 -> :1534-1846): (w_j - 1) b_j b_j^T on top of
+    the shared matrix, lambda x (sum of the row's weights + its absent entries (+ p))."""
+    g = gc.load("g28_na_as_zero_weighted_sideinfo", dtype)
+    d = gc.naz_weighted_problem(dtype)
+    for ci, (name, sides, opts) in enumerate(gc.NAZ_WEIGHTED_SIDE_CASES):
+        got = gc.naz_side_oracle(oracles[dtype], d, sides, opts, weights=True)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < TOL_FIT[dtype], name
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_NA_as_zero_UI(oracles, dtype):
     """G21: NA_as_zero_U / NA_as_zero_I (the reference's sparse branches, collective.c:1277-1457, :5790-5836, C / D by optimizeA
     Case 3 with the column means as a rank-one correction) against the restatement: the dense route on the zero-filled

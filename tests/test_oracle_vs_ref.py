@@ -675,6 +675,39 @@ def test_NA_as_zero_weighted_fit_live(oracles, refs, dtype):
         assert abs(ro["glob_mean"] - rr["glob_mean"]) < 1e-6 * max(1.0, abs(rr["glob_mean"])), o
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_NA_as_zero_weighted_sideinfo_fit_live(oracles, refs, dtype):
+    """... and with DENSE side information on top (closed form): the rows with entries leave the factorised block matrix
+    (collective.c:1367-1372 wants weight == NULL || nnz == 0) for the general branch of collective_closed_form_block (:1534-1846);
+    rows without entries keep the shared factorisation.  Both sides, one side only, k_user / k_item / k_main, scale_lam /
+    scale_lam_sideinfo."""
+    O, R = oracles[dtype], refs[dtype]
+    m, n, row, col, val, wt = weights_problem(dtype, seed=94, m=120, n=90, nnz=2500)      # (entries ordered by column, see there)
+    keep = col != 11                                                                       # a column without entries
+    row, col, val, wt = row[keep], col[keep], val[keep], wt[keep]
+    k, p, q = 6, 7, 5
+    rng = np.random.default_rng(19)
+    U = rng.standard_normal((m, p)).astype(dtype); II = rng.standard_normal((n, q)).astype(dtype)
+    cases = [("UI", dict()), ("UI", dict(scale_lam=True)), ("UI", dict(scale_lam_sideinfo=True)),
+             ("UI", dict(user_bias=False, item_bias=False, center=False)),
+             ("UI", dict(center=False, item_bias=False, k_user=2, k_item=1, k_main=2, w_user=0.7, w_item=1.3)),
+             ("U", dict()), ("I", dict(scale_lam=True))]
+    for sides, o in cases:
+        ku, ki, km = o.get("k_user", 0), o.get("k_item", 0), o.get("k_main", 0)
+        A0 = (rng.standard_normal((m, ku + k + km)) * 0.1).astype(dtype); B0 = (rng.standard_normal((n, ki + k + km)) * 0.1).astype(dtype)
+        bA = (rng.standard_normal(m) * 0.1).astype(dtype); bB = (rng.standard_normal(n) * 0.1).astype(dtype)
+        kw = dict(U=U if "U" in sides else None, II=II if "I" in sides else None, lam=0.4, niter=3, nthreads=2, NA_as_zero_X=True,
+                  use_cg=False, weight=wt, **o)
+        ro = O.fit_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        rr = R.fit_collective_explicit_als(A0.copy(), B0.copy(), row, col, val, k, biasA=bA.copy(), biasB=bB.copy(), **kw)
+        assert ro["ret"] == 0 and rr["ret"] == 0, (sides, o)
+        keys = ("A", "B") + (("C",) if "U" in sides else ()) + (("D",) if "I" in sides else ())
+        keys += (("biasA",) if o.get("user_bias", True) else ()) + (("biasB",) if o.get("item_bias", True) else ())
+        for key in keys:
+            assert rel_err(ro[key], rr[key]) < 100 * TOL[dtype], (sides, o, key)
+        assert abs(ro["glob_mean"] - rr["glob_mean"]) < 1e-6 * max(1.0, abs(rr["glob_mean"])), o
+
+
 # ---- NA_as_zero for the main matrix together with SPARSE side information --------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("seed", [51, 52])
