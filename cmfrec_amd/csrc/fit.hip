@@ -1095,7 +1095,8 @@ int_t fit_collective_explicit_als(
     // observation weights (one per entry of X): every row solver and the start values of the biases take them; the lambda
     // multipliers of scale_lam become sums of weights (collective.c:7931-8008).  Not together with the options whose weight
     // bookkeeping is not restated: implicit features, sparse / NaN side information, scale_lam_sideinfo, scale_bias_const.
-    if (weight && (add_implicit_features || spU || spI || nan_side || scale_lam_sideinfo ||
+    // (scale_lam_sideinfo with weights under NA_as_zero_X: the multiplier is the weights' sum + the absent entries + p, no start values)
+    if (weight && (add_implicit_features || spU || spI || nan_side || (scale_lam_sideinfo && !NA_as_zero_X) ||
                    (scale_bias_const && scale_lam && (user_bias || item_bias))))
         return fail(verbose, "cmfrec_hip: observation weights together with implicit features / sparse or NaN side information / "
                              "scale_lam_sideinfo / scale_bias_const are not implemented.");
