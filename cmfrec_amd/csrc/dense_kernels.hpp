@@ -623,6 +623,16 @@ __global__ void restore_rows_kernel(T *__restrict__ M, const T *__restrict__ kee
     if (!mask[e / ld]) M[e] = keep[e];
 }
 
+// M[r, :] := keep[r, :] for the rows whose mask byte is NOT `value`
+template <typename T>
+__global__ void keep_rows_unless_kernel(T *__restrict__ M, const T *__restrict__ keep, size_t ld, size_t rows, const unsigned char *__restrict__ mask,
+                                        unsigned char value)
+{
+    const size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (e >= rows * ld) return;
+    if (mask[e / ld] != value) M[e] = keep[e];
+}
+
 // M[rows[e], 0 .. ncols) := 0
 template <typename T>
 __global__ void zero_rows_kernel(T *__restrict__ M, size_t ld, int ncols, const int *__restrict__ rows, int count)

@@ -83,6 +83,30 @@ int fail(bool verbose, const char *msg)
 struct DenseNanSide {
     std::vector<int_t> row, col;
     std::vector<real_t> val;
+    std::vector<int_t> na_col;                  // missing values per attribute
+    int_t n_rows = 0;
+    // What the reference's dense C / D update (optimizeA Cases 1-2 on the transposed matrix, common.c:2793-3116) does differently
+    // from the sparse one, per attribute.  An attribute that misses fewer than 2 kc values is solved from the precomputed Gramian
+    // minus the missing rows (factors_closed_form :759-790, ahead of the CG branch at :884): in closed form whatever use_cg says
+    // (mask 1), under scale_lam with the n_rows x lam of a complete attribute (:3031-3032 / :2832).  When at least 75 % of the
+    // attributes are complete (helpers.c:151-250) those share one factorisation (mask 1) and the ones that miss 2 kc values or
+    // more are redone by CG from zero with kc steps (mask 2; Case 1's fix-up loop, :2953-2985).  Mask 0: the solver asked for.
+    void rules(int_t kc, bool scale_lam, std::vector<unsigned char> &mask, std::vector<real_t> &mult) const
+    {
+        const int_t p = (int_t)na_col.size();
+        int_t with_na = 0;
+        bool any_few = false;
+        for (int_t c = 0; c < p; c++) { with_na += (na_col[c] > 0); any_few = any_few || (na_col[c] > 0 && na_col[c] < 2 * kc); }
+        const bool near = (p - with_na) >= (int_t)((real_t)0.75 * (real_t)p);
+        mask.resize((size_t)p);
+        for (int_t c = 0; c < p; c++) mask[c] = (na_col[c] < 2 * kc) ? 1 : (near ? 2 : 0);
+        mult.clear();
+        if (scale_lam && any_few) {
+            mult.resize((size_t)p);
+            for (int_t c = 0; c < p; c++)
+                mult[c] = (na_col[c] < 2 * kc) ? (real_t)n_rows : (na_col[c] < n_rows ? (real_t)(n_rows - na_col[c]) : (real_t)1);
+        }
+    }
     bool convert(const real_t *M, int_t rows, int_t cols, real_t *means)
     {
         bool any = false;
@@ -96,6 +120,8 @@ struct DenseNanSide {
                 if (!std::isnan(v)) { sum[c] += v; cnt[c]++; }
             }
         for (int_t c = 0; means && c < cols; c++) means[c] = (real_t)(sum[c] / (double)cnt[c]);
+        n_rows = rows; na_col.resize((size_t)cols);
+        for (int_t c = 0; c < cols; c++) na_col[c] = rows - (int_t)cnt[c];
         for (int_t r = 0; r < rows; r++)
             for (int_t c = 0; c < cols; c++) {
                 const real_t v = M[(size_t)r * cols + c];
@@ -728,10 +754,11 @@ int_t fit_collective_implicit_als(
         return fail(verbose, "cmfrec_hip: L1 together with side information beyond X is not implemented.");
     if (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique) use_cg = false;    // collective.c:9568-9571 (any of them, unlike the explicit model)
     // For rows with few missing values the reference corrects a precomputed Gramian instead of summing the present entries
-    // (factors_closed_form, common.c:762-790): the same solution with the Cholesky solver, but CG then restarts from zero with
-    // k steps (:2958-2985) and the non-negative / L1 solvers see another matrix layout -- not restated, so not offered.
-    if (nan_side && (use_cg || nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
-        return fail(verbose, "cmfrec_hip: NaN in dense side information: only the plain Cholesky solver is implemented.");
+    // (factors_closed_form, common.c:762-790): the same solution with the Cholesky solver; under CG such attributes are solved in
+    // closed form or restart from zero with k steps (:2958-2985) -- DenseNanSide::rules, handed to the session below.  The
+    // non-negative / L1 solvers see another matrix layout -- not restated, so not offered.
+    if (nan_side && (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
+        return fail(verbose, "cmfrec_hip: NaN in dense side information: not together with nonneg / L1.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     if (m <= 0 || n <= 0 || k + k_main <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
@@ -845,6 +872,15 @@ int_t fit_collective_implicit_als(
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
+    // dense side information with NaN: the per-attribute rules of the dense C / D update (DenseNanSide::rules)
+    for (int side = 0; side < 2 && !rc; side++) {
+        const DenseNanSide &ns = side ? nanI : nanU;
+        if (ns.na_col.empty() || !(side ? spI : spU)) continue;
+        std::vector<unsigned char> mask; std::vector<real_t> mult;
+        ns.rules((side ? k_item : k_user) + k, false, mask, mult);
+        if (use_cg) rc = cmfrec_hip_session_set_closed_form_rows(s, side ? 'D' : 'C', mask.data());
+        if (!rc && !mult.empty()) rc = cmfrec_hip_session_set_lambda_multipliers(s, side ? 'D' : 'C', mult.data());
+    }
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
     if (!rc && (lam_unique || l1_lam_unique))
@@ -1086,10 +1122,11 @@ int_t fit_collective_explicit_als(
     if (nonneg || l1_lam != 0 || l1_lam_unique) use_cg = false;           // collective.c:7474-7479
     // For rows with few missing values the reference corrects a precomputed Gramian instead of summing the present entries
     // (factors_closed_form, common.c:762-790).  Unscaled lambda + Cholesky: the same solution.  Under scale_lam that Gramian
-    // already carries lam x (all rows) (:3031-3032), CG restarts from zero with k steps (:2958-2985), and the non-negative /
-    // L1 solvers see another matrix layout -- per-row rules that are not restated, so those combinations are not offered.
-    if (nan_side && (use_cg || scale_lam || scale_lam_sideinfo || nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
-        return fail(verbose, "cmfrec_hip: NaN in dense side information: only the Cholesky solver with unscaled lambda is implemented.");
+    // already carries lam x (all rows) (:3031-3032) and under CG such attributes are solved in closed form or restart from zero
+    // with k steps (:2958-2985): per-attribute rules (DenseNanSide::rules, round 5) handed to the session below.  The
+    // non-negative / L1 solvers see another matrix layout -- not restated, so not offered.
+    if (nan_side && (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
+        return fail(verbose, "cmfrec_hip: NaN in dense side information: not together with nonneg / L1.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     // observation weights (one per entry of X): every row solver and the start values of the biases take them; the lambda
@@ -1337,6 +1374,15 @@ int_t fit_collective_explicit_als(
     if (!rc) rc = cmfrec_hip_session_set_sideinfo(s, U ? Uc.data() : nullptr, II ? Ic.data() : nullptr);
     if (!rc && spU) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'U', U_row, U_col, U_sp, nnz_U);
     if (!rc && spI) rc = cmfrec_hip_session_set_sideinfo_sparse(s, 'I', I_row, I_col, I_sp, nnz_I);
+    // dense side information with NaN: the per-attribute rules of the dense C / D update (DenseNanSide::rules)
+    for (int side = 0; side < 2 && !rc; side++) {
+        const DenseNanSide &ns = side ? nanI : nanU;
+        if (ns.na_col.empty() || !(side ? spI : spU)) continue;
+        std::vector<unsigned char> mask; std::vector<real_t> mult;
+        ns.rules((side ? k_item : k_user) + k, (scale_lam || scale_lam_sideinfo), mask, mult);
+        if (use_cg) rc = cmfrec_hip_session_set_closed_form_rows(s, side ? 'D' : 'C', mask.data());
+        if (!rc && !mult.empty()) rc = cmfrec_hip_session_set_lambda_multipliers(s, side ? 'D' : 'C', mult.data());
+    }
     if (!rc && (nonneg || nonneg_C || nonneg_D)) rc = cmfrec_hip_session_set_nonneg(s, nonneg, nonneg_C, nonneg_D, (int)max_cd_steps);
     if (!rc && l1_lam != 0) rc = cmfrec_hip_session_set_l1(s, l1_lam, (int)max_cd_steps);
     if (!rc && (lam_unique || l1_lam_unique || scale_bias_const))

@@ -894,6 +894,9 @@ struct cmfrec_hip_session {
     DevBuf<int> zrowsA, zrowsB;   // rows every update of A / B leaves at zero (cmfrec_hip_session_set_zero_rows)
     int n_zrowsA = 0, n_zrowsB = 0;
     DevBuf<unsigned char> cfmaskA, cfmaskB;   // rows that take the closed form inside a CG update (cmfrec_hip_session_set_closed_form_rows)
+    // ... and the attributes of dense side information with NaN (C / D updates): 1 = closed form, 2 = CG from zero with k_side + k steps
+    DevBuf<unsigned char> cfmaskC, cfmaskD;
+    bool cfC_any[3] = {false, false, false}, cfD_any[3] = {false, false, false};   // which mask values occur
     bool has_cfA = false, has_cfB = false;
     DevBuf<real_t> cf_keep;
     real_t l1_lam = 0;              // L1 penalty (after the w_main rescaling); C / D use l1_lam / w_user, / w_item
@@ -1552,7 +1555,27 @@ int cmfrec_hip_session_set_closed_form_rows(cmfrec_hip_session *s, int which, co
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
-        if (which != 'A' && which != 'B') { g_last_error = "cmfrec_hip_session_set_closed_form_rows: which must be 'A' or 'B'"; return 2; }
+        if (which == 'C' || which == 'D') {
+            // attributes of DENSE side information with NaN, which the session holds as the sparse matrix of its present values: what
+            // the reference's dense C / D update does per attribute inside a CG update (0: CG as asked for, 1: closed form, 2: CG from
+            // zero with k_side + k steps; fit.hip, DenseNanSide::rules)
+            const bool isC = which == 'C';
+            const size_t rows = (size_t)(isC ? s->mdl.p : s->mdl.q);
+            bool *any = isC ? s->cfC_any : s->cfD_any;
+            any[0] = any[1] = any[2] = false;
+            if (mask == nullptr) return 0;
+            if (!(isC ? s->sparseU : s->sparseI)) { g_last_error = "cmfrec_hip_session_set_closed_form_rows: 'C' / 'D' need sparse side information on that side"; return 2; }
+            for (size_t r = 0; r < rows; r++) {
+                if (mask[r] > 2) { g_last_error = "cmfrec_hip_session_set_closed_form_rows: mask values 0, 1, 2"; return 2; }
+                any[mask[r]] = true;
+            }
+            DevBuf<unsigned char> &buf = isC ? s->cfmaskC : s->cfmaskD;
+            buf.alloc_at_least(rows);
+            HIP_CHECK(hipMemcpyAsync(buf.ptr, mask, rows, hipMemcpyHostToDevice, s->dev.stream));
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+            return 0;
+        }
+        if (which != 'A' && which != 'B') { g_last_error = "cmfrec_hip_session_set_closed_form_rows: which must be 'A', 'B', 'C' or 'D'"; return 2; }
         const size_t rows = (size_t)(which == 'A' ? s->mdl.m : s->mdl.n);
         (which == 'A' ? s->has_cfA : s->has_cfB) = (mask != nullptr);
         if (mask != nullptr) {
@@ -1569,7 +1592,22 @@ int cmfrec_hip_session_set_lambda_multipliers(cmfrec_hip_session *s, int which, 
 {
     return guarded([&]() {
         HIP_CHECK(hipSetDevice(s->dev.device));
-        if ((which != 'A' && which != 'B') || mult == nullptr) { g_last_error = "cmfrec_hip_session_set_lambda_multipliers: which must be 'A' or 'B', mult non-null"; return 2; }
+        if (mult != nullptr && (which == 'C' || which == 'D')) {
+            // attributes of dense side information with NaN under scale_lam (DenseNanSide::rules): unit weights on the attribute-major
+            // shard of the present values (a multiplication by one: the unweighted numbers bit for bit) carry the multipliers
+            SparseShard &Us = which == 'C' ? s->Usc : s->Isc;
+            if (!(which == 'C' ? s->sparseU : s->sparseI) || Us.nnz == 0) {
+                g_last_error = "cmfrec_hip_session_set_lambda_multipliers: 'C' / 'D' need sparse side information on that side";
+                return 2;
+            }
+            Us.w.alloc_at_least(Us.nnz);
+            hipLaunchKernelGGL(fill_kernel<real_t>, grid1d(Us.nnz), dim3(256), 0, s->dev.stream, Us.w.ptr, Us.nnz, (real_t)1);
+            HIP_CHECK(hipGetLastError());
+            Us.wsum.upload(mult, (size_t)Us.nrows, s->dev.stream);
+            HIP_CHECK(hipStreamSynchronize(s->dev.stream));
+            return 0;
+        }
+        if ((which != 'A' && which != 'B') || mult == nullptr) { g_last_error = "cmfrec_hip_session_set_lambda_multipliers: which must be 'A', 'B', 'C' or 'D', mult non-null"; return 2; }
         SparseShard &X = which == 'A' ? s->Xr : s->Xc;
         if (!X.weighted() || s->mdl.implicit) {
             g_last_error = "cmfrec_hip_session_set_lambda_multipliers: the explicit model with observation weights on X (unit weights will do)";
@@ -2359,7 +2397,7 @@ static int update_implicit_feats(cmfrec_hip_session *s, bool isAi)
 }
 
 // C / D update: optimizeA Case 1 with do_B (common.c:2793-2991; Q6: always the transposed gemm)
-static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol)
+static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol, int cg_steps = -1)
 {
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
@@ -2380,7 +2418,7 @@ static int update_sideinfo(cmfrec_hip_session *s, bool isC, bool chol)
         // first k_side+k columns of the factor matrix (collective.c:8354-8386; attributes nobody has stay untouched)
         const SparseShard &Uc = isC ? s->Usc : s->Isc;
         if (!chol) {
-            CgCall cg{Cm, (size_t)kc, F, ldF, kc, nullptr, nullptr, lam, lam, scale_lam, false, m.max_cg_steps, false,
+            CgCall cg{Cm, (size_t)kc, F, ldF, kc, nullptr, nullptr, lam, lam, scale_lam, false, cg_steps > 0 ? cg_steps : m.max_cg_steps, false,
                       (bool)m.precondition_cg};
             return launch_cg_any(dev, cg, Uc);
         }
@@ -2600,7 +2638,30 @@ int cmfrec_hip_session_update(cmfrec_hip_session *s, int which, int use_cholesky
                                "cmfrec_hip_session_sideinfo_partial / _finish";
                 return 2;
             }
-            return update_sideinfo(s, which == 'C', chol);
+            const bool isC = which == 'C';
+            int rc = update_sideinfo(s, isC, chol);
+            const bool *any = isC ? s->cfC_any : s->cfD_any;
+            if (rc == 0 && !chol && (isC ? s->sparseU : s->sparseI) && (any[1] || any[2])) {
+                // dense side information with NaN (cmfrec_hip_session_set_closed_form_rows 'C' / 'D'): next to the CG attributes the
+                // reference solves some in closed form (mask 1) and some by CG from zero with k_side + k steps (mask 2)
+                real_t *Cm = isC ? s->C.ptr : s->D.ptr;
+                const int kc = (isC ? s->mdl.k_user : s->mdl.k_item) + s->mdl.k;
+                const size_t rows = (size_t)(isC ? s->mdl.p : s->mdl.q), ld = (size_t)kc;
+                const unsigned char *mask = (isC ? s->cfmaskC : s->cfmaskD).ptr;
+                hipStream_t st = s->dev.stream;
+                s->cf_keep.alloc_at_least(rows * ld);
+                for (int value = 1; value <= 2 && rc == 0; value++) {
+                    if (!any[value]) continue;
+                    HIP_CHECK(hipMemcpyAsync(s->cf_keep.ptr, Cm, rows * ld * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+                    if (value == 2) HIP_CHECK(hipMemsetAsync(Cm, 0, rows * ld * sizeof(real_t), st));
+                    rc = value == 1 ? update_sideinfo(s, isC, true) : update_sideinfo(s, isC, false, kc);
+                    if (rc != 0) { HIP_CHECK(hipMemcpyAsync(Cm, s->cf_keep.ptr, rows * ld * sizeof(real_t), hipMemcpyDeviceToDevice, st)); break; }
+                    hipLaunchKernelGGL(keep_rows_unless_kernel<real_t>, grid1d(rows * ld), dim3(256), 0, st, Cm, s->cf_keep.ptr, ld, rows, mask,
+                                       (unsigned char)value);
+                    HIP_CHECK(hipGetLastError());
+                }
+            }
+            return rc;
         }
         if ((which == 'a' || which == 'b') && s->implicit_feats) return update_implicit_feats(s, which == 'a');
         g_last_error = "cmfrec_hip: unknown update target";

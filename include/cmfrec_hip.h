@@ -389,13 +389,22 @@ int cmfrec_hip_session_set_zero_rows(cmfrec_hip_session *s, int which, const int
  * others: a dense X whose half-step (optimizeA Case 2, src/common.c:2992-3116) has rows missing fewer than 2 k entries (closed form
  * from the precomputed B^T B, factors_closed_form :662, :759-790) next to rows missing more (the solver asked for).  mask: one byte
  * per row of the matrix, non-zero = closed form; NULL clears it.  A CG update then solves every row by CG, keeps a copy, solves
- * every row in closed form and puts the copy back for the rows whose byte is zero. */
+ * every row in closed form and puts the copy back for the rows whose byte is zero.
+ * 'C' / 'D' (round 5): the attributes of DENSE side information with NaN, which the session holds as the sparse matrix of its
+ * present, centred values (cmfrec_hip_session_set_sideinfo_sparse).  The reference's dense C / D update (optimizeA Cases 1-2 on
+ * the transposed matrix, src/common.c:2793-3116) treats an attribute by the number of values it misses; one byte per attribute:
+ * 0 = the solver asked for, 1 = closed form (fewer than 2 (k_side + k) missing values, :759-790; the complete attributes of a
+ * matrix with at least 75 % complete ones), 2 = CG from zero with k_side + k steps (the other attributes of such a matrix,
+ * :2953-2985).  fit_collective_*_als sets them (fit.hip, DenseNanSide::rules). */
 int cmfrec_hip_session_set_closed_form_rows(cmfrec_hip_session *s, int which, const unsigned char *mask);
 /* The lambda multipliers of the rows of A ('A') / B ('B') under scale_lam, instead of the rows' own sums of weights: a dense X
  * under scale_lam, where a row that misses fewer than 2 k entries keeps the n lam of a complete row (its matrix is the precomputed
  * B^T B + n lam I minus the missing rows, src/common.c:759-790, :3031-3032) while the others take lam times their present entries.
  * The session must hold X with observation weights (unit weights for this use); call after the bias start values.  mult: one
- * value per row of the matrix. */
+ * value per row of the matrix.
+ * 'C' / 'D' (round 5): the multipliers of the attributes of dense side information with NaN under scale_lam (the same rule:
+ * the rows of U x lam for an attribute that misses fewer than 2 (k_side + k) values, its present values otherwise); the
+ * session puts unit weights on its attribute-major copy of the sparse side information. */
 int cmfrec_hip_session_set_lambda_multipliers(cmfrec_hip_session *s, int which, const real_t *mult);
 /* Bias start values of the explicit model from the resident X, as initialize_biases_twosided /
  * _onesided (src/common.c:4410-4909, 4265-4289; call sites src/collective.c:8166-8220): written to the

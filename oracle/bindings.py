@@ -390,6 +390,14 @@ class Oracle:
         self._lmB = None if multB is None else np.ascontiguousarray(multB, self.dtype)
         self.lib.oracle_set_lambda_multipliers(_ptr(self._lmA), _ptr(self._lmB))
 
+    def set_sideinfo_dense_rules(self, cfC=None, multC=None, cfD=None, multD=None):
+        """Per-attribute rules of the NEXT fit_als_sparse_sideinfo call when it stands for DENSE side information with NaN: closed
+        form inside a CG half-step (cf*, one byte per attribute) and the lambda multipliers under scale_lam (mult*).  The arrays
+        must stay alive until that fit returns."""
+        self._scf = [None if a is None else np.ascontiguousarray(a, np.uint8) for a in (cfC, cfD)]
+        self._smu = [None if a is None else np.ascontiguousarray(a, self.dtype) for a in (multC, multD)]
+        self.lib.oracle_set_sideinfo_dense_rules(_ptr(self._scf[0]), _ptr(self._smu[0]), _ptr(self._scf[1]), _ptr(self._smu[1]))
+
     def set_zero_rows(self, rowsA=None, rowsB=None):
         """Rows of A / B the NEXT fit sets to zero after their update (NA_as_zero_U / _I: rows with neither an entry of X nor of
         the side information, which the reference does not solve).  The arrays must stay alive until that fit returns."""

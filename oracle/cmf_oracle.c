@@ -569,11 +569,16 @@ void oracle_optimizeA_explicit(real_t *A, size_t lda, const real_t *B, size_t ld
         }
         real_t *buf = bufs + szbuf * (size_t)omp_get_thread_num();
         real_t *a = A + (size_t)ix * lda;
-        const bool row_cg = use_cg && !(cf != NULL && cf[ix]);
+        const bool row_cg = use_cg && !(cf != NULL && cf[ix] == 1);
+        int_t steps_i = max_cg_steps;
+        if (row_cg && cf != NULL && cf[ix] == 2) {                             /* Case 1's fix-up loop: from zero, k steps (:2953-2985) */
+            memset(a, 0, (size_t)k * sizeof(real_t));
+            steps_i = k;
+        }
         if (row_cg && !precondition_cg)
-            explicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, max_cg_steps, buf);
+            explicit_cg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, steps_i, buf);
         else if (row_cg)
-            explicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, max_cg_steps, buf);
+            explicit_pcg_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, steps_i, buf);
         else
             explicit_chol_row(a, k, B, ldb, Xcsr + st, Xcsr_i + st, nnz, wt, lam_i, lam_last_i, buf);
     }
@@ -2320,6 +2325,22 @@ void oracle_optimizeA_collective_sparse_chol(real_t *A, size_t lda, const real_t
  * without side information is optimizeA Case 3. */
 static bool g_spfit_naz = false;
 void oracle_set_sparse_fit_NA_as_zero_X(bool on) { g_spfit_naz = on; }
+/* DENSE side information with NaN runs as this fit on its centred present entries; what the dense C / D update (optimizeA Cases
+ * 1-2 on the transposed matrix, common.c:2793-3116) does differently for an attribute that misses only a few of its m_u values
+ * arrives as per-attribute rules of the oracle_fit_als_sparse_sideinfo call that follows (cleared by the call), the ones of the
+ * dense main matrix above (oracle_set_closed_form_rows / oracle_set_lambda_multipliers):
+ *   cf*:   1 = solved in closed form whatever use_cg says (fewer than 2 (k_side + k) missing values: the precomputed Gramian
+ *          minus the missing rows, factors_closed_form :759-790, which comes before the CG branch at :884; complete attributes of
+ *          a matrix with >= 75 % complete ones: Case 1's shared factorisation); 2 = CG from zero with k_side + k steps (the other
+ *          attributes of such a matrix: Case 1's fix-up loop, :2953-2985);
+ *   mult*: the lambda multiplier under scale_lam (such an attribute keeps the m_u lam of a complete one, :3031-3032 / :2832, the
+ *          others lam times their present values). */
+static const unsigned char *g_side_cf_C = NULL, *g_side_cf_D = NULL;
+static const real_t *g_side_mult_C = NULL, *g_side_mult_D = NULL;
+void oracle_set_sideinfo_dense_rules(const unsigned char *cfC, const real_t *multC, const unsigned char *cfD, const real_t *multD)
+{
+    g_side_cf_C = cfC; g_side_mult_C = multC; g_side_cf_D = cfD; g_side_mult_D = multD;
+}
 
 int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                                    real_t *glob_mean, int_t m, int_t n, int_t k,
@@ -2334,10 +2355,16 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
 {
     const bool naz = g_spfit_naz && !implicit;
     g_spfit_naz = false;
+    const unsigned char *cfC = g_side_cf_C, *cfD = g_side_cf_D;
+    const real_t *multC = g_side_mult_C, *multD = g_side_mult_D;
+    g_side_cf_C = g_side_cf_D = NULL; g_side_mult_C = g_side_mult_D = NULL;
     if (nnz_U == 0) { m_u = 0; p = 0; }
     if (nnz_I == 0) { n_i = 0; q = 0; }
     if (m_u > m || n_i > n || (k_user && !p) || (k_item && !q)) return 2;
     if (naz && (use_cg || (p && m_u != m) || (q && n_i != n) || g_nn_AB || g_l1_base != 0)) return 2;    /* (not restated) */
+    real_t *onesU = NULL, *onesI = NULL;                                       /* unit weights: the multipliers ride on the weighted solvers */
+    if (multC != NULL && nnz_U) { onesU = (real_t *)malloc(nnz_U * sizeof(real_t)); for (size_t e = 0; e < nnz_U; e++) onesU[e] = 1; }
+    if (multD != NULL && nnz_I) { onesI = (real_t *)malloc(nnz_I * sizeof(real_t)); for (size_t e = 0; e < nnz_I; e++) onesI[e] = 1; }
     if (implicit) { user_bias = item_bias = center = false; scale_lam = scale_lam_sideinfo = false; }
     scale_lam = scale_lam || scale_lam_sideinfo;                               /* :7465 */
     const real_t l1f = g_l1_base / ((w_main != (real_t)1.) ? w_main : (real_t)1.);
@@ -2401,9 +2428,13 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
     for (int_t iter = 0; iter < niter; iter++) {
         if (iter == niter - 1 && use_cg && finalize_chol) use_cg = false;          /* :8336-8340, :9829-9830 */
         g_nonneg = g_nn_C; g_l1 = l1f / w_user;
+        if (p && onesU != NULL && scale_lam) oracle_set_row_weights(onesU, multC);
+        if (p && use_cg) g_cf_now = cfC;
         if (p) oracle_optimizeA_explicit(C, (size_t)kcu, A_b, ldA, p, m_u, kcu, Uc_p, Uc_i, Uc_v, lam / w_user, lam / w_user,
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         g_nonneg = g_nn_D; g_l1 = l1f / w_item;
+        if (q && onesI != NULL && scale_lam) oracle_set_row_weights(onesI, multD);
+        if (q && use_cg) g_cf_now = cfD;
         if (q) oracle_optimizeA_explicit(D, (size_t)kci, B_b, ldB, q, n_i, kci, Ic_p, Ic_i, Ic_v, lam / w_item, lam / w_item,
                                          scale_lam, false, nthreads, use_cg, precondition_cg, max_cg_steps);
         g_nonneg = g_nn_AB; g_l1 = l1f;
@@ -2485,6 +2516,6 @@ int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, 
     free(csr_orig); free(csc_orig);
     free(csr_p); free(csc_p); free(csr_i); free(csc_i); free(csr_v); free(csc_v);
     free(Ur_p); free(Uc_p); free(Ir_p); free(Ic_p); free(Ur_i); free(Uc_i); free(Ir_i); free(Ic_i);
-    free(Ur_v); free(Uc_v); free(Ir_v); free(Ic_v);
+    free(Ur_v); free(Uc_v); free(Ir_v); free(Ic_v); free(onesU); free(onesI);
     return 0;
 }

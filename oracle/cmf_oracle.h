@@ -247,6 +247,8 @@ void oracle_optimizeA_collective_sparse_cg(real_t *A, size_t lda, const real_t *
  * injected start values: fit_collective_explicit_als (collective.c:7263-9370) / fit_collective_implicit_als (:9375-10207). */
 /* NA_as_zero_X of the next oracle_fit_als_sparse_sideinfo / oracle_optimizeA_collective_sparse_chol call (explicit model, closed form) */
 void oracle_set_sparse_fit_NA_as_zero_X(bool on);
+/* dense side information with NaN run as the sparse fit: per-attribute rules of the dense C / D update (see cmf_oracle.c) */
+void oracle_set_sideinfo_dense_rules(const unsigned char *cfC, const real_t *multC, const unsigned char *cfD, const real_t *multD);
 void oracle_set_collective_sparse_naz(bool on, const real_t *bias_BtX);
 int oracle_fit_als_sparse_sideinfo(bool implicit, real_t *biasA, real_t *biasB, real_t *A, real_t *B, real_t *C, real_t *D,
                                    real_t *glob_mean, int_t m, int_t n, int_t k,

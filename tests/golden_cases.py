@@ -960,13 +960,25 @@ def nan_side_problem(dtype, seed=61):
     few = lambda rows, cols: (lambda M: (M.__setitem__(rng.random((rows, cols)) < 0.04, np.nan), M)[1])(
         rng.standard_normal((rows, cols)).astype(dtype))
     d["U_few"], d["I_few"] = few(*d["U_nan"].shape), few(*d["I_nan"].shape)
+    # (round 5) attributes of both kinds in one matrix -- some miss a handful of values, some most of them, one is complete -- and
+    # matrices with at least 75 % complete attributes (optimizeA Case 1 with its fix-up loop, common.c:2905-2985)
+    def mixed(rows, cols, complete):
+        M = rng.standard_normal((rows, cols)).astype(dtype)
+        for c in range(cols):
+            if c < complete: continue
+            frac = 0.6 if (c % 2) else 0.05
+            M[rng.random(rows) < frac, c] = np.nan
+        return M
+    d["U_mixed"], d["I_mixed"] = mixed(*d["U_nan"].shape, 1), mixed(*d["I_nan"].shape, 1)
+    d["U_near"], d["I_near"] = mixed(*d["U_nan"].shape, 7), mixed(*d["I_nan"].shape, 6)      # 7 of 9 / 6 of 7 attributes complete
     return d
 
 
 def _nan_mats(d, solver):
     solver = dict(solver or {})
     few = solver.pop("few", False)
-    return (d["U_few"], d["I_few"]) if few else (d["U_nan"], d["I_nan"]), (solver or None)
+    variant = solver.pop("variant", "few" if few else "nan")
+    return (d["U_" + variant], d["I_" + variant]), (solver or None)
 
 
 def centred_coo(M):
@@ -978,12 +990,24 @@ def centred_coo(M):
 
 # Cholesky solver, unscaled lambda: there the reference's shortcut for rows with few missing values (a precomputed Gramian
 # minus the missing rows, common.c:762-790) solves the same system.  Under scale_lam that Gramian already carries
-# lam x (all rows), and CG restarts such rows from zero with k steps -- per-row rules the product does not restate (it
-# returns 2 for them); measured here: 3e-2 .. 1e-1 apart on the nearly complete matrices.
+# lam x (all rows), and under CG such attributes are solved in closed form (or from zero with k steps) -- the per-attribute rules
+# of nan_side_rules below (round 5; without them the nearly complete matrices come out 3e-2 .. 1e-1 apart).
 NAN_SIDE_CASES = [("implicit UI", True, "UI", False, False, None), ("explicit UI", False, "UI", False, False, None),
                   ("explicit U", False, "U", False, False, None), ("implicit I", True, "I", False, False, None),
                   ("explicit UI nearly complete", False, "UI", False, False, dict(few=True)),
-                  ("implicit UI nearly complete", True, "UI", False, False, dict(few=True))]
+                  ("implicit UI nearly complete", True, "UI", False, False, dict(few=True)),
+                  # round 5: scale_lam and the CG solvers (per-attribute rules of the dense C / D update, nan_side_rules)
+                  ("explicit UI nearly complete, scale_lam", False, "UI", True, False, dict(few=True)),
+                  ("explicit UI nearly complete, scale_lam_sideinfo", False, "UI", True, True, dict(few=True)),
+                  ("explicit UI nearly complete, cg", False, "UI", False, False, dict(few=True, use_cg=True)),
+                  ("implicit UI nearly complete, cg + finalize", True, "UI", False, False, dict(few=True, use_cg=True, finalize_chol=True)),
+                  ("explicit UI mixed attributes, scale_lam, cg", False, "UI", True, False, dict(variant="mixed", use_cg=True)),
+                  ("explicit U mixed attributes, scale_lam_sideinfo", False, "U", True, True, dict(variant="mixed")),
+                  ("implicit UI mixed attributes, cg", True, "UI", False, False, dict(variant="mixed", use_cg=True)),
+                  ("explicit UI 75 % complete, scale_lam, cg", False, "UI", True, False, dict(variant="near", use_cg=True)),
+                  ("explicit I 75 % complete, scale_lam", False, "I", True, False, dict(variant="near")),
+                  ("implicit UI 75 % complete, cg", True, "UI", False, False, dict(variant="near", use_cg=True)),
+                  ("explicit UI sparse-like, scale_lam_sideinfo, cg + finalize", False, "UI", True, True, dict(use_cg=True, finalize_chol=True))]
 
 
 def nan_side_reference(R, d, implicit, which, sl, sls, nthreads=2, solver=None):
@@ -1006,12 +1030,38 @@ def nan_side_reference(R, d, implicit, which, sl, sls, nthreads=2, solver=None):
                 U_colmeans=r["U_colmeans"], I_colmeans=r["I_colmeans"])
 
 
+def nan_side_rules(M, kc, scale_lam):
+    """What the dense C / D update does differently from the sparse one, per attribute (column of M [rows, p], NaN = missing;
+    optimizeA Cases 1-2 on the transposed matrix, common.c:2793-3116): (closed-form mask, lambda multipliers or None).  An
+    attribute that misses fewer than 2 kc values is solved from the precomputed Gramian minus the missing rows -- in closed form
+    whatever use_cg says (mask 1), under scale_lam with the `rows` x lam of a complete one (:759-790, :3031-3032); when at least
+    75 % of the attributes are complete (helpers.c:151-250) those share one factorisation (mask 1) and the ones that miss 2 kc
+    values or more are redone by CG from zero with kc steps (mask 2; :2953-2985)."""
+    rows, p = M.shape
+    na = np.isnan(M).sum(0)
+    near = (p - int((na > 0).sum())) >= int(0.75 * p)
+    cf = (na < 2 * kc).astype(np.uint8)
+    if near: cf[na >= 2 * kc] = 2
+    mult = None
+    if scale_lam and ((na > 0) & (na < 2 * kc)).any():
+        mult = np.where(na < 2 * kc, rows, np.where(na < rows, rows - na, 1)).astype(M.dtype)
+    return cf, mult
+
+
 def nan_side_oracle(O, d, implicit, which, sl, sls, nthreads=2, solver=None):
-    """The oracle's sparse-side-information fit on the centred present entries."""
+    """The oracle's sparse-side-information fit on the centred present entries, with the per-attribute rules of the dense C / D
+    update (nan_side_rules)."""
     d2 = dict(d)
     (Un, In), solver = _nan_mats(d, solver)
     d2["U_coo"], _ = centred_coo(Un); d2["I_coo"], _ = centred_coo(In)
-    return sparse_sideinfo_oracle(O, d2, implicit, which, sl, sls, nthreads=nthreads, solver=solver)
+    scaled = (sl or sls) and not implicit
+    cfC, multC = nan_side_rules(Un, d["ku"] + d["k"], scaled) if "U" in which else (None, None)
+    cfD, multD = nan_side_rules(In, d["ki"] + d["k"], scaled) if "I" in which else (None, None)
+    O.set_sideinfo_dense_rules(cfC, multC, cfD, multD)
+    try:
+        return sparse_sideinfo_oracle(O, d2, implicit, which, sl, sls, nthreads=nthreads, solver=solver)
+    finally:
+        O.set_sideinfo_dense_rules()
 
 
 def nan_side_hip(d, implicit, which, sl, sls, dtype, solver=None):
