@@ -34,6 +34,20 @@ constexpr int MAX_W = 8;          // max cooperating waves per row
 #ifndef CMF_CG_WAVES_PER_SIMD
 #define CMF_CG_WAVES_PER_SIMD 2   // register budget of the row kernels: 2 -> 256 VGPRs, 3 -> 168 (spills)
 #endif
+// Single precision, teams of up to four wavefronts on one resident tile: three wavefronts per SIMD (168 VGPRs).  Round 4's build fitted
+// that by itself (167); with the row body compiled per tile size (round 5) the allocator drifted to 193-195 registers and the
+// kernels lost a third of their wavefronts -- config 4's 65..256-entry bins ran 15-20 % slower until the budget was stated
+// (same-box A/B against the round-4 build, profiles/r05/r05_q_*).
+#ifndef CMF_CG_WAVES_PER_SIMD_F32
+#define CMF_CG_WAVES_PER_SIMD_F32 3
+#endif
+template <typename T, int W, int NRES_> constexpr int cg_waves_per_simd()
+{
+    return (sizeof(T) == 4 && W <= 4 && NRES_ == 0) ? CMF_CG_WAVES_PER_SIMD_F32 : CMF_CG_WAVES_PER_SIMD;
+}
+#ifndef CMF_CG_NT_F32
+#define CMF_CG_NT_F32 1           // single precision takes part in the tiles by row length (0: the 64-entry tile, A/B build)
+#endif
 #ifndef CMF_CG_NT_MIN_S
 #define CMF_CG_NT_MIN_S 4         // tiles by row length (cg_rows_kernel, round 5) for k > 8 (S - 1): below, the tile products are a small
                                   // part of a pass and the extra pass bodies only cost build time.  9 = the 64-entry tile everywhere
@@ -180,19 +194,24 @@ __device__ __forceinline__ T wave_sum(T v) { return lanes::wave_sum(v); }
 // member v[i+4] does not exist is a plain sum into the lower half-group -- three instructions instead of the seven of a
 // transposing step in double precision; the lanes b >= NT end with undefined bits nobody reads (their entry is not valid:
 // pass_weight selects zero for it).
+// (first stage for the pair (v[I], v[I + 4]); `if constexpr`: an ordinary `if` on the loop counter of the unrolled loop left the
+//  single-precision kernels 12 registers heavier -- 179 instead of 167, a wavefront per SIMD less -- although it folds away)
+template <typename T, int NT, int I>
+__device__ __forceinline__ T treduce8_low_first(const T (&v)[8], bool h)
+{
+    if constexpr (I + 4 < NT) {
+        T keep = h ? v[I + 4] : v[I];
+        return keep + lanes::recv_xor4(v[I], v[I + 4]);
+    } else return v[I] + lanes::xor4_lower(v[I]);          // (the lanes with bit 2 set stand for entry I + 4: none)
+}
 template <typename T, int NT = 8>
 __device__ __forceinline__ T treduce8_low(const T (&v)[8], int lane)
 {
     static_assert(NT >= 4 && NT <= 8, "entries per lane group");
     T u[4], q[2];
     bool h = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i + 4 < NT) {
-            T keep = h ? v[i + 4] : v[i];
-            u[i] = keep + lanes::recv_xor4(v[i], v[i + 4]);
-        } else u[i] = v[i] + lanes::xor4_lower(v[i]);      // (the lanes with bit 2 set stand for entry i + 4: none)
-    }
+    u[0] = treduce8_low_first<T, NT, 0>(v, h); u[1] = treduce8_low_first<T, NT, 1>(v, h);
+    u[2] = treduce8_low_first<T, NT, 2>(v, h); u[3] = treduce8_low_first<T, NT, 3>(v, h);
     h = (lane & 2) != 0;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -538,7 +557,7 @@ __device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane)
 // five only take part in the barriers (config 4: the 257..1024 bin ran at 0.43-0.46 of the HBM peak against 0.55-0.62 for the
 // 4-wave bin below it).
 template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0>
-__global__ void __launch_bounds__(64 * W * RPB, CMF_CG_WAVES_PER_SIMD)
+__global__ void __launch_bounds__(64 * W * RPB, (cg_waves_per_simd<T, W, NRES_>()))
 cg_rows_kernel(const CgParams<T> P)
 {
     constexpr bool GRAM = IMPLICIT || GRAMX;
@@ -607,7 +626,7 @@ cg_rows_kernel(const CgParams<T> P)
     // pass, its share of the reduction over the column lanes, a weight broadcast and S gather instructions.  NT is a function of
     // the row's length alone, so a row's arithmetic (and its bits) do not depend on the launch, the shard or the neighbours.
     // Rows that are not resident (more than W NRES 64 entries: launches outside the length bins) keep the 64-entry tile.
-    constexpr int NT_MIN = (S >= CMF_CG_NT_MIN_S) ? (std::is_same<T, float>::value ? 6 : 5) : 8;
+    constexpr int NT_MIN = (S >= CMF_CG_NT_MIN_S && (CMF_CG_NT_F32 || !std::is_same<T, float>::value)) ? (std::is_same<T, float>::value ? 6 : 5) : 8;
     auto nt_of = [&](int nnz_) -> int {
         int nt = (nnz_ + 8 * W * NRES - 1) / (8 * W * NRES);
         if (std::is_same<T, float>::value) nt = (nt + 1) & ~1;

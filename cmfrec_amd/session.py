@@ -274,4 +274,8 @@ class AlsSession:
 
     def reload_switches(self):
         """Read the CMFREC_HIP_* environment switches again (they are read when a session is created)."""
-        self.lib.cmfrec_hip_reload_switches()
+        try:
+            fn = self.lib.cmfrec_hip_reload_switches
+        except AttributeError:      # a comparison build of an earlier round (CMFREC_HIP_LIBDIR): it reads the environment at every launch
+            return
+        fn()
