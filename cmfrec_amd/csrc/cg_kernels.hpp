@@ -41,10 +41,26 @@ constexpr int MAX_W = 8;          // max cooperating waves per row
 #ifndef CMF_CG_WAVES_PER_SIMD_F32
 #define CMF_CG_WAVES_PER_SIMD_F32 3
 #endif
-template <typename T, int W, int NRES_> constexpr int cg_waves_per_simd()
+// Double precision (round 5, NTSEL): the register need of a row follows its tile -- k = 50: 154-163 VGPRs with 5 entries per lane
+// group, 168 with 6, 184-196 with 7, 230-240 with 8 -- so a build that only holds the bodies for 5 and 6 fits three wavefronts per
+// SIMD where the build for all four sizes has two.  The host launches a length bin as two ranges of its processing order (rows are
+// sorted by length): NTSEL = 2 for the rows of more than 48 W entries (7 or 8 per lane group), NTSEL = 1 for the others; 0 = one
+// launch with every body (single precision, eight-wave teams, k < 25, k > 56).  A row's arithmetic does not depend on the launch it is in.
+#ifndef CMF_CG_WAVES_PER_SIMD_LOW
+#define CMF_CG_WAVES_PER_SIMD_LOW 3
+#endif
+// (k <= 56: with S = 8 columns per lane the bodies for 5 and 6 entries need 30-55 registers more than the budget)
+constexpr int CG_NTSEL_MAX_S = 7;
+// Single precision likewise: the body for 6 entries per lane group alone needs 126-136 registers and fits FOUR wavefronts per SIMD (128,
+// no spills), the body for 8 alone is the round-4 kernel (160-167: three).
+template <typename T, int W, int NRES_, int NTSEL = 0> constexpr int cg_waves_per_simd()
 {
+    if (sizeof(T) == 8 && NTSEL == 1 && W <= 4) return CMF_CG_WAVES_PER_SIMD_LOW;
+    if (sizeof(T) == 4 && NTSEL == 1 && W <= 4 && NRES_ == 0) return CMF_CG_WAVES_PER_SIMD_F32 + 1;
     return (sizeof(T) == 4 && W <= 4 && NRES_ == 0) ? CMF_CG_WAVES_PER_SIMD_F32 : CMF_CG_WAVES_PER_SIMD;
 }
+// entries per lane group below which a row belongs to the NTSEL = 1 launch: nnz <= CG_NT_LOW * 8 * W
+constexpr int CG_NT_LOW = 6;
 #ifndef CMF_CG_NT_F32
 #define CMF_CG_NT_F32 1           // single precision takes part in the tiles by row length (0: the 64-entry tile, A/B build)
 #endif
@@ -556,8 +572,8 @@ __device__ __forceinline__ void replicate(T vdist, T (&vrep)[S], int lane)
 // single-precision rows of 257..512 entries run on FOUR waves with two tiles each instead of eight waves of which three to
 // five only take part in the barriers (config 4: the 257..1024 bin ran at 0.43-0.46 of the HBM peak against 0.55-0.62 for the
 // 4-wave bin below it).
-template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0>
-__global__ void __launch_bounds__(64 * W * RPB, (cg_waves_per_simd<T, W, NRES_>()))
+template <typename T, int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0, int NTSEL = 0>
+__global__ void __launch_bounds__(64 * W * RPB, (cg_waves_per_simd<T, W, NRES_, NTSEL>()))
 cg_rows_kernel(const CgParams<T> P)
 {
     constexpr bool GRAM = IMPLICIT || GRAMX;
@@ -626,6 +642,8 @@ cg_rows_kernel(const CgParams<T> P)
     // pass, its share of the reduction over the column lanes, a weight broadcast and S gather instructions.  NT is a function of
     // the row's length alone, so a row's arithmetic (and its bits) do not depend on the launch, the shard or the neighbours.
     // Rows that are not resident (more than W NRES 64 entries: launches outside the length bins) keep the 64-entry tile.
+    static_assert(NTSEL == 0 || (S >= CMF_CG_NT_MIN_S && (sizeof(T) == 4 || S <= CG_NTSEL_MAX_S) && NRES_ == 0),
+                  "launches by tile size: tiles by row length (double precision: k <= 56)");
     constexpr int NT_MIN = (S >= CMF_CG_NT_MIN_S && (CMF_CG_NT_F32 || !std::is_same<T, float>::value)) ? (std::is_same<T, float>::value ? 6 : 5) : 8;
     auto nt_of = [&](int nnz_) -> int {
         int nt = (nnz_ + 8 * W * NRES - 1) / (8 * W * NRES);
@@ -825,7 +843,15 @@ cg_rows_kernel(const CgParams<T> P)
         const int nt = nt_of(dcur.nnz);      // uniform over the team
         if constexpr (NT_MIN == 8) solve_row(std::integral_constant<int, 8>{});
         else if constexpr (std::is_same<T, float>::value) {
-            if (nt == 6) solve_row(std::integral_constant<int, 6>{});
+            if constexpr (NTSEL == 1) solve_row(std::integral_constant<int, 6>{});         // the launch holds rows of at most CG_NT_LOW * 8 W entries
+            else if constexpr (NTSEL == 2) solve_row(std::integral_constant<int, 8>{});    // ... of more than that
+            else if (nt == 6) solve_row(std::integral_constant<int, 6>{});
+            else solve_row(std::integral_constant<int, 8>{});
+        } else if constexpr (NTSEL == 1) {      // the launch holds rows of at most CG_NT_LOW * 8 W entries
+            if (nt <= 5) solve_row(std::integral_constant<int, 5>{});
+            else solve_row(std::integral_constant<int, 6>{});
+        } else if constexpr (NTSEL == 2) {      // ... of more than that
+            if (nt <= 7) solve_row(std::integral_constant<int, 7>{});
             else solve_row(std::integral_constant<int, 8>{});
         } else {
             switch (nt) {

@@ -51,6 +51,7 @@ struct Switches {
     bool gemm_library = false;      // CMFREC_HIP_GEMM_OWN=0: rocBLAS instead of the own MFMA GEMM
     int pair = 0;                   // CMFREC_HIP_PAIR=1: rows of <= 32 entries two per wavefront
     int bins_par = 2;               // CMFREC_HIP_BINS_PAR: streams the nnz bins of a half-step are spread over (1: in line)
+    bool nt_split = true;           // CMFREC_HIP_NT_SPLIT=0: a double-precision length bin as one launch instead of two by tile size
     bool cg_generic = false;        // CMFREC_HIP_CG_KERNEL=generic: lane <-> unknown CG kernel everywhere
     int chol = 0;                   // CMFREC_HIP_CHOL: 1 = rows (workgroup-per-row kernel only), 2 = noslices
     int gramk = -1;                 // CMFREC_HIP_GRAMK: 0 / 1 force the producer / consumer pair off / on (-1: by width)
@@ -71,6 +72,7 @@ struct Switches {
         v = str("CMFREC_HIP_GEMM_OWN"); gemm_library = v && v[0] == '0';
         pair = num("CMFREC_HIP_PAIR", 0);
         bins_par = num("CMFREC_HIP_BINS_PAR", 2);
+        nt_split = num("CMFREC_HIP_NT_SPLIT", 1) != 0;
         v = str("CMFREC_HIP_CG_KERNEL"); cg_generic = v && strcmp(v, "generic") == 0;
         v = str("CMFREC_HIP_CHOL"); chol = !v ? 0 : strcmp(v, "rows") == 0 ? 1 : strcmp(v, "noslices") == 0 ? 2 : 0;
         gramk = num("CMFREC_HIP_GRAMK", -1);
@@ -189,6 +191,7 @@ struct SparseShard {
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
     int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
     int n_gt512 = 0;         // rows with more than 512 entries (single precision: the 257..512 part of the heavy bin runs on 4-wave teams)
+    int n_gt_low[3] = {0, 0, 0};   // rows with more than CG_NT_LOW * 8 W entries, W = 1, 2, 4 (48 / 96 / 192): where a length bin's launch by tile size begins
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
     // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
@@ -310,6 +313,7 @@ struct SparseShard {
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
         n_empty = 0; n_long = 0; n_gt16 = 0; n_gt512 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
+        n_gt_low[0] = n_gt_low[1] = n_gt_low[2] = 0;
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         // few split rows (C2's users: 50 rows, 65 k entries): short slices, so that their Gramian kernels -- which run in line
@@ -335,6 +339,7 @@ struct SparseShard {
             if (l > LONG_ROW) n_long++;
             if (l > 16) n_gt16++;
             if (l > 512) n_gt512++;
+            for (int w = 0; w < 3; w++) if (l > (long long)CG_NT_LOW * 8 * (1 << w)) n_gt_low[w]++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -618,7 +623,7 @@ enum class CgVariant { Auto, Generic };
 CgVariant cg_variant_from_env();
 
 // layout of DeviceInfo::row_counter: [0, 64) the Cholesky kernels' counters, then CG_NCOUNTERS padded counters per nnz bin
-constexpr int NCOUNTER_SETS = NBINS + 2;   // one set per nnz bin + spares for bins that run as two launches
+constexpr int NCOUNTER_SETS = 2 * NBINS + 2;   // one set per nnz bin + spares for bins that run as two launches (NBINS, NBINS + 1; NBINS + 2 + bin)
 constexpr size_t ROW_COUNTER_INTS = 64 + (size_t)NCOUNTER_SETS * CG_NCOUNTERS * CG_COUNTER_STRIDE;
 inline size_t cg_counter_offset(int bin) { return 64 + (size_t)bin * CG_NCOUNTERS * CG_COUNTER_STRIDE; }
 
@@ -644,7 +649,7 @@ inline void poison_lds(hipStream_t st, int num_cus)
     HIP_CHECK(hipGetLastError());
 }
 
-template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0>
+template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX = false, int NRES_ = 0, int NTSEL = 0>
 inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, int bin, hipStream_t st, int counter_set = -1)
 {
     if (count <= 0) return;
@@ -661,7 +666,7 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     P.counter = dev.row_counter.ptr + cg_counter_offset(counter_set >= 0 ? counter_set : bin);          // zeroed by launch_cg_S
     constexpr int threads = 64 * W * RPB;
     size_t smem = (((IMPLICIT || GRAMX) ? (size_t)gram_elems<real_t>(S) : 0) + (size_t)RPB * 2 * W * 64) * sizeof(real_t);
-    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB, GRAMX, NRES_>;
+    auto kern = cg_rows_kernel<real_t, S, IMPLICIT, W, RPB, GRAMX, NRES_, NTSEL>;
     // per device: the dynamic-LDS attribute and the occupancy belong to the device the kernel was loaded on
     static thread_local int bpc_dev[MAX_DEVICES] = {0};
     int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)];
@@ -850,6 +855,35 @@ inline int cg_bin_streams()
     return std::min(std::max(n, 1), DeviceInfo::MAX_BIN_STREAMS + 1);
 }
 
+// A length bin of double-precision rows as two launches by tile size (cg_kernels.hpp, NTSEL): the rows of more than 48 W entries lead
+// the bin's processing order and keep two wavefronts per SIMD, the others run on the build that fits three.  One event pair around
+// both; the second launch on its own counter set.  CMFREC_HIP_NT_SPLIT=0: one launch (A/B switch).
+template <int S, bool IMPLICIT, int W, int RPB, bool GRAMX>
+inline void launch_cg_bin_by_tile(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, int first, int count, BinTimers *tm, int bin,
+                                  hipStream_t st)
+{
+    // (double precision: not the two-wave teams -- a workgroup of two wavefronts with its own copy of the Gramian, 28 KB, fits five
+    //  times into the 160 KB of LDS, not the six that three wavefronts per SIMD would be: measured 4-7 % slower as two launches, r05_u)
+#ifdef CMFREC_HIP_FLOAT
+    constexpr bool by_tile = S >= CMF_CG_NT_MIN_S && CMF_CG_NT_F32 && W <= 4;
+#else
+    constexpr bool by_tile = S >= CMF_CG_NT_MIN_S && S <= CG_NTSEL_MAX_S && (W == 1 || W == 4);
+#endif
+    if (count <= 0) return;
+    if constexpr (by_tile) {
+        if (switches().nt_split) {
+            const int n_hi = std::min(count, std::max(0, X.n_gt_low[W == 1 ? 0 : W == 2 ? 1 : 2] - first));
+            EventPair ev{nullptr, nullptr};
+            if (tm) { HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); HIP_CHECK(hipEventRecord(ev.a, st)); }
+            launch_cg_bin<S, IMPLICIT, W, RPB, GRAMX, 0, 2>(dev, P, first, n_hi, nullptr, bin, st);
+            launch_cg_bin<S, IMPLICIT, W, RPB, GRAMX, 0, 1>(dev, P, first + n_hi, count - n_hi, nullptr, bin, st, NBINS + 2 + bin);
+            if (tm) { HIP_CHECK(hipEventRecord(ev.b, st)); tm->ev[bin].push_back(ev); }
+            return;
+        }
+    }
+    launch_cg_bin<S, IMPLICIT, W, RPB, GRAMX>(dev, P, first, count, tm, bin, st);
+}
+
 // one of the register-tiled bins (8 / 4 / 2 / 1 wavefronts per row)
 template <int S, bool IMPLICIT, bool GRAMX>
 inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, const SparseShard &X, BinTimers *tm, int bin, hipStream_t st)
@@ -873,9 +907,9 @@ inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, 
             //  0.184 -> 0.203 for its users, profiles/r04/r04_u -- a second launch per bin costs more than the idle waves)
 #endif
             launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
-        case BIN_MED4: launch_cg_bin<S, IMPLICIT, 4, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
-        case BIN_MED2: launch_cg_bin<S, IMPLICIT, 2, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
-        default: launch_cg_bin<S, IMPLICIT, 1, 4, GRAMX>(dev, P, first, count, tm, bin, st); break;
+        case BIN_MED4: launch_cg_bin_by_tile<S, IMPLICIT, 4, 1, GRAMX>(dev, P, X, first, count, tm, bin, st); break;
+        case BIN_MED2: launch_cg_bin_by_tile<S, IMPLICIT, 2, 1, GRAMX>(dev, P, X, first, count, tm, bin, st); break;
+        default: launch_cg_bin_by_tile<S, IMPLICIT, 1, 4, GRAMX>(dev, P, X, first, count, tm, bin, st); break;
     }
 }
 
