@@ -189,6 +189,7 @@ struct SparseShard {
     int n_nonempty = 0, n_empty = 0;
     int max_nnz = 0;
     int n_long = 0;          // rows with more than LONG_ROW entries (they lead the processing order)
+    int n_gt96 = 0;          // rows with more than 96 entries (the six-block low-rank build of double precision, session.hip)
     int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
     int n_gt512 = 0;         // rows with more than 512 entries (single precision: the 257..512 part of the heavy bin runs on 4-wave teams)
     int n_gt_low[3] = {0, 0, 0};   // rows with more than CG_NT_LOW * 8 W entries, W = 1, 2, 4 (48 / 96 / 192): where a length bin's launch by tile size begins
@@ -218,6 +219,7 @@ struct SparseShard {
         else if (maxlen >= LONG_ROW) n = n_long;
         else if (maxlen >= 256) n = bin_first[BIN_MED4];
         else if (maxlen >= 128) n = bin_first[BIN_MED2];
+        else if (maxlen >= 96) n = n_gt96;
         else if (maxlen >= 64) n = bin_first[BIN_LIGHT];
         else if (maxlen >= 32) n = bin_first[BIN_TINY];
         else n = n_nonempty;
@@ -312,7 +314,7 @@ struct SparseShard {
     void build_bins(const unsigned *lens_sorted, hipStream_t st)
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
-        n_empty = 0; n_long = 0; n_gt16 = 0; n_gt512 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
+        n_empty = 0; n_long = 0; n_gt16 = 0; n_gt96 = 0; n_gt512 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
         n_gt_low[0] = n_gt_low[1] = n_gt_low[2] = 0;
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
@@ -338,6 +340,7 @@ struct SparseShard {
             const long long l = (long long)lens_sorted[q];
             if (l > LONG_ROW) n_long++;
             if (l > 16) n_gt16++;
+            if (l > 96) n_gt96++;
             if (l > 512) n_gt512++;
             for (int w = 0; w < 3; w++) if (l > (long long)CG_NT_LOW * 8 * (1 << w)) n_gt_low[w]++;
             const int b = bin_of(l);

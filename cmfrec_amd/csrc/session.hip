@@ -782,12 +782,17 @@ static int launch_collective_lowrank(const DeviceInfo &dev, LowRankScratch &S, C
 // row's matrix is lam_i I + sum_j B_j B_j^T -- already diagonal plus a rank-s update, so the low-rank kernel applies without any
 // rotation (lowrank_kernels.hpp, !rotated / !collective): an s x s system instead of a k_t^3 / 3 factorisation.  Config 3's users
 // (k_t = 129, double): 38 % of the rows hold at most 64 entries.  -1 when the path does not apply.
+#ifndef CMF_LR_MAX_F64
+#define CMF_LR_MAX_F64 96      // 64: the four-block build only (the A/B build of round 5)
+#endif
 static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const SparseShard &X)
 {
     const int lr_sw = switches().lowrank;       // CMFREC_HIP_LOWRANK: 0 / 1 force the path off / on
     const int kt = c.kt;
+    // (double precision, k_t >= 128: rows of 65..96 entries on a six-block build, 21 tiles at one wavefront per SIMD -- the full
+    //  path costs such a row the 36-tile rank-k update, a 133 KB round trip through HBM and the eight-block factorisation)
     const int lr_type_max = (sizeof(real_t) == 4) ? 128 : 64;
-    const int lr_max = (kt >= 256 && lr_type_max >= 128) ? 128 : (kt >= 128 ? 64 : 32);
+    const int lr_max = (kt >= 256 && lr_type_max >= 128) ? 128 : (kt >= 128 ? (sizeof(real_t) == 8 ? CMF_LR_MAX_F64 : 64) : 32);
     const int n_rows = X.n_nonempty;                                  // rows without entries stay as they are (common.c:3270)
     const int n_full = X.rows_longer_than(lr_max, n_rows);
     const int n_light = n_rows - n_full;
@@ -826,6 +831,7 @@ static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const 
     lr_launch(lowrank_rows_kernel<real_t, 4, 3>, 4, 3, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
     lr_launch(lowrank_rows_kernel<real_t, 2, 4>, 2, 4, std::max(n_full, n_gt32), n_rows, 2);
 #else
+    if (lr_max > 64) lr_launch(lowrank_rows_kernel<real_t, 6, 1>, 6, 1, n_full, std::max(n_full, n_gt64), 0);
     lr_launch(lowrank_rows_kernel<real_t, 4, 2>, 4, 2, std::max(n_full, n_gt64), std::max(n_full, n_gt32), 1);
     lr_launch(lowrank_rows_kernel<real_t, 2, 3>, 2, 3, std::max(n_full, n_gt32), n_rows, 2);
 #endif

@@ -224,5 +224,5 @@ def test_plain_lowrank_rows(oracles, dtype, k, scale_lam, monkeypatch):
     assert not np.array_equal(Ah, Af)                       # the two paths are different arithmetic ...
     assert np.array_equal(Ah[0], A0[0])                     # ... and a row without entries is left alone by both
     lens = np.diff(csr[0].astype(np.int64))
-    big = lens > (128 if (dtype is np.float32 and k >= 256) else 64 if k >= 128 else 32)
+    big = lens > (128 if (dtype is np.float32 and k >= 256) else (96 if dtype is np.float64 else 64) if k >= 128 else 32)
     assert np.array_equal(Ah[big], Af[big])                 # rows beyond the low-rank limit take the same factorisation
