@@ -8,6 +8,8 @@
 #                              to cmfrec_amd/ (`lib` = the default build, `lib_nt8` = an experiment build made with
 #                              `make -C cmfrec_amd/csrc OUTDIR=../lib_nt8 EXTRA=-D...`)
 #   env <VAR> <v1> <v2> ...    the C2 line (and c4shard) once per value of an environment switch
+#   sidestats <workload> ...   rocprofv3 kernel statistics of side workloads (c3, c5shard, c1, c4shard)
+#   sideab <workload> <libdirA> <libdirB>   a side workload on two builds, alternating
 #   final [nosuite]            the end-of-round set: suite, smoke, counter passes with the bins in line, kernel statistics of the
 #                              default and the in-line run, the default bench line, side workloads, the --force-dist launch paths on
 #                              one rank, the suite again with poisoned LDS
@@ -57,6 +59,19 @@ env)
     env $V=$x $B --steps 40 --warmup 5 2>$O/err_$x.txt | python /tmp/line.py "c2 $V=$x" | tee -a $O/lines.txt
   done; done
   for x in "$@"; do env $V=$x $B --workload c4shard --steps 20 --warmup 3 2>/dev/null | python /tmp/line.py "c4shard $V=$x" | tee -a $O/lines.txt; done ;;
+sidestats)
+  # rocprofv3 kernel statistics of bench.py's side workloads (c3, c5shard, ...), one csv each
+  for w in "$@"; do
+    cd /tmp; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/trace_$w -o $w -- python $R/bench.py --no-cpu-baseline --workload $w --steps 10 --warmup 3 > $R/$O/bench_$w.json 2>$R/$O/bench_$w.err; echo "trace $w rc=$?"
+    cd $R; f=$(find $O/trace_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$w.csv
+    rm -rf $O/trace_$w; tail -1 $O/bench_$w.json | cut -c1-400
+  done ;;
+sideab)
+  # sideab <workload> <libdirA> <libdirB>: a side workload on two builds, alternating on this box
+  w=$1; shift
+  for rep in 1 2 3; do for L in "$@"; do
+    CMFREC_HIP_LIBDIR=$R/cmfrec_amd/$L $B --workload $w --steps 10 --warmup 3 2>/dev/null | python /tmp/line.py "$w $L" | tee -a $O/lines.txt
+  done; done ;;
 final)
   if [ "$1" != "nosuite" ]; then
     suite | tee $O/pytest_gpu.log
