@@ -101,6 +101,8 @@ __host__ __device__ constexpr size_t chol_wave_lds_elems(int NB)
     return (size_t)NB * 16 * CholMfma<T>::LDR + 2 * (16 * (size_t)NB + 16) + 16 * (size_t)NB + 16 + 2 * 64 * (size_t)NB;
 }
 
+__host__ __device__ constexpr size_t chol_wave_lds_elems_producer(int NB) { return 2 * (16 * (size_t)NB + 16); }
+
 // slices of the rows that lead the processing order (positions < n_heavy): slice s covers entries
 // [first[s], first[s] + count[s]) of the row at position vrow[s]; row_off[v] .. row_off[v + 1] are the slices of position v
 template <typename T>
@@ -164,9 +166,11 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lm = lane & 15, g = lane >> 4;
-    T *wbase = reinterpret_cast<T *>(smem_raw) + (size_t)wave * chol_wave_lds_elems<T>(NB);
+    // (the producer build only passes its right-hand side / border partials through LDS: 2 NV elements per wavefront, so that two
+    //  workgroups of the two-wavefronts-per-SIMD build fit a CU)
+    T *wbase = reinterpret_cast<T *>(smem_raw) + (size_t)wave * (PRODUCER ? chol_wave_lds_elems_producer(NB) : chol_wave_lds_elems<T>(NB));
     T *rinv = wbase;                         // [NB][16][LDR]
-    T *yv0 = rinv + (size_t)NB * RSZ;        // [NV]  right-hand side -> y -> z
+    T *yv0 = PRODUCER ? wbase : rinv + (size_t)NB * RSZ;        // [NV]  right-hand side -> y -> z
     T *yv1 = yv0 + NV;                       // [NV]  border column g -> R^-T g
     T *xall = yv1 + NV;                      // [NV]  solution
     T *stash = xall + NV;                    // [2][NB][64]  per-lane partials of right-hand side / border column (EV builds)
@@ -246,8 +250,12 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
         const T *M2 = (!full && has_u) ? P.Minit : nullptr;        // [kc, kc], rows with side information
         const int kc = P.kc;
         vec acc[NT];
+        // (producer in sweeps: a sweep's tiles are cleared when the sweep begins -- cleared here, the tiles of the later sweeps would
+        //  be live through the earlier ones and the two-wavefronts-per-SIMD build would spill them)
+        if constexpr (!(PRODUCER && NOV > 0)) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) acc[t] = vec{0, 0, 0, 0};
+            for (int t = 0; t < NT; t++) acc[t] = vec{0, 0, 0, 0};
+        }
         // (four tiles of loads in flight at a time: left to itself the scheduler issues all NT x 4 loads first and the
         //  register allocation of the whole kernel pays for it)
         auto add_matrix = [&](const T *Mi, int lim) __attribute__((always_inline)) {              // collective.c:1566-1571
@@ -424,12 +432,14 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
             if constexpr (PRODUCER && NOV > 0) {
                 // The tiles do not fit the 256 accumulator registers (36 x 8 in double at 8 blocks, 153 x 4 in single at 17):
                 // NOV tiles per sweep, stored, then the next NOV tiles in another sweep over the same entries (a sweep reads
-                // only the blocks its tiles touch; the first one carries the right-hand side and border partials).
+                // only the blocks its tiles touch; the first one carries the right-hand side and border partials -- the LAST one in the
+                // builds for two wavefronts per SIMD, whose first sweep holds more tiles than the last and has no registers to spare).
                 constexpr int TP = NOV, NP = (NT + TP - 1) / TP;
                 T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
                 static_for<0, NP>([&](auto pc) {
                     constexpr int T0 = decltype(pc)::value * TP, T1 = (T0 + TP < NT) ? T0 + TP : NT;
-                    rank_pass(std::integral_constant<int, T0>{}, std::integral_constant<int, T1>{}, std::integral_constant<bool, T0 == 0>{});
+                    static_for<T0, T1>([&](auto tc) { acc[decltype(tc)::value] = vec{0, 0, 0, 0}; });
+                    rank_pass(std::integral_constant<int, T0>{}, std::integral_constant<int, T1>{}, std::integral_constant<bool, (WPS >= 2) ? (T1 == NT) : (T0 == 0)>{});
                     static_for<T0, T1>([&](auto tc) {
                         constexpr int t = decltype(tc)::value;
 #pragma unroll
@@ -656,6 +666,198 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
         if (BORDER && lane == 0) arow[kt - 1] = xlast;
         CMF_LDS_FENCE();                     // this wave's LDS is reused by its next row
         rix = P.row_first + nwaves + __builtin_amdgcn_readfirstlane(claim);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the rank-k update of the eight-block rows by TWO (or four) wavefronts per row -- the producer of the two-kernel closed
+// form in double precision at k_t = 128 / 129 (config 3).  One wavefront per SIMD issues a v_mfma_f64_16x16x4 every ~130 cycles, two or
+// more keep the pipe busy (35-38 against 75 TFLOP/s on the whole chip, profiles/r05/r05_za_mfma_f64_occupancy.txt) -- and the
+// one-wavefront-per-row producer holds 32 tiles in 256 accumulator registers, one wavefront per SIMD.  Its tiles in sweeps of 16 fit
+// two wavefronts per SIMD, but every sweep gathers the row again and for the item step those re-reads go to HBM (measured slower,
+// r05_zb).  Here the NP wavefronts of a workgroup take the SAME row (or slice) at the same time, each a part of the 36 tiles --
+// halves: the tile rows {0, 3, 4, 7} / {1, 2, 5, 6}, 18 tiles = 144 registers, 8 / 7 block loads per step of four entries;
+// quarters: the rows {Q, 7 - Q}, nine tiles -- straight from the gather like gramk_producer_kernel: the second wavefront finds the
+// lines in cache.  Two wavefronts per SIMD (halves: four workgroups of 128 threads per CU).  The right-hand side and border-column
+// partials of a part's own blocks ride with it.  Measured on config 3 (same box, alternating, tools/experiments/
+// r05_rank_k_two_waves_per_simd): quarters 15.08 -> 15.00 ms (the per-step bookkeeping is paid four times, on the datapath the matrix
+// instructions use), halves 15.10 -> 14.75-14.84 ms (the kernel 1.64 -> 1.47 ms per launch): the halves are the default.  FULL: every
+// unknown of the tiles takes a gathered value (the only build instantiated; other shapes keep the one-wavefront producer).
+// Output: the partial of chol_wave_kernel's producer build (tiles in the accumulator layout, packed order; right-hand side; border
+// column; two scalars), so the factorisation build (WMODE 2) and gram_cg_wide_kernel consume it unchanged.
+// tile rows of part Q of NP: quarters {Q, 7 - Q} (9 tiles each), halves {0, 3, 4, 7} / {1, 2, 5, 6} (18 tiles each)
+__host__ __device__ constexpr int cq_row(int NP, int Q, int i)
+{
+    if (NP == 4) return i == 0 ? Q : 7 - Q;
+    return Q == 0 ? (i == 0 ? 0 : i == 1 ? 3 : i == 2 ? 4 : 7) : (i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 5 : 6);
+}
+__host__ __device__ constexpr int cq_off(int NP, int Q, int i)      // first accumulator of the part's i-th tile row
+{
+    int o = 0;
+    for (int j = 0; j < i; j++) o += 8 - cq_row(NP, Q, j);
+    return o;
+}
+template <typename T, int NB, bool BORDER, int PD, int NP, int Q, bool FULL>
+__device__ __forceinline__ void chol_part_rank_k(const CholParams<T> &P, size_t st, int nnz, T *__restrict__ pp, int lane)
+{
+    using Mf = CholMfma<T>;
+    using vec = typename Mf::vec;
+    static_assert(NB == 8 && (NP == 4 || NP == 2) && Q >= 0 && Q < NP, "parts of an eight-block grid");
+    constexpr int NR = NB / NP;                       // tile rows of this part
+    constexpr int R0 = cq_row(NP, Q, 0);              // its first row: the part loads the blocks R0 .. NB - 1
+    constexpr int NTP = cq_off(NP, Q, NR);
+    constexpr int NT = NB * (NB + 1) / 2;
+    vec acc[NTP];
+#pragma unroll
+    for (int i = 0; i < NTP; i++) acc[i] = vec{0, 0, 0, 0};
+    const int lm = lane & 15, g = lane >> 4;
+    const int kt = P.kt, koff = P.koff;
+    const int kq = kt - (BORDER ? 1 : 0);
+    const int kbcols = kt - koff;
+    // FULL: every unknown of the tiles takes a gathered value (koff = 0, kq = 16 NB: config 3) -- the loads of a row are one address
+    // plus immediate offsets and no operand is masked; otherwise the clamped column per block and the mask of chol_wave_kernel
+    int colb[FULL ? 1 : NB];
+    unsigned vmask = 0;
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const int u = 16 * b + lm;
+            const bool ok = (u >= koff) && (u < kq);
+            colb[b] = min(max(u - koff, 0), kbcols - 1);
+            vmask |= ok ? (1u << b) : 0u;
+        }
+    }
+    const int bcol = kbcols - 1;
+    const bool impl_w = (P.mode == CHOL_IMPLICIT || P.mode == CHOL_COLLECTIVE_IMPLICIT);
+    T rp[NR], gp[NR], gam = T(0), rbs = T(0);
+#pragma unroll
+    for (int i = 0; i < NR; i++) { rp[i] = T(0); gp[i] = T(0); }
+    const int nsteps = (nnz + 3) >> 2;
+    const int niter = (nsteps + PD - 1) / PD;
+    T opb[PD][NB], bvb[PD], xraw[PD], bsv[PD];
+    bool vld[PD];
+    int idxn[PD]; T xn[PD]; bool vn[PD];
+    auto load_entry = [&](int s, int step) {
+        const int e = 4 * step + g;
+        vn[s] = e < nnz;
+        const int ec = max(min(e, nnz - 1), 0);
+        idxn[s] = P.indices[st + ec];
+        xn[s] = P.values[st + ec];
+    };
+    auto issue_rows = [&](int s) {
+        const T *rowp = P.B + (size_t)idxn[s] * P.ldb;
+        if constexpr (FULL) {
+            const T *rl = rowp + lm;
+            static_for<R0, NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                opb[s][b] = rl[16 * b];
+            });
+        } else {
+            static_for<R0, NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                opb[s][b] = rowp[colb[b]];
+            });
+        }
+        bvb[s] = BORDER ? rowp[bcol] : T(0);
+        bsv[s] = (P.bias_sub != nullptr) ? P.bias_sub[idxn[s]] : T(0);
+        xraw[s] = xn[s]; vld[s] = vn[s];
+    };
+    if (nnz > 0) {
+#pragma unroll
+        for (int s = 0; s < PD; s++) load_entry(s, s);
+#pragma unroll
+        for (int s = 0; s < PD; s++) { issue_rows(s); load_entry(s, PD + s); }
+    }
+    for (int it = 0; it < niter; it++) {
+#pragma unroll
+        for (int s = 0; s < PD; s++) {
+            const T x = xraw[s] - bsv[s];
+            T ws = impl_w ? x : T(1);               // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
+            T xw = impl_w ? x + T(1) : x;           // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
+            if (!vld[s]) { ws = T(0); xw = T(0); }
+            T o[NB];
+            static_for<R0, NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                o[b] = (FULL || ((vmask >> b) & 1u)) ? opb[s][b] : T(0);
+            });
+            const T bv = bvb[s];
+            if (it + 1 < niter) { issue_rows(s); load_entry(s, (it + 2) * PD + s); }
+            static_for<0, NR>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int R = cq_row(NP, Q, i), OFF = cq_off(NP, Q, i);
+                const T a = o[R] * ws;
+                static_for<R, NB>([&](auto bjc) {
+                    constexpr int bj = decltype(bjc)::value;
+                    acc[OFF + bj - R] = Mf::mma(a, o[bj], acc[OFF + bj - R]);
+                });
+                rp[i] += xw * o[R];
+                if (BORDER) gp[i] += (ws * bv) * o[R];
+            });
+            if (BORDER && Q == 0) { gam += (ws * bv) * bv; rbs += xw * bv; }
+        }
+    }
+    static_for<0, NR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int R = cq_row(NP, Q, i), OFF = cq_off(NP, Q, i);
+#pragma unroll
+        for (int j = 0; j < NB - R; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) pp[(size_t)wtix(R, R + j, NB) * 256 + r * 64 + lane] = acc[OFF + j][r];
+    });
+    T *pv = pp + (size_t)NT * 256;
+    auto over_groups = [&](T v) -> T { v = lanes::tswap16_add(v, v); return lanes::tswap32_add(v, v); };
+    static_for<0, NR>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int R = cq_row(NP, Q, i);
+        const T v = over_groups(rp[i]);
+        if (lane < 16) pv[16 * R + lane] = v;
+        if (BORDER) {
+            const T w = over_groups(gp[i]);
+            if (lane < 16) pv[16 * NB + 16 * R + lane] = w;
+        }
+    });
+    if (BORDER && Q == 0) {
+        gam = over_groups(gam); rbs = over_groups(rbs);
+        if (lane == 0) { pv[32 * NB] = gam; pv[32 * NB + 1] = rbs; }
+    }
+}
+
+// NP wavefronts per workgroup and work item (4: quarters, 2: halves); WPS wavefronts per SIMD = 4 WPS / NP workgroups per CU
+template <typename T, int NB, bool BORDER, int PD, int WPS, bool FULL, int NP = 4>
+__global__ void __launch_bounds__(64 * NP, WPS)
+chol_parts_producer_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const CholSlices<T> SL)
+{
+    constexpr size_t PART = chol_wave_part_elems(NB);
+    __shared__ int s_next;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // work items are claimed per workgroup: position blockIdx.x first, then gridDim.x + counter
+    int rix = P.row_first + blockIdx.x;
+    while (rix < P.nrows) {
+        if (threadIdx.x == 0) s_next = atomicAdd(P.counter, 1);
+        int ritem, sfirst = 0, scount;
+        if (rix < SL.n_slices) { ritem = SL.vrow[rix]; sfirst = SL.first[rix]; scount = SL.count[rix]; }
+        else { ritem = SL.n_heavy + (rix - SL.n_slices); scount = -1; }
+        const RowDesc d = desc[ritem];
+        const int nnz_row = __builtin_amdgcn_readfirstlane(d.nnz);
+        const size_t st_row = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(d.st >> 32)) << 32) |
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)(d.st & 0xffffffffu));
+        const int nnz = (scount >= 0) ? __builtin_amdgcn_readfirstlane(scount) : nnz_row;
+        const size_t st = st_row + (size_t)__builtin_amdgcn_readfirstlane(sfirst);
+        T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
+        if constexpr (NP == 4) {
+            switch (wave) {
+                case 0: chol_part_rank_k<T, NB, BORDER, PD, 4, 0, FULL>(P, st, nnz, pp, lane); break;
+                case 1: chol_part_rank_k<T, NB, BORDER, PD, 4, 1, FULL>(P, st, nnz, pp, lane); break;
+                case 2: chol_part_rank_k<T, NB, BORDER, PD, 4, 2, FULL>(P, st, nnz, pp, lane); break;
+                default: chol_part_rank_k<T, NB, BORDER, PD, 4, 3, FULL>(P, st, nnz, pp, lane); break;
+            }
+        } else {
+            if (wave == 0) chol_part_rank_k<T, NB, BORDER, PD, 2, 0, FULL>(P, st, nnz, pp, lane);
+            else chol_part_rank_k<T, NB, BORDER, PD, 2, 1, FULL>(P, st, nnz, pp, lane);
+        }
+        __syncthreads();
+        rix = P.row_first + (int)gridDim.x + s_next;
+        __syncthreads();
     }
 }
 

@@ -68,6 +68,11 @@ static int launch_chol_rows(const DeviceInfo &dev, const CholCall &c, const Spar
 
 static int launch_plain_lowrank(const DeviceInfo &dev, const CholCall &c, const SparseShard &X);
 
+#ifndef CMF_PARTS_NP
+#define CMF_PARTS_NP 2             // wavefronts per row of chol_parts_producer_kernel: 2 = halves of 18 tiles (default), 4 = quarters of 9 (measured on par with the round-2 producer)
+#define CMF_PARTS_PD 2             // steps of four gathered rows in flight per wavefront (quarters: 4)
+#define CMF_PARTS_WPS 2            // wavefronts per SIMD
+#endif
 // X may be null for CHOL_PREFILLED (then nrows_prefilled rows are solved in natural order)
 static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseShard *X, int nrows_prefilled = 0)
 {
@@ -150,7 +155,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 W.row_first = first; W.nrows = last; W.counter = dev.row_counter.ptr + counter;
                 auto wlaunch = [&](auto kern, int nb_, int wps) {
                     poison_lds(st, dev.num_cus);      // test hook, device.hpp
-                    const size_t smem = 4 * chol_wave_lds_elems<real_t>(nb_) * sizeof(real_t);
+                    const size_t smem = 4 * (wmode == 1 ? chol_wave_lds_elems_producer(nb_) : chol_wave_lds_elems<real_t>(nb_)) * sizeof(real_t);
                     const int grid = std::min((last - first + 3) / 4, dev.num_cus * wps);
                     if (smem > 48 * 1024)
                         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -170,7 +175,28 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                 else if (nbw <= 4) wlaunch(WAVE_KERN(4, 3, 2, 0), 4, 2);
                 else if (nbw <= 6) wlaunch(WAVE_KERN(6, 2, 1, 0), 6, 1);
                 // 7 and 8 blocks in double: two kernels, see below
-                else if (wmode == 1) wlaunch(WAVE_KERN_M(8, 3, 1, 32, 1), 8, 1);      // 32 tiles per sweep
+                // Round 5: one wavefront per SIMD issues a double-precision MFMA every ~130 cycles, two keep the pipe busy (35-38 against
+                // 75 TFLOP/s, profiles/r05/r05_za_mfma_f64_occupancy.txt).  Where every unknown of the tiles is gathered (koff = 0,
+                // k_t = 128 / 129: config 3) the rank-k update is done by TWO wavefronts per row with 18 tiles each, four workgroups
+                // of 128 threads per CU (chol_parts_producer_kernel; config 3 15.10 -> 14.75-14.84 ms, r05_ze); the other shapes and
+                // -DCMF_WAVE_PROD_ONE_WAVE keep the round-2 producer (one wavefront per row and SIMD, 32 + 4 tiles in two sweeps).
+                else if (wmode == 1) {
+                    const bool fullq = c.koff == 0 && c.kt - (border ? 1 : 0) == 128;
+#ifdef CMF_WAVE_PROD_ONE_WAVE
+                    const bool parts = false;
+#else
+                    const bool parts = fullq;
+#endif
+                    if (!parts) wlaunch(WAVE_KERN_M(8, 3, 1, 32, 1), 8, 1);      // 32 tiles per sweep
+                    else {
+                        poison_lds(st, dev.num_cus);
+                        constexpr int NPQ = CMF_PARTS_NP;
+                        auto kern = border ? chol_parts_producer_kernel<real_t, 8, true, CMF_PARTS_PD, CMF_PARTS_WPS, true, NPQ>
+                                           : chol_parts_producer_kernel<real_t, 8, false, CMF_PARTS_PD, CMF_PARTS_WPS, true, NPQ>;
+                        const int grid = std::min(last - first, dev.num_cus * CMF_PARTS_WPS * 4 / NPQ);
+                        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NPQ), 0, st, W, X->desc.ptr, SL);
+                    }
+                }
                 else wlaunch((border ? chol_wave_kernel<real_t, 8, true, 1, 1, 6, 2, true> : chol_wave_kernel<real_t, 8, false, 1, 1, 6, 2, true>), 8, 1);
 #endif
 #undef WAVE_KERN
