@@ -518,7 +518,9 @@ inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
         const int bm = (M + GEMM_BM - 1) / GEMM_BM, bn = (N + GEMM_BN - 1) / GEMM_BN;
         int nsplit = 1;
         if ((long long)bm * bn < 2LL * dev.num_cus && K >= 4096)
-            nsplit = (int)std::min<long long>((K + 1023) / 1024, std::max<long long>(1, (4LL * dev.num_cus) / ((long long)bm * bn)));
+            // (chunks of at least 256: config 3's I^T B -- 64 x 128 outputs over 10,677 rows -- ran as 11 workgroups of 1024 rows each,
+            //  204 us per call on 11 of 256 CUs; round 5: 42 workgroups)
+            nsplit = (int)std::min<long long>((K + 255) / 256, std::max<long long>(1, (4LL * dev.num_cus) / ((long long)bm * bn)));
         int kchunk = (std::max(K, 1) + nsplit - 1) / nsplit;
         kchunk = (kchunk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
         nsplit = (std::max(K, 1) + kchunk - 1) / kchunk;
