@@ -875,7 +875,7 @@ def pmc_traffic(dom):
     ks = json.load(open(path))["kernels"]
     # (the row kernel's template arguments are <T, slots, implicit, waves per row, rows per workgroup, weighted>)
     tags = {"cg_rows_kernel<W=8>": [", 8, 1, "], "cg_rows_kernel<W=4>": [", 4, 1, "], "cg_rows_kernel<W=2>": [", 2, 1, "],
-            "cg_rows_kernel<W=1>": [", 1, 4, "], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel", "cg_rows_pair_kernel"],
+            "cg_rows_kernel<W=1>": [", 1, 4, "], "cg_rows_tiny_kernel": ["cg_rows_tiny_kernel"],
             "vh_pass": ["vh_pass_kernel", "vh_update_kernel"], "gram_wave": ["gram_wave_kernel", "gram_cg_kernel"]}
     want = next(v for k, v in tags.items() if dom["kernel"].startswith(k))
     tot, found = 0.0, False

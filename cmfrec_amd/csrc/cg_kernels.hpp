@@ -163,9 +163,6 @@ struct CgParams {
     // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
     const T *rconst = nullptr;
     size_t ldr = 0;
-    // two-rows-per-wavefront kernel (cg_pair_kernels.hpp): the first pair_split rows of the launch (more than 16 entries) pair among
-    // themselves on the 32-slot tile, the others on the 16-slot tile -- a row's arithmetic never depends on its partner
-    int pair_split = 0;
 #ifdef CMF_CG_DEBUG
     int dbg = 0;   // phase skipping for timing experiments (results are wrong): 1 gathers, 2 Gramian product, 4 tile products, 8 dot products
 #endif
@@ -1346,18 +1343,6 @@ cg_rows_tiny_kernel(const CgParams<T> P)
         rix += nwaves;
         d0 = d2; p0 = p2; d1 = d3; p1 = p3; d2 = d4;
     }
-}
-
-// sum over the 32 lanes of each half of the wavefront (the two-rows-per-wavefront kernel, cg_pair_kernels.hpp), identical on
-// every lane of the half
-template <typename T>
-__device__ __forceinline__ T half_sum(T v)
-{
-    v += lanes::xor1(v);
-    v += lanes::xor2(v);
-    v += lanes::qxor4(v);
-    v += lanes::xor8(v);
-    return lanes::tswap16_add(v, v);            // lanes l and l + 16 of each half
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2,7 +2,6 @@
 // nnz-binned row schedule, and the launchers of the row-update kernels.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +15,6 @@
 #include "chol_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gram_cg_kernels.hpp"
-#include "cg_pair_kernels.hpp"
 #include "topn_kernels.hpp"
 
 namespace cmfhip {
@@ -48,8 +46,6 @@ struct Switches {
     int vh_min = 0;                 // CMFREC_HIP_VH_MIN: where the split rows begin (0: by precision and path)
     int vh = 0;                     // CMFREC_HIP_VH: split rows 1 = stream (launch pair per CG pass), 2 = gram (one gather, CG on the row's Gramian); 0: by shape
     bool gram_slice = false;        // CMFREC_HIP_GRAM_KERNEL=slice: LDS-staged workgroup kernel for the slice partials
-    bool gemm_library = false;      // CMFREC_HIP_GEMM_OWN=0: rocBLAS instead of the own MFMA GEMM
-    int pair = 0;                   // CMFREC_HIP_PAIR=1: rows of <= 32 entries two per wavefront
     int bins_par = 2;               // CMFREC_HIP_BINS_PAR: streams the nnz bins of a half-step are spread over (1: in line)
     bool nt_split = true;           // CMFREC_HIP_NT_SPLIT=0: a double-precision length bin as one launch instead of two by tile size
     bool cg_generic = false;        // CMFREC_HIP_CG_KERNEL=generic: lane <-> unknown CG kernel everywhere
@@ -57,7 +53,7 @@ struct Switches {
     int gramk = -1;                 // CMFREC_HIP_GRAMK: 0 / 1 force the producer / consumer pair off / on (-1: by width)
     int gramk_batch = 0;            // CMFREC_HIP_GRAMK_BATCH: work items per batch (test hook: several batches on a small problem)
     int lowrank = -1;               // CMFREC_HIP_LOWRANK: 0 / 1 force the low-rank row kernel off / on (-1: by shape)
-    bool eig_jacobi = false;        // CMFREC_HIP_EIG=jacobi: the built-in eigen-decomposition instead of rocSOLVER's
+    bool eig_jacobi = false;        // CMFREC_HIP_EIG=jacobi: the one-workgroup Jacobi kernel instead of tridiagonalisation + QL (cross-check)
     int debug_skip = 0;             // CMFREC_HIP_CG_SKIP / _CHOL_SKIP / _WAVE_SKIP (timing builds only: -DCMF_CG_DEBUG / -DCMF_CHOL_DEBUG)
     bool debug_ticks = false;       // CMFREC_HIP_GRAM_TICKS / _CHOL_TICKS (timing builds only)
     void reload()
@@ -69,8 +65,6 @@ struct Switches {
         const char *v = str("CMFREC_HIP_VH");
         vh = !v ? 0 : strcmp(v, "stream") == 0 ? 1 : strcmp(v, "gram") == 0 ? 2 : 1;       // (any other value streams, as before)
         v = str("CMFREC_HIP_GRAM_KERNEL"); gram_slice = v && strcmp(v, "slice") == 0;
-        v = str("CMFREC_HIP_GEMM_OWN"); gemm_library = v && v[0] == '0';
-        pair = num("CMFREC_HIP_PAIR", 0);
         bins_par = num("CMFREC_HIP_BINS_PAR", 2);
         nt_split = num("CMFREC_HIP_NT_SPLIT", 1) != 0;
         v = str("CMFREC_HIP_CG_KERNEL"); cg_generic = v && strcmp(v, "generic") == 0;
@@ -180,6 +174,10 @@ struct SparseShard {
     // of lambda under scale_lam -- the sum of the row's weights, 1 for a row without entries (wsumA / wsumB of the driver,
     // collective.c:7978-8008; summed in double, entry by entry, as there)
     DevBuf<real_t> w, wsum;
+    // NA_as_zero_X with observation weights: the multipliers of that model -- sum of the row's weights + number of its ABSENT entries
+    // (collective.c:7991-8022) -- in a buffer of their own, rebuilt by the session whenever X or the flag changes (round 6; they
+    // used to overwrite wsum in place, which a second upload of X or switching the flag off left stale)
+    DevBuf<real_t> wsum_naz;
     bool weighted() const { return w.ptr != nullptr && nnz > 0; }
     DevBuf<int> order;       // row ids sorted by nnz descending: [bin 0 | bin 1 | ... | bin 4 | empty rows]
     DevBuf<RowDesc> desc;    // same order: {row, nnz, CSR offset}
@@ -399,27 +397,11 @@ struct DeviceInfo {
     // third stream for the eigen-decomposition of the low-rank path (one workgroup, overlaps the row kernels of both other streams)
     hipStream_t eig_stream_ = nullptr;
     hipEvent_t eig_fork = nullptr;
-    rocblas_handle blas_eig = nullptr;      // own handle (own workspace) for library calls on the eigen-decomposition's stream
-    rocblas_handle ensure_blas_eig()
-    {
-        if (!blas_eig) {
-            if (rocblas_create_handle(&blas_eig) != rocblas_status_success) {
-                blas_eig = nullptr;
-                g_last_error = "cmfrec_hip: rocblas_create_handle failed";
-                throw HipError{1};
-            }
-        }
-        (void)rocblas_set_stream(blas_eig, eig_stream());
-        return blas_eig;
-    }
     hipStream_t eig_stream()
     {
         if (!eig_stream_) HIP_CHECK(hipStreamCreateWithFlags(&eig_stream_, hipStreamNonBlocking));
         return eig_stream_;
     }
-    // rocBLAS handle for the plain dense contractions of the side-information path (U C, U^T A, A^T A for k > 64);
-    // created on first use, bound to `stream`, atomics off (bit-reproducible results)
-    rocblas_handle blas = nullptr;
     // solver option of the update in progress (set by the session around a half-step): closed-form rows are solved by
     // the non-negative coordinate descent instead of the Cholesky factorisation
     mutable bool nonneg_now = false;
@@ -432,8 +414,6 @@ struct DeviceInfo {
     DeviceInfo &operator=(const DeviceInfo &) = delete;
     ~DeviceInfo()
     {
-        if (blas) (void)rocblas_destroy_handle(blas);
-        if (blas_eig) (void)rocblas_destroy_handle(blas_eig);
         if (eig_fork) (void)hipEventDestroy(eig_fork);
         if (eig_stream_) (void)hipStreamDestroy(eig_stream_);
         if (fork_ev) (void)hipEventDestroy(fork_ev);
@@ -444,20 +424,6 @@ struct DeviceInfo {
         }
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (stream) (void)hipStreamDestroy(stream);
-    }
-    rocblas_handle ensure_blas()
-    {
-        if (!blas) {
-            if (rocblas_create_handle(&blas) != rocblas_status_success) {
-                blas = nullptr;
-                g_last_error = "cmfrec_hip: rocblas_create_handle failed";
-                throw HipError{1};
-            }
-            (void)rocblas_set_atomics_mode(blas, rocblas_atomics_not_allowed);
-            (void)rocblas_set_pointer_mode(blas, rocblas_pointer_mode_host);
-        }
-        (void)rocblas_set_stream(blas, stream);
-        return blas;
     }
     void ensure_aux()
     {
@@ -498,9 +464,6 @@ struct BinTimers {
 
 // ------------------------------------------------------------------------------------------
 // dense contractions
-// per-thread override of CMFREC_HIP_GEMM_OWN (-1: follow the environment; 0 rocBLAS; 1 the library's own kernel): what
-// cmfrec_hip_gemm_probe switches between its two timings instead of mutating the process environment
-inline thread_local int g_gemm_force = -1;
 template <bool TRANSA>
 inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha, const real_t *A, size_t lda,
                         const real_t *B, size_t ldb, real_t *C, size_t ldc)
@@ -509,11 +472,10 @@ inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
     // C[M, N] = alpha * op(A) B, all row-major: the dense contractions of the side-information path (w U C, U^T A, I D, the
     // rotations of the low-rank path).  Round 3: the library's own MFMA kernel (dense_kernels.hpp, gemm_mfma_kernel) -- the
     // matrix cores under an LDS-staged 128 x 128 tile, split over K with an ordered reduction where M x N alone would leave
-    // CUs idle (U^T A: 512 x 256 outputs over 1.5 M rows).  CMFREC_HIP_GEMM_OWN=0 calls rocBLAS instead (A/B timing and
-    // cross-check; row-major C is the column-major C^T = B^T op(A)^T, so: first operand B, second operand A with the
-    // transposition flag inverted).
-    const bool use_own = (g_gemm_force >= 0) ? (g_gemm_force != 0) : !switches().gemm_library;
-    if (use_own) {
+    // CUs idle (U^T A: 512 x 256 outputs over 1.5 M rows).  Round 6: the only GEMM of the library -- the rocBLAS alternative
+    // (CMFREC_HIP_GEMM_OWN=0, rounds 3-5) went with the link against it; cmfrec_hip_gemm_probe still times rocBLAS beside it
+    // when that library can be loaded at run time (a measurement tool, not a path).
+    {
         DeviceInfo &d = const_cast<DeviceInfo &>(dev);
         const int bm = (M + GEMM_BM - 1) / GEMM_BM, bn = (N + GEMM_BN - 1) / GEMM_BN;
         int nsplit = 1;
@@ -539,15 +501,6 @@ inline void launch_gemm(const DeviceInfo &dev, int M, int N, int K, real_t alpha
         HIP_CHECK(hipGetLastError());
         return;
     }
-    rocblas_handle h = const_cast<DeviceInfo &>(dev).ensure_blas();
-    const real_t zero = 0;
-    const rocblas_operation opA = TRANSA ? rocblas_operation_transpose : rocblas_operation_none;
-#ifdef CMFREC_HIP_FLOAT
-    rocblas_status rs = rocblas_sgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
-#else
-    rocblas_status rs = rocblas_dgemm(h, rocblas_operation_none, opA, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &zero, C, (int)ldc);
-#endif
-    if (rs != rocblas_status_success) { g_last_error = "cmfrec_hip: rocBLAS gemm failed"; throw HipError{1}; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -692,14 +645,9 @@ inline void launch_cg_bin(const DeviceInfo &dev, CgParams<real_t> P, int first, 
     }
 }
 
-// CMFREC_HIP_PAIR: how the rows of at most 32 entries run.  0 (default): one row per wavefront (cg_rows_tiny_kernel).  1: two rows
-// per wavefront, one launch for the bin (cg_pair_kernels.hpp; the 16-slot tile for the pairs of rows of <= 16 entries).  Measured side
-// by side in round 5 (profiles/r05/r05_e_*): the pair kernel issues 15 % fewer vector instructions per row, but reads its Gramian
-// from LDS in every pass (no room for a register copy beside two rows' tiles) and a pair costs its longer row -- C2 3.375 against
-// 3.348 ms; a second launch for the rows of <= 16 entries with the Gramian in registers: 3.384.  It stays as an A/B switch and
-// on-device cross-check.
-inline int cg_pair_mode() { return switches().pair; }
-
+// The rows of at most 32 entries: one row per wavefront (cg_rows_tiny_kernel).  Two rows per wavefront (round 5, cg_rows_pair_kernel)
+// issued 15 % fewer vector instructions per row but read its Gramian from LDS in every pass and a pair cost its longer row -- C2 3.375
+// against 3.348 ms (profiles/r05/r05_e_*, r05_w_*); removed in round 6, the sources are in the history (git log -- cmfrec_amd/csrc/cg_pair_kernels.hpp).
 template <int S, bool IMPLICIT, bool GRAMX = false>
 inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first, int count, BinTimers *tm, hipStream_t st, int n_gt16)
 {
@@ -722,25 +670,7 @@ inline void launch_cg_tiny(const DeviceInfo &dev, CgParams<real_t> P, int first,
     P1.desc += first;
     P1.nrows = count;
     P1.counter = dev.row_counter.ptr + cg_counter_offset(BIN_TINY);
-    auto pair_launch = [&](auto kern, int cache_slot, CgParams<real_t> Pk, int rows) {
-        static thread_local int bpc_dev[MAX_DEVICES][4] = {{0}};
-        int &blocks_per_cu = bpc_dev[di][cache_slot];
-        if (blocks_per_cu == 0) {
-            int nb = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, smem));
-            blocks_per_cu = std::max(1, nb);
-        }
-        const int npairs = (Pk.pair_split + 1) / 2 + (rows - Pk.pair_split + 1) / 2;
-        const int grid = std::min((npairs + 3) / 4, dev.num_cus * blocks_per_cu);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, Pk);
-    };
-    if (cg_pair_mode() != 0) {
-        // two rows per wavefront, paired in processing order inside their length class (round 5)
-        const bool mixed = tiny16_on && count_le16 > 0;
-        P1.pair_split = mixed ? count - count_le16 : count;        // rows of more than 16 entries lead the bin
-        if (mixed) pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 0, false>, 2, P1, count);
-        else pair_launch(cg_rows_pair_kernel<real_t, S, IMPLICIT, GRAMX, 8, false>, 0, P1, count);
-    } else {
+    {
         const bool mixed = tiny16_on && count_le16 > 0;
         auto kern = mixed ? cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX, 0> : cg_rows_tiny_kernel<real_t, S, IMPLICIT, GRAMX, 4>;
         static thread_local int bpc_dev[MAX_DEVICES][2] = {{0}};
@@ -1059,7 +989,7 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
 #endif
     const int S = (c.k + 7) / 8;
     if (c.values_override != nullptr) P.values = c.values_override;
-    if (c.weights_override != nullptr) { P.weights = c.weights_override; P.wsum = X.wsum.ptr; }
+    if (c.weights_override != nullptr) { P.weights = c.weights_override; P.wsum = X.wsum_naz.ptr; }     // (NA_as_zero_X with weights only)
     if (c.Gx != nullptr) {
         // shared matrix + per-row constant on the GRAMX builds (no block structure: the explicit model's own lambda rules apply)
         if (c.implicit || c.precond || S > 8 || c.kc > 0 || c.Bi != nullptr || c.koff != 0 || c.skip_first != 0) {

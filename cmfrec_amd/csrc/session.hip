@@ -10,6 +10,7 @@
 #include "chol_wave_kernels.hpp"
 #include "gramk_kernels.hpp"
 #include "lowrank_kernels.hpp"
+#include "eig_kernels.hpp"
 #include "gram_cg_wide_kernels.hpp"
 #include <dlfcn.h>
 #include <functional>
@@ -87,7 +88,7 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
     // observation weights of the explicit model ride on the shard (SparseShard::w / wsum)
     const bool weighted = X != nullptr && X->weighted() && (c.mode == CHOL_EXPLICIT || c.mode == CHOL_COLLECTIVE) && c.values_override == nullptr;
     if (weighted) { P.weights = X->w.ptr; P.wsum = X->wsum.ptr; }
-    if (c.mode == CHOL_NAZ_W) { P.weights = c.weights_override; P.wsum = X->wsum.ptr; }
+    if (c.mode == CHOL_NAZ_W) { P.weights = c.weights_override; P.wsum = X->wsum_naz.ptr; }
     if (c.mult_override != nullptr) P.wsum = c.mult_override;
     P.x_rhs_only = c.x_rhs_only ? 1 : 0;
     if (c.entry_pairs) { P.entry_pairs = 1; P.weights = c.weights_override; }
@@ -584,21 +585,23 @@ static int launch_cg_any(const DeviceInfo &dev, const CgCall &c, const SparseSha
     return rc >= 0 ? rc : launch_cg(dev, c, X, tm);
 }
 
-// Eigenvectors / values of one side's shared matrix w C^T C.  The decomposition is a chain of some four thousand small
-// launches (rocSOLVER's tridiagonalisation is launch-bound: ~4.5 ms of host time, ~6 ms on an idle device at k = 256), so
+// Eigenvectors / values of one side's shared matrix w C^T C (eig_kernels.hpp: tridiagonalisation + implicit QL, two launches
+// of 1 and ceil(k_c / 64) workgroups -- a few milliseconds of mostly sequential work on a handful of CUs), so
 //  * inside a half-step it is enqueued BEHIND the launches of the rows that do not need it (the producer / consumer batches of
 //    the long rows), on the eigen stream, waiting only for an event recorded in front of them;
 //  * a half-step also enqueues the decomposition the NEXT half-step of the other side will ask for (`wanted`: that side took
 //    the low-rank path before), since C and D are final once their own updates have run (cmfrec's order C, D, B, A):
 //    `fresh` says the cached vectors belong to the side matrix as it stands; every update / upload of C or D clears it.
+// (Rounds 3-5 bound rocSOLVER's dsyevd here -- ~4000 launches per decomposition, 6 ms on an idle device and 33 ms beside the
+//  persistent batches, profiles/r05/r05_zg_*; round 6 replaced it and the link against rocBLAS went with it.)
 struct EigCache {
-    DevBuf<double> W, V, D, E;
+    DevBuf<double> W, V, D, E, Tau;
     DevBuf<int> info;
     DevBuf<real_t> Q, Qt, Lam, M;     // M: the matrix a prefetch decomposes (the half-step's own one lives in the session's ctc)
     hipEvent_t ev = nullptr;          // recorded behind the chain on the eigen stream
     bool fresh = false, wanted = false;
-    int kind = 0;                     // 1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel
-    int checked_kc = 0;               // dsyevd's info word has been read back for this matrix size (once per size and cache)
+    int kind = 0;                     // 3 tridiagonalisation + QL (eig_kernels.hpp), 2 the one-workgroup Jacobi kernel
+    int checked_kc = 0;               // the QL kernel's status word has been read back for this matrix size (once per size and cache)
     ~EigCache() { if (ev) (void)hipEventDestroy(ev); }
 };
 
@@ -606,49 +609,8 @@ struct LowRankScratch {
     DevBuf<real_t> Ct, Bt, R, T;
     EigCache own;                 // callers without a cache per side (the stand-alone operator)
     int last_rows = 0;            // rows the low-rank kernels solved in the most recent launch (0: path not taken)
-    int last_eig = 0;             // its eigen-decomposition: 1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel
+    int last_eig = 0;             // its eigen-decomposition: 3 tridiagonalisation + QL, 2 the one-workgroup Jacobi kernel
 };
-
-// The symmetric eigen-decomposition of the k x k matrix w C^T C (once per half-step of the low-rank path) is a plain dense
-// library operation like the side-information GEMMs: rocSOLVER's divide-and-conquer syevd when the library can be loaded
-// (6 ms at k = 256 on this part), the built-in one-workgroup Jacobi kernel of lowrank_kernels.hpp otherwise (91 ms; also
-// CMFREC_HIP_EIG=jacobi, the on-device cross-check).  Both run on the GPU; the library is bound at run time so that the
-// shared objects do not depend on it.
-struct RocSolverApi {
-    typedef rocblas_status (*dsyevd_t)(rocblas_handle, int /*rocblas_evect*/, rocblas_fill, int, double *, int, double *, double *, int *);
-    dsyevd_t dsyevd = nullptr;
-    RocSolverApi()
-    {
-        void *lib = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_LOCAL);
-        if (!lib) lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_LOCAL);
-        if (lib) dsyevd = (dsyevd_t)dlsym(lib, "rocsolver_dsyevd");
-    }
-};
-static const RocSolverApi &rocsolver_api()
-{
-    static const RocSolverApi api;
-    return api;
-}
-
-// W (double, n x n) := A ;  after syevd (column-major eigenvectors in W, eigenvalues in D): Q[i][c] = W[c n + i], Qt = its transpose
-template <typename T>
-__global__ void eig_pack_kernel(const T *__restrict__ A, double *__restrict__ W, int n)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n * n) W[e] = (double)A[e];
-}
-template <typename T>
-__global__ void eig_unpack_kernel(const double *__restrict__ W, const double *__restrict__ D, int n, T *__restrict__ Q, T *__restrict__ Qt,
-                                  T *__restrict__ lam)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n * n) {
-        const int c = e / n, i = e % n;
-        Qt[(size_t)c * n + i] = (T)W[e];
-        Q[(size_t)i * n + c] = (T)W[e];
-    }
-    if (e < n) lam[e] = (T)fmax(D[e], 0.0);
-}
 
 // Enqueues the decomposition of the kc x kc matrix Minit on the eigen stream, behind `after` (an event of the main stream:
 // what produced Minit), and records E.ev behind it.
@@ -658,33 +620,38 @@ static void issue_eig(DeviceInfo &d, EigCache &E, const real_t *Minit, int kc, h
     E.Q.alloc_at_least((size_t)kc * kc); E.Qt.alloc_at_least((size_t)kc * kc); E.Lam.alloc_at_least((size_t)kc);
     if (!E.ev) HIP_CHECK(hipEventCreateWithFlags(&E.ev, hipEventDisableTiming));
     HIP_CHECK(hipStreamWaitEvent(d.eig_stream(), after, 0));
-    const RocSolverApi &rs = rocsolver_api();
-    // CMFREC_HIP_EIG=jacobi takes the built-in kernel
-    static bool dsyevd_bad = false;       // the library reported a failed decomposition once: the built-in kernel from then on
+    // default: Householder tridiagonalisation + implicit QL with the rotations applied row-parallel (eig_kernels.hpp);
+    // CMFREC_HIP_EIG=jacobi takes the one-workgroup Jacobi kernel (on-device cross-check; also the fallback should a QL iteration
+    // ever fail to converge: the status word is read back the first time a matrix of this size goes through a cache)
+    static bool ql_bad = false;
     bool done = false;
-    if (rs.dsyevd != nullptr && !dsyevd_bad && !switches().eig_jacobi) {
-        E.D.alloc_at_least((size_t)kc); E.E.alloc_at_least((size_t)kc); E.info.alloc_at_least(1);
-        hipLaunchKernelGGL(eig_pack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), Minit, E.W.ptr, kc);
-        rocblas_handle he = d.ensure_blas_eig();
-        done = rs.dsyevd(he, 211 /* rocblas_evect_original (rocsolver-extra-types.h) */, rocblas_fill_upper, kc, E.W.ptr, kc, E.D.ptr, E.E.ptr, E.info.ptr) ==
-               rocblas_status_success;
-        if (done && E.checked_kc != kc) {
-            // the return status only covers the launch: the device-side `info` (off-diagonals that did not converge) is read
-            // back the first time a matrix of this size goes through the library in this cache
+    if (!ql_bad && !switches().eig_jacobi && kc <= EIG_MAX_N) {
+        E.D.alloc_at_least((size_t)kc); E.E.alloc_at_least((size_t)kc); E.Tau.alloc_at_least((size_t)kc);
+        if (E.info.n < 1) { E.info.alloc(1); HIP_CHECK(hipMemsetAsync(E.info.ptr, 0, sizeof(int), d.eig_stream())); }
+        hipLaunchKernelGGL(eig_tridiag_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), Minit, kc, E.W.ptr, E.D.ptr, E.E.ptr, E.Tau.ptr);
+        const bool wide = kc > 288;                          // rows of the eigenvector matrix per workgroup: 64, or 32 (LDS: kc rows doubles)
+        const int rows = wide ? 32 : 64;
+        const size_t smem = ((size_t)kc * rows + 2 * (size_t)kc) * sizeof(double);
+        auto kern = wide ? eig_ql_rows_kernel<real_t, 32> : eig_ql_rows_kernel<real_t, 64>;
+        static thread_local bool attr_set[MAX_DEVICES][2] = {{false}};
+        bool &as = attr_set[std::min(std::max(d.device, 0), MAX_DEVICES - 1)][wide ? 1 : 0];
+        if (!as) { HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); as = true; }
+        hipLaunchKernelGGL(kern, dim3((kc + rows - 1) / rows), dim3(64), smem, d.eig_stream(), kc, E.W.ptr, E.D.ptr, E.E.ptr, E.Tau.ptr, E.Q.ptr,
+                           E.Qt.ptr, (size_t)kc, E.Lam.ptr, E.info.ptr);
+        HIP_CHECK(hipGetLastError());
+        done = true;
+        if (E.checked_kc != kc) {
             int h_info = 0;
             HIP_CHECK(hipMemcpyAsync(&h_info, E.info.ptr, sizeof(int), hipMemcpyDeviceToHost, d.eig_stream()));
             HIP_CHECK(hipStreamSynchronize(d.eig_stream()));
             E.checked_kc = kc;
-            if (h_info != 0) { dsyevd_bad = true; done = false; }
+            if (h_info != 0) { ql_bad = true; done = false; }
         }
-        if (done)
-            hipLaunchKernelGGL(eig_unpack_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, d.eig_stream(), E.W.ptr, E.D.ptr, kc, E.Q.ptr,
-                               E.Qt.ptr, E.Lam.ptr);
     }
     if (!done)
         hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), Minit, kc, E.W.ptr, E.V.ptr, E.Q.ptr, E.Qt.ptr,
                            (size_t)kc, E.Lam.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
-    E.kind = done ? 1 : 2;
+    E.kind = done ? 3 : 2;
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(E.ev, d.eig_stream()));
 }
@@ -1074,6 +1041,23 @@ static int weights_allowed(const cmfrec_hip_session *s, const char *fn)
     return 0;
 }
 
+// NA_as_zero_X with observation weights: an absent entry is a zero of weight one, so the rows' lambda multipliers under scale_lam
+// count them (wsumA / wsumB, collective.c:7991-8022).  Kept in SparseShard::wsum_naz beside the plain sums of the weights and
+// rebuilt whenever the flag is switched on or X is uploaded again (the plain sums stay what the ordinary weighted updates and
+// cmfrec_hip_session_set_lambda_multipliers('A' / 'B') use).
+static void refresh_naz_multipliers(cmfrec_hip_session *s)
+{
+    if (!s->naz_X || !s->Xr.weighted()) { s->Xr.wsum_naz.release(); s->Xc.wsum_naz.release(); return; }
+    HIP_CHECK(hipSetDevice(s->dev.device));
+    hipStream_t st = s->dev.stream;
+    s->Xr.wsum_naz.alloc_at_least((size_t)s->Xr.nrows); s->Xc.wsum_naz.alloc_at_least((size_t)s->Xc.nrows);
+    hipLaunchKernelGGL(naz_wsum_kernel<real_t>, grid1d((size_t)s->Xr.nrows), dim3(256), 0, st, s->Xr.p.ptr, s->Xr.w.ptr, s->Xr.nrows,
+                       s->mdl.n, s->Xr.wsum_naz.ptr);
+    hipLaunchKernelGGL(naz_wsum_kernel<real_t>, grid1d((size_t)s->Xc.nrows), dim3(256), 0, st, s->Xc.p.ptr, s->Xc.w.ptr, s->Xc.nrows,
+                       s->mdl.m, s->Xc.wsum_naz.ptr);
+    HIP_CHECK(hipGetLastError());
+}
+
 int cmfrec_hip_session_set_X_weighted(cmfrec_hip_session *s, const size_t *csr_p, const int_t *csr_i, const real_t *csr_v,
                                       const real_t *csr_w, const size_t *csc_p, const int_t *csc_i, const real_t *csc_v,
                                       const real_t *csc_w)
@@ -1085,6 +1069,7 @@ int cmfrec_hip_session_set_X_weighted(cmfrec_hip_session *s, const size_t *csr_p
         s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(s->mdl.k + s->mdl.k_main) * sizeof(real_t);
         shard_from_csr(s->Xr, s->mdl.row_end - s->mdl.row_begin, csr_p, csr_i, csr_v, s->mdl.n, s->dev.stream, csr_w);
         shard_from_csr(s->Xc, s->mdl.col_end - s->mdl.col_begin, csc_p, csc_i, csc_v, s->mdl.m, s->dev.stream, csc_w);
+        refresh_naz_multipliers(s);
         return 0;
     });
 }
@@ -1177,6 +1162,7 @@ int cmfrec_hip_session_set_X_coo_weighted(cmfrec_hip_session *s, const int_t *ro
         s->x_subtract = subtract;
         shard_from_coo(s->Xr, m.m, m.n, dr.ptr, dc.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream, dw.ptr);
         shard_from_coo(s->Xc, m.n, m.m, dc.ptr, dr.ptr, dv.ptr, nnz, subtract, alpha, s->dev.stream, dw.ptr);
+        refresh_naz_multipliers(s);
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
@@ -1202,6 +1188,7 @@ int cmfrec_hip_session_set_X_coo_device(cmfrec_hip_session *s, int which, const 
         s->Xr.opp_row_bytes_hint = s->Xc.opp_row_bytes_hint = (size_t)(m.k + m.k_main) * sizeof(real_t);
         if (which == 'r') shard_from_coo(s->Xr, m.row_end - m.row_begin, m.n, d_key, d_other, d_val, nnz, subtract, alpha, s->dev.stream);
         else shard_from_coo(s->Xc, m.col_end - m.col_begin, m.m, d_key, d_other, d_val, nnz, subtract, alpha, s->dev.stream);
+        refresh_naz_multipliers(s);       // (this upload carries no weights: the multipliers of a weighted predecessor go)
         HIP_CHECK(hipStreamSynchronize(s->dev.stream));
         return 0;
     });
@@ -1548,17 +1535,8 @@ int cmfrec_hip_session_set_NA_as_zero_X(cmfrec_hip_session *s, int on, int cente
                            "column range";
             return 2;
         }
-        if (on && s->Xr.weighted() && !s->naz_X) {
-            // with observation weights an absent entry is a zero of weight one: the rows' lambda multipliers under scale_lam count
-            // them (wsumA / wsumB, collective.c:7991-8022)
-            hipStream_t st = s->dev.stream;
-            hipLaunchKernelGGL(naz_wsum_kernel<real_t>, grid1d((size_t)s->Xr.nrows), dim3(256), 0, st, s->Xr.p.ptr, s->Xr.w.ptr, s->Xr.nrows,
-                               s->mdl.n, s->Xr.wsum.ptr);
-            hipLaunchKernelGGL(naz_wsum_kernel<real_t>, grid1d((size_t)s->Xc.nrows), dim3(256), 0, st, s->Xc.p.ptr, s->Xc.w.ptr, s->Xc.nrows,
-                               s->mdl.m, s->Xc.wsum.ptr);
-            HIP_CHECK(hipGetLastError());
-        }
         s->naz_X = on != 0; s->naz_center = center != 0; s->naz_mean = glob_mean;
+        refresh_naz_multipliers(s);
         return 0;
     });
 }
@@ -2004,7 +1982,7 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
     CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, s->ctc.ptr, kc, rows_u, p_self, lam_self, lam_last_self, scaled,
                (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE, s->naz_M.ptr};
     c.rhs_prefilled_all = true; c.entry_pairs = true; c.values_override = s->naz_xt.ptr; c.weights_override = s->naz_g.ptr;
-    if (scaled) c.mult_override = X.wsum.ptr;            // sum of the row's weights + its absent entries (cmfrec_hip_session_set_NA_as_zero_X)
+    if (scaled) c.mult_override = X.wsum_naz.ptr;        // sum of the row's weights + its absent entries (cmfrec_hip_session_set_NA_as_zero_X)
     return launch_chol(dev, c, &X);
 }
 
@@ -2105,7 +2083,7 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
     if (has_cst && X.nrows > X.n_nonempty) {
         const int cnt = X.nrows - X.n_nonempty;
         hipLaunchKernelGGL(cg_shared_matrix_rows_kernel<real_t>, dim3((cnt + 3) / 4), dim3(256), 0, st, self, ld_self, X.order.ptr + X.n_nonempty, cnt, ks,
-                           s->gram.ptr, cst, lam_self, lam_last_self, m.scale_lam ? X.wsum.ptr : nullptr, s->scale_bias_const ? 1 : 0, m.max_cg_steps);
+                           s->gram.ptr, cst, lam_self, lam_last_self, m.scale_lam ? X.wsum_naz.ptr : nullptr, s->scale_bias_const ? 1 : 0, m.max_cg_steps);
         HIP_CHECK(hipGetLastError());
     }
     return 0;
@@ -3369,8 +3347,40 @@ __global__ void lanes_selftest_kernel(real_t *out)
 }  // namespace cmfhip
 
 // Timing probe of the dense contraction C[M, N] = op(A) B on the device (tools/microbench/gemm_probe.py): milliseconds per call of
-// the library's own MFMA kernel and of rocBLAS on the same operands, and the largest difference between their results relative
-// to the largest entry.  transa != 0: A is stored [K, M].
+// the library's own MFMA kernel and -- when librocblas can be loaded at run time; the shared objects are not linked against it since
+// round 6 -- of rocBLAS on the same operands, and the largest difference between their results relative to the largest entry
+// (ms_rocblas = -1 and the difference against a plain one-thread-per-output kernel when the library is not there).
+// transa != 0: A is stored [K, M].
+namespace cmfhip {
+template <typename T>
+__global__ void gemm_naive_kernel(int M, int N, int K, int transa, const T *__restrict__ A, size_t lda, const T *__restrict__ B, size_t ldb,
+                                  T *__restrict__ C, size_t ldc)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)M * N) return;
+    const int i = (int)(e / N), j = (int)(e % N);
+    double acc = 0;
+    for (int q = 0; q < K; q++) acc += (double)(transa ? A[(size_t)q * lda + i] : A[(size_t)i * lda + q]) * (double)B[(size_t)q * ldb + j];
+    C[(size_t)i * ldc + j] = (T)acc;
+}
+struct RocBlasProbe {          // (measurement tool only)
+    typedef int (*create_t)(void **);
+    typedef int (*destroy_t)(void *);
+    typedef int (*set_stream_t)(void *, hipStream_t);
+    typedef int (*gemm_t)(void *, int, int, int, int, int, const real_t *, const real_t *, int, const real_t *, int, const real_t *, real_t *, int);
+    create_t create = nullptr; destroy_t destroy = nullptr; set_stream_t set_stream = nullptr; gemm_t gemm = nullptr;
+    RocBlasProbe()
+    {
+        void *lib = dlopen("librocblas.so.5", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return;
+        create = (create_t)dlsym(lib, "rocblas_create_handle"); destroy = (destroy_t)dlsym(lib, "rocblas_destroy_handle");
+        set_stream = (set_stream_t)dlsym(lib, "rocblas_set_stream");
+        gemm = (gemm_t)dlsym(lib, sizeof(real_t) == 4 ? "rocblas_sgemm" : "rocblas_dgemm");
+    }
+    bool ok() const { return create && destroy && set_stream && gemm; }
+};
+}  // namespace cmfhip
 extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, double *ms_own, double *ms_rocblas, double *max_rel_diff)
 {
     return guarded([&]() {
@@ -3387,11 +3397,16 @@ extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, 
         const size_t lda = transa ? (size_t)M : (size_t)K;
         hipEvent_t e0, e1;
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        static const RocBlasProbe rb;
+        void *h = nullptr;
+        const bool have_lib = rb.ok() && rb.create(&h) == 0 && rb.set_stream(h, dev.stream) == 0;
         auto run = [&](bool own, real_t *C, double *ms) {
-            g_gemm_force = own ? 1 : 0;
+            const real_t one = 1, zero = 0;
             for (int r = 0; r < reps + 1; r++) {
                 if (r == 1) HIP_CHECK(hipEventRecord(e0, dev.stream));
-                if (transa) launch_gemm<true>(dev, M, N, K, (real_t)1, A.ptr, lda, B.ptr, (size_t)N, C, (size_t)N);
+                if (!own)   // row-major C is the column-major C^T = B^T op(A)^T: first operand B, second operand A with the flag inverted
+                    (void)rb.gemm(h, 111 /* none */, transa ? 112 /* transpose */ : 111, N, M, K, &one, B.ptr, N, A.ptr, (int)lda, &zero, C, N);
+                else if (transa) launch_gemm<true>(dev, M, N, K, (real_t)1, A.ptr, lda, B.ptr, (size_t)N, C, (size_t)N);
                 else launch_gemm<false>(dev, M, N, K, (real_t)1, A.ptr, lda, B.ptr, (size_t)N, C, (size_t)N);
             }
             HIP_CHECK(hipEventRecord(e1, dev.stream));
@@ -3401,15 +3416,70 @@ extern "C" int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, 
             if (ms) *ms = (double)t / std::max(reps, 1);
         };
         run(true, C1.ptr, ms_own);
-        run(false, C2.ptr, ms_rocblas);
-        g_gemm_force = -1;
+        if (have_lib) run(false, C2.ptr, ms_rocblas);
+        else {
+            if (ms_rocblas) *ms_rocblas = -1.0;
+            hipLaunchKernelGGL(gemm_naive_kernel<real_t>, grid1d((size_t)M * N), dim3(256), 0, dev.stream, M, N, K, transa, A.ptr, lda, B.ptr, (size_t)N,
+                               C2.ptr, (size_t)N);
+            HIP_CHECK(hipGetLastError());
+        }
         std::vector<real_t> h1((size_t)M * N), h2((size_t)M * N);
         C1.download(h1.data(), h1.size(), dev.stream); C2.download(h2.data(), h2.size(), dev.stream);
         HIP_CHECK(hipStreamSynchronize(dev.stream));
+        if (h) (void)rb.destroy(h);
         double mx = 0, df = 0;
         for (size_t e = 0; e < h1.size(); e++) { mx = std::max(mx, std::fabs((double)h2[e])); df = std::max(df, std::fabs((double)h1[e] - (double)h2[e])); }
         if (max_rel_diff) *max_rel_diff = df / std::max(mx, 1e-300);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return 0;
+    });
+}
+
+// The symmetric eigen-decomposition of the low-rank path on its own (tests/test_gpu_operators.py::test_sym_eig,
+// tools/microbench/eig_probe.py): A [n, n] symmetric -> Q [n, n] (Q[i][c] = component i of eigenvector c), lam [n] (clamped at
+// zero); method 0 = tridiagonalisation + QL (eig_kernels.hpp), 1 = the one-workgroup Jacobi kernel.  ms: device time of `reps` runs.
+extern "C" int cmfrec_hip_sym_eig(int n, const real_t *A, real_t *Q, real_t *lam, int method, int reps, double *ms)
+{
+    return guarded([&]() {
+        if (n < 2 || n > EIG_MAX_N) { g_last_error = "cmfrec_hip_sym_eig: 2 <= n <= 320"; return 2; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        DevBuf<real_t> dA, dQ, dQt, dL;
+        DevBuf<double> W, V, D, E, Tau;
+        DevBuf<int> info;
+        const size_t nn = (size_t)n * n;
+        dA.upload(A, nn, dev.stream); dQ.alloc(nn); dQt.alloc(nn); dL.alloc((size_t)n);
+        W.alloc(nn); V.alloc(nn); D.alloc((size_t)n); E.alloc((size_t)n); Tau.alloc((size_t)n); info.alloc(1);
+        HIP_CHECK(hipMemsetAsync(info.ptr, 0, sizeof(int), dev.stream));
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+        const bool wide = n > 288;
+        const int rows = wide ? 32 : 64;
+        const size_t smem = ((size_t)n * rows + 2 * (size_t)n) * sizeof(double);
+        auto kern = wide ? eig_ql_rows_kernel<real_t, 32> : eig_ql_rows_kernel<real_t, 64>;
+        HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int r = 0; r < std::max(reps, 1) + 1; r++) {
+            if (r == 1) HIP_CHECK(hipEventRecord(e0, dev.stream));
+            if (method == 0) {
+                hipLaunchKernelGGL(eig_tridiag_kernel<real_t>, dim3(1), dim3(1024), 0, dev.stream, dA.ptr, n, W.ptr, D.ptr, E.ptr, Tau.ptr);
+                hipLaunchKernelGGL(kern, dim3((n + rows - 1) / rows), dim3(64), smem, dev.stream, n, W.ptr, D.ptr, E.ptr, Tau.ptr, dQ.ptr, dQt.ptr,
+                                   (size_t)n, dL.ptr, info.ptr);
+            } else
+                hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, dev.stream, dA.ptr, n, W.ptr, V.ptr, dQ.ptr, dQt.ptr, (size_t)n,
+                                   dL.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);
+            HIP_CHECK(hipGetLastError());
+        }
+        HIP_CHECK(hipEventRecord(e1, dev.stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = (double)t / std::max(reps, 1);
+        int h_info = 0;
+        HIP_CHECK(hipMemcpyAsync(&h_info, info.ptr, sizeof(int), hipMemcpyDeviceToHost, dev.stream));
+        dQ.download(Q, nn, dev.stream); dL.download(lam, (size_t)n, dev.stream);
+        HIP_CHECK(hipStreamSynchronize(dev.stream));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (h_info != 0) { g_last_error = "cmfrec_hip_sym_eig: a QL iteration did not converge"; return 4; }
         return 0;
     });
 }

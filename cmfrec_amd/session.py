@@ -111,6 +111,14 @@ class AlsSession:
         _lib.check(self.lib.cmfrec_hip_session_set_lam_unique(self.handle, _lib.ptr(l6), _lib.ptr(l16), C.c_int(int(max_cd_steps))),
                    self.lib, "set_lam_unique")
 
+    def set_NA_as_zero_X(self, on=True, center=False, glob_mean=0.0):
+        """The main matrix missing-as-zero (explicit model; reference NA_as_zero_X, src/collective.c:8334-8898): X must have been set
+        uncentred.  With observation weights the rows' lambda multipliers under scale_lam count the absent entries; the session
+        rebuilds them whenever X is uploaded again or the flag changes."""
+        R = _lib.real(self.dtype)
+        _lib.check(self.lib.cmfrec_hip_session_set_NA_as_zero_X(self.handle, C.c_int(int(on)), C.c_int(int(center)), R(glob_mean)),
+                   self.lib, "set_NA_as_zero_X")
+
     def init_biases(self, lam_user, lam_item):
         """Bias start values on the device (reference initialize_biases_*, src/common.c:4410-4909)."""
         R = _lib.real(self.dtype)

@@ -539,8 +539,14 @@ int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B
  * are built on; returns the number of mismatching lanes (0 = ok), negative = HIP failure. */
 int cmfrec_hip_selftest_lanes(void);
 /* timing / agreement probe of the dense contraction C[M, N] = op(A) B (transa: A stored [K, M]) on random operands: ms per call of
-   the library's own MFMA kernel and of rocBLAS, largest difference of the two results relative to the largest entry */
+   the library's own MFMA kernel and of rocBLAS (loaded at run time if it is there; -1 and a plain reference kernel otherwise),
+   largest difference of the two results relative to the largest entry */
 int cmfrec_hip_gemm_probe(int M, int N, int K, int transa, int reps, double *ms_own, double *ms_rocblas, double *max_rel_diff);
+/* The symmetric eigen-decomposition the low-rank row path runs once per half-step on w C^T C (replaces what the reference gets
+ * from a k_t x k_t dposv per row, src/collective.c:1823, for rows of few entries): A [n, n] symmetric (2 <= n <= 320) ->
+ * Q [n, n] with Q[i][c] = component i of eigenvector c, lam [n] clamped at zero.  method 0: Householder tridiagonalisation +
+ * implicit QL (the default of the path), 1: one-workgroup Jacobi (cross-check).  ms: device milliseconds per run over `reps`. */
+int cmfrec_hip_sym_eig(int n, const real_t *A, real_t *Q, real_t *lam, int method, int reps, double *ms);
 
 /* Start values as the reference's random_parallel draws them (src/helpers.c:927-1043; xoshiro256++
  * seeded by splitmix64, truncated ziggurat normals or uniforms, scaled 2^-7): A <- stream(seed),

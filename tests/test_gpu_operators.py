@@ -171,10 +171,9 @@ def test_very_heavy_rows_split_path(oracles, dtype, implicit, vh, k, monkeypatch
 @pytest.mark.parametrize("implicit", [True, False])
 @pytest.mark.parametrize("k", [50, 8, 64])
 def test_two_rows_per_wave(oracles, dtype, implicit, k):
-    """Rows of at most 32 entries (one per wavefront by default; two per wavefront -- cg_rows_pair_kernel, cg_pair_kernels.hpp --
-    under CMFREC_HIP_PAIR=1, which tests/test_gpu_switches.py runs on the same kind of rows): every length 0 .. 32
-    several times -- pairs of two short rows (16-slot tiles), of two longer ones, and mixed pairs at the boundary -- an odd number
-    of such rows (the last wavefront holds one), rows that take the first exit (warm start = zero in the implicit model with unit
+    """Rows of at most 32 entries (cg_rows_tiny_kernel, one row per wavefront; the name dates from round 5's two-rows-per-wavefront
+    kernel, removed in round 6): every length 0 .. 32 several times -- rows on the 16-slot tile, on the 32-slot tile and at the
+    boundary between them -- an odd number of such rows, rows that take the first exit (warm start = zero in the implicit model with unit
     counts does not; a row whose start already solves its system does), next to rows of 33 .. 60 entries on the one-row kernels."""
     from cmfrec_amd import ops
     O = oracles[dtype]
@@ -569,3 +568,46 @@ def test_explicit_cg_beyond_64_unknowns(oracles, dtype, k):
         assert rel_err(Ah, Ao) < TOL[dtype]
         check_rows(Ah, Ao, dtype)
         assert np.array_equal(Ah[0], A0[0])                  # a row without entries stays as it is
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_session_naz_weighted_multipliers_follow_uploads(dtype):
+    """Level-2 session API, NA_as_zero_X with observation weights under scale_lam: the lambda multipliers of that model (sum of
+    the row's weights + its absent entries) live beside the plain sums of the weights and are rebuilt whenever X is uploaded
+    again or the flag changes (they used to overwrite the plain sums once).  A second upload of X + a second
+    set_NA_as_zero_X(on) gives the bits of a fresh session; switching the flag off gives the bits of a session that never had it;
+    a different X after the flag gives what a fresh session gives for that X."""
+    from cmfrec_amd.session import AlsSession
+    rng = np.random.default_rng(11)
+    m, n, k, nnz = 300, 200, 12, 6000
+    lin = rng.choice(m * n, size=nnz, replace=False)
+    row, col = (lin // n).astype(np.int32), (lin % n).astype(np.int32)
+    val = rng.standard_normal(nnz).astype(dtype)
+    w = rng.uniform(0.5, 3.0, nnz).astype(dtype)
+    A0 = (rng.standard_normal((m, k)) * 0.1).astype(dtype)
+    B0 = (rng.standard_normal((n, k)) * 0.1).astype(dtype)
+
+    def run(steps):
+        s = AlsSession(m, n, k, implicit=False, dtype=dtype, lam=0.05, use_cg=False, scale_lam=True)
+        for st in steps:
+            if st == "X": s.set_X_coo(row, col, val, weight=w)
+            elif st == "X2": s.set_X_coo(row[: nnz // 2], col[: nnz // 2], val[: nnz // 2], weight=w[: nnz // 2])
+            elif st == "on": s.set_NA_as_zero_X(True)
+            elif st == "off": s.set_NA_as_zero_X(False)
+        s.set_factors(A=A0, B=B0)
+        s.update("A", use_cholesky=True)
+        s.update("B", use_cholesky=True)
+        out = s.get_factors()
+        s.close()
+        return out["A"].copy(), out["B"].copy()
+
+    fresh = run(["X", "on"])
+    again = run(["X", "on", "X", "on"])
+    assert np.array_equal(fresh[0], again[0]) and np.array_equal(fresh[1], again[1])
+    flag_first = run(["X2", "on", "X"])                   # the upload after the flag rebuilds the multipliers for the new X
+    assert np.array_equal(fresh[0], flag_first[0]) and np.array_equal(fresh[1], flag_first[1])
+    plain = run(["X"])
+    back = run(["X", "on", "off"])
+    assert np.array_equal(plain[0], back[0]) and np.array_equal(plain[1], back[1])
+    assert np.abs(plain[0] - fresh[0]).max() > 1e-3       # (the flag changes the model)
