@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-point", action="store_true", help="skip the N = 1 point of the scaling series (config 4 on one GPU)")
+    ap.add_argument("--no-side-points", action="store_true", help="skip the other BASELINE configurations (c1, c3, c4shard, c5shard, whole fit)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalid as a result)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded engine + collectives even with 1 rank (test)")
     ap.add_argument("--item-blocks", default="dealt", choices=["dealt", "contiguous"],
@@ -326,6 +327,11 @@ def main():
         except Exception as e:        # the headline above must not depend on it
             scale_point = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    # ---- the other BASELINE configurations on this GPU, one child process each ----
+    side = None
+    if rank == 0 and world == 1 and not use_dist and args.scale == 1.0 and not args.no_scale_point and not args.no_side_points:
+        side = side_points(args)
+
     if rank == 0:
         out = {"metric": "ALS rows/sec ((users+items)/iteration time), implicit ALS-CG k=50 fp64",
                "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps,
@@ -336,7 +342,7 @@ def main():
                                                                                " (1 LastFM-sized user block per GPU)" if world > 1 else ""),
                           "parallelism": "row-block x%d + all-gather" % world if world > 1 else "single GPU",
                           "gen_seconds": round(t_gen, 1)},
-               "roofline": roofline, "cpu_baseline": cpu, "parity_vs_reference": parity, "scale_point": scale_point}
+               "roofline": roofline, "cpu_baseline": cpu, "parity_vs_reference": parity, "scale_point": scale_point, "side_points": side}
         if args.scale != 1.0:
             out["config"]["INVALID_scaled_down"] = args.scale
         final_line = json.dumps(out)
@@ -644,7 +650,7 @@ def c5_distributed(args, rank, world, local_rank):
                "halfstep_ms_rank0": {"A": msA / max(cA, 1), "B": msB / max(cB, 1)},
                "halfstep_TFLOPs_rank0_share": {"A": round(flA / world / (msA / max(cA, 1) * 1e-3) / 1e12, 1) if cA else None,
                                                "B": round(flB / world / (msB / max(cB, 1) * 1e-3) / 1e12, 1) if cB else None},
-               "lowrank_rows_rank0": lr_rows, "lowrank_eig": {0: "not taken", 1: "rocSOLVER dsyevd", 2: "built-in Jacobi"}[lr_eig],
+               "lowrank_rows_rank0": lr_rows, "lowrank_eig": {0: "not taken", 2: "one-workgroup Jacobi", 3: "tridiagonalisation + QL (own)"}.get(lr_eig, lr_eig),
                "finite": None if f is None else bool(np.isfinite(f["A"]).all() and np.isfinite(f["B"]).all() and np.isfinite(f["C"]).all()),
                "roofline": None, "cpu_baseline": None}
         if args.scale != 1.0:
@@ -834,7 +840,16 @@ def side_workload(args, device):
         # Gramians nnz*kt*(kt+1) + Cholesky kt^3/3 + 2 kt^2 per row, both half-steps (+ the small side-information GEMMs)
         flops = 2 * nnz * kt * (kt + 1) + (m + n) * (kt ** 3 / 3 + 2 * kt * kt) + 3 * 2 * n * q * k
         gath = 2 * (nnz * kt * 8 + nnz * 12)
+        # flops the half-steps EXECUTE: item rows and the user rows beyond 96 entries take the rank-k update + the k_t^3 / 3
+        # factorisation; user rows of at most 96 entries (no side information on that side) take the low-rank kernel
+        # (session.hip launch_plain_lowrank, CMF_LR_MAX_F64): an s x s Gramian over k_t, its factorisation and two s x k_t products
+        ucnt = np.bincount(row, minlength=m).astype(np.float64)
+        icnt = np.bincount(col, minlength=n).astype(np.float64)
+        full = lambda c: float((c * kt * (kt + 1) + kt ** 3 / 3.0 + 2.0 * kt * kt).sum())
+        light = ucnt[(ucnt <= 96) & (ucnt > 0)]
+        executed = full(icnt) + full(ucnt[ucnt > 96]) + float((light * (light + 1) * kt + light ** 3 / 3.0 + 4.0 * light * kt).sum()) + 3 * 2 * n * q * k
         extra = {"alg_TFLOP": round(flops / 1e12, 3), "TFLOPs": round(flops / dt / 1e12, 1),
+                 "executed_TFLOP": round(executed / 1e12, 3), "executed_frac_of_fp64_peak_78.6": round(executed / dt / 78.6e12, 3),
                  "frac_of_fp64_vector_peak_78.6": round(flops / dt / 78.6e12, 3),
                  "gather_GB": round(gath / 1e9, 2), "gather_frac_of_hbm_peak": round(gath / dt / 8e12, 3)}
     else:
@@ -936,6 +951,7 @@ def cpu_baseline(row, col, val, m, n, A0, compare=None):
     if best is None:
         return {"value": None, "unit": "rows/s", "cores": 0, "kind": "failed", "sample": "CPU baseline child failed"}, None
     best["threads_tried"] = tried
+    best["host"] = host_cpu_info()
     parity = None
     if factors is not None:
         try:
@@ -943,6 +959,72 @@ def cpu_baseline(row, col, val, m, n, A0, compare=None):
         except Exception as e:            # the baseline number must not depend on it
             parity = {"error": "%s: %s" % (type(e).__name__, e)}
     return best, parity
+
+
+def host_cpu_info():
+    """What the CPU baseline had to run on: logical cpus, the affinity mask of this process and the cgroup's cpu quota (a quota below
+    the thread count, or an affinity mask narrower than cpu_count, explains a baseline that gets slower with more threads)."""
+    info = {"cpu_count": os.cpu_count()}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["sched_affinity"] = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            info["cgroup:" + f.rsplit("/", 1)[1]] = open(f).read().strip()
+            break
+        except Exception:
+            pass
+    try:
+        info["loadavg"] = os.getloadavg()[0]
+    except Exception:
+        pass
+    return info
+
+
+def side_points(args):
+    """BASELINE.json's other configurations (and the whole fit) on this GPU, driver-timed like the headline: each runs as a child
+    process of this script (`--workload X`), so that none of them can take the headline down; one line per workload with its time
+    per step, the roofline that bounds it and the fraction reached -- HBM for the CG configurations (algorithmic bytes),
+    EXECUTED flops against the fp64 / fp32 peak for the Cholesky configurations (not the surveyed full-factorisation count)."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    plan = [("c1", 20, 3, []), ("c3", 10, 3, []), ("c4shard", 10, 3, []), ("c5shard", 3, 1, []), ("fit", 5, 0, [])]
+    out = {}
+    for w, st, wu, extra in plan:
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, here, "--no-cpu-baseline", "--workload", w, "--steps", str(st), "--warmup", str(wu)] + extra,
+                               capture_output=True, text=True, timeout=420)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[w] = {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            if w == "fit":
+                e = {"what": d["workload"], "seconds_best": d["best_s"], "rows_per_s_whole_fit": d["rows_per_s_whole_fit"],
+                     "bound": "host + PCIe + 15 iterations", "frac": None}
+            elif w in ("c1", "c4shard"):
+                e = {"what": ("BASELINE configs[0] on the GPU: CMF explicit ALS-CG k=50 fp64, MovieLens10M shape, biases, scale_lam" if w == "c1"
+                              else "one rank's share of BASELINE configs[3] at N = 8: 1.25 M users x 1 M-item replica, 62.5 M nnz, k=64 fp32"),
+                     "ms_per_step": d["ms_per_iteration"], "bound": "hbm", "frac": d["frac_of_hbm_peak"], "alg_GB": d.get("alg_GB")}
+            elif w == "c3":
+                e = {"what": "BASELINE configs[2]: CMF explicit ALS-Chol k=128 fp64 + 64-dim item side info, MovieLens10M shape",
+                     "ms_per_step": d["ms_per_iteration"], "bound": "fp64 peak 78.6 TFLOP/s (vector = matrix in double precision)",
+                     "frac": d.get("executed_frac_of_fp64_peak_78.6"), "executed_TFLOP": d.get("executed_TFLOP"),
+                     "surveyed_full_cholesky_frac": d.get("frac_of_fp64_vector_peak_78.6")}
+            else:
+                it = d.get("item_step", {})
+                e = {"what": "an eighth of one rank's share of BASELINE configs[4]: " + d["workload"], "ms_per_step": d["ms_per_iteration"],
+                     "bound": "fp32 matrix peak 157.3 TFLOP/s, item step on its executed flops (the user step runs the low-rank path)",
+                     "frac": it.get("frac_of_fp32_matrix_peak_157"), "item_step_ms": it.get("ms"), "user_step_ms": d.get("user_step_ms")}
+            e["halfstep_ms"] = d.get("halfstep_ms")
+            e["finite"] = d.get("finite")
+            e["steps"], e["warmup"], e["wall_s"] = st, wu, round(time.time() - t0, 1)
+            out[w] = e
+        except Exception as ex:            # the headline above must not depend on it
+            out[w] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    return out
 
 
 def cpu_worker(path, nthreads):
@@ -980,8 +1062,8 @@ def cpu_worker(path, nthreads):
                       "s_per_iteration": round(s_per_iter, 3),
                       "sample": "%d full ALS iteration(s) after one warm-up iteration (optimizeA_implicit B-step + A-step, the "
                                 "reference's OpenMP row loop) of the same workload, nthreads=%d of %d host cpus pinned "
-                                "(OMP_PROC_BIND=close, OMP_PLACES=cores), BLAS = SciPy OpenBLAS"
-                                % (iters, nthreads, os.cpu_count() or 1)}))
+                                "(OMP_PROC_BIND=close, OMP_PLACES=cores; affinity mask of the worker: %d cpus), BLAS = SciPy OpenBLAS"
+                                % (iters, nthreads, os.cpu_count() or 1, len(os.sched_getaffinity(0)))}))
 
 
 if __name__ == "__main__":

@@ -43,7 +43,7 @@ EXPORTED = [
     "cmfrec_hip_session_set_sideinfo", "cmfrec_hip_session_set_sideinfo_local", "cmfrec_hip_session_sideinfo_partial", "cmfrec_hip_session_sideinfo_finish", "cmfrec_hip_session_set_nonneg", "cmfrec_hip_session_set_l1", "cmfrec_hip_session_set_lam_unique", "cmfrec_hip_session_set_scale_bias_const", "cmfrec_hip_session_set_NA_as_zero_X", "cmfrec_hip_session_set_zero_rows", "cmfrec_hip_session_set_closed_form_rows", "cmfrec_hip_session_set_lambda_multipliers", "cmfrec_hip_session_set_implicit_features", "cmfrec_hip_session_get_implicit_features", "cmfrec_hip_session_set_sideinfo_sparse", "cmfrec_hip_session_update", "cmfrec_hip_session_iterate",
     "cmfrec_hip_session_sync", "cmfrec_hip_session_device_ptr", "cmfrec_hip_session_stream",
     "cmfrec_hip_session_after_gather", "cmfrec_hip_session_kernel_time",
-    "cmfrec_hip_session_reset_timers", "cmfrec_hip_session_bin_overlaps", "cmfrec_hip_session_vh_mode", "cmfrec_hip_session_vh_min", "cmfrec_hip_session_lowrank_info", "cmfrec_hip_session_bin_stats", "cmfrec_hip_sizeof_real", "cmfrec_hip_sizeof_model", "cmfrec_hip_build_info", "cmfrec_hip_reload_switches", "cmfrec_hip_selftest_lanes", "cmfrec_hip_exchange_plan", "cmfrec_hip_gemm_probe", "cmfrec_hip_sym_eig", "cmfrec_hip_random_parallel",
+    "cmfrec_hip_session_reset_timers", "cmfrec_hip_session_bin_overlaps", "cmfrec_hip_session_vh_mode", "cmfrec_hip_session_vh_min", "cmfrec_hip_session_lowrank_info", "cmfrec_hip_session_bin_stats", "cmfrec_hip_sizeof_real", "cmfrec_hip_sizeof_model", "cmfrec_hip_build_info", "cmfrec_hip_reload_switches", "cmfrec_hip_selftest_lanes", "cmfrec_hip_exchange_plan", "cmfrec_hip_gemm_probe", "cmfrec_hip_sym_eig", "precompute_collective_explicit", "precompute_collective_implicit", "topN_old_collective_explicit", "topN_old_collective_implicit", "cmfrec_hip_random_parallel",
 ]
 
 _cache = {}

@@ -427,7 +427,9 @@ __device__ __forceinline__ T entry_weight(const CgParams<T> &P, size_t pos)
     return (P.weights != nullptr) ? P.weights[pos] : T(1);
 }
 
-template <int S, bool IMPLICIT, int MODE, int NT = 8>
+// INIT (round 6): the pass accumulators are DEFINED by this call (first products as multiplications) instead of cleared beforehand and
+// accumulated into -- the S (double) / S (packed single) clearing moves per pass go; the unused slots S .. 7 are cleared here.
+template <int S, bool IMPLICIT, int MODE, int NT = 8, bool INIT = false>
 __device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, const float (&vrep)[S], float x, bool valid,
                                           PassAcc<float> &out, int lane, float g = 1.f)
 {
@@ -450,16 +452,20 @@ __device__ __forceinline__ void tile_pass_f32(const RegTile<float, S> &tile, con
     for (int q = 0; q < NT / 2; q++) {
         const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
 #pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += w2 * tile.v[q][s];
+        for (int s = 0; s < S; s++) out.v[s] = (INIT && q == 0) ? w2 * tile.v[q][s] : out.v[s] + w2 * tile.v[q][s];
+    }
+    if constexpr (INIT) {
+#pragma unroll
+        for (int s = S; s < 8; s++) out.v[s] = f32x2{0.f, 0.f};
     }
 }
 
-template <typename T, int S, bool IMPLICIT, int MODE, int NT = 8>
+template <typename T, int S, bool IMPLICIT, int MODE, int NT = 8, bool INIT = false>
 __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&vrep)[S], T x, bool valid,
                                           PassAcc<T> &out, int lane, T g = T(1))
 {
     if constexpr (std::is_same<T, float>::value) {
-        tile_pass_f32<S, IMPLICIT, MODE, NT>(tile, vrep, x, valid, out, lane, g);
+        tile_pass_f32<S, IMPLICIT, MODE, NT, INIT>(tile, vrep, x, valid, out, lane, g);
     } else {
     T c[8];
 #pragma unroll
@@ -480,7 +486,11 @@ __device__ __forceinline__ void tile_pass(const RegTile<T, S> &tile, const T (&v
 #pragma unroll
     for (int t = 0; t < NT; t++) {
 #pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
+        for (int s = 0; s < S; s++) out.v[s] = (INIT && t == 0) ? wts[t] * tile.v[t][s] : out.v[s] + wts[t] * tile.v[t][s];
+    }
+    if constexpr (INIT) {
+#pragma unroll
+        for (int s = S; s < 8; s++) out.v[s] = T(0);
     }
     }
 }
@@ -579,7 +589,7 @@ cg_rows_kernel(const CgParams<T> P)
     T *red = G + (GRAM ? gram_elems<T>(S) : 0);                              // [RPB][2][W][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: what depends on it branches instead of masking lanes)
     const int grp = wave / W;      // which concurrent row of this workgroup
     const int wr = wave % W;       // wave index inside the row team
     const int k = P.k;
@@ -758,15 +768,19 @@ cg_rows_kernel(const CgParams<T> P)
             if constexpr (PV) pass_vector_lds<T, S, GR>(vdist, vrep, gw, lane, &s_pv[wave][0]);
             else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
-            acc.zero();
             if constexpr (NRES == 2) {
                 // both tiles of the wave are resident: the launch holds rows of at most 2 * W * 64 = 1024 entries (the host
                 // keeps the split-row boundary at or below that in single precision)
-                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x_res, valid_res, acc, lane, g_res);
+                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT, true>(tile, vrep, x_res, valid_res, acc, lane, g_res);
+                else acc.zero();
                 if (cnt1 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile2, vrep, x2_res, valid2_res, acc, lane, g2_res);
             } else if constexpr (NT < 8) {
-                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x_res, valid_res, acc, lane, g_res);
-            } else
+                // (the accumulators are defined by the tile pass itself: no clearing moves.  Teams of up to four wavefronts: a row of
+                //  this launch holds more than 32 W entries and its tile at least 40 per wavefront, so every wavefront has some)
+                if ((W <= 4 || cnt0 > 0) && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT, true>(tile, vrep, x_res, valid_res, acc, lane, g_res);
+                else acc.zero();
+            } else {
+            acc.zero();
             for (int tl = wr; tl < ntiles; tl += W) {
                 T x, g; bool valid;
                 const bool have = (tl == wr) && (resident || first);   // still in registers
@@ -784,6 +798,7 @@ cg_rows_kernel(const CgParams<T> P)
                     x = x_res; g = g_res; valid = valid_res;
                 }
                 if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x, valid, acc, lane, g);
+            }
             }
             if (GRAM && !CMF_DBG(P, 2)) {   // common.c:1932 / :1958; collective.c:2609-2643
                 if constexpr (PV) gram_pass_w<MODE == 0, T, S, W, GR>(G, gw, acc, lane, wr);
@@ -931,7 +946,7 @@ __device__ __forceinline__ T treduce4_low(const T (&v)[4], int lane)
 }
 
 // (TILE: a RegTile4, or a RegTile whose first four entries per lane group are used -- the mixed launch of the pair kernel)
-template <int S, bool IMPLICIT, int MODE, typename TILE>
+template <int S, bool IMPLICIT, int MODE, typename TILE, bool INIT = false>
 __device__ __forceinline__ void tile_pass4_f32(const TILE &tile, const float (&vrep)[S], float x, bool valid,
                                            PassAcc<float> &out, int lane, float g = 1.f)
 {
@@ -951,16 +966,20 @@ __device__ __forceinline__ void tile_pass4_f32(const TILE &tile, const float (&v
     for (int q = 0; q < 2; q++) {
         const f32x2 w2 = f32x2{wts[2 * q], wts[2 * q + 1]};
 #pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += w2 * tile.v[q][s];
+        for (int s = 0; s < S; s++) out.v[s] = (INIT && q == 0) ? w2 * tile.v[q][s] : out.v[s] + w2 * tile.v[q][s];
+    }
+    if constexpr (INIT) {
+#pragma unroll
+        for (int s = S; s < 8; s++) out.v[s] = f32x2{0.f, 0.f};
     }
 }
 
-template <typename T, int S, bool IMPLICIT, int MODE, typename TILE>
+template <typename T, int S, bool IMPLICIT, int MODE, typename TILE, bool INIT = false>
 __device__ __forceinline__ void tile_pass4(const TILE &tile, const T (&vrep)[S], T x, bool valid,
                                            PassAcc<T> &out, int lane, T g = T(1))
 {
     if constexpr (std::is_same<T, float>::value) {
-        tile_pass4_f32<S, IMPLICIT, MODE>(tile, vrep, x, valid, out, lane, g);
+        tile_pass4_f32<S, IMPLICIT, MODE, TILE, INIT>(tile, vrep, x, valid, out, lane, g);
     } else {
     T c[4];
 #pragma unroll
@@ -977,7 +996,11 @@ __device__ __forceinline__ void tile_pass4(const TILE &tile, const T (&vrep)[S],
 #pragma unroll
     for (int t = 0; t < 4; t++) {
 #pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += wts[t] * tile.v[t][s];
+        for (int s = 0; s < S; s++) out.v[s] = (INIT && t == 0) ? wts[t] * tile.v[t][s] : out.v[s] + wts[t] * tile.v[t][s];
+    }
+    if constexpr (INIT) {
+#pragma unroll
+        for (int s = S; s < 8; s++) out.v[s] = T(0);
     }
     }
 }
@@ -1028,7 +1051,7 @@ __device__ __forceinline__ T treduce2_low(const T (&v)[2], int lane)
     return u + lanes::xor1(u);          // lanes 4t .. 4t+3 hold the total of v[t]
 }
 
-template <typename T, int S, bool IMPLICIT, int MODE, typename TILE>
+template <typename T, int S, bool IMPLICIT, int MODE, typename TILE, bool INIT = false>
 __device__ __forceinline__ void tile_pass2(const TILE &tile, const T (&vrep)[S], T x, bool valid,
                                            PassAcc<T> &out, int lane, T g = T(1))
 {
@@ -1053,12 +1076,20 @@ __device__ __forceinline__ void tile_pass2(const TILE &tile, const T (&vrep)[S],
     if constexpr (std::is_same<T, float>::value) {
         const f32x2 w2 = f32x2{w0, w1};
 #pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += w2 * tile.pair0(s);
+        for (int s = 0; s < S; s++) out.v[s] = INIT ? w2 * tile.pair0(s) : out.v[s] + w2 * tile.pair0(s);
+        if constexpr (INIT) {
+#pragma unroll
+            for (int s = S; s < 8; s++) out.v[s] = f32x2{0.f, 0.f};
+        }
     } else {
 #pragma unroll
-        for (int s = 0; s < S; s++) out.v[s] += w0 * tile.get(0, s);
+        for (int s = 0; s < S; s++) out.v[s] = INIT ? w0 * tile.get(0, s) : out.v[s] + w0 * tile.get(0, s);
 #pragma unroll
         for (int s = 0; s < S; s++) out.v[s] += w1 * tile.get(1, s);
+        if constexpr (INIT) {
+#pragma unroll
+            for (int s = S; s < 8; s++) out.v[s] = T(0);
+        }
     }
 }
 
@@ -1239,11 +1270,10 @@ cg_rows_tiny_kernel(const CgParams<T> P)
             if constexpr (PV) pass_vector_lds<T, S, GR>(vdist, vrep, gw, lane, &s_pv[tid >> 6][0]);
             else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
-            acc.zero();
-            if (!CMF_DBG(P, 4)) {
-                if constexpr (!T2) tile_pass4<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
-                else tile_pass2<T, S, IMPLICIT, MODE>(tile, vrep, pr.x, valid, acc, lane, pr.g);
-            }
+            if (!CMF_DBG(P, 4)) {          // (the accumulators are defined by the tile pass itself: no clearing moves)
+                if constexpr (!T2) tile_pass4<T, S, IMPLICIT, MODE, decltype(tile), true>(tile, vrep, pr.x, valid, acc, lane, pr.g);
+                else tile_pass2<T, S, IMPLICIT, MODE, decltype(tile), true>(tile, vrep, pr.x, valid, acc, lane, pr.g);
+            } else acc.zero();
             if constexpr (GREG) {
                 if (!CMF_DBG(P, 2)) {
                     if constexpr (PV) gram_pass_regs_w<MODE == 0>(greg, gw, acc);

@@ -50,6 +50,7 @@ struct Switches {
     bool nt_split = true;           // CMFREC_HIP_NT_SPLIT=0: a double-precision length bin as one launch instead of two by tile size
     bool cg_generic = false;        // CMFREC_HIP_CG_KERNEL=generic: lane <-> unknown CG kernel everywhere
     int chol = 0;                   // CMFREC_HIP_CHOL: 1 = rows (workgroup-per-row kernel only), 2 = noslices
+    bool chol_wg = true;            // CMFREC_HIP_CHOL_WG=0: eight-block rows in double precision factorised by one wavefront per row (rounds 2-5) instead of a four-wavefront workgroup
     int gramk = -1;                 // CMFREC_HIP_GRAMK: 0 / 1 force the producer / consumer pair off / on (-1: by width)
     int gramk_batch = 0;            // CMFREC_HIP_GRAMK_BATCH: work items per batch (test hook: several batches on a small problem)
     int lowrank = -1;               // CMFREC_HIP_LOWRANK: 0 / 1 force the low-rank row kernel off / on (-1: by shape)
@@ -69,6 +70,7 @@ struct Switches {
         nt_split = num("CMFREC_HIP_NT_SPLIT", 1) != 0;
         v = str("CMFREC_HIP_CG_KERNEL"); cg_generic = v && strcmp(v, "generic") == 0;
         v = str("CMFREC_HIP_CHOL"); chol = !v ? 0 : strcmp(v, "rows") == 0 ? 1 : strcmp(v, "noslices") == 0 ? 2 : 0;
+        chol_wg = num("CMFREC_HIP_CHOL_WG", 1) != 0;
         gramk = num("CMFREC_HIP_GRAMK", -1);
         gramk_batch = num("CMFREC_HIP_GRAMK_BATCH", 0);
         lowrank = num("CMFREC_HIP_LOWRANK", -1);

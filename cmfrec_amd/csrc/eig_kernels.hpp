@@ -5,7 +5,7 @@
 // launch-bound: 6 ms on an idle device, 33 ms beside the persistent batches of the long rows -- profiles/r05/r05_zg_*), and the
 // one-workgroup Jacobi kernel (91 ms) as the fallback.  This file is the library's own decomposition in TWO launches:
 //
-//   eig_tridiag_kernel   one workgroup of 16 wavefronts: Householder tridiagonalisation  A = Q1 T Q1^T  (the scheme of LAPACK's
+//   eig_tridiag_kernel   one workgroup of 8 wavefronts: Householder tridiagonalisation  A = Q1 T Q1^T  (the scheme of LAPACK's
 //                        dsytd2, lower variant, on a full symmetric copy in double precision that stays in L2: per step one
 //                        matrix-vector product and one rank-2 update of the trailing square, three barriers).
 //   eig_ql_rows_kernel   ceil(n / 64) workgroups of one wavefront: every LANE owns one ROW of the eigenvector matrix (n doubles
@@ -29,14 +29,16 @@ constexpr int EIG_MAX_N = 320;
 
 // A [n, n] row-major symmetric (any precision T) -> W [n, n] doubles: the reflector of step i in W[i][i+2 ..] (v[0] = 1 implied at
 // column i + 1), the trailing squares as they were consumed; d [n], e [n] the tridiagonal matrix (e[i] couples i and i + 1), tau [n].
+constexpr int EIG_TRIDIAG_THREADS = 512;          // 8 wavefronts, two per SIMD: 256 registers each for the rows a trip keeps in flight
 template <typename T>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(EIG_TRIDIAG_THREADS)
 eig_tridiag_kernel(const T *__restrict__ A, int n, double *W, double *__restrict__ d, double *__restrict__ e, double *__restrict__ tau)
 {
     __shared__ double s_v[EIG_MAX_N], s_p[EIG_MAX_N];
     __shared__ double s_tau;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int x = tid; x < n * n; x += 1024) W[x] = (double)A[x];
+    constexpr int NQ = EIG_MAX_N / 64, RB = 12, NW = EIG_TRIDIAG_THREADS / 64;
+    for (int x = tid; x < n * n; x += EIG_TRIDIAG_THREADS) W[x] = (double)A[x];
     __syncthreads();
     for (int i = 0; i < n - 1; i++) {
         const int L = n - i - 1;                     // x = W[i][i+1 .. n-1], the part of row (= column) i beside the diagonal
@@ -72,24 +74,59 @@ eig_tridiag_kernel(const T *__restrict__ A, int n, double *W, double *__restrict
         __syncthreads();
         const double t = s_tau;
         if (t != 0.0) {                                 // (uniform over the workgroup)
-            for (int r = wave; r < L; r += 16) {        // p = t A22 v
-                const double *ar = W + (size_t)(i + 1 + r) * n + i + 1;
-                double acc = 0.0;
-                for (int c = lane; c < L; c += 64) acc += ar[c] * s_v[c];
-                acc = lanes::wave_sum(acc);
-                if (lane == 0) s_p[r] = t * acc;
+            // A wavefront takes the rows wave, wave + NW, ..; RB of them per trip with all their loads in flight before the first
+            // product (the matrix lives in L2: a trip is one memory latency, not RB of them)
+            double vv[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) { const int c = lane + 64 * q; vv[q] = (c < L) ? s_v[c] : 0.0; }
+            for (int r0 = wave; r0 < L; r0 += NW * RB) {        // p = t A22 v
+                double a[RB][NQ];
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const int r = r0 + NW * b;
+                    const double *ar = W + (size_t)(i + 1 + min(r, L - 1)) * n + i + 1;
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) { const int c = lane + 64 * q; a[b][q] = (r < L && c < L) ? ar[c] : 0.0; }
+                }
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acc = __builtin_fma(a[b][q], vv[q], acc);
+                    acc = lanes::wave_sum(acc);
+                    if (lane == 0 && r0 + NW * b < L) s_p[r0 + NW * b] = t * acc;
+                }
             }
             __syncthreads();
             double dot = 0.0;                           // w = p - (t / 2) (p . v) v ;  A22 -= v w^T + w v^T
-            for (int c = lane; c < L; c += 64) dot += s_p[c] * s_v[c];
+            double wc[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) { const int c = lane + 64 * q; wc[q] = (c < L) ? s_p[c] : 0.0; dot = __builtin_fma(wc[q], vv[q], dot); }
             dot = lanes::wave_sum(dot);
             const double a2 = -0.5 * t * dot;
-            for (int r = wave; r < L; r += 16) {
-                double *ar = W + (size_t)(i + 1 + r) * n + i + 1;
-                const double vr = s_v[r], wr = s_p[r] + a2 * vr;
-                for (int c = lane; c < L; c += 64) {
-                    const double vc = s_v[c], wc = s_p[c] + a2 * vc;
-                    ar[c] -= vr * wc + wr * vc;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) wc[q] = __builtin_fma(a2, vv[q], wc[q]);
+            for (int r0 = wave; r0 < L; r0 += NW * RB) {
+                double a[RB][NQ];
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const int r = r0 + NW * b;
+                    const double *ar = W + (size_t)(i + 1 + min(r, L - 1)) * n + i + 1;
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) { const int c = lane + 64 * q; a[b][q] = (r < L && c < L) ? ar[c] : 0.0; }
+                }
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const int r = r0 + NW * b;
+                    if (r < L) {
+                        double *ar = W + (size_t)(i + 1 + r) * n + i + 1;
+                        const double vr = s_v[r], wr = __builtin_fma(a2, vr, s_p[r]);
+#pragma unroll
+                        for (int q = 0; q < NQ; q++) {
+                            const int c = lane + 64 * q;
+                            if (c < L) ar[c] = a[b][q] - (vr * wc[q] + wr * vv[q]);
+                        }
+                    }
                 }
             }
         }
@@ -112,7 +149,7 @@ __device__ __forceinline__ void eig_sqrt_inv(double x, double &r, double &inv)
 
 // Q [n, ldq] row-major: Q[i][c] = component i of eigenvector c;  Qt its transpose;  lam [n] (clamped at zero: the matrix is
 // positive semi-definite up to rounding).  status[0] |= 1 when a QL iteration did not converge in 60 sweeps.
-// Dynamic LDS: (n ROWS + 2 n) doubles.
+// Dynamic LDS: (n ROWS + 4 n) doubles.
 template <typename T, int ROWS>
 __global__ void __launch_bounds__(64)
 eig_ql_rows_kernel(int n, const double *__restrict__ W, const double *__restrict__ d_in, const double *__restrict__ e_in,
@@ -123,6 +160,7 @@ eig_ql_rows_kernel(int n, const double *__restrict__ W, const double *__restrict
     double *Z = eig_sm;                     // [n][ROWS]: element c of the lane's row at Z[c ROWS + lane]
     double *d = Z + (size_t)n * ROWS;
     double *e = d + n;
+    double *sv = e + n;                     // [2][n]: the reflector of the step in hand (broadcast reads) and the next one
     const int lane = threadIdx.x;
     const int zl = (ROWS == 64) ? lane : (lane & (ROWS - 1));       // (ROWS = 32: the upper half-wavefront mirrors the lower one)
     const int r = blockIdx.x * ROWS + zl;
@@ -132,26 +170,47 @@ eig_ql_rows_kernel(int n, const double *__restrict__ W, const double *__restrict
     for (int c = lane; c < n; c += 64) { d[c] = d_in[c]; e[c] = e_in[c]; }
     __syncthreads();
     // ---- row r of Q1 = H(0) H(1) .. H(n-3): the unit row times the reflectors in order ----
-    for (int i = 0; i + 2 < n; i++) {
-        const double t = tau[i];
-        if (t == 0.0) continue;
-        const double *v = W + (size_t)i * n + i + 1;    // v[0] = 1 implied
+    // (the reflector of step i + 1 is on its way from L2 while step i is applied: two buffers in LDS)
+    constexpr int NQ = EIG_MAX_N / 64;
+    double vpre[NQ];
+    auto fetch = [&](int i) {
+        const double *v = W + (size_t)i * n + i + 1;
         const int L = n - i - 1;
-        double *z = Z + (size_t)(i + 1) * ROWS + zl;
-        double a0 = z[0], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int c = 1;
-        for (; c + 3 < L; c += 4) {
-            a0 = __builtin_fma(z[(size_t)c * ROWS], v[c], a0);
-            a1 = __builtin_fma(z[(size_t)(c + 1) * ROWS], v[c + 1], a1);
-            a2 = __builtin_fma(z[(size_t)(c + 2) * ROWS], v[c + 2], a2);
-            a3 = __builtin_fma(z[(size_t)(c + 3) * ROWS], v[c + 3], a3);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int c = 1 + lane + 64 * q; vpre[q] = (i + 2 < n && c < L) ? v[c] : 0.0; }
+    };
+    auto stash = [&](int i, double *buf) {
+        const int L = n - i - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { const int c = 1 + lane + 64 * q; if (c < L) buf[c] = vpre[q]; }
+    };
+    fetch(0);
+    stash(0, sv);
+    __syncthreads();
+    for (int i = 0; i + 2 < n; i++) {
+        const double *svi = sv + (size_t)(i & 1) * n;
+        fetch(i + 1);
+        const double t = tau[i];
+        if (t != 0.0) {                                 // (uniform)
+            const int L = n - i - 1;
+            double *z = Z + (size_t)(i + 1) * ROWS + zl;
+            double a0 = z[0], a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int c = 1;
+            for (; c + 3 < L; c += 4) {
+                a0 = __builtin_fma(z[(size_t)c * ROWS], svi[c], a0);
+                a1 = __builtin_fma(z[(size_t)(c + 1) * ROWS], svi[c + 1], a1);
+                a2 = __builtin_fma(z[(size_t)(c + 2) * ROWS], svi[c + 2], a2);
+                a3 = __builtin_fma(z[(size_t)(c + 3) * ROWS], svi[c + 3], a3);
+            }
+            for (; c < L; c++) a0 = __builtin_fma(z[(size_t)c * ROWS], svi[c], a0);
+            const double dot = t * ((a0 + a1) + (a2 + a3));
+            if (writer) {
+                z[0] -= dot;
+                for (c = 1; c < L; c++) z[(size_t)c * ROWS] = __builtin_fma(-dot, svi[c], z[(size_t)c * ROWS]);
+            }
         }
-        for (; c < L; c++) a0 = __builtin_fma(z[(size_t)c * ROWS], v[c], a0);
-        const double dot = t * ((a0 + a1) + (a2 + a3));
-        if (writer) {
-            z[0] -= dot;
-            for (c = 1; c < L; c++) z[(size_t)c * ROWS] = __builtin_fma(-dot, v[c], z[(size_t)c * ROWS]);
-        }
+        stash(i + 1, sv + (size_t)((i + 1) & 1) * n);
+        __syncthreads();
     }
     __syncthreads();
     // ---- implicit QL with shifts on (d, e), every rotation applied to the lane's row (EISPACK tql2) ----
@@ -182,30 +241,34 @@ eig_ql_rows_kernel(int n, const double *__restrict__ W, const double *__restrict
                 p = d[m];
                 double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
                 const double el1 = e[l + 1];
-                double e_i = e[m - 1], d_i = d[m - 1];
+                // Software pipeline: the operands of trip i - 1 (e, d and the row's element i - 1) are read from LDS at the top of
+                // trip i and waited for at its end, behind the ~12 dependent double-precision operations of the rotation; the
+                // stores are unconditional (every lane writes the same e / d: no exec-mask juggling in the loop).
                 double *zp = Z + zl;
+                double e_i = e[m - 1], d_i = d[m - 1], z_lo = zp[(size_t)(m - 1) * ROWS];
                 double z_hi = zp[(size_t)m * ROWS];          // element i + 1 of the row, carried from rotation to rotation
                 for (int i = m - 1; i >= l; i--) {
-                    const double e_n = (i > l) ? e[i - 1] : 0.0, d_n = (i > l) ? d[i - 1] : 0.0;     // the next trip's operands, early
-                    const double z_lo = zp[(size_t)i * ROWS];
+                    const int ip = max(i - 1, 0);            // (i == l: loaded and not used)
+                    const double e_n = e[ip], d_n = d[ip], z_n = zp[(size_t)ip * ROWS];
                     c3 = c2; c2 = c; s2 = s;
                     g = c * e_i;
                     const double h = c * p;
                     const double x = __builtin_fma(p, p, e_i * e_i);
-                    double rt = 0.0, inv = 0.0;
-                    if (x > 0.0) eig_sqrt_inv(x, rt, inv);
-                    const double e_out = s * rt;
-                    s = (x > 0.0) ? e_i * inv : 0.0;
+                    double rt, inv;
+                    eig_sqrt_inv((x > 0.0) ? x : 1.0, rt, inv);
+                    const double e_out = (x > 0.0) ? s * rt : 0.0;
+                    s = e_i * inv;                           // (x == 0: e_i == 0)
                     c = (x > 0.0) ? p * inv : 1.0;
                     p = __builtin_fma(c, d_i, -s * g);
                     const double d_out = __builtin_fma(s, __builtin_fma(c, g, s * d_i), h);
-                    if (lane == 0) { e[i + 1] = e_out; d[i + 1] = d_out; }
-                    if (writer) zp[(size_t)(i + 1) * ROWS] = __builtin_fma(s, z_lo, c * z_hi);
+                    e[i + 1] = e_out; d[i + 1] = d_out;
+                    const double z_new = __builtin_fma(s, z_lo, c * z_hi);
+                    if (ROWS == 64 || writer) zp[(size_t)(i + 1) * ROWS] = z_new;
                     z_hi = __builtin_fma(c, z_lo, -s * z_hi);
-                    e_i = e_n; d_i = d_n;
+                    e_i = e_n; d_i = d_n; z_lo = z_n;
                 }
                 if (writer) zp[(size_t)l * ROWS] = z_hi;
-                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                p = -s * s2 * c3 * el1 * el / dl1;
                 __syncthreads();
                 if (lane == 0) { e[l] = s * p; d[l] = c * p; }
                 __syncthreads();

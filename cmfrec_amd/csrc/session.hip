@@ -11,6 +11,7 @@
 #include "gramk_kernels.hpp"
 #include "lowrank_kernels.hpp"
 #include "eig_kernels.hpp"
+#include "chol_wg_kernels.hpp"
 #include "gram_cg_wide_kernels.hpp"
 #include <dlfcn.h>
 #include <functional>
@@ -197,6 +198,21 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                         const int grid = std::min(last - first, dev.num_cus * CMF_PARTS_WPS * 4 / NPQ);
                         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NPQ), 0, st, W, X->desc.ptr, SL);
                     }
+                }
+                else if (switches().chol_wg) {
+                    // Round 6: the factorisation by one workgroup of four wavefronts per row, the 36 tiles dealt to them (chol_wg_kernels.hpp;
+                    // two to three rows per CU in flight, no spills) instead of one wavefront per row and SIMD with 263 spilled registers.
+                    // CMFREC_HIP_CHOL_WG=0: the one-wavefront build below (A/B switch and on-device cross-check).
+                    poison_lds(st, dev.num_cus);
+                    auto kern = border ? chol_wg8_kernel<real_t, true> : chol_wg8_kernel<real_t, false>;
+                    static thread_local int bpc_dev[MAX_DEVICES][2] = {{0}};
+                    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)][border ? 1 : 0];
+                    if (blocks_per_cu == 0) {
+                        int nb2 = 0;
+                        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, kern, 256, 0));
+                        blocks_per_cu = std::max(1, nb2);
+                    }
+                    hipLaunchKernelGGL(kern, dim3(std::min(last - first, dev.num_cus * blocks_per_cu)), dim3(256), 0, st, W, X->desc.ptr, SL);
                 }
                 else wlaunch((border ? chol_wave_kernel<real_t, 8, true, 1, 1, 6, 2, true> : chol_wave_kernel<real_t, 8, false, 1, 1, 6, 2, true>), 8, 1);
 #endif
@@ -628,10 +644,10 @@ static void issue_eig(DeviceInfo &d, EigCache &E, const real_t *Minit, int kc, h
     if (!ql_bad && !switches().eig_jacobi && kc <= EIG_MAX_N) {
         E.D.alloc_at_least((size_t)kc); E.E.alloc_at_least((size_t)kc); E.Tau.alloc_at_least((size_t)kc);
         if (E.info.n < 1) { E.info.alloc(1); HIP_CHECK(hipMemsetAsync(E.info.ptr, 0, sizeof(int), d.eig_stream())); }
-        hipLaunchKernelGGL(eig_tridiag_kernel<real_t>, dim3(1), dim3(1024), 0, d.eig_stream(), Minit, kc, E.W.ptr, E.D.ptr, E.E.ptr, E.Tau.ptr);
+        hipLaunchKernelGGL(eig_tridiag_kernel<real_t>, dim3(1), dim3(EIG_TRIDIAG_THREADS), 0, d.eig_stream(), Minit, kc, E.W.ptr, E.D.ptr, E.E.ptr, E.Tau.ptr);
         const bool wide = kc > 288;                          // rows of the eigenvector matrix per workgroup: 64, or 32 (LDS: kc rows doubles)
         const int rows = wide ? 32 : 64;
-        const size_t smem = ((size_t)kc * rows + 2 * (size_t)kc) * sizeof(double);
+        const size_t smem = ((size_t)kc * rows + 4 * (size_t)kc) * sizeof(double);
         auto kern = wide ? eig_ql_rows_kernel<real_t, 32> : eig_ql_rows_kernel<real_t, 64>;
         static thread_local bool attr_set[MAX_DEVICES][2] = {{false}};
         bool &as = attr_set[std::min(std::max(d.device, 0), MAX_DEVICES - 1)][wide ? 1 : 0];
@@ -2781,7 +2797,7 @@ int cmfrec_hip_session_bin_overlaps(cmfrec_hip_session *s, int which, int bin)
 }
 
 // The most recent collective Cholesky half-step of the session: rows solved by the low-rank kernels (0: the path was not taken)
-// and the eigen-decomposition behind them (1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel)
+// and the eigen-decomposition behind them (3 tridiagonalisation + QL, 2 the one-workgroup Jacobi kernel)
 int cmfrec_hip_session_lowrank_info(cmfrec_hip_session *s, int *rows, int *eig)
 {
     if (rows) *rows = s->lr.last_rows;
@@ -2964,6 +2980,304 @@ int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B
         HIP_CHECK(hipStreamSynchronize(dev.stream));
         return 0;
     });
+}
+
+// ---- the reference's stand-alone entry points for the prediction matrices and the ranking, under their own names and with
+// ---- their own signatures (round 6; src/cmfrec.h:1922-1960, :2104-2127) ------------------------------------------------------
+// Host buffers in and out like the fit entry points.  The Gramians run on the library's MFMA kernels, the solves with many
+// right-hand sides on the row Cholesky kernel (CHOL_PREFILLED), the factorisation of the small block matrix on potrf_upper_kernel.
+// Like the reference (syrk / potrf with one triangle referenced, src/collective.c:10345-10470) the symmetric outputs carry their
+// UPPER triangle (row-major), the strictly lower part is zero.
+static void zero_strictly_lower(real_t *M, int n)
+{
+    if (M == nullptr) return;
+    for (int i = 1; i < n; i++) for (int j = 0; j < i; j++) M[(size_t)i * n + j] = 0;
+}
+// out[kd, kd] = scale * X[:, :kd]^T X[:, :kd] over `rows` rows (X on the host, leading dimension ldx, first used column at X)
+static void host_gram(const DeviceInfo &dev, GramWorkspace &gws, const real_t *X, size_t ldx, int rows, int kd, real_t scale, DevBuf<real_t> &dX,
+                      DevBuf<real_t> &out)
+{
+    dX.upload(X, (size_t)rows * ldx, dev.stream);
+    out.alloc_at_least((size_t)kd * kd);
+    launch_gram(dev, gws, dX.ptr, ldx, rows, kd, out.ptr, scale, (real_t)0);
+}
+
+int_t precompute_collective_implicit(
+    real_t *B, int_t n, real_t *C, int_t p, real_t *U_colmeans, bool NA_as_zero_U,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t w_main, real_t w_user, real_t w_main_multiplier,
+    bool nonneg, bool extra_precision,
+    real_t *BtB, real_t *BeTBe, real_t *BeTBeChol, real_t *CtUbias)
+{
+    (void)extra_precision;                                  // (the two summation orders of the reference; one here)
+    return guarded([&]() {
+        if (B == nullptr || BtB == nullptr || n <= 0 || k + k_main <= 0) { g_last_error = "precompute_collective_implicit: B, BtB and n > 0 are required"; return 2; }
+        if (p > 0 && (C == nullptr || BeTBe == nullptr)) { g_last_error = "precompute_collective_implicit: p > 0 needs C and BeTBe"; return 2; }
+        if (w_main_multiplier != (real_t)1) w_main *= w_main_multiplier;       // collective.c:10501-10507
+        if (w_main != (real_t)1) { lam /= w_main; w_user /= w_main; }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        GramWorkspace gws;
+        hipStream_t st = dev.stream;
+        const int kk = k + k_main, ktB = k_item + kk, kc = k_user + k, kq = k_user + kk;
+        DevBuf<real_t> dB, dC, G, CtC, M;
+        dB.upload(B, (size_t)n * ktB, st);
+        G.alloc((size_t)kk * kk);
+        launch_gram(dev, gws, dB.ptr + k_item, (size_t)ktB, n, kk, G.ptr, (real_t)1, lam);      // B^T B + lam I (:10509-10515)
+        G.download(BtB, (size_t)kk * kk, st);
+        if (p > 0) {
+            host_gram(dev, gws, C, (size_t)kc, p, kc, w_user, dC, CtC);                            // w C^T C (:10523-10543)
+            M.alloc((size_t)kq * kq);
+            HIP_CHECK(hipMemsetAsync(M.ptr, 0, (size_t)kq * kq * sizeof(real_t), st));
+            hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kk * kk), dim3(256), 0, st, G.ptr, kk, (real_t)1, M.ptr, kq, k_user);
+            hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, (real_t)1, M.ptr, kq, 0);
+            if (k_user) hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(k_user), dim3(256), 0, st, M.ptr, kq, 0, k_user, lam);   // :10545-10546
+            M.download(BeTBe, (size_t)kq * kq, st);
+            if (BeTBeChol != nullptr && !nonneg) {                                                 // :10548-10555
+                hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, st, M.ptr, kq);
+                M.download(BeTBeChol, (size_t)kq * kq, st);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+        zero_strictly_lower(BtB, kk);
+        if (p > 0) {
+            zero_strictly_lower(BeTBe, kq);
+            if (BeTBeChol != nullptr && !nonneg) zero_strictly_lower(BeTBeChol, kq);
+            if (C != nullptr && CtUbias != nullptr && U_colmeans != nullptr && NA_as_zero_U)       // :10557-10564
+                for (int f = 0; f < kc; f++) {
+                    double acc = 0;
+                    for (int_t j = 0; j < p; j++) acc += (double)C[(size_t)j * kc + f] * (double)U_colmeans[j];
+                    CtUbias[f] = (real_t)(-(double)w_user * acc);
+                }
+        }
+        return 0;
+    });
+}
+
+int_t precompute_collective_explicit(
+    real_t *B, int_t n, int_t n_max, bool include_all_X,
+    real_t *C, int_t p,
+    real_t *Bi, bool add_implicit_features,
+    real_t *biasB, real_t glob_mean, bool NA_as_zero_X,
+    real_t *U_colmeans, bool NA_as_zero_U,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    bool user_bias,
+    bool nonneg,
+    real_t lam, real_t *lam_unique,
+    bool scale_lam, bool scale_lam_sideinfo,
+    bool scale_bias_const, real_t scaling_biasA,
+    real_t w_main, real_t w_user, real_t w_implicit,
+    real_t *B_plus_bias,
+    real_t *BtB, real_t *TransBtBinvBt, real_t *BtXbias, real_t *BeTBeChol, real_t *BiTBi,
+    real_t *TransCtCinvCt, real_t *CtCw, real_t *CtUbias)
+{
+    return guarded([&]() {
+        if (B == nullptr || n <= 0) { g_last_error = "precompute_collective_explicit: B and n > 0 are required"; return 2; }
+        if (user_bias && B_plus_bias == nullptr) { g_last_error = "precompute_collective_explicit: user_bias needs the B_plus_bias buffer"; return 2; }
+        if ((TransBtBinvBt != nullptr || BeTBeChol != nullptr || (Bi != nullptr && add_implicit_features)) && BtB == nullptr) {
+            g_last_error = "precompute_collective_explicit: the matrices derived from BtB need the BtB buffer";
+            return 2;
+        }
+        if (n_max == 0) n_max = n;                                                 // collective.c:10240-10241
+        if (include_all_X) n = n_max;
+        const int k_main_i = k_main;
+        real_t lam_last = lam;
+        if (lam_unique != nullptr) { lam_last = lam_unique[user_bias ? 0 : 2]; lam = lam_unique[2]; }    // :10245-10249
+        if (w_main != (real_t)1) { lam /= w_main; lam_last /= w_main; w_user /= w_main; w_implicit /= w_main; }
+        real_t lam_B = lam, lam_last_B = lam_last, lam_C = lam;
+        if (scale_lam || scale_lam_sideinfo) {                                      // :10263-10277
+            const real_t multiplier = (real_t)(n + (scale_lam_sideinfo ? p : 0));
+            lam *= multiplier;
+            lam_C *= (real_t)p;
+            lam_last *= scale_bias_const ? scaling_biasA : multiplier;
+            lam_B = lam; lam_last_B = lam_last;
+        }
+        const int ktB0 = k_item + k + k_main;
+        const real_t *Bh = B;
+        if (user_bias) {                                                            // append_ones_last_col, :10279-10300
+            for (int_t c = 0; c < n_max; c++) {
+                memcpy(B_plus_bias + (size_t)c * (ktB0 + 1), B + (size_t)c * ktB0, (size_t)ktB0 * sizeof(real_t));
+                B_plus_bias[(size_t)c * (ktB0 + 1) + ktB0] = 1;
+            }
+            k_main++;
+            Bh = B_plus_bias;
+        }
+        const int kk = k + k_main, ktB = k_item + kk, kc = k_user + k, kq = k_user + kk, kki = k + k_main_i;
+        if (NA_as_zero_X && BtXbias != nullptr) {                                   // :10302-10342
+            std::vector<double> acc((size_t)kk, 0.);
+            if (n_max > n && glob_mean != (real_t)0)
+                for (int_t c = n; c < n_max; c++) for (int f = 0; f < kk; f++) acc[f] -= (double)glob_mean * (double)Bh[(size_t)c * ktB + k_item + f];
+            if (biasB != nullptr || glob_mean != (real_t)0)
+                for (int_t c = 0; c < n; c++) {
+                    const double coef = -((biasB != nullptr ? (double)biasB[c] : 0.) + (double)glob_mean);
+                    for (int f = 0; f < kk; f++) acc[f] += coef * (double)Bh[(size_t)c * ktB + k_item + f];
+                }
+            for (int f = 0; f < kk; f++) BtXbias[f] = (real_t)acc[f];
+        }
+        DeviceInfo dev;
+        init_device(dev, -1);
+        GramWorkspace gws;
+        hipStream_t st = dev.stream;
+        DevBuf<real_t> dB, dBi, dC, G, Gi, CtC, M, Bp, Cc;
+        if (BtB != nullptr) {                                                       // :10344-10351
+            dB.upload(Bh, (size_t)n_max * ktB, st);
+            G.alloc((size_t)kk * kk);
+            launch_gram(dev, gws, dB.ptr + k_item, (size_t)ktB, n, kk, G.ptr, (real_t)1, (real_t)0);
+            G.download(BtB, (size_t)kk * kk, st);
+        }
+        const bool with_bi = Bi != nullptr && add_implicit_features;
+        if (with_bi) {                                                              // :10353-10360
+            if (BiTBi == nullptr) { g_last_error = "precompute_collective_explicit: add_implicit_features needs the BiTBi buffer"; return 2; }
+            host_gram(dev, gws, Bi, (size_t)kki, n, kki, w_implicit, dBi, Gi);
+            Gi.download(BiTBi, (size_t)kki * kki, st);
+        }
+        if (TransBtBinvBt != nullptr && !nonneg && !add_implicit_features) {        // :10362-10386
+            M.alloc((size_t)kk * kk); Bp.alloc((size_t)n * kk);
+            HIP_CHECK(hipMemcpyAsync(M.ptr, G.ptr, (size_t)kk * kk * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kk), dim3(256), 0, st, M.ptr, kk, 0, kk - 1, lam_B);
+            hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(1), dim3(256), 0, st, M.ptr, kk, kk - 1, kk, lam_last_B);
+            hipLaunchKernelGGL(copy_mat_kernel<real_t>, grid1d((size_t)n * kk), dim3(256), 0, st, dB.ptr + k_item, (size_t)ktB, Bp.ptr, (size_t)kk, (size_t)n, kk);
+            CholCall c{Bp.ptr, (size_t)kk, nullptr, 0, kk, 0, nullptr, M.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+            const int rc = launch_chol(dev, c, nullptr, n);
+            if (rc) return rc;
+            Bp.download(TransBtBinvBt, (size_t)n * kk, st);
+        }
+        const bool with_c = p > 0 && C != nullptr;
+        if (with_c && CtCw != nullptr) {                                            // :10388-10421
+            host_gram(dev, gws, C, (size_t)kc, p, kc, (real_t)1, dC, CtC);
+            if (TransCtCinvCt != nullptr && !add_implicit_features && !nonneg) {
+                M.alloc((size_t)kc * kc); Cc.alloc((size_t)p * kc);
+                HIP_CHECK(hipMemcpyAsync(M.ptr, CtC.ptr, (size_t)kc * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+                HIP_CHECK(hipMemcpyAsync(Cc.ptr, dC.ptr, (size_t)p * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kc), dim3(256), 0, st, M.ptr, kc, 0, kc, lam_C / w_user);
+                CholCall c{Cc.ptr, (size_t)kc, nullptr, 0, kc, 0, nullptr, M.ptr, 0, 0, 0, 0, 0, false, false, false, CHOL_PREFILLED};
+                const int rc = launch_chol(dev, c, nullptr, p);
+                if (rc) return rc;
+                Cc.download(TransCtCinvCt, (size_t)p * kc, st);
+            }
+            if (w_user != (real_t)1) {                                              // :10419-10420 (in place, stays on the device for the block matrix)
+                DevBuf<real_t> T1;
+                T1.alloc((size_t)kc * kc);
+                HIP_CHECK(hipMemsetAsync(T1.ptr, 0, (size_t)kc * kc * sizeof(real_t), st));
+                hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, w_user, T1.ptr, kc, 0);
+                HIP_CHECK(hipMemcpyAsync(CtC.ptr, T1.ptr, (size_t)kc * kc * sizeof(real_t), hipMemcpyDeviceToDevice, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+            }
+            CtC.download(CtCw, (size_t)kc * kc, st);
+        }
+        if (BeTBeChol != nullptr && (C != nullptr || add_implicit_features) && !nonneg) {      // :10423-10461
+            M.alloc((size_t)kq * kq);
+            HIP_CHECK(hipMemsetAsync(M.ptr, 0, (size_t)kq * kq * sizeof(real_t), st));
+            hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kk * kk), dim3(256), 0, st, G.ptr, kk, (real_t)1, M.ptr, kq, k_user);
+            if (with_c && CtCw != nullptr)
+                hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, (real_t)1, M.ptr, kq, 0);
+            else if (with_c) {
+                host_gram(dev, gws, C, (size_t)kc, p, kc, w_user, dC, CtC);
+                hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kc * kc), dim3(256), 0, st, CtC.ptr, kc, (real_t)1, M.ptr, kq, 0);
+            }
+            if (with_bi) hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kki * kki), dim3(256), 0, st, Gi.ptr, kki, (real_t)1, M.ptr, kq, k_user);
+            hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(kq), dim3(256), 0, st, M.ptr, kq, 0, kq - 1, lam);           // add_to_diag2
+            hipLaunchKernelGGL(add_diag_kernel<real_t>, grid1d(1), dim3(256), 0, st, M.ptr, kq, kq - 1, kq, lam_last);
+            hipLaunchKernelGGL(potrf_upper_kernel<real_t>, dim3(1), dim3(256), 0, st, M.ptr, kq);
+            M.download(BeTBeChol, (size_t)kq * kq, st);
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(st));
+        zero_strictly_lower(BtB, kk);
+        if (with_bi) zero_strictly_lower(BiTBi, kki);
+        if (with_c && CtCw != nullptr) zero_strictly_lower(CtCw, kc);
+        if (BeTBeChol != nullptr && (C != nullptr || add_implicit_features) && !nonneg) zero_strictly_lower(BeTBeChol, kq);
+        if (C != nullptr && CtUbias != nullptr && p > 0 && U_colmeans != nullptr && NA_as_zero_U)      // :10463-10470
+            for (int f = 0; f < kc; f++) {
+                double acc = 0;
+                for (int_t j = 0; j < p; j++) acc += (double)C[(size_t)j * kc + f] * (double)U_colmeans[j];
+                CtUbias[f] = (real_t)(-(double)w_user * acc);
+            }
+        return 0;
+    });
+}
+
+// topN (src/common.c:5127-5380) for one user: scores of the candidate items on the device (one thread per item), a stable radix
+// sort by descending score (rocPRIM; ties: the earlier candidate, i.e. the lower item id without an include list), the first n_top.
+static int topn_one_user(const real_t *a_vec, int_t k_user, const real_t *B, int_t k_item, const real_t *biasB, real_t glob_mean, real_t biasA,
+                         int_t k, int_t k_main, int_t *include_ix, int_t n_include, int_t *exclude_ix, int_t n_exclude, int_t *outp_ix,
+                         real_t *outp_score, int_t n_top, int_t n)
+{
+    auto bad = [&](const char *msg) { g_last_error = msg; fprintf(stderr, "%s\n", msg); return 2; };
+    if (a_vec == nullptr || B == nullptr || outp_ix == nullptr) return bad("topN: a_vec, B and outp_ix are required");
+    if (include_ix != nullptr && exclude_ix != nullptr) return bad("Cannot pass both 'include_ix' and 'exclude_ix'.");
+    if (n_top <= 0) return bad("'n_top' must be greater than zero.");
+    if (exclude_ix != nullptr && n_exclude > n - n_top) return bad("Number of rankeable entities is less than 'n_top'");
+    if (include_ix != nullptr && n_include > n) return bad("Number of entities to include is larger than 'n'.");
+    if (include_ix != nullptr) for (int_t i = 0; i < n_include; i++) if (include_ix[i] < 0 || include_ix[i] >= n) return bad("'include_ix' contains invalid entries");
+    if (exclude_ix != nullptr) for (int_t i = 0; i < n_exclude; i++) if (exclude_ix[i] < 0 || exclude_ix[i] >= n) return bad("'exclude_ix' contains invalid entries");
+    for (int_t f = 0; f < k_user + k + k_main; f++) if (std::isnan((double)a_vec[f])) return bad("The latent factors contain NAN values");
+    if (std::isnan((double)biasA)) return bad("The bias is a NAN value");
+    const int k_pred = k + k_main, ktB = k_item + k + k_main;
+    std::vector<int> cand;
+    if (include_ix != nullptr) cand.assign(include_ix, include_ix + n_include);
+    else {
+        std::vector<char> out((size_t)n, 0);
+        if (exclude_ix != nullptr) for (int_t i = 0; i < n_exclude; i++) out[(size_t)exclude_ix[i]] = 1;
+        cand.reserve((size_t)n);
+        for (int_t i = 0; i < n; i++) if (!out[(size_t)i]) cand.push_back((int)i);
+    }
+    const int ncand = (int)cand.size();
+    if (ncand < n_top) return bad("Number of rankeable entities is less than 'n_top'");
+    DeviceInfo dev;
+    init_device(dev, -1);
+    hipStream_t st = dev.stream;
+    DevBuf<real_t> da, dB, dbias, sc_in, sc_out;
+    DevBuf<int> id_in, id_out;
+    DevBuf<unsigned char> tmp;
+    da.upload(a_vec + k_user, (size_t)k_pred, st);
+    dB.upload(B, (size_t)n * ktB, st);
+    if (biasB != nullptr) dbias.upload(biasB, (size_t)n, st);
+    id_in.upload(cand.data(), (size_t)ncand, st);
+    sc_in.alloc((size_t)ncand); sc_out.alloc((size_t)ncand); id_out.alloc((size_t)ncand);
+    hipLaunchKernelGGL(topn_one_user_scores_kernel<real_t>, grid1d((size_t)ncand), dim3(256), 0, st, da.ptr, k_pred, dB.ptr + k_item, (size_t)ktB,
+                       biasB != nullptr ? dbias.ptr : nullptr, id_in.ptr, ncand, sc_in.ptr);
+    HIP_CHECK(hipGetLastError());
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, bytes, sc_in.ptr, sc_out.ptr, id_in.ptr, id_out.ptr, (size_t)ncand, 0, 8 * sizeof(real_t), st));
+    tmp.alloc(std::max<size_t>(bytes, 1));
+    HIP_CHECK(rocprim::radix_sort_pairs_desc(tmp.ptr, bytes, sc_in.ptr, sc_out.ptr, id_in.ptr, id_out.ptr, (size_t)ncand, 0, 8 * sizeof(real_t), st));
+    std::vector<real_t> hs((size_t)n_top);
+    std::vector<int> hi((size_t)n_top);
+    id_out.download(hi.data(), (size_t)n_top, st);
+    sc_out.download(hs.data(), (size_t)n_top, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    for (int_t i = 0; i < n_top; i++) {
+        outp_ix[i] = hi[(size_t)i];
+        if (outp_score != nullptr) outp_score[i] = hs[(size_t)i] + (glob_mean + biasA);          // common.c:5349-5358
+    }
+    return 0;
+}
+
+int_t topN_old_collective_explicit(
+    real_t *a_vec, real_t a_bias, real_t *A, real_t *biasA, int_t row_index, real_t *B, real_t *biasB, real_t glob_mean,
+    int_t k, int_t k_user, int_t k_item, int_t k_main, int_t *include_ix, int_t n_include, int_t *exclude_ix, int_t n_exclude,
+    int_t *outp_ix, real_t *outp_score, int_t n_top, int_t n, int_t n_max, bool include_all_X, int nthreads)
+{
+    (void)nthreads;
+    return guarded([&]() {
+        if (include_all_X || n == 0) n = n_max;                                                   // collective.c:11560-11561
+        if (a_vec != nullptr)
+            return topn_one_user(a_vec, k_user, B, k_item, biasB, glob_mean, a_bias, k, k_main, include_ix, n_include, exclude_ix, n_exclude, outp_ix, outp_score, n_top, n);
+        if (A == nullptr) { g_last_error = "topN_old_collective_explicit: a_vec or A is required"; return 2; }
+        return topn_one_user(A + (size_t)row_index * (size_t)(k_user + k + k_main), k_user, B, k_item, biasB, glob_mean,
+                             biasA == nullptr ? (real_t)0 : biasA[row_index], k, k_main, include_ix, n_include, exclude_ix, n_exclude, outp_ix,
+                             outp_score, n_top, n);
+    });
+}
+
+int_t topN_old_collective_implicit(
+    real_t *a_vec, real_t *A, int_t row_index, real_t *B, int_t k, int_t k_user, int_t k_item, int_t k_main,
+    int_t *include_ix, int_t n_include, int_t *exclude_ix, int_t n_exclude, int_t *outp_ix, real_t *outp_score, int_t n_top, int_t n, int nthreads)
+{
+    return topN_old_collective_explicit(a_vec, (real_t)0, A, nullptr, row_index, B, nullptr, (real_t)0, k, k_user, k_item, k_main, include_ix, n_include,
+                                        exclude_ix, n_exclude, outp_ix, outp_score, n_top, n, n, false, nthreads);
 }
 
 int cmfrec_hip_optimizeA_collective(real_t *A, size_t lda, const real_t *B, size_t ldb, const real_t *C, int_t m,
@@ -3455,15 +3769,16 @@ extern "C" int cmfrec_hip_sym_eig(int n, const real_t *A, real_t *Q, real_t *lam
         HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
         const bool wide = n > 288;
         const int rows = wide ? 32 : 64;
-        const size_t smem = ((size_t)n * rows + 2 * (size_t)n) * sizeof(double);
+        const size_t smem = ((size_t)n * rows + 4 * (size_t)n) * sizeof(double);
         auto kern = wide ? eig_ql_rows_kernel<real_t, 32> : eig_ql_rows_kernel<real_t, 64>;
         HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         for (int r = 0; r < std::max(reps, 1) + 1; r++) {
             if (r == 1) HIP_CHECK(hipEventRecord(e0, dev.stream));
-            if (method == 0) {
-                hipLaunchKernelGGL(eig_tridiag_kernel<real_t>, dim3(1), dim3(1024), 0, dev.stream, dA.ptr, n, W.ptr, D.ptr, E.ptr, Tau.ptr);
-                hipLaunchKernelGGL(kern, dim3((n + rows - 1) / rows), dim3(64), smem, dev.stream, n, W.ptr, D.ptr, E.ptr, Tau.ptr, dQ.ptr, dQt.ptr,
-                                   (size_t)n, dL.ptr, info.ptr);
+            if (method == 0 || method == 2) {        // (2: only the tridiagonalisation inside the timed runs -- where the time goes)
+                hipLaunchKernelGGL(eig_tridiag_kernel<real_t>, dim3(1), dim3(EIG_TRIDIAG_THREADS), 0, dev.stream, dA.ptr, n, W.ptr, D.ptr, E.ptr, Tau.ptr);
+                if (method == 0 || r == 0)
+                    hipLaunchKernelGGL(kern, dim3((n + rows - 1) / rows), dim3(64), smem, dev.stream, n, W.ptr, D.ptr, E.ptr, Tau.ptr, dQ.ptr, dQt.ptr,
+                                       (size_t)n, dL.ptr, info.ptr);
             } else
                 hipLaunchKernelGGL(jacobi_eig_kernel<real_t>, dim3(1), dim3(1024), 0, dev.stream, dA.ptr, n, W.ptr, V.ptr, dQ.ptr, dQt.ptr, (size_t)n,
                                    dL.ptr, 30, sizeof(real_t) == 4 ? 1e-9 : 1e-13);

@@ -137,4 +137,18 @@ topn_kernel(const TopnParams<T> P)
     }
 }
 
+// scores of ONE user over a list of candidate items (the reference's per-user topN under its own name, session.hip topn_one_user)
+template <typename T>
+__global__ void topn_one_user_scores_kernel(const T *__restrict__ a, int k, const T *__restrict__ B, size_t ldb, const T *__restrict__ biasB,
+                                            const int *__restrict__ ids, int ncand, T *__restrict__ score)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ncand) return;
+    const int item = ids[e];
+    const T *b = B + (size_t)item * ldb;
+    T s = T(0);
+    for (int f = 0; f < k; f++) s += a[f] * b[f];
+    score[e] = s + (biasB != nullptr ? biasB[item] : T(0));
+}
+
 }  // namespace cmfhip

@@ -268,7 +268,7 @@ class AlsSession:
 
     def lowrank_info(self):
         """(rows, eig) of the most recent collective Cholesky half-step: rows solved by the low-rank kernels (0: path not taken),
-        eigen-decomposition 1 = rocSOLVER dsyevd, 2 = built-in Jacobi kernel."""
+        eigen-decomposition 3 = tridiagonalisation + QL (eig_kernels.hpp), 2 = one-workgroup Jacobi kernel."""
         rows, eig = C.c_int(0), C.c_int(0)
         self.lib.cmfrec_hip_session_lowrank_info(self.handle, C.byref(rows), C.byref(eig))
         return int(rows.value), int(eig.value)

@@ -521,7 +521,7 @@ int cmfrec_hip_session_vh_mode(cmfrec_hip_session *s, int which);
    the split rows go through their own Gramian) */
 int cmfrec_hip_session_vh_min(cmfrec_hip_session *s, int which);
 /* the most recent collective Cholesky half-step: rows solved by the low-rank kernels (0: path not taken) and the
-   eigen-decomposition behind them (1 rocSOLVER dsyevd, 2 the built-in Jacobi kernel; CMFREC_HIP_EIG=jacobi forces 2) */
+   eigen-decomposition behind them (3 tridiagonalisation + implicit QL, 2 the one-workgroup Jacobi kernel; CMFREC_HIP_EIG=jacobi forces 2) */
 int cmfrec_hip_session_lowrank_info(cmfrec_hip_session *s, int *rows, int *eig);
 void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 
@@ -534,6 +534,73 @@ void cmfrec_hip_session_reset_timers(cmfrec_hip_session *s);
 int cmfrec_hip_topN_batch(const real_t *A, size_t lda, int_t nu, const real_t *B, size_t ldb, int_t n, int_t k,
                           const real_t *biasB, const size_t excl_p[], const int_t excl_i[], int_t n_top,
                           int_t *out_ids, real_t *out_scores);
+
+/* Replace precompute_collective_explicit / precompute_collective_implicit, /root/reference/src/cmfrec.h:1922-1960 (bodies
+ * src/collective.c:10209-10485, :10487-10566): the matrices the prediction functions reuse, from factors the caller holds -- the
+ * same positional parameters, the same return codes.  Host buffers in and out; the Gramians run on the library's MFMA kernels,
+ * the solves with many right-hand sides (TransBtBinvBt, TransCtCinvCt) on the row Cholesky kernel, BeTBeChol on the small
+ * factorisation kernel.  As in the reference the symmetric outputs carry their upper triangle (row-major), the strictly lower
+ * part is zero.  extra_precision (the reference's second summation order) is accepted and ignored. */
+int_t precompute_collective_explicit(
+    real_t *B, int_t n, int_t n_max, bool include_all_X,
+    real_t *C, int_t p,
+    real_t *Bi, bool add_implicit_features,
+    real_t *biasB, real_t glob_mean, bool NA_as_zero_X,
+    real_t *U_colmeans, bool NA_as_zero_U,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    bool user_bias,
+    bool nonneg,
+    real_t lam, real_t *lam_unique,
+    bool scale_lam, bool scale_lam_sideinfo,
+    bool scale_bias_const, real_t scaling_biasA,
+    real_t w_main, real_t w_user, real_t w_implicit,
+    real_t *B_plus_bias,
+    real_t *BtB,
+    real_t *TransBtBinvBt,
+    real_t *BtXbias,
+    real_t *BeTBeChol,
+    real_t *BiTBi,
+    real_t *TransCtCinvCt,
+    real_t *CtCw,
+    real_t *CtUbias);
+int_t precompute_collective_implicit(
+    real_t *B, int_t n,
+    real_t *C, int_t p,
+    real_t *U_colmeans, bool NA_as_zero_U,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    real_t lam, real_t w_main, real_t w_user, real_t w_main_multiplier,
+    bool nonneg,
+    bool extra_precision,
+    real_t *BtB,
+    real_t *BeTBe,
+    real_t *BeTBeChol,
+    real_t *CtUbias);
+
+/* Replace topN_old_collective_explicit / topN_old_collective_implicit, /root/reference/src/cmfrec.h:2104-2127 (bodies
+ * src/collective.c:11546-11613 over topN, src/common.c:5127-5380): the n_top best items of ONE user whose factors exist, with an
+ * include list or an exclude list, scores (+ glob_mean + the user's bias) on request.  Same argument checks and return codes.
+ * Scores of the candidates on the device, a stable descending radix sort; ties go to the earlier candidate (the lower item id
+ * without an include list) where the reference's qsort leaves their order open.  Many users at once: cmfrec_hip_topN_batch. */
+int_t topN_old_collective_explicit(
+    real_t *a_vec, real_t a_bias,
+    real_t *A, real_t *biasA, int_t row_index,
+    real_t *B,
+    real_t *biasB,
+    real_t glob_mean,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    int_t *include_ix, int_t n_include,
+    int_t *exclude_ix, int_t n_exclude,
+    int_t *outp_ix, real_t *outp_score,
+    int_t n_top, int_t n, int_t n_max, bool include_all_X, int nthreads);
+int_t topN_old_collective_implicit(
+    real_t *a_vec,
+    real_t *A, int_t row_index,
+    real_t *B,
+    int_t k, int_t k_user, int_t k_item, int_t k_main,
+    int_t *include_ix, int_t n_include,
+    int_t *exclude_ix, int_t n_exclude,
+    int_t *outp_ix, real_t *outp_score,
+    int_t n_top, int_t n, int nthreads);
 
 /* Runs the on-device self-test of the cross-lane primitives (DPP / permlane swaps) the row kernels
  * are built on; returns the number of mismatching lanes (0 = ok), negative = HIP failure. */

@@ -360,6 +360,25 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g28_na_as_zero_weighted_sideinfo_" + tag, **out)
 
+        # ---- G29: the stand-alone prediction matrices (precompute_collective_explicit / _implicit) ----
+        out = {}
+        d = gc.precompute_problem(dt)
+        for ci, (name, opts) in enumerate(gc.PRECOMPUTE_EXPLICIT_CASES):
+            for key, v in gc.precompute_explicit_call(R.lib, d, opts, dt).items():
+                out["e%d_%s" % (ci, key)] = v
+        for ci, (name, opts) in enumerate(gc.PRECOMPUTE_IMPLICIT_CASES):
+            for key, v in gc.precompute_implicit_call(R.lib, d, opts, dt).items():
+                out["i%d_%s" % (ci, key)] = v
+        save("g29_precompute_standalone_" + tag, **out)
+
+        # ---- G30: the per-user ranking under the reference's names (topN_old_collective_explicit / _implicit) ----
+        out = {}
+        d = gc.topn_problem(dt)
+        for ci, (name, opts) in enumerate(gc.TOPN_CASES):
+            for key, v in gc.topn_call(R.lib, d, opts, dt).items():
+                out["c%d_%s" % (ci, key)] = v
+        save("g30_topn_old_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

@@ -1649,3 +1649,176 @@ def dense_hip(d, opts, dtype, as_sparse=False):
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     return out
+
+
+# ---- the reference's stand-alone prediction matrices and per-user ranking under their own names (round 6; fixtures g29 / g30):
+# ---- precompute_collective_explicit / _implicit (src/collective.c:10209-10566), topN_old_collective_explicit / _implicit
+# ---- (:11546-11613 over topN, src/common.c:5127-5380).  One marshalling for either shared object -- the product's
+# ---- (cmfrec_amd._lib.load) or the compiled reference's (oracle.bindings.Reference(dtype).lib): same C signature.
+import ctypes as _C
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_C.c_void_p)
+
+
+def _real(dt):
+    return _C.c_double if dt is np.float64 else _C.c_float
+
+
+def precompute_problem(dtype):
+    rng = np.random.default_rng(2906)
+    n, n_max, k, p = 140, 150, 6, 9
+    return dict(n=n, n_max=n_max, k=k, p=p, rng_seed=2906,
+                glob_mean=dtype(0.37), biasB=(rng.standard_normal(n_max) * 0.3).astype(dtype),
+                U_colmeans=(rng.standard_normal(p) * 0.5).astype(dtype),
+                lam6=np.array([0.11, 0.23, 0.31, 0.43, 0.53, 0.61], dtype))
+
+
+# (name, options): k_user / k_item / k_main and the switches of the signature; "C": user side information present; "Bi": implicit features
+PRECOMPUTE_EXPLICIT_CASES = [
+    ("plain, user bias", dict()),
+    ("no user bias", dict(user_bias=False)),
+    ("side information, k_user / k_item / k_main, w_user, lam_unique", dict(C=True, k_user=2, k_item=1, k_main=2, w_user=0.7, lam_unique=True)),
+    ("side information, scale_lam + scale_lam_sideinfo", dict(C=True, scale_lam=True, scale_lam_sideinfo=True, k_user=1)),
+    ("scale_lam, scale_bias_const", dict(scale_lam=True, scale_bias_const=True, scaling_biasA=17.5)),
+    ("w_main, side information", dict(C=True, w_main=1.6, w_user=0.8, k_main=1)),
+    ("NA_as_zero_X: BtXbias, rows beyond n", dict(NA_as_zero_X=True, with_biasB=True)),
+    ("NA_as_zero_X, no item bias, include_all_X", dict(NA_as_zero_X=True, include_all_X=True, user_bias=False)),
+    ("NA_as_zero_U: CtUbias", dict(C=True, NA_as_zero_U=True, w_user=1.3, k_user=2)),
+    ("implicit features", dict(Bi=True, w_implicit=0.6, k_main=1)),
+    ("implicit features + side information", dict(Bi=True, C=True, w_implicit=0.5, k_user=1)),
+    ("nonneg, side information", dict(C=True, nonneg=True)),
+]
+PRECOMPUTE_IMPLICIT_CASES = [
+    ("plain", dict()),
+    ("side information, k_user / k_item / k_main, w_user", dict(C=True, k_user=2, k_item=1, k_main=2, w_user=0.7)),
+    ("w_main and its multiplier", dict(C=True, w_main=1.4, w_main_multiplier=2.5, w_user=0.9)),
+    ("NA_as_zero_U, nonneg", dict(C=True, NA_as_zero_U=True, nonneg=True, k_user=1)),
+]
+
+
+def _precompute_inputs(d, o, dtype, implicit):
+    rng = np.random.default_rng(d["rng_seed"] + 1)
+    k, ku, ki, km = d["k"], o.get("k_user", 0), o.get("k_item", 0), o.get("k_main", 0)
+    rows = d["n"] if implicit else d["n_max"]
+    B = (rng.standard_normal((rows, ki + k + km)) * 0.4).astype(dtype)
+    Cm = (rng.standard_normal((d["p"], ku + k)) * 0.4).astype(dtype) if o.get("C") else None
+    Bi = (rng.standard_normal((d["n_max"], k + km)) * 0.4).astype(dtype) if o.get("Bi") else None
+    return B, Cm, Bi
+
+
+def precompute_explicit_call(lib, d, opts, dtype):
+    o = dict(opts); R = _real(dtype)
+    B, Cm, Bi = _precompute_inputs(d, o, dtype, False)
+    k, ku, ki, km = d["k"], o.get("k_user", 0), o.get("k_item", 0), o.get("k_main", 0)
+    ub = o.get("user_bias", True)
+    kk = k + km + int(ub); kc = ku + k; kq = ku + kk; p = d["p"] if Cm is not None else 0
+    n, n_max = d["n"], d["n_max"]
+    n_used = n_max if o.get("include_all_X") else n
+    out = dict(B_plus_bias=np.zeros((n_max, ki + k + km + 1), dtype), BtB=np.zeros((kk, kk), dtype),
+               TransBtBinvBt=np.zeros((n_used, kk), dtype), BtXbias=np.zeros(kk, dtype), BeTBeChol=np.zeros((kq, kq), dtype),
+               BiTBi=np.zeros((k + km, k + km), dtype), TransCtCinvCt=np.zeros((max(p, 1), max(kc, 1)), dtype),
+               CtCw=np.zeros((max(kc, 1), max(kc, 1)), dtype), CtUbias=np.zeros(max(kc, 1), dtype))
+    biasB = d["biasB"].copy() if o.get("with_biasB") else None
+    lam6 = d["lam6"].copy() if o.get("lam_unique") else None
+    fn = lib.precompute_collective_explicit
+    fn.restype = _C.c_int
+    ret = fn(_p(B), _C.c_int(n), _C.c_int(n_max), _C.c_bool(bool(o.get("include_all_X"))),
+             _p(Cm), _C.c_int(p), _p(Bi), _C.c_bool(Bi is not None),
+             _p(biasB), R(float(d["glob_mean"])), _C.c_bool(bool(o.get("NA_as_zero_X"))),
+             _p(d["U_colmeans"].copy()), _C.c_bool(bool(o.get("NA_as_zero_U"))),
+             _C.c_int(k), _C.c_int(ku), _C.c_int(ki), _C.c_int(km),
+             _C.c_bool(ub), _C.c_bool(bool(o.get("nonneg"))),
+             R(0.35), _p(lam6), _C.c_bool(bool(o.get("scale_lam"))), _C.c_bool(bool(o.get("scale_lam_sideinfo"))),
+             _C.c_bool(bool(o.get("scale_bias_const"))), R(o.get("scaling_biasA", 0.0)),
+             R(o.get("w_main", 1.0)), R(o.get("w_user", 1.0)), R(o.get("w_implicit", 1.0)),
+             _p(out["B_plus_bias"]) if ub else None, _p(out["BtB"]), _p(out["TransBtBinvBt"]), _p(out["BtXbias"]), _p(out["BeTBeChol"]),
+             _p(out["BiTBi"]) if Bi is not None else None, _p(out["TransCtCinvCt"]) if p else None, _p(out["CtCw"]) if p else None,
+             _p(out["CtUbias"]) if p else None)
+    assert ret == 0, ret
+    # only what the call defines: upper triangles of the symmetric outputs; matrices the options leave untouched are dropped
+    res = dict(BtB=np.triu(out["BtB"]))
+    if ub: res["B_plus_bias"] = out["B_plus_bias"]
+    if not o.get("nonneg") and Bi is None: res["TransBtBinvBt"] = out["TransBtBinvBt"]
+    if o.get("NA_as_zero_X"): res["BtXbias"] = out["BtXbias"]
+    if Bi is not None: res["BiTBi"] = np.triu(out["BiTBi"])
+    if p:
+        res["CtCw"] = np.triu(out["CtCw"])
+        if not o.get("nonneg") and Bi is None: res["TransCtCinvCt"] = out["TransCtCinvCt"]
+        if o.get("NA_as_zero_U"): res["CtUbias"] = out["CtUbias"]
+    if (p or Bi is not None) and not o.get("nonneg"): res["BeTBeChol"] = np.triu(out["BeTBeChol"])
+    return res
+
+
+def precompute_implicit_call(lib, d, opts, dtype):
+    o = dict(opts); R = _real(dtype)
+    B, Cm, _ = _precompute_inputs(d, o, dtype, True)
+    k, ku, ki, km = d["k"], o.get("k_user", 0), o.get("k_item", 0), o.get("k_main", 0)
+    kk = k + km; kc = ku + k; kq = ku + kk; p = d["p"] if Cm is not None else 0
+    out = dict(BtB=np.zeros((kk, kk), dtype), BeTBe=np.zeros((kq, kq), dtype), BeTBeChol=np.zeros((kq, kq), dtype), CtUbias=np.zeros(max(kc, 1), dtype))
+    fn = lib.precompute_collective_implicit
+    fn.restype = _C.c_int
+    ret = fn(_p(B), _C.c_int(d["n"]), _p(Cm), _C.c_int(p), _p(d["U_colmeans"].copy()), _C.c_bool(bool(o.get("NA_as_zero_U"))),
+             _C.c_int(k), _C.c_int(ku), _C.c_int(ki), _C.c_int(km),
+             R(0.8), R(o.get("w_main", 1.0)), R(o.get("w_user", 1.0)), R(o.get("w_main_multiplier", 1.0)),
+             _C.c_bool(bool(o.get("nonneg"))), _C.c_bool(False),
+             _p(out["BtB"]), _p(out["BeTBe"]), _p(out["BeTBeChol"]), _p(out["CtUbias"]))
+    assert ret == 0, ret
+    res = dict(BtB=np.triu(out["BtB"]))
+    if p:
+        res["BeTBe"] = np.triu(out["BeTBe"])
+        if not o.get("nonneg"): res["BeTBeChol"] = np.triu(out["BeTBeChol"])
+        if o.get("NA_as_zero_U"): res["CtUbias"] = out["CtUbias"]
+    return res
+
+
+def topn_problem(dtype):
+    rng = np.random.default_rng(3007)
+    n, n_max, m, k, ku, ki, km = 500, 520, 7, 8, 2, 1, 1
+    return dict(n=n, n_max=n_max, m=m, k=k, k_user=ku, k_item=ki, k_main=km,
+                A=rng.standard_normal((m, ku + k + km)).astype(dtype), B=rng.standard_normal((n_max, ki + k + km)).astype(dtype),
+                biasA=(rng.standard_normal(m) * 0.2).astype(dtype), biasB=(rng.standard_normal(n_max) * 0.2).astype(dtype),
+                glob_mean=dtype(3.1),
+                excl_few=np.sort(rng.choice(n, 12, replace=False)).astype(np.int32),
+                excl_many=rng.permutation(n)[:130].astype(np.int32),          # more than n / 20, unsorted
+                incl=rng.permutation(n)[:60].astype(np.int32))
+
+
+# (name, options)
+TOPN_CASES = [
+    ("all items, row of A", dict(n_top=10)),
+    ("own vector and bias", dict(n_top=7, a_vec=True)),
+    ("few exclusions", dict(n_top=15, exclude="excl_few")),
+    ("many exclusions, unsorted", dict(n_top=15, exclude="excl_many")),
+    ("include list", dict(n_top=9, include="incl")),
+    ("include list, all of it", dict(n_top=60, include="incl")),
+    ("include_all_X (n_max items)", dict(n_top=12, include_all_X=True)),
+    ("more than 128", dict(n_top=200)),
+    ("implicit model", dict(n_top=10, implicit=True, exclude="excl_few")),
+]
+
+
+def topn_call(lib, d, opts, dtype, expect=0):
+    o = dict(opts); R = _real(dtype)
+    n_top = o["n_top"]
+    incl = d[o["include"]].copy() if o.get("include") else None
+    excl = d[o["exclude"]].copy() if o.get("exclude") else None
+    ids = np.full(n_top, -7, np.int32); sc = np.zeros(n_top, dtype)
+    row_index = 3
+    A, B = d["A"].copy(), d["B"].copy()
+    a_vec = (A[5] * dtype(0.5)).copy() if o.get("a_vec") else None
+    common = (_C.c_int(d["k"]), _C.c_int(d["k_user"]), _C.c_int(d["k_item"]), _C.c_int(d["k_main"]),
+              _p(incl), _C.c_int(0 if incl is None else len(incl)), _p(excl), _C.c_int(0 if excl is None else len(excl)),
+              _p(ids), _p(sc), _C.c_int(n_top), _C.c_int(d["n"]))
+    if o.get("implicit"):
+        fn = lib.topN_old_collective_implicit
+        fn.restype = _C.c_int
+        ret = fn(_p(a_vec), _p(A), _C.c_int(row_index), _p(B), *common, _C.c_int(1))
+    else:
+        fn = lib.topN_old_collective_explicit
+        fn.restype = _C.c_int
+        ret = fn(_p(a_vec), R(0.25), _p(A), _p(d["biasA"].copy()), _C.c_int(row_index), _p(B), _p(d["biasB"].copy()), R(float(d["glob_mean"])),
+                 *common, _C.c_int(d["n_max"]), _C.c_bool(bool(o.get("include_all_X"))), _C.c_int(1))
+    assert ret == expect, (ret, expect)
+    return dict(ids=ids, scores=sc)

@@ -14,7 +14,7 @@ def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "cmfrec_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt)
-    keep = [n for n in names if n.startswith("cmfrec_hip_") or n.startswith("fit_collective_") or n.startswith("factors_collective_")]
+    keep = [n for n in names if n.startswith(("cmfrec_hip_", "fit_collective_", "factors_collective_", "precompute_collective_", "topN_old_collective_"))]
     return sorted(set(keep))
 
 

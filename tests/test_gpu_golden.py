@@ -541,3 +541,60 @@ def test_dense_X(oracles, dtype):
     assert gc.compare_fits(gc.dense_hip(ds, dict(use_cg=False), dtype), both) > 1e-4
     with pytest.raises(ValueError):
         CMF(k=4, NA_as_zero=True, precompute_for_predictions=False).fit(dn["X"])
+
+
+def _ref_lib(dtype):
+    from oracle.bindings import Reference, ref_available
+    return Reference(dtype).lib if ref_available(dtype) else None
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_precompute_standalone(dtype):
+    """G29: precompute_collective_explicit / precompute_collective_implicit under the reference's names and signatures
+    (src/cmfrec.h:1922-1960) -- every output the options define (B_plus_bias, BtB, TransBtBinvBt, BtXbias, BeTBeChol, BiTBi,
+    TransCtCinvCt, CtCw, CtUbias; BtB, BeTBe, BeTBeChol, CtUbias) against the fixtures generated by the compiled reference, and
+    against the compiled reference itself where it travelled with the snapshot."""
+    from cmfrec_amd import _lib
+    g = gc.load("g29_precompute_standalone", dtype)
+    d = gc.precompute_problem(dtype)
+    lib = _lib.load(dtype)
+    ref = _ref_lib(dtype)
+    tol = 1e-9 if dtype is np.float64 else 2e-4
+    def close(a, b, what):
+        assert a.shape == b.shape, what
+        assert np.abs(a.astype(np.float64) - b).max() <= tol * max(np.abs(b).max(), 1e-30), (what, float(np.abs(a - b).max()), float(np.abs(b).max()))
+    for tag, cases, call in (("e", gc.PRECOMPUTE_EXPLICIT_CASES, gc.precompute_explicit_call), ("i", gc.PRECOMPUTE_IMPLICIT_CASES, gc.precompute_implicit_call)):
+        for ci, (name, opts) in enumerate(cases):
+            got = call(lib, d, opts, dtype)
+            keys = sorted(k2[len("%s%d_" % (tag, ci)):] for k2 in g.files if k2.startswith("%s%d_" % (tag, ci)))
+            assert sorted(got) == keys, (name, sorted(got), keys)
+            for key in keys:
+                close(got[key], g["%s%d_%s" % (tag, ci, key)], (name, key))
+            if ref is not None:
+                live = call(ref, d, opts, dtype)
+                for key in keys:
+                    close(got[key], live[key], (name, key, "live"))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_topN_old_names(dtype):
+    """G30: topN_old_collective_explicit / _implicit under the reference's names (src/cmfrec.h:2104-2127; topN, common.c:5127-5380):
+    the same item ids in the same order and the same scores (+ glob_mean + the user's bias) as the compiled reference -- all items,
+    exclusion lists below and above n / 20 (the reference's three code paths), include lists, n_max items, more than 128 results,
+    the implicit twin -- and its argument checks (return code 2)."""
+    from cmfrec_amd import _lib
+    g = gc.load("g30_topn_old", dtype)
+    d = gc.topn_problem(dtype)
+    lib = _lib.load(dtype)
+    ref = _ref_lib(dtype)
+    tol = 1e-12 if dtype is np.float64 else 1e-5
+    for ci, (name, opts) in enumerate(gc.TOPN_CASES):
+        got = gc.topn_call(lib, d, opts, dtype)
+        assert np.array_equal(got["ids"], g["c%d_ids" % ci]), name
+        assert np.abs(got["scores"] - g["c%d_scores" % ci]).max() <= tol * np.abs(g["c%d_scores" % ci]).max(), name
+        if ref is not None:
+            live = gc.topn_call(ref, d, opts, dtype)
+            assert np.array_equal(got["ids"], live["ids"]), (name, "live")
+    gc.topn_call(lib, d, dict(n_top=5, include="incl", exclude="excl_few"), dtype, expect=2)
+    gc.topn_call(lib, d, dict(n_top=0), dtype, expect=2)
+    gc.topn_call(lib, d, dict(n_top=495, exclude="excl_few"), dtype, expect=2)

@@ -611,3 +611,43 @@ def test_session_naz_weighted_multipliers_follow_uploads(dtype):
     back = run(["X", "on", "off"])
     assert np.array_equal(plain[0], back[0]) and np.array_equal(plain[1], back[1])
     assert np.abs(plain[0] - fresh[0]).max() > 1e-3       # (the flag changes the model)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n", [2, 3, 17, 64, 65, 129, 256, 257, 289, 320])
+@pytest.mark.parametrize("kind", ["gram", "rank_deficient", "diagonal", "clustered"])
+def test_sym_eig(dtype, n, kind):
+    """The library's own symmetric eigen-decomposition (eig_kernels.hpp: Householder tridiagonalisation + implicit QL, the
+    rotations applied row-parallel; what the low-rank row path runs on w C^T C once per half-step) against numpy.linalg.eigh:
+    eigenvalues, A Q = Q diag(lam), Q^T Q = I -- on Gramians of full and of deficient rank (p < k: a null space), on a matrix
+    that is already diagonal (every reflector is the identity) and on clustered spectra; widths around the 64-row workgroups of
+    the QL kernel and its 32-row form (n > 288).  The one-workgroup Jacobi kernel (CMFREC_HIP_EIG=jacobi) gives the same."""
+    import ctypes as C
+    from cmfrec_amd import _lib
+    lib = _lib.load(dtype)
+    rng = np.random.default_rng(n * 7 + len(kind))
+    if kind == "gram":
+        Cm = rng.standard_normal((2 * n + 3, n)); A = Cm.T @ Cm * 0.3
+    elif kind == "rank_deficient":
+        Cm = rng.standard_normal((max(1, n // 3), n)); A = Cm.T @ Cm
+    elif kind == "diagonal":
+        A = np.diag(rng.uniform(0.0, 5.0, n))
+    else:
+        Qr, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam0 = np.concatenate([np.full(n // 2, 2.0), np.full(n - n // 2, 2.0 + 1e-9)]) if n > 3 else np.arange(1.0, n + 1)
+        A = (Qr * lam0) @ Qr.T
+    A = (0.5 * (A + A.T)).astype(dtype)
+    R = _lib.real(dtype)
+    tol = 2e-12 if dtype is np.float64 else 2e-5        # (float: the results are rounded to single precision on the way out)
+    ref = np.linalg.eigvalsh(A.astype(np.float64))
+    scale = max(np.abs(ref).max(), 1e-30)
+    for method in (0, 1):
+        Q = np.empty((n, n), dtype); lam = np.empty(n, dtype); ms = C.c_double(0)
+        rc = lib.cmfrec_hip_sym_eig(C.c_int(n), _lib.ptr(A), _lib.ptr(Q), _lib.ptr(lam), C.c_int(method), C.c_int(1), C.byref(ms))
+        assert rc == 0, (method, lib.cmfrec_hip_last_error())
+        Q64, l64, A64 = Q.astype(np.float64), lam.astype(np.float64), A.astype(np.float64)
+        assert np.isfinite(Q64).all() and np.isfinite(l64).all()
+        assert np.abs(np.sort(l64) - np.maximum(ref, 0.0)).max() <= tol * scale * 20, (method, kind, n)
+        assert np.abs(A64 @ Q64 - Q64 * l64).max() <= tol * scale * 50, (method, kind, n)
+        assert np.abs(Q64.T @ Q64 - np.eye(n)).max() <= tol * 50, (method, kind, n)

@@ -42,7 +42,7 @@ np.savez(sys.argv[1], **out)
 def _run(tmp_path, name, env, k=20, nnz=30000):
     path = str(tmp_path / (name + ".npz"))
     e = dict(os.environ)
-    for name_ in ("CMFREC_HIP_CG_KERNEL", "CMFREC_HIP_CHOL", "CMFREC_HIP_VH_MIN", "CMFREC_HIP_GEMM_OWN", "CMFREC_HIP_NT_SPLIT"):
+    for name_ in ("CMFREC_HIP_CG_KERNEL", "CMFREC_HIP_CHOL", "CMFREC_HIP_VH_MIN", "CMFREC_HIP_NT_SPLIT"):
         e.pop(name_, None)
     e.update(env)
     code = CHILD % dict(root=ROOT, tests=os.path.join(ROOT, "tests"))
@@ -57,7 +57,7 @@ def default_fits(tmp_path_factory):
 
 
 @pytest.mark.parametrize("env", [{"CMFREC_HIP_CG_KERNEL": "generic"}, {"CMFREC_HIP_CHOL": "rows"},
-                                 {"CMFREC_HIP_VH_MIN": "400"}, {"CMFREC_HIP_GEMM_OWN": "0"}],
+                                 {"CMFREC_HIP_VH_MIN": "400"}],
                          ids=lambda e: "-".join("%s=%s" % kv for kv in e.items()))
 def test_process_wide_switch_agrees_with_default(default_fits, tmp_path, env):
     got = _run(tmp_path, "alt", env)

@@ -150,7 +150,7 @@ def run(N=8, scale=1.0, timed_iters=2, n_check=24, verbose=True):
            "entries_item_block": nnz_items, "replica_rows": {"A": m, "B": n},
            "ms": {w: round(v, 2) for w, v in ms.items()}, "ms_per_iteration": round(sum(ms.values()), 2),
            "TFLOPs": {"A": round(flA / (ms["A"] * 1e-3) / 1e12, 1), "B": round(flB / (ms["B"] * 1e-3) / 1e12, 1)},
-           "lowrank_rows": lr_rows, "lowrank_eig": {0: "not taken", 1: "rocSOLVER dsyevd", 2: "built-in"}.get(lr_eig, lr_eig),
+           "lowrank_rows": lr_rows, "lowrank_eig": {0: "not taken", 2: "one-workgroup Jacobi", 3: "tridiagonalisation + QL (own)"}.get(lr_eig, lr_eig),
            "memory_GB": {"device_total": round(total / 1e9, 1), "free_before": round(free0 / 1e9, 1),
                          "high_water_used": round((free0 - low_water[0]) / 1e9, 1)},
            "generation_s": round(t_gen, 1), "setup_s": round(t_setup, 1)}
