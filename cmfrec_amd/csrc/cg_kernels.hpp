@@ -163,6 +163,11 @@ struct CgParams {
     // constant -- w (U C)_row and / or w_i sum_{j observed} Bi_j -- is added to the first residual from rconst[row, ldr]
     const T *rconst = nullptr;
     size_t ldr = 0;
+    // generic kernel, explicit model (round 6): the same pair -- a matrix every row shares (through BtB, acting on the unknowns
+    // [koff, kt)) and a per-row constant in the first residual -- for the Jacobi-preconditioned solver of NA_as_zero_X with
+    // observation weights (factors_explicit_pcg_NA_as_zero_weighted, common.c:1443-1613); rows without entries that the host put
+    // into the launch are solved like the others (optimizeA's rule, common.c:3270-3271)
+    int gx = 0;
 #ifdef CMF_CG_DEBUG
     int dbg = 0;   // phase skipping for timing experiments (results are wrong): 1 gathers, 2 Gramian product, 4 tile products, 8 dot products
 #endif
@@ -589,7 +594,7 @@ cg_rows_kernel(const CgParams<T> P)
     T *red = G + (GRAM ? gram_elems<T>(S) : 0);                              // [RPB][2][W][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (scalar: what depends on it branches instead of masking lanes)
+    const int wave = tid >> 6;
     const int grp = wave / W;      // which concurrent row of this workgroup
     const int wr = wave % W;       // wave index inside the row team
     const int k = P.k;
@@ -768,19 +773,18 @@ cg_rows_kernel(const CgParams<T> P)
             if constexpr (PV) pass_vector_lds<T, S, GR>(vdist, vrep, gw, lane, &s_pv[wave][0]);
             else replicate<T, S>(vdist, vrep, lane);
             PassAcc<T> acc;
+            acc.zero();
             if constexpr (NRES == 2) {
                 // both tiles of the wave are resident: the launch holds rows of at most 2 * W * 64 = 1024 entries (the host
                 // keeps the split-row boundary at or below that in single precision)
-                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT, true>(tile, vrep, x_res, valid_res, acc, lane, g_res);
-                else acc.zero();
+                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x_res, valid_res, acc, lane, g_res);
                 if (cnt1 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile2, vrep, x2_res, valid2_res, acc, lane, g2_res);
             } else if constexpr (NT < 8) {
-                // (the accumulators are defined by the tile pass itself: no clearing moves.  Teams of up to four wavefronts: a row of
-                //  this launch holds more than 32 W entries and its tile at least 40 per wavefront, so every wavefront has some)
-                if ((W <= 4 || cnt0 > 0) && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT, true>(tile, vrep, x_res, valid_res, acc, lane, g_res);
-                else acc.zero();
-            } else {
-            acc.zero();
+                // (round 6: defining the accumulators by the first tile product instead of clearing them was measured here -- the
+                //  guard for a wavefront without entries brings the clearing moves back, 3022 -> 3054 vector instructions; the
+                //  tiny kernel, which has no such guard, keeps that form)
+                if (cnt0 > 0 && !CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x_res, valid_res, acc, lane, g_res);
+            } else
             for (int tl = wr; tl < ntiles; tl += W) {
                 T x, g; bool valid;
                 const bool have = (tl == wr) && (resident || first);   // still in registers
@@ -798,7 +802,6 @@ cg_rows_kernel(const CgParams<T> P)
                     x = x_res; g = g_res; valid = valid_res;
                 }
                 if (!CMF_DBG(P, 4)) tile_pass<T, S, IMPLICIT, MODE, NT>(tile, vrep, x, valid, acc, lane, g);
-            }
             }
             if (GRAM && !CMF_DBG(P, 2)) {   // common.c:1932 / :1958; collective.c:2609-2643
                 if constexpr (PV) gram_pass_w<MODE == 0, T, S, W, GR>(G, gw, acc, lane, wr);
@@ -1575,7 +1578,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
         const size_t st = P.indptr[row];
         const int nnz = (int)(P.indptr[row + 1] - st);
         const bool has_u = coll && row < P.rows_with_u;
-        if (nnz == 0 && !has_u) {                             // plain rows without entries stay untouched (common.c:3270,3354)
+        if (nnz == 0 && !has_u && !(P.gx != 0 && !IMPLICIT)) {   // plain rows without entries stay untouched (common.c:3270,3354)
             if (P.Bi != nullptr && (TEAM == 1 || wv == 0))    // ... but with implicit features the row runs through
                 for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);   // optimizeA_collective: zeros (collective.c:1258-1268)
             continue;
@@ -1618,7 +1621,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
         auto matvec = [&](const T (&v)[NF], T (&out)[NF], int mode) {
 #pragma unroll
             for (int c = 0; c < NF; c++) out[c] = T(0);
-            if (IMPLICIT) {
+            if (IMPLICIT || P.gx != 0) {
                 for (int j = 0; j < kx; j++) {                 // out[koff:] = +-BtB v[koff:]
                     T vj = bcast(v, koff + j);
                     if (mode == 0) vj = -vj;
@@ -1752,6 +1755,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
             int f = lane + 64 * c;
             r[c] -= lam * a[c];
             if (!IMPLICIT && lam != lam_last && f == kt - 1) r[c] -= (lam_last - lam) * a[c];
+            if (!IMPLICIT && P.gx != 0 && P.rconst != nullptr && f >= koff && f < kt) r[c] += P.rconst[(size_t)row * P.ldr + (f - koff)];   // common.c:1525-1546
             if (!live(f)) r[c] = T(0);
             p[c] = r[c];
         }
@@ -1803,6 +1807,7 @@ cg_rows_generic_kernel(const CgParams<T> P)
                     PC[c] += P.BiTBi[(size_t)(f - koff) * P.ki + (f - koff)];           // unweighted too (collective.c:2301-2304)
                 if (IMPLICIT) PC[c] += (f >= koff && f < kt) ? P.BtB[(size_t)(f - koff) * kx + (f - koff)] : T(0);
                 else {
+                    if (P.gx != 0) PC[c] += (f >= koff && f < kt) ? P.BtB[(size_t)(f - koff) * kx + (f - koff)] : T(0);   // common.c:1486-1497
                     PC[c] += lam;
                     if (lam != lam_last && f == kt - 1) PC[c] += (lam_last - lam);
                 }

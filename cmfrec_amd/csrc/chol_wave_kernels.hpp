@@ -637,8 +637,13 @@ chol_wave_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const 
         for (int bjk = ((WMODE == 2 && (SL.dbg_skip & 8)) ? -1 : nb - 1); bjk >= 0; bjk--) {
             const T *rslot = rinv + (size_t)bjk * RSZ;
             T xm = T(0);                          // x[16 bjk + lm], computed redundantly by every 16-lane group
-#pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) xm += rslot[lm * LDR + n2] * yv0[16 * bjk + n2];
+{   // (round 6: the block of the right-hand side once, its elements broadcast inside the 16-lane row by DPP instead of sixteen more LDS reads)
+                const T yb = yv0[16 * bjk + lm];
+                static_for<0, 16>([&](auto nc) {
+                    constexpr int n2 = decltype(nc)::value;
+                    xm += rslot[lm * LDR + n2] * lanes::row_bcast16<n2>(yb);
+                });
+            }
             if (lane < 16) xall[16 * bjk + lane] = xm;
             CMF_LDS_FENCE();
             static_for<0, NB>([&](auto jc) {

@@ -50,7 +50,7 @@ struct Switches {
     bool nt_split = true;           // CMFREC_HIP_NT_SPLIT=0: a double-precision length bin as one launch instead of two by tile size
     bool cg_generic = false;        // CMFREC_HIP_CG_KERNEL=generic: lane <-> unknown CG kernel everywhere
     int chol = 0;                   // CMFREC_HIP_CHOL: 1 = rows (workgroup-per-row kernel only), 2 = noslices
-    bool chol_wg = true;            // CMFREC_HIP_CHOL_WG=0: eight-block rows in double precision factorised by one wavefront per row (rounds 2-5) instead of a four-wavefront workgroup
+    int chol_wg = 2;                // CMFREC_HIP_CHOL_WG: eight-block rows in double precision factorised by a workgroup of 2 (default) / 4 wavefronts per row (chol_wg_kernels.hpp); 0 = one wavefront per row (rounds 2-5)
     int gramk = -1;                 // CMFREC_HIP_GRAMK: 0 / 1 force the producer / consumer pair off / on (-1: by width)
     int gramk_batch = 0;            // CMFREC_HIP_GRAMK_BATCH: work items per batch (test hook: several batches on a small problem)
     int lowrank = -1;               // CMFREC_HIP_LOWRANK: 0 / 1 force the low-rank row kernel off / on (-1: by shape)
@@ -70,7 +70,8 @@ struct Switches {
         nt_split = num("CMFREC_HIP_NT_SPLIT", 1) != 0;
         v = str("CMFREC_HIP_CG_KERNEL"); cg_generic = v && strcmp(v, "generic") == 0;
         v = str("CMFREC_HIP_CHOL"); chol = !v ? 0 : strcmp(v, "rows") == 0 ? 1 : strcmp(v, "noslices") == 0 ? 2 : 0;
-        chol_wg = num("CMFREC_HIP_CHOL_WG", 1) != 0;
+        chol_wg = num("CMFREC_HIP_CHOL_WG", 2);
+        if (chol_wg == 1) chol_wg = 2;
         gramk = num("CMFREC_HIP_GRAMK", -1);
         gramk_batch = num("CMFREC_HIP_GRAMK_BATCH", 0);
         lowrank = num("CMFREC_HIP_LOWRANK", -1);
@@ -577,6 +578,7 @@ struct CgCall {
     const real_t *Gx = nullptr, *rconst_x = nullptr;
     size_t ldr_x = 0;
     const real_t *values_override = nullptr, *weights_override = nullptr;
+    bool gx_all_rows = false;         // ... with the preconditioner (generic kernel): the rows without entries are part of the launch
 };
 
 enum class CgVariant { Auto, Generic };
@@ -927,9 +929,9 @@ inline void launch_cg_S(const DeviceInfo &dev, const CgParams<real_t> &P, const 
 }
 
 template <int NF, bool IMPLICIT>
-inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, int first = 0)
+inline void launch_cg_generic(const DeviceInfo &dev, CgParams<real_t> P, const SparseShard &X, int first = 0, bool all_rows = false)
 {
-    int count = (P.kc > 0 || P.Bi != nullptr) ? X.nrows : X.n_nonempty;   // rows without entries still have side information / get zeroed
+    int count = (P.kc > 0 || P.Bi != nullptr || all_rows) ? X.nrows : X.n_nonempty;   // rows without entries still have side information / get zeroed
     if (count <= first) return;
     // rows of 129 non-zeros and more (they lead the processing order): a workgroup per row -- sixteen wavefronts for the
     // rows beyond 1024 non-zeros (the longest row is the critical path of the launch: C1's items with implicit features
@@ -992,6 +994,24 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     const int S = (c.k + 7) / 8;
     if (c.values_override != nullptr) P.values = c.values_override;
     if (c.weights_override != nullptr) { P.weights = c.weights_override; P.wsum = X.wsum_naz.ptr; }     // (NA_as_zero_X with weights only)
+    if (c.Gx != nullptr && c.precond) {
+        // ... with the Jacobi preconditioner (factors_explicit_pcg_NA_as_zero_weighted, common.c:1443-1613): the lane <-> unknown kernel
+        // with the shared matrix and the per-row constant (CgParams::gx), any width it takes
+        if (c.implicit || c.kc > 0 || c.Bi != nullptr || c.koff != 0 || c.skip_first != 0 || c.X2 != nullptr) {
+            g_last_error = "cmfrec_hip: preconditioned CG with a shared matrix: plain explicit rows";
+            return 2;
+        }
+        P.BtB = c.Gx; P.rconst = c.rconst_x; P.ldr = c.ldr_x; P.gx = 1;
+        const int NFx = (c.k + 63) / 64;
+        switch (NFx) {
+            case 1: launch_cg_generic<1, false>(dev, P, X, 0, c.gx_all_rows); return 0;
+            case 2: launch_cg_generic<2, false>(dev, P, X, 0, c.gx_all_rows); return 0;
+            case 3: launch_cg_generic<3, false>(dev, P, X, 0, c.gx_all_rows); return 0;
+            default: break;
+        }
+        g_last_error = "cmfrec_hip: preconditioned CG with a shared matrix: at most 192 unknowns per row";
+        return 2;
+    }
     if (c.Gx != nullptr) {
         // shared matrix + per-row constant on the GRAMX builds (no block structure: the explicit model's own lambda rules apply)
         if (c.implicit || c.precond || S > 8 || c.kc > 0 || c.Bi != nullptr || c.koff != 0 || c.skip_first != 0) {

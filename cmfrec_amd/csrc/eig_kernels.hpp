@@ -250,21 +250,27 @@ eig_ql_rows_kernel(int n, const double *__restrict__ W, const double *__restrict
                 for (int i = m - 1; i >= l; i--) {
                     const int ip = max(i - 1, 0);            // (i == l: loaded and not used)
                     const double e_n = e[ip], d_n = d[ip], z_n = zp[(size_t)ip * ROWS];
+                    __builtin_amdgcn_sched_barrier(0);       // (the three reads first: their latency belongs behind the whole rotation)
                     c3 = c2; c2 = c; s2 = s;
                     g = c * e_i;
                     const double h = c * p;
-                    const double x = __builtin_fma(p, p, e_i * e_i);
-                    double rt, inv;
-                    eig_sqrt_inv((x > 0.0) ? x : 1.0, rt, inv);
-                    const double e_out = (x > 0.0) ? s * rt : 0.0;
-                    s = e_i * inv;                           // (x == 0: e_i == 0)
-                    c = (x > 0.0) ? p * inv : 1.0;
+                    // r = hypot(p, e_i) and 1 / r from one v_rsq_f64 + two Newton steps.  (x > 0: inside an unreduced block e_i is
+                    //  above eps x the matrix's scale; the clamp only keeps a denormal-scale matrix free of NaN)
+                    const double x = fmax(__builtin_fma(p, p, e_i * e_i), 1e-290);
+                    double inv = __builtin_amdgcn_rsq(x);
+                    const double hx = 0.5 * x;
+                    inv = inv * __builtin_fma(-hx * inv, inv, 1.5);
+                    inv = inv * __builtin_fma(-hx * inv, inv, 1.5);
+                    const double e_out = s * (x * inv);
+                    s = e_i * inv;
+                    c = p * inv;
                     p = __builtin_fma(c, d_i, -s * g);
                     const double d_out = __builtin_fma(s, __builtin_fma(c, g, s * d_i), h);
                     e[i + 1] = e_out; d[i + 1] = d_out;
                     const double z_new = __builtin_fma(s, z_lo, c * z_hi);
                     if (ROWS == 64 || writer) zp[(size_t)(i + 1) * ROWS] = z_new;
                     z_hi = __builtin_fma(c, z_lo, -s * z_hi);
+                    __builtin_amdgcn_sched_barrier(0);
                     e_i = e_n; d_i = d_n; z_lo = z_n;
                 }
                 if (writer) zp[(size_t)l * ROWS] = z_hi;

@@ -1062,8 +1062,8 @@ int_t fit_collective_explicit_als(
         if ((user_bias || item_bias) && reset_values)
             return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights: pass start values for the biases (reset_values = false); "
                                  "the reference's own start values are not defined for this combination.");
-        if (use_cg && (precondition_cg || k + k_main + 1 > 64) )
-            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights under CG: k + k_main + bias <= 64, no preconditioner.");
+        if (use_cg && !precondition_cg && k + k_main + 1 > 64)
+            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights under CG: k + k_main + bias <= 64 (precondition_cg takes more).");
     }
     if (NA_as_zero_X && (U || II)) {
         // (use_cg is accepted: with a factorised shared block matrix the reference takes the closed form whatever the solver asked for)

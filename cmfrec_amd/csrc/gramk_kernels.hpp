@@ -331,9 +331,12 @@ __device__ __forceinline__ void gc_row(const CholParams<T> &P, GcShared<T> &S, c
 #pragma unroll
             for (int r = 0; r < 4; r++) ainv[r] = -rslot[Mf::row_of(lane, r) * LDR + lm];
             if (Q == ((kbk + 1) & 3)) {           // y_k = inv(R_kk)^T rhs_k, in place (a wave that is not the next diagonal's owner... any wave)
+                const T vk = S.rhs[16 * kbk + lm];
                 T yv = T(0);
-#pragma unroll
-                for (int l = 0; l < 16; l++) yv += rslot[l * LDR + lm] * S.rhs[16 * kbk + l];
+                static_for<0, 16>([&](auto lc) {
+                    constexpr int l = decltype(lc)::value;
+                    yv += rslot[l * LDR + lm] * lanes::row_bcast16<l>(vk);
+                });
                 if (lane < 16) S.rhs[16 * kbk + lane] = yv;
             }
             static_for<0, NTQ>([&](auto ic) {
@@ -411,12 +414,21 @@ __device__ __forceinline__ void gc_row(const CholParams<T> &P, GcShared<T> &S, c
         sr += lanes::xor8(sr);
         T *ps = &S.psum[bi & 1][0][0];
         if (lm < 4) ps[Q * 16 + Mf::row_of(lane, lm)] = sr;
-        __syncthreads();
+        // Round 6 (measured first in chol_wg8_kernel, where this loop as 96 LDS reads per block row cost more than the whole
+        // factorisation's matrix instructions): the row of inv(R_ii) this lane multiplies with is on its way while the partial
+        // sums meet at the barrier; t = y_i - sum_j R_ij x_j sits with element lm in lane lm of every 16-lane row and is
+        // broadcast inside the row by DPP instead of being re-read from LDS sixteen times.  Same sums in the same order.
         const T *rslot = S.rinv + bi * RSZ;
-        T xm = T(0);                              // x[16 bi + lm], computed redundantly by every 16-lane group of every wave
+        T ri[16];
 #pragma unroll
-        for (int n2 = 0; n2 < 16; n2++)
-            xm += rslot[lm * LDR + n2] * (S.rhs[16 * bi + n2] - ((ps[n2] + ps[16 + n2]) + (ps[32 + n2] + ps[48 + n2])));
+        for (int n2 = 0; n2 < 16; n2++) ri[n2] = rslot[lm * LDR + n2];
+        __syncthreads();
+        const T tv = S.rhs[16 * bi + lm] - ((ps[lm] + ps[16 + lm]) + (ps[32 + lm] + ps[48 + lm]));
+        T xm = T(0);                              // x[16 bi + lm], computed redundantly by every 16-lane group of every wave
+        static_for<0, 16>([&](auto nc) {
+            constexpr int n2 = decltype(nc)::value;
+            xm += ri[n2] * lanes::row_bcast16<n2>(tv);
+        });
         if constexpr (gc_has_col(Q, bi)) xs[gc_xslot(Q, bi)] = xm;
         if (Q == 0 && lane < 16) S.xall[16 * bi + lane] = xm;
     });

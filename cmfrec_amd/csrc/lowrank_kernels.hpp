@@ -432,8 +432,13 @@ lowrank_rows_kernel(const LrParams<T> P, const RowDesc *__restrict__ desc)
         for (int bjk = nb - 1; bjk >= 0; bjk--) {
             const T *rslot = rinv + (size_t)bjk * RSZ;
             T xm = T(0);
-#pragma unroll
-            for (int n2 = 0; n2 < 16; n2++) xm += rslot[lm * LDR + n2] * yv0[16 * bjk + n2];
+{   // (round 6: the block of the right-hand side once, its elements broadcast inside the 16-lane row by DPP instead of sixteen more LDS reads)
+                const T yb = yv0[16 * bjk + lm];
+                static_for<0, 16>([&](auto nc) {
+                    constexpr int n2 = decltype(nc)::value;
+                    xm += rslot[lm * LDR + n2] * lanes::row_bcast16<n2>(yb);
+                });
+            }
             if (lane < 16) xall[16 * bjk + lane] = xm;
             CMF_LDS_FENCE();
             static_for<0, NB>([&](auto jc) {

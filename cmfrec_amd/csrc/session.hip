@@ -11,7 +11,6 @@
 #include "gramk_kernels.hpp"
 #include "lowrank_kernels.hpp"
 #include "eig_kernels.hpp"
-#include "chol_wg_kernels.hpp"
 #include "gram_cg_wide_kernels.hpp"
 #include <dlfcn.h>
 #include <functional>
@@ -26,6 +25,8 @@ thread_local int g_last_rc = 0;      // return code that goes with g_last_error 
 CgVariant cg_variant_from_env() { return switches().cg_generic ? CgVariant::Generic : CgVariant::Auto; }
 
 inline dim3 grid1d(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+// (chol_wg_tu.hip: the four-wavefront factorisation of the eight-block rows, double precision)
+hipError_t launch_chol_wg8(int num_cus, bool border, int waves_per_row, hipStream_t st, const CholParams<real_t> &W, const RowDesc *desc, const CholSlices<real_t> &SL);
 
 struct CholCall {
     real_t *A; size_t lda;
@@ -200,19 +201,12 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                     }
                 }
                 else if (switches().chol_wg) {
-                    // Round 6: the factorisation by one workgroup of four wavefronts per row, the 36 tiles dealt to them (chol_wg_kernels.hpp;
-                    // two to three rows per CU in flight, no spills) instead of one wavefront per row and SIMD with 263 spilled registers.
-                    // CMFREC_HIP_CHOL_WG=0: the one-wavefront build below (A/B switch and on-device cross-check).
+                    // Round 6: the factorisation by one workgroup of TWO wavefronts per row, the 36 tiles dealt to them, four rows per CU in
+                    // flight (chol_wg_kernels.hpp) instead of one wavefront per row and SIMD with 263 spilled registers: config 3
+                    // 14.2 -> 13.0 ms (profiles/r06/r06_j_*).  CMFREC_HIP_CHOL_WG=4: four wavefronts per row, two rows per CU (14.0);
+                    // =0: the one-wavefront build below (A/B switch and on-device cross-check).
                     poison_lds(st, dev.num_cus);
-                    auto kern = border ? chol_wg8_kernel<real_t, true> : chol_wg8_kernel<real_t, false>;
-                    static thread_local int bpc_dev[MAX_DEVICES][2] = {{0}};
-                    int &blocks_per_cu = bpc_dev[std::min(std::max(dev.device, 0), MAX_DEVICES - 1)][border ? 1 : 0];
-                    if (blocks_per_cu == 0) {
-                        int nb2 = 0;
-                        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, kern, 256, 0));
-                        blocks_per_cu = std::max(1, nb2);
-                    }
-                    hipLaunchKernelGGL(kern, dim3(std::min(last - first, dev.num_cus * blocks_per_cu)), dim3(256), 0, st, W, X->desc.ptr, SL);
+                    HIP_CHECK(launch_chol_wg8(dev.num_cus, border, switches().chol_wg == 2 ? 2 : 4, st, W, X->desc.ptr, SL));       // chol_wg_tu.hip
                 }
                 else wlaunch((border ? chol_wave_kernel<real_t, 8, true, 1, 1, 6, 2, true> : chol_wave_kernel<real_t, 8, false, 1, 1, 6, 2, true>), 8, 1);
 #endif
@@ -2034,8 +2028,8 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
     const real_t lam_self = s->lam6[isA ? 2 : 3];
     const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
     const int ks = m.k + m.k_main + (self_bias ? 1 : 0);
-    if (!chol && (ks > 64 || m.precondition_cg)) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights under CG: at most 64 unknowns per row, no preconditioner";
+    if (!chol && ks > 64 && !m.precondition_cg) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights under CG: at most 64 unknowns per row (the preconditioned solver takes more)";
         return 2;
     }
     if (self_bias)                            // the opposing bias column is fixed to 1 (collective.c:8538-8543, :8728-8732)
@@ -2094,9 +2088,12 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
     CgCall c{self, ld_self, opp, ld_opp, ks, nullptr, nullptr, lam_self, lam_last_self, m.scale_lam != 0, s->scale_bias_const, m.max_cg_steps, false};
     c.Gx = s->gram.ptr; c.rconst_x = s->naz_rhs.ptr; c.ldr_x = (size_t)ks;
     c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_g.ptr;
+    // precondition_cg (round 6; factors_explicit_pcg_NA_as_zero_weighted, common.c:1443-1613): the lane <-> unknown kernel with the
+    // shared matrix, its diagonal in the Jacobi preconditioner, the rows without entries in the same launch when the constant exists
+    c.precond = m.precondition_cg != 0; c.gx_all_rows = c.precond && has_cst;
     int rc = launch_cg(dev, c, X);
     if (rc) return rc;
-    if (has_cst && X.nrows > X.n_nonempty) {
+    if (!c.precond && has_cst && X.nrows > X.n_nonempty) {
         const int cnt = X.nrows - X.n_nonempty;
         hipLaunchKernelGGL(cg_shared_matrix_rows_kernel<real_t>, dim3((cnt + 3) / 4), dim3(256), 0, st, self, ld_self, X.order.ptr + X.n_nonempty, cnt, ks,
                            s->gram.ptr, cst, lam_self, lam_last_self, m.scale_lam ? X.wsum_naz.ptr : nullptr, s->scale_bias_const ? 1 : 0, m.max_cg_steps);

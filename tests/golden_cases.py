@@ -1336,6 +1336,11 @@ NAZ_WEIGHTED_CASES = [
     ("cg, no biases, no centring: rows without entries stay", dict(use_cg=True, finalize_chol=False, user_bias=False, item_bias=False, center=False)),
     ("chol, no biases, centred, k_main", dict(use_cg=False, user_bias=False, item_bias=False, k_main=2)),
     ("cg, per-matrix lambdas", dict(use_cg=True, finalize_chol=False, lam_unique=LAM6)),
+    # precondition_cg (round 6): factors_explicit_pcg_NA_as_zero_weighted, common.c:1443-1613
+    ("pcg, biases", dict(use_cg=True, finalize_chol=False, precondition_cg=True)),
+    ("pcg, scale_lam, item bias", dict(use_cg=True, finalize_chol=False, precondition_cg=True, scale_lam=True, user_bias=False)),
+    ("pcg, no biases, no centring: rows without entries stay", dict(use_cg=True, finalize_chol=False, precondition_cg=True, user_bias=False, item_bias=False, center=False)),
+    ("pcg + finalize, per-matrix lambdas, k_main", dict(use_cg=True, finalize_chol=True, precondition_cg=True, lam_unique=LAM6, k_main=2)),
 ]
 
 

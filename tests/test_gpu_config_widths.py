@@ -40,10 +40,14 @@ def _collective_case(O, dtype, m, n, k, p, nnz, seed, heavy, w, ragged=True):
     return csr, Bm, Cm, U, A0, bias
 
 
+@pytest.mark.parametrize("chol_wg", ["4", "2", "0"])
 @pytest.mark.parametrize("scale_lam", [True, False])
-def test_c3_width_collective_double(oracles, scale_lam):
-    """k = 128 + bias, q = 64, fp64: the 8-block + border wave kernel and, for the heavy row, the 9-tile row kernel."""
+def test_c3_width_collective_double(oracles, scale_lam, chol_wg, monkeypatch):
+    """k = 128 + bias, q = 64, fp64: the rank-k producer + the factorisation of the eight-block rows with their border column --
+    by a workgroup of four wavefronts per row (the default), of two (CMFREC_HIP_CHOL_WG=2), by one wavefront per row (=0: the
+    kernel of rounds 2-5) -- and, for the heavy row, its slices' partials."""
     from cmfrec_amd import ops
+    monkeypatch.setenv("CMFREC_HIP_CHOL_WG", chol_wg)
     dtype = np.float64
     O = oracles[dtype]
     m, n, k, p = 56, 2400, 128, 64
@@ -59,12 +63,16 @@ def test_c3_width_collective_double(oracles, scale_lam):
     assert np.abs(Ah[4]).max() > 0
 
 
-def test_c3_width_explicit_double(oracles):
-    """The user side of C3 has no side information: plain explicit Cholesky at k_t = 129."""
+@pytest.mark.parametrize("chol_wg", ["4", "2", "0"])
+@pytest.mark.parametrize("k", [128, 127, 120])
+def test_c3_width_explicit_double(oracles, k, chol_wg, monkeypatch):
+    """The user side of C3 has no side information: plain explicit Cholesky at k_t = 129 (bias as the border column), 128 (no
+    border: the bias inside the tiles) and 121 (padding inside the last block), on each of the three factorisation kernels."""
     from cmfrec_amd import ops
+    monkeypatch.setenv("CMFREC_HIP_CHOL_WG", chol_wg)
     dtype = np.float64
     O = oracles[dtype]
-    m, n, k = 64, 2000, 128
+    m, n = 64, 2000
     row, col, val = make_coo(m, n, 9000, 5, counts=False, dtype=dtype, heavy_row=(9, 1300), empty_rows=(2,))
     csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
     rng = np.random.default_rng(6)
