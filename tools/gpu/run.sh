@@ -87,7 +87,7 @@ final)
   pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64
   pass mfmai SQ_INSTS_MFMA
   pass lds SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
-  python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/pmc_busy $O/pmc_tcc $O/pmc_mfma $O/pmc_mfmai $O/pmc_lds --calibration profiles/fetch_calibration.json --round ${ROUND:-r05}_final -o $O/pmc_summary.json 2>&1 | tail -2
+  python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/pmc_busy $O/pmc_tcc $O/pmc_mfma $O/pmc_mfmai $O/pmc_lds --calibration profiles/fetch_calibration.json --round ${ROUND:-r06}_final -o $O/pmc_summary.json 2>&1 | tail -2
   cp $O/pmc_summary.json profiles/pmc_latest.json      # read by bench.py below (roofline.traffic)
   rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_valu $O/pmc_busy $O/pmc_tcc $O/pmc_mfma $O/pmc_mfmai $O/pmc_lds
   for mode in default inline; do
