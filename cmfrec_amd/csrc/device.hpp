@@ -165,10 +165,13 @@ struct SparseShard {
     }
     static bool gram_pays(double vh_nnz, int n_other_, size_t opp_bytes_per_row)
     {
-        if (sizeof(real_t) == 4) return true;
-        if (n_other_ <= 0) return false;
-        const double refs = vh_nnz / (double)n_other_;
-        return refs < 3.5 || (refs < 40.0 && (double)n_other_ * (double)opp_bytes_per_row > 100e6);
+        // Round 6: always.  Rounds 3-5 streamed the split rows of double precision once per CG pass where they share their opposing
+        // rows often enough to live in cache (more than 40 references per opposing row, or 3.5 with a matrix below 100 MB: C1).  Measured
+        // again on C1 with the slice kernel as it stands (remainder columns on the vector ALU, the boundary at 513): 2.24 -> 1.86 ms per
+        // iteration, its item step 1.31 -> 0.93 (profiles/r06/r06_n_c1_split_rows_sweep.txt); the streamed path stays behind
+        // CMFREC_HIP_VH=stream, for k > 64 and for block systems.
+        (void)vh_nnz; (void)opp_bytes_per_row;
+        return sizeof(real_t) == 4 || n_other_ > 0;
     }
     DevBuf<size_t> p;
     DevBuf<int> i;
@@ -202,7 +205,8 @@ struct SparseShard {
     // precision always takes the Gramian (the matrix cores outrun any gather).  In double precision v_mfma_f64_16x16x4 is no
     // faster than the VALU, and streaming wins once the split rows of a launch share their opposing rows often enough to live
     // in cache: C2's items (15 references per opposing row, a 144 MB opposing matrix) still favour the Gramian; C1
-    // (MovieLens-10M-shaped: 4 / 28 MB opposing matrices, 100+ references) does not -- 1.29 against 1.06 ms for its A-step.
+    // (MovieLens-10M-shaped: 4 / 28 MB opposing matrices, 100+ references) did not in round 3 -- 1.29 against 1.06 ms for its A-step --
+    // and does since (gram_pays above: round 6).
     // `opp_bytes_per_row` = k x sizeof(real_t) of the launch.  CMFREC_HIP_VH=gram / stream force one.
     bool prefer_gram(size_t opp_bytes_per_row) const { return gram_pays((double)bin_nnz[0], n_other, opp_bytes_per_row); }
     // few split rows (less than about one round of workgroups per CG pass): their launch sequence is a chain of
