@@ -55,7 +55,7 @@ constexpr int CG_NTSEL_MAX_S = 7;
 // no spills), the body for 8 alone is the round-4 kernel (160-167: three).
 template <typename T, int W, int NRES_, int NTSEL = 0> constexpr int cg_waves_per_simd()
 {
-    if (sizeof(T) == 8 && NTSEL == 1 && W <= 4) return CMF_CG_WAVES_PER_SIMD_LOW;
+    if (sizeof(T) == 8 && NTSEL == 1 && W <= 8) return CMF_CG_WAVES_PER_SIMD_LOW;
     if (sizeof(T) == 4 && NTSEL == 1 && W <= 4 && NRES_ == 0) return CMF_CG_WAVES_PER_SIMD_F32 + 1;
     return (sizeof(T) == 4 && W <= 4 && NRES_ == 0) ? CMF_CG_WAVES_PER_SIMD_F32 : CMF_CG_WAVES_PER_SIMD;
 }

@@ -196,7 +196,7 @@ struct SparseShard {
     int n_gt96 = 0;          // rows with more than 96 entries (the six-block low-rank build of double precision, session.hip)
     int n_gt16 = 0;          // rows with more than 16 entries: the rest of the tiny bin goes two rows per wavefront
     int n_gt512 = 0;         // rows with more than 512 entries (single precision: the 257..512 part of the heavy bin runs on 4-wave teams)
-    int n_gt_low[3] = {0, 0, 0};   // rows with more than CG_NT_LOW * 8 W entries, W = 1, 2, 4 (48 / 96 / 192): where a length bin's launch by tile size begins
+    int n_gt_low[4] = {0, 0, 0, 0};   // rows with more than CG_NT_LOW * 8 W entries, W = 1, 2, 4, 8 (48 / 96 / 192 / 384): where a length bin's launch by tile size begins
     bool is_part = false;    // one of several parts of a block that are updated one after the other (session.hip)
     int n_other = 0;         // rows of the opposing matrix the entries refer to
     // Split rows: read their gathered rows once and run the CG on the row's own Gramian (gram_cg_kernels.hpp, one wavefront
@@ -320,7 +320,7 @@ struct SparseShard {
     {
         for (int b = 0; b < NBINS; b++) { bin_rows[b] = 0; bin_nnz[b] = 0; }
         n_empty = 0; n_long = 0; n_gt16 = 0; n_gt96 = 0; n_gt512 = 0; n_slices = 0; h_row_sl_off.assign(1, 0);
-        n_gt_low[0] = n_gt_low[1] = n_gt_low[2] = 0;
+        n_gt_low[0] = n_gt_low[1] = n_gt_low[2] = n_gt_low[3] = 0;
         std::vector<int> c_row, c_first, c_cnt, c_off(1, 0);
         std::vector<int> s_row, s_first, s_count, s_off(1, 0);
         // few split rows (C2's users: 50 rows, 65 k entries): short slices, so that their Gramian kernels -- which run in line
@@ -347,7 +347,7 @@ struct SparseShard {
             if (l > 16) n_gt16++;
             if (l > 96) n_gt96++;
             if (l > 512) n_gt512++;
-            for (int w = 0; w < 3; w++) if (l > (long long)CG_NT_LOW * 8 * (1 << w)) n_gt_low[w]++;
+            for (int w = 0; w < 4; w++) if (l > (long long)CG_NT_LOW * 8 * (1 << w)) n_gt_low[w]++;
             const int b = bin_of(l);
             if (b < 0) { n_empty++; continue; }
             if (b == BIN_VHEAVY) {
@@ -810,12 +810,14 @@ inline void launch_cg_bin_by_tile(const DeviceInfo &dev, const CgParams<real_t> 
 #ifdef CMFREC_HIP_FLOAT
     constexpr bool by_tile = S >= CMF_CG_NT_MIN_S && CMF_CG_NT_F32 && W <= 4;
 #else
-    constexpr bool by_tile = S >= CMF_CG_NT_MIN_S && S <= CG_NTSEL_MAX_S && (W == 1 || W == 4);
+    // (round 6: the eight-wave teams too -- their rows of 257..384 entries on the build for 5 / 6 entries per lane group, 168 registers:
+    //  the workgroup no longer owns every register of its CU, the neighbouring stream's workgroups fit beside it)
+    constexpr bool by_tile = S >= CMF_CG_NT_MIN_S && S <= CG_NTSEL_MAX_S && (W == 1 || W == 4 || W == 8);
 #endif
     if (count <= 0) return;
     if constexpr (by_tile) {
         if (switches().nt_split) {
-            const int n_hi = std::min(count, std::max(0, X.n_gt_low[W == 1 ? 0 : W == 2 ? 1 : 2] - first));
+            const int n_hi = std::min(count, std::max(0, X.n_gt_low[W == 1 ? 0 : W == 2 ? 1 : W == 4 ? 2 : 3] - first));
             EventPair ev{nullptr, nullptr};
             if (tm) { HIP_CHECK(hipEventCreate(&ev.a)); HIP_CHECK(hipEventCreate(&ev.b)); HIP_CHECK(hipEventRecord(ev.a, st)); }
             launch_cg_bin<S, IMPLICIT, W, RPB, GRAMX, 0, 2>(dev, P, first, n_hi, nullptr, bin, st);
@@ -849,7 +851,7 @@ inline void launch_cg_any_bin(const DeviceInfo &dev, const CgParams<real_t> &P, 
             // (double precision: rows of 257..384 entries on six-wave teams were measured slower -- 0.245 -> 0.27 ms for C2's items,
             //  0.184 -> 0.203 for its users, profiles/r04/r04_u -- a second launch per bin costs more than the idle waves)
 #endif
-            launch_cg_bin<S, IMPLICIT, 8, 1, GRAMX>(dev, P, first, count, tm, bin, st); break;
+            launch_cg_bin_by_tile<S, IMPLICIT, 8, 1, GRAMX>(dev, P, X, first, count, tm, bin, st); break;
         case BIN_MED4: launch_cg_bin_by_tile<S, IMPLICIT, 4, 1, GRAMX>(dev, P, X, first, count, tm, bin, st); break;
         case BIN_MED2: launch_cg_bin_by_tile<S, IMPLICIT, 2, 1, GRAMX>(dev, P, X, first, count, tm, bin, st); break;
         default: launch_cg_bin_by_tile<S, IMPLICIT, 1, 4, GRAMX>(dev, P, X, first, count, tm, bin, st); break;

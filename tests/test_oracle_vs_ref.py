@@ -744,3 +744,28 @@ def test_NA_as_zero_implicit_features_fit_live(oracles, refs, dtype, seed):
         for key, v in ref.items():
             if v is not None and np.size(v) > 1:
                 assert rel_err(got[key], v) < 100 * TOL[dtype], (name, key)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_standalone_fixtures_are_the_reference(dtype):
+    """Fixtures g29 (precompute_collective_explicit / _implicit) and g30 (topN_old_collective_explicit / _implicit) against the
+    compiled reference run live: what the GPU tests of the same names compare the product with is what the reference returns here
+    (the summation order of its BLAS may differ between hosts: tolerance of the fixture's precision, ids exact)."""
+    import golden_cases as gc
+    if not ref_available(dtype):
+        pytest.skip("oracle/_ref for this precision not built")
+    lib = Reference(dtype).lib
+    tol = 1e-10 if dtype is np.float64 else 1e-4
+    g = gc.load("g29_precompute_standalone", dtype)
+    d = gc.precompute_problem(dtype)
+    for tag, cases, call in (("e", gc.PRECOMPUTE_EXPLICIT_CASES, gc.precompute_explicit_call), ("i", gc.PRECOMPUTE_IMPLICIT_CASES, gc.precompute_implicit_call)):
+        for ci, (name, opts) in enumerate(cases):
+            for key, v in call(lib, d, opts, dtype).items():
+                ref = g["%s%d_%s" % (tag, ci, key)]
+                assert np.abs(v.astype(np.float64) - ref).max() <= tol * max(np.abs(ref).max(), 1e-30), (name, key)
+    g = gc.load("g30_topn_old", dtype)
+    d = gc.topn_problem(dtype)
+    for ci, (name, opts) in enumerate(gc.TOPN_CASES):
+        got = gc.topn_call(lib, d, opts, dtype)
+        assert np.array_equal(got["ids"], g["c%d_ids" % ci]), name
+        assert np.abs(got["scores"] - g["c%d_scores" % ci]).max() <= tol * np.abs(g["c%d_scores" % ci]).max(), name
