@@ -264,7 +264,7 @@ def main():
             o = by_key.get(("A" if e["step"] == "B" else "B", e["kernel"]))
             e["inline_ms"] = r["inline_ms"]; e["inline_GBps"] = r["GBps"]; e["inline_frac"] = r["frac"]
             e["rocprof"]["avg_ms_over_both_halfsteps"] = round((r["inline_ms"] + (o["inline_ms"] if o else 0.0)) / (2 if o else 1), 4)
-            e["rocprof"]["mode"] = "bins in line (CMFREC_HIP_BINS_PAR=1): the run profiles/r05/*_kernel_stats_inline.csv is taken from"
+            e["rocprof"]["mode"] = "bins in line (CMFREC_HIP_BINS_PAR=1): the run profiles/<round>/*_kernel_stats_inline.csv is taken from"
         worst = min(tab, key=lambda r: r["frac"])
         roofline["inline"] = {"halfstep_ms": hs_inline, "iteration_ms": round(hs_inline["A"] + hs_inline["B"], 4),
                               "worst_bin": {k2: worst[k2] for k2 in ("step", "kernel", "inline_ms", "GBps", "frac")},
@@ -357,7 +357,7 @@ def inline_bin_leg(sess, step_fn, sync_fn, nsteps, names, k, itemsize):
     """A few more iterations with the nnz bins of a half-step IN LINE (CMFREC_HIP_BINS_PAR=1, read again through
     cmfrec_hip_reload_switches): only then a bin's HIP-event pair -- recorded on the stream the kernel is launched on -- brackets that kernel alone, and
     only then `rocprofv3 --kernel-trace --stats` of the same kernels has durations of their own to compare with
-    (profiles/r04/*_kernel_stats_inline.csv).  Returns one row per (half-step, bin): its own duration, algorithmic GB/s and
+    (profiles/<round>/*_kernel_stats_inline.csv).  Returns one row per (half-step, bin): its own duration, algorithmic GB/s and
     fraction of the HBM peak -- the per-kernel roofline the side-by-side default cannot show."""
     keep = os.environ.get("CMFREC_HIP_BINS_PAR")
     os.environ["CMFREC_HIP_BINS_PAR"] = "1"
