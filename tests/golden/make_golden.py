@@ -379,6 +379,16 @@ def main():
                 out["c%d_%s" % (ci, key)] = v
         save("g30_topn_old_" + tag, **out)
 
+        # ---- G31: observation weights together with SPARSE side information ----
+        out = {}
+        d = gc.weights_sparse_side_problem(dt)
+        for ci, (name, which, opts) in enumerate(gc.WEIGHT_SPARSE_SIDE_CASES):
+            r = gc.weights_sparse_side_reference(R, d, which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g31_weights_sparse_side_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

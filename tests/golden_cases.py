@@ -1195,6 +1195,73 @@ def weights_hip(d, side, opts, dtype, weights=True, nthreads=1):
     return out
 
 
+# ---- observation weights together with SPARSE side information (round 6): collective_closed_form_block's weight branches with
+#      u_vec_sp (collective.c:1636-1653, :1673-1699, :1738-1753) and collective_block_cg's (:2187-2208, :2292-2298) -- fixture g31
+def weights_sparse_side_problem(dtype, seed=83):
+    d = weights_problem(dtype, seed)
+    rng = np.random.default_rng(seed + 7)
+    m, n, p, q = d["m"], d["n"], 7, 6
+    def coo(rows, cols, cnt, empty):
+        lin = rng.choice(rows * cols, size=cnt, replace=False)
+        r = (lin // cols).astype(np.int32); c = (lin % cols).astype(np.int32)
+        keep = ~np.isin(r, empty)
+        return r[keep], c[keep]
+    ur, uc = coo(m, p, 3 * m, (2, 9)); ir, ic = coo(n - 3, q, 2 * n, (11,))
+    d["U_coo"] = (ur, uc, rng.standard_normal(len(ur)).astype(dtype), m, p)
+    d["I_coo"] = (ir, ic, rng.standard_normal(len(ir)).astype(dtype), n - 3, q)
+    d["p"], d["q"] = p, q
+    return d
+
+
+# (name, sides, options); closed form without centring for the reason given at WEIGHT_CASES
+WEIGHT_SPARSE_SIDE_CASES = [
+    ("chol", "UI", dict(use_cg=False, center=False, k_user=1, k_item=2)),
+    ("chol scale_lam", "UI", dict(use_cg=False, scale_lam=True, center=False, k_main=1)),
+    ("chol U, no biases", "U", dict(use_cg=False, center=False, user_bias=False, item_bias=False)),
+    ("cg scale_lam", "UI", dict(use_cg=True, finalize_chol=False, scale_lam=True, k_user=1)),
+    ("cg I", "I", dict(use_cg=True, finalize_chol=False, k_item=1, k_main=1)),
+    ("pcg finalize", "UI", dict(use_cg=True, precondition_cg=True, finalize_chol=True, center=False)),
+]
+
+
+def weights_sparse_side_reference(R, d, which, opts, nthreads=2):
+    o = dict(opts)
+    if "U" not in which: o["k_user"] = 0
+    if "I" not in which: o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    kw = dict(use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), **o)
+    ku, ki = o.get("k_user", 0), o.get("k_item", 0)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, w_user=2.0, w_item=0.5, nthreads=nthreads, weight=d["W"],
+                                      U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
+                                      Cm=np.zeros((d["p"], ku + d["k"]), d["A0"].dtype) if "U" in which else None,
+                                      Dm=np.zeros((d["q"], ki + d["k"]), d["A0"].dtype) if "I" in which else None, **kw)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def weights_sparse_side_hip(d, which, opts, dtype, weights=True):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "U" not in which: o["k_user"] = 0
+    if "I" not in which: o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    U = mk(d["U_coo"]) if "U" in which else None; II = mk(d["I_coo"]) if "I" in which else None
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), W=d["W"] if weights else None,
+            A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
 #      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
 # (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded

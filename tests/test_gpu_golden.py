@@ -329,6 +329,23 @@ def test_observation_weights(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_observation_weights_with_sparse_side_information(dtype):
+    """G31 through the estimator: observation weights on X together with sparse U / I -- the weighted row solvers with the row's
+    attributes as their second, unweighted gather source (closed form, block CG, its Jacobi-preconditioned form), sums of weights
+    under scale_lam.  The fixture's closed-form cases are pinned by plain linear algebra in tests/test_oracle_vs_ref.py."""
+    g = gc.load("g31_weights_sparse_side", dtype)
+    d = gc.weights_sparse_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, which, opts) in enumerate(gc.WEIGHT_SPARSE_SIDE_CASES):
+        got = gc.weights_sparse_side_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+    name, which, opts = gc.WEIGHT_SPARSE_SIDE_CASES[0]
+    assert gc.compare_fits(gc.weights_sparse_side_hip(d, which, opts, dtype, weights=False),
+                           {k[3:]: g[k] for k in g.files if k.startswith("c0_")}) > 1e-2
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_X(oracles, dtype):
     """G18 through the estimator (CMF(NA_as_zero=True)): the mean over all cells, one shared matrix per half-step, the
     right-hand-side constant of the opposing biases and the mean, rows and columns without entries solved like the others,

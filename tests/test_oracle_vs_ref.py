@@ -769,3 +769,49 @@ def test_standalone_fixtures_are_the_reference(dtype):
         got = gc.topn_call(lib, d, opts, dtype)
         assert np.array_equal(got["ids"], g["c%d_ids" % ci]), name
         assert np.abs(got["scores"] - g["c%d_scores" % ci]).max() <= tol * np.abs(g["c%d_scores" % ci]).max(), name
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_weights_sparse_side_fixture_normal_equations(ci):
+    """Fixture g31 (observation weights + sparse side information, closed form) checked by plain linear algebra: the A-step is the
+    last update of an iteration (collective.c:8802), so every row of the fixture's A solves
+        (sum_j w_ij b_j b_j^T  (+)  w_user sum_l c_l c_l^T  +  lam mult_i I) a_i = sum_j w_ij (x_ij - biasB_j) b_j  (+)  w_user sum_l u_il c_l
+    over the fixture's B, C and item biases, with b_j = [B_j, 1] when the user bias is fitted (its unknown is the last one) and
+    mult_i = the sum of the row's weights under scale_lam (collective.c:1285-1292)."""
+    import golden_cases as gc
+    dtype = np.float64
+    g = gc.load("g31_weights_sparse_side", dtype)
+    d = gc.weights_sparse_side_problem(dtype)
+    name, which, opts = gc.WEIGHT_SPARSE_SIDE_CASES[ci]
+    assert not opts.get("use_cg", False) and not opts.get("center", True)
+    ku = opts.get("k_user", 0) if "U" in which else 0
+    ki = opts.get("k_item", 0) if "I" in which else 0
+    km, k = opts.get("k_main", 0), d["k"]
+    A, B, Cm = g["c%d_A" % ci], g["c%d_B" % ci], g["c%d_C" % ci]
+    ub = opts.get("user_bias", True)
+    bB = g["c%d_biasB" % ci] if opts.get("item_bias", True) else np.zeros(d["n"])
+    bA = g["c%d_biasA" % ci] if ub else None
+    ur, uc, uv, m_u, p = d["U_coo"]
+    kt = ku + k + km + (1 if ub else 0)
+    lam, w_user = 0.3, 2.0
+    worst = 0.0
+    for i in range(d["m"]):
+        sel = d["row"] == i; usel = ur == i
+        if not sel.any() and not usel.any():
+            assert not A[i].any()
+            continue
+        M = np.zeros((kt, kt)); rhs = np.zeros(kt)
+        Bt = np.zeros((int(sel.sum()), kt)); Bt[:, ku:ku + k + km] = B[d["col"][sel], ki:]
+        if ub: Bt[:, -1] = 1.0
+        w = d["W"][sel]
+        M += (Bt * w[:, None]).T @ Bt
+        rhs += Bt.T @ (w * (d["ratings"][sel] - bB[d["col"][sel]]))
+        Ct = np.zeros((int(usel.sum()), kt)); Ct[:, :ku + k] = Cm[uc[usel]]
+        M += w_user * Ct.T @ Ct
+        rhs += w_user * Ct.T @ uv[usel]
+        mult = (w.sum() if sel.any() else 1.0) if opts.get("scale_lam", False) else 1.0
+        M += lam * mult * np.eye(kt)
+        sol = np.linalg.solve(M, rhs)
+        got = np.concatenate([A[i], [bA[i]]]) if ub else A[i]
+        worst = max(worst, np.abs(sol - got).max() / max(np.abs(sol).max(), 1e-30))
+    assert worst < 1e-9, (name, worst)
