@@ -1591,7 +1591,10 @@ cg_rows_generic_kernel(const CgParams<T> P)
                 for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);
             continue;
         }
-        const int lo = has_u ? 0 : koff;                      // rows without side information: the X block only (collective.c:4832-5101)
+        // rows without side information: the X block only (collective.c:4832-4900) -- but with implicit features the reference
+        // sends them through the block solver again with every unknown in the system (:4906-4960): the unknowns in front of the X
+        // block then see lambda alone and share the step lengths
+        const int lo = (has_u || (!IMPLICIT && P.Bi != nullptr)) ? 0 : koff;
         T lam = P.lam, lam_last = P.lam_last;
         if (!IMPLICIT) {
             if (has_u) {

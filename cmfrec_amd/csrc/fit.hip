@@ -966,16 +966,28 @@ int_t fit_collective_explicit_als(
     // in exact arithmetic -- and the closed form here); otherwise (Case 2) a row that misses fewer than twice as many entries
     // as its system has unknowns is solved in closed form from the precomputed B^T B (factors_closed_form, :662, :759-790:
     // that branch comes before the CG one), the others by the solver asked for.  A half-step that has rows of both kinds under
-    // use_cg runs both solvers (dense_cf_A / _B).  With weights every row takes the solver asked for.  Plain model only (no side information /
-    // implicit features).
+    // use_cg runs both solvers (dense_cf_A / _B).  With weights every row takes the solver asked for.
     DenseX dx;
     bool dense_chol_A = false, dense_chol_B = false;
     std::vector<unsigned char> dense_cf_A, dense_cf_B;
     std::vector<real_t> dense_mult_A, dense_mult_B;
     bool unit_weights = false;
+    // With side information (round 6, fixture g33): the side that has it goes through optimizeA_collective, whose dense-X branches are the
+    // same systems over the present entries (collective.c:5115-5565 shared factorisation + row-by-row corrections; :5566-5968 row by
+    // row; lambda's multiplier n - cnt_NA_x = the number of present entries, :1296-1302, no precomputed matrix with lambda inside) with
+    // this choice of solver: closed form whatever use_cg says when X is complete or nearly complete on that orientation and the side
+    // information is dense or missing-as-zero (:5121-5130), the solver asked for otherwise.  The side without side information keeps
+    // optimizeA's rules above.  Side information on exactly the rows / columns of X (the rows beyond it would take optimizeA's dense
+    // cases on a sub-block, :4832-5099), complete (no NaN), no weights.
+    const bool dense_side_A = Xfull && (U != nullptr || nnz_U > 0), dense_side_B = Xfull && (II != nullptr || nnz_I > 0);
+    const bool had_dense_X = Xfull != nullptr;
     if (Xfull) {
-        if (U || II || nnz_U || nnz_I || add_implicit_features || NA_as_zero_X)
-            return fail(verbose, "cmfrec_hip: dense X is implemented for the model without side information and implicit features.");
+        if (add_implicit_features || NA_as_zero_X)
+            return fail(verbose, "cmfrec_hip: dense X is implemented for the model without implicit features and NA_as_zero_X.");
+        if ((dense_side_A || dense_side_B) && (weight || NA_as_zero_U || NA_as_zero_I))
+            return fail(verbose, "cmfrec_hip: dense X with side information: not together with observation weights or NA_as_zero_U / _I.");
+        if ((dense_side_A && m_u != m) || (dense_side_B && n_i != n))
+            return fail(verbose, "cmfrec_hip: dense X with side information: U / I must have exactly the rows / columns of X.");
         if (m <= 0 || n <= 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");
         dx.convert(Xfull, weight, m, n);
         if (dx.val.empty()) return fail(verbose, "cmfrec_hip: 'X' has all entries missing.");
@@ -987,12 +999,13 @@ int_t fit_collective_explicit_als(
         // (cmfrec_hip_session_set_lambda_multipliers).
         if (!weight && (scale_lam || scale_lam_sideinfo)) {
             bool any = false;
-            for (int_t r = 0; r < m && !any; r++) any = (dx.na_row[r] > 0 && dx.na_row[r] < fewA);
-            for (int_t c = 0; c < n && !any; c++) any = (dx.na_col[c] > 0 && dx.na_col[c] < fewB);
+            for (int_t r = 0; r < m && !any && !dense_side_A; r++) any = (dx.na_row[r] > 0 && dx.na_row[r] < fewA);
+            for (int_t c = 0; c < n && !any && !dense_side_B; c++) any = (dx.na_col[c] > 0 && dx.na_col[c] < fewB);
             if (any) {
+                // (a side with side information: the present entries, like a sparse X -- collective.c:1296-1302)
                 dense_mult_A.resize((size_t)m); dense_mult_B.resize((size_t)n);
-                for (int_t r = 0; r < m; r++) dense_mult_A[r] = (dx.na_row[r] < fewA) ? (real_t)n : (dx.na_row[r] < n ? (real_t)(n - dx.na_row[r]) : (real_t)1);
-                for (int_t c = 0; c < n; c++) dense_mult_B[c] = (dx.na_col[c] < fewB) ? (real_t)m : (dx.na_col[c] < m ? (real_t)(m - dx.na_col[c]) : (real_t)1);
+                for (int_t r = 0; r < m; r++) dense_mult_A[r] = (!dense_side_A && dx.na_row[r] < fewA) ? (real_t)n : (dx.na_row[r] < n ? (real_t)(n - dx.na_row[r]) : (real_t)1);
+                for (int_t c = 0; c < n; c++) dense_mult_B[c] = (!dense_side_B && dx.na_col[c] < fewB) ? (real_t)m : (dx.na_col[c] < m ? (real_t)(m - dx.na_col[c]) : (real_t)1);
                 // (the bias start values of a weighted session do not restate scale_lam_sideinfo / scale_bias_const: say so here,
                 //  before anything is uploaded, and in terms of what the caller passed -- no weights)
                 if ((scale_lam_sideinfo || scale_bias_const) && user_bias && item_bias && reset_values)
@@ -1016,6 +1029,8 @@ int_t fit_collective_explicit_als(
             bool mixA = false, mixB = false;
             dense_chol_A = dx.full || dx.near_row || case2_chol(dx.na_row, n, fewA, mixA);
             dense_chol_B = dx.full || dx.near_col || case2_chol(dx.na_col, m, fewB, mixB);
+            if (dense_side_A) { dense_chol_A = (dx.full || dx.near_row) && U != nullptr; mixA = false; }
+            if (dense_side_B) { dense_chol_B = (dx.full || dx.near_col) && II != nullptr; mixB = false; }
             // a half-step with rows of both kinds under use_cg: the rows that miss few entries are marked for the closed form
             // (cmfrec_hip_session_set_closed_form_rows), the update runs both solvers
             if (use_cg && !nonneg && l1_lam == 0 && !l1_lam_unique) {
@@ -1094,12 +1109,11 @@ int_t fit_collective_explicit_als(
     }
     if (nan_side && nnz_U == 0 && nanU.row.empty() && hadU && U == nullptr)
         return fail(verbose, "cmfrec_hip: U has no present entries.");
-    // implicit features (Ai, Bi on the binary "was observed" matrix): closed-form solves, dense or no side information
-    // inside the shape of X, prediction matrices not produced
+    // implicit features (Ai, Bi on the binary "was observed" matrix): closed-form solves, dense, sparse (round 6, fixture g32) or no
+    // side information inside the shape of X, prediction matrices not produced
     if (add_implicit_features) {
         if (!Ai || !Bi) return fail(verbose, "cmfrec_hip: add_implicit_features needs the Ai and Bi outputs.");
-        if (nnz_U || nnz_I) return fail(verbose, "cmfrec_hip: implicit features with sparse side information are not implemented.");
-        if ((U && m_u > m) || (II && n_i > n))
+        if (((U || nnz_U) && m_u > m) || ((II || nnz_I) && n_i > n))
             return fail(verbose, "cmfrec_hip: implicit features with side information beyond X are not implemented.");
         if (precompute_for_predictions)
             return fail(verbose, "cmfrec_hip: implicit features: precompute_for_predictions is not implemented.");
@@ -1127,6 +1141,8 @@ int_t fit_collective_explicit_als(
     // non-negative / L1 solvers see another matrix layout -- not restated, so not offered.
     if (nan_side && (nonneg || nonneg_C || nonneg_D || l1_lam != 0 || l1_lam_unique))
         return fail(verbose, "cmfrec_hip: NaN in dense side information: not together with nonneg / L1.");
+    if (nan_side && had_dense_X)
+        return fail(verbose, "cmfrec_hip: dense X with side information: NaN in U / I is not implemented.");
     if (precompute_for_predictions && precomputedBtB == nullptr)
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     // observation weights (one per entry of X): every row solver and the start values of the biases take them; the lambda
@@ -1281,8 +1297,9 @@ int_t fit_collective_explicit_als(
     // :667-677) -- factors and bias -- whereas the sparse path leaves such rows at their start values
     auto zero_empty_dense = [&]() {
         if (dx.na_row.empty()) return;
-        for (int_t r = 0; r < m; r++) if (dx.na_row[r] == n) { memset(A + (size_t)r * k_totA, 0, (size_t)k_totA * sizeof(real_t)); if (biasA) biasA[r] = 0; }
-        for (int_t c = 0; c < n; c++) if (dx.na_col[c] == m) { memset(B + (size_t)c * k_totB, 0, (size_t)k_totB * sizeof(real_t)); if (biasB) biasB[c] = 0; }
+        // (a side with side information solves such rows from their attributes: optimizeA_collective, collective.c:1285-1331)
+        for (int_t r = 0; r < m && !dense_side_A; r++) if (dx.na_row[r] == n) { memset(A + (size_t)r * k_totA, 0, (size_t)k_totA * sizeof(real_t)); if (biasA) biasA[r] = 0; }
+        for (int_t c = 0; c < n && !dense_side_B; c++) if (dx.na_col[c] == m) { memset(B + (size_t)c * k_totB, 0, (size_t)k_totB * sizeof(real_t)); if (biasB) biasB[c] = 0; }
     };
     if (niter > 0) zero_empty_dense();
     cmfrec_hip_model mdl;

@@ -1464,10 +1464,6 @@ int cmfrec_hip_session_set_implicit_features(cmfrec_hip_session *s, real_t w_imp
             g_last_error = "cmfrec_hip: add_implicit_features: sharded sessions are not built";
             return 2;
         }
-        if (s->sparseU || s->sparseI) {
-            g_last_error = "cmfrec_hip: add_implicit_features together with sparse side information is not built";
-            return 2;
-        }
         if ((m.m_x > 0 && m.m_x < m.m) || (m.n_x > 0 && m.n_x < m.n)) {
             g_last_error = "cmfrec_hip: add_implicit_features: side information must not cover rows / columns beyond X";
             return 2;
@@ -2135,7 +2131,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
     const bool sparse_side = isA ? s->sparseU : s->sparseI;
     if (p_self > 0 && sparse_side) {
         // sparse side information (missing = absent): the row's attributes are a second gather source of the same
-        // Cholesky launch (collective.c:1636-1653, :1719-1731 / :2003-2021); the block CG on it is not built
+        // Cholesky launch (collective.c:1636-1653, :1719-1731 / :2003-2021) or of the lane <-> unknown CG kernel
         const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
         const SparseShard &Us = isA ? s->Usr : s->Isr;
         const int rows_u = isA ? m.m_u : m.n_i;
@@ -2162,10 +2158,16 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
                      (bool)m.precondition_cg};
             c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
             c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo; c.X2 = &Us; c.C2 = Cm;
+            if (s->implicit_feats && !m.implicit) {             // collective.c:2301-2304, :2624-2643, :2862-2868 (round 6: with u_vec_sp too)
+                const real_t *Fc = isA ? s->Bi.ptr : s->Ai.ptr;
+                launch_gram(dev, s->gws, Fc, (size_t)kk, rows_opp, kk, s->bitbi.ptr, (real_t)1, (real_t)0);
+                c.Bi = Fc; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit;
+                if (part < 0 && launch_gsum(s, isA, X, Fc, kk)) c.gsum = s->grhs.ptr;
+            }
             return launch_cg_any(dev, c, X, nullptr);
         }
-        if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822, :6018-6019
         if (m.implicit) {
+            if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :6018-6019
             const int kt = k_side_self + kk;
             launch_gram(dev, s->gws, opp + k_side_opp, ld_opp, rows_opp, kk, s->gram.ptr, (real_t)1, lam_self);
             hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d(kt * kt), dim3(256), 0, st, s->gram.ptr, kk, k_side_self, lam_self,
@@ -2175,17 +2177,7 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
             c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
             return launch_chol(dev, c, &X);
         }
-        if (self_bias) {
-            const int rows_fill = isA ? m.n : m.m;
-            hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_fill), dim3(256), 0, st, opp, ld_opp, rows_fill,
-                               isA ? s->k_totB : s->k_totA, (real_t)1);
-        }
-        const int kt = k_side_self + kk + (self_bias ? 1 : 0);
-        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr,
-                   nullptr, kc, rows_u, p_self, lam_self, lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo),
-                   (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE};
-        c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w;
-        return launch_chol(dev, c, &X);
+        // (the explicit model's closed form: below, after the implicit-features term it may carry)
     }
     if (p_self > 0 && !chol) {
         // block CG on the collective system, dense full side information: collective_block_cg (explicit,
@@ -2310,6 +2302,24 @@ static int update_factor(cmfrec_hip_session *s, bool isA, bool chol, int part = 
         c.X2 = &X; c.values2 = s->ones.ptr; c.B2 = Fi; c.ldb2 = (size_t)kk; c.kc2 = kk; c.koff2 = k_side_self;
         c.w2 = s->w_implicit; c.w2_syr_zero = true; c.rows2 = X.nrows;
     };
+    if (p_self > 0 && sparse_side) {
+        // sparse side information, closed form: the row's attributes as the second gather source (collective.c:1636-1653, :1719-1731);
+        // round 6: together with the implicit-features term (its right-hand side by the segmented gather-sum)
+        const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
+        const SparseShard &Us = isA ? s->Usr : s->Isr;
+        const int rows_u = isA ? m.m_u : m.n_i;
+        const int kc = k_side_self + m.k, kt = k_side_self + ksolve;
+        if (X.nrows) HIP_CHECK(hipMemsetAsync(self_blk, 0, (size_t)X.nrows * ld_self * sizeof(real_t), st));   // :4817-4822
+        CholCall c{self_blk, ld_self, opp + k_side_opp, ld_opp, kt, k_side_self, bias_sub, nullptr, kc, rows_u, p_self, lam_self,
+                   lam_last_self, (bool)(m.scale_lam || m.scale_lam_sideinfo), (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE};
+        add_implicit_term(c);
+        if (c.X2 != nullptr) {
+            g_last_error = "cmfrec_hip: implicit features with sparse side information: k + k_main beyond the gather-sum's width";
+            return 2;
+        }
+        c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = isA ? m.w_user : m.w_item;
+        return launch_chol(dev, c, &X);
+    }
     if (p_self > 0) {
         // optimizeA_collective general branch, Cholesky (collective.c:5566-5968)
         const real_t *Cm = isA ? s->C.ptr : s->D.ptr;

@@ -389,6 +389,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g31_weights_sparse_side_" + tag, **out)
 
+        # ---- G32: implicit features together with SPARSE side information ----
+        out = {}
+        d = gc.weights_sparse_side_problem(dt)
+        for ci, (name, which, opts) in enumerate(gc.IMPF_SPARSE_SIDE_CASES):
+            r = gc.impf_sparse_side_reference(R, d, which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g32_implicit_features_sparse_side_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):
@@ -397,6 +407,15 @@ def main():
                 if v is not None:
                     out["c%d_%s" % (ci, key)] = v
         save("g19_dense_X_" + tag, **out)
+
+        # ---- G33: dense X together with side information ----
+        out = {}
+        for ci, (name, variant, which, opts) in enumerate(gc.DENSE_SIDE_CASES):
+            r = gc.dense_side_reference(R, gc.dense_side_problem(dt, variant), which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g33_dense_X_sideinfo_" + tag, **out)
 
         # ---- G20: NA_as_zero_X together with dense side information (shared block matrix, collective.c:5607-5617) ----
         out = {}

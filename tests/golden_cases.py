@@ -1262,6 +1262,70 @@ def weights_sparse_side_hip(d, which, opts, dtype, weights=True):
     return out
 
 
+# ---- implicit features together with SPARSE side information (round 6): collective_closed_form_block with u_vec_sp and
+#      add_implicit_features (collective.c:1636-1653 beside :1704-1707, :1757-1771), collective_block_cg (:2292-2304) -- fixture g32
+IMPF_SPARSE_SIDE_CASES = [
+    ("chol UI", "UI", dict(k_user=2, k_item=1, k_main=1, w_implicit=1.5)),
+    ("chol scaled U", "U", dict(scale_lam=True, scale_lam_sideinfo=True, w_implicit=0.7)),
+    ("chol no biases", "UI", dict(user_bias=False, item_bias=False, center=False)),
+    ("cg UI", "UI", dict(use_cg=True, k_user=1, k_main=1, w_implicit=0.6)),
+    ("cg finalize I", "I", dict(use_cg=True, finalize_chol=True, k_item=1, scale_lam=True)),
+    ("pcg UI", "UI", dict(use_cg=True, precondition_cg=True, w_implicit=1.3, user_bias=False)),
+    # DENSE side information that covers fewer rows than X ("u" / "i": the first m - 4 users / n - 3 items): with implicit features
+    # the reference solves the remaining rows on the whole vector, not on the X block only (collective.c:4906-4960)
+    ("cg dense short U", "u", dict(use_cg=True, k_user=2, w_implicit=0.8)),
+    ("cg dense short UI finalize", "ui", dict(use_cg=True, finalize_chol=True, k_user=1, k_item=2, scale_lam=True)),
+    ("chol dense short I", "i", dict(k_item=1, k_main=1)),
+]
+
+
+def _impf_sides(d, which):
+    """(dense U, dense I, sparse U, sparse I) of a case: capitals = the sparse triplets, small letters = dense, fewer rows than X."""
+    return (d["U"][:d["m"] - 4] if "u" in which else None, d["I"][:d["n"] - 3] if "i" in which else None,
+            d["U_coo"] if "U" in which else None, d["I_coo"] if "I" in which else None)
+
+
+def impf_sparse_side_reference(R, d, which, opts, nthreads=2):
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    ku, ki = o.get("k_user", 0), o.get("k_item", 0)
+    Ud, Id, Us, Is = _impf_sides(d, which)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, w_user=2.0, w_item=0.5, nthreads=nthreads,
+                                      use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      U=Ud, II=Id, U_coo=Us, I_coo=Is,
+                                      Cm=np.zeros((d["p"], ku + d["k"]), d["A0"].dtype) if Us is not None else None,
+                                      Dm=np.zeros((d["q"], ki + d["k"]), d["A0"].dtype) if Is is not None else None,
+                                      add_implicit_features=True, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], glob_mean=r["glob_mean"], Ai=r["Ai"], Bi=r["Bi"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def impf_sparse_side_hip(d, which, opts, dtype):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    o.setdefault("w_implicit", 1.0)
+    A0, B0 = _impf_start(d, o)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    Ud, Id, Us, Is = _impf_sides(d, which)
+    U = mk(Us) if Us is not None else Ud; II = mk(Is) if Is is not None else Id
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), add_implicit_features=True, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_, Ai=mdl.Ai_, Bi=mdl.Bi_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
 #      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
 # (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded
@@ -1718,6 +1782,86 @@ def dense_hip(d, opts, dtype, as_sparse=False):
     else:
         mdl.fit(d["X"], W=d["Wfull"] if weights else None, **start)
     out = dict(A=mdl.A_, B=mdl.B_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
+# ---- dense X together with side information (round 6; fixture g33): optimizeA_collective's dense-X branches
+#      (collective.c:5115-5565 shared factorisation + corrections, :5566-5968 row by row) ------------------------------------------
+def dense_side_problem(dtype, variant, seed=137):
+    d = dense_problem(dtype, variant)
+    rng = np.random.default_rng(seed)
+    m, n, p, q = d["m"], d["n"], 5, 4
+    d["U"] = rng.standard_normal((m, p)).astype(dtype); d["I"] = rng.standard_normal((n, q)).astype(dtype)
+    def coo(rows, cols, cnt, empty):
+        lin = rng.choice(rows * cols, size=cnt, replace=False)
+        r = (lin // cols).astype(np.int32); c = (lin % cols).astype(np.int32)
+        keep = ~np.isin(r, empty)
+        return r[keep], c[keep]
+    ur, uc = coo(m, p, 3 * m, (2, 4)); ir, ic = coo(n, q, 2 * n, (7, 11))
+    d["U_coo"] = (ur, uc, rng.standard_normal(len(ur)).astype(dtype), m, p)
+    d["I_coo"] = (ir, ic, rng.standard_normal(len(ir)).astype(dtype), n, q)
+    d["p"], d["q"] = p, q
+    return d
+
+
+# (name, pattern of X, sides -- small letters dense, capitals sparse --, options)
+DENSE_SIDE_CASES = [
+    ("full, dense UI, chol", "full", "ui", dict(use_cg=False, k_user=1, k_item=1)),
+    ("full, dense UI, cg asked for, scaled", "full", "ui", dict(use_cg=True, finalize_chol=False, scale_lam=True, scale_lam_sideinfo=True)),
+    ("near dense, dense U only, cg asked for", "near", "u", dict(use_cg=True, finalize_chol=False, k_main=1)),
+    ("holes, dense UI, cg", "holes", "ui", dict(use_cg=True, finalize_chol=True, k_user=2)),
+    ("holes, dense UI, chol, scale_lam", "holes", "ui", dict(use_cg=False, scale_lam=True)),
+    ("holes, sparse UI, chol", "holes", "UI", dict(use_cg=False, k_item=1)),
+    # (a nearly complete X with one sparse and one dense side: the reference's own build dies with SIGSEGV -- "near" with "Ui" or "uI",
+    #  either solver, both precisions -- so that combination has nothing to be pinned against; both sparse or both dense run)
+    ("near dense, sparse UI, cg", "near", "UI", dict(use_cg=True, finalize_chol=False)),
+    ("full, sparse U + dense I, cg", "full", "Ui", dict(use_cg=True, finalize_chol=False, k_user=1)),
+    ("holes, sparse UI, pcg, no biases", "holes", "UI", dict(use_cg=True, precondition_cg=True, finalize_chol=False, user_bias=False, item_bias=False)),
+    ("rows and columns on both sides, dense U, chol, scale_lam", "split2", "u", dict(use_cg=False, scale_lam=True)),
+]
+
+
+def _dense_sides(d, which):
+    return (d["U"] if "u" in which else None, d["I"] if "i" in which else None,
+            d["U_coo"] if "U" in which else None, d["I_coo"] if "I" in which else None)
+
+
+def dense_side_reference(R, d, which, opts, nthreads=2):
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    ku, ki = o.get("k_user", 0), o.get("k_item", 0)
+    Ud, Id, Us, Is = _dense_sides(d, which)
+    r = R.fit_collective_explicit_als(A0, B0, None, None, None, d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3, niter=3,
+                                      w_user=2.0, w_item=0.5, nthreads=nthreads, Xfull=d["X"],
+                                      use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      U=Ud, II=Id, U_coo=Us, I_coo=Is,
+                                      Cm=np.zeros((d["p"], ku + d["k"]), d["A0"].dtype) if Us is not None else None,
+                                      Dm=np.zeros((d["q"], ki + d["k"]), d["A0"].dtype) if Is is not None else None, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def dense_side_hip(d, which, opts, dtype):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    Ud, Id, Us, Is = _dense_sides(d, which)
+    U = mk(Us) if Us is not None else Ud; II = mk(Is) if Is is not None else Id
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
+              use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1, **o)
+    mdl.fit(d["X"], U=U, I=II, A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
     if mdl.user_bias: out["biasA"] = mdl.user_bias_
     if mdl.item_bias: out["biasB"] = mdl.item_bias_
     return out

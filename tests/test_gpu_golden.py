@@ -346,6 +346,39 @@ def test_observation_weights_with_sparse_side_information(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_implicit_features_with_sparse_side_information(dtype):
+    """G32 through the estimator: add_implicit_features together with sparse U / I -- the row solvers with the attributes as
+    their second gather source AND the implicit-features term (w_i Bi^T Bi in every row's matrix, w_i sum of the observed rows of Bi
+    in its right-hand side), closed form and block CG / PCG.  The closed-form cases are pinned by plain linear algebra in
+    tests/test_oracle_vs_ref.py."""
+    g = gc.load("g32_implicit_features_sparse_side", dtype)
+    d = gc.weights_sparse_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    for ci, (name, which, opts) in enumerate(gc.IMPF_SPARSE_SIDE_CASES):
+        got = gc.impf_sparse_side_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dense_X_with_side_information(dtype):
+    """G33 through the estimator: a dense X (NaN = missing) together with dense / sparse side information -- the present entries on
+    the collective row solvers, the reference's choice of solver per half-step (closed form whatever use_cg says where X is complete
+    or nearly complete on that orientation and the side information is dense; the solver asked for otherwise; the side without side
+    information by optimizeA's own dense rules), lambda's multipliers by present entries."""
+    g = gc.load("g33_dense_X_sideinfo", dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    bad = []
+    for ci, (name, variant, which, opts) in enumerate(gc.DENSE_SIDE_CASES):
+        got = gc.dense_side_hip(gc.dense_side_problem(dtype, variant), which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        err = gc.compare_fits(got, exp)
+        if not (exp and err < tol):
+            bad.append((name, err))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_X(oracles, dtype):
     """G18 through the estimator (CMF(NA_as_zero=True)): the mean over all cells, one shared matrix per half-step, the
     right-hand-side constant of the opposing biases and the mean, rows and columns without entries solved like the others,
@@ -544,12 +577,12 @@ def test_dense_X(oracles, dtype):
     d = gc.dense_problem(dtype, "holes")
     got = gc.dense_hip(d, dict(use_cg=False), dtype)
     assert not got["A"][4].any() and not got["B"][7].any() and got["biasA"][4] == 0 and got["biasB"][7] == 0
-    # refused: side information, NA_as_zero (scale_lam with rows that miss only a few entries -- the reference's multiplier there
-    # is n, not the entry count -- is among the cases above)
+    # refused: side information on other rows than X has, NA_as_zero (scale_lam with rows that miss only a few entries -- the
+    # reference's multiplier there is n, not the entry count -- is among the cases above; side information: test_dense_X_with_side_information)
     from cmfrec_amd import CMF
     dn = gc.dense_problem(dtype, "near")
     with pytest.raises(RuntimeError):
-        CMF(k=4, precompute_for_predictions=False).fit(dn["X"], U=np.ones((dn["m"], 2), dtype))
+        CMF(k=4, precompute_for_predictions=False).fit(dn["X"], U=np.ones((dn["m"] - 3, 2), dtype))
     # under use_cg a half-step whose rows partly miss few and partly many entries runs both solvers (the 'split' cases above): the
     # result is neither the all-CG nor the all-closed-form fit of the same entries
     ds = gc.dense_problem(dtype, "split")

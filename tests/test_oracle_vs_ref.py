@@ -815,3 +815,54 @@ def test_weights_sparse_side_fixture_normal_equations(ci):
         got = np.concatenate([A[i], [bA[i]]]) if ub else A[i]
         worst = max(worst, np.abs(sol - got).max() / max(np.abs(sol).max(), 1e-30))
     assert worst < 1e-9, (name, worst)
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_implicit_features_sparse_side_fixture_normal_equations(ci):
+    """Fixture g32 (implicit features + sparse side information, closed form) by plain linear algebra, as for g31: every row of the
+    fixture's A solves the system of its X entries, its attributes and the implicit-features term  w_i Bi^T Bi  /  w_i sum_j Bi_j
+    on the X block (collective.c:1704-1707, :1757-1771); lambda's multiplier under scale_lam (+ scale_lam_sideinfo) is the number of
+    entries (+ of present attributes), :1285-1346."""
+    import golden_cases as gc
+    dtype = np.float64
+    g = gc.load("g32_implicit_features_sparse_side", dtype)
+    d = gc.weights_sparse_side_problem(dtype)
+    name, which, opts = gc.IMPF_SPARSE_SIDE_CASES[ci]
+    assert not opts.get("use_cg", False)
+    ku = opts.get("k_user", 0) if "U" in which else 0
+    ki = opts.get("k_item", 0) if "I" in which else 0
+    km, k = opts.get("k_main", 0), d["k"]
+    A, B, Cm, Bi = g["c%d_A" % ci], g["c%d_B" % ci], g["c%d_C" % ci], g["c%d_Bi" % ci]
+    ub = opts.get("user_bias", True)
+    bB = g["c%d_biasB" % ci] if opts.get("item_bias", True) else np.zeros(d["n"])
+    bA = g["c%d_biasA" % ci] if ub else None
+    gm = float(g["c%d_glob_mean" % ci]) if opts.get("center", True) else 0.0
+    ur, uc, uv, m_u, p = d["U_coo"]
+    kt = ku + k + km + (1 if ub else 0)
+    lam, w_user, w_imp = 0.3, 2.0, opts.get("w_implicit", 1.0)
+    BiTBi = Bi.T @ Bi
+    worst = 0.0
+    for i in range(d["m"]):
+        sel = d["row"] == i; usel = ur == i
+        if not sel.any() and not usel.any():
+            assert not A[i].any()
+            continue
+        M = np.zeros((kt, kt)); rhs = np.zeros(kt)
+        Bt = np.zeros((int(sel.sum()), kt)); Bt[:, ku:ku + k + km] = B[d["col"][sel], ki:]
+        if ub: Bt[:, -1] = 1.0
+        M += Bt.T @ Bt
+        rhs += Bt.T @ (d["ratings"][sel] - gm - bB[d["col"][sel]])
+        Ct = np.zeros((int(usel.sum()), kt)); Ct[:, :ku + k] = Cm[uc[usel]]
+        M += w_user * Ct.T @ Ct
+        rhs += w_user * Ct.T @ uv[usel]
+        M[ku:ku + k + km, ku:ku + k + km] += w_imp * BiTBi
+        rhs[ku:ku + k + km] += w_imp * Bi[d["col"][sel]].sum(axis=0)
+        mult = 1.0
+        if opts.get("scale_lam", False) or opts.get("scale_lam_sideinfo", False):
+            mult = float(sel.sum()) if sel.any() else 1.0
+            if opts.get("scale_lam_sideinfo", False): mult += float(usel.sum())
+        M += lam * mult * np.eye(kt)
+        sol = np.linalg.solve(M, rhs)
+        got = np.concatenate([A[i], [bA[i]]]) if ub else A[i]
+        worst = max(worst, np.abs(sol - got).max() / max(np.abs(sol).max(), 1e-30))
+    assert worst < 1e-9, (name, worst)
