@@ -1586,7 +1586,9 @@ cg_rows_generic_kernel(const CgParams<T> P)
         const bool sparse_u = P.indptr2 != nullptr;
         const size_t st2 = (sparse_u && has_u) ? P.indptr2[row] : 0;
         const int nnz2 = (sparse_u && has_u) ? (int)(P.indptr2[row + 1] - st2) : 0;
-        if (sparse_u && has_u && nnz == 0 && nnz2 == 0) {     // neither observations nor attributes: zeros (collective.c:1258-1268)
+        // neither observations nor attributes: zeros (collective.c:1258-1268) -- unless the main matrix is missing-as-zero and its
+        // constant exists (gx == 2; :1260-1261): then the row is solved like the others
+        if (sparse_u && has_u && nnz == 0 && nnz2 == 0 && P.gx != 2) {
             if (TEAM == 1 || wv == 0)
                 for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);
             continue;

@@ -583,6 +583,7 @@ struct CgCall {
     size_t ldr_x = 0;
     const real_t *values_override = nullptr, *weights_override = nullptr;
     bool gx_all_rows = false;         // ... with the preconditioner (generic kernel): the rows without entries are part of the launch
+    const real_t *wsum_override = nullptr;   // lambda's per-row multipliers under scale_lam instead of the rows' own counts / sums
 };
 
 enum class CgVariant { Auto, Generic };
@@ -1000,6 +1001,25 @@ inline int launch_cg(const DeviceInfo &dev, const CgCall &c, const SparseShard &
     const int S = (c.k + 7) / 8;
     if (c.values_override != nullptr) P.values = c.values_override;
     if (c.weights_override != nullptr) { P.weights = c.weights_override; P.wsum = X.wsum_naz.ptr; }     // (NA_as_zero_X with weights only)
+    if (c.wsum_override != nullptr) P.wsum = c.wsum_override;
+    if (c.Gx != nullptr && (c.kc > 0 || c.X2 != nullptr || c.Bi != nullptr)) {
+        // block systems whose X block is a matrix every row shares (NA_as_zero_X: collective_block_cg's NA_as_zero_X branches with the
+        // precomputed B^T B, collective.c:2430-2445, :2700-2760): the lane <-> unknown kernel with CgParams::gx, every row of the launch
+        if (c.implicit || c.skip_first != 0) {
+            g_last_error = "cmfrec_hip: block CG with a shared matrix: the explicit model";
+            return 2;
+        }
+        P.BtB = c.Gx; P.rconst = c.rconst_x; P.ldr = c.ldr_x; P.gx = c.gx_all_rows ? 2 : 1;   // 2: the constant of the biases / the mean exists
+        const int NFb = (c.koff + c.k + 63) / 64;
+        switch (NFb) {
+            case 1: launch_cg_generic<1, false>(dev, P, X, 0, true); return 0;
+            case 2: launch_cg_generic<2, false>(dev, P, X, 0, true); return 0;
+            case 3: launch_cg_generic<3, false>(dev, P, X, 0, true); return 0;
+            default: break;
+        }
+        g_last_error = "cmfrec_hip: block CG with a shared matrix: at most 192 unknowns per row";
+        return 2;
+    }
     if (c.Gx != nullptr && c.precond) {
         // ... with the Jacobi preconditioner (factors_explicit_pcg_NA_as_zero_weighted, common.c:1443-1613): the lane <-> unknown kernel
         // with the shared matrix and the per-row constant (CgParams::gx), any width it takes

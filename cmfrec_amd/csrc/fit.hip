@@ -1052,15 +1052,13 @@ int_t fit_collective_explicit_als(
         return fail(verbose, "cmfrec_hip: NA_as_zero_X with precompute_for_predictions: the model without side information and implicit features.");
     // ... with implicit features (round 5): the model without side information and weights, closed form (optimizeA_collective's
     // general branch on a matrix all rows share, collective.c:8612 / :8783 -> :1534-1846)
-    if (NA_as_zero_X && add_implicit_features && (U || II || nnz_U || nnz_I || weight != nullptr || use_cg))
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information and weights, closed "
-                             "form (use_cg = false).");
+    // (use_cg is accepted: the reference takes its closed-form Case 1 whatever the solver asked for, collective.c:5121-5130)
+    if (NA_as_zero_X && add_implicit_features && (U || II || nnz_U || nnz_I || weight != nullptr))
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information and weights.");
     // ... with SPARSE side information (round 5): row by row on the shared B^T B plus the rank-1 terms of the row's own attributes
     // (collective_closed_form_block with prefer_BtB, collective.c:1534-1846) -- closed form, side information on exactly the rows /
     // columns of X, no weights
     if (NA_as_zero_X && ((U == nullptr && nnz_U) || (II == nullptr && nnz_I))) {
-        if (use_cg)
-            return fail(verbose, "cmfrec_hip: NA_as_zero_X with sparse side information: closed form only (use_cg = false).");
         if (weight != nullptr || NA_as_zero_U || NA_as_zero_I)
             return fail(verbose, "cmfrec_hip: NA_as_zero_X with sparse side information: not together with weights or NA_as_zero_U / _I.");
         if ((U == nullptr && nnz_U && m_u != m) || (II == nullptr && nnz_I && n_i != n))

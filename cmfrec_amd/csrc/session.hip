@@ -1743,10 +1743,6 @@ static int update_factor_naz_sparse_side(cmfrec_hip_session *s, bool isA, bool c
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
-    if (!chol) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with sparse side information: closed form only (use_cg = false)";
-        return 2;
-    }
     const int p_self = isA ? m.p : m.q, rows_u = isA ? m.m_u : m.n_i;
     const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
     if (rows_u != rows_self) {
@@ -1769,6 +1765,50 @@ static int update_factor_naz_sparse_side(cmfrec_hip_session *s, bool isA, bool c
     if (self_bias)
         hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
     launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);
+    if (!chol) {
+        // Block CG (round 6; collective_block_cg with NA_as_zero_X and u_vec_sp, collective.c:2134-2903): the X block of every row's
+        // system is the shared B^T B (:2430-2445 first residual, :2700-2760 the products), its right-hand side sum_j x_j b_j + cst;
+        // the row's attributes gather rows of C.  On the lane <-> unknown kernel: B^T B as its shared matrix (CgParams::gx), the
+        // right-hand side of the X block as the per-row constant of the first residual, the entries of X with rank-1 weight zero.
+        s->naz_rhs.alloc_at_least((size_t)rows_self * ks);
+        HIP_CHECK(hipMemsetAsync(s->naz_rhs.ptr, 0, (size_t)rows_self * ks * sizeof(real_t), st));
+        {
+            CholCall cr{s->naz_rhs.ptr, (size_t)ks, oppx, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
+            cr.rhs_only = true;
+            int rc = launch_chol(dev, cr, &X);
+            if (rc) return rc;
+        }
+        if (opp_bias || s->naz_center) {
+            const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
+            s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
+            const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
+            hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, oppx, ld_opp, rows_opp, ks, bias,
+                               s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
+            hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
+            hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, s->naz_rhs.ptr, (size_t)ks, (size_t)rows_self, ks,
+                               s->naz_vec.ptr);
+        }
+        const size_t nnz = std::max<size_t>(X.nnz, 1);
+        if (s->naz_zero.n < nnz) {
+            s->naz_zero.alloc(nnz);
+            HIP_CHECK(hipMemsetAsync(s->naz_zero.ptr, 0, nnz * sizeof(real_t), st));
+        }
+        const bool scaled_cg = m.scale_lam || m.scale_lam_sideinfo;
+        if (scaled_cg) {
+            s->naz_mult.alloc_at_least((size_t)rows_self);
+            hipLaunchKernelGGL(fill_kernel<real_t>, grid1d((size_t)rows_self), dim3(256), 0, st, s->naz_mult.ptr, (size_t)rows_self, (real_t)rows_opp);
+        }
+        HIP_CHECK(hipGetLastError());
+        CgCall c{self, ld_self, oppx, ld_opp, ks, nullptr, nullptr, lam_self, lam_last_self, scaled_cg, false, m.max_cg_steps, false,
+                 (bool)m.precondition_cg};
+        c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
+        c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo; c.X2 = &Us; c.C2 = Cm;
+        c.Gx = s->gram.ptr; c.rconst_x = s->naz_rhs.ptr; c.ldr_x = (size_t)ks;
+        c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_zero.ptr;
+        if (scaled_cg) c.wsum_override = s->naz_mult.ptr;
+        c.gx_all_rows = opp_bias || s->naz_center;         // rows with neither entries nor attributes: solved from the constant, zero without it
+        return launch_cg(dev, c, X);
+    }
     s->naz_M.alloc_at_least((size_t)kt * kt);
     hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, st, s->gram.ptr, ks, k_side_self, (real_t)0, s->naz_M.ptr);
     // right-hand sides start from [0 ; cst]
@@ -1822,8 +1862,10 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
     // optimizeA_collective's general branch (collective.c:8612 / :8783 -> :1534-1846 with prefer_BtB), which without side
     // information is ONE matrix for all rows, B^T B + w_i Bi^T Bi + lam mult I, and right-hand sides X B + w_i sum_{observed} Bi_j
     // + the constant: the shared-matrix half-step below with two more terms.  Closed form (the block CG is not restated).
-    if (s->implicit_feats && (m.p > 0 || m.q > 0 || !chol)) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information, closed form (use_cg = false)";
+    // (use_cg: the reference takes its closed-form Case 1 here whatever the solver asked for -- collective.c:5121-5130 -- and returns
+    //  the same numbers bit for bit)
+    if (s->implicit_feats && (m.p > 0 || m.q > 0)) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information";
         return 2;
     }
     if (p_self > 0 && (isA ? s->sparseU : s->sparseI)) return update_factor_naz_sparse_side(s, isA, chol);

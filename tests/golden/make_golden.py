@@ -360,6 +360,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g28_na_as_zero_weighted_sideinfo_" + tag, **out)
 
+        # ---- G35: ... under use_cg ----
+        out = {}
+        d = gc.naz_weighted_problem(dt)
+        for ci, (name, sides, opts) in enumerate(gc.NAZ_WEIGHTED_SIDE_CG_CASES):
+            r = gc.naz_side_reference(R, d, sides, opts, weights=True)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g35_na_as_zero_weighted_sideinfo_cg_" + tag, **out)
+
         # ---- G29: the stand-alone prediction matrices (precompute_collective_explicit / _implicit) ----
         out = {}
         d = gc.precompute_problem(dt)
@@ -398,6 +408,16 @@ def main():
                 if v is not None:
                     out["c%d_%s" % (ci, key)] = v
         save("g32_implicit_features_sparse_side_" + tag, **out)
+
+        # ---- G34: NA_as_zero for the main matrix together with sparse side information under use_cg ----
+        out = {}
+        d = gc.naz_sparse_side_problem(dt)
+        for ci, (name, which, opts) in enumerate(gc.NAZ_SPARSE_SIDE_CG_CASES):
+            r = gc.naz_sparse_side_reference(R, d, which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g34_na_as_zero_sparse_side_cg_" + tag, **out)
 
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}

@@ -525,6 +525,15 @@ NAZ_SPARSE_SIDE_CASES = [
 ]
 
 
+# ... under use_cg (round 6; fixture g34): collective_block_cg's NA_as_zero_X branches with the row's attributes as a sparse vector
+NAZ_SPARSE_SIDE_CG_CASES = [
+    ("cg, both sides", "UI", dict(use_cg=True, finalize_chol=False)),
+    ("cg, scaled, finalize", "UI", dict(use_cg=True, finalize_chol=True, scale_lam=True, scale_lam_sideinfo=True)),
+    ("pcg, user side, no biases", "U", dict(use_cg=True, precondition_cg=True, finalize_chol=False, user_bias=False, item_bias=False, center=False)),
+    ("cg, item side, user bias", "I", dict(use_cg=True, finalize_chol=False, item_bias=False)),
+]
+
+
 def _naz_sparse_args(d, which, opts):
     o = dict(opts); nks = o.pop("no_k_side", False)
     ku = d["ku"] if ("U" in which and not nks) else 0; ki = d["ki"] if ("I" in which and not nks) else 0
@@ -535,7 +544,8 @@ def _naz_sparse_args(d, which, opts):
 def naz_sparse_side_reference(R, d, which, opts, nthreads=2):
     o, ku, ki, A0, B0 = _naz_sparse_args(d, which, opts)
     r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(), lam=0.3,
-                                      k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads, use_cg=False,
+                                      k_main=d["km"], k_user=ku, k_item=ki, w_user=3.0, w_item=0.7, niter=3, nthreads=nthreads,
+                                      use_cg=o.pop("use_cg", False),
                                       U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None,
                                       NA_as_zero_X=True, **o)
     assert r["ret"] == 0
@@ -1567,6 +1577,16 @@ NAZ_WEIGHTED_SIDE_CASES = [
     ("user side only", "U", dict()),
     ("item side only, scale_lam", "I", dict(scale_lam=True)),
     ("per-matrix lambdas, item bias", "UI", dict(lam_unique=LAM6, user_bias=False)),
+]
+
+
+# ... under use_cg (round 6; fixture g35): collective_block_cg's NA_as_zero_X + weight branches (collective.c:2446-2493, :2700-2760) for
+# the rows with entries, the shared factorisation for the rows without (:1367-1372)
+NAZ_WEIGHTED_SIDE_CG_CASES = [
+    ("cg, both sides", "UI", dict(use_cg=True, finalize_chol=False)),
+    ("cg, scaled", "UI", dict(use_cg=True, finalize_chol=False, scale_lam=True, scale_lam_sideinfo=True)),
+    ("pcg, user side, k_user, user bias", "U", dict(use_cg=True, precondition_cg=True, finalize_chol=False, k_user=2, center=False, item_bias=False)),
+    ("cg + finalize, item side", "I", dict(use_cg=True, finalize_chol=True)),
 ]
 
 

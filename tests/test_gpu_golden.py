@@ -458,8 +458,12 @@ def test_NA_as_zero_X_sparse_sideinfo(oracles, dtype):
     # the option changes the model; CG is refused (the reference's block CG with NA_as_zero_X is not restated)
     c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
     assert gc.compare_fits(gc.naz_sparse_side_hip(d, "UI", {}, dtype, NA_as_zero=False), c0) > 1e-2
-    with pytest.raises(RuntimeError):
-        gc.naz_sparse_side_hip(d, "UI", {}, dtype, use_cg=True)
+    # ... under use_cg (G34): the block CG with the shared B^T B on the lane <-> unknown kernel
+    g = gc.load("g34_na_as_zero_sparse_side_cg", dtype)
+    for ci, (name, which, opts) in enumerate(gc.NAZ_SPARSE_SIDE_CG_CASES):
+        got = gc.naz_sparse_side_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert exp and gc.compare_fits(got, exp) < tol, name
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -476,8 +480,12 @@ def test_NA_as_zero_X_implicit_features(oracles, dtype):
         assert gc.compare_fits(got, gc.naz_impf_oracle(oracles[dtype], d, opts)) < tol, name
     c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
     assert gc.compare_fits(gc.naz_impf_hip(d, {}, dtype, NA_as_zero=False), c0) > 1e-2
-    with pytest.raises(RuntimeError):
-        gc.naz_impf_hip(d, {}, dtype, use_cg=True)          # the block CG with NA_as_zero_X is not restated
+    # use_cg: the reference takes its closed-form Case 1 whatever the solver asked for (collective.c:5121-5130; bit for bit the same
+    # numbers from the compiled reference) -- so does the product
+    for ci in (0, 3):
+        name, opts = gc.NAZ_IMPF_CASES[ci]
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        assert gc.compare_fits(gc.naz_impf_hip(d, opts, dtype, use_cg=True, finalize_chol=False), exp) < tol, name
 
 
 @pytest.mark.parametrize("dtype", DT)
