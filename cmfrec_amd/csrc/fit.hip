@@ -1070,8 +1070,6 @@ int_t fit_collective_explicit_als(
     // with start values for the biases: the reference's own (initialize_biases with NA_as_zero and weights) index the item biases
     // by row inside the item sweep (common.c:4727-4731).
     if (NA_as_zero_X && weight != nullptr) {
-        if ((U || II) && use_cg)
-            return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights and side information: closed form only (use_cg = false).");
         if ((user_bias || item_bias) && reset_values)
             return fail(verbose, "cmfrec_hip: NA_as_zero_X with observation weights: pass start values for the biases (reset_values = false); "
                                  "the reference's own start values are not defined for this combination.");

@@ -1977,10 +1977,6 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
-    if (!chol) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights and side information: closed form only (use_cg = false)";
-        return 2;
-    }
     const int p_self = isA ? m.p : m.q, rows_u = isA ? m.m_u : m.n_i;
     const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
     if (rows_u != rows_self) {
@@ -2005,12 +2001,59 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
     launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);
     s->naz_M.alloc_at_least((size_t)kt * kt);
     hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, st, s->gram.ptr, ks, k_side_self, (real_t)0, s->naz_M.ptr);
+    const bool has_cst = opp_bias || s->naz_center;
+    const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
+    if (!chol) {
+        // Block CG (round 6; fixture g35).  The rows WITH entries: collective_block_cg with NA_as_zero_X and weights (collective.c:2446-2493
+        // first residual, :2700-2760 products) -- the shared B^T B, the corrections (w_j - 1) b_j b_j^T of the row's entries, the dense
+        // side-information block through C^T C and U C -- on the lane <-> unknown kernel (CgParams::gx).  The rows WITHOUT entries run
+        // the same CG from their side information and the constant: the reference factorises the shared block matrix for them only
+        // when the caller hands it the buffers of precompute_for_predictions (filled_BtB, :5702-5716), which this model does not offer.
+        real_t *uc = isA ? s->ucA.ptr : s->ucB.ptr;
+        launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, (real_t)1, (real_t)0);                 // C^T C, unweighted
+        launch_gemm<false>(dev, rows_self, kc, p_self, (real_t)1, Um, (size_t)p_self, Cm, (size_t)kc, uc, (size_t)kc);   // U C
+        const size_t nnzc = X.nnz;
+        s->naz_g.alloc_at_least(std::max<size_t>(nnzc, 1)); s->naz_xt.alloc_at_least(std::max<size_t>(nnzc, 1));
+        if (nnzc > 0)
+            hipLaunchKernelGGL(naz_entry_transform_kernel<real_t>, grid1d(nnzc), dim3(256), 0, st, X.v.ptr, X.w.ptr, X.i.ptr, nnzc,
+                               has_cst ? bias : nullptr, s->naz_center ? s->naz_mean : (real_t)0, s->naz_g.ptr, s->naz_xt.ptr);
+        s->naz_rhs.alloc_at_least((size_t)rows_self * ks);
+        HIP_CHECK(hipMemsetAsync(s->naz_rhs.ptr, 0, (size_t)rows_self * ks * sizeof(real_t), st));
+        {
+            CholCall cr{s->naz_rhs.ptr, (size_t)ks, oppx, ld_opp, ks, 0, nullptr, s->gram.ptr, 0, 0, 0, lam_self, lam_last_self, false, false, false, CHOL_NAZ};
+            cr.rhs_only = true; cr.values_override = s->naz_xt.ptr;
+            int rc = launch_chol(dev, cr, &X);
+            if (rc) return rc;
+        }
+        if (has_cst) {
+            const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
+            s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
+            hipLaunchKernelGGL(weighted_colsum_partial_kernel<real_t>, dim3(nb), dim3(256), 0, st, oppx, ld_opp, rows_opp, ks, bias,
+                               s->naz_center ? s->naz_mean : (real_t)0, s->naz_part.ptr);
+            hipLaunchKernelGGL(colsum_finish_kernel<real_t>, grid1d(ks), dim3(256), 0, st, s->naz_part.ptr, nb, ks, (real_t)-1, s->naz_vec.ptr);
+            hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, s->naz_rhs.ptr, (size_t)ks, (size_t)rows_self, ks,
+                               s->naz_vec.ptr);
+        }
+        const size_t nz = std::max<size_t>(nnzc, 1);
+        if (s->naz_zero.n < nz) {
+            s->naz_zero.alloc(nz);
+            HIP_CHECK(hipMemsetAsync(s->naz_zero.ptr, 0, nz * sizeof(real_t), st));
+        }
+        HIP_CHECK(hipGetLastError());
+        const bool scaled_cg = m.scale_lam || m.scale_lam_sideinfo;
+        CgCall c{self, ld_self, oppx, ld_opp, ks, nullptr, nullptr, lam_self, lam_last_self, scaled_cg, false, m.max_cg_steps, false,
+                 (bool)m.precondition_cg};
+        c.koff = k_side_self; c.kc = kc; c.CtC = s->ctc.ptr; c.UC = uc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
+        c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo;
+        c.Gx = s->gram.ptr; c.rconst_x = s->naz_rhs.ptr; c.ldr_x = (size_t)ks;
+        c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_g.ptr;      // (the multipliers: X.wsum_naz, launch_cg)
+        c.gx_all_rows = has_cst;
+        return launch_cg(dev, c, X);
+    }
     launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);
     // right-hand sides start from [w U C ; cst]
     HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
     launch_gemm<false>(dev, rows_self, kc, p_self, w, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
-    const bool has_cst = opp_bias || s->naz_center;
-    const real_t *bias = opp_bias ? (isA ? s->biasB.ptr : s->biasA.ptr) : nullptr;
     if (has_cst) {
         const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
         s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);

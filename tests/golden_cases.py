@@ -1595,7 +1595,7 @@ def naz_side_reference(R, d, sides, opts, nthreads=2, weights=False):
     seed = o.pop("seed", None)
     A0, B0 = _impf_start(d, o)
     U, II = _naz_side(d, sides)
-    kw = dict(U=U, II=II, lam=0.3, niter=3, nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
+    kw = dict(U=U, II=II, lam=0.3, niter=o.pop("niter", 3), nthreads=nthreads, NA_as_zero_X=True, use_cg=o.pop("use_cg", False),
               finalize_chol=o.pop("finalize_chol", False), **o)
     if weights: kw["weight"] = d["W"]
     if seed is not None:

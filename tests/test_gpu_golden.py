@@ -526,11 +526,19 @@ def test_NA_as_zero_X_weighted_sideinfo(oracles, dtype):
         exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
         assert exp and gc.compare_fits(got, exp) < tol, name
         assert gc.compare_fits(got, gc.naz_side_oracle(oracles[dtype], d, sides, opts, weights=True)) < tol, name
-    # the weights change the model, and the CG variant is refused
+    # the weights change the model
     c0 = {k[3:]: g[k] for k in g.files if k.startswith("c0_")}
     assert gc.compare_fits(gc.naz_side_hip(d, "UI", dict(), dtype), c0) > 1e-3
-    with pytest.raises(RuntimeError):
-        gc.naz_side_hip(d, "UI", dict(use_cg=True), dtype, weights=True)
+    # ... under use_cg (G35): the block CG with the shared B^T B, the entries' corrections and the dense side-information block for the rows
+    # with entries, the shared factorisation for the others
+    g = gc.load("g35_na_as_zero_weighted_sideinfo_cg", dtype)
+    bad = []
+    for ci, (name, sides, opts) in enumerate(gc.NAZ_WEIGHTED_SIDE_CG_CASES):
+        got = gc.naz_side_hip(d, sides, opts, dtype, weights=True)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        err = gc.compare_fits(got, exp)
+        if not (exp and err < tol): bad.append((name, err))
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("dtype", DT)
