@@ -984,6 +984,8 @@ int_t fit_collective_explicit_als(
     if (Xfull) {
         if (add_implicit_features || NA_as_zero_X)
             return fail(verbose, "cmfrec_hip: dense X is implemented for the model without implicit features and NA_as_zero_X.");
+        // (with weights the compiled reference corrupts its heap -- "free(): invalid pointer" on a dense X with holes, dense U and I and
+        //  dense weights, either solver, both precisions -- so that combination has nothing to be pinned against)
         if ((dense_side_A || dense_side_B) && (weight || NA_as_zero_U || NA_as_zero_I))
             return fail(verbose, "cmfrec_hip: dense X with side information: not together with observation weights or NA_as_zero_U / _I.");
         if ((dense_side_A && m_u != m) || (dense_side_B && n_i != n))
