@@ -1990,6 +1990,10 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
     const SparseShard &X = isA ? s->Xr : s->Xc;
     const real_t *Cm = isA ? s->C.ptr : s->D.ptr;
     const real_t *Um = isA ? s->U.ptr : s->II.ptr;
+    // sparse side information (missing = absent; round 6, fixture g36): the row's attributes as the second gather source instead of the
+    // shared w C^T C / w U C (collective.c:1636-1653 / :2292-2298 beside the weight branches)
+    const bool sparse_side = isA ? s->sparseU : s->sparseI;
+    const SparseShard &Us = isA ? s->Usr : s->Isr;
     const real_t w = isA ? m.w_user : m.w_item;
     const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
     const real_t lam_self = s->lam6[isA ? 2 : 3];
@@ -2010,8 +2014,10 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
         // the same CG from their side information and the constant: the reference factorises the shared block matrix for them only
         // when the caller hands it the buffers of precompute_for_predictions (filled_BtB, :5702-5716), which this model does not offer.
         real_t *uc = isA ? s->ucA.ptr : s->ucB.ptr;
-        launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, (real_t)1, (real_t)0);                 // C^T C, unweighted
-        launch_gemm<false>(dev, rows_self, kc, p_self, (real_t)1, Um, (size_t)p_self, Cm, (size_t)kc, uc, (size_t)kc);   // U C
+        if (!sparse_side) {
+            launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, (real_t)1, (real_t)0);                 // C^T C, unweighted
+            launch_gemm<false>(dev, rows_self, kc, p_self, (real_t)1, Um, (size_t)p_self, Cm, (size_t)kc, uc, (size_t)kc);   // U C
+        }
         const size_t nnzc = X.nnz;
         s->naz_g.alloc_at_least(std::max<size_t>(nnzc, 1)); s->naz_xt.alloc_at_least(std::max<size_t>(nnzc, 1));
         if (nnzc > 0)
@@ -2043,17 +2049,18 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
         const bool scaled_cg = m.scale_lam || m.scale_lam_sideinfo;
         CgCall c{self, ld_self, oppx, ld_opp, ks, nullptr, nullptr, lam_self, lam_last_self, scaled_cg, false, m.max_cg_steps, false,
                  (bool)m.precondition_cg};
-        c.koff = k_side_self; c.kc = kc; c.CtC = s->ctc.ptr; c.UC = uc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
+        c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
+        if (sparse_side) { c.X2 = &Us; c.C2 = Cm; } else { c.CtC = s->ctc.ptr; c.UC = uc; }
         c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo;
         c.Gx = s->gram.ptr; c.rconst_x = s->naz_rhs.ptr; c.ldr_x = (size_t)ks;
         c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_g.ptr;      // (the multipliers: X.wsum_naz, launch_cg)
         c.gx_all_rows = has_cst;
         return launch_cg(dev, c, X);
     }
-    launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);
-    // right-hand sides start from [w U C ; cst]
+    if (!sparse_side) launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);
+    // right-hand sides start from [w U C ; cst]  (sparse side information: [0 ; cst], the attributes are gathered by the row kernel)
     HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
-    launch_gemm<false>(dev, rows_self, kc, p_self, w, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
+    if (!sparse_side) launch_gemm<false>(dev, rows_self, kc, p_self, w, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
     if (has_cst) {
         const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
         s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
@@ -2070,9 +2077,10 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
                            has_cst ? bias : nullptr, s->naz_center ? s->naz_mean : (real_t)0, s->naz_g.ptr, s->naz_xt.ptr);
     HIP_CHECK(hipGetLastError());
     const bool scaled = m.scale_lam || m.scale_lam_sideinfo;
-    CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, s->ctc.ptr, kc, rows_u, p_self, lam_self, lam_last_self, scaled,
-               (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE, s->naz_M.ptr};
+    CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, sparse_side ? nullptr : s->ctc.ptr, kc, rows_u, p_self, lam_self, lam_last_self,
+               scaled, (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE, s->naz_M.ptr};
     c.rhs_prefilled_all = true; c.entry_pairs = true; c.values_override = s->naz_xt.ptr; c.weights_override = s->naz_g.ptr;
+    if (sparse_side) { c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w; }
     if (scaled) c.mult_override = X.wsum_naz.ptr;        // sum of the row's weights + its absent entries (cmfrec_hip_session_set_NA_as_zero_X)
     return launch_chol(dev, c, &X);
 }
@@ -2094,9 +2102,8 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
     const int p_self = isA ? m.p : m.q;
-    if (s->implicit_feats || dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || s->sparseU || s->sparseI ||
-        s->side_local) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without sparse side information, implicit features, nonneg / L1";
+    if (s->implicit_feats || dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || s->side_local) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without implicit features, nonneg / L1";
         return 2;
     }
     if (p_self > 0) return update_factor_naz_weighted_side(s, isA, chol);

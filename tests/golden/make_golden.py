@@ -35,6 +35,20 @@ def save(name, **arrs):
 def main():
     for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
         R = Reference(dt)
+        # ---- G36: NA_as_zero for the main matrix with observation weights AND sparse side information ----
+        # (the fixtures of round 6 are checked against a fresh run of the compiled reference by tests/test_oracle_vs_ref.py.  A note for
+        #  whoever adds cases: the reference writes out of bounds on some combinations -- a nearly complete dense X with dense side
+        #  information, a dense X with weights and side information -- and then a LATER block of this script dies ('SystemError: unknown
+        #  opcode', a segmentation fault in the garbage collector); golden_cases.py names the combinations found so far)
+        out = {}
+        d = gc.weights_sparse_side_problem(dt)
+        for ci, (name, which, opts) in enumerate(gc.NAZ_WEIGHTED_SPARSE_SIDE_CASES):
+            r = gc.naz_weighted_sparse_side_reference(R, d, which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g36_na_as_zero_weighted_sparse_side_" + tag, **out)
+
         # ---- G6: COO -> CSR/CSC ordering, global mean, bias initialisation ----
         m, n = 120, 90
         row, col, val = make_coo(m, n, 1500, 101, counts=False, dtype=dt, heavy_row=(3, 60), empty_rows=(7,))

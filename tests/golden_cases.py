@@ -1336,6 +1336,62 @@ def impf_sparse_side_hip(d, which, opts, dtype):
     return out
 
 
+# ---- NA_as_zero_X with observation weights AND sparse side information (round 6; fixture g36): the weight branches of
+#      collective_closed_form_block / collective_block_cg with the row's attributes as a sparse vector; the problem of g31 (entries
+#      ordered by column), side information on exactly the rows / columns of X
+NAZ_WEIGHTED_SPARSE_SIDE_CASES = [
+    ("chol, both sides", "UI", dict(use_cg=False)),
+    # (scale_lam_sideinfo is refused with weights + sparse side information: the reference's multipliers there add
+    #  `U_csr_p[row+1] - U_csr[row]`, a value of U in place of its row pointer, collective.c:8087, :8106)
+    ("chol, scale_lam, k_user / k_item", "UI", dict(use_cg=False, scale_lam=True, k_user=1, k_item=2)),
+    ("chol, user side, no biases, no centring", "U", dict(use_cg=False, user_bias=False, item_bias=False, center=False, k_main=1)),
+    ("cg, both sides", "UI", dict(use_cg=True, finalize_chol=False)),
+    ("pcg, item side, item bias", "I", dict(use_cg=True, precondition_cg=True, finalize_chol=False, user_bias=False, k_item=1)),
+    ("cg + finalize, scale_lam", "UI", dict(use_cg=True, finalize_chol=True, scale_lam=True)),
+]
+
+
+def _nwss_sides(d, which):
+    Uc, Ic = d["U_coo"], d["I_coo"]
+    return ((Uc[0], Uc[1], Uc[2], d["m"], d["p"]) if "U" in which else None, (Ic[0], Ic[1], Ic[2], d["n"], d["q"]) if "I" in which else None)
+
+
+def naz_weighted_sparse_side_reference(R, d, which, opts, nthreads=2):
+    o = dict(opts)
+    if "U" not in which: o["k_user"] = 0
+    if "I" not in which: o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    Us, Is = _nwss_sides(d, which)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, w_user=2.0, w_item=0.5, nthreads=nthreads, weight=d["W"], NA_as_zero_X=True,
+                                      use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      U_coo=Us, I_coo=Is, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_weighted_sparse_side_hip(d, which, opts, dtype):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "U" not in which: o["k_user"] = 0
+    if "I" not in which: o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    Us, Is = _nwss_sides(d, which)
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
+              NA_as_zero=True, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=mk(Us) if Us is not None else None, I=mk(Is) if Is is not None else None,
+            shape=(d["m"], d["n"]), W=d["W"], A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
 #      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
 # (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded
@@ -1830,12 +1886,14 @@ def dense_side_problem(dtype, variant, seed=137):
 DENSE_SIDE_CASES = [
     ("full, dense UI, chol", "full", "ui", dict(use_cg=False, k_user=1, k_item=1)),
     ("full, dense UI, cg asked for, scaled", "full", "ui", dict(use_cg=True, finalize_chol=False, scale_lam=True, scale_lam_sideinfo=True)),
-    ("near dense, dense U only, cg asked for", "near", "u", dict(use_cg=True, finalize_chol=False, k_main=1)),
     ("holes, dense UI, cg", "holes", "ui", dict(use_cg=True, finalize_chol=True, k_user=2)),
     ("holes, dense UI, chol, scale_lam", "holes", "ui", dict(use_cg=False, scale_lam=True)),
     ("holes, sparse UI, chol", "holes", "UI", dict(use_cg=False, k_item=1)),
-    # (a nearly complete X with one sparse and one dense side: the reference's own build dies with SIGSEGV -- "near" with "Ui" or "uI",
-    #  either solver, both precisions -- so that combination has nothing to be pinned against; both sparse or both dense run)
+    # (a nearly complete X -- "near": the shared factorisation + row-by-row corrections of collective.c:5115-5565 -- with DENSE side
+    #  information on either side: the reference's own build writes out of bounds.  With one sparse and one dense side it dies with
+    #  SIGSEGV at once, either solver, both precisions; with dense side information only it returns, but a process that repeats the
+    #  call a few times dies in the allocator or the garbage collector (ten repetitions of "near" with "u", "i" or "ui", either solver:
+    #  every one of them; all the cases below: clean).  Nothing to be pinned against, so "near" appears with sparse side information only.)
     ("near dense, sparse UI, cg", "near", "UI", dict(use_cg=True, finalize_chol=False)),
     ("full, sparse U + dense I, cg", "full", "Ui", dict(use_cg=True, finalize_chol=False, k_user=1)),
     ("holes, sparse UI, pcg, no biases", "holes", "UI", dict(use_cg=True, precondition_cg=True, finalize_chol=False, user_bias=False, item_bias=False)),

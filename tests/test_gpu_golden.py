@@ -542,6 +542,23 @@ def test_NA_as_zero_X_weighted_sideinfo(oracles, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_weighted_sparse_sideinfo(dtype):
+    """G36 through the estimator (CMF(NA_as_zero=True).fit(X, U=sparse, I=sparse, W=)): the weighted missing-as-zero half-step with
+    the row's attributes as the second gather source -- closed form on the row Cholesky kernel (blockdiag(0, B^T B) as the matrix every
+    row starts from, the entries' pairs, the attributes' rank-1 terms), block CG / PCG on the lane <-> unknown kernel."""
+    g = gc.load("g36_na_as_zero_weighted_sparse_side", dtype)
+    d = gc.weights_sparse_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    bad = []
+    for ci, (name, which, opts) in enumerate(gc.NAZ_WEIGHTED_SPARSE_SIDE_CASES):
+        got = gc.naz_weighted_sparse_side_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        err = gc.compare_fits(got, exp)
+        if not (exp and err < tol): bad.append((name, err))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_UI(oracles, dtype):
     """G21 through the estimators (NA_as_zero_user / NA_as_zero_item with SciPy sparse U / I): the fits of the reference's
     sparse missing-as-zero branches; the flag changes the model; the constant the reference keeps for new rows

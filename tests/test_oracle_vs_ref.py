@@ -866,3 +866,31 @@ def test_implicit_features_sparse_side_fixture_normal_equations(ci):
         got = np.concatenate([A[i], [bA[i]]]) if ub else A[i]
         worst = max(worst, np.abs(sol - got).max() / max(np.abs(sol).max(), 1e-30))
     assert worst < 1e-9, (name, worst)
+
+
+def test_round6_fixtures_are_the_reference():
+    """Fixtures g31 .. g36 (the f4 remainder of round 6: weights / implicit features with sparse side information, dense X with side
+    information, NA_as_zero_X under use_cg and with weights + sparse side information) against the compiled reference run live, double
+    precision: what the GPU tests compare the product with is what the reference returns on this host too."""
+    import golden_cases as gc
+    dtype = np.float64
+    if not ref_available(dtype):
+        pytest.skip("oracle/_ref for this precision not built")
+    R = Reference(dtype)
+    def check(fixture, cases, run):
+        g = gc.load(fixture, dtype)
+        for ci, case in enumerate(cases):
+            for key, v in run(case).items():
+                if v is None:
+                    continue
+                ref = g["c%d_%s" % (ci, key)]
+                assert np.abs(np.asarray(v, np.float64) - ref).max() <= 1e-9 * max(np.abs(ref).max(), 1e-30), (fixture, case[0], key)
+    d = gc.weights_sparse_side_problem(dtype)
+    check("g31_weights_sparse_side", gc.WEIGHT_SPARSE_SIDE_CASES, lambda c: gc.weights_sparse_side_reference(R, d, c[1], c[2]))
+    check("g32_implicit_features_sparse_side", gc.IMPF_SPARSE_SIDE_CASES, lambda c: gc.impf_sparse_side_reference(R, d, c[1], c[2]))
+    check("g36_na_as_zero_weighted_sparse_side", gc.NAZ_WEIGHTED_SPARSE_SIDE_CASES, lambda c: gc.naz_weighted_sparse_side_reference(R, d, c[1], c[2]))
+    check("g33_dense_X_sideinfo", gc.DENSE_SIDE_CASES, lambda c: gc.dense_side_reference(R, gc.dense_side_problem(dtype, c[1]), c[2], c[3]))
+    dn = gc.naz_sparse_side_problem(dtype)
+    check("g34_na_as_zero_sparse_side_cg", gc.NAZ_SPARSE_SIDE_CG_CASES, lambda c: gc.naz_sparse_side_reference(R, dn, c[1], c[2]))
+    dw = gc.naz_weighted_problem(dtype)
+    check("g35_na_as_zero_weighted_sideinfo_cg", gc.NAZ_WEIGHTED_SIDE_CG_CASES, lambda c: gc.naz_side_reference(R, dw, c[1], c[2], weights=True))
