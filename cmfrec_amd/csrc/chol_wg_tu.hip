@@ -5,6 +5,7 @@
 #include <algorithm>
 #include "../../include/cmfrec_hip.h"
 #include "chol_wg_kernels.hpp"
+#include "chol_parts_coop_kernels.hpp"
 
 namespace cmfhip {
 
@@ -31,6 +32,23 @@ hipError_t launch_chol_wg8(int num_cus, bool border, int waves_per_row, hipStrea
     const int rows = W.nrows - W.row_first;
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(std::min(rows, num_cus * blocks_per_cu)), dim3(64 * nw), 0, st, W, desc, SL);
+    return hipGetLastError();
+#endif
+}
+
+// launches chol_parts_coop_kernel<real_t, border> over the work items [W.row_first, W.nrows) on `st` (chol_parts_coop_kernels.hpp)
+hipError_t launch_chol_parts_coop(int num_cus, bool border, int depth, hipStream_t st, const CholParams<real_t> &W, const RowDesc *desc, const CholSlices<real_t> &SL)
+{
+#ifdef CMFREC_HIP_FLOAT
+    (void)num_cus; (void)border; (void)depth; (void)st; (void)W; (void)desc; (void)SL;
+    return hipErrorNotSupported;
+#else
+    // depth: steps of four entries in flight in registers (3: no spilled register in either build; 4: the build with the border column spills)
+    auto kern = (depth == 4) ? (border ? chol_parts_coop_kernel<real_t, true, 4> : chol_parts_coop_kernel<real_t, false, 4>)
+                             : (border ? chol_parts_coop_kernel<real_t, true, 3> : chol_parts_coop_kernel<real_t, false, 3>);
+    const int items = W.nrows - W.row_first;
+    if (items <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3(std::min(items, num_cus * 4)), dim3(128), 0, st, W, desc, SL);
     return hipGetLastError();
 #endif
 }

@@ -50,6 +50,7 @@ struct Switches {
     bool nt_split = true;           // CMFREC_HIP_NT_SPLIT=0: a double-precision length bin as one launch instead of two by tile size
     bool cg_generic = false;        // CMFREC_HIP_CG_KERNEL=generic: lane <-> unknown CG kernel everywhere
     int chol = 0;                   // CMFREC_HIP_CHOL: 1 = rows (workgroup-per-row kernel only), 2 = noslices
+    int parts_coop = 1;             // CMFREC_HIP_PARTS_COOP: the rank-k update of those rows with ONE gather shared by the row's two wavefronts through LDS (chol_parts_coop_kernels.hpp; 3: three steps in flight instead of four); 0 = each wavefront gathers for itself (round 5)
     int chol_wg = 2;                // CMFREC_HIP_CHOL_WG: eight-block rows in double precision factorised by a workgroup of 2 (default) / 4 wavefronts per row (chol_wg_kernels.hpp); 0 = one wavefront per row (rounds 2-5)
     int gramk = -1;                 // CMFREC_HIP_GRAMK: 0 / 1 force the producer / consumer pair off / on (-1: by width)
     int gramk_batch = 0;            // CMFREC_HIP_GRAMK_BATCH: work items per batch (test hook: several batches on a small problem)
@@ -70,6 +71,7 @@ struct Switches {
         nt_split = num("CMFREC_HIP_NT_SPLIT", 1) != 0;
         v = str("CMFREC_HIP_CG_KERNEL"); cg_generic = v && strcmp(v, "generic") == 0;
         v = str("CMFREC_HIP_CHOL"); chol = !v ? 0 : strcmp(v, "rows") == 0 ? 1 : strcmp(v, "noslices") == 0 ? 2 : 0;
+        parts_coop = num("CMFREC_HIP_PARTS_COOP", 1);
         chol_wg = num("CMFREC_HIP_CHOL_WG", 2);
         if (chol_wg == 1) chol_wg = 2;
         gramk = num("CMFREC_HIP_GRAMK", -1);

@@ -27,6 +27,7 @@ CgVariant cg_variant_from_env() { return switches().cg_generic ? CgVariant::Gene
 inline dim3 grid1d(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 // (chol_wg_tu.hip: the four-wavefront factorisation of the eight-block rows, double precision)
 hipError_t launch_chol_wg8(int num_cus, bool border, int waves_per_row, hipStream_t st, const CholParams<real_t> &W, const RowDesc *desc, const CholSlices<real_t> &SL);
+hipError_t launch_chol_parts_coop(int num_cus, bool border, int depth, hipStream_t st, const CholParams<real_t> &W, const RowDesc *desc, const CholSlices<real_t> &SL);
 
 struct CholCall {
     real_t *A; size_t lda;
@@ -191,6 +192,12 @@ static int launch_chol(const DeviceInfo &dev, const CholCall &c, const SparseSha
                     const bool parts = fullq;
 #endif
                     if (!parts) wlaunch(WAVE_KERN_M(8, 3, 1, 32, 1), 8, 1);      // 32 tiles per sweep
+                    else if (switches().parts_coop && CMF_PARTS_NP == 2) {
+                        // Round 6: the row's two wavefronts share ONE gather through LDS (chol_parts_coop_kernels.hpp, chol_wg_tu.hip):
+                        // config 3 12.97 -> 12.80 ms, the partials bit for bit the same (CMFREC_HIP_PARTS_COOP=0: round 5's kernel)
+                        poison_lds(st, dev.num_cus);
+                        HIP_CHECK(launch_chol_parts_coop(dev.num_cus, border, switches().parts_coop == 3 ? 3 : 4, st, W, X->desc.ptr, SL));
+                    }
                     else {
                         poison_lds(st, dev.num_cus);
                         constexpr int NPQ = CMF_PARTS_NP;

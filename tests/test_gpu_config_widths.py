@@ -89,6 +89,44 @@ def test_c3_width_explicit_double(oracles, k, chol_wg, monkeypatch):
     assert np.array_equal(Ah[2], A0[2])
 
 
+@pytest.mark.parametrize("k", [128, 127])
+def test_c3_width_shared_gather_is_the_per_wavefront_gather(oracles, k, monkeypatch):
+    """The rank-k update of the eight-block rows with ONE gather shared by the row's two wavefronts through LDS
+    (chol_parts_coop_kernels.hpp, the default since round 6) against each wavefront gathering for itself (CMFREC_HIP_PARTS_COOP=0,
+    round 5): the sums are taken in the same order, so the factors are bit for bit the same -- rows of one to 1300 entries (steps that
+    are not a multiple of the registers' depth, a slice boundary, entries that are not a multiple of four), with and without the
+    border column; and both agree with the oracle."""
+    from cmfrec_amd import ops
+    dtype = np.float64
+    O = oracles[dtype]
+    m, n = 72, 2000
+    row, col, val = make_coo(m, n, 9000, 15, counts=False, dtype=dtype, heavy_row=(9, 1300), empty_rows=(2,))
+    keep = np.ones(len(row), bool)
+    for r, cnt in ((6, 1), (7, 2), (8, 3), (10, 5), (11, 17), (12, 99), (13, 100), (14, 101)):
+        idx = np.flatnonzero(row == r)
+        keep[idx[cnt:]] = False
+    row, col, val = row[keep], col[keep], val[keep]
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(16)
+    A0 = (rng.standard_normal((m, k + 1)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k + 1)) * 0.2).astype(dtype)
+    B[:, k] = 1
+    bias = (rng.standard_normal(n) * 0.3).astype(dtype)
+    kw = dict(k=k + 1, lam_last=0.3, scale_lam=True, use_cg=False)
+    out = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("CMFREC_HIP_PARTS_COOP", coop)
+        monkeypatch.setenv("CMFREC_HIP_LOWRANK", "0")          # every row through the producer / factorisation pair
+        Ah = A0.copy()
+        ops.optimizeA_explicit(Ah, B, csr, 0.05, bias_sub=bias, **kw)
+        out[coop] = Ah
+    assert np.array_equal(out["1"], out["0"])
+    Ao = A0.copy()
+    csr_sub = (csr[0], csr[1], (csr[2] - bias[csr[1]]).astype(dtype))
+    O.optimizeA_explicit(Ao, B, csr_sub, 0.05, nthreads=4, **kw)
+    assert rel_err(out["1"], Ao) < 1e-10
+
+
 @pytest.mark.parametrize("side", ["users", "items"])
 @pytest.mark.parametrize("gramk", ["default", "off", "batch7"])
 def test_c5_width_collective_single(oracles, side, gramk, monkeypatch):

@@ -10,6 +10,7 @@
 #   env <VAR> <v1> <v2> ...    the C2 line (and c4shard) once per value of an environment switch
 #   sidestats <workload> ...   rocprofv3 kernel statistics of side workloads (c3, c5shard, c1, c4shard)
 #   sideab <workload> <libdirA> <libdirB>   a side workload on two builds, alternating
+#   sideenv <workload> <VAR> <v1> <v2> ...  a side workload once per value of an environment switch, alternating
 #   final [nosuite]            the end-of-round set: suite, smoke, counter passes with the bins in line, kernel statistics of the
 #                              default and the in-line run, the default bench line, side workloads, the --force-dist launch paths on
 #                              one rank, the suite again with poisoned LDS
@@ -59,6 +60,12 @@ env)
     env $V=$x $B --steps 40 --warmup 5 2>$O/err_$x.txt | python /tmp/line.py "c2 $V=$x" | tee -a $O/lines.txt
   done; done
   for x in "$@"; do env $V=$x $B --workload c4shard --steps 20 --warmup 3 2>/dev/null | python /tmp/line.py "c4shard $V=$x" | tee -a $O/lines.txt; done ;;
+sideenv)
+  # sideenv <workload> <VAR> <v1> <v2> ...: a side workload once per value of an environment switch, alternating three times
+  w=$1; V=$2; shift; shift
+  for rep in 1 2 3; do for x in "$@"; do
+    env $V=$x $B --workload $w --steps 10 --warmup 3 2>/dev/null | python /tmp/line.py "$w $V=$x" | tee -a $O/lines.txt
+  done; done ;;
 sidestats)
   # rocprofv3 kernel statistics of bench.py's side workloads (c3, c5shard, ...), one csv each
   for w in "$@"; do
