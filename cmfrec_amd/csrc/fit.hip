@@ -1055,8 +1055,9 @@ int_t fit_collective_explicit_als(
     // ... with implicit features (round 5): the model without side information and weights, closed form (optimizeA_collective's
     // general branch on a matrix all rows share, collective.c:8612 / :8783 -> :1534-1846)
     // (use_cg is accepted: the reference takes its closed-form Case 1 whatever the solver asked for, collective.c:5121-5130)
-    if (NA_as_zero_X && add_implicit_features && (U || II || nnz_U || nnz_I || weight != nullptr))
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information and weights.");
+    // (round 6, fixture g37: with dense or sparse side information on exactly the rows / columns of X)
+    if (NA_as_zero_X && add_implicit_features && weight != nullptr)
+        return fail(verbose, "cmfrec_hip: NA_as_zero_X with implicit features: the model without observation weights.");
     // ... with SPARSE side information (round 5): row by row on the shared B^T B plus the rank-1 terms of the row's own attributes
     // (collective_closed_form_block with prefer_BtB, collective.c:1534-1846) -- closed form, side information on exactly the rows /
     // columns of X, no weights

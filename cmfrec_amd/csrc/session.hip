@@ -1772,6 +1772,20 @@ static int update_factor_naz_sparse_side(cmfrec_hip_session *s, bool isA, bool c
     if (self_bias)
         hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
     launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);
+    // implicit features (round 6, fixture g37): w_i Bi^T Bi on the first k + k_main unknowns of the X block (collective.c:1704-1707;
+    // the block CG keeps it apart, unweighted: :2301-2304, :2626-2629), w_i times the sum of the opposing implicit factors at the
+    // row's observed positions in the right-hand side (:1757-1771)
+    const real_t *Fi = s->implicit_feats ? (isA ? s->Bi.ptr : s->Ai.ptr) : nullptr;
+    if (Fi != nullptr) {
+        launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, chol ? s->w_implicit : (real_t)1, (real_t)0);
+        if (chol) {
+            hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kk * kk), dim3(256), 0, st, s->bitbi.ptr, kk, (real_t)1, s->gram.ptr, ks, 0);
+            if (!launch_gsum(s, isA, X, Fi, kk)) {
+                g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: k + k_main too wide for the gather-sum";
+                return 2;
+            }
+        }
+    }
     if (!chol) {
         // Block CG (round 6; collective_block_cg with NA_as_zero_X and u_vec_sp, collective.c:2134-2903): the X block of every row's
         // system is the shared B^T B (:2430-2445 first residual, :2700-2760 the products), its right-hand side sum_j x_j b_j + cst;
@@ -1814,6 +1828,7 @@ static int update_factor_naz_sparse_side(cmfrec_hip_session *s, bool isA, bool c
         c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_zero.ptr;
         if (scaled_cg) c.wsum_override = s->naz_mult.ptr;
         c.gx_all_rows = opp_bias || s->naz_center;         // rows with neither entries nor attributes: solved from the constant, zero without it
+        if (Fi != nullptr) { c.Bi = Fi; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit; }     // (the kernel gathers Bi_j at the row's entries itself)
         return launch_cg(dev, c, X);
     }
     s->naz_M.alloc_at_least((size_t)kt * kt);
@@ -1830,6 +1845,9 @@ static int update_factor_naz_sparse_side(cmfrec_hip_session *s, bool isA, bool c
         hipLaunchKernelGGL(add_rowvec_kernel<real_t>, grid1d((size_t)rows_self * ks), dim3(256), 0, st, self + k_side_self, ld_self, (size_t)rows_self, ks,
                            s->naz_vec.ptr);
     }
+    if (Fi != nullptr)
+        hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)X.nrows * kk), dim3(256), 0, st, self, ld_self, k_side_self, s->grhs.ptr, kk,
+                           s->w_implicit, (size_t)X.nrows);
     const bool scaled = m.scale_lam || m.scale_lam_sideinfo;
     if (scaled) {
         s->naz_mult.alloc_at_least((size_t)rows_self);
@@ -1871,10 +1889,8 @@ static int update_factor_naz(cmfrec_hip_session *s, bool isA, bool chol)
     // + the constant: the shared-matrix half-step below with two more terms.  Closed form (the block CG is not restated).
     // (use_cg: the reference takes its closed-form Case 1 here whatever the solver asked for -- collective.c:5121-5130 -- and returns
     //  the same numbers bit for bit)
-    if (s->implicit_feats && (m.p > 0 || m.q > 0)) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: the model without side information";
-        return 2;
-    }
+    // (round 6, fixture g37: with side information too -- dense: the shared block matrix takes w_i Bi^T Bi on its X block and the
+    //  right-hand sides the gather-sum like below; sparse: update_factor_naz_sparse_side)
     if (p_self > 0 && (isA ? s->sparseU : s->sparseI)) return update_factor_naz_sparse_side(s, isA, chol);
     if (p_self > 0 && rows_u != rows_self) {
         // (m > m_u takes optimizeA Case 3 for the rows beyond in the reference -- its build corrupts the heap there, so nothing

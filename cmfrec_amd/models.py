@@ -263,13 +263,12 @@ class CMF(_Base):
         # sparse side information whose absent entries are zeros (not missing): cmfrec/__init__.py:2903-2905.  The C library
         # runs it as the zero-filled dense matrix it denotes (fit.hip, ZeroFilledSide)
         self.NA_as_zero_user = bool(NA_as_zero_user); self.NA_as_zero_item = bool(NA_as_zero_item)
-        # NA_as_zero (absent entries of a sparse X are zeros): without side information or with dense complete side information on
-        # exactly the rows / columns of X (closed form); the matrices for predictions on new data (with BtXbias) for the model
-        # without side information and implicit features only.  With observation weights (fit(..., W=)): the model without side information, closed
-        # form or CG (k + k_main + bias <= 64), or with dense complete side information (closed form); start values given by the
-        # caller (A0 / B0 / biasA0 / biasB0) when the model has biases -- the reference's own bias start values are not defined
-        # for that combination (common.c:4727-4731).  With sparse side information (on exactly the rows / columns of X) or with
-        # add_implicit_features (no side information): use_cg=False.
+        # NA_as_zero (absent entries of a sparse X are zeros): without side information or with dense complete / sparse side
+        # information on exactly the rows / columns of X, closed form or CG, with add_implicit_features too; the matrices for
+        # predictions on new data (with BtXbias) for the model without side information and implicit features only.  With
+        # observation weights (fit(..., W=)): the same models without implicit features; start values given by the caller
+        # (A0 / B0 / biasA0 / biasB0) when the model has biases -- the reference's own bias start values are not defined for that
+        # combination (common.c:4727-4731).  What is refused and why: DESIGN.md section 7.
         self.NA_as_zero = bool(NA_as_zero)
         # (precompute_for_predictions with NA_as_zero: the model without side information -- checked in fit(), where the data is known)
         self.scale_bias_const = bool(scale_bias_const)

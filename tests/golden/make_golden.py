@@ -433,6 +433,15 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g34_na_as_zero_sparse_side_cg_" + tag, **out)
 
+        # ---- G37: NA_as_zero for the main matrix with implicit features AND side information ----
+        out = {}
+        for ci, (name, kind, which, opts) in enumerate(gc.NAZ_IMPF_SIDE_CASES):
+            r = gc.naz_impf_side_reference(R, kind, which, opts, dt)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g37_na_as_zero_implicit_features_sideinfo_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

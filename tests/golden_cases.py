@@ -1392,6 +1392,66 @@ def naz_weighted_sparse_side_hip(d, which, opts, dtype):
     return out
 
 
+# ---- NA_as_zero_X with implicit features AND side information (round 6; fixture g37): dense side information -- the shared block
+#      matrix with w_i Bi^T Bi on its X block, whatever the solver asked for (collective.c:5121-5230) --, sparse -- row by row, closed form
+#      or block CG (:1534-1846, :2134-2903)
+NAZ_IMPF_SIDE_CASES = [
+    # (name, "dense" / "sparse", sides, options)
+    ("dense UI", "dense", "UI", dict()),
+    ("dense UI, cg asked for, scaled", "dense", "UI", dict(use_cg=True, finalize_chol=False, scale_lam=True, scale_lam_sideinfo=True, w_implicit=0.6)),
+    ("dense U, k_user, no centring, user bias", "dense", "U", dict(k_user=2, k_main=1, center=False, item_bias=False)),
+    ("sparse UI, chol", "sparse", "UI", dict()),
+    ("sparse I, chol, scale_lam, w_implicit", "sparse", "I", dict(scale_lam=True, w_implicit=1.4)),
+    ("sparse UI, cg", "sparse", "UI", dict(use_cg=True, finalize_chol=False)),
+    ("sparse U, pcg, no biases", "sparse", "U", dict(use_cg=True, precondition_cg=True, finalize_chol=False, user_bias=False, item_bias=False, center=False)),
+]
+
+
+def _naz_impf_side_inputs(kind, which, opts, dtype):
+    """problem, start values, side-information keyword arguments of the reference call, and the estimator's U / I."""
+    import scipy.sparse as sp
+    o = dict(opts)
+    if kind == "dense":
+        d = naz_problem(dtype)
+        A0, B0 = _impf_start(d, o)
+        U, II = _naz_side(d, which)
+        return d, o, A0, B0, dict(U=U, II=II), U, II
+    d = naz_sparse_side_problem(dtype)
+    ku = d["ku"] if "U" in which else 0; ki = d["ki"] if "I" in which else 0
+    A0 = d["A0"][:, d["ku"] - ku:].copy(); B0 = d["B0"][:, d["ki"] - ki:].copy()
+    o.update(k_main=d["km"], k_user=ku, k_item=ki)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    kw = dict(U_coo=d["U_coo"] if "U" in which else None, I_coo=d["I_coo"] if "I" in which else None)
+    return d, o, A0, B0, kw, (mk(d["U_coo"]) if "U" in which else None), (mk(d["I_coo"]) if "I" in which else None)
+
+
+def naz_impf_side_reference(R, kind, which, opts, dtype, nthreads=2):
+    d, o, A0, B0, kw, _, _ = _naz_impf_side_inputs(kind, which, opts, dtype)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, w_user=3.0, w_item=0.7, nthreads=nthreads, NA_as_zero_X=True,
+                                      add_implicit_features=True, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      **kw, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], Ai=r["Ai"], Bi=r["Bi"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_impf_side_hip(kind, which, opts, dtype):
+    from cmfrec_amd import CMF
+    d, o, A0, B0, _, U, II = _naz_impf_side_inputs(kind, which, opts, dtype)
+    o.setdefault("w_implicit", 1.0)
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=3.0, w_item=0.7, use_float=dtype is np.float32, precompute_for_predictions=False,
+              NA_as_zero=True, add_implicit_features=True, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+              nthreads=1, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, Ai=mdl.Ai_, Bi=mdl.Bi_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
 #      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
 # (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded

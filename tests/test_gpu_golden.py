@@ -559,6 +559,23 @@ def test_NA_as_zero_X_weighted_sparse_sideinfo(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_implicit_features_sideinfo(dtype):
+    """G37 through the estimator (CMF(NA_as_zero=True, add_implicit_features=True).fit(X, U=, I=)): dense side information -- the
+    shared block matrix with w_i Bi^T Bi on its X block and the gather-sum of the opposing implicit factors in the right-hand sides,
+    whatever the solver asked for --, sparse side information -- the row Cholesky kernel with the same two terms, the lane <-> unknown CG
+    kernel with the shared B^T B, the unweighted Bi^T Bi and its own gather of Bi at the row's entries."""
+    g = gc.load("g37_na_as_zero_implicit_features_sideinfo", dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    bad = []
+    for ci, (name, kind, which, opts) in enumerate(gc.NAZ_IMPF_SIDE_CASES):
+        got = gc.naz_impf_side_hip(kind, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        err = gc.compare_fits(got, exp)
+        if not (exp and err < tol): bad.append((name, err))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_UI(oracles, dtype):
     """G21 through the estimators (NA_as_zero_user / NA_as_zero_item with SciPy sparse U / I): the fits of the reference's
     sparse missing-as-zero branches; the flag changes the model; the constant the reference keeps for new rows

@@ -869,7 +869,7 @@ def test_implicit_features_sparse_side_fixture_normal_equations(ci):
 
 
 def test_round6_fixtures_are_the_reference():
-    """Fixtures g31 .. g36 (the f4 remainder of round 6: weights / implicit features with sparse side information, dense X with side
+    """Fixtures g31 .. g37 (the f4 remainder of round 6: weights / implicit features with sparse side information, dense X with side
     information, NA_as_zero_X under use_cg and with weights + sparse side information) against the compiled reference run live, double
     precision: what the GPU tests compare the product with is what the reference returns on this host too."""
     import golden_cases as gc
@@ -894,3 +894,4 @@ def test_round6_fixtures_are_the_reference():
     check("g34_na_as_zero_sparse_side_cg", gc.NAZ_SPARSE_SIDE_CG_CASES, lambda c: gc.naz_sparse_side_reference(R, dn, c[1], c[2]))
     dw = gc.naz_weighted_problem(dtype)
     check("g35_na_as_zero_weighted_sideinfo_cg", gc.NAZ_WEIGHTED_SIDE_CG_CASES, lambda c: gc.naz_side_reference(R, dw, c[1], c[2], weights=True))
+    check("g37_na_as_zero_implicit_features_sideinfo", gc.NAZ_IMPF_SIDE_CASES, lambda c: gc.naz_impf_side_reference(R, c[1], c[2], c[3], dtype))
