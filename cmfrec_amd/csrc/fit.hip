@@ -1146,7 +1146,7 @@ int_t fit_collective_explicit_als(
         return fail(verbose, "cmfrec_hip: precompute_for_predictions needs the output buffers (cmfrec.h.in:760-778).");
     // observation weights (one per entry of X): every row solver and the start values of the biases take them; the lambda
     // multipliers of scale_lam become sums of weights (collective.c:7931-8008).  Not together with the options whose weight
-    // bookkeeping is not restated: implicit features, NaN side information, scale_lam_sideinfo, scale_bias_const.
+    // bookkeeping is not restated: NaN side information, scale_lam_sideinfo, scale_bias_const.
     // (scale_lam_sideinfo with weights under NA_as_zero_X: the multiplier is the weights' sum + the absent entries + p, no start values)
     // Sparse side information (round 6): the row's attributes are the second gather source of the weighted row solvers, unweighted
     // themselves (collective.c:1636-1653 beside :1673-1699; block CG :2187-2208 beside :2292-2298) -- fixture g31.
@@ -1155,10 +1155,12 @@ int_t fit_collective_explicit_als(
     if (weight && scale_lam_sideinfo && (spU || spI))
         return fail(verbose, "cmfrec_hip: observation weights with sparse side information under scale_lam_sideinfo are not implemented "
                              "(the reference's lambda multipliers for this combination read a value of U / I in place of a row pointer).");
-    if (weight && (add_implicit_features || nan_side || (scale_lam_sideinfo && !NA_as_zero_X) ||
+    // (round 6, fixture g38: with implicit features too -- the weighted row solvers with the implicit-features term, whose own
+    //  gather-sum and Ai / Bi updates take no weights, collective.c:1757-1771, :8449-8535)
+    if (weight && (nan_side || (scale_lam_sideinfo && !NA_as_zero_X) ||
                    (scale_bias_const && scale_lam && (user_bias || item_bias))))
-        return fail(verbose, "cmfrec_hip: observation weights together with implicit features / NaN side information / "
-                             "scale_lam_sideinfo / scale_bias_const are not implemented.");
+        return fail(verbose, "cmfrec_hip: observation weights together with NaN side information / scale_lam_sideinfo / "
+                             "scale_bias_const are not implemented.");
     if (U == nullptr && !spU) { m_u = 0; p = 0; }
     if (II == nullptr && !spI) { n_i = 0; q = 0; }
     if (m <= 0 || n <= 0 || nnz == 0) return fail(verbose, "cmfrec_hip: invalid dimensions.");

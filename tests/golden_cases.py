@@ -1452,6 +1452,68 @@ def naz_impf_side_hip(kind, which, opts, dtype):
     return out
 
 
+# ---- observation weights together with implicit features (round 6; fixture g38): the weighted row solvers with the implicit-features
+#      term (collective.c:1673-1699 beside :1704-1707, :1757-1771; block CG :2187-2208 beside :2301-2304, :2624-2643).  The problem of
+#      g31 (entries ordered by column); closed form without centring for the reason given at WEIGHT_CASES
+WEIGHT_IMPF_CASES = [
+    # (name, side information: "" none / small letters dense / capitals sparse, options)
+    ("chol", "", dict(use_cg=False, center=False)),
+    ("chol, scale_lam, k_main", "", dict(use_cg=False, center=False, scale_lam=True, k_main=2, w_implicit=0.7)),
+    ("cg", "", dict(use_cg=True, finalize_chol=False, w_implicit=0.6)),
+    ("pcg, no biases", "", dict(use_cg=True, precondition_cg=True, finalize_chol=False, user_bias=False, item_bias=False)),
+    ("dense side info, chol", "ui", dict(use_cg=False, center=False, k_user=1, k_item=2)),
+    ("dense side info, cg + finalize", "ui", dict(use_cg=True, finalize_chol=True, scale_lam=True, center=False)),
+    ("sparse side info, chol", "UI", dict(use_cg=False, center=False, k_item=1)),
+    ("sparse side info, cg", "UI", dict(use_cg=True, finalize_chol=False, k_user=1, w_implicit=1.3)),
+]
+
+
+def _wimpf_sides(d, which):
+    return (d["U"] if "u" in which else None, d["I"] if "i" in which else None,
+            d["U_coo"] if "U" in which else None, d["I_coo"] if "I" in which else None)
+
+
+def weights_impf_reference(R, d, which, opts, nthreads=2):
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    ku, ki = o.get("k_user", 0), o.get("k_item", 0)
+    Ud, Id, Us, Is = _wimpf_sides(d, which)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, w_user=2.0, w_item=0.5, nthreads=nthreads, weight=d["W"], add_implicit_features=True,
+                                      use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      U=Ud, II=Id, U_coo=Us, I_coo=Is,
+                                      Cm=np.zeros((d["p"], ku + d["k"]), d["A0"].dtype) if Us is not None else None,
+                                      Dm=np.zeros((d["q"], ki + d["k"]), d["A0"].dtype) if Is is not None else None, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], Ai=r["Ai"], Bi=r["Bi"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def weights_impf_hip(d, which, opts, dtype, weights=True):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    o.setdefault("w_implicit", 1.0)
+    A0, B0 = _impf_start(d, o)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    Ud, Id, Us, Is = _wimpf_sides(d, which)
+    U = mk(Us) if Us is not None else Ud; II = mk(Is) if Is is not None else Id
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
+              add_implicit_features=True, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False), nthreads=1, **o)
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), W=d["W"] if weights else None,
+            A0=A0, B0=B0, biasA0=d["bA"], biasB0=d["bB"])
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, Ai=mdl.Ai_, Bi=mdl.Bi_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
 #      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
 # (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded

@@ -323,7 +323,7 @@ def test_observation_weights(oracles, dtype):
     name, side, opts = gc.WEIGHT_CASES[0]
     assert gc.compare_fits(gc.weights_hip(d, side, opts, dtype, weights=False), {k[3:]: g[k] for k in g.files if k.startswith("c0_")}) > 1e-2
     # combinations whose weight bookkeeping is not restated are refused
-    for bad in (dict(scale_lam_sideinfo=True), dict(add_implicit_features=True, use_cg=False), dict(scale_lam=True, scale_bias_const=True)):
+    for bad in (dict(scale_lam_sideinfo=True), dict(scale_lam=True, scale_bias_const=True)):
         with pytest.raises(RuntimeError):
             gc.weights_hip(d, True, bad, dtype)
 
@@ -376,6 +376,25 @@ def test_dense_X_with_side_information(dtype):
         if not (exp and err < tol):
             bad.append((name, err))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_observation_weights_with_implicit_features(dtype):
+    """G38 through the estimator: observation weights together with add_implicit_features, without and with dense / sparse side
+    information -- the weighted row solvers (closed form, block CG, PCG) with w_i Bi^T Bi in the matrix and the unweighted gather-sum
+    of the opposing implicit factors in the right-hand side; the Ai / Bi updates take no weights."""
+    g = gc.load("g38_weights_implicit_features", dtype)
+    d = gc.weights_sparse_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    bad = []
+    for ci, (name, which, opts) in enumerate(gc.WEIGHT_IMPF_CASES):
+        got = gc.weights_impf_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        err = gc.compare_fits(got, exp)
+        if not (exp and err < tol): bad.append((name, err))
+    assert not bad, bad
+    name, which, opts = gc.WEIGHT_IMPF_CASES[0]
+    assert gc.compare_fits(gc.weights_impf_hip(d, which, opts, dtype, weights=False), {k[3:]: g[k] for k in g.files if k.startswith("c0_")}) > 1e-2
 
 
 @pytest.mark.parametrize("dtype", DT)
