@@ -1578,6 +1578,13 @@ cg_rows_generic_kernel(const CgParams<T> P)
         const size_t st = P.indptr[row];
         const int nnz = (int)(P.indptr[row + 1] - st);
         const bool has_u = coll && row < P.rows_with_u;
+        if (!IMPLICIT && nnz == 0 && !has_u && P.gx == 1 && P.Bi != nullptr) {
+            // shared matrix without the bias / mean constant, implicit features, no side information on this side: the reference's
+            // collective route zeroes a row without entries (collective.c:1258-1268)
+            if (TEAM == 1 || wv == 0)
+                for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);
+            continue;
+        }
         if (nnz == 0 && !has_u && !(P.gx != 0 && !IMPLICIT)) {   // plain rows without entries stay untouched (common.c:3270,3354)
             if (P.Bi != nullptr && (TEAM == 1 || wv == 0))    // ... but with implicit features the row runs through
                 for (int f = lane; f < kt; f += 64) P.A[(size_t)row * P.lda + f] = T(0);   // optimizeA_collective: zeros (collective.c:1258-1268)

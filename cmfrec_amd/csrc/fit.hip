@@ -1056,8 +1056,7 @@ int_t fit_collective_explicit_als(
     // general branch on a matrix all rows share, collective.c:8612 / :8783 -> :1534-1846)
     // (use_cg is accepted: the reference takes its closed-form Case 1 whatever the solver asked for, collective.c:5121-5130)
     // (round 6, fixture g37: with dense or sparse side information on exactly the rows / columns of X)
-    if (NA_as_zero_X && add_implicit_features && weight != nullptr)
-        return fail(verbose, "cmfrec_hip: NA_as_zero_X with implicit features: the model without observation weights.");
+    // (and with observation weights: fixture g39)
     // ... with SPARSE side information (round 5): row by row on the shared B^T B plus the rank-1 terms of the row's own attributes
     // (collective_closed_form_block with prefer_BtB, collective.c:1534-1846) -- closed form, side information on exactly the rows /
     // columns of X, no weights

@@ -2000,8 +2000,13 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
     const cmfrec_hip_model &m = s->mdl;
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
-    const int p_self = isA ? m.p : m.q, rows_u = isA ? m.m_u : m.n_i;
+    // has_side == false (round 6, fixture g39): no side information on this side, but implicit features -- the reference still takes its
+    // collective route (collective.c:8612, :8783), whose rows without entries are zeroed unless the bias / mean constant exists
+    // (:1258-1268); every row then counts as "with side information" of zero attributes
+    const int p_self = isA ? m.p : m.q;
+    const bool has_side = p_self > 0;
     const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
+    const int rows_u = has_side ? (isA ? m.m_u : m.n_i) : rows_self;
     if (rows_u != rows_self) {
         g_last_error = "cmfrec_hip: NA_as_zero_X with side information: side information on exactly the rows / columns of X";
         return 2;
@@ -2015,17 +2020,31 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
     const real_t *Um = isA ? s->U.ptr : s->II.ptr;
     // sparse side information (missing = absent; round 6, fixture g36): the row's attributes as the second gather source instead of the
     // shared w C^T C / w U C (collective.c:1636-1653 / :2292-2298 beside the weight branches)
-    const bool sparse_side = isA ? s->sparseU : s->sparseI;
+    const bool sparse_side = has_side && (isA ? s->sparseU : s->sparseI);
     const SparseShard &Us = isA ? s->Usr : s->Isr;
     const real_t w = isA ? m.w_user : m.w_item;
     const bool self_bias = isA ? m.user_bias : m.item_bias, opp_bias = isA ? m.item_bias : m.user_bias;
     const real_t lam_self = s->lam6[isA ? 2 : 3];
     const real_t lam_last_self = self_bias ? s->lam6[isA ? 0 : 1] : lam_self;
-    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0), kc = k_side_self + m.k, kt = k_side_self + ks;
+    const int kk = m.k + m.k_main, ks = kk + (self_bias ? 1 : 0), kc = has_side ? k_side_self + m.k : 0, kt = k_side_self + ks;
     const real_t *oppx = opp + k_side_opp;
     if (self_bias)
         hipLaunchKernelGGL(col_fill_kernel<real_t>, grid1d(rows_opp), dim3(256), 0, st, opp, ld_opp, rows_opp, isA ? s->k_totB : s->k_totA, (real_t)1);
     launch_gram(dev, s->gws, oppx, ld_opp, rows_opp, ks, s->gram.ptr, (real_t)1, (real_t)0);
+    // implicit features: w_i Bi^T Bi on the first k + k_main unknowns of the X block (closed form: inside the matrix every row starts
+    // from; block CG: the kernel's own product with the unweighted matrix), w_i times the gather-sum of the opposing implicit factors in
+    // the right-hand sides (closed form; the CG kernel gathers them itself)
+    const real_t *Fi = s->implicit_feats ? (isA ? s->Bi.ptr : s->Ai.ptr) : nullptr;
+    if (Fi != nullptr) {
+        launch_gram(dev, s->gws, Fi, (size_t)kk, rows_opp, kk, s->bitbi.ptr, chol ? s->w_implicit : (real_t)1, (real_t)0);
+        if (chol) {
+            hipLaunchKernelGGL(add_block_kernel<real_t>, grid1d((size_t)kk * kk), dim3(256), 0, st, s->bitbi.ptr, kk, (real_t)1, s->gram.ptr, ks, 0);
+            if (!launch_gsum(s, isA, X, Fi, kk)) {
+                g_last_error = "cmfrec_hip: NA_as_zero_X with implicit features: k + k_main too wide for the gather-sum";
+                return 2;
+            }
+        }
+    }
     s->naz_M.alloc_at_least((size_t)kt * kt);
     hipLaunchKernelGGL(betbe_base_kernel<real_t>, grid1d((size_t)kt * kt), dim3(256), 0, st, s->gram.ptr, ks, k_side_self, (real_t)0, s->naz_M.ptr);
     const bool has_cst = opp_bias || s->naz_center;
@@ -2037,7 +2056,7 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
         // the same CG from their side information and the constant: the reference factorises the shared block matrix for them only
         // when the caller hands it the buffers of precompute_for_predictions (filled_BtB, :5702-5716), which this model does not offer.
         real_t *uc = isA ? s->ucA.ptr : s->ucB.ptr;
-        if (!sparse_side) {
+        if (has_side && !sparse_side) {
             launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, (real_t)1, (real_t)0);                 // C^T C, unweighted
             launch_gemm<false>(dev, rows_self, kc, p_self, (real_t)1, Um, (size_t)p_self, Cm, (size_t)kc, uc, (size_t)kc);   // U C
         }
@@ -2073,17 +2092,21 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
         CgCall c{self, ld_self, oppx, ld_opp, ks, nullptr, nullptr, lam_self, lam_last_self, scaled_cg, false, m.max_cg_steps, false,
                  (bool)m.precondition_cg};
         c.koff = k_side_self; c.kc = kc; c.w_side = w; c.rows_with_u = rows_u; c.p_side = p_self;
-        if (sparse_side) { c.X2 = &Us; c.C2 = Cm; } else { c.CtC = s->ctc.ptr; c.UC = uc; }
+        if (sparse_side) { c.X2 = &Us; c.C2 = Cm; } else if (has_side) { c.CtC = s->ctc.ptr; c.UC = uc; }
+        if (Fi != nullptr) { c.Bi = Fi; c.BiTBi = s->bitbi.ptr; c.ki = kk; c.w_imp = s->w_implicit; }
         c.scale_lam_sideinfo = (bool)m.scale_lam_sideinfo;
         c.Gx = s->gram.ptr; c.rconst_x = s->naz_rhs.ptr; c.ldr_x = (size_t)ks;
         c.values_override = s->naz_zero.ptr; c.weights_override = s->naz_g.ptr;      // (the multipliers: X.wsum_naz, launch_cg)
         c.gx_all_rows = has_cst;
         return launch_cg(dev, c, X);
     }
-    if (!sparse_side) launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);
+    if (has_side && !sparse_side) launch_gram(dev, s->gws, Cm, (size_t)kc, p_self, kc, s->ctc.ptr, w, (real_t)0);
     // right-hand sides start from [w U C ; cst]  (sparse side information: [0 ; cst], the attributes are gathered by the row kernel)
     HIP_CHECK(hipMemset2DAsync(self, ld_self * sizeof(real_t), 0, (size_t)kt * sizeof(real_t), (size_t)rows_self, st));
-    if (!sparse_side) launch_gemm<false>(dev, rows_self, kc, p_self, w, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
+    if (has_side && !sparse_side) launch_gemm<false>(dev, rows_self, kc, p_self, w, Um, (size_t)p_self, Cm, (size_t)kc, self, ld_self);
+    if (Fi != nullptr)
+        hipLaunchKernelGGL(add_cols_scaled_kernel<real_t>, grid1d((size_t)X.nrows * kk), dim3(256), 0, st, self, ld_self, k_side_self, s->grhs.ptr, kk,
+                           s->w_implicit, (size_t)X.nrows);
     if (has_cst) {
         const int nb = (rows_opp + COLSUM_ROWS - 1) / COLSUM_ROWS;
         s->naz_part.alloc_at_least((size_t)nb * ks); s->naz_vec.alloc_at_least((size_t)ks);
@@ -2100,7 +2123,7 @@ static int update_factor_naz_weighted_side(cmfrec_hip_session *s, bool isA, bool
                            has_cst ? bias : nullptr, s->naz_center ? s->naz_mean : (real_t)0, s->naz_g.ptr, s->naz_xt.ptr);
     HIP_CHECK(hipGetLastError());
     const bool scaled = m.scale_lam || m.scale_lam_sideinfo;
-    CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, sparse_side ? nullptr : s->ctc.ptr, kc, rows_u, p_self, lam_self, lam_last_self,
+    CholCall c{self, ld_self, oppx, ld_opp, kt, k_side_self, nullptr, (sparse_side || !has_side) ? nullptr : s->ctc.ptr, kc, rows_u, p_self, lam_self, lam_last_self,
                scaled, (bool)m.scale_lam_sideinfo, false, CHOL_COLLECTIVE, s->naz_M.ptr};
     c.rhs_prefilled_all = true; c.entry_pairs = true; c.values_override = s->naz_xt.ptr; c.weights_override = s->naz_g.ptr;
     if (sparse_side) { c.X2 = &Us; c.B2 = Cm; c.ldb2 = (size_t)kc; c.kc2 = kc; c.w2 = w; }
@@ -2125,11 +2148,11 @@ static int update_factor_naz_weighted(cmfrec_hip_session *s, bool isA, bool chol
     const DeviceInfo &dev = s->dev;
     hipStream_t st = dev.stream;
     const int p_self = isA ? m.p : m.q;
-    if (s->implicit_feats || dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || s->side_local) {
-        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without implicit features, nonneg / L1";
+    if (dev.nonneg_now || dev.l1_now != (real_t)0 || dev.l1_last_now != (real_t)0 || s->side_local) {
+        g_last_error = "cmfrec_hip: NA_as_zero_X with observation weights: the model without nonneg / L1";
         return 2;
     }
-    if (p_self > 0) return update_factor_naz_weighted_side(s, isA, chol);
+    if (p_self > 0 || s->implicit_feats) return update_factor_naz_weighted_side(s, isA, chol);
     const int rows_self = isA ? m.m : m.n, rows_opp = isA ? m.n : m.m;
     real_t *self = isA ? s->A.ptr : s->B.ptr;
     real_t *opp = (isA ? s->B.ptr : s->A.ptr) + (isA ? m.k_item : m.k_user);      // the columns X refers to (the other side may carry k_item / k_user)

@@ -452,6 +452,16 @@ def main():
                     out["c%d_%s" % (ci, key)] = v
         save("g38_weights_implicit_features_" + tag, **out)
 
+        # ---- G39: NA_as_zero for the main matrix with observation weights AND implicit features ----
+        out = {}
+        d = gc.weights_sparse_side_problem(dt)
+        for ci, (name, which, opts) in enumerate(gc.NAZ_WEIGHTED_IMPF_CASES):
+            r = gc.naz_weighted_impf_reference(R, d, which, opts)
+            for key, v in r.items():
+                if v is not None:
+                    out["c%d_%s" % (ci, key)] = v
+        save("g39_na_as_zero_weighted_implicit_features_" + tag, **out)
+
         # ---- G19: dense X with NaN for the missing entries (optimizeA Cases 1-2) ----
         out = {}
         for ci, (name, variant, opts) in enumerate(gc.DENSE_CASES):

@@ -1514,6 +1514,69 @@ def weights_impf_hip(d, which, opts, dtype, weights=True):
     return out
 
 
+# ---- NA_as_zero_X with observation weights AND implicit features (round 6; fixture g39), without and with side information on exactly
+#      the rows / columns of X: the reference's collective route row by row (collective.c:1534-1846 / :2134-2903 with weight, NA_as_zero_X
+#      and add_implicit_features); a row without entries is zero unless the bias / mean constant exists (:1258-1268)
+NAZ_WEIGHTED_IMPF_CASES = [
+    # (name, side information: "" none / small letters dense / capitals sparse, options)
+    ("chol", "", dict(use_cg=False)),
+    ("chol, no biases, no centring, scale_lam", "", dict(use_cg=False, user_bias=False, item_bias=False, center=False, scale_lam=True, w_implicit=0.7)),
+    ("cg", "", dict(use_cg=True, finalize_chol=False, k_main=1)),
+    ("cg, no biases, no centring", "", dict(use_cg=True, finalize_chol=False, user_bias=False, item_bias=False, center=False)),
+    ("pcg, user bias", "", dict(use_cg=True, precondition_cg=True, finalize_chol=False, item_bias=False, w_implicit=1.3)),
+    ("dense side info, chol", "ui", dict(use_cg=False, k_user=1, k_item=1)),
+    ("dense side info, cg", "ui", dict(use_cg=True, finalize_chol=False, scale_lam=True)),
+    ("sparse side info, chol", "UI", dict(use_cg=False, k_item=2)),
+    ("sparse side info, cg + finalize", "UI", dict(use_cg=True, finalize_chol=True, k_user=1)),
+]
+
+
+def _nwi_sides(d, which):
+    Uc, Ic = d["U_coo"], d["I_coo"]
+    return (d["U"] if "u" in which else None, d["I"] if "i" in which else None,
+            (Uc[0], Uc[1], Uc[2], d["m"], d["p"]) if "U" in which else None, (Ic[0], Ic[1], Ic[2], d["n"], d["q"]) if "I" in which else None)
+
+
+def naz_weighted_impf_reference(R, d, which, opts, nthreads=2):
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    A0, B0 = _impf_start(d, o)
+    Ud, Id, Us, Is = _nwi_sides(d, which)
+    r = R.fit_collective_explicit_als(A0, B0, d["row"], d["col"], d["ratings"], d["k"], biasA=d["bA"].copy(), biasB=d["bB"].copy(),
+                                      lam=0.3, niter=3, w_user=2.0, w_item=0.5, nthreads=nthreads, weight=d["W"], NA_as_zero_X=True,
+                                      add_implicit_features=True, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+                                      U=Ud, II=Id, U_coo=Us, I_coo=Is, **o)
+    assert r["ret"] == 0
+    out = dict(A=r["A"], B=r["B"], C=r["C"], D=r["D"], Ai=r["Ai"], Bi=r["Bi"], glob_mean=r["glob_mean"])
+    if o.get("user_bias", True): out["biasA"] = r["biasA"]
+    if o.get("item_bias", True): out["biasB"] = r["biasB"]
+    return out
+
+
+def naz_weighted_impf_hip(d, which, opts, dtype):
+    import scipy.sparse as sp
+    from cmfrec_amd import CMF
+    o = dict(opts)
+    if "U" not in which.upper(): o["k_user"] = 0
+    if "I" not in which.upper(): o["k_item"] = 0
+    o.setdefault("w_implicit", 1.0)
+    A0, B0 = _impf_start(d, o)
+    mk = lambda c: sp.coo_matrix((c[2], (c[0], c[1])), shape=(c[3], c[4]))
+    Ud, Id, Us, Is = _nwi_sides(d, which)
+    U = mk(Us) if Us is not None else Ud; II = mk(Is) if Is is not None else Id
+    mdl = CMF(k=d["k"], lambda_=0.3, niter=3, w_user=2.0, w_item=0.5, use_float=dtype is np.float32, precompute_for_predictions=False,
+              NA_as_zero=True, add_implicit_features=True, use_cg=o.pop("use_cg", False), finalize_chol=o.pop("finalize_chol", False),
+              nthreads=1, **o)
+    start = dict(A0=A0, B0=B0)
+    if mdl.user_bias or mdl.item_bias: start.update(biasA0=d["bA"], biasB0=d["bB"])
+    mdl.fit((d["row"], d["col"], d["ratings"]), U=U, I=II, shape=(d["m"], d["n"]), W=d["W"], **start)
+    out = dict(A=mdl.A_, B=mdl.B_, C=mdl.C_, D=mdl.D_, Ai=mdl.Ai_, Bi=mdl.Bi_, glob_mean=mdl.glob_mean_)
+    if mdl.user_bias: out["biasA"] = mdl.user_bias_
+    if mdl.item_bias: out["biasB"] = mdl.item_bias_
+    return out
+
+
 # ---- the global mean a caller with nthreads >= 8 receives (calc_mean_and_center, common.c:3496-3513 unweighted: sum / count;
 #      :3561-3571 weighted: the UNWEIGHTED sum over the sum of the weights) -- fixture g23 -----------------------------------
 # (name, weighted, options): centred fits through the 82-argument entry point with nthreads = 8, given start values and seeded

@@ -595,6 +595,29 @@ def test_NA_as_zero_X_implicit_features_sideinfo(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+def test_NA_as_zero_X_weighted_implicit_features(dtype):
+    """G39 through the estimator (CMF(NA_as_zero=True, add_implicit_features=True).fit(X, W=, [U=, I=])): the weighted
+    missing-as-zero half-step with the implicit-features term, without side information (the reference's collective route all the
+    same: a row without entries is zero unless the bias / mean constant exists) and with dense / sparse side information, closed form,
+    block CG and PCG."""
+    g = gc.load("g39_na_as_zero_weighted_implicit_features", dtype)
+    g64 = gc.load("g39_na_as_zero_weighted_implicit_features", np.float64)
+    d = gc.weights_sparse_side_problem(dtype)
+    tol = 1e-6 if dtype is np.float64 else 1e-2
+    bad = []
+    for ci, (name, which, opts) in enumerate(gc.NAZ_WEIGHTED_IMPF_CASES):
+        got = gc.naz_weighted_impf_hip(d, which, opts, dtype)
+        exp = {key[len("c%d_" % ci):]: g[key] for key in g.files if key.startswith("c%d_" % ci)}
+        err = gc.compare_fits(got, exp)
+        # single precision: the preconditioned solver has no early exit and this problem's systems amplify rounding -- the reference's own
+        # two precisions are 1.8e-2 apart on the PCG case -- so the yardstick is three times that distance where it exceeds the tolerance
+        ref64 = {key[len("c%d_" % ci):]: g64[key] for key in g64.files if key.startswith("c%d_" % ci)}
+        lim = tol if dtype is np.float64 else max(tol, 3 * gc.compare_fits(exp, ref64))
+        if not (exp and err < lim): bad.append((name, err, lim))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_NA_as_zero_UI(oracles, dtype):
     """G21 through the estimators (NA_as_zero_user / NA_as_zero_item with SciPy sparse U / I): the fits of the reference's
     sparse missing-as-zero branches; the flag changes the model; the constant the reference keeps for new rows

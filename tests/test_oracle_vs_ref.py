@@ -869,7 +869,7 @@ def test_implicit_features_sparse_side_fixture_normal_equations(ci):
 
 
 def test_round6_fixtures_are_the_reference():
-    """Fixtures g31 .. g38 (the f4 remainder of round 6: weights / implicit features with sparse side information, dense X with side
+    """Fixtures g31 .. g39 (the f4 remainder of round 6: weights / implicit features with sparse side information, dense X with side
     information, NA_as_zero_X under use_cg and with weights + sparse side information) against the compiled reference run live, double
     precision: what the GPU tests compare the product with is what the reference returns on this host too."""
     import golden_cases as gc
@@ -889,6 +889,7 @@ def test_round6_fixtures_are_the_reference():
     check("g31_weights_sparse_side", gc.WEIGHT_SPARSE_SIDE_CASES, lambda c: gc.weights_sparse_side_reference(R, d, c[1], c[2]))
     check("g32_implicit_features_sparse_side", gc.IMPF_SPARSE_SIDE_CASES, lambda c: gc.impf_sparse_side_reference(R, d, c[1], c[2]))
     check("g38_weights_implicit_features", gc.WEIGHT_IMPF_CASES, lambda c: gc.weights_impf_reference(R, d, c[1], c[2]))
+    check("g39_na_as_zero_weighted_implicit_features", gc.NAZ_WEIGHTED_IMPF_CASES, lambda c: gc.naz_weighted_impf_reference(R, d, c[1], c[2]))
     check("g36_na_as_zero_weighted_sparse_side", gc.NAZ_WEIGHTED_SPARSE_SIDE_CASES, lambda c: gc.naz_weighted_sparse_side_reference(R, d, c[1], c[2]))
     check("g33_dense_X_sideinfo", gc.DENSE_SIDE_CASES, lambda c: gc.dense_side_reference(R, gc.dense_side_problem(dtype, c[1]), c[2], c[3]))
     dn = gc.naz_sparse_side_problem(dtype)
