@@ -25,37 +25,33 @@ __device__ __forceinline__ void rank_k_coop3(const CholParams<T> &P, size_t st, 
 #pragma unroll
     for (int i = 0; i < NR; i++) { rp[i] = T(0); gp[i] = T(0); }
     const int nsteps = (nnz + 3) >> 2;
-    // loader: elements tid + 192 j, j < 3, of the step's 512 values + 16 meta values
-    const int e0 = tid, e1 = tid + 192, e2 = tid + 384;
-    const bool d2 = e2 < 512, m2 = e2 >= 512 && e2 < 528;
-    const int en0 = e0 >> 7, en1 = e1 >> 7, en2 = d2 ? (e2 >> 7) : ((e2 - 512) >> 2) & 3;
-    const int c0 = e0 & 127, c1 = e1 & 127, c2 = e2 & 127, role = (e2 - 512) & 3;
+    // loader: 48 threads per entry, thread w of them the values w, w + 48, w + 96 of the entry's 128 columns + 4 meta values
+    const int le = tid / 48, lw = tid - 48 * le;
+    const int c2 = lw + 96;                         // < 128: a column; 128 .. 131: meta role c2 - 128; beyond: nothing
+    const bool d2 = c2 < 128, m2 = c2 >= 128 && c2 < 132;
+    const int role = c2 - 128;
     T sv[G][3];
-    int iq[G][3];
-    auto load_idx = [&](int s, int step) {
-        iq[s][0] = P.indices[st + max(min(4 * step + en0, nnz - 1), 0)];
-        iq[s][1] = P.indices[st + max(min(4 * step + en1, nnz - 1), 0)];
-        iq[s][2] = P.indices[st + max(min(4 * step + en2, nnz - 1), 0)];
-    };
+    int iq[G];
+    auto load_idx = [&](int s, int step) { iq[s] = P.indices[st + max(min(4 * step + le, nnz - 1), 0)]; };
     auto issue_rows = [&](int s, int step) {
-        sv[s][0] = P.B[(size_t)iq[s][0] * P.ldb + c0];
-        sv[s][1] = P.B[(size_t)iq[s][1] * P.ldb + c1];
-        const size_t pos = st + max(min(4 * step + en2, nnz - 1), 0);
-        const T *rowp = P.B + (size_t)iq[s][2] * P.ldb;
-        const T *xp = d2 ? rowp + c2 : (role == 1 && P.bias_sub != nullptr) ? P.bias_sub + iq[s][2] : (BORDER && role == 2) ? rowp + bcol : P.values + pos;
+        const size_t pos = st + max(min(4 * step + le, nnz - 1), 0);
+        const T *rowp = P.B + (size_t)iq[s] * P.ldb;
+        sv[s][0] = rowp[lw];
+        sv[s][1] = rowp[lw + 48];
+        const T *xp = d2 ? rowp + c2 : (role == 1 && P.bias_sub != nullptr) ? P.bias_sub + iq[s] : (BORDER && role == 2) ? rowp + bcol : P.values + pos;
         sv[s][2] = *xp;
     };
     auto write_slot = [&](int s, int slot, int step) {
         T *dst = ring + (size_t)slot * PC_SLOT;
-        dst[en0 * PC_ROW + c0] = sv[s][0];
-        dst[en1 * PC_ROW + c1] = sv[s][1];
+        dst[le * PC_ROW + lw] = sv[s][0];
+        dst[le * PC_ROW + lw + 48] = sv[s][1];
         T mv = sv[s][2];
         if (!d2) {
             if (role == 1 && P.bias_sub == nullptr) mv = T(0);
-            if (role == 3) mv = (4 * step + en2 < nnz) ? T(1) : T(0);
+            if (role == 3) mv = (4 * step + le < nnz) ? T(1) : T(0);
         }
-        if (d2) dst[en2 * PC_ROW + c2] = mv;
-        else if (m2) dst[4 * PC_ROW + (e2 - 512)] = mv;
+        if (d2) dst[le * PC_ROW + c2] = mv;
+        else if (m2) dst[4 * PC_ROW + 4 * le + role] = mv;
     };
     if (nsteps > 0) {
         static_for<0, G>([&](auto sc) { constexpr int s = decltype(sc)::value; load_idx(s, s); });
@@ -84,15 +80,14 @@ __device__ __forceinline__ void rank_k_coop3(const CholParams<T> &P, size_t st, 
                 T xw = impl_w ? x + T(1) : x;
                 if (!vld) { ws = T(0); xw = T(0); }
                 const T *orow = src + g * PC_ROW + lm;
-                T o[NB];
-                static_for<R0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; o[b] = orow[16 * b]; });
                 static_for<0, NR>([&](auto ic) {
                     constexpr int ii = decltype(ic)::value;
                     constexpr int R = c3_row(Q, ii), OFF = c3_off(Q, ii);
-                    const T a = o[R] * ws;
-                    static_for<R, NB>([&](auto bjc) { constexpr int bj = decltype(bjc)::value; acc[OFF + bj - R] = Mf::mma(a, o[bj], acc[OFF + bj - R]); });
-                    rp[ii] += xw * o[R];
-                    if (BORDER) gp[ii] += (ws * bv) * o[R];
+                    const T oR = orow[16 * R];
+                    const T a = oR * ws;
+                    static_for<R, NB>([&](auto bjc) { constexpr int bj = decltype(bjc)::value; acc[OFF + bj - R] = Mf::mma(a, bj == R ? oR : orow[16 * bj], acc[OFF + bj - R]); });
+                    rp[ii] += xw * oR;
+                    if (BORDER) gp[ii] += (ws * bv) * oR;
                 });
                 if (BORDER && Q == 0) { gam += (ws * bv) * bv; rbs += xw * bv; }
             }
