@@ -25,7 +25,11 @@ constexpr int PC_ROW = 144;                      // doubles per staged row: 128 
 constexpr int PC_SLOT = 4 * PC_ROW + 16;         // a step's four rows + their meta values (4 x {x, opposing bias, border, valid})
 
 // one work item (row or slice): entries [st, st + nnz), partial written to pp.  Q: this wavefront's half of the tiles.
-template <typename T, bool BORDER, int Q, int G>
+// EXPL: explicit-feedback weights (an entry's matrix weight is one): the operand is the gathered row itself, nothing is multiplied or
+// selected per step -- the entries past the end of the item are zeroed where they are written to the slot (the item's last step
+// only).  Vector instructions run on the datapath the double-precision matrix instructions use, so each one off the step is
+// matrix-pipe time.  The sums are the general form's bit for bit (a product with one, a product with zero).
+template <typename T, bool BORDER, int Q, int G, bool EXPL>
 __device__ __forceinline__ void chol_part_rank_k_coop(const CholParams<T> &P, size_t st, int nnz, T *__restrict__ pp, int lane, int tid,
                                                       T *__restrict__ ring)
 {
@@ -52,19 +56,22 @@ __device__ __forceinline__ void chol_part_rank_k_coop(const CholParams<T> &P, si
     //  the rows it addresses are issued -- so waiting for it drains nothing that should still be in flight)
     T sv[G][4], sx[G];
     int idxq[G];
+    // (e >= 0 and nnz >= 1 wherever these run: one clamp; the row offset as one 32 x 32 -> 64-bit multiply-add -- indices and leading
+    //  dimensions are below 2^31 -- instead of the 64 x 64-bit product's three quarter-rate instructions)
+    const unsigned ldb32 = (unsigned)P.ldb;
     auto load_idx = [&](int s, int step) {
         const int e = 4 * step + le;
-        idxq[s] = P.indices[st + max(min(e, nnz - 1), 0)];
+        idxq[s] = P.indices[st + (unsigned)min(e, nnz - 1)];
     };
     auto issue_rows = [&](int s, int step) {
         const int e = 4 * step + le;
-        const size_t pos = st + max(min(e, nnz - 1), 0);
+        const size_t pos = st + (unsigned)min(e, nnz - 1);
 #ifdef CMF_COOP_IDXMASK
         const int idxn = idxq[s] & CMF_COOP_IDXMASK;      // experiment: every gather inside a few rows (what the kernel does without memory latency)
 #else
         const int idxn = idxq[s];
 #endif
-        const T *rowp = P.B + (size_t)idxn * P.ldb;
+        const T *rowp = P.B + (unsigned long long)(unsigned)idxn * ldb32;
 #pragma unroll
         for (int j = 0; j < 4; j++) sv[s][j] = rowp[lc + 32 * j];
         // one more value per thread, always from a valid address and untouched until it is written to the slot (a use here would wait
@@ -79,8 +86,17 @@ __device__ __forceinline__ void chol_part_rank_k_coop(const CholParams<T> &P, si
         for (int j = 0; j < 4; j++) dst[le * PC_ROW + lc + 32 * j] = sv[s][j];
         T mv = sx[s];
         if (role == 1 && P.bias_sub == nullptr) mv = T(0);
-        if (role == 3) mv = (4 * step + le < nnz) ? T(1) : T(0);
-        if (role < 4) dst[4 * PC_ROW + 4 * le + role] = mv;
+        if constexpr (EXPL) {
+            if (4 * step + 4 > nnz && 4 * step + le >= nnz) {          // (uniform first test: the last step of the item and beyond)
+#pragma unroll
+                for (int j = 0; j < 4; j++) dst[le * PC_ROW + lc + 32 * j] = T(0);
+                mv = T(0);                                             // ... and its value, bias and border element
+            }
+            if (role < 3) dst[4 * PC_ROW + 4 * le + role] = mv;
+        } else {
+            if (role == 3) mv = (4 * step + le < nnz) ? T(1) : T(0);
+            if (role < 4) dst[4 * PC_ROW + 4 * le + role] = mv;
+        }
     };
     if (nsteps > 0) {
         static_for<0, G>([&](auto sc) { constexpr int s = decltype(sc)::value; load_idx(s, s); });
@@ -106,10 +122,13 @@ __device__ __forceinline__ void chol_part_rank_k_coop(const CholParams<T> &P, si
                 const T *mrow = src + 4 * PC_ROW + 4 * g;
                 const T x = mrow[0] - mrow[1];
                 const T bv = BORDER ? mrow[2] : T(0);
-                const bool vld = mrow[3] != T(0);
-                T ws = impl_w ? x : T(1);               // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
-                T xw = impl_w ? x + T(1) : x;           // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
-                if (!vld) { ws = T(0); xw = T(0); }
+                T ws = T(1), xw = x;
+                if constexpr (!EXPL) {
+                    const bool vld = mrow[3] != T(0);
+                    ws = impl_w ? x : T(1);               // common.c:2091-2095, collective.c:2103-2108 vs common.c:1007-1012
+                    xw = impl_w ? x + T(1) : x;           // common.c:2082-2085, collective.c:2097-2101 vs common.c:991-996
+                    if (!vld) { ws = T(0); xw = T(0); }
+                }
                 const T *orow = src + g * PC_ROW + lm;
                 T o[NB];
                 static_for<R0, NB>([&](auto bc) {
@@ -119,15 +138,15 @@ __device__ __forceinline__ void chol_part_rank_k_coop(const CholParams<T> &P, si
                 static_for<0, NR>([&](auto ic) {
                     constexpr int ii = decltype(ic)::value;
                     constexpr int R = cq_row(NP, Q, ii), OFF = cq_off(NP, Q, ii);
-                    const T a = o[R] * ws;
+                    const T a = EXPL ? o[R] : o[R] * ws;
                     static_for<R, NB>([&](auto bjc) {
                         constexpr int bj = decltype(bjc)::value;
                         acc[OFF + bj - R] = Mf::mma(a, o[bj], acc[OFF + bj - R]);
                     });
                     rp[ii] += xw * o[R];
-                    if (BORDER) gp[ii] += (ws * bv) * o[R];
+                    if (BORDER) gp[ii] += (EXPL ? bv : ws * bv) * o[R];
                 });
-                if (BORDER && Q == 0) { gam += (ws * bv) * bv; rbs += xw * bv; }
+                if (BORDER && Q == 0) { gam += (EXPL ? bv : ws * bv) * bv; rbs += xw * bv; }
             }
             __syncthreads();
         });
@@ -159,7 +178,7 @@ __device__ __forceinline__ void chol_part_rank_k_coop(const CholParams<T> &P, si
 }
 
 // workgroup = two wavefronts = one work item at a time; two wavefronts per SIMD (four workgroups per CU)
-template <typename T, bool BORDER, int G>
+template <typename T, bool BORDER, int G, bool EXPL>
 __global__ void __launch_bounds__(128, 2)
 chol_parts_coop_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, const CholSlices<T> SL)
 {
@@ -180,8 +199,8 @@ chol_parts_coop_kernel(const CholParams<T> P, const RowDesc *__restrict__ desc, 
         const int nnz = (scount >= 0) ? __builtin_amdgcn_readfirstlane(scount) : nnz_row;
         const size_t st = st_row + (size_t)__builtin_amdgcn_readfirstlane(sfirst);
         T *pp = SL.part + (size_t)(rix - SL.part_base) * PART;
-        if (wave == 0) chol_part_rank_k_coop<T, BORDER, 0, G>(P, st, nnz, pp, lane, tid, ring);
-        else chol_part_rank_k_coop<T, BORDER, 1, G>(P, st, nnz, pp, lane, tid, ring);
+        if (wave == 0) chol_part_rank_k_coop<T, BORDER, 0, G, EXPL>(P, st, nnz, pp, lane, tid, ring);
+        else chol_part_rank_k_coop<T, BORDER, 1, G, EXPL>(P, st, nnz, pp, lane, tid, ring);
         __syncthreads();
         rix = P.row_first + (int)gridDim.x + s_next;
         __syncthreads();

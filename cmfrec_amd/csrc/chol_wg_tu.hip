@@ -44,8 +44,12 @@ hipError_t launch_chol_parts_coop(int num_cus, bool border, int depth, hipStream
     return hipErrorNotSupported;
 #else
     // depth: steps of four entries in flight in registers (3: no spilled register in either build; 4: the build with the border column spills)
-    auto kern = (depth == 4) ? (border ? chol_parts_coop_kernel<real_t, true, 4> : chol_parts_coop_kernel<real_t, false, 4>)
-                             : (border ? chol_parts_coop_kernel<real_t, true, 3> : chol_parts_coop_kernel<real_t, false, 3>);
+    // explicit-feedback weights (every mode but the implicit model's): the build without per-step weights and selects
+    const bool expl = !(W.mode == CHOL_IMPLICIT || W.mode == CHOL_COLLECTIVE_IMPLICIT);
+    auto kern = expl ? ((depth == 4) ? (border ? chol_parts_coop_kernel<real_t, true, 4, true> : chol_parts_coop_kernel<real_t, false, 4, true>)
+                                     : (border ? chol_parts_coop_kernel<real_t, true, 3, true> : chol_parts_coop_kernel<real_t, false, 3, true>))
+                     : ((depth == 4) ? (border ? chol_parts_coop_kernel<real_t, true, 4, false> : chol_parts_coop_kernel<real_t, false, 4, false>)
+                                     : (border ? chol_parts_coop_kernel<real_t, true, 3, false> : chol_parts_coop_kernel<real_t, false, 3, false>));
     const int items = W.nrows - W.row_first;
     if (items <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3(std::min(items, num_cus * 4)), dim3(128), 0, st, W, desc, SL);

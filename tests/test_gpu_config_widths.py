@@ -127,6 +127,31 @@ def test_c3_width_shared_gather_is_the_per_wavefront_gather(oracles, k, monkeypa
     assert rel_err(out["1"], Ao) < 1e-10
 
 
+def test_c3_width_shared_gather_implicit_model(oracles, monkeypatch):
+    """The same kernel with the implicit model's weights (k = 128, closed form: every entry's matrix weight is its confidence -- the
+    build that keeps the per-step weights and selects) against the per-wavefront gather, bit for bit, and against the oracle."""
+    from cmfrec_amd import ops
+    dtype = np.float64
+    O = oracles[dtype]
+    m, n, k = 60, 1800, 128
+    row, col, val = make_coo(m, n, 8000, 25, counts=True, dtype=dtype, heavy_row=(5, 1250), empty_rows=(3,))
+    csr, _ = O.coo_to_csr_and_csc(row, col, val, m, n)
+    rng = np.random.default_rng(26)
+    A0 = (rng.standard_normal((m, k)) * 0.05).astype(dtype)
+    B = (rng.standard_normal((n, k)) * 0.2).astype(dtype)
+    out = {}
+    for coop in ("1", "0"):
+        monkeypatch.setenv("CMFREC_HIP_PARTS_COOP", coop)
+        monkeypatch.setenv("CMFREC_HIP_LOWRANK", "0")
+        Ah = A0.copy()
+        ops.optimizeA_implicit(Ah, B, csr, 4.0, use_cg=False)
+        out[coop] = Ah
+    assert np.array_equal(out["1"], out["0"])
+    Ao = A0.copy()
+    O.optimizeA_implicit(Ao, B, csr, 4.0, nthreads=4, use_cg=False)
+    assert rel_err(out["1"], Ao) < 1e-9
+
+
 @pytest.mark.parametrize("side", ["users", "items"])
 @pytest.mark.parametrize("gramk", ["default", "off", "batch7"])
 def test_c5_width_collective_single(oracles, side, gramk, monkeypatch):
